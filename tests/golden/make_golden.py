@@ -1,0 +1,302 @@
+"""Generate the golden vectors under tests/golden/*.npz by RUNNING THE REFERENCE'S OWN CODE.
+
+Run in the build container only (needs /root/reference):
+    python oracle/build_ref.py && python tests/golden/make_golden.py
+
+Each .npz holds inputs, the random weights used, and the reference's outputs.  Nothing of the
+reference's source text is stored -- only data.  What is called, per file:
+
+  raster.npz       lib/draw_rectangles/draw_rectangles.pyx:12  draw_union_boxes (re-cythonized)
+  union_feats.npz  lib/get_union_boxes.py:17,63               UnionBoxesAndFeats(...).forward (eval)
+  gru.npz          torch.nn.GRUCell as instantiated at sgg_models/rel_model_stanford.py:36-37
+  message_pass.npz sgg_models/rel_model_stanford.py:48        RelModelStanford.message_pass
+  predict.npz      sgg_models/rel_model_stanford.py:97        RelModelStanford.predict
+  pairs.npz        sgg_models/rel_model_base.py:143 get_rel_inds ; lib/proposal_assignments_gtbox.py:7
+  eval_tail.npz    lib/surgery.py:17 filter_dets + the softmax/sort lines rel_model_stanford.py:187-204
+  losses.npz       lib/losses.py:5,73
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+
+dr = ref_import.install()
+from lib.get_union_boxes import UnionBoxesAndFeats  # noqa: E402
+from lib.losses import edge_losses, node_losses  # noqa: E402
+from lib.proposal_assignments_gtbox import proposal_assignments_gtbox  # noqa: E402
+from lib.surgery import filter_dets  # noqa: E402
+from sgg_models.rel_model_stanford import RelModelStanford  # noqa: E402
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('%-18s %7.1f kB  %d arrays' % (name, os.path.getsize(path) / 1e3, len(out)))
+
+
+def sd(module, prefix=''):
+    return {prefix + k: v.detach().clone() for k, v in module.state_dict().items() if 'num_batches' not in k}
+
+
+def rand_boxes(rng, n, lo=0, hi=400, wmin=12, wmax=192, clip=591):
+    xy = rng.uniform(lo, hi, size=(n, 2))
+    wh = rng.uniform(wmin, wmax, size=(n, 2))
+    return np.concatenate((xy, np.minimum(xy + wh, clip)), 1).astype(np.float32)
+
+
+# ---------------------------------------------------------------- raster
+def gold_raster():
+    rng = np.random.RandomState(111)
+    a, b = rand_boxes(rng, 56), rand_boxes(rng, 56)
+    pairs = np.concatenate((a, b), 1)
+    special = np.array([
+        [10, 10, 50, 50, 10, 10, 50, 50],            # identical
+        [0, 0, 100, 100, 25, 25, 75, 75],            # nested
+        [0, 0, 10, 10, 90, 90, 100, 100],            # disjoint
+        [0, 0, 50, 50, 50, 0, 100, 50],              # touching edge
+        [0, 0, 27, 27, 0, 0, 13.5, 13.5],            # grid-aligned
+        [3.25, 7.5, 300.75, 20.125, 100, 1, 120, 500],   # thin / tall
+        [0, 0, 591, 591, 1, 1, 2, 2],                # tiny inside huge
+        [5, 5, 6, 6, 5.5, 5.5, 6.5, 6.5],            # sub-pixel
+    ], dtype=np.float32)
+    pairs = np.concatenate((pairs, special), 0).astype(np.float32)
+    out27 = dr.draw_union_boxes(pairs, 27)
+    out7 = dr.draw_union_boxes(pairs[:16], 7)
+    save('raster', pairs=pairs, out27=out27, out7=out7)
+
+
+# ---------------------------------------------------------------- UnionBoxesAndFeats
+def randomize_bn(m, g):
+    for mod in m.modules():
+        if isinstance(mod, nn.BatchNorm2d):
+            mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+            mod.weight.data.copy_(torch.rand(mod.weight.shape, generator=g) + 0.5)
+            mod.bias.data.copy_(torch.randn(mod.bias.shape, generator=g) * 0.1)
+
+
+def gold_union_feats():
+    g = torch.Generator().manual_seed(111)
+    rng = np.random.RandomState(5)
+    arrs = {}
+    for dim, n, tag in ((128, 6, 'd128'), (32, 9, 'd32')):
+        torch.manual_seed(7 + dim)
+        m = UnionBoxesAndFeats(pooling_size=7, stride=16, dim=dim, edge_model='motifs')
+        randomize_bn(m, g)
+        m.eval()
+        boxes = rand_boxes(rng, n)
+        rois = np.concatenate((np.zeros((n, 1), np.float32), boxes), 1)
+        ui = np.array([(i, j) for i in range(n) for j in range(n) if i != j], dtype=np.int64)
+        if dim == 128:
+            ui = ui[::3]
+        pools = torch.randn(len(ui), dim, 7, 7, generator=g)
+        with torch.no_grad():
+            out = m(pools, torch.from_numpy(rois), torch.from_numpy(ui), None)
+            conv_out = out - pools
+        assert conv_out.shape[-1] == 7 and torch.allclose(conv_out[..., :1, :1].expand_as(conv_out), conv_out, atol=1e-6)
+        arrs.update({tag + '_rois': rois, tag + '_union_inds': ui, tag + '_pools': pools, tag + '_out': out,
+                     tag + '_rect_feat': (out - pools)[:, :, 0, 0]})
+        for k, v in sd(m).items():
+            arrs[tag + '_w_' + k] = v
+    save('union_feats', **arrs)
+
+
+# ---------------------------------------------------------------- model without torchvision
+class _Data(object):
+    ind_to_classes = ['c%d' % i for i in range(151)]
+    ind_to_predicates = ['p%d' % i for i in range(51)]
+
+
+def make_model(C, fc_dim, hidden, mp_iter=3, num_classes=151, num_rels=51, seed=0):
+    """RelModelStanford built field by field (its constructor needs torchvision,
+    sgg_models/rel_model_base.py:92-112); the attached sub-modules are the same torch.nn classes with the
+    same names as rel_model_base.py:110-120 and rel_model_stanford.py:29-45."""
+    torch.manual_seed(seed)
+    m = RelModelStanford.__new__(RelModelStanford)
+    nn.Module.__init__(m)
+    m.classes = ['c%d' % i for i in range(num_classes)]
+    m.rel_classes = ['p%d' % i for i in range(num_rels)]
+    m.mode, m.backbone, m.RELS_PER_IMG, m.pool_sz, m.stride = 'sgcls', 'vgg16', 1024, 7, 16
+    m.use_bias = m.test_bias = m.require_overlap = False
+    m.obj_dim, m.hidden_dim, m.mp_iter, m.edge_dim = fc_dim, hidden, mp_iter, C
+    cls = lambda: nn.Sequential(nn.Linear(C * 49, fc_dim), nn.ReLU(True), nn.Dropout(),
+                                nn.Linear(fc_dim, fc_dim), nn.ReLU(True), nn.Dropout())
+    vc = cls()
+    del vc._modules['5']
+    del vc._modules['4']
+    m.roi_fmap = nn.Sequential(nn.Flatten(), vc)
+    m.roi_fmap_obj = cls()
+    m.union_boxes = UnionBoxesAndFeats(pooling_size=7, stride=16, dim=C, edge_model='motifs')
+    m.rel_fc = nn.Linear(hidden, num_rels)
+    m.obj_fc = nn.Linear(hidden, num_classes)
+    m.obj_unary = nn.Linear(fc_dim, hidden)
+    m.edge_unary = nn.Linear(fc_dim, hidden)
+    m.edge_gru = nn.GRUCell(hidden, hidden)
+    m.node_gru = nn.GRUCell(hidden, hidden)
+    for nm in ('sub_vert_w_fc', 'obj_vert_w_fc', 'out_edge_w_fc', 'in_edge_w_fc'):
+        setattr(m, nm, nn.Sequential(nn.Linear(hidden * 2, 1), nn.Sigmoid()))
+    g = torch.Generator().manual_seed(seed + 1)
+    randomize_bn(m, g)
+    # default GRU/Linear init is tiny at these widths; widen a little so gates are not all ~0.5
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if 'w_fc' in n_ or 'gru' in n_:
+                p_.mul_(3.0)
+    m.eval()
+    return m
+
+
+def graph(rng, sizes, drop=0.0):
+    """ragged multi-image graph: returns im_inds, rel_inds[E,3] sorted like the reference."""
+    im = np.concatenate([np.full(n, i, np.int64) for i, n in enumerate(sizes)])
+    rel, off = [], 0
+    for i, n in enumerate(sizes):
+        for s in range(n):
+            for o in range(n):
+                if s != o and rng.rand() >= drop:
+                    rel.append((i, off + s, off + o))
+        off += n
+    return im, np.array(rel, dtype=np.int64)
+
+
+def gold_gru():
+    torch.manual_seed(3)
+    cell = nn.GRUCell(48, 48)
+    x, h = torch.randn(21, 48), torch.randn(21, 48)
+    with torch.no_grad():
+        save('gru', x=x, h=h, out=cell(x, h), out_h0=cell(x, torch.zeros_like(h)),
+             **{'w_' + k: v for k, v in sd(cell).items()})
+
+
+def gold_message_pass():
+    rng = np.random.RandomState(11)
+    arrs = {}
+    for tag, hidden, sizes, drop in (('h32_b1', 32, (7,), 0.0), ('h64_b3', 64, (5, 9, 3), 0.0),
+                                     ('h32_sampled', 32, (6, 4), 0.4), ('h128_b2', 128, (4, 3), 0.0)):
+        m = make_model(8, 16, hidden, seed=sum(map(ord, tag)))
+        im, rel = graph(rng, sizes, drop)
+        N, E = len(im), len(rel)
+        g = torch.Generator().manual_seed(E)
+        obj_rep, rel_rep = torch.randn(N, hidden, generator=g), torch.randn(E, hidden, generator=g).relu()
+        with torch.no_grad():
+            for it in range(4):
+                m.mp_iter = it
+                v, e = m.message_pass(rel_rep, obj_rep, torch.from_numpy(rel[:, 1:3]))
+                arrs['%s_v%d' % (tag, it)], arrs['%s_e%d' % (tag, it)] = v, e
+        arrs.update({tag + '_obj_rep': obj_rep, tag + '_rel_rep': rel_rep, tag + '_rel_inds': rel})
+        for k, v in sd(m).items():
+            if 'gru' in k or 'w_fc' in k:
+                arrs[tag + '_w_' + k] = v
+    save('message_pass', **arrs)
+
+
+def gold_predict():
+    rng = np.random.RandomState(21)
+    arrs = {}
+    for tag, C, fc, hidden, sizes in (('small', 8, 24, 32, (5, 4)), ('b3', 16, 32, 64, (3, 6, 2))):
+        m = make_model(C, fc, hidden, seed=len(tag))
+        im, rel = graph(rng, sizes)
+        N, E = len(im), len(rel)
+        boxes = rand_boxes(rng, N)
+        rois = np.concatenate((im[:, None].astype(np.float32), boxes), 1)
+        g = torch.Generator().manual_seed(N * E)
+        nf, ef = torch.randn(N, C, 7, 7, generator=g), torch.randn(E, C, 7, 7, generator=g)
+        with torch.no_grad():
+            od, rd = m.predict(nf, ef, torch.from_numpy(rel), torch.from_numpy(rois), None)
+        arrs.update({tag + '_node_feat': nf, tag + '_edge_feat': ef, tag + '_rel_inds': rel, tag + '_rois': rois,
+                     tag + '_obj_dists': od, tag + '_rel_dists': rd})
+        for k, v in sd(m).items():
+            arrs[tag + '_w_' + k] = v
+    save('predict', **arrs)
+
+
+def gold_pairs():
+    rng = np.random.RandomState(31)
+    arrs = {}
+    m = make_model(8, 16, 32)
+    for tag, sizes in (('b1', (6,)), ('b3', (4, 7, 2)), ('b8x32', (32,) * 8)):
+        im = np.concatenate([np.full(n, i, np.int64) for i, n in enumerate(sizes)])
+        boxes = rand_boxes(rng, len(im))
+        cls = rng.randint(1, 151, size=len(im))
+        gt_classes = np.stack((im, cls), 1).astype(np.int64)
+        rels = []
+        for i, n in enumerate(sizes):
+            seen = set()
+            while len(seen) < min(6, n * (n - 1) // 2):
+                s, o = rng.randint(n), rng.randint(n)
+                if s != o and (s, o) not in seen:
+                    seen.add((s, o))
+                    rels.append((i, s, o, rng.randint(1, 51)))
+        gt_rels = np.array(rels, dtype=np.int64)
+        tim, tb = torch.from_numpy(im), torch.from_numpy(boxes)
+        for ov in (False, True):
+            m.require_overlap = ov
+            m.eval()
+            ri = m.get_rel_inds(None, tim, tb)
+            arrs['%s_eval_ov%d' % (tag, int(ov))] = ri
+        rois = torch.cat((tim[:, None].float(), tb), 1)
+        r, lab, rl = proposal_assignments_gtbox(rois, tb, torch.from_numpy(gt_classes), torch.from_numpy(gt_rels),
+                                                0, 1024)
+        m.train()
+        arrs.update({tag + '_im_inds': im, tag + '_boxes': boxes, tag + '_gt_classes': gt_classes,
+                     tag + '_gt_rels': gt_rels, tag + '_train_labels': lab, tag + '_train_rel_labels': rl,
+                     tag + '_train_rel_inds': m.get_rel_inds(rl, tim, tb)})
+        m.eval()
+    save('pairs', **arrs)
+
+
+def gold_eval_tail():
+    rng = np.random.RandomState(41)
+    g = torch.Generator().manual_seed(41)
+    N = 12
+    im, rel = graph(rng, (N,))
+    od, rd = torch.randn(N, 151, generator=g) * 2, torch.randn(len(rel), 51, generator=g) * 2
+    boxes = torch.from_numpy(rand_boxes(rng, N))
+    s = torch.softmax(od, 1)
+    s[:, 0] = 0
+    sc, order = s[:, 1:].sort(dim=1, descending=True)
+    obj_preds, obj_scores = order[:, 0] + 1, sc[:, 0]
+    rel_rep = torch.softmax(rd, 1)
+    b, c, s_, r, ps = filter_dets(boxes, obj_scores, obj_preds, torch.from_numpy(rel[:, 1:]), rel_rep)
+    gt_cls = torch.from_numpy(rng.randint(1, 151, size=N))
+    b2, c2, s2, r2, ps2 = filter_dets(boxes, torch.ones(N), gt_cls, torch.from_numpy(rel[:, 1:]), rel_rep)
+    save('eval_tail', obj_dists=od, rel_dists=rd, rel_inds=rel, boxes=boxes, gt_classes=gt_cls,
+         sg_boxes=b, sg_classes=c, sg_scores=s_, sg_rels=r, sg_pred_scores=ps,
+         pc_boxes=b2, pc_classes=c2, pc_scores=s2, pc_rels=r2, pc_pred_scores=ps2)
+
+
+def gold_losses():
+    g = torch.Generator().manual_seed(51)
+    rd = torch.randn(40, 51, generator=g)
+    lab = torch.zeros(40, dtype=torch.long)
+    lab[[3, 7, 20]] = torch.tensor([5, 50, 1])
+    od, ol = torch.randn(10, 151, generator=g), torch.randint(1, 151, (10,), generator=g)
+    arrs = dict(rel_dists=rd, rel_labels=lab, obj_dists=od, obj_labels=ol,
+                node=node_losses(od, ol)['obj_loss'])
+    for lt in ('baseline', 'dnorm', 'dnorm-fgbg'):
+        arrs['edge_' + lt] = edge_losses(rd, lab, loss_type=lt)['rel_loss']
+        arrs['edge_nofg_' + lt] = edge_losses(rd, torch.zeros_like(lab), loss_type=lt)['rel_loss']
+    save('losses', **arrs)
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(1)
+    gold_raster()
+    gold_union_feats()
+    gold_gru()
+    gold_message_pass()
+    gold_predict()
+    gold_pairs()
+    gold_eval_tail()
+    gold_losses()
