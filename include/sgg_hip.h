@@ -1,0 +1,141 @@
+/* sgg_hip.h -- C ABI of libsgg_hip.so: the MI355X (gfx950) scene-graph hot path.
+ *
+ * Drop-in boundary for the SGCls / PredCls IMP forward of bknyaz/sgg.  Every entry point takes raw
+ * DEVICE pointers, sizes and a hipStream_t (as void*), allocates nothing, never synchronises and returns
+ * 0 or a negative SGG_ERR_* code.  The caller (sgg_amd/, a Python host over torch for memory and streams)
+ * owns every buffer.  Citations are file:line in the reference tree (/root/reference).
+ *
+ * Element types: SGG_F32 (fp32 storage, fp32 MFMA/VALU arithmetic -- the 1e-3 parity mode) and SGG_BF16
+ * (bf16 storage, fp32 accumulate -- the throughput mode of BASELINE config 2).
+ *
+ * Feature-map / RoI-feature layout is channels-last (NHWC): the same logical tensors the reference holds
+ * as NCHW, handed to Python as permuted views.
+ */
+#ifndef SGG_HIP_H_
+#define SGG_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGG_ABI_VERSION 1
+
+enum { SGG_F32 = 0, SGG_BF16 = 1 };
+enum { SGG_ACT_NONE = 0, SGG_ACT_RELU = 1 };
+enum {
+    SGG_OK = 0,
+    SGG_ERR_ARG = -1,      /* bad size / alignment / null pointer          -> ValueError  */
+    SGG_ERR_DTYPE = -2,    /* unsupported element type                     -> TypeError   */
+    SGG_ERR_LAUNCH = -3,   /* hipLaunch failed                             -> RuntimeError */
+    SGG_ERR_CAPACITY = -4  /* caller-provided output capacity too small    -> ValueError  */
+};
+
+int sgg_abi_version(void);
+const char* sgg_build_info(void);
+
+/* ---- a-1  detector transform: [3P] GeneralizedRCNNTransform called at sgg_models/rel_model_base.py:183 ----
+ * One image: (x-mean)/std, bilinear resize to (rh,rw) (align_corners=False; identity when (rh,rw)==(h,w)),
+ * written into the zero-bordered NHWC4 fp32 plane out[(Hp+2),(Wp+2),4] of batch slot b (border and the pad
+ * region rh..Hp / rw..Wp must be zero: the caller memsets the buffer once). */
+int sgg_image_prep(const float* img_chw, int h, int w, int rh, int rw, float* out_nhwc4, int b, int Hp, int Wp,
+                   void* stream);
+
+/* ---- a-2  VGG-16 features: [3P] vgg16.features minus the last pool, rel_model_base.py:92-93,184,310-312 ----
+ * Activations live in zero-bordered NHWC buffers [B, H+2*pad, W+2*pad, C]. */
+int sgg_conv1_1(const float* in_nhwc4, const float* w /*[64][27] (ky,kx,c)*/, const float* bias, void* out, int B,
+                int H, int W, int out_dtype, void* stream);
+int sgg_conv3x3_relu(const void* in /*pad 1*/, const void* w /*[Cout][3][3][Cin]*/, const float* bias, void* out,
+                     int out_pad, int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
+int sgg_maxpool2x2(const void* in /*pad 1*/, void* out, int out_pad, int B, int H, int W, int C, int dtype,
+                   void* stream);
+
+/* ---- a-3  pair indexing ----
+ * eval: RelModelBase.get_rel_inds, rel_model_base.py:147-163 (row-major nonzero of same-image, off-diagonal,
+ *       optionally IoU>0 (bbox_overlaps, lib/pytorch_misc.py:60)).  rel_inds i64[cap,3]=(img,subj,obj).
+ * train: proposal_assignments_gtbox, lib/proposal_assignments_gtbox.py:7-80, no-sampling path: every same-image
+ *       ordered pair, label = predicate of the FG relation on it (one row per FG relation) else 0, sorted by
+ *       (img,subj,obj).  gt_rels i64[R,4]=(img,subj_local,obj_local,pred); img_first i32[num_im] = first box of
+ *       each image.  rel_labels i64[cap,4].
+ * `count` (device int32) receives the number of rows; rows beyond cap are not written and the call still
+ * returns SGG_OK (the host compares count with cap).  work = int32 scratch of >= N+2+N*N (train) / N+2 (eval). */
+int sgg_pair_index_eval(const int64_t* im_inds, const float* boxes /*[N,4] or NULL*/, int N, int require_overlap,
+                        int64_t* rel_inds, int cap, int* count, int* work, void* stream);
+int sgg_pair_index_train(const int64_t* im_inds, int N, const int64_t* gt_rels, int R, const int* img_first,
+                         int64_t* rel_labels, int cap, int* count, int* work, void* stream);
+/* CSR of the edges by object node (in-edges), by counting sort; edges keep ascending order inside a node.
+ * in_ptr i32[N+1], in_ids i32[E].  Also out_ptr/out_ids by subject.  work >= 2*(N+1) int32. */
+int sgg_edge_csr(const int64_t* rel_inds /*[E,3]*/, int E, int N, int* out_ptr, int* out_ids, int* in_ptr, int* in_ids,
+                 int* work, void* stream);
+
+/* ---- a-4  RoIAlign (+ fused union box): RelModelBase.node_edge_features, rel_model_base.py:245-260, and
+ * [3P] torchvision roi_align(output_size=7, sampling_ratio=2, aligned=False, spatial_scale) ----
+ * fmap [B,H,W,C] NHWC.  rois f32[Nroi,5]=(img,x1,y1,x2,y2).  pairs == NULL: out[r] = align(rois[r]), R = Nroi.
+ * pairs i64[R,2]: out[r] = align(union(rois[p0], rois[p1])) (rel_model_base.py:248-250).
+ * add_ec (optional, f32[R,C]): out[r,ph,pw,c] += add_ec[r,c]  (the broadcast add of lib/get_union_boxes.py:101,
+ * fused).  out [R,P,P,C]. */
+int sgg_roi_align_fwd(const void* fmap, int B, int H, int W, int C, const float* rois, int Nroi, const int64_t* pairs,
+                      int R, float spatial_scale, int P, int sampling, const float* add_ec, void* out, int dtype,
+                      void* stream);
+
+/* ---- a-5  union-mask raster: draw_union_boxes, lib/draw_rectangles/draw_rectangles.pyx:12-67 ----
+ * rois f32[N,5], pairs i64[E,2] -> out f32[E,2,P,P] + offset (the caller's `- 0.5`, lib/get_union_boxes.py:67). */
+int sgg_union_rects_fwd(const float* rois, const int64_t* pairs, int E, int P, float offset, float* out, void* stream);
+/* Same raster, emitted directly as the 4 stride-16 7x7 patches the (typo'd) conv stack reads
+ * (lib/get_union_boxes.py:40-43,52): out[E*4, Kpad] with k = c*49+ky*7+kx, zero padded, raster-0.5 inside. */
+int sgg_union_rect_patches(const float* rois, const int64_t* pairs, int E, int P, void* out, int Kpad, int dtype,
+                           void* stream);
+/* MaxPool2d(3,2,1) over the 2x2 map = max over 4 consecutive rows (lib/get_union_boxes.py:55). in[E*4,C] -> out[E,C] */
+int sgg_max4_rows(const void* in, void* out, int E, int C, int dtype, void* stream);
+/* x[r,p,c] += add[r,c] in place (lib/get_union_boxes.py:101 when the add is not fused in RoIAlign). */
+int sgg_bcast_add(void* x, const float* add_rc, int R, int PP, int C, int dtype, void* stream);
+
+/* ---- a-7  dense projections (nn.Linear): rel_model_stanford.py:29-37,103-107; rel_model_base.py:110-111 ----
+ * C[M,N] = post_scale * act(A[M,K] . W[N,K]^T + bias) + post_shift.   A may be split along K in two pieces:
+ * A[:, :K1] from A (lda) and A[:, K1:] from A2 (lda2) (K1 == K when A2 is NULL).  K, K1 multiples of 64 (bf16)
+ * / 32 (f32); lda, lda2, ldw multiples of 8 elements; 16-byte aligned bases.  bias/post_* are f32[N] or NULL. */
+int sgg_gemm(const void* A, int lda, const void* A2, int lda2, int K1, const void* W, int ldw, const float* bias,
+             const float* post_scale, const float* post_shift, void* C, int ldc, int M, int N, int K, int act,
+             int in_dtype, int out_dtype, void* stream);
+
+/* ---- a-8  IMP gather / gate / scatter: RelModelStanford.message_pass, rel_model_stanford.py:74-91 ----
+ * node_gate_dots: d[n,4] = (w_sub[:H].v, w_obj[:H].v, w_out[:H].v, w_in[:H].v)  (vertex halves of the four
+ *   Linear(2H,1) gates, :41-45).  gate_w f32[4,2H] rows = sub_vert, obj_vert, out_edge, in_edge; gate_b f32[4].
+ * edge_ctx: per edge e=(s,o): g_k = sigmoid(d[node,k] + w_k[H:].e_i[e] + b_k);
+ *   e_in[e] = g_sub*v[s] + g_obj*v[o] (:78-81);  gates[e] = (g_out, g_in) for the scatter (:86-89).
+ * node_scatter: ctx[n] = sum_{e in out(n)} g_out[e] e_i[e] + sum_{e in in(n)} g_in[e] e_i[e]  (:91; the two dense
+ *   one-hot [N,E] matmuls of :60-66 as a wavefront segmented reduction over the CSR lists). */
+int sgg_imp_node_gate_dots(const void* v, int N, int H, const float* gate_w, float* dots, int dtype, void* stream);
+int sgg_imp_edge_ctx_fwd(const void* v, const void* e, const int64_t* rel_inds /*[E,3]*/, int E, int H,
+                         const float* node_dots, const float* gate_w, const float* gate_b, void* e_in,
+                         float* gates /*[E,2]*/, int dtype, void* stream);
+int sgg_imp_node_scatter_fwd(const void* e, const float* gates, const int* out_ptr, const int* out_ids,
+                             const int* in_ptr, const int* in_ids, int N, int H, void* ctx, int dtype, void* stream);
+
+/* ---- a-9  GRU cell pointwise part: nn.GRUCell, rel_model_stanford.py:36-37,71-72,83,92 ----
+ * gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh come from sgg_gemm ([M,3H], gate order r,z,n).
+ * gh == NULL means h == 0: gh = b_hh (f32[3H]) and h_prev = 0 (first call, :68-72).
+ * g_dtype = element type of gi/gh (f32 pre-activations may feed bf16 states), dtype = type of h_prev/h_out. */
+int sgg_gru_gate_fwd(const void* gi, const void* gh, const float* b_hh, const void* h_prev, void* h_out, int M, int H,
+                     int g_dtype, int dtype, void* stream);
+
+/* ---- a-11  eval tail: rel_model_stanford.py:183-207 + filter_dets, lib/surgery.py:17-55 ----
+ * obj: softmax over C classes, best class in 1..C-1 and its prob (sgcls/sgdet), or score 1 / given class (predcls
+ *   when gt_classes != NULL).  rel: softmax over P predicates, triple score = max_{p>=1} * s_subj * s_obj.
+ * sort: descending by score, ties by ascending edge index (torch.sort leaves ties unspecified).
+ * Outputs: obj_scores f32[N], obj_preds i64[N], rels i64[E,2] (sorted), pred_scores f32[E,P] (sorted).
+ * work: f32/i32 scratch of >= 2*E + 2*pow2ceil(E) + E*P words. */
+int sgg_eval_tail(const void* obj_dists, int N, int C, const void* rel_dists, int E, int P,
+                  const int64_t* rel_inds /*[E,3]*/, const int64_t* gt_classes /*[N] or NULL*/, float* obj_scores,
+                  int64_t* obj_preds, int64_t* rels, float* pred_scores, void* work, int dtype, void* stream);
+
+/* ---- utilities used by the host for weight preparation (load time, not on the step path) ---- */
+int sgg_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, void* stream);
+/* out[n][p][c] = in[n][c][p]  (fc6 K-order (c,ph,pw) -> (ph,pw,c); conv OIHW -> O(HW)I) */
+int sgg_permute_ncp_to_npc(const void* in, void* out, int Nn, int C, int Pp, int in_dtype, int out_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGG_HIP_H_ */

@@ -1,0 +1,15 @@
+"""sgg_amd -- MI355X-native hot path of bknyaz/sgg (Faster-R-CNN features + Stanford IMP relation model).
+
+Host side in Python (torch for device memory / streams / torch.distributed), numerics in libsgg_hip.so
+(hand-written HIP for gfx950, C ABI in include/sgg_hip.h).  Importing this package loads the library and
+raises ImportError if it has not been built: there is no CPU or torch fallback.
+"""
+from . import _lib
+
+_lib.load()
+
+from .result import Result  # noqa: E402,F401
+from .rel_model_base import RelModelBase  # noqa: E402,F401
+from .rel_model_stanford import RelModelStanford  # noqa: E402,F401
+
+__all__ = ['Result', 'RelModelBase', 'RelModelStanford']

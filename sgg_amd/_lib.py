@@ -1,0 +1,81 @@
+"""ctypes binding of libsgg_hip.so (the C ABI declared in include/sgg_hip.h).
+
+There is NO fallback: if the shared library is missing or does not export a symbol, importing the
+product path raises.  The oracle (oracle/) is never imported from here.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsgg_hip.so')
+
+SGG_F32, SGG_BF16 = 0, 1
+ACT_NONE, ACT_RELU = 0, 1
+ABI_VERSION = 1
+
+_P, _I, _F, _L = c_void_p, c_int, c_float, c_int64
+
+# name -> argtypes (all return int unless listed in _RESTYPE)
+SIGNATURES = {
+    'sgg_abi_version': [],
+    'sgg_build_info': [],
+    'sgg_image_prep': [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
+    'sgg_conv1_1': [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'sgg_conv3x3_relu': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    'sgg_maxpool2x2': [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    'sgg_pair_index_eval': [_P, _P, _I, _I, _P, _I, _P, _P, _P],
+    'sgg_pair_index_train': [_P, _I, _P, _I, _P, _P, _I, _P, _P, _P],
+    'sgg_edge_csr': [_P, _I, _I, _P, _P, _P, _P, _P, _P],
+    'sgg_roi_align_fwd': [_P, _I, _I, _I, _I, _P, _I, _P, _I, _F, _I, _I, _P, _P, _I, _P],
+    'sgg_union_rects_fwd': [_P, _P, _I, _I, _F, _P, _P],
+    'sgg_union_rect_patches': [_P, _P, _I, _I, _P, _I, _I, _P],
+    'sgg_max4_rows': [_P, _P, _I, _I, _I, _P],
+    'sgg_bcast_add': [_P, _P, _I, _I, _I, _I, _P],
+    'sgg_gemm': [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    'sgg_imp_node_gate_dots': [_P, _I, _I, _P, _P, _I, _P],
+    'sgg_imp_edge_ctx_fwd': [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
+    'sgg_imp_node_scatter_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P],
+    'sgg_gru_gate_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'sgg_eval_tail': [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    'sgg_cast': [_P, _P, _L, _I, _I, _P],
+    'sgg_permute_ncp_to_npc': [_P, _P, _I, _I, _I, _I, _I, _P],
+}
+_RESTYPE = {'sgg_build_info': c_char_p}
+
+_ERRORS = {-1: (ValueError, 'bad argument (size / alignment / null pointer)'),
+           -2: (TypeError, 'unsupported element type'),
+           -3: (RuntimeError, 'HIP kernel launch failed'),
+           -4: (ValueError, 'output capacity too small')}
+
+_lib = None
+
+
+def load():
+    """Load (once) and type the shared library.  Raises ImportError if it is absent: build it with
+    `python -c "import __graft_entry__ as g; g.build()"` or `make -C sgg_amd/csrc`."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError('sgg_amd: %s not found -- the HIP extension is mandatory (no CPU fallback). '
+                          'Build it: make -C sgg_amd/csrc' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, c_int)
+    if lib.sgg_abi_version() != ABI_VERSION:
+        raise ImportError('sgg_amd: ABI version mismatch (%d != %d): rebuild' % (lib.sgg_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        exc, msg = _ERRORS.get(code, (RuntimeError, 'error %d' % code))
+        raise exc('%s: %s' % (what, msg))
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

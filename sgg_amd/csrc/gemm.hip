@@ -1,0 +1,313 @@
+// MFMA tile kernels for gfx950: nn.Linear-shaped GEMM and 3x3 convolution as implicit GEMM.
+//
+//   C[m][n] = post_scale[n] * act( sum_k A[m][k] * W[n][k] + bias[n] ) + post_shift[n]
+//
+// Both operands are K-contiguous (activations [M,K], weights [N,K] = nn.Linear / [Cout][3][3][Cin]), so one
+// 128-byte LDS row holds a K-slab of 64 bf16 or 32 f32 for one m (or n).  Tiles are staged HBM->LDS with
+// global_load_lds_dwordx4 (no VGPR round trip); the LDS image is lane-linear, so the bank swizzle
+// (16-byte slot ^= (row>>1)&7, conflict-free for the 32-row ds_read_b128 fragment reads) is applied on the
+// per-lane SOURCE address and again on the read.  Each of the 4 waves owns a 64x64 output tile = 2x2 MFMA
+// 32x32 tiles (v_mfma_f32_32x32x16_bf16, or v_mfma_f32_32x32x2_f32 for the exact-fp32 parity mode), computed
+// transposed (weights as the MFMA A operand) so that a lane holds 4 consecutive n.  The epilogue goes through
+// LDS so that global stores are row-contiguous 16-byte pieces.
+//
+// Replaces (reference): nn.Linear calls at sgg_models/rel_model_stanford.py:29-37,103-107 and
+// sgg_models/rel_model_base.py:110-111; [3P] cuDNN 3x3 convs of vgg16.features (rel_model_base.py:184).
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+constexpr int ROWB = 128;  // bytes of K per LDS row
+
+struct GemmArgs {
+    const char* A;
+    const char* A2;
+    const char* Wt;
+    long lda_b, lda2_b, ldw_b;  // bytes
+    int nt1, nt;                // k-tiles in segment 1 / total
+    const float* bias;
+    const float* pscale;
+    const float* pshift;
+    char* C;
+    long ldc;  // elements
+    int M, N, act, out_bf16;
+    // conv mode
+    int H, W, Cin, out_pad;
+};
+
+__device__ __forceinline__ void glds16(const char* g, char* l) {
+    __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)l, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// WM x WN waves of 64x64; block tile (64*WM) x (64*WN); 256 threads.
+template <bool BF16, int WM, int WN, bool CONV>
+__global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int LA = 2 * WM, LB = 2 * WN;  // 8-row load instructions per wave per tile
+    constexpr int ESZ = BF16 ? 2 : 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WN, wc = wave % WN;
+
+    // ---- block -> tile: XCD-contiguous ids, then groups of 8 M-panels walk N (L2 reuse of both panels)
+    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    const int nwg = tilesM * tilesN;
+    int L = xcd_remap(blockIdx.x, nwg);
+    constexpr int GM = 8;
+    const int per_group = GM * tilesN;
+    const int grp = L / per_group;
+    const int gm0 = grp * GM;
+    const int gsz = min(GM, tilesM - gm0);
+    const int inl = L - grp * per_group;
+    const int tm = gm0 + inl % gsz, tn = inl / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- per-lane source pointers (16-byte chunk of a 128-byte row, swizzled)
+    const int lrow = lane >> 3;  // row inside an 8-row load
+    const char* arp[LA];
+    const char* arp2[LA];
+    const char* brp[LB];
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+        const int r = (wave * LA + j) * 8 + lrow;
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        const int m = min(m0 + r, g.M - 1);
+        if constexpr (CONV) {
+            const int hw = g.H * g.W;
+            const int b = m / hw, rem = m - b * hw;
+            const int y = rem / g.W, x = rem - y * g.W;
+            arp[j] = g.A + ((long)(b * (g.H + 2) + y) * (g.W + 2) + x) * g.Cin * ESZ + chunk * 16;
+            arp2[j] = nullptr;
+        } else {
+            arp[j] = g.A + (long)m * g.lda_b + chunk * 16;
+            arp2[j] = g.A2 ? g.A2 + (long)m * g.lda2_b + chunk * 16 : nullptr;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+        const int r = (wave * LB + j) * 8 + lrow;
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        const int n = min(n0 + r, g.N - 1);
+        brp[j] = g.Wt + (long)n * g.ldw_b + chunk * 16;
+    }
+    const int tpc = CONV ? (g.Cin * ESZ) / ROWB : 1;  // k-tiles per conv tap
+
+    auto stage = [&](int kt, int buf) {
+        char* sa = smem + buf * STAGE;
+        char* sb = sa + A_BYTES;
+        long koff;
+        bool seg2 = false;
+        if constexpr (CONV) {
+            const int tap = kt / tpc, c0 = kt - tap * tpc;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            koff = ((long)(ky * (g.W + 2) + kx) * g.Cin) * ESZ + c0 * ROWB;
+        } else {
+            seg2 = kt >= g.nt1;
+            koff = (long)(seg2 ? kt - g.nt1 : kt) * ROWB;
+        }
+#pragma unroll
+        for (int j = 0; j < LA; ++j)
+            glds16((seg2 ? arp2[j] : arp[j]) + koff, sa + (wave * LA + j) * 8 * ROWB);
+        const long koffb = (long)kt * ROWB;
+#pragma unroll
+        for (int j = 0; j < LB; ++j) glds16(brp[j] + koffb, sb + (wave * LB + j) * 8 * ROWB);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets: row = base + (lane&31), logical slot = 2*s + (lane>>5)
+    const int fr = lane & 31, fh = lane >> 5;
+    int aoff[2], boff[2], akey[2], bkey[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = wr * 64 + i * 32 + fr, rb = wc * 64 + i * 32 + fr;
+        aoff[i] = ra * ROWB;
+        boff[i] = rb * ROWB;
+        akey[i] = (ra >> 1) & 7;
+        bkey[i] = (rb >> 1) & 7;
+    }
+
+    stage(0, 0);
+    for (int kt = 0; kt < g.nt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < g.nt) {
+            stage(kt + 1, buf ^ 1);
+            wait_vmcnt<LA + LB>();  // tile kt landed (this wave's part); tile kt+1 stays in flight
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        const char* sa = smem + buf * STAGE;
+        const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int slot = 2 * s + fh;
+            u32x4 av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                av[i] = *reinterpret_cast<const u32x4*>(sa + aoff[i] + ((slot ^ akey[i]) << 4));
+                bv[i] = *reinterpret_cast<const u32x4*>(sb + boff[i] + ((slot ^ bkey[i]) << 4));
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    if constexpr (BF16) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8_t, bv[ni]), __builtin_bit_cast(bf16x8_t, av[mi]), acc[mi][ni], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                __uint_as_float(bv[ni][q]), __uint_as_float(av[mi][q]), acc[mi][ni], 0, 0, 0);
+                    }
+                }
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue through LDS: per wave a [32][64] f32 staging tile (row stride 272 B), two halves (mi)
+    constexpr int ESTRIDE = 272;
+    char* est = smem + wave * (32 * ESTRIDE);
+    const bool vec_ok = CONV || ((g.ldc & 7) == 0);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        __syncthreads();
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+                *reinterpret_cast<f32x4*>(est + fr * ESTRIDE + (ni * 32 + 8 * q + 4 * fh) * 4) = v;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rl = (lane >> 3) + 8 * it, cl = (lane & 7) * 8;
+            const int m = m0 + wr * 64 + mi * 32 + rl;
+            const int n = n0 + wc * 64 + cl;
+            if (m >= g.M || n >= g.N) continue;
+            float v[8];
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(est + rl * ESTRIDE + cl * 4);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(est + rl * ESTRIDE + cl * 4 + 16);
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            const int nv = min(8, g.N - n);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k < nv) {
+                    float t = v[k] + (g.bias ? g.bias[n + k] : 0.f);
+                    if (g.act == SGG_ACT_RELU) t = fmaxf(t, 0.f);
+                    if (g.pscale) t = t * g.pscale[n + k];
+                    if (g.pshift) t = t + g.pshift[n + k];
+                    v[k] = t;
+                }
+            }
+            long off;
+            if constexpr (CONV) {
+                const int hw = g.H * g.W;
+                const int b = m / hw, rem = m - b * hw;
+                const int y = rem / g.W, x = rem - y * g.W;
+                const int op = g.out_pad;
+                off = ((long)(b * (g.H + 2 * op) + y + op) * (g.W + 2 * op) + x + op) * g.N + n;
+            } else {
+                off = (long)m * g.ldc + n;
+            }
+            if (vec_ok && nv == 8) {
+                if (g.out_bf16) store8(reinterpret_cast<bf16_t*>(g.C) + off, v);
+                else store8(reinterpret_cast<float*>(g.C) + off, v);
+            } else {
+                for (int k = 0; k < nv; ++k) {
+                    if (g.out_bf16) reinterpret_cast<bf16_t*>(g.C)[off + k] = f32_to_bf16(v[k]);
+                    else reinterpret_cast<float*>(g.C)[off + k] = v[k];
+                }
+            }
+        }
+    }
+}
+
+template <bool BF16, int WM, int WN, bool CONV>
+int launch(const GemmArgs& g, hipStream_t s) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int smem = 2 * (BM + BN) * ROWB;
+    static_assert(smem >= 4 * 32 * 272, "epilogue staging fits");
+    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    auto k = mfma_tile_kernel<BF16, WM, WN, CONV>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return SGG_ERR_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(tilesM * tilesN), dim3(256), smem, s, g);
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+template <bool CONV>
+int dispatch(const GemmArgs& g, bool bf16, hipStream_t s) {
+    // N <= 64 (or a ragged small N): 256x64 tiles; otherwise 128x128
+    const bool narrow = g.N <= 64 || (g.N < 128);
+    if (bf16) return narrow ? launch<true, 4, 1, CONV>(g, s) : launch<true, 2, 2, CONV>(g, s);
+    return narrow ? launch<false, 4, 1, CONV>(g, s) : launch<false, 2, 2, CONV>(g, s);
+}
+
+}  // namespace
+
+extern "C" int sgg_gemm(const void* A, int lda, const void* A2, int lda2, int K1, const void* W, int ldw,
+                        const float* bias, const float* post_scale, const float* post_shift, void* C, int ldc, int M,
+                        int N, int K, int act, int in_dtype, int out_dtype, void* stream) {
+    if (in_dtype != SGG_F32 && in_dtype != SGG_BF16) return SGG_ERR_DTYPE;
+    if (out_dtype != SGG_F32 && out_dtype != SGG_BF16) return SGG_ERR_DTYPE;
+    if (M == 0 || N == 0) return SGG_OK;
+    const int esz = in_dtype == SGG_BF16 ? 2 : 4;
+    const int bke = ROWB / esz;
+    if (!A || !W || !C || M < 0 || N < 0 || K <= 0 || K % bke) return SGG_ERR_ARG;
+    if (!A2) K1 = K;
+    if (K1 <= 0 || K1 > K || K1 % bke) return SGG_ERR_ARG;
+    if ((lda & 7) || (ldw & 7) || (A2 && (lda2 & 7))) return SGG_ERR_ARG;
+    if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)(A2 ? A2 : A)) & 15) return SGG_ERR_ARG;
+    if (lda < K1 || ldw < K || ldc < N || (A2 && lda2 < K - K1)) return SGG_ERR_ARG;
+    GemmArgs g{};
+    g.A = (const char*)A; g.A2 = (const char*)A2; g.Wt = (const char*)W;
+    g.lda_b = (long)lda * esz; g.lda2_b = (long)lda2 * esz; g.ldw_b = (long)ldw * esz;
+    g.nt1 = K1 / bke; g.nt = K / bke;
+    g.bias = bias; g.pscale = post_scale; g.pshift = post_shift;
+    g.C = (char*)C; g.ldc = ldc; g.M = M; g.N = N; g.act = act; g.out_bf16 = out_dtype == SGG_BF16;
+    return dispatch<false>(g, in_dtype == SGG_BF16, (hipStream_t)stream);
+}
+
+extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H,
+                                int W, int Cin, int Cout, int dtype, void* stream) {
+    if (dtype != SGG_F32 && dtype != SGG_BF16) return SGG_ERR_DTYPE;
+    const int esz = dtype == SGG_BF16 ? 2 : 4;
+    const int bke = ROWB / esz;
+    if (!in || !w || !out || B <= 0 || H <= 0 || W <= 0 || Cin % bke || Cout % 64 || (out_pad != 0 && out_pad != 1))
+        return SGG_ERR_ARG;
+    if ((long)B * H * W > 0x7fffffffL) return SGG_ERR_ARG;
+    GemmArgs g{};
+    g.A = (const char*)in; g.Wt = (const char*)w;
+    g.ldw_b = (long)9 * Cin * esz;
+    g.nt = 9 * Cin / bke; g.nt1 = g.nt;
+    g.bias = bias; g.C = (char*)out; g.M = B * H * W; g.N = Cout; g.act = SGG_ACT_RELU;
+    g.out_bf16 = dtype == SGG_BF16;
+    g.H = H; g.W = W; g.Cin = Cin; g.out_pad = out_pad;
+    return dispatch<true>(g, dtype == SGG_BF16, (hipStream_t)stream);
+}

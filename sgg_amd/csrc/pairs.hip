@@ -1,0 +1,211 @@
+// Candidate-pair indexing (int64 index work, bit-exact with the reference) and the CSR edge lists of the IMP scatter.
+//   eval : RelModelBase.get_rel_inds, sgg_models/rel_model_base.py:147-163
+//   train: proposal_assignments_gtbox, lib/proposal_assignments_gtbox.py:7-80 (no-sampling path)
+// Order-preserving stream compaction: one wave per subject row, ballot / prefix inside the wave, a block scan over
+// the row counts.  No atomics decide positions, so results are deterministic.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ bool same_img_pair(const int64_t* im, int i, int j) { return i != j && im[i] == im[j]; }
+
+// [3P] torchvision box_iou (no +1) as used by bbox_overlaps, lib/pytorch_misc.py:60-67
+__device__ __forceinline__ bool iou_positive(const float* b, int i, int j) {
+    const float* p = b + 4 * (long)i;
+    const float* q = b + 4 * (long)j;
+    const float a1 = (p[2] - p[0]) * (p[3] - p[1]), a2 = (q[2] - q[0]) * (q[3] - q[1]);
+    const float w = fmaxf(fminf(p[2], q[2]) - fmaxf(p[0], q[0]), 0.f);
+    const float h = fmaxf(fminf(p[3], q[3]) - fmaxf(p[1], q[1]), 0.f);
+    const float inter = w * h;
+    return inter / (a1 + a2 - inter) > 0.f;
+}
+
+__device__ __forceinline__ int lanes_below(unsigned long long mask, int lane) {
+    return __popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// wave-inclusive prefix sum
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// ---- eval: count (WRITE=false) / write (WRITE=true); grid = N rows, 64 threads
+template <bool WRITE>
+__global__ __launch_bounds__(64) void pair_eval_kernel(const int64_t* __restrict__ im, const float* __restrict__ boxes, int N,
+                                                       int overlap, int* __restrict__ rowoff, int64_t* __restrict__ out,
+                                                       int cap) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    int base = WRITE ? rowoff[i] : 0;
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        const int j = j0 + lane;
+        bool ok = j < N && same_img_pair(im, i, j);
+        if (ok && overlap) ok = iou_positive(boxes, i, j);
+        const unsigned long long m = __ballot(ok);
+        if (WRITE) {
+            const int pos = base + lanes_below(m, lane);
+            if (ok && pos < cap) {
+                out[3 * (long)pos] = im[i];
+                out[3 * (long)pos + 1] = i;
+                out[3 * (long)pos + 2] = j;
+            }
+        }
+        base += __popcll(m);
+    }
+    if (!WRITE && lane == 0) rowoff[i] = base;
+}
+
+// exclusive scan of a[0..n) in place, total -> a[n] and *count.  One block of 1024 threads.
+__global__ __launch_bounds__(1024) void excl_scan_kernel(int* __restrict__ a, int n, int* __restrict__ count) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int idx = base + tid;
+        const int v = idx < n ? a[idx] : 0;
+        const int inc = wave_incl_scan(v, lane);
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const int carry = carry_s;
+        if (idx < n) a[idx] = carry + woff + inc - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        a[n] = carry_s;
+        if (count) *count = carry_s;
+    }
+}
+
+// ---- train
+// cnt[s*N+o] += 1 per FG relation; rank[r] = # earlier FG relations on the same pair (deterministic duplicate order)
+__global__ __launch_bounds__(256) void fg_mark_kernel(const int64_t* __restrict__ gt_rels, int R, const int* __restrict__ first,
+                                                      int N, int* __restrict__ cnt, int* __restrict__ rank) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const int f = first[gt_rels[4 * (long)r]];
+    const long s = f + gt_rels[4 * (long)r + 1], o = f + gt_rels[4 * (long)r + 2];
+    atomicAdd(&cnt[s * N + o], 1);
+    int rk = 0;
+    for (int q = 0; q < r; ++q) {
+        const int fq = first[gt_rels[4 * (long)q]];
+        if (fq + gt_rels[4 * (long)q + 1] == s && fq + gt_rels[4 * (long)q + 2] == o) ++rk;
+    }
+    rank[r] = rk;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void pair_train_kernel(const int64_t* __restrict__ im, int N, int* __restrict__ cnt,
+                                                        int* __restrict__ rowoff, int64_t* __restrict__ out, int cap) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    int base = WRITE ? rowoff[i] : 0;
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        const int j = j0 + lane;
+        const bool ok = j < N && same_img_pair(im, i, j);
+        const int c = ok ? cnt[(long)i * N + j] : 0;
+        const int rows = ok ? max(c, 1) : 0;
+        const int inc = wave_incl_scan(rows, lane);
+        if (WRITE && ok) {
+            const int pos = base + inc - rows;
+            if (c == 0) {
+                if (pos < cap) {
+                    out[4 * (long)pos] = im[i];
+                    out[4 * (long)pos + 1] = i;
+                    out[4 * (long)pos + 2] = j;
+                    out[4 * (long)pos + 3] = 0;
+                }
+            } else {
+                cnt[(long)i * N + j] = pos;  // position of the pair's first FG row, for fg_fill_kernel
+            }
+        }
+        base += __shfl(inc, 63, 64);
+    }
+    if (!WRITE && lane == 0) rowoff[i] = base;
+}
+
+__global__ __launch_bounds__(256) void fg_fill_kernel(const int64_t* __restrict__ gt_rels, int R, const int* __restrict__ first,
+                                                      int N, const int* __restrict__ posmap, const int* __restrict__ rank,
+                                                      int64_t* __restrict__ out, int cap) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const int f = first[gt_rels[4 * (long)r]];
+    const long s = f + gt_rels[4 * (long)r + 1], o = f + gt_rels[4 * (long)r + 2];
+    const int pos = posmap[s * N + o] + rank[r];
+    if (pos < cap) {
+        out[4 * (long)pos] = gt_rels[4 * (long)r];
+        out[4 * (long)pos + 1] = s;
+        out[4 * (long)pos + 2] = o;
+        out[4 * (long)pos + 3] = gt_rels[4 * (long)r + 3];
+    }
+}
+
+// ---- CSR lists: one wave per (node, side); scans the edge list in order (ballot compaction keeps edge order)
+template <bool WRITE>
+__global__ __launch_bounds__(64) void csr_kernel(const int64_t* __restrict__ rel, int E, int N, int* __restrict__ optr,
+                                                 int* __restrict__ iptr, int* __restrict__ oids, int* __restrict__ iids) {
+    const int n = blockIdx.x >> 1, side = blockIdx.x & 1, lane = threadIdx.x;
+    int* ptr = side ? iptr : optr;
+    int* ids = side ? iids : oids;
+    int base = WRITE ? ptr[n] : 0;
+    for (int e0 = 0; e0 < E; e0 += 64) {
+        const int e = e0 + lane;
+        const bool ok = e < E && rel[3 * (long)e + 1 + side] == n;
+        const unsigned long long m = __ballot(ok);
+        if (WRITE && ok) ids[base + lanes_below(m, lane)] = e;
+        base += __popcll(m);
+    }
+    if (!WRITE && lane == 0) ptr[n] = base;
+}
+
+}  // namespace
+
+extern "C" int sgg_pair_index_eval(const int64_t* im_inds, const float* boxes, int N, int require_overlap,
+                                   int64_t* rel_inds, int cap, int* count, int* work, void* stream) {
+    if (!im_inds || !rel_inds || !count || !work || N <= 0 || cap < 0 || (require_overlap && !boxes)) return SGG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pair_eval_kernel<false>, dim3(N), dim3(64), 0, s, im_inds, boxes, N, require_overlap, work, rel_inds, cap);
+    hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, s, work, N, count);
+    hipLaunchKernelGGL(pair_eval_kernel<true>, dim3(N), dim3(64), 0, s, im_inds, boxes, N, require_overlap, work, rel_inds, cap);
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_pair_index_train(const int64_t* im_inds, int N, const int64_t* gt_rels, int R, const int* img_first,
+                                    int64_t* rel_labels, int cap, int* count, int* work, void* stream) {
+    if (!im_inds || !rel_labels || !count || !work || N <= 0 || cap < 0 || R < 0 || (R > 0 && (!gt_rels || !img_first)))
+        return SGG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int* rowoff = work;                 // N+1
+    int* cnt = work + N + 2;            // N*N
+    int* rank = cnt + (long)N * N;      // R
+    if (hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)N * N, s) != hipSuccess) return SGG_ERR_LAUNCH;
+    if (R > 0) hipLaunchKernelGGL(fg_mark_kernel, dim3((R + 255) / 256), dim3(256), 0, s, gt_rels, R, img_first, N, cnt, rank);
+    hipLaunchKernelGGL(pair_train_kernel<false>, dim3(N), dim3(64), 0, s, im_inds, N, cnt, rowoff, rel_labels, cap);
+    hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, s, rowoff, N, count);
+    hipLaunchKernelGGL(pair_train_kernel<true>, dim3(N), dim3(64), 0, s, im_inds, N, cnt, rowoff, rel_labels, cap);
+    if (R > 0) hipLaunchKernelGGL(fg_fill_kernel, dim3((R + 255) / 256), dim3(256), 0, s, gt_rels, R, img_first, N, cnt, rank, rel_labels, cap);
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_edge_csr(const int64_t* rel_inds, int E, int N, int* out_ptr, int* out_ids, int* in_ptr, int* in_ids,
+                            int* work, void* stream) {
+    (void)work;
+    if (!rel_inds || !out_ptr || !out_ids || !in_ptr || !in_ids || N <= 0 || E < 0) return SGG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(csr_kernel<false>, dim3(2 * N), dim3(64), 0, s, rel_inds, E, N, out_ptr, in_ptr, out_ids, in_ids);
+    hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, s, out_ptr, N, (int*)nullptr);
+    hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, s, in_ptr, N, (int*)nullptr);
+    hipLaunchKernelGGL(csr_kernel<true>, dim3(2 * N), dim3(64), 0, s, rel_inds, E, N, out_ptr, in_ptr, out_ids, in_ids);
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}

@@ -1,0 +1,277 @@
+// Detector front-end pieces that are HBM-bound: image prep, VGG conv1_1 (Cin=3), 2x2 max-pool, RoIAlign.
+// Layout: zero-bordered channels-last planes, so the 3x3 convs never test image borders.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// a-1  [3P] GeneralizedRCNNTransform (called at sgg_models/rel_model_base.py:183): normalise, bilinear
+// resize (align_corners=False, scale recomputed from sizes), into the interior of a zero NHWC4 plane.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void image_prep_kernel(const float* __restrict__ img, int h, int w, int rh, int rw,
+                                                         float* __restrict__ out, int b, int Hp, int Wp) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= rw || y >= rh) return;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    float v[3];
+    if (rh == h && rw == w) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (img[((long)c * h + y) * w + x] - mean[c]) / stdv[c];
+    } else {
+        const float sy = (float)h / (float)rh, sx = (float)w / (float)rw;
+        float fy = sy * ((float)y + 0.5f) - 0.5f, fx = sx * ((float)x + 0.5f) - 0.5f;
+        fy = fy < 0.f ? 0.f : fy;
+        fx = fx < 0.f ? 0.f : fx;
+        const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
+        const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* p = img + (long)c * h * w;
+            const float a = (p[(long)y0 * w + x0] - mean[c]) / stdv[c], bq = (p[(long)y0 * w + x1] - mean[c]) / stdv[c];
+            const float cq = (p[(long)y1 * w + x0] - mean[c]) / stdv[c], d = (p[(long)y1 * w + x1] - mean[c]) / stdv[c];
+            v[c] = hy * (hx * a + lx * bq) + ly * (hx * cq + lx * d);
+        }
+    }
+    f32x4 o = {v[0], v[1], v[2], 0.f};
+    *reinterpret_cast<f32x4*>(out + (((long)b * (Hp + 2) + y + 1) * (Wp + 2) + x + 1) * 4) = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a-2  conv1_1 (3 -> 64, 3x3, pad 1) + ReLU, fp32 VALU (K = 27 is too thin for MFMA, the layer is
+// write-bound: 64 outputs per 27 inputs).  256 threads = 64 pixels x 4 groups of 16 output channels.
+// ------------------------------------------------------------------------------------------------
+template <typename OutT>
+__global__ __launch_bounds__(256) void conv1_1_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, OutT* __restrict__ out, long npix,
+                                                      int H, int W) {
+    __shared__ float ws[27 * 64];
+    __shared__ float bs[64];
+    for (int i = threadIdx.x; i < 27 * 64; i += 256) {
+        const int k = i >> 6, co = i & 63;
+        ws[i] = w[co * 27 + k];
+    }
+    if (threadIdx.x < 64) bs[threadIdx.x] = bias[threadIdx.x];
+    __syncthreads();
+    const long pix = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int cg = (threadIdx.x & 3) * 16;
+    if (pix >= npix) return;
+    const long hw = (long)H * W;
+    const int b = (int)(pix / hw);
+    const int rem = (int)(pix - (long)b * hw);
+    const int y = rem / W, x = rem - y * W;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = bs[cg + j];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const f32x4 p = *reinterpret_cast<const f32x4*>(in + (((long)b * (H + 2) + y + ky) * (W + 2) + x + kx) * 4);
+            const float pv[3] = {p.x, p.y, p.z};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* wk = ws + ((ky * 3 + kx) * 3 + c) * 64 + cg;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j] = fmaf(pv[c], wk[j], acc[j]);
+            }
+        }
+    float o0[8], o1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        o0[j] = fmaxf(acc[j], 0.f);
+        o1[j] = fmaxf(acc[8 + j], 0.f);
+    }
+    OutT* op = out + (((long)b * (H + 2) + y + 1) * (W + 2) + x + 1) * 64 + cg;
+    store8(op, o0);
+    store8(op + 8, o1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2x2 / stride-2 max pool between the VGG blocks (thread = output pixel x 8 channels)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, T* __restrict__ out, int op, int H, int W,
+                                                      int C, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c8 = C >> 3;
+    const int cc = (int)(i % c8) * 8;
+    long p = i / c8;
+    const int Wo = W >> 1, Ho = H >> 1;
+    const int xo = (int)(p % Wo);
+    p /= Wo;
+    const int yo = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const T* s = in + (((long)b * (H + 2) + 2 * yo + 1) * (W + 2) + 2 * xo + 1) * C + cc;
+    float a[8], t[8];
+    load8(s, a);
+    load8(s + C, t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = fmaxf(a[k], t[k]);
+    load8(s + (long)(W + 2) * C, t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = fmaxf(a[k], t[k]);
+    load8(s + (long)(W + 2) * C + C, t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = fmaxf(a[k], t[k]);
+    store8(out + (((long)b * (Ho + 2 * op) + yo + op) * (Wo + 2 * op) + xo + op) * C + cc, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a-4  RoIAlign, torchvision semantics (aligned=False), union box fused (rel_model_base.py:248-250),
+// optional fused broadcast add (lib/get_union_boxes.py:101).  One workgroup per RoI; one wave per bin;
+// a lane owns 8 consecutive channels, so every feature-map access is a full 16-byte (bf16) / 32-byte (f32)
+// piece of one pixel's channel vector (1 KiB per wave for C=512) and every output row is written whole.
+// RoIs are visited XCD-contiguously: RoIs are sorted by image, so one image's map stays in one XCD's L2.
+// ------------------------------------------------------------------------------------------------
+constexpr int MAXS = 32;  // max P*sampling samples per axis
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_kernel(const T* __restrict__ fmap, int B, int H, int W, int C,
+                                                        const float* __restrict__ rois, const int64_t* __restrict__ pairs,
+                                                        int R, float scale, int P, int S, const float* __restrict__ add_ec,
+                                                        T* __restrict__ out) {
+    __shared__ int s_lo[2][MAXS], s_hi[2][MAXS];
+    __shared__ float s_l[2][MAXS], s_h[2][MAXS];  // s_h < 0 marks an out-of-range sample
+    __shared__ int s_b;
+    const int r = xcd_remap(blockIdx.x, R);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int PS = P * S;
+    if (tid < 2 * PS) {
+        const int axis = tid / PS, k = tid - axis * PS;  // axis 0 = y, 1 = x
+        float lo_c, hi_c, bi;
+        if (pairs) {
+            const float* a = rois + pairs[2 * (long)r] * 5;
+            const float* b = rois + pairs[2 * (long)r + 1] * 5;
+            bi = a[0];
+            lo_c = fminf(a[2 - axis], b[2 - axis]);
+            hi_c = fmaxf(a[4 - axis], b[4 - axis]);
+        } else {
+            const float* a = rois + (long)r * 5;
+            bi = a[0];
+            lo_c = a[2 - axis];
+            hi_c = a[4 - axis];
+        }
+        const int L = axis == 0 ? H : W;
+        const float start = lo_c * scale, end = hi_c * scale;
+        const float len = fmaxf(end - start, 1.0f);
+        const float bin = len / (float)P;
+        const int p = k / S, i = k - p * S;
+        float c = start + (float)p * bin + ((float)i + 0.5f) * bin / (float)S;
+        const bool valid = !(c < -1.0f || c > (float)L);
+        c = c <= 0.f ? 0.f : c;
+        int lo = (int)c, hi;
+        if (lo >= L - 1) {
+            hi = lo = L - 1;
+            c = (float)lo;
+        } else {
+            hi = lo + 1;
+        }
+        const float l = c - (float)lo;
+        s_lo[axis][k] = valid ? lo : 0;
+        s_hi[axis][k] = valid ? hi : 0;
+        s_l[axis][k] = l;
+        s_h[axis][k] = valid ? 1.f - l : -1.f;
+        if (tid == 0) s_b = min(max((int)bi, 0), B - 1);
+    }
+    __syncthreads();
+    const T* fm = fmap + (long)s_b * H * W * C;
+    const float inv = 1.0f / (float)(S * S);
+    for (int c0 = lane * 8; c0 < C; c0 += 512) {
+        float addv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) addv[k] = add_ec ? add_ec[(long)r * C + c0 + k] : 0.f;
+        for (int bin = wave; bin < P * P; bin += 4) {
+            const int ph = bin / P, pw = bin - ph * P;
+            float acc[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+            for (int iy = 0; iy < S; ++iy) {
+                const int ky = ph * S + iy;
+                const float hy = s_h[0][ky], ly = s_l[0][ky];
+                if (hy < 0.f) continue;
+                const T* row_lo = fm + (long)s_lo[0][ky] * W * C + c0;
+                const T* row_hi = fm + (long)s_hi[0][ky] * W * C + c0;
+                for (int ix = 0; ix < S; ++ix) {
+                    const int kx = pw * S + ix;
+                    const float hx = s_h[1][kx], lx = s_l[1][kx];
+                    if (hx < 0.f) continue;
+                    const int xl = s_lo[1][kx] * C, xh = s_hi[1][kx] * C;
+                    float v1[8], v2[8], v3[8], v4[8];
+                    load8(row_lo + xl, v1);
+                    load8(row_lo + xh, v2);
+                    load8(row_hi + xl, v3);
+                    load8(row_hi + xh, v4);
+                    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] += w1 * v1[k] + w2 * v2[k] + w3 * v3[k] + w4 * v4[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = acc[k] * inv + addv[k];
+            store8(out + ((long)r * P * P + bin) * C + c0, acc);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sgg_image_prep(const float* img, int h, int w, int rh, int rw, float* out, int b, int Hp, int Wp,
+                              void* stream) {
+    if (!img || !out || h <= 0 || w <= 0 || rh <= 0 || rw <= 0 || rh > Hp || rw > Wp || b < 0) return SGG_ERR_ARG;
+    dim3 grid((rw + 255) / 256, rh);
+    hipLaunchKernelGGL(image_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, h, w, rh, rw, out, b, Hp, Wp);
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_conv1_1(const float* in, const float* w, const float* bias, void* out, int B, int H, int W,
+                           int out_dtype, void* stream) {
+    if (!in || !w || !bias || !out || B <= 0 || H <= 0 || W <= 0) return SGG_ERR_ARG;
+    const long npix = (long)B * H * W;
+    const int grid = (int)((npix + 63) / 64);
+    if (out_dtype == SGG_BF16)
+        hipLaunchKernelGGL(conv1_1_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, w, bias, (bf16_t*)out, npix, H, W);
+    else if (out_dtype == SGG_F32)
+        hipLaunchKernelGGL(conv1_1_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, w, bias, (float*)out, npix, H, W);
+    else
+        return SGG_ERR_DTYPE;
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_maxpool2x2(const void* in, void* out, int out_pad, int B, int H, int W, int C, int dtype, void* stream) {
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || (C & 7) || (out_pad != 0 && out_pad != 1))
+        return SGG_ERR_ARG;
+    const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+    const int grid = (int)((total + 255) / 256);
+    if (dtype == SGG_BF16)
+        hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, out_pad, H, W, C, total);
+    else if (dtype == SGG_F32)
+        hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)in, (float*)out, out_pad, H, W, C, total);
+    else
+        return SGG_ERR_DTYPE;
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_roi_align_fwd(const void* fmap, int B, int H, int W, int C, const float* rois, int Nroi,
+                                 const int64_t* pairs, int R, float spatial_scale, int P, int sampling,
+                                 const float* add_ec, void* out, int dtype, void* stream) {
+    if (R == 0) return SGG_OK;
+    if (!fmap || !rois || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || R < 0 || Nroi <= 0 || P <= 0 ||
+        sampling <= 0 || P * sampling > MAXS)
+        return SGG_ERR_ARG;
+    if (!pairs && R != Nroi) return SGG_ERR_ARG;
+    if (dtype == SGG_BF16)
+        hipLaunchKernelGGL(roi_align_kernel<bf16_t>, dim3(R), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)fmap, B, H, W, C,
+                           rois, pairs, R, spatial_scale, P, sampling, add_ec, (bf16_t*)out);
+    else if (dtype == SGG_F32)
+        hipLaunchKernelGGL(roi_align_kernel<float>, dim3(R), dim3(256), 0, (hipStream_t)stream, (const float*)fmap, B, H, W, C,
+                           rois, pairs, R, spatial_scale, P, sampling, add_ec, (float*)out);
+    else
+        return SGG_ERR_DTYPE;
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}

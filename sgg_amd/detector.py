@@ -1,0 +1,163 @@
+"""Frozen VGG-16 Faster-R-CNN front end (feature extractor part) on the HIP path.
+
+Mirrors the module tree of the torchvision `FasterRCNN(vgg.features, ...)` object the reference builds at
+sgg_models/rel_model_base.py:92-108, so that `state_dict()` keys are identical
+(`detector.backbone.{0,2,5,...}.{weight,bias}`, `detector.rpn.head.*`, `detector.roi_heads.box_head.fc{6,7}.*`,
+`detector.roi_heads.box_predictor.{cls_score,bbox_pred}.*`) and reference checkpoints load
+(lib/pytorch_misc.py:183-203).  torchvision itself is not used (it is not installed); the nn.Modules below only
+HOLD parameters -- the arithmetic runs in libsgg_hip.so.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+VGG16_CFG = (64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512)
+
+
+def make_vgg_features():
+    """[3P] torchvision vgg16().features with module '30' (last max-pool) deleted (rel_model_base.py:312)."""
+    layers, cin = [], 3
+    for v in VGG16_CFG:
+        if v == 'M':
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    seq = nn.Sequential(*layers)
+    seq.out_channels = 512
+    return seq
+
+
+def make_vgg_classifier(in_dim=512 * 7 * 7, dim=4096):
+    """[3P] vgg16().classifier with '6' deleted (rel_model_base.py:313): Linear ReLU Dropout Linear ReLU Dropout."""
+    return nn.Sequential(nn.Linear(in_dim, dim), nn.ReLU(True), nn.Dropout(), nn.Linear(dim, dim), nn.ReLU(True),
+                         nn.Dropout())
+
+
+class _RPNHead(nn.Module):
+    def __init__(self, c, a):
+        super(_RPNHead, self).__init__()
+        self.conv = nn.Conv2d(c, c, 3, padding=1)
+        self.cls_logits = nn.Conv2d(c, a, 1)
+        self.bbox_pred = nn.Conv2d(c, a * 4, 1)
+
+
+class _RPN(nn.Module):
+    def __init__(self, c, a):
+        super(_RPN, self).__init__()
+        self.head = _RPNHead(c, a)
+
+
+class _TwoMLPHead(nn.Module):
+    def __init__(self, i, d):
+        super(_TwoMLPHead, self).__init__()
+        self.fc6 = nn.Linear(i, d)
+        self.fc7 = nn.Linear(d, d)
+
+
+class _Predictor(nn.Module):
+    def __init__(self, d, ncls):
+        super(_Predictor, self).__init__()
+        self.cls_score = nn.Linear(d, ncls)
+        self.bbox_pred = nn.Linear(d, ncls * 4)
+
+
+class _RoIHeads(nn.Module):
+    def __init__(self, c, pool, d, ncls, score_thresh, dets):
+        super(_RoIHeads, self).__init__()
+        self.box_head = _TwoMLPHead(c * pool * pool, d)
+        self.box_predictor = _Predictor(d, ncls)
+        self.score_thresh, self.nms_thresh, self.detections_per_img = score_thresh, 0.5, dets
+
+
+class Transform(object):
+    """[3P] GeneralizedRCNNTransform(min_size, max_size, ImageNet mean/std), size_divisible=32."""
+
+    def __init__(self, min_size, max_size):
+        self.min_size, self.max_size, self.size_divisible = min_size, max_size, 32
+
+    def resized_hw(self, h, w):
+        scale = min(float(self.min_size) / min(h, w), float(self.max_size) / max(h, w))
+        return int(math.floor(h * scale)), int(math.floor(w * scale))
+
+
+class VGGDetector(nn.Module):
+    """Holds the detector parameters and runs transform + backbone (SURVEY a-1, a-2) through the C ABI."""
+
+    def __init__(self, num_classes, min_size, max_size, pool_sz=7, obj_dim=4096, box_score_thresh=0.2,
+                 box_detections_per_img=50):
+        super(VGGDetector, self).__init__()
+        self.backbone = make_vgg_features()
+        self.rpn = _RPN(512, 15)  # 5 sizes x 3 ratios (rel_model_base.py:94-95)
+        self.roi_heads = _RoIHeads(512, pool_sz, obj_dim, num_classes, box_score_thresh, box_detections_per_img)
+        self.transform = Transform(min_size, max_size)
+        self.mode = 'gtbox'
+        self._prep = {}
+        self._bufs = {}
+
+    # ---- weights in kernel layout: conv1_1 [64,27] f32 (ky,kx,c); others [Cout,3,3,Cin] in the compute dtype
+    def prepared(self, dtype):
+        convs = [m for m in self.backbone if isinstance(m, nn.Conv2d)]
+        key = (dtype,) + tuple((c.weight.data_ptr(), c.weight._version, c.bias._version) for c in convs)
+        if self._prep.get('key') != key:
+            ws = []
+            for i, c in enumerate(convs):
+                w = c.weight.detach().float()
+                co, ci = w.shape[0], w.shape[1]
+                wk = ops.permute_ncp_to_npc(w.reshape(co, ci, 9), torch.float32 if i == 0 else dtype)  # [co,9,ci]
+                ws.append((wk.reshape(co, 9 * ci), c.bias.detach().float().contiguous(), ci, co))
+            self._prep = dict(key=key, val=ws)
+        return self._prep['val']
+
+    def _buf(self, name, shape, dtype, device, zero):
+        k = (name, tuple(shape), dtype, str(device))
+        b = self._bufs.get(k)
+        if b is None:
+            # zero-bordered planes are allocated (and zeroed) once; kernels only ever write interiors
+            b = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
+            self._bufs[k] = b
+        return b
+
+    def features(self, images, dtype):
+        """images: list of f32[3,h,w] tensors (host or device).  Returns (fmap NHWC [B,Hf,Wf,512] in `dtype`,
+        image_sizes [(h,w)] after resize, (Hp,Wp) padded size)."""
+        dev = self.backbone[0].weight.device
+        sizes = [self.transform.resized_hw(int(im.shape[-2]), int(im.shape[-1])) for im in images]
+        d = self.transform.size_divisible
+        Hp = int(math.ceil(max(s[0] for s in sizes) / d) * d)
+        Wp = int(math.ceil(max(s[1] for s in sizes) / d) * d)
+        B = len(images)
+        ws = self.prepared(dtype)
+        x0 = self._buf('img', (B, Hp + 2, Wp + 2, 4), torch.float32, dev, True)
+        uniform = all(s == sizes[0] for s in sizes) and sizes[0] == (Hp, Wp)
+        if not uniform:
+            x0.zero_()  # ragged batch: the pad region of a previous, larger image must be cleared
+        for b, im in enumerate(images):
+            im = im.squeeze()
+            if im.dtype != torch.float32 or not im.is_cuda:
+                im = im.to(device=dev, dtype=torch.float32, non_blocking=True)
+            ops.image_prep(im.contiguous(), sizes[b][0], sizes[b][1], x0, b)
+        H, W = Hp, Wp
+        x, ci_layer, n_conv = x0, 0, len(ws)
+        for li, v in enumerate(VGG16_CFG):
+            if v == 'M':
+                y = self._buf('a%d' % li, (B, H // 2 + 2, W // 2 + 2, x.shape[3]), dtype, dev, True)
+                ops.maxpool2x2(x, y, 1)
+                H, W = H // 2, W // 2
+            else:
+                w, bias, ci, co = ws[ci_layer]
+                last = ci_layer == n_conv - 1
+                op = 0 if last else 1
+                # the final map is handed to the caller (Result.fmap): a fresh tensor, never a cached plane
+                y = torch.empty((B, H, W, co), dtype=dtype, device=dev) if last else \
+                    self._buf('a%d' % li, (B, H + 2, W + 2, co), dtype, dev, True)
+                if ci_layer == 0:
+                    ops.conv1_1(x, w, bias, y)
+                else:
+                    ops.conv3x3_relu(x, w.view(co, 3, 3, ci), bias, y, op)
+                ci_layer += 1
+            x = y
+        return x, sizes, (Hp, Wp)

@@ -1,0 +1,246 @@
+"""Thin torch-tensor wrappers over the C ABI (include/sgg_hip.h).
+
+torch is used for device memory and the current HIP stream only; every wrapper hands raw device pointers
+to libsgg_hip.so.  Nothing here computes on the CPU and nothing falls back to torch ops.
+"""
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, SGG_BF16, SGG_F32  # noqa: F401
+
+_DT = {torch.float32: SGG_F32, torch.bfloat16: SGG_BF16}
+
+
+def dt(t):
+    try:
+        return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
+    except KeyError:
+        raise TypeError('sgg_amd: unsupported dtype %s (float32 / bfloat16 only)' % (t,))
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t, dtype=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('sgg_amd: tensor is not on the GPU (the HIP path has no CPU fallback)')
+    if not t.is_contiguous():
+        raise ValueError('sgg_amd: tensor must be contiguous')
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError('sgg_amd: expected %s, got %s' % (dtype, t.dtype))
+    return t.data_ptr()
+
+
+def pow2ceil(x):
+    p = 1
+    while p < x:
+        p <<= 1
+    return p
+
+
+# ---------------------------------------------------------------- a-1 / a-2
+def image_prep(img_chw, rh, rw, out_nhwc4, b):
+    """img f32[3,h,w] (device) -> out f32[B,Hp+2,Wp+2,4] slot b (interior), normalised + resized."""
+    _, h, w = img_chw.shape
+    Hp, Wp = out_nhwc4.shape[1] - 2, out_nhwc4.shape[2] - 2
+    _lib.call('sgg_image_prep', _p(img_chw, torch.float32), h, w, rh, rw, _p(out_nhwc4, torch.float32), b, Hp, Wp,
+              _stream())
+
+
+def conv1_1(x_nhwc4, w, bias, out):
+    B, H, W = x_nhwc4.shape[0], x_nhwc4.shape[1] - 2, x_nhwc4.shape[2] - 2
+    _lib.call('sgg_conv1_1', _p(x_nhwc4, torch.float32), _p(w, torch.float32), _p(bias, torch.float32), _p(out),
+              B, H, W, dt(out), _stream())
+
+
+def conv3x3_relu(x, w, bias, out, out_pad):
+    """x [B,H+2,W+2,Cin] zero-bordered; w [Cout,3,3,Cin]; out [B,H+2p,W+2p,Cout]."""
+    B, H, W, Cin = x.shape[0], x.shape[1] - 2, x.shape[2] - 2, x.shape[3]
+    Cout = w.shape[0]
+    assert w.dtype == x.dtype == out.dtype
+    _lib.call('sgg_conv3x3_relu', _p(x), _p(w), _p(bias, torch.float32), _p(out), out_pad, B, H, W, Cin, Cout, dt(x),
+              _stream())
+
+
+def maxpool2x2(x, out, out_pad):
+    B, H, W, C = x.shape[0], x.shape[1] - 2, x.shape[2] - 2, x.shape[3]
+    assert x.dtype == out.dtype
+    _lib.call('sgg_maxpool2x2', _p(x), _p(out), out_pad, B, H, W, C, dt(x), _stream())
+
+
+# ---------------------------------------------------------------- a-3
+def pair_index_eval(im_inds, boxes=None, require_overlap=False, cap=None):
+    """-> (rel_inds i64[cap,3], count int32[1] on device)."""
+    N = im_inds.shape[0]
+    cap = N * (N - 1) if cap is None else cap
+    out = torch.empty((max(cap, 1), 3), dtype=torch.int64, device=im_inds.device)
+    count = torch.empty(1, dtype=torch.int32, device=im_inds.device)
+    work = torch.empty(N + 2, dtype=torch.int32, device=im_inds.device)
+    _lib.call('sgg_pair_index_eval', _p(im_inds, torch.int64), _p(boxes, torch.float32) if require_overlap else None,
+              N, int(bool(require_overlap)), _p(out), cap, _p(count), _p(work), _stream())
+    return out, count
+
+
+def pair_index_train(im_inds, gt_rels, img_first, cap):
+    N, R = im_inds.shape[0], gt_rels.shape[0]
+    out = torch.empty((max(cap, 1), 4), dtype=torch.int64, device=im_inds.device)
+    count = torch.empty(1, dtype=torch.int32, device=im_inds.device)
+    work = torch.empty(N + 2 + N * N + max(R, 1), dtype=torch.int32, device=im_inds.device)
+    _lib.call('sgg_pair_index_train', _p(im_inds, torch.int64), N, _p(gt_rels, torch.int64) if R else None, R,
+              _p(img_first, torch.int32) if R else None, _p(out), cap, _p(count), _p(work), _stream())
+    return out, count
+
+
+def edge_csr(rel_inds, N):
+    E = rel_inds.shape[0]
+    dev = rel_inds.device
+    out_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    in_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    out_ids = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    in_ids = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    _lib.call('sgg_edge_csr', _p(rel_inds, torch.int64), E, N, _p(out_ptr), _p(out_ids), _p(in_ptr), _p(in_ids), None,
+              _stream())
+    return out_ptr, out_ids, in_ptr, in_ids
+
+
+# ---------------------------------------------------------------- a-4
+def roi_align(fmap_nhwc, rois, pairs=None, spatial_scale=1.0 / 16, P=7, sampling=2, add_ec=None, out=None):
+    """fmap [B,H,W,C]; rois f32[N,5]; pairs i64[R,2] or None -> [R,P,P,C] (same dtype as fmap)."""
+    B, H, W, C = fmap_nhwc.shape
+    R = rois.shape[0] if pairs is None else pairs.shape[0]
+    if out is None:
+        out = torch.empty((R, P, P, C), dtype=fmap_nhwc.dtype, device=fmap_nhwc.device)
+    _lib.call('sgg_roi_align_fwd', _p(fmap_nhwc), B, H, W, C, _p(rois, torch.float32), rois.shape[0],
+              _p(pairs, torch.int64) if pairs is not None else None, R, float(spatial_scale), P, sampling,
+              _p(add_ec, torch.float32) if add_ec is not None else None, _p(out), dt(fmap_nhwc), _stream())
+    return out
+
+
+# ---------------------------------------------------------------- a-5 / a-6
+def union_rects(rois, pairs, P=27, offset=-0.5):
+    E = pairs.shape[0]
+    out = torch.empty((E, 2, P, P), dtype=torch.float32, device=rois.device)
+    _lib.call('sgg_union_rects_fwd', _p(rois, torch.float32), _p(pairs, torch.int64), E, P, float(offset), _p(out),
+              _stream())
+    return out
+
+
+def union_rect_patches(rois, pairs, dtype, P=27, Kpad=128):
+    E = pairs.shape[0]
+    out = torch.empty((E * 4, Kpad), dtype=dtype, device=rois.device)
+    _lib.call('sgg_union_rect_patches', _p(rois, torch.float32), _p(pairs, torch.int64), E, P, _p(out), Kpad, dt(dtype),
+              _stream())
+    return out
+
+
+def max4_rows(x):
+    E4, C = x.shape
+    out = torch.empty((E4 // 4, C), dtype=x.dtype, device=x.device)
+    _lib.call('sgg_max4_rows', _p(x), _p(out), E4 // 4, C, dt(x), _stream())
+    return out
+
+
+def bcast_add_(x, add_rc):
+    """x [R,PP,C] += add[R,C] (in place)."""
+    R, PP, C = x.shape
+    _lib.call('sgg_bcast_add', _p(x), _p(add_rc, torch.float32), R, PP, C, dt(x), _stream())
+    return x
+
+
+# ---------------------------------------------------------------- a-7
+def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None, post_shift=None, out=None):
+    """act(A[M,K1] | A2[M,K2]) . W[N,K]^T + bias) * post_scale + post_shift -> [M,N]."""
+    M, K1 = A.shape
+    N, K = W.shape
+    assert A.dtype == W.dtype and (A2 is None or A2.dtype == A.dtype)
+    assert K == K1 + (A2.shape[1] if A2 is not None else 0), (A.shape, W.shape)
+    out_dtype = out_dtype or A.dtype
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    _lib.call('sgg_gemm', _p(A), A.stride(0) if A.dim() == 2 else K1, _p(A2) if A2 is not None else None,
+              A2.shape[1] if A2 is not None else 0, K1, _p(W), K, _p(bias, torch.float32) if bias is not None else None,
+              _p(post_scale, torch.float32) if post_scale is not None else None,
+              _p(post_shift, torch.float32) if post_shift is not None else None,
+              _p(out), out.stride(0), M, N, K, act, dt(A), dt(out), _stream())
+    return out
+
+
+# ---------------------------------------------------------------- a-8 / a-9
+def imp_node_gate_dots(v, gate_w):
+    N, H = v.shape
+    dots = torch.empty((N, 4), dtype=torch.float32, device=v.device)
+    _lib.call('sgg_imp_node_gate_dots', _p(v), N, H, _p(gate_w, torch.float32), _p(dots), dt(v), _stream())
+    return dots
+
+
+def imp_edge_ctx(v, e, rel_inds, dots, gate_w, gate_b, e_in=None, gates=None):
+    E, H = e.shape
+    if e_in is None:
+        e_in = torch.empty_like(e)
+    if gates is None:
+        gates = torch.empty((E, 2), dtype=torch.float32, device=e.device)
+    _lib.call('sgg_imp_edge_ctx_fwd', _p(v), _p(e), _p(rel_inds, torch.int64), E, H, _p(dots, torch.float32),
+              _p(gate_w, torch.float32), _p(gate_b, torch.float32), _p(e_in), _p(gates), dt(e), _stream())
+    return e_in, gates
+
+
+def imp_node_scatter(e, gates, csr, N, ctx=None):
+    H = e.shape[1]
+    out_ptr, out_ids, in_ptr, in_ids = csr
+    if ctx is None:
+        ctx = torch.empty((N, H), dtype=e.dtype, device=e.device)
+    _lib.call('sgg_imp_node_scatter_fwd', _p(e), _p(gates, torch.float32), _p(out_ptr), _p(out_ids), _p(in_ptr),
+              _p(in_ids), N, H, _p(ctx), dt(e), _stream())
+    return ctx
+
+
+def gru_gate(gi, gh, b_hh, h_prev, out_dtype):
+    M, H3 = gi.shape
+    H = H3 // 3
+    out = torch.empty((M, H), dtype=out_dtype, device=gi.device)
+    _lib.call('sgg_gru_gate_fwd', _p(gi), _p(gh) if gh is not None else None,
+              _p(b_hh, torch.float32) if b_hh is not None else None, _p(h_prev) if h_prev is not None else None, _p(out),
+              M, H, dt(gi), dt(out), _stream())
+    return out
+
+
+# ---------------------------------------------------------------- a-11
+def eval_tail(obj_dists, rel_dists, rel_inds, gt_classes=None):
+    N, C = obj_dists.shape
+    E, P = rel_dists.shape
+    dev = obj_dists.device
+    obj_scores = torch.empty(N, dtype=torch.float32, device=dev)
+    obj_preds = torch.empty(N, dtype=torch.int64, device=dev)
+    rels = torch.empty((E, 2), dtype=torch.int64, device=dev)
+    pred_scores = torch.empty((E, P), dtype=torch.float32, device=dev)
+    work = torch.empty(2 * pow2ceil(max(E, 1)) + E * P + 2, dtype=torch.float32, device=dev)
+    _lib.call('sgg_eval_tail', _p(obj_dists), N, C, _p(rel_dists), E, P, _p(rel_inds, torch.int64),
+              _p(gt_classes, torch.int64) if gt_classes is not None else None, _p(obj_scores), _p(obj_preds), _p(rels),
+              _p(pred_scores), _p(work), dt(obj_dists), _stream())
+    return obj_scores, obj_preds, rels, pred_scores
+
+
+# ---------------------------------------------------------------- utilities
+def cast(x, dtype):
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _lib.call('sgg_cast', _p(x), _p(out), x.numel(), dt(x), dt(out), _stream())
+    return out
+
+
+def permute_ncp_to_npc(x, dtype=None):
+    """x [N,C,P] -> [N,P,C] (optionally cast)."""
+    x = x.contiguous()
+    Nn, C, Pp = x.shape
+    out = torch.empty((Nn, Pp, C), dtype=dtype or x.dtype, device=x.device)
+    if Nn <= 65535:
+        _lib.call('sgg_permute_ncp_to_npc', _p(x), _p(out), Nn, C, Pp, dt(x), dt(out), _stream())
+    else:
+        for s in range(0, Nn, 32768):
+            e = min(Nn, s + 32768)
+            _lib.call('sgg_permute_ncp_to_npc', x[s:e].data_ptr(), out[s:e].data_ptr(), e - s, C, Pp, dt(x), dt(out),
+                      _stream())
+    return out

@@ -1,0 +1,214 @@
+"""RelModelBase on the HIP path -- mirror of sgg_models/rel_model_base.py (same constructor, attributes, method
+names, state_dict keys and exceptions), with the arithmetic in libsgg_hip.so.
+
+Layout note: feature maps and RoI features are channels-last in memory.  `fmap`, `node_feat`, `edge_feat` are
+handed out as [.,C,H,W]-shaped views of NHWC storage, i.e. the same logical tensors the reference returns.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .detector import VGGDetector, make_vgg_classifier
+from .result import Result
+from .union_boxes import UnionBoxesAndFeats
+
+IM_SCALE = 592            # config.py:31
+REL_FG_FRACTION = 0.25    # config.py:33
+
+
+def enumerate_by_image_host(im_inds_host):
+    """lib/pytorch_misc.py:493-502 on an already-host list of image indices: yields (img, start, end)."""
+    s, cur = 0, int(im_inds_host[0])
+    for i, val in enumerate(im_inds_host):
+        if int(val) != cur:
+            yield cur, s, i
+            cur, s = int(val), i
+    yield cur, s, len(im_inds_host)
+
+
+def as_nchw_view(x_nhwc):
+    return x_nhwc.permute(0, 3, 1, 2)
+
+
+def to_nhwc(x, dtype):
+    """[R,C,P,P]-shaped tensor (either a view of NHWC storage, or a plain NCHW tensor from another producer, e.g. the
+    GAN of main.py:141-149) -> contiguous [R,P,P,C] in `dtype`."""
+    R, C, Ph, Pw = x.shape
+    v = x.permute(0, 2, 3, 1)
+    if v.is_contiguous():
+        return v if v.dtype == dtype else ops.cast(v, dtype)
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        x = x.float()
+    return ops.permute_ncp_to_npc(x.reshape(R, C, Ph * Pw), dtype).view(R, Ph, Pw, C)
+
+
+class RelModelBase(nn.Module):
+    """RELATIONSHIPS (sgg_models/rel_model_base.py:22-123)."""
+
+    def __init__(self, train_data, mode='sgcls', require_overlap_det=True, use_bias=False, test_bias=False,
+                 backbone='vgg16', RELS_PER_IMG=1024, min_size=None, max_size=None, edge_model='motifs'):
+        super(RelModelBase, self).__init__()
+        self.classes = train_data.ind_to_classes
+        self.rel_classes = train_data.ind_to_predicates
+        self.mode = mode
+        self.backbone = backbone
+        self.RELS_PER_IMG = RELS_PER_IMG
+        self.pool_sz = 7
+        self.stride = 16
+        self.use_bias = use_bias
+        self.test_bias = test_bias
+        self.require_overlap = require_overlap_det and self.mode == 'sgdet'
+        if self.backbone == 'vgg16':
+            self.obj_dim = 4096
+            self.fmap_sz = 38
+            min_size = IM_SCALE if min_size is None else min_size
+            max_size = IM_SCALE if max_size is None else max_size
+            self.detector = VGGDetector(len(self.classes), min_size, max_size, self.pool_sz, self.obj_dim)
+            # rel_model_base.py:110-111: roi_fmap = Flatten + [fc6,ReLU,Dropout,fc7]; roi_fmap_obj = full classifier
+            cls = make_vgg_classifier(512 * self.pool_sz ** 2, self.obj_dim)
+            del cls._modules['5']
+            del cls._modules['4']
+            self.roi_fmap = nn.Sequential(nn.Flatten(), cls)
+            self.roi_fmap_obj = make_vgg_classifier(512 * self.pool_sz ** 2, self.obj_dim)
+        elif self.backbone == 'resnet50':
+            # GQA / Mask-R-CNN-R50-FPN detector (rel_model_base.py:58-81): SURVEY 8f-4, not on this path
+            raise NotImplementedError('backbone resnet50 is outside the MI355X hot path (SURVEY 8f-4)')
+        else:
+            raise NotImplementedError(self.backbone)
+        self.edge_dim = self.detector.backbone.out_channels
+        self.union_boxes = UnionBoxesAndFeats(pooling_size=self.pool_sz, stride=self.stride, dim=self.edge_dim,
+                                              edge_model=edge_model)
+        if self.use_bias:
+            raise NotImplementedError('FrequencyBias (lib/sparse_targets.py) is an optional flag outside SURVEY 8a')
+        # HIP-path settings (not in the reference): storage/compute type of activations and weights.
+        self.compute_dtype = torch.bfloat16
+        self._prep = {}
+
+    # ------------------------------------------------------------------ reference API
+    @property
+    def num_classes(self):
+        return len(self.classes)
+
+    @property
+    def num_rels(self):
+        return len(self.rel_classes)
+
+    def predict(self, node_feat, edge_feat, rel_inds, rois, im_sizes):
+        raise NotImplementedError('predict')
+
+    def forward(self, batch):
+        raise NotImplementedError('forward')
+
+    def set_compute_dtype(self, dtype):
+        """torch.float32 = exact-fp32 MFMA parity mode; torch.bfloat16 = throughput mode (fp32 accumulate)."""
+        ops.dt(dtype)
+        self.compute_dtype = dtype
+        return self
+
+    def spatial_scale(self, im_sizes):
+        """[3P] MultiScaleRoIAlign.infer_scale: 2^round(log2(fmap_size / image_size)); 1/16 at the configs."""
+        size = max(max(s[0], s[1]) for s in im_sizes)
+        return 2.0 ** round(math.log2(float(self.fmap_hw[0]) / float(size))) if hasattr(self, 'fmap_hw') else 1.0 / 16
+
+    def get_rel_inds(self, rel_labels, im_inds, box_priors, _num=None):
+        """rel_model_base.py:143-165.  `_num` (private): the pair count when the caller already knows it on the host
+        (all same-image ordered pairs, no overlap filter), which saves the device->host read of the count."""
+        if self.training:
+            return rel_labels[:, :3].data.clone()
+        out, count = ops.pair_index_eval(im_inds.contiguous(), box_priors.float().contiguous() if self.require_overlap
+                                         else None, self.require_overlap)
+        n = _num if (_num is not None and not self.require_overlap) else int(count.item())
+        if n == 0:
+            return im_inds.new_zeros((1, 3))  # :160-161
+        return out[:n]
+
+    def set_box_score_thresh(self, box_score_thresh):
+        self.detector.roi_heads.score_thresh = box_score_thresh  # rel_model_base.py:168-172
+
+    def faster_rcnn(self, x, gt_boxes, gt_classes, gt_rels):
+        """rel_model_base.py:175-242, gt-box branch (predcls / sgcls)."""
+        if self.mode == 'sgdet':
+            raise NotImplementedError('SGDet front end (RPN + RoIHeads) is SURVEY 8f-3, not built yet')
+        dtype = self.compute_dtype
+        im_host = gt_classes[:, 0].detach().to('cpu').tolist()           # the one D2H sync of the forward
+        segs = list(enumerate_by_image_host(im_host))
+        images = [x[i] for i, _, _ in segs]                              # :180 (x is indexed by image id)
+        fmap, sizes, _ = self.detector.features(images, dtype)           # :183-184
+        self.fmap_hw = (fmap.shape[1], fmap.shape[2])
+        # boxes scaled by the resize ratio, per image ([3P] resize_boxes)
+        ratios = []
+        for (i, s, e), (nh, nw) in zip(segs, sizes):
+            h, w = int(x[i].shape[-2]), int(x[i].shape[-1])
+            ratios.append((s, e, float(nw) / float(w), float(nh) / float(h)))
+        gt_boxes = gt_boxes.float()
+        if all(r[2] == 1.0 and r[3] == 1.0 for r in ratios):
+            priors = gt_boxes.clone()
+        else:
+            scale = torch.ones((gt_boxes.shape[0], 4), dtype=torch.float32)
+            for s, e, rw, rh in ratios:
+                scale[s:e] = torch.tensor([rw, rh, rw, rh])
+            priors = gt_boxes * scale.to(gt_boxes.device, non_blocking=True)
+        rois, obj_labels, rel_labels = self.gt_labels(gt_boxes, gt_classes, gt_rels, segs=segs)   # :189
+        im_inds = gt_classes[:, 0].long()
+        result = Result(od_obj_labels=obj_labels, rm_box_priors=priors, rm_obj_labels=obj_labels,
+                        rel_labels=rel_labels, im_inds=im_inds)
+        result.rm_box_priors_org = gt_boxes
+        result.im_sizes_org = [tuple(x[i].shape[-2:]) for i, _, _ in segs]
+        result.im_sizes = sizes
+        result.fmap = as_nchw_view(fmap)
+        result.rois = torch.cat((im_inds.float()[:, None], priors), 1)
+        result._num_pairs = sum((e - s) * (e - s - 1) for _, s, e in segs)   # host-side count (private)
+        return result
+
+    def node_edge_features(self, fmap, rois, union_inds, im_sizes):
+        """rel_model_base.py:245-260: RoIAlign of the boxes and of the pair union boxes (union fused in-kernel)."""
+        assert union_inds.shape[1] == 2, union_inds.shape
+        dtype = self.compute_dtype
+        fm = to_nhwc(fmap, dtype)
+        self.fmap_hw = (fm.shape[1], fm.shape[2])
+        scale = self.spatial_scale(im_sizes) if im_sizes is not None else 1.0 / self.stride
+        rois = rois.float().contiguous()
+        node = ops.roi_align(fm, rois, None, scale, self.pool_sz, 2)
+        edge = ops.roi_align(fm, rois, union_inds.contiguous(), scale, self.pool_sz, 2)
+        return as_nchw_view(node), as_nchw_view(edge)
+
+    def get_scaled_boxes(self, boxes, im_inds, im_sizes):
+        """rel_model_base.py:263-274."""
+        boxes_scaled = boxes.clone()
+        for im_ind, s, e in enumerate_by_image_host(im_inds.long().to('cpu').tolist()):
+            boxes_scaled[s:e, [0, 2]] = boxes_scaled[s:e, [0, 2]] / im_sizes[im_ind][1]
+            boxes_scaled[s:e, [1, 3]] = boxes_scaled[s:e, [1, 3]] / im_sizes[im_ind][0]
+        assert boxes_scaled.max() <= 1 + 1e-3, (boxes_scaled.max(), boxes.max(), im_sizes)
+        return boxes_scaled
+
+    def gt_labels(self, gt_boxes, gt_classes, gt_rels=None, sample_factor=-1, segs=None):
+        """rel_model_base.py:277-300 + proposal_assignments_gtbox (lib/proposal_assignments_gtbox.py:7-80)."""
+        assert gt_boxes is not None
+        im_inds = gt_classes[:, 0]
+        rois = torch.cat((im_inds.float()[:, None], gt_boxes.float()), 1)
+        if gt_rels is not None and self.training:
+            if segs is None:
+                segs = list(enumerate_by_image_host(im_inds.to('cpu').tolist()))
+            num_im = segs[-1][0] + 1
+            first = [0] * num_im
+            for i, s, _ in segs:
+                first[i] = s
+            n_cand = sum((e - s) * (e - s - 1) for _, s, e in segs)
+            R = gt_rels.shape[0]
+            num_fg_cap = int(self.RELS_PER_IMG * REL_FG_FRACTION * num_im)
+            if R > num_fg_cap or n_cand > int(self.RELS_PER_IMG * num_im) - min(R, num_fg_cap) or sample_factor > -1:
+                raise NotImplementedError('relation sub-sampling (random_choose) is not on the HIP path yet; '
+                                          'raise RELS_PER_IMG or cap boxes per image')
+            cap = n_cand + R
+            out, count = ops.pair_index_train(im_inds.long().contiguous(), gt_rels.long().contiguous(),
+                                              torch.tensor(first, dtype=torch.int32).to(im_inds.device), cap)
+            # rows = candidates + (extra rows for duplicate FG relations on one pair); FG pairs replace a candidate
+            n = int(count.item())
+            rel_labels = out[:n]
+            obj_labels = gt_classes[:, 1].contiguous()
+        else:
+            obj_labels = gt_classes[:, 1]
+            rel_labels = None
+        return rois, obj_labels, rel_labels

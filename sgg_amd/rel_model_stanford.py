@@ -1,0 +1,142 @@
+"""RelModelStanford (IMP) on the HIP path -- mirror of sgg_models/rel_model_stanford.py."""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .imp import GATES, ImpWeights, message_pass
+from .rel_model_base import RelModelBase, to_nhwc
+
+
+class RelModelStanford(RelModelBase):
+    """Message Passing Model from "Scene Graph Generation by Iterative Message Passing" (rel_model_stanford.py:11-45).
+    Same parameters / names as the reference, so `vgrel.pth` checkpoints load with load_state_dict."""
+
+    def __init__(self, train_data, hidden_dim=512, mp_iter=3, **kwargs):
+        super(RelModelStanford, self).__init__(train_data, **kwargs)
+        self.hidden_dim = hidden_dim
+        self.rel_fc = nn.Linear(hidden_dim, self.num_rels)
+        self.obj_fc = nn.Linear(hidden_dim, self.num_classes)
+        self.obj_unary = nn.Linear(self.obj_dim, hidden_dim)
+        self.edge_unary = nn.Linear(self.obj_dim, hidden_dim)
+        self.edge_gru = nn.GRUCell(input_size=hidden_dim, hidden_size=hidden_dim)
+        self.node_gru = nn.GRUCell(input_size=hidden_dim, hidden_size=hidden_dim)
+        self.mp_iter = mp_iter
+        for g in GATES:
+            setattr(self, g, nn.Sequential(nn.Linear(hidden_dim * 2, 1), nn.Sigmoid()))
+
+    # ------------------------------------------------------------------ weights in kernel layout
+    def prepared(self):
+        """Device operands derived from the fp32 master parameters, cached until a parameter changes:
+        fc6 with its K axis re-ordered (c,ph,pw)->(ph,pw,c) to match channels-last RoI features; for edges also the
+        512 extra K columns  sum_p W6[:, c, p]  that fold `union_pools + conv(rects)` (lib/get_union_boxes.py:101)
+        into fc6 by linearity (fc6(x + r (x) 1_49) = fc6(x) + W6sum r)."""
+        dtype = self.compute_dtype
+        params = [p for n, p in self.named_parameters() if not n.startswith('detector.')]
+        key = (dtype,) + tuple((p.data_ptr(), p._version) for p in params)
+        if self._prep.get('key') == key:
+            return self._prep['val']
+        C, PP = self.edge_dim, self.pool_sz ** 2
+        f = lambda t: t.detach().float().contiguous()
+        w = {}
+        w6o = f(self.roi_fmap_obj[0].weight)
+        w['fc6_obj'] = ops.permute_ncp_to_npc(w6o.view(-1, C, PP), dtype).view(w6o.shape[0], -1)
+        w6e = f(self.roi_fmap[1][0].weight)
+        w6e_p = ops.permute_ncp_to_npc(w6e.view(-1, C, PP), dtype).view(w6e.shape[0], -1)
+        w6sum = w6e.view(-1, C, PP).sum(2)                                    # load-time only
+        w['fc6_edge'] = torch.cat((w6e_p, w6sum.to(dtype)), 1).contiguous()   # [4096, 25088+512]
+        w['fc6_edge_raw_k'] = C * PP
+        for name, mod in (('fc7_obj', self.roi_fmap_obj[3]), ('fc7_edge', self.roi_fmap[1][3]),
+                          ('obj_unary', self.obj_unary), ('edge_unary', self.edge_unary), ('obj_fc', self.obj_fc),
+                          ('rel_fc', self.rel_fc)):
+            w[name] = f(mod.weight).to(dtype).contiguous()
+            w[name + '_b'] = f(mod.bias)
+        w['fc6_obj_b'] = f(self.roi_fmap_obj[0].bias)
+        w['fc6_edge_b'] = f(self.roi_fmap[1][0].bias)
+        sd = {k: v for k, v in self.state_dict().items() if 'gru' in k or 'w_fc' in k}
+        w['imp'] = ImpWeights.from_state(sd, dtype)
+        self._prep = dict(key=key, val=w)
+        return w
+
+    # ------------------------------------------------------------------ reference API
+    def message_pass(self, rel_rep, obj_rep, rel_inds):
+        """rel_model_stanford.py:48-94.  rel_inds i64[E,2] = (subj, obj)."""
+        w = self.prepared()
+        dtype = self.compute_dtype
+        ri3 = torch.cat((rel_inds.new_zeros((rel_inds.shape[0], 1)), rel_inds), 1).contiguous()
+        csr = ops.edge_csr(ri3, obj_rep.shape[0])
+        cast = lambda t: t.contiguous() if t.dtype == dtype else ops.cast(t.float() if t.dtype not in
+                                                                          (torch.float32, torch.bfloat16) else t, dtype)
+        return message_pass(cast(rel_rep), cast(obj_rep), ri3, csr, w['imp'], self.mp_iter, dtype)
+
+    def predict(self, node_feat, edge_feat, rel_inds, rois, im_sizes, _csr=None):
+        """rel_model_stanford.py:97-107.  node_feat [N,C,7,7], edge_feat [E,C,7,7] (raw RoIAlign), rel_inds i64[E,3]
+        -> (obj_dists f32[N,151], rel_dists f32[E,51])."""
+        if self.training and (torch.is_grad_enabled()):
+            # Dropout / train-mode BatchNorm / autograd of the trainable head are the next step; fail loudly.
+            raise NotImplementedError('training forward/backward of the relation head is not on the HIP path yet; '
+                                      'call under model.eval()')
+        w = self.prepared()
+        dtype = self.compute_dtype
+        N, E = node_feat.shape[0], edge_feat.shape[0]
+        rel_inds = rel_inds.contiguous()
+        nf = to_nhwc(node_feat.view(N, -1, self.pool_sz, self.pool_sz), dtype).view(N, -1)
+        ef = to_nhwc(edge_feat.view(E, -1, self.pool_sz, self.pool_sz), dtype).view(E, -1)
+        # :100  union_boxes(edge_feat, rois, rel_inds[:,1:]) -- conv(rects)[E,512]; the broadcast add rides in fc6's K
+        rect = self.union_boxes.rect_feat(rois, rel_inds[:, 1:].contiguous(), dtype)
+        # :103  obj_unary(roi_fmap_obj(node_feat))
+        x = ops.gemm(nf, w['fc6_obj'], w['fc6_obj_b'], ops.ACT_RELU)
+        x = ops.gemm(x, w['fc7_obj'], w['fc7_obj_b'], ops.ACT_RELU)
+        obj_rep = ops.gemm(x, w['obj_unary'], w['obj_unary_b'])
+        # :104  relu(edge_unary(roi_fmap(edge_feat)))
+        y = ops.gemm(ef, w['fc6_edge'], w['fc6_edge_b'], ops.ACT_RELU, A2=rect)
+        y = ops.gemm(y, w['fc7_edge'], w['fc7_edge_b'])
+        rel_rep = ops.gemm(y, w['edge_unary'], w['edge_unary_b'], ops.ACT_RELU)
+        # :105
+        csr = _csr if _csr is not None else ops.edge_csr(rel_inds, N)
+        vert, edge = message_pass(rel_rep, obj_rep, rel_inds, csr, w['imp'], self.mp_iter, dtype)
+        # :107
+        return (ops.gemm(vert, w['obj_fc'], w['obj_fc_b'], out_dtype=torch.float32),
+                ops.gemm(edge, w['rel_fc'], w['rel_fc_b'], out_dtype=torch.float32))
+
+    def forward(self, batch):
+        """rel_model_stanford.py:110-207.  batch[0] = Blob tuple (dataloaders/blob.py:244-249); only items 0,3,4,5
+        (imgs, gt_boxes, gt_classes, gt_rels) are read."""
+        assert len(batch) == 1, ('single GPU is only supported in this code', len(batch))
+        x, gt_boxes, gt_classes, gt_rels = batch[0][0], batch[0][3], batch[0][4], batch[0][5]
+        dev = self.rel_fc.weight.device
+        gt_boxes, gt_classes = gt_boxes.to(dev), gt_classes.to(dev)
+        gt_rels = gt_rels.to(dev) if gt_rels is not None else None
+        with torch.no_grad():
+            result = self.faster_rcnn(x, gt_boxes, gt_classes, gt_rels)                  # :125-129
+            result.fmap = result.fmap.detach()                                           # :131
+            im_inds, boxes = result.im_inds, result.rm_box_priors
+            if self.training and not hasattr(result, 'rel_labels'):
+                raise NotImplementedError('sgdet training (lib/rel_assignments.py) is documented as unsupported '
+                                          'by the reference (README.md:214-218)')
+            elif not hasattr(result, 'rel_labels'):
+                result.rel_labels = None
+            rel_inds = self.get_rel_inds(result.rel_labels if self.training else None, im_inds, boxes,
+                                         _num=getattr(result, '_num_pairs', None))       # :144
+            result.rel_inds = rel_inds
+            rois = torch.cat((im_inds[:, None].float(), boxes), 1)                       # :146
+            result.node_feat, result.edge_feat = self.node_edge_features(
+                result.fmap, rois, rel_inds[:, 1:], im_sizes=result.im_sizes)            # :148
+        result.rm_obj_dists, result.rel_dists = self.predict(result.node_feat, result.edge_feat, rel_inds,
+                                                             rois=rois, im_sizes=result.im_sizes)   # :153
+        if self.training:
+            result.rois = rois
+            return result                                                                # :179-181
+        if self.mode == 'predcls':
+            gt = gt_classes[:, 1].contiguous()                                           # :184-185
+        elif self.mode in ['sgcls', 'sgdet']:
+            gt = None
+        else:
+            raise NotImplementedError(self.mode)
+        obj_scores, obj_preds, rels, pred_scores = ops.eval_tail(result.rm_obj_dists, result.rel_dists, rel_inds, gt)
+        result.obj_scores, result.obj_preds = obj_scores, obj_preds
+        bboxes = result.rm_box_priors_org                                                # :199
+        if bboxes.dim() != 2:
+            raise ValueError('Boxes needs to be [num_box, 4] but its {}'.format(bboxes.size()))
+        # lib/surgery.py:49-55: host numpy copies
+        return (bboxes.cpu().numpy(), obj_preds.cpu().numpy(), obj_scores.cpu().numpy(), rels.cpu().numpy(),
+                pred_scores.cpu().numpy())

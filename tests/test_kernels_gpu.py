@@ -1,0 +1,361 @@
+"""GPU parity: every HIP kernel, called through the C ABI, against the CPU oracle on the same seeded inputs.
+Integer / index work and the raster must be bit-exact; fp32 kernels within 1e-3 absolute (north_star) -- in practice
+the asserted bounds are much tighter; bf16 kernels are checked against the oracle fed with bf16-rounded operands."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sgg_oracle as O
+from tests.conftest import weights
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from sgg_amd import ops as _ops
+    return _ops
+
+
+def cu(x, dtype=None):
+    t = torch.as_tensor(x)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV).contiguous()
+
+
+def rand_boxes(rng, n):
+    xy = rng.uniform(0, 400, size=(n, 2))
+    wh = rng.uniform(12, 192, size=(n, 2))
+    return np.concatenate((xy, np.minimum(xy + wh, 591)), 1).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (256, 256, 512), (200, 151, 512), (37, 51, 128), (1000, 1536, 512),
+                                   (130, 4096, 1024), (5, 64, 64)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_gemm(ops, M, N, K, dtype):
+    g = torch.Generator().manual_seed(M * N + K)
+    A = torch.randn(M, K, generator=g).to(dtype)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype)
+    b = torch.randn(N, generator=g)
+    ref = (A.float() @ W.float().t() + b).relu()
+    out = ops.gemm(cu(A), cu(W), cu(b), act=ops.ACT_RELU, out_dtype=torch.float32)
+    tol = 2e-5 if dtype == torch.float32 else 2e-3
+    torch.testing.assert_close(out.cpu(), ref, atol=tol * max(1.0, float(ref.abs().max())), rtol=0)
+
+
+def test_gemm_transpose_detecting(ops):
+    # A = I pattern with an asymmetric W: catches a transposed C write
+    M = N = K = 128
+    A = torch.eye(M, K)
+    W = torch.arange(N * K, dtype=torch.float32).reshape(N, K) / (N * K)
+    out = ops.gemm(cu(A), cu(W), out_dtype=torch.float32)
+    torch.testing.assert_close(out.cpu(), W.t().contiguous(), atol=1e-6, rtol=0)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_gemm_split_k_and_affine(ops, dtype):
+    g = torch.Generator().manual_seed(5)
+    M, K1, K2, N = 300, 256, 128, 192
+    A1, A2 = torch.randn(M, K1, generator=g).to(dtype), torch.randn(M, K2, generator=g).to(dtype)
+    W = (torch.randn(N, K1 + K2, generator=g) / 20).to(dtype)
+    b, sc, sh = torch.randn(N, generator=g), torch.rand(N, generator=g) + .5, torch.randn(N, generator=g)
+    ref = (torch.cat((A1, A2), 1).float() @ W.float().t() + b).relu() * sc + sh
+    out = ops.gemm(cu(A1), cu(W), cu(b), act=ops.ACT_RELU, out_dtype=torch.float32, A2=cu(A2), post_scale=cu(sc),
+                   post_shift=cu(sh))
+    torch.testing.assert_close(out.cpu(), ref, atol=1e-4 if dtype == torch.float32 else 3e-2, rtol=0)
+    outb = ops.gemm(cu(A1), cu(W), cu(b), act=ops.ACT_RELU, out_dtype=dtype, A2=cu(A2), post_scale=cu(sc),
+                    post_shift=cu(sh))
+    torch.testing.assert_close(outb.float().cpu(), ref, atol=1e-4 if dtype == torch.float32 else 6e-2, rtol=0)
+
+
+def test_gemm_rejects_bad_k(ops):
+    with pytest.raises(ValueError):
+        ops.gemm(cu(torch.zeros(8, 40)), cu(torch.zeros(8, 40)))
+
+
+# ----------------------------------------------------------------------------------------- conv / pool / prep
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(1, 16, 16, 64, 64), (2, 10, 14, 64, 128), (1, 38, 38, 128, 256)])
+def test_conv3x3(ops, dtype, B, H, W, Cin, Cout):
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g).to(dtype)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(dtype)
+    b = torch.randn(Cout, generator=g)
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), b, padding=1).relu()
+    xp = torch.zeros(B, H + 2, W + 2, Cin, dtype=dtype)
+    xp[:, 1:-1, 1:-1] = x.permute(0, 2, 3, 1)
+    for op in (0, 1):
+        out = torch.full((B, H + 2 * op, W + 2 * op, Cout), 7.0, dtype=dtype, device=DEV)
+        ops.conv3x3_relu(cu(xp), cu(w.permute(0, 2, 3, 1)), cu(b), out, op)
+        got = out.float().cpu()
+        inner = got[:, op:H + op, op:W + op] if op else got
+        tol = 1e-4 if dtype == torch.float32 else 3e-2
+        torch.testing.assert_close(inner.permute(0, 3, 1, 2), ref, atol=tol, rtol=tol)
+        if op:  # border untouched
+            assert float(got[:, 0].min()) == 7.0 and float(got[:, :, 0].min()) == 7.0
+
+
+def test_image_prep_conv1_1_maxpool(ops):
+    g = torch.Generator().manual_seed(3)
+    B, S, Hp = 2, 40, 64
+    imgs = [torch.rand(3, S, S, generator=g) for _ in range(B)]
+    batch, sizes, _ = O.transform(imgs, None, min_size=S, max_size=S)
+    assert batch.shape[-1] == Hp
+    buf = torch.zeros(B, Hp + 2, Hp + 2, 4, device=DEV)
+    for b, im in enumerate(imgs):
+        ops.image_prep(cu(im), S, S, buf, b)
+    torch.testing.assert_close(buf[:, 1:-1, 1:-1, :3].permute(0, 3, 1, 2).cpu(), batch, atol=1e-6, rtol=1e-6)
+    assert float(buf[..., 3].abs().max()) == 0
+    # resize path (20 -> 40)
+    small = torch.rand(3, 20, 20, generator=g)
+    b2, _, _ = O.transform([small], None, min_size=S, max_size=S)
+    buf2 = torch.zeros(1, Hp + 2, Hp + 2, 4, device=DEV)
+    ops.image_prep(cu(small), S, S, buf2, 0)
+    torch.testing.assert_close(buf2[:, 1:-1, 1:-1, :3].permute(0, 3, 1, 2).cpu(), b2, atol=1e-5, rtol=1e-5)
+    # conv1_1
+    w = torch.randn(64, 3, 3, 3, generator=g) * 0.2
+    bias = torch.randn(64, generator=g) * 0.1
+    ref = torch.nn.functional.conv2d(batch, w, bias, padding=1).relu()
+    out = torch.zeros(B, Hp + 2, Hp + 2, 64, device=DEV)
+    ops.conv1_1(buf, cu(w.permute(0, 2, 3, 1).reshape(64, 27)), cu(bias), out)
+    torch.testing.assert_close(out[:, 1:-1, 1:-1].permute(0, 3, 1, 2).cpu(), ref, atol=1e-5, rtol=1e-5)
+    # maxpool
+    pooled = torch.zeros(B, Hp // 2 + 2, Hp // 2 + 2, 64, device=DEV)
+    ops.maxpool2x2(out, pooled, 1)
+    torch.testing.assert_close(pooled[:, 1:-1, 1:-1].permute(0, 3, 1, 2).cpu(), torch.nn.functional.max_pool2d(ref, 2),
+                               atol=1e-5, rtol=1e-5)
+    assert float(pooled[:, 0].abs().max()) == 0
+
+
+# ----------------------------------------------------------------------------------------- pairs (bit-exact)
+@pytest.mark.parametrize('tag', ['b1', 'b3', 'b8x32'])
+def test_pair_index_matches_reference_golden(ops, golden, tag):
+    g = golden('pairs')
+    im, boxes = cu(g[tag + '_im_inds']), cu(g[tag + '_boxes'])
+    for ov in (0, 1):
+        out, cnt = ops.pair_index_eval(im, boxes, bool(ov))
+        n = int(cnt.item())
+        np.testing.assert_array_equal(out[:n].cpu().numpy(), g['%s_eval_ov%d' % (tag, ov)])
+    imn = g[tag + '_im_inds']
+    first = np.array([np.argmax(imn == i) for i in range(imn.max() + 1)], np.int32)
+    exp = g[tag + '_train_rel_labels']
+    out, cnt = ops.pair_index_train(im, cu(g[tag + '_gt_rels']), cu(first), len(exp) + 5)
+    assert int(cnt.item()) == len(exp)
+    np.testing.assert_array_equal(out[:len(exp)].cpu().numpy(), exp)
+
+
+def test_pair_index_ragged_large_and_capacity(ops):
+    rng = np.random.RandomState(0)
+    sizes = [1, 70, 3, 129, 2]
+    im = np.concatenate([np.full(n, i, np.int64) for i, n in enumerate(sizes)])
+    boxes = rand_boxes(rng, len(im))
+    for ov in (False, True):
+        exp = O.get_rel_inds_eval(im, boxes, ov)
+        out, cnt = ops.pair_index_eval(cu(im), cu(boxes), ov)
+        assert int(cnt.item()) == len(exp)
+        np.testing.assert_array_equal(out[:len(exp)].cpu().numpy(), exp)
+    # capacity smaller than needed: count still reported, no overflow write
+    out, cnt = ops.pair_index_eval(cu(im), None, False, cap=10)
+    assert int(cnt.item()) == sum(n * (n - 1) for n in sizes) and out.shape[0] == 10
+    # duplicate FG relation on one pair -> two rows
+    gt_rels = np.array([[1, 0, 1, 5], [1, 0, 1, 9], [3, 2, 0, 7]], np.int64)
+    first = np.cumsum([0] + sizes[:-1]).astype(np.int32)
+    rois = np.concatenate((im[:, None].astype(np.float32), boxes), 1)
+    _, _, exp = O.proposal_assignments_gtbox(rois, boxes, np.stack((im, im), 1), gt_rels, RELS_PER_IMG=100000)
+    out, cnt = ops.pair_index_train(cu(im), cu(gt_rels), cu(first), len(exp))
+    assert int(cnt.item()) == len(exp)
+    np.testing.assert_array_equal(out.cpu().numpy(), exp)
+
+
+def test_edge_csr(ops):
+    rng = np.random.RandomState(1)
+    im = np.concatenate([np.full(n, i, np.int64) for i, n in enumerate([5, 9, 1, 4])])
+    rel = O.get_rel_inds_eval(im)
+    rel = rel[rng.rand(len(rel)) > 0.3]
+    N = len(im)
+    optr, oids, iptr, iids = [t.cpu().numpy() for t in ops.edge_csr(cu(rel), N)]
+    for n in range(N):
+        np.testing.assert_array_equal(oids[optr[n]:optr[n + 1]], np.nonzero(rel[:, 1] == n)[0])
+        np.testing.assert_array_equal(iids[iptr[n]:iptr[n + 1]], np.nonzero(rel[:, 2] == n)[0])
+    assert optr[N] == iptr[N] == len(rel)
+
+
+# ----------------------------------------------------------------------------------------- raster (bit-exact)
+def test_union_rects_bit_exact_vs_reference_golden(ops, golden):
+    g = golden('raster')
+    pairs8 = g['pairs']
+    E = len(pairs8)
+    rois = np.concatenate((np.zeros((2 * E, 1), np.float32), pairs8.reshape(2 * E, 4)), 1)
+    pidx = np.arange(2 * E, dtype=np.int64).reshape(E, 2)
+    out = ops.union_rects(cu(rois), cu(pidx), 27, 0.0)
+    np.testing.assert_array_equal(out.cpu().numpy(), g['out27'])
+    out7 = ops.union_rects(cu(rois), cu(pidx[:16]), 7, 0.0)
+    np.testing.assert_array_equal(out7.cpu().numpy(), g['out7'])
+    # with the caller's -0.5 (lib/get_union_boxes.py:67)
+    outm = ops.union_rects(cu(rois), cu(pidx), 27, -0.5)
+    np.testing.assert_array_equal(outm.cpu().numpy(), g['out27'] - np.float32(0.5))
+
+
+def test_union_rects_full_size_and_patches(ops):
+    rng = np.random.RandomState(2)
+    N = 32
+    boxes = rand_boxes(rng, N)
+    rois = np.concatenate((np.zeros((N, 1), np.float32), boxes), 1)
+    pairs = O.get_rel_inds_eval(np.zeros(N, np.int64))[:, 1:]
+    pr = np.concatenate((boxes[pairs[:, 0]], boxes[pairs[:, 1]]), 1)
+    exp = O.draw_union_boxes(pr, 27) - np.float32(0.5)
+    out = ops.union_rects(cu(rois), cu(pairs), 27, -0.5).cpu().numpy()
+    np.testing.assert_array_equal(out, exp)
+    # patches: rows {-3..3} and {13..19} with zero padding
+    pat = ops.union_rect_patches(cu(rois), cu(pairs), torch.float32).cpu().numpy().reshape(len(pairs), 4, 128)
+    padded = np.zeros((len(pairs), 2, 27 + 6, 27 + 6), np.float32)
+    padded[:, :, 3:30, 3:30] = exp
+    for pos in range(4):
+        oy, ox = pos >> 1, pos & 1
+        win = padded[:, :, oy * 16:oy * 16 + 7, ox * 16:ox * 16 + 7].reshape(len(pairs), 98)
+        np.testing.assert_array_equal(pat[:, pos, :98], win)
+    assert np.abs(pat[:, :, 98:]).max() == 0
+
+
+def test_degenerate_union_matches_reference_nan_behaviour(ops):
+    rois = np.array([[0, 5, 5, 5, 9], [0, 5, 6, 5, 8]], np.float32)
+    out = ops.union_rects(cu(rois), cu(np.array([[0, 1]], np.int64)), 27, 0.0).cpu().numpy()
+    exp = O.draw_union_boxes(np.array([[5, 5, 5, 9, 5, 6, 5, 8]], np.float32), 27)
+    np.testing.assert_array_equal(np.isnan(out), np.isnan(exp))
+    np.testing.assert_array_equal(np.nan_to_num(out, nan=-7), np.nan_to_num(exp, nan=-7))
+
+
+@pytest.mark.parametrize('tag', ['d128', 'd32'])
+def test_rect_feat_pipeline_vs_reference_golden(ops, golden, tag):
+    """raster patches -> GEMM(+ReLU+BN) -> max4 -> GEMM(+ReLU+BN) == UnionBoxesAndFeats.conv of the reference."""
+    g = golden('union_feats')
+    from sgg_amd.union_boxes import fold_rect_conv, rect_feat
+    p = {k: cu(v) for k, v in weights(g, tag).items()}
+    prep = fold_rect_conv(p, torch.float32)
+    rf = rect_feat(cu(g[tag + '_rois']), cu(g[tag + '_union_inds']), prep, torch.float32)
+    np.testing.assert_allclose(rf.cpu().numpy(), g[tag + '_rect_feat'], atol=2e-5)
+
+
+# ----------------------------------------------------------------------------------------- RoIAlign
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_roi_align(ops, dtype):
+    rng = np.random.RandomState(4)
+    B, C, H, W, N = 3, 64, 38, 38, 12
+    fm = torch.from_numpy(rng.randn(B, C, H, W).astype(np.float32)).to(dtype)
+    boxes = rand_boxes(rng, N)
+    boxes[0] = [80, 80, 80, 80]            # degenerate -> min size 1
+    boxes[1] = [560, 560, 607, 607]        # touches the map edge
+    im = np.sort(rng.randint(0, B, N)).astype(np.float32)
+    rois = np.concatenate((im[:, None], boxes), 1)
+    pairs = np.array([(i, j) for i in range(N) for j in range(N) if i != j and im[i] == im[j]], np.int64)
+    exp_n, exp_e = O.node_edge_features(fm.float().numpy(), rois, pairs)
+    fm_nhwc = cu(fm.permute(0, 2, 3, 1))
+    got_n = ops.roi_align(fm_nhwc, cu(rois)).float().cpu().permute(0, 3, 1, 2).numpy()
+    got_e = ops.roi_align(fm_nhwc, cu(rois), cu(pairs)).float().cpu().permute(0, 3, 1, 2).numpy()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    np.testing.assert_allclose(got_n, exp_n, atol=tol)
+    np.testing.assert_allclose(got_e, exp_e, atol=tol)
+    if dtype == torch.float32:  # fused broadcast add
+        add = torch.from_numpy(rng.randn(len(pairs), C).astype(np.float32))
+        got = ops.roi_align(fm_nhwc, cu(rois), cu(pairs), add_ec=cu(add)).cpu().permute(0, 3, 1, 2).numpy()
+        np.testing.assert_allclose(got, exp_e + add.numpy()[:, :, None, None], atol=tol)
+        x = cu(torch.from_numpy(exp_e).permute(0, 2, 3, 1)).reshape(len(pairs), 49, C).contiguous()
+        ops.bcast_add_(x, cu(add))
+        np.testing.assert_allclose(x.cpu().numpy().reshape(len(pairs), 7, 7, C).transpose(0, 3, 1, 2),
+                                   exp_e + add.numpy()[:, :, None, None], atol=1e-6)
+
+
+# ----------------------------------------------------------------------------------------- IMP + GRU
+def test_gru_gate_vs_reference_golden(ops, golden):
+    g = golden('gru')
+    w = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('w_')}
+    x, h = torch.from_numpy(g['x']), torch.from_numpy(g['h'])
+    gi = x @ w['weight_ih'].t() + w['bias_ih']
+    gh = h @ w['weight_hh'].t() + w['bias_hh']
+    out = ops.gru_gate(cu(gi), cu(gh), None, cu(h), torch.float32)
+    np.testing.assert_allclose(out.cpu().numpy(), g['out'], atol=2e-6)
+    out0 = ops.gru_gate(cu(gi), None, cu(w['bias_hh']), None, torch.float32)
+    np.testing.assert_allclose(out0.cpu().numpy(), g['out_h0'], atol=2e-6)
+
+
+@pytest.mark.parametrize('tag', ['h32_b1', 'h64_b3', 'h32_sampled', 'h128_b2'])
+def test_message_pass_vs_reference_golden(ops, golden, tag):
+    g = golden('message_pass')
+    from sgg_amd.imp import ImpWeights, message_pass
+    p = {k: cu(v) for k, v in weights(g, tag).items()}
+    wts = ImpWeights.from_state(p, torch.float32)
+    rel = cu(g[tag + '_rel_inds'])
+    N = g[tag + '_obj_rep'].shape[0]
+    csr = ops.edge_csr(rel, N)
+    for it in range(4):
+        v, e = message_pass(cu(g[tag + '_rel_rep']), cu(g[tag + '_obj_rep']), rel, csr, wts, it, torch.float32)
+        np.testing.assert_allclose(v.cpu().numpy(), g['%s_v%d' % (tag, it)], atol=3e-5)
+        np.testing.assert_allclose(e.cpu().numpy(), g['%s_e%d' % (tag, it)], atol=3e-5)
+
+
+def test_imp_kernels_full_size_vs_oracle(ops):
+    """BASELINE size (B=2 here to keep the oracle's dense [N,E] matmul fast): N=64, E=1984, H=512."""
+    rng = np.random.RandomState(7)
+    g = torch.Generator().manual_seed(7)
+    B, n, H = 2, 32, 512
+    im = np.repeat(np.arange(B), n).astype(np.int64)
+    rel = O.get_rel_inds_eval(im)
+    N, E = len(im), len(rel)
+    v, e = torch.randn(N, H, generator=g), torch.randn(E, H, generator=g)
+    gw, gb = torch.randn(4, 2 * H, generator=g) / 30, torch.randn(4, generator=g)
+    dots = ops.imp_node_gate_dots(cu(v), cu(gw))
+    e_in, gates = ops.imp_edge_ctx(cu(v), cu(e), cu(rel), dots, cu(gw), cu(gb))
+    ctx = ops.imp_node_scatter(cu(e), gates, ops.edge_csr(cu(rel), N), N)
+    s, o = torch.from_numpy(rel[:, 1]), torch.from_numpy(rel[:, 2])
+    sv, ov = v[s], v[o]
+    gt = [torch.sigmoid(torch.cat((a, e), 1) @ gw[k] + gb[k]) for k, a in enumerate((sv, ov, sv, ov))]
+    exp_ein = gt[0][:, None] * sv + gt[1][:, None] * ov
+    exp_ctx = torch.zeros(N, H).index_add_(0, s, gt[2][:, None] * e).index_add_(0, o, gt[3][:, None] * e)
+    torch.testing.assert_close(e_in.cpu(), exp_ein, atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(ctx.cpu(), exp_ctx, atol=1e-4, rtol=1e-5)
+    # bf16 storage: same math on bf16-rounded inputs
+    vb, eb = v.bfloat16(), e.bfloat16()
+    dots = ops.imp_node_gate_dots(cu(vb), cu(gw))
+    e_in, gates = ops.imp_edge_ctx(cu(vb), cu(eb), cu(rel), dots, cu(gw), cu(gb))
+    ctx = ops.imp_node_scatter(cu(eb), gates, ops.edge_csr(cu(rel), N), N)
+    sv, ov, ef = vb.float()[s], vb.float()[o], eb.float()
+    gt = [torch.sigmoid(torch.cat((a, ef), 1) @ gw[k] + gb[k]) for k, a in enumerate((sv, ov, sv, ov))]
+    torch.testing.assert_close(e_in.float().cpu(), gt[0][:, None] * sv + gt[1][:, None] * ov, atol=3e-2, rtol=1e-2)
+    exp_ctx = torch.zeros(N, H).index_add_(0, s, gt[2][:, None] * ef).index_add_(0, o, gt[3][:, None] * ef)
+    torch.testing.assert_close(ctx.float().cpu(), exp_ctx, atol=0.3, rtol=2e-2)
+
+
+# ----------------------------------------------------------------------------------------- eval tail
+def test_eval_tail_vs_reference_golden(ops, golden):
+    g = golden('eval_tail')
+    od, rd, rel = cu(g['obj_dists']), cu(g['rel_dists']), cu(g['rel_inds'])
+    sc, pr, rels, ps = ops.eval_tail(od, rd, rel)
+    np.testing.assert_array_equal(pr.cpu().numpy(), g['sg_classes'])
+    np.testing.assert_allclose(sc.cpu().numpy(), g['sg_scores'], atol=1e-6)
+    np.testing.assert_array_equal(rels.cpu().numpy(), g['sg_rels'])
+    np.testing.assert_allclose(ps.cpu().numpy(), g['sg_pred_scores'], atol=1e-6)
+    sc, pr, rels, ps = ops.eval_tail(od, rd, rel, cu(g['gt_classes']))
+    np.testing.assert_array_equal(pr.cpu().numpy(), g['pc_classes'])
+    np.testing.assert_array_equal(rels.cpu().numpy(), g['pc_rels'])
+    np.testing.assert_allclose(ps.cpu().numpy(), g['pc_pred_scores'], atol=1e-6)
+
+
+@pytest.mark.parametrize('E', [1, 992, 2450, 9000])
+def test_eval_tail_sizes_sorted_and_permutation(ops, E):
+    g = torch.Generator().manual_seed(E)
+    N = 50
+    od, rd = torch.randn(N, 151, generator=g), torch.randn(E, 51, generator=g)
+    rel = torch.stack((torch.zeros(E, dtype=torch.long), torch.randint(0, N, (E,), generator=g),
+                       torch.randint(0, N, (E,), generator=g)), 1)
+    sc, pr, rels, ps = ops.eval_tail(cu(od), cu(rd), cu(rel))
+    b, c, s, r, p = O.eval_tail(od, rd, rel, torch.zeros(N, 4))
+    np.testing.assert_array_equal(pr.cpu().numpy(), c)
+    score = ps.cpu()[:, 1:].max(1)[0] * sc.cpu()[rels.cpu()[:, 0]] * sc.cpu()[rels.cpu()[:, 1]]
+    assert bool((score[:-1] >= score[1:] - 1e-7).all())          # sortedness
+    np.testing.assert_allclose(np.sort(ps.cpu().numpy().sum(1)), np.sort(p.sum(1)), atol=1e-5)  # permutation of rows
+    np.testing.assert_allclose(ps.cpu().numpy(), p, atol=1e-5)   # same order as the stable oracle (ties are measure-zero)

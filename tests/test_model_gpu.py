@@ -1,0 +1,128 @@
+"""GPU parity of the whole drop-in path: RelModelStanford.forward() on the HIP library vs the CPU oracle
+chained in the reference's order (oracle.forward_gtbox), on identical seeded inputs and weights.
+
+Tolerances: fp32 mode 1e-3 absolute on obj_dists / rel_dists (north_star).  bf16 mode is checked on the
+quantities R@K depends on (ranking of triples), not on raw logits."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sgg_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def setup():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import sgg_amd
+    from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
+    S = 160
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls', min_size=S, max_size=S))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV).eval()
+    batch = synthetic_batch(B=3, S=S, n_boxes=7, n_fg=3, seed=5, ragged=True)
+    with torch.no_grad():
+        ref = O.forward_gtbox(batch[0], batch[3], batch[4], batch[5], sd, mode='sgcls', min_size=S, max_size=S)
+    return model, batch, ref, sd
+
+
+def run(model, batch, dtype, mode='sgcls', train=False):
+    model.set_compute_dtype(dtype)
+    model.mode = mode
+    model.train(train)
+    with torch.no_grad():
+        out = model([batch])
+    model.eval()
+    return out
+
+
+def test_forward_fp32_eval_matches_oracle(setup):
+    model, batch, ref, _ = setup
+    boxes, cls, scores, rels, pred_scores = run(model, batch, torch.float32)
+    rb, rc, rs, rr, rp = ref['dets']
+    np.testing.assert_array_equal(boxes, rb)
+    np.testing.assert_array_equal(cls, rc)
+    np.testing.assert_allclose(scores, rs, atol=1e-3)
+    np.testing.assert_array_equal(rels, rr)
+    np.testing.assert_allclose(pred_scores, rp, atol=1e-3)
+
+
+def test_forward_fp32_intermediates_within_1e3(setup):
+    model, batch, ref, _ = setup
+    model.set_compute_dtype(torch.float32)
+    model.mode = 'sgcls'
+    with torch.no_grad():
+        gt_boxes, gt_classes = batch[3].to(DEV), batch[4].to(DEV)
+        res = model.faster_rcnn(batch[0], gt_boxes, gt_classes, None)
+        np.testing.assert_allclose(res.fmap.float().cpu().numpy(), ref['fmap'].numpy(), atol=1e-3, rtol=1e-3)
+        rel_inds = model.get_rel_inds(None, res.im_inds, res.rm_box_priors)
+        np.testing.assert_array_equal(rel_inds.cpu().numpy(), ref['rel_inds'])
+        rois = torch.cat((res.im_inds[:, None].float(), res.rm_box_priors), 1)
+        nf, ef = model.node_edge_features(res.fmap, rois, rel_inds[:, 1:], res.im_sizes)
+        assert tuple(nf.shape) == ref['node_feat'].shape and tuple(ef.shape) == ref['edge_feat'].shape
+        np.testing.assert_allclose(nf.float().cpu().numpy(), ref['node_feat'], atol=1e-3, rtol=1e-3)
+        np.testing.assert_allclose(ef.float().cpu().numpy(), ref['edge_feat'], atol=1e-3, rtol=1e-3)
+        od, rd = model.predict(nf, ef, rel_inds, rois, res.im_sizes)
+        np.testing.assert_allclose(od.cpu().numpy(), ref['rm_obj_dists'].numpy(), atol=1e-3)
+        np.testing.assert_allclose(rd.cpu().numpy(), ref['rel_dists'].numpy(), atol=1e-3)
+        # reference-layout (plain NCHW) inputs from another producer give the same answer
+        od2, rd2 = model.predict(nf.contiguous(), ef.contiguous(), rel_inds, rois, res.im_sizes)
+        np.testing.assert_allclose(od2.cpu().numpy(), od.cpu().numpy(), atol=1e-5)
+        np.testing.assert_allclose(rd2.cpu().numpy(), rd.cpu().numpy(), atol=1e-5)
+        # UnionBoxesAndFeats.forward == union_pools + conv(rects)
+        ub = model.union_boxes(ef, rois, rel_inds[:, 1:], res.im_sizes)
+        up = {k[len('union_boxes.'):]: v for k, v in setup[3].items() if k.startswith('union_boxes.')}
+        exp = O.union_boxes_and_feats(torch.from_numpy(ref['edge_feat']), rois.cpu().numpy(),
+                                      rel_inds[:, 1:].cpu().numpy(), up)
+        np.testing.assert_allclose(ub.float().cpu().numpy(), exp.numpy(), atol=1e-3, rtol=1e-3)
+
+
+def test_forward_predcls_and_result_fields(setup):
+    model, batch, ref, sd = setup
+    out = run(model, batch, torch.float32, mode='predcls')
+    with torch.no_grad():
+        refp = O.eval_tail(ref['rm_obj_dists'], ref['rel_dists'], ref['rel_inds'], batch[3].numpy(), 'predcls',
+                           batch[4][:, 1].numpy())
+    np.testing.assert_array_equal(out[1], refp[1])
+    np.testing.assert_array_equal(out[2], np.ones(len(refp[1]), np.float32))
+    np.testing.assert_array_equal(out[3], refp[3])
+    np.testing.assert_allclose(out[4], refp[4], atol=1e-3)
+
+
+def test_forward_bf16_ranking_close_to_oracle(setup):
+    model, batch, ref, _ = setup
+    boxes, cls, scores, rels, pred_scores = run(model, batch, torch.bfloat16)
+    rb, rc, rs, rr, rp = ref['dets']
+    assert (cls == rc).mean() >= 0.85                 # argmax object class mostly unchanged by bf16
+    np.testing.assert_allclose(scores, rs, atol=0.08)
+    # top-K triple sets overlap (what R@K consumes)
+    K = 50
+    top = set(map(tuple, rels[:K]))
+    rtop = set(map(tuple, rr[:K]))
+    assert len(top & rtop) >= int(0.7 * K)
+
+
+def test_state_dict_round_trip_and_reference_keys(setup):
+    model, _, _, sd = setup
+    for k in ('detector.backbone.0.weight', 'detector.backbone.28.bias', 'roi_fmap.1.0.weight', 'roi_fmap.1.3.bias',
+              'roi_fmap_obj.0.weight', 'roi_fmap_obj.3.bias', 'union_boxes.conv.0.weight',
+              'union_boxes.conv.6.running_var', 'obj_unary.weight', 'edge_unary.bias', 'edge_gru.weight_ih',
+              'node_gru.bias_hh', 'sub_vert_w_fc.0.weight', 'in_edge_w_fc.0.bias', 'obj_fc.weight', 'rel_fc.bias',
+              'detector.roi_heads.box_head.fc6.weight', 'detector.rpn.head.conv.weight'):
+        assert k in sd, k
+    assert sd['roi_fmap.1.0.weight'].shape == (4096, 25088) and sd['edge_gru.weight_ih'].shape == (1536, 512)
+    model.load_state_dict(sd)
+
+
+def test_error_contract(setup):
+    model, batch, _, _ = setup
+    with pytest.raises(AssertionError):
+        model([batch, batch])                       # rel_model_stanford.py:121
+    model.mode = 'bogus'
+    with pytest.raises(NotImplementedError):
+        with torch.no_grad():
+            model([batch])                          # rel_model_stanford.py:193
+    model.mode = 'sgcls'
