@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the VG SGCls IMP forward (BASELINE.json configs[1]) on N MI355X of one node.
+
+A step = one pass of the hot path (RelModelStanford.forward in eval mode: transform -> VGG-16 -> pair indexing ->
+RoIAlign(objects + union boxes) -> union-mask conv -> fc6/fc7 -> 3 IMP iterations -> heads -> eval tail incl. the
+D2H copy of the result tuple) over one batch of synthetic 592x592 frames, 32 boxes and 32*31 candidate edges per
+image, B images per GPU, inputs resident in HBM.  Images are sharded over ranks (one process per GPU, no data-path
+collective: inference needs none) => weak scaling.  Prints ONE JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype bf16|f32]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+MFMA_PEAK_TF = {'bf16': 2500.0, 'f32': 157.3}   # dense peaks, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='images per GPU (global batch 64 at 8 GPUs)')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-images', type=int, default=2)
+    return ap.parse_args()
+
+
+def kernel_times(model, batch, reps):
+    """Per-kernel average launch duration from HIP events on the launch stream (separate, untimed passes)."""
+    import torch
+    from sgg_amd import _lib
+    prof = {}
+    _lib.profiler = prof
+    try:
+        for _ in range(reps):
+            with torch.no_grad():
+                model([batch])
+        torch.cuda.synchronize()
+    finally:
+        _lib.profiler = None
+    out = {}
+    for (name, tag), evs in prof.items():
+        ms = [a.elapsed_time(b) for a, b in evs]
+        out[(name, tag)] = (sum(ms) / len(ms), len(ms) // reps)   # avg ms per launch, launches per step
+    return out
+
+
+def cpu_baseline(n_images, seed):
+    """The oracle (a structural CPU restatement of the reference path, validated against the reference's own
+    outputs) timed on this box's host cores on a bounded sample of the same workload."""
+    import torch
+    import sgg_amd
+    from oracle import sgg_oracle as O
+    from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls'))
+    sd = model.state_dict()
+    batch = synthetic_batch(B=n_images, S=592, n_boxes=32, n_fg=6, seed=seed)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        t0 = time.time()
+        O.forward_gtbox(batch[0], batch[3], batch[4], batch[5], sd, mode='sgcls')
+        dt = time.time() - t0
+    return {'value': round(n_images / dt, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': '1 forward of %d synthetic 592x592 images (32 boxes, 992 edges each), torch-CPU fp32 oracle, '
+                      '%.1f s' % (n_images, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device('cuda', local if world > 1 else 0)
+
+    import sgg_amd
+    from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
+    tdtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    B = args.batch
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls')).to(dev).eval()
+    model.set_compute_dtype(tdtype)
+    # images sharded by rank: rank r owns global images [r*B, (r+1)*B)  (seed differs per rank)
+    batch = list(synthetic_batch(B=B, S=592, n_boxes=32, n_fg=6, seed=111 + rank))
+    batch[0] = [im.to(dev) for im in batch[0]]          # inputs resident in HBM before the timed region
+    batch[3], batch[4], batch[5] = batch[3].to(dev), batch[4].to(dev), batch[5].to(dev)
+    batch = tuple(batch)
+
+    def step():
+        with torch.no_grad():
+            return model([batch])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel roofline (rank 0, outside the timed region)
+    line = None
+    if rank == 0:
+        kt = kernel_times(model, batch, reps=5)
+        E, N, H = 992 * B, 32 * B, 512
+        s = 2 if args.dtype == 'bf16' else 4
+        get = lambda name, tag: kt.get((name, tag), (0.0, 0))
+        fc6_ms, _ = get('sgg_gemm', 'fc6_edge')
+        fc6_flop = 2.0 * E * 4096 * (25088 + 512)
+        fc6_tf = fc6_flop / (fc6_ms * 1e-3) / 1e12 if fc6_ms else 0.0
+        imp_ms = get('sgg_imp_edge_ctx_fwd', 'imp')[0] + get('sgg_imp_node_scatter_fwd', 'imp')[0] + \
+            get('sgg_imp_node_gate_dots', 'imp')[0]
+        imp_bytes = (2.0 * (E + N) * H) * s + 8.0 * E           # per iteration
+        imp_gbs = imp_bytes / (imp_ms * 1e-3) / 1e9 if imp_ms else 0.0
+        roi_ms = sum(v[0] * v[1] for (n, t), v in kt.items() if n == 'sgg_roi_align_fwd')
+        roi_bytes = (E + N) * 25088.0 * s + B * 38 * 38 * 512.0 * s
+        conv_ms = sum(v[0] * v[1] for (n, t), v in kt.items() if n in ('sgg_conv3x3_relu', 'sgg_conv1_1', 'sgg_maxpool2x2'))
+        vgg_flop = 226.13e9 * B
+        total_ms = sum(v[0] * v[1] for v in kt.values())
+        top = sorted(((v[0] * v[1], n, t) for (n, t), v in kt.items()), reverse=True)[:8]
+        peak = MFMA_PEAK_TF[args.dtype]
+        line = {
+            'metric': 'images/sec (whole node), VG SGCls IMP forward', 'value': round(world * B * args.steps / elapsed, 3),
+            'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'VG SGCls rel_model_stanford (IMP) eval forward, 592x592 frames, 32 boxes/img, '
+                                   '992 edges/img, 3 IMP iters (BASELINE configs[1])',
+                       'images_per_gpu': B, 'global_batch': world * B, 'parallelism': 'image-sharded dp%d, no collective '
+                       '(inference)' % world, 'weights': 'random init (He), frozen VGG16 + IMP head'},
+            'roofline': {'kernel': 'mfma_tile_kernel (fc6 on edges: [%d x %d] . [4096 x %d]^T)' % (E, 25600, 25600),
+                         'bound': 'mfma', 'achieved': round(fc6_tf, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': round(fc6_tf / peak, 4), 'traffic': None, 'avg_launch_ms': round(fc6_ms, 4)},
+            'roofline_imp': {'kernel': 'edge_ctx + node_scatter (+gate dots), per IMP iteration', 'bound': 'hbm',
+                             'achieved': round(imp_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                             'frac': round(imp_gbs / HBM_PEAK_GBS, 4), 'traffic': None,
+                             'algorithmic_bytes': imp_bytes, 'avg_iter_ms': round(imp_ms, 5)},
+            'kernels': {'sum_kernel_ms_per_step': round(total_ms, 3),
+                        'vgg16_ms': round(conv_ms, 3), 'vgg16_tflops': round(vgg_flop / (conv_ms * 1e-3) / 1e12, 1) if conv_ms else 0,
+                        'roi_align_ms': round(roi_ms, 4), 'roi_align_GBs': round(roi_bytes / (roi_ms * 1e-3) / 1e9, 1) if roi_ms else 0,
+                        'top': [{'ms_per_step': round(ms, 3), 'call': n, 'tag': t} for ms, n, t in top]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args.cpu_images, 111)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

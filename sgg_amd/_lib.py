@@ -77,5 +77,23 @@ def check(code, what):
         raise exc('%s: %s' % (what, msg))
 
 
+# Optional per-call timing (bench.py / tests only): when `profiler` is a dict, every C-ABI call is bracketed by
+# HIP events recorded on the stream the kernel is launched on; keys are (symbol, tag).
+profiler = None
+_tag = ['']
+
+
+def set_tag(tag):
+    _tag[0] = tag
+
+
 def call(name, *args):
+    if profiler is None:
+        check(getattr(load(), name)(*args), name)
+        return
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(getattr(load(), name)(*args), name)
+    e1.record()
+    profiler.setdefault((name, _tag[0]), []).append((e0, e1))

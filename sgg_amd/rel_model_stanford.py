@@ -2,7 +2,7 @@
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from .imp import GATES, ImpWeights, message_pass
 from .rel_model_base import RelModelBase, to_nhwc
 
@@ -84,19 +84,29 @@ class RelModelStanford(RelModelBase):
         # :100  union_boxes(edge_feat, rois, rel_inds[:,1:]) -- conv(rects)[E,512]; the broadcast add rides in fc6's K
         rect = self.union_boxes.rect_feat(rois, rel_inds[:, 1:].contiguous(), dtype)
         # :103  obj_unary(roi_fmap_obj(node_feat))
+        _lib.set_tag('fc6_obj')
         x = ops.gemm(nf, w['fc6_obj'], w['fc6_obj_b'], ops.ACT_RELU)
+        _lib.set_tag('fc7_obj')
         x = ops.gemm(x, w['fc7_obj'], w['fc7_obj_b'], ops.ACT_RELU)
+        _lib.set_tag('unary')
         obj_rep = ops.gemm(x, w['obj_unary'], w['obj_unary_b'])
         # :104  relu(edge_unary(roi_fmap(edge_feat)))
+        _lib.set_tag('fc6_edge')
         y = ops.gemm(ef, w['fc6_edge'], w['fc6_edge_b'], ops.ACT_RELU, A2=rect)
+        _lib.set_tag('fc7_edge')
         y = ops.gemm(y, w['fc7_edge'], w['fc7_edge_b'])
+        _lib.set_tag('unary')
         rel_rep = ops.gemm(y, w['edge_unary'], w['edge_unary_b'], ops.ACT_RELU)
         # :105
+        _lib.set_tag('imp')
         csr = _csr if _csr is not None else ops.edge_csr(rel_inds, N)
         vert, edge = message_pass(rel_rep, obj_rep, rel_inds, csr, w['imp'], self.mp_iter, dtype)
         # :107
-        return (ops.gemm(vert, w['obj_fc'], w['obj_fc_b'], out_dtype=torch.float32),
-                ops.gemm(edge, w['rel_fc'], w['rel_fc_b'], out_dtype=torch.float32))
+        _lib.set_tag('heads')
+        out = (ops.gemm(vert, w['obj_fc'], w['obj_fc_b'], out_dtype=torch.float32),
+               ops.gemm(edge, w['rel_fc'], w['rel_fc_b'], out_dtype=torch.float32))
+        _lib.set_tag('')
+        return out
 
     def forward(self, batch):
         """rel_model_stanford.py:110-207.  batch[0] = Blob tuple (dataloaders/blob.py:244-249); only items 0,3,4,5

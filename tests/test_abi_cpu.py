@@ -1,0 +1,87 @@
+"""CPU: the C-ABI library builds/loads here (hipcc cross-compiles gfx950 without a GPU) and exports every symbol that
+include/sgg_hip.h declares; the Python mirror has the reference's surface.  No compute calls (no GPU)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'sgg_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(sgg_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_header_symbols_all_exported_and_typed():
+    from sgg_amd import _lib
+    lib = _lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), s
+        assert s in _lib.SIGNATURES, 'ctypes signature missing for %s' % s
+    assert sorted(_lib.SIGNATURES) == syms
+    assert lib.sgg_abi_version() == _lib.ABI_VERSION
+    assert b'gfx950' in lib.sgg_build_info()
+
+
+def test_argument_counts_match_header():
+    from sgg_amd import _lib
+    txt = open(os.path.join(ROOT, 'include', 'sgg_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    for name, args in re.findall(r'\b(sgg_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;', txt, flags=re.S):
+        n = 0 if args.strip() in ('', 'void') else len(args.split(','))
+        assert n == len(_lib.SIGNATURES[name]), (name, n, len(_lib.SIGNATURES[name]))
+
+
+def test_library_is_gfx950_code_object():
+    from sgg_amd import _lib
+    blob = open(_lib.LIB_PATH, 'rb').read()
+    assert b'gfx950' in blob and b'gfx942' not in blob and b'sm_' not in blob[:0]
+
+
+def test_product_path_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'sgg_amd')
+    for f in os.listdir(pkg):
+        if f.endswith('.py'):
+            src = open(os.path.join(pkg, f)).read()
+            assert 'oracle' not in re.sub(r'""".*?"""', '', src, flags=re.S).replace('# oracle', ''), f
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from sgg_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(ImportError):
+        _lib.load()
+
+
+def test_cpu_tensor_is_rejected_not_silently_computed():
+    import torch
+    from sgg_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.gemm(torch.zeros(64, 64), torch.zeros(64, 64))
+
+
+def test_model_surface_matches_reference():
+    import torch
+    import sgg_amd
+    from sgg_amd.synthetic import SyntheticData
+    m = sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls')
+    for attr in ('detector', 'edge_dim', 'pool_sz', 'fmap_sz', 'mode', 'roi_fmap', 'roi_fmap_obj', 'union_boxes',
+                 'obj_dim', 'hidden_dim', 'mp_iter', 'RELS_PER_IMG', 'require_overlap', 'num_classes', 'num_rels'):
+        assert hasattr(m, attr), attr
+    for meth in ('forward', 'predict', 'message_pass', 'node_edge_features', 'get_scaled_boxes', 'set_box_score_thresh',
+                 'get_rel_inds', 'faster_rcnn', 'gt_labels'):
+        assert callable(getattr(m, meth)), meth
+    assert (m.edge_dim, m.pool_sz, m.fmap_sz, m.obj_dim) == (512, 7, 38, 4096)
+    trainable = sum(p.numel() for n, p in m.named_parameters() if not n.startswith('detector.'))
+    assert trainable == 247753678          # DP gradient payload
+    # LR groups of lib/pytorch_misc.py:135-136 key on the 'roi_fmap' prefix
+    assert any(n.startswith('roi_fmap') for n, _ in m.named_parameters())
+    with pytest.raises(NotImplementedError):
+        sgg_amd.RelModelStanford(SyntheticData(), backbone='vgg16_old')
+    r = sgg_amd.Result(rm_obj_dists=torch.zeros(1), rel_labels=None)
+    assert hasattr(r, 'rm_obj_dists') and not hasattr(r, 'rel_labels')     # lib/pytorch_misc.py:696-700
