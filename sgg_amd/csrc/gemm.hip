@@ -13,40 +13,15 @@
 //
 // Replaces (reference): nn.Linear calls at sgg_models/rel_model_stanford.py:29-37,103-107 and
 // sgg_models/rel_model_base.py:110-111; [3P] cuDNN 3x3 convs of vgg16.features (rel_model_base.py:184).
-#include "common.h"
+#include <stdlib.h>
+
+#include "gemm_args.h"
+
+int sgg_launch_pingpong(const GemmArgs& g, bool bf16, bool conv, hipStream_t s);  // gemm256.hip
 
 namespace {
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void glb_void_t;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-
 constexpr int ROWB = 128;  // bytes of K per LDS row
-
-struct GemmArgs {
-    const char* A;
-    const char* A2;
-    const char* Wt;
-    long lda_b, lda2_b, ldw_b;  // bytes
-    int nt1, nt;                // k-tiles in segment 1 / total
-    const float* bias;
-    const float* pscale;
-    const float* pshift;
-    char* C;
-    long ldc;  // elements
-    int M, N, act, out_bf16;
-    // conv mode
-    int H, W, Cin, out_pad;
-};
-
-__device__ __forceinline__ void glds16(const char* g, char* l) {
-    __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)l, 16, 0, 0);
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // WM x WN waves of 64x64; block tile (64*WM) x (64*WN); 256 threads.
 template <bool BF16, int WM, int WN, bool CONV>
@@ -61,17 +36,9 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WN, wc = wave % WN;
 
-    // ---- block -> tile: XCD-contiguous ids, then groups of 8 M-panels walk N (L2 reuse of both panels)
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
-    const int nwg = tilesM * tilesN;
-    int L = xcd_remap(blockIdx.x, nwg);
-    constexpr int GM = 8;
-    const int per_group = GM * tilesN;
-    const int grp = L / per_group;
-    const int gm0 = grp * GM;
-    const int gsz = min(GM, tilesM - gm0);
-    const int inl = L - grp * per_group;
-    const int tm = gm0 + inl % gsz, tn = inl / gsz;
+    int tm, tn;
+    tile_coords(blockIdx.x, tilesM, tilesN, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- per-lane source pointers (16-byte chunk of a 128-byte row, swizzled)
@@ -261,10 +228,19 @@ int launch(const GemmArgs& g, hipStream_t s) {
     return SGG_OK;
 }
 
+// Kernel choice: the 256x256 ping-pong kernel when the problem fills the chip with 256-wide tiles
+// (N >= 256, M large); 256x64 tiles for narrow N; 128x128 otherwise.  SGG_GEMM_FORCE=128 disables the big kernel.
 template <bool CONV>
-int dispatch(const GemmArgs& g, bool bf16, hipStream_t s) {
-    // N <= 64 (or a ragged small N): 256x64 tiles; otherwise 128x128
-    const bool narrow = g.N <= 64 || (g.N < 128);
+int dispatch(GemmArgs g, bool bf16, hipStream_t s) {
+    static const char* force = getenv("SGG_GEMM_FORCE");
+    const bool allow256 = !(force && force[0] == '1' && force[1] == '2');
+    const long tiles256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
+    if (allow256 && g.N >= 256 && tiles256 >= 128) {
+        g.nt *= 2;   // 64-byte K-tiles
+        g.nt1 *= 2;
+        return sgg_launch_pingpong(g, bf16, CONV, s);
+    }
+    const bool narrow = g.N < 128;
     if (bf16) return narrow ? launch<true, 4, 1, CONV>(g, s) : launch<true, 2, 2, CONV>(g, s);
     return narrow ? launch<false, 4, 1, CONV>(g, s) : launch<false, 2, 2, CONV>(g, s);
 }

@@ -1,0 +1,242 @@
+// 256x256 ping-pong MFMA tile kernel (gfx950): the large-N GEMMs (fc6/fc7/GRU/unary) and the wide VGG convs.
+//
+// 8 waves = two groups of four (one wave of each group per SIMD).  Each wave owns a 128(M) x 64(N) slab of the
+// 256x256 block tile: 4x2 MFMA 32x32 tiles = 128 accumulator registers.  K advances in 64-byte slabs per row
+// (32 bf16 / 16 f32): one K-tile = 2 MFMA k-steps.  The two groups run the same K-tile sequence one PHASE apart:
+//
+//   slot      0        1        2        3        4   ...
+//   group 0   LOAD 0   MFMA 0   LOAD 1   MFMA 1   LOAD 2
+//   group 1   -        LOAD 0   MFMA 0   LOAD 1   MFMA 1
+//
+// so on every SIMD one wave is issuing 16 back-to-back MFMAs (512 cycles) while its partner issues the next
+// K-tile's 12 ds_read_b128 and its share of the global->LDS DMA for the tile three ahead.  A 4-deep LDS ring
+// (4 x 32 KiB) keeps 2-3 K-tiles of global_load_lds in flight across the barriers (counted vmcnt, never 0 in
+// the main loop).  One s_barrier per slot.
+//
+// LDS image per stage: A rows [256][64 B] then W rows [256][64 B], lane-linear for global_load_lds
+// (16 rows per 1-KiB wave instruction); 16-byte slot swizzle phys = slot ^ ((row>>2)&3) applied on the source
+// address and on the ds_read_b128 (conflict-free for the 32-row fragment reads).
+#include "gemm_args.h"
+
+namespace {
+
+constexpr int ROW = 64;                 // bytes of K per LDS row
+constexpr int STAGE = 512 * ROW;        // A 256 rows + W 256 rows = 32 KiB
+constexpr int NSTAGE = 4;
+constexpr int SMEM = NSTAGE * STAGE;    // 128 KiB
+
+template <bool BF16, bool CONV>
+__global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ESZ = BF16 ? 2 : 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, q = wave & 3;  // grp: which half of M; q: which 64-wide N slab
+
+    const int tilesM = (g.M + 255) / 256, tilesN = (g.N + 255) / 256;
+    int tm, tn;
+    tile_coords(blockIdx.x, tilesM, tilesN, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    // ---- DMA duty: waves 0-3 stage the A rows, waves 4-7 the W rows; 4 instructions of 16 rows each
+    const bool loads_a = wave < 4;
+    const char* rp[4];
+    const char* rp2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave & 3) * 64 + j * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((r >> 2) & 3);
+        if (loads_a) {
+            const int m = min(m0 + r, g.M - 1);
+            rp[j] = a_row_ptr<CONV>(g, m, ESZ) + chunk * 16;
+            rp2[j] = (!CONV && g.A2) ? g.A2 + (long)m * g.lda2_b + chunk * 16 : nullptr;
+        } else {
+            const int n = min(n0 + r, g.N - 1);
+            rp[j] = g.Wt + (long)n * g.ldw_b + chunk * 16;
+            rp2[j] = nullptr;
+        }
+    }
+    const int tpc = CONV ? (g.Cin * ESZ) / ROW : 1;
+    const int lds_rows0 = (loads_a ? 0 : 256 * ROW) + (wave & 3) * 64 * ROW;
+
+    auto issue = [&](int kt) {
+        char* dst = smem + (kt & (NSTAGE - 1)) * STAGE + lds_rows0;
+        long koff;
+        bool seg2 = false;
+        if (loads_a) {
+            if constexpr (CONV) {
+                const int tap = kt / tpc, c0 = kt - tap * tpc;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                koff = ((long)(ky * (g.W + 2) + kx) * g.Cin) * ESZ + c0 * ROW;
+            } else {
+                seg2 = kt >= g.nt1;
+                koff = (long)(seg2 ? kt - g.nt1 : kt) * ROW;
+            }
+        } else {
+            koff = (long)kt * ROW;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16((seg2 ? rp2[j] : rp[j]) + koff, dst + j * 16 * ROW);
+    };
+
+    // ---- fragment addressing: row = base + (lane&31); logical slot = 2*s + (lane>>5)
+    const int fr = lane & 31, fh = lane >> 5;
+    int aoff[4], akey[4], boff[2], bkey[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = grp * 128 + i * 32 + fr;
+        aoff[i] = r * ROW;
+        akey[i] = (r >> 2) & 3;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = q * 64 + i * 32 + fr;
+        boff[i] = 256 * ROW + r * ROW;
+        bkey[i] = (r >> 2) & 3;
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 af[4][2], bf[2][2];
+
+    auto load_frags = [&](int kt) {
+        const char* st = smem + (kt & (NSTAGE - 1)) * STAGE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int slot = 2 * s + fh;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) bf[i][s] = *reinterpret_cast<const u32x4*>(st + boff[i] + ((slot ^ bkey[i]) << 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i][s] = *reinterpret_cast<const u32x4*>(st + aoff[i] + ((slot ^ akey[i]) << 4));
+        }
+    };
+
+    auto compute = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    if constexpr (BF16) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8_t, bf[ni][s]), __builtin_bit_cast(bf16x8_t, af[mi][s]), acc[mi][ni], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                __uint_as_float(bf[ni][s][c]), __uint_as_float(af[mi][s][c]), acc[mi][ni], 0, 0, 0);
+                    }
+                }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // wait until this wave's DMA pieces of tile kt+1 have landed (pieces of later tiles may stay in flight)
+    auto wait_next_tile = [&](int kt) {
+        const int later = min(2, g.nt - 2 - kt);   // tiles issued after kt+1 by the time of this wait
+        if (later >= 2) wait_vmcnt<8>();
+        else if (later == 1) wait_vmcnt<4>();
+        else wait_vmcnt<0>();
+    };
+
+    const int nt = g.nt;
+    // ---- prologue: tiles 0..2 in flight, tile 0 landed and visible
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (t < nt) issue(t);
+    if (nt >= 3) wait_vmcnt<8>();
+    else if (nt == 2) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+
+    if (grp == 0) {
+        for (int kt = 0; kt < nt; ++kt) {
+            // slot 2kt : LOAD
+            if (kt + 3 < nt) issue(kt + 3);
+            load_frags(kt);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // slot 2kt+1 : MFMA
+            compute();
+            __builtin_amdgcn_sched_barrier(0);
+            wait_next_tile(kt);
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_barrier();  // slot 2nt: group 1 finishes its last MFMA phase
+    } else {
+        __builtin_amdgcn_s_barrier();  // slot 0: idle
+        for (int kt = 0; kt < nt; ++kt) {
+            // slot 2kt+1 : LOAD
+            if (kt + 3 < nt) issue(kt + 3);
+            load_frags(kt);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            wait_next_tile(kt);
+            __builtin_amdgcn_s_barrier();
+            // slot 2kt+2 : MFMA
+            compute();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
+    // ---- epilogue through LDS: per wave a [32][64] f32 staging tile (row stride 272 B), one 32-row block at a time
+    constexpr int ESTRIDE = 272;
+    char* est = smem + wave * (32 * ESTRIDE);
+    const bool vec_ok = CONV || ((g.ldc & 7) == 0);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        __syncthreads();
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 v = {acc[mi][ni][4 * c], acc[mi][ni][4 * c + 1], acc[mi][ni][4 * c + 2], acc[mi][ni][4 * c + 3]};
+                *reinterpret_cast<f32x4*>(est + fr * ESTRIDE + (ni * 32 + 8 * c + 4 * fh) * 4) = v;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rl = (lane >> 3) + 8 * it, cl = (lane & 7) * 8;
+            const int m = m0 + grp * 128 + mi * 32 + rl;
+            const int n = n0 + q * 64 + cl;
+            if (m >= g.M || n >= g.N) continue;
+            float v[8];
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(est + rl * ESTRIDE + cl * 4);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(est + rl * ESTRIDE + cl * 4 + 16);
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            epilogue_store8(g, v, n, out_offset<CONV>(g, m, n), vec_ok);
+        }
+    }
+}
+
+template <bool BF16, bool CONV>
+int launch256(const GemmArgs& g, hipStream_t s) {
+    const int tilesM = (g.M + 255) / 256, tilesN = (g.N + 255) / 256;
+    auto k = mfma_pingpong_kernel<BF16, CONV>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+            return SGG_ERR_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(tilesM * tilesN), dim3(512), SMEM, s, g);
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+}  // namespace
+
+// g.nt / g.nt1 are in units of 64-byte K-tiles here
+int sgg_launch_pingpong(const GemmArgs& g, bool bf16, bool conv, hipStream_t s) {
+    if (bf16) return conv ? launch256<true, true>(g, s) : launch256<true, false>(g, s);
+    return conv ? launch256<false, true>(g, s) : launch256<false, false>(g, s);
+}

@@ -1,0 +1,94 @@
+// Shared argument block of the MFMA tile kernels (gemm.hip: 128x128 / 256x64 tiles; gemm256.hip: 256x256 ping-pong).
+#pragma once
+#include "common.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+struct GemmArgs {
+    const char* A;
+    const char* A2;
+    const char* Wt;
+    long lda_b, lda2_b, ldw_b;  // bytes
+    int nt1, nt;                // k-tiles in segment 1 / total (in units of the kernel's K-tile)
+    const float* bias;
+    const float* pscale;
+    const float* pshift;
+    char* C;
+    long ldc;  // elements
+    int M, N, act, out_bf16;
+    // conv mode: A is a zero-bordered NHWC plane [B,H+2,W+2,Cin]; C is [B,H+2p,W+2p,N]
+    int H, W, Cin, out_pad;
+};
+
+__device__ __forceinline__ void glds16(const char* g, char* l) {
+    __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)l, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// XCD-contiguous logical id, then groups of GM M-panels walk N (L2 reuse of both operand panels)
+__device__ __forceinline__ void tile_coords(int bid, int tilesM, int tilesN, int& tm, int& tn) {
+    const int L = xcd_remap(bid, tilesM * tilesN);
+    constexpr int GM = 8;
+    const int per_group = GM * tilesN;
+    const int grp = L / per_group;
+    const int gm0 = grp * GM;
+    const int gsz = min(GM, tilesM - gm0);
+    const int inl = L - grp * per_group;
+    tm = gm0 + inl % gsz;
+    tn = inl / gsz;
+}
+
+// bias -> act -> per-channel affine on 8 consecutive n, then store (vector when aligned and full)
+__device__ __forceinline__ void epilogue_store8(const GemmArgs& g, float (&v)[8], int n, long off, bool vec_ok) {
+    const int nv = min(8, g.N - n);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k < nv) {
+            float t = v[k] + (g.bias ? g.bias[n + k] : 0.f);
+            if (g.act == SGG_ACT_RELU) t = fmaxf(t, 0.f);
+            if (g.pscale) t = t * g.pscale[n + k];
+            if (g.pshift) t = t + g.pshift[n + k];
+            v[k] = t;
+        }
+    }
+    if (vec_ok && nv == 8) {
+        if (g.out_bf16) store8(reinterpret_cast<bf16_t*>(g.C) + off, v);
+        else store8(reinterpret_cast<float*>(g.C) + off, v);
+    } else {
+        for (int k = 0; k < nv; ++k) {
+            if (g.out_bf16) reinterpret_cast<bf16_t*>(g.C)[off + k] = f32_to_bf16(v[k]);
+            else reinterpret_cast<float*>(g.C)[off + k] = v[k];
+        }
+    }
+}
+
+template <bool CONV>
+__device__ __forceinline__ long out_offset(const GemmArgs& g, int m, int n) {
+    if constexpr (CONV) {
+        const int hw = g.H * g.W;
+        const int b = m / hw, rem = m - b * hw;
+        const int y = rem / g.W, x = rem - y * g.W;
+        const int op = g.out_pad;
+        return ((long)(b * (g.H + 2 * op) + y + op) * (g.W + 2 * op) + x + op) * g.N + n;
+    } else {
+        return (long)m * g.ldc + n;
+    }
+}
+
+template <bool CONV>
+__device__ __forceinline__ const char* a_row_ptr(const GemmArgs& g, int m, int esz) {
+    if constexpr (CONV) {
+        const int hw = g.H * g.W;
+        const int b = m / hw, rem = m - b * hw;
+        const int y = rem / g.W, x = rem - y * g.W;
+        return g.A + ((long)(b * (g.H + 2) + y) * (g.W + 2) + x) * g.Cin * esz;
+    } else {
+        return g.A + (long)m * g.lda_b;
+    }
+}

@@ -35,7 +35,9 @@ def rand_boxes(rng, n):
 
 # ----------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize('M,N,K', [(128, 128, 64), (256, 256, 512), (200, 151, 512), (37, 51, 128), (1000, 1536, 512),
-                                   (130, 4096, 1024), (5, 64, 64)])
+                                   (130, 4096, 1024), (5, 64, 64),
+                                   # 256x256 ping-pong kernel (N >= 256 and >= 128 tiles): ragged M/N tails, 1..many K-tiles
+                                   (4096, 2048, 512), (5000, 1800, 96), (4100, 2048, 32), (4096, 2050, 64), (7936, 4096, 1024)])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_gemm(ops, M, N, K, dtype):
     g = torch.Generator().manual_seed(M * N + K)
@@ -80,7 +82,8 @@ def test_gemm_rejects_bad_k(ops):
 
 # ----------------------------------------------------------------------------------------- conv / pool / prep
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('B,H,W,Cin,Cout', [(1, 16, 16, 64, 64), (2, 10, 14, 64, 128), (1, 38, 38, 128, 256)])
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(1, 16, 16, 64, 64), (2, 10, 14, 64, 128), (1, 38, 38, 128, 256),
+                                            (2, 76, 76, 64, 1024), (3, 62, 70, 128, 512)])
 def test_conv3x3(ops, dtype, B, H, W, Cin, Cout):
     g = torch.Generator().manual_seed(Cin + Cout)
     x = torch.randn(B, Cin, H, W, generator=g).to(dtype)
