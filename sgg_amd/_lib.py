@@ -8,7 +8,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsgg_hip.so')
+LIB_PATH = os.environ.get('SGG_HIP_LIB') or os.path.join(_HERE, 'libsgg_hip.so')   # override: kernel experiments only
 
 SGG_F32, SGG_BF16 = 0, 1
 ACT_NONE, ACT_RELU = 0, 1

@@ -2,16 +2,19 @@
 //
 // 8 waves = two groups of four (one wave of each group per SIMD).  Each wave owns a 128(M) x 64(N) slab of the
 // 256x256 block tile: 4x2 MFMA 32x32 tiles = 128 accumulator registers.  K advances in 64-byte slabs per row
-// (32 bf16 / 16 f32): one K-tile = 2 MFMA k-steps.  The two groups run the same K-tile sequence one PHASE apart:
+// (32 bf16 / 16 f32): one K-tile = 2 MFMA k-steps = 16 MFMAs per wave.  The two groups run the same K-tile
+// sequence one PHASE apart, one s_barrier per phase:
 //
 //   slot      0        1        2        3        4   ...
 //   group 0   LOAD 0   MFMA 0   LOAD 1   MFMA 1   LOAD 2
 //   group 1   -        LOAD 0   MFMA 0   LOAD 1   MFMA 1
 //
-// so on every SIMD one wave is issuing 16 back-to-back MFMAs (512 cycles) while its partner issues the next
-// K-tile's 12 ds_read_b128 and its share of the global->LDS DMA for the tile three ahead.  A 4-deep LDS ring
-// (4 x 32 KiB) keeps 2-3 K-tiles of global_load_lds in flight across the barriers (counted vmcnt, never 0 in
-// the main loop).  One s_barrier per slot.
+// LOAD = 12 ds_read_b128 (fragments, single-buffered in registers); MFMA = 16 MFMAs with this wave's 4 global->LDS
+// DMA pieces of the K-tile three ahead issued between them (an LDS-DMA issue costs ~60 cycles in an MFMA phase,
+// 100-185 in a LOAD phase: measured 1053 vs 963 TFLOP/s).  A 4-deep LDS ring (4 x 32 KiB) keeps 2-3 K-tiles of
+// DMA in flight across the barriers (counted vmcnt, never 0 in the main loop).
+// Ablation on fc6 (7936x4096x25600 bf16, random normal data): full 1055 TF; without the DMA 1398; without
+// ds_reads 1099; MFMA only 1519 (the matrix pipe is then 82 % busy at 1.88 GHz: the chip clocks down under load).
 //
 // LDS image per stage: A rows [256][64 B] then W rows [256][64 B], lane-linear for global_load_lds
 // (16 rows per 1-KiB wave instruction); 16-byte slot swizzle phys = slot ^ ((row>>2)&3) applied on the source
@@ -117,12 +120,32 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
         }
     };
 
-    auto compute = [&]() {
+    // 16 MFMAs; the 4 DMA pieces of K-tile `pf` (or none if pf < 0) are issued between them, where the wave is
+    // matrix-pipe bound and has free issue slots (an LDS-DMA issue costs ~60 cycles there, 100-185 in a LOAD phase)
+    auto compute = [&](int pf) {
+        char* dst = nullptr;
+        long koff = 0;
+        bool seg2 = false;
+        if (pf >= 0) {
+            dst = smem + (pf & (NSTAGE - 1)) * STAGE + lds_rows0;
+            if (loads_a) {
+                if constexpr (CONV) {
+                    const int tap = pf / tpc, c0 = pf - tap * tpc;
+                    const int ky = tap / 3, kx = tap - ky * 3;
+                    koff = ((long)(ky * (g.W + 2) + kx) * g.Cin) * ESZ + c0 * ROW;
+                } else {
+                    seg2 = pf >= g.nt1;
+                    koff = (long)(seg2 ? pf - g.nt1 : pf) * ROW;
+                }
+            } else {
+                koff = (long)pf * ROW;
+            }
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     if constexpr (BF16) {
@@ -135,12 +158,16 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
                                 __uint_as_float(bf[ni][s][c]), __uint_as_float(af[mi][s][c]), acc[mi][ni], 0, 0, 0);
                     }
                 }
+                if (s == 0 && pf >= 0) {   // after MFMA 2,4,6,8
+                    glds16((seg2 ? rp2[mi] : rp[mi]) + koff, dst + mi * 16 * ROW);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         __builtin_amdgcn_s_setprio(0);
     };
 
-    // wait until this wave's DMA pieces of tile kt+1 have landed (pieces of later tiles may stay in flight)
-    auto wait_next_tile = [&](int kt) {
-        const int later = min(2, g.nt - 2 - kt);   // tiles issued after kt+1 by the time of this wait
+    // wait until this wave's DMA pieces of tile kt+1 have landed; `later` = tiles it issued after kt+1
+    auto wait_tiles_in_flight = [&](int later) {
         if (later >= 2) wait_vmcnt<8>();
         else if (later == 1) wait_vmcnt<4>();
         else wait_vmcnt<0>();
@@ -156,18 +183,20 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
 
+    // Two s_barriers per K-tile (measured better than one: 1053 vs 1008 TFLOP/s on fc6 -- with a single barrier the
+    // two waves of a SIMD drift into the same phase).  Tile kt+3 goes into the stage tile kt-1 occupied; its last
+    // readers (group 1, LOAD kt-1) retired their ds_reads before the barrier that ended slot 2kt-1.
     if (grp == 0) {
         for (int kt = 0; kt < nt; ++kt) {
             // slot 2kt : LOAD
-            if (kt + 3 < nt) issue(kt + 3);
             load_frags(kt);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
-            // slot 2kt+1 : MFMA
-            compute();
+            // slot 2kt+1 : MFMA (+ DMA issue of tile kt+3)
+            compute(kt + 3 < nt ? kt + 3 : -1);
             __builtin_amdgcn_sched_barrier(0);
-            wait_next_tile(kt);
+            wait_tiles_in_flight(min(2, nt - 2 - kt));     // tile kt+1 landed; issued so far: .. kt+3
             __builtin_amdgcn_s_barrier();
         }
         __builtin_amdgcn_s_barrier();  // slot 2nt: group 1 finishes its last MFMA phase
@@ -175,14 +204,13 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
         __builtin_amdgcn_s_barrier();  // slot 0: idle
         for (int kt = 0; kt < nt; ++kt) {
             // slot 2kt+1 : LOAD
-            if (kt + 3 < nt) issue(kt + 3);
             load_frags(kt);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            wait_next_tile(kt);
+            wait_tiles_in_flight(min(1, nt - 2 - kt));     // tile kt+1 landed; issued so far: .. kt+2
             __builtin_amdgcn_s_barrier();
-            // slot 2kt+2 : MFMA
-            compute();
+            // slot 2kt+2 : MFMA (+ DMA issue of tile kt+3)
+            compute(kt + 3 < nt ? kt + 3 : -1);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
         }

@@ -37,7 +37,7 @@ def rand_boxes(rng, n):
 @pytest.mark.parametrize('M,N,K', [(128, 128, 64), (256, 256, 512), (200, 151, 512), (37, 51, 128), (1000, 1536, 512),
                                    (130, 4096, 1024), (5, 64, 64),
                                    # 256x256 ping-pong kernel (N >= 256 and >= 128 tiles): ragged M/N tails, 1..many K-tiles
-                                   (4096, 2048, 512), (5000, 1800, 96), (4100, 2048, 32), (4096, 2050, 64), (7936, 4096, 1024)])
+                                   (4096, 2048, 512), (5000, 1800, 192), (4100, 2048, 128), (4096, 2050, 64), (7936, 4096, 1024)])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_gemm(ops, M, N, K, dtype):
     g = torch.Generator().manual_seed(M * N + K)
