@@ -64,10 +64,11 @@ int sgg_pair_index_eval(const int64_t* im_inds, const float* boxes /*[N,4] or NU
                         int64_t* rel_inds, int cap, int* count, int* work, void* stream);
 int sgg_pair_index_train(const int64_t* im_inds, int N, const int64_t* gt_rels, int R, const int* img_first,
                          int64_t* rel_labels, int cap, int* count, int* work, void* stream);
-/* CSR of the edges by object node (in-edges), by counting sort; edges keep ascending order inside a node.
- * in_ptr i32[N+1], in_ids i32[E].  Also out_ptr/out_ids by subject.  work >= 2*(N+1) int32. */
-int sgg_edge_csr(const int64_t* rel_inds /*[E,3]*/, int E, int N, int* out_ptr, int* out_ids, int* in_ptr, int* in_ids,
-                 int* work, void* stream);
+/* CSR lists of the edges by subject node (out_ptr/out_ids) and by object node (in_ptr/in_ids); edges keep ascending
+ * order inside a node.  ptr i32[N+1], ids i32[E].  im_inds (optional, i64[N] node->image): when given, rel_inds must be
+ * sorted by image (as both pair-index calls emit it) and only the node's own image segment is scanned. */
+int sgg_edge_csr(const int64_t* rel_inds /*[E,3]*/, int E, int N, const int64_t* im_inds, int* out_ptr, int* out_ids,
+                 int* in_ptr, int* in_ids, void* stream);
 
 /* ---- a-4  RoIAlign (+ fused union box): RelModelBase.node_edge_features, rel_model_base.py:245-260, and
  * [3P] torchvision roi_align(output_size=7, sampling_ratio=2, aligned=False, spatial_scale) ----
@@ -125,7 +126,7 @@ int sgg_gru_gate_fwd(const void* gi, const void* gh, const float* b_hh, const vo
  *   when gt_classes != NULL).  rel: softmax over P predicates, triple score = max_{p>=1} * s_subj * s_obj.
  * sort: descending by score, ties by ascending edge index (torch.sort leaves ties unspecified).
  * Outputs: obj_scores f32[N], obj_preds i64[N], rels i64[E,2] (sorted), pred_scores f32[E,P] (sorted).
- * work: f32/i32 scratch of >= 2*E + 2*pow2ceil(E) + E*P words. */
+ * work: f32/i32 scratch of >= 2*pow2ceil(E) + E*P words. */
 int sgg_eval_tail(const void* obj_dists, int N, int C, const void* rel_dists, int E, int P,
                   const int64_t* rel_inds /*[E,3]*/, const int64_t* gt_classes /*[N] or NULL*/, float* obj_scores,
                   int64_t* obj_preds, int64_t* rels, float* pred_scores, void* work, int dtype, void* stream);

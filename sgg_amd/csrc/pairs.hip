@@ -148,17 +148,36 @@ __global__ __launch_bounds__(256) void fg_fill_kernel(const int64_t* __restrict_
     }
 }
 
-// ---- CSR lists: one wave per (node, side); scans the edge list in order (ballot compaction keeps edge order)
+// ---- CSR lists: one wave per (node, side); scans the edge list in order (ballot compaction keeps edge order).
+// When the node->image map is given, rel_inds is sorted by image (both pair-index kernels emit it so) and only the
+// node's own image segment [lower_bound, upper_bound) is scanned.
+__device__ __forceinline__ int bound_img(const int64_t* rel, int E, int64_t img, bool upper) {
+    int lo = 0, hi = E;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int64_t v = rel[3 * (long)mid];
+        if (upper ? v <= img : v < img) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
 template <bool WRITE>
-__global__ __launch_bounds__(64) void csr_kernel(const int64_t* __restrict__ rel, int E, int N, int* __restrict__ optr,
-                                                 int* __restrict__ iptr, int* __restrict__ oids, int* __restrict__ iids) {
+__global__ __launch_bounds__(64) void csr_kernel(const int64_t* __restrict__ rel, int E, int N, const int64_t* __restrict__ im,
+                                                 int* __restrict__ optr, int* __restrict__ iptr, int* __restrict__ oids,
+                                                 int* __restrict__ iids) {
     const int n = blockIdx.x >> 1, side = blockIdx.x & 1, lane = threadIdx.x;
     int* ptr = side ? iptr : optr;
     int* ids = side ? iids : oids;
     int base = WRITE ? ptr[n] : 0;
-    for (int e0 = 0; e0 < E; e0 += 64) {
+    int e_lo = 0, e_hi = E;
+    if (im) {
+        e_lo = bound_img(rel, E, im[n], false);
+        e_hi = bound_img(rel, E, im[n], true);
+    }
+    for (int e0 = e_lo; e0 < e_hi; e0 += 64) {
         const int e = e0 + lane;
-        const bool ok = e < E && rel[3 * (long)e + 1 + side] == n;
+        const bool ok = e < e_hi && rel[3 * (long)e + 1 + side] == n;
         const unsigned long long m = __ballot(ok);
         if (WRITE && ok) ids[base + lanes_below(m, lane)] = e;
         base += __popcll(m);
@@ -197,15 +216,14 @@ extern "C" int sgg_pair_index_train(const int64_t* im_inds, int N, const int64_t
     return SGG_OK;
 }
 
-extern "C" int sgg_edge_csr(const int64_t* rel_inds, int E, int N, int* out_ptr, int* out_ids, int* in_ptr, int* in_ids,
-                            int* work, void* stream) {
-    (void)work;
+extern "C" int sgg_edge_csr(const int64_t* rel_inds, int E, int N, const int64_t* im_inds, int* out_ptr, int* out_ids,
+                            int* in_ptr, int* in_ids, void* stream) {
     if (!rel_inds || !out_ptr || !out_ids || !in_ptr || !in_ids || N <= 0 || E < 0) return SGG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(csr_kernel<false>, dim3(2 * N), dim3(64), 0, s, rel_inds, E, N, out_ptr, in_ptr, out_ids, in_ids);
+    hipLaunchKernelGGL(csr_kernel<false>, dim3(2 * N), dim3(64), 0, s, rel_inds, E, N, im_inds, out_ptr, in_ptr, out_ids, in_ids);
     hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, s, out_ptr, N, (int*)nullptr);
     hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, s, in_ptr, N, (int*)nullptr);
-    hipLaunchKernelGGL(csr_kernel<true>, dim3(2 * N), dim3(64), 0, s, rel_inds, E, N, out_ptr, in_ptr, out_ids, in_ids);
+    hipLaunchKernelGGL(csr_kernel<true>, dim3(2 * N), dim3(64), 0, s, rel_inds, E, N, im_inds, out_ptr, in_ptr, out_ids, in_ids);
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

@@ -91,39 +91,7 @@ __device__ __forceinline__ bool before(float ka, int ia, float kb, int ib) {
     return ka > kb || (ka == kb && ia < ib);
 }
 
-// single-workgroup bitonic sort in LDS (n2 <= 8192)
-__global__ __launch_bounds__(1024) void bitonic_lds_kernel(float* __restrict__ keys, int* __restrict__ idx, int n2) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* k = reinterpret_cast<float*>(smem);
-    int* id = reinterpret_cast<int*>(smem + (size_t)n2 * 4);
-    for (int i = threadIdx.x; i < n2; i += 1024) {
-        k[i] = keys[i];
-        id[i] = idx[i];
-    }
-    __syncthreads();
-    for (int size = 2; size <= n2; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = threadIdx.x; t < (n2 >> 1); t += 1024) {
-                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
-                const bool asc = (lo & size) == 0;  // "ascending" = our order (best first)
-                const float ka = k[lo], kb = k[hi];
-                const int ia = id[lo], ib = id[hi];
-                const bool in_order = !before(kb, ib, ka, ia);
-                if (in_order != asc) {
-                    k[lo] = kb; k[hi] = ka;
-                    id[lo] = ib; id[hi] = ia;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (int i = threadIdx.x; i < n2; i += 1024) {
-        keys[i] = k[i];
-        idx[i] = id[i];
-    }
-}
-
-// one compare-exchange step in global memory (n2 > 8192)
+// one compare-exchange step of a bitonic network in global memory (E > 16384)
 __global__ __launch_bounds__(256) void bitonic_step_kernel(float* __restrict__ k, int* __restrict__ id, int n2, int size,
                                                            int stride) {
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -137,6 +105,38 @@ __global__ __launch_bounds__(256) void bitonic_step_kernel(float* __restrict__ k
         k[lo] = kb; k[hi] = ka;
         id[lo] = ib; id[hi] = ia;
     }
+}
+
+// Rank sort for moderate E (<= 16384): rank[i] = #{j : j sorts before i}.  O(E^2) compares spread over
+// (E/256) x SPLIT blocks of 256 threads, keys streamed through LDS in 1024-key chunks (broadcast reads).
+// Deterministic (strict total order) and ~20x faster than a single-workgroup bitonic network at E = 7936.
+constexpr int RANK_CHUNK = 1024;
+__global__ __launch_bounds__(256) void rank_kernel(const float* __restrict__ keys, int E, int* __restrict__ rank, int split) {
+    __shared__ float sk[RANK_CHUNK];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float ki = i < E ? keys[i] : 0.f;
+    const int per = (E + split - 1) / split;
+    const int j0 = blockIdx.y * per, j1 = min(E, j0 + per);
+    int cnt = 0;
+    for (int base = j0; base < j1; base += RANK_CHUNK) {
+        const int n = min(RANK_CHUNK, j1 - base);
+        __syncthreads();
+        for (int t = threadIdx.x; t < n; t += 256) sk[t] = keys[base + t];
+        __syncthreads();
+        for (int t = 0; t < n; ++t) cnt += before(sk[t], base + t, ki, i) ? 1 : 0;
+    }
+    if (i < E && cnt) atomicAdd(&rank[i], cnt);
+}
+
+// scatter form of the gather: source edge e goes to output row rank[e]
+__global__ __launch_bounds__(256) void tail_scatter_kernel(const int* __restrict__ rank, const int64_t* __restrict__ rel,
+                                                           const float* __restrict__ probs, int E, int P,
+                                                           int64_t* __restrict__ rels, float* __restrict__ out) {
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= E) return;
+    const int r = rank[e];
+    if (lane < 2) rels[2 * (long)r + lane] = rel[3 * (long)e + 1 + lane];
+    for (int p = lane; p < P; p += 64) out[(long)r * P + p] = probs[(long)e * P + p];
 }
 
 __global__ __launch_bounds__(256) void tail_gather_kernel(const int* __restrict__ idx, const int64_t* __restrict__ rel,
@@ -178,21 +178,17 @@ extern "C" int sgg_eval_tail(const void* obj_dists, int N, int C, const void* re
             hipLaunchKernelGGL(rel_tail_kernel<bf16_t>, dim3((n2 + 3) / 4), dim3(256), 0, s, (const bf16_t*)rel_dists, E, P, rel_inds, obj_scores, probs, keys, idx, n2);
         else
             hipLaunchKernelGGL(rel_tail_kernel<float>, dim3((n2 + 3) / 4), dim3(256), 0, s, (const float*)rel_dists, E, P, rel_inds, obj_scores, probs, keys, idx, n2);
-        if (n2 <= 8192) {
-            const size_t smem = (size_t)n2 * 8;
-            static bool attr_done = false;
-            if (!attr_done) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(bitonic_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess)
-                    return SGG_ERR_LAUNCH;
-                attr_done = true;
-            }
-            hipLaunchKernelGGL(bitonic_lds_kernel, dim3(1), dim3(1024), smem, s, keys, idx, n2);
+        if (E <= 16384) {
+            if (hipMemsetAsync(idx, 0, sizeof(int) * (size_t)E, s) != hipSuccess) return SGG_ERR_LAUNCH;
+            const int split = E >= 2048 ? 8 : 1;
+            hipLaunchKernelGGL(rank_kernel, dim3((E + 255) / 256, split), dim3(256), 0, s, keys, E, idx, split);
+            hipLaunchKernelGGL(tail_scatter_kernel, dim3((E + 3) / 4), dim3(256), 0, s, idx, rel_inds, probs, E, P, rels, pred_scores);
         } else {
             for (int size = 2; size <= n2; size <<= 1)
                 for (int stride = size >> 1; stride > 0; stride >>= 1)
                     hipLaunchKernelGGL(bitonic_step_kernel, dim3((n2 / 2 + 255) / 256), dim3(256), 0, s, keys, idx, n2, size, stride);
+            hipLaunchKernelGGL(tail_gather_kernel, dim3((E + 3) / 4), dim3(256), 0, s, idx, rel_inds, probs, E, P, rels, pred_scores);
         }
-        hipLaunchKernelGGL(tail_gather_kernel, dim3((E + 3) / 4), dim3(256), 0, s, idx, rel_inds, probs, E, P, rels, pred_scores);
     }
     SGG_CHECK_LAUNCH();
     return SGG_OK;

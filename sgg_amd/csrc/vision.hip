@@ -88,6 +88,101 @@ __global__ __launch_bounds__(256) void conv1_1_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv1_1 on the matrix cores (bf16 storage mode).  K = 27 padded to 32 = two v_mfma_f32_32x32x16_bf16 k-steps.
+// A wave owns 32 consecutive pixels of one image row x all 64 output channels: each lane gathers its pixel's 3x3x3
+// patch with nine 16-byte loads (NHWC4 fp32, coalesced along x), packs the k-slice its MFMA fragment needs to bf16,
+// and the 32x64 result goes through LDS so that the wave writes one contiguous 4-KiB piece of the output row.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
+
+__global__ __launch_bounds__(256) void conv1_1_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                           int nseg, int segs_per_row, int H, int W) {
+    constexpr int LROW = 136;  // bytes per staged pixel row (128 + 8: conflict-free ds_write_b64)
+    __shared__ __attribute__((aligned(16))) char stage[4][32 * LROW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    // weight fragments: n = nt*32 + m, k = s*16 + h*8 + j  (k = (ky*3+kx)*3 + c, zero for k >= 27)
+    u32x4 wf[2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = s * 16 + h * 8 + j;
+                v[j] = k < 27 ? w[(nt * 32 + m) * 27 + k] : 0.f;
+            }
+            wf[nt][s] = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        }
+    float bv[2][4][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bv[nt][q][c] = bias[nt * 32 + 8 * q + 4 * h + c];
+    char* st = stage[wave];
+    for (int seg = blockIdx.x * 4 + wave; seg < nseg; seg += gridDim.x * 4) {
+        const int row = seg / segs_per_row, x0 = (seg - row * segs_per_row) * 32;
+        const int b = row / H, y = row - b * H;
+        const int x = min(x0 + m, W - 1);
+        float V[32];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const f32x4 p = *reinterpret_cast<const f32x4*>(in + (((long)b * (H + 2) + y + ky) * (W + 2) + x + kx) * 4);
+                V[(ky * 3 + kx) * 3 + 0] = p.x;
+                V[(ky * 3 + kx) * 3 + 1] = p.y;
+                V[(ky * 3 + kx) * 3 + 2] = p.z;
+            }
+#pragma unroll
+        for (int k = 27; k < 32; ++k) V[k] = 0.f;
+        u32x4 af[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = h ? V[s * 16 + 8 + j] : V[s * 16 + j];
+            af[s] = u32x4{pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3]), pack_bf16x2(t[4], t[5]), pack_bf16x2(t[6], t[7])};
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, wf[nt][s]),
+                                                              __builtin_bit_cast(bf16x8_v, af[s]), acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float o0 = fmaxf(acc[4 * q] + bv[nt][q][0], 0.f), o1 = fmaxf(acc[4 * q + 1] + bv[nt][q][1], 0.f);
+                const float o2 = fmaxf(acc[4 * q + 2] + bv[nt][q][2], 0.f), o3 = fmaxf(acc[4 * q + 3] + bv[nt][q][3], 0.f);
+                u32x2 pk = {pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)};
+                *reinterpret_cast<u32x2*>(st + m * LROW + (nt * 32 + 8 * q + 4 * h) * 2) = pk;
+            }
+        }
+        // wave-private staging: LDS ops of one wave complete in order, no barrier needed; the fence keeps the
+        // compiler from moving the reads above the writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        bf16_t* orow = out + (((long)b * (H + 2) + y + 1) * (W + 2) + x0 + 1) * 64;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int px = it * 8 + (lane >> 3), ch = (lane & 7) * 16;
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(st + px * LROW + ch);
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(st + px * LROW + ch + 8);
+            if (x0 + px < W) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(orow) + px * 128 + ch) = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 2x2 / stride-2 max pool between the VGG blocks (thread = output pixel x 8 channels)
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -231,8 +326,12 @@ extern "C" int sgg_conv1_1(const float* in, const float* w, const float* bias, v
     if (!in || !w || !bias || !out || B <= 0 || H <= 0 || W <= 0) return SGG_ERR_ARG;
     const long npix = (long)B * H * W;
     const int grid = (int)((npix + 63) / 64);
-    if (out_dtype == SGG_BF16)
-        hipLaunchKernelGGL(conv1_1_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, w, bias, (bf16_t*)out, npix, H, W);
+    if (out_dtype == SGG_BF16) {
+        const int segs_per_row = (W + 31) / 32, nseg = B * H * segs_per_row;
+        const int g2 = min((nseg + 3) / 4, 256 * 8);
+        hipLaunchKernelGGL(conv1_1_mfma_kernel, dim3(g2), dim3(256), 0, (hipStream_t)stream, in, w, bias, (bf16_t*)out, nseg,
+                           segs_per_row, H, W);
+    }
     else if (out_dtype == SGG_F32)
         hipLaunchKernelGGL(conv1_1_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, w, bias, (float*)out, npix, H, W);
     else

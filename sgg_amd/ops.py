@@ -94,15 +94,16 @@ def pair_index_train(im_inds, gt_rels, img_first, cap):
     return out, count
 
 
-def edge_csr(rel_inds, N):
+def edge_csr(rel_inds, N, im_inds=None):
+    """CSR lists by subject / object.  im_inds (node -> image, i64[N]) may be given when rel_inds is sorted by image."""
     E = rel_inds.shape[0]
     dev = rel_inds.device
     out_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
     in_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
     out_ids = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
     in_ids = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
-    _lib.call('sgg_edge_csr', _p(rel_inds, torch.int64), E, N, _p(out_ptr), _p(out_ids), _p(in_ptr), _p(in_ids), None,
-              _stream())
+    _lib.call('sgg_edge_csr', _p(rel_inds, torch.int64), E, N, _p(im_inds, torch.int64) if im_inds is not None else None,
+              _p(out_ptr), _p(out_ids), _p(in_ptr), _p(in_ids), _stream())
     return out_ptr, out_ids, in_ptr, in_ids
 
 

@@ -68,7 +68,7 @@ class RelModelStanford(RelModelBase):
                                                                           (torch.float32, torch.bfloat16) else t, dtype)
         return message_pass(cast(rel_rep), cast(obj_rep), ri3, csr, w['imp'], self.mp_iter, dtype)
 
-    def predict(self, node_feat, edge_feat, rel_inds, rois, im_sizes, _csr=None):
+    def predict(self, node_feat, edge_feat, rel_inds, rois, im_sizes, _im_inds=None):
         """rel_model_stanford.py:97-107.  node_feat [N,C,7,7], edge_feat [E,C,7,7] (raw RoIAlign), rel_inds i64[E,3]
         -> (obj_dists f32[N,151], rel_dists f32[E,51])."""
         if self.training and (torch.is_grad_enabled()):
@@ -99,7 +99,7 @@ class RelModelStanford(RelModelBase):
         rel_rep = ops.gemm(y, w['edge_unary'], w['edge_unary_b'], ops.ACT_RELU)
         # :105
         _lib.set_tag('imp')
-        csr = _csr if _csr is not None else ops.edge_csr(rel_inds, N)
+        csr = ops.edge_csr(rel_inds, N, _im_inds)   # _im_inds: only forward() passes it (its rel_inds are image-sorted)
         vert, edge = message_pass(rel_rep, obj_rep, rel_inds, csr, w['imp'], self.mp_iter, dtype)
         # :107
         _lib.set_tag('heads')
@@ -132,7 +132,8 @@ class RelModelStanford(RelModelBase):
             result.node_feat, result.edge_feat = self.node_edge_features(
                 result.fmap, rois, rel_inds[:, 1:], im_sizes=result.im_sizes)            # :148
         result.rm_obj_dists, result.rel_dists = self.predict(result.node_feat, result.edge_feat, rel_inds,
-                                                             rois=rois, im_sizes=result.im_sizes)   # :153
+                                                             rois=rois, im_sizes=result.im_sizes,
+                                                             _im_inds=im_inds.contiguous())         # :153
         if self.training:
             result.rois = rois
             return result                                                                # :179-181
