@@ -131,10 +131,60 @@ int sgg_eval_tail(const void* obj_dists, int N, int C, const void* rel_dists, in
                   const int64_t* rel_inds /*[E,3]*/, const int64_t* gt_classes /*[N] or NULL*/, float* obj_scores,
                   int64_t* obj_preds, int64_t* rels, float* pred_scores, void* work, int dtype, void* stream);
 
+/* ---- training side of the trainable relation head (main.py:100-120: forward in train mode, backward) ----
+ * Dense gradient contractions reuse sgg_gemm on transposed operands.  All *_bwd calls are stream-ordered like the
+ * forward ones; buffers documented "zeroed by the callee" are cleared with hipMemsetAsync on the same stream. */
+/* nn.Dropout(p), in place, counter-based RNG (element i keeps iff hash(seed,i) >= p*2^32): rel_model_base.py:110-111 */
+int sgg_dropout_fwd(void* x, int64_t n, float p, uint64_t seed, int dtype, void* stream);
+/* dx = dy * (y > 0) * scale : backward of ReLU (scale 1) / ReLU->Dropout (y = saved post-dropout output, scale 1/(1-p)) */
+int sgg_act_bwd(const void* dy, const void* y, void* dx, int64_t n, float scale, int g_dtype, int y_dtype, void* stream);
+/* out[N] = column sums of x[M,N] (row stride ld): bias gradients.  out zeroed by the callee. */
+int sgg_colsum(const void* x, int M, int N, int ld, float* out, int dtype, void* stream);
+/* train-mode BatchNorm2d of the rect conv (lib/get_union_boxes.py:54,58) on row-major [rows, C] activations:
+ * bn_stats: sums[2][C] = (sum x, sum x^2), zeroed by the callee; bn_finalize: batch mean / invstd, the affine
+ * (scale, shift) and the running-stat update (momentum 0.01, unbiased var); bn_apply: y = x*scale+shift, optionally
+ * followed by the max over 4 consecutive rows (MaxPool2d(3,2,1) on the 2x2 map, :55) with arg-max rows to `arg`;
+ * bn_bwd: backward of ReLU -> BN [-> max4]: x = post-ReLU BN input, dy [rows(/4), C] -> dx [rows, C] (gradient at the
+ * conv output), sums[2][C] = (dbeta, dgamma), zeroed by the callee. */
+int sgg_bn_stats(const void* x, int M, int C, float* sums, int dtype, void* stream);
+int sgg_bn_finalize(const float* sums, int C, int count, const float* gamma, const float* beta, float eps, float momentum,
+                    float* run_mean, float* run_var, float* mean, float* invstd, float* scale, float* shift, void* stream);
+int sgg_bn_apply(const void* x, const float* scale, const float* shift, void* out, unsigned char* arg, int rows_out, int C,
+                 int max4, int dtype, void* stream);
+int sgg_bn_bwd(const void* dy, const unsigned char* arg, const void* x, const float* mean, const float* invstd,
+               const float* gamma, void* dx, float* sums, int rows, int C, int max4, int dtype, void* stream);
+/* nn.GRUCell backward, pointwise part: from dh[M,H] and the saved fp32 pre-activations gi/gh ([M,3H]; gh NULL = the
+ * h=0 first call, b_hh given) -> d_gi, d_gh [M,3H] and dh_prev [M,H] (may be NULL). */
+int sgg_gru_gate_bwd(const void* dh, const float* gi, const float* gh, const float* b_hh, const void* h_prev, void* d_gi,
+                     void* d_gh, void* dh_prev, int M, int H, int dtype, void* stream);
+/* backward of sgg_imp_edge_ctx_fwd + sgg_imp_node_scatter_fwd (rel_model_stanford.py:76-91):
+ * edge side: d_e[e] += g_out*d_ctx[s] + g_in*d_ctx[o] + sum_k da_k*w_k[H:];  da[E,4] = gate pre-activation gradients
+ *   (order sub,obj,out,in);  gsave[E,2] = (g_sub, g_obj).
+ * node side: d_v[n] += sum_out g_sub*d_e_in + sum_in g_obj*d_e_in + sum_k S_k[n]*w_k[:H];  nsum[N,4] = S_k[n].
+ * gate-weight gradients: d_w_k[H:] = rank4_reduce(da, e_i), d_w_k[:H] = rank4_reduce(nsum, v), d_b = colsum(da). */
+int sgg_imp_edge_ctx_bwd(const void* v, const void* e, const int64_t* rel_inds, int E, int H, const float* node_dots,
+                         const float* gate_w, const float* gate_b, const void* d_e_in, const void* d_ctx, void* d_e, float* da,
+                         float* gsave, int dtype, void* stream);
+int sgg_imp_node_scatter_bwd(const void* d_e_in, const float* gsave, const float* da, const int* out_ptr, const int* out_ids,
+                             const int* in_ptr, const int* in_ids, const float* gate_w, int N, int H, void* d_v, float* nsum,
+                             int dtype, void* stream);
+/* out[k,:H] += sum_r a[r,k]*x[r,:], k<4 (out row stride out_ld; accumulates: the caller zeroes once per step) */
+int sgg_rank4_reduce(const float* a, const void* x, int R, int H, float* out, int out_ld, int dtype, void* stream);
+
 /* ---- utilities used by the host for weight preparation (load time, not on the step path) ---- */
 int sgg_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, void* stream);
 /* out[n][p][c] = in[n][c][p]  (fc6 K-order (c,ph,pw) -> (ph,pw,c); conv OIHW -> O(HW)I) */
 int sgg_permute_ncp_to_npc(const void* in, void* out, int Nn, int C, int Pp, int in_dtype, int out_dtype, void* stream);
+
+/* out[c][r] = in[r][c] (row strides in elements); used to feed d W = dY^T X to sgg_gemm */
+int sgg_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int R, int C, int in_dtype, int out_dtype,
+                  void* stream);
+/* y += x (n multiple of 8) */
+int sgg_add(void* y, const void* x, int64_t n, int y_dtype, int x_dtype, void* stream);
+/* out[n][c][p] = in[n][p*C + c] (+ add[n][c]): fc6 weight gradient back to the reference's (c,ph,pw) K order, plus the
+ * folded rect-conv term */
+int sgg_unpermute_add(const float* in, int64_t ld_in, const float* add, int64_t ld_add, float* out, int Nn, int C, int Pp,
+                      void* stream);
 
 #ifdef __cplusplus
 }

@@ -38,6 +38,20 @@ SIGNATURES = {
     'sgg_imp_node_scatter_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P],
     'sgg_gru_gate_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sgg_eval_tail': [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    'sgg_dropout_fwd': [_P, _L, _F, ctypes.c_uint64, _I, _P],
+    'sgg_act_bwd': [_P, _P, _P, _L, _F, _I, _I, _P],
+    'sgg_colsum': [_P, _I, _I, _I, _P, _I, _P],
+    'sgg_bn_stats': [_P, _I, _I, _P, _I, _P],
+    'sgg_bn_finalize': [_P, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],
+    'sgg_bn_apply': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'sgg_bn_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'sgg_gru_gate_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    'sgg_imp_edge_ctx_bwd': [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    'sgg_imp_node_scatter_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
+    'sgg_rank4_reduce': [_P, _P, _I, _I, _P, _I, _I, _P],
+    'sgg_transpose': [_P, _L, _P, _L, _I, _I, _I, _I, _P],
+    'sgg_add': [_P, _P, _L, _I, _I, _P],
+    'sgg_unpermute_add': [_P, _L, _P, _L, _P, _I, _I, _I, _P],
     'sgg_cast': [_P, _P, _L, _I, _I, _P],
     'sgg_permute_ncp_to_npc': [_P, _P, _I, _I, _I, _I, _I, _P],
 }

@@ -1,0 +1,624 @@
+// Training-side kernels of the relation head: Dropout, ReLU/Dropout backward, bias-gradient column sums,
+// train-mode BatchNorm of the rect conv (lib/get_union_boxes.py:54,58), GRU-cell backward, and the backward of the
+// IMP gather / gate / scatter (sgg_models/rel_model_stanford.py:74-91).  Dense gradient contractions reuse sgg_gemm
+// on transposed operands (sgg_permute_ncp_to_npc with N=1 is the transpose).
+#include "common.h"
+
+namespace {
+
+constexpr int MAXH = 512;
+
+// counter-based RNG: one 32-bit hash per element index (splitmix/murmur-style finaliser)
+__device__ __forceinline__ unsigned int hash_u32(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x = x ^ (x >> 31);
+    return (unsigned int)(x >> 32);
+}
+
+// nn.Dropout(p) in training mode, in place: x = keep ? x/(1-p) : 0   (rel_model_base.py:110-111 classifier Dropouts)
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(T* __restrict__ x, long n8, float p, unsigned long long seed) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    float v[8];
+    load8(x + i * 8, v);
+    const float scale = 1.f / (1.f - p);
+    const unsigned int thr = (unsigned int)(p * 4294967296.0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = hash_u32(seed ^ (unsigned long long)(i * 8 + k)) >= thr ? v[k] * scale : 0.f;
+    store8(x + i * 8, v);
+}
+
+// dx = dy * (y > 0) * scale  : backward of ReLU (scale 1) or ReLU->Dropout (y is the saved post-dropout value,
+// scale 1/(1-p): y > 0 iff the unit was kept and its pre-activation was positive)
+template <typename TG, typename TY>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const TG* __restrict__ dy, const TY* __restrict__ y, TG* __restrict__ dx,
+                                                      long n8, float scale) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    float g[8], v[8];
+    load8(dy + i * 8, g);
+    load8(y + i * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g[k] = v[k] > 0.f ? g[k] * scale : 0.f;
+    store8(dx + i * 8, g);
+}
+
+// column sums of x[M,N] (bias gradients): grid (N/64, MSPLIT); each block reduces a row range, atomics merge
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int M, int N, int ld, float* __restrict__ out,
+                                                     int rows_per_block) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    if (c < N)
+        for (int r = r0 + w; r < r1; r += 4) s += Elem<T>::ld(x + (long)r * ld + c);
+    red[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < N) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// per-channel sums for BatchNorm: out[0][c] = sum x, out[1][c] = sum x*y  (y == x for statistics: sum x^2;
+// y = xhat-source for the backward reductions).  Same decomposition as colsum.
+template <typename T, typename T2>
+__global__ __launch_bounds__(256) void colsum2_kernel(const T* __restrict__ x, const T2* __restrict__ y, int M, int N,
+                                                      float* __restrict__ out, int rows_per_block) {
+    __shared__ float red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s = 0.f, q = 0.f;
+    if (c < N)
+        for (int r = r0 + w; r < r1; r += 4) {
+            const float a = Elem<T>::ld(x + (long)r * N + c), b = Elem<T2>::ld(y + (long)r * N + c);
+            s += a;
+            q += a * b;
+        }
+    red[0][w][threadIdx.x & 63] = s;
+    red[1][w][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (w == 0 && c < N) {
+        const int t = threadIdx.x;
+        atomicAdd(&out[c], red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]);
+        atomicAdd(&out[N + c], red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]);
+    }
+}
+
+// BatchNorm apply with given per-channel scale/shift, optionally followed by the max over 4 consecutive rows
+// (MaxPool2d(3,2,1) on the 2x2 map), recording the arg-max row for the backward.
+template <typename T, bool MAX4>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ sc,
+                                                       const float* __restrict__ sh, T* __restrict__ out,
+                                                       unsigned char* __restrict__ arg, long rows_out, int C) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // over rows_out * C/8
+    const int c8 = C >> 3;
+    if (i >= rows_out * c8) return;
+    const long r = i / c8;
+    const int c = (int)(i - r * c8) * 8;
+    float s[8], t[8], best[8];
+    load8(sc + c, s);
+    load8(sh + c, t);
+    unsigned char bi[8];
+    constexpr int R = MAX4 ? 4 : 1;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        float v[8];
+        load8(x + (r * R + q) * C + c, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float y = v[k] * s[k] + t[k];
+            if (q == 0 || y > best[k]) {
+                best[k] = y;
+                bi[k] = (unsigned char)q;
+            }
+        }
+    }
+    store8(out + r * C + c, best);
+    if (MAX4 && arg) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) arg[r * C + c + k] = bi[k];
+    }
+}
+
+// BatchNorm backward elementwise part (x is the pre-BN activation, post-ReLU; the ReLU backward is folded in):
+//   dxhat-form: dx = gamma*invstd * (dy - mean_dy - xhat * mean_dyxhat), then * (x > 0)
+// With MAX4 the incoming gradient dy[rows/4, C] is routed to the arg-max row (others get 0) first.
+template <typename T, bool MAX4>
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ arg,
+                                                     const T* __restrict__ x, const float* __restrict__ mean,
+                                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                     const float* __restrict__ sums /*[2][C]: sum dy, sum dy*xhat*/,
+                                                     T* __restrict__ dx, long rows, int C, float inv_count) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // over rows * C/8
+    const int c8 = C >> 3;
+    if (i >= rows * c8) return;
+    const long r = i / c8;
+    const int c = (int)(i - r * c8) * 8;
+    float g[8], v[8], mu[8], is[8], ga[8], s1[8], s2[8];
+    load8(x + r * C + c, v);
+    load8(mean + c, mu);
+    load8(invstd + c, is);
+    load8(gamma + c, ga);
+    load8(sums + c, s1);
+    load8(sums + C + c, s2);
+    if (MAX4) {
+        float t[8];
+        load8(dy + (r >> 2) * C + c, t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] = arg[(r >> 2) * C + c + k] == (unsigned char)(r & 3) ? t[k] : 0.f;
+    } else {
+        load8(dy + r * C + c, g);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float xh = (v[k] - mu[k]) * is[k];
+        const float d = ga[k] * is[k] * (g[k] - s1[k] * inv_count - xh * s2[k] * inv_count);
+        g[k] = v[k] > 0.f ? d : 0.f;  // ReLU in front of the BN (v = relu(conv) so v > 0 iff conv > 0)
+    }
+    store8(dx + r * C + c, g);
+}
+
+// reductions for the BN backward: sums[0][c] = sum_r g, sums[1][c] = sum_r g * xhat, g routed through MAX4 if needed
+template <typename T, bool MAX4>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ arg,
+                                                            const T* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, float* __restrict__ sums,
+                                                            int rows, int C, int rows_per_block) {
+    __shared__ float red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float s = 0.f, q = 0.f;
+    if (c < C) {
+        const float mu = mean[c], is = invstd[c];
+        for (int r = r0 + w; r < r1; r += 4) {
+            float g;
+            if (MAX4) g = arg[(long)(r >> 2) * C + c] == (unsigned char)(r & 3) ? Elem<T>::ld(dy + (long)(r >> 2) * C + c) : 0.f;
+            else g = Elem<T>::ld(dy + (long)r * C + c);
+            const float xh = (Elem<T>::ld(x + (long)r * C + c) - mu) * is;
+            s += g;
+            q += g * xh;
+        }
+    }
+    red[0][w][threadIdx.x & 63] = s;
+    red[1][w][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        const int t = threadIdx.x;
+        atomicAdd(&sums[c], red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]);
+        atomicAdd(&sums[C + c], red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]);
+    }
+}
+
+// GRU cell backward (pointwise): recomputes r,z,n from the saved pre-activations.
+//   d_gi = [d_rpre, d_zpre, d_npre], d_gh = [d_rpre, d_zpre, d_npre * r], dh_prev = dh * z
+template <typename T>
+__global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const T* __restrict__ dh, const float* __restrict__ gi,
+                                                           const float* __restrict__ gh, const float* __restrict__ b_hh,
+                                                           const T* __restrict__ h_prev, T* __restrict__ d_gi,
+                                                           T* __restrict__ d_gh, T* __restrict__ dh_prev, long total, int H) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // over M*H/8
+    if (i >= total) return;
+    const int h8 = H >> 3;
+    const long m = i / h8;
+    const int c = (int)(i - m * h8) * 8;
+    float ir[8], iz[8], in_[8], hr[8], hz[8], hn[8], hp[8], g[8];
+    const float* gim = gi + m * 3 * H + c;
+    load8(gim, ir);
+    load8(gim + H, iz);
+    load8(gim + 2 * H, in_);
+    if (gh) {
+        const float* ghm = gh + m * 3 * H + c;
+        load8(ghm, hr);
+        load8(ghm + H, hz);
+        load8(ghm + 2 * H, hn);
+        load8(h_prev + m * H + c, hp);
+    } else {
+        load8(b_hh + c, hr);
+        load8(b_hh + H + c, hz);
+        load8(b_hh + 2 * H + c, hn);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hp[j] = 0.f;
+    }
+    load8(dh + m * H + c, g);
+    float o_r[8], o_z[8], o_n[8], o_hn[8], o_h[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float r = 1.f / (1.f + expf(-(ir[j] + hr[j])));
+        const float z = 1.f / (1.f + expf(-(iz[j] + hz[j])));
+        const float n = tanhf(in_[j] + r * hn[j]);
+        const float dn = g[j] * (1.f - z), dz = g[j] * (hp[j] - n);
+        const float dnpre = dn * (1.f - n * n);
+        o_n[j] = dnpre;
+        o_hn[j] = dnpre * r;
+        o_r[j] = dnpre * hn[j] * r * (1.f - r);
+        o_z[j] = dz * z * (1.f - z);
+        o_h[j] = g[j] * z;
+    }
+    T* a = d_gi + m * 3 * H + c;
+    store8(a, o_r);
+    store8(a + H, o_z);
+    store8(a + 2 * H, o_n);
+    T* b = d_gh + m * 3 * H + c;
+    store8(b, o_r);
+    store8(b + H, o_z);
+    store8(b + 2 * H, o_hn);
+    if (dh_prev) store8(dh_prev + m * H + c, o_h);
+}
+
+// IMP edge-side backward, one wave per edge e=(s,o).  Inputs: v, e_i (saved), d_e_in[e], d_ctx rows of s and o.
+// Recomputes the four gates, then
+//   d_e[e]    (+)= g_out*d_ctx[s] + g_in*d_ctx[o] + sum_k da_k * w_k[H:]          (accumulated into d_e, which
+//                 already holds the GRU's dh_prev)
+//   da[e,0..3] = d g_k * g_k(1-g_k)   with  d g_sub=<d_e_in,v[s]>, d g_obj=<d_e_in,v[o]>, d g_out=<d_ctx[s],e>, d g_in=<d_ctx[o],e>
+//   gsave[e]   = (g_sub, g_obj) for the node-side reduction of d_v
+template <typename T>
+__global__ __launch_bounds__(256) void edge_ctx_bwd_kernel(const T* __restrict__ v, const T* __restrict__ e,
+                                                           const int64_t* __restrict__ rel, int E, int H,
+                                                           const float* __restrict__ dots, const float* __restrict__ gw,
+                                                           const float* __restrict__ gb, const T* __restrict__ d_e_in,
+                                                           const T* __restrict__ d_ctx, T* __restrict__ d_e,
+                                                           float* __restrict__ da, float* __restrict__ gsave) {
+    const int ed = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (ed >= E) return;
+    const long s = rel[(long)ed * 3 + 1], o = rel[(long)ed * 3 + 2];
+    const int c0 = lane * 8;
+    const bool act = c0 < H;
+    float ee[8], sv[8], ov[8], din[8], dcs[8], dco[8], w[4][8];
+    float p[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    if (act) {
+        load8(e + (long)ed * H + c0, ee);
+        load8(v + s * H + c0, sv);
+        load8(v + o * H + c0, ov);
+        load8(d_e_in + (long)ed * H + c0, din);
+        load8(d_ctx + s * H + c0, dcs);
+        load8(d_ctx + o * H + c0, dco);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            load8(gw + (long)k * 2 * H + H + c0, w[k]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[k] = fmaf(w[k][j], ee[j], p[k]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            q[0] = fmaf(din[j], sv[j], q[0]);
+            q[1] = fmaf(din[j], ov[j], q[1]);
+            q[2] = fmaf(dcs[j], ee[j], q[2]);
+            q[3] = fmaf(dco[j], ee[j], q[3]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        p[k] = wave_sum(p[k]);
+        q[k] = wave_sum(q[k]);
+    }
+    float gk[4], dak[4];
+    gk[0] = sigmoidf_(dots[s * 4 + 0] + p[0] + gb[0]);
+    gk[1] = sigmoidf_(dots[o * 4 + 1] + p[1] + gb[1]);
+    gk[2] = sigmoidf_(dots[s * 4 + 2] + p[2] + gb[2]);
+    gk[3] = sigmoidf_(dots[o * 4 + 3] + p[3] + gb[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dak[k] = q[k] * gk[k] * (1.f - gk[k]);
+    if (act) {
+        float r[8];
+        load8(d_e + (long)ed * H + c0, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            r[j] += gk[2] * dcs[j] + gk[3] * dco[j] + dak[0] * w[0][j] + dak[1] * w[1][j] + dak[2] * w[2][j] + dak[3] * w[3][j];
+        store8(d_e + (long)ed * H + c0, r);
+    }
+    if (lane < 4) da[(long)ed * 4 + lane] = dak[lane];
+    if (lane < 2) gsave[(long)ed * 2 + lane] = gk[lane];
+}
+
+// IMP node-side backward, one workgroup per node n:
+//   d_v[n] (+)= sum_{e in out(n)} g_sub[e]*d_e_in[e] + sum_{e in in(n)} g_obj[e]*d_e_in[e]
+//              + S_sub*w_sub[:H] + S_out*w_out[:H] + S_obj*w_obj[:H] + S_in*w_in[:H]
+//   with S_sub/S_out = sums of da[.,0]/da[.,2] over out(n), S_obj/S_in = sums of da[.,1]/da[.,3] over in(n);
+//   nsum[n,0..3] = (S_sub, S_obj, S_out, S_in) is also written: the gate weights' vertex-half gradient is nsum^T . v.
+template <typename T>
+__global__ __launch_bounds__(256) void node_scatter_bwd_kernel(const T* __restrict__ d_e_in, const float* __restrict__ gsave,
+                                                               const float* __restrict__ da, const int* __restrict__ out_ptr,
+                                                               const int* __restrict__ out_ids, const int* __restrict__ in_ptr,
+                                                               const int* __restrict__ in_ids, const float* __restrict__ gw,
+                                                               int H, T* __restrict__ d_v, float* __restrict__ nsum) {
+    __shared__ float red[4][MAXH];
+    __shared__ float sred[4][4];
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = lane * 8;
+    const bool act = c0 < H;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    float S[4] = {0.f, 0.f, 0.f, 0.f};  // (S_sub, S_obj, S_out, S_in) partials of this wave (lane-uniform)
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const int* ptr = side ? in_ptr : out_ptr;
+        const int* ids = side ? in_ids : out_ids;
+        const int beg = ptr[n], end = ptr[n + 1];
+        for (int k = beg + wave; k < end; k += 4) {
+            const int id = ids[k];
+            const float g = gsave[(long)id * 2 + side];
+            S[side] += da[(long)id * 4 + side];
+            S[2 + side] += da[(long)id * 4 + 2 + side];
+            if (act) {
+                float x[8];
+                load8(d_e_in + (long)id * H + c0, x);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(g, x[j], acc[j]);
+            }
+        }
+    }
+    if (act) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wave][c0 + j] = acc[j];
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sred[wave][k] = S[k];
+    }
+    __syncthreads();
+    float St[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) St[k] = sred[0][k] + sred[1][k] + sred[2][k] + sred[3][k];
+    if (threadIdx.x < 4) nsum[(long)n * 4 + threadIdx.x] = St[threadIdx.x];
+    for (int c = threadIdx.x; c < H; c += 256) {
+        float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        t += St[0] * gw[0 * 2 * H + c] + St[1] * gw[1 * 2 * H + c] + St[2] * gw[2 * 2 * H + c] + St[3] * gw[3 * 2 * H + c];
+        Elem<T>::st(d_v + (long)n * H + c, Elem<T>::ld(d_v + (long)n * H + c) + t);
+    }
+}
+
+// small dense reduction  out[k][h] += sum_r a[r][k] * x[r][h]  for k < 4 (gate-weight gradients):
+// grid (H/64, RSPLIT); a is f32 [R,4], x is T [R,H]
+template <typename T>
+__global__ __launch_bounds__(256) void rank4_reduce_kernel(const float* __restrict__ a, const T* __restrict__ x, int R, int H,
+                                                           float* __restrict__ out, int out_ld, int rows_per_block) {
+    __shared__ float red[4][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < H)
+        for (int r = r0 + w; r < r1; r += 4) {
+            const float xv = Elem<T>::ld(x + (long)r * H + c);
+            const f32x4 av = *reinterpret_cast<const f32x4*>(a + (long)r * 4);
+            s[0] = fmaf(av.x, xv, s[0]);
+            s[1] = fmaf(av.y, xv, s[1]);
+            s[2] = fmaf(av.z, xv, s[2]);
+            s[3] = fmaf(av.w, xv, s[3]);
+        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[k][w][threadIdx.x & 63] = s[k];
+    __syncthreads();
+    if (w == 0 && c < H) {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            atomicAdd(&out[(long)k * out_ld + c], red[k][0][t] + red[k][1][t] + red[k][2][t] + red[k][3][t]);
+    }
+}
+
+// from (sum x, sum x^2): batch mean / biased var -> invstd, the affine (scale, shift) used by bn_apply, and the
+// running-statistics update of nn.BatchNorm2d (momentum m, unbiased variance) -- lib/get_union_boxes.py:54,58
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sums, int C, float count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float momentum, float* __restrict__ run_mean,
+                                                          float* __restrict__ run_var, float* __restrict__ mean,
+                                                          float* __restrict__ invstd, float* __restrict__ scale,
+                                                          float* __restrict__ shift) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float mu = sums[c] / count;
+    const float var = fmaxf(sums[C + c] / count - mu * mu, 0.f);
+    const float is = rsqrtf(var + eps);
+    mean[c] = mu;
+    invstd[c] = is;
+    scale[c] = gamma[c] * is;
+    shift[c] = beta[c] - mu * gamma[c] * is;
+    if (run_mean) {
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (count > 1.f ? count / (count - 1.f) : 1.f);
+    }
+}
+
+template <typename T, bool MAX4>
+void bn_bwd_launch(const void* dy, const unsigned char* arg, const void* x, const float* mean, const float* invstd,
+                   const float* gamma, void* dx, float* sums, int rows, int C, int rpb, dim3 g1, dim3 g2, float inv,
+                   hipStream_t s) {
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MAX4>), g1, dim3(256), 0, s, (const T*)dy, arg, (const T*)x, mean, invstd, sums, rows, C, rpb);
+    hipLaunchKernelGGL((bn_bwd_kernel<T, MAX4>), g2, dim3(256), 0, s, (const T*)dy, arg, (const T*)x, mean, invstd, gamma, sums, (T*)dx, (long)rows, C, inv);
+}
+
+inline int split_rows(int M, int& rows_per_block) {
+    int split = (M + 511) / 512;
+    if (split > 64) split = 64;
+    if (split < 1) split = 1;
+    rows_per_block = (M + split - 1) / split;
+    return split;
+}
+
+}  // namespace
+
+#define DISPATCH2(dtype, BF, F32) \
+    if ((dtype) == SGG_BF16) { BF; } else if ((dtype) == SGG_F32) { F32; } else return SGG_ERR_DTYPE;
+
+extern "C" int sgg_dropout_fwd(void* x, int64_t n, float p, uint64_t seed, int dtype, void* stream) {
+    if (n == 0) return SGG_OK;
+    if (!x || n < 0 || (n & 7) || !(p >= 0.f && p < 1.f)) return SGG_ERR_ARG;
+    const long n8 = n / 8;
+    const dim3 grid((unsigned)((n8 + 255) / 256)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH2(dtype, hipLaunchKernelGGL(dropout_kernel<bf16_t>, grid, blk, 0, s, (bf16_t*)x, n8, p, (unsigned long long)seed),
+              hipLaunchKernelGGL(dropout_kernel<float>, grid, blk, 0, s, (float*)x, n8, p, (unsigned long long)seed));
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_act_bwd(const void* dy, const void* y, void* dx, int64_t n, float scale, int g_dtype, int y_dtype,
+                           void* stream) {
+    if (n == 0) return SGG_OK;
+    if (!dy || !y || !dx || n < 0 || (n & 7)) return SGG_ERR_ARG;
+    const long n8 = n / 8;
+    const dim3 grid((unsigned)((n8 + 255) / 256)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (g_dtype == SGG_BF16 && y_dtype == SGG_BF16)
+        hipLaunchKernelGGL((act_bwd_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, n8, scale);
+    else if (g_dtype == SGG_F32 && y_dtype == SGG_F32)
+        hipLaunchKernelGGL((act_bwd_kernel<float, float>), grid, blk, 0, s, (const float*)dy, (const float*)y, (float*)dx, n8, scale);
+    else if (g_dtype == SGG_F32 && y_dtype == SGG_BF16)
+        hipLaunchKernelGGL((act_bwd_kernel<float, bf16_t>), grid, blk, 0, s, (const float*)dy, (const bf16_t*)y, (float*)dx, n8, scale);
+    else if (g_dtype == SGG_BF16 && y_dtype == SGG_F32)
+        hipLaunchKernelGGL((act_bwd_kernel<bf16_t, float>), grid, blk, 0, s, (const bf16_t*)dy, (const float*)y, (bf16_t*)dx, n8, scale);
+    else
+        return SGG_ERR_DTYPE;
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_colsum(const void* x, int M, int N, int ld, float* out /*zeroed by the callee*/, int dtype, void* stream) {
+    if (!out || N <= 0 || M < 0 || ld < N) return SGG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s) != hipSuccess) return SGG_ERR_LAUNCH;
+    if (M == 0) return SGG_OK;
+    if (!x) return SGG_ERR_ARG;
+    int rpb;
+    const int split = split_rows(M, rpb);
+    const dim3 grid((N + 63) / 64, split), blk(256);
+    DISPATCH2(dtype, hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)x, M, N, ld, out, rpb),
+              hipLaunchKernelGGL(colsum_kernel<float>, grid, blk, 0, s, (const float*)x, M, N, ld, out, rpb));
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+// train-mode BatchNorm statistics of x[M,C]: sums[0][c] = sum x, sums[1][c] = sum x^2 (zeroed by the callee)
+extern "C" int sgg_bn_stats(const void* x, int M, int C, float* sums, int dtype, void* stream) {
+    if (!x || !sums || M <= 0 || C <= 0) return SGG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, sizeof(float) * 2 * (size_t)C, s) != hipSuccess) return SGG_ERR_LAUNCH;
+    int rpb;
+    const int split = split_rows(M, rpb);
+    const dim3 grid((C + 63) / 64, split), blk(256);
+    DISPATCH2(dtype, hipLaunchKernelGGL((colsum2_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (const bf16_t*)x, (const bf16_t*)x, M, C, sums, rpb),
+              hipLaunchKernelGGL((colsum2_kernel<float, float>), grid, blk, 0, s, (const float*)x, (const float*)x, M, C, sums, rpb));
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_bn_finalize(const float* sums, int C, int count, const float* gamma, const float* beta, float eps,
+                               float momentum, float* run_mean, float* run_var, float* mean, float* invstd, float* scale,
+                               float* shift, void* stream) {
+    if (!sums || !gamma || !beta || !mean || !invstd || !scale || !shift || C <= 0 || count <= 0 || (run_mean && !run_var))
+        return SGG_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C, (float)count, gamma,
+                       beta, eps, momentum, run_mean, run_var, mean, invstd, scale, shift);
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+// y = x*scale[c] + shift[c]; max4 != 0: additionally max over 4 consecutive rows, arg-max row index to `arg` (u8)
+extern "C" int sgg_bn_apply(const void* x, const float* scale, const float* shift, void* out, unsigned char* arg, int rows_out,
+                            int C, int max4, int dtype, void* stream) {
+    if (rows_out == 0) return SGG_OK;
+    if (!x || !scale || !shift || !out || rows_out < 0 || C <= 0 || (C & 7)) return SGG_ERR_ARG;
+    const long total = (long)rows_out * (C / 8);
+    const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (max4) {
+        DISPATCH2(dtype, hipLaunchKernelGGL((bn_apply_kernel<bf16_t, true>), grid, blk, 0, s, (const bf16_t*)x, scale, shift, (bf16_t*)out, arg, (long)rows_out, C),
+                  hipLaunchKernelGGL((bn_apply_kernel<float, true>), grid, blk, 0, s, (const float*)x, scale, shift, (float*)out, arg, (long)rows_out, C));
+    } else {
+        DISPATCH2(dtype, hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), grid, blk, 0, s, (const bf16_t*)x, scale, shift, (bf16_t*)out, arg, (long)rows_out, C),
+                  hipLaunchKernelGGL((bn_apply_kernel<float, false>), grid, blk, 0, s, (const float*)x, scale, shift, (float*)out, arg, (long)rows_out, C));
+    }
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+// backward of [ReLU ->] BatchNorm(batch stats) [-> max over 4 rows]: x[rows,C] = post-ReLU input of the BN,
+// dy[rows(/4),C]; outputs dx[rows,C] (gradient at the conv output, ReLU folded) and sums[2][C] = (dbeta, dgamma).
+extern "C" int sgg_bn_bwd(const void* dy, const unsigned char* arg, const void* x, const float* mean, const float* invstd,
+                          const float* gamma, void* dx, float* sums, int rows, int C, int max4, int dtype, void* stream) {
+    if (!dy || !x || !mean || !invstd || !gamma || !dx || !sums || rows <= 0 || C <= 0 || (C & 7) || (max4 && !arg))
+        return SGG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, sizeof(float) * 2 * (size_t)C, s) != hipSuccess) return SGG_ERR_LAUNCH;
+    int rpb;
+    const int split = split_rows(rows, rpb);
+    const dim3 g1((C + 63) / 64, split);
+    const long total = (long)rows * (C / 8);
+    const dim3 g2((unsigned)((total + 255) / 256));
+    const float inv = 1.0f / (float)rows;
+    if (dtype == SGG_BF16) {
+        if (max4) bn_bwd_launch<bf16_t, true>(dy, arg, x, mean, invstd, gamma, dx, sums, rows, C, rpb, g1, g2, inv, s);
+        else bn_bwd_launch<bf16_t, false>(dy, arg, x, mean, invstd, gamma, dx, sums, rows, C, rpb, g1, g2, inv, s);
+    } else if (dtype == SGG_F32) {
+        if (max4) bn_bwd_launch<float, true>(dy, arg, x, mean, invstd, gamma, dx, sums, rows, C, rpb, g1, g2, inv, s);
+        else bn_bwd_launch<float, false>(dy, arg, x, mean, invstd, gamma, dx, sums, rows, C, rpb, g1, g2, inv, s);
+    } else {
+        return SGG_ERR_DTYPE;
+    }
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_gru_gate_bwd(const void* dh, const float* gi, const float* gh, const float* b_hh, const void* h_prev,
+                                void* d_gi, void* d_gh, void* dh_prev, int M, int H, int dtype, void* stream) {
+    if (M == 0) return SGG_OK;
+    if (!dh || !gi || !d_gi || !d_gh || M < 0 || H <= 0 || (H & 7)) return SGG_ERR_ARG;
+    if (gh ? !h_prev : !b_hh) return SGG_ERR_ARG;
+    const long total = (long)M * (H / 8);
+    const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH2(dtype,
+        hipLaunchKernelGGL(gru_gate_bwd_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)dh, gi, gh, b_hh, (const bf16_t*)h_prev, (bf16_t*)d_gi, (bf16_t*)d_gh, (bf16_t*)dh_prev, total, H),
+        hipLaunchKernelGGL(gru_gate_bwd_kernel<float>, grid, blk, 0, s, (const float*)dh, gi, gh, b_hh, (const float*)h_prev, (float*)d_gi, (float*)d_gh, (float*)dh_prev, total, H));
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_imp_edge_ctx_bwd(const void* v, const void* e, const int64_t* rel_inds, int E, int H, const float* node_dots,
+                                    const float* gate_w, const float* gate_b, const void* d_e_in, const void* d_ctx, void* d_e,
+                                    float* da, float* gsave, int dtype, void* stream) {
+    if (E == 0) return SGG_OK;
+    if (!v || !e || !rel_inds || !node_dots || !gate_w || !gate_b || !d_e_in || !d_ctx || !d_e || !da || !gsave || E < 0 ||
+        H <= 0 || (H & 7) || H > MAXH)
+        return SGG_ERR_ARG;
+    const dim3 grid((E + 3) / 4), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH2(dtype,
+        hipLaunchKernelGGL(edge_ctx_bwd_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)v, (const bf16_t*)e, rel_inds, E, H, node_dots, gate_w, gate_b, (const bf16_t*)d_e_in, (const bf16_t*)d_ctx, (bf16_t*)d_e, da, gsave),
+        hipLaunchKernelGGL(edge_ctx_bwd_kernel<float>, grid, blk, 0, s, (const float*)v, (const float*)e, rel_inds, E, H, node_dots, gate_w, gate_b, (const float*)d_e_in, (const float*)d_ctx, (float*)d_e, da, gsave));
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_imp_node_scatter_bwd(const void* d_e_in, const float* gsave, const float* da, const int* out_ptr,
+                                        const int* out_ids, const int* in_ptr, const int* in_ids, const float* gate_w, int N,
+                                        int H, void* d_v, float* nsum, int dtype, void* stream) {
+    if (N == 0) return SGG_OK;
+    if (!d_e_in || !gsave || !da || !out_ptr || !out_ids || !in_ptr || !in_ids || !gate_w || !d_v || !nsum || N < 0 || H <= 0 ||
+        (H & 7) || H > MAXH)
+        return SGG_ERR_ARG;
+    const dim3 grid(N), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH2(dtype,
+        hipLaunchKernelGGL(node_scatter_bwd_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)d_e_in, gsave, da, out_ptr, out_ids, in_ptr, in_ids, gate_w, H, (bf16_t*)d_v, nsum),
+        hipLaunchKernelGGL(node_scatter_bwd_kernel<float>, grid, blk, 0, s, (const float*)d_e_in, gsave, da, out_ptr, out_ids, in_ptr, in_ids, gate_w, H, (float*)d_v, nsum));
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+// out[k, :H] += sum_r a[r,k] * x[r,:]  (k < 4; out row stride out_ld; NOT zeroed: accumulates over IMP iterations)
+extern "C" int sgg_rank4_reduce(const float* a, const void* x, int R, int H, float* out, int out_ld, int dtype, void* stream) {
+    if (R == 0) return SGG_OK;
+    if (!a || !x || !out || R < 0 || H <= 0 || out_ld < H) return SGG_ERR_ARG;
+    int rpb;
+    const int split = split_rows(R, rpb);
+    const dim3 grid((H + 63) / 64, split), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH2(dtype, hipLaunchKernelGGL(rank4_reduce_kernel<bf16_t>, grid, blk, 0, s, a, (const bf16_t*)x, R, H, out, out_ld, rpb),
+              hipLaunchKernelGGL(rank4_reduce_kernel<float>, grid, blk, 0, s, a, (const float*)x, R, H, out, out_ld, rpb));
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}

@@ -33,6 +33,55 @@ __global__ __launch_bounds__(256) void permute_kernel(const TI* __restrict__ in,
     }
 }
 
+// out[c][r] = in[r][c] for r < R, c < C (row strides ld_in / ld_out); 32x32 tiles through LDS
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ in, long ld_in, TO* __restrict__ out, long ld_out,
+                                                        int R, int C) {
+    __shared__ float t[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        t[k][tx] = (r < R && c < C) ? Elem<TI>::ld(in + (long)r * ld_in + c) : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (c < C && r < R) Elem<TO>::st(out + (long)c * ld_out + r, t[tx][k]);
+    }
+}
+
+template <typename T, typename TX>
+__global__ __launch_bounds__(256) void add_kernel(T* __restrict__ y, const TX* __restrict__ x, long n8) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    float a[8], b[8];
+    load8(y + i * 8, a);
+    load8(x + i * 8, b);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] += b[k];
+    store8(y + i * 8, a);
+}
+
+// out[n][c][p] = in[n][p][c] + add[n][c]  (fp32; un-does the fc6 K re-order on the gradient and adds the folded
+// rect-conv term: d W6[n,c,p] = G[n,(p,c)] + Gsum[n,c])
+__global__ __launch_bounds__(256) void unpermute_add_kernel(const float* __restrict__ in, long ld_in, const float* __restrict__ add,
+                                                            long ld_add, float* __restrict__ out, int C, int Pp) {
+    __shared__ float t[32][33];
+    const long n = blockIdx.z;
+    const int p0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {   // read in[n][p][c]: c fastest
+        const int p = p0 + k, c = c0 + tx;
+        t[k][tx] = (p < Pp && c < C) ? in[n * ld_in + (long)p * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {   // write out[n][c][p]: p fastest
+        const int c = c0 + k, p = p0 + tx;
+        if (c < C && p < Pp) out[(n * C + c) * Pp + p] = t[tx][k] + (add ? add[n * ld_add + c] : 0.f);
+    }
+}
+
 }  // namespace
 
 extern "C" int sgg_abi_version(void) { return SGG_ABI_VERSION; }
@@ -74,6 +123,56 @@ extern "C" int sgg_permute_ncp_to_npc(const void* in, void* out, int Nn, int C, 
         hipLaunchKernelGGL((permute_kernel<bf16_t, float>), grid, blk, 0, s, (const bf16_t*)in, (float*)out, C, Pp);
     else
         return SGG_ERR_DTYPE;
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int R, int C, int in_dtype, int out_dtype,
+                             void* stream) {
+    if (R == 0 || C == 0) return SGG_OK;
+    if (!in || !out || R < 0 || C < 0 || ld_in < C || ld_out < R) return SGG_ERR_ARG;
+    const dim3 grid((C + 31) / 32, (R + 31) / 32), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (in_dtype == SGG_BF16 && out_dtype == SGG_BF16)
+        hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (const bf16_t*)in, (long)ld_in, (bf16_t*)out, (long)ld_out, R, C);
+    else if (in_dtype == SGG_F32 && out_dtype == SGG_F32)
+        hipLaunchKernelGGL((transpose_kernel<float, float>), grid, blk, 0, s, (const float*)in, (long)ld_in, (float*)out, (long)ld_out, R, C);
+    else if (in_dtype == SGG_F32 && out_dtype == SGG_BF16)
+        hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, blk, 0, s, (const float*)in, (long)ld_in, (bf16_t*)out, (long)ld_out, R, C);
+    else if (in_dtype == SGG_BF16 && out_dtype == SGG_F32)
+        hipLaunchKernelGGL((transpose_kernel<bf16_t, float>), grid, blk, 0, s, (const bf16_t*)in, (long)ld_in, (float*)out, (long)ld_out, R, C);
+    else
+        return SGG_ERR_DTYPE;
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_add(void* y, const void* x, int64_t n, int y_dtype, int x_dtype, void* stream) {
+    if (n == 0) return SGG_OK;
+    if (!y || !x || n < 0 || (n & 7)) return SGG_ERR_ARG;
+    const long n8 = n / 8;
+    const dim3 grid((unsigned)((n8 + 255) / 256)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (y_dtype == SGG_BF16 && x_dtype == SGG_BF16)
+        hipLaunchKernelGGL((add_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (bf16_t*)y, (const bf16_t*)x, n8);
+    else if (y_dtype == SGG_F32 && x_dtype == SGG_F32)
+        hipLaunchKernelGGL((add_kernel<float, float>), grid, blk, 0, s, (float*)y, (const float*)x, n8);
+    else if (y_dtype == SGG_BF16 && x_dtype == SGG_F32)
+        hipLaunchKernelGGL((add_kernel<bf16_t, float>), grid, blk, 0, s, (bf16_t*)y, (const float*)x, n8);
+    else if (y_dtype == SGG_F32 && x_dtype == SGG_BF16)
+        hipLaunchKernelGGL((add_kernel<float, bf16_t>), grid, blk, 0, s, (float*)y, (const bf16_t*)x, n8);
+    else
+        return SGG_ERR_DTYPE;
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_unpermute_add(const float* in, int64_t ld_in, const float* add, int64_t ld_add, float* out, int Nn, int C,
+                                 int Pp, void* stream) {
+    if (Nn == 0) return SGG_OK;
+    if (!in || !out || Nn < 0 || Nn > 65535 || C <= 0 || Pp <= 0 || ld_in < (int64_t)C * Pp || (add && ld_add < C)) return SGG_ERR_ARG;
+    const dim3 grid((C + 31) / 32, (Pp + 31) / 32, Nn), blk(256);
+    hipLaunchKernelGGL(unpermute_add_kernel, grid, blk, 0, (hipStream_t)stream, in, (long)ld_in, add, (long)ld_add, out, C, Pp);
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

@@ -22,12 +22,12 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _p(t, dtype=None):
+def _p(t, dtype=None, rows_ok=False):
     if t is None:
         return None
     if not t.is_cuda:
         raise RuntimeError('sgg_amd: tensor is not on the GPU (the HIP path has no CPU fallback)')
-    if not t.is_contiguous():
+    if not t.is_contiguous() and not (rows_ok and t.dim() == 2 and t.stride(1) == 1):
         raise ValueError('sgg_amd: tensor must be contiguous')
     if dtype is not None and t.dtype != dtype:
         raise TypeError('sgg_amd: expected %s, got %s' % (dtype, t.dtype))
@@ -165,7 +165,7 @@ def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None
               A2.shape[1] if A2 is not None else 0, K1, _p(W), K, _p(bias, torch.float32) if bias is not None else None,
               _p(post_scale, torch.float32) if post_scale is not None else None,
               _p(post_shift, torch.float32) if post_shift is not None else None,
-              _p(out), out.stride(0), M, N, K, act, dt(A), dt(out), _stream())
+              _p(out, rows_ok=True), out.stride(0), M, N, K, act, dt(A), dt(out), _stream())
     return out
 
 
@@ -198,10 +198,11 @@ def imp_node_scatter(e, gates, csr, N, ctx=None):
     return ctx
 
 
-def gru_gate(gi, gh, b_hh, h_prev, out_dtype):
+def gru_gate(gi, gh, b_hh, h_prev, out_dtype, out=None):
     M, H3 = gi.shape
     H = H3 // 3
-    out = torch.empty((M, H), dtype=out_dtype, device=gi.device)
+    if out is None:
+        out = torch.empty((M, H), dtype=out_dtype, device=gi.device)
     _lib.call('sgg_gru_gate_fwd', _p(gi), _p(gh) if gh is not None else None,
               _p(b_hh, torch.float32) if b_hh is not None else None, _p(h_prev) if h_prev is not None else None, _p(out),
               M, H, dt(gi), dt(out), _stream())
@@ -244,4 +245,113 @@ def permute_ncp_to_npc(x, dtype=None):
             e = min(Nn, s + 32768)
             _lib.call('sgg_permute_ncp_to_npc', x[s:e].data_ptr(), out[s:e].data_ptr(), e - s, C, Pp, dt(x), dt(out),
                       _stream())
+    return out
+
+
+# ---------------------------------------------------------------- training side
+def dropout_(x, p, seed):
+    _lib.call('sgg_dropout_fwd', _p(x), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, dt(x), _stream())
+    return x
+
+
+def act_bwd(dy, y, scale=1.0):
+    dx = torch.empty_like(dy)
+    _lib.call('sgg_act_bwd', _p(dy), _p(y), _p(dx), dy.numel(), float(scale), dt(dy), dt(y), _stream())
+    return dx
+
+
+def colsum(x):
+    M, N = x.shape
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    _lib.call('sgg_colsum', _p(x, rows_ok=True), M, N, x.stride(0), _p(out), dt(x), _stream())
+    return out
+
+
+def bn_train(x, gamma, beta, run_mean, run_var, eps, momentum, max4):
+    """train-mode BatchNorm over the rows of x[M,C] (+ optional max over 4 consecutive rows).
+    -> (y, arg or None, mean, invstd)"""
+    M, C = x.shape
+    dev = x.device
+    sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
+    _lib.call('sgg_bn_stats', _p(x), M, C, _p(sums), dt(x), _stream())
+    mean, invstd, sc, sh = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
+    _lib.call('sgg_bn_finalize', _p(sums), C, M, _p(gamma, torch.float32), _p(beta, torch.float32), float(eps),
+              float(momentum), _p(run_mean, torch.float32), _p(run_var, torch.float32), _p(mean), _p(invstd), _p(sc),
+              _p(sh), _stream())
+    rows_out = M // 4 if max4 else M
+    y = torch.empty((rows_out, C), dtype=x.dtype, device=dev)
+    arg = torch.empty((rows_out, C), dtype=torch.uint8, device=dev) if max4 else None
+    _lib.call('sgg_bn_apply', _p(x), _p(sc), _p(sh), _p(y), _p(arg) if max4 else None, rows_out, C, int(max4), dt(x),
+              _stream())
+    return y, arg, mean, invstd
+
+
+def bn_bwd(dy, arg, x, mean, invstd, gamma, max4):
+    """-> (dx [rows,C] at the conv output (ReLU folded), dbeta [C], dgamma [C])"""
+    rows, C = x.shape
+    dx = torch.empty_like(x)
+    sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    _lib.call('sgg_bn_bwd', _p(dy), _p(arg) if max4 else None, _p(x), _p(mean), _p(invstd), _p(gamma, torch.float32),
+              _p(dx), _p(sums), rows, C, int(max4), dt(x), _stream())
+    return dx, sums[:C], sums[C:]
+
+
+def gru_gate_bwd(dh, gi, gh, b_hh, h_prev, d_gi, d_gh, want_dh_prev=True):
+    M, H = dh.shape
+    dh_prev = torch.empty_like(dh) if want_dh_prev else None
+    _lib.call('sgg_gru_gate_bwd', _p(dh), _p(gi, torch.float32), _p(gh, torch.float32) if gh is not None else None,
+              _p(b_hh, torch.float32) if b_hh is not None else None, _p(h_prev) if h_prev is not None else None,
+              _p(d_gi), _p(d_gh), _p(dh_prev) if want_dh_prev else None, M, H, dt(dh), _stream())
+    return dh_prev
+
+
+def imp_edge_ctx_bwd(v, e, rel_inds, dots, gate_w, gate_b, d_e_in, d_ctx, d_e):
+    E, H = e.shape
+    da = torch.empty((E, 4), dtype=torch.float32, device=e.device)
+    gsave = torch.empty((E, 2), dtype=torch.float32, device=e.device)
+    _lib.call('sgg_imp_edge_ctx_bwd', _p(v), _p(e), _p(rel_inds, torch.int64), E, H, _p(dots, torch.float32),
+              _p(gate_w, torch.float32), _p(gate_b, torch.float32), _p(d_e_in), _p(d_ctx), _p(d_e), _p(da), _p(gsave),
+              dt(e), _stream())
+    return da, gsave
+
+
+def imp_node_scatter_bwd(d_e_in, gsave, da, csr, gate_w, d_v):
+    N, H = d_v.shape
+    out_ptr, out_ids, in_ptr, in_ids = csr
+    nsum = torch.empty((N, 4), dtype=torch.float32, device=d_v.device)
+    _lib.call('sgg_imp_node_scatter_bwd', _p(d_e_in), _p(gsave), _p(da), _p(out_ptr), _p(out_ids), _p(in_ptr), _p(in_ids),
+              _p(gate_w, torch.float32), N, H, _p(d_v), _p(nsum), dt(d_v), _stream())
+    return nsum
+
+
+def rank4_reduce_(a, x, out, col0=0):
+    """out[k, col0:col0+H] += sum_r a[r,k] * x[r,:]   (out f32 [4, ld])"""
+    R, H = x.shape
+    _lib.call('sgg_rank4_reduce', _p(a, torch.float32), _p(x), R, H, out.data_ptr() + 4 * col0, out.stride(0), dt(x),
+              _stream())
+
+
+def transpose(x, pad_to=64, dtype=None):
+    """x [R,C] (row-strided ok) -> [C, Rp] with Rp = R rounded up to `pad_to`, zero padded."""
+    R, C = x.shape
+    Rp = (R + pad_to - 1) // pad_to * pad_to
+    dtype = dtype or x.dtype
+    out = (torch.zeros if Rp != R else torch.empty)((C, Rp), dtype=dtype, device=x.device)
+    _lib.call('sgg_transpose', _p(x, rows_ok=True), x.stride(0), _p(out), Rp, R, C, dt(x), dt(out), _stream())
+    return out
+
+
+def add_(y, x):
+    _lib.call('sgg_add', _p(y), _p(x), y.numel(), dt(y), dt(x), _stream())
+    return y
+
+
+def unpermute_add(g, C, Pp, add=None):
+    """g f32 [N, >= Pp*C] (row-strided) in (p,c) K order -> [N, C*Pp] in (c,p) order, + add[N,C] broadcast over p."""
+    Nn = g.shape[0]
+    out = torch.empty((Nn, C * Pp), dtype=torch.float32, device=g.device)
+    for s in range(0, Nn, 32768):
+        e = min(Nn, s + 32768)
+        _lib.call('sgg_unpermute_add', g[s:e].data_ptr(), g.stride(0), add[s:e].data_ptr() if add is not None else None,
+                  add.stride(0) if add is not None else 0, out[s:e].data_ptr(), e - s, C, Pp, _stream())
     return out

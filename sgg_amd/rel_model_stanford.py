@@ -21,6 +21,7 @@ class RelModelStanford(RelModelBase):
         self.edge_gru = nn.GRUCell(input_size=hidden_dim, hidden_size=hidden_dim)
         self.node_gru = nn.GRUCell(input_size=hidden_dim, hidden_size=hidden_dim)
         self.mp_iter = mp_iter
+        self.dropout_p = 0.5   # nn.Dropout() of the VGG classifier copies (rel_model_base.py:110-111)
         for g in GATES:
             setattr(self, g, nn.Sequential(nn.Linear(hidden_dim * 2, 1), nn.Sigmoid()))
 
@@ -71,16 +72,16 @@ class RelModelStanford(RelModelBase):
     def predict(self, node_feat, edge_feat, rel_inds, rois, im_sizes, _im_inds=None):
         """rel_model_stanford.py:97-107.  node_feat [N,C,7,7], edge_feat [E,C,7,7] (raw RoIAlign), rel_inds i64[E,3]
         -> (obj_dists f32[N,151], rel_dists f32[E,51])."""
-        if self.training and (torch.is_grad_enabled()):
-            # Dropout / train-mode BatchNorm / autograd of the trainable head are the next step (DESIGN.md); fail loudly.
-            raise NotImplementedError('training forward/backward of the relation head is not on the HIP path yet; '
-                                      'call under model.eval()')
-        w = self.prepared()
         dtype = self.compute_dtype
         N, E = node_feat.shape[0], edge_feat.shape[0]
         rel_inds = rel_inds.contiguous()
         nf = to_nhwc(node_feat.view(N, -1, self.pool_sz, self.pool_sz), dtype).view(N, -1)
         ef = to_nhwc(edge_feat.view(E, -1, self.pool_sz, self.pool_sz), dtype).view(E, -1)
+        if self.training:
+            # Dropout, batch-statistic BatchNorm and the autograd node of the whole head (sgg_amd/train.py)
+            from .train import predict_train
+            return predict_train(self, nf, ef, rel_inds, rois, _im_inds, dropout_p=self.dropout_p)
+        w = self.prepared()
         # :100  union_boxes(edge_feat, rois, rel_inds[:,1:]) -- conv(rects)[E,512]; the broadcast add rides in fc6's K
         rect = self.union_boxes.rect_feat(rois, rel_inds[:, 1:].contiguous(), dtype)
         # :103  obj_unary(roi_fmap_obj(node_feat))

@@ -1,0 +1,286 @@
+"""Training-mode forward and backward of the trainable relation head on the HIP path.
+
+Covers everything `RelModelStanford.predict` does in `model.train()` (sgg_models/rel_model_stanford.py:97-107 with the
+classifier Dropouts of rel_model_base.py:110-111 and the batch-statistic BatchNorms of lib/get_union_boxes.py:54,58)
+and its gradient w.r.t. every trainable parameter.  RoI features are leaves (the detector is frozen and `fmap` is
+detached, rel_model_stanford.py:131), so no gradient flows into RoIAlign.  The whole head is ONE autograd node
+(`PredictFn`): the reference's losses (lib/losses.py) and optimiser (lib/pytorch_misc.py:130-157) run on top of it
+unchanged.
+
+Dense gradient contractions reuse the MFMA GEMM:  dX = dY . W  is  gemm(dY, W^T)  with W^T prepared per step,
+dW = dY^T . X  is  gemm(dY^T, X^T)  on transposed copies.  GRU weights are shared by the 4 calls of each cell; their
+gradients are single GEMMs over the row-stacked calls (no accumulation passes).
+"""
+import torch
+
+from . import _lib, ops
+from .imp import GATES
+
+DROPOUT_P = 0.5  # nn.Dropout() default in torchvision's VGG classifier
+
+
+def param_names(model):
+    names = ['roi_fmap.1.0.weight', 'roi_fmap.1.0.bias', 'roi_fmap.1.3.weight', 'roi_fmap.1.3.bias',
+             'roi_fmap_obj.0.weight', 'roi_fmap_obj.0.bias', 'roi_fmap_obj.3.weight', 'roi_fmap_obj.3.bias',
+             'union_boxes.conv.0.weight', 'union_boxes.conv.0.bias', 'union_boxes.conv.2.weight',
+             'union_boxes.conv.2.bias', 'union_boxes.conv.4.weight', 'union_boxes.conv.4.bias',
+             'union_boxes.conv.6.weight', 'union_boxes.conv.6.bias', 'rel_fc.weight', 'rel_fc.bias', 'obj_fc.weight',
+             'obj_fc.bias', 'obj_unary.weight', 'obj_unary.bias', 'edge_unary.weight', 'edge_unary.bias']
+    for g in ('edge_gru', 'node_gru'):
+        names += [g + '.weight_ih', g + '.weight_hh', g + '.bias_ih', g + '.bias_hh']
+    for g in GATES:
+        names += [g + '.0.weight', g + '.0.bias']
+    return names
+
+
+def _pad_cols(x, mult, dtype):
+    M, N = x.shape
+    Np = (N + mult - 1) // mult * mult
+    if Np == N and x.dtype == dtype and x.is_contiguous():
+        return x
+    buf = torch.zeros((M, Np), dtype=dtype, device=x.device)
+    buf[:, :N].copy_(x)     # cast + pad copy (data movement only)
+    return buf
+
+
+def tn_gemm(X, Y, out=None):
+    """X[M,a]^T . Y[M,b] -> f32 [a,b]  (weight gradients).  Rows are zero-padded to a multiple of 64 by the transposes."""
+    return ops.gemm(ops.transpose(X), ops.transpose(Y), out_dtype=torch.float32, out=out)
+
+
+def train_weights(model):
+    """Forward operands (model.prepared()) + the transposed copies the backward needs, cached on the same key."""
+    w = model.prepared()
+    if 'train' in w:
+        return w
+    dt = model.compute_dtype
+    t = {}
+    for name in ('fc7_obj', 'obj_unary', 'fc7_edge', 'edge_unary', 'obj_fc', 'rel_fc'):
+        t[name + '_t'] = ops.transpose(w[name])                         # [K, Np]
+    C = model.edge_dim
+    t['w6sum_t'] = ops.transpose(w['fc6_edge'][:, w['fc6_edge_raw_k']:])   # [C, 4096]
+    imp = w['imp']
+    for g in ('edge_gru', 'node_gru'):
+        t[g + '_w_ih_t'] = ops.transpose(getattr(imp, g + '_w_ih'))     # [H, 3H]
+        t[g + '_w_hh_t'] = ops.transpose(getattr(imp, g + '_w_hh'))
+    ub = model.union_boxes
+    f = lambda p: p.detach().float().contiguous()
+    d2, d = ub.conv[0].weight.shape[0], ub.conv[4].weight.shape[0]
+    if d2 % 64:
+        raise NotImplementedError('training needs union_boxes dim/2 to be a multiple of 64')
+    w1 = torch.zeros((d2, 128), dtype=torch.float32, device=ub.conv[0].weight.device)
+    w1[:, :98] = f(ub.conv[0].weight).reshape(d2, 98)
+    t['rc_w1'] = w1.to(dt)
+    t['rc_b1'] = f(ub.conv[0].bias)
+    t['rc_w2'] = f(ub.conv[4].weight)[:, :, 1, 1].contiguous().to(dt)     # centre tap (the only one that sees data)
+    t['rc_b2'] = f(ub.conv[4].bias)
+    t['rc_w2_t'] = ops.transpose(t['rc_w2'])                               # [d2, d]
+    t['rc_g1'], t['rc_be1'] = f(ub.conv[2].weight), f(ub.conv[2].bias)
+    t['rc_g2'], t['rc_be2'] = f(ub.conv[6].weight), f(ub.conv[6].bias)
+    t['ones'] = None
+    w['train'] = t
+    return w
+
+
+def _gru_fwd(x, h, w_ih, w_hh, b_ih, b_hh, dtype, out):
+    gi = ops.gemm(x, w_ih, b_ih, out_dtype=torch.float32)
+    gh = ops.gemm(h, w_hh, b_hh, out_dtype=torch.float32) if h is not None else None
+    ops.gru_gate(gi, gh, b_hh if h is None else None, h, dtype, out=out)
+    return gi, gh
+
+
+class PredictFn(torch.autograd.Function):
+    """(obj_dists, rel_dists) = predict(node_feat, edge_feat, ...) in training mode; gradients for all head parameters."""
+
+    @staticmethod
+    def forward(ctx, model, nf, ef, rois, rel_inds, im_inds, seed, dropout_p, *params):
+        w = train_weights(model)
+        t, imp, dt = w['train'], w['imp'], model.compute_dtype
+        N, E, H = nf.shape[0], ef.shape[0], model.hidden_dim
+        ub = model.union_boxes
+        dev = nf.device
+        sv = {}
+        # ---- rect conv, batch-statistics BatchNorm (lib/get_union_boxes.py:51-59)
+        pairs = rel_inds[:, 1:].contiguous()
+        patches = ops.union_rect_patches(rois, pairs, dt, ub.pooling_size * 4 - 1, 128)           # [4E,128]
+        h1 = ops.gemm(patches, t['rc_w1'], t['rc_b1'], ops.ACT_RELU)                               # [4E,d2]
+        bn1, bn2 = ub.conv[2], ub.conv[6]
+        h2, arg, m1, is1 = ops.bn_train(h1, t['rc_g1'], t['rc_be1'], bn1.running_mean, bn1.running_var, bn1.eps,
+                                        bn1.momentum, True)                                        # [E,d2]
+        h3 = ops.gemm(h2, t['rc_w2'], t['rc_b2'], ops.ACT_RELU)                                    # [E,d]
+        rect, _, m2, is2 = ops.bn_train(h3, t['rc_g2'], t['rc_be2'], bn2.running_mean, bn2.running_var, bn2.eps,
+                                        bn2.momentum, False)
+        with torch.no_grad():
+            bn1.num_batches_tracked += 1
+            bn2.num_batches_tracked += 1
+        sv.update(patches=patches, h1=h1, h2=h2, arg=arg, m1=m1, is1=is1, h3=h3, m2=m2, is2=is2, rect=rect)
+        # ---- nodes: obj_unary(roi_fmap_obj(node_feat))  (Linear ReLU Dropout Linear ReLU Dropout)
+        x6 = ops.gemm(nf, w['fc6_obj'], w['fc6_obj_b'], ops.ACT_RELU)
+        if dropout_p > 0:
+            ops.dropout_(x6, dropout_p, seed * 4 + 1)
+        x7 = ops.gemm(x6, w['fc7_obj'], w['fc7_obj_b'], ops.ACT_RELU)
+        if dropout_p > 0:
+            ops.dropout_(x7, dropout_p, seed * 4 + 2)
+        # row-stacked inputs / states of the 4 calls of each GRU cell
+        XN = torch.empty((4 * N, H), dtype=dt, device=dev)
+        XE = torch.empty((4 * E, H), dtype=dt, device=dev)
+        HN = torch.empty((4 * N, H), dtype=dt, device=dev)     # block c = vert_c (hidden state entering call c+1)
+        HE = torch.empty((4 * E, H), dtype=dt, device=dev)
+        ops.gemm(x7, w['obj_unary'], w['obj_unary_b'], out=XN[:N])
+        # ---- edges: relu(edge_unary(roi_fmap(edge_feat + conv(rects))))  (Linear ReLU Dropout Linear)
+        y6 = ops.gemm(ef, w['fc6_edge'], w['fc6_edge_b'], ops.ACT_RELU, A2=rect)
+        if dropout_p > 0:
+            ops.dropout_(y6, dropout_p, seed * 4 + 3)
+        y7 = ops.gemm(y6, w['fc7_edge'], w['fc7_edge_b'])
+        ops.gemm(y7, w['edge_unary'], w['edge_unary_b'], ops.ACT_RELU, out=XE[:E])
+        sv.update(x6=x6, x7=x7, y6=y6, y7=y7)
+        # ---- message passing (rel_model_stanford.py:68-94)
+        csr = ops.edge_csr(rel_inds, N, im_inds)
+        gin, ghn, gie, ghe, dots_l, gates_l = [], [], [], [], [], []
+        a, b = _gru_fwd(XN[:N], None, imp.node_gru_w_ih, imp.node_gru_w_hh, imp.node_gru_b_ih, imp.node_gru_b_hh, dt, HN[:N])
+        gin.append(a); ghn.append(b)
+        a, b = _gru_fwd(XE[:E], None, imp.edge_gru_w_ih, imp.edge_gru_w_hh, imp.edge_gru_b_ih, imp.edge_gru_b_hh, dt, HE[:E])
+        gie.append(a); ghe.append(b)
+        for i in range(model.mp_iter):
+            v_i, e_i = HN[i * N:(i + 1) * N], HE[i * E:(i + 1) * E]
+            dots = ops.imp_node_gate_dots(v_i, imp.gate_w)
+            _, gates = ops.imp_edge_ctx(v_i, e_i, rel_inds, dots, imp.gate_w, imp.gate_b, e_in=XE[(i + 1) * E:(i + 2) * E])
+            ops.imp_node_scatter(e_i, gates, csr, N, ctx=XN[(i + 1) * N:(i + 2) * N])
+            a, b = _gru_fwd(XE[(i + 1) * E:(i + 2) * E], e_i, imp.edge_gru_w_ih, imp.edge_gru_w_hh, imp.edge_gru_b_ih,
+                            imp.edge_gru_b_hh, dt, HE[(i + 1) * E:(i + 2) * E])
+            gie.append(a); ghe.append(b)
+            a, b = _gru_fwd(XN[(i + 1) * N:(i + 2) * N], v_i, imp.node_gru_w_ih, imp.node_gru_w_hh, imp.node_gru_b_ih,
+                            imp.node_gru_b_hh, dt, HN[(i + 1) * N:(i + 2) * N])
+            gin.append(a); ghn.append(b)
+            dots_l.append(dots)
+        T = model.mp_iter
+        vT, eT = HN[T * N:(T + 1) * N], HE[T * E:(T + 1) * E]
+        obj = ops.gemm(vT, w['obj_fc'], w['obj_fc_b'], out_dtype=torch.float32)
+        rel = ops.gemm(eT, w['rel_fc'], w['rel_fc_b'], out_dtype=torch.float32)
+        sv.update(XN=XN, XE=XE, HN=HN, HE=HE, gin=gin, ghn=ghn, gie=gie, ghe=ghe, dots=dots_l, csr=csr, nf=nf, ef=ef,
+                  rel_inds=rel_inds, N=N, E=E, H=H, dropout_p=dropout_p)
+        ctx.model, ctx.sv = model, sv
+        return obj, rel
+
+    @staticmethod
+    def backward(ctx, d_obj, d_rel):
+        model, sv = ctx.model, ctx.sv
+        w = train_weights(model)
+        t, imp, dt = w['train'], w['imp'], model.compute_dtype
+        N, E, H, T = sv['N'], sv['E'], sv['H'], model.mp_iter
+        XN, XE, HN, HE = sv['XN'], sv['XE'], sv['HN'], sv['HE']
+        dev = XN.device
+        G = {}
+        rows = lambda buf, c, n: buf[c * n:(c + 1) * n]
+
+        def lin_bwd(dY, X, Wt, name, want_dx=True):
+            """Y = X W^T + b : returns dX; stores dW (f32 [N,K]) and db."""
+            G[name + '.weight'] = tn_gemm(dY, X)
+            G[name + '.bias'] = ops.colsum(dY)
+            return ops.gemm(_pad_cols(dY, 64, dt), Wt) if want_dx else None
+
+        d_obj = d_obj.contiguous().to(dt) if d_obj.dtype != dt else d_obj.contiguous()
+        d_rel = d_rel.contiguous().to(dt) if d_rel.dtype != dt else d_rel.contiguous()
+        d_v = lin_bwd(d_obj, rows(HN, T, N), t['obj_fc_t'], 'obj_fc')
+        d_e = lin_bwd(d_rel, rows(HE, T, E), t['rel_fc_t'], 'rel_fc')
+        # ---- IMP backward (rel_model_stanford.py:74-92 in reverse)
+        dGIn = torch.empty((4 * N, 3 * H), dtype=dt, device=dev)
+        dGHn = torch.empty((4 * N, 3 * H), dtype=dt, device=dev)
+        dGIe = torch.empty((4 * E, 3 * H), dtype=dt, device=dev)
+        dGHe = torch.empty((4 * E, 3 * H), dtype=dt, device=dev)
+        d_gw = torch.zeros((4, 2 * H), dtype=torch.float32, device=dev)
+        d_gb = torch.zeros((4, 1), dtype=torch.float32, device=dev)
+        ones = torch.ones((E, 1), dtype=dt, device=dev)
+        for i in range(T - 1, -1, -1):
+            v_i, e_i = rows(HN, i, N), rows(HE, i, E)
+            # v_{i+1} = GRU_n(ctx_i, v_i)
+            d_v_prev = ops.gru_gate_bwd(d_v, sv['gin'][i + 1], sv['ghn'][i + 1], None, v_i, rows(dGIn, i + 1, N),
+                                        rows(dGHn, i + 1, N))
+            d_ctx = ops.gemm(rows(dGIn, i + 1, N), t['node_gru_w_ih_t'])
+            ops.add_(d_v_prev, ops.gemm(rows(dGHn, i + 1, N), t['node_gru_w_hh_t']))
+            # e_{i+1} = GRU_e(e_in_i, e_i)
+            d_e_prev = ops.gru_gate_bwd(d_e, sv['gie'][i + 1], sv['ghe'][i + 1], None, e_i, rows(dGIe, i + 1, E),
+                                        rows(dGHe, i + 1, E))
+            d_e_in = ops.gemm(rows(dGIe, i + 1, E), t['edge_gru_w_ih_t'])
+            ops.add_(d_e_prev, ops.gemm(rows(dGHe, i + 1, E), t['edge_gru_w_hh_t']))
+            # gather / gate / scatter
+            da, gsave = ops.imp_edge_ctx_bwd(v_i, e_i, sv['rel_inds'], sv['dots'][i], imp.gate_w, imp.gate_b, d_e_in, d_ctx,
+                                             d_e_prev)
+            nsum = ops.imp_node_scatter_bwd(d_e_in, gsave, da, sv['csr'], imp.gate_w, d_v_prev)
+            ops.rank4_reduce_(da, e_i, d_gw, col0=H)
+            ops.rank4_reduce_(nsum, v_i, d_gw, col0=0)
+            ops.rank4_reduce_(da, ones, d_gb)
+            d_v, d_e = d_v_prev, d_e_prev
+        # first calls (h = 0): gh = b_hh only
+        ops.gru_gate_bwd(d_v, sv['gin'][0], None, imp.node_gru_b_hh, None, rows(dGIn, 0, N), rows(dGHn, 0, N), False)
+        d_obj_rep = ops.gemm(rows(dGIn, 0, N), t['node_gru_w_ih_t'])
+        ops.gru_gate_bwd(d_e, sv['gie'][0], None, imp.edge_gru_b_hh, None, rows(dGIe, 0, E), rows(dGHe, 0, E), False)
+        d_rel_rep = ops.gemm(rows(dGIe, 0, E), t['edge_gru_w_ih_t'])
+        # GRU parameter gradients: one contraction over the 4 stacked calls; hidden state of call 0 is zero
+        HprevN = torch.cat((torch.zeros_like(HN[:N]), HN[:3 * N]), 0) if T == 3 else None
+        HprevE = torch.cat((torch.zeros_like(HE[:E]), HE[:3 * E]), 0) if T == 3 else None
+        if HprevN is None:
+            raise NotImplementedError('training is wired for mp_iter == 3')
+        G['node_gru.weight_ih'] = tn_gemm(dGIn, XN)
+        G['node_gru.weight_hh'] = tn_gemm(dGHn, HprevN)
+        G['node_gru.bias_ih'], G['node_gru.bias_hh'] = ops.colsum(dGIn), ops.colsum(dGHn)
+        G['edge_gru.weight_ih'] = tn_gemm(dGIe, XE)
+        G['edge_gru.weight_hh'] = tn_gemm(dGHe, HprevE)
+        G['edge_gru.bias_ih'], G['edge_gru.bias_hh'] = ops.colsum(dGIe), ops.colsum(dGHe)
+        for k, g in enumerate(GATES):
+            G[g + '.0.weight'] = d_gw[k:k + 1].clone()
+            G[g + '.0.bias'] = d_gb[k].clone()
+        # ---- edge MLP backward
+        p = sv['dropout_p']
+        ds = 1.0 / (1.0 - p) if p > 0 else 1.0
+        d_u = ops.act_bwd(d_rel_rep, rows(XE, 0, E))                               # relu(edge_unary)
+        d_y7 = lin_bwd(d_u, sv['y7'], t['edge_unary_t'], 'edge_unary')
+        d_y6 = lin_bwd(d_y7, sv['y6'], t['fc7_edge_t'], 'roi_fmap.1.3')
+        d_pre6 = ops.act_bwd(d_y6, sv['y6'], ds)                                   # dropout + relu
+        C, PP = model.edge_dim, model.pool_sz ** 2
+        K1 = C * PP
+        d6t = ops.transpose(d_pre6)                                                # [4096, Ep]
+        g6 = torch.empty((d_pre6.shape[1], K1 + C), dtype=torch.float32, device=dev)
+        ops.gemm(d6t, ops.transpose(sv['ef']), out_dtype=torch.float32, out=g6[:, :K1])
+        ops.gemm(d6t, ops.transpose(sv['rect']), out_dtype=torch.float32, out=g6[:, K1:])
+        G['roi_fmap.1.0.weight'] = ops.unpermute_add(g6, C, PP, add=g6[:, K1:])    # (p,c)->(c,p) + folded W6sum term
+        G['roi_fmap.1.0.bias'] = ops.colsum(d_pre6)
+        d_rect = ops.gemm(d_pre6, t['w6sum_t'])                                    # [E,C]
+        # ---- rect conv backward (BatchNorm with batch statistics)
+        d_c2, db2, dg2 = ops.bn_bwd(d_rect, None, sv['h3'], sv['m2'], sv['is2'], t['rc_g2'], False)
+        G['union_boxes.conv.6.weight'], G['union_boxes.conv.6.bias'] = dg2.clone(), db2.clone()
+        gw2 = tn_gemm(d_c2, sv['h2'])                                              # [d, d2] centre tap
+        full = torch.zeros(tuple(model.union_boxes.conv[4].weight.shape), dtype=torch.float32, device=dev)
+        full[:, :, 1, 1] = gw2
+        G['union_boxes.conv.4.weight'] = full
+        G['union_boxes.conv.4.bias'] = ops.colsum(d_c2)
+        d_h2 = ops.gemm(d_c2, t['rc_w2_t'])                                        # [E,d2]
+        d_c1, db1, dg1 = ops.bn_bwd(d_h2, sv['arg'], sv['h1'], sv['m1'], sv['is1'], t['rc_g1'], True)
+        G['union_boxes.conv.2.weight'], G['union_boxes.conv.2.bias'] = dg1.clone(), db1.clone()
+        gw1 = tn_gemm(d_c1, sv['patches'])                                         # [d2,128]
+        G['union_boxes.conv.0.weight'] = gw1[:, :98].reshape(tuple(model.union_boxes.conv[0].weight.shape)).contiguous()
+        G['union_boxes.conv.0.bias'] = ops.colsum(d_c1)
+        # ---- node MLP backward
+        d_x7 = lin_bwd(d_obj_rep, sv['x7'], t['obj_unary_t'], 'obj_unary')
+        d_p7 = ops.act_bwd(d_x7, sv['x7'], ds)
+        d_x6 = lin_bwd(d_p7, sv['x6'], t['fc7_obj_t'], 'roi_fmap_obj.3')
+        d_p6 = ops.act_bwd(d_x6, sv['x6'], ds)
+        g6o = tn_gemm(d_p6, sv['nf'])                                              # [4096, K1] in (p,c) order
+        G['roi_fmap_obj.0.weight'] = ops.unpermute_add(g6o, C, PP)
+        G['roi_fmap_obj.0.bias'] = ops.colsum(d_p6)
+        ctx.sv = None
+        shapes = dict(model.named_parameters())
+        grads = [G[n].reshape(shapes[n].shape) for n in param_names(model)]
+        return (None,) * 8 + tuple(grads)
+
+
+def predict_train(model, node_feat, edge_feat, rel_inds, rois, im_inds=None, seed=None, dropout_p=DROPOUT_P):
+    """Autograd-connected training forward of the head.  node_feat/edge_feat: [.,P,P,C]-contiguous (NHWC) tensors
+    in the compute dtype."""
+    N, E = node_feat.shape[0], edge_feat.shape[0]
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    named = dict(model.named_parameters())
+    params = [named[n] for n in param_names(model)]
+    return PredictFn.apply(model, node_feat.reshape(N, -1), edge_feat.reshape(E, -1), rois.float().contiguous(),
+                           rel_inds.contiguous(), im_inds, seed, float(dropout_p), *params)
