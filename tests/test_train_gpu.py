@@ -57,7 +57,9 @@ def test_train_forward_and_all_gradients_match_oracle_autograd(env):
     model.zero_grad()
     loss.backward()
     # ---- oracle: same features (from the HIP front end, verified elsewhere), torch autograd on the CPU
-    p = {k: v.clone().requires_grad_(v.is_floating_point() and not k.startswith('detector.')) for k, v in sd.items()}
+    from sgg_amd.train import param_names
+    pn = set(param_names(model))
+    p = {k: v.clone().requires_grad_(k in pn) for k, v in sd.items()}
     nf = res.node_feat.float().cpu().contiguous()
     ef = res.edge_feat.float().cpu().contiguous()
     od, rd = O.predict(nf, ef, res.rel_inds.cpu().numpy(), res.rois.cpu().numpy(), p, training=True)
@@ -65,7 +67,6 @@ def test_train_forward_and_all_gradients_match_oracle_autograd(env):
     torch.testing.assert_close(res.rm_obj_dists.detach().cpu(), od.detach(), atol=1e-3, rtol=1e-3)
     torch.testing.assert_close(res.rel_dists.detach().cpu(), rd.detach(), atol=1e-3, rtol=1e-3)
     ((od * Wo).sum() + (rd * Wr).sum()).backward()
-    from sgg_amd.train import param_names
     named = dict(model.named_parameters())
     worst = 0.0
     for n in param_names(model):
