@@ -171,6 +171,14 @@ int sgg_imp_node_scatter_bwd(const void* d_e_in, const float* gsave, const float
 /* out[k,:H] += sum_r a[r,k]*x[r,:], k<4 (out row stride out_ld; accumulates: the caller zeroes once per step) */
 int sgg_rank4_reduce(const float* a, const void* x, int R, int H, float* out, int out_ld, int dtype, void* stream);
 
+/* optimiser step of main.py:119-120: global-norm gradient clip (lib/pytorch_misc.py:625-656) + torch.optim.SGD
+ * (momentum, weight decay, lib/pytorch_misc.py:144), fused and sync-free: sqnorm_acc accumulates sum(g^2) over all
+ * parameters into one device float; sgd_step reads it: coef = min(1, max_norm/(sqrt(norm_sq)*grad_scale + 1e-6)),
+ * g' = coef*grad_scale*g + wd*p, buf = first ? g' : momentum*buf + g', p -= lr*buf.  p, buf fp32; g fp32 or bf16. */
+int sgg_sqnorm_acc(const void* g, int64_t n, float* acc, int dtype, void* stream);
+int sgg_sgd_step(float* p, const void* g, float* momentum_buf, int64_t n, float lr, float weight_decay, float momentum,
+                 int first_step, const float* norm_sq, float max_norm, float grad_scale, int g_dtype, void* stream);
+
 /* ---- utilities used by the host for weight preparation (load time, not on the step path) ---- */
 int sgg_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, void* stream);
 /* out[n][p][c] = in[n][c][p]  (fc6 K-order (c,ph,pw) -> (ph,pw,c); conv OIHW -> O(HW)I) */

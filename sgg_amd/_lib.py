@@ -52,6 +52,8 @@ SIGNATURES = {
     'sgg_transpose': [_P, _L, _P, _L, _I, _I, _I, _I, _P],
     'sgg_add': [_P, _P, _L, _I, _I, _P],
     'sgg_unpermute_add': [_P, _L, _P, _L, _P, _I, _I, _I, _P],
+    'sgg_sqnorm_acc': [_P, _L, _P, _I, _P],
+    'sgg_sgd_step': [_P, _P, _P, _L, _F, _F, _F, _I, _P, _F, _F, _I, _P],
     'sgg_cast': [_P, _P, _L, _I, _I, _P],
     'sgg_permute_ncp_to_npc': [_P, _P, _I, _I, _I, _I, _I, _P],
 }

@@ -430,6 +430,52 @@ void bn_bwd_launch(const void* dy, const unsigned char* arg, const void* x, cons
     hipLaunchKernelGGL((bn_bwd_kernel<T, MAX4>), g2, dim3(256), 0, s, (const T*)dy, arg, (const T*)x, mean, invstd, gamma, sums, (T*)dx, (long)rows, C, inv);
 }
 
+// ---- optimiser step (main.py:119-120: grad_clip then SGD with momentum, lib/pytorch_misc.py:144,625-656)
+// sum of squares of g into *acc (one atomic per block)
+template <typename T>
+__global__ __launch_bounds__(256) void sqnorm_kernel(const T* __restrict__ g, long n, float* __restrict__ acc) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (long)gridDim.x * 256 * 8) {
+        if (i + 8 <= n) {
+            float v[8];
+            load8(g + i, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s = fmaf(v[k], v[k], s);
+        } else {
+            for (long k = i; k < n; ++k) {
+                const float v = Elem<T>::ld(g + k);
+                s = fmaf(v, v, s);
+            }
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+}
+
+// torch.optim.SGD(momentum, weight_decay, dampening 0) with the global-norm clip folded in:
+//   coef = min(1, max_norm / (sqrt(*norm_sq) + 1e-6))  (1 if norm_sq == NULL);  g' = coef*grad_scale*g + wd*p;
+//   buf = first ? g' : mom*buf + g';  p -= lr*buf
+template <typename TG>
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const TG* __restrict__ g, float* __restrict__ buf,
+                                                  long n, float lr, float wd, float mom, int first,
+                                                  const float* __restrict__ norm_sq, float max_norm, float grad_scale) {
+    float coef = grad_scale;
+    if (norm_sq) {
+        const float c = max_norm / (sqrtf(*norm_sq) * grad_scale + 1e-6f);
+        if (c < 1.f) coef *= c;
+    }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float pv = p[i];
+        const float gv = coef * Elem<TG>::ld(g + i) + wd * pv;
+        const float b = first ? gv : mom * buf[i] + gv;
+        buf[i] = b;
+        p[i] = pv - lr * b;
+    }
+}
+
 inline int split_rows(int M, int& rows_per_block) {
     int split = (M + 511) / 512;
     if (split > 64) split = 64;
@@ -619,6 +665,35 @@ extern "C" int sgg_rank4_reduce(const float* a, const void* x, int R, int H, flo
     hipStream_t s = (hipStream_t)stream;
     DISPATCH2(dtype, hipLaunchKernelGGL(rank4_reduce_kernel<bf16_t>, grid, blk, 0, s, a, (const bf16_t*)x, R, H, out, out_ld, rpb),
               hipLaunchKernelGGL(rank4_reduce_kernel<float>, grid, blk, 0, s, a, (const float*)x, R, H, out, out_ld, rpb));
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+// acc += sum(g^2)  (acc NOT zeroed: the caller clears it once per step and accumulates over all parameters)
+extern "C" int sgg_sqnorm_acc(const void* g, int64_t n, float* acc, int dtype, void* stream) {
+    if (n == 0) return SGG_OK;
+    if (!g || !acc || n < 0) return SGG_ERR_ARG;
+    long blocks = (n / 8 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH2(dtype, hipLaunchKernelGGL(sqnorm_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)g, (long)n, acc),
+              hipLaunchKernelGGL(sqnorm_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)g, (long)n, acc));
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_sgd_step(float* p, const void* g, float* momentum_buf, int64_t n, float lr, float weight_decay,
+                            float momentum, int first_step, const float* norm_sq, float max_norm, float grad_scale,
+                            int g_dtype, void* stream) {
+    if (n == 0) return SGG_OK;
+    if (!p || !g || !momentum_buf || n < 0) return SGG_ERR_ARG;
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH2(g_dtype,
+        hipLaunchKernelGGL(sgd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, p, (const bf16_t*)g, momentum_buf, (long)n, lr, weight_decay, momentum, first_step, norm_sq, max_norm, grad_scale),
+        hipLaunchKernelGGL(sgd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, p, (const float*)g, momentum_buf, (long)n, lr, weight_decay, momentum, first_step, norm_sq, max_norm, grad_scale));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

@@ -54,48 +54,51 @@ def sum_over_ranks(values, device='cpu'):
 
 
 class GradBuckets(object):
-    """Flat gradient buckets for the DP all-reduce.  Parameters are packed in REVERSE registration order (heads, GRU
-    and unary layers finish their backward first, fc6 -- 83 % of the bytes -- last), `bucket_bytes` per bucket, so
-    that early buckets overlap with the remaining backward GEMMs.  xGMI is point-to-point, a ring all-reduce is
-    per-link bound: few, large buckets (default 128 MiB) keep RCCL on its bandwidth-optimal path."""
+    """Gradient all-reduce for the DP step.  The payload is dominated by four tensors (fc6 x2: 2 x 411 MB fp32,
+    fc7 x2: 2 x 67 MB); everything else is < 13 MB in total.  Tensors >= `big_bytes` are reduced one by one (no packing
+    copies), the small ones are packed into one flat bucket.  xGMI is point-to-point, so a ring all-reduce is per-link
+    bound: few, large messages keep RCCL on its bandwidth-optimal path, and `comm_dtype=bfloat16` halves the bytes on
+    the links (the sum is still applied to fp32 master gradients).  All collectives are issued asynchronously and
+    waited for together."""
 
-    def __init__(self, params, bucket_bytes=128 << 20, dtype=None):
+    def __init__(self, params, big_bytes=8 << 20, comm_dtype=None):
         self.params = [p for p in params if p.requires_grad]
-        self.dtype = dtype
-        self.buckets, cur, size = [], [], 0
-        for p in reversed(self.params):
-            nbytes = p.numel() * (torch.finfo(dtype).bits // 8 if dtype else p.element_size())
-            if cur and size + nbytes > bucket_bytes:
-                self.buckets.append(cur)
-                cur, size = [], 0
-            cur.append(p)
-            size += nbytes
-        if cur:
-            self.buckets.append(cur)
-        self._flat = [None] * len(self.buckets)
+        self.comm_dtype = comm_dtype
+        self.big = [p for p in self.params if p.numel() * p.element_size() >= big_bytes]
+        self.small = [p for p in self.params if p.numel() * p.element_size() < big_bytes]
 
     def all_reduce(self, average=True):
-        """Sum (or mean) p.grad over ranks, bucket by bucket, asynchronously; returns after all are complete."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
         world = dist.get_world_size()
-        works = []
-        for i, bucket in enumerate(self.buckets):
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
-            flat = torch.cat([g.reshape(-1).to(self.dtype or g.dtype) for g in grads])
-            self._flat[i] = flat
+        works, bufs = [], []
+        for p in self.big:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            g = p.grad
+            buf = g.to(self.comm_dtype) if (self.comm_dtype is not None and self.comm_dtype != g.dtype) else g
+            bufs.append((p, buf))
+            works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.small]
+        flat = torch.cat([g.reshape(-1).float() for g in grads]) if grads else None
+        if flat is not None:
             works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
-        for i, (bucket, w) in enumerate(zip(self.buckets, works)):
+        for w in works:
             w.wait()
-            flat, off = self._flat[i], 0
+        for p, buf in bufs:
+            if buf is not p.grad:
+                p.grad.copy_(buf)
+            if average:
+                p.grad.div_(world)
+        if flat is not None:
             if average:
                 flat.div_(world)
-            for p in bucket:
+            off = 0
+            for p in self.small:
                 n = p.numel()
-                g = flat[off:off + n].view_as(p).to(p.dtype)
+                g = flat[off:off + n].view_as(p)
                 if p.grad is None:
                     p.grad = g.clone()
                 else:
                     p.grad.copy_(g)
                 off += n
-            self._flat[i] = None

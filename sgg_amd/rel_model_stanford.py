@@ -33,7 +33,7 @@ class RelModelStanford(RelModelBase):
         into fc6 by linearity (fc6(x + r (x) 1_49) = fc6(x) + W6sum r)."""
         dtype = self.compute_dtype
         params = [p for n, p in self.named_parameters() if not n.startswith('detector.')]
-        key = (dtype,) + tuple((p.data_ptr(), p._version) for p in params)
+        key = (dtype, getattr(self, 'weights_version', 0)) + tuple((p.data_ptr(), p._version) for p in params)
         if self._prep.get('key') == key:
             return self._prep['val']
         C, PP = self.edge_dim, self.pool_sz ** 2

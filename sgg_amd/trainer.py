@@ -1,0 +1,121 @@
+"""Train step of main.py:100-120 on the HIP path, data-parallel over one process per GPU.
+
+    res  = model(batch)                                   # train-mode forward (sgg_amd/train.py)
+    loss = node CE + edge CE, normalised by the GLOBAL batch (lib/losses.py:34-63,74)
+    loss.backward()                                       # HIP backward of the head
+    all-reduce(SUM) of the 247.75 M gradients over RCCL   # sgg_amd/dist.py
+    global-norm clip (5.0) + SGD(momentum 0.9, wd 1e-4, LR/10 for roi_fmap*)   # fused HIP kernels, no host sync
+"""
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from . import _lib, ops
+from .dist import GradBuckets, sum_over_ranks
+
+
+class FusedSGD(object):
+    """torch.optim.SGD(momentum, weight_decay) + clip_grad_norm (lib/pytorch_misc.py:625-656) as HIP kernels.
+    Same parameter groups as get_optim (lib/pytorch_misc.py:135-144): names starting with 'roi_fmap' get lr/10."""
+
+    def __init__(self, named_params, lr, momentum=0.9, weight_decay=1e-4, clip=5.0):
+        self.groups = []
+        for n, p in named_params:
+            if p.requires_grad:
+                self.groups.append(dict(name=n, p=p, lr=lr / 10.0 if n.startswith('roi_fmap') else lr, buf=None))
+        self.momentum, self.weight_decay, self.clip = momentum, weight_decay, clip
+        self.steps = 0
+        self._norm = None
+        self.on_update = None
+
+    def zero_grad(self):
+        for g in self.groups:
+            g['p'].grad = None
+
+    @torch.no_grad()
+    def step(self, grad_scale=1.0):
+        stream = torch.cuda.current_stream().cuda_stream
+        dev = self.groups[0]['p'].device
+        if self._norm is None:
+            self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._norm.zero_()
+        live = [g for g in self.groups if g['p'].grad is not None]
+        if self.clip and self.clip > 0:
+            for g in live:
+                gr = g['p'].grad
+                _lib.call('sgg_sqnorm_acc', gr.data_ptr(), gr.numel(), self._norm.data_ptr(), ops.dt(gr), stream)
+        for g in live:
+            p, gr = g['p'], g['p'].grad
+            first = g['buf'] is None
+            if first:
+                g['buf'] = torch.empty_like(p, dtype=torch.float32)
+            _lib.call('sgg_sgd_step', p.data_ptr(), gr.contiguous().data_ptr(), g['buf'].data_ptr(), p.numel(), float(g['lr']),
+                      float(self.weight_decay), float(self.momentum), int(first),
+                      self._norm.data_ptr() if self.clip and self.clip > 0 else None, float(self.clip or 0.0),
+                      float(grad_scale), ops.dt(gr), stream)
+        self.steps += 1
+        if self.on_update is not None:
+            self.on_update()   # parameters changed through raw pointers: tell the owner to refresh derived operands
+
+    def grad_norm(self):
+        return float(self._norm.sqrt().item())
+
+
+class Trainer(object):
+    """One data-parallel train step.  `loss_type` as lib/losses.py ('baseline' is the reference default, config.py:184)."""
+
+    def __init__(self, model, lr=1e-3, momentum=0.9, weight_decay=1e-4, clip=5.0, loss_type='baseline',
+                 comm_dtype=torch.bfloat16):
+        self.model = model
+        for n, p in model.named_parameters():
+            if n.startswith('detector.'):
+                p.requires_grad = False                     # main.py:62-63: the detector is frozen
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        self.opt = FusedSGD(named, lr, momentum, weight_decay, clip)
+        self.opt.on_update = self._bump
+        self.buckets = GradBuckets([p for _, p in named], comm_dtype=comm_dtype)
+        self.loss_type = loss_type
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def _bump(self):
+        self.model.weights_version = getattr(self.model, 'weights_version', 0) + 1
+
+    def losses(self, res):
+        """node + edge classification losses with GLOBAL-batch normalisers: summed local CE / global counts, so that
+        the all-reduce(SUM) of the gradients equals the single-process gradient on the concatenated batch."""
+        obj_ce = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels, reduction='sum')
+        labels = res.rel_labels[:, -1]
+        rel_ce = F.cross_entropy(res.rel_dists, labels, reduction='none')
+        n_obj, M = float(res.rm_obj_labels.shape[0]), float(labels.shape[0])
+        if self.loss_type == 'baseline':
+            if self.world > 1:
+                n_obj, M = sum_over_ranks([n_obj, M], device=res.rel_dists.device)
+            return obj_ce / n_obj + rel_ce.sum() / M                                 # lib/losses.py:41-42,74
+        fg = labels > 0
+        m_fg, m_bg = float(fg.sum().item()), float((~fg).sum().item())
+        if self.world > 1:
+            n_obj, m_fg, m_bg = sum_over_ranks([n_obj, m_fg, m_bg], device=res.rel_dists.device)
+        w = torch.ones_like(rel_ce)
+        if m_fg > 0:
+            w[fg] = 1.0 / m_fg                                                        # :50
+        if self.loss_type == 'dnorm':
+            if m_bg > 0 and m_fg > 0:
+                w[~fg] = 1.0 / m_fg                                                   # :56
+        elif self.loss_type == 'dnorm-fgbg':
+            if m_bg > 0:
+                w[~fg] = 1.0 / m_bg                                                   # :59
+        else:
+            raise NotImplementedError(self.loss_type)
+        return obj_ce / n_obj + (rel_ce * w).sum()
+
+    def step(self, batch):
+        self.model.train()
+        res = self.model([batch])
+        loss = self.losses(res)
+        self.opt.zero_grad()
+        loss.backward()
+        if self.world > 1:
+            self.buckets.all_reduce(average=False)
+        self.opt.step()
+        self.model.global_batch_iter = getattr(self.model, 'global_batch_iter', 0) + 1
+        return loss.detach()

@@ -29,7 +29,7 @@ def _worker(rank, world, port, q):
     x = torch.full((3, 8), float(r + 1))
     lin(x).sum().backward()
     local = [p.grad.clone() for p in lin.parameters()]
-    D.GradBuckets(lin.parameters(), bucket_bytes=256).all_reduce(average=True)
+    D.GradBuckets(lin.parameters(), big_bytes=256).all_reduce(average=True)   # Linear(8,16).weight is 'big'
     q.put((r, (lo, hi), mx, tot, [g.tolist() for g in local], [p.grad.tolist() for p in lin.parameters()]))
     dist.barrier()
     dist.destroy_process_group()

@@ -107,3 +107,49 @@ def test_train_step_bf16_runs_and_decreases_loss(env):
         losses.append(float(loss))
     assert losses[-1] < losses[0], losses
     model.eval()
+
+
+def test_fused_sgd_matches_torch_sgd_with_global_norm_clip(env):
+    from sgg_amd.trainer import FusedSGD
+    g = torch.Generator().manual_seed(1)
+    shapes = [(300, 257), (64,), (5, 3, 3, 3), (1000, 100)]
+    ref_p = [torch.randn(s, generator=g) for s in shapes]
+    ref_named = [('roi_fmap.x%d' % i if i == 0 else 'w%d' % i, torch.nn.Parameter(p.clone())) for i, p in enumerate(ref_p)]
+    hip_named = [(n, torch.nn.Parameter(p.detach().clone().to(DEV))) for n, p in ref_named]
+    lr, mom, wd, clip = 0.05, 0.9, 1e-4, 5.0
+    ref_opt = torch.optim.SGD([{'params': [ref_named[0][1]], 'lr': lr / 10}, {'params': [p for _, p in ref_named[1:]]}],
+                              lr=lr, momentum=mom, weight_decay=wd)
+    hip_opt = FusedSGD(hip_named, lr, mom, wd, clip)
+    for step in range(3):
+        grads = [torch.randn(s, generator=g) * (30.0 if step == 1 else 0.01) for s in shapes]   # step 1 triggers the clip
+        for (_, p), gr in zip(ref_named, grads):
+            p.grad = gr.clone()
+        total = torch.sqrt(sum((p.grad ** 2).sum() for _, p in ref_named))
+        coef = clip / (total + 1e-6)                                      # lib/pytorch_misc.py:641-649
+        if coef < 1:
+            for _, p in ref_named:
+                p.grad.mul_(coef)
+        ref_opt.step()
+        for (_, p), gr in zip(hip_named, grads):
+            p.grad = gr.clone().to(DEV)
+        hip_opt.step()
+        assert abs(hip_opt.grad_norm() - float(total)) < 1e-3 * float(total)
+        for (_, a), (_, b) in zip(ref_named, hip_named):
+            torch.testing.assert_close(b.detach().cpu(), a.detach(), atol=1e-6, rtol=1e-5)
+
+
+def test_trainer_step_updates_weights_and_refreshes_operands(env):
+    model, sd, batch = env
+    from sgg_amd.trainer import Trainer
+    model.load_state_dict(sd)
+    model.set_compute_dtype(torch.bfloat16)
+    tr = Trainer(model, lr=1e-3)
+    dev_batch = list(batch)
+    l0 = float(tr.step(tuple(dev_batch)))
+    k0 = model._prep['key']
+    for _ in range(4):
+        l1 = float(tr.step(tuple(dev_batch)))
+    assert model._prep['key'] != k0                 # derived bf16 operands were rebuilt after the in-place update
+    assert l1 < l0
+    assert not any(p.requires_grad for n, p in model.named_parameters() if n.startswith('detector.'))
+    model.eval()
