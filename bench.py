@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
-"""bench.py -- images/sec of the VG SGCls IMP forward (BASELINE.json configs[1]) on N MI355X of one node.
+"""bench.py -- images/sec of the VG SGCls IMP hot path (BASELINE.json configs[1] / [3]) on N MI355X of one node.
 
-A step = one pass of the hot path (RelModelStanford.forward in eval mode: transform -> VGG-16 -> pair indexing ->
-RoIAlign(objects + union boxes) -> union-mask conv -> fc6/fc7 -> 3 IMP iterations -> heads -> eval tail incl. the
-D2H copy of the result tuple) over one batch of synthetic 592x592 frames, 32 boxes and 32*31 candidate edges per
-image, B images per GPU, inputs resident in HBM.  Images are sharded over ranks (one process per GPU, no data-path
-collective: inference needs none) => weak scaling.  Prints ONE JSON line on rank 0.
+--mode train (default): a step = one data-parallel TRAIN step of main.py:100-120 on the HIP path: train-mode forward
+  (transform -> VGG-16 -> pair indexing -> RoIAlign(objects + union boxes) -> union-mask conv -> fc6/fc7 -> 3 IMP
+  iterations -> heads), node + edge losses, backward of the trainable head, RCCL gradient all-reduce (N > 1),
+  global-norm clip and SGD step -- nothing skipped.
+--mode infer: a step = RelModelStanford.forward in eval mode incl. the eval tail and the D2H copy of the result tuple
+  (no collective).
+One batch = B synthetic 592x592 frames per GPU, 32 boxes and 32*31 candidate edges per image, inputs resident in HBM.
+Images are sharded over ranks (one process per GPU) => weak scaling.  Prints ONE JSON line on rank 0; the other mode's
+throughput is reported alongside under "other_mode".
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype bf16|f32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype bf16|f32] [--mode train|infer]
 """
 import argparse
 import json
@@ -30,12 +34,13 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=8, help='images per GPU (global batch 64 at 8 GPUs)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--mode', default='train', choices=['train', 'infer'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=2)
     return ap.parse_args()
 
 
-def kernel_times(model, batch, reps):
+def kernel_times(step_fn, reps):
     """Per-kernel average launch duration from HIP events on the launch stream (separate, untimed passes)."""
     import torch
     from sgg_amd import _lib
@@ -43,8 +48,7 @@ def kernel_times(model, batch, reps):
     _lib.profiler = prof
     try:
         for _ in range(reps):
-            with torch.no_grad():
-                model([batch])
+            step_fn()
         torch.cuda.synchronize()
     finally:
         _lib.profiler = None
@@ -104,39 +108,71 @@ def main():
     batch[3], batch[4], batch[5] = batch[3].to(dev), batch[4].to(dev), batch[5].to(dev)
     batch = tuple(batch)
 
-    def step():
+    from sgg_amd.trainer import Trainer
+    trainer = Trainer(model, lr=1e-3) if args.mode == 'train' else None
+
+    def infer_step():
+        model.eval()
         with torch.no_grad():
             return model([batch])
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def train_step():
+        return trainer.step(batch)
 
-    # ---- per-kernel roofline (rank 0, outside the timed region)
-    line = None
+    step = train_step if args.mode == 'train' else infer_step
+
+    def timed(fn, warmup, steps):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    elapsed = timed(step, args.warmup, args.steps)
+
+    # ---- per-kernel roofline (rank 0, outside the timed region; single-GPU kernels, no collective inside)
     if rank == 0:
-        kt = kernel_times(model, batch, reps=5)
+        if args.mode == 'train':
+            def prof_step():
+                model.train()
+                res = model([batch])
+                loss = trainer.losses(res)
+                trainer.opt.zero_grad()
+                loss.backward()
+                trainer.opt.step()
+            kt = kernel_times(prof_step, reps=3)
+        else:
+            kt = kernel_times(infer_step, reps=5)
         E, N, H = 992 * B, 32 * B, 512
         s = 2 if args.dtype == 'bf16' else 4
+        peak = MFMA_PEAK_TF[args.dtype]
         get = lambda name, tag: kt.get((name, tag), (0.0, 0))
-        fc6_ms, _ = get('sgg_gemm', 'fc6_edge')
-        fc6_flop = 2.0 * E * 4096 * (25088 + 512)
-        fc6_tf = fc6_flop / (fc6_ms * 1e-3) / 1e12 if fc6_ms else 0.0
+        per_step = lambda name, tag: get(name, tag)[0] * get(name, tag)[1]
+        # the two largest contractions: fc6 on edges forward, and its weight gradient in training
+        cands = {'fc6_edge': ('fc6 on edges, forward: [%d x 25600] . [4096 x 25600]^T' % E, 2.0 * E * 4096 * 25600),
+                 'bwd_fc6_edge_dW': ('fc6 weight gradient: [4096 x %d] . [25600 x %d]^T (2 launches: 25088 + 512 cols)' % (E, E),
+                                     2.0 * E * 4096 * 25600)}
+        best = None
+        for tag, (desc, flop) in cands.items():
+            ms = per_step('sgg_gemm', tag)
+            if ms > 0 and (best is None or ms > best[1]):
+                best = (tag, ms, desc, flop)
+        tag, ms, desc, flop = best
+        tf = flop / (ms * 1e-3) / 1e12
         imp_ms = get('sgg_imp_edge_ctx_fwd', 'imp')[0] + get('sgg_imp_node_scatter_fwd', 'imp')[0] + \
             get('sgg_imp_node_gate_dots', 'imp')[0]
         imp_bytes = (2.0 * (E + N) * H) * s + 8.0 * E           # per iteration
@@ -146,20 +182,29 @@ def main():
         conv_ms = sum(v[0] * v[1] for (n, t), v in kt.items() if n in ('sgg_conv3x3_relu', 'sgg_conv1_1', 'sgg_maxpool2x2'))
         vgg_flop = 226.13e9 * B
         total_ms = sum(v[0] * v[1] for v in kt.values())
-        top = sorted(((v[0] * v[1], n, t) for (n, t), v in kt.items()), reverse=True)[:8]
-        peak = MFMA_PEAK_TF[args.dtype]
+        top = sorted(((v[0] * v[1], n, t) for (n, t), v in kt.items()), reverse=True)[:10]
+        # the other mode, for reference (short run)
+        other = infer_step if args.mode == 'train' else None
+        other_line = None
+        if other is not None and world == 1:
+            el2 = timed(other, 2, 10)
+            other_line = {'mode': 'infer', 'value': round(B * 10 / el2, 2), 'unit': 'images/s', 'ms_per_step': round(1e3 * el2 / 10, 3)}
         line = {
-            'metric': 'images/sec (whole node), VG SGCls IMP forward', 'value': round(world * B * args.steps / elapsed, 3),
+            'metric': 'images/sec (whole node), VG SGCls IMP %s step' % ('train' if args.mode == 'train' else 'inference'),
+            'value': round(world * B * args.steps / elapsed, 3),
             'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': 'VG SGCls rel_model_stanford (IMP) eval forward, 592x592 frames, 32 boxes/img, '
-                                   '992 edges/img, 3 IMP iters (BASELINE configs[1])',
-                       'images_per_gpu': B, 'global_batch': world * B, 'parallelism': 'image-sharded dp%d, no collective '
-                       '(inference)' % world, 'weights': 'random init (He), frozen VGG16 + IMP head'},
-            'roofline': {'kernel': 'mfma_tile_kernel (fc6 on edges: [%d x %d] . [4096 x %d]^T)' % (E, 25600, 25600),
-                         'bound': 'mfma', 'achieved': round(fc6_tf, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': round(fc6_tf / peak, 4), 'traffic': None, 'avg_launch_ms': round(fc6_ms, 4)},
+            'config': {'workload': 'VG SGCls rel_model_stanford (IMP) %s, 592x592 frames, 32 boxes/img, 992 edges/img, '
+                                   '3 IMP iters (BASELINE configs[1]/[3])' %
+                                   ('train step: fwd + losses + bwd + grad all-reduce + clip + SGD' if args.mode == 'train'
+                                    else 'eval forward incl. eval tail'),
+                       'mode': args.mode, 'images_per_gpu': B, 'global_batch': world * B,
+                       'parallelism': 'image-sharded dp%d, %s' % (world, 'RCCL gradient all-reduce (bf16 on the wire)'
+                                                                  if args.mode == 'train' else 'no collective'),
+                       'weights': 'random init (He), frozen VGG16 + trainable IMP head (247.75 M params)'},
+            'roofline': {'kernel': 'MFMA tile kernel, %s' % desc, 'bound': 'mfma', 'achieved': round(tf, 2), 'peak': peak,
+                         'unit': 'TFLOP/s', 'frac': round(tf / peak, 4), 'traffic': None, 'ms_per_step': round(ms, 4)},
             'roofline_imp': {'kernel': 'edge_ctx + node_scatter (+gate dots), per IMP iteration', 'bound': 'hbm',
                              'achieved': round(imp_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                              'frac': round(imp_gbs / HBM_PEAK_GBS, 4), 'traffic': None,
@@ -167,8 +212,10 @@ def main():
             'kernels': {'sum_kernel_ms_per_step': round(total_ms, 3),
                         'vgg16_ms': round(conv_ms, 3), 'vgg16_tflops': round(vgg_flop / (conv_ms * 1e-3) / 1e12, 1) if conv_ms else 0,
                         'roi_align_ms': round(roi_ms, 4), 'roi_align_GBs': round(roi_bytes / (roi_ms * 1e-3) / 1e9, 1) if roi_ms else 0,
-                        'top': [{'ms_per_step': round(ms, 3), 'call': n, 'tag': t} for ms, n, t in top]},
+                        'top': [{'ms_per_step': round(ms_, 3), 'call': n, 'tag': t} for ms_, n, t in top]},
         }
+        if other_line:
+            line['other_mode'] = other_line
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.cpu_images, 111)
         print(json.dumps(line), flush=True)

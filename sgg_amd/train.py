@@ -115,7 +115,9 @@ class PredictFn(torch.autograd.Function):
             bn2.num_batches_tracked += 1
         sv.update(patches=patches, h1=h1, h2=h2, arg=arg, m1=m1, is1=is1, h3=h3, m2=m2, is2=is2, rect=rect)
         # ---- nodes: obj_unary(roi_fmap_obj(node_feat))  (Linear ReLU Dropout Linear ReLU Dropout)
+        _lib.set_tag('fc6_obj')
         x6 = ops.gemm(nf, w['fc6_obj'], w['fc6_obj_b'], ops.ACT_RELU)
+        _lib.set_tag('mlp')
         if dropout_p > 0:
             ops.dropout_(x6, dropout_p, seed * 4 + 1)
         x7 = ops.gemm(x6, w['fc7_obj'], w['fc7_obj_b'], ops.ACT_RELU)
@@ -128,13 +130,16 @@ class PredictFn(torch.autograd.Function):
         HE = torch.empty((4 * E, H), dtype=dt, device=dev)
         ops.gemm(x7, w['obj_unary'], w['obj_unary_b'], out=XN[:N])
         # ---- edges: relu(edge_unary(roi_fmap(edge_feat + conv(rects))))  (Linear ReLU Dropout Linear)
+        _lib.set_tag('fc6_edge')
         y6 = ops.gemm(ef, w['fc6_edge'], w['fc6_edge_b'], ops.ACT_RELU, A2=rect)
+        _lib.set_tag('mlp')
         if dropout_p > 0:
             ops.dropout_(y6, dropout_p, seed * 4 + 3)
         y7 = ops.gemm(y6, w['fc7_edge'], w['fc7_edge_b'])
         ops.gemm(y7, w['edge_unary'], w['edge_unary_b'], ops.ACT_RELU, out=XE[:E])
         sv.update(x6=x6, x7=x7, y6=y6, y7=y7)
         # ---- message passing (rel_model_stanford.py:68-94)
+        _lib.set_tag('imp')
         csr = ops.edge_csr(rel_inds, N, im_inds)
         gin, ghn, gie, ghe, dots_l, gates_l = [], [], [], [], [], []
         a, b = _gru_fwd(XN[:N], None, imp.node_gru_w_ih, imp.node_gru_w_hh, imp.node_gru_b_ih, imp.node_gru_b_hh, dt, HN[:N])
@@ -155,10 +160,12 @@ class PredictFn(torch.autograd.Function):
             dots_l.append(dots)
         T = model.mp_iter
         vT, eT = HN[T * N:(T + 1) * N], HE[T * E:(T + 1) * E]
+        _lib.set_tag('heads')
         obj = ops.gemm(vT, w['obj_fc'], w['obj_fc_b'], out_dtype=torch.float32)
         rel = ops.gemm(eT, w['rel_fc'], w['rel_fc_b'], out_dtype=torch.float32)
         sv.update(XN=XN, XE=XE, HN=HN, HE=HE, gin=gin, ghn=ghn, gie=gie, ghe=ghe, dots=dots_l, csr=csr, nf=nf, ef=ef,
                   rel_inds=rel_inds, N=N, E=E, H=H, dropout_p=dropout_p)
+        _lib.set_tag('')
         ctx.model, ctx.sv = model, sv
         return obj, rel
 
@@ -179,11 +186,13 @@ class PredictFn(torch.autograd.Function):
             G[name + '.bias'] = ops.colsum(dY)
             return ops.gemm(_pad_cols(dY, 64, dt), Wt) if want_dx else None
 
+        _lib.set_tag('bwd_heads')
         d_obj = d_obj.contiguous().to(dt) if d_obj.dtype != dt else d_obj.contiguous()
         d_rel = d_rel.contiguous().to(dt) if d_rel.dtype != dt else d_rel.contiguous()
         d_v = lin_bwd(d_obj, rows(HN, T, N), t['obj_fc_t'], 'obj_fc')
         d_e = lin_bwd(d_rel, rows(HE, T, E), t['rel_fc_t'], 'rel_fc')
         # ---- IMP backward (rel_model_stanford.py:74-92 in reverse)
+        _lib.set_tag('bwd_imp')
         dGIn = torch.empty((4 * N, 3 * H), dtype=dt, device=dev)
         dGHn = torch.empty((4 * N, 3 * H), dtype=dt, device=dev)
         dGIe = torch.empty((4 * E, 3 * H), dtype=dt, device=dev)
@@ -231,6 +240,7 @@ class PredictFn(torch.autograd.Function):
             G[g + '.0.weight'] = d_gw[k:k + 1].clone()
             G[g + '.0.bias'] = d_gb[k].clone()
         # ---- edge MLP backward
+        _lib.set_tag('bwd_mlp')
         p = sv['dropout_p']
         ds = 1.0 / (1.0 - p) if p > 0 else 1.0
         d_u = ops.act_bwd(d_rel_rep, rows(XE, 0, E))                               # relu(edge_unary)
@@ -239,12 +249,14 @@ class PredictFn(torch.autograd.Function):
         d_pre6 = ops.act_bwd(d_y6, sv['y6'], ds)                                   # dropout + relu
         C, PP = model.edge_dim, model.pool_sz ** 2
         K1 = C * PP
+        _lib.set_tag('bwd_fc6_edge_dW')
         d6t = ops.transpose(d_pre6)                                                # [4096, Ep]
         g6 = torch.empty((d_pre6.shape[1], K1 + C), dtype=torch.float32, device=dev)
         ops.gemm(d6t, ops.transpose(sv['ef']), out_dtype=torch.float32, out=g6[:, :K1])
         ops.gemm(d6t, ops.transpose(sv['rect']), out_dtype=torch.float32, out=g6[:, K1:])
         G['roi_fmap.1.0.weight'] = ops.unpermute_add(g6, C, PP, add=g6[:, K1:])    # (p,c)->(c,p) + folded W6sum term
         G['roi_fmap.1.0.bias'] = ops.colsum(d_pre6)
+        _lib.set_tag('bwd_rect')
         d_rect = ops.gemm(d_pre6, t['w6sum_t'])                                    # [E,C]
         # ---- rect conv backward (BatchNorm with batch statistics)
         d_c2, db2, dg2 = ops.bn_bwd(d_rect, None, sv['h3'], sv['m2'], sv['is2'], t['rc_g2'], False)
@@ -261,6 +273,7 @@ class PredictFn(torch.autograd.Function):
         G['union_boxes.conv.0.weight'] = gw1[:, :98].reshape(tuple(model.union_boxes.conv[0].weight.shape)).contiguous()
         G['union_boxes.conv.0.bias'] = ops.colsum(d_c1)
         # ---- node MLP backward
+        _lib.set_tag('bwd_mlp_obj')
         d_x7 = lin_bwd(d_obj_rep, sv['x7'], t['obj_unary_t'], 'obj_unary')
         d_p7 = ops.act_bwd(d_x7, sv['x7'], ds)
         d_x6 = lin_bwd(d_p7, sv['x6'], t['fc7_obj_t'], 'roi_fmap_obj.3')
@@ -268,6 +281,7 @@ class PredictFn(torch.autograd.Function):
         g6o = tn_gemm(d_p6, sv['nf'])                                              # [4096, K1] in (p,c) order
         G['roi_fmap_obj.0.weight'] = ops.unpermute_add(g6o, C, PP)
         G['roi_fmap_obj.0.bias'] = ops.colsum(d_p6)
+        _lib.set_tag('')
         ctx.sv = None
         shapes = dict(model.named_parameters())
         grads = [G[n].reshape(shapes[n].shape) for n in param_names(model)]
