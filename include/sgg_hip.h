@@ -114,6 +114,13 @@ int sgg_imp_edge_ctx_fwd(const void* v, const void* e, const int64_t* rel_inds /
 int sgg_imp_node_scatter_fwd(const void* e, const float* gates, const int* out_ptr, const int* out_ids,
                              const int* in_ptr, const int* in_ids, int N, int H, void* ctx, int dtype, void* stream);
 
+/* Fused form of the three calls above, ONE launch per iteration (the kernel the forward uses): workgroup (n, side);
+ * side 0 handles n's out-edges (writes e_in rows, reduces ctx2[0][n] = sum g_out*e), side 1 n's in-edges
+ * (ctx2[1][n] = sum g_in*e).  ctx = ctx2[0] + ctx2[1]; the node GRU consumes the halves as a K-split GEMM operand. */
+int sgg_imp_fused_fwd(const void* v, const void* e, const int64_t* rel_inds /*[E,3]*/, const int* out_ptr, const int* out_ids,
+                      const int* in_ptr, const int* in_ids, int N, int E, int H, const float* gate_w, const float* gate_b,
+                      void* e_in, void* ctx2 /*[2,N,H]*/, int dtype, void* stream);
+
 /* ---- a-9  GRU cell pointwise part: nn.GRUCell, rel_model_stanford.py:36-37,71-72,83,92 ----
  * gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh come from sgg_gemm ([M,3H], gate order r,z,n).
  * gh == NULL means h == 0: gh = b_hh (f32[3H]) and h_prev = 0 (first call, :68-72).

@@ -36,6 +36,7 @@ SIGNATURES = {
     'sgg_imp_node_gate_dots': [_P, _I, _I, _P, _P, _I, _P],
     'sgg_imp_edge_ctx_fwd': [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     'sgg_imp_node_scatter_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P],
+    'sgg_imp_fused_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     'sgg_gru_gate_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sgg_eval_tail': [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     'sgg_dropout_fwd': [_P, _L, _F, ctypes.c_uint64, _I, _P],

@@ -20,6 +20,8 @@ class ImpWeights(object):
         w.gate_w = torch.cat([p[g + '.0.weight'].detach().float().reshape(1, -1) for g in GATES], 0).contiguous()
         w.gate_b = torch.cat([p[g + '.0.bias'].detach().float().reshape(1) for g in GATES], 0).contiguous()
         w.H = w.edge_gru_w_hh.shape[1]
+        # node GRU input weight doubled along K: ctx = ctx_out + ctx_in is fed as a K-split operand (linearity)
+        w.node_gru_w_ih2 = torch.cat((w.node_gru_w_ih, w.node_gru_w_ih), 1).contiguous()
         return w
 
 
@@ -39,10 +41,11 @@ def message_pass(rel_rep, obj_rep, rel_inds, csr, wts, mp_iter, dtype):
     vert = _gru(wts, 'node_gru', obj_rep, None, dtype)                       # :71
     edge = _gru(wts, 'edge_gru', rel_rep, None, dtype)                       # :72
     for _ in range(mp_iter):                                                 # :74
-        dots = ops.imp_node_gate_dots(vert, wts.gate_w)
-        e_in, gates = ops.imp_edge_ctx(vert, edge, rel_inds, dots, wts.gate_w, wts.gate_b)   # :76-81,86-89
-        ctx = ops.imp_node_scatter(edge, gates, csr, N)                      # :91
+        e_in, ctx2 = ops.imp_fused(vert, edge, rel_inds, csr, wts.gate_w, wts.gate_b)   # :76-81,86-91 in one launch
         edge_new = _gru(wts, 'edge_gru', e_in, edge, dtype)                  # :83
-        vert = _gru(wts, 'node_gru', ctx, vert, dtype)                       # :92
+        # :92  node_gru(ctx_out + ctx_in, vert): the sum rides in the GEMM's K axis
+        gi = ops.gemm(ctx2[0], wts.node_gru_w_ih2, wts.node_gru_b_ih, out_dtype=torch.float32, A2=ctx2[1])
+        gh = ops.gemm(vert, wts.node_gru_w_hh, wts.node_gru_b_hh, out_dtype=torch.float32)
+        vert = ops.gru_gate(gi, gh, None, vert, dtype)
         edge = edge_new
     return vert, edge

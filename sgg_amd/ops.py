@@ -198,6 +198,20 @@ def imp_node_scatter(e, gates, csr, N, ctx=None):
     return ctx
 
 
+def imp_fused(v, e, rel_inds, csr, gate_w, gate_b, e_in=None, ctx2=None):
+    """One launch per IMP iteration: -> (e_in [E,H], ctx2 [2,N,H]) with ctx = ctx2[0] + ctx2[1]."""
+    N, H = v.shape
+    E = e.shape[0]
+    out_ptr, out_ids, in_ptr, in_ids = csr
+    if e_in is None:
+        e_in = torch.empty_like(e)
+    if ctx2 is None:
+        ctx2 = torch.empty((2, N, H), dtype=v.dtype, device=v.device)
+    _lib.call('sgg_imp_fused_fwd', _p(v), _p(e), _p(rel_inds, torch.int64), _p(out_ptr), _p(out_ids), _p(in_ptr), _p(in_ids),
+              N, E, H, _p(gate_w, torch.float32), _p(gate_b, torch.float32), _p(e_in), _p(ctx2), dt(v), _stream())
+    return e_in, ctx2
+
+
 def gru_gate(gi, gh, b_hh, h_prev, out_dtype, out=None):
     M, H3 = gi.shape
     H = H3 // 3

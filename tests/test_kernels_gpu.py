@@ -328,6 +328,23 @@ def test_imp_kernels_full_size_vs_oracle(ops):
     exp_ctx = torch.zeros(N, H).index_add_(0, s, gt[2][:, None] * e).index_add_(0, o, gt[3][:, None] * e)
     torch.testing.assert_close(e_in.cpu(), exp_ein, atol=2e-5, rtol=1e-5)
     torch.testing.assert_close(ctx.cpu(), exp_ctx, atol=1e-4, rtol=1e-5)
+    # the fused one-launch kernel: same e_in, ctx = ctx2[0] + ctx2[1]
+    csr = ops.edge_csr(cu(rel), N, cu(im))
+    e_in_f, ctx2 = ops.imp_fused(cu(v), cu(e), cu(rel), csr, cu(gw), cu(gb))
+    torch.testing.assert_close(e_in_f.cpu(), exp_ein, atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close((ctx2[0] + ctx2[1]).cpu(), exp_ctx, atol=1e-4, rtol=1e-5)
+    # ragged / sampled graph (nodes without in- or out-edges)
+    keep = rng.rand(E) > 0.6
+    keep[rel[:, 1] == 3] = False
+    relk = rel[keep]
+    csrk = ops.edge_csr(cu(relk), N, cu(im))
+    e_in_k, ctx2k = ops.imp_fused(cu(v), cu(e[torch.from_numpy(keep)]), cu(relk), csrk, cu(gw), cu(gb))
+    sk, ok, ek = torch.from_numpy(relk[:, 1]), torch.from_numpy(relk[:, 2]), e[torch.from_numpy(keep)]
+    gk = [torch.sigmoid(torch.cat((a, ek), 1) @ gw[k] + gb[k]) for k, a in enumerate((v[sk], v[ok], v[sk], v[ok]))]
+    torch.testing.assert_close(e_in_k.cpu(), gk[0][:, None] * v[sk] + gk[1][:, None] * v[ok], atol=2e-5, rtol=1e-5)
+    exp_k = torch.zeros(N, H).index_add_(0, sk, gk[2][:, None] * ek).index_add_(0, ok, gk[3][:, None] * ek)
+    torch.testing.assert_close((ctx2k[0] + ctx2k[1]).cpu(), exp_k, atol=1e-4, rtol=1e-5)
+    assert float((ctx2k[0][3]).abs().max()) == 0                    # node 3 has no out-edges
     # bf16 storage: same math on bf16-rounded inputs
     vb, eb = v.bfloat16(), e.bfloat16()
     dots = ops.imp_node_gate_dots(cu(vb), cu(gw))
