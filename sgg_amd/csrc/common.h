@@ -65,11 +65,46 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
     *reinterpret_cast<u32x4*>(p) = a;
 }
 
-// 64-lane wave reductions (all lanes receive the result)
+// raw 8-element row pieces kept packed in registers (4 VGPRs for bf16, 8 for f32) until they are used
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+    u32x4 r;
+    __device__ __forceinline__ void load(const bf16_t* p) { r = *reinterpret_cast<const u32x4*>(p); }
+    __device__ __forceinline__ void zero() { r = u32x4{0, 0, 0, 0}; }
+    __device__ __forceinline__ void get(float (&v)[8]) const {
+        v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+        v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+        v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+        v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+    }
+};
+template <> struct Raw8<float> {
+    f32x4 a, b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const f32x4*>(p);
+        b = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+    __device__ __forceinline__ void zero() { a = f32x4{0, 0, 0, 0}; b = a; }
+    __device__ __forceinline__ void get(float (&v)[8]) const {
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+};
+
+// 64-lane wave sum on the DPP path (no LDS crossbar): 4 in-row steps, row_bcast15 / row_bcast31 across rows, total in
+// lane 63, broadcast through an SGPR (v_readlane) -- the result is wave-uniform.  gfx9-family DPP controls.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    int x;
+#define SGG_DPP_ADD(ctrl, rmask)                                                                      \
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, false);                  \
+    v += __int_as_float(x);
+    SGG_DPP_ADD(0xB1, 0xF)   // quad_perm [1,0,3,2]
+    SGG_DPP_ADD(0x4E, 0xF)   // quad_perm [2,3,0,1]
+    SGG_DPP_ADD(0x141, 0xF)  // row_half_mirror
+    SGG_DPP_ADD(0x140, 0xF)  // row_mirror : every lane of a 16-lane row holds the row sum
+    SGG_DPP_ADD(0x142, 0xA)  // row_bcast15 into rows 1,3
+    SGG_DPP_ADD(0x143, 0xC)  // row_bcast31 into rows 2,3 : lane 63 holds the wave sum
+#undef SGG_DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -130,146 +130,131 @@ __global__ __launch_bounds__(256) void node_scatter_kernel(const T* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 // Fused IMP gather / gate / scatter: ONE launch per iteration (replaces gate_dots + edge_ctx + node_scatter).
-// Node-centric: workgroup (n, side).  side 0 owns n's out-edges (n -> o): it computes g_sub, g_obj, g_out for each of
-// them, writes e_in[e] = g_sub*v[n] + g_obj*v[o], and reduces ctx_out[n] = sum g_out*e.  side 1 owns n's in-edges
-// (m -> n): g_in needs only a_in[n] and the edge row it reads anyway, so it reduces ctx_in[n] = sum g_in*e with no
-// cross-workgroup dependency, no gate array and no atomics.  ctx = ctx_out + ctx_in is never formed: the node GRU's
-// input GEMM takes the two halves as a K-split A operand against [W_ih | W_ih] (linearity).
-// Each e row is read twice (once per side) -- the second read is an L2 / Infinity-Cache hit -- and written never;
-// v rows are L2-resident.  A lane owns 8 channels: every row access is one 16-byte (bf16) piece per lane, 1 KiB per wave.
-// 8 waves per workgroup, two edge rows in flight per wave.
+// Node-centric, one WAVE per unit (n, side), persistent over units (the six gate vectors a lane needs stay in
+// registers).  side 0 owns n's out-edges (n -> o): g_sub, g_obj, g_out for each, e_in[e] = g_sub*v[n] + g_obj*v[o]
+// written, ctx_out[n] = sum g_out*e reduced in registers.  side 1 owns n's in-edges (m -> n): g_in needs only a_in[n]
+// and the edge row it streams anyway, so ctx_in[n] = sum g_in*e has no cross-wave dependency: no gate array, no
+// atomics, no LDS, no barrier.  ctx = ctx_out + ctx_in is never formed: the node GRU's input GEMM takes the two
+// halves as a K-split A operand against [W_ih | W_ih] (linearity).
+// HBM view: each e row is read twice (second read = L2 / Infinity-Cache hit), e_in written once; v rows are
+// L2-resident.  A lane owns 8 channels: every row access is one 16-byte (bf16) piece per lane, 1 KiB per wave; four
+// edge rows (+ four vertex rows) are in flight per wave; gate dot products reduce on the DPP path.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(512) void imp_fused_kernel(const T* __restrict__ v, const T* __restrict__ e,
+__global__ __launch_bounds__(256, 3) void imp_fused_kernel(const T* __restrict__ v, const T* __restrict__ e,
                                                         const int64_t* __restrict__ rel, const int* __restrict__ out_ptr,
                                                         const int* __restrict__ out_ids, const int* __restrict__ in_ptr,
                                                         const int* __restrict__ in_ids, int N, int H,
                                                         const float* __restrict__ gw, const float* __restrict__ gb,
                                                         T* __restrict__ e_in, T* __restrict__ ctx2) {
-    __shared__ float red[8][MAXH];
-    const int n = blockIdx.x >> 1, side = blockIdx.x & 1;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const int c0 = lane * 8;
     const bool act = c0 < H;
-    float acc[8];
+    // side 0 units first (heavier), then side 1: unit u < N -> (n=u, out-edges); u >= N -> (n=u-N, in-edges)
+    float w0[8], w1[8], w2[8], w3[8], w4[8], w5[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    float vn[8];
+    for (int j = 0; j < 8; ++j) w0[j] = w1[j] = w2[j] = w3[j] = w4[j] = w5[j] = 0.f;
+    int loaded = -1;
+    for (int u = wave_g; u < 2 * N; u += nwaves) {
+        const int side = u >= N ? 1 : 0, n = side ? u - N : u;
+        if (loaded != side && act) {
+            if (side == 0) {
+                load8(gw + 0 * 2 * H + c0, w0);        // sub_vert, vertex half
+                load8(gw + 2 * 2 * H + c0, w1);        // out_edge, vertex half
+                load8(gw + 0 * 2 * H + H + c0, w2);    // sub_vert, edge half
+                load8(gw + 1 * 2 * H + c0, w3);        // obj_vert, vertex half
+                load8(gw + 1 * 2 * H + H + c0, w4);    // obj_vert, edge half
+                load8(gw + 2 * 2 * H + H + c0, w5);    // out_edge, edge half
+            } else {
+                load8(gw + 3 * 2 * H + c0, w0);        // in_edge, vertex half
+                load8(gw + 3 * 2 * H + H + c0, w1);    // in_edge, edge half
+            }
+        }
+        loaded = side;
+        float vn[8], acc[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) vn[j] = 0.f;
-    if (act) load8(v + (long)n * H + c0, vn);
-    if (side == 0) {
-        float wsv[8], wov[8], wse[8], wobv[8], wobe[8], woe[8];
-        float a_sub = 0.f, a_out = 0.f;
-        if (act) {
-            load8(gw + 0 * 2 * H + c0, wsv);        // sub_vert, vertex half
-            load8(gw + 2 * 2 * H + c0, wov);        // out_edge, vertex half
-            load8(gw + 0 * 2 * H + H + c0, wse);    // sub_vert, edge half
-            load8(gw + 1 * 2 * H + c0, wobv);       // obj_vert, vertex half
-            load8(gw + 1 * 2 * H + H + c0, wobe);   // obj_vert, edge half
-            load8(gw + 2 * 2 * H + H + c0, woe);    // out_edge, edge half
+        for (int j = 0; j < 8; ++j) vn[j] = acc[j] = 0.f;
+        if (act) load8(v + (long)n * H + c0, vn);
+        if (side == 0) {
+            float a_sub = 0.f, a_out = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                a_sub = fmaf(wsv[j], vn[j], a_sub);
-                a_out = fmaf(wov[j], vn[j], a_out);
+                a_sub = fmaf(w0[j], vn[j], a_sub);
+                a_out = fmaf(w1[j], vn[j], a_out);
             }
-        }
-        a_sub = wave_sum(a_sub) + gb[0];
-        a_out = wave_sum(a_out) + gb[2];
-        const float b_obj = gb[1];
-        const int beg = out_ptr[n], end = out_ptr[n + 1];
-        for (int k = beg + wave; k < end; k += 16) {
-            const int k2 = k + 8;
-            const bool two = k2 < end;
-            const int id0 = out_ids[k], id1 = two ? out_ids[k2] : id0;
-            const long o0 = rel[(long)id0 * 3 + 2], o1 = rel[(long)id1 * 3 + 2];
-            float e0[8], e1[8], v0[8], v1[8];
-            if (act) {
-                load8(e + (long)id0 * H + c0, e0);
-                load8(e + (long)id1 * H + c0, e1);
-                load8(v + o0 * H + c0, v0);
-                load8(v + o1 * H + c0, v1);
-            }
-            float p[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (act) {
+            a_sub = wave_sum(a_sub) + gb[0];
+            a_out = wave_sum(a_out) + gb[2];
+            const float b_obj = gb[1];
+            const int beg = out_ptr[n], end = out_ptr[n + 1];
+            for (int k = beg; k < end; k += 4) {
+                int id[4];
+                Raw8<T> er[4], vr[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    p[0] = fmaf(wse[j], e0[j], p[0]);
-                    p[1] = fmaf(wobe[j], e0[j], fmaf(wobv[j], v0[j], p[1]));
-                    p[2] = fmaf(woe[j], e0[j], p[2]);
-                    p[3] = fmaf(wse[j], e1[j], p[3]);
-                    p[4] = fmaf(wobe[j], e1[j], fmaf(wobv[j], v1[j], p[4]));
-                    p[5] = fmaf(woe[j], e1[j], p[5]);
+                for (int q = 0; q < 4; ++q) {
+                    id[q] = out_ids[min(k + q, end - 1)];
+                    const long o = rel[(long)id[q] * 3 + 2];
+                    if (act) {
+                        er[q].load(e + (long)id[q] * H + c0);
+                        vr[q].load(v + o * H + c0);
+                    } else {
+                        er[q].zero();
+                        vr[q].zero();
+                    }
                 }
-            }
 #pragma unroll
-            for (int q = 0; q < 6; ++q) p[q] = wave_sum(p[q]);
-            const float gs0 = sigmoidf_(a_sub + p[0]), go0 = sigmoidf_(p[1] + b_obj), gx0 = sigmoidf_(a_out + p[2]);
-            const float gs1 = sigmoidf_(a_sub + p[3]), go1 = sigmoidf_(p[4] + b_obj), gx1 = two ? sigmoidf_(a_out + p[5]) : 0.f;
-            if (act) {
-                float r[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    r[j] = gs0 * vn[j] + go0 * v0[j];
-                    acc[j] = fmaf(gx0, e0[j], acc[j]);
-                }
-                store8(e_in + (long)id0 * H + c0, r);
-                if (two) {
+                for (int q = 0; q < 4; ++q) {
+                    float ee[8], ov[8];
+                    er[q].get(ee);
+                    vr[q].get(ov);
+                    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        r[j] = gs1 * vn[j] + go1 * v1[j];
-                        acc[j] = fmaf(gx1, e1[j], acc[j]);
+                        p0 = fmaf(w2[j], ee[j], p0);
+                        p1 = fmaf(w4[j], ee[j], fmaf(w3[j], ov[j], p1));
+                        p2 = fmaf(w5[j], ee[j], p2);
                     }
-                    store8(e_in + (long)id1 * H + c0, r);
+                    const float gs = sigmoidf_(a_sub + wave_sum(p0)), go = sigmoidf_(wave_sum(p1) + b_obj);
+                    const float gx = sigmoidf_(a_out + wave_sum(p2));
+                    if (k + q < end && act) {
+                        float r[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            r[j] = gs * vn[j] + go * ov[j];
+                            acc[j] = fmaf(gx, ee[j], acc[j]);
+                        }
+                        store8(e_in + (long)id[q] * H + c0, r);
+                    }
+                }
+            }
+        } else {
+            float a_in = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a_in = fmaf(w0[j], vn[j], a_in);
+            a_in = wave_sum(a_in) + gb[3];
+            const int beg = in_ptr[n], end = in_ptr[n + 1];
+            for (int k = beg; k < end; k += 8) {
+                Raw8<T> er[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int id = in_ids[min(k + q, end - 1)];
+                    if (act) er[q].load(e + (long)id * H + c0);
+                    else er[q].zero();
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float ee[8];
+                    er[q].get(ee);
+                    float p = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) p = fmaf(w1[j], ee[j], p);
+                    const float g = (k + q < end) ? sigmoidf_(a_in + wave_sum(p)) : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(g, ee[j], acc[j]);
                 }
             }
         }
-    } else {
-        float wiv[8], wie[8];
-        float a_in = 0.f;
-        if (act) {
-            load8(gw + 3 * 2 * H + c0, wiv);        // in_edge, vertex half
-            load8(gw + 3 * 2 * H + H + c0, wie);    // in_edge, edge half
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a_in = fmaf(wiv[j], vn[j], a_in);
-        }
-        a_in = wave_sum(a_in) + gb[3];
-        const int beg = in_ptr[n], end = in_ptr[n + 1];
-        for (int k = beg + wave; k < end; k += 16) {
-            const int k2 = k + 8;
-            const bool two = k2 < end;
-            const int id0 = in_ids[k], id1 = two ? in_ids[k2] : id0;
-            float e0[8], e1[8];
-            float p0 = 0.f, p1 = 0.f;
-            if (act) {
-                load8(e + (long)id0 * H + c0, e0);
-                load8(e + (long)id1 * H + c0, e1);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    p0 = fmaf(wie[j], e0[j], p0);
-                    p1 = fmaf(wie[j], e1[j], p1);
-                }
-            }
-            p0 = wave_sum(p0);
-            p1 = wave_sum(p1);
-            const float g0 = sigmoidf_(a_in + p0), g1 = two ? sigmoidf_(a_in + p1) : 0.f;
-            if (act) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fmaf(g0, e0[j], fmaf(g1, e1[j], acc[j]));
-            }
-        }
-    }
-    if (act) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) red[wave][c0 + j] = acc[j];
-    }
-    __syncthreads();
-    T* dst = ctx2 + ((long)side * N + n) * H;
-    for (int c = threadIdx.x; c < H; c += 512) {
-        float t = 0.f;
-#pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8) t += red[w8][c];
-        Elem<T>::st(dst + c, t);
+        if (act) store8(ctx2 + ((long)side * N + n) * H + c0, acc);
     }
 }
 
@@ -387,7 +372,9 @@ extern "C" int sgg_imp_fused_fwd(const void* v, const void* e, const int64_t* re
     if (!v || !e || !rel_inds || !out_ptr || !out_ids || !in_ptr || !in_ids || !gate_w || !gate_b || !e_in || !ctx2 || N < 0 ||
         E < 0 || H <= 0 || (H & 7) || H > MAXH)
         return SGG_ERR_ARG;
-    const dim3 grid(2 * N), blk(512);
+    // one wave per (node, side) unit; at most 8 workgroups of 4 waves per CU, grid-stride beyond that
+    const int wgs = min((2 * N + 3) / 4, 256 * 8);
+    const dim3 grid(wgs), blk(256);
     hipStream_t s = (hipStream_t)stream;
     SGG_DISPATCH_T(dtype,
         hipLaunchKernelGGL(imp_fused_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)v, (const bf16_t*)e, rel_inds, out_ptr, out_ids, in_ptr, in_ids, N, H, gate_w, gate_b, (bf16_t*)e_in, (bf16_t*)ctx2),
