@@ -77,14 +77,14 @@ def imp_iter_ms(model, B, dtype, reps=50):
     imp = model.prepared()['imp']
     e_in, ctx2 = torch.empty_like(e), torch.empty((2, N, H), dtype=dtype, device=dev)
     for _ in range(3):
-        ops.imp_fused(v, e, rel, csr, imp.gate_w, imp.gate_b, e_in, ctx2)
+        ops.imp_fused(v, e, rel, csr, imp.gate_w_c, imp.gate_b, e_in, ctx2)
     torch.cuda.synchronize()
     # `reps` launches captured into one hipGraph so that the host launch path (Python + ctypes, ~10 us per call)
     # is not what is being timed; events bracket the replay on the replay stream
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         for _ in range(reps):
-            ops.imp_fused(v, e, rel, csr, imp.gate_w, imp.gate_b, e_in, ctx2)
+            ops.imp_fused(v, e, rel, csr, imp.gate_w_c, imp.gate_b, e_in, ctx2)
     graph.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

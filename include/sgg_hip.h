@@ -66,9 +66,11 @@ int sgg_pair_index_train(const int64_t* im_inds, int N, const int64_t* gt_rels, 
                          int64_t* rel_labels, int cap, int* count, int* work, void* stream);
 /* CSR lists of the edges by subject node (out_ptr/out_ids) and by object node (in_ptr/in_ids); edges keep ascending
  * order inside a node.  ptr i32[N+1], ids i32[E].  im_inds (optional, i64[N] node->image): when given, rel_inds must be
- * sorted by image (as both pair-index calls emit it) and only the node's own image segment is scanned. */
+ * sorted by image (as both pair-index calls emit it) and only the node's own image segment is scanned.
+ * so (optional) i32[E,2] = (subject, object) per edge; flags (optional) i32[1]: flags[0] = 1 iff the edge list is sorted
+ * by subject (out_ids is the identity), which lets sgg_imp_fused_fwd skip the out-edge index loads. */
 int sgg_edge_csr(const int64_t* rel_inds /*[E,3]*/, int E, int N, const int64_t* im_inds, int* out_ptr, int* out_ids,
-                 int* in_ptr, int* in_ids, void* stream);
+                 int* in_ptr, int* in_ids, int* so, int* flags, void* stream);
 
 /* ---- a-4  RoIAlign (+ fused union box): RelModelBase.node_edge_features, rel_model_base.py:245-260, and
  * [3P] torchvision roi_align(output_size=7, sampling_ratio=2, aligned=False, spatial_scale) ----
@@ -114,12 +116,13 @@ int sgg_imp_edge_ctx_fwd(const void* v, const void* e, const int64_t* rel_inds /
 int sgg_imp_node_scatter_fwd(const void* e, const float* gates, const int* out_ptr, const int* out_ids,
                              const int* in_ptr, const int* in_ids, int N, int H, void* ctx, int dtype, void* stream);
 
-/* Fused form of the three calls above, ONE launch per iteration (the kernel the forward uses): workgroup (n, side);
+/* Fused form of the three calls above, ONE launch per iteration (the kernel the forward uses): units (n, side);
  * side 0 handles n's out-edges (writes e_in rows, reduces ctx2[0][n] = sum g_out*e), side 1 n's in-edges
- * (ctx2[1][n] = sum g_in*e).  ctx = ctx2[0] + ctx2[1]; the node GRU consumes the halves as a K-split GEMM operand. */
-int sgg_imp_fused_fwd(const void* v, const void* e, const int64_t* rel_inds /*[E,3]*/, const int* out_ptr, const int* out_ids,
-                      const int* in_ptr, const int* in_ids, int N, int E, int H, const float* gate_w, const float* gate_b,
-                      void* e_in, void* ctx2 /*[2,N,H]*/, int dtype, void* stream);
+ * (ctx2[1][n] = sum g_in*e).  ctx = ctx2[0] + ctx2[1]; the node GRU consumes the halves as a K-split GEMM operand.
+ * so / flags / CSR lists from sgg_edge_csr; gate_w here is [4,2H] in the COMPUTE dtype (same rows as above). */
+int sgg_imp_fused_fwd(const void* v, const void* e, const int* so /*[E,2]*/, const int* flags, const int* out_ptr,
+                      const int* out_ids, const int* in_ptr, const int* in_ids, int N, int E, int H, const void* gate_w,
+                      const float* gate_b, void* e_in, void* ctx2 /*[2,N,H]*/, int dtype, void* stream);
 
 /* ---- a-9  GRU cell pointwise part: nn.GRUCell, rel_model_stanford.py:36-37,71-72,83,92 ----
  * gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh come from sgg_gemm ([M,3H], gate order r,z,n).

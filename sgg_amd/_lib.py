@@ -26,7 +26,7 @@ SIGNATURES = {
     'sgg_maxpool2x2': [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     'sgg_pair_index_eval': [_P, _P, _I, _I, _P, _I, _P, _P, _P],
     'sgg_pair_index_train': [_P, _I, _P, _I, _P, _P, _I, _P, _P, _P],
-    'sgg_edge_csr': [_P, _I, _I, _P, _P, _P, _P, _P, _P],  # rel, E, N, im_inds, out_ptr, out_ids, in_ptr, in_ids, stream
+    'sgg_edge_csr': [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],  # rel, E, N, im_inds, out_ptr, out_ids, in_ptr, in_ids, so, flags, stream
     'sgg_roi_align_fwd': [_P, _I, _I, _I, _I, _P, _I, _P, _I, _F, _I, _I, _P, _P, _I, _P],
     'sgg_union_rects_fwd': [_P, _P, _I, _I, _F, _P, _P],
     'sgg_union_rect_patches': [_P, _P, _I, _I, _P, _I, _I, _P],
@@ -36,7 +36,7 @@ SIGNATURES = {
     'sgg_imp_node_gate_dots': [_P, _I, _I, _P, _P, _I, _P],
     'sgg_imp_edge_ctx_fwd': [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     'sgg_imp_node_scatter_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P],
-    'sgg_imp_fused_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P],
+    'sgg_imp_fused_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     'sgg_gru_gate_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sgg_eval_tail': [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     'sgg_dropout_fwd': [_P, _L, _F, ctypes.c_uint64, _I, _P],

@@ -130,45 +130,50 @@ __global__ __launch_bounds__(256) void node_scatter_kernel(const T* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 // Fused IMP gather / gate / scatter: ONE launch per iteration (replaces gate_dots + edge_ctx + node_scatter).
-// Node-centric, one WAVE per unit (n, side), persistent over units (the six gate vectors a lane needs stay in
-// registers).  side 0 owns n's out-edges (n -> o): g_sub, g_obj, g_out for each, e_in[e] = g_sub*v[n] + g_obj*v[o]
-// written, ctx_out[n] = sum g_out*e reduced in registers.  side 1 owns n's in-edges (m -> n): g_in needs only a_in[n]
-// and the edge row it streams anyway, so ctx_in[n] = sum g_in*e has no cross-wave dependency: no gate array, no
-// atomics, no LDS, no barrier.  ctx = ctx_out + ctx_in is never formed: the node GRU's input GEMM takes the two
-// halves as a K-split A operand against [W_ih | W_ih] (linearity).
-// HBM view: each e row is read twice (second read = L2 / Infinity-Cache hit), e_in written once; v rows are
-// L2-resident.  A lane owns 8 channels: every row access is one 16-byte (bf16) piece per lane, 1 KiB per wave; four
-// edge rows (+ four vertex rows) are in flight per wave; gate dot products reduce on the DPP path.
+// Node-centric units (n, side), persistent waves.  side 0 owns n's out-edges (n -> o): g_sub, g_obj, g_out for each,
+// e_in[e] = g_sub*v[n] + g_obj*v[o] written, ctx_out[n] = sum g_out*e reduced in registers.  side 1 owns n's in-edges
+// (m -> n): g_in needs only a_in[n] and the edge row it streams anyway, so ctx_in[n] = sum g_in*e has no cross-unit
+// dependency: no gate array, no atomics.  ctx = ctx_out + ctx_in is never formed: the node GRU's input GEMM takes the
+// two halves as a K-split A operand against [W_ih | W_ih] (linearity).
+// W = waves per unit: 1 when there are enough units to fill the chip (no LDS, no barrier), 4 (one workgroup per unit,
+// LDS reduction) for small graphs.  Edge indices come as int32 (s,o) pairs; when the edge list is sorted by subject
+// (flags[0], set by sgg_edge_csr) out-edge ids are the identity and need no index load.  The six gate vectors a lane
+// needs stay packed in registers across units; rows stay packed (4 VGPRs per 8 bf16) until used; the next chunk's
+// object indices are fetched one chunk ahead; gate dot products reduce on the DPP path.
+// HBM view: each e row is read twice (second read = L2 / Infinity-Cache hit), e_in written once; v rows are L2-resident.
+// A lane owns 8 channels: every row access is one 16-byte (bf16) piece per lane, 1 KiB per wave.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int W>
 __global__ __launch_bounds__(256, 3) void imp_fused_kernel(const T* __restrict__ v, const T* __restrict__ e,
-                                                        const int64_t* __restrict__ rel, const int* __restrict__ out_ptr,
-                                                        const int* __restrict__ out_ids, const int* __restrict__ in_ptr,
-                                                        const int* __restrict__ in_ids, int N, int H,
-                                                        const float* __restrict__ gw, const float* __restrict__ gb,
-                                                        T* __restrict__ e_in, T* __restrict__ ctx2) {
-    const int lane = threadIdx.x & 63;
-    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+                                                           const int* __restrict__ so, const int* __restrict__ flags,
+                                                           const int* __restrict__ out_ptr, const int* __restrict__ out_ids,
+                                                           const int* __restrict__ in_ptr, const int* __restrict__ in_ids,
+                                                           int N, int H, const T* __restrict__ gw, const float* __restrict__ gb,
+                                                           T* __restrict__ e_in, T* __restrict__ ctx2) {
+    __shared__ float red[W > 1 ? 4 : 1][W > 1 ? MAXH : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = W > 1 ? wave : 0;
+    const int u0 = W > 1 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    const int ustride = W > 1 ? (int)gridDim.x : (int)gridDim.x * 4;
     const int c0 = lane * 8;
     const bool act = c0 < H;
-    // side 0 units first (heavier), then side 1: unit u < N -> (n=u, out-edges); u >= N -> (n=u-N, in-edges)
-    float w0[8], w1[8], w2[8], w3[8], w4[8], w5[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) w0[j] = w1[j] = w2[j] = w3[j] = w4[j] = w5[j] = 0.f;
+    const bool contig = flags[0] != 0;
+    Raw8<T> w0, w1, w2, w3, w4, w5;
+    w0.zero(); w1.zero(); w2.zero(); w3.zero(); w4.zero(); w5.zero();
     int loaded = -1;
-    for (int u = wave_g; u < 2 * N; u += nwaves) {
+    for (int u = u0; u < 2 * N; u += ustride) {
         const int side = u >= N ? 1 : 0, n = side ? u - N : u;
         if (loaded != side && act) {
             if (side == 0) {
-                load8(gw + 0 * 2 * H + c0, w0);        // sub_vert, vertex half
-                load8(gw + 2 * 2 * H + c0, w1);        // out_edge, vertex half
-                load8(gw + 0 * 2 * H + H + c0, w2);    // sub_vert, edge half
-                load8(gw + 1 * 2 * H + c0, w3);        // obj_vert, vertex half
-                load8(gw + 1 * 2 * H + H + c0, w4);    // obj_vert, edge half
-                load8(gw + 2 * 2 * H + H + c0, w5);    // out_edge, edge half
+                w0.load(gw + 0 * 2 * H + c0);        // sub_vert, vertex half
+                w1.load(gw + 2 * 2 * H + c0);        // out_edge, vertex half
+                w2.load(gw + 0 * 2 * H + H + c0);    // sub_vert, edge half
+                w3.load(gw + 1 * 2 * H + c0);        // obj_vert, vertex half
+                w4.load(gw + 1 * 2 * H + H + c0);    // obj_vert, edge half
+                w5.load(gw + 2 * 2 * H + H + c0);    // out_edge, edge half
             } else {
-                load8(gw + 3 * 2 * H + c0, w0);        // in_edge, vertex half
-                load8(gw + 3 * 2 * H + H + c0, w1);    // in_edge, edge half
+                w0.load(gw + 3 * 2 * H + c0);        // in_edge, vertex half
+                w1.load(gw + 3 * 2 * H + H + c0);    // in_edge, edge half
             }
         }
         loaded = side;
@@ -178,30 +183,58 @@ __global__ __launch_bounds__(256, 3) void imp_fused_kernel(const T* __restrict__
         if (act) load8(v + (long)n * H + c0, vn);
         if (side == 0) {
             float a_sub = 0.f, a_out = 0.f;
+            {
+                float t0[8], t1[8];
+                w0.get(t0);
+                w1.get(t1);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                a_sub = fmaf(w0[j], vn[j], a_sub);
-                a_out = fmaf(w1[j], vn[j], a_out);
+                for (int j = 0; j < 8; ++j) {
+                    a_sub = fmaf(t0[j], vn[j], a_sub);
+                    a_out = fmaf(t1[j], vn[j], a_out);
+                }
             }
             a_sub = wave_sum(a_sub) + gb[0];
             a_out = wave_sum(a_out) + gb[2];
             const float b_obj = gb[1];
             const int beg = out_ptr[n], end = out_ptr[n + 1];
-            for (int k = beg; k < end; k += 4) {
+            int idn[4], on[4];   // ids / objects of the NEXT chunk (fetched one chunk ahead)
+            {
+                const int k = beg + sub * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int kk = min(k + q, end - 1);
+                    idn[q] = (contig || kk < 0) ? kk : out_ids[kk];
+                    on[q] = kk >= 0 ? so[2 * (long)idn[q] + 1] : 0;
+                }
+            }
+            for (int k = beg + sub * 4; k < end; k += 4 * W) {
                 int id[4];
                 Raw8<T> er[4], vr[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    id[q] = out_ids[min(k + q, end - 1)];
-                    const long o = rel[(long)id[q] * 3 + 2];
+                    id[q] = idn[q];
                     if (act) {
                         er[q].load(e + (long)id[q] * H + c0);
-                        vr[q].load(v + o * H + c0);
+                        vr[q].load(v + (long)on[q] * H + c0);
                     } else {
                         er[q].zero();
                         vr[q].zero();
                     }
                 }
+                {
+                    const int kn = k + 4 * W;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int kk = min(kn + q, end - 1);
+                        idn[q] = contig ? kk : out_ids[kk];
+                        on[q] = so[2 * (long)idn[q] + 1];
+                    }
+                }
+                float ws[8], wobv[8], wobe[8], wo[8];
+                w2.get(ws);
+                w3.get(wobv);
+                w4.get(wobe);
+                w5.get(wo);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float ee[8], ov[8];
@@ -210,9 +243,9 @@ __global__ __launch_bounds__(256, 3) void imp_fused_kernel(const T* __restrict__
                     float p0 = 0.f, p1 = 0.f, p2 = 0.f;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        p0 = fmaf(w2[j], ee[j], p0);
-                        p1 = fmaf(w4[j], ee[j], fmaf(w3[j], ov[j], p1));
-                        p2 = fmaf(w5[j], ee[j], p2);
+                        p0 = fmaf(ws[j], ee[j], p0);
+                        p1 = fmaf(wobe[j], ee[j], fmaf(wobv[j], ov[j], p1));
+                        p2 = fmaf(wo[j], ee[j], p2);
                     }
                     const float gs = sigmoidf_(a_sub + wave_sum(p0)), go = sigmoidf_(wave_sum(p1) + b_obj);
                     const float gx = sigmoidf_(a_out + wave_sum(p2));
@@ -229,11 +262,17 @@ __global__ __launch_bounds__(256, 3) void imp_fused_kernel(const T* __restrict__
             }
         } else {
             float a_in = 0.f;
+            float wie[8];
+            {
+                float t0[8];
+                w0.get(t0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a_in = fmaf(w0[j], vn[j], a_in);
+                for (int j = 0; j < 8; ++j) a_in = fmaf(t0[j], vn[j], a_in);
+            }
+            w1.get(wie);
             a_in = wave_sum(a_in) + gb[3];
             const int beg = in_ptr[n], end = in_ptr[n + 1];
-            for (int k = beg; k < end; k += 8) {
+            for (int k = beg + sub * 8; k < end; k += 8 * W) {
                 Raw8<T> er[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -247,14 +286,25 @@ __global__ __launch_bounds__(256, 3) void imp_fused_kernel(const T* __restrict__
                     er[q].get(ee);
                     float p = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) p = fmaf(w1[j], ee[j], p);
+                    for (int j = 0; j < 8; ++j) p = fmaf(wie[j], ee[j], p);
                     const float g = (k + q < end) ? sigmoidf_(a_in + wave_sum(p)) : 0.f;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) acc[j] = fmaf(g, ee[j], acc[j]);
                 }
             }
         }
-        if (act) store8(ctx2 + ((long)side * N + n) * H + c0, acc);
+        T* dst = ctx2 + ((long)side * N + n) * H;
+        if constexpr (W > 1) {
+            __syncthreads();
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[wave][c0 + j] = acc[j];
+            }
+            __syncthreads();
+            for (int c = threadIdx.x; c < H; c += 256) Elem<T>::st(dst + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+        } else {
+            if (act) store8(dst + c0, acc);
+        }
     }
 }
 
@@ -365,20 +415,27 @@ extern "C" int sgg_gru_gate_fwd(const void* gi, const void* gh, const float* b_h
     return SGG_OK;
 }
 
-extern "C" int sgg_imp_fused_fwd(const void* v, const void* e, const int64_t* rel_inds, const int* out_ptr, const int* out_ids,
-                                 const int* in_ptr, const int* in_ids, int N, int E, int H, const float* gate_w,
-                                 const float* gate_b, void* e_in, void* ctx2, int dtype, void* stream) {
+extern "C" int sgg_imp_fused_fwd(const void* v, const void* e, const int* so, const int* flags, const int* out_ptr,
+                                 const int* out_ids, const int* in_ptr, const int* in_ids, int N, int E, int H,
+                                 const void* gate_w, const float* gate_b, void* e_in, void* ctx2, int dtype, void* stream) {
     if (N == 0) return SGG_OK;
-    if (!v || !e || !rel_inds || !out_ptr || !out_ids || !in_ptr || !in_ids || !gate_w || !gate_b || !e_in || !ctx2 || N < 0 ||
+    if (!v || !e || !so || !flags || !out_ptr || !out_ids || !in_ptr || !in_ids || !gate_w || !gate_b || !e_in || !ctx2 || N < 0 ||
         E < 0 || H <= 0 || (H & 7) || H > MAXH)
         return SGG_ERR_ARG;
-    // one wave per (node, side) unit; at most 8 workgroups of 4 waves per CU, grid-stride beyond that
-    const int wgs = min((2 * N + 3) / 4, 256 * 8);
-    const dim3 grid(wgs), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    SGG_DISPATCH_T(dtype,
-        hipLaunchKernelGGL(imp_fused_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)v, (const bf16_t*)e, rel_inds, out_ptr, out_ids, in_ptr, in_ids, N, H, gate_w, gate_b, (bf16_t*)e_in, (bf16_t*)ctx2),
-        hipLaunchKernelGGL(imp_fused_kernel<float>, grid, blk, 0, s, (const float*)v, (const float*)e, rel_inds, out_ptr, out_ids, in_ptr, in_ids, N, H, gate_w, gate_b, (float*)e_in, (float*)ctx2));
+    const int units = 2 * N;
+    // enough units to give every CU >= 8 single-wave units: one wave per unit; otherwise one workgroup (4 waves) per unit
+    if (units >= 256 * 8) {
+        const dim3 grid(min((units + 3) / 4, 256 * 3)), blk(256);
+        SGG_DISPATCH_T(dtype,
+            hipLaunchKernelGGL((imp_fused_kernel<bf16_t, 1>), grid, blk, 0, s, (const bf16_t*)v, (const bf16_t*)e, so, flags, out_ptr, out_ids, in_ptr, in_ids, N, H, (const bf16_t*)gate_w, gate_b, (bf16_t*)e_in, (bf16_t*)ctx2),
+            hipLaunchKernelGGL((imp_fused_kernel<float, 1>), grid, blk, 0, s, (const float*)v, (const float*)e, so, flags, out_ptr, out_ids, in_ptr, in_ids, N, H, (const float*)gate_w, gate_b, (float*)e_in, (float*)ctx2));
+    } else {
+        const dim3 grid(units), blk(256);
+        SGG_DISPATCH_T(dtype,
+            hipLaunchKernelGGL((imp_fused_kernel<bf16_t, 4>), grid, blk, 0, s, (const bf16_t*)v, (const bf16_t*)e, so, flags, out_ptr, out_ids, in_ptr, in_ids, N, H, (const bf16_t*)gate_w, gate_b, (bf16_t*)e_in, (bf16_t*)ctx2),
+            hipLaunchKernelGGL((imp_fused_kernel<float, 4>), grid, blk, 0, s, (const float*)v, (const float*)e, so, flags, out_ptr, out_ids, in_ptr, in_ids, N, H, (const float*)gate_w, gate_b, (float*)e_in, (float*)ctx2));
+    }
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

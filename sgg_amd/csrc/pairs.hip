@@ -165,7 +165,7 @@ __device__ __forceinline__ int bound_img(const int64_t* rel, int E, int64_t img,
 template <bool WRITE>
 __global__ __launch_bounds__(64) void csr_kernel(const int64_t* __restrict__ rel, int E, int N, const int64_t* __restrict__ im,
                                                  int* __restrict__ optr, int* __restrict__ iptr, int* __restrict__ oids,
-                                                 int* __restrict__ iids) {
+                                                 int* __restrict__ iids, int* __restrict__ so, int* __restrict__ flags) {
     const int n = blockIdx.x >> 1, side = blockIdx.x & 1, lane = threadIdx.x;
     int* ptr = side ? iptr : optr;
     int* ids = side ? iids : oids;
@@ -179,11 +179,23 @@ __global__ __launch_bounds__(64) void csr_kernel(const int64_t* __restrict__ rel
         const int e = e0 + lane;
         const bool ok = e < e_hi && rel[3 * (long)e + 1 + side] == n;
         const unsigned long long m = __ballot(ok);
-        if (WRITE && ok) ids[base + lanes_below(m, lane)] = e;
+        if (WRITE && ok) {
+            const int pos = base + lanes_below(m, lane);
+            ids[pos] = e;
+            if (side == 0) {
+                if (so) {   // every edge is an out-edge of exactly one node: compact int32 (subject, object)
+                    so[2 * (long)e] = n;
+                    so[2 * (long)e + 1] = (int)rel[3 * (long)e + 2];
+                }
+                if (flags && pos != e) flags[0] = 0;   // out-lists are NOT the identity (edges not sorted by subject)
+            }
+        }
         base += __popcll(m);
     }
     if (!WRITE && lane == 0) ptr[n] = base;
 }
+
+__global__ void set_flag_kernel(int* flags) { flags[0] = 1; }
 
 }  // namespace
 
@@ -217,13 +229,14 @@ extern "C" int sgg_pair_index_train(const int64_t* im_inds, int N, const int64_t
 }
 
 extern "C" int sgg_edge_csr(const int64_t* rel_inds, int E, int N, const int64_t* im_inds, int* out_ptr, int* out_ids,
-                            int* in_ptr, int* in_ids, void* stream) {
+                            int* in_ptr, int* in_ids, int* so, int* flags, void* stream) {
     if (!rel_inds || !out_ptr || !out_ids || !in_ptr || !in_ids || N <= 0 || E < 0) return SGG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(csr_kernel<false>, dim3(2 * N), dim3(64), 0, s, rel_inds, E, N, im_inds, out_ptr, in_ptr, out_ids, in_ids);
+    if (flags) hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(1), 0, s, flags);
+    hipLaunchKernelGGL(csr_kernel<false>, dim3(2 * N), dim3(64), 0, s, rel_inds, E, N, im_inds, out_ptr, in_ptr, out_ids, in_ids, so, flags);
     hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, s, out_ptr, N, (int*)nullptr);
     hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, s, in_ptr, N, (int*)nullptr);
-    hipLaunchKernelGGL(csr_kernel<true>, dim3(2 * N), dim3(64), 0, s, rel_inds, E, N, im_inds, out_ptr, in_ptr, out_ids, in_ids);
+    hipLaunchKernelGGL(csr_kernel<true>, dim3(2 * N), dim3(64), 0, s, rel_inds, E, N, im_inds, out_ptr, in_ptr, out_ids, in_ids, so, flags);
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

@@ -18,6 +18,7 @@ class ImpWeights(object):
             setattr(w, g + '_b_ih', p[g + '.bias_ih'].detach().float().contiguous())
             setattr(w, g + '_b_hh', p[g + '.bias_hh'].detach().float().contiguous())
         w.gate_w = torch.cat([p[g + '.0.weight'].detach().float().reshape(1, -1) for g in GATES], 0).contiguous()
+        w.gate_w_c = w.gate_w.to(dtype).contiguous()      # compute-dtype copy for the fused kernel
         w.gate_b = torch.cat([p[g + '.0.bias'].detach().float().reshape(1) for g in GATES], 0).contiguous()
         w.H = w.edge_gru_w_hh.shape[1]
         # node GRU input weight doubled along K: ctx = ctx_out + ctx_in is fed as a K-split operand (linearity)
@@ -41,7 +42,7 @@ def message_pass(rel_rep, obj_rep, rel_inds, csr, wts, mp_iter, dtype):
     vert = _gru(wts, 'node_gru', obj_rep, None, dtype)                       # :71
     edge = _gru(wts, 'edge_gru', rel_rep, None, dtype)                       # :72
     for _ in range(mp_iter):                                                 # :74
-        e_in, ctx2 = ops.imp_fused(vert, edge, rel_inds, csr, wts.gate_w, wts.gate_b)   # :76-81,86-91 in one launch
+        e_in, ctx2 = ops.imp_fused(vert, edge, rel_inds, csr, wts.gate_w_c, wts.gate_b)   # :76-81,86-91 in one launch
         edge_new = _gru(wts, 'edge_gru', e_in, edge, dtype)                  # :83
         # :92  node_gru(ctx_out + ctx_in, vert): the sum rides in the GEMM's K axis
         gi = ops.gemm(ctx2[0], wts.node_gru_w_ih2, wts.node_gru_b_ih, out_dtype=torch.float32, A2=ctx2[1])

@@ -102,9 +102,11 @@ def edge_csr(rel_inds, N, im_inds=None):
     in_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
     out_ids = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
     in_ids = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    so = torch.empty((max(E, 1), 2), dtype=torch.int32, device=dev)
+    flags = torch.empty(1, dtype=torch.int32, device=dev)
     _lib.call('sgg_edge_csr', _p(rel_inds, torch.int64), E, N, _p(im_inds, torch.int64) if im_inds is not None else None,
-              _p(out_ptr), _p(out_ids), _p(in_ptr), _p(in_ids), _stream())
-    return out_ptr, out_ids, in_ptr, in_ids
+              _p(out_ptr), _p(out_ids), _p(in_ptr), _p(in_ids), _p(so), _p(flags), _stream())
+    return out_ptr, out_ids, in_ptr, in_ids, so, flags
 
 
 # ---------------------------------------------------------------- a-4
@@ -190,7 +192,7 @@ def imp_edge_ctx(v, e, rel_inds, dots, gate_w, gate_b, e_in=None, gates=None):
 
 def imp_node_scatter(e, gates, csr, N, ctx=None):
     H = e.shape[1]
-    out_ptr, out_ids, in_ptr, in_ids = csr
+    out_ptr, out_ids, in_ptr, in_ids = csr[:4]
     if ctx is None:
         ctx = torch.empty((N, H), dtype=e.dtype, device=e.device)
     _lib.call('sgg_imp_node_scatter_fwd', _p(e), _p(gates, torch.float32), _p(out_ptr), _p(out_ids), _p(in_ptr),
@@ -199,16 +201,17 @@ def imp_node_scatter(e, gates, csr, N, ctx=None):
 
 
 def imp_fused(v, e, rel_inds, csr, gate_w, gate_b, e_in=None, ctx2=None):
-    """One launch per IMP iteration: -> (e_in [E,H], ctx2 [2,N,H]) with ctx = ctx2[0] + ctx2[1]."""
+    """One launch per IMP iteration: -> (e_in [E,H], ctx2 [2,N,H]) with ctx = ctx2[0] + ctx2[1].
+    gate_w: [4,2H] in the compute dtype of v/e."""
     N, H = v.shape
     E = e.shape[0]
-    out_ptr, out_ids, in_ptr, in_ids = csr
+    out_ptr, out_ids, in_ptr, in_ids, so, flags = csr
     if e_in is None:
         e_in = torch.empty_like(e)
     if ctx2 is None:
         ctx2 = torch.empty((2, N, H), dtype=v.dtype, device=v.device)
-    _lib.call('sgg_imp_fused_fwd', _p(v), _p(e), _p(rel_inds, torch.int64), _p(out_ptr), _p(out_ids), _p(in_ptr), _p(in_ids),
-              N, E, H, _p(gate_w, torch.float32), _p(gate_b, torch.float32), _p(e_in), _p(ctx2), dt(v), _stream())
+    _lib.call('sgg_imp_fused_fwd', _p(v), _p(e), _p(so), _p(flags), _p(out_ptr), _p(out_ids), _p(in_ptr), _p(in_ids),
+              N, E, H, _p(gate_w, v.dtype), _p(gate_b, torch.float32), _p(e_in), _p(ctx2), dt(v), _stream())
     return e_in, ctx2
 
 
@@ -331,7 +334,7 @@ def imp_edge_ctx_bwd(v, e, rel_inds, dots, gate_w, gate_b, d_e_in, d_ctx, d_e):
 
 def imp_node_scatter_bwd(d_e_in, gsave, da, csr, gate_w, d_v):
     N, H = d_v.shape
-    out_ptr, out_ids, in_ptr, in_ids = csr
+    out_ptr, out_ids, in_ptr, in_ids = csr[:4]
     nsum = torch.empty((N, 4), dtype=torch.float32, device=d_v.device)
     _lib.call('sgg_imp_node_scatter_bwd', _p(d_e_in), _p(gsave), _p(da), _p(out_ptr), _p(out_ids), _p(in_ptr), _p(in_ids),
               _p(gate_w, torch.float32), N, H, _p(d_v), _p(nsum), dt(d_v), _stream())

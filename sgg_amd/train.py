@@ -149,7 +149,7 @@ class PredictFn(torch.autograd.Function):
         for i in range(model.mp_iter):
             v_i, e_i = HN[i * N:(i + 1) * N], HE[i * E:(i + 1) * E]
             dots = ops.imp_node_gate_dots(v_i, imp.gate_w)                      # saved for the backward
-            _, ctx2 = ops.imp_fused(v_i, e_i, rel_inds, csr, imp.gate_w, imp.gate_b, e_in=XE[(i + 1) * E:(i + 2) * E])
+            _, ctx2 = ops.imp_fused(v_i, e_i, rel_inds, csr, imp.gate_w_c, imp.gate_b, e_in=XE[(i + 1) * E:(i + 2) * E])
             ctx_i = XN[(i + 1) * N:(i + 2) * N]                                # ctx = ctx_out + ctx_in (kept for d W_ih)
             ctx_i.copy_(ctx2[0])
             ops.add_(ctx_i, ctx2[1])
