@@ -143,13 +143,15 @@ def test_trainer_step_updates_weights_and_refreshes_operands(env):
     from sgg_amd.trainer import Trainer
     model.load_state_dict(sd)
     model.set_compute_dtype(torch.bfloat16)
-    tr = Trainer(model, lr=1e-3)
+    model.dropout_p = 0.0                           # deterministic objective for the monotonicity check
+    tr = Trainer(model, lr=2e-2)
     dev_batch = list(batch)
     l0 = float(tr.step(tuple(dev_batch)))
     k0 = model._prep['key']
-    for _ in range(4):
+    for _ in range(8):
         l1 = float(tr.step(tuple(dev_batch)))
     assert model._prep['key'] != k0                 # derived bf16 operands were rebuilt after the in-place update
     assert l1 < l0
     assert not any(p.requires_grad for n, p in model.named_parameters() if n.startswith('detector.'))
+    model.dropout_p = 0.5
     model.eval()
