@@ -76,8 +76,8 @@ int sgg_edge_csr(const int64_t* rel_inds /*[E,3]*/, int E, int N, const int64_t*
  * [3P] torchvision roi_align(output_size=7, sampling_ratio=2, aligned=False, spatial_scale) ----
  * fmap [B,H,W,C] NHWC.  rois f32[Nroi,5]=(img,x1,y1,x2,y2).  pairs == NULL: out[r] = align(rois[r]), R = Nroi.
  * pairs i64[R,2]: out[r] = align(union(rois[p0], rois[p1])) (rel_model_base.py:248-250).
- * add_ec (optional, f32[R,C]): out[r,ph,pw,c] += add_ec[r,c]  (the broadcast add of lib/get_union_boxes.py:101,
- * fused).  out [R,P,P,C]. */
+ * add_ec (optional, f32[R,C]): out[r,c,ph,pw] += add_ec[r,c]  (the broadcast add of lib/get_union_boxes.py:101,
+ * fused).  out [R,C,P,P] -- the reference's layout, so fc6 consumes it with un-permuted weights. */
 int sgg_roi_align_fwd(const void* fmap, int B, int H, int W, int C, const float* rois, int Nroi, const int64_t* pairs,
                       int R, float spatial_scale, int P, int sampling, const float* add_ec, void* out, int dtype,
                       void* stream);
@@ -91,14 +91,17 @@ int sgg_union_rect_patches(const float* rois, const int64_t* pairs, int E, int P
                            void* stream);
 /* MaxPool2d(3,2,1) over the 2x2 map = max over 4 consecutive rows (lib/get_union_boxes.py:55). in[E*4,C] -> out[E,C] */
 int sgg_max4_rows(const void* in, void* out, int E, int C, int dtype, void* stream);
-/* x[r,p,c] += add[r,c] in place (lib/get_union_boxes.py:101 when the add is not fused in RoIAlign). */
+/* x[r,c,p] += add[r,c] in place (lib/get_union_boxes.py:101 when the add is not fused in RoIAlign). */
 int sgg_bcast_add(void* x, const float* add_rc, int R, int PP, int C, int dtype, void* stream);
 
 /* ---- a-7  dense projections (nn.Linear): rel_model_stanford.py:29-37,103-107; rel_model_base.py:110-111 ----
  * C[M,N] = post_scale * act(A[M,K] . W[N,K]^T + bias) + post_shift.   A may be split along K in two pieces:
  * A[:, :K1] from A (lda) and A[:, K1:] from A2 (lda2) (K1 == K when A2 is NULL).  K, K1 multiples of 64 (bf16)
- * / 32 (f32); lda, lda2, ldw multiples of 8 elements; 16-byte aligned bases.  bias/post_* are f32[N] or NULL. */
-int sgg_gemm(const void* A, int lda, const void* A2, int lda2, int K1, const void* W, int ldw, const float* bias,
+ * / 32 (f32); lda, lda2, ldw multiples of 8 elements; 16-byte aligned bases.  bias/post_* are f32[N] or NULL.
+ * W2 (optional, needs A2): the weights of the second K segment as their own [N, K-K1] matrix (row stride ldw2);
+ * when NULL, W holds all K columns. */
+int sgg_gemm(const void* A, int lda, const void* A2, int lda2, int K1, const void* W, int ldw, const void* W2, int ldw2,
+             const float* bias,
              const float* post_scale, const float* post_shift, void* C, int ldc, int M, int N, int K, int act,
              int in_dtype, int out_dtype, void* stream);
 
@@ -194,16 +197,15 @@ int sgg_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, 
 /* out[n][p][c] = in[n][c][p]  (fc6 K-order (c,ph,pw) -> (ph,pw,c); conv OIHW -> O(HW)I) */
 int sgg_permute_ncp_to_npc(const void* in, void* out, int Nn, int C, int Pp, int in_dtype, int out_dtype, void* stream);
 
-/* out[c][r] = in[r][c] (row strides in elements); used to feed d W = dY^T X to sgg_gemm */
-int sgg_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int R, int C, int in_dtype, int out_dtype,
+/* out[c][r] = in[r][c] (+ add[r][c / group], add f32 with row stride ld_add, or NULL); row strides in elements.
+ * Feeds d W = dY^T X to sgg_gemm; the add form builds (edge_feat + conv(rects))^T for fc6's weight gradient. */
+int sgg_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int R, int C, const float* add, int64_t ld_add,
+                  int group, int in_dtype, int out_dtype, void* stream);
+/* out[n][c] = sum_{p<group} in[n][c*group + p]  (fp32 in): fc6's folded columns W6sum[n,c] = sum_p W6[n,c,p] */
+int sgg_group_sum(const float* in, int64_t ld_in, void* out, int64_t ld_out, int Nn, int C, int group, int out_dtype,
                   void* stream);
 /* y += x (n multiple of 8) */
 int sgg_add(void* y, const void* x, int64_t n, int y_dtype, int x_dtype, void* stream);
-/* out[n][c][p] = in[n][p*C + c] (+ add[n][c]): fc6 weight gradient back to the reference's (c,ph,pw) K order, plus the
- * folded rect-conv term */
-int sgg_unpermute_add(const float* in, int64_t ld_in, const float* add, int64_t ld_add, float* out, int Nn, int C, int Pp,
-                      void* stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -32,7 +32,7 @@ SIGNATURES = {
     'sgg_union_rect_patches': [_P, _P, _I, _I, _P, _I, _I, _P],
     'sgg_max4_rows': [_P, _P, _I, _I, _I, _P],
     'sgg_bcast_add': [_P, _P, _I, _I, _I, _I, _P],
-    'sgg_gemm': [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    'sgg_gemm': [_P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'sgg_imp_node_gate_dots': [_P, _I, _I, _P, _P, _I, _P],
     'sgg_imp_edge_ctx_fwd': [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     'sgg_imp_node_scatter_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P],
@@ -50,9 +50,9 @@ SIGNATURES = {
     'sgg_imp_edge_ctx_bwd': [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     'sgg_imp_node_scatter_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
     'sgg_rank4_reduce': [_P, _P, _I, _I, _P, _I, _I, _P],
-    'sgg_transpose': [_P, _L, _P, _L, _I, _I, _I, _I, _P],
+    'sgg_transpose': [_P, _L, _P, _L, _I, _I, _P, _L, _I, _I, _I, _P],
+    'sgg_group_sum': [_P, _L, _P, _L, _I, _I, _I, _I, _P],
     'sgg_add': [_P, _P, _L, _I, _I, _P],
-    'sgg_unpermute_add': [_P, _L, _P, _L, _P, _I, _I, _I, _P],
     'sgg_sqnorm_acc': [_P, _L, _P, _I, _P],
     'sgg_sgd_step': [_P, _P, _P, _L, _F, _F, _F, _I, _P, _F, _F, _I, _P],
     'sgg_cast': [_P, _P, _L, _I, _I, _P],

@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
     const char* arp[LA];
     const char* arp2[LA];
     const char* brp[LB];
+    const char* brp2[LB];
 #pragma unroll
     for (int j = 0; j < LA; ++j) {
         const int r = (wave * LA + j) * 8 + lrow;
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
         const int n = min(n0 + r, g.N - 1);
         brp[j] = g.Wt + (long)n * g.ldw_b + chunk * 16;
+        brp2[j] = (!CONV && g.W2) ? g.W2 + (long)n * g.ldw2_b + chunk * 16 : nullptr;
     }
     const int tpc = CONV ? (g.Cin * ESZ) / ROWB : 1;  // k-tiles per conv tap
 
@@ -87,9 +89,10 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < LA; ++j)
             glds16((seg2 ? arp2[j] : arp[j]) + koff, sa + (wave * LA + j) * 8 * ROWB);
-        const long koffb = (long)kt * ROWB;
+        const bool wseg2 = !CONV && g.W2 && kt >= g.nt1;
+        const long koffb = (long)(wseg2 ? kt - g.nt1 : kt) * ROWB;
 #pragma unroll
-        for (int j = 0; j < LB; ++j) glds16(brp[j] + koffb, sb + (wave * LB + j) * 8 * ROWB);
+        for (int j = 0; j < LB; ++j) glds16((wseg2 ? brp2[j] : brp[j]) + koffb, sb + (wave * LB + j) * 8 * ROWB);
     };
 
     f32x16 acc[2][2];
@@ -247,8 +250,8 @@ int dispatch(GemmArgs g, bool bf16, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int sgg_gemm(const void* A, int lda, const void* A2, int lda2, int K1, const void* W, int ldw,
-                        const float* bias, const float* post_scale, const float* post_shift, void* C, int ldc, int M,
+extern "C" int sgg_gemm(const void* A, int lda, const void* A2, int lda2, int K1, const void* W, int ldw, const void* W2,
+                        int ldw2, const float* bias, const float* post_scale, const float* post_shift, void* C, int ldc, int M,
                         int N, int K, int act, int in_dtype, int out_dtype, void* stream) {
     if (in_dtype != SGG_F32 && in_dtype != SGG_BF16) return SGG_ERR_DTYPE;
     if (out_dtype != SGG_F32 && out_dtype != SGG_BF16) return SGG_ERR_DTYPE;
@@ -258,12 +261,13 @@ extern "C" int sgg_gemm(const void* A, int lda, const void* A2, int lda2, int K1
     if (!A || !W || !C || M < 0 || N < 0 || K <= 0 || K % bke) return SGG_ERR_ARG;
     if (!A2) K1 = K;
     if (K1 <= 0 || K1 > K || K1 % bke) return SGG_ERR_ARG;
-    if ((lda & 7) || (ldw & 7) || (A2 && (lda2 & 7))) return SGG_ERR_ARG;
+    if ((lda & 7) || (ldw & 7) || (A2 && (lda2 & 7)) || (W2 && (ldw2 & 7))) return SGG_ERR_ARG;
+    if (W2 && (!A2 || (((uintptr_t)W2) & 15) || ldw2 < K - K1 || ldw < K1)) return SGG_ERR_ARG;
     if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)(A2 ? A2 : A)) & 15) return SGG_ERR_ARG;
-    if (lda < K1 || ldw < K || ldc < N || (A2 && lda2 < K - K1)) return SGG_ERR_ARG;
+    if (lda < K1 || (!W2 && ldw < K) || ldc < N || (A2 && lda2 < K - K1)) return SGG_ERR_ARG;
     GemmArgs g{};
-    g.A = (const char*)A; g.A2 = (const char*)A2; g.Wt = (const char*)W;
-    g.lda_b = (long)lda * esz; g.lda2_b = (long)lda2 * esz; g.ldw_b = (long)ldw * esz;
+    g.A = (const char*)A; g.A2 = (const char*)A2; g.Wt = (const char*)W; g.W2 = (const char*)W2;
+    g.lda_b = (long)lda * esz; g.lda2_b = (long)lda2 * esz; g.ldw_b = (long)ldw * esz; g.ldw2_b = (long)ldw2 * esz;
     g.nt1 = K1 / bke; g.nt = K / bke;
     g.bias = bias; g.pscale = post_scale; g.pshift = post_shift;
     g.C = (char*)C; g.ldc = ldc; g.M = M; g.N = N; g.act = act; g.out_bf16 = out_dtype == SGG_BF16;

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
         } else {
             const int n = min(n0 + r, g.N - 1);
             rp[j] = g.Wt + (long)n * g.ldw_b + chunk * 16;
-            rp2[j] = nullptr;
+            rp2[j] = (!CONV && g.W2) ? g.W2 + (long)n * g.ldw2_b + chunk * 16 : nullptr;
         }
     }
     const int tpc = CONV ? (g.Cin * ESZ) / ROW : 1;
@@ -76,7 +76,8 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
                 koff = (long)(seg2 ? kt - g.nt1 : kt) * ROW;
             }
         } else {
-            koff = (long)kt * ROW;
+            seg2 = !CONV && g.W2 && kt >= g.nt1;
+            koff = (long)(seg2 ? kt - g.nt1 : kt) * ROW;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) glds16((seg2 ? rp2[j] : rp[j]) + koff, dst + j * 16 * ROW);
@@ -138,7 +139,8 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
                     koff = (long)(seg2 ? pf - g.nt1 : pf) * ROW;
                 }
             } else {
-                koff = (long)pf * ROW;
+                seg2 = !CONV && g.W2 && pf >= g.nt1;
+                koff = (long)(seg2 ? pf - g.nt1 : pf) * ROW;
             }
         }
         __builtin_amdgcn_s_setprio(1);

@@ -10,7 +10,8 @@ struct GemmArgs {
     const char* A;
     const char* A2;
     const char* Wt;
-    long lda_b, lda2_b, ldw_b;  // bytes
+    const char* W2;             // optional second K-segment of the weights (rows = N, k-tiles >= nt1)
+    long lda_b, lda2_b, ldw_b, ldw2_b;  // bytes
     int nt1, nt;                // k-tiles in segment 1 / total (in units of the kernel's K-tile)
     const float* bias;
     const float* pscale;

@@ -97,18 +97,26 @@ __global__ __launch_bounds__(256) void max4_kernel(const T* __restrict__ in, T* 
     store8(out + e * C + c, a);
 }
 
+// x[r][c][p] += add[r][c]  (8 consecutive elements of a row per thread)
 template <typename T>
 __global__ __launch_bounds__(256) void bcast_add_kernel(T* __restrict__ x, const float* __restrict__ add, long total, int PP,
                                                         int C) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // index over R*PP*C/8
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // index over R*C*PP/8
     if (i >= total) return;
-    const int c8 = C >> 3;
-    const int c = (int)(i % c8) * 8;
-    const long r = i / ((long)c8 * PP);
+    const long row8 = (long)C * PP / 8;
+    const long r = i / row8;
+    const int L0 = (int)(i - r * row8) * 8;
     float a[8];
     load8(x + i * 8, a);
+    int c = L0 / PP, p = L0 - c * PP;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] += add[r * C + c + k];
+    for (int k = 0; k < 8; ++k) {
+        a[k] += add[r * C + c];
+        if (++p == PP) {
+            p = 0;
+            ++c;
+        }
+    }
     store8(x + i * 8, a);
 }
 
@@ -155,8 +163,8 @@ extern "C" int sgg_max4_rows(const void* in, void* out, int E, int C, int dtype,
 
 extern "C" int sgg_bcast_add(void* x, const float* add_rc, int R, int PP, int C, int dtype, void* stream) {
     if (R == 0) return SGG_OK;
-    if (!x || !add_rc || R < 0 || PP <= 0 || C <= 0 || (C & 7)) return SGG_ERR_ARG;
-    const long total = (long)R * PP * (C / 8);
+    if (!x || !add_rc || R < 0 || PP <= 0 || C <= 0 || (((long)C * PP) & 7)) return SGG_ERR_ARG;
+    const long total = (long)R * ((long)C * PP / 8);
     const int grid = (int)((total + 255) / 256);
     if (dtype == SGG_BF16)
         hipLaunchKernelGGL(bcast_add_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, add_rc, total, PP, C);

@@ -33,22 +33,66 @@ __global__ __launch_bounds__(256) void permute_kernel(const TI* __restrict__ in,
     }
 }
 
-// out[c][r] = in[r][c] for r < R, c < C (row strides ld_in / ld_out); 32x32 tiles through LDS
+// out[c][r] = in[r][c] (+ add[r][c / group]) for r < R, c < C (row strides ld_in / ld_out).
+// 64x64 tiles through LDS: both the read (along c) and the write (along r) are 16-byte (bf16) / 32-byte (f32)
+// pieces per lane when the strides allow it; ragged edges fall back to scalars.
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ in, long ld_in, TO* __restrict__ out, long ld_out,
-                                                        int R, int C) {
-    __shared__ float t[32][33];
-    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int k = ty; k < 32; k += 8) {
-        const int r = r0 + k, c = c0 + tx;
-        t[k][tx] = (r < R && c < C) ? Elem<TI>::ld(in + (long)r * ld_in + c) : 0.f;
+                                                        int R, int C, const float* __restrict__ add, long ld_add, int group) {
+    __shared__ float t[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    const bool vin = ((ld_in & 7) == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+    const bool vout = ((ld_out & 7) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    // read: 64 rows x 8 chunks of 8 elements = 512 chunks, 2 per thread
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int id = tid + q * 256, rr = id >> 3, cc = (id & 7) * 8;
+        const int r = r0 + rr, c = c0 + cc;
+        float v[8];
+        if (r < R && c + 8 <= C && vin) {
+            load8(in + (long)r * ld_in + c, v);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (r < R && c + k < C) ? Elem<TI>::ld(in + (long)r * ld_in + c + k) : 0.f;
+        }
+        if (add && r < R) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (c + k < C) v[k] += add[(long)r * ld_add + (c + k) / group];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[rr][cc + k] = v[k];
     }
     __syncthreads();
-    for (int k = ty; k < 32; k += 8) {
-        const int c = c0 + k, r = r0 + tx;
-        if (c < C && r < R) Elem<TO>::st(out + (long)c * ld_out + r, t[tx][k]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int id = tid + q * 256, cc = id >> 3, rr = (id & 7) * 8;
+        const int c = c0 + cc, r = r0 + rr;
+        if (c >= C) continue;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = t[rr + k][cc];
+        if (r + 8 <= R && vout) {
+            store8(out + (long)c * ld_out + r, v);
+        } else {
+            for (int k = 0; k < 8 && r + k < R; ++k) Elem<TO>::st(out + (long)c * ld_out + r + k, v[k]);
+        }
     }
+}
+
+// out[n][c] = sum_{p < group} in[n][c*group + p]   (W6sum: the K columns that fold `+ conv(rects)` into fc6)
+template <typename TO>
+__global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict__ in, long ld_in, TO* __restrict__ out, long ld_out,
+                                                        int Nn, int C, int group) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)Nn * C) return;
+    const long n = i / C;
+    const int c = (int)(i - n * C);
+    const float* p = in + n * ld_in + (long)c * group;
+    float s = 0.f;
+    for (int k = 0; k < group; ++k) s += p[k];
+    Elem<TO>::st(out + n * ld_out + c, s);
 }
 
 template <typename T, typename TX>
@@ -61,25 +105,6 @@ __global__ __launch_bounds__(256) void add_kernel(T* __restrict__ y, const TX* _
 #pragma unroll
     for (int k = 0; k < 8; ++k) a[k] += b[k];
     store8(y + i * 8, a);
-}
-
-// out[n][c][p] = in[n][p][c] + add[n][c]  (fp32; un-does the fc6 K re-order on the gradient and adds the folded
-// rect-conv term: d W6[n,c,p] = G[n,(p,c)] + Gsum[n,c])
-__global__ __launch_bounds__(256) void unpermute_add_kernel(const float* __restrict__ in, long ld_in, const float* __restrict__ add,
-                                                            long ld_add, float* __restrict__ out, int C, int Pp) {
-    __shared__ float t[32][33];
-    const long n = blockIdx.z;
-    const int p0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int k = ty; k < 32; k += 8) {   // read in[n][p][c]: c fastest
-        const int p = p0 + k, c = c0 + tx;
-        t[k][tx] = (p < Pp && c < C) ? in[n * ld_in + (long)p * C + c] : 0.f;
-    }
-    __syncthreads();
-    for (int k = ty; k < 32; k += 8) {   // write out[n][c][p]: p fastest
-        const int c = c0 + k, p = p0 + tx;
-        if (c < C && p < Pp) out[(n * C + c) * Pp + p] = t[tx][k] + (add ? add[n * ld_add + c] : 0.f);
-    }
 }
 
 }  // namespace
@@ -127,20 +152,38 @@ extern "C" int sgg_permute_ncp_to_npc(const void* in, void* out, int Nn, int C, 
     return SGG_OK;
 }
 
-extern "C" int sgg_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int R, int C, int in_dtype, int out_dtype,
-                             void* stream) {
+extern "C" int sgg_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int R, int C, const float* add,
+                             int64_t ld_add, int group, int in_dtype, int out_dtype, void* stream) {
     if (R == 0 || C == 0) return SGG_OK;
-    if (!in || !out || R < 0 || C < 0 || ld_in < C || ld_out < R) return SGG_ERR_ARG;
-    const dim3 grid((C + 31) / 32, (R + 31) / 32), blk(256);
+    if (!in || !out || R < 0 || C < 0 || ld_in < C || ld_out < R || (add && group <= 0)) return SGG_ERR_ARG;
+    const dim3 grid((C + 63) / 64, (R + 63) / 64), blk(256);
     hipStream_t s = (hipStream_t)stream;
+    if (group <= 0) group = 1;
     if (in_dtype == SGG_BF16 && out_dtype == SGG_BF16)
-        hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (const bf16_t*)in, (long)ld_in, (bf16_t*)out, (long)ld_out, R, C);
+        hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (const bf16_t*)in, (long)ld_in, (bf16_t*)out, (long)ld_out, R, C, add, (long)ld_add, group);
     else if (in_dtype == SGG_F32 && out_dtype == SGG_F32)
-        hipLaunchKernelGGL((transpose_kernel<float, float>), grid, blk, 0, s, (const float*)in, (long)ld_in, (float*)out, (long)ld_out, R, C);
+        hipLaunchKernelGGL((transpose_kernel<float, float>), grid, blk, 0, s, (const float*)in, (long)ld_in, (float*)out, (long)ld_out, R, C, add, (long)ld_add, group);
     else if (in_dtype == SGG_F32 && out_dtype == SGG_BF16)
-        hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, blk, 0, s, (const float*)in, (long)ld_in, (bf16_t*)out, (long)ld_out, R, C);
+        hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, blk, 0, s, (const float*)in, (long)ld_in, (bf16_t*)out, (long)ld_out, R, C, add, (long)ld_add, group);
     else if (in_dtype == SGG_BF16 && out_dtype == SGG_F32)
-        hipLaunchKernelGGL((transpose_kernel<bf16_t, float>), grid, blk, 0, s, (const bf16_t*)in, (long)ld_in, (float*)out, (long)ld_out, R, C);
+        hipLaunchKernelGGL((transpose_kernel<bf16_t, float>), grid, blk, 0, s, (const bf16_t*)in, (long)ld_in, (float*)out, (long)ld_out, R, C, add, (long)ld_add, group);
+    else
+        return SGG_ERR_DTYPE;
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_group_sum(const float* in, int64_t ld_in, void* out, int64_t ld_out, int Nn, int C, int group, int out_dtype,
+                             void* stream) {
+    if (Nn == 0) return SGG_OK;
+    if (!in || !out || Nn < 0 || C <= 0 || group <= 0 || ld_in < (int64_t)C * group || ld_out < C) return SGG_ERR_ARG;
+    const long total = (long)Nn * C;
+    const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (out_dtype == SGG_BF16)
+        hipLaunchKernelGGL(group_sum_kernel<bf16_t>, grid, blk, 0, s, in, (long)ld_in, (bf16_t*)out, (long)ld_out, Nn, C, group);
+    else if (out_dtype == SGG_F32)
+        hipLaunchKernelGGL(group_sum_kernel<float>, grid, blk, 0, s, in, (long)ld_in, (float*)out, (long)ld_out, Nn, C, group);
     else
         return SGG_ERR_DTYPE;
     SGG_CHECK_LAUNCH();
@@ -163,16 +206,6 @@ extern "C" int sgg_add(void* y, const void* x, int64_t n, int y_dtype, int x_dty
         hipLaunchKernelGGL((add_kernel<float, bf16_t>), grid, blk, 0, s, (float*)y, (const bf16_t*)x, n8);
     else
         return SGG_ERR_DTYPE;
-    SGG_CHECK_LAUNCH();
-    return SGG_OK;
-}
-
-extern "C" int sgg_unpermute_add(const float* in, int64_t ld_in, const float* add, int64_t ld_add, float* out, int Nn, int C,
-                                 int Pp, void* stream) {
-    if (Nn == 0) return SGG_OK;
-    if (!in || !out || Nn < 0 || Nn > 65535 || C <= 0 || Pp <= 0 || ld_in < (int64_t)C * Pp || (add && ld_add < C)) return SGG_ERR_ARG;
-    const dim3 grid((C + 31) / 32, (Pp + 31) / 32, Nn), blk(256);
-    hipLaunchKernelGGL(unpermute_add_kernel, grid, blk, 0, (hipStream_t)stream, in, (long)ld_in, add, (long)ld_add, out, C, Pp);
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

@@ -215,9 +215,12 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, 
 
 // ------------------------------------------------------------------------------------------------
 // a-4  RoIAlign, torchvision semantics (aligned=False), union box fused (rel_model_base.py:248-250),
-// optional fused broadcast add (lib/get_union_boxes.py:101).  One workgroup per RoI; one wave per bin;
-// a lane owns 8 consecutive channels, so every feature-map access is a full 16-byte (bf16) / 32-byte (f32)
-// piece of one pixel's channel vector (1 KiB per wave for C=512) and every output row is written whole.
+// optional fused broadcast add (lib/get_union_boxes.py:101).  One workgroup per RoI.
+// Phase 1: one wave per bin, a lane owns 8 consecutive channels, so every feature-map access is a full 16-byte
+//   (bf16) / 32-byte (f32) piece of one pixel's channel vector (1 KiB per wave for C=512); the [P*P][C] result tile
+//   stays in LDS.
+// Phase 2: the tile is written out transposed, as the reference's [C][P][P] block (what fc6's K axis expects without
+//   any weight re-ordering): 25088 contiguous elements per RoI, 16-byte pieces per lane.
 // RoIs are visited XCD-contiguously: RoIs are sorted by image, so one image's map stays in one XCD's L2.
 // ------------------------------------------------------------------------------------------------
 constexpr int MAXS = 32;  // max P*sampling samples per axis
@@ -227,6 +230,9 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const T* __restrict__ fm
                                                         const float* __restrict__ rois, const int64_t* __restrict__ pairs,
                                                         int R, float scale, int P, int S, const float* __restrict__ add_ec,
                                                         T* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    T* tile = reinterpret_cast<T*>(dyn);            // [P*P][C + 8]
+    const int TS = C + 8;
     __shared__ int s_lo[2][MAXS], s_hi[2][MAXS];
     __shared__ float s_l[2][MAXS], s_h[2][MAXS];  // s_h < 0 marks an out-of-range sample
     __shared__ int s_b;
@@ -273,11 +279,12 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const T* __restrict__ fm
     __syncthreads();
     const T* fm = fmap + (long)s_b * H * W * C;
     const float inv = 1.0f / (float)(S * S);
+    const int PP = P * P;
     for (int c0 = lane * 8; c0 < C; c0 += 512) {
         float addv[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) addv[k] = add_ec ? add_ec[(long)r * C + c0 + k] : 0.f;
-        for (int bin = wave; bin < P * P; bin += 4) {
+        for (int bin = wave; bin < PP; bin += 4) {
             const int ph = bin / P, pw = bin - ph * P;
             float acc[8];
 #pragma unroll
@@ -305,8 +312,27 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const T* __restrict__ fm
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[k] = acc[k] * inv + addv[k];
-            store8(out + ((long)r * P * P + bin) * C + c0, acc);
+            store8(tile + bin * TS + c0, acc);
         }
+    }
+    __syncthreads();
+    // phase 2: out[r][c][p], 8 consecutive linear elements per thread
+    T* o = out + (long)r * C * PP;
+    const int total = C * PP;
+    for (int L0 = tid * 8; L0 < total; L0 += 256 * 8) {
+        float v[8];
+        int c = L0 / PP, p = L0 - c * PP;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = (L0 + k < total) ? Elem<T>::ld(tile + p * TS + c) : 0.f;
+            if (++p == PP) {
+                p = 0;
+                ++c;
+            }
+        }
+        if (L0 + 8 <= total) store8(o + L0, v);
+        else
+            for (int k = 0; L0 + k < total; ++k) Elem<T>::st(o + L0 + k, v[k]);
     }
 }
 
@@ -363,14 +389,30 @@ extern "C" int sgg_roi_align_fwd(const void* fmap, int B, int H, int W, int C, c
         sampling <= 0 || P * sampling > MAXS)
         return SGG_ERR_ARG;
     if (!pairs && R != Nroi) return SGG_ERR_ARG;
-    if (dtype == SGG_BF16)
-        hipLaunchKernelGGL(roi_align_kernel<bf16_t>, dim3(R), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)fmap, B, H, W, C,
+    const size_t esz = dtype == SGG_BF16 ? 2 : 4;
+    const size_t smem = (size_t)P * P * (C + 8) * esz;
+    if (smem > 150 * 1024) return SGG_ERR_ARG;
+    if (dtype == SGG_BF16) {
+        static bool done = false;
+        if (!done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+                return SGG_ERR_LAUNCH;
+            done = true;
+        }
+        hipLaunchKernelGGL(roi_align_kernel<bf16_t>, dim3(R), dim3(256), smem, (hipStream_t)stream, (const bf16_t*)fmap, B, H, W, C,
                            rois, pairs, R, spatial_scale, P, sampling, add_ec, (bf16_t*)out);
-    else if (dtype == SGG_F32)
-        hipLaunchKernelGGL(roi_align_kernel<float>, dim3(R), dim3(256), 0, (hipStream_t)stream, (const float*)fmap, B, H, W, C,
+    } else if (dtype == SGG_F32) {
+        static bool done = false;
+        if (!done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+                return SGG_ERR_LAUNCH;
+            done = true;
+        }
+        hipLaunchKernelGGL(roi_align_kernel<float>, dim3(R), dim3(256), smem, (hipStream_t)stream, (const float*)fmap, B, H, W, C,
                            rois, pairs, R, spatial_scale, P, sampling, add_ec, (float*)out);
-    else
+    } else {
         return SGG_ERR_DTYPE;
+    }
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

@@ -111,11 +111,12 @@ def edge_csr(rel_inds, N, im_inds=None):
 
 # ---------------------------------------------------------------- a-4
 def roi_align(fmap_nhwc, rois, pairs=None, spatial_scale=1.0 / 16, P=7, sampling=2, add_ec=None, out=None):
-    """fmap [B,H,W,C]; rois f32[N,5]; pairs i64[R,2] or None -> [R,P,P,C] (same dtype as fmap)."""
+    """fmap [B,H,W,C] (NHWC); rois f32[N,5]; pairs i64[R,2] or None -> [R,C,P,P] contiguous (the reference's layout),
+    same dtype as fmap."""
     B, H, W, C = fmap_nhwc.shape
     R = rois.shape[0] if pairs is None else pairs.shape[0]
     if out is None:
-        out = torch.empty((R, P, P, C), dtype=fmap_nhwc.dtype, device=fmap_nhwc.device)
+        out = torch.empty((R, C, P, P), dtype=fmap_nhwc.dtype, device=fmap_nhwc.device)
     _lib.call('sgg_roi_align_fwd', _p(fmap_nhwc), B, H, W, C, _p(rois, torch.float32), rois.shape[0],
               _p(pairs, torch.int64) if pairs is not None else None, R, float(spatial_scale), P, sampling,
               _p(add_ec, torch.float32) if add_ec is not None else None, _p(out), dt(fmap_nhwc), _stream())
@@ -147,24 +148,30 @@ def max4_rows(x):
 
 
 def bcast_add_(x, add_rc):
-    """x [R,PP,C] += add[R,C] (in place)."""
-    R, PP, C = x.shape
+    """x [R,C,PP] += add[R,C] (in place)."""
+    R, C, PP = x.shape
     _lib.call('sgg_bcast_add', _p(x), _p(add_rc, torch.float32), R, PP, C, dt(x), _stream())
     return x
 
 
 # ---------------------------------------------------------------- a-7
-def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None, post_shift=None, out=None):
-    """act(A[M,K1] | A2[M,K2]) . W[N,K]^T + bias) * post_scale + post_shift -> [M,N]."""
+def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None, post_shift=None, out=None, W2=None):
+    """act([A[M,K1] | A2[M,K2]] . [W | W2]^T + bias) * post_scale + post_shift -> [M,N].
+    W is [N,K1+K2], or [N,K1] when the second K segment's weights are given separately as W2 [N,K2]."""
     M, K1 = A.shape
-    N, K = W.shape
-    assert A.dtype == W.dtype and (A2 is None or A2.dtype == A.dtype)
-    assert K == K1 + (A2.shape[1] if A2 is not None else 0), (A.shape, W.shape)
+    N = W.shape[0]
+    K2 = A2.shape[1] if A2 is not None else 0
+    K = K1 + K2
+    assert A.dtype == W.dtype and (A2 is None or A2.dtype == A.dtype) and (W2 is None or W2.dtype == A.dtype)
+    assert W.shape[1] == (K1 if W2 is not None else K), (A.shape, W.shape)
+    assert W2 is None or (A2 is not None and tuple(W2.shape) == (N, K2))
     out_dtype = out_dtype or A.dtype
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=A.device)
-    _lib.call('sgg_gemm', _p(A), A.stride(0) if A.dim() == 2 else K1, _p(A2) if A2 is not None else None,
-              A2.shape[1] if A2 is not None else 0, K1, _p(W), K, _p(bias, torch.float32) if bias is not None else None,
+    _lib.call('sgg_gemm', _p(A, rows_ok=True), A.stride(0), _p(A2, rows_ok=True) if A2 is not None else None,
+              A2.stride(0) if A2 is not None else 0, K1, _p(W, rows_ok=True), W.stride(0),
+              _p(W2, rows_ok=True) if W2 is not None else None, W2.stride(0) if W2 is not None else 0,
+              _p(bias, torch.float32) if bias is not None else None,
               _p(post_scale, torch.float32) if post_scale is not None else None,
               _p(post_shift, torch.float32) if post_shift is not None else None,
               _p(out, rows_ok=True), out.stride(0), M, N, K, act, dt(A), dt(out), _stream())
@@ -348,27 +355,27 @@ def rank4_reduce_(a, x, out, col0=0):
               _stream())
 
 
-def transpose(x, pad_to=64, dtype=None):
-    """x [R,C] (row-strided ok) -> [C, Rp] with Rp = R rounded up to `pad_to`, zero padded."""
+def transpose(x, pad_to=64, dtype=None, add=None, group=1):
+    """x [R,C] (row-strided ok) -> [C, Rp] with Rp = R rounded up to `pad_to`, zero padded.
+    add f32[R, C/group]: out[c][r] = x[r][c] + add[r][c // group]."""
     R, C = x.shape
     Rp = (R + pad_to - 1) // pad_to * pad_to
     dtype = dtype or x.dtype
     out = (torch.zeros if Rp != R else torch.empty)((C, Rp), dtype=dtype, device=x.device)
-    _lib.call('sgg_transpose', _p(x, rows_ok=True), x.stride(0), _p(out), Rp, R, C, dt(x), dt(out), _stream())
+    _lib.call('sgg_transpose', _p(x, rows_ok=True), x.stride(0), _p(out), Rp, R, C,
+              _p(add, torch.float32) if add is not None else None, add.stride(0) if add is not None else 0, group,
+              dt(x), dt(out), _stream())
+    return out
+
+
+def group_sum(w, C, group, dtype):
+    """w f32[N, C*group] -> [N, C] in dtype: sums over each run of `group` consecutive columns."""
+    Nn = w.shape[0]
+    out = torch.empty((Nn, C), dtype=dtype, device=w.device)
+    _lib.call('sgg_group_sum', _p(w, torch.float32), w.stride(0), _p(out), C, Nn, C, group, dt(out), _stream())
     return out
 
 
 def add_(y, x):
     _lib.call('sgg_add', _p(y), _p(x), y.numel(), dt(y), dt(x), _stream())
     return y
-
-
-def unpermute_add(g, C, Pp, add=None):
-    """g f32 [N, >= Pp*C] (row-strided) in (p,c) K order -> [N, C*Pp] in (c,p) order, + add[N,C] broadcast over p."""
-    Nn = g.shape[0]
-    out = torch.empty((Nn, C * Pp), dtype=torch.float32, device=g.device)
-    for s in range(0, Nn, 32768):
-        e = min(Nn, s + 32768)
-        _lib.call('sgg_unpermute_add', g[s:e].data_ptr(), g.stride(0), add[s:e].data_ptr() if add is not None else None,
-                  add.stride(0) if add is not None else 0, out[s:e].data_ptr(), e - s, C, Pp, _stream())
-    return out

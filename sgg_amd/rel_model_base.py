@@ -1,8 +1,9 @@
 """RelModelBase on the HIP path -- mirror of sgg_models/rel_model_base.py (same constructor, attributes, method
 names, state_dict keys and exceptions), with the arithmetic in libsgg_hip.so.
 
-Layout note: feature maps and RoI features are channels-last in memory.  `fmap`, `node_feat`, `edge_feat` are
-handed out as [.,C,H,W]-shaped views of NHWC storage, i.e. the same logical tensors the reference returns.
+Layout note: the feature map is channels-last in memory and handed out as a [B,C,H,W]-shaped view of NHWC storage
+(the same logical tensor the reference returns).  RoI features (`node_feat`, `edge_feat`) are plain contiguous
+[R,C,7,7] tensors exactly as in the reference (RoIAlign transposes through LDS), so fc6 weights are used un-permuted.
 """
 import math
 
@@ -33,8 +34,8 @@ def as_nchw_view(x_nhwc):
 
 
 def to_nhwc(x, dtype):
-    """[R,C,P,P]-shaped tensor (either a view of NHWC storage, or a plain NCHW tensor from another producer, e.g. the
-    GAN of main.py:141-149) -> contiguous [R,P,P,C] in `dtype`."""
+    """[B,C,H,W]-shaped feature map (a view of NHWC storage, or a plain NCHW tensor from another producer, e.g. the
+    GAN of main.py:141-149) -> contiguous [B,H,W,C] in `dtype`."""
     R, C, Ph, Pw = x.shape
     v = x.permute(0, 2, 3, 1)
     if v.is_contiguous():
@@ -42,6 +43,17 @@ def to_nhwc(x, dtype):
     if x.dtype not in (torch.float32, torch.bfloat16):
         x = x.float()
     return ops.permute_ncp_to_npc(x.reshape(R, C, Ph * Pw), dtype).view(R, Ph, Pw, C)
+
+
+def to_rows(x, dtype):
+    """RoI features [R,C,P,P] (any strides / float dtype) -> contiguous [R, C*P*P] in `dtype` (fc6's A operand)."""
+    R = x.shape[0]
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        x = x.float()
+    x = x.contiguous()                      # no-op for the tensors RoIAlign produced
+    if x.dtype != dtype:
+        x = ops.cast(x, dtype)
+    return x.view(R, -1)
 
 
 class RelModelBase(nn.Module):
@@ -172,7 +184,7 @@ class RelModelBase(nn.Module):
         rois = rois.float().contiguous()
         node = ops.roi_align(fm, rois, None, scale, self.pool_sz, 2)
         edge = ops.roi_align(fm, rois, union_inds.contiguous(), scale, self.pool_sz, 2)
-        return as_nchw_view(node), as_nchw_view(edge)
+        return node, edge
 
     def get_scaled_boxes(self, boxes, im_inds, im_sizes):
         """rel_model_base.py:263-274."""

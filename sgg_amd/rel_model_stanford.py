@@ -4,7 +4,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 from .imp import GATES, ImpWeights, message_pass
-from .rel_model_base import RelModelBase, to_nhwc
+from .rel_model_base import RelModelBase, to_rows
 
 
 class RelModelStanford(RelModelBase):
@@ -27,10 +27,9 @@ class RelModelStanford(RelModelBase):
 
     # ------------------------------------------------------------------ weights in kernel layout
     def prepared(self):
-        """Device operands derived from the fp32 master parameters, cached until a parameter changes:
-        fc6 with its K axis re-ordered (c,ph,pw)->(ph,pw,c) to match channels-last RoI features; for edges also the
-        512 extra K columns  sum_p W6[:, c, p]  that fold `union_pools + conv(rects)` (lib/get_union_boxes.py:101)
-        into fc6 by linearity (fc6(x + r (x) 1_49) = fc6(x) + W6sum r)."""
+        """Device operands derived from the fp32 master parameters, cached until a parameter changes: casts to the
+        compute dtype, plus W6sum[n,c] = sum_p W6[n,c,p] -- the 512 extra K columns that fold `union_pools + conv(rects)`
+        (lib/get_union_boxes.py:101) into fc6 by linearity: fc6(x + r (x) 1_49) = fc6(x) + W6sum r."""
         dtype = self.compute_dtype
         params = [p for n, p in self.named_parameters() if not n.startswith('detector.')]
         key = (dtype, getattr(self, 'weights_version', 0)) + tuple((p.data_ptr(), p._version) for p in params)
@@ -38,18 +37,16 @@ class RelModelStanford(RelModelBase):
             return self._prep['val']
         C, PP = self.edge_dim, self.pool_sz ** 2
         f = lambda t: t.detach().float().contiguous()
+        cast = lambda t: t if t.dtype == dtype else ops.cast(t, dtype)
         w = {}
-        w6o = f(self.roi_fmap_obj[0].weight)
-        w['fc6_obj'] = ops.permute_ncp_to_npc(w6o.view(-1, C, PP), dtype).view(w6o.shape[0], -1)
+        w['fc6_obj'] = cast(f(self.roi_fmap_obj[0].weight))
         w6e = f(self.roi_fmap[1][0].weight)
-        w6e_p = ops.permute_ncp_to_npc(w6e.view(-1, C, PP), dtype).view(w6e.shape[0], -1)
-        w6sum = w6e.view(-1, C, PP).sum(2)                                    # load-time only
-        w['fc6_edge'] = torch.cat((w6e_p, w6sum.to(dtype)), 1).contiguous()   # [4096, 25088+512]
-        w['fc6_edge_raw_k'] = C * PP
+        w['fc6_edge'] = cast(w6e)                                  # [4096, 25088], K order (c,ph,pw) as in the reference
+        w['fc6_edge_sum'] = ops.group_sum(w6e, C, PP, dtype)       # [4096, 512]
         for name, mod in (('fc7_obj', self.roi_fmap_obj[3]), ('fc7_edge', self.roi_fmap[1][3]),
                           ('obj_unary', self.obj_unary), ('edge_unary', self.edge_unary), ('obj_fc', self.obj_fc),
                           ('rel_fc', self.rel_fc)):
-            w[name] = f(mod.weight).to(dtype).contiguous()
+            w[name] = cast(f(mod.weight))
             w[name + '_b'] = f(mod.bias)
         w['fc6_obj_b'] = f(self.roi_fmap_obj[0].bias)
         w['fc6_edge_b'] = f(self.roi_fmap[1][0].bias)
@@ -75,8 +72,8 @@ class RelModelStanford(RelModelBase):
         dtype = self.compute_dtype
         N, E = node_feat.shape[0], edge_feat.shape[0]
         rel_inds = rel_inds.contiguous()
-        nf = to_nhwc(node_feat.view(N, -1, self.pool_sz, self.pool_sz), dtype).view(N, -1)
-        ef = to_nhwc(edge_feat.view(E, -1, self.pool_sz, self.pool_sz), dtype).view(E, -1)
+        nf = to_rows(node_feat.view(N, -1, self.pool_sz, self.pool_sz), dtype)
+        ef = to_rows(edge_feat.view(E, -1, self.pool_sz, self.pool_sz), dtype)
         if self.training:
             # Dropout, batch-statistic BatchNorm and the autograd node of the whole head (sgg_amd/train.py)
             from .train import predict_train
@@ -93,7 +90,7 @@ class RelModelStanford(RelModelBase):
         obj_rep = ops.gemm(x, w['obj_unary'], w['obj_unary_b'])
         # :104  relu(edge_unary(roi_fmap(edge_feat)))
         _lib.set_tag('fc6_edge')
-        y = ops.gemm(ef, w['fc6_edge'], w['fc6_edge_b'], ops.ACT_RELU, A2=rect)
+        y = ops.gemm(ef, w['fc6_edge'], w['fc6_edge_b'], ops.ACT_RELU, A2=rect, W2=w['fc6_edge_sum'])
         _lib.set_tag('fc7_edge')
         y = ops.gemm(y, w['fc7_edge'], w['fc7_edge_b'])
         _lib.set_tag('unary')

@@ -58,7 +58,7 @@ def train_weights(model):
     for name in ('fc7_obj', 'obj_unary', 'fc7_edge', 'edge_unary', 'obj_fc', 'rel_fc'):
         t[name + '_t'] = ops.transpose(w[name])                         # [K, Np]
     C = model.edge_dim
-    t['w6sum_t'] = ops.transpose(w['fc6_edge'][:, w['fc6_edge_raw_k']:])   # [C, 4096]
+    t['w6sum_t'] = ops.transpose(w['fc6_edge_sum'])                      # [C, 4096]
     imp = w['imp']
     for g in ('edge_gru', 'node_gru'):
         t[g + '_w_ih_t'] = ops.transpose(getattr(imp, g + '_w_ih'))     # [H, 3H]
@@ -131,7 +131,7 @@ class PredictFn(torch.autograd.Function):
         ops.gemm(x7, w['obj_unary'], w['obj_unary_b'], out=XN[:N])
         # ---- edges: relu(edge_unary(roi_fmap(edge_feat + conv(rects))))  (Linear ReLU Dropout Linear)
         _lib.set_tag('fc6_edge')
-        y6 = ops.gemm(ef, w['fc6_edge'], w['fc6_edge_b'], ops.ACT_RELU, A2=rect)
+        y6 = ops.gemm(ef, w['fc6_edge'], w['fc6_edge_b'], ops.ACT_RELU, A2=rect, W2=w['fc6_edge_sum'])
         _lib.set_tag('mlp')
         if dropout_p > 0:
             ops.dropout_(y6, dropout_p, seed * 4 + 3)
@@ -250,13 +250,10 @@ class PredictFn(torch.autograd.Function):
         d_y6 = lin_bwd(d_y7, sv['y6'], t['fc7_edge_t'], 'roi_fmap.1.3')
         d_pre6 = ops.act_bwd(d_y6, sv['y6'], ds)                                   # dropout + relu
         C, PP = model.edge_dim, model.pool_sz ** 2
-        K1 = C * PP
         _lib.set_tag('bwd_fc6_edge_dW')
-        d6t = ops.transpose(d_pre6)                                                # [4096, Ep]
-        g6 = torch.empty((d_pre6.shape[1], K1 + C), dtype=torch.float32, device=dev)
-        ops.gemm(d6t, ops.transpose(sv['ef']), out_dtype=torch.float32, out=g6[:, :K1])
-        ops.gemm(d6t, ops.transpose(sv['rect']), out_dtype=torch.float32, out=g6[:, K1:])
-        G['roi_fmap.1.0.weight'] = ops.unpermute_add(g6, C, PP, add=g6[:, K1:])    # (p,c)->(c,p) + folded W6sum term
+        # d W6[n,(c,p)] = sum_e d_pre6[e,n] * (edge_feat[e,c,p] + rect[e,c]): the folded term rides in the transpose
+        x6t = ops.transpose(sv['ef'], add=sv['rect'].float() if sv['rect'].dtype != torch.float32 else sv['rect'], group=PP)
+        G['roi_fmap.1.0.weight'] = ops.gemm(ops.transpose(d_pre6), x6t, out_dtype=torch.float32)
         G['roi_fmap.1.0.bias'] = ops.colsum(d_pre6)
         _lib.set_tag('bwd_rect')
         d_rect = ops.gemm(d_pre6, t['w6sum_t'])                                    # [E,C]
@@ -280,8 +277,7 @@ class PredictFn(torch.autograd.Function):
         d_p7 = ops.act_bwd(d_x7, sv['x7'], ds)
         d_x6 = lin_bwd(d_p7, sv['x6'], t['fc7_obj_t'], 'roi_fmap_obj.3')
         d_p6 = ops.act_bwd(d_x6, sv['x6'], ds)
-        g6o = tn_gemm(d_p6, sv['nf'])                                              # [4096, K1] in (p,c) order
-        G['roi_fmap_obj.0.weight'] = ops.unpermute_add(g6o, C, PP)
+        G['roi_fmap_obj.0.weight'] = tn_gemm(d_p6, sv['nf'])
         G['roi_fmap_obj.0.bias'] = ops.colsum(d_p6)
         _lib.set_tag('')
         ctx.sv = None

@@ -89,12 +89,12 @@ class UnionBoxesAndFeats(nn.Module):
                          self.pooling_size * 4 - 1)
 
     def forward(self, union_pools, rois, union_inds, im_sizes=None):
-        """union_pools [E,dim,7,7] (any strides) -> union_pools + conv(rects) (lib/get_union_boxes.py:101)."""
+        """union_pools [E,dim,7,7] -> union_pools + conv(rects) (lib/get_union_boxes.py:101), a new tensor."""
         E, C = union_pools.shape[0], union_pools.shape[1]
-        dtype = union_pools.dtype
-        rf = self.rect_feat(rois, union_inds, dtype).float().contiguous()
-        x = union_pools.permute(0, 2, 3, 1)
-        x = x.contiguous().clone() if x.is_contiguous() else ops.permute_ncp_to_npc(
-            union_pools.reshape(E, C, -1)).view(E, self.pooling_size, self.pooling_size, C)
-        ops.bcast_add_(x.view(E, -1, C), rf)
-        return x.permute(0, 3, 1, 2)
+        x = union_pools
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        rf = self.rect_feat(rois, union_inds, x.dtype).float().contiguous()
+        x = x.contiguous().clone()
+        ops.bcast_add_(x.view(E, C, -1), rf)
+        return x

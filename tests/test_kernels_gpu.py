@@ -75,6 +75,40 @@ def test_gemm_split_k_and_affine(ops, dtype):
     torch.testing.assert_close(outb.float().cpu(), ref, atol=1e-4 if dtype == torch.float32 else 6e-2, rtol=0)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_gemm_split_weights_w2(ops, dtype):
+    g = torch.Generator().manual_seed(8)
+    M, K1, K2, N = 5000, 1024, 512, 2048          # big enough for the 256x256 kernel too
+    A1, A2 = torch.randn(M, K1, generator=g).to(dtype), torch.randn(M, K2, generator=g).to(dtype)
+    W1, W2 = (torch.randn(N, K1, generator=g) / 30).to(dtype), (torch.randn(N, K2, generator=g) / 30).to(dtype)
+    ref = A1.float() @ W1.float().t() + A2.float() @ W2.float().t()
+    for rows in (M, 200):                         # ping-pong kernel / 128x128 kernel
+        out = ops.gemm(cu(A1[:rows]), cu(W1), out_dtype=torch.float32, A2=cu(A2[:rows]), W2=cu(W2))
+        torch.testing.assert_close(out.cpu(), ref[:rows], atol=2e-4 if dtype == torch.float32 else 8e-2, rtol=0)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_transpose_add_and_group_sum(ops, dtype):
+    g = torch.Generator().manual_seed(2)
+    R, C, group = 203, 7 * 24, 7
+    x = torch.randn(R, C, generator=g).to(dtype)
+    add = torch.randn(R, C // group, generator=g)
+    t = ops.transpose(cu(x))
+    assert tuple(t.shape) == (C, 256) and float(t[:, R:].float().abs().max()) == 0
+    torch.testing.assert_close(t[:, :R].float().cpu(), x.float().t(), atol=0, rtol=0)
+    ta = ops.transpose(cu(x), add=cu(add), group=group)
+    exp = (x.float() + add.repeat_interleave(group, 1)).t()
+    torch.testing.assert_close(ta[:, :R].float().cpu(), exp.to(dtype).float(), atol=1e-6 if dtype == torch.float32 else 2e-2, rtol=0)
+    # strided input (a column block of a wider matrix)
+    wide = torch.randn(R, C + 40, generator=g).to(dtype)
+    tv = ops.transpose(cu(wide)[:, 8:8 + C])
+    torch.testing.assert_close(tv[:, :R].float().cpu(), wide[:, 8:8 + C].float().t(), atol=0, rtol=0)
+    w = torch.randn(37, C, generator=g)
+    gs = ops.group_sum(cu(w), C // group, group, dtype)
+    torch.testing.assert_close(gs.float().cpu(), w.view(37, C // group, group).sum(2).to(dtype).float(),
+                               atol=1e-5 if dtype == torch.float32 else 3e-2, rtol=0)
+
+
 def test_gemm_rejects_bad_k(ops):
     with pytest.raises(ValueError):
         ops.gemm(cu(torch.zeros(8, 40)), cu(torch.zeros(8, 40)))
@@ -267,19 +301,21 @@ def test_roi_align(ops, dtype):
     pairs = np.array([(i, j) for i in range(N) for j in range(N) if i != j and im[i] == im[j]], np.int64)
     exp_n, exp_e = O.node_edge_features(fm.float().numpy(), rois, pairs)
     fm_nhwc = cu(fm.permute(0, 2, 3, 1))
-    got_n = ops.roi_align(fm_nhwc, cu(rois)).float().cpu().permute(0, 3, 1, 2).numpy()
-    got_e = ops.roi_align(fm_nhwc, cu(rois), cu(pairs)).float().cpu().permute(0, 3, 1, 2).numpy()
+    out_n = ops.roi_align(fm_nhwc, cu(rois))
+    assert tuple(out_n.shape) == (N, C, 7, 7) and out_n.is_contiguous()      # the reference's layout
+    got_n = out_n.float().cpu().numpy()
+    got_e = ops.roi_align(fm_nhwc, cu(rois), cu(pairs)).float().cpu().numpy()
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     np.testing.assert_allclose(got_n, exp_n, atol=tol)
     np.testing.assert_allclose(got_e, exp_e, atol=tol)
     if dtype == torch.float32:  # fused broadcast add
         add = torch.from_numpy(rng.randn(len(pairs), C).astype(np.float32))
-        got = ops.roi_align(fm_nhwc, cu(rois), cu(pairs), add_ec=cu(add)).cpu().permute(0, 3, 1, 2).numpy()
+        got = ops.roi_align(fm_nhwc, cu(rois), cu(pairs), add_ec=cu(add)).cpu().numpy()
         np.testing.assert_allclose(got, exp_e + add.numpy()[:, :, None, None], atol=tol)
-        x = cu(torch.from_numpy(exp_e).permute(0, 2, 3, 1)).reshape(len(pairs), 49, C).contiguous()
+        x = cu(torch.from_numpy(exp_e)).reshape(len(pairs), C, 49).contiguous()
         ops.bcast_add_(x, cu(add))
-        np.testing.assert_allclose(x.cpu().numpy().reshape(len(pairs), 7, 7, C).transpose(0, 3, 1, 2),
-                                   exp_e + add.numpy()[:, :, None, None], atol=1e-6)
+        np.testing.assert_allclose(x.cpu().numpy().reshape(len(pairs), C, 7, 7), exp_e + add.numpy()[:, :, None, None],
+                                   atol=1e-6)
 
 
 # ----------------------------------------------------------------------------------------- IMP + GRU
