@@ -82,17 +82,24 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ i
 }
 
 // out[n][c] = sum_{p < group} in[n][c*group + p]   (W6sum: the K columns that fold `+ conv(rects)` into fc6)
+// One workgroup per (row n, 64 channels): the 64*group floats are loaded coalesced into LDS, then 64 threads each sum
+// one run (LDS stride = group floats; conflict-free for odd group, e.g. 49).
 template <typename TO>
 __global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict__ in, long ld_in, TO* __restrict__ out, long ld_out,
                                                         int Nn, int C, int group) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)Nn * C) return;
-    const long n = i / C;
-    const int c = (int)(i - n * C);
-    const float* p = in + n * ld_in + (long)c * group;
-    float s = 0.f;
-    for (int k = 0; k < group; ++k) s += p[k];
-    Elem<TO>::st(out + n * ld_out + c, s);
+    extern __shared__ float gs_lds[];
+    const long n = blockIdx.y;
+    const int c0 = blockIdx.x * 64;
+    const int cnt = min(64, C - c0) * group;
+    const float* src = in + n * ld_in + (long)c0 * group;
+    for (int i = threadIdx.x; i < cnt; i += 256) gs_lds[i] = src[i];
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < 64 && c0 + t < C) {
+        float s = 0.f;
+        for (int k = 0; k < group; ++k) s += gs_lds[t * group + k];
+        Elem<TO>::st(out + n * ld_out + c0 + t, s);
+    }
 }
 
 template <typename T, typename TX>
@@ -177,13 +184,14 @@ extern "C" int sgg_group_sum(const float* in, int64_t ld_in, void* out, int64_t 
                              void* stream) {
     if (Nn == 0) return SGG_OK;
     if (!in || !out || Nn < 0 || C <= 0 || group <= 0 || ld_in < (int64_t)C * group || ld_out < C) return SGG_ERR_ARG;
-    const long total = (long)Nn * C;
-    const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+    if (Nn > 65535 || group > 256) return SGG_ERR_ARG;
+    const dim3 grid((C + 63) / 64, Nn), blk(256);
+    const size_t smem = sizeof(float) * 64 * (size_t)group;
     hipStream_t s = (hipStream_t)stream;
     if (out_dtype == SGG_BF16)
-        hipLaunchKernelGGL(group_sum_kernel<bf16_t>, grid, blk, 0, s, in, (long)ld_in, (bf16_t*)out, (long)ld_out, Nn, C, group);
+        hipLaunchKernelGGL(group_sum_kernel<bf16_t>, grid, blk, smem, s, in, (long)ld_in, (bf16_t*)out, (long)ld_out, Nn, C, group);
     else if (out_dtype == SGG_F32)
-        hipLaunchKernelGGL(group_sum_kernel<float>, grid, blk, 0, s, in, (long)ld_in, (float*)out, (long)ld_out, Nn, C, group);
+        hipLaunchKernelGGL(group_sum_kernel<float>, grid, blk, smem, s, in, (long)ld_in, (float*)out, (long)ld_out, Nn, C, group);
     else
         return SGG_ERR_DTYPE;
     SGG_CHECK_LAUNCH();

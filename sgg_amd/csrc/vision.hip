@@ -231,8 +231,9 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const T* __restrict__ fm
                                                         int R, float scale, int P, int S, const float* __restrict__ add_ec,
                                                         T* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
-    T* tile = reinterpret_cast<T*>(dyn);            // [P*P][C + 8]
-    const int TS = C + 8;
+    T* tile = reinterpret_cast<T*>(dyn);            // [P*P][CS + 8], CS = channels of this workgroup's slice
+    const int nsplit = gridDim.y, CS = C / nsplit, cbase = blockIdx.y * CS;
+    const int TS = CS + 8;
     __shared__ int s_lo[2][MAXS], s_hi[2][MAXS];
     __shared__ float s_l[2][MAXS], s_h[2][MAXS];  // s_h < 0 marks an out-of-range sample
     __shared__ int s_b;
@@ -280,7 +281,8 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const T* __restrict__ fm
     const T* fm = fmap + (long)s_b * H * W * C;
     const float inv = 1.0f / (float)(S * S);
     const int PP = P * P;
-    for (int c0 = lane * 8; c0 < C; c0 += 512) {
+    for (int cl = lane * 8; cl < CS; cl += 512) {
+        const int c0 = cbase + cl;
         float addv[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) addv[k] = add_ec ? add_ec[(long)r * C + c0 + k] : 0.f;
@@ -312,27 +314,46 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const T* __restrict__ fm
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[k] = acc[k] * inv + addv[k];
-            store8(tile + bin * TS + c0, acc);
+            store8(tile + bin * TS + cl, acc);
         }
     }
     __syncthreads();
     // phase 2: out[r][c][p], 8 consecutive linear elements per thread
-    T* o = out + (long)r * C * PP;
-    const int total = C * PP;
+    T* o = out + ((long)r * C + cbase) * PP;
+    const int total = CS * PP;
     for (int L0 = tid * 8; L0 < total; L0 += 256 * 8) {
-        float v[8];
         int c = L0 / PP, p = L0 - c * PP;
+        if constexpr (sizeof(T) == 2) {
+            // raw 16-bit moves: no bf16 -> f32 -> bf16 round trip
+            unsigned int w[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            v[k] = (L0 + k < total) ? Elem<T>::ld(tile + p * TS + c) : 0.f;
-            if (++p == PP) {
-                p = 0;
-                ++c;
+            for (int k = 0; k < 8; ++k) {
+                const unsigned int h = (L0 + k < total) ? (unsigned int)tile[p * TS + c] : 0u;
+                w[k >> 1] |= h << ((k & 1) * 16);
+                if (++p == PP) {
+                    p = 0;
+                    ++c;
+                }
             }
+            if (L0 + 8 <= total) {
+                *reinterpret_cast<u32x4*>(o + L0) = u32x4{w[0], w[1], w[2], w[3]};
+            } else {
+                for (int k = 0; L0 + k < total; ++k) o[L0 + k] = (T)((w[k >> 1] >> ((k & 1) * 16)) & 0xffffu);
+            }
+        } else {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                v[k] = (L0 + k < total) ? Elem<T>::ld(tile + p * TS + c) : 0.f;
+                if (++p == PP) {
+                    p = 0;
+                    ++c;
+                }
+            }
+            if (L0 + 8 <= total) store8(o + L0, v);
+            else
+                for (int k = 0; L0 + k < total; ++k) Elem<T>::st(o + L0 + k, v[k]);
         }
-        if (L0 + 8 <= total) store8(o + L0, v);
-        else
-            for (int k = 0; L0 + k < total; ++k) Elem<T>::st(o + L0 + k, v[k]);
     }
 }
 
@@ -390,8 +411,13 @@ extern "C" int sgg_roi_align_fwd(const void* fmap, int B, int H, int W, int C, c
         return SGG_ERR_ARG;
     if (!pairs && R != Nroi) return SGG_ERR_ARG;
     const size_t esz = dtype == SGG_BF16 ? 2 : 4;
-    const size_t smem = (size_t)P * P * (C + 8) * esz;
-    if (smem > 150 * 1024) return SGG_ERR_ARG;
+    // channel slices per RoI only when the LDS tile would not fit (measured: slicing for occupancy is slower, the
+    // kernel is bound by the per-RoI sample setup and gathers, not by resident waves); slices stay multiples of 8
+    // channels and (CS*P*P) a multiple of 8 elements so that every store is a full 16-byte piece
+    int nsplit = 1;
+    while ((size_t)P * P * (C / nsplit + 8) * esz > 104 * 1024 && (C / nsplit) % 16 == 0 && nsplit < 16) nsplit *= 2;
+    const size_t smem = (size_t)P * P * (C / nsplit + 8) * esz;
+    if (smem > 150 * 1024 || C % (8 * nsplit)) return SGG_ERR_ARG;
     if (dtype == SGG_BF16) {
         static bool done = false;
         if (!done) {
@@ -399,7 +425,7 @@ extern "C" int sgg_roi_align_fwd(const void* fmap, int B, int H, int W, int C, c
                 return SGG_ERR_LAUNCH;
             done = true;
         }
-        hipLaunchKernelGGL(roi_align_kernel<bf16_t>, dim3(R), dim3(256), smem, (hipStream_t)stream, (const bf16_t*)fmap, B, H, W, C,
+        hipLaunchKernelGGL(roi_align_kernel<bf16_t>, dim3(R, nsplit), dim3(256), smem, (hipStream_t)stream, (const bf16_t*)fmap, B, H, W, C,
                            rois, pairs, R, spatial_scale, P, sampling, add_ec, (bf16_t*)out);
     } else if (dtype == SGG_F32) {
         static bool done = false;
@@ -408,7 +434,7 @@ extern "C" int sgg_roi_align_fwd(const void* fmap, int B, int H, int W, int C, c
                 return SGG_ERR_LAUNCH;
             done = true;
         }
-        hipLaunchKernelGGL(roi_align_kernel<float>, dim3(R), dim3(256), smem, (hipStream_t)stream, (const float*)fmap, B, H, W, C,
+        hipLaunchKernelGGL(roi_align_kernel<float>, dim3(R, nsplit), dim3(256), smem, (hipStream_t)stream, (const float*)fmap, B, H, W, C,
                            rois, pairs, R, spatial_scale, P, sampling, add_ec, (float*)out);
     } else {
         return SGG_ERR_DTYPE;
