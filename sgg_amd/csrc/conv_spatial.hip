@@ -1,0 +1,224 @@
+// 3x3 convolution with an LDS-resident input patch (gfx950): the wide-spatial VGG layers (conv1_2 .. conv3_3).
+//
+// The implicit-GEMM kernels re-stage every input pixel once per filter tap (9x) -- and the global->LDS DMA issue
+// rate, not the matrix pipe, is what bounds those kernels (gemm256.hip ablation).  Here a workgroup owns a 16x16
+// output tile x CN output channels and, per 64-byte... per 128-byte input-channel slab (64 bf16 / 32 f32 channels),
+// stages the 18x18 input patch ONCE; the nine taps read it at shifted LDS rows.  Only the per-tap weight slab
+// [CN][128 B] is streamed (double-buffered, prefetched one tap ahead).  DMA per MFMA drops 3x vs the 128x128
+// implicit GEMM (0.16 vs 0.5 KiB per v_mfma_f32_32x32x16_bf16).
+//
+// 4*WN waves: wave (wm, wn) computes pixels rows 4wm..4wm+3 (64 px = two 32-px MFMA column blocks) x channels
+// 64wn..64wn+63 (two 32-row blocks): 2x2 MFMA 32x32 tiles, weights as the A operand (lane holds 4 consecutive n).
+// LDS rows are 128 B; 16-byte slot swizzle phys = slot ^ ((row>>1)&7) on the DMA source address and on the read.
+// Activations are zero-bordered NHWC planes, so the patch never needs border tests; tiles that overhang the right /
+// bottom edge clamp their loads inside the plane and mask their stores.
+#include "gemm_args.h"
+
+namespace {
+
+constexpr int TILE = 16, PW = TILE + 2, PROWS = PW * PW;   // 18x18 = 324 patch rows
+constexpr int PROWS_PAD = 328;                              // multiple of 8 (one DMA instruction = 8 rows)
+constexpr int RB = 128;                                     // bytes per LDS row
+
+struct ConvArgs {
+    const char* in;      // [B, H+2, W+2, Cin]
+    const char* w;       // [Cout][9][Cin]
+    const float* bias;
+    char* out;           // [B, H+2p, W+2p, Cout]
+    int B, H, W, Cin, Cout, out_pad, tiles_x, tiles_y;
+};
+
+template <bool BF16, int WN>
+__global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArgs g) {
+    constexpr int NW = 4 * WN, CN = 64 * WN;
+    constexpr int ESZ = BF16 ? 2 : 4;
+    constexpr int PATCH_B = PROWS_PAD * RB, WSLAB_B = CN * RB;
+    constexpr int PI = PROWS_PAD / 8;                        // 41 patch DMA instructions
+    constexpr int PI_W = (PI + NW - 1) / NW;                 // per wave
+    constexpr int WI_W = (CN / 8) / NW;                      // weight-slab DMA instructions per wave (= 2)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* patch = smem;
+    char* wbuf = smem + PATCH_B;                             // 2 x WSLAB_B
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // block -> (image, tile, channel block); channel blocks of one tile are adjacent (they share the input patch in L2)
+    const int ncb = g.Cout / CN;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int cb = bid % ncb;
+    bid /= ncb;
+    const int tx = bid % g.tiles_x;
+    bid /= g.tiles_x;
+    const int ty = bid % g.tiles_y;
+    const int b = bid / g.tiles_y;
+    const int y0 = ty * TILE, x0 = tx * TILE, n0 = cb * CN;
+
+    // ---- DMA source pointers
+    const char* psrc[PI_W];
+#pragma unroll
+    for (int j = 0; j < PI_W; ++j) {
+        const int instr = min(wave + j * NW, PI - 1);
+        const int r = min(instr * 8 + (lane >> 3), PROWS - 1);
+        const int py = r / PW, px = r - py * PW;
+        const int gy = min(y0 + py, g.H + 1), gx = min(x0 + px, g.W + 1);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        psrc[j] = g.in + (((long)b * (g.H + 2) + gy) * (g.W + 2) + gx) * g.Cin * ESZ + chunk * 16;
+    }
+    const char* wsrc[WI_W];
+#pragma unroll
+    for (int j = 0; j < WI_W; ++j) {
+        const int r = (wave * WI_W + j) * 8 + (lane >> 3);   // row = output channel inside the block
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        wsrc[j] = g.w + (long)(n0 + r) * 9 * g.Cin * ESZ + chunk * 16;
+    }
+    auto stage_patch = [&](int chunk) {
+        const long koff = (long)chunk * RB;
+#pragma unroll
+        for (int j = 0; j < PI_W; ++j)
+            if (wave + j * NW < PI) glds16(psrc[j] + koff, patch + (wave + j * NW) * 8 * RB);
+    };
+    auto stage_w = [&](int tap, int chunk, int buf) {
+        const long koff = ((long)tap * g.Cin) * ESZ + (long)chunk * RB;
+#pragma unroll
+        for (int j = 0; j < WI_W; ++j) glds16(wsrc[j] + koff, wbuf + buf * WSLAB_B + (wave * WI_W + j) * 8 * RB);
+    };
+
+    // ---- fragment addressing
+    const int fr = lane & 31, fh = lane >> 5;
+    int prow0[2];          // patch row of this lane's pixel (tap 0,0) for the two 32-pixel column blocks
+#pragma unroll
+    for (int j = 0; j < 2; ++j) prow0[j] = (wm * 4 + j * 2 + (fr >> 4)) * PW + (fr & 15);
+    int woff[2], wkey[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = wn * 64 + i * 32 + fr;
+        woff[i] = r * RB;
+        wkey[i] = (r >> 1) & 7;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunk = (g.Cin * ESZ) / RB;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        stage_patch(ch);
+        stage_w(0, ch, 0);
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) {
+                stage_w(tap + 1, ch, (tap + 1) & 1);
+                wait_vmcnt<WI_W>();                      // everything but the slab just issued has landed
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            const char* wb = wbuf + (tap & 1) * WSLAB_B;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int dp = ky * PW + kx;
+            int poff[2], pkey[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int pr = prow0[j] + dp;
+                poff[j] = pr * RB;
+                pkey[j] = (pr >> 1) & 7;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int slot = 2 * s + fh;
+                u32x4 av[2], bv[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    av[i] = *reinterpret_cast<const u32x4*>(wb + woff[i] + ((slot ^ wkey[i]) << 4));
+                    bv[i] = *reinterpret_cast<const u32x4*>(patch + poff[i] + ((slot ^ pkey[i]) << 4));
+                }
+#pragma unroll
+                for (int pj = 0; pj < 2; ++pj)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        if constexpr (BF16) {
+                            acc[pj][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8_t, av[ni]), __builtin_bit_cast(bf16x8_t, bv[pj]), acc[pj][ni], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                acc[pj][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                    __uint_as_float(av[ni][q]), __uint_as_float(bv[pj][q]), acc[pj][ni], 0, 0, 0);
+                        }
+                    }
+            }
+            __builtin_amdgcn_s_barrier();                // slab buffer (tap&1) and, after tap 8, the patch are free
+        }
+    }
+
+    // ---- epilogue through LDS: per wave a [32 px][64 ch] f32 tile (row stride 272 B), one pixel block at a time
+    constexpr int ESTRIDE = 272;
+    char* est = smem + wave * (32 * ESTRIDE);
+#pragma unroll
+    for (int pj = 0; pj < 2; ++pj) {
+        __syncthreads();
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {acc[pj][ni][4 * q], acc[pj][ni][4 * q + 1], acc[pj][ni][4 * q + 2], acc[pj][ni][4 * q + 3]};
+                *reinterpret_cast<f32x4*>(est + fr * ESTRIDE + (ni * 32 + 8 * q + 4 * fh) * 4) = v;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int pl = (lane >> 3) + 8 * it, cl = (lane & 7) * 8;   // pixel inside the 32-block, channel chunk
+            const int y = y0 + wm * 4 + pj * 2 + (pl >> 4), x = x0 + (pl & 15);
+            if (y >= g.H || x >= g.W) continue;
+            float v[8];
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(est + pl * ESTRIDE + cl * 4);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(est + pl * ESTRIDE + cl * 4 + 16);
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            const int n = n0 + wn * 64 + cl;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] + g.bias[n + k], 0.f);
+            const int op = g.out_pad;
+            const long off = (((long)b * (g.H + 2 * op) + y + op) * (g.W + 2 * op) + x + op) * g.Cout + n;
+            if constexpr (BF16) store8(reinterpret_cast<bf16_t*>(g.out) + off, v);
+            else store8(reinterpret_cast<float*>(g.out) + off, v);
+        }
+    }
+}
+
+template <bool BF16, int WN>
+int launch_spatial(const ConvArgs& g, hipStream_t s) {
+    constexpr int CN = 64 * WN;
+    constexpr int smem = PROWS_PAD * RB + 2 * CN * RB;
+    static_assert(smem >= 4 * WN * 32 * 272, "epilogue staging fits");
+    auto k = conv3x3_spatial_kernel<BF16, WN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return SGG_ERR_LAUNCH;
+        attr_done = true;
+    }
+    const int blocks = g.B * g.tiles_y * g.tiles_x * (g.Cout / CN);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256 * WN), smem, s, g);
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+}  // namespace
+
+// returns SGG_OK, or 1 if the shape is not handled here (caller falls through to the implicit-GEMM kernels)
+int sgg_launch_conv_spatial(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H, int W,
+                            int Cin, int Cout, bool bf16, hipStream_t s) {
+    ConvArgs g{};
+    g.in = (const char*)in; g.w = (const char*)w; g.bias = bias; g.out = (char*)out;
+    g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.out_pad = out_pad;
+    g.tiles_x = (W + TILE - 1) / TILE;
+    g.tiles_y = (H + TILE - 1) / TILE;
+    if (Cout % 128 == 0) return bf16 ? launch_spatial<true, 2>(g, s) : launch_spatial<false, 2>(g, s);
+    if (Cout % 64 == 0) return bf16 ? launch_spatial<true, 1>(g, s) : launch_spatial<false, 1>(g, s);
+    return 1;
+}

@@ -18,6 +18,8 @@
 #include "gemm_args.h"
 
 int sgg_launch_pingpong(const GemmArgs& g, bool bf16, bool conv, hipStream_t s);  // gemm256.hip
+int sgg_launch_conv_spatial(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H, int W,
+                            int Cin, int Cout, bool bf16, hipStream_t s);            // conv_spatial.hip
 
 namespace {
 
@@ -282,6 +284,16 @@ extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias
     if (!in || !w || !out || B <= 0 || H <= 0 || W <= 0 || Cin % bke || Cout % 64 || (out_pad != 0 && out_pad != 1))
         return SGG_ERR_ARG;
     if ((long)B * H * W > 0x7fffffffL) return SGG_ERR_ARG;
+    {
+        // wide-spatial layers: LDS-resident input patch kernel (conv_spatial.hip); small maps: implicit GEMM.
+        // SGG_CONV_FORCE=gemm|spatial overrides (experiments only).
+        static const char* force = getenv("SGG_CONV_FORCE");
+        const bool want = force ? (force[0] == 's') : (H >= 128 && W >= 128);
+        if (want) {
+            const int rc = sgg_launch_conv_spatial(in, w, bias, out, out_pad, B, H, W, Cin, Cout, dtype == SGG_BF16, (hipStream_t)stream);
+            if (rc <= 0) return rc;
+        }
+    }
     GemmArgs g{};
     g.A = (const char*)in; g.Wt = (const char*)w;
     g.ldw_b = (long)9 * Cin * esz;
