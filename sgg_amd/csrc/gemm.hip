@@ -288,7 +288,7 @@ extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias
         // wide-spatial layers: LDS-resident input patch kernel (conv_spatial.hip); small maps: implicit GEMM.
         // SGG_CONV_FORCE=gemm|spatial overrides (experiments only).
         static const char* force = getenv("SGG_CONV_FORCE");
-        const bool want = force ? (force[0] == 's') : (H >= 128 && W >= 128);
+        const bool want = force ? (force[0] == 's') : (H >= 64 && W >= 64);   // measured: conv1_2..conv4_3 faster here, conv5 (38x38) on the implicit GEMM
         if (want) {
             const int rc = sgg_launch_conv_spatial(in, w, bias, out, out_pad, B, H, W, Cin, Cout, dtype == SGG_BF16, (hipStream_t)stream);
             if (rc <= 0) return rc;

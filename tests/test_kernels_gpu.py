@@ -118,7 +118,7 @@ def test_gemm_rejects_bad_k(ops):
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('B,H,W,Cin,Cout', [(1, 16, 16, 64, 64), (2, 10, 14, 64, 128), (1, 38, 38, 128, 256),
                                             (2, 76, 76, 64, 1024), (3, 62, 70, 128, 512),
-                                            # LDS-resident-patch kernel (H,W >= 128): ragged tiles, 1-2 channel slabs, 64/128/256 outputs
+                                            # LDS-resident-patch kernel (H,W >= 64): ragged tiles, 1-2 channel slabs, 64/128/256 outputs
                                             (1, 128, 128, 64, 64), (2, 130, 152, 64, 128), (1, 144, 135, 128, 256)])
 def test_conv3x3(ops, dtype, B, H, W, Cin, Cout):
     g = torch.Generator().manual_seed(Cin + Cout)
