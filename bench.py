@@ -59,6 +59,15 @@ def kernel_times(step_fn, reps):
     return out
 
 
+def pmc_traffic(key):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_r01.json), or None."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_r01.json')) as f:
+            return json.load(f)[key]['traffic_bytes']
+    except Exception:
+        return None
+
+
 def imp_iter_ms(model, B, dtype, reps=50):
     """Average duration of ONE fused IMP gather/gate/scatter launch on a complete 32-box/image graph of B images:
     `reps` launches back-to-back between two HIP events on the launch stream (outputs pre-allocated)."""
@@ -243,15 +252,19 @@ def main():
                                                                   if args.mode == 'train' else 'no collective'),
                        'weights': 'random init (He), frozen VGG16 + trainable IMP head (247.75 M params)'},
             'roofline': {'kernel': 'MFMA tile kernel, %s' % desc, 'bound': 'mfma', 'achieved': round(tf, 2), 'peak': peak,
-                         'unit': 'TFLOP/s', 'frac': round(tf / peak, 4), 'traffic': None, 'ms_per_step': round(ms, 4)},
+                         'unit': 'TFLOP/s', 'frac': round(tf / peak, 4),
+                         'traffic': pmc_traffic('fc6_edge_gemm') if (tag == 'fc6_edge' and B == 8 and args.dtype == 'bf16') else None,
+                         'ms_per_step': round(ms, 4)},
             'roofline_imp': {'kernel': 'imp_fused_kernel (gather + 4 gates + scatter), one launch per IMP iteration', 'bound': 'hbm',
                              'achieved': round(imp_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                             'frac': round(imp_gbs / HBM_PEAK_GBS, 4), 'traffic': None,
+                             'frac': round(imp_gbs / HBM_PEAK_GBS, 4),
+                             'traffic': pmc_traffic('imp_fused_B8') if (B == 8 and args.dtype == 'bf16') else None,
                              'algorithmic_bytes': imp_bytes, 'avg_launch_ms': round(imp_ms, 5),
                              'note': '16.8 MB per launch at B=8: 2.7 us at 6.3 TB/s, below launch + dependent-latency floor'},
             'roofline_imp_large': {'kernel': 'same kernel, %d images (%d edges) per launch' % (BL, 992 * BL), 'bound': 'hbm',
                                    'achieved': round(impL_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                   'frac': round(impL_gbs / HBM_PEAK_GBS, 4), 'traffic': None,
+                                   'frac': round(impL_gbs / HBM_PEAK_GBS, 4),
+                                   'traffic': pmc_traffic('imp_fused_B128') if args.dtype == 'bf16' else None,
                                    'algorithmic_bytes': impL_bytes, 'avg_launch_ms': round(impL_ms, 5)},
             'kernels': {'sum_kernel_ms_per_step': round(total_ms, 3),
                         'vgg16_ms': round(conv_ms, 3), 'vgg16_tflops': round(vgg_flop / (conv_ms * 1e-3) / 1e12, 1) if conv_ms else 0,

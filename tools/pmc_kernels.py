@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Runs the two roofline kernels in isolation (for rocprofv3 --pmc passes): the fc6-on-edges GEMM and the fused IMP
+gather/gate/scatter at B=8 and B=128.  Usage under the profiler:
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d out -o fetch -- python3 tools/pmc_kernels.py
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d out -o write -- python3 tools/pmc_kernels.py
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sgg_amd import ops  # noqa: E402
+
+dev = 'cuda:0'
+g = torch.Generator().manual_seed(0)
+dt = torch.bfloat16
+# fc6 on edges
+M, N, K1, K2 = 7936, 4096, 25088, 512
+A = torch.randn(M, K1, generator=g).to(dev).to(dt).relu()
+A2 = torch.randn(M, K2, generator=g).to(dev).to(dt)
+W = (torch.randn(N, K1, generator=g) / 160).to(dev).to(dt)
+W2 = (torch.randn(N, K2, generator=g) / 160).to(dev).to(dt)
+b = torch.randn(N, generator=g).to(dev)
+out = torch.empty(M, N, device=dev, dtype=dt)
+for _ in range(3):
+    ops.gemm(A, W, b, ops.ACT_RELU, A2=A2, W2=W2, out=out)
+torch.cuda.synchronize()
+# IMP fused
+H, n = 512, 32
+gw = (torch.randn(4, 2 * H, generator=g) / 30).to(dev)
+gb = torch.randn(4, generator=g).to(dev)
+for B in (8, 128):
+    Nn, E = n * B, n * (n - 1) * B
+    im = torch.arange(B, device=dev).repeat_interleave(n)
+    rel, _ = ops.pair_index_eval(im)
+    rel = rel[:E]
+    csr = ops.edge_csr(rel, Nn, im)
+    v = torch.randn(Nn, H, generator=g).to(dev).to(dt)
+    e = torch.randn(E, H, generator=g).to(dev).to(dt)
+    for _ in range(3):
+        ops.imp_fused(v, e, rel, csr, gw.to(dt), gb)
+    torch.cuda.synchronize()
+print('done')
