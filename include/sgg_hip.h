@@ -14,6 +14,7 @@
 #ifndef SGG_HIP_H_
 #define SGG_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -143,6 +144,33 @@ int sgg_gru_gate_fwd(const void* gi, const void* gh, const float* b_hh, const vo
 int sgg_eval_tail(const void* obj_dists, int N, int C, const void* rel_dists, int E, int P,
                   const int64_t* rel_inds /*[E,3]*/, const int64_t* gt_classes /*[N] or NULL*/, float* obj_scores,
                   int64_t* obj_preds, int64_t* rels, float* pred_scores, void* work, int dtype, void* stream);
+
+/* ---- a-12  SGDet front end after the backbone: [3P] torchvision RPN + RoIHeads in eval mode, called at
+ * sgg_models/rel_model_base.py:210-213.  Dense parts use sgg_conv3x3_relu / sgg_gemm / sgg_roi_align_fwd. ----
+ * rpn_decode: head f32[B*Hf*Wf, ldh] (cols [0,A) objectness, [A,5A) deltas a*4+c) + base anchors f32[A,4] ->
+ *   boxes f32[B,Hf*Wf*A,4] (BoxCoder weights 1,1,1,1, not clipped), scores = raw objectness, anchors in (y,x,a) order.
+ * segmented_sort_desc: stable descending sort of each segment (rocPRIM); vals_out = position inside the segment.
+ * gather_topk: first `take` sorted entries per segment -> clipped boxes, scores, labels, valid (finite score, w,h >= min_size).
+ * nms: greedy NMS on score-ordered boxes [B,n,4], IoU > thresh suppresses (class-aware when labels != NULL).
+ * compact_rois: kept boxes of all images -> rois f32[total,5], offsets i32[B+1].
+ * det_candidates: pred f32[K,ldp] (cols [0,C) logits, [C,5C) regression c*4+k) -> per (roi, class>=1) softmax score
+ *   (-inf unless > thresh and box >= min_size), decoded (weights 10,10,5,5) clipped box, label.
+ * det_output: gather of the kept candidates -> boxes f32[B,max_keep,4], scores, labels i64. */
+int sgg_rpn_decode(const float* head, int ldh, const float* base_anchors, int A, int Hf, int Wf, float stride_y, float stride_x,
+                   int B, float* boxes, float* scores, void* stream);
+int sgg_segmented_sort_desc(const float* keys_in, float* keys_out, int* vals_tmp, int* vals_out, int n, int nseg,
+                            const int* seg_off, int seg_len_hint, void* temp, size_t* temp_bytes, void* stream);
+int sgg_gather_topk(const float* keys_sorted, const int* vals_sorted, const int* seg_off, const float* boxes,
+                    const int* labels_in, const float* img_hw, int B, int take, float min_size, float* out_boxes,
+                    float* out_scores, int* out_labels, unsigned char* valid, void* stream);
+int sgg_nms(const float* boxes, const int* labels, const unsigned char* valid, int B, int n, float thresh, int max_keep,
+            void* mask_ws, int* keep_idx, int* keep_cnt, void* stream);
+int sgg_compact_rois(const float* boxes, const int* keep_idx, const int* keep_cnt, int B, int n, int max_keep, float* rois,
+                     int* offsets, void* stream);
+int sgg_det_candidates(const float* pred, int ldp, const float* rois, int K, int C, const float* img_hw, float score_thresh,
+                       float min_size, float* cand_score, float* cand_box, int* cand_label, void* stream);
+int sgg_det_output(const float* boxes, const float* scores, const int* labels, const int* keep_idx, const int* keep_cnt, int B,
+                   int n, int max_keep, float* out_boxes, float* out_scores, int64_t* out_labels, void* stream);
 
 /* ---- training side of the trainable relation head (main.py:100-120: forward in train mode, backward) ----
  * Dense gradient contractions reuse sgg_gemm on transposed operands.  All *_bwd calls are stream-ordered like the

@@ -39,6 +39,13 @@ SIGNATURES = {
     'sgg_imp_fused_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     'sgg_gru_gate_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sgg_eval_tail': [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    'sgg_rpn_decode': [_P, _I, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P],
+    'sgg_segmented_sort_desc': [_P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P],
+    'sgg_gather_topk': [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P],
+    'sgg_nms': [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P],
+    'sgg_compact_rois': [_P, _P, _P, _I, _I, _I, _P, _P, _P],
+    'sgg_det_candidates': [_P, _I, _P, _I, _I, _P, _F, _F, _P, _P, _P, _P],
+    'sgg_det_output': [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     'sgg_dropout_fwd': [_P, _L, _F, ctypes.c_uint64, _I, _P],
     'sgg_act_bwd': [_P, _P, _P, _L, _F, _I, _I, _P],
     'sgg_colsum': [_P, _I, _I, _I, _P, _I, _P],

@@ -140,9 +140,9 @@ class RelModelBase(nn.Module):
         self.detector.roi_heads.score_thresh = box_score_thresh  # rel_model_base.py:168-172
 
     def faster_rcnn(self, x, gt_boxes, gt_classes, gt_rels):
-        """rel_model_base.py:175-242, gt-box branch (predcls / sgcls)."""
+        """rel_model_base.py:175-242: gt-box branch (predcls / sgcls) and the detector branch (sgdet, eval only)."""
         if self.mode == 'sgdet':
-            raise NotImplementedError('SGDet front end (RPN + RoIHeads) is SURVEY 8f-3, not built yet')
+            return self._faster_rcnn_sgdet(x, gt_classes)
         dtype = self.compute_dtype
         im_host = gt_classes[:, 0].detach().to('cpu').tolist()           # the one D2H sync of the forward
         segs = list(enumerate_by_image_host(im_host))
@@ -172,6 +172,42 @@ class RelModelBase(nn.Module):
         result.fmap = as_nchw_view(fmap)
         result.rois = torch.cat((im_inds.float()[:, None], priors), 1)
         result._num_pairs = sum((e - s) * (e - s - 1) for _, s, e in segs)   # host-side count (private)
+        return result
+
+    def _faster_rcnn_sgdet(self, x, gt_classes):
+        """rel_model_base.py:209-235: RPN + RoI heads (sgg_amd/sgdet.py), <= 50 detections per image."""
+        from . import sgdet
+        if self.training:
+            raise NotImplementedError('SGDet training is documented as unsupported by the reference (README.md:214-218)')
+        dtype = self.compute_dtype
+        if gt_classes is not None and gt_classes.numel() > 0:
+            ids = sorted(set(int(v) for v in gt_classes[:, 0].detach().to('cpu').tolist()))
+        else:
+            ids = list(range(len(x)))
+        images = [x[i] for i in ids]
+        fmap, sizes, padded = self.detector.features(images, dtype)
+        self.fmap_hw = (fmap.shape[1], fmap.shape[2])
+        orig = [tuple(int(v) for v in im.shape[-2:]) for im in images]
+        dets = sgdet.detect(self, fmap, sizes, padded, orig, self.spatial_scale(sizes))
+        priors, priors_org, labels, im_inds = [], [], [], []
+        for i, (bx, bx_org, lab, _) in enumerate(dets):
+            if bx.shape[0] <= 1:
+                raise ValueError('at least two objects must be detected to build relationships, make sure the detector is '
+                                 'properly pretrained', dets)                                       # :216-219
+            priors.append(bx)
+            priors_org.append(bx_org)
+            labels.append(lab)
+            im_inds.append(torch.full((bx.shape[0],), i, dtype=torch.int64, device=bx.device))
+        im_inds = torch.cat(im_inds)
+        result = Result(rm_obj_labels=torch.cat(labels).view(-1), rm_box_priors=torch.cat(priors), rel_labels=None,
+                        im_inds=im_inds)
+        result.rm_box_priors_org = torch.cat(priors_org)
+        if result.rm_box_priors.shape[0] <= 1:
+            raise ValueError('at least two objects must be detected to build relationships')        # :234-235
+        result.im_sizes_org = orig
+        result.im_sizes = sizes
+        result.fmap = as_nchw_view(fmap)
+        result.rois = torch.cat((im_inds.float()[:, None], result.rm_box_priors), 1)
         return result
 
     def node_edge_features(self, fmap, rois, union_inds, im_sizes):

@@ -1,0 +1,167 @@
+"""SGDet front end after the backbone (SURVEY a-12): what `detector.rpn`, `detector.roi_heads` and
+`detector.transform.postprocess` do in eval mode at sgg_models/rel_model_base.py:210-213 ([3P] torchvision FasterRCNN),
+on the HIP path.  Dense parts: sgg_conv3x3_relu (RPN 3x3), sgg_gemm (1x1 heads, box head fc6/fc7, predictor),
+sgg_roi_align_fwd; the rest in csrc/det.hip.  Eval only -- torchvision's RoIHeads returns no detections in training mode,
+which is why the reference documents SGDet training as unsupported (README.md:214-218).
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib, ops
+
+ANCHOR_SIZES = (32, 64, 128, 256, 512)      # rel_model_base.py:94
+ANCHOR_RATIOS = (0.5, 1.0, 2.0)             # rel_model_base.py:95
+RPN_PRE_NMS, RPN_POST_NMS, RPN_NMS_THRESH, RPN_MIN_SIZE = 1000, 1000, 0.7, 1e-3   # [3P] FasterRCNN test-time defaults
+DET_MIN_SIZE = 1e-2                          # [3P] RoIHeads.postprocess_detections
+DET_PRE_NMS_CAP = 4096                       # documented deviation: candidates entering the per-class NMS
+
+
+def base_anchors(device):
+    """[3P] AnchorGenerator.generate_anchors (ratio-major, scale-minor, rounded); 15 x 4 floats, computed on the host."""
+    out = []
+    for r in ANCHOR_RATIOS:
+        hr = math.sqrt(r)
+        wr = 1.0 / hr
+        for s in ANCHOR_SIZES:
+            w, h = torch.tensor(wr, dtype=torch.float32) * s, torch.tensor(hr, dtype=torch.float32) * s
+            out.append([float(torch.round(-w / 2)), float(torch.round(-h / 2)), float(torch.round(w / 2)),
+                        float(torch.round(h / 2))])
+    return torch.tensor(out, dtype=torch.float32, device=device)
+
+
+def _sort_desc(keys, seg_off, nseg, seg_len_hint=0):
+    """stable descending sort per segment -> (keys_sorted, pos_in_segment)."""
+    n = keys.numel()
+    dev = keys.device
+    keys_out = torch.empty_like(keys)
+    vals_tmp = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    vals_out = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    nbytes = ctypes.c_size_t(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.call('sgg_segmented_sort_desc', None, None, None, None, n, nseg, None, seg_len_hint, None, ctypes.byref(nbytes), stream)
+    temp = torch.empty(max(int(nbytes.value), 8), dtype=torch.uint8, device=dev)
+    _lib.call('sgg_segmented_sort_desc', keys.data_ptr(), keys_out.data_ptr(), vals_tmp.data_ptr(), vals_out.data_ptr(), n,
+              nseg, seg_off.data_ptr(), seg_len_hint, temp.data_ptr(), ctypes.byref(nbytes), stream)
+    return keys_out, vals_out
+
+
+def _nms(boxes, labels, valid, thresh, max_keep):
+    B, n = boxes.shape[0], boxes.shape[1]
+    dev = boxes.device
+    ws = torch.empty(B * n * ((n + 63) // 64), dtype=torch.int64, device=dev)
+    keep_idx = torch.empty((B, max_keep), dtype=torch.int32, device=dev)
+    keep_cnt = torch.empty(B, dtype=torch.int32, device=dev)
+    _lib.call('sgg_nms', boxes.data_ptr(), labels.data_ptr() if labels is not None else None, valid.data_ptr(), B, n,
+              float(thresh), max_keep, ws.data_ptr(), keep_idx.data_ptr(), keep_cnt.data_ptr(),
+              torch.cuda.current_stream().cuda_stream)
+    return keep_idx, keep_cnt
+
+
+def prepared(model):
+    """RPN / box-head weights in kernel layout (the detector is frozen: built once)."""
+    det = model.detector
+    dt = model.compute_dtype
+    key = ('sgdet', dt, det.rpn.head.conv.weight.data_ptr(), det.rpn.head.conv.weight._version)
+    if getattr(det, '_sgdet_prep', {}).get('key') == key:
+        return det._sgdet_prep['val']
+    f = lambda t: t.detach().float().contiguous()
+    cast = lambda t: t if t.dtype == dt else ops.cast(t, dt)
+    h, rh = det.rpn.head, det.roi_heads
+    w = {}
+    cw = f(h.conv.weight)
+    w['rpn_conv'] = ops.permute_ncp_to_npc(cw.reshape(cw.shape[0], cw.shape[1], 9), dt).view(cw.shape[0], 3, 3, cw.shape[1])
+    w['rpn_conv_b'] = f(h.conv.bias)
+    A = h.cls_logits.weight.shape[0]
+    w['rpn_head'] = cast(torch.cat((f(h.cls_logits.weight).reshape(A, -1), f(h.bbox_pred.weight).reshape(4 * A, -1)), 0))
+    w['rpn_head_b'] = torch.cat((f(h.cls_logits.bias), f(h.bbox_pred.bias)))
+    w['A'] = A
+    w['fc6'], w['fc6_b'] = cast(f(rh.box_head.fc6.weight)), f(rh.box_head.fc6.bias)
+    w['fc7'], w['fc7_b'] = cast(f(rh.box_head.fc7.weight)), f(rh.box_head.fc7.bias)
+    w['pred'] = cast(torch.cat((f(rh.box_predictor.cls_score.weight), f(rh.box_predictor.bbox_pred.weight)), 0))
+    w['pred_b'] = torch.cat((f(rh.box_predictor.cls_score.bias), f(rh.box_predictor.bbox_pred.bias)))
+    w['C'] = rh.box_predictor.cls_score.weight.shape[0]
+    w['anchors'] = base_anchors(cw.device)
+    det._sgdet_prep = dict(key=key, val=w)
+    return w
+
+
+def detect(model, fmap, image_sizes, padded_hw, orig_sizes, spatial_scale):
+    """fmap [B,Hf,Wf,512] NHWC (compute dtype).  Returns per-image lists (boxes in resized space, boxes in original
+    space, labels i64, scores) -- rel_model_base.py:215-232 consumes them."""
+    w = prepared(model)
+    det = model.detector
+    dt = model.compute_dtype
+    dev = fmap.device
+    B, Hf, Wf, Cf = fmap.shape
+    stream = torch.cuda.current_stream().cuda_stream
+    A, C = w['A'], w['C']
+    img_hw = torch.tensor([[float(s[0]), float(s[1])] for s in image_sizes], dtype=torch.float32, device=dev)
+    # ---- RPN head: 3x3 conv + ReLU, then the two 1x1 convs as one GEMM over pixels
+    fpad = torch.zeros((B, Hf + 2, Wf + 2, Cf), dtype=dt, device=dev)
+    fpad[:, 1:-1, 1:-1].copy_(fmap)
+    t = torch.empty((B, Hf, Wf, Cf), dtype=dt, device=dev)
+    ops.conv3x3_relu(fpad, w['rpn_conv'], w['rpn_conv_b'], t, 0)
+    head = ops.gemm(t.view(B * Hf * Wf, Cf), w['rpn_head'], w['rpn_head_b'], out_dtype=torch.float32)     # [B*HW, 5A]
+    n_anch = Hf * Wf * A
+    boxes = torch.empty((B, n_anch, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((B, n_anch), dtype=torch.float32, device=dev)
+    _lib.call('sgg_rpn_decode', head.data_ptr(), head.stride(0), w['anchors'].data_ptr(), A, Hf, Wf,
+              float(padded_hw[0] // Hf), float(padded_hw[1] // Wf), B, boxes.data_ptr(), scores.data_ptr(), stream)
+    # ---- top-k by objectness, clip, drop small, NMS 0.7, keep <= 1000
+    seg = torch.arange(0, B + 1, dtype=torch.int32, device=dev) * n_anch
+    ks, vs = _sort_desc(scores.view(-1), seg, B, n_anch)
+    take = min(RPN_PRE_NMS, n_anch)
+    pb = torch.empty((B, take, 4), dtype=torch.float32, device=dev)
+    ps = torch.empty((B, take), dtype=torch.float32, device=dev)
+    pv = torch.empty((B, take), dtype=torch.uint8, device=dev)
+    _lib.call('sgg_gather_topk', ks.data_ptr(), vs.data_ptr(), seg.data_ptr(), boxes.data_ptr(), None, img_hw.data_ptr(), B, take,
+              RPN_MIN_SIZE, pb.data_ptr(), ps.data_ptr(), None, pv.data_ptr(), stream)
+    keep_idx, keep_cnt = _nms(pb, None, pv, RPN_NMS_THRESH, min(RPN_POST_NMS, take))
+    rois = torch.empty((B * take, 5), dtype=torch.float32, device=dev)
+    offs = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    _lib.call('sgg_compact_rois', pb.data_ptr(), keep_idx.data_ptr(), keep_cnt.data_ptr(), B, take, keep_idx.shape[1],
+              rois.data_ptr(), offs.data_ptr(), stream)
+    offs_h = offs.cpu().tolist()                                 # one D2H read: proposal counts size the box-head GEMMs
+    K = offs_h[-1]
+    if K == 0:
+        raise ValueError('at least two objects must be detected to build relationships, make sure the detector is properly '
+                         'pretrained', [])
+    rois = rois[:K]
+    # ---- RoI heads: RoIAlign -> fc6 -> fc7 -> (cls_score | bbox_pred)
+    feat = ops.roi_align(fmap, rois, None, spatial_scale, model.pool_sz, 2).view(K, -1)
+    x = ops.gemm(feat, w['fc6'], w['fc6_b'], ops.ACT_RELU)
+    x = ops.gemm(x, w['fc7'], w['fc7_b'], ops.ACT_RELU)
+    pred = ops.gemm(x, w['pred'], w['pred_b'], out_dtype=torch.float32)                                    # [K, 5C]
+    ncand = K * (C - 1)
+    cs = torch.empty(ncand, dtype=torch.float32, device=dev)
+    cb = torch.empty((ncand, 4), dtype=torch.float32, device=dev)
+    cl = torch.empty(ncand, dtype=torch.int32, device=dev)
+    _lib.call('sgg_det_candidates', pred.data_ptr(), pred.stride(0), rois.data_ptr(), K, C, img_hw.data_ptr(),
+              float(det.roi_heads.score_thresh), DET_MIN_SIZE, cs.data_ptr(), cb.data_ptr(), cl.data_ptr(), stream)
+    cseg = torch.tensor([o * (C - 1) for o in offs_h], dtype=torch.int32, device=dev)
+    ks2, vs2 = _sort_desc(cs, cseg, B, 0)
+    cap = DET_PRE_NMS_CAP
+    db = torch.empty((B, cap, 4), dtype=torch.float32, device=dev)
+    ds = torch.empty((B, cap), dtype=torch.float32, device=dev)
+    dl = torch.empty((B, cap), dtype=torch.int32, device=dev)
+    dv = torch.empty((B, cap), dtype=torch.uint8, device=dev)
+    _lib.call('sgg_gather_topk', ks2.data_ptr(), vs2.data_ptr(), cseg.data_ptr(), cb.data_ptr(), cl.data_ptr(), img_hw.data_ptr(), B,
+              cap, DET_MIN_SIZE, db.data_ptr(), ds.data_ptr(), dl.data_ptr(), dv.data_ptr(), stream)
+    mk = int(det.roi_heads.detections_per_img)
+    kidx, kcnt = _nms(db, dl, dv, float(det.roi_heads.nms_thresh), mk)
+    ob = torch.zeros((B, mk, 4), dtype=torch.float32, device=dev)
+    osc = torch.zeros((B, mk), dtype=torch.float32, device=dev)
+    ol = torch.zeros((B, mk), dtype=torch.int64, device=dev)
+    _lib.call('sgg_det_output', db.data_ptr(), ds.data_ptr(), dl.data_ptr(), kidx.data_ptr(), kcnt.data_ptr(), B, cap, mk,
+              ob.data_ptr(), osc.data_ptr(), ol.data_ptr(), stream)
+    cnt = kcnt.cpu().tolist()
+    out = []
+    for b in range(B):
+        n = cnt[b]
+        bx = ob[b, :n]
+        rh, rw = float(orig_sizes[b][0]) / float(image_sizes[b][0]), float(orig_sizes[b][1]) / float(image_sizes[b][1])
+        scale = torch.tensor([rw, rh, rw, rh], dtype=torch.float32, device=dev)     # [3P] transform.postprocess
+        out.append((bx, bx * scale, ol[b, :n], osc[b, :n]))
+    return out

@@ -39,7 +39,10 @@ def test_argument_counts_match_header():
 def test_library_is_gfx950_code_object():
     from sgg_amd import _lib
     blob = open(_lib.LIB_PATH, 'rb').read()
-    assert b'gfx950' in blob and b'gfx942' not in blob and b'sm_' not in blob[:0]
+    # every embedded device code object (offload-bundle entry id "...amdhsa--gfxNNN") targets gfx950 only
+    # (rocPRIM's host-side arch-name table also mentions other gfx names; those are strings, not code)
+    targets = set(re.findall(rb'amdhsa--(gfx[0-9a-z]+)', blob))
+    assert targets == {b'gfx950'}, targets
 
 
 def test_product_path_never_imports_oracle():
