@@ -431,25 +431,41 @@ void bn_bwd_launch(const void* dy, const unsigned char* arg, const void* x, cons
 }
 
 // ---- optimiser step (main.py:119-120: grad_clip then SGD with momentum, lib/pytorch_misc.py:144,625-656)
-// sum of squares of g into *acc (one atomic per block)
+// sum of squares of g into *acc (one atomic per block); 4 independent 8-element pieces in flight per thread
 template <typename T>
 __global__ __launch_bounds__(256) void sqnorm_kernel(const T* __restrict__ g, long n, float* __restrict__ acc) {
     __shared__ float red[4];
-    float s = 0.f;
-    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (long)gridDim.x * 256 * 8) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const long stride = (long)gridDim.x * 256 * 8;
+    long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+    for (; i + 3 * stride + 8 <= n; i += 4 * stride) {
+        float a[8], b[8], c[8], d[8];
+        load8(g + i, a);
+        load8(g + i + stride, b);
+        load8(g + i + 2 * stride, c);
+        load8(g + i + 3 * stride, d);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            s0 = fmaf(a[k], a[k], s0);
+            s1 = fmaf(b[k], b[k], s1);
+            s2 = fmaf(c[k], c[k], s2);
+            s3 = fmaf(d[k], d[k], s3);
+        }
+    }
+    for (; i < n; i += stride) {
         if (i + 8 <= n) {
             float v[8];
             load8(g + i, v);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) s = fmaf(v[k], v[k], s);
+            for (int k = 0; k < 8; ++k) s0 = fmaf(v[k], v[k], s0);
         } else {
             for (long k = i; k < n; ++k) {
                 const float v = Elem<T>::ld(g + k);
-                s = fmaf(v, v, s);
+                s0 = fmaf(v, v, s0);
             }
         }
     }
-    s = wave_sum(s);
+    float s = wave_sum((s0 + s1) + (s2 + s3));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
@@ -674,7 +690,7 @@ extern "C" int sgg_sqnorm_acc(const void* g, int64_t n, float* acc, int dtype, v
     if (n == 0) return SGG_OK;
     if (!g || !acc || n < 0) return SGG_ERR_ARG;
     long blocks = (n / 8 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     hipStream_t s = (hipStream_t)stream;
     DISPATCH2(dtype, hipLaunchKernelGGL(sqnorm_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)g, (long)n, acc),

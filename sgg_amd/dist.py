@@ -68,9 +68,13 @@ class GradBuckets(object):
         self.small = [p for p in self.params if p.numel() * p.element_size() < big_bytes]
 
     def all_reduce(self, average=True):
+        """Returns {param: reduced buffer} for the big tensors when they were reduced in a narrower comm dtype (the
+        optimiser can consume those directly); p.grad of every parameter also holds the reduced gradient, except that the
+        copy back into fp32 .grad is skipped for those big tensors when `average` is False (the caller uses the dict)."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-            return
+            return {}
         world = dist.get_world_size()
+        direct = {}
         works, bufs = [], []
         for p in self.big:
             if p.grad is None:
@@ -87,7 +91,10 @@ class GradBuckets(object):
             w.wait()
         for p, buf in bufs:
             if buf is not p.grad:
-                p.grad.copy_(buf)
+                if average:
+                    p.grad.copy_(buf)
+                else:
+                    direct[p] = buf          # consumed as is (bf16) by the fused optimiser: no copy back
             if average:
                 p.grad.div_(world)
         if flat is not None:
@@ -102,3 +109,4 @@ class GradBuckets(object):
                 else:
                     p.grad.copy_(g)
                 off += n
+        return direct

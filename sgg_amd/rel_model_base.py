@@ -245,16 +245,28 @@ class RelModelBase(nn.Module):
                 first[i] = s
             n_cand = sum((e - s) * (e - s - 1) for _, s, e in segs)
             R = gt_rels.shape[0]
-            num_fg_cap = int(self.RELS_PER_IMG * REL_FG_FRACTION * num_im)
-            if R > num_fg_cap or n_cand > int(self.RELS_PER_IMG * num_im) - min(R, num_fg_cap) or sample_factor > -1:
-                raise NotImplementedError('relation sub-sampling (random_choose) is not on the HIP path yet; '
-                                          'raise RELS_PER_IMG or cap boxes per image')
             cap = n_cand + R
             out, count = ops.pair_index_train(im_inds.long().contiguous(), gt_rels.long().contiguous(),
                                               torch.tensor(first, dtype=torch.int32).to(im_inds.device), cap)
             # rows = candidates + (extra rows for duplicate FG relations on one pair); FG pairs replace a candidate
             n = int(count.item())
             rel_labels = out[:n]
+            # sub-sampling (lib/proposal_assignments_gtbox.py:47-66): at most RELS_PER_IMG*0.25*num_im FG rows and
+            # RELS_PER_IMG*num_im rows in total (or num_fg*sample_factor BG rows).  random_choose is a uniform random
+            # subset; rows keep their (img, subj, obj) order, so the final sort of :74-77 is already satisfied.
+            num_fg = min(R, int(self.RELS_PER_IMG * REL_FG_FRACTION * num_im))
+            n_bg_all = n - R
+            sample_bg = num_im > 1 and sample_factor > -1
+            num_bg = min(n_bg_all, int(num_fg * sample_factor) if sample_bg else int(self.RELS_PER_IMG * num_im) - num_fg)
+            if num_fg < R or num_bg < n_bg_all:
+                is_fg = rel_labels[:, 3] > 0
+                keep = torch.ones(n, dtype=torch.bool, device=rel_labels.device)
+                for mask, want, have in ((is_fg, num_fg, R), (~is_fg, max(num_bg, 0), n_bg_all)):
+                    if want < have:
+                        pos = torch.nonzero(mask).view(-1)
+                        drop = pos[torch.randperm(have, device=pos.device)[want:]]
+                        keep[drop] = False
+                rel_labels = rel_labels[keep].contiguous()
             obj_labels = gt_classes[:, 1].contiguous()
         else:
             obj_labels = gt_classes[:, 1]

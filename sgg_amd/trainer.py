@@ -33,19 +33,23 @@ class FusedSGD(object):
             g['p'].grad = None
 
     @torch.no_grad()
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, grads=None):
+        """grads (optional): {param: tensor} overriding p.grad -- e.g. the bf16 buffers an all-reduce left behind, consumed
+        directly (fp32 or bf16) instead of being copied back into fp32 .grad tensors."""
         stream = torch.cuda.current_stream().cuda_stream
         dev = self.groups[0]['p'].device
         if self._norm is None:
             self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._norm.zero_()
-        live = [g for g in self.groups if g['p'].grad is not None]
+        grads = grads or {}
+        grad_of = lambda p: grads.get(p, p.grad)
+        live = [g for g in self.groups if grad_of(g['p']) is not None]
         if self.clip and self.clip > 0:
             for g in live:
-                gr = g['p'].grad
+                gr = grad_of(g['p'])
                 _lib.call('sgg_sqnorm_acc', gr.data_ptr(), gr.numel(), self._norm.data_ptr(), ops.dt(gr), stream)
         for g in live:
-            p, gr = g['p'], g['p'].grad
+            p, gr = g['p'], grad_of(g['p'])
             first = g['buf'] is None
             if first:
                 g['buf'] = torch.empty_like(p, dtype=torch.float32)
@@ -114,8 +118,7 @@ class Trainer(object):
         loss = self.losses(res)
         self.opt.zero_grad()
         loss.backward()
-        if self.world > 1:
-            self.buckets.all_reduce(average=False)
-        self.opt.step()
+        reduced = self.buckets.all_reduce(average=False) if self.world > 1 else None
+        self.opt.step(grads=reduced)
         self.model.global_batch_iter = getattr(self.model, 'global_batch_iter', 0) + 1
         return loss.detach()

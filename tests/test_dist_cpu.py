@@ -30,7 +30,14 @@ def _worker(rank, world, port, q):
     lin(x).sum().backward()
     local = [p.grad.clone() for p in lin.parameters()]
     D.GradBuckets(lin.parameters(), big_bytes=256).all_reduce(average=True)   # Linear(8,16).weight is 'big'
-    q.put((r, (lo, hi), mx, tot, [g.tolist() for g in local], [p.grad.tolist() for p in lin.parameters()]))
+    avg = [p.grad.clone() for p in lin.parameters()]
+    # the DP train-step form: SUM in a different wire dtype, big tensors handed back as buffers (no copy into .grad)
+    for p, g in zip(lin.parameters(), local):
+        p.grad = g.clone()
+    direct = D.GradBuckets(lin.parameters(), big_bytes=256, comm_dtype=torch.float64).all_reduce(average=False)
+    summed = [(direct[p] if p in direct else p.grad).float() for p in lin.parameters()]
+    ok = len(direct) == 1 and all(torch.allclose(s, a * 2, atol=1e-6) for s, a in zip(summed, avg))
+    q.put((r, (lo, hi), mx, tot, [g.tolist() for g in local], [g.tolist() for g in avg], ok))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -46,7 +53,8 @@ def test_world_size_2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, s0, m0, t0, l0, g0), (r1, s1, m1, t1, l1, g1) = out
+    (r0, s0, m0, t0, l0, g0, ok0), (r1, s1, m1, t1, l1, g1, ok1) = out
+    assert ok0 and ok1
     assert s0 == (0, 7) and s1 == (7, 13)                 # contiguous, covers all images once
     assert m0 == m1 == 2.0                                # max over ranks
     assert t0 == t1 == [13.0, 2.0]

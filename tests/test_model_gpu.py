@@ -126,3 +126,28 @@ def test_error_contract(setup):
         with torch.no_grad():
             model([batch])                          # rel_model_stanford.py:193
     model.mode = 'sgcls'
+
+
+def test_train_relation_subsampling_keeps_order_and_caps(setup):
+    """lib/proposal_assignments_gtbox.py:47-66: more candidates than RELS_PER_IMG -> random subset, still sorted."""
+    model, batch, _, _ = setup
+    model.train()
+    old = model.RELS_PER_IMG
+    model.RELS_PER_IMG = 8                      # 3 images: <= 6 FG rows, 24 rows in total
+    try:
+        gt_boxes, gt_classes, gt_rels = batch[3].to(DEV), batch[4].to(DEV), batch[5].to(DEV)
+        torch.manual_seed(0)
+        _, labels, rl = model.gt_labels(gt_boxes, gt_classes, gt_rels)
+        rl = rl.cpu().numpy()
+        assert len(rl) == 24 and (rl[:, 3] > 0).sum() == 6
+        key = rl[:, 0] * 10 ** 6 + rl[:, 1] * 1000 + rl[:, 2]
+        assert (np.diff(key) >= 0).all()                                  # still sorted by (img, subj, obj)
+        full = O.proposal_assignments_gtbox(np.concatenate((batch[4][:, :1].float().numpy(), batch[3].numpy()), 1),
+                                            batch[3].numpy(), batch[4].numpy(), batch[5].numpy(), RELS_PER_IMG=10 ** 6)[2]
+        rows = set(map(tuple, full.tolist()))
+        assert all(tuple(r) in rows for r in rl.tolist())                 # a subset of the un-sampled assignment
+        _, _, rl2 = model.gt_labels(gt_boxes, gt_classes, gt_rels)
+        assert not np.array_equal(rl, rl2.cpu().numpy())                 # random subset
+    finally:
+        model.RELS_PER_IMG = old
+        model.eval()
