@@ -36,7 +36,7 @@ def _worker(rank, world, port, q):
         p.grad = g.clone()
     direct = D.GradBuckets(lin.parameters(), big_bytes=256, comm_dtype=torch.float64).all_reduce(average=False)
     summed = [(direct[p] if p in direct else p.grad).float() for p in lin.parameters()]
-    ok = len(direct) == 1 and all(torch.allclose(s, a * 2, atol=1e-6) for s, a in zip(summed, avg))
+    ok = len(direct) == 2 and all(torch.allclose(s, a * 2, atol=1e-6) for s, a in zip(summed, avg))
     q.put((r, (lo, hi), mx, tot, [g.tolist() for g in local], [g.tolist() for g in avg], ok))
     dist.barrier()
     dist.destroy_process_group()
