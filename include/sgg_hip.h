@@ -106,6 +106,12 @@ int sgg_gemm(const void* A, int lda, const void* A2, int lda2, int K1, const voi
              const float* post_scale, const float* post_shift, void* C, int ldc, int M, int N, int K, int act,
              int in_dtype, int out_dtype, void* stream);
 
+/* Split-K form for short-M contractions (fc6 on the object rows: M = 32B): `splits` workgroups per output tile reduce
+ * K ranges into workspace f32[splits, M, N]; one reduce + epilogue pass writes C[M,N] (ldc == N, N % 8 == 0). */
+int sgg_gemm_splitk(const void* A, int lda, const void* W, int ldw, const float* bias, const float* post_scale,
+                    const float* post_shift, void* C, int M, int N, int K, int act, int in_dtype, int out_dtype, int splits,
+                    float* workspace, void* stream);
+
 /* ---- a-8  IMP gather / gate / scatter: RelModelStanford.message_pass, rel_model_stanford.py:74-91 ----
  * node_gate_dots: d[n,4] = (w_sub[:H].v, w_obj[:H].v, w_out[:H].v, w_in[:H].v)  (vertex halves of the four
  *   Linear(2H,1) gates, :41-45).  gate_w f32[4,2H] rows = sub_vert, obj_vert, out_edge, in_edge; gate_b f32[4].

@@ -33,6 +33,7 @@ SIGNATURES = {
     'sgg_max4_rows': [_P, _P, _I, _I, _I, _P],
     'sgg_bcast_add': [_P, _P, _I, _I, _I, _I, _P],
     'sgg_gemm': [_P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    'sgg_gemm_splitk': [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     'sgg_imp_node_gate_dots': [_P, _I, _I, _P, _P, _I, _P],
     'sgg_imp_edge_ctx_fwd': [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     'sgg_imp_node_scatter_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P],

@@ -117,10 +117,13 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
         bkey[i] = (rb >> 1) & 7;
     }
 
-    stage(0, 0);
-    for (int kt = 0; kt < g.nt; ++kt) {
+    // split-K (gridDim.y > 1): this block reduces k-tiles [kt0, kt1) into its own fp32 partial output
+    const int nsplit = gridDim.y;
+    const int kt0 = (int)((long)g.nt * blockIdx.y / nsplit), kt1 = (int)((long)g.nt * (blockIdx.y + 1) / nsplit);
+    stage(kt0, kt0 & 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < g.nt) {
+        if (kt + 1 < kt1) {
             stage(kt + 1, buf ^ 1);
             wait_vmcnt<LA + LB>();  // tile kt landed (this wave's part); tile kt+1 stays in flight
         } else {
@@ -160,6 +163,8 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
     constexpr int ESTRIDE = 272;
     char* est = smem + wave * (32 * ESTRIDE);
     const bool vec_ok = CONV || ((g.ldc & 7) == 0);
+    GemmArgs ge = g;
+    ge.C = g.C + (long)blockIdx.y * g.splitk_stride;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         __syncthreads();
@@ -181,42 +186,13 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
             const f32x4 lo = *reinterpret_cast<const f32x4*>(est + rl * ESTRIDE + cl * 4);
             const f32x4 hi = *reinterpret_cast<const f32x4*>(est + rl * ESTRIDE + cl * 4 + 16);
             v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-            const int nv = min(8, g.N - n);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (k < nv) {
-                    float t = v[k] + (g.bias ? g.bias[n + k] : 0.f);
-                    if (g.act == SGG_ACT_RELU) t = fmaxf(t, 0.f);
-                    if (g.pscale) t = t * g.pscale[n + k];
-                    if (g.pshift) t = t + g.pshift[n + k];
-                    v[k] = t;
-                }
-            }
-            long off;
-            if constexpr (CONV) {
-                const int hw = g.H * g.W;
-                const int b = m / hw, rem = m - b * hw;
-                const int y = rem / g.W, x = rem - y * g.W;
-                const int op = g.out_pad;
-                off = ((long)(b * (g.H + 2 * op) + y + op) * (g.W + 2 * op) + x + op) * g.N + n;
-            } else {
-                off = (long)m * g.ldc + n;
-            }
-            if (vec_ok && nv == 8) {
-                if (g.out_bf16) store8(reinterpret_cast<bf16_t*>(g.C) + off, v);
-                else store8(reinterpret_cast<float*>(g.C) + off, v);
-            } else {
-                for (int k = 0; k < nv; ++k) {
-                    if (g.out_bf16) reinterpret_cast<bf16_t*>(g.C)[off + k] = f32_to_bf16(v[k]);
-                    else reinterpret_cast<float*>(g.C)[off + k] = v[k];
-                }
-            }
+            epilogue_store8(ge, v, n, out_offset<CONV>(g, m, n), vec_ok);
         }
     }
 }
 
 template <bool BF16, int WM, int WN, bool CONV>
-int launch(const GemmArgs& g, hipStream_t s) {
+int launch(const GemmArgs& g, hipStream_t s, int splits = 1) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int smem = 2 * (BM + BN) * ROWB;
     static_assert(smem >= 4 * 32 * 272, "epilogue staging fits");
@@ -228,7 +204,7 @@ int launch(const GemmArgs& g, hipStream_t s) {
             return SGG_ERR_LAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL(k, dim3(tilesM * tilesN), dim3(256), smem, s, g);
+    hipLaunchKernelGGL(k, dim3(tilesM * tilesN, splits), dim3(256), smem, s, g);
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -274,6 +250,66 @@ extern "C" int sgg_gemm(const void* A, int lda, const void* A2, int lda2, int K1
     g.bias = bias; g.pscale = post_scale; g.pshift = post_shift;
     g.C = (char*)C; g.ldc = ldc; g.M = M; g.N = N; g.act = act; g.out_bf16 = out_dtype == SGG_BF16;
     return dispatch<false>(g, in_dtype == SGG_BF16, (hipStream_t)stream);
+}
+
+namespace {
+// out[m][n] = post_scale * act(sum_s ws[s][m][n] + bias) + post_shift
+template <typename TO>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, long MN, int N, const float* __restrict__ bias,
+                                                            int act, const float* __restrict__ ps, const float* __restrict__ pt,
+                                                            TO* __restrict__ out) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= MN) return;
+    float acc[8], t[8];
+    load8(ws + i, acc);
+    for (int s = 1; s < S; ++s) {
+        load8(ws + (long)s * MN + i, t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += t[k];
+    }
+    const int n = (int)(i % N);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float v = acc[k] + (bias ? bias[n + k] : 0.f);
+        if (act == SGG_ACT_RELU) v = fmaxf(v, 0.f);
+        if (ps) v *= ps[n + k];
+        if (pt) v += pt[n + k];
+        acc[k] = v;
+    }
+    store8(out + i, acc);
+}
+}  // namespace
+
+// Split-K form for short-M GEMMs (e.g. fc6 on the 256 object rows: 64 tiles x K = 25088): `splits` blocks per output
+// tile, each reducing a K range into workspace[s] (fp32 [M,N]), then one reduce + epilogue pass.  N % 8 == 0, ldc == N.
+extern "C" int sgg_gemm_splitk(const void* A, int lda, const void* W, int ldw, const float* bias, const float* post_scale,
+                               const float* post_shift, void* C, int M, int N, int K, int act, int in_dtype, int out_dtype,
+                               int splits, float* workspace, void* stream) {
+    if (in_dtype != SGG_F32 && in_dtype != SGG_BF16) return SGG_ERR_DTYPE;
+    if (out_dtype != SGG_F32 && out_dtype != SGG_BF16) return SGG_ERR_DTYPE;
+    if (M == 0 || N == 0) return SGG_OK;
+    const int esz = in_dtype == SGG_BF16 ? 2 : 4;
+    const int bke = ROWB / esz;
+    if (!A || !W || !C || !workspace || M < 0 || N <= 0 || (N & 7) || K <= 0 || K % bke || splits < 1 || splits > K / bke) return SGG_ERR_ARG;
+    if ((lda & 7) || (ldw & 7) || lda < K || ldw < K || (((uintptr_t)A | (uintptr_t)W) & 15)) return SGG_ERR_ARG;
+    GemmArgs g{};
+    g.A = (const char*)A; g.Wt = (const char*)W;
+    g.lda_b = (long)lda * esz; g.ldw_b = (long)ldw * esz;
+    g.nt = K / bke; g.nt1 = g.nt;
+    g.C = (char*)workspace; g.ldc = N; g.M = M; g.N = N; g.act = SGG_ACT_NONE; g.out_bf16 = 0;
+    g.splitk_stride = (long)M * N * 4;
+    hipStream_t s = (hipStream_t)stream;
+    const bool bf16 = in_dtype == SGG_BF16;
+    const int rc = bf16 ? launch<true, 2, 2, false>(g, s, splits) : launch<false, 2, 2, false>(g, s, splits);
+    if (rc != SGG_OK) return rc;
+    const long MN = (long)M * N;
+    const dim3 grid((unsigned)((MN / 8 + 255) / 256)), blk(256);
+    if (out_dtype == SGG_BF16)
+        hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, grid, blk, 0, s, workspace, splits, MN, N, bias, act, post_scale, post_shift, (bf16_t*)C);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel<float>, grid, blk, 0, s, workspace, splits, MN, N, bias, act, post_scale, post_shift, (float*)C);
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
 }
 
 extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H,

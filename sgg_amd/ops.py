@@ -168,6 +168,18 @@ def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None
     out_dtype = out_dtype or A.dtype
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    # short-M, long-K contractions (fc6 on the object rows) do not fill the chip with output tiles: split K
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    kt = K // (64 if A.dtype == torch.bfloat16 else 32)
+    if A2 is None and tiles <= 96 and kt >= 64 and N % 8 == 0 and out.is_contiguous() and A.stride(0) >= K and W.stride(0) >= K:
+        splits = max(2, min(16, 512 // tiles, kt // 8))
+        ws = torch.empty((splits, M, N), dtype=torch.float32, device=A.device)
+        _lib.call('sgg_gemm_splitk', _p(A, rows_ok=True), A.stride(0), _p(W, rows_ok=True), W.stride(0),
+                  _p(bias, torch.float32) if bias is not None else None,
+                  _p(post_scale, torch.float32) if post_scale is not None else None,
+                  _p(post_shift, torch.float32) if post_shift is not None else None, _p(out), M, N, K, act, dt(A), dt(out),
+                  splits, _p(ws), _stream())
+        return out
     _lib.call('sgg_gemm', _p(A, rows_ok=True), A.stride(0), _p(A2, rows_ok=True) if A2 is not None else None,
               A2.stride(0) if A2 is not None else 0, K1, _p(W, rows_ok=True), W.stride(0),
               _p(W2, rows_ok=True) if W2 is not None else None, W2.stride(0) if W2 is not None else 0,

@@ -36,6 +36,8 @@ def rand_boxes(rng, n):
 # ----------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize('M,N,K', [(128, 128, 64), (256, 256, 512), (200, 151, 512), (37, 51, 128), (1000, 1536, 512),
                                    (130, 4096, 1024), (5, 64, 64),
+                                   # short M, long K -> split-K path
+                                   (256, 4096, 8192), (37, 512, 4096), (200, 1536, 6400),
                                    # 256x256 ping-pong kernel (N >= 256 and >= 128 tiles): ragged M/N tails, 1..many K-tiles
                                    (4096, 2048, 512), (5000, 1800, 192), (4100, 2048, 128), (4096, 2050, 64), (7936, 4096, 1024)])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
