@@ -66,6 +66,18 @@ class GradBuckets(object):
         self.comm_dtype = comm_dtype
         self.big = [p for p in self.params if p.numel() * p.element_size() >= big_bytes]
         self.small = [p for p in self.params if p.numel() * p.element_size() < big_bytes]
+        self._early = {}      # param -> (wire buffer, work handle): all-reduces launched from inside the backward
+
+    def is_big(self, p):
+        return any(p is q for q in self.big)
+
+    def start(self, p, grad):
+        """Launch the all-reduce of one big gradient as soon as the backward has produced it (overlaps the rest of the
+        backward); `all_reduce` later waits for it instead of issuing it."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        buf = grad.to(self.comm_dtype) if (self.comm_dtype is not None and self.comm_dtype != grad.dtype) else grad
+        self._early[p] = (buf, dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
 
     def all_reduce(self, average=True):
         """Returns {param: reduced buffer} for the big tensors when they were reduced in a narrower comm dtype (the
@@ -77,6 +89,13 @@ class GradBuckets(object):
         direct = {}
         works, bufs = [], []
         for p in self.big:
+            if p in self._early:
+                buf, work = self._early.pop(p)
+                if average and p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                bufs.append((p, buf))
+                works.append(work)
+                continue
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
             g = p.grad
@@ -94,7 +113,7 @@ class GradBuckets(object):
                 if average:
                     p.grad.copy_(buf)
                 else:
-                    direct[p] = buf          # consumed as is (bf16) by the fused optimiser: no copy back
+                    direct[p] = buf          # consumed as is (wire dtype) by the fused optimiser: no copy back
             if average:
                 p.grad.div_(world)
         if flat is not None:

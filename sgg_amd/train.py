@@ -181,6 +181,11 @@ class PredictFn(torch.autograd.Function):
         dev = XN.device
         G = {}
         rows = lambda buf, c, n: buf[c * n:(c + 1) * n]
+        grad_hook = getattr(model, '_grad_ready_hook', None)     # set by the DP trainer: early all-reduce of big gradients
+
+        def hook(name):
+            if grad_hook is not None:
+                grad_hook(name, G[name])
 
         def lin_bwd(dY, X, Wt, name, want_dx=True):
             """Y = X W^T + b : returns dX; stores dW (f32 [N,K]) and db."""
@@ -241,6 +246,16 @@ class PredictFn(torch.autograd.Function):
         for k, g in enumerate(GATES):
             G[g + '.0.weight'] = d_gw[k:k + 1].clone()
             G[g + '.0.bias'] = d_gb[k].clone()
+        # ---- node MLP backward
+        _lib.set_tag('bwd_mlp_obj')
+        d_x7 = lin_bwd(d_obj_rep, sv['x7'], t['obj_unary_t'], 'obj_unary')
+        d_p7 = ops.act_bwd(d_x7, sv['x7'], ds)
+        d_x6 = lin_bwd(d_p7, sv['x6'], t['fc7_obj_t'], 'roi_fmap_obj.3')
+        hook('roi_fmap_obj.3.weight')
+        d_p6 = ops.act_bwd(d_x6, sv['x6'], ds)
+        G['roi_fmap_obj.0.weight'] = tn_gemm(d_p6, sv['nf'])
+        hook('roi_fmap_obj.0.weight')            # 411 MB: its all-reduce overlaps the edge-MLP backward below
+        G['roi_fmap_obj.0.bias'] = ops.colsum(d_p6)
         # ---- edge MLP backward
         _lib.set_tag('bwd_mlp')
         p = sv['dropout_p']
@@ -248,12 +263,14 @@ class PredictFn(torch.autograd.Function):
         d_u = ops.act_bwd(d_rel_rep, rows(XE, 0, E))                               # relu(edge_unary)
         d_y7 = lin_bwd(d_u, sv['y7'], t['edge_unary_t'], 'edge_unary')
         d_y6 = lin_bwd(d_y7, sv['y6'], t['fc7_edge_t'], 'roi_fmap.1.3')
+        hook('roi_fmap.1.3.weight')
         d_pre6 = ops.act_bwd(d_y6, sv['y6'], ds)                                   # dropout + relu
         C, PP = model.edge_dim, model.pool_sz ** 2
         _lib.set_tag('bwd_fc6_edge_dW')
         # d W6[n,(c,p)] = sum_e d_pre6[e,n] * (edge_feat[e,c,p] + rect[e,c]): the folded term rides in the transpose
         x6t = ops.transpose(sv['ef'], add=sv['rect'].float() if sv['rect'].dtype != torch.float32 else sv['rect'], group=PP)
         G['roi_fmap.1.0.weight'] = ops.gemm(ops.transpose(d_pre6), x6t, out_dtype=torch.float32)
+        hook('roi_fmap.1.0.weight')
         G['roi_fmap.1.0.bias'] = ops.colsum(d_pre6)
         _lib.set_tag('bwd_rect')
         d_rect = ops.gemm(d_pre6, t['w6sum_t'])                                    # [E,C]
@@ -271,14 +288,6 @@ class PredictFn(torch.autograd.Function):
         gw1 = tn_gemm(d_c1, sv['patches'])                                         # [d2,128]
         G['union_boxes.conv.0.weight'] = gw1[:, :98].reshape(tuple(model.union_boxes.conv[0].weight.shape)).contiguous()
         G['union_boxes.conv.0.bias'] = ops.colsum(d_c1)
-        # ---- node MLP backward
-        _lib.set_tag('bwd_mlp_obj')
-        d_x7 = lin_bwd(d_obj_rep, sv['x7'], t['obj_unary_t'], 'obj_unary')
-        d_p7 = ops.act_bwd(d_x7, sv['x7'], ds)
-        d_x6 = lin_bwd(d_p7, sv['x6'], t['fc7_obj_t'], 'roi_fmap_obj.3')
-        d_p6 = ops.act_bwd(d_x6, sv['x6'], ds)
-        G['roi_fmap_obj.0.weight'] = tn_gemm(d_p6, sv['nf'])
-        G['roi_fmap_obj.0.bias'] = ops.colsum(d_p6)
         _lib.set_tag('')
         ctx.sv = None
         shapes = dict(model.named_parameters())

@@ -80,6 +80,14 @@ class Trainer(object):
         self.buckets = GradBuckets([p for _, p in named], comm_dtype=comm_dtype)
         self.loss_type = loss_type
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if self.world > 1:
+            by_name = dict(named)
+
+            def early(name, grad):      # called from PredictFn.backward the moment a big gradient exists
+                p = by_name.get(name)
+                if p is not None and self.buckets.is_big(p):
+                    self.buckets.start(p, grad)
+            model._grad_ready_hook = early
 
     def _bump(self):
         self.model.weights_version = getattr(self.model, 'weights_version', 0) + 1

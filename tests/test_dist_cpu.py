@@ -34,7 +34,10 @@ def _worker(rank, world, port, q):
     # the DP train-step form: SUM in a different wire dtype, big tensors handed back as buffers (no copy into .grad)
     for p, g in zip(lin.parameters(), local):
         p.grad = g.clone()
-    direct = D.GradBuckets(lin.parameters(), big_bytes=256, comm_dtype=torch.float64).all_reduce(average=False)
+    gb = D.GradBuckets(lin.parameters(), big_bytes=256, comm_dtype=torch.float64)
+    first = next(iter(lin.parameters()))
+    gb.start(first, first.grad)                      # early launch from inside the backward (overlap path)
+    direct = gb.all_reduce(average=False)
     summed = [(direct[p] if p in direct else p.grad).float() for p in lin.parameters()]
     ok = len(direct) == 2 and all(torch.allclose(s, a * 2, atol=1e-6) for s, a in zip(summed, avg))
     q.put((r, (lo, hi), mx, tot, [g.tolist() for g in local], [g.tolist() for g in avg], ok))
