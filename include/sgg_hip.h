@@ -232,9 +232,10 @@ int sgg_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, 
 int sgg_permute_ncp_to_npc(const void* in, void* out, int Nn, int C, int Pp, int in_dtype, int out_dtype, void* stream);
 
 /* out[c][r] = in[r][c] (+ add[r][c / group], add f32 with row stride ld_add, or NULL); row strides in elements.
- * Feeds d W = dY^T X to sgg_gemm; the add form builds (edge_feat + conv(rects))^T for fc6's weight gradient. */
+ * Feeds d W = dY^T X to sgg_gemm; the add form builds (edge_feat + conv(rects))^T for fc6's weight gradient.
+ * colsum (optional, f32[C], zeroed by the callee): column sums of `in` (+add) -- the bias gradient of the same dY. */
 int sgg_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int R, int C, const float* add, int64_t ld_add,
-                  int group, int in_dtype, int out_dtype, void* stream);
+                  int group, float* colsum, int in_dtype, int out_dtype, void* stream);
 /* out[n][c] = sum_{p<group} in[n][c*group + p]  (fp32 in): fc6's folded columns W6sum[n,c] = sum_p W6[n,c,p] */
 int sgg_group_sum(const float* in, int64_t ld_in, void* out, int64_t ld_out, int Nn, int C, int group, int out_dtype,
                   void* stream);

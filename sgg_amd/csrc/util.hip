@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void permute_kernel(const TI* __restrict__ in,
 // pieces per lane when the strides allow it; ragged edges fall back to scalars.
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ in, long ld_in, TO* __restrict__ out, long ld_out,
-                                                        int R, int C, const float* __restrict__ add, long ld_add, int group) {
+                                                        int R, int C, const float* __restrict__ add, long ld_add, int group,
+                                                        float* __restrict__ colsum) {
     __shared__ float t[64][65];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tid = threadIdx.x;
@@ -65,6 +66,12 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ i
         for (int k = 0; k < 8; ++k) t[rr][cc + k] = v[k];
     }
     __syncthreads();
+    if (colsum && tid < 64 && c0 + tid < C) {   // bias gradient for free: column sums of the tile (rows >= R are zero)
+        float s = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 64; ++k) s += t[k][tid];
+        atomicAdd(&colsum[c0 + tid], s);
+    }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int id = tid + q * 256, cc = id >> 3, rr = (id & 7) * 8;
@@ -160,20 +167,21 @@ extern "C" int sgg_permute_ncp_to_npc(const void* in, void* out, int Nn, int C, 
 }
 
 extern "C" int sgg_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int R, int C, const float* add,
-                             int64_t ld_add, int group, int in_dtype, int out_dtype, void* stream) {
+                             int64_t ld_add, int group, float* colsum, int in_dtype, int out_dtype, void* stream) {
     if (R == 0 || C == 0) return SGG_OK;
     if (!in || !out || R < 0 || C < 0 || ld_in < C || ld_out < R || (add && group <= 0)) return SGG_ERR_ARG;
     const dim3 grid((C + 63) / 64, (R + 63) / 64), blk(256);
     hipStream_t s = (hipStream_t)stream;
     if (group <= 0) group = 1;
+    if (colsum && hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)C, s) != hipSuccess) return SGG_ERR_LAUNCH;
     if (in_dtype == SGG_BF16 && out_dtype == SGG_BF16)
-        hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (const bf16_t*)in, (long)ld_in, (bf16_t*)out, (long)ld_out, R, C, add, (long)ld_add, group);
+        hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (const bf16_t*)in, (long)ld_in, (bf16_t*)out, (long)ld_out, R, C, add, (long)ld_add, group, colsum);
     else if (in_dtype == SGG_F32 && out_dtype == SGG_F32)
-        hipLaunchKernelGGL((transpose_kernel<float, float>), grid, blk, 0, s, (const float*)in, (long)ld_in, (float*)out, (long)ld_out, R, C, add, (long)ld_add, group);
+        hipLaunchKernelGGL((transpose_kernel<float, float>), grid, blk, 0, s, (const float*)in, (long)ld_in, (float*)out, (long)ld_out, R, C, add, (long)ld_add, group, colsum);
     else if (in_dtype == SGG_F32 && out_dtype == SGG_BF16)
-        hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, blk, 0, s, (const float*)in, (long)ld_in, (bf16_t*)out, (long)ld_out, R, C, add, (long)ld_add, group);
+        hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, blk, 0, s, (const float*)in, (long)ld_in, (bf16_t*)out, (long)ld_out, R, C, add, (long)ld_add, group, colsum);
     else if (in_dtype == SGG_BF16 && out_dtype == SGG_F32)
-        hipLaunchKernelGGL((transpose_kernel<bf16_t, float>), grid, blk, 0, s, (const bf16_t*)in, (long)ld_in, (float*)out, (long)ld_out, R, C, add, (long)ld_add, group);
+        hipLaunchKernelGGL((transpose_kernel<bf16_t, float>), grid, blk, 0, s, (const bf16_t*)in, (long)ld_in, (float*)out, (long)ld_out, R, C, add, (long)ld_add, group, colsum);
     else
         return SGG_ERR_DTYPE;
     SGG_CHECK_LAUNCH();

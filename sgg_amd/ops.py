@@ -367,17 +367,18 @@ def rank4_reduce_(a, x, out, col0=0):
               _stream())
 
 
-def transpose(x, pad_to=64, dtype=None, add=None, group=1):
+def transpose(x, pad_to=64, dtype=None, add=None, group=1, want_colsum=False):
     """x [R,C] (row-strided ok) -> [C, Rp] with Rp = R rounded up to `pad_to`, zero padded.
-    add f32[R, C/group]: out[c][r] = x[r][c] + add[r][c // group]."""
+    add f32[R, C/group]: out[c][r] = x[r][c] + add[r][c // group].  want_colsum: also return the column sums of x (f32[C])."""
     R, C = x.shape
     Rp = (R + pad_to - 1) // pad_to * pad_to
     dtype = dtype or x.dtype
     out = (torch.zeros if Rp != R else torch.empty)((C, Rp), dtype=dtype, device=x.device)
+    cs = torch.empty(C, dtype=torch.float32, device=x.device) if want_colsum else None
     _lib.call('sgg_transpose', _p(x, rows_ok=True), x.stride(0), _p(out), Rp, R, C,
               _p(add, torch.float32) if add is not None else None, add.stride(0) if add is not None else 0, group,
-              dt(x), dt(out), _stream())
-    return out
+              _p(cs) if want_colsum else None, dt(x), dt(out), _stream())
+    return (out, cs) if want_colsum else out
 
 
 def group_sum(w, C, group, dtype):

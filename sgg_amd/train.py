@@ -43,8 +43,12 @@ def _pad_cols(x, mult, dtype):
     return buf
 
 
-def tn_gemm(X, Y, out=None):
-    """X[M,a]^T . Y[M,b] -> f32 [a,b]  (weight gradients).  Rows are zero-padded to a multiple of 64 by the transposes."""
+def tn_gemm(X, Y, out=None, want_colsum=False):
+    """X[M,a]^T . Y[M,b] -> f32 [a,b]  (weight gradients).  Rows are zero-padded to a multiple of 64 by the transposes.
+    want_colsum: also return colsum(X) (the bias gradient when X = dY), computed inside X's transpose pass."""
+    if want_colsum:
+        xt, cs = ops.transpose(X, want_colsum=True)
+        return ops.gemm(xt, ops.transpose(Y), out_dtype=torch.float32, out=out), cs
     return ops.gemm(ops.transpose(X), ops.transpose(Y), out_dtype=torch.float32, out=out)
 
 
@@ -189,8 +193,7 @@ class PredictFn(torch.autograd.Function):
 
         def lin_bwd(dY, X, Wt, name, want_dx=True):
             """Y = X W^T + b : returns dX; stores dW (f32 [N,K]) and db."""
-            G[name + '.weight'] = tn_gemm(dY, X)
-            G[name + '.bias'] = ops.colsum(dY)
+            G[name + '.weight'], G[name + '.bias'] = tn_gemm(dY, X, want_colsum=True)
             return ops.gemm(_pad_cols(dY, 64, dt), Wt) if want_dx else None
 
         _lib.set_tag('bwd_heads')
@@ -237,12 +240,10 @@ class PredictFn(torch.autograd.Function):
         HprevE = torch.cat((torch.zeros_like(HE[:E]), HE[:3 * E]), 0) if T == 3 else None
         if HprevN is None:
             raise NotImplementedError('training is wired for mp_iter == 3')
-        G['node_gru.weight_ih'] = tn_gemm(dGIn, XN)
-        G['node_gru.weight_hh'] = tn_gemm(dGHn, HprevN)
-        G['node_gru.bias_ih'], G['node_gru.bias_hh'] = ops.colsum(dGIn), ops.colsum(dGHn)
-        G['edge_gru.weight_ih'] = tn_gemm(dGIe, XE)
-        G['edge_gru.weight_hh'] = tn_gemm(dGHe, HprevE)
-        G['edge_gru.bias_ih'], G['edge_gru.bias_hh'] = ops.colsum(dGIe), ops.colsum(dGHe)
+        G['node_gru.weight_ih'], G['node_gru.bias_ih'] = tn_gemm(dGIn, XN, want_colsum=True)
+        G['node_gru.weight_hh'], G['node_gru.bias_hh'] = tn_gemm(dGHn, HprevN, want_colsum=True)
+        G['edge_gru.weight_ih'], G['edge_gru.bias_ih'] = tn_gemm(dGIe, XE, want_colsum=True)
+        G['edge_gru.weight_hh'], G['edge_gru.bias_hh'] = tn_gemm(dGHe, HprevE, want_colsum=True)
         for k, g in enumerate(GATES):
             G[g + '.0.weight'] = d_gw[k:k + 1].clone()
             G[g + '.0.bias'] = d_gb[k].clone()
@@ -256,9 +257,8 @@ class PredictFn(torch.autograd.Function):
         d_x6 = lin_bwd(d_p7, sv['x6'], t['fc7_obj_t'], 'roi_fmap_obj.3')
         hook('roi_fmap_obj.3.weight')
         d_p6 = ops.act_bwd(d_x6, sv['x6'], ds)
-        G['roi_fmap_obj.0.weight'] = tn_gemm(d_p6, sv['nf'])
+        G['roi_fmap_obj.0.weight'], G['roi_fmap_obj.0.bias'] = tn_gemm(d_p6, sv['nf'], want_colsum=True)
         hook('roi_fmap_obj.0.weight')            # 411 MB: its all-reduce overlaps the edge-MLP backward below
-        G['roi_fmap_obj.0.bias'] = ops.colsum(d_p6)
         # ---- edge MLP backward
         _lib.set_tag('bwd_mlp')
         d_u = ops.act_bwd(d_rel_rep, rows(XE, 0, E))                               # relu(edge_unary)
@@ -269,25 +269,25 @@ class PredictFn(torch.autograd.Function):
         _lib.set_tag('bwd_fc6_edge_dW')
         # d W6[n,(c,p)] = sum_e d_pre6[e,n] * (edge_feat[e,c,p] + rect[e,c]): the folded term rides in the transpose
         x6t = ops.transpose(sv['ef'], add=sv['rect'].float() if sv['rect'].dtype != torch.float32 else sv['rect'], group=PP)
-        G['roi_fmap.1.0.weight'] = ops.gemm(ops.transpose(d_pre6), x6t, out_dtype=torch.float32)
+        d6t, G['roi_fmap.1.0.bias'] = ops.transpose(d_pre6, want_colsum=True)
+        G['roi_fmap.1.0.weight'] = ops.gemm(d6t, x6t, out_dtype=torch.float32)
         hook('roi_fmap.1.0.weight')
-        G['roi_fmap.1.0.bias'] = ops.colsum(d_pre6)
         _lib.set_tag('bwd_rect')
         d_rect = ops.gemm(d_pre6, t['w6sum_t'])                                    # [E,C]
         # ---- rect conv backward (BatchNorm with batch statistics)
         d_c2, db2, dg2 = ops.bn_bwd(d_rect, None, sv['h3'], sv['m2'], sv['is2'], t['rc_g2'], False)
         G['union_boxes.conv.6.weight'], G['union_boxes.conv.6.bias'] = dg2.clone(), db2.clone()
-        gw2 = tn_gemm(d_c2, sv['h2'])                                              # [d, d2] centre tap
+        gw2, gb2 = tn_gemm(d_c2, sv['h2'], want_colsum=True)                       # [d, d2] centre tap
         full = torch.zeros(tuple(model.union_boxes.conv[4].weight.shape), dtype=torch.float32, device=dev)
         full[:, :, 1, 1] = gw2
         G['union_boxes.conv.4.weight'] = full
-        G['union_boxes.conv.4.bias'] = ops.colsum(d_c2)
+        G['union_boxes.conv.4.bias'] = gb2
         d_h2 = ops.gemm(d_c2, t['rc_w2_t'])                                        # [E,d2]
         d_c1, db1, dg1 = ops.bn_bwd(d_h2, sv['arg'], sv['h1'], sv['m1'], sv['is1'], t['rc_g1'], True)
         G['union_boxes.conv.2.weight'], G['union_boxes.conv.2.bias'] = dg1.clone(), db1.clone()
-        gw1 = tn_gemm(d_c1, sv['patches'])                                         # [d2,128]
+        gw1, gb1 = tn_gemm(d_c1, sv['patches'], want_colsum=True)                  # [d2,128]
         G['union_boxes.conv.0.weight'] = gw1[:, :98].reshape(tuple(model.union_boxes.conv[0].weight.shape)).contiguous()
-        G['union_boxes.conv.0.bias'] = ops.colsum(d_c1)
+        G['union_boxes.conv.0.bias'] = gb1
         _lib.set_tag('')
         ctx.sv = None
         shapes = dict(model.named_parameters())

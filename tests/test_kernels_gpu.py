@@ -98,6 +98,9 @@ def test_transpose_add_and_group_sum(ops, dtype):
     t = ops.transpose(cu(x))
     assert tuple(t.shape) == (C, 256) and float(t[:, R:].float().abs().max()) == 0
     torch.testing.assert_close(t[:, :R].float().cpu(), x.float().t(), atol=0, rtol=0)
+    t2, cs = ops.transpose(cu(x), want_colsum=True)
+    torch.testing.assert_close(t2[:, :R].float().cpu(), x.float().t(), atol=0, rtol=0)
+    torch.testing.assert_close(cs.cpu(), x.float().sum(0), atol=1e-3, rtol=1e-4)
     ta = ops.transpose(cu(x), add=cu(add), group=group)
     exp = (x.float() + add.repeat_interleave(group, 1)).t()
     torch.testing.assert_close(ta[:, :R].float().cpu(), exp.to(dtype).float(), atol=1e-6 if dtype == torch.float32 else 2e-2, rtol=0)
