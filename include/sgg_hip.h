@@ -226,6 +226,15 @@ int sgg_sqnorm_acc(const void* g, int64_t n, float* acc, int dtype, void* stream
 int sgg_sgd_step(float* p, const void* g, float* momentum_buf, int64_t n, float lr, float weight_decay, float momentum,
                  int first_step, const float* norm_sq, float max_norm, float grad_scale, int g_dtype, void* stream);
 
+/* Multi-tensor forms of the two calls above: host arrays (length count) of device pointers and sizes, one launch per
+ * 32 tensors instead of one per parameter.  All pointers 16-byte aligned.  lr per tensor (the reference's two
+ * parameter groups, lib/pytorch_misc.py:135-144).  shadow: optional array (entries may be NULL) of bf16 buffers that
+ * receive the updated parameter in the same pass -- the next forward's MFMA operand, so no separate cast pass. */
+int sgg_sqnorm_multi(const void* const* g, const int64_t* n, int count, float* acc, int dtype, void* stream);
+int sgg_sgd_multi(float* const* p, const void* const* g, float* const* momentum_buf, void* const* shadow,
+                  const int64_t* n, const float* lr, int count, float weight_decay, float momentum, int first_step,
+                  const float* norm_sq, float max_norm, float grad_scale, int g_dtype, void* stream);
+
 /* ---- utilities used by the host for weight preparation (load time, not on the step path) ---- */
 int sgg_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, void* stream);
 /* out[n][p][c] = in[n][c][p]  (fc6 K-order (c,ph,pw) -> (ph,pw,c); conv OIHW -> O(HW)I) */

@@ -492,6 +492,134 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const T
     }
 }
 
+// ---- multi-tensor forms: ONE launch walks every parameter (36 tensors from 51 floats to 103 M floats), so the
+// optimiser costs two kernels per step instead of 72 and the small tensors stop paying a launch each.
+constexpr int MT_MAX = 32;          // tensors per launch (table travels by value in the kernarg segment)
+constexpr int MT_CHUNK = 4096;      // elements per block-iteration: 256 threads x 16
+
+struct MultiTab {
+    const void* g[MT_MAX];
+    float* p[MT_MAX];
+    float* buf[MT_MAX];
+    bf16_t* shadow[MT_MAX];         // optional compute-dtype copy of the updated parameter (the next forward's operand)
+    long n[MT_MAX];
+    int chunk0[MT_MAX + 1];         // prefix sum of ceil(n / MT_CHUNK)
+    float lr[MT_MAX];
+    int count;
+};
+
+__device__ __forceinline__ int mt_find(const MultiTab& tab, int c) {
+    int t = 0;
+    while (t + 1 < tab.count && c >= tab.chunk0[t + 1]) ++t;
+    return t;
+}
+
+template <typename TG>
+__device__ __forceinline__ void mt_load4(const TG* g, float (&v)[4]) {
+    if constexpr (sizeof(TG) == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(g);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+        const uint2 q = *reinterpret_cast<const uint2*>(g);
+        v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u);
+        v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
+    }
+}
+
+template <typename TG>
+__global__ __launch_bounds__(256) void sqnorm_multi_kernel(const MultiTab tab, float* __restrict__ acc) {
+    __shared__ float red[4];
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const int total = tab.chunk0[tab.count];
+    for (int c = blockIdx.x; c < total; c += gridDim.x) {
+        const int t = mt_find(tab, c);
+        const long n = tab.n[t];
+        const TG* g = reinterpret_cast<const TG*>(tab.g[t]);
+        const long base = (long)(c - tab.chunk0[t]) * MT_CHUNK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long i = base + (q * 256 + threadIdx.x) * 4;
+            if (i + 4 <= n) {
+                float v[4];
+                mt_load4(g + i, v);
+                s[q] = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], s[q]))));
+            } else {
+                for (long k = i; k < n; ++k) {
+                    const float v = Elem<TG>::ld(g + k);
+                    s[q] = fmaf(v, v, s[q]);
+                }
+            }
+        }
+    }
+    const float w = wave_sum((s[0] + s[1]) + (s[2] + s[3]));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+}
+
+template <typename TG>
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const MultiTab tab, float wd, float mom, int first,
+                                                        const float* __restrict__ norm_sq, float max_norm, float grad_scale) {
+    float coef = grad_scale;
+    if (norm_sq) {
+        const float c = max_norm / (sqrtf(*norm_sq) * grad_scale + 1e-6f);
+        if (c < 1.f) coef *= c;
+    }
+    const int total = tab.chunk0[tab.count];
+    for (int c = blockIdx.x; c < total; c += gridDim.x) {
+        const int t = mt_find(tab, c);
+        const long n = tab.n[t];
+        const TG* g = reinterpret_cast<const TG*>(tab.g[t]);
+        float* p = tab.p[t];
+        float* buf = tab.buf[t];
+        bf16_t* sh = tab.shadow[t];
+        const float lr = tab.lr[t];
+        const long base = (long)(c - tab.chunk0[t]) * MT_CHUNK;
+        float gv[4][4], pv[4][4], bv[4][4];
+        bool full[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // all loads of the chunk in flight before the first use
+            const long i = base + (q * 256 + threadIdx.x) * 4;
+            full[q] = i + 4 <= n;
+            if (full[q]) {
+                mt_load4(g + i, gv[q]);
+                mt_load4(p + i, pv[q]);
+                if (!first) mt_load4(buf + i, bv[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long i = base + (q * 256 + threadIdx.x) * 4;
+            if (full[q]) {
+                float nb[4], np[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float gg = coef * gv[q][k] + wd * pv[q][k];
+                    nb[k] = first ? gg : mom * bv[q][k] + gg;
+                    np[k] = pv[q][k] - lr * nb[k];
+                }
+                *reinterpret_cast<float4*>(buf + i) = make_float4(nb[0], nb[1], nb[2], nb[3]);
+                *reinterpret_cast<float4*>(p + i) = make_float4(np[0], np[1], np[2], np[3]);
+                if (sh) {
+                    uint2 o;
+                    o.x = pack_bf16x2(np[0], np[1]);
+                    o.y = pack_bf16x2(np[2], np[3]);
+                    *reinterpret_cast<uint2*>(sh + i) = o;
+                }
+            } else {
+                for (long k = i; k < n; ++k) {
+                    const float pk = p[k];
+                    const float gg = coef * Elem<TG>::ld(g + k) + wd * pk;
+                    const float b = first ? gg : mom * buf[k] + gg;
+                    buf[k] = b;
+                    p[k] = pk - lr * b;
+                    if (sh) sh[k] = f32_to_bf16(p[k]);
+                }
+            }
+        }
+    }
+}
+
 inline int split_rows(int M, int& rows_per_block) {
     int split = (M + 511) / 512;
     if (split > 64) split = 64;
@@ -711,5 +839,75 @@ extern "C" int sgg_sgd_step(float* p, const void* g, float* momentum_buf, int64_
         hipLaunchKernelGGL(sgd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, p, (const bf16_t*)g, momentum_buf, (long)n, lr, weight_decay, momentum, first_step, norm_sq, max_norm, grad_scale),
         hipLaunchKernelGGL(sgd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, p, (const float*)g, momentum_buf, (long)n, lr, weight_decay, momentum, first_step, norm_sq, max_norm, grad_scale));
     SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+namespace {
+// fills `tab` from entries [lo, hi) of the host arrays; returns the chunk count
+int mt_fill(MultiTab& tab, int lo, int hi, const void* const* g, float* const* p, float* const* buf, void* const* shadow,
+            const int64_t* n, const float* lr) {
+    tab.count = 0;
+    tab.chunk0[0] = 0;
+    for (int i = lo; i < hi; ++i) {
+        if (n[i] <= 0) continue;
+        const int k = tab.count++;
+        tab.g[k] = g[i];
+        tab.p[k] = p ? p[i] : nullptr;
+        tab.buf[k] = buf ? buf[i] : nullptr;
+        tab.shadow[k] = shadow ? (bf16_t*)shadow[i] : nullptr;
+        tab.n[k] = n[i];
+        tab.lr[k] = lr ? lr[i] : 0.f;
+        tab.chunk0[k + 1] = tab.chunk0[k] + (int)((n[i] + MT_CHUNK - 1) / MT_CHUNK);
+    }
+    return tab.chunk0[tab.count];
+}
+}  // namespace
+
+// acc += sum_i sum(g_i^2) over `count` tensors in one launch per 32 tensors (host arrays of device pointers / sizes).
+// Every g_i must be 16-byte aligned.
+extern "C" int sgg_sqnorm_multi(const void* const* g, const int64_t* n, int count, float* acc, int dtype, void* stream) {
+    if (count == 0) return SGG_OK;
+    if (!g || !n || !acc || count < 0) return SGG_ERR_ARG;
+    for (int i = 0; i < count; ++i)
+        if (n[i] < 0 || (n[i] > 0 && (!g[i] || ((uintptr_t)g[i] & 15)))) return SGG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    for (int lo = 0; lo < count; lo += MT_MAX) {
+        MultiTab tab;
+        const int chunks = mt_fill(tab, lo, min(count, lo + MT_MAX), g, nullptr, nullptr, nullptr, n, nullptr);
+        if (!chunks) continue;
+        const dim3 grid((unsigned)min(chunks, 2048));
+        DISPATCH2(dtype, hipLaunchKernelGGL(sqnorm_multi_kernel<bf16_t>, grid, dim3(256), 0, s, tab, acc),
+                  hipLaunchKernelGGL(sqnorm_multi_kernel<float>, grid, dim3(256), 0, s, tab, acc));
+        SGG_CHECK_LAUNCH();
+    }
+    return SGG_OK;
+}
+
+// sgg_sgd_step over `count` tensors in one launch per 32 tensors; lr per tensor (parameter groups).  shadow (optional
+// array, entries may be NULL): bf16 copy of each updated parameter, written in the same pass.
+extern "C" int sgg_sgd_multi(float* const* p, const void* const* g, float* const* momentum_buf, void* const* shadow,
+                             const int64_t* n, const float* lr, int count, float weight_decay, float momentum,
+                             int first_step, const float* norm_sq, float max_norm, float grad_scale, int g_dtype,
+                             void* stream) {
+    if (count == 0) return SGG_OK;
+    if (!p || !g || !momentum_buf || !n || !lr || count < 0) return SGG_ERR_ARG;
+    for (int i = 0; i < count; ++i) {
+        if (n[i] < 0) return SGG_ERR_ARG;
+        if (n[i] == 0) continue;
+        if (!p[i] || !g[i] || !momentum_buf[i]) return SGG_ERR_ARG;
+        if (((uintptr_t)p[i] | (uintptr_t)g[i] | (uintptr_t)momentum_buf[i] | (shadow ? (uintptr_t)shadow[i] : 0)) & 15)
+            return SGG_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    for (int lo = 0; lo < count; lo += MT_MAX) {
+        MultiTab tab;
+        const int chunks = mt_fill(tab, lo, min(count, lo + MT_MAX), g, p, momentum_buf, shadow, n, lr);
+        if (!chunks) continue;
+        const dim3 grid((unsigned)min(chunks, 4096));
+        DISPATCH2(g_dtype,
+            hipLaunchKernelGGL(sgd_multi_kernel<bf16_t>, grid, dim3(256), 0, s, tab, weight_decay, momentum, first_step, norm_sq, max_norm, grad_scale),
+            hipLaunchKernelGGL(sgd_multi_kernel<float>, grid, dim3(256), 0, s, tab, weight_decay, momentum, first_step, norm_sq, max_norm, grad_scale));
+        SGG_CHECK_LAUNCH();
+    }
     return SGG_OK;
 }

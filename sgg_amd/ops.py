@@ -262,9 +262,10 @@ def eval_tail(obj_dists, rel_dists, rel_inds, gt_classes=None):
 
 
 # ---------------------------------------------------------------- utilities
-def cast(x, dtype):
+def cast(x, dtype, out=None):
     x = x.contiguous()
-    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    if out is None:
+        out = torch.empty(x.shape, dtype=dtype, device=x.device)
     _lib.call('sgg_cast', _p(x), _p(out), x.numel(), dt(x), dt(out), _stream())
     return out
 

@@ -97,6 +97,7 @@ class RelModelBase(nn.Module):
         # HIP-path settings (not in the reference): storage/compute type of activations and weights.
         self.compute_dtype = torch.bfloat16
         self._prep = {}
+        self._shadow, self._shadow_tags = {}, {}     # compute-dtype weight copies (rel_model_stanford._shadow_cast)
 
     # ------------------------------------------------------------------ reference API
     @property

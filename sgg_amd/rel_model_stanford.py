@@ -37,16 +37,16 @@ class RelModelStanford(RelModelBase):
             return self._prep['val']
         C, PP = self.edge_dim, self.pool_sz ** 2
         f = lambda t: t.detach().float().contiguous()
-        cast = lambda t: t if t.dtype == dtype else ops.cast(t, dtype)
         w = {}
-        w['fc6_obj'] = cast(f(self.roi_fmap_obj[0].weight))
+        w['fc6_obj'] = self._shadow_cast('roi_fmap_obj.0.weight', self.roi_fmap_obj[0].weight)
         w6e = f(self.roi_fmap[1][0].weight)
-        w['fc6_edge'] = cast(w6e)                                  # [4096, 25088], K order (c,ph,pw) as in the reference
+        w['fc6_edge'] = self._shadow_cast('roi_fmap.1.0.weight', w6e)   # [4096, 25088], K order (c,ph,pw) as in the reference
         w['fc6_edge_sum'] = ops.group_sum(w6e, C, PP, dtype)       # [4096, 512]
-        for name, mod in (('fc7_obj', self.roi_fmap_obj[3]), ('fc7_edge', self.roi_fmap[1][3]),
-                          ('obj_unary', self.obj_unary), ('edge_unary', self.edge_unary), ('obj_fc', self.obj_fc),
-                          ('rel_fc', self.rel_fc)):
-            w[name] = cast(f(mod.weight))
+        for name, pname, mod in (('fc7_obj', 'roi_fmap_obj.3', self.roi_fmap_obj[3]),
+                                 ('fc7_edge', 'roi_fmap.1.3', self.roi_fmap[1][3]),
+                                 ('obj_unary', 'obj_unary', self.obj_unary), ('edge_unary', 'edge_unary', self.edge_unary),
+                                 ('obj_fc', 'obj_fc', self.obj_fc), ('rel_fc', 'rel_fc', self.rel_fc)):
+            w[name] = self._shadow_cast(pname + '.weight', mod.weight)
             w[name + '_b'] = f(mod.bias)
         w['fc6_obj_b'] = f(self.roi_fmap_obj[0].bias)
         w['fc6_edge_b'] = f(self.roi_fmap[1][0].bias)
@@ -54,6 +54,42 @@ class RelModelStanford(RelModelBase):
         w['imp'] = ImpWeights.from_state(sd, dtype)
         self._prep = dict(key=key, val=w)
         return w
+
+    # Compute-dtype copies of the plain-cast weights live in stable buffers: the fused optimiser writes them in its
+    # update pass (sgg_sgd_multi `shadow`), so a train step never re-reads 1 GB of fp32 masters just to cast them.
+    _SHADOWED = ('roi_fmap_obj.0.weight', 'roi_fmap.1.0.weight', 'roi_fmap_obj.3.weight', 'roi_fmap.1.3.weight',
+                 'obj_unary.weight', 'edge_unary.weight', 'obj_fc.weight', 'rel_fc.weight')
+
+    def _shadow_tag(self, p):
+        return (getattr(self, 'weights_version', 0), p.data_ptr(), p._version)
+
+    def _shadow_cast(self, pname, p):
+        dtype = self.compute_dtype
+        src = p.detach().float().contiguous()
+        if dtype == torch.float32:
+            return src
+        sh = self._shadow.get(pname)
+        if sh is None or sh.shape != src.shape or sh.dtype != dtype or sh.device != src.device:
+            sh = self._shadow[pname] = torch.empty(src.shape, dtype=dtype, device=src.device)
+            self._shadow_tags.pop(pname, None)
+        tag = self._shadow_tag(p)
+        if self._shadow_tags.get(pname) != tag:
+            ops.cast(src, dtype, out=sh)
+            self._shadow_tags[pname] = tag
+        return sh
+
+    def shadow_buffers(self):
+        """{param name: bf16 buffer} the optimiser may refresh in place of a later cast (empty in fp32 mode)."""
+        if self.compute_dtype != torch.bfloat16:
+            return {}
+        return {n: t for n, t in self._shadow.items() if t.dtype == torch.bfloat16}
+
+    def mark_shadow_fresh(self, names):
+        """The optimiser just wrote these shadows from the updated masters (call after weights_version moved)."""
+        params = dict(self.named_parameters())
+        for n in names:
+            if n in params and n in self._shadow:
+                self._shadow_tags[n] = self._shadow_tag(params[n])
 
     # ------------------------------------------------------------------ reference API
     def message_pass(self, rel_rep, obj_rep, rel_inds):

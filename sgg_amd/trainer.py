@@ -27,6 +27,8 @@ class FusedSGD(object):
         self.steps = 0
         self._norm = None
         self.on_update = None
+        self.shadow_of = None      # callable -> {param name: compute-dtype buffer the update should also write}
+        self.wrote_shadow = []
 
     def zero_grad(self):
         for g in self.groups:
@@ -44,19 +46,37 @@ class FusedSGD(object):
         grads = grads or {}
         grad_of = lambda p: grads.get(p, p.grad)
         live = [g for g in self.groups if grad_of(g['p']) is not None]
-        if self.clip and self.clip > 0:
-            for g in live:
-                gr = grad_of(g['p'])
-                _lib.call('sgg_sqnorm_acc', gr.data_ptr(), gr.numel(), self._norm.data_ptr(), ops.dt(gr), stream)
+        import numpy as np
+        first = any(g['buf'] is None for g in live)
+        if first and not all(g['buf'] is None for g in live):
+            raise RuntimeError('FusedSGD: a parameter received its first gradient after step 1 (unsupported)')
         for g in live:
-            p, gr = g['p'], grad_of(g['p'])
-            first = g['buf'] is None
-            if first:
-                g['buf'] = torch.empty_like(p, dtype=torch.float32)
-            _lib.call('sgg_sgd_step', p.data_ptr(), gr.contiguous().data_ptr(), g['buf'].data_ptr(), p.numel(), float(g['lr']),
-                      float(self.weight_decay), float(self.momentum), int(first),
-                      self._norm.data_ptr() if self.clip and self.clip > 0 else None, float(self.clip or 0.0),
-                      float(grad_scale), ops.dt(gr), stream)
+            if g['buf'] is None:
+                g['buf'] = torch.empty_like(g['p'], dtype=torch.float32)
+        keep = [grad_of(g['p']).contiguous() for g in live]
+        shadows = self.shadow_of() if self.shadow_of is not None else {}
+        norm = self._norm.data_ptr() if self.clip and self.clip > 0 else None
+        pending = []
+        for dtype in (torch.float32, torch.bfloat16):          # gradients arrive fp32 (local) or bf16 (off the wire)
+            idx = [i for i, gr in enumerate(keep) if gr.dtype == dtype]
+            if not idx:
+                continue
+            arr = lambda vals: np.ascontiguousarray(np.array(vals, dtype=np.uint64))
+            gp = arr([keep[i].data_ptr() for i in idx])
+            pp = arr([live[i]['p'].data_ptr() for i in idx])
+            bp = arr([live[i]['buf'].data_ptr() for i in idx])
+            sh = [shadows.get(live[i]['name']) for i in idx]
+            sp = arr([t.data_ptr() if t is not None else 0 for t in sh])
+            nn = np.ascontiguousarray(np.array([keep[i].numel() for i in idx], dtype=np.int64))
+            lr = np.ascontiguousarray(np.array([live[i]['lr'] for i in idx], dtype=np.float32))
+            if norm is not None:
+                _lib.call('sgg_sqnorm_multi', gp.ctypes.data, nn.ctypes.data, len(idx), norm, ops.dt(keep[idx[0]]), stream)
+            pending.append((dtype, gp, pp, bp, sp, nn, lr, len(idx)))
+        for dtype, gp, pp, bp, sp, nn, lr, cnt in pending:  # every norm contribution lands before the first update
+            _lib.call('sgg_sgd_multi', pp.ctypes.data, gp.ctypes.data, bp.ctypes.data, sp.ctypes.data, nn.ctypes.data,
+                      lr.ctypes.data, cnt, float(self.weight_decay), float(self.momentum), int(first), norm,
+                      float(self.clip or 0.0), float(grad_scale), ops.dt(dtype), stream)
+        self.wrote_shadow = [n for n in shadows if any(g['name'] == n for g in live)]
         self.steps += 1
         if self.on_update is not None:
             self.on_update()   # parameters changed through raw pointers: tell the owner to refresh derived operands
@@ -77,6 +97,8 @@ class Trainer(object):
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         self.opt = FusedSGD(named, lr, momentum, weight_decay, clip)
         self.opt.on_update = self._bump
+        if hasattr(model, 'shadow_buffers'):
+            self.opt.shadow_of = model.shadow_buffers
         self.buckets = GradBuckets([p for _, p in named], comm_dtype=comm_dtype)
         self.loss_type = loss_type
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -91,6 +113,8 @@ class Trainer(object):
 
     def _bump(self):
         self.model.weights_version = getattr(self.model, 'weights_version', 0) + 1
+        if hasattr(self.model, 'mark_shadow_fresh'):
+            self.model.mark_shadow_fresh(self.opt.wrote_shadow)
 
     def losses(self, res):
         """node + edge classification losses with GLOBAL-batch normalisers: summed local CE / global counts, so that

@@ -120,6 +120,9 @@ def test_fused_sgd_matches_torch_sgd_with_global_norm_clip(env):
     ref_opt = torch.optim.SGD([{'params': [ref_named[0][1]], 'lr': lr / 10}, {'params': [p for _, p in ref_named[1:]]}],
                               lr=lr, momentum=mom, weight_decay=wd)
     hip_opt = FusedSGD(hip_named, lr, mom, wd, clip)
+    shadow = {'w3': torch.zeros(shapes[3], dtype=torch.bfloat16, device=DEV),
+              'w2': torch.zeros(shapes[2], dtype=torch.bfloat16, device=DEV)}
+    hip_opt.shadow_of = lambda: shadow
     for step in range(3):
         grads = [torch.randn(s, generator=g) * (30.0 if step == 1 else 0.01) for s in shapes]   # step 1 triggers the clip
         for (_, p), gr in zip(ref_named, grads):
@@ -136,6 +139,22 @@ def test_fused_sgd_matches_torch_sgd_with_global_norm_clip(env):
         assert abs(hip_opt.grad_norm() - float(total)) < 1e-3 * float(total)
         for (_, a), (_, b) in zip(ref_named, hip_named):
             torch.testing.assert_close(b.detach().cpu(), a.detach(), atol=1e-6, rtol=1e-5)
+        for n, sh in shadow.items():                 # the bf16 operand copy is written by the same pass, RNE like .to()
+            assert torch.equal(sh, dict(hip_named)[n].detach().to(torch.bfloat16))
+        assert sorted(hip_opt.wrote_shadow) == ['w2', 'w3']
+    # gradients handed over as bf16 buffers (what the all-reduce leaves behind) mixed with fp32 ones
+    before = [p.detach().clone() for _, p in hip_named]
+    gb = {hip_named[3][1]: torch.full(shapes[3], 0.5, dtype=torch.bfloat16, device=DEV)}
+    for _, p in hip_named[:3]:
+        p.grad = torch.zeros_like(p)
+    hip_named[3][1].grad = None
+    hip_opt.clip = 0.0
+    bufs = [g['buf'].clone() for g in hip_opt.groups]
+    hip_opt.step(grads=gb)
+    for i, ((_, p), b0, m0) in enumerate(zip(hip_named, before, bufs)):
+        gexp = (0.5 if i == 3 else 0.0) + wd * b0
+        m1 = mom * m0 + gexp
+        torch.testing.assert_close(p.detach(), b0 - (lr / 10 if i == 0 else lr) * m1, atol=1e-6, rtol=1e-5)
 
 
 def test_trainer_step_updates_weights_and_refreshes_operands(env):
@@ -151,6 +170,10 @@ def test_trainer_step_updates_weights_and_refreshes_operands(env):
     for _ in range(8):
         l1 = float(tr.step(tuple(dev_batch)))
     assert model._prep['key'] != k0                 # derived bf16 operands were rebuilt after the in-place update
+    w = model.prepared()                            # ... and the shadows the optimiser wrote ARE the casts of the masters
+    assert torch.equal(w['fc6_edge'], model.roi_fmap[1][0].weight.detach().to(torch.bfloat16))
+    assert torch.equal(w['fc7_obj'], model.roi_fmap_obj[3].weight.detach().to(torch.bfloat16))
+    assert torch.equal(w['rel_fc'], model.rel_fc.weight.detach().to(torch.bfloat16))
     assert l1 < l0
     assert not any(p.requires_grad for n, p in model.named_parameters() if n.startswith('detector.'))
     model.dropout_p = 0.5
