@@ -1,4 +1,6 @@
 // Load-time utilities: dtype casts and the weight re-layouts ((c,p)->(p,c) K-order for fc6, OIHW->O(HW)I for convs).
+#include <cstdlib>
+#include <cstring>
 #include "common.h"
 
 namespace {
@@ -84,6 +86,87 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ i
             store8(out + (long)c * ld_out + r, v);
         } else {
             for (int k = 0; k < 8 && r + k < R; ++k) Elem<TO>::st(out + (long)c * ld_out + r + k, v[k]);
+        }
+    }
+}
+
+// 16-bit-output form: 128x128 tiles (eight 16-byte loads in flight per thread, 256-byte row segments), the tile kept
+// in LDS as bf16 PAIRS [row][col/2] with a 65-word row stride: the b32 writes and the column reads (8 row-chunks x 8
+// column pairs per wave) are both bank-conflict free, and one ds_read_b32 feeds two output columns.
+template <typename TI>
+__global__ __launch_bounds__(256) void transpose16_kernel(const TI* __restrict__ in, long ld_in, bf16_t* __restrict__ out,
+                                                          long ld_out, int R, int C, const float* __restrict__ add,
+                                                          long ld_add, int group, float* __restrict__ colsum) {
+    __shared__ unsigned int t[128][65];
+    const int r0 = blockIdx.y * 128, c0 = blockIdx.x * 128;
+    const int tid = threadIdx.x;
+    const bool vin = ((ld_in & 7) == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+    const bool vout = ((ld_out & 7) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    float v[8][8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int id = tid + q * 256, rr = id >> 4, cc = (id & 15) * 8;
+        const int r = r0 + rr, c = c0 + cc;
+        if (r < R && c + 8 <= C && vin) {
+            load8(in + (long)r * ld_in + c, v[q]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[q][k] = (r < R && c + k < C) ? Elem<TI>::ld(in + (long)r * ld_in + c + k) : 0.f;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int id = tid + q * 256, rr = id >> 4, cc = (id & 15) * 8;
+        const int r = r0 + rr, c = c0 + cc;
+        if (add && r < R && c < C) {
+            if (group >= 8) {   // an 8-element piece spans at most two groups: one division, two loads
+                const int cg = c / group, left = group - (c - cg * group);
+                const float a0 = add[(long)r * ld_add + cg];
+                const float a1 = (left < 8 && c + left < C) ? add[(long)r * ld_add + cg + 1] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (c + k < C) v[q][k] += (k < left) ? a0 : a1;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (c + k < C) v[q][k] += add[(long)r * ld_add + (c + k) / group];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[rr][(cc >> 1) + k] = pack_bf16x2(v[q][2 * k], v[q][2 * k + 1]);
+    }
+    __syncthreads();
+    if (colsum && tid < 128 && c0 + tid < C) {   // bias gradient for free (rows >= R are zero)
+        float s = 0.f;
+        const int sh = (tid & 1) * 16;
+#pragma unroll 8
+        for (int k = 0; k < 128; ++k) s += __uint_as_float(((t[k][tid >> 1] >> sh) & 0xffffu) << 16);
+        atomicAdd(&colsum[c0 + tid], s);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int id = tid + q * 256, hi = id >> 6;
+        const int rc = (id & 7) + 8 * (hi & 1), cp = ((id >> 3) & 7) + 8 * (hi >> 1);
+        const int r = r0 + rc * 8, c = c0 + cp * 2;
+        if (c >= C || r >= R) continue;
+        unsigned int w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = t[rc * 8 + k][cp];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (c + h >= C) break;
+            const unsigned sel = h ? 0x07060302u : 0x05040100u;   // v_perm_b32: one selector BYTE per output byte
+            bf16_t* dst = out + (long)(c + h) * ld_out + r;
+            if (r + 8 <= R && vout) {
+                u32x4 o;
+                o.x = __builtin_amdgcn_perm(w[1], w[0], sel);
+                o.y = __builtin_amdgcn_perm(w[3], w[2], sel);
+                o.z = __builtin_amdgcn_perm(w[5], w[4], sel);
+                o.w = __builtin_amdgcn_perm(w[7], w[6], sel);
+                *reinterpret_cast<u32x4*>(dst) = o;
+            } else {
+                for (int k = 0; k < 8 && r + k < R; ++k) dst[k] = (bf16_t)((w[k] >> (16 * h)) & 0xffffu);
+            }
         }
     }
 }
@@ -174,12 +257,13 @@ extern "C" int sgg_transpose(const void* in, int64_t ld_in, void* out, int64_t l
     hipStream_t s = (hipStream_t)stream;
     if (group <= 0) group = 1;
     if (colsum && hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)C, s) != hipSuccess) return SGG_ERR_LAUNCH;
+    const dim3 grid16((C + 127) / 128, (R + 127) / 128);
     if (in_dtype == SGG_BF16 && out_dtype == SGG_BF16)
-        hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (const bf16_t*)in, (long)ld_in, (bf16_t*)out, (long)ld_out, R, C, add, (long)ld_add, group, colsum);
+        hipLaunchKernelGGL(transpose16_kernel<bf16_t>, grid16, blk, 0, s, (const bf16_t*)in, (long)ld_in, (bf16_t*)out, (long)ld_out, R, C, add, (long)ld_add, group, colsum);
     else if (in_dtype == SGG_F32 && out_dtype == SGG_F32)
         hipLaunchKernelGGL((transpose_kernel<float, float>), grid, blk, 0, s, (const float*)in, (long)ld_in, (float*)out, (long)ld_out, R, C, add, (long)ld_add, group, colsum);
     else if (in_dtype == SGG_F32 && out_dtype == SGG_BF16)
-        hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, blk, 0, s, (const float*)in, (long)ld_in, (bf16_t*)out, (long)ld_out, R, C, add, (long)ld_add, group, colsum);
+        hipLaunchKernelGGL(transpose16_kernel<float>, grid16, blk, 0, s, (const float*)in, (long)ld_in, (bf16_t*)out, (long)ld_out, R, C, add, (long)ld_add, group, colsum);
     else if (in_dtype == SGG_BF16 && out_dtype == SGG_F32)
         hipLaunchKernelGGL((transpose_kernel<bf16_t, float>), grid, blk, 0, s, (const bf16_t*)in, (long)ld_in, (float*)out, (long)ld_out, R, C, add, (long)ld_add, group, colsum);
     else

@@ -108,6 +108,15 @@ def test_transpose_add_and_group_sum(ops, dtype):
     wide = torch.randn(R, C + 40, generator=g).to(dtype)
     tv = ops.transpose(cu(wide)[:, 8:8 + C])
     torch.testing.assert_close(tv[:, :R].float().cpu(), wide[:, 8:8 + C].float().t(), atol=0, rtol=0)
+    # odd sizes on both axes (scalar edges), more than one 128-tile each way, and the casting form f32 -> bf16
+    xo = torch.randn(300, 515, generator=g).to(dtype)
+    to, cso = ops.transpose(cu(xo), want_colsum=True)
+    assert tuple(to.shape) == (515, 320) and float(to[:, 300:].float().abs().max()) == 0
+    torch.testing.assert_close(to[:, :300].float().cpu(), xo.float().t(), atol=0, rtol=0)
+    torch.testing.assert_close(cso.cpu(), xo.float().sum(0), atol=2e-3, rtol=1e-4)
+    tc = ops.transpose(cu(xo.float()), dtype=torch.bfloat16)
+    assert tc.dtype == torch.bfloat16
+    torch.testing.assert_close(tc[:, :300].cpu(), xo.float().t().to(torch.bfloat16), atol=0, rtol=0)
     w = torch.randn(37, C, generator=g)
     gs = ops.group_sum(cu(w), C // group, group, dtype)
     torch.testing.assert_close(gs.float().cpu(), w.view(37, C // group, group).sum(2).to(dtype).float(),
