@@ -166,28 +166,55 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             const T* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* __restrict__ sums,
                                                             int rows, int C, int rows_per_block) {
-    __shared__ float red[2][4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    // 8 lanes x 8 channels cover the block's 64 channels with 16-byte loads; 32 row-lanes walk the rows (C % 8 == 0)
+    __shared__ float red[2][32][65];
+    const int cl = (threadIdx.x & 7) * 8, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 64 + cl;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-    float s = 0.f, q = 0.f;
+    float s[8], q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = q[k] = 0.f;
     if (c < C) {
-        const float mu = mean[c], is = invstd[c];
-        for (int r = r0 + w; r < r1; r += 4) {
-            float g;
-            if (MAX4) g = arg[(long)(r >> 2) * C + c] == (unsigned char)(r & 3) ? Elem<T>::ld(dy + (long)(r >> 2) * C + c) : 0.f;
-            else g = Elem<T>::ld(dy + (long)r * C + c);
-            const float xh = (Elem<T>::ld(x + (long)r * C + c) - mu) * is;
-            s += g;
-            q += g * xh;
+        float mu[8], is[8];
+        load8(mean + c, mu);
+        load8(invstd + c, is);
+#pragma unroll 2
+        for (int r = r0 + rl; r < r1; r += 32) {
+            float g[8], xv[8];
+            load8(x + (long)r * C + c, xv);
+            if (MAX4) {
+                load8(dy + (long)(r >> 2) * C + c, g);
+                const uint2 a = *reinterpret_cast<const uint2*>(arg + (long)(r >> 2) * C + c);
+                const unsigned want = (unsigned)(r & 3);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned av = ((k < 4 ? a.x : a.y) >> (8 * (k & 3))) & 0xffu;
+                    if (av != want) g[k] = 0.f;
+                }
+            } else {
+                load8(dy + (long)r * C + c, g);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                s[k] += g[k];
+                q[k] = fmaf(g[k], (xv[k] - mu[k]) * is[k], q[k]);
+            }
         }
     }
-    red[0][w][threadIdx.x & 63] = s;
-    red[1][w][threadIdx.x & 63] = q;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        red[0][rl][cl + k] = s[k];
+        red[1][rl][cl + k] = q[k];
+    }
     __syncthreads();
-    if (w == 0 && c < C) {
-        const int t = threadIdx.x;
-        atomicAdd(&sums[c], red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]);
-        atomicAdd(&sums[C + c], red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]);
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, cc = threadIdx.x & 63;
+        if (blockIdx.x * 64 + cc < C) {
+            float a = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) a += red[which][k][cc];
+            atomicAdd(&sums[which * C + blockIdx.x * 64 + cc], a);
+        }
     }
 }
 
