@@ -230,7 +230,7 @@ def main():
         conv_ms = sum(v[0] * v[1] for (n, t), v in kt.items() if n in ('sgg_conv3x3_relu', 'sgg_conv1_1', 'sgg_maxpool2x2'))
         vgg_flop = 226.13e9 * B
         total_ms = sum(v[0] * v[1] for v in kt.values())
-        top = sorted(((v[0] * v[1], n, t) for (n, t), v in kt.items()), reverse=True)[:10]
+        top = sorted(((v[0] * v[1], n, t) for (n, t), v in kt.items()), reverse=True)[:int(os.environ.get('SGG_BENCH_TOP', '10'))]
         # the other mode, for reference (short run)
         other = infer_step if args.mode == 'train' else None
         other_line = None

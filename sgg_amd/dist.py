@@ -61,11 +61,12 @@ class GradBuckets(object):
     the links (the sum is still applied to fp32 master gradients).  All collectives are issued asynchronously and
     waited for together."""
 
-    def __init__(self, params, big_bytes=8 << 20, comm_dtype=None):
+    def __init__(self, params, big_bytes=8 << 20, comm_dtype=None, force=False):
         self.params = [p for p in params if p.requires_grad]
         self.comm_dtype = comm_dtype
         self.big = [p for p in self.params if p.numel() * p.element_size() >= big_bytes]
         self.small = [p for p in self.params if p.numel() * p.element_size() < big_bytes]
+        self.force = force    # also run on a 1-rank group (tests)
         self._early = {}      # param -> (wire buffer, work handle): all-reduces launched from inside the backward
 
     def is_big(self, p):
@@ -74,7 +75,7 @@ class GradBuckets(object):
     def start(self, p, grad):
         """Launch the all-reduce of one big gradient as soon as the backward has produced it (overlaps the rest of the
         backward); `all_reduce` later waits for it instead of issuing it."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not self.force):
             return
         buf = grad.to(self.comm_dtype) if (self.comm_dtype is not None and self.comm_dtype != grad.dtype) else grad
         self._early[p] = (buf, dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
@@ -83,7 +84,7 @@ class GradBuckets(object):
         """Returns {param: reduced buffer} for the big tensors when they were reduced in a narrower comm dtype (the
         optimiser can consume those directly); p.grad of every parameter also holds the reduced gradient, except that the
         copy back into fp32 .grad is skipped for those big tensors when `average` is False (the caller uses the dict)."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not self.force):
             return {}
         world = dist.get_world_size()
         direct = {}

@@ -43,13 +43,13 @@ def _pad_cols(x, mult, dtype):
     return buf
 
 
-def tn_gemm(X, Y, out=None, want_colsum=False):
+def tn_gemm(X, Y, out=None, want_colsum=False, out_dtype=torch.float32):
     """X[M,a]^T . Y[M,b] -> f32 [a,b]  (weight gradients).  Rows are zero-padded to a multiple of 64 by the transposes.
     want_colsum: also return colsum(X) (the bias gradient when X = dY), computed inside X's transpose pass."""
     if want_colsum:
         xt, cs = ops.transpose(X, want_colsum=True)
-        return ops.gemm(xt, ops.transpose(Y), out_dtype=torch.float32, out=out), cs
-    return ops.gemm(ops.transpose(X), ops.transpose(Y), out_dtype=torch.float32, out=out)
+        return ops.gemm(xt, ops.transpose(Y), out_dtype=out_dtype, out=out), cs
+    return ops.gemm(ops.transpose(X), ops.transpose(Y), out_dtype=out_dtype, out=out)
 
 
 def train_weights(model):
@@ -185,23 +185,46 @@ class PredictFn(torch.autograd.Function):
         dev = XN.device
         G = {}
         rows = lambda buf, c, n: buf[c * n:(c + 1) * n]
-        grad_hook = getattr(model, '_grad_ready_hook', None)     # set by the DP trainer: early all-reduce of big gradients
+        # Data-parallel hooks (set by the trainer): a big gradient is handed over the moment it exists so that its
+        # all-reduce overlaps the rest of the backward; with a bf16 wire the GEMM emits the wire dtype directly.
+        grad_hook = getattr(model, '_grad_ready_hook', None)
+        wire = getattr(model, '_grad_wire_dtype', None) if grad_hook is not None else None
+        handed = set()
+
+        def big_dtype():
+            return wire if wire is not None else torch.float32
 
         def hook(name):
-            if grad_hook is not None:
-                grad_hook(name, G[name])
+            if grad_hook is None:
+                return
+            if grad_hook(name, G[name]) and G[name].dtype != torch.float32:
+                handed.add(name)                 # the all-reduce owns the wire-dtype buffer; autograd gets nothing
+            elif G[name].dtype != torch.float32:
+                G[name] = G[name].float()
 
-        def lin_bwd(dY, X, Wt, name, want_dx=True):
-            """Y = X W^T + b : returns dX; stores dW (f32 [N,K]) and db."""
-            G[name + '.weight'], G[name + '.bias'] = tn_gemm(dY, X, want_colsum=True)
+        # Order: (A) the dX chain alone -- the critical path down to the two fc6 inputs; (B) the fc6 weight gradients
+        # (83 % of all gradient bytes), each followed by its hook; (C) every other weight gradient, deferred to here so
+        # that it runs while the fc6 all-reduces occupy the links.
+        deferred = []
+
+        def lin_bwd(dY, X, Wt, name, tag, want_dx=True, big=False):
+            """Y = X W^T + b : returns dX now; dW (f32 [N,K]) and db are computed in phase C."""
+            def dw():
+                _lib.set_tag(tag)
+                G[name + '.weight'], G[name + '.bias'] = tn_gemm(dY, X, want_colsum=True,
+                                                                 out_dtype=big_dtype() if big else torch.float32)
+                if big:
+                    hook(name + '.weight')
+            deferred.append(dw)
             return ops.gemm(_pad_cols(dY, 64, dt), Wt) if want_dx else None
 
+        # ---- phase A
         _lib.set_tag('bwd_heads')
         d_obj = d_obj.contiguous().to(dt) if d_obj.dtype != dt else d_obj.contiguous()
         d_rel = d_rel.contiguous().to(dt) if d_rel.dtype != dt else d_rel.contiguous()
-        d_v = lin_bwd(d_obj, rows(HN, T, N), t['obj_fc_t'], 'obj_fc')
-        d_e = lin_bwd(d_rel, rows(HE, T, E), t['rel_fc_t'], 'rel_fc')
-        # ---- IMP backward (rel_model_stanford.py:74-92 in reverse)
+        d_v = lin_bwd(d_obj, rows(HN, T, N), t['obj_fc_t'], 'obj_fc', 'bwd_heads')
+        d_e = lin_bwd(d_rel, rows(HE, T, E), t['rel_fc_t'], 'rel_fc', 'bwd_heads')
+        # IMP backward (rel_model_stanford.py:74-92 in reverse)
         _lib.set_tag('bwd_imp')
         dGIn = torch.empty((4 * N, 3 * H), dtype=dt, device=dev)
         dGHn = torch.empty((4 * N, 3 * H), dtype=dt, device=dev)
@@ -210,6 +233,7 @@ class PredictFn(torch.autograd.Function):
         d_gw = torch.zeros((4, 2 * H), dtype=torch.float32, device=dev)
         d_gb = torch.zeros((4, 1), dtype=torch.float32, device=dev)
         ones = torch.ones((E, 1), dtype=dt, device=dev)
+        gate_terms = []
         for i in range(T - 1, -1, -1):
             v_i, e_i = rows(HN, i, N), rows(HE, i, E)
             # v_{i+1} = GRU_n(ctx_i, v_i)
@@ -226,55 +250,60 @@ class PredictFn(torch.autograd.Function):
             da, gsave = ops.imp_edge_ctx_bwd(v_i, e_i, sv['rel_inds'], sv['dots'][i], imp.gate_w, imp.gate_b, d_e_in, d_ctx,
                                              d_e_prev)
             nsum = ops.imp_node_scatter_bwd(d_e_in, gsave, da, sv['csr'], imp.gate_w, d_v_prev)
-            ops.rank4_reduce_(da, e_i, d_gw, col0=H)
-            ops.rank4_reduce_(nsum, v_i, d_gw, col0=0)
-            ops.rank4_reduce_(da, ones, d_gb)
+            gate_terms.append((da, nsum, v_i, e_i))      # gate weight gradients: phase C
             d_v, d_e = d_v_prev, d_e_prev
         # first calls (h = 0): gh = b_hh only
         ops.gru_gate_bwd(d_v, sv['gin'][0], None, imp.node_gru_b_hh, None, rows(dGIn, 0, N), rows(dGHn, 0, N), False)
         d_obj_rep = ops.gemm(rows(dGIn, 0, N), t['node_gru_w_ih_t'])
         ops.gru_gate_bwd(d_e, sv['gie'][0], None, imp.edge_gru_b_hh, None, rows(dGIe, 0, E), rows(dGHe, 0, E), False)
         d_rel_rep = ops.gemm(rows(dGIe, 0, E), t['edge_gru_w_ih_t'])
-        # GRU parameter gradients: one contraction over the 4 stacked calls; hidden state of call 0 is zero
-        HprevN = torch.cat((torch.zeros_like(HN[:N]), HN[:3 * N]), 0) if T == 3 else None
-        HprevE = torch.cat((torch.zeros_like(HE[:E]), HE[:3 * E]), 0) if T == 3 else None
-        if HprevN is None:
+        if T != 3:
             raise NotImplementedError('training is wired for mp_iter == 3')
-        G['node_gru.weight_ih'], G['node_gru.bias_ih'] = tn_gemm(dGIn, XN, want_colsum=True)
-        G['node_gru.weight_hh'], G['node_gru.bias_hh'] = tn_gemm(dGHn, HprevN, want_colsum=True)
-        G['edge_gru.weight_ih'], G['edge_gru.bias_ih'] = tn_gemm(dGIe, XE, want_colsum=True)
-        G['edge_gru.weight_hh'], G['edge_gru.bias_hh'] = tn_gemm(dGHe, HprevE, want_colsum=True)
-        for k, g in enumerate(GATES):
-            G[g + '.0.weight'] = d_gw[k:k + 1].clone()
-            G[g + '.0.bias'] = d_gb[k].clone()
         p = sv['dropout_p']
         ds = 1.0 / (1.0 - p) if p > 0 else 1.0
         C, PP = model.edge_dim, model.pool_sz ** 2
-        # ---- node MLP backward (first: its 411 MB fc6 gradient can start its all-reduce early)
-        _lib.set_tag('bwd_mlp_obj')
-        d_x7 = lin_bwd(d_obj_rep, sv['x7'], t['obj_unary_t'], 'obj_unary')
-        d_p7 = ops.act_bwd(d_x7, sv['x7'], ds)
-        d_x6 = lin_bwd(d_p7, sv['x6'], t['fc7_obj_t'], 'roi_fmap_obj.3')
-        hook('roi_fmap_obj.3.weight')
-        d_p6 = ops.act_bwd(d_x6, sv['x6'], ds)
-        G['roi_fmap_obj.0.weight'], G['roi_fmap_obj.0.bias'] = tn_gemm(d_p6, sv['nf'], want_colsum=True)
-        hook('roi_fmap_obj.0.weight')            # 411 MB: its all-reduce overlaps the edge-MLP backward below
-        # ---- edge MLP backward
         _lib.set_tag('bwd_mlp')
         d_u = ops.act_bwd(d_rel_rep, rows(XE, 0, E))                               # relu(edge_unary)
-        d_y7 = lin_bwd(d_u, sv['y7'], t['edge_unary_t'], 'edge_unary')
-        d_y6 = lin_bwd(d_y7, sv['y6'], t['fc7_edge_t'], 'roi_fmap.1.3')
-        hook('roi_fmap.1.3.weight')
+        d_y7 = lin_bwd(d_u, sv['y7'], t['edge_unary_t'], 'edge_unary', 'bwd_mlp')
+        d_y6 = lin_bwd(d_y7, sv['y6'], t['fc7_edge_t'], 'roi_fmap.1.3', 'bwd_mlp', big=True)
         d_pre6 = ops.act_bwd(d_y6, sv['y6'], ds)                                   # dropout + relu
+        _lib.set_tag('bwd_mlp_obj')
+        d_x7 = lin_bwd(d_obj_rep, sv['x7'], t['obj_unary_t'], 'obj_unary', 'bwd_mlp_obj')
+        d_p7 = ops.act_bwd(d_x7, sv['x7'], ds)
+        d_x6 = lin_bwd(d_p7, sv['x6'], t['fc7_obj_t'], 'roi_fmap_obj.3', 'bwd_mlp_obj', big=True)
+        d_p6 = ops.act_bwd(d_x6, sv['x6'], ds)
+        # ---- phase B: the two fc6 weight gradients
         _lib.set_tag('bwd_fc6_edge_dW')
         # d W6[n,(c,p)] = sum_e d_pre6[e,n] * (edge_feat[e,c,p] + rect[e,c]): the folded term rides in the transpose
         x6t = ops.transpose(sv['ef'], add=sv['rect'].float() if sv['rect'].dtype != torch.float32 else sv['rect'], group=PP)
         d6t, G['roi_fmap.1.0.bias'] = ops.transpose(d_pre6, want_colsum=True)
-        G['roi_fmap.1.0.weight'] = ops.gemm(d6t, x6t, out_dtype=torch.float32)
+        G['roi_fmap.1.0.weight'] = ops.gemm(d6t, x6t, out_dtype=big_dtype())
         hook('roi_fmap.1.0.weight')
+        del x6t, d6t
+        _lib.set_tag('bwd_mlp_obj')
+        G['roi_fmap_obj.0.weight'], G['roi_fmap_obj.0.bias'] = tn_gemm(d_p6, sv['nf'], want_colsum=True, out_dtype=big_dtype())
+        hook('roi_fmap_obj.0.weight')
+        # ---- phase C: everything deferred, largest first (fc7 x2 carry their own hooks)
+        for dw in deferred[::-1]:                      # fc7 node, unary node, fc7 edge, unary edge, heads
+            dw()
+        _lib.set_tag('bwd_imp')
+        # GRU parameter gradients: one contraction over the 4 stacked calls; hidden state of call 0 is zero
+        HprevN = torch.cat((torch.zeros_like(HN[:N]), HN[:3 * N]), 0)
+        HprevE = torch.cat((torch.zeros_like(HE[:E]), HE[:3 * E]), 0)
+        G['edge_gru.weight_ih'], G['edge_gru.bias_ih'] = tn_gemm(dGIe, XE, want_colsum=True)
+        G['edge_gru.weight_hh'], G['edge_gru.bias_hh'] = tn_gemm(dGHe, HprevE, want_colsum=True)
+        G['node_gru.weight_ih'], G['node_gru.bias_ih'] = tn_gemm(dGIn, XN, want_colsum=True)
+        G['node_gru.weight_hh'], G['node_gru.bias_hh'] = tn_gemm(dGHn, HprevN, want_colsum=True)
+        for da, nsum, v_i, e_i in gate_terms:
+            ops.rank4_reduce_(da, e_i, d_gw, col0=H)
+            ops.rank4_reduce_(nsum, v_i, d_gw, col0=0)
+            ops.rank4_reduce_(da, ones, d_gb)
+        for k, g in enumerate(GATES):
+            G[g + '.0.weight'] = d_gw[k:k + 1].clone()
+            G[g + '.0.bias'] = d_gb[k].clone()
         _lib.set_tag('bwd_rect')
         d_rect = ops.gemm(d_pre6, t['w6sum_t'])                                    # [E,C]
-        # ---- rect conv backward (BatchNorm with batch statistics)
+        # rect conv backward (BatchNorm with batch statistics)
         d_c2, db2, dg2 = ops.bn_bwd(d_rect, None, sv['h3'], sv['m2'], sv['is2'], t['rc_g2'], False)
         G['union_boxes.conv.6.weight'], G['union_boxes.conv.6.bias'] = dg2.clone(), db2.clone()
         gw2, gb2 = tn_gemm(d_c2, sv['h2'], want_colsum=True)                       # [d, d2] centre tap
@@ -291,7 +320,8 @@ class PredictFn(torch.autograd.Function):
         _lib.set_tag('')
         ctx.sv = None
         shapes = dict(model.named_parameters())
-        grads = [G[n].reshape(shapes[n].shape) for n in param_names(model)]
+        # gradients already handed to the all-reduce in the wire dtype are not returned to autograd (no fp32 copy)
+        grads = [None if n in handed else G[n].reshape(shapes[n].shape) for n in param_names(model)]
         return (None,) * 8 + tuple(grads)
 
 

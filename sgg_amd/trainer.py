@@ -89,7 +89,7 @@ class Trainer(object):
     """One data-parallel train step.  `loss_type` as lib/losses.py ('baseline' is the reference default, config.py:184)."""
 
     def __init__(self, model, lr=1e-3, momentum=0.9, weight_decay=1e-4, clip=5.0, loss_type='baseline',
-                 comm_dtype=torch.bfloat16):
+                 comm_dtype=torch.bfloat16, force_dist=False):
         self.model = model
         for n, p in model.named_parameters():
             if n.startswith('detector.'):
@@ -99,17 +99,24 @@ class Trainer(object):
         self.opt.on_update = self._bump
         if hasattr(model, 'shadow_buffers'):
             self.opt.shadow_of = model.shadow_buffers
-        self.buckets = GradBuckets([p for _, p in named], comm_dtype=comm_dtype)
+        self.buckets = GradBuckets([p for _, p in named], comm_dtype=comm_dtype, force=force_dist)
         self.loss_type = loss_type
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        if self.world > 1:
+        # force_dist: run the distributed code path on a 1-rank group too (tests exercise RCCL plumbing on one GPU)
+        self.dist_on = self.world > 1 or (force_dist and dist.is_available() and dist.is_initialized())
+        if self.dist_on:
             by_name = dict(named)
 
             def early(name, grad):      # called from PredictFn.backward the moment a big gradient exists
                 p = by_name.get(name)
                 if p is not None and self.buckets.is_big(p):
                     self.buckets.start(p, grad)
+                    return True
+                return False
             model._grad_ready_hook = early
+            # bf16 on the wire: the weight-gradient GEMMs of the hooked tensors emit bf16 directly (fp32 accumulate,
+            # one rounding -- the same numbers as casting an fp32 gradient, without writing and re-reading it)
+            model._grad_wire_dtype = comm_dtype if comm_dtype == torch.bfloat16 else None
 
     def _bump(self):
         self.model.weights_version = getattr(self.model, 'weights_version', 0) + 1
@@ -150,7 +157,7 @@ class Trainer(object):
         loss = self.losses(res)
         self.opt.zero_grad()
         loss.backward()
-        reduced = self.buckets.all_reduce(average=False) if self.world > 1 else None
+        reduced = self.buckets.all_reduce(average=False) if self.dist_on else None
         self.opt.step(grads=reduced)
         self.model.global_batch_iter = getattr(self.model, 'global_batch_iter', 0) + 1
         return loss.detach()

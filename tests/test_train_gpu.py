@@ -178,3 +178,46 @@ def test_trainer_step_updates_weights_and_refreshes_operands(env):
     assert not any(p.requires_grad for n, p in model.named_parameters() if n.startswith('detector.'))
     model.dropout_p = 0.5
     model.eval()
+
+
+def test_trainer_distributed_path_on_one_rank_matches_local(env):
+    """The DP code path (hooks from inside the backward, bf16 wire buffers written by the GEMMs, RCCL all-reduce, the
+    optimiser consuming the wire buffers) on a 1-rank RCCL group must reproduce the local step up to bf16 rounding of
+    the big gradients."""
+    import os
+    import torch.distributed as dist
+    from sgg_amd.trainer import Trainer
+    model, sd, batch = env
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29577')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        model.set_compute_dtype(torch.bfloat16)
+        model.dropout_p = 0.0
+        names = ['roi_fmap.1.0.weight', 'roi_fmap_obj.0.weight', 'roi_fmap.1.3.weight', 'rel_fc.weight',
+                 'edge_gru.weight_ih', 'union_boxes.conv.0.weight']
+        out = {}
+        for mode in ('local', 'dist'):
+            model.load_state_dict(sd)
+            tr = Trainer(model, lr=2e-2, force_dist=(mode == 'dist'))
+            assert tr.dist_on == (mode == 'dist')
+            loss = float(tr.step(tuple(batch)))
+            params = dict(model.named_parameters())
+            out[mode] = (loss, {n: params[n].detach().float().cpu().clone() for n in names})
+            if mode == 'dist':
+                hooked = ('roi_fmap.1.0.weight', 'roi_fmap_obj.0.weight', 'roi_fmap.1.3.weight', 'roi_fmap_obj.3.weight')
+                assert all(tr.buckets.is_big(params[n]) for n in hooked)
+                assert all(params[n].grad is None for n in hooked)   # handed over in bf16, never materialised in fp32
+        assert abs(out['local'][0] - out['dist'][0]) < 1e-5
+        for n in names:
+            w0 = sd[n].float()
+            step = (out['local'][1][n] - w0).abs().max()
+            diff = (out['local'][1][n] - out['dist'][1][n]).abs().max()
+            assert step > 0 and diff <= 2e-2 * step + 1e-9, (n, float(step), float(diff))
+    finally:
+        dist.destroy_process_group()
+        model._grad_ready_hook = None
+        model._grad_wire_dtype = None
+        model.dropout_p = 0.5
+        model.eval()
