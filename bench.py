@@ -36,6 +36,8 @@ def parse():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--mode', default='train', choices=['train', 'infer'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='diagnostic: at 1 GPU, run the data-parallel code path on a 1-rank RCCL group')
     ap.add_argument('--cpu-images', type=int, default=8)
     return ap.parse_args()
 
@@ -133,12 +135,19 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
+        if rank != 0:
+            os.dup2(2, 1)      # only rank 0 owns stdout (the JSON line); anything other ranks print goes to stderr
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local)
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
     else:
         torch.cuda.set_device(0)
+        if args.force_dist:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29581')
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     dev = torch.device('cuda', local if world > 1 else 0)
 
     import sgg_amd
@@ -154,7 +163,7 @@ def main():
     batch = tuple(batch)
 
     from sgg_amd.trainer import Trainer
-    trainer = Trainer(model, lr=1e-3) if args.mode == 'train' else None
+    trainer = Trainer(model, lr=1e-3, force_dist=args.force_dist) if args.mode == 'train' else None
 
     def infer_step():
         model.eval()
@@ -199,7 +208,11 @@ def main():
                 trainer.opt.zero_grad()
                 loss.backward()
                 trainer.opt.step()
+            # rank 0 alone runs these extra steps: no collective may be issued (the other ranks wait at the barrier)
+            saved_hook, trainer.world = getattr(model, '_grad_ready_hook', None), 1
+            model._grad_ready_hook = None
             kt = kernel_times(prof_step, reps=3)
+            model._grad_ready_hook, trainer.world = saved_hook, world
         else:
             kt = kernel_times(infer_step, reps=5)
         E, N, H = 992 * B, 32 * B, 512
@@ -209,8 +222,8 @@ def main():
         per_step = lambda name, tag: get(name, tag)[0] * get(name, tag)[1]
         # the two largest contractions: fc6 on edges forward, and its weight gradient in training
         cands = {'fc6_edge': ('fc6 on edges, forward: [%d x 25600] . [4096 x 25600]^T' % E, 2.0 * E * 4096 * 25600),
-                 'bwd_fc6_edge_dW': ('fc6 weight gradient: [4096 x %d] . [25600 x %d]^T (2 launches: 25088 + 512 cols)' % (E, E),
-                                     2.0 * E * 4096 * 25600)}
+                 'bwd_fc6_edge_dW': ('fc6 weight gradient: [4096 x %d] . [25088 x %d]^T (the rect term rides in the transpose)' % (E, E),
+                                     2.0 * E * 4096 * 25088)}
         best = None
         for tag, (desc, flop) in cands.items():
             ms = per_step('sgg_gemm', tag)
@@ -275,10 +288,17 @@ def main():
             line['other_mode'] = other_line
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.cpu_images, 111)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+    else:
+        line = None
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        # RCCL prints its version banner through C stdio, which is block-buffered on a pipe and would otherwise be
+        # flushed at exit, AFTER this line: push it out first so that the JSON is the last thing rank 0 writes.
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == '__main__':

@@ -81,9 +81,10 @@ class GradBuckets(object):
         self._early[p] = (buf, dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
 
     def all_reduce(self, average=True):
-        """Returns {param: reduced buffer} for the big tensors when they were reduced in a narrower comm dtype (the
-        optimiser can consume those directly); p.grad of every parameter also holds the reduced gradient, except that the
-        copy back into fp32 .grad is skipped for those big tensors when `average` is False (the caller uses the dict)."""
+        """average=True: p.grad of every parameter holds the mean gradient afterwards (returns {}).
+        average=False (the trainer: losses are already normalised by the global batch): returns {param: reduced buffer}
+        -- wire-dtype buffers of the big tensors and views into the flat bucket for the small ones -- for the fused
+        optimiser to consume in place; nothing is copied back into p.grad."""
         if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not self.force):
             return {}
         world = dist.get_world_size()
@@ -103,8 +104,17 @@ class GradBuckets(object):
             buf = g.to(self.comm_dtype) if (self.comm_dtype is not None and self.comm_dtype != g.dtype) else g
             bufs.append((p, buf))
             works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.small]
-        flat = torch.cat([g.reshape(-1).float() for g in grads]) if grads else None
+        # small tensors: one flat fp32 bucket, every slot padded to 4 elements so that views into it stay 16-byte aligned
+        pieces, offs, off = [], [], 0
+        for p in self.small:
+            n = p.numel()
+            pieces.append(p.grad.reshape(-1).float() if p.grad is not None else p.new_zeros(n, dtype=torch.float32))
+            offs.append(off)
+            pad = (-n) % 4
+            if pad:
+                pieces.append(p.new_zeros(pad, dtype=torch.float32))
+            off += n + pad
+        flat = torch.cat(pieces) if pieces else None
         if flat is not None:
             works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
         for w in works:
@@ -120,13 +130,12 @@ class GradBuckets(object):
         if flat is not None:
             if average:
                 flat.div_(world)
-            off = 0
-            for p in self.small:
-                n = p.numel()
-                g = flat[off:off + n].view_as(p)
-                if p.grad is None:
+            for p, o in zip(self.small, offs):
+                g = flat[o:o + p.numel()].view_as(p)
+                if not average:
+                    direct[p] = g            # the optimiser reads the bucket in place
+                elif p.grad is None:
                     p.grad = g.clone()
                 else:
                     p.grad.copy_(g)
-                off += n
         return direct

@@ -25,7 +25,7 @@ def _worker(rank, world, port, q):
     mx = D.max_over_ranks(1.0 + r)
     tot = D.sum_over_ranks([hi - lo, 2.0 * r])
     torch.manual_seed(0)
-    lin = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4))
+    lin = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 3))
     x = torch.full((3, 8), float(r + 1))
     lin(x).sum().backward()
     local = [p.grad.clone() for p in lin.parameters()]
@@ -39,7 +39,8 @@ def _worker(rank, world, port, q):
     gb.start(first, first.grad)                      # early launch from inside the backward (overlap path)
     direct = gb.all_reduce(average=False)
     summed = [(direct[p] if p in direct else p.grad).float() for p in lin.parameters()]
-    ok = len(direct) == 2 and all(torch.allclose(s, a * 2, atol=1e-6) for s, a in zip(summed, avg))
+    ok = len(direct) == 4 and all(torch.allclose(s, a * 2, atol=1e-6) for s, a in zip(summed, avg))
+    ok = ok and all(t.data_ptr() % 16 == 0 for t in direct.values())     # bucket views stay 16-byte aligned (3-element bias)
     q.put((r, (lo, hi), mx, tot, [g.tolist() for g in local], [g.tolist() for g in avg], ok))
     dist.barrier()
     dist.destroy_process_group()
