@@ -28,9 +28,9 @@ struct ConvArgs {
     int B, H, W, Cin, Cout, out_pad, tiles_x, tiles_y;
 };
 
-template <bool BF16, int WN>
+template <bool BF16, int WN, int NI>
 __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArgs g) {
-    constexpr int NW = 4 * WN, CN = 64 * WN;
+    constexpr int NW = 4 * WN, CNW = 32 * NI, CN = CNW * WN;   // channels per wave / per block
     constexpr int ESZ = BF16 ? 2 : 4;
     constexpr int PATCH_B = PROWS_PAD * RB, WSLAB_B = CN * RB;
     constexpr int PI = PROWS_PAD / 8;                        // 41 patch DMA instructions
@@ -90,19 +90,19 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
     int prow0[2];          // patch row of this lane's pixel (tap 0,0) for the two 32-pixel column blocks
 #pragma unroll
     for (int j = 0; j < 2; ++j) prow0[j] = (wm * 4 + j * 2 + (fr >> 4)) * PW + (fr & 15);
-    int woff[2], wkey[2];
+    int woff[NI], wkey[NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = wn * 64 + i * 32 + fr;
+    for (int i = 0; i < NI; ++i) {
+        const int r = wn * CNW + i * 32 + fr;
         woff[i] = r * RB;
         wkey[i] = (r >> 1) & 7;
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NI];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -131,16 +131,15 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int slot = 2 * s + fh;
-                u32x4 av[2], bv[2];
+                u32x4 av[NI], bv[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    av[i] = *reinterpret_cast<const u32x4*>(wb + woff[i] + ((slot ^ wkey[i]) << 4));
-                    bv[i] = *reinterpret_cast<const u32x4*>(patch + poff[i] + ((slot ^ pkey[i]) << 4));
-                }
+                for (int i = 0; i < NI; ++i) av[i] = *reinterpret_cast<const u32x4*>(wb + woff[i] + ((slot ^ wkey[i]) << 4));
+#pragma unroll
+                for (int i = 0; i < 2; ++i) bv[i] = *reinterpret_cast<const u32x4*>(patch + poff[i] + ((slot ^ pkey[i]) << 4));
 #pragma unroll
                 for (int pj = 0; pj < 2; ++pj)
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
+                    for (int ni = 0; ni < NI; ++ni) {
                         if constexpr (BF16) {
                             acc[pj][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                                 __builtin_bit_cast(bf16x8_t, av[ni]), __builtin_bit_cast(bf16x8_t, bv[pj]), acc[pj][ni], 0, 0, 0);
@@ -156,14 +155,16 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
         }
     }
 
-    // ---- epilogue through LDS: per wave a [32 px][64 ch] f32 tile (row stride 272 B), one pixel block at a time
-    constexpr int ESTRIDE = 272;
+    // ---- epilogue through LDS: per wave a [32 px][CNW ch] f32 tile (row stride CNW*4+16 B), one pixel block at a time
+    constexpr int ESTRIDE = CNW * 4 + 16;
+    constexpr int LPR = CNW / 8;                  // lanes per pixel row (8 channels each)
+    constexpr int PPI = 64 / LPR;                 // pixels per pass
     char* est = smem + wave * (32 * ESTRIDE);
 #pragma unroll
     for (int pj = 0; pj < 2; ++pj) {
         __syncthreads();
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 v = {acc[pj][ni][4 * q], acc[pj][ni][4 * q + 1], acc[pj][ni][4 * q + 2], acc[pj][ni][4 * q + 3]};
@@ -171,15 +172,15 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
             }
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int pl = (lane >> 3) + 8 * it, cl = (lane & 7) * 8;   // pixel inside the 32-block, channel chunk
+        for (int it = 0; it < 32 / PPI; ++it) {
+            const int pl = lane / LPR + PPI * it, cl = (lane % LPR) * 8;   // pixel inside the 32-block, channel chunk
             const int y = y0 + wm * 4 + pj * 2 + (pl >> 4), x = x0 + (pl & 15);
             if (y >= g.H || x >= g.W) continue;
             float v[8];
             const f32x4 lo = *reinterpret_cast<const f32x4*>(est + pl * ESTRIDE + cl * 4);
             const f32x4 hi = *reinterpret_cast<const f32x4*>(est + pl * ESTRIDE + cl * 4 + 16);
             v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-            const int n = n0 + wn * 64 + cl;
+            const int n = n0 + wn * CNW + cl;
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] + g.bias[n + k], 0.f);
             const int op = g.out_pad;
@@ -190,12 +191,12 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
     }
 }
 
-template <bool BF16, int WN>
+template <bool BF16, int WN, int NI>
 int launch_spatial(const ConvArgs& g, hipStream_t s) {
-    constexpr int CN = 64 * WN;
+    constexpr int CN = 32 * NI * WN;
     constexpr int smem = PROWS_PAD * RB + 2 * CN * RB;
-    static_assert(smem >= 4 * WN * 32 * 272, "epilogue staging fits");
-    auto k = conv3x3_spatial_kernel<BF16, WN>;
+    static_assert(smem >= 4 * WN * 32 * (32 * NI * 4 + 16), "epilogue staging fits");
+    auto k = conv3x3_spatial_kernel<BF16, WN, NI>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -218,7 +219,9 @@ int sgg_launch_conv_spatial(const void* in, const void* w, const float* bias, vo
     g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.out_pad = out_pad;
     g.tiles_x = (W + TILE - 1) / TILE;
     g.tiles_y = (H + TILE - 1) / TILE;
-    if (Cout % 128 == 0) return bf16 ? launch_spatial<true, 2>(g, s) : launch_spatial<false, 2>(g, s);
-    if (Cout % 64 == 0) return bf16 ? launch_spatial<true, 1>(g, s) : launch_spatial<false, 1>(g, s);
+    // (4 waves x [64 px x 128 ch] per wave -- NI = 4, a quarter fewer LDS reads -- measured 10-20 % slower than
+    //  8 waves x [64 x 64]: the kernel is latency-, not LDS-bandwidth-bound, and the extra waves hide more of it.)
+    if (Cout % 128 == 0) return bf16 ? launch_spatial<true, 2, 2>(g, s) : launch_spatial<false, 2, 2>(g, s);
+    if (Cout % 64 == 0) return bf16 ? launch_spatial<true, 1, 2>(g, s) : launch_spatial<false, 1, 2>(g, s);
     return 1;
 }

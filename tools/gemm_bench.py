@@ -27,7 +27,7 @@ def main():
     dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == 'bf16') else torch.float32
     shapes = [('fc6_edge', 7936, 4096, 25600), ('fc7_edge', 7936, 4096, 4096), ('unary', 7936, 512, 4096),
               ('gru', 7936, 1536, 512), ('fc6_obj', 256, 4096, 25088), ('rel_fc', 7936, 51, 512)]
-    for name, M, N, K in shapes:
+    for name, M, N, K in ([] if os.environ.get('CONV_ONLY') else shapes):
         A = torch.randn(M, K, device=dev).to(dt)
         W = (torch.randn(N, K, device=dev) / K ** 0.5).to(dt)
         b = torch.randn(N, device=dev)
@@ -35,9 +35,9 @@ def main():
         ms = timeit(lambda: ops.gemm(A, W, b, ops.ACT_RELU, out=out))
         print('%-10s M=%6d N=%5d K=%6d  %8.3f ms  %7.1f TFLOP/s' % (name, M, N, K, ms, 2.0 * M * N * K / ms / 1e9))
     B = 8
-    for name, H, Cin, Cout in [('conv1_2', 608, 64, 64), ('conv2_1', 304, 64, 128), ('conv2_2', 304, 128, 128),
-                               ('conv3_1', 152, 128, 256), ('conv3_2', 152, 256, 256), ('conv4_1', 76, 256, 512),
-                               ('conv4_2', 76, 512, 512), ('conv5_1', 38, 512, 512)]:
+    for name, H, Cin, Cout in [('conv1_2', 592, 64, 64), ('conv2_1', 296, 64, 128), ('conv2_2', 296, 128, 128),
+                               ('conv3_1', 148, 128, 256), ('conv3_2', 148, 256, 256), ('conv4_1', 74, 256, 512),
+                               ('conv4_2', 74, 512, 512), ('conv5_1', 37, 512, 512)]:
         x = torch.randn(B, H + 2, H + 2, Cin, device=dev).to(dt)
         w = (torch.randn(Cout, 3, 3, Cin, device=dev) / (3 * Cin ** 0.5)).to(dt)
         b = torch.randn(Cout, device=dev)
