@@ -209,10 +209,10 @@ def main():
                 loss.backward()
                 trainer.opt.step()
             # rank 0 alone runs these extra steps: no collective may be issued (the other ranks wait at the barrier)
-            saved_hook, trainer.world = getattr(model, '_grad_ready_hook', None), 1
-            model._grad_ready_hook = None
+            saved_hook, saved_bn, trainer.world = getattr(model, '_grad_ready_hook', None), getattr(model, '_bn_sync', None), 1
+            model._grad_ready_hook = model._bn_sync = None
             kt = kernel_times(prof_step, reps=3)
-            model._grad_ready_hook, trainer.world = saved_hook, world
+            model._grad_ready_hook, model._bn_sync, trainer.world = saved_hook, saved_bn, world
         else:
             kt = kernel_times(infer_step, reps=5)
         E, N, H = 992 * B, 32 * B, 512

@@ -192,14 +192,19 @@ int sgg_colsum(const void* x, int M, int N, int ld, float* out, int dtype, void*
  * (scale, shift) and the running-stat update (momentum 0.01, unbiased var); bn_apply: y = x*scale+shift, optionally
  * followed by the max over 4 consecutive rows (MaxPool2d(3,2,1) on the 2x2 map, :55) with arg-max rows to `arg`;
  * bn_bwd: backward of ReLU -> BN [-> max4]: x = post-ReLU BN input, dy [rows(/4), C] -> dx [rows, C] (gradient at the
- * conv output), sums[2][C] = (dbeta, dgamma), zeroed by the callee. */
+ * conv output), sums[2][C] = (dbeta, dgamma), zeroed by the callee.
+ * Synchronised statistics across data-parallel ranks (BatchNorm row): the caller all-reduces `sums` plus a
+ * row count between the reduction and its use; count_dev (optional, device f32) then overrides `count` / `rows` as the
+ * divisor.  bn_bwd phase: 0 = reduce + apply in one call, 1 = reduce only (local sums out), 2 = apply only (sums in). */
 int sgg_bn_stats(const void* x, int M, int C, float* sums, int dtype, void* stream);
-int sgg_bn_finalize(const float* sums, int C, int count, const float* gamma, const float* beta, float eps, float momentum,
-                    float* run_mean, float* run_var, float* mean, float* invstd, float* scale, float* shift, void* stream);
+int sgg_bn_finalize(const float* sums, int C, int count, const float* count_dev, const float* gamma, const float* beta,
+                    float eps, float momentum, float* run_mean, float* run_var, float* mean, float* invstd, float* scale,
+                    float* shift, void* stream);
 int sgg_bn_apply(const void* x, const float* scale, const float* shift, void* out, unsigned char* arg, int rows_out, int C,
                  int max4, int dtype, void* stream);
 int sgg_bn_bwd(const void* dy, const unsigned char* arg, const void* x, const float* mean, const float* invstd,
-               const float* gamma, void* dx, float* sums, int rows, int C, int max4, int dtype, void* stream);
+               const float* gamma, void* dx, float* sums, int rows, int C, int max4, int phase, const float* count_dev,
+               int dtype, void* stream);
 /* nn.GRUCell backward, pointwise part: from dh[M,H] and the saved fp32 pre-activations gi/gh ([M,3H]; gh NULL = the
  * h=0 first call, b_hh given) -> d_gi, d_gh [M,3H] and dh_prev [M,H] (may be NULL). */
 int sgg_gru_gate_bwd(const void* dh, const float* gi, const float* gh, const float* b_hh, const void* h_prev, void* d_gi,

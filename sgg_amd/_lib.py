@@ -51,9 +51,9 @@ SIGNATURES = {
     'sgg_act_bwd': [_P, _P, _P, _L, _F, _I, _I, _P],
     'sgg_colsum': [_P, _I, _I, _I, _P, _I, _P],
     'sgg_bn_stats': [_P, _I, _I, _P, _I, _P],
-    'sgg_bn_finalize': [_P, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],
+    'sgg_bn_finalize': [_P, _I, _I, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],
     'sgg_bn_apply': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    'sgg_bn_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'sgg_bn_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P],
     'sgg_gru_gate_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     'sgg_imp_edge_ctx_bwd': [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     'sgg_imp_node_scatter_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P],

@@ -130,7 +130,9 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const T* __restrict__ dy, c
                                                      const T* __restrict__ x, const float* __restrict__ mean,
                                                      const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                      const float* __restrict__ sums /*[2][C]: sum dy, sum dy*xhat*/,
-                                                     T* __restrict__ dx, long rows, int C, float inv_count) {
+                                                     T* __restrict__ dx, long rows, int C, float inv_count,
+                                                     const float* __restrict__ count_dev) {
+    if (count_dev) inv_count = 1.0f / *count_dev;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;  // over rows * C/8
     const int c8 = C >> 3;
     if (i >= rows * c8) return;
@@ -429,6 +431,7 @@ __global__ __launch_bounds__(256) void rank4_reduce_kernel(const float* __restri
 // from (sum x, sum x^2): batch mean / biased var -> invstd, the affine (scale, shift) used by bn_apply, and the
 // running-statistics update of nn.BatchNorm2d (momentum m, unbiased variance) -- lib/get_union_boxes.py:54,58
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sums, int C, float count,
+                                                          const float* __restrict__ count_dev,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float momentum, float* __restrict__ run_mean,
                                                           float* __restrict__ run_var, float* __restrict__ mean,
@@ -436,6 +439,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* __restrict__ shift) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
+    if (count_dev) count = *count_dev;     // synchronised BN: the all-reduced row count lives next to the all-reduced sums
     const float mu = sums[c] / count;
     const float var = fmaxf(sums[C + c] / count - mu * mu, 0.f);
     const float is = rsqrtf(var + eps);
@@ -452,9 +456,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 template <typename T, bool MAX4>
 void bn_bwd_launch(const void* dy, const unsigned char* arg, const void* x, const float* mean, const float* invstd,
                    const float* gamma, void* dx, float* sums, int rows, int C, int rpb, dim3 g1, dim3 g2, float inv,
-                   hipStream_t s) {
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MAX4>), g1, dim3(256), 0, s, (const T*)dy, arg, (const T*)x, mean, invstd, sums, rows, C, rpb);
-    hipLaunchKernelGGL((bn_bwd_kernel<T, MAX4>), g2, dim3(256), 0, s, (const T*)dy, arg, (const T*)x, mean, invstd, gamma, sums, (T*)dx, (long)rows, C, inv);
+                   int phase, const float* count_dev, hipStream_t s) {
+    if (phase != 2)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MAX4>), g1, dim3(256), 0, s, (const T*)dy, arg, (const T*)x, mean, invstd, sums, rows, C, rpb);
+    if (phase != 1)
+        hipLaunchKernelGGL((bn_bwd_kernel<T, MAX4>), g2, dim3(256), 0, s, (const T*)dy, arg, (const T*)x, mean, invstd, gamma, sums, (T*)dx, (long)rows, C, inv, count_dev);
 }
 
 // ---- optimiser step (main.py:119-120: grad_clip then SGD with momentum, lib/pytorch_misc.py:144,625-656)
@@ -722,13 +728,13 @@ extern "C" int sgg_bn_stats(const void* x, int M, int C, float* sums, int dtype,
     return SGG_OK;
 }
 
-extern "C" int sgg_bn_finalize(const float* sums, int C, int count, const float* gamma, const float* beta, float eps,
-                               float momentum, float* run_mean, float* run_var, float* mean, float* invstd, float* scale,
-                               float* shift, void* stream) {
+extern "C" int sgg_bn_finalize(const float* sums, int C, int count, const float* count_dev, const float* gamma,
+                               const float* beta, float eps, float momentum, float* run_mean, float* run_var, float* mean,
+                               float* invstd, float* scale, float* shift, void* stream) {
     if (!sums || !gamma || !beta || !mean || !invstd || !scale || !shift || C <= 0 || count <= 0 || (run_mean && !run_var))
         return SGG_ERR_ARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C, (float)count, gamma,
-                       beta, eps, momentum, run_mean, run_var, mean, invstd, scale, shift);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C, (float)count, count_dev,
+                       gamma, beta, eps, momentum, run_mean, run_var, mean, invstd, scale, shift);
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -755,11 +761,13 @@ extern "C" int sgg_bn_apply(const void* x, const float* scale, const float* shif
 // backward of [ReLU ->] BatchNorm(batch stats) [-> max over 4 rows]: x[rows,C] = post-ReLU input of the BN,
 // dy[rows(/4),C]; outputs dx[rows,C] (gradient at the conv output, ReLU folded) and sums[2][C] = (dbeta, dgamma).
 extern "C" int sgg_bn_bwd(const void* dy, const unsigned char* arg, const void* x, const float* mean, const float* invstd,
-                          const float* gamma, void* dx, float* sums, int rows, int C, int max4, int dtype, void* stream) {
+                          const float* gamma, void* dx, float* sums, int rows, int C, int max4, int phase,
+                          const float* count_dev, int dtype, void* stream) {
     if (!dy || !x || !mean || !invstd || !gamma || !dx || !sums || rows <= 0 || C <= 0 || (C & 7) || (max4 && !arg))
         return SGG_ERR_ARG;
+    if (phase < 0 || phase > 2 || (count_dev && phase != 2)) return SGG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(sums, 0, sizeof(float) * 2 * (size_t)C, s) != hipSuccess) return SGG_ERR_LAUNCH;
+    if (phase != 2 && hipMemsetAsync(sums, 0, sizeof(float) * 2 * (size_t)C, s) != hipSuccess) return SGG_ERR_LAUNCH;
     int rpb;
     const int split = split_rows(rows, rpb);
     const dim3 g1((C + 63) / 64, split);
@@ -767,11 +775,11 @@ extern "C" int sgg_bn_bwd(const void* dy, const unsigned char* arg, const void* 
     const dim3 g2((unsigned)((total + 255) / 256));
     const float inv = 1.0f / (float)rows;
     if (dtype == SGG_BF16) {
-        if (max4) bn_bwd_launch<bf16_t, true>(dy, arg, x, mean, invstd, gamma, dx, sums, rows, C, rpb, g1, g2, inv, s);
-        else bn_bwd_launch<bf16_t, false>(dy, arg, x, mean, invstd, gamma, dx, sums, rows, C, rpb, g1, g2, inv, s);
+        if (max4) bn_bwd_launch<bf16_t, true>(dy, arg, x, mean, invstd, gamma, dx, sums, rows, C, rpb, g1, g2, inv, phase, count_dev, s);
+        else bn_bwd_launch<bf16_t, false>(dy, arg, x, mean, invstd, gamma, dx, sums, rows, C, rpb, g1, g2, inv, phase, count_dev, s);
     } else if (dtype == SGG_F32) {
-        if (max4) bn_bwd_launch<float, true>(dy, arg, x, mean, invstd, gamma, dx, sums, rows, C, rpb, g1, g2, inv, s);
-        else bn_bwd_launch<float, false>(dy, arg, x, mean, invstd, gamma, dx, sums, rows, C, rpb, g1, g2, inv, s);
+        if (max4) bn_bwd_launch<float, true>(dy, arg, x, mean, invstd, gamma, dx, sums, rows, C, rpb, g1, g2, inv, phase, count_dev, s);
+        else bn_bwd_launch<float, false>(dy, arg, x, mean, invstd, gamma, dx, sums, rows, C, rpb, g1, g2, inv, phase, count_dev, s);
     } else {
         return SGG_ERR_DTYPE;
     }

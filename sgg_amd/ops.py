@@ -304,15 +304,22 @@ def colsum(x):
     return out
 
 
-def bn_train(x, gamma, beta, run_mean, run_var, eps, momentum, max4):
+def bn_train(x, gamma, beta, run_mean, run_var, eps, momentum, max4, reduce_fn=None):
     """train-mode BatchNorm over the rows of x[M,C] (+ optional max over 4 consecutive rows).
+    reduce_fn (data-parallel, synchronised statistics): in-place SUM all-reduce of a small f32 tensor; the batch
+    statistics then cover the rows of every rank, as in a single-process step on the concatenated batch.
     -> (y, arg or None, mean, invstd)"""
     M, C = x.shape
     dev = x.device
-    sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
+    sums = torch.empty(2 * C + 1, dtype=torch.float32, device=dev)      # [sum x | sum x^2 | row count]
     _lib.call('sgg_bn_stats', _p(x), M, C, _p(sums), dt(x), _stream())
+    count_dev = None
+    if reduce_fn is not None:
+        sums[2 * C:].fill_(float(M))
+        reduce_fn(sums)
+        count_dev = sums.data_ptr() + 8 * C
     mean, invstd, sc, sh = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
-    _lib.call('sgg_bn_finalize', _p(sums), C, M, _p(gamma, torch.float32), _p(beta, torch.float32), float(eps),
+    _lib.call('sgg_bn_finalize', _p(sums), C, M, count_dev, _p(gamma, torch.float32), _p(beta, torch.float32), float(eps),
               float(momentum), _p(run_mean, torch.float32), _p(run_var, torch.float32), _p(mean), _p(invstd), _p(sc),
               _p(sh), _stream())
     rows_out = M // 4 if max4 else M
@@ -323,14 +330,24 @@ def bn_train(x, gamma, beta, run_mean, run_var, eps, momentum, max4):
     return y, arg, mean, invstd
 
 
-def bn_bwd(dy, arg, x, mean, invstd, gamma, max4):
-    """-> (dx [rows,C] at the conv output (ReLU folded), dbeta [C], dgamma [C])"""
+def bn_bwd(dy, arg, x, mean, invstd, gamma, max4, reduce_fn=None):
+    """-> (dx [rows,C] at the conv output (ReLU folded), dbeta [C], dgamma [C]).  With reduce_fn the two batch sums of
+    the backward are synchronised like the forward statistics; dbeta / dgamma stay LOCAL sums (the gradient all-reduce
+    adds them up later)."""
     rows, C = x.shape
     dx = torch.empty_like(x)
-    sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
-    _lib.call('sgg_bn_bwd', _p(dy), _p(arg) if max4 else None, _p(x), _p(mean), _p(invstd), _p(gamma, torch.float32),
-              _p(dx), _p(sums), rows, C, int(max4), dt(x), _stream())
-    return dx, sums[:C], sums[C:]
+    sums = torch.empty(2 * C + 1, dtype=torch.float32, device=x.device)
+    args = (_p(dy), _p(arg) if max4 else None, _p(x), _p(mean), _p(invstd), _p(gamma, torch.float32), _p(dx), _p(sums),
+            rows, C, int(max4))
+    if reduce_fn is None:
+        _lib.call('sgg_bn_bwd', *args, 0, None, dt(x), _stream())
+        return dx, sums[:C], sums[C:2 * C]
+    _lib.call('sgg_bn_bwd', *args, 1, None, dt(x), _stream())
+    local = sums[:2 * C].clone()
+    sums[2 * C:].fill_(float(rows))
+    reduce_fn(sums)
+    _lib.call('sgg_bn_bwd', *args, 2, sums.data_ptr() + 8 * C, dt(x), _stream())
+    return dx, local[:C], local[C:]
 
 
 def gru_gate_bwd(dh, gi, gh, b_hh, h_prev, d_gi, d_gh, want_dh_prev=True):

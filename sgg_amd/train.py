@@ -109,11 +109,12 @@ class PredictFn(torch.autograd.Function):
         patches = ops.union_rect_patches(rois, pairs, dt, ub.pooling_size * 4 - 1, 128)           # [4E,128]
         h1 = ops.gemm(patches, t['rc_w1'], t['rc_b1'], ops.ACT_RELU)                               # [4E,d2]
         bn1, bn2 = ub.conv[2], ub.conv[6]
+        bn_sync = getattr(model, '_bn_sync', None)      # DP trainer: batch statistics over the rows of every rank
         h2, arg, m1, is1 = ops.bn_train(h1, t['rc_g1'], t['rc_be1'], bn1.running_mean, bn1.running_var, bn1.eps,
-                                        bn1.momentum, True)                                        # [E,d2]
+                                        bn1.momentum, True, bn_sync)                               # [E,d2]
         h3 = ops.gemm(h2, t['rc_w2'], t['rc_b2'], ops.ACT_RELU)                                    # [E,d]
         rect, _, m2, is2 = ops.bn_train(h3, t['rc_g2'], t['rc_be2'], bn2.running_mean, bn2.running_var, bn2.eps,
-                                        bn2.momentum, False)
+                                        bn2.momentum, False, bn_sync)
         with torch.no_grad():
             bn1.num_batches_tracked += 1
             bn2.num_batches_tracked += 1
@@ -304,7 +305,8 @@ class PredictFn(torch.autograd.Function):
         _lib.set_tag('bwd_rect')
         d_rect = ops.gemm(d_pre6, t['w6sum_t'])                                    # [E,C]
         # rect conv backward (BatchNorm with batch statistics)
-        d_c2, db2, dg2 = ops.bn_bwd(d_rect, None, sv['h3'], sv['m2'], sv['is2'], t['rc_g2'], False)
+        bn_sync = getattr(model, '_bn_sync', None)
+        d_c2, db2, dg2 = ops.bn_bwd(d_rect, None, sv['h3'], sv['m2'], sv['is2'], t['rc_g2'], False, bn_sync)
         G['union_boxes.conv.6.weight'], G['union_boxes.conv.6.bias'] = dg2.clone(), db2.clone()
         gw2, gb2 = tn_gemm(d_c2, sv['h2'], want_colsum=True)                       # [d, d2] centre tap
         full = torch.zeros(tuple(model.union_boxes.conv[4].weight.shape), dtype=torch.float32, device=dev)
@@ -312,7 +314,7 @@ class PredictFn(torch.autograd.Function):
         G['union_boxes.conv.4.weight'] = full
         G['union_boxes.conv.4.bias'] = gb2
         d_h2 = ops.gemm(d_c2, t['rc_w2_t'])                                        # [E,d2]
-        d_c1, db1, dg1 = ops.bn_bwd(d_h2, sv['arg'], sv['h1'], sv['m1'], sv['is1'], t['rc_g1'], True)
+        d_c1, db1, dg1 = ops.bn_bwd(d_h2, sv['arg'], sv['h1'], sv['m1'], sv['is1'], t['rc_g1'], True, bn_sync)
         G['union_boxes.conv.2.weight'], G['union_boxes.conv.2.bias'] = dg1.clone(), db1.clone()
         gw1, gb1 = tn_gemm(d_c1, sv['patches'], want_colsum=True)                  # [d2,128]
         G['union_boxes.conv.0.weight'] = gw1[:, :98].reshape(tuple(model.union_boxes.conv[0].weight.shape)).contiguous()

@@ -89,7 +89,7 @@ class Trainer(object):
     """One data-parallel train step.  `loss_type` as lib/losses.py ('baseline' is the reference default, config.py:184)."""
 
     def __init__(self, model, lr=1e-3, momentum=0.9, weight_decay=1e-4, clip=5.0, loss_type='baseline',
-                 comm_dtype=torch.bfloat16, force_dist=False):
+                 comm_dtype=torch.bfloat16, force_dist=False, sync_bn=True):
         self.model = model
         for n, p in model.named_parameters():
             if n.startswith('detector.'):
@@ -117,6 +117,9 @@ class Trainer(object):
             # bf16 on the wire: the weight-gradient GEMMs of the hooked tensors emit bf16 directly (fp32 accumulate,
             # one rounding -- the same numbers as casting an fp32 gradient, without writing and re-reading it)
             model._grad_wire_dtype = comm_dtype if comm_dtype == torch.bfloat16 else None
+            # union_boxes.conv BatchNorm: statistics over the edges of the GLOBAL batch, i.e. the numbers a
+            # single process would compute on the concatenated batch; sync_bn=False = replica-local statistics.
+            model._bn_sync = (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)) if sync_bn else None
 
     def _bump(self):
         self.model.weights_version = getattr(self.model, 'weights_version', 0) + 1

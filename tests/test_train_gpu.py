@@ -221,3 +221,42 @@ def test_trainer_distributed_path_on_one_rank_matches_local(env):
         model._grad_wire_dtype = None
         model.dropout_p = 0.5
         model.eval()
+
+
+def test_synchronised_batchnorm_matches_concatenated_batch(env):
+    """SURVEY 8(e) BatchNorm row: with the statistics all-reduced over ranks, each rank must produce what a single process
+    computes on the concatenated batch.  Two 'ranks' holding the two halves of x are simulated by a reduce_fn that adds
+    the other half's partial sums."""
+    from sgg_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for max4, rows, C in ((True, 512, 64), (False, 384, 128)):
+        x = torch.randn(rows, C, generator=g).relu().to(DEV).to(torch.bfloat16)
+        gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+        dy = torch.randn(rows // 4 if max4 else rows, C, generator=g).to(DEV).to(torch.bfloat16)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        y_all, arg_all, m_all, is_all = ops.bn_train(x, gamma, beta, rm.clone(), rv.clone(), 1e-5, 0.1, max4)
+        dx_all, db_all, dg_all = ops.bn_bwd(dy, arg_all, x, m_all, is_all, gamma, max4)
+        h = rows // 2
+        halves = [(x[:h].contiguous(), dy[:dy.shape[0] // 2].contiguous()), (x[h:].contiguous(), dy[dy.shape[0] // 2:].contiguous())]
+        # pass 1: every rank's partial sums (what the all-reduce would add)
+        fwd_part, bwd_part = [], []
+        for xr, dyr in halves:
+            ops.bn_train(xr, gamma, beta, rm.clone(), rv.clone(), 1e-5, 0.1, max4, reduce_fn=lambda t: fwd_part.append(t.clone()))
+        fwd_tot = fwd_part[0] + fwd_part[1]
+        outs = []
+        for (xr, dyr) in halves:
+            run_m, run_v = rm.clone(), rv.clone()
+            y, arg, m, istd = ops.bn_train(xr, gamma, beta, run_m, run_v, 1e-5, 0.1, max4, reduce_fn=lambda t: t.copy_(fwd_tot))
+            torch.testing.assert_close(m, m_all, atol=1e-5, rtol=1e-5)
+            torch.testing.assert_close(istd, is_all, atol=1e-4, rtol=1e-4)
+            ops.bn_bwd(dyr, arg, xr, m, istd, gamma, max4, reduce_fn=lambda t: bwd_part.append(t.clone()))
+            outs.append((y, arg, m, istd, run_m, run_v))
+        bwd_tot = bwd_part[0] + bwd_part[1]
+        ys, dxs, dbs, dgs = [], [], [], []
+        for (xr, dyr), (y, arg, m, istd, run_m, run_v) in zip(halves, outs):
+            dx, db, dg = ops.bn_bwd(dyr, arg, xr, m, istd, gamma, max4, reduce_fn=lambda t: t.copy_(bwd_tot))
+            ys.append(y); dxs.append(dx); dbs.append(db); dgs.append(dg)
+        torch.testing.assert_close(torch.cat(ys).float(), y_all.float(), atol=2e-2, rtol=2e-2)
+        torch.testing.assert_close(torch.cat(dxs).float(), dx_all.float(), atol=2e-2, rtol=2e-2)
+        torch.testing.assert_close(dbs[0] + dbs[1], db_all, atol=1e-2, rtol=1e-3)       # the gradient all-reduce adds the local sums
+        torch.testing.assert_close(dgs[0] + dgs[1], dg_all, atol=1e-2, rtol=1e-3)
