@@ -255,6 +255,19 @@ int sgg_group_sum(const float* in, int64_t ld_in, void* out, int64_t ld_out, int
                   void* stream);
 /* y += x (n multiple of 8) */
 int sgg_add(void* y, const void* x, int64_t n, int y_dtype, int x_dtype, void* stream);
+/* ---- f-1: scene-graph recall matching (lib/sgg_eval.py:280-417 -- evaluate_recall, _triplet, _compute_pred_matches), batched over
+ * images.  gt_trip i32[G,3] / pred_trip i32[P,3] = (class_subj, predicate, class_obj); gt_box / pred_box f32[.,8] = (subject box,
+ * object box) xyxy; gt_img i32[G] = image of each GT triplet; pred_ptr i32[B+1] = CSR offsets of each image's predictions, which
+ * are in rank order (descending triple score).  A prediction matches a GT triplet when the three classes are equal and both
+ * boxes have IoU >= iou_thresh (phrdet: the union boxes, :393-401).  first_rank[g] = rank inside its image of the first
+ * matching prediction, INT32_MAX if none -- R@K = #{g : first_rank[g] < K} / G (the reference's |union(pred_to_gt[:K])| / G).
+ * Optional per-triplet ranks (:236-272): gt_pair i32[G,2] / pred_pair i32[P,2] = box indices; pair_rank[g] = rank of the first
+ * match among the predictions on the same box pair in either direction, -1 if none. */
+int sgg_recall_first_match(const int32_t* gt_trip, const float* gt_box, const int32_t* gt_img, int G, const int32_t* pred_trip,
+                           const float* pred_box, const int32_t* pred_ptr, int B, const int32_t* gt_pair,
+                           const int32_t* pred_pair, float iou_thresh, int phrdet, int32_t* first_rank, int32_t* pair_rank,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@ reference's source text is stored -- only data.  What is called, per file:
   pairs.npz        sgg_models/rel_model_base.py:143 get_rel_inds ; lib/proposal_assignments_gtbox.py:7
   eval_tail.npz    lib/surgery.py:17 filter_dets + the softmax/sort lines rel_model_stanford.py:187-204
   losses.npz       lib/losses.py:5,73
+  recall.npz       lib/sgg_eval.py:14 BasicSceneGraphEvaluator (GC / no-GC / per-triplet, all modes), :420 mean recall, :481 eval_entry
 """
 import os
 import sys
@@ -290,6 +291,107 @@ def gold_losses():
     save('losses', **arrs)
 
 
+# ---------------------------------------------------------------- recall evaluator
+def recall_cases(n_cases=6, seed=61, n_cls=12, n_pred=9):
+    """Synthetic gt / pred entries in the format of lib/eval.py:150-164.  Small class spaces so that matches happen."""
+    rng = np.random.RandomState(seed)
+    cases = []
+    for ci in range(n_cases):
+        nb = int(rng.randint(6, 15))
+        gt_boxes = rand_boxes(rng, nb)
+        gt_classes = rng.randint(1, n_cls, size=nb).astype(np.int64)
+        G = int(rng.randint(3, 11))
+        pairs = np.array([(i, j) for i in range(nb) for j in range(nb) if i != j], dtype=np.int64)
+        gi = rng.choice(len(pairs), size=G, replace=(ci == 0))       # case 0: duplicate pairs allowed
+        gt_rels = np.column_stack((pairs[gi], rng.randint(1, n_pred, size=G))).astype(np.int64)
+        pred_classes = gt_classes.copy()
+        flip = rng.rand(nb) < 0.3
+        pred_classes[flip] = rng.randint(1, n_cls, size=int(flip.sum()))
+        obj_scores = rng.uniform(0.1, 1.0, size=nb).astype(np.float32)
+        logits = rng.randn(len(pairs), n_pred).astype(np.float32) * 2
+        logits[gi[: G // 2], gt_rels[: G // 2, 2]] += 4                  # some GT predicates rank high
+        rel_scores = np.exp(logits) / np.exp(logits).sum(1, keepdims=True)
+        order = rng.permutation(len(pairs))
+        jitter = rng.uniform(-1, 1, size=(nb, 4)).astype(np.float32) * rng.choice([2.0, 8.0, 40.0], size=(nb, 1)).astype(np.float32)
+        pred_boxes = gt_boxes + jitter
+        pred_boxes[:, 2:] = np.maximum(pred_boxes[:, 2:], pred_boxes[:, :2] + 4)
+        cases.append(dict(gt_boxes=gt_boxes, gt_classes=gt_classes, gt_relations=gt_rels, pred_boxes=pred_boxes.astype(np.float32),
+                          pred_classes=pred_classes, obj_scores=obj_scores, pred_rel_inds=pairs[order],
+                          rel_scores=rel_scores[order].astype(np.float32)))
+    return cases
+
+
+def gold_recall():
+    import contextlib
+    import io
+    np.int = int                                                  # lib/sgg_eval.py:238 uses the removed alias
+    from lib.sgg_eval import BasicSceneGraphEvaluator, calculate_mR_from_evaluator_list, eval_entry
+    cases = recall_cases()
+    arrs = {'n_cases': len(cases)}
+    for i, c in enumerate(cases):
+        for k, v in c.items():
+            arrs['c%d_%s' % (i, k)] = v
+    split = lambda c: ({k: c[k] for k in ('gt_boxes', 'gt_classes', 'gt_relations')},
+                       {k: c[k].copy() for k in ('pred_boxes', 'pred_classes', 'obj_scores', 'pred_rel_inds', 'rel_scores')})
+    quiet = contextlib.redirect_stdout(io.StringIO())
+    for mode in ('predcls', 'sgcls', 'sgdet', 'phrdet', 'objcls', 'preddet'):
+        for mp in (False, True):
+            ev = BasicSceneGraphEvaluator(mode, multiple_preds=mp)
+            firsts = []
+            for c in cases:
+                gt, pr = split(c)
+                pred_to_gt, _, _ = ev.evaluate_scene_graph_entry(gt, pr)
+                if pred_to_gt is not None:
+                    first = np.full(len(c['gt_relations']), 2 ** 31 - 1, np.int64)
+                    for p, lst in enumerate(pred_to_gt):
+                        for g_ in lst:
+                            first[g_] = min(first[g_], p)
+                    firsts.append(first)
+                    arrs.setdefault('nmatch_%s_%d' % (mode, mp), []).append(sum(len(x) for x in pred_to_gt))
+            tag = '%s_%d' % (mode, int(mp))
+            for k, v in ev.result_dict[mode + '_recall'].items():
+                arrs['recall_%s_%d' % (tag, k)] = np.array(v, dtype=np.float64)
+            if firsts:
+                arrs['first_%s' % tag] = np.concatenate(firsts)
+    # per-triplet statistics (needs the graph-unconstrained ranking)
+    rng = np.random.RandomState(62)
+    counts = {}
+    for c in cases:
+        for (o, s_, R) in c['gt_relations']:
+            if rng.rand() < 0.7:
+                counts['{}_{}_{}'.format(c['gt_classes'][o], R, c['gt_classes'][s_])] = int(rng.randint(0, 200))
+    arrs['tc_keys'] = np.array(sorted(counts), dtype='U32')
+    arrs['tc_vals'] = np.array([counts[k] for k in sorted(counts)], dtype=np.int64)
+    ev = BasicSceneGraphEvaluator('sgcls', multiple_preds=True, per_triplet=True, triplet_counts=counts)
+    for c in cases:
+        ev.evaluate_scene_graph_entry(*split(c))
+    with quiet:
+        ev.print_stats()
+    rd = ev.result_dict
+    arrs['pt_rank'] = np.array(rd['sgcls_rank'], dtype=np.float64)
+    arrs['pt_counts'] = np.array(rd['sgcls_counts'], dtype=np.float64)
+    for k, v in rd['sgcls_recall_norm'].items():
+        arrs['pt_recall_norm_%d' % k] = np.array(v, dtype=np.float64)
+    for sfx in ('', '_norm'):
+        arrs['pt_recall_triplet' + sfx] = np.array([rd['sgcls_recall_triplet' + sfx][k] for k in (5, 10, 15, 20, 50)], dtype=np.float64)
+    arrs['pt_scalars'] = np.array([rd['sgcls_meanrank_triplet'], rd['sgcls_meanrank_triplet_norm'], rd['sgcls_medianrank_triplet'],
+                                   rd['sgcls_medianrankclass_triplet'], rd['sgcls_medianrank_triplet_norm']], dtype=np.float64)
+    # mean recall over predicates (lib/eval.py:46-53,76-80)
+    for mp in (False, True):
+        lst = [(pid, 'p%d' % pid, BasicSceneGraphEvaluator.all_modes(multiple_preds=mp)) for pid in range(1, 9)]
+        other = [(pid, 'p%d' % pid, BasicSceneGraphEvaluator.all_modes(multiple_preds=not mp)) for pid in range(1, 9)]
+        for c in cases:
+            gt, pr = split(c)
+            eval_entry('sgcls', gt, pr, lst if not mp else other, other if not mp else lst)
+        with quiet:
+            mr = calculate_mR_from_evaluator_list(lst, 'sgcls', multiple_preds=mp)
+        arrs['mR_%d' % int(mp)] = np.array([mr['R@%d' % k] for k in (20, 50, 100, 200, 300)], dtype=np.float64)
+    for k in list(arrs):
+        if k.startswith('nmatch_'):
+            arrs[k] = np.array(arrs[k], dtype=np.int64)
+    save('recall', **arrs)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)
     gold_raster()
@@ -300,3 +402,4 @@ if __name__ == '__main__':
     gold_pairs()
     gold_eval_tail()
     gold_losses()
+    gold_recall()

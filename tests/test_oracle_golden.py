@@ -144,3 +144,30 @@ def test_transform_identity_at_592_and_pad():
 
 def test_vgg_names():
     assert O.vgg16_layer_names() == [0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28]
+
+
+def _recall_cases(d):
+    n = int(d['n_cases'])
+    return [{k[len('c%d_' % i):]: d[k] for k in d if k.startswith('c%d_' % i)} for i in range(n)]
+
+
+@pytest.mark.parametrize('mode', ['predcls', 'sgcls', 'sgdet', 'phrdet', 'objcls'])
+@pytest.mark.parametrize('mp', [0, 1])
+def test_recall_oracle_matches_reference_evaluator(golden, mode, mp):
+    """lib/sgg_eval.py run in the build container (tests/golden/make_golden.py: gold_recall) vs the oracle's restatement."""
+    d = golden('recall')
+    firsts, nmatch, recs = [], [], {k: [] for k in (20, 50, 100, 200, 300)}
+    for c in _recall_cases(d):
+        rec, first, m = O.recall_entry(c, c, mode, bool(mp))
+        firsts.append(first)
+        nmatch.append(m)
+        for k in recs:
+            recs[k].append(rec[k])
+    for k in recs:
+        np.testing.assert_allclose(recs[k], d['recall_%s_%d_%d' % (mode, mp, k)], rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(nmatch, d['nmatch_%s_%d' % (mode, mp)])
+    got, exp = np.concatenate(firsts), d['first_%s_%d' % (mode, mp)]
+    if (mode, mp) == ('objcls', 1):     # one-hot predicate scores: pairs (a,b) / (b,a) tie exactly, numpy's argsort order is unspecified
+        np.testing.assert_array_equal(got == 2 ** 31 - 1, exp == 2 ** 31 - 1)
+    else:
+        np.testing.assert_array_equal(got, exp)
