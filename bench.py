@@ -250,6 +250,42 @@ def main():
         if other is not None and world == 1:
             el2 = timed(other, 2, 10)
             other_line = {'mode': 'infer', 'value': round(B * 10 / el2, 2), 'unit': 'images/s', 'ms_per_step': round(1e3 * el2 / 10, 3)}
+        # PCIe-inclusive rates (never `value`): the reference's boundary hands over HOST images (list of f32 [3,S,S],
+        # rel_model_base.py:180); (a) exactly that, per-image pageable copies inside the forward; (b) decoded u8 images
+        # through sgg_amd.blob.DeviceStager (pinned, one async copy per batch, prefetched one step ahead)
+        pcie = None
+        if world == 1 and not args.force_dist:
+            from sgg_amd.blob import DeviceStager
+            run = (lambda b: trainer.step(b)) if args.mode == 'train' else (lambda b: model([b]))
+            ctx = torch.enable_grad() if args.mode == 'train' else torch.no_grad()
+            n = 10
+            host = list(batch)
+            host[0] = [im.cpu() for im in batch[0]]
+            host[3], host[4], host[5] = batch[3].cpu(), batch[4].cpu(), batch[5].cpu()
+            u8 = list(host)
+            u8[0] = [(im * 255).round().to(torch.uint8).permute(1, 2, 0).contiguous() for im in host[0]]
+            stager = DeviceStager()
+            with ctx:
+                if args.mode != 'train':
+                    model.eval()
+                for _ in range(2):
+                    run(tuple(host))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    run(tuple(host))
+                torch.cuda.synchronize()
+                t_f32 = time.perf_counter() - t0
+                for b_ in stager.prefetch([tuple(u8)] * 2):
+                    run(b_)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for b_ in stager.prefetch([tuple(u8)] * n):
+                    run(b_)
+                torch.cuda.synchronize()
+                t_u8 = time.perf_counter() - t0
+            pcie = {'host_f32_per_image_copies': round(B * n / t_f32, 2), 'host_u8_pinned_prefetch': round(B * n / t_u8, 2),
+                    'unit': 'images/s', 'note': 'inputs start in host memory; not the headline value'}
         line = {
             'metric': 'images/sec (whole node), VG SGCls IMP %s step' % ('train' if args.mode == 'train' else 'inference'),
             'value': round(world * B * args.steps / elapsed, 3),
@@ -286,6 +322,8 @@ def main():
         }
         if other_line:
             line['other_mode'] = other_line
+        if pcie:
+            line['pcie_inclusive'] = pcie
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.cpu_images, 111)
     else:

@@ -42,6 +42,11 @@ const char* sgg_build_info(void);
  * region rh..Hp / rw..Wp must be zero: the caller memsets the buffer once). */
 int sgg_image_prep(const float* img_chw, int h, int w, int rh, int rw, float* out_nhwc4, int b, int Hp, int Wp,
                    void* stream);
+/* f-2: the same from the decoded image itself, u8 [h0,w0,3] (RGB, HWC): SquarePad to S = max(h0,w0) with the fill
+ * colour int(mean*256) (dataloaders/image_transforms.py:8-13) and ToTensor's /255 (dataloaders/visual_genome.py:264-266)
+ * are fused in, so the host hands over 1 byte per sample instead of 4.  (rh,rw) = resized size of the S x S image. */
+int sgg_image_prep_u8(const uint8_t* img_hwc, int h0, int w0, int rh, int rw, float* out_nhwc4, int b, int Hp, int Wp,
+                      void* stream);
 
 /* ---- a-2  VGG-16 features: [3P] vgg16.features minus the last pool, rel_model_base.py:92-93,184,310-312 ----
  * Activations live in zero-bordered NHWC buffers [B, H+2*pad, W+2*pad, C]. */

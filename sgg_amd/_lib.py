@@ -21,6 +21,7 @@ SIGNATURES = {
     'sgg_abi_version': [],
     'sgg_build_info': [],
     'sgg_image_prep': [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
+    'sgg_image_prep_u8': [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     'sgg_conv1_1': [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sgg_conv3x3_relu': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'sgg_maxpool2x2': [_P, _P, _I, _I, _I, _I, _I, _I, _P],

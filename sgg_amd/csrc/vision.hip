@@ -8,7 +8,26 @@ namespace {
 // a-1  [3P] GeneralizedRCNNTransform (called at sgg_models/rel_model_base.py:183): normalise, bilinear
 // resize (align_corners=False, scale recomputed from sizes), into the interior of a zero NHWC4 plane.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void image_prep_kernel(const float* __restrict__ img, int h, int w, int rh, int rw,
+// Pixel sources: a planar fp32 CHW tensor in [0,1] (what the reference's ToTensor hands over), or the decoded
+// u8 HWC image itself -- then SquarePad (dataloaders/image_transforms.py:8-13: pad right/bottom to a square with
+// the fill colour int(mean*256)) and ToTensor (u8 / 255) happen here, and the PCIe copy is 4x smaller.
+struct SrcF32 {
+    const float* img;
+    int h, w;
+    __device__ __forceinline__ float at(int c, int y, int x) const { return img[((long)c * h + y) * w + x]; }
+};
+struct SrcU8 {
+    const unsigned char* img;   // [h0, w0, 3]
+    int h0, w0;
+    __device__ __forceinline__ float at(int c, int y, int x) const {
+        const int fill[3] = {124, 116, 103};   // int(0.485*256), int(0.456*256), int(0.406*256)
+        const int u = (y < h0 && x < w0) ? (int)img[((long)y * w0 + x) * 3 + c] : fill[c];
+        return __fdiv_rn((float)u, 255.0f);
+    }
+};
+
+template <typename Src>
+__global__ __launch_bounds__(256) void image_prep_kernel(const Src src, int h, int w, int rh, int rw,
                                                          float* __restrict__ out, int b, int Hp, int Wp) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= rw || y >= rh) return;
@@ -16,7 +35,7 @@ __global__ __launch_bounds__(256) void image_prep_kernel(const float* __restrict
     float v[3];
     if (rh == h && rw == w) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) v[c] = (img[((long)c * h + y) * w + x] - mean[c]) / stdv[c];
+        for (int c = 0; c < 3; ++c) v[c] = (src.at(c, y, x) - mean[c]) / stdv[c];
     } else {
         const float sy = (float)h / (float)rh, sx = (float)w / (float)rw;
         float fy = sy * ((float)y + 0.5f) - 0.5f, fx = sx * ((float)x + 0.5f) - 0.5f;
@@ -27,9 +46,8 @@ __global__ __launch_bounds__(256) void image_prep_kernel(const float* __restrict
         const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float* p = img + (long)c * h * w;
-            const float a = (p[(long)y0 * w + x0] - mean[c]) / stdv[c], bq = (p[(long)y0 * w + x1] - mean[c]) / stdv[c];
-            const float cq = (p[(long)y1 * w + x0] - mean[c]) / stdv[c], d = (p[(long)y1 * w + x1] - mean[c]) / stdv[c];
+            const float a = (src.at(c, y0, x0) - mean[c]) / stdv[c], bq = (src.at(c, y0, x1) - mean[c]) / stdv[c];
+            const float cq = (src.at(c, y1, x0) - mean[c]) / stdv[c], d = (src.at(c, y1, x1) - mean[c]) / stdv[c];
             v[c] = hy * (hx * a + lx * bq) + ly * (hx * cq + lx * d);
         }
     }
@@ -363,7 +381,17 @@ extern "C" int sgg_image_prep(const float* img, int h, int w, int rh, int rw, fl
                               void* stream) {
     if (!img || !out || h <= 0 || w <= 0 || rh <= 0 || rw <= 0 || rh > Hp || rw > Wp || b < 0) return SGG_ERR_ARG;
     dim3 grid((rw + 255) / 256, rh);
-    hipLaunchKernelGGL(image_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, h, w, rh, rw, out, b, Hp, Wp);
+    hipLaunchKernelGGL(image_prep_kernel<SrcF32>, grid, dim3(256), 0, (hipStream_t)stream, SrcF32{img, h, w}, h, w, rh, rw, out, b, Hp, Wp);
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_image_prep_u8(const uint8_t* img_hwc, int h0, int w0, int rh, int rw, float* out, int b, int Hp, int Wp,
+                                 void* stream) {
+    if (!img_hwc || !out || h0 <= 0 || w0 <= 0 || rh <= 0 || rw <= 0 || rh > Hp || rw > Wp || b < 0) return SGG_ERR_ARG;
+    const int S = h0 > w0 ? h0 : w0;     // SquarePad: the transform sees an S x S image
+    dim3 grid((rw + 255) / 256, rh);
+    hipLaunchKernelGGL(image_prep_kernel<SrcU8>, grid, dim3(256), 0, (hipStream_t)stream, SrcU8{img_hwc, h0, w0}, S, S, rh, rw, out, b, Hp, Wp);
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

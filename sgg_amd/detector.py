@@ -84,6 +84,18 @@ class Transform(object):
         return int(math.floor(h * scale)), int(math.floor(w * scale))
 
 
+def is_u8_image(im):
+    return im.dtype == torch.uint8 and im.dim() == 3 and im.shape[-1] == 3
+
+
+def image_hw(im):
+    """(h, w) the transform sees: the tensor's own size, or the SquarePad-ed size of a decoded u8 HWC image."""
+    if is_u8_image(im):
+        s = int(max(im.shape[0], im.shape[1]))
+        return s, s
+    return int(im.shape[-2]), int(im.shape[-1])
+
+
 class VGGDetector(nn.Module):
     """Holds the detector parameters and runs transform + backbone (SURVEY a-1, a-2) through the C ABI."""
 
@@ -122,10 +134,11 @@ class VGGDetector(nn.Module):
         return b
 
     def features(self, images, dtype):
-        """images: list of f32[3,h,w] tensors (host or device).  Returns (fmap NHWC [B,Hf,Wf,512] in `dtype`,
-        image_sizes [(h,w)] after resize, (Hp,Wp) padded size)."""
+        """images: list of f32[3,h,w] tensors in [0,1] (host or device) -- what the reference's SquarePad + ToTensor
+        produce -- or of u8[h0,w0,3] decoded images, for which those two steps run inside the prep kernel.
+        Returns (fmap NHWC [B,Hf,Wf,512] in `dtype`, image_sizes [(h,w)] after resize, (Hp,Wp) padded size)."""
         dev = self.backbone[0].weight.device
-        sizes = [self.transform.resized_hw(int(im.shape[-2]), int(im.shape[-1])) for im in images]
+        sizes = [self.transform.resized_hw(*image_hw(im)) for im in images]
         d = self.transform.size_divisible
         Hp = int(math.ceil(max(s[0] for s in sizes) / d) * d)
         Wp = int(math.ceil(max(s[1] for s in sizes) / d) * d)
@@ -136,6 +149,11 @@ class VGGDetector(nn.Module):
         if not uniform:
             x0.zero_()  # ragged batch: the pad region of a previous, larger image must be cleared
         for b, im in enumerate(images):
+            if is_u8_image(im):
+                if not im.is_cuda:
+                    im = im.to(device=dev, non_blocking=True)
+                ops.image_prep_u8(im.contiguous(), sizes[b][0], sizes[b][1], x0, b)
+                continue
             im = im.squeeze()
             if im.dtype != torch.float32 or not im.is_cuda:
                 im = im.to(device=dev, dtype=torch.float32, non_blocking=True)

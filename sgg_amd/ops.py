@@ -42,6 +42,16 @@ def pow2ceil(x):
 
 
 # ---------------------------------------------------------------- a-1 / a-2
+def image_prep_u8(img_hwc, rh, rw, out_nhwc4, b):
+    """img u8[h0,w0,3] (device, as decoded) -> slot b: SquarePad + ToTensor + normalise + resize in one kernel."""
+    h0, w0, c = img_hwc.shape
+    if c != 3 or img_hwc.dtype != torch.uint8:
+        raise TypeError('image_prep_u8: expected a uint8 [h, w, 3] image')
+    Hp, Wp = out_nhwc4.shape[1] - 2, out_nhwc4.shape[2] - 2
+    _lib.call('sgg_image_prep_u8', _p(img_hwc, torch.uint8), h0, w0, rh, rw, _p(out_nhwc4, torch.float32), b, Hp, Wp,
+              _stream())
+
+
 def image_prep(img_chw, rh, rw, out_nhwc4, b):
     """img f32[3,h,w] (device) -> out f32[B,Hp+2,Wp+2,4] slot b (interior), normalised + resized."""
     _, h, w = img_chw.shape

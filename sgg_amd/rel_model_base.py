@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .detector import VGGDetector, make_vgg_classifier
+from .detector import VGGDetector, image_hw, make_vgg_classifier
 from .result import Result
 from .union_boxes import UnionBoxesAndFeats
 
@@ -153,7 +153,7 @@ class RelModelBase(nn.Module):
         # boxes scaled by the resize ratio, per image ([3P] resize_boxes)
         ratios = []
         for (i, s, e), (nh, nw) in zip(segs, sizes):
-            h, w = int(x[i].shape[-2]), int(x[i].shape[-1])
+            h, w = image_hw(x[i])
             ratios.append((s, e, float(nw) / float(w), float(nh) / float(h)))
         gt_boxes = gt_boxes.float()
         if all(r[2] == 1.0 and r[3] == 1.0 for r in ratios):
@@ -168,7 +168,7 @@ class RelModelBase(nn.Module):
         result = Result(od_obj_labels=obj_labels, rm_box_priors=priors, rm_obj_labels=obj_labels,
                         rel_labels=rel_labels, im_inds=im_inds)
         result.rm_box_priors_org = gt_boxes
-        result.im_sizes_org = [tuple(x[i].shape[-2:]) for i, _, _ in segs]
+        result.im_sizes_org = [image_hw(x[i]) for i, _, _ in segs]
         result.im_sizes = sizes
         result.fmap = as_nchw_view(fmap)
         result.rois = torch.cat((im_inds.float()[:, None], priors), 1)
@@ -188,7 +188,7 @@ class RelModelBase(nn.Module):
         images = [x[i] for i in ids]
         fmap, sizes, padded = self.detector.features(images, dtype)
         self.fmap_hw = (fmap.shape[1], fmap.shape[2])
-        orig = [tuple(int(v) for v in im.shape[-2:]) for im in images]
+        orig = [image_hw(im) for im in images]
         dets = sgdet.detect(self, fmap, sizes, padded, orig, self.spatial_scale(sizes))
         priors, priors_org, labels, im_inds = [], [], [], []
         for i, (bx, bx_org, lab, _) in enumerate(dets):

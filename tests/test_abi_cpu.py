@@ -88,3 +88,33 @@ def test_model_surface_matches_reference():
         sgg_amd.RelModelStanford(SyntheticData(), backbone='vgg16_old')
     r = sgg_amd.Result(rm_obj_dists=torch.zeros(1), rel_labels=None)
     assert hasattr(r, 'rm_obj_dists') and not hasattr(r, 'rel_labels')     # lib/pytorch_misc.py:696-700
+
+
+def test_blob_tuple_layout_matches_reference_contract():
+    """dataloaders/blob.py:77-126,145-166,214-261 for the one-device case (the 8/9-tuple the model's forward unpacks)."""
+    import numpy as np
+    import torch
+    from sgg_amd.blob import Blob, vg_collate
+    rng = np.random.RandomState(0)
+    data = []
+    for i, nb in enumerate((3, 5)):
+        data.append({'img': rng.randint(0, 255, size=(40 + i, 50, 3)).astype(np.uint8), 'img_size': (592, 592, 1.0),
+                     'gt_boxes': rng.rand(nb, 4) * 100, 'gt_classes': rng.randint(1, 151, nb), 'scale': 0.5,
+                     'gt_relations': np.array([[0, 1, 7], [2, 0, 3]]), 'fn': '/some/dir/%d.jpg' % i})
+    blob = vg_collate(data, num_gpus=1, is_train=True, mode='rel')
+    t = blob[0]
+    assert len(t) == 9 and len(blob) == 1 and t[2] == 0 and t[7] is None and t[8] == ['0.jpg', '1.jpg']
+    assert t[1].shape == (2, 3) and t[3].dtype == torch.float32 and tuple(t[3].shape) == (8, 4)
+    np.testing.assert_allclose(t[3][:3].numpy(), (data[0]['gt_boxes'].astype(np.float32) * 0.5))
+    assert t[4].dtype == torch.int64 and t[4][:, 0].tolist() == [0, 0, 0, 1, 1, 1, 1, 1]
+    assert t[5].tolist() == [[0, 0, 1, 7], [0, 2, 0, 3], [1, 0, 1, 7], [1, 2, 0, 3]] and t[6] is None
+    ev = vg_collate(data, is_train=False, mode='rel')[0]
+    assert len(ev) == 8 and ev[7] == ['0.jpg', '1.jpg']
+    with pytest.raises(ValueError):
+        b = Blob(mode='rel', batch_size_per_gpu=3)
+        b.append(data[0])
+        b.reduce()
+    with pytest.raises(ValueError):
+        Blob(num_gpus=2)
+    with pytest.raises(ValueError):
+        blob[1]
