@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, 
 constexpr int MAXS = 32;  // max P*sampling samples per axis
 
 template <typename T>
-__global__ __launch_bounds__(256) void roi_align_kernel(const T* __restrict__ fmap, int B, int H, int W, int C,
+__global__ __launch_bounds__(512) void roi_align_kernel(const T* __restrict__ fmap, int B, int H, int W, int C,
                                                         const float* __restrict__ rois, const int64_t* __restrict__ pairs,
                                                         int R, float scale, int P, int S, const float* __restrict__ add_ec,
                                                         T* __restrict__ out) {
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const T* __restrict__ fm
     __shared__ float s_l[2][MAXS], s_h[2][MAXS];  // s_h < 0 marks an out-of-range sample
     __shared__ int s_b;
     const int r = xcd_remap(blockIdx.x, R);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NWV = blockDim.x >> 6;
     const int PS = P * S;
     if (tid < 2 * PS) {
         const int axis = tid / PS, k = tid - axis * PS;  // axis 0 = y, 1 = x
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const T* __restrict__ fm
                 for (int k = 0; k < 8; ++k) acc[k] = acc[k] * inv + addv[k];
                 store8(tile + bin * TS + cl, acc);
             };
-            for (int bin = wave; bin < PP; bin += 4) {   // (two bins = 32 loads in flight measured slower: 0.46 vs 0.38 ms)
+            for (int bin = wave; bin < PP; bin += NWV) {   // (two bins = 32 loads in flight measured slower: 0.46 vs 0.38 ms)
                 Raw8<T> tap[16];
                 float wgt[16];
                 issue(bin, tap, wgt);
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const T* __restrict__ fm
             }
             continue;
         }
-        for (int bin = wave; bin < PP; bin += 4) {
+        for (int bin = wave; bin < PP; bin += NWV) {
             const int ph = bin / P, pw = bin - ph * P;
             float acc[8];
 #pragma unroll
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const T* __restrict__ fm
     // phase 2: out[r][c][p], 8 consecutive linear elements per thread
     T* o = out + ((long)r * C + cbase) * PP;
     const int total = CS * PP;
-    for (int L0 = tid * 8; L0 < total; L0 += 256 * 8) {
+    for (int L0 = tid * 8; L0 < total; L0 += (int)blockDim.x * 8) {
         int c = L0 / PP, p = L0 - c * PP;
         if constexpr (sizeof(T) == 2) {
             // raw 16-bit moves: no bf16 -> f32 -> bf16 round trip
@@ -488,6 +488,9 @@ extern "C" int sgg_maxpool2x2(const void* in, void* out, int out_pad, int B, int
     return SGG_OK;
 }
 
+// 8 waves per RoI (49 bins over 8 waves): more gathers in flight per CU than 4 waves (0.370 -> 0.342 ms)
+static constexpr int roi_threads() { return 512; }
+
 extern "C" int sgg_roi_align_fwd(const void* fmap, int B, int H, int W, int C, const float* rois, int Nroi,
                                  const int64_t* pairs, int R, float spatial_scale, int P, int sampling,
                                  const float* add_ec, void* out, int dtype, void* stream) {
@@ -511,7 +514,7 @@ extern "C" int sgg_roi_align_fwd(const void* fmap, int B, int H, int W, int C, c
                 return SGG_ERR_LAUNCH;
             done = true;
         }
-        hipLaunchKernelGGL(roi_align_kernel<bf16_t>, dim3(R, nsplit), dim3(256), smem, (hipStream_t)stream, (const bf16_t*)fmap, B, H, W, C,
+        hipLaunchKernelGGL(roi_align_kernel<bf16_t>, dim3(R, nsplit), dim3(roi_threads()), smem, (hipStream_t)stream, (const bf16_t*)fmap, B, H, W, C,
                            rois, pairs, R, spatial_scale, P, sampling, add_ec, (bf16_t*)out);
     } else if (dtype == SGG_F32) {
         static bool done = false;
@@ -520,7 +523,7 @@ extern "C" int sgg_roi_align_fwd(const void* fmap, int B, int H, int W, int C, c
                 return SGG_ERR_LAUNCH;
             done = true;
         }
-        hipLaunchKernelGGL(roi_align_kernel<float>, dim3(R, nsplit), dim3(256), smem, (hipStream_t)stream, (const float*)fmap, B, H, W, C,
+        hipLaunchKernelGGL(roi_align_kernel<float>, dim3(R, nsplit), dim3(roi_threads()), smem, (hipStream_t)stream, (const float*)fmap, B, H, W, C,
                            rois, pairs, R, spatial_scale, P, sampling, add_ec, (float*)out);
     } else {
         return SGG_ERR_DTYPE;
