@@ -404,27 +404,46 @@ __global__ __launch_bounds__(256) void node_scatter_bwd_kernel(const T* __restri
 template <typename T>
 __global__ __launch_bounds__(256) void rank4_reduce_kernel(const float* __restrict__ a, const T* __restrict__ x, int R, int H,
                                                            float* __restrict__ out, int out_ld, int rows_per_block) {
-    __shared__ float red[4][4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    // 8 lanes x 8 channels (16-byte loads when H % 8 == 0) cover the block's 64 channels, 32 row lanes walk the rows
+    __shared__ float red[32][4][65];
+    const int cl = (threadIdx.x & 7) * 8, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 64 + cl;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    if (c < H)
-        for (int r = r0 + w; r < r1; r += 4) {
-            const float xv = Elem<T>::ld(x + (long)r * H + c);
-            const f32x4 av = *reinterpret_cast<const f32x4*>(a + (long)r * 4);
-            s[0] = fmaf(av.x, xv, s[0]);
-            s[1] = fmaf(av.y, xv, s[1]);
-            s[2] = fmaf(av.z, xv, s[2]);
-            s[3] = fmaf(av.w, xv, s[3]);
+    float s[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[k][j] = 0.f;
+    const bool vec = (H & 7) == 0 && c + 8 <= H;
+#pragma unroll 2
+    for (int r = r0 + rl; r < r1; r += 32) {
+        float xv[8];
+        if (vec) {
+            load8(x + (long)r * H + c, xv);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[j] = c + j < H ? Elem<T>::ld(x + (long)r * H + c + j) : 0.f;
         }
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a + (long)r * 4);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) red[k][w][threadIdx.x & 63] = s[k];
+        for (int j = 0; j < 8; ++j) {
+            s[0][j] = fmaf(av.x, xv[j], s[0][j]);
+            s[1][j] = fmaf(av.y, xv[j], s[1][j]);
+            s[2][j] = fmaf(av.z, xv[j], s[2][j]);
+            s[3][j] = fmaf(av.w, xv[j], s[3][j]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[rl][k][cl + j] = s[k][j];
     __syncthreads();
-    if (w == 0 && c < H) {
-        const int t = threadIdx.x;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            atomicAdd(&out[(long)k * out_ld + c], red[k][0][t] + red[k][1][t] + red[k][2][t] + red[k][3][t]);
+    const int k = threadIdx.x >> 6, cc = threadIdx.x & 63;
+    if (blockIdx.x * 64 + cc < H) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) t += red[q][k][cc];
+        atomicAdd(&out[(long)k * out_ld + blockIdx.x * 64 + cc], t);
     }
 }
 

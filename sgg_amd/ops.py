@@ -369,9 +369,10 @@ def gru_gate_bwd(dh, gi, gh, b_hh, h_prev, d_gi, d_gh, want_dh_prev=True):
     return dh_prev
 
 
-def imp_edge_ctx_bwd(v, e, rel_inds, dots, gate_w, gate_b, d_e_in, d_ctx, d_e):
+def imp_edge_ctx_bwd(v, e, rel_inds, dots, gate_w, gate_b, d_e_in, d_ctx, d_e, da=None):
     E, H = e.shape
-    da = torch.empty((E, 4), dtype=torch.float32, device=e.device)
+    if da is None:
+        da = torch.empty((E, 4), dtype=torch.float32, device=e.device)
     gsave = torch.empty((E, 2), dtype=torch.float32, device=e.device)
     _lib.call('sgg_imp_edge_ctx_bwd', _p(v), _p(e), _p(rel_inds, torch.int64), E, H, _p(dots, torch.float32),
               _p(gate_w, torch.float32), _p(gate_b, torch.float32), _p(d_e_in), _p(d_ctx), _p(d_e), _p(da), _p(gsave),
@@ -379,10 +380,11 @@ def imp_edge_ctx_bwd(v, e, rel_inds, dots, gate_w, gate_b, d_e_in, d_ctx, d_e):
     return da, gsave
 
 
-def imp_node_scatter_bwd(d_e_in, gsave, da, csr, gate_w, d_v):
+def imp_node_scatter_bwd(d_e_in, gsave, da, csr, gate_w, d_v, nsum=None):
     N, H = d_v.shape
     out_ptr, out_ids, in_ptr, in_ids = csr[:4]
-    nsum = torch.empty((N, 4), dtype=torch.float32, device=d_v.device)
+    if nsum is None:
+        nsum = torch.empty((N, 4), dtype=torch.float32, device=d_v.device)
     _lib.call('sgg_imp_node_scatter_bwd', _p(d_e_in), _p(gsave), _p(da), _p(out_ptr), _p(out_ids), _p(in_ptr), _p(in_ids),
               _p(gate_w, torch.float32), N, H, _p(d_v), _p(nsum), dt(d_v), _stream())
     return nsum
