@@ -52,8 +52,10 @@ int sgg_image_prep_u8(const uint8_t* img_hwc, int h0, int w0, int rh, int rw, fl
  * Activations live in zero-bordered NHWC buffers [B, H+2*pad, W+2*pad, C]. */
 int sgg_conv1_1(const float* in_nhwc4, const float* w /*[64][27] (ky,kx,c)*/, const float* bias, void* out, int B,
                 int H, int W, int out_dtype, void* stream);
+/* pool = 1: the following MaxPool2d(2) is fused into the epilogue -- out is the pooled plane [B, H/2+2p, W/2+2p, Cout]
+ * (H, W even; LDS-patch kernel only: returns SGG_ERR_ARG for shapes that kernel does not take). */
 int sgg_conv3x3_relu(const void* in /*pad 1*/, const void* w /*[Cout][3][3][Cin]*/, const float* bias, void* out,
-                     int out_pad, int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
+                     int out_pad, int B, int H, int W, int Cin, int Cout, int pool, int dtype, void* stream);
 int sgg_maxpool2x2(const void* in /*pad 1*/, void* out, int out_pad, int B, int H, int W, int C, int dtype,
                    void* stream);
 

@@ -37,6 +37,7 @@ struct ConvArgs {
     const float* bias;
     char* out;           // [B, H+2p, W+2p, Cout]
     int B, H, W, Cin, Cout, out_pad, tiles_x, tiles_y;
+    int pool;            // 1: out is the 2x2-max-pooled plane [B, H/2+2p, W/2+2p, Cout] (H, W even)
 };
 
 template <bool BF16, int WN, int NI, bool ONEBAR>
@@ -191,6 +192,40 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
                 *reinterpret_cast<f32x4*>(est + fr * ESTRIDE + (ni * 32 + 8 * q + 4 * fh) * 4) = v;
             }
         __syncthreads();
+        if (g.pool) {
+            // fused MaxPool2d(2): a wave's 32-pixel block is 2 image rows x 16 columns, i.e. 8 complete 2x2 windows;
+            // max first, then bias + ReLU (they commute with max).  Column c of the staged tile holds pixel
+            // (frag_py(c), frag_px(c)); window b = pixels x in {2b, 2b+1} of both rows.
+            constexpr int WPI = 64 / LPR;                 // windows per pass
+#pragma unroll
+            for (int it = 0; it < (8 + WPI - 1) / WPI; ++it) {
+                const int wb = lane / LPR + WPI * it, cl = (lane % LPR) * 8;
+                if (wb >= 8) continue;
+                const int yo = (y0 + wm * 4 + pj * 2) >> 1, xo = (x0 >> 1) + wb;
+                if (2 * yo >= g.H || 2 * xo >= g.W) continue;
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = -3.0e38f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int px = 2 * wb + (q & 1), py = q >> 1;
+                    // inverse of (frag_py, frag_px): column index of pixel (py, px)
+                    const int col = py == 0 ? (px < 4 ? px : px < 8 ? px + 8 : px + 12) : (px < 8 ? px + 4 : px < 12 ? px + 8 : px + 16);
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(est + col * ESTRIDE + cl * 4);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(est + col * ESTRIDE + cl * 4 + 16);
+                    v[0] = fmaxf(v[0], lo.x); v[1] = fmaxf(v[1], lo.y); v[2] = fmaxf(v[2], lo.z); v[3] = fmaxf(v[3], lo.w);
+                    v[4] = fmaxf(v[4], hi.x); v[5] = fmaxf(v[5], hi.y); v[6] = fmaxf(v[6], hi.z); v[7] = fmaxf(v[7], hi.w);
+                }
+                const int n = n0 + wn * CNW + cl;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] + g.bias[n + k], 0.f);
+                const int op = g.out_pad, Ho = g.H >> 1, Wo = g.W >> 1;
+                const long off = (((long)b * (Ho + 2 * op) + yo + op) * (Wo + 2 * op) + xo + op) * g.Cout + n;
+                if constexpr (BF16) store8(reinterpret_cast<bf16_t*>(g.out) + off, v);
+                else store8(reinterpret_cast<float*>(g.out) + off, v);
+            }
+            continue;
+        }
 #pragma unroll
         for (int it = 0; it < 32 / PPI; ++it) {
             const int pl = lane / LPR + PPI * it, cl = (lane % LPR) * 8;   // pixel inside the 32-block, channel chunk
@@ -233,8 +268,9 @@ int launch_spatial(const ConvArgs& g, hipStream_t s) {
 
 // returns SGG_OK, or 1 if the shape is not handled here (caller falls through to the implicit-GEMM kernels)
 int sgg_launch_conv_spatial(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H, int W,
-                            int Cin, int Cout, bool bf16, hipStream_t s) {
+                            int Cin, int Cout, bool bf16, int pool, hipStream_t s) {
     ConvArgs g{};
+    g.pool = pool;
     g.in = (const char*)in; g.w = (const char*)w; g.bias = bias; g.out = (char*)out;
     g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.out_pad = out_pad;
     g.tiles_x = (W + TILE - 1) / TILE;

@@ -19,7 +19,7 @@
 
 int sgg_launch_pingpong(const GemmArgs& g, bool bf16, bool conv, hipStream_t s);  // gemm256.hip
 int sgg_launch_conv_spatial(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H, int W,
-                            int Cin, int Cout, bool bf16, hipStream_t s);            // conv_spatial.hip
+                            int Cin, int Cout, bool bf16, int pool, hipStream_t s);            // conv_spatial.hip
 
 namespace {
 
@@ -313,7 +313,7 @@ extern "C" int sgg_gemm_splitk(const void* A, int lda, const void* W, int ldw, c
 }
 
 extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H,
-                                int W, int Cin, int Cout, int dtype, void* stream) {
+                                int W, int Cin, int Cout, int pool, int dtype, void* stream) {
     if (dtype != SGG_F32 && dtype != SGG_BF16) return SGG_ERR_DTYPE;
     const int esz = dtype == SGG_BF16 ? 2 : 4;
     const int bke = ROWB / esz;
@@ -325,10 +325,12 @@ extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias
         // SGG_CONV_FORCE=gemm|spatial overrides (experiments only).
         static const char* force = getenv("SGG_CONV_FORCE");
         const bool want = force ? (force[0] == 's') : (H >= 64 && W >= 64);   // measured: conv1_2..conv4_3 faster here, conv5 (38x38) on the implicit GEMM
-        if (want) {
-            const int rc = sgg_launch_conv_spatial(in, w, bias, out, out_pad, B, H, W, Cin, Cout, dtype == SGG_BF16, (hipStream_t)stream);
+        if (pool && ((H | W) & 1)) return SGG_ERR_ARG;
+        if (want || pool) {
+            const int rc = sgg_launch_conv_spatial(in, w, bias, out, out_pad, B, H, W, Cin, Cout, dtype == SGG_BF16, pool, (hipStream_t)stream);
             if (rc <= 0) return rc;
         }
+        if (pool) return SGG_ERR_ARG;    // the fused pool lives in the spatial kernel only
     }
     GemmArgs g{};
     g.A = (const char*)in; g.Wt = (const char*)w;

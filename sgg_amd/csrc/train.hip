@@ -86,6 +86,46 @@ __global__ __launch_bounds__(256) void colsum2_kernel(const T* __restrict__ x, c
     }
 }
 
+// BatchNorm statistics (sum x, sum x^2) with 16-byte loads: 8 lanes x 8 channels per block column, 32 row lanes (C % 8 == 0)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int M, int C, float* __restrict__ out,
+                                                       int rows_per_block) {
+    __shared__ float red[2][32][65];
+    const int cl = (threadIdx.x & 7) * 8, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s[8], q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = q[k] = 0.f;
+    if (c < C) {
+#pragma unroll 4
+        for (int r = r0 + rl; r < r1; r += 32) {
+            float v[8];
+            load8(x + (long)r * C + c, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                s[k] += v[k];
+                q[k] = fmaf(v[k], v[k], q[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        red[0][rl][cl + k] = s[k];
+        red[1][rl][cl + k] = q[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, cc = threadIdx.x & 63;
+        if (blockIdx.x * 64 + cc < C) {
+            float a = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) a += red[which][k][cc];
+            atomicAdd(&out[which * C + blockIdx.x * 64 + cc], a);
+        }
+    }
+}
+
 // BatchNorm apply with given per-channel scale/shift, optionally followed by the max over 4 consecutive rows
 // (MaxPool2d(3,2,1) on the 2x2 map), recording the arg-max row for the backward.
 template <typename T, bool MAX4>
@@ -741,8 +781,13 @@ extern "C" int sgg_bn_stats(const void* x, int M, int C, float* sums, int dtype,
     int rpb;
     const int split = split_rows(M, rpb);
     const dim3 grid((C + 63) / 64, split), blk(256);
-    DISPATCH2(dtype, hipLaunchKernelGGL((colsum2_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (const bf16_t*)x, (const bf16_t*)x, M, C, sums, rpb),
-              hipLaunchKernelGGL((colsum2_kernel<float, float>), grid, blk, 0, s, (const float*)x, (const float*)x, M, C, sums, rpb));
+    if ((C & 7) == 0) {
+        DISPATCH2(dtype, hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)x, M, C, sums, rpb),
+                  hipLaunchKernelGGL(bn_stats_kernel<float>, grid, blk, 0, s, (const float*)x, M, C, sums, rpb));
+    } else {
+        DISPATCH2(dtype, hipLaunchKernelGGL((colsum2_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (const bf16_t*)x, (const bf16_t*)x, M, C, sums, rpb),
+                  hipLaunchKernelGGL((colsum2_kernel<float, float>), grid, blk, 0, s, (const float*)x, (const float*)x, M, C, sums, rpb));
+    }
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

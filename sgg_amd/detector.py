@@ -160,7 +160,10 @@ class VGGDetector(nn.Module):
             ops.image_prep(im.contiguous(), sizes[b][0], sizes[b][1], x0, b)
         H, W = Hp, Wp
         x, ci_layer, n_conv = x0, 0, len(ws)
-        for li, v in enumerate(VGG16_CFG):
+        cfg = list(VGG16_CFG)
+        li = 0
+        while li < len(cfg):
+            v = cfg[li]
             if v == 'M':
                 y = self._buf('a%d' % li, (B, H // 2 + 2, W // 2 + 2, x.shape[3]), dtype, dev, True)
                 ops.maxpool2x2(x, y, 1)
@@ -169,13 +172,22 @@ class VGGDetector(nn.Module):
                 w, bias, ci, co = ws[ci_layer]
                 last = ci_layer == n_conv - 1
                 op = 0 if last else 1
-                # the final map is handed to the caller (Result.fmap): a fresh tensor, never a cached plane
-                y = torch.empty((B, H, W, co), dtype=dtype, device=dev) if last else \
-                    self._buf('a%d' % li, (B, H + 2, W + 2, co), dtype, dev, True)
-                if ci_layer == 0:
-                    ops.conv1_1(x, w, bias, y)
+                # conv followed by MaxPool2d(2): the pool rides in the conv epilogue (the full-resolution map is never written)
+                fuse = (ci_layer > 0 and li + 1 < len(cfg) and cfg[li + 1] == 'M' and ops.conv_pool_fusable(H, W, co))
+                if fuse:
+                    y = self._buf('a%d' % (li + 1), (B, H // 2 + 2, W // 2 + 2, co), dtype, dev, True)
+                    ops.conv3x3_relu(x, w.view(co, 3, 3, ci), bias, y, 1, pool=True)
+                    H, W = H // 2, W // 2
+                    li += 1
                 else:
-                    ops.conv3x3_relu(x, w.view(co, 3, 3, ci), bias, y, op)
+                    # the final map is handed to the caller (Result.fmap): a fresh tensor, never a cached plane
+                    y = torch.empty((B, H, W, co), dtype=dtype, device=dev) if last else \
+                        self._buf('a%d' % li, (B, H + 2, W + 2, co), dtype, dev, True)
+                    if ci_layer == 0:
+                        ops.conv1_1(x, w, bias, y)
+                    else:
+                        ops.conv3x3_relu(x, w.view(co, 3, 3, ci), bias, y, op)
                 ci_layer += 1
             x = y
+            li += 1
         return x, sizes, (Hp, Wp)

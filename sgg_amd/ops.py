@@ -66,13 +66,19 @@ def conv1_1(x_nhwc4, w, bias, out):
               B, H, W, dt(out), _stream())
 
 
-def conv3x3_relu(x, w, bias, out, out_pad):
-    """x [B,H+2,W+2,Cin] zero-bordered; w [Cout,3,3,Cin]; out [B,H+2p,W+2p,Cout]."""
+def conv_pool_fusable(H, W, Cout):
+    """Shapes for which conv3x3_relu(pool=True) exists: the LDS-patch kernel's (wide maps, even sizes)."""
+    return H >= 64 and W >= 64 and H % 2 == 0 and W % 2 == 0 and Cout % 64 == 0
+
+
+def conv3x3_relu(x, w, bias, out, out_pad, pool=False):
+    """x [B,H+2,W+2,Cin] zero-bordered; w [Cout,3,3,Cin]; out [B,H+2p,W+2p,Cout], or with pool=True the 2x2-max-pooled
+    plane [B,H/2+2p,W/2+2p,Cout] (MaxPool2d(2) fused into the conv epilogue)."""
     B, H, W, Cin = x.shape[0], x.shape[1] - 2, x.shape[2] - 2, x.shape[3]
     Cout = w.shape[0]
     assert w.dtype == x.dtype == out.dtype
-    _lib.call('sgg_conv3x3_relu', _p(x), _p(w), _p(bias, torch.float32), _p(out), out_pad, B, H, W, Cin, Cout, dt(x),
-              _stream())
+    _lib.call('sgg_conv3x3_relu', _p(x), _p(w), _p(bias, torch.float32), _p(out), out_pad, B, H, W, Cin, Cout, int(pool),
+              dt(x), _stream())
 
 
 def maxpool2x2(x, out, out_pad):

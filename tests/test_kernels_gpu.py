@@ -153,6 +153,30 @@ def test_conv3x3(ops, dtype, B, H, W, Cin, Cout):
             assert float(got[:, 0].min()) == 7.0 and float(got[:, :, 0].min()) == 7.0
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv3x3_relu_with_fused_maxpool(ops, dtype):
+    """conv + ReLU + MaxPool2d(2) in one kernel == the two separate kernels, bit for bit (max commutes with bias + ReLU
+    and with the output rounding); sizes that leave partial 16x16 tiles on both axes."""
+    g = torch.Generator().manual_seed(12)
+    B, H, W, Cin, Cout = 2, 74, 100, 64, 128
+    x = torch.zeros(B, H + 2, W + 2, Cin)
+    x[:, 1:-1, 1:-1] = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, generator=g) / 24
+    bias = torch.randn(Cout, generator=g) * 0.2
+    xd, wd, bd = cu(x.to(dtype)), cu(w.to(dtype)), cu(bias)
+    full = torch.zeros(B, H + 2, W + 2, Cout, device=DEV, dtype=dtype)
+    ops.conv3x3_relu(xd, wd, bd, full, 1)
+    ref = torch.zeros(B, H // 2 + 2, W // 2 + 2, Cout, device=DEV, dtype=dtype)
+    ops.maxpool2x2(full, ref, 1)
+    got = torch.full((B, H // 2 + 2, W // 2 + 2, Cout), 7.0, device=DEV, dtype=dtype)
+    ops.conv3x3_relu(xd, wd, bd, got, 1, pool=True)
+    assert torch.equal(got[:, 1:-1, 1:-1], ref[:, 1:-1, 1:-1])
+    assert float(got[:, 0].float().min()) == 7.0 and float(got[:, :, -1].float().min()) == 7.0     # border untouched
+    assert ops.conv_pool_fusable(H, W, Cout) and not ops.conv_pool_fusable(37, 37, 512)
+    with pytest.raises(ValueError):
+        ops.conv3x3_relu(xd[:, :-1], wd, bd, got, 1, pool=True)                                   # odd height
+
+
 def test_image_prep_conv1_1_maxpool(ops):
     g = torch.Generator().manual_seed(3)
     B, S, Hp = 2, 40, 64
