@@ -26,27 +26,74 @@ class ImpWeights(object):
         return w
 
 
-def _gru(wts, which, x, h, dtype):
+def _gru(wts, which, x, h, dtype, out=None):
     """nn.GRUCell: two MFMA GEMMs (fp32 pre-activations) + the fused pointwise gate kernel.  h is None for the
     first call (hidden state 0: the hidden GEMM is skipped, b_hh still applies -- rel_model_stanford.py:68-72)."""
     gi = ops.gemm(x, getattr(wts, which + '_w_ih'), getattr(wts, which + '_b_ih'), out_dtype=torch.float32)
     if h is None:
-        return ops.gru_gate(gi, None, getattr(wts, which + '_b_hh'), None, dtype)
+        return ops.gru_gate(gi, None, getattr(wts, which + '_b_hh'), None, dtype, out=out)
     gh = ops.gemm(h, getattr(wts, which + '_w_hh'), getattr(wts, which + '_b_hh'), out_dtype=torch.float32)
-    return ops.gru_gate(gi, gh, None, h, dtype)
+    return ops.gru_gate(gi, gh, None, h, dtype, out=out)
+
+
+_SIDE = {}
+
+
+def node_lane(device):
+    """A second HIP stream (+ two events) per device for the node-side work of the loop.  The node GRU is three tiny
+    GEMMs and a gate kernel on 32B rows -- pure launch/DRAM latency (~15 us each) -- and depends only on (ctx, v_i); run
+    on its own stream it hides behind the edge GRU of the same iteration instead of queueing after it.
+    SGG_IMP_STREAMS=0 keeps everything on one stream."""
+    import os
+    if os.environ.get('SGG_IMP_STREAMS', '1') == '0':
+        return None
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = (torch.cuda.Stream(device=device), torch.cuda.Event(), torch.cuda.Event())
+    return _SIDE[key]
 
 
 def message_pass(rel_rep, obj_rep, rel_inds, csr, wts, mp_iter, dtype):
     """rel_rep [E,H], obj_rep [N,H] (dtype), rel_inds i64[E,3] -> (vert[N,H], edge[E,H])."""
-    N = obj_rep.shape[0]
-    vert = _gru(wts, 'node_gru', obj_rep, None, dtype)                       # :71
-    edge = _gru(wts, 'edge_gru', rel_rep, None, dtype)                       # :72
-    for _ in range(mp_iter):                                                 # :74
-        e_in, ctx2 = ops.imp_fused(vert, edge, rel_inds, csr, wts.gate_w_c, wts.gate_b)   # :76-81,86-91 in one launch
-        edge_new = _gru(wts, 'edge_gru', e_in, edge, dtype)                  # :83
-        # :92  node_gru(ctx_out + ctx_in, vert): the sum rides in the GEMM's K axis
-        gi = ops.gemm(ctx2[0], wts.node_gru_w_ih2, wts.node_gru_b_ih, out_dtype=torch.float32, A2=ctx2[1])
-        gh = ops.gemm(vert, wts.node_gru_w_hh, wts.node_gru_b_hh, out_dtype=torch.float32)
-        vert = ops.gru_gate(gi, gh, None, vert, dtype)
-        edge = edge_new
-    return vert, edge
+    N, H = obj_rep.shape
+    lane = node_lane(obj_rep.device)
+    if lane is None:
+        vert = _gru(wts, 'node_gru', obj_rep, None, dtype)                       # :71
+        edge = _gru(wts, 'edge_gru', rel_rep, None, dtype)                       # :72
+        for _ in range(mp_iter):                                                 # :74
+            e_in, ctx2 = ops.imp_fused(vert, edge, rel_inds, csr, wts.gate_w_c, wts.gate_b)   # :76-81,86-91 in one launch
+            edge_new = _gru(wts, 'edge_gru', e_in, edge, dtype)                  # :83
+            # :92  node_gru(ctx_out + ctx_in, vert): the sum rides in the GEMM's K axis
+            gi = ops.gemm(ctx2[0], wts.node_gru_w_ih2, wts.node_gru_b_ih, out_dtype=torch.float32, A2=ctx2[1])
+            gh = ops.gemm(vert, wts.node_gru_w_hh, wts.node_gru_b_hh, out_dtype=torch.float32)
+            vert = ops.gru_gate(gi, gh, None, vert, dtype)
+            edge = edge_new
+        return vert, edge
+    # Two streams.  Memory rules that keep the caching allocator out of trouble: every tensor that crosses streams is
+    # allocated on the main stream and stays referenced until the main stream has waited for the last side-stream
+    # event (verts, keep); temporaries of the side stream (gi, gh) are allocated and freed under the side stream.
+    side, ev_main, ev_side = lane
+    main = torch.cuda.current_stream(obj_rep.device)
+    verts = [torch.empty((N, H), dtype=dtype, device=obj_rep.device) for _ in range(mp_iter + 1)]
+    keep = []
+    ev_main.record(main)
+    side.wait_event(ev_main)                                                     # obj_rep is ready
+    with torch.cuda.stream(side):
+        _gru(wts, 'node_gru', obj_rep, None, dtype, out=verts[0])                # :71
+        ev_side.record(side)
+    edge = _gru(wts, 'edge_gru', rel_rep, None, dtype)                           # :72
+    for i in range(mp_iter):                                                     # :74
+        main.wait_event(ev_side)                                                 # v_i is ready
+        e_in, ctx2 = ops.imp_fused(verts[i], edge, rel_inds, csr, wts.gate_w_c, wts.gate_b)   # :76-81,86-91 in one launch
+        keep.append(ctx2)
+        ev_main.record(main)
+        side.wait_event(ev_main)
+        with torch.cuda.stream(side):                                            # :92, K-split sum of the two ctx halves
+            gi = ops.gemm(ctx2[0], wts.node_gru_w_ih2, wts.node_gru_b_ih, out_dtype=torch.float32, A2=ctx2[1])
+            gh = ops.gemm(verts[i], wts.node_gru_w_hh, wts.node_gru_b_hh, out_dtype=torch.float32)
+            ops.gru_gate(gi, gh, None, verts[i], dtype, out=verts[i + 1])
+            del gi, gh
+            ev_side.record(side)
+        edge = _gru(wts, 'edge_gru', e_in, edge, dtype)                          # :83
+    main.wait_event(ev_side)
+    return verts[-1], edge

@@ -3,7 +3,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from .imp import GATES, ImpWeights, message_pass
+from .imp import GATES, ImpWeights, message_pass, node_lane
 from .rel_model_base import RelModelBase, to_rows
 
 
@@ -117,13 +117,24 @@ class RelModelStanford(RelModelBase):
         w = self.prepared()
         # :100  union_boxes(edge_feat, rois, rel_inds[:,1:]) -- conv(rects)[E,512]; the broadcast add rides in fc6's K
         rect = self.union_boxes.rect_feat(rois, rel_inds[:, 1:].contiguous(), dtype)
-        # :103  obj_unary(roi_fmap_obj(node_feat))
-        _lib.set_tag('fc6_obj')
-        x = ops.gemm(nf, w['fc6_obj'], w['fc6_obj_b'], ops.ACT_RELU)
-        _lib.set_tag('fc7_obj')
-        x = ops.gemm(x, w['fc7_obj'], w['fc7_obj_b'], ops.ACT_RELU)
-        _lib.set_tag('unary')
-        obj_rep = ops.gemm(x, w['obj_unary'], w['obj_unary_b'])
+        # :103  obj_unary(roi_fmap_obj(node_feat)) -- three short-M GEMMs (256 rows), latency-bound: on the node lane's
+        # stream they run under the edge MLP below instead of in front of it (message_pass keeps using that lane)
+        def node_mlp():
+            _lib.set_tag('fc6_obj')
+            x = ops.gemm(nf, w['fc6_obj'], w['fc6_obj_b'], ops.ACT_RELU)
+            _lib.set_tag('fc7_obj')
+            x = ops.gemm(x, w['fc7_obj'], w['fc7_obj_b'], ops.ACT_RELU)
+            _lib.set_tag('unary')
+            return ops.gemm(x, w['obj_unary'], w['obj_unary_b'])
+        lane = node_lane(nf.device)
+        if lane is None:
+            obj_rep = node_mlp()
+        else:
+            side, ev_main, _ = lane
+            ev_main.record(torch.cuda.current_stream(nf.device))
+            side.wait_event(ev_main)                                 # nf is ready
+            with torch.cuda.stream(side):
+                obj_rep = node_mlp()                                 # consumed on the same stream by message_pass
         # :104  relu(edge_unary(roi_fmap(edge_feat)))
         _lib.set_tag('fc6_edge')
         y = ops.gemm(ef, w['fc6_edge'], w['fc6_edge_b'], ops.ACT_RELU, A2=rect, W2=w['fc6_edge_sum'])
