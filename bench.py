@@ -302,7 +302,7 @@ def main():
                        'weights': 'random init (He), frozen VGG16 + trainable IMP head (247.75 M params)'},
             'roofline': {'kernel': 'MFMA tile kernel, %s' % desc, 'bound': 'mfma', 'achieved': round(tf, 2), 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': round(tf / peak, 4),
-                         'traffic': pmc_traffic('fc6_edge_gemm') if (tag == 'fc6_edge' and B == 8 and args.dtype == 'bf16') else None,
+                         'traffic': pmc_traffic('fc6_edge_gemm' if tag == 'fc6_edge' else 'fc6_dW_gemm') if (B == 8 and args.dtype == 'bf16') else None,
                          'ms_per_step': round(ms, 4)},
             'roofline_imp': {'kernel': 'imp_fused_kernel (gather + 4 gates + scatter), one launch per IMP iteration', 'bound': 'hbm',
                              'achieved': round(imp_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

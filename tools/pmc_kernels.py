@@ -26,6 +26,15 @@ out = torch.empty(M, N, device=dev, dtype=dt)
 for _ in range(3):
     ops.gemm(A, W, b, ops.ACT_RELU, A2=A2, W2=W2, out=out)
 torch.cuda.synchronize()
+# fc6 weight gradient (the train step's largest contraction): dW[4096, 25088] = d_pre6^T [4096, 7936] . x6^T [25088, 7936]^T, fp32 out
+Mg, Ng, Kg = 4096, 25088, 7936
+At = (torch.randn(Mg, Kg, generator=g) / 50).to(dev).to(dt)
+Bt = torch.randn(Ng, Kg, generator=g).to(dev).to(dt).relu()
+dW = torch.empty(Mg, Ng, device=dev, dtype=torch.float32)
+for _ in range(3):
+    ops.gemm(At, Bt, out_dtype=torch.float32, out=dW)
+torch.cuda.synchronize()
+del At, Bt, dW
 # IMP fused
 H, n = 512, 32
 gw = (torch.randn(4, 2 * H, generator=g) / 30).to(dev)
