@@ -300,7 +300,7 @@ def main():
                        'parallelism': 'image-sharded dp%d, %s' % (world, 'RCCL gradient all-reduce (bf16 on the wire)'
                                                                   if args.mode == 'train' else 'no collective'),
                        'weights': 'random init (He), frozen VGG16 + trainable IMP head (247.75 M params)'},
-            'roofline': {'kernel': 'MFMA tile kernel, %s' % desc, 'bound': 'mfma', 'achieved': round(tf, 2), 'peak': peak,
+            'roofline': {'kernel': '256x256 ping-pong MFMA kernel, %s' % desc, 'bound': 'mfma', 'achieved': round(tf, 2), 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': round(tf / peak, 4),
                          'traffic': pmc_traffic('fc6_edge_gemm' if tag == 'fc6_edge' else 'fc6_dW_gemm') if (B == 8 and args.dtype == 'bf16') else None,
                          'ms_per_step': round(ms, 4)},
