@@ -90,6 +90,22 @@ template <> struct Raw8<float> {
     }
 };
 
+// dot product of two packed 8-element pieces: bf16 pairs go through v_dot2_f32_bf16 (4 instructions instead of
+// 8 unpacks + 8 FMAs); fp32 pieces through 8 FMAs
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ float dot8(const Raw8<bf16_t>& w, const Raw8<bf16_t>& x, float acc) {
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.r.x), __builtin_bit_cast(bf16x2_t, x.r.x), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.r.y), __builtin_bit_cast(bf16x2_t, x.r.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.r.z), __builtin_bit_cast(bf16x2_t, x.r.z), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.r.w), __builtin_bit_cast(bf16x2_t, x.r.w), acc, false);
+    return acc;
+}
+__device__ __forceinline__ float dot8(const Raw8<float>& w, const Raw8<float>& x, float acc) {
+    acc = fmaf(w.a.x, x.a.x, acc); acc = fmaf(w.a.y, x.a.y, acc); acc = fmaf(w.a.z, x.a.z, acc); acc = fmaf(w.a.w, x.a.w, acc);
+    acc = fmaf(w.b.x, x.b.x, acc); acc = fmaf(w.b.y, x.b.y, acc); acc = fmaf(w.b.z, x.b.z, acc); acc = fmaf(w.b.w, x.b.w, acc);
+    return acc;
+}
+
 // 64-lane wave sum on the DPP path (no LDS crossbar): 4 in-row steps, row_bcast15 / row_bcast31 across rows, total in
 // lane 63, broadcast through an SGPR (v_readlane) -- the result is wave-uniform.  gfx9-family DPP controls.
 __device__ __forceinline__ float wave_sum(float v) {

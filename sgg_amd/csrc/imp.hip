@@ -230,23 +230,15 @@ __global__ __launch_bounds__(256, 3) void imp_fused_kernel(const T* __restrict__
                         on[q] = so[2 * (long)idn[q] + 1];
                     }
                 }
-                float ws[8], wobv[8], wobe[8], wo[8];
-                w2.get(ws);
-                w3.get(wobv);
-                w4.get(wobe);
-                w5.get(wo);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float ee[8], ov[8];
                     er[q].get(ee);
                     vr[q].get(ov);
-                    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        p0 = fmaf(ws[j], ee[j], p0);
-                        p1 = fmaf(wobe[j], ee[j], fmaf(wobv[j], ov[j], p1));
-                        p2 = fmaf(wo[j], ee[j], p2);
-                    }
+                    // the three edge-side gate dot products on the packed rows (v_dot2_f32_bf16 for bf16)
+                    const float p0 = dot8(w2, er[q], 0.f);
+                    const float p1 = dot8(w4, er[q], dot8(w3, vr[q], 0.f));
+                    const float p2 = dot8(w5, er[q], 0.f);
                     const float gs = sigmoidf_(a_sub + wave_sum(p0)), go = sigmoidf_(wave_sum(p1) + b_obj);
                     const float gx = sigmoidf_(a_out + wave_sum(p2));
                     if (k + q < end && act) {
@@ -262,14 +254,12 @@ __global__ __launch_bounds__(256, 3) void imp_fused_kernel(const T* __restrict__
             }
         } else {
             float a_in = 0.f;
-            float wie[8];
             {
                 float t0[8];
                 w0.get(t0);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) a_in = fmaf(t0[j], vn[j], a_in);
             }
-            w1.get(wie);
             a_in = wave_sum(a_in) + gb[3];
             const int beg = in_ptr[n], end = in_ptr[n + 1];
             for (int k = beg + sub * 8; k < end; k += 8 * W) {
@@ -284,9 +274,7 @@ __global__ __launch_bounds__(256, 3) void imp_fused_kernel(const T* __restrict__
                 for (int q = 0; q < 8; ++q) {
                     float ee[8];
                     er[q].get(ee);
-                    float p = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) p = fmaf(wie[j], ee[j], p);
+                    const float p = dot8(w1, er[q], 0.f);
                     const float g = (k + q < end) ? sigmoidf_(a_in + wave_sum(p)) : 0.f;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) acc[j] = fmaf(g, ee[j], acc[j]);
