@@ -181,9 +181,14 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
     constexpr int LPR = CNW / 8;                  // lanes per pixel row (8 channels each)
     constexpr int PPI = 64 / LPR;                 // pixels per pass
     char* est = smem + wave * (32 * ESTRIDE);
+    float bias8[8];   // the lane's 8 output channels are the same in every store below: two 16-byte loads, once
+    load8(g.bias + n0 + wn * CNW + (lane % LPR) * 8, bias8);
+    // The staging tile is private to the wave (est = smem + wave * ...): after ONE workgroup barrier (every wave has
+    // finished reading operand tiles out of this memory) the wave's own LDS write -> read order is all that is needed.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int pj = 0; pj < 2; ++pj) {
-        __syncthreads();
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
                 f32x4 v = {acc[pj][ni][4 * q], acc[pj][ni][4 * q + 1], acc[pj][ni][4 * q + 2], acc[pj][ni][4 * q + 3]};
                 *reinterpret_cast<f32x4*>(est + fr * ESTRIDE + (ni * 32 + 8 * q + 4 * fh) * 4) = v;
             }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own LDS writes landed (same wave reads them back)
         if (g.pool) {
             // fused MaxPool2d(2): a wave's 32-pixel block is 2 image rows x 16 columns, i.e. 8 complete 2x2 windows;
             // max first, then bias + ReLU (they commute with max).  Column c of the staged tile holds pixel
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
                 }
                 const int n = n0 + wn * CNW + cl;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] + g.bias[n + k], 0.f);
+                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] + bias8[k], 0.f);
                 const int op = g.out_pad, Ho = g.H >> 1, Wo = g.W >> 1;
                 const long off = (((long)b * (Ho + 2 * op) + yo + op) * (Wo + 2 * op) + xo + op) * g.Cout + n;
                 if constexpr (BF16) store8(reinterpret_cast<bf16_t*>(g.out) + off, v);
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
             v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
             const int n = n0 + wn * CNW + cl;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] + g.bias[n + k], 0.f);
+            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] + bias8[k], 0.f);
             const int op = g.out_pad;
             const long off = (((long)b * (g.H + 2 * op) + y + op) * (g.W + 2 * op) + x + op) * g.Cout + n;
             if constexpr (BF16) store8(reinterpret_cast<bf16_t*>(g.out) + off, v);

@@ -165,9 +165,13 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
     const bool vec_ok = CONV || ((g.ldc & 7) == 0);
     GemmArgs ge = g;
     ge.C = g.C + (long)blockIdx.y * g.splitk_stride;
+    // The staging tile is private to the wave (est = smem + wave * ...): after ONE workgroup barrier (every wave has
+    // finished reading operand tiles out of this memory) the wave's own LDS write -> read order is all that is needed.
+    const ChanVec8 cv = load_chanvec8(g, n0 + wc * 64 + (lane & 7) * 8);   // the lane's 8 channels: the same in every store below
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-        __syncthreads();
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
                 f32x4 v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
                 *reinterpret_cast<f32x4*>(est + fr * ESTRIDE + (ni * 32 + 8 * q + 4 * fh) * 4) = v;
             }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own LDS writes landed (same wave reads them back)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int rl = (lane >> 3) + 8 * it, cl = (lane & 7) * 8;
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
             const f32x4 lo = *reinterpret_cast<const f32x4*>(est + rl * ESTRIDE + cl * 4);
             const f32x4 hi = *reinterpret_cast<const f32x4*>(est + rl * ESTRIDE + cl * 4 + 16);
             v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-            epilogue_store8(ge, v, n, out_offset<CONV>(g, m, n), vec_ok);
+            epilogue_store8(ge, cv, v, n, out_offset<CONV>(g, m, n), vec_ok);
         }
     }
 }

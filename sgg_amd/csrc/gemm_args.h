@@ -46,18 +46,46 @@ __device__ __forceinline__ void tile_coords(int bid, int tilesM, int tilesN, int
     tn = inl / gsz;
 }
 
+// The per-channel epilogue vectors (bias, post-scale, post-shift) of the 8 consecutive n a lane stores: loaded ONCE per
+// thread with two 16-byte loads each.  (Loading them element-wise inside every store -- 64 scattered dword loads per
+// lane and tile -- cost ~10 us of a 744-tile launch: the vector-memory issue rate, not bytes.)
+struct ChanVec8 {
+    float bias[8], ps[8], pt[8];
+    bool has_ps, has_pt;
+};
+__device__ __forceinline__ void load_chan8(const float* p, int n, int N, float (&out)[8], float fill) {
+    if (!p) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[k] = fill;
+        return;
+    }
+    if (n + 8 <= N && ((reinterpret_cast<uintptr_t>(p + n) & 15) == 0)) {
+        load8(p + n, out);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[k] = n + k < N ? p[n + k] : fill;
+    }
+}
+__device__ __forceinline__ ChanVec8 load_chanvec8(const GemmArgs& g, int n) {
+    ChanVec8 c;
+    load_chan8(g.bias, n, g.N, c.bias, 0.f);
+    load_chan8(g.pscale, n, g.N, c.ps, 1.f);
+    load_chan8(g.pshift, n, g.N, c.pt, 0.f);
+    c.has_ps = g.pscale != nullptr;
+    c.has_pt = g.pshift != nullptr;
+    return c;
+}
+
 // bias -> act -> per-channel affine on 8 consecutive n, then store (vector when aligned and full)
-__device__ __forceinline__ void epilogue_store8(const GemmArgs& g, float (&v)[8], int n, long off, bool vec_ok) {
+__device__ __forceinline__ void epilogue_store8(const GemmArgs& g, const ChanVec8& c, float (&v)[8], int n, long off, bool vec_ok) {
     const int nv = min(8, g.N - n);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        if (k < nv) {
-            float t = v[k] + (g.bias ? g.bias[n + k] : 0.f);
-            if (g.act == SGG_ACT_RELU) t = fmaxf(t, 0.f);
-            if (g.pscale) t = t * g.pscale[n + k];
-            if (g.pshift) t = t + g.pshift[n + k];
-            v[k] = t;
-        }
+        float t = v[k] + c.bias[k];
+        if (g.act == SGG_ACT_RELU) t = fmaxf(t, 0.f);
+        if (c.has_ps) t = t * c.ps[k];
+        if (c.has_pt) t = t + c.pt[k];
+        v[k] = t;
     }
     if (vec_ok && nv == 8) {
         if (g.out_bf16) store8(reinterpret_cast<bf16_t*>(g.C) + off, v);
