@@ -98,6 +98,10 @@ class PredictFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, nf, ef, rois, rel_inds, im_inds, seed, dropout_p, *params):
+        ev = getattr(model, '_operands_ready', None)     # trainer: operands rebuilt on a side stream under the VGG forward
+        if ev is not None:
+            torch.cuda.current_stream(nf.device).wait_event(ev)
+            model._operands_ready = None
         w = train_weights(model)
         t, imp, dt = w['train'], w['imp'], model.compute_dtype
         N, E, H = nf.shape[0], ef.shape[0], model.hidden_dim

@@ -154,8 +154,29 @@ class Trainer(object):
             raise NotImplementedError(self.loss_type)
         return obj_ce / n_obj + (rel_ce * w).sum()
 
+    def _prefetch_operands(self):
+        """The optimiser just changed the masters, so the derived operands (W^T copies for the dX GEMMs, W6sum, the GRU /
+        rect-conv operands: ~0.3 ms of HBM-bound transposes and casts) must be rebuilt.  They are rebuilt on the node
+        lane's stream while the main stream runs the (MFMA-bound, frozen) VGG forward; PredictFn.forward waits for the
+        event.  The side stream first waits for everything already queued on the main stream: the previous step may
+        still be reading the buffers this rebuild recycles."""
+        from .imp import node_lane
+        from .train import train_weights
+        dev = next(self.model.parameters()).device
+        lane = node_lane(dev)
+        if lane is None:
+            return
+        side = lane[0]
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            train_weights(self.model)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self.model._operands_ready = ev
+
     def step(self, batch):
         self.model.train()
+        self._prefetch_operands()
         res = self.model([batch])
         loss = self.losses(res)
         self.opt.zero_grad()
