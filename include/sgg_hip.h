@@ -119,6 +119,13 @@ int sgg_gemm_splitk(const void* A, int lda, const void* W, int ldw, const float*
                     const float* post_shift, void* C, int M, int N, int K, int act, int in_dtype, int out_dtype, int splits,
                     float* workspace, void* stream);
 
+/* Weight-gradient contraction without transposed operand copies: C[N, K] = A[Mred, N]^T . B[Mred, K], bf16 in, f32 / bf16 out
+ * (d W = dY^T X of every nn.Linear on the path, main.py:118).  The reduction rows are staged as they lie and reach the MFMA
+ * through ds_read_b64_tr_b16.  Mred % 64 == 0, N % 128 == 0, K % 128 == 0; row strides in elements, multiples of 8.
+ * splits > 1: split over the reduction rows, workspace f32[splits, N, K], ldc == K. */
+int sgg_gemm_tn(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int Mred, int N, int K, int out_dtype,
+                int splits, float* workspace, void* stream);
+
 /* ---- a-8  IMP gather / gate / scatter: RelModelStanford.message_pass, rel_model_stanford.py:74-91 ----
  * node_gate_dots: d[n,4] = (w_sub[:H].v, w_obj[:H].v, w_out[:H].v, w_in[:H].v)  (vertex halves of the four
  *   Linear(2H,1) gates, :41-45).  gate_w f32[4,2H] rows = sub_vert, obj_vert, out_edge, in_edge; gate_b f32[4].

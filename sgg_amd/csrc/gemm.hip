@@ -195,6 +195,144 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// TN form for weight gradients: C[n][k] = sum_m A[m][n] * B[m][k]  (A = dY [Mred, N], B = X [Mred, K], both row-major,
+// the reduction index m is the SLOW axis of both).  The NT kernel above needs A^T and B^T materialised first (a
+// read+write pass over each operand per GEMM: ~1 ms of the train step); here the K-tile is 64 reduction rows of each
+// operand staged AS THEY LIE -- per operand two [64 rows][128 B] column halves in the usual swizzled layout, filled by
+// the same lane-linear global->LDS DMA -- and the MFMA fragments (8 consecutive reduction elements of one column per
+// lane) come out of LDS through ds_read_b64_tr_b16, the gfx950 transposing read: within a 16-lane group lane p hands in
+// the address of 4 consecutive bf16 and lane i receives element i%4 of lanes i/4, i/4+4, i/4+8, i/4+12 (probed on
+// hardware: tools/exp/tr16_probe.hip).  Which 4 stage rows form one read is free as long as both operands agree
+// (a sum does not care about the order of its terms): rows {a, a+1, a+8, a+9} differ in row parity (128 B apart) and in
+// bit 2 of the swizzle key, so the 4 x 64 B a 32-lane pass touches cover all 64 banks exactly once.
+// bf16 only (tr_b16 moves 16-bit elements).  128x128 output tile, 4 waves of 64x64, split-K over the reduction rows.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mfma_tile_tn_kernel(const GemmArgs g) {
+    constexpr int HALF = 64 * ROWB;                 // one [64 rows][128 B] column half
+    constexpr int STAGE = 4 * HALF;                 // A: 2 halves (128 n), B: 2 halves (128 k)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;        // wave's 64 n / 64 k = column half wr of A / wc of B
+    const int tilesM = g.M / 128, tilesN = g.N / 128;
+    int tm, tn;
+    tile_coords(blockIdx.x, tilesM, tilesN, tm, tn);
+    const int n0 = tm * 128, k0 = tn * 128;         // output rows (A columns) / output columns (B columns)
+
+    // ---- DMA sources: instruction i of a half covers stage rows 8i..8i+7; lane -> (row 8i + lane/8, 16-byte chunk)
+    const int lrow = lane >> 3;
+    const char* asrc[4];
+    const char* bsrc[4];
+    int ldst[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = wave * 4 + j;               // 16 instructions per operand: half = idx / 8, row block = idx % 8
+        const int half = idx >> 3, r = (idx & 7) * 8 + lrow;
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        asrc[j] = g.A + (long)r * g.lda_b + (long)(n0 + half * 64) * 2 + chunk * 16;
+        bsrc[j] = g.Wt + (long)r * g.ldw_b + (long)(k0 + half * 64) * 2 + chunk * 16;
+        ldst[j] = half * HALF + (idx & 7) * 8 * ROWB;
+    }
+    auto stage = [&](int kt, int buf) {
+        char* sa = smem + buf * STAGE;
+        char* sb = sa + 2 * HALF;
+        const long roff_a = (long)kt * 64 * g.lda_b, roff_b = (long)kt * 64 * g.ldw_b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(asrc[j] + roff_a, sa + ldst[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(bsrc[j] + roff_b, sb + ldst[j]);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- transposing fragment reads.  lane: kg = lane>>5 (which 8 of the k-step's 16 reduction rows), g16 = (lane>>4)&1
+    // (columns 16*g16.. of the 32-column block), p = lane&15 -> stage row offset (0,1,8,9)[p>>2], 4 columns 4*(p&3)..
+    const int kg = lane >> 5, g16 = (lane >> 4) & 1, p = lane & 15;
+    const int rsel = ((p >> 2) & 1) + ((p >> 3) << 3);          // (0,1,8,9)[p>>2]
+    const int nsplit = gridDim.y;
+    const int kt0 = (int)((long)g.nt * blockIdx.y / nsplit), kt1 = (int)((long)g.nt * (blockIdx.y + 1) / nsplit);
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    stage(kt0, kt0 & 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < kt1) {
+            stage(kt + 1, buf ^ 1);
+            wait_vmcnt<8>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        const unsigned sa = lds0 + buf * STAGE + wr * HALF, sb = lds0 + buf * STAGE + 2 * HALF + wc * HALF;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            // k-step s = stage rows 16s..16s+15 (s is a compile-time constant after unrolling: the offsets fold)
+            unsigned long long a_lo[2], a_hi[2], b_lo[2], b_hi[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = 16 * s + 2 * (2 * kg + h) + rsel;
+                    const int col = i * 32 + g16 * 16 + 4 * (p & 3);
+                    const unsigned off = row * ROWB + ((((col >> 3) ^ ((row >> 1) & 7)) << 4) | (((col >> 2) & 1) << 3));
+                    unsigned long long va, vb;
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(va) : "v"(sa + off) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vb) : "v"(sb + off) : "memory");
+                    if (h == 0) { a_lo[i] = va; b_lo[i] = vb; } else { a_hi[i] = va; b_hi[i] = vb; }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const u32x4 av = {(unsigned)a_lo[mi], (unsigned)(a_lo[mi] >> 32), (unsigned)a_hi[mi], (unsigned)(a_hi[mi] >> 32)};
+                    const u32x4 bv = {(unsigned)b_lo[ni], (unsigned)(b_lo[ni] >> 32), (unsigned)b_hi[ni], (unsigned)(b_hi[ni] >> 32)};
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bv), __builtin_bit_cast(bf16x8_t, av),
+                                                                         acc[mi][ni], 0, 0, 0);
+                }
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue (as the NT kernel): per wave a [32][64] f32 staging tile, rows = output rows n, 64 output columns k
+    constexpr int ESTRIDE = 272;
+    char* est = smem + wave * (32 * ESTRIDE);
+    GemmArgs ge = g;
+    ge.C = g.C + (long)blockIdx.y * g.splitk_stride;
+    const ChanVec8 cv = load_chanvec8(ge, k0 + wc * 64 + (lane & 7) * 8);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int efr = lane & 31, efh = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+                *reinterpret_cast<f32x4*>(est + efr * ESTRIDE + (ni * 32 + 8 * q + 4 * efh) * 4) = v;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rl = (lane >> 3) + 8 * it, cl = (lane & 7) * 8;
+            const int m = n0 + wr * 64 + mi * 32 + rl;
+            const int n = k0 + wc * 64 + cl;
+            float v[8];
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(est + rl * ESTRIDE + cl * 4);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(est + rl * ESTRIDE + cl * 4 + 16);
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            epilogue_store8(ge, cv, v, n, (long)m * g.ldc + n, true);
+        }
+    }
+}
+
 template <bool BF16, int WM, int WN, bool CONV>
 int launch(const GemmArgs& g, hipStream_t s, int splits = 1) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -313,6 +451,48 @@ extern "C" int sgg_gemm_splitk(const void* A, int lda, const void* W, int ldw, c
     else
         hipLaunchKernelGGL(splitk_reduce_kernel<float>, grid, blk, 0, s, workspace, splits, MN, N, bias, act, post_scale, post_shift, (float*)C);
     SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+// C[N, K] = A[Mred, N]^T . B[Mred, K]  (bf16 in, f32 or bf16 out): the weight-gradient contraction without transposed
+// copies of its operands.  Mred % 64 == 0, N % 128 == 0, K % 128 == 0, lda/ldb/ldc multiples of 8.  splits > 1: the
+// reduction rows are split over `splits` workgroups per tile, partial sums in workspace f32[splits, N, K], then one reduce.
+extern "C" int sgg_gemm_tn(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int Mred, int N, int K,
+                           int out_dtype, int splits, float* workspace, void* stream) {
+    if (out_dtype != SGG_F32 && out_dtype != SGG_BF16) return SGG_ERR_DTYPE;
+    if (!A || !B || !C || Mred <= 0 || N <= 0 || K <= 0 || (Mred & 63) || (N & 127) || (K & 127) || lda < N || ldb < K ||
+        ldc < K || ((lda | ldb | ldc) & 7) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) || splits < 1 ||
+        splits > Mred / 64 || (splits > 1 && (!workspace || ldc != K)))
+        return SGG_ERR_ARG;
+    GemmArgs g{};
+    g.A = (const char*)A; g.Wt = (const char*)B;
+    g.lda_b = (long)lda * 2; g.ldw_b = (long)ldb * 2;
+    g.nt = Mred / 64; g.nt1 = g.nt;
+    g.M = N; g.N = K; g.act = SGG_ACT_NONE;
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int smem = 2 * 4 * 64 * ROWB;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_tile_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return SGG_ERR_LAUNCH;
+        attr_done = true;
+    }
+    if (splits == 1) {
+        g.C = (char*)C; g.ldc = ldc; g.out_bf16 = out_dtype == SGG_BF16;
+    } else {
+        g.C = (char*)workspace; g.ldc = K; g.out_bf16 = 0; g.splitk_stride = (long)N * K * 4;
+    }
+    hipLaunchKernelGGL(mfma_tile_tn_kernel, dim3((N / 128) * (K / 128), splits), dim3(256), smem, s, g);
+    SGG_CHECK_LAUNCH();
+    if (splits > 1) {
+        const long MN = (long)N * K;
+        const dim3 grid((unsigned)((MN / 8 + 255) / 256)), blk(256);
+        if (out_dtype == SGG_BF16)
+            hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, grid, blk, 0, s, workspace, splits, MN, K, (const float*)nullptr, SGG_ACT_NONE, (const float*)nullptr, (const float*)nullptr, (bf16_t*)C);
+        else
+            hipLaunchKernelGGL(splitk_reduce_kernel<float>, grid, blk, 0, s, workspace, splits, MN, K, (const float*)nullptr, SGG_ACT_NONE, (const float*)nullptr, (const float*)nullptr, (float*)C);
+        SGG_CHECK_LAUNCH();
+    }
     return SGG_OK;
 }
 

@@ -61,6 +61,37 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     if (w == 0 && c < N) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// column sums with 16-byte loads: 8 lanes x 8 columns per block column, 32 row lanes (N % 8 == 0, ld % 8 == 0, 16-byte base)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum8_kernel(const T* __restrict__ x, int M, int N, int ld, float* __restrict__ out,
+                                                      int rows_per_block) {
+    __shared__ float red[32][65];
+    const int cl = (threadIdx.x & 7) * 8, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = 0.f;
+    if (c < N) {
+#pragma unroll 4
+        for (int r = r0 + rl; r < r1; r += 32) {
+            float v[8];
+            load8(x + (long)r * ld + c, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += v[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[rl][cl + k] = s[k];
+    __syncthreads();
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < N) {
+        float a = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) a += red[k][threadIdx.x];
+        atomicAdd(&out[blockIdx.x * 64 + threadIdx.x], a);
+    }
+}
+
 // per-channel sums for BatchNorm: out[0][c] = sum x, out[1][c] = sum x*y  (y == x for statistics: sum x^2;
 // y = xhat-source for the backward reductions).  Same decomposition as colsum.
 template <typename T, typename T2>
@@ -767,8 +798,13 @@ extern "C" int sgg_colsum(const void* x, int M, int N, int ld, float* out /*zero
     int rpb;
     const int split = split_rows(M, rpb);
     const dim3 grid((N + 63) / 64, split), blk(256);
-    DISPATCH2(dtype, hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)x, M, N, ld, out, rpb),
-              hipLaunchKernelGGL(colsum_kernel<float>, grid, blk, 0, s, (const float*)x, M, N, ld, out, rpb));
+    if ((N & 7) == 0 && (ld & 7) == 0 && ((uintptr_t)x & 15) == 0) {
+        DISPATCH2(dtype, hipLaunchKernelGGL(colsum8_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)x, M, N, ld, out, rpb),
+                  hipLaunchKernelGGL(colsum8_kernel<float>, grid, blk, 0, s, (const float*)x, M, N, ld, out, rpb));
+    } else {
+        DISPATCH2(dtype, hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)x, M, N, ld, out, rpb),
+                  hipLaunchKernelGGL(colsum_kernel<float>, grid, blk, 0, s, (const float*)x, M, N, ld, out, rpb));
+    }
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

@@ -206,6 +206,30 @@ def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None
     return out
 
 
+def gemm_tn_ok(A, B):
+    """Shapes / dtypes sgg_gemm_tn takes (bf16, reduction rows % 64, both column counts % 128, 16-byte aligned rows)."""
+    return (A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.shape[0] == B.shape[0] and A.shape[0] % 64 == 0 and
+            A.shape[1] % 128 == 0 and B.shape[1] % 128 == 0 and A.stride(1) == 1 and B.stride(1) == 1 and
+            A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
+
+
+def gemm_tn(A, B, out_dtype=torch.float32, out=None, splits=None):
+    """A[Mred,N]^T . B[Mred,K] -> [N,K]: the weight gradient dW = dY^T X without transposed copies of dY and X."""
+    Mred, N = A.shape
+    K = B.shape[1]
+    if out is None:
+        out = torch.empty((N, K), dtype=out_dtype, device=A.device)
+    tiles = (N // 128) * (K // 128)
+    if splits is None:
+        splits = 1
+        if tiles < 256:                       # few output tiles, long reduction: split it so that the chip is full
+            splits = max(1, min(16, 512 // tiles, Mred // 256))
+    ws = torch.empty((splits, N, K), dtype=torch.float32, device=A.device) if splits > 1 else None
+    _lib.call('sgg_gemm_tn', _p(A, rows_ok=True), A.stride(0), _p(B, rows_ok=True), B.stride(0), _p(out, rows_ok=True),
+              out.stride(0), Mred, N, K, dt(out), splits, _p(ws) if ws is not None else None, _stream())
+    return out
+
+
 # ---------------------------------------------------------------- a-8 / a-9
 def imp_node_gate_dots(v, gate_w):
     N, H = v.shape

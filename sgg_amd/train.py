@@ -46,6 +46,10 @@ def _pad_cols(x, mult, dtype):
 def tn_gemm(X, Y, out=None, want_colsum=False, out_dtype=torch.float32):
     """X[M,a]^T . Y[M,b] -> f32 [a,b]  (weight gradients).  Rows are zero-padded to a multiple of 64 by the transposes.
     want_colsum: also return colsum(X) (the bias gradient when X = dY), computed inside X's transpose pass."""
+    if out is None and ops.gemm_tn_ok(X, Y):
+        # bf16, aligned shapes: the TN kernel reads dY and X as they lie (no transposed copies); bias gradient = colsum(dY)
+        dw = ops.gemm_tn(X, Y, out_dtype=out_dtype)
+        return (dw, ops.colsum(X)) if want_colsum else dw
     if want_colsum:
         xt, cs = ops.transpose(X, want_colsum=True)
         return ops.gemm(xt, ops.transpose(Y), out_dtype=out_dtype, out=out), cs

@@ -493,3 +493,23 @@ def test_eval_tail_sizes_sorted_and_permutation(ops, E):
     for i in np.nonzero(~same)[0]:      # a mismatching row must sit in a near-tie
         gaps = [abs(float(ref_score[i]) - float(ref_score[j])) for j in (i - 1, i + 1) if 0 <= j < E]
         assert min(gaps) <= 2e-6 * float(ref_score[i])
+
+
+@pytest.mark.parametrize('shape', [(64, 128, 128), (256, 256, 384), (7936, 512, 256), (1024, 1536, 512)])
+@pytest.mark.parametrize('out_dtype', [torch.float32, torch.bfloat16])
+def test_gemm_tn_matches_transposed_product(ops, shape, out_dtype):
+    """sgg_gemm_tn (reduction rows staged as they lie, ds_read_b64_tr_b16 fragments) == A^T . B, single pass and split-K."""
+    Mred, N, K = shape
+    g = torch.Generator().manual_seed(Mred + N)
+    A = (torch.randn(Mred, N, generator=g) / 4).to(torch.bfloat16)
+    B = torch.randn(Mred, K, generator=g).to(torch.bfloat16)
+    ref = A.float().t() @ B.float()
+    assert ops.gemm_tn_ok(cu(A), cu(B)) and not ops.gemm_tn_ok(cu(A[:, :100]), cu(B))
+    for splits in (1, None, min(4, Mred // 64)):
+        got = ops.gemm_tn(cu(A), cu(B), out_dtype=out_dtype, splits=splits)
+        tol = dict(atol=2e-3 * (Mred ** 0.5), rtol=1e-4) if out_dtype == torch.float32 else dict(atol=0.02 * (Mred ** 0.5), rtol=2e-2)
+        torch.testing.assert_close(got.float().cpu(), ref, **tol)
+    # strided operands: column blocks of wider matrices
+    wide = torch.randn(Mred, N + 128, generator=g).to(torch.bfloat16)
+    got = ops.gemm_tn(cu(wide)[:, 128:], cu(B), out_dtype=torch.float32, splits=1)
+    torch.testing.assert_close(got.cpu(), wide[:, 128:].float().t() @ B.float(), atol=2e-3 * (Mred ** 0.5), rtol=1e-4)
