@@ -127,6 +127,21 @@ class PredictFn(torch.autograd.Function):
             bn1.num_batches_tracked += 1
             bn2.num_batches_tracked += 1
         sv.update(patches=patches, h1=h1, h2=h2, arg=arg, m1=m1, is1=is1, h3=h3, m2=m2, is2=is2, rect=rect)
+        # (edge_feat + conv(rects))^T, the X operand of fc6's weight gradient, depends on forward data only: its 0.25 ms of
+        # HBM-bound transposing runs NOW on the node lane's stream, under the MFMA-bound fc6 GEMMs below, instead of on the
+        # backward's critical path.  The buffer is allocated under that stream and handed back to it when sv is dropped.
+        from .imp import node_lane
+        lane = node_lane(dev)
+        if lane is not None and dt == torch.bfloat16:
+            side, ev_main, _ = lane
+            ev_main.record(torch.cuda.current_stream(dev))
+            side.wait_event(ev_main)                                 # ef and rect are ready
+            with torch.cuda.stream(side):
+                PPs = model.pool_sz ** 2
+                sv['x6t'] = ops.transpose(ef, add=rect.float() if rect.dtype != torch.float32 else rect, group=PPs)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            sv['x6t_ready'] = ev
         # ---- nodes: obj_unary(roi_fmap_obj(node_feat))  (Linear ReLU Dropout Linear ReLU Dropout)
         _lib.set_tag('fc6_obj')
         x6 = ops.gemm(nf, w['fc6_obj'], w['fc6_obj_b'], ops.ACT_RELU)
@@ -286,7 +301,11 @@ class PredictFn(torch.autograd.Function):
         # ---- phase B: the two fc6 weight gradients
         _lib.set_tag('bwd_fc6_edge_dW')
         # d W6[n,(c,p)] = sum_e d_pre6[e,n] * (edge_feat[e,c,p] + rect[e,c]): the folded term rides in the transpose
-        x6t = ops.transpose(sv['ef'], add=sv['rect'].float() if sv['rect'].dtype != torch.float32 else sv['rect'], group=PP)
+        if 'x6t' in sv:
+            torch.cuda.current_stream(dev).wait_event(sv['x6t_ready'])
+            x6t = sv['x6t']
+        else:
+            x6t = ops.transpose(sv['ef'], add=sv['rect'].float() if sv['rect'].dtype != torch.float32 else sv['rect'], group=PP)
         d6t, G['roi_fmap.1.0.bias'] = ops.transpose(d_pre6, want_colsum=True)
         G['roi_fmap.1.0.weight'] = ops.gemm(d6t, x6t, out_dtype=big_dtype())
         hook('roi_fmap.1.0.weight')
