@@ -163,7 +163,7 @@ def main():
     batch = tuple(batch)
 
     from sgg_amd.trainer import Trainer
-    trainer = Trainer(model, lr=1e-3, force_dist=args.force_dist) if args.mode == 'train' else None
+    trainer = Trainer(model, lr=1e-3, force_dist=args.force_dist, pipeline=os.environ.get('SGG_PIPELINE', '1') != '0') if args.mode == 'train' else None
 
     def infer_step():
         model.eval()
@@ -208,6 +208,7 @@ def main():
                 trainer.opt.zero_grad()
                 loss.backward()
                 trainer.opt.step()
+            trainer.flush()
             # rank 0 alone runs these extra steps: no collective may be issued (the other ranks wait at the barrier)
             saved_hook, saved_bn, trainer.world = getattr(model, '_grad_ready_hook', None), getattr(model, '_bn_sync', None), 1
             model._grad_ready_hook = model._bn_sync = None

@@ -30,6 +30,10 @@ class RelModelStanford(RelModelBase):
         """Device operands derived from the fp32 master parameters, cached until a parameter changes: casts to the
         compute dtype, plus W6sum[n,c] = sum_p W6[n,c,p] -- the 512 extra K columns that fold `union_pools + conv(rects)`
         (lib/get_union_boxes.py:101) into fc6 by linearity: fc6(x + r (x) 1_49) = fc6(x) + W6sum r."""
+        ev = getattr(self, '_operands_ready', None)     # a trainer may have queued an update / rebuild on its side stream
+        if ev is not None:
+            torch.cuda.current_stream(self.rel_fc.weight.device).wait_event(ev)
+            self._operands_ready = None
         dtype = self.compute_dtype
         params = [p for n, p in self.named_parameters() if not n.startswith('detector.')]
         key = (dtype, getattr(self, 'weights_version', 0)) + tuple((p.data_ptr(), p._version) for p in params)

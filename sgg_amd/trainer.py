@@ -89,7 +89,7 @@ class Trainer(object):
     """One data-parallel train step.  `loss_type` as lib/losses.py ('baseline' is the reference default, config.py:184)."""
 
     def __init__(self, model, lr=1e-3, momentum=0.9, weight_decay=1e-4, clip=5.0, loss_type='baseline',
-                 comm_dtype=torch.bfloat16, force_dist=False, sync_bn=True):
+                 comm_dtype=torch.bfloat16, force_dist=False, sync_bn=True, pipeline=False):
         self.model = model
         for n, p in model.named_parameters():
             if n.startswith('detector.'):
@@ -101,6 +101,12 @@ class Trainer(object):
             self.opt.shadow_of = model.shadow_buffers
         self.buckets = GradBuckets([p for _, p in named], comm_dtype=comm_dtype, force=force_dist)
         self.loss_type = loss_type
+        # pipeline=True: the optimiser update of step k (HBM-bound, ~1.1 ms) and the rebuild of the weight-derived operands
+        # run on the side stream UNDER the frozen VGG forward of step k+1 (MFMA-bound, ~2 ms), which does not read the
+        # weights being updated (main.py:62-63: the detector is frozen).  The head of step k+1 waits for the event.
+        # Every update still happens, in order; read parameters through flush() in this mode.
+        self.pipeline = pipeline
+        self._queued = False
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         # force_dist: run the distributed code path on a 1-rank group too (tests exercise RCCL plumbing on one GPU)
         self.dist_on = self.world > 1 or (force_dist and dist.is_available() and dist.is_initialized())
@@ -174,14 +180,45 @@ class Trainer(object):
             ev.record(side)
         self.model._operands_ready = ev
 
+    def flush(self):
+        """Make the current stream wait for a queued optimiser update (pipeline mode) before parameters are read."""
+        ev = getattr(self.model, '_operands_ready', None)
+        if ev is not None:
+            torch.cuda.current_stream(next(self.model.parameters()).device).wait_event(ev)
+
+    def _queue_update(self, reduced):
+        """pipeline mode: optimiser step + operand rebuild on the side stream, after everything this step queued."""
+        from .imp import node_lane
+        from .train import train_weights
+        dev = next(self.model.parameters()).device
+        lane = node_lane(dev)
+        if lane is None:
+            return False
+        side = lane[0]
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for g in self.opt.groups:                      # gradients were allocated on the main stream: keep their memory
+                t = (reduced or {}).get(g['p'], g['p'].grad)   # from being recycled there while the side stream reads it
+                if t is not None:
+                    t.record_stream(side)
+            self.opt.step(grads=reduced)
+            train_weights(self.model)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self.model._operands_ready = ev
+        return True
+
     def step(self, batch):
         self.model.train()
-        self._prefetch_operands()
+        if not self._queued:
+            self._prefetch_operands()
         res = self.model([batch])
         loss = self.losses(res)
         self.opt.zero_grad()
         loss.backward()
         reduced = self.buckets.all_reduce(average=False) if self.dist_on else None
-        self.opt.step(grads=reduced)
+        self._queued = self.pipeline and self._queue_update(reduced)
+        if not self._queued:
+            self.opt.step(grads=reduced)
         self.model.global_batch_iter = getattr(self.model, 'global_batch_iter', 0) + 1
         return loss.detach()
