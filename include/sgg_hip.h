@@ -252,7 +252,8 @@ int sgg_sgd_step(float* p, const void* g, float* momentum_buf, int64_t n, float 
 int sgg_sqnorm_multi(const void* const* g, const int64_t* n, int count, float* acc, int dtype, void* stream);
 int sgg_sgd_multi(float* const* p, const void* const* g, float* const* momentum_buf, void* const* shadow,
                   const int64_t* n, const float* lr, int count, float weight_decay, float momentum, int first_step,
-                  const float* norm_sq, float max_norm, float grad_scale, int g_dtype, void* stream);
+                  const float* norm_sq, float max_norm, float grad_scale, int g_dtype, int max_blocks /* 0: default 512 */,
+                  void* stream);
 
 /* ---- utilities used by the host for weight preparation (load time, not on the step path) ---- */
 int sgg_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, void* stream);

@@ -62,7 +62,7 @@ SIGNATURES = {
     'sgg_recall_first_match': [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _F, _I, _P, _P, _P],
     'sgg_gemm_tn': [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     'sgg_sqnorm_multi': [_P, _P, _I, _P, _I, _P],
-    'sgg_sgd_multi': [_P, _P, _P, _P, _P, _P, _I, _F, _F, _I, _P, _F, _F, _I, _P],
+    'sgg_sgd_multi': [_P, _P, _P, _P, _P, _P, _I, _F, _F, _I, _P, _F, _F, _I, _I, _P],
     'sgg_transpose': [_P, _L, _P, _L, _I, _I, _P, _L, _I, _P, _I, _I, _P],
     'sgg_group_sum': [_P, _L, _P, _L, _I, _I, _I, _I, _P],
     'sgg_add': [_P, _P, _L, _I, _I, _P],

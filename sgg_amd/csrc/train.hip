@@ -1023,7 +1023,7 @@ extern "C" int sgg_sqnorm_multi(const void* const* g, const int64_t* n, int coun
 extern "C" int sgg_sgd_multi(float* const* p, const void* const* g, float* const* momentum_buf, void* const* shadow,
                              const int64_t* n, const float* lr, int count, float weight_decay, float momentum,
                              int first_step, const float* norm_sq, float max_norm, float grad_scale, int g_dtype,
-                             void* stream) {
+                             int max_blocks, void* stream) {
     if (count == 0) return SGG_OK;
     if (!p || !g || !momentum_buf || !n || !lr || count < 0) return SGG_ERR_ARG;
     for (int i = 0; i < count; ++i) {
@@ -1038,7 +1038,9 @@ extern "C" int sgg_sgd_multi(float* const* p, const void* const* g, float* const
         MultiTab tab;
         const int chunks = mt_fill(tab, lo, min(count, lo + MT_MAX), g, p, momentum_buf, shadow, n, lr);
         if (!chunks) continue;
-        const dim3 grid((unsigned)min(chunks, 4096));
+        // few, fat workgroups (12 float4 loads in flight per thread): 512 already stream at full bandwidth, and leave wave
+        // slots for the kernels of another stream (the trainer's pipeline mode asks for 256: the VGG forward runs beside it)
+        const dim3 grid((unsigned)min(chunks, max_blocks > 0 ? max_blocks : 512));
         DISPATCH2(g_dtype,
             hipLaunchKernelGGL(sgd_multi_kernel<bf16_t>, grid, dim3(256), 0, s, tab, weight_decay, momentum, first_step, norm_sq, max_norm, grad_scale),
             hipLaunchKernelGGL(sgd_multi_kernel<float>, grid, dim3(256), 0, s, tab, weight_decay, momentum, first_step, norm_sq, max_norm, grad_scale));

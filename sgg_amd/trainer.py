@@ -27,6 +27,7 @@ class FusedSGD(object):
         self.steps = 0
         self._norm = None
         self.on_update = None
+        self.max_blocks = 0        # workgroups of the update kernel (0: library default); the pipelined trainer lowers it
         self.shadow_of = None      # callable -> {param name: compute-dtype buffer the update should also write}
         self.wrote_shadow = []
 
@@ -75,7 +76,7 @@ class FusedSGD(object):
         for dtype, gp, pp, bp, sp, nn, lr, cnt in pending:  # every norm contribution lands before the first update
             _lib.call('sgg_sgd_multi', pp.ctypes.data, gp.ctypes.data, bp.ctypes.data, sp.ctypes.data, nn.ctypes.data,
                       lr.ctypes.data, cnt, float(self.weight_decay), float(self.momentum), int(first), norm,
-                      float(self.clip or 0.0), float(grad_scale), ops.dt(dtype), stream)
+                      float(self.clip or 0.0), float(grad_scale), ops.dt(dtype), int(self.max_blocks), stream)
         self.wrote_shadow = [n for n in shadows if any(g['name'] == n for g in live)]
         self.steps += 1
         if self.on_update is not None:
@@ -106,6 +107,8 @@ class Trainer(object):
         # weights being updated (main.py:62-63: the detector is frozen).  The head of step k+1 waits for the event.
         # Every update still happens, in order; read parameters through flush() in this mode.
         self.pipeline = pipeline
+        if pipeline:
+            self.opt.max_blocks = 256      # leave wave slots for the VGG forward running beside the update
         self._queued = False
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         # force_dist: run the distributed code path on a 1-rank group too (tests exercise RCCL plumbing on one GPU)
