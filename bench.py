@@ -13,6 +13,10 @@ throughput is reported alongside under "other_mode".
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype bf16|f32] [--mode train|infer]
 """
+import os
+
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # before the HIP runtime starts: see sgg_amd/__init__.py
+
 import argparse
 import json
 import os
@@ -163,7 +167,7 @@ def main():
     batch = tuple(batch)
 
     from sgg_amd.trainer import Trainer
-    trainer = Trainer(model, lr=1e-3, force_dist=args.force_dist, pipeline=os.environ.get('SGG_PIPELINE', '1') != '0') if args.mode == 'train' else None
+    trainer = Trainer(model, lr=1e-3, force_dist=args.force_dist, pipeline=os.environ.get('SGG_PIPELINE', '1') != '0', sync_bn=os.environ.get('SGG_SYNC_BN', '1') != '0') if args.mode == 'train' else None
 
     def infer_step():
         model.eval()

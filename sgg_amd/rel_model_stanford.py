@@ -26,6 +26,15 @@ class RelModelStanford(RelModelBase):
             setattr(self, g, nn.Sequential(nn.Linear(hidden_dim * 2, 1), nn.Sigmoid()))
 
     # ------------------------------------------------------------------ weights in kernel layout
+    def head_named_parameters(self):
+        """[(name, parameter)] of everything but the detector, cached: walking the module tree (named_parameters /
+        state_dict) costs ~1 ms of Python per call, and the train step asks several times."""
+        cache = self.__dict__.get('_head_named')
+        if cache is None:
+            cache = [(n, p) for n, p in self.named_parameters() if not n.startswith('detector.')]
+            self.__dict__['_head_named'] = cache
+        return cache
+
     def prepared(self):
         """Device operands derived from the fp32 master parameters, cached until a parameter changes: casts to the
         compute dtype, plus W6sum[n,c] = sum_p W6[n,c,p] -- the 512 extra K columns that fold `union_pools + conv(rects)`
@@ -35,7 +44,7 @@ class RelModelStanford(RelModelBase):
             torch.cuda.current_stream(self.rel_fc.weight.device).wait_event(ev)
             self._operands_ready = None
         dtype = self.compute_dtype
-        params = [p for n, p in self.named_parameters() if not n.startswith('detector.')]
+        params = [p for _, p in self.head_named_parameters()]
         key = (dtype, getattr(self, 'weights_version', 0)) + tuple((p.data_ptr(), p._version) for p in params)
         if self._prep.get('key') == key:
             return self._prep['val']
@@ -54,7 +63,7 @@ class RelModelStanford(RelModelBase):
             w[name + '_b'] = f(mod.bias)
         w['fc6_obj_b'] = f(self.roi_fmap_obj[0].bias)
         w['fc6_edge_b'] = f(self.roi_fmap[1][0].bias)
-        sd = {k: v for k, v in self.state_dict().items() if 'gru' in k or 'w_fc' in k}
+        sd = {k: v for k, v in self.head_named_parameters() if 'gru' in k or 'w_fc' in k}
         w['imp'] = ImpWeights.from_state(sd, dtype)
         self._prep = dict(key=key, val=w)
         return w
@@ -90,7 +99,7 @@ class RelModelStanford(RelModelBase):
 
     def mark_shadow_fresh(self, names):
         """The optimiser just wrote these shadows from the updated masters (call after weights_version moved)."""
-        params = dict(self.named_parameters())
+        params = dict(self.head_named_parameters())
         for n in names:
             if n in params and n in self._shadow:
                 self._shadow_tags[n] = self._shadow_tag(params[n])

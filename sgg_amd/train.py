@@ -349,7 +349,7 @@ class PredictFn(torch.autograd.Function):
         G['union_boxes.conv.0.bias'] = gb1
         _lib.set_tag('')
         ctx.sv = None
-        shapes = dict(model.named_parameters())
+        shapes = dict(model.head_named_parameters())
         # gradients already handed to the all-reduce in the wire dtype are not returned to autograd (no fp32 copy)
         grads = [None if n in handed else G[n].reshape(shapes[n].shape) for n in param_names(model)]
         return (None,) * 8 + tuple(grads)
@@ -361,7 +361,7 @@ def predict_train(model, node_feat, edge_feat, rel_inds, rois, im_inds=None, see
     N, E = node_feat.shape[0], edge_feat.shape[0]
     if seed is None:
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-    named = dict(model.named_parameters())
+    named = dict(model.head_named_parameters())
     params = [named[n] for n in param_names(model)]
     return PredictFn.apply(model, node_feat.reshape(N, -1), edge_feat.reshape(E, -1), rois.float().contiguous(),
                            rel_inds.contiguous(), im_inds, seed, float(dropout_p), *params)

@@ -189,8 +189,10 @@ class Trainer(object):
         if ev is not None:
             torch.cuda.current_stream(next(self.model.parameters()).device).wait_event(ev)
 
-    def _queue_update(self, reduced):
-        """pipeline mode: optimiser step + operand rebuild on the side stream, after everything this step queued."""
+    def _queue_update(self):
+        """pipeline mode: wait for the gradient all-reduce, optimiser step and operand rebuild, all on the side stream
+        and after everything this step queued -- the main stream goes straight on to the next step's VGG forward, so
+        the tail of the all-reduce hides under it as well."""
         from .imp import node_lane
         from .train import train_weights
         dev = next(self.model.parameters()).device
@@ -201,9 +203,11 @@ class Trainer(object):
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for g in self.opt.groups:                      # gradients were allocated on the main stream: keep their memory
-                t = (reduced or {}).get(g['p'], g['p'].grad)   # from being recycled there while the side stream reads it
-                if t is not None:
-                    t.record_stream(side)
+                if g['p'].grad is not None:                # from being recycled there while the side stream reads it
+                    g['p'].grad.record_stream(side)
+            reduced = self.buckets.all_reduce(average=False) if self.dist_on else None
+            for t in (reduced or {}).values():
+                t.record_stream(side)
             self.opt.step(grads=reduced)
             train_weights(self.model)
             ev = torch.cuda.Event()
@@ -219,9 +223,9 @@ class Trainer(object):
         loss = self.losses(res)
         self.opt.zero_grad()
         loss.backward()
-        reduced = self.buckets.all_reduce(average=False) if self.dist_on else None
-        self._queued = self.pipeline and self._queue_update(reduced)
+        self._queued = self.pipeline and self._queue_update()
         if not self._queued:
+            reduced = self.buckets.all_reduce(average=False) if self.dist_on else None
             self.opt.step(grads=reduced)
         self.model.global_batch_iter = getattr(self.model, 'global_batch_iter', 0) + 1
         return loss.detach()
