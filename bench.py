@@ -304,7 +304,8 @@ def main():
                        'mode': args.mode, 'images_per_gpu': B, 'global_batch': world * B,
                        'parallelism': 'image-sharded dp%d, %s' % (world, 'RCCL gradient all-reduce (bf16 on the wire)'
                                                                   if args.mode == 'train' else 'no collective'),
-                       'weights': 'random init (He), frozen VGG16 + trainable IMP head (247.75 M params)'},
+                       'weights': 'random init (He), frozen VGG16 + trainable IMP head (247.75 M params)',
+                       'pipeline': 'optimiser update of step k runs on a side stream under the frozen VGG forward of step k+1 (every update inside the timed region)'},
             'roofline': {'kernel': '256x256 ping-pong MFMA kernel, %s' % desc, 'bound': 'mfma', 'achieved': round(tf, 2), 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': round(tf / peak, 4),
                          'traffic': pmc_traffic('fc6_edge_gemm' if tag == 'fc6_edge' else 'fc6_dW_gemm') if (B == 8 and args.dtype == 'bf16') else None,
