@@ -235,6 +235,14 @@ class PredictFn(torch.autograd.Function):
             """Y = X W^T + b : returns dX now; dW (f32 [N,K]) and db are computed in phase C."""
             def dw():
                 _lib.set_tag(tag)
+                n_out = dY.shape[1]
+                if n_out % 128 and dt == torch.bfloat16 and not big:
+                    # narrow heads (151 / 51 outputs): zero-pad dY to 128 columns so that the TN kernel takes it
+                    dYp = _pad_cols(dY, 128, dt)
+                    if ops.gemm_tn_ok(dYp, X):
+                        G[name + '.weight'] = ops.gemm_tn(dYp, X)[:n_out].contiguous()
+                        G[name + '.bias'] = ops.colsum(dYp)[:n_out].contiguous()
+                        return
                 G[name + '.weight'], G[name + '.bias'] = tn_gemm(dY, X, want_colsum=True,
                                                                  out_dtype=big_dtype() if big else torch.float32)
                 if big:
