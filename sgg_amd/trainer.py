@@ -144,7 +144,13 @@ class Trainer(object):
         n_obj, M = float(res.rm_obj_labels.shape[0]), float(labels.shape[0])
         if self.loss_type == 'baseline':
             if self.world > 1:
-                n_obj, M = sum_over_ranks([n_obj, M], device=res.rel_dists.device)
+                # global normalisers stay on the device (fill_ = a launch, no host round trip): a .tolist() here would
+                # stall the host between forward and backward on every rank
+                t = torch.empty(2, dtype=torch.float32, device=res.rel_dists.device)
+                t[0].fill_(n_obj)
+                t[1].fill_(M)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                return obj_ce / t[0] + rel_ce.sum() / t[1]
             return obj_ce / n_obj + rel_ce.sum() / M                                 # lib/losses.py:41-42,74
         fg = labels > 0
         m_fg, m_bg = float(fg.sum().item()), float((~fg).sum().item())
