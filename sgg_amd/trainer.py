@@ -143,7 +143,7 @@ class Trainer(object):
         rel_ce = F.cross_entropy(res.rel_dists, labels, reduction='none')
         n_obj, M = float(res.rm_obj_labels.shape[0]), float(labels.shape[0])
         if self.loss_type == 'baseline':
-            if self.world > 1:
+            if self.dist_on:
                 # global normalisers stay on the device (fill_ = a launch, no host round trip): a .tolist() here would
                 # stall the host between forward and backward on every rank
                 t = torch.empty(2, dtype=torch.float32, device=res.rel_dists.device)
