@@ -163,7 +163,9 @@ def main():
     # images sharded by rank: rank r owns global images [r*B, (r+1)*B)  (seed differs per rank)
     batch = list(synthetic_batch(B=B, S=592, n_boxes=32, n_fg=6, seed=111 + rank))
     batch[0] = [im.to(dev) for im in batch[0]]          # inputs resident in HBM before the timed region
-    batch[3], batch[4], batch[5] = batch[3].to(dev), batch[4].to(dev), batch[5].to(dev)
+    from sgg_amd.rel_model_base import to_device_with_mirror
+    # the index tensors keep their host originals as mirrors (as a Blob keeps its chunk sizes): no D2H sync inside the step
+    batch[3], batch[4], batch[5] = batch[3].to(dev), to_device_with_mirror(batch[4], dev), to_device_with_mirror(batch[5], dev)
     batch = tuple(batch)
 
     from sgg_amd.trainer import Trainer

@@ -174,6 +174,8 @@ class DeviceStager(object):
         out[0] = views[:len(imgs)]
         for k, i in enumerate(sorted(rest)):
             out[i] = views[len(imgs) + k]
+            if i in (4, 5):
+                out[i]._sgg_host = rest[i]     # host mirror of gt_classes / gt_rels (rel_model_base.host_of): no D2H sync later
         return tuple(out), slot
 
     def stage(self, batch):

@@ -29,6 +29,24 @@ def enumerate_by_image_host(im_inds_host):
     yield cur, s, len(im_inds_host)
 
 
+def to_device_with_mirror(t_host, device, non_blocking=True):
+    """Index tensors of the batch (gt_classes, gt_rels) are born on the host (dataloaders/blob.py builds them from numpy):
+    the device copy keeps a reference to its host original, so the forward's bookkeeping (boxes per image, number of
+    relation rows) reads the host copy instead of synchronising the stream for a D2H copy of data the host already has.
+    The mirror is only attached here and by DeviceStager; a tensor without one goes through the D2H path."""
+    t_dev = t_host.to(device, non_blocking=non_blocking)
+    t_dev._sgg_host = t_host
+    return t_dev
+
+
+def host_of(t):
+    """Host copy of a small index tensor: the attached mirror if there is one (same shape), else a synchronising D2H."""
+    m = getattr(t, '_sgg_host', None)
+    if m is not None and tuple(m.shape) == tuple(t.shape):
+        return m
+    return t.detach().to('cpu')
+
+
 def as_nchw_view(x_nhwc):
     return x_nhwc.permute(0, 3, 1, 2)
 
@@ -145,7 +163,7 @@ class RelModelBase(nn.Module):
         if self.mode == 'sgdet':
             return self._faster_rcnn_sgdet(x, gt_classes)
         dtype = self.compute_dtype
-        im_host = gt_classes[:, 0].detach().to('cpu').tolist()           # the one D2H sync of the forward
+        im_host = host_of(gt_classes)[:, 0].tolist()           # a D2H sync only when the batch carries no host mirror
         segs = list(enumerate_by_image_host(im_host))
         images = [x[i] for i, _, _ in segs]                              # :180 (x is indexed by image id)
         fmap, sizes, _ = self.detector.features(images, dtype)           # :183-184
@@ -249,8 +267,20 @@ class RelModelBase(nn.Module):
             cap = n_cand + R
             out, count = ops.pair_index_train(im_inds.long().contiguous(), gt_rels.long().contiguous(),
                                               torch.tensor(first, dtype=torch.int32).to(im_inds.device), cap)
-            # rows = candidates + (extra rows for duplicate FG relations on one pair); FG pairs replace a candidate
-            n = int(count.item())
+            # rows = candidates + (extra rows for duplicate FG relations on one pair); FG pairs replace a candidate.
+            # With a host mirror of gt_rels the count is computed here (R is a few dozen); otherwise read it back.
+            rels_host = getattr(gt_rels, '_sgg_host', None)
+            if rels_host is not None and tuple(rels_host.shape) == tuple(gt_rels.shape):
+                sizes = {i: e - s for i, s, e in segs}
+                fg_pairs, regular = set(), True
+                for im, s_, o_, _ in rels_host.tolist():
+                    if im in sizes and s_ != o_ and 0 <= s_ < sizes[im] and 0 <= o_ < sizes[im]:
+                        fg_pairs.add((im, s_, o_))
+                    else:
+                        regular = False          # self / out-of-range relation: let the device count decide
+                n = n_cand - len(fg_pairs) + R if regular else int(count.item())
+            else:
+                n = int(count.item())
             rel_labels = out[:n]
             # sub-sampling (lib/proposal_assignments_gtbox.py:47-66): at most RELS_PER_IMG*0.25*num_im FG rows and
             # RELS_PER_IMG*num_im rows in total (or num_fg*sample_factor BG rows).  random_choose is a uniform random

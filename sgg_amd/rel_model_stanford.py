@@ -4,7 +4,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 from .imp import GATES, ImpWeights, message_pass, node_lane
-from .rel_model_base import RelModelBase, to_rows
+from .rel_model_base import RelModelBase, to_device_with_mirror, to_rows
 
 
 class RelModelStanford(RelModelBase):
@@ -172,8 +172,10 @@ class RelModelStanford(RelModelBase):
         assert len(batch) == 1, ('single GPU is only supported in this code', len(batch))
         x, gt_boxes, gt_classes, gt_rels = batch[0][0], batch[0][3], batch[0][4], batch[0][5]
         dev = self.rel_fc.weight.device
-        gt_boxes, gt_classes = gt_boxes.to(dev), gt_classes.to(dev)
-        gt_rels = gt_rels.to(dev) if gt_rels is not None else None
+        # index tensors that arrive on the host keep a host mirror (no D2H sync later for data the host already has)
+        mv = lambda t: to_device_with_mirror(t, dev) if not t.is_cuda else t
+        gt_boxes, gt_classes = gt_boxes.to(dev), mv(gt_classes)
+        gt_rels = mv(gt_rels) if gt_rels is not None else None
         with torch.no_grad():
             result = self.faster_rcnn(x, gt_boxes, gt_classes, gt_rels)                  # :125-129
             result.fmap = result.fmap.detach()                                           # :131
