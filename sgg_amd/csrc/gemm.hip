@@ -257,7 +257,9 @@ __global__ __launch_bounds__(256) void mfma_tile_tn_kernel(const GemmArgs g) {
     const int rsel = ((p >> 2) & 1) + ((p >> 3) << 3);          // (0,1,8,9)[p>>2]
     const int nsplit = gridDim.y;
     const int kt0 = (int)((long)g.nt * blockIdx.y / nsplit), kt1 = (int)((long)g.nt * (blockIdx.y + 1) / nsplit);
-    const unsigned lds0 = (unsigned)(size_t)smem;
+    // workgroup-RELATIVE LDS byte offset for the ds_read asm: through an address_space(3) pointer.  (The low 32 bits of the
+    // generic pointer are only right for the first workgroup on a CU: a co-resident one got garbage.)
+    const unsigned lds0 = (unsigned)(unsigned long)(lds_void_t*)smem;
     stage(kt0, kt0 & 1);
     for (int kt = kt0; kt < kt1; ++kt) {
         const int buf = kt & 1;
@@ -286,7 +288,14 @@ __global__ __launch_bounds__(256) void mfma_tile_tn_kernel(const GemmArgs g) {
                     if (h == 0) { a_lo[i] = va; b_lo[i] = vb; } else { a_hi[i] = va; b_hi[i] = vb; }
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // the waitcnt TAKES the eight results as in/out operands: the compiler only sees register outputs of the asm reads
+            // and would otherwise be free to schedule a copy of them in front of this wait (it did, once two workgroups
+            // shared a CU and the copies were no longer coalesced away: garbage in, NaN out)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(a_lo[0]), "+v"(a_lo[1]), "+v"(a_hi[0]), "+v"(a_hi[1]), "+v"(b_lo[0]), "+v"(b_lo[1]), "+v"(b_hi[0]),
+                           "+v"(b_hi[1])
+                         :
+                         : "memory");
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll

@@ -495,7 +495,8 @@ def test_eval_tail_sizes_sorted_and_permutation(ops, E):
         assert min(gaps) <= 2e-6 * float(ref_score[i])
 
 
-@pytest.mark.parametrize('shape', [(64, 128, 128), (256, 256, 384), (7936, 512, 256), (1024, 1536, 512)])
+@pytest.mark.parametrize('shape', [(64, 128, 128), (256, 256, 384), (7936, 512, 256), (1024, 1536, 512),
+                                   (7936, 512, 4096), (512, 4096, 2048)])   # the last two: > 256 workgroups (two per CU)
 @pytest.mark.parametrize('out_dtype', [torch.float32, torch.bfloat16])
 def test_gemm_tn_matches_transposed_product(ops, shape, out_dtype):
     """sgg_gemm_tn (reduction rows staged as they lie, ds_read_b64_tr_b16 fragments) == A^T . B, single pass and split-K."""

@@ -15,7 +15,8 @@ __global__ void probe(unsigned short* out, int mode) {
         const int g = l >> 4, p = l & 15, r = p >> 2, q = p & 3;
         elem = r * 64 + g * 16 + 4 * q;
     }
-    unsigned addr = (unsigned)(size_t)(lds) + elem * 2;
+    // workgroup-relative LDS offset: via an address_space(3) pointer (NOT the low bits of the generic pointer)
+    unsigned addr = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned short*)lds + elem * 2;
     unsigned long long v;
     asm volatile("ds_read_b64_tr_b16 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
     for (int j = 0; j < 4; ++j) out[l * 4 + j] = (unsigned short)(v >> (16 * j));
