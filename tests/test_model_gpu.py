@@ -158,3 +158,51 @@ def test_train_relation_subsampling_keeps_order_and_caps(setup):
     finally:
         model.RELS_PER_IMG = old
         model.eval()
+
+
+def test_full_size_forward_fp32_matches_oracle_and_bf16_batch_is_sane():
+    """BASELINE-size inputs (592x592 frames, 32 boxes, 992 edges per image): one image in exact-fp32 mode against the
+    oracle within the 1e-3 bar, then the benchmark batch (8 images, bf16) through size-independent properties -- finite,
+    triple scores sorted, every image's 992 ordered pairs present exactly once."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import sgg_amd
+    from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls'))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV).eval()
+    b1 = synthetic_batch(B=1, S=592, n_boxes=32, n_fg=6, seed=77)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        ref = O.forward_gtbox(b1[0], b1[3], b1[4], b1[5], sd, mode='sgcls')
+    model.set_compute_dtype(torch.float32)
+    model.train()                                   # Result with the raw distributions (eval would only give the tuple)
+    model.dropout_p = 0.0
+    with torch.no_grad():
+        model.eval()
+        boxes, cls, scores, rels, pred_scores = model([b1])
+    rb, rc, rs, rr, rp = ref['dets']
+    np.testing.assert_allclose(scores, rs, atol=1e-3)
+    assert (cls == rc).all()
+    # same triples; rows are rank-ordered, so compare as {pair: scores} maps
+    got = {tuple(r): p for r, p in zip(rels.tolist(), pred_scores)}
+    exp = {tuple(r): p for r, p in zip(rr.tolist(), rp)}
+    assert got.keys() == exp.keys() and len(got) == 992
+    worst = max(float(np.abs(got[k] - exp[k]).max()) for k in exp)
+    assert worst <= 1e-3, worst
+    # the benchmark batch in bf16
+    model.set_compute_dtype(torch.bfloat16)
+    model.eval()
+    b8 = synthetic_batch(B=8, S=592, n_boxes=32, n_fg=6, seed=111)
+    with torch.no_grad():
+        boxes, cls, scores, rels, pred_scores = model([b8])
+    assert boxes.shape == (256, 4) and rels.shape == (7936, 2) and pred_scores.shape == (7936, 51)
+    assert np.isfinite(pred_scores).all() and np.isfinite(scores).all()
+    np.testing.assert_allclose(pred_scores.sum(1), 1.0, atol=2e-2)
+    trip = pred_scores[:, 1:].max(1) * scores[rels[:, 0]] * scores[rels[:, 1]]
+    assert (np.diff(trip) <= 1e-6).all()                                       # rank order of filter_dets
+    pairs = set(map(tuple, rels.tolist()))
+    assert len(pairs) == 7936 and all(s // 32 == o // 32 and s != o for s, o in pairs)
+    model.dropout_p = 0.5
+    del model
+    torch.cuda.empty_cache()
