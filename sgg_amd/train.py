@@ -43,10 +43,13 @@ def _pad_cols(x, mult, dtype):
     return buf
 
 
+USE_TN = True      # tests flip this to cross-check the TN kernel against the transposes + NT path at benchmark grid sizes
+
+
 def tn_gemm(X, Y, out=None, want_colsum=False, out_dtype=torch.float32):
     """X[M,a]^T . Y[M,b] -> f32 [a,b]  (weight gradients).  Rows are zero-padded to a multiple of 64 by the transposes.
     want_colsum: also return colsum(X) (the bias gradient when X = dY), computed inside X's transpose pass."""
-    if out is None and ops.gemm_tn_ok(X, Y):
+    if out is None and USE_TN and ops.gemm_tn_ok(X, Y):
         # bf16, aligned shapes: the TN kernel reads dY and X as they lie (no transposed copies); bias gradient = colsum(dY)
         dw = ops.gemm_tn(X, Y, out_dtype=out_dtype)
         return (dw, ops.colsum(X)) if want_colsum else dw
@@ -239,7 +242,7 @@ class PredictFn(torch.autograd.Function):
                 if n_out % 128 and dt == torch.bfloat16 and not big:
                     # narrow heads (151 / 51 outputs): zero-pad dY to 128 columns so that the TN kernel takes it
                     dYp = _pad_cols(dY, 128, dt)
-                    if ops.gemm_tn_ok(dYp, X):
+                    if USE_TN and ops.gemm_tn_ok(dYp, X):
                         G[name + '.weight'] = ops.gemm_tn(dYp, X)[:n_out].contiguous()
                         G[name + '.bias'] = ops.colsum(dYp)[:n_out].contiguous()
                         return
