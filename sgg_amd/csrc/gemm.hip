@@ -282,10 +282,15 @@ __global__ __launch_bounds__(256) void mfma_tile_tn_kernel(const GemmArgs g) {
                     const int row = 16 * s + 2 * (2 * kg + h) + rsel;
                     const int col = i * 32 + g16 * 16 + 4 * (p & 3);
                     const unsigned off = row * ROWB + ((((col >> 3) ^ ((row >> 1) & 7)) << 4) | (((col >> 2) & 1) << 3));
-                    unsigned long long va, vb;
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(va) : "v"(sa + off) : "memory");
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vb) : "v"(sb + off) : "memory");
-                    if (h == 0) { a_lo[i] = va; b_lo[i] = vb; } else { a_hi[i] = va; b_hi[i] = vb; }
+                    // outputs go STRAIGHT into the registers that the s_waitcnt below is tied to: no intermediate copy that
+                    // could be scheduled (and read stale data) before the wait
+                    if (h == 0) {
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a_lo[i]) : "v"(sa + off) : "memory");
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b_lo[i]) : "v"(sb + off) : "memory");
+                    } else {
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a_hi[i]) : "v"(sa + off) : "memory");
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b_hi[i]) : "v"(sb + off) : "memory");
+                    }
                 }
             }
             // the waitcnt TAKES the eight results as in/out operands: the compiler only sees register outputs of the asm reads
