@@ -283,6 +283,17 @@ int sgg_recall_first_match(const int32_t* gt_trip, const float* gt_box, const in
                            const int32_t* pred_pair, float iou_thresh, int phrdet, int32_t* first_rank, int32_t* pair_rank,
                            void* stream);
 
+/* ---- a-10 (optional flags -use_bias / -test_bias): FrequencyBias, lib/sparse_targets.py:26-31 (index_with_labels) as used at
+ * sgg_models/rel_model_stanford.py:159-177.  obj_preds i64[N] (out) = best class in 1..C-1 of softmax(obj_dists [N,C], `dtype`),
+ * or gt_classes i64[N] when that is not NULL (predcls, :166-167; obj_dists may then be NULL).  rel_out f32[E,P] =
+ * table[obj_preds[subj]*C + obj_preds[obj], :] (+ rel_in f32[E,P] unless NULL = the test_bias form, :173-174); table f32[C*C,P] is
+ * the embedding weight.  row_idx i32[E] (optional out) = the table row of each edge, the input of the backward:
+ * d_table[row_idx[e], :] += d_out[e, :] (d_table zeroed by the caller; d rel_in = d_out). */
+int sgg_freq_bias_fwd(const void* obj_dists, int N, int C, const int64_t* gt_classes, const int64_t* rel_inds /*[E,3]*/, int E,
+                      const float* table, int P, const float* rel_in, float* rel_out, int64_t* obj_preds, int32_t* row_idx,
+                      int dtype, void* stream);
+int sgg_freq_bias_bwd(const float* d_out, const int32_t* row_idx, int E, int P, float* d_table, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

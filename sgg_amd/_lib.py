@@ -60,6 +60,8 @@ SIGNATURES = {
     'sgg_imp_node_scatter_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
     'sgg_rank4_reduce': [_P, _P, _I, _I, _P, _I, _I, _P],
     'sgg_recall_first_match': [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _F, _I, _P, _P, _P],
+    'sgg_freq_bias_fwd': [_P, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P],
+    'sgg_freq_bias_bwd': [_P, _P, _I, _I, _P, _P],
     'sgg_gemm_tn': [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     'sgg_sqnorm_multi': [_P, _P, _I, _P, _I, _P],
     'sgg_sgd_multi': [_P, _P, _P, _P, _P, _P, _I, _F, _F, _I, _P, _F, _F, _I, _I, _P],

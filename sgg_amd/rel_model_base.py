@@ -111,7 +111,8 @@ class RelModelBase(nn.Module):
         self.union_boxes = UnionBoxesAndFeats(pooling_size=self.pool_sz, stride=self.stride, dim=self.edge_dim,
                                               edge_model=edge_model)
         if self.use_bias:
-            raise NotImplementedError('FrequencyBias (lib/sparse_targets.py) is an optional flag outside SURVEY 8a')
+            from .sparse_targets import FrequencyBias
+            self.freq_bias = FrequencyBias(train_data)                                # rel_model_base.py:120-121
         # HIP-path settings (not in the reference): storage/compute type of activations and weights.
         self.compute_dtype = torch.bfloat16
         self._prep = {}

@@ -194,6 +194,10 @@ class RelModelStanford(RelModelBase):
         result.rm_obj_dists, result.rel_dists = self.predict(result.node_feat, result.edge_feat, rel_inds,
                                                              rois=rois, im_sizes=result.im_sizes,
                                                              _im_inds=im_inds.contiguous())         # :153
+        if self.use_bias:                                                                # :159-177, one fused lookup
+            result.rel_dists, result.obj_preds = self.freq_bias.apply_to(
+                result.rel_dists, result.rm_obj_dists, rel_inds,
+                gt_classes=gt_classes[:, 1].contiguous() if self.mode == 'predcls' else None, replace=self.test_bias)
         if self.training:
             result.rois = rois
             return result                                                                # :179-181

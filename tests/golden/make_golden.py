@@ -15,6 +15,8 @@ reference's source text is stored -- only data.  What is called, per file:
   eval_tail.npz    lib/surgery.py:17 filter_dets + the softmax/sort lines rel_model_stanford.py:187-204
   losses.npz       lib/losses.py:5,73
   recall.npz       lib/sgg_eval.py:14 BasicSceneGraphEvaluator (GC / no-GC / per-triplet, all modes), :420 mean recall, :481 eval_entry
+  freq_bias.npz    lib/get_dataset_counts.py:10 get_counts, lib/sparse_targets.py:7 FrequencyBias, and the use_bias block
+                   sgg_models/rel_model_stanford.py:159-177 (executed on the reference's FrequencyBias module)
 """
 import os
 import sys
@@ -392,8 +394,83 @@ def gold_recall():
     save('recall', **arrs)
 
 
+class _CountData(object):
+    """The attributes lib/get_dataset_counts.py reads from a VG split (dataloaders/visual_genome.py:377-455)."""
+
+    def __init__(self, seed=7, n_img=24, n_cls=12, n_pred=9):
+        rng = np.random.RandomState(seed)
+        self.num_classes, self.num_predicates = n_cls, n_pred
+        self.gt_classes, self.relationships, self.gt_boxes = [], [], []
+        for i in range(n_img):
+            nb = int(rng.randint(2, 9))
+            if i == 3:        # an image whose boxes do not overlap at all: box_filter falls back to every pair (:58-59)
+                boxes = np.array([[0, 0, 10, 10], [100, 100, 130, 140], [300, 20, 350, 60]], dtype=np.float32)
+                nb = 3
+            else:
+                boxes = rand_boxes(rng, nb, hi=300)
+            self.gt_boxes.append(boxes)
+            self.gt_classes.append(rng.randint(1, n_cls, size=nb).astype(np.int64))
+            pairs = np.array([(a, b) for a in range(nb) for b in range(nb) if a != b], dtype=np.int64)
+            G = int(rng.randint(1, min(len(pairs), 6) + 1))
+            gi = rng.choice(len(pairs), size=G, replace=False)
+            self.relationships.append(np.column_stack((pairs[gi], rng.randint(1, n_pred, size=G))).astype(np.int64))
+
+    def __len__(self):
+        return len(self.gt_classes)
+
+
+def gold_freq_bias():
+    import torch.nn.functional as F
+    np.float, np.bool = float, bool                               # lib/get_dataset_counts.py:52,55 use the removed aliases
+    from lib.get_dataset_counts import get_counts
+    from lib.sparse_targets import FrequencyBias
+    data = _CountData()
+    arrs = {'n_img': len(data), 'n_cls': data.num_classes, 'n_pred': data.num_predicates}
+    for i in range(len(data)):
+        arrs['boxes_%d' % i], arrs['classes_%d' % i], arrs['rels_%d' % i] = data.gt_boxes[i], data.gt_classes[i], data.relationships[i]
+    for ov in (True, False):
+        fg, bg = get_counts(data, must_overlap=ov)
+        arrs['fg_%d' % ov], arrs['bg_%d' % ov] = fg, bg
+    fb = FrequencyBias(data)
+    arrs['table'] = fb.obj_baseline.weight
+    # the use_bias block of RelModelStanford.forward (rel_model_stanford.py:159-177) on one two-image graph
+    rng = np.random.RandomState(5)
+    N, C, P = 11, data.num_classes, data.num_predicates
+    im = np.array([0] * 6 + [1] * 5)
+    rel_inds = np.array([(im[a], a, b) for a in range(N) for b in range(N) if a != b and im[a] == im[b]], dtype=np.int64)
+    obj_dists = torch.from_numpy(rng.randn(N, C).astype(np.float32) * 2)
+    rel_dists = torch.from_numpy(rng.randn(len(rel_inds), P).astype(np.float32))
+    gt_classes = torch.from_numpy(np.column_stack((im, rng.randint(1, C, size=N))).astype(np.int64))
+    rel_t = torch.from_numpy(rel_inds)
+    arrs.update(obj_dists=obj_dists, rel_dists=rel_dists, rel_inds=rel_inds, gt_classes=gt_classes)
+    for mode in ('sgcls', 'predcls'):
+        for test_bias in (False, True):
+            scores_nz = F.softmax(obj_dists, dim=1).data
+            scores_nz[:, 0] = 0.0
+            _, score_ord = scores_nz[:, 1:].sort(dim=1, descending=True)
+            obj_preds = score_ord[:, 0] + 1
+            if mode == 'predcls':
+                obj_preds = gt_classes.data[:, 1]
+            freq_pred = fb.index_with_labels(torch.stack((obj_preds[rel_t[:, 1]], obj_preds[rel_t[:, 2]]), 1))
+            out = freq_pred if test_bias else rel_dists + freq_pred
+            arrs['preds_%s' % mode] = obj_preds
+            arrs['out_%s_%d' % (mode, test_bias)] = out
+    # gradient of the embedding under a seeded upstream gradient (train mode, sgcls)
+    fb.zero_grad()
+    g = torch.from_numpy(rng.randn(len(rel_inds), P).astype(np.float32))
+    scores_nz = F.softmax(obj_dists, dim=1).data
+    obj_preds = scores_nz[:, 1:].argmax(1) + 1
+    (fb.index_with_labels(torch.stack((obj_preds[rel_t[:, 1]], obj_preds[rel_t[:, 2]]), 1)) * g).sum().backward()
+    arrs.update(d_out=g, d_table=fb.obj_baseline.weight.grad)
+    save('freq_bias', **arrs)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)
+    if len(sys.argv) > 1:                     # e.g. `make_golden.py freq_bias`: regenerate one file
+        for name in sys.argv[1:]:
+            globals()['gold_' + name]()
+        sys.exit(0)
     gold_raster()
     gold_union_feats()
     gold_gru()
@@ -403,3 +480,4 @@ if __name__ == '__main__':
     gold_eval_tail()
     gold_losses()
     gold_recall()
+    gold_freq_bias()

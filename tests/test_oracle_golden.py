@@ -171,3 +171,23 @@ def test_recall_oracle_matches_reference_evaluator(golden, mode, mp):
         np.testing.assert_array_equal(got == 2 ** 31 - 1, exp == 2 ** 31 - 1)
     else:
         np.testing.assert_array_equal(got, exp)
+
+
+def test_freq_bias_oracle_equals_reference(golden):
+    """lib/get_dataset_counts.py + lib/sparse_targets.py + rel_model_stanford.py:159-177 (tests/golden/freq_bias.npz)"""
+    g = golden('freq_bias')
+    n, C, P = int(g['n_img']), int(g['n_cls']), int(g['n_pred'])
+    cls = [g['classes_%d' % i] for i in range(n)]
+    rels = [g['rels_%d' % i] for i in range(n)]
+    boxes = [g['boxes_%d' % i] for i in range(n)]
+    for ov in (True, False):
+        fg, bg = O.get_counts(cls, rels, boxes, C, P, ov)
+        np.testing.assert_array_equal(fg, g['fg_%d' % ov])
+        np.testing.assert_array_equal(bg, g['bg_%d' % ov])
+    fg, bg = O.get_counts(cls, rels, boxes, C, P, True)
+    np.testing.assert_allclose(O.freq_bias_table(fg, bg), g['table'], rtol=0, atol=1e-7)
+    for mode in ('sgcls', 'predcls'):
+        for tb in (False, True):
+            preds, out = O.freq_bias_apply(g['obj_dists'], g['rel_dists'], g['rel_inds'], g['table'], C, mode, g['gt_classes'], tb)
+            np.testing.assert_array_equal(preds, g['preds_%s' % mode])
+            np.testing.assert_allclose(out, g['out_%s_%d' % (mode, tb)], rtol=0, atol=1e-7)
