@@ -74,9 +74,10 @@ def pmc_traffic(key):
         return None
 
 
-def imp_iter_ms(model, B, dtype, reps=50):
-    """Average duration of ONE fused IMP gather/gate/scatter launch on a complete 32-box/image graph of B images:
-    `reps` launches back-to-back between two HIP events on the launch stream (outputs pre-allocated)."""
+def imp_iter_ms(model, B, dtype, reps=50, kind='sliced'):
+    """Average duration of ONE IMP gather/gate/scatter launch on a complete 32-box/image graph of B images: `reps` launches
+    back-to-back between two HIP events on the launch stream (outputs pre-allocated).  kind: 'sliced' (the kernel the forward
+    runs: every edge row read once, gate dot products supplied by the GRU gate kernels) or 'fused' (node-centric, any graph)."""
     import torch
     from sgg_amd import ops
     dev = model.rel_fc.weight.device
@@ -85,21 +86,28 @@ def imp_iter_ms(model, B, dtype, reps=50):
     im = torch.arange(B, device=dev).repeat_interleave(n)
     rel, cnt = ops.pair_index_eval(im)
     rel = rel[:E]
-    csr = ops.edge_csr(rel, N, im)
+    csr = ops.edge_csr(rel, N, im, graphs=(B, n, n * (n - 1)))
     g = torch.Generator(device='cpu').manual_seed(1)
     v = torch.randn(N, H, generator=g).to(dev).to(dtype)
     e = torch.randn(E, H, generator=g).to(dev).to(dtype)
     imp = model.prepared()['imp']
     e_in, ctx2 = torch.empty_like(e), torch.empty((2, N, H), dtype=dtype, device=dev)
+    if kind == 'sliced':
+        assert ops.imp_sliced_ok(csr, H, dtype)
+        nd = (v.float() @ imp.gate_w[:, :H].t()).contiguous()     # what sgg_gru_gate_fwd's dot epilogue hands over
+        ed = (e.float() @ imp.gate_w[:, H:].t()).contiguous()
+        launch = lambda: ops.imp_sliced(v, e, csr, nd, ed, imp.gate_b, e_in, ctx2)
+    else:
+        launch = lambda: ops.imp_fused(v, e, rel, csr, imp.gate_w_c, imp.gate_b, e_in, ctx2)
     for _ in range(3):
-        ops.imp_fused(v, e, rel, csr, imp.gate_w_c, imp.gate_b, e_in, ctx2)
+        launch()
     torch.cuda.synchronize()
     # `reps` launches captured into one hipGraph so that the host launch path (Python + ctypes, ~10 us per call)
     # is not what is being timed; events bracket the replay on the replay stream
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         for _ in range(reps):
-            ops.imp_fused(v, e, rel, csr, imp.gate_w_c, imp.gate_b, e_in, ctx2)
+            launch()
     graph.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -243,6 +251,7 @@ def main():
         imp_gbs = imp_bytes / (imp_ms * 1e-3) / 1e9 if imp_ms else 0.0
         BL = 128                                                 # same kernel on a graph that fills the chip
         impL_ms = imp_iter_ms(model, BL, tdtype)
+        imp_old = {'B%d' % b_: round(imp_iter_ms(model, b_, tdtype, kind='fused'), 5) for b_ in (B, BL)}   # node-centric kernel, for comparison
         impL_bytes = (2.0 * (992 * BL + 32 * BL) * H) * s + 8.0 * 992 * BL
         impL_gbs = impL_bytes / (impL_ms * 1e-3) / 1e9
         roi_ms = sum(v[0] * v[1] for (n, t), v in kt.items() if n == 'sgg_roi_align_fwd')
@@ -312,17 +321,18 @@ def main():
                          'unit': 'TFLOP/s', 'frac': round(tf / peak, 4),
                          'traffic': pmc_traffic('fc6_edge_gemm' if tag == 'fc6_edge' else 'fc6_dW_gemm') if (B == 8 and args.dtype == 'bf16') else None,
                          'ms_per_step': round(ms, 4)},
-            'roofline_imp': {'kernel': 'imp_fused_kernel (gather + 4 gates + scatter), one launch per IMP iteration', 'bound': 'hbm',
+            'roofline_imp': {'kernel': 'imp_sliced_kernel (gather + 4 gates + scatter, every edge row read once), one launch per IMP iteration', 'bound': 'hbm',
                              'achieved': round(imp_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                              'frac': round(imp_gbs / HBM_PEAK_GBS, 4),
-                             'traffic': pmc_traffic('imp_fused_B8') if (B == 8 and args.dtype == 'bf16') else None,
+                             'traffic': pmc_traffic('imp_sliced_B8') if (B == 8 and args.dtype == 'bf16') else None,
                              'algorithmic_bytes': imp_bytes, 'avg_launch_ms': round(imp_ms, 5),
                              'note': '16.8 MB per launch at B=8: 2.7 us at 6.3 TB/s, below launch + dependent-latency floor'},
             'roofline_imp_large': {'kernel': 'same kernel, %d images (%d edges) per launch' % (BL, 992 * BL), 'bound': 'hbm',
                                    'achieved': round(impL_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                    'frac': round(impL_gbs / HBM_PEAK_GBS, 4),
-                                   'traffic': pmc_traffic('imp_fused_B128') if args.dtype == 'bf16' else None,
-                                   'algorithmic_bytes': impL_bytes, 'avg_launch_ms': round(impL_ms, 5)},
+                                   'traffic': pmc_traffic('imp_sliced_B128') if args.dtype == 'bf16' else None,
+                                   'algorithmic_bytes': impL_bytes, 'avg_launch_ms': round(impL_ms, 5),
+                                   'node_centric_kernel_ms': imp_old},
             'kernels': {'sum_kernel_ms_per_step': round(total_ms, 3),
                         'vgg16_ms': round(conv_ms, 3), 'vgg16_tflops': round(vgg_flop / (conv_ms * 1e-3) / 1e12, 1) if conv_ms else 0,
                         'roi_align_ms': round(roi_ms, 4), 'roi_align_GBs': round(roi_bytes / (roi_ms * 1e-3) / 1e9, 1) if roi_ms else 0,

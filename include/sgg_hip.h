@@ -148,12 +148,30 @@ int sgg_imp_fused_fwd(const void* v, const void* e, const int* so /*[E,2]*/, con
                       const int* out_ids, const int* in_ptr, const int* in_ids, int N, int E, int H, const void* gate_w,
                       const float* gate_b, void* e_in, void* ctx2 /*[2,N,H]*/, int dtype, void* stream);
 
+/* Sliced form (every edge row read once; the kernel the forward uses when the graphs fit): a workgroup owns (graph, 128-byte
+ * slice of the rows); edge pieces are staged in LDS by LDS-DMA, gates come from node_dots f32[N,4] / edge_dots f32[E,4]
+ * (sgg_gru_gate_fwd's dot outputs, vertex / edge halves of gate_w), e_in pieces stream out, ctx2 halves are reduced from
+ * LDS.  Requires: rel_inds sorted by (graph, subject) (both pair-index calls emit that; out-lists are then ranges), nodes
+ * grouped by graph with img_ptr i32[2(B+1)] (sgg_graph_ptr), every graph with <= max_nodes <= 64 nodes and <= max_edges edges
+ * (SGG_ERR_CAPACITY above sgg_imp_sliced_capacity(H, dtype)).  Same outputs as sgg_imp_fused_fwd. */
+int sgg_imp_sliced_capacity(int H, int dtype);
+int sgg_imp_sliced_fwd(const void* v, const void* e, const int* so /*[E,2]*/, const int* out_ptr, const int* in_ptr,
+                       const int* in_ids, const int* img_ptr, int B, int N, int E, int H, const float* node_dots,
+                       const float* edge_dots, const float* gate_b, void* e_in, void* ctx2 /*[2,N,H]*/, int max_edges,
+                       int max_nodes, int dtype, void* stream);
+/* img_ptr i32[2*(B+1)]: img_ptr[b] = first node of graph b (im_inds i64[N] ascending), img_ptr[B] = N; then
+ * img_ptr[B+1+b] = out_ptr[first node of b] = first edge of graph b (out_ptr from sgg_edge_csr, same stream, edges sorted) */
+int sgg_graph_ptr(const int64_t* im_inds, int N, int B, const int* out_ptr, int* img_ptr, void* stream);
+
 /* ---- a-9  GRU cell pointwise part: nn.GRUCell, rel_model_stanford.py:36-37,71-72,83,92 ----
  * gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh come from sgg_gemm ([M,3H], gate order r,z,n).
  * gh == NULL means h == 0: gh = b_hh (f32[3H]) and h_prev = 0 (first call, :68-72).
  * g_dtype = element type of gi/gh (f32 pre-activations may feed bf16 states), dtype = type of h_prev/h_out. */
 int sgg_gru_gate_fwd(const void* gi, const void* gh, const float* b_hh, const void* h_prev, void* h_out, int M, int H,
-                     int g_dtype, int dtype, void* stream);
+                     const float* dot_w, int dot_ld, float* dots, int g_dtype, int dtype, void* stream);
+/*   dots (optional, f32[M,4]): dots[m,k] = dot_w[k*dot_ld : k*dot_ld+H] . h_out[m,:] (on the stored, rounded values) -- the
+ *   vertex / edge halves of the four gate pre-activations of the NEXT message-passing step (:78-89), made while the row is
+ *   in registers so that sgg_imp_sliced_fwd never needs a whole row.  Needs H/8 a power of two <= 64. */
 
 /* ---- a-11  eval tail: rel_model_stanford.py:183-207 + filter_dets, lib/surgery.py:17-55 ----
  * obj: softmax over C classes, best class in 1..C-1 and its prob (sgcls/sgdet), or score 1 / given class (predcls

@@ -39,7 +39,10 @@ SIGNATURES = {
     'sgg_imp_edge_ctx_fwd': [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     'sgg_imp_node_scatter_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P],
     'sgg_imp_fused_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P],
-    'sgg_gru_gate_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'sgg_gru_gate_fwd': [_P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _P],
+    'sgg_imp_sliced_capacity': [_I, _I],
+    'sgg_imp_sliced_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    'sgg_graph_ptr': [_P, _I, _I, _P, _P, _P],
     'sgg_eval_tail': [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     'sgg_rpn_decode': [_P, _I, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P],
     'sgg_segmented_sort_desc': [_P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P],

@@ -20,17 +20,15 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned int)v) << 16); }
 
-// round-to-nearest-even, NaN kept quiet
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    unsigned int u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
-
+// f32 -> bf16, round-to-nearest-even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, two elements per
+// instruction); the integer sequence (add 0x7fff + lsb, shift, NaN test) it replaces was ~11 VALU operations per pair and
+// showed up in every kernel that stores bf16
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-    return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -90,14 +88,17 @@ template <> struct Raw8<float> {
     }
 };
 
-// dot product of two packed 8-element pieces: bf16 pairs go through v_dot2_f32_bf16 (4 instructions instead of
-// 8 unpacks + 8 FMAs); fp32 pieces through 8 FMAs
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// dot product of two packed 8-element pieces, fp32 accumulate.  bf16 pieces are unpacked and go through FMAs: the
+// v_dot2_f32_bf16 form (__builtin_amdgcn_fdot2_f32_bf16, 4 instructions) is correct in isolation (tools/exp/dot2_probe.hip) but
+// gave WRONG gate sums inside imp_fused_kernel, where its results feed DPP wave reductions directly (mean |error| 0.27 on
+// e_in at unit scale; round 1, ROCm 7.2 -- suspected missing wait states between the dot and the DPP read).  Do not bring it
+// back without the unit test `test_imp_sliced_vs_oracle_math`, which compares this kernel in bf16 with the dense formula.
 __device__ __forceinline__ float dot8(const Raw8<bf16_t>& w, const Raw8<bf16_t>& x, float acc) {
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.r.x), __builtin_bit_cast(bf16x2_t, x.r.x), acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.r.y), __builtin_bit_cast(bf16x2_t, x.r.y), acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.r.z), __builtin_bit_cast(bf16x2_t, x.r.z), acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.r.w), __builtin_bit_cast(bf16x2_t, x.r.w), acc, false);
+    float a[8], b[8];
+    w.get(a);
+    x.get(b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = fmaf(a[j], b[j], acc);
     return acc;
 }
 __device__ __forceinline__ float dot8(const Raw8<float>& w, const Raw8<float>& x, float acc) {

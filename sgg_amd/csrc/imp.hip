@@ -5,7 +5,10 @@
 // kernel, gather v rows (N*H*s, each re-used ~2(n-1) times -> L2), write e_in (E*H*s), write ctx (N*H*s).
 // A lane owns 8 consecutive channels, so every row access is 16-byte (bf16) / 32-byte (f32) pieces of one
 // contiguous H-row: a wave reads/writes one whole row (1-2 KiB for H=512) per instruction group.
+#include <cstdlib>
+
 #include "common.h"
+#include "gemm_args.h"
 
 namespace {
 
@@ -300,7 +303,8 @@ __global__ __launch_bounds__(256, 3) void imp_fused_kernel(const T* __restrict__
 template <typename TG, typename T>
 __global__ __launch_bounds__(256) void gru_gate_kernel(const TG* __restrict__ gi, const TG* __restrict__ gh,
                                                        const float* __restrict__ b_hh, const T* __restrict__ h_prev,
-                                                       T* __restrict__ h_out, long total, int H) {
+                                                       T* __restrict__ h_out, long total, int H,
+                                                       const float* __restrict__ dot_w, int dot_ld, float* __restrict__ dots) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;  // over M*H/8
     if (i >= total) return;
     const int h8 = H >> 3;
@@ -332,6 +336,283 @@ __global__ __launch_bounds__(256) void gru_gate_kernel(const TG* __restrict__ gi
         o[j] = (hp[j] - n) * z + n;
     }
     store8(h_out + m * H + c, o);
+    if (dots) {
+        // gate pre-activations of the NEXT message-passing step, produced while the row is in registers:
+        // dots[m,k] = dot_w[k,:] . h'[m,:] on the values as stored (rounded to T).  H/8 lanes (a power of two <= 64) hold one
+        // row, rows never straddle a wave, and whole rows are active or inactive together (total = M * H/8).
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = bf16_to_f32(f32_to_bf16(o[j]));
+        }
+        float p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float w[8];
+            load8(dot_w + (long)k * dot_ld + c, w);
+            p[k] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[k] = fmaf(w[j], o[j], p[k]);
+        }
+        for (int off = h8 >> 1; off > 0; off >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p[k] += __shfl_xor(p[k], off, 64);
+        }
+        if (c == 0) *reinterpret_cast<f32x4*>(dots + m * 4) = f32x4{p[0], p[1], p[2], p[3]};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sliced IMP step: every edge row read ONCE.  A workgroup owns (graph g, channel slice): LP lanes x 16 B = one PIECE of a
+// row (128 B: 64 bf16 / 32 f32 channels at LP = 8).  The gate pre-activations arrive as dot products made by the kernels
+// that wrote v and e (gru_gate_kernel above), so nothing here needs a whole row:
+//   phase 0  the graph's vertex pieces, vertex dots, list offsets and in-list ids -> LDS
+//   phase 1  a lane group owns (subject n, part of n's out-list): per edge it loads the row piece (U edges in flight),
+//            makes the four gates on 4 lanes (shared through DPP quad broadcasts, no LDS), writes
+//            e_in piece = g_sub * v[n] + g_obj * v[o] to HBM, adds g_out * row to its ctx_out partial (registers), and parks
+//            the row piece and g_in in LDS
+//   phase 2  a lane group owns (object n, part of n's in-list): ctx_in partial = sum g_in * parked piece
+//   the P lane groups of a node sit in one wave: their partials are added with xor-shuffles, part 0 stores
+// HBM traffic = algorithmic (e read once, e_in written once) + 16 B of dots per edge and slice.  LDS instructions per edge
+// and lane group: 4 in phase 1 (vertex dot, v[o] piece, park row, park gate) + 3 in phase 2.  Needs the edge list sorted by
+// (graph, subject) -- out-lists are ranges -- and the graph to fit: edges <= EMAX, nodes <= SL_NMAX.
+// ------------------------------------------------------------------------------------------------
+constexpr int SL_THREADS = 1024;
+constexpr int SL_NMAX = 64;
+#ifndef SGG_SLICED_ABL
+#define SGG_SLICED_ABL 0   // kernel experiments only: 1 no phase 2, 2 no e_in stores
+#endif
+
+// 16 bytes of a row: 8 bf16 or 4 f32 channels
+template <typename T> struct Piece16;
+template <> struct Piece16<bf16_t> {
+    u32x4 r;
+    __device__ __forceinline__ void get(float (&x)[8]) const {
+        x[0] = __uint_as_float(r.x << 16); x[1] = __uint_as_float(r.x & 0xffff0000u);
+        x[2] = __uint_as_float(r.y << 16); x[3] = __uint_as_float(r.y & 0xffff0000u);
+        x[4] = __uint_as_float(r.z << 16); x[5] = __uint_as_float(r.z & 0xffff0000u);
+        x[6] = __uint_as_float(r.w << 16); x[7] = __uint_as_float(r.w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&x)[8]) { store8(p, x); }
+};
+template <> struct Piece16<float> {
+    f32x4 r;
+    __device__ __forceinline__ void get(float (&x)[4]) const { x[0] = r.x; x[1] = r.y; x[2] = r.z; x[3] = r.w; }
+    static __device__ __forceinline__ void store(float* p, const float (&x)[4]) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{x[0], x[1], x[2], x[3]};
+    }
+};
+
+template <int LP> struct SliceCfg;
+template <> struct SliceCfg<8> { static constexpr int EMAX = 1024; };   // 128 KB of parked pieces
+template <> struct SliceCfg<4> { static constexpr int EMAX = 1792; };   // 112 KB
+template <> struct SliceCfg<2> { static constexpr int EMAX = 3072; };   //  96 KB
+
+// LDS bytes for graphs of at most `emax` edges (emax a multiple of 8)
+template <int LP> constexpr int slice_lds_bytes(int emax) {
+    return emax * (LP * 16 + 4 + 2) + SL_NMAX * (LP * 16 + 16) + (SL_NMAX + 4) * 4;
+}
+
+// value of lane (quad base + q) for every lane of a quad (DPP quad_perm: VALU only, no LDS crossbar)
+template <int CTRL> __device__ __forceinline__ float quad_bcast(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+
+template <typename T, int LP>
+__global__ __launch_bounds__(SL_THREADS) void imp_sliced_kernel(const T* __restrict__ v, const T* __restrict__ e,
+                                                                const int* __restrict__ so, const int* __restrict__ out_ptr,
+                                                                const int* __restrict__ in_ptr, const int* __restrict__ in_ids,
+                                                                const int* __restrict__ img_ptr, int B, int N, int H,
+                                                                const float* __restrict__ ndots, const float* __restrict__ edots,
+                                                                const float* __restrict__ gb, T* __restrict__ e_in,
+                                                                T* __restrict__ ctx2, int EMAX) {
+    constexpr int PIECE = LP * 16, CHL = 16 / (int)sizeof(T), GROUPS = SL_THREADS / LP;
+    constexpr int U = 8;                         // edges in flight per lane group: their loads are issued before any is used
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* stage = smem;                                                        // [EMAX][PIECE] parked row pieces
+    float* gin = reinterpret_cast<float*>(stage + (long)EMAX * PIECE);         // [EMAX] g_in of each edge
+    unsigned short* in_loc = reinterpret_cast<unsigned short*>(gin + EMAX);    // [EMAX] in-list entries, graph-local
+    char* vs = reinterpret_cast<char*>(in_loc + EMAX);                          // [SL_NMAX][PIECE]
+    float* nd = reinterpret_cast<float*>(vs + SL_NMAX * PIECE);                 // [SL_NMAX][4]
+    int* iptr = reinterpret_cast<int*>(nd + SL_NMAX * 4);                       // [SL_NMAX + 1], graph-local
+    const int S = H * (int)sizeof(T) / PIECE;                                   // slices per graph
+    const int L = xcd_remap((int)blockIdx.x, B * S);                            // a graph's slices share an XCD (dots, lists in its L2)
+    const int g = L / S, slice = L - g * S;
+    const int tid = threadIdx.x, sub = tid % LP, grp = tid / LP;
+#if SGG_SLICED_ABL == 5
+    long long tck[8];
+    tck[0] = clock64();
+#define SGG_TICK(i) tck[i] = clock64();
+#else
+#define SGG_TICK(i)
+#endif
+    // dependent-load level 1 (scalar): img_ptr = [node offsets (B+1) | edge offsets (B+1)]
+    const int n0 = img_ptr[g], n1 = img_ptr[g + 1], Nn = n1 - n0;
+    const int e0 = img_ptr[B + 1 + g], e1 = img_ptr[B + 2 + g], Ee = e1 - e0;
+    const int i0 = e0;                           // edges are grouped by graph: the in-lists of earlier graphs hold e0 entries
+    const long col = (long)slice * (PIECE / (int)sizeof(T)) + sub * CHL;        // this lane's first channel
+    // the four gates of an edge are spread over the lanes of a quad: lane q makes gate q (LP >= 4), or gates q&1, (q&1)+2 (LP = 2)
+    constexpr int GI = LP >= 4 ? 1 : 2;
+    int gk[GI];
+    float bias[GI];
+#pragma unroll
+    for (int i = 0; i < GI; ++i) {
+        gk[i] = LP >= 4 ? (sub & 3) : (sub & 1) + 2 * i;
+        bias[i] = gb[gk[i]];
+    }
+    // P lane groups share a node (P a power of two, the P groups inside one wave): its lists are cut into P contiguous parts.
+    // Nn <= SL_NMAX <= GROUPS: every node has its own lane group(s), one node per group.
+    int P = 1;
+    while (2 * P * LP <= 64 && 2 * P * Nn <= GROUPS) P *= 2;
+    const int part = grp % P, n = grp / P;
+    const bool has_node = n < Nn;
+    // level 2 (vector, all independent): this group's out-list range + everything phase 0 parks in LDS
+    int ob = 0, oe = 0;
+    if (has_node) {
+        ob = out_ptr[n0 + n] - e0;
+        oe = out_ptr[n0 + n + 1] - e0;
+    }
+    u32x4 p_v = {0, 0, 0, 0};
+    f32x4 p_nd = {0, 0, 0, 0};
+    int p_ip = 0;
+    if (grp < Nn) p_v = *reinterpret_cast<const u32x4*>(v + (long)(n0 + grp) * H + col);
+    if (tid < Nn) p_nd = *reinterpret_cast<const f32x4*>(ndots + (long)(n0 + tid) * 4);
+    if (tid <= Nn) p_ip = in_ptr[n0 + tid] - i0;
+    constexpr int INL = 3;                       // in-list entries per thread held in registers (more: strided loop below)
+    int p_in[INL];
+#pragma unroll
+    for (int q = 0; q < INL; ++q) p_in[q] = (tid + q * SL_THREADS < Ee) ? in_ids[i0 + tid + q * SL_THREADS] - e0 : 0;
+    // level 3: the first U edges of this group's part of the out-list
+    const int chunk = (oe - ob + P - 1) / P;
+    const int k0 = ob + part * chunk, k1 = min(oe, k0 + chunk);
+    Piece16<T> row[U];
+    float de[U][GI];
+    int on[U];
+    auto issue = [&](int kb) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ec = e0 + max(min(kb + u, k1 - 1), 0);
+            row[u].r = *reinterpret_cast<const decltype(row[u].r)*>(e + (long)ec * H + col);
+#pragma unroll
+            for (int i = 0; i < GI; ++i) de[u][i] = edots[(long)ec * 4 + gk[i]];
+            on[u] = so[2 * (long)ec + 1] - n0;
+        }
+    };
+    SGG_TICK(1)
+    if (k0 < k1) issue(k0);
+    // ---- phase 0: park
+    if (grp < Nn) *reinterpret_cast<u32x4*>(vs + grp * PIECE + sub * 16) = p_v;
+    if (tid < Nn) *reinterpret_cast<f32x4*>(nd + tid * 4) = p_nd;
+    if (tid <= Nn) iptr[tid] = p_ip;
+#pragma unroll
+    for (int q = 0; q < INL; ++q)
+        if (tid + q * SL_THREADS < Ee) in_loc[tid + q * SL_THREADS] = (unsigned short)p_in[q];
+    for (int k = tid + INL * SL_THREADS; k < Ee; k += SL_THREADS) in_loc[k] = (unsigned short)(in_ids[i0 + k] - e0);
+    SGG_TICK(2)
+    __syncthreads();
+    SGG_TICK(3)
+    // ---- phase 1: out-lists
+    if (has_node) {
+        Piece16<T> vnp;
+        vnp.r = *reinterpret_cast<const decltype(vnp.r)*>(vs + n * PIECE + sub * 16);
+        float vn[CHL], acc[CHL];
+        vnp.get(vn);
+#pragma unroll
+        for (int j = 0; j < CHL; ++j) acc[j] = 0.f;
+        float ndn[GI];                            // dots of v[n] for this lane's even gates (sub_vert, out_edge)
+#pragma unroll
+        for (int i = 0; i < GI; ++i) ndn[i] = nd[n * 4 + gk[i]];
+        for (int kb = k0; kb < k1; kb += U) {
+            if (kb != k0) issue(kb);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int el = kb + u;
+                const bool live = el < k1;       // lanes of a quad share `live`: the DPP broadcasts below stay inside a lane group
+                // gate k: 0 sub_vert(v[s]), 1 obj_vert(v[o]), 2 out_edge(v[s]), 3 in_edge(v[o])  (rel_model_stanford.py:78-89)
+                float gate[GI];
+#pragma unroll
+                for (int i = 0; i < GI; ++i) {
+                    const float vd = (gk[i] & 1) ? nd[on[u] * 4 + gk[i]] : ndn[i];
+                    gate[i] = sigmoidf_(vd + de[u][i] + bias[i]);
+                }
+                float gs, go, gx;
+                if constexpr (LP >= 4) {
+                    gs = quad_bcast<0x00>(gate[0]);
+                    go = quad_bcast<0x55>(gate[0]);
+                    gx = quad_bcast<0xAA>(gate[0]);
+                    if (live && sub == 3) gin[el] = gate[0];
+                } else {                          // pairs: lane 0 holds (sub, out), lane 1 holds (obj, in)
+                    gs = quad_bcast<0xA0>(gate[0]);
+                    go = quad_bcast<0xF5>(gate[0]);
+                    gx = quad_bcast<0xA0>(gate[1]);
+                    if (live && sub == 1) gin[el] = gate[1];
+                }
+                if (live) {
+                    *reinterpret_cast<decltype(row[u].r)*>(stage + (long)el * PIECE + sub * 16) = row[u].r;
+                    Piece16<T> vop;
+                    vop.r = *reinterpret_cast<const decltype(vop.r)*>(vs + on[u] * PIECE + sub * 16);
+                    float x[CHL], y[CHL], r[CHL];
+                    row[u].get(x);
+                    vop.get(y);
+#pragma unroll
+                    for (int j = 0; j < CHL; ++j) {
+                        r[j] = gs * vn[j] + go * y[j];
+                        acc[j] = fmaf(gx, x[j], acc[j]);
+                    }
+                    if (SGG_SLICED_ABL != 2) Piece16<T>::store(e_in + (long)(e0 + el) * H + col, r);
+                }
+            }
+        }
+        for (int off = LP; off < P * LP; off <<= 1) {
+#pragma unroll
+            for (int j = 0; j < CHL; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+        }
+        if (part == 0) Piece16<T>::store(ctx2 + (long)(n0 + n) * H + col, acc);
+    }
+    SGG_TICK(4)
+    __syncthreads();
+    SGG_TICK(5)
+    // ---- phase 2: in-lists, from the parked pieces
+    if (has_node && SGG_SLICED_ABL != 1) {
+        const int beg = iptr[n], end = iptr[n + 1], ch = (end - beg + P - 1) / P;
+        const int j0 = beg + part * ch, j1 = min(end, j0 + ch);
+        float acc[CHL];
+#pragma unroll
+        for (int j = 0; j < CHL; ++j) acc[j] = 0.f;
+        for (int kb = j0; kb < j1; kb += U) {
+            int el[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) el[u] = in_loc[min(kb + u, j1 - 1)];
+            Piece16<T> rw[U];
+            float gv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                rw[u].r = *reinterpret_cast<const decltype(rw[u].r)*>(stage + (long)el[u] * PIECE + sub * 16);
+                gv[u] = (kb + u < j1) ? gin[el[u]] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float x[CHL];
+                rw[u].get(x);
+#pragma unroll
+                for (int j = 0; j < CHL; ++j) acc[j] = fmaf(gv[u], x[j], acc[j]);
+            }
+        }
+        for (int off = LP; off < P * LP; off <<= 1) {
+#pragma unroll
+            for (int j = 0; j < CHL; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+        }
+        if (part == 0) Piece16<T>::store(ctx2 + ((long)N + n0 + n) * H + col, acc);
+    }
+#if SGG_SLICED_ABL == 5
+    SGG_TICK(6)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SGG_TICK(7)
+    if ((tid & 63) == 0 && blockIdx.x < 4) {
+        long long* dbg = reinterpret_cast<long long*>(ctx2) + ((long)blockIdx.x * 16 + (tid >> 6)) * 8;
+        for (int i = 0; i < 8; ++i) dbg[i] = tck[i];
+    }
+#endif
+#undef SGG_TICK
 }
 
 }  // namespace
@@ -384,23 +665,116 @@ extern "C" int sgg_imp_node_scatter_fwd(const void* e, const float* gates, const
 }
 
 extern "C" int sgg_gru_gate_fwd(const void* gi, const void* gh, const float* b_hh, const void* h_prev, void* h_out, int M,
-                                int H, int g_dtype, int dtype, void* stream) {
+                                int H, const float* dot_w, int dot_ld, float* dots, int g_dtype, int dtype, void* stream) {
     if (M == 0) return SGG_OK;
     if (!gi || !h_out || M < 0 || H <= 0 || (H & 7)) return SGG_ERR_ARG;
     if (gh ? !h_prev : !b_hh) return SGG_ERR_ARG;
+    if (dots) {   // the dot epilogue reduces over the H/8 lanes of a row with xor-shuffles
+        const int h8 = H / 8;
+        if (!dot_w || dot_ld < H || h8 > 64 || (h8 & (h8 - 1))) return SGG_ERR_ARG;
+    }
     const long total = (long)M * (H / 8);
     const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
     hipStream_t s = (hipStream_t)stream;
     if (g_dtype == SGG_F32 && dtype == SGG_BF16)
-        hipLaunchKernelGGL((gru_gate_kernel<float, bf16_t>), grid, blk, 0, s, (const float*)gi, (const float*)gh, b_hh, (const bf16_t*)h_prev, (bf16_t*)h_out, total, H);
+        hipLaunchKernelGGL((gru_gate_kernel<float, bf16_t>), grid, blk, 0, s, (const float*)gi, (const float*)gh, b_hh, (const bf16_t*)h_prev, (bf16_t*)h_out, total, H, dot_w, dot_ld, dots);
     else if (g_dtype == SGG_F32 && dtype == SGG_F32)
-        hipLaunchKernelGGL((gru_gate_kernel<float, float>), grid, blk, 0, s, (const float*)gi, (const float*)gh, b_hh, (const float*)h_prev, (float*)h_out, total, H);
+        hipLaunchKernelGGL((gru_gate_kernel<float, float>), grid, blk, 0, s, (const float*)gi, (const float*)gh, b_hh, (const float*)h_prev, (float*)h_out, total, H, dot_w, dot_ld, dots);
     else if (g_dtype == SGG_BF16 && dtype == SGG_BF16)
-        hipLaunchKernelGGL((gru_gate_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (const bf16_t*)gi, (const bf16_t*)gh, b_hh, (const bf16_t*)h_prev, (bf16_t*)h_out, total, H);
+        hipLaunchKernelGGL((gru_gate_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (const bf16_t*)gi, (const bf16_t*)gh, b_hh, (const bf16_t*)h_prev, (bf16_t*)h_out, total, H, dot_w, dot_ld, dots);
     else
         return SGG_ERR_DTYPE;
     SGG_CHECK_LAUNCH();
     return SGG_OK;
+}
+
+namespace {
+__global__ void graph_ptr_kernel(const int64_t* __restrict__ im, int N, int B, const int* __restrict__ out_ptr,
+                                 int* __restrict__ ptr) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b > B) return;
+    int lo = 0, hi = N;            // first node with im >= b
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (im[mid] < b) lo = mid + 1;
+        else hi = mid;
+    }
+    ptr[b] = lo;
+    ptr[B + 1 + b] = out_ptr[lo];  // first edge of graph b when the edge list is sorted by (graph, subject)
+}
+
+template <typename T, int LP>
+int launch_sliced(const void* v, const void* e, const int* so, const int* out_ptr, const int* in_ptr, const int* in_ids,
+                  const int* img_ptr, int B, int N, int H, const float* ndots, const float* edots, const float* gb, void* e_in,
+                  void* ctx2, int max_edges, hipStream_t s) {
+    auto k = imp_sliced_kernel<T, LP>;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                slice_lds_bytes<LP>(SliceCfg<LP>::EMAX)) != hipSuccess)
+            return SGG_ERR_LAUNCH;
+        configured = true;
+    }
+    // the staging area is sized for THIS batch's largest graph: smaller graphs leave room for a second workgroup on the CU
+    const int emax = (max(max_edges, 8) + 7) & ~7;
+    const int S = H * (int)sizeof(T) / (LP * 16);
+    hipLaunchKernelGGL(k, dim3(B * S), dim3(SL_THREADS), slice_lds_bytes<LP>(emax), s, (const T*)v, (const T*)e, so, out_ptr, in_ptr,
+                       in_ids, img_ptr, B, N, H, ndots, edots, gb, (T*)e_in, (T*)ctx2, emax);
+    return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
+}
+}  // namespace
+
+extern "C" int sgg_graph_ptr(const int64_t* im_inds, int N, int B, const int* out_ptr, int* img_ptr, void* stream) {
+    if (!im_inds || !img_ptr || !out_ptr || N < 0 || B < 0) return SGG_ERR_ARG;
+    hipLaunchKernelGGL(graph_ptr_kernel, dim3((B + 256) / 256), dim3(256), 0, (hipStream_t)stream, im_inds, N, B, out_ptr, img_ptr);
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+// largest per-graph edge count the sliced kernel takes at this row width (0: rows too narrow for any slicing)
+extern "C" int sgg_imp_sliced_capacity(int H, int dtype) {
+    const int row = H * (dtype == SGG_BF16 ? 2 : 4);
+    if (row % 32 || H <= 0) return 0;
+    return SliceCfg<2>::EMAX;   // the narrowest pieces hold the most edges
+}
+
+extern "C" int sgg_imp_sliced_fwd(const void* v, const void* e, const int* so, const int* out_ptr, const int* in_ptr,
+                                  const int* in_ids, const int* img_ptr, int B, int N, int E, int H, const float* node_dots,
+                                  const float* edge_dots, const float* gate_b, void* e_in, void* ctx2, int max_edges, int max_nodes,
+                                  int dtype, void* stream) {
+    if (N == 0 || B == 0) return SGG_OK;
+    if (!v || !e || !so || !out_ptr || !in_ptr || !in_ids || !img_ptr || !node_dots || !edge_dots || !gate_b || !e_in || !ctx2 ||
+        N < 0 || E < 0 || B < 0 || H <= 0)
+        return SGG_ERR_ARG;
+    if (dtype != SGG_BF16 && dtype != SGG_F32) return SGG_ERR_DTYPE;
+    const int row = H * (dtype == SGG_BF16 ? 2 : 4);
+    if (row % 32) return SGG_ERR_ARG;
+    if (max_nodes > SL_NMAX) return SGG_ERR_CAPACITY;
+    hipStream_t s = (hipStream_t)stream;
+    // piece width: 128-B pieces (whole cache lines per edge and slice) when they fit
+    int lp = 0;
+    if (row % 128 == 0 && max_edges <= SliceCfg<8>::EMAX) lp = 8;
+    else if (row % 64 == 0 && max_edges <= SliceCfg<4>::EMAX) lp = 4;
+    else if (max_edges <= SliceCfg<2>::EMAX) lp = 2;
+    else return SGG_ERR_CAPACITY;
+    static const char* force = getenv("SGG_IMP_LP");     // kernel experiments only
+    if (force) {
+        const int f = atoi(force);
+        if ((f == 8 || f == 4 || f == 2) && f <= lp && row % (f * 16) == 0) lp = f;
+    }
+#define SGG_SLICED(T, LPV) \
+    return launch_sliced<T, LPV>(v, e, so, out_ptr, in_ptr, in_ids, img_ptr, B, N, H, node_dots, edge_dots, gate_b, e_in, ctx2, \
+                                 max_edges, s)
+    if (dtype == SGG_BF16) {
+        if (lp == 8) SGG_SLICED(bf16_t, 8);
+        if (lp == 4) SGG_SLICED(bf16_t, 4);
+        SGG_SLICED(bf16_t, 2);
+    } else {
+        if (lp == 8) SGG_SLICED(float, 8);
+        if (lp == 4) SGG_SLICED(float, 4);
+        SGG_SLICED(float, 2);
+    }
+#undef SGG_SLICED
 }
 
 extern "C" int sgg_imp_fused_fwd(const void* v, const void* e, const int* so, const int* flags, const int* out_ptr,

@@ -26,14 +26,17 @@ class ImpWeights(object):
         return w
 
 
-def _gru(wts, which, x, h, dtype, out=None):
+def _gru(wts, which, x, h, dtype, out=None, dots=False):
     """nn.GRUCell: two MFMA GEMMs (fp32 pre-activations) + the fused pointwise gate kernel.  h is None for the
-    first call (hidden state 0: the hidden GEMM is skipped, b_hh still applies -- rel_model_stanford.py:68-72)."""
+    first call (hidden state 0: the hidden GEMM is skipped, b_hh still applies -- rel_model_stanford.py:68-72).
+    dots=True: also the four gate dot products of the new state (vertex halves for node_gru, edge halves for edge_gru),
+    -> (state, dots f32[M,4])."""
     gi = ops.gemm(x, getattr(wts, which + '_w_ih'), getattr(wts, which + '_b_ih'), out_dtype=torch.float32)
+    dot_w = (wts.gate_w[:, :wts.H] if which == 'node_gru' else wts.gate_w[:, wts.H:]) if dots else None
     if h is None:
-        return ops.gru_gate(gi, None, getattr(wts, which + '_b_hh'), None, dtype, out=out)
+        return ops.gru_gate(gi, None, getattr(wts, which + '_b_hh'), None, dtype, out=out, dot_w=dot_w)
     gh = ops.gemm(h, getattr(wts, which + '_w_hh'), getattr(wts, which + '_b_hh'), out_dtype=torch.float32)
-    return ops.gru_gate(gi, gh, None, h, dtype, out=out)
+    return ops.gru_gate(gi, gh, None, h, dtype, out=out, dot_w=dot_w)
 
 
 _SIDE = {}
@@ -54,46 +57,65 @@ def node_lane(device):
 
 
 def message_pass(rel_rep, obj_rep, rel_inds, csr, wts, mp_iter, dtype):
-    """rel_rep [E,H], obj_rep [N,H] (dtype), rel_inds i64[E,3] -> (vert[N,H], edge[E,H])."""
+    """rel_rep [E,H], obj_rep [N,H] (dtype), rel_inds i64[E,3] -> (vert[N,H], edge[E,H]).
+    Two forms of the gather / gate / scatter step: `imp_sliced` (every edge row read once; needs the host-side graph facts
+    of ops.edge_csr(graphs=...), the gate dot products then come out of the GRU gate kernels) or `imp_fused` (any edge list)."""
     N, H = obj_rep.shape
     lane = node_lane(obj_rep.device)
+    sliced = mp_iter > 0 and ops.imp_sliced_ok(csr, H, dtype)
+
+    def step(vert, nd, edge, ed):
+        if sliced:
+            return ops.imp_sliced(vert, edge, csr, nd, ed, wts.gate_b)                       # :76-81,86-91 in one launch
+        return ops.imp_fused(vert, edge, rel_inds, csr, wts.gate_w_c, wts.gate_b)
+
+    def unpack(r, want):
+        return r if want else (r, None)
+
     if lane is None:
-        vert = _gru(wts, 'node_gru', obj_rep, None, dtype)                       # :71
-        edge = _gru(wts, 'edge_gru', rel_rep, None, dtype)                       # :72
-        for _ in range(mp_iter):                                                 # :74
-            e_in, ctx2 = ops.imp_fused(vert, edge, rel_inds, csr, wts.gate_w_c, wts.gate_b)   # :76-81,86-91 in one launch
-            edge_new = _gru(wts, 'edge_gru', e_in, edge, dtype)                  # :83
+        vert, nd = unpack(_gru(wts, 'node_gru', obj_rep, None, dtype, dots=sliced), sliced)   # :71
+        edge, ed = unpack(_gru(wts, 'edge_gru', rel_rep, None, dtype, dots=sliced), sliced)   # :72
+        for i in range(mp_iter):                                                 # :74
+            more = sliced and i + 1 < mp_iter
+            e_in, ctx2 = step(vert, nd, edge, ed)
+            edge_new, ed = unpack(_gru(wts, 'edge_gru', e_in, edge, dtype, dots=more), more)  # :83
             # :92  node_gru(ctx_out + ctx_in, vert): the sum rides in the GEMM's K axis
             gi = ops.gemm(ctx2[0], wts.node_gru_w_ih2, wts.node_gru_b_ih, out_dtype=torch.float32, A2=ctx2[1])
             gh = ops.gemm(vert, wts.node_gru_w_hh, wts.node_gru_b_hh, out_dtype=torch.float32)
-            vert = ops.gru_gate(gi, gh, None, vert, dtype)
+            vert, nd = unpack(ops.gru_gate(gi, gh, None, vert, dtype, dot_w=wts.gate_w[:, :H] if more else None), more)
             edge = edge_new
         return vert, edge
     # Two streams.  Memory rules that keep the caching allocator out of trouble: every tensor that crosses streams is
     # allocated on the main stream and stays referenced until the main stream has waited for the last side-stream
-    # event (verts, keep); temporaries of the side stream (gi, gh) are allocated and freed under the side stream.
+    # event (verts, ndots, keep); temporaries of the side stream (gi, gh) are allocated and freed under the side stream.
     side, ev_main, ev_side = lane
     main = torch.cuda.current_stream(obj_rep.device)
     verts = [torch.empty((N, H), dtype=dtype, device=obj_rep.device) for _ in range(mp_iter + 1)]
+    ndots = [torch.empty((N, 4), dtype=torch.float32, device=obj_rep.device) if sliced else None for _ in range(mp_iter)]
     keep = []
     ev_main.record(main)
     side.wait_event(ev_main)                                                     # obj_rep is ready
     with torch.cuda.stream(side):
-        _gru(wts, 'node_gru', obj_rep, None, dtype, out=verts[0])                # :71
+        gi = ops.gemm(obj_rep, wts.node_gru_w_ih, wts.node_gru_b_ih, out_dtype=torch.float32)
+        ops.gru_gate(gi, None, wts.node_gru_b_hh, None, dtype, out=verts[0],                 # :71
+                     dot_w=wts.gate_w[:, :H] if sliced else None, dots=ndots[0] if mp_iter else None)
+        del gi
         ev_side.record(side)
-    edge = _gru(wts, 'edge_gru', rel_rep, None, dtype)                           # :72
+    edge, ed = unpack(_gru(wts, 'edge_gru', rel_rep, None, dtype, dots=sliced), sliced)       # :72
     for i in range(mp_iter):                                                     # :74
-        main.wait_event(ev_side)                                                 # v_i is ready
-        e_in, ctx2 = ops.imp_fused(verts[i], edge, rel_inds, csr, wts.gate_w_c, wts.gate_b)   # :76-81,86-91 in one launch
+        more = sliced and i + 1 < mp_iter
+        main.wait_event(ev_side)                                                 # v_i (and its gate dots) are ready
+        e_in, ctx2 = step(verts[i], ndots[i], edge, ed)
         keep.append(ctx2)
         ev_main.record(main)
         side.wait_event(ev_main)
         with torch.cuda.stream(side):                                            # :92, K-split sum of the two ctx halves
             gi = ops.gemm(ctx2[0], wts.node_gru_w_ih2, wts.node_gru_b_ih, out_dtype=torch.float32, A2=ctx2[1])
             gh = ops.gemm(verts[i], wts.node_gru_w_hh, wts.node_gru_b_hh, out_dtype=torch.float32)
-            ops.gru_gate(gi, gh, None, verts[i], dtype, out=verts[i + 1])
+            ops.gru_gate(gi, gh, None, verts[i], dtype, out=verts[i + 1], dot_w=wts.gate_w[:, :H] if more else None,
+                         dots=ndots[i + 1] if more else None)
             del gi, gh
             ev_side.record(side)
-        edge = _gru(wts, 'edge_gru', e_in, edge, dtype)                          # :83
+        edge, ed = unpack(_gru(wts, 'edge_gru', e_in, edge, dtype, dots=more), more)          # :83
     main.wait_event(ev_side)
     return verts[-1], edge

@@ -3,6 +3,8 @@
 torch is used for device memory and the current HIP stream only; every wrapper hands raw device pointers
 to libsgg_hip.so.  Nothing here computes on the CPU and nothing falls back to torch ops.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -110,8 +112,17 @@ def pair_index_train(im_inds, gt_rels, img_first, cap):
     return out, count
 
 
-def edge_csr(rel_inds, N, im_inds=None):
-    """CSR lists by subject / object.  im_inds (node -> image, i64[N]) may be given when rel_inds is sorted by image."""
+class Csr(tuple):
+    """(out_ptr, out_ids, in_ptr, in_ids, so, flags) + what the sliced IMP kernel needs: `img_ptr` i32[B+1] (first node of each
+    graph) and `graphs` = (B, max_nodes, max_edges) known on the host; both None when the caller gave no hint."""
+    img_ptr = None
+    graphs = None
+
+
+def edge_csr(rel_inds, N, im_inds=None, graphs=None):
+    """CSR lists by subject / object.  im_inds (node -> image, i64[N]) may be given when rel_inds is sorted by image.
+    graphs = (B, max_nodes, max_edges) (host-side facts, optional): rel_inds is sorted by (image, subject) and no image has
+    more nodes / edges than stated -- enables the sliced IMP kernel (imp_sliced_ok)."""
     E = rel_inds.shape[0]
     dev = rel_inds.device
     out_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
@@ -122,7 +133,13 @@ def edge_csr(rel_inds, N, im_inds=None):
     flags = torch.empty(1, dtype=torch.int32, device=dev)
     _lib.call('sgg_edge_csr', _p(rel_inds, torch.int64), E, N, _p(im_inds, torch.int64) if im_inds is not None else None,
               _p(out_ptr), _p(out_ids), _p(in_ptr), _p(in_ids), _p(so), _p(flags), _stream())
-    return out_ptr, out_ids, in_ptr, in_ids, so, flags
+    csr = Csr((out_ptr, out_ids, in_ptr, in_ids, so, flags))
+    if graphs is not None and im_inds is not None and E > 0:
+        B = int(graphs[0])
+        csr.img_ptr = torch.empty(2 * (B + 1), dtype=torch.int32, device=dev)    # node offsets, then edge offsets
+        _lib.call('sgg_graph_ptr', _p(im_inds, torch.int64), N, B, _p(out_ptr), _p(csr.img_ptr), _stream())
+        csr.graphs = (B, int(graphs[1]), int(graphs[2]))
+    return csr
 
 
 # ---------------------------------------------------------------- a-4
@@ -274,15 +291,52 @@ def imp_fused(v, e, rel_inds, csr, gate_w, gate_b, e_in=None, ctx2=None):
     return e_in, ctx2
 
 
-def gru_gate(gi, gh, b_hh, h_prev, out_dtype, out=None):
+def imp_sliced_ok(csr, H, dtype):
+    """True when the sliced kernel takes these graphs (host-side facts in csr.graphs, see edge_csr)."""
+    g = getattr(csr, 'graphs', None)
+    if g is None or os.environ.get('SGG_IMP_SLICED', '1') == '0':
+        return False
+    h8 = H // 8
+    if H % 8 or h8 > 64 or (h8 & (h8 - 1)):
+        return False                                   # the gate-dot epilogue of gru_gate needs H/8 a power of two
+    cap = _lib.load().sgg_imp_sliced_capacity(H, _lib.SGG_BF16 if dtype == torch.bfloat16 else _lib.SGG_F32)
+    return g[1] <= 64 and g[2] <= cap
+
+
+def imp_sliced(v, e, csr, node_dots, edge_dots, gate_b, e_in=None, ctx2=None):
+    """One launch per IMP iteration, every edge row read once: -> (e_in [E,H], ctx2 [2,N,H]).  node_dots f32[N,4] /
+    edge_dots f32[E,4] come from gru_gate(dot_w=...)."""
+    N, H = v.shape
+    E = e.shape[0]
+    out_ptr, out_ids, in_ptr, in_ids, so, flags = csr
+    B, max_nodes, max_edges = csr.graphs
+    if e_in is None:
+        e_in = torch.empty_like(e)
+    if ctx2 is None:
+        ctx2 = torch.empty((2, N, H), dtype=v.dtype, device=v.device)
+    _lib.call('sgg_imp_sliced_fwd', _p(v), _p(e), _p(so), _p(out_ptr), _p(in_ptr), _p(in_ids), _p(csr.img_ptr), B, N, E, H,
+              _p(node_dots, torch.float32), _p(edge_dots, torch.float32), _p(gate_b, torch.float32), _p(e_in), _p(ctx2),
+              max_edges, max_nodes, dt(v), _stream())
+    return e_in, ctx2
+
+
+def gru_gate(gi, gh, b_hh, h_prev, out_dtype, out=None, dot_w=None, dots=None):
+    """dot_w (optional): f32 view [4,H] of the gate matrix [4,2H] (row stride 2H) -- vertex halves gate_w[:, :H] or edge halves
+    gate_w[:, H:]; with it the call also returns dots f32[M,4] = h' . dot_w^T (the next IMP step's gate pre-activations)."""
     M, H3 = gi.shape
     H = H3 // 3
     if out is None:
         out = torch.empty((M, H), dtype=out_dtype, device=gi.device)
+    if dot_w is not None:
+        if dot_w.dtype != torch.float32 or dot_w.stride(1) != 1 or dot_w.shape != (4, H):
+            raise ValueError('gru_gate: dot_w must be an f32 [4,H] view with unit column stride')
+        if dots is None:
+            dots = torch.empty((M, 4), dtype=torch.float32, device=gi.device)
     _lib.call('sgg_gru_gate_fwd', _p(gi), _p(gh) if gh is not None else None,
               _p(b_hh, torch.float32) if b_hh is not None else None, _p(h_prev) if h_prev is not None else None, _p(out),
-              M, H, dt(gi), dt(out), _stream())
-    return out
+              M, H, dot_w.data_ptr() if dot_w is not None else None, dot_w.stride(0) if dot_w is not None else 0,
+              _p(dots, torch.float32) if dot_w is not None else None, dt(gi), dt(out), _stream())
+    return (out, dots) if dot_w is not None else out
 
 
 # ---------------------------------------------------------------- a-11

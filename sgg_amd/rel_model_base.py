@@ -192,6 +192,11 @@ class RelModelBase(nn.Module):
         result.fmap = as_nchw_view(fmap)
         result.rois = torch.cat((im_inds.float()[:, None], priors), 1)
         result._num_pairs = sum((e - s) * (e - s - 1) for _, s, e in segs)   # host-side count (private)
+        # host-side facts about the graphs (private): (images, most nodes, most candidate edges in one image).  In training
+        # gt_labels knows the exact rows per image (duplicate FG relations add rows) when the batch has a host mirror.
+        worst = getattr(rel_labels, '_sgg_max_edges', None) if rel_labels is not None else \
+            max((e - s) * (e - s - 1) for _, s, e in segs)
+        result._graphs = (segs[-1][0] + 1, max(e - s for _, s, e in segs), worst) if worst is not None else None
         return result
 
     def _faster_rcnn_sgdet(self, x, gt_classes):
@@ -280,8 +285,17 @@ class RelModelBase(nn.Module):
                     else:
                         regular = False          # self / out-of-range relation: let the device count decide
                 n = n_cand - len(fg_pairs) + R if regular else int(count.item())
+                max_edges = None
+                if regular:      # rows of image i = its candidates - its distinct FG pairs + its FG relations
+                    per_im = {i: sz * (sz - 1) for i, sz in sizes.items()}
+                    for im, _, _ in fg_pairs:
+                        per_im[im] -= 1
+                    for im, _, _, _ in rels_host.tolist():
+                        per_im[im] += 1
+                    max_edges = max(per_im.values())
             else:
                 n = int(count.item())
+                max_edges = None
             rel_labels = out[:n]
             # sub-sampling (lib/proposal_assignments_gtbox.py:47-66): at most RELS_PER_IMG*0.25*num_im FG rows and
             # RELS_PER_IMG*num_im rows in total (or num_fg*sample_factor BG rows).  random_choose is a uniform random
@@ -299,6 +313,8 @@ class RelModelBase(nn.Module):
                         drop = pos[torch.randperm(have, device=pos.device)[want:]]
                         keep[drop] = False
                 rel_labels = rel_labels[keep].contiguous()
+            if max_edges is not None:
+                rel_labels._sgg_max_edges = max_edges       # sub-sampling only removes rows: still an upper bound
             obj_labels = gt_classes[:, 1].contiguous()
         else:
             obj_labels = gt_classes[:, 1]

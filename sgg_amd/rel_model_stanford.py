@@ -115,7 +115,7 @@ class RelModelStanford(RelModelBase):
                                                                           (torch.float32, torch.bfloat16) else t, dtype)
         return message_pass(cast(rel_rep), cast(obj_rep), ri3, csr, w['imp'], self.mp_iter, dtype)
 
-    def predict(self, node_feat, edge_feat, rel_inds, rois, im_sizes, _im_inds=None):
+    def predict(self, node_feat, edge_feat, rel_inds, rois, im_sizes, _im_inds=None, _graphs=None):
         """rel_model_stanford.py:97-107.  node_feat [N,C,7,7], edge_feat [E,C,7,7] (raw RoIAlign), rel_inds i64[E,3]
         -> (obj_dists f32[N,151], rel_dists f32[E,51])."""
         dtype = self.compute_dtype
@@ -126,7 +126,7 @@ class RelModelStanford(RelModelBase):
         if self.training:
             # Dropout, batch-statistic BatchNorm and the autograd node of the whole head (sgg_amd/train.py)
             from .train import predict_train
-            return predict_train(self, nf, ef, rel_inds, rois, _im_inds, dropout_p=self.dropout_p)
+            return predict_train(self, nf, ef, rel_inds, rois, _im_inds, dropout_p=self.dropout_p, graphs=_graphs)
         w = self.prepared()
         # :100  union_boxes(edge_feat, rois, rel_inds[:,1:]) -- conv(rects)[E,512]; the broadcast add rides in fc6's K
         rect = self.union_boxes.rect_feat(rois, rel_inds[:, 1:].contiguous(), dtype)
@@ -157,7 +157,8 @@ class RelModelStanford(RelModelBase):
         rel_rep = ops.gemm(y, w['edge_unary'], w['edge_unary_b'], ops.ACT_RELU)
         # :105
         _lib.set_tag('imp')
-        csr = ops.edge_csr(rel_inds, N, _im_inds)   # _im_inds: only forward() passes it (its rel_inds are image-sorted)
+        # _im_inds / _graphs: only forward() passes them (its rel_inds are sorted by (image, subject, object))
+        csr = ops.edge_csr(rel_inds, N, _im_inds, graphs=_graphs)
         vert, edge = message_pass(rel_rep, obj_rep, rel_inds, csr, w['imp'], self.mp_iter, dtype)
         # :107
         _lib.set_tag('heads')
@@ -193,7 +194,8 @@ class RelModelStanford(RelModelBase):
                 result.fmap, rois, rel_inds[:, 1:], im_sizes=result.im_sizes)            # :148
         result.rm_obj_dists, result.rel_dists = self.predict(result.node_feat, result.edge_feat, rel_inds,
                                                              rois=rois, im_sizes=result.im_sizes,
-                                                             _im_inds=im_inds.contiguous())         # :153
+                                                             _im_inds=im_inds.contiguous(),
+                                                             _graphs=getattr(result, '_graphs', None))   # :153
         if self.use_bias:                                                                # :159-177, one fused lookup
             result.rel_dists, result.obj_preds = self.freq_bias.apply_to(
                 result.rel_dists, result.rm_obj_dists, rel_inds,

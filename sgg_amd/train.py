@@ -93,11 +93,12 @@ def train_weights(model):
     return w
 
 
-def _gru_fwd(x, h, w_ih, w_hh, b_ih, b_hh, dtype, out):
+def _gru_fwd(x, h, w_ih, w_hh, b_ih, b_hh, dtype, out, dot_w=None):
+    """-> (gi, gh, dots): dots f32[M,4] = the new state's gate dot products against dot_w (None without dot_w)."""
     gi = ops.gemm(x, w_ih, b_ih, out_dtype=torch.float32)
     gh = ops.gemm(h, w_hh, b_hh, out_dtype=torch.float32) if h is not None else None
-    ops.gru_gate(gi, gh, b_hh if h is None else None, h, dtype, out=out)
-    return gi, gh
+    r = ops.gru_gate(gi, gh, b_hh if h is None else None, h, dtype, out=out, dot_w=dot_w)
+    return gi, gh, (r[1] if dot_w is not None else None)
 
 
 class PredictFn(torch.autograd.Function):
@@ -171,24 +172,33 @@ class PredictFn(torch.autograd.Function):
         sv.update(x6=x6, x7=x7, y6=y6, y7=y7)
         # ---- message passing (rel_model_stanford.py:68-94)
         _lib.set_tag('imp')
-        csr = ops.edge_csr(rel_inds, N, im_inds)
+        csr = ops.edge_csr(rel_inds, N, im_inds, graphs=getattr(model, '_graphs_hint', None))
+        # sliced step (every edge row read once): the gate dot products come out of the GRU gate kernels -- the vertex ones
+        # are also what the backward needs (`dots`), so the separate node_gate_dots launches go away with it
+        sliced = model.mp_iter > 0 and ops.imp_sliced_ok(csr, H, dt)
+        wv, we = (imp.gate_w[:, :H], imp.gate_w[:, H:]) if sliced else (None, None)
         gin, ghn, gie, ghe, dots_l, gates_l = [], [], [], [], [], []
-        a, b = _gru_fwd(XN[:N], None, imp.node_gru_w_ih, imp.node_gru_w_hh, imp.node_gru_b_ih, imp.node_gru_b_hh, dt, HN[:N])
+        a, b, nd = _gru_fwd(XN[:N], None, imp.node_gru_w_ih, imp.node_gru_w_hh, imp.node_gru_b_ih, imp.node_gru_b_hh, dt, HN[:N], wv)
         gin.append(a); ghn.append(b)
-        a, b = _gru_fwd(XE[:E], None, imp.edge_gru_w_ih, imp.edge_gru_w_hh, imp.edge_gru_b_ih, imp.edge_gru_b_hh, dt, HE[:E])
+        a, b, ed = _gru_fwd(XE[:E], None, imp.edge_gru_w_ih, imp.edge_gru_w_hh, imp.edge_gru_b_ih, imp.edge_gru_b_hh, dt, HE[:E], we)
         gie.append(a); ghe.append(b)
         for i in range(model.mp_iter):
             v_i, e_i = HN[i * N:(i + 1) * N], HE[i * E:(i + 1) * E]
-            dots = ops.imp_node_gate_dots(v_i, imp.gate_w)                      # saved for the backward
-            _, ctx2 = ops.imp_fused(v_i, e_i, rel_inds, csr, imp.gate_w_c, imp.gate_b, e_in=XE[(i + 1) * E:(i + 2) * E])
+            more = sliced and i + 1 < model.mp_iter
+            if sliced:
+                dots = nd                                                       # saved for the backward
+                _, ctx2 = ops.imp_sliced(v_i, e_i, csr, nd, ed, imp.gate_b, e_in=XE[(i + 1) * E:(i + 2) * E])
+            else:
+                dots = ops.imp_node_gate_dots(v_i, imp.gate_w)                  # saved for the backward
+                _, ctx2 = ops.imp_fused(v_i, e_i, rel_inds, csr, imp.gate_w_c, imp.gate_b, e_in=XE[(i + 1) * E:(i + 2) * E])
             ctx_i = XN[(i + 1) * N:(i + 2) * N]                                # ctx = ctx_out + ctx_in (kept for d W_ih)
             ctx_i.copy_(ctx2[0])
             ops.add_(ctx_i, ctx2[1])
-            a, b = _gru_fwd(XE[(i + 1) * E:(i + 2) * E], e_i, imp.edge_gru_w_ih, imp.edge_gru_w_hh, imp.edge_gru_b_ih,
-                            imp.edge_gru_b_hh, dt, HE[(i + 1) * E:(i + 2) * E])
+            a, b, ed = _gru_fwd(XE[(i + 1) * E:(i + 2) * E], e_i, imp.edge_gru_w_ih, imp.edge_gru_w_hh, imp.edge_gru_b_ih,
+                                imp.edge_gru_b_hh, dt, HE[(i + 1) * E:(i + 2) * E], we if more else None)
             gie.append(a); ghe.append(b)
-            a, b = _gru_fwd(XN[(i + 1) * N:(i + 2) * N], v_i, imp.node_gru_w_ih, imp.node_gru_w_hh, imp.node_gru_b_ih,
-                            imp.node_gru_b_hh, dt, HN[(i + 1) * N:(i + 2) * N])
+            a, b, nd = _gru_fwd(XN[(i + 1) * N:(i + 2) * N], v_i, imp.node_gru_w_ih, imp.node_gru_w_hh, imp.node_gru_b_ih,
+                                imp.node_gru_b_hh, dt, HN[(i + 1) * N:(i + 2) * N], wv if more else None)
             gin.append(a); ghn.append(b)
             dots_l.append(dots)
         T = model.mp_iter
@@ -366,7 +376,7 @@ class PredictFn(torch.autograd.Function):
         return (None,) * 8 + tuple(grads)
 
 
-def predict_train(model, node_feat, edge_feat, rel_inds, rois, im_inds=None, seed=None, dropout_p=DROPOUT_P):
+def predict_train(model, node_feat, edge_feat, rel_inds, rois, im_inds=None, seed=None, dropout_p=DROPOUT_P, graphs=None):
     """Autograd-connected training forward of the head.  node_feat/edge_feat: [.,P,P,C]-contiguous (NHWC) tensors
     in the compute dtype."""
     N, E = node_feat.shape[0], edge_feat.shape[0]
@@ -374,5 +384,6 @@ def predict_train(model, node_feat, edge_feat, rel_inds, rois, im_inds=None, see
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
     named = dict(model.head_named_parameters())
     params = [named[n] for n in param_names(model)]
+    model._graphs_hint = graphs     # host-side facts about the graphs (ops.edge_csr), read by PredictFn.forward
     return PredictFn.apply(model, node_feat.reshape(N, -1), edge_feat.reshape(E, -1), rois.float().contiguous(),
                            rel_inds.contiguous(), im_inds, seed, float(dropout_p), *params)

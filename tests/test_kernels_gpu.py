@@ -456,6 +456,110 @@ def test_imp_kernels_full_size_vs_oracle(ops):
     torch.testing.assert_close(ctx.float().cpu(), exp_ctx, atol=0.3, rtol=2e-2)
 
 
+def _imp_expect(v, e, rel, gw, gb):
+    s, o = torch.from_numpy(rel[:, 1]), torch.from_numpy(rel[:, 2])
+    sv, ov = v[s], v[o]
+    gt = [torch.sigmoid(torch.cat((a, e), 1) @ gw[k] + gb[k]) for k, a in enumerate((sv, ov, sv, ov))]
+    e_in = gt[0][:, None] * sv + gt[1][:, None] * ov
+    ctx_out = torch.zeros(v.shape[0], v.shape[1]).index_add_(0, s, gt[2][:, None] * e)
+    ctx_in = torch.zeros(v.shape[0], v.shape[1]).index_add_(0, o, gt[3][:, None] * e)
+    return e_in, ctx_out, ctx_in
+
+
+@pytest.mark.parametrize('H,sizes,dtype', [
+    (512, [32, 32], torch.float32),              # benchmark graphs, f32: 32-channel slices
+    (512, [32, 7, 1, 20, 2], torch.float32),     # ragged batch incl. a graph without edges
+    (512, [32] * 3, torch.bfloat16),             # bf16: 64-channel slices (LP = 8)
+    (512, [40, 36], torch.bfloat16),             # 1560 edges per graph: 64-byte pieces (LP = 4)
+    (512, [52, 5], torch.bfloat16),              # 2652 edges: 32-byte pieces (LP = 2)
+    (64, [9, 32, 4], torch.float32),             # narrow rows (golden-sized hidden dim)
+    (32, [6, 6], torch.bfloat16),                # 64-byte rows: one LP = 4 slice
+])
+def test_imp_sliced_vs_oracle_math(ops, H, sizes, dtype):
+    """sgg_imp_sliced_fwd (+ the gate-dot epilogue of sgg_gru_gate_fwd feeding it) against the dense restatement of
+    rel_model_stanford.py:76-91, and against sgg_imp_fused_fwd on the same inputs."""
+    g = torch.Generator().manual_seed(11 + H + len(sizes))
+    im = np.concatenate([np.full(n, b) for b, n in enumerate(sizes)]).astype(np.int64)
+    rel = O.get_rel_inds_eval(im)
+    if sizes[0] == 32 and len(sizes) == 5:       # sampled edge list: drop ~40 % of the rows, node 3 loses its out-edges
+        rng = np.random.RandomState(2)
+        keep = rng.rand(len(rel)) > 0.4
+        keep[rel[:, 1] == 3] = False
+        rel = rel[keep]
+    N, E = len(im), len(rel)
+    gw, gb = torch.randn(4, 2 * H, generator=g) / (H ** 0.5), torch.randn(4, generator=g)
+    # v and e are produced by the GRU gate kernel itself so that its dot epilogue is what feeds the sliced kernel
+    def state(M, dot_w):
+        gi, gh = torch.randn(M, 3 * H, generator=g), torch.randn(M, 3 * H, generator=g)
+        hp = torch.randn(M, H, generator=g)
+        out, dots = ops.gru_gate(cu(gi), cu(gh), None, cu(hp.to(dtype)), dtype, dot_w=dot_w)
+        plain = ops.gru_gate(cu(gi), cu(gh), None, cu(hp.to(dtype)), dtype)
+        assert torch.equal(out, plain)                                   # the epilogue does not change the state
+        return out, dots
+    gwd = cu(gw)
+    v_d, nd = state(N, gwd[:, :H])
+    e_d, ed = state(E, gwd[:, H:])
+    v, e = v_d.float().cpu(), e_d.float().cpu()
+    torch.testing.assert_close(nd.cpu(), v @ gw[:, :H].t(), atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(ed.cpu(), e @ gw[:, H:].t(), atol=2e-5, rtol=1e-5)
+    graphs = (len(sizes), max(sizes), max(int(((rel[:, 0] == b).sum())) for b in range(len(sizes))))
+    csr = ops.edge_csr(cu(rel), N, cu(im), graphs=graphs)
+    assert ops.imp_sliced_ok(csr, H, dtype)
+    np.testing.assert_array_equal(csr.img_ptr.cpu().numpy()[:len(sizes) + 1], np.concatenate(([0], np.cumsum(sizes))))
+    per_graph = [int((rel[:, 0] == b).sum()) for b in range(len(sizes))]
+    np.testing.assert_array_equal(csr.img_ptr.cpu().numpy()[len(sizes) + 1:], np.concatenate(([0], np.cumsum(per_graph))))
+    e_in, ctx2 = ops.imp_sliced(v_d, e_d, csr, nd, ed, cu(gb))
+    exp_ein, exp_out, exp_in = _imp_expect(v, e, rel, gw, gb)
+    tol = dict(atol=2e-5, rtol=1e-5) if dtype == torch.float32 else dict(atol=3e-2, rtol=1e-2)
+    ctol = dict(atol=1e-4, rtol=1e-5) if dtype == torch.float32 else dict(atol=0.3, rtol=2e-2)
+    torch.testing.assert_close(e_in.float().cpu(), exp_ein, **tol)
+    torch.testing.assert_close(ctx2[0].float().cpu(), exp_out, **ctol)
+    torch.testing.assert_close(ctx2[1].float().cpu(), exp_in, **ctol)
+    # the node-centric kernel on the same inputs
+    e_in_f, ctx2f = ops.imp_fused(v_d, e_d, cu(rel), csr, cu(gw).to(dtype), cu(gb))
+    torch.testing.assert_close(e_in.float(), e_in_f.float(), **tol)
+    torch.testing.assert_close(ctx2.float(), ctx2f.float(), **ctol)
+
+
+def test_imp_sliced_capacity_and_fallback(ops):
+    """Graphs the staging area cannot hold are refused by the C entry (SGG_ERR_CAPACITY -> ValueError) and by imp_sliced_ok;
+    message_pass then runs the node-centric kernel and gives the same result as without the hint."""
+    from sgg_amd.imp import ImpWeights, message_pass
+    H = 64
+    g = torch.Generator().manual_seed(5)
+    sizes = [70, 3]                                  # 70 nodes > 64
+    im = np.concatenate([np.full(n, b) for b, n in enumerate(sizes)]).astype(np.int64)
+    rel = O.get_rel_inds_eval(im)
+    N, E = len(im), len(rel)
+    csr = ops.edge_csr(cu(rel), N, cu(im), graphs=(2, 70, 70 * 69))
+    assert not ops.imp_sliced_ok(csr, H, torch.float32)
+    v, e = cu(torch.randn(N, H, generator=g)), cu(torch.randn(E, H, generator=g))
+    with pytest.raises(ValueError):
+        ops.imp_sliced(v, e, csr, cu(torch.zeros(N, 4)), cu(torch.zeros(E, 4)), cu(torch.zeros(4)))
+    p = {}
+    for gname in ('edge_gru', 'node_gru'):
+        p[gname + '.weight_ih'], p[gname + '.weight_hh'] = torch.randn(3 * H, H, generator=g) / 8, torch.randn(3 * H, H, generator=g) / 8
+        p[gname + '.bias_ih'], p[gname + '.bias_hh'] = torch.randn(3 * H, generator=g) / 8, torch.randn(3 * H, generator=g) / 8
+    for gname in ('sub_vert_w_fc', 'obj_vert_w_fc', 'out_edge_w_fc', 'in_edge_w_fc'):
+        p[gname + '.0.weight'], p[gname + '.0.bias'] = torch.randn(1, 2 * H, generator=g) / 8, torch.randn(1, generator=g)
+    wts = ImpWeights.from_state({k: cu(t) for k, t in p.items()}, torch.float32)
+    got = message_pass(e, v, cu(rel), csr, wts, 2, torch.float32)
+    # a batch the sliced kernel does take: same numbers with and without the hint
+    sizes = [12, 9]
+    im = np.concatenate([np.full(n, b) for b, n in enumerate(sizes)]).astype(np.int64)
+    rel = O.get_rel_inds_eval(im)
+    N, E = len(im), len(rel)
+    v, e = cu(torch.randn(N, H, generator=g)), cu(torch.randn(E, H, generator=g))
+    hint = ops.edge_csr(cu(rel), N, cu(im), graphs=(2, 12, 132))
+    plain = ops.edge_csr(cu(rel), N, cu(im))
+    assert ops.imp_sliced_ok(hint, H, torch.float32) and not ops.imp_sliced_ok(plain, H, torch.float32)
+    a = message_pass(e, v, cu(rel), hint, wts, 3, torch.float32)
+    b = message_pass(e, v, cu(rel), plain, wts, 3, torch.float32)
+    torch.testing.assert_close(a[0], b[0], atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(a[1], b[1], atol=2e-5, rtol=1e-5)
+    assert all(torch.isfinite(t).all() for t in got)
+
+
 # ----------------------------------------------------------------------------------------- eval tail
 def test_eval_tail_vs_reference_golden(ops, golden):
     g = golden('eval_tail')

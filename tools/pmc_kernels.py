@@ -44,10 +44,13 @@ for B in (8, 128):
     im = torch.arange(B, device=dev).repeat_interleave(n)
     rel, _ = ops.pair_index_eval(im)
     rel = rel[:E]
-    csr = ops.edge_csr(rel, Nn, im)
+    csr = ops.edge_csr(rel, Nn, im, graphs=(B, n, n * (n - 1)))
     v = torch.randn(Nn, H, generator=g).to(dev).to(dt)
     e = torch.randn(E, H, generator=g).to(dev).to(dt)
+    nd, ed = (v.float() @ gw[:, :H].t()).contiguous(), (e.float() @ gw[:, H:].t()).contiguous()
     for _ in range(3):
         ops.imp_fused(v, e, rel, csr, gw.to(dt), gb)
+    for _ in range(3):
+        ops.imp_sliced(v, e, csr, nd, ed, gb)
     torch.cuda.synchronize()
 print('done')
