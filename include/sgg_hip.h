@@ -152,15 +152,16 @@ int sgg_imp_fused_fwd(const void* v, const void* e, const int* so /*[E,2]*/, con
  * slice of the rows); edge pieces are staged in LDS by LDS-DMA, gates come from node_dots f32[N,4] / edge_dots f32[E,4]
  * (sgg_gru_gate_fwd's dot outputs, vertex / edge halves of gate_w), e_in pieces stream out, ctx2 halves are reduced from
  * LDS.  Requires: rel_inds sorted by (graph, subject) (both pair-index calls emit that; out-lists are then ranges), nodes
- * grouped by graph with img_ptr i32[2(B+1)] (sgg_graph_ptr), every graph with <= max_nodes <= 64 nodes and <= max_edges edges
+ * grouped by graph with img_ptr from sgg_graph_ptr, every graph with <= max_nodes <= 64 nodes and <= max_edges edges
  * (SGG_ERR_CAPACITY above sgg_imp_sliced_capacity(H, dtype)).  Same outputs as sgg_imp_fused_fwd. */
 int sgg_imp_sliced_capacity(int H, int dtype);
 int sgg_imp_sliced_fwd(const void* v, const void* e, const int* so /*[E,2]*/, const int* out_ptr, const int* in_ptr,
                        const int* in_ids, const int* img_ptr, int B, int N, int E, int H, const float* node_dots,
                        const float* edge_dots, const float* gate_b, void* e_in, void* ctx2 /*[2,N,H]*/, int max_edges,
                        int max_nodes, int dtype, void* stream);
-/* img_ptr i32[2*(B+1)]: img_ptr[b] = first node of graph b (im_inds i64[N] ascending), img_ptr[B] = N; then
- * img_ptr[B+1+b] = out_ptr[first node of b] = first edge of graph b (out_ptr from sgg_edge_csr, same stream, edges sorted) */
+/* img_ptr i32[2*(B+1) + 66*B]: img_ptr[b] = first node of graph b (im_inds i64[N] ascending), img_ptr[B] = N; then
+ * img_ptr[B+1+b] = out_ptr[first node of b] = first edge of graph b (out_ptr from sgg_edge_csr, same stream, edges sorted);
+ * then per graph 66 graph-relative out-list offsets of its nodes (entries past the last node repeat the edge count). */
 int sgg_graph_ptr(const int64_t* im_inds, int N, int B, const int* out_ptr, int* img_ptr, void* stream);
 
 /* ---- a-9  GRU cell pointwise part: nn.GRUCell, rel_model_stanford.py:36-37,71-72,83,92 ----

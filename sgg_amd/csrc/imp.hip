@@ -376,7 +376,10 @@ __global__ __launch_bounds__(256) void gru_gate_kernel(const TG* __restrict__ gi
 // and lane group: 4 in phase 1 (vertex dot, v[o] piece, park row, park gate) + 3 in phase 2.  Needs the edge list sorted by
 // (graph, subject) -- out-lists are ranges -- and the graph to fit: edges <= EMAX, nodes <= SL_NMAX.
 // ------------------------------------------------------------------------------------------------
-constexpr int SL_THREADS = 1024;
+#ifndef SGG_SL_THREADS
+#define SGG_SL_THREADS 512   // 8 waves: two workgroups share a CU when the parked pieces leave room (measured best)
+#endif
+constexpr int SL_THREADS = SGG_SL_THREADS;
 constexpr int SL_NMAX = 64;
 #ifndef SGG_SLICED_ABL
 #define SGG_SLICED_ABL 0   // kernel experiments only: 1 no phase 2, 2 no e_in stores
@@ -445,7 +448,20 @@ __global__ __launch_bounds__(SL_THREADS) void imp_sliced_kernel(const T* __restr
 #else
 #define SGG_TICK(i)
 #endif
-    // dependent-load level 1 (scalar): img_ptr = [node offsets (B+1) | edge offsets (B+1)]
+    // dependent-load level 1: img_ptr = [node offsets (B+1) | edge offsets (B+1) | per graph: SL_NMAX+2 relative out offsets].
+    // Which node a lane group owns depends on P, i.e. on the node count that is being loaded right now: fetch the list range of
+    // every candidate (P = 1, 2, 4, ...) from the graph's table -- its address needs blockIdx only -- and pick afterwards.
+    constexpr int NC = LP == 8 ? 4 : LP == 4 ? 5 : 6;         // lg P in [0, NC): P LP <= 64
+    int cand_b[NC], cand_e[NC];
+    {
+        const int* tab = img_ptr + 2 * (B + 1) + (long)g * (SL_NMAX + 2);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int nc = min(grp >> c, SL_NMAX);
+            cand_b[c] = tab[nc];
+            cand_e[c] = tab[nc + 1];
+        }
+    }
     const int n0 = img_ptr[g], n1 = img_ptr[g + 1], Nn = n1 - n0;
     const int e0 = img_ptr[B + 1 + g], e1 = img_ptr[B + 2 + g], Ee = e1 - e0;
     const int i0 = e0;                           // edges are grouped by graph: the in-lists of earlier graphs hold e0 entries
@@ -461,16 +477,22 @@ __global__ __launch_bounds__(SL_THREADS) void imp_sliced_kernel(const T* __restr
     }
     // P lane groups share a node (P a power of two, the P groups inside one wave): its lists are cut into P contiguous parts.
     // Nn <= SL_NMAX <= GROUPS: every node has its own lane group(s), one node per group.
-    int P = 1;
-    while (2 * P * LP <= 64 && 2 * P * Nn <= GROUPS) P *= 2;
+    int P = 1, lgP = 0;
+    while (2 * P * LP <= 64 && 2 * P * Nn <= GROUPS) {
+        P *= 2;
+        ++lgP;
+    }
     const int part = grp % P, n = grp / P;
     const bool has_node = n < Nn;
-    // level 2 (vector, all independent): this group's out-list range + everything phase 0 parks in LDS
-    int ob = 0, oe = 0;
-    if (has_node) {
-        ob = out_ptr[n0 + n] - e0;
-        oe = out_ptr[n0 + n + 1] - e0;
+    int ob = cand_b[0], oe = cand_e[0];
+#pragma unroll
+    for (int c = 1; c < NC; ++c) {
+        if (lgP == c) {
+            ob = cand_b[c];
+            oe = cand_e[c];
+        }
     }
+    // level 2 (vector, all independent): the first edges of this group's list + everything phase 0 parks in LDS
     u32x4 p_v = {0, 0, 0, 0};
     f32x4 p_nd = {0, 0, 0, 0};
     int p_ip = 0;
@@ -700,7 +722,23 @@ __global__ void graph_ptr_kernel(const int64_t* __restrict__ im, int N, int B, c
         else hi = mid;
     }
     ptr[b] = lo;
-    ptr[B + 1 + b] = out_ptr[lo];  // first edge of graph b when the edge list is sorted by (graph, subject)
+    const int e0 = out_ptr[lo];
+    ptr[B + 1 + b] = e0;           // first edge of graph b when the edge list is sorted by (graph, subject)
+    if (b == B) return;
+    // graph-relative out-list offsets of the graph's nodes at an address that depends on b only: the sliced kernel loads them
+    // together with ptr[b] instead of after it.  Entries past the graph's last node repeat its edge count.
+    int nxt = lo;
+    {
+        int l2 = lo, h2 = N;
+        while (l2 < h2) {
+            const int mid = (l2 + h2) >> 1;
+            if (im[mid] < b + 1) l2 = mid + 1;
+            else h2 = mid;
+        }
+        nxt = l2;
+    }
+    int* tab = ptr + 2 * (B + 1) + (long)b * (SL_NMAX + 2);
+    for (int n = 0; n < SL_NMAX + 2; ++n) tab[n] = out_ptr[min(lo + n, nxt)] - e0;
 }
 
 template <typename T, int LP>
@@ -751,16 +789,19 @@ extern "C" int sgg_imp_sliced_fwd(const void* v, const void* e, const int* so, c
     if (row % 32) return SGG_ERR_ARG;
     if (max_nodes > SL_NMAX) return SGG_ERR_CAPACITY;
     hipStream_t s = (hipStream_t)stream;
-    // piece width: 128-B pieces (whole cache lines per edge and slice) when they fit
+    // piece width: 64-byte pieces (LP = 4) first -- a 992-edge graph then parks 62 KB, two workgroups fit a CU and one's loads
+    // run under the other's gate / accumulate phases (measured: 9.1 vs 12.2 us at B=8, 70 vs 72 us at B=128 against 128-byte
+    // pieces with one workgroup per CU); 32-byte pieces for graphs above LP = 4's capacity
     int lp = 0;
-    if (row % 128 == 0 && max_edges <= SliceCfg<8>::EMAX) lp = 8;
-    else if (row % 64 == 0 && max_edges <= SliceCfg<4>::EMAX) lp = 4;
+    if (row % 64 == 0 && max_edges <= SliceCfg<4>::EMAX) lp = 4;
     else if (max_edges <= SliceCfg<2>::EMAX) lp = 2;
     else return SGG_ERR_CAPACITY;
     static const char* force = getenv("SGG_IMP_LP");     // kernel experiments only
     if (force) {
         const int f = atoi(force);
-        if ((f == 8 || f == 4 || f == 2) && f <= lp && row % (f * 16) == 0) lp = f;
+        if ((f == 8 || f == 4 || f == 2) && row % (f * 16) == 0 &&
+            max_edges <= (f == 8 ? SliceCfg<8>::EMAX : f == 4 ? SliceCfg<4>::EMAX : SliceCfg<2>::EMAX))
+            lp = f;
     }
 #define SGG_SLICED(T, LPV) \
     return launch_sliced<T, LPV>(v, e, so, out_ptr, in_ptr, in_ids, img_ptr, B, N, H, node_dots, edge_dots, gate_b, e_in, ctx2, \

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, 
 constexpr int MAXS = 32;  // max P*sampling samples per axis
 
 template <typename T>
-__global__ __launch_bounds__(512) void roi_align_kernel(const T* __restrict__ fmap, int B, int H, int W, int C,
+__global__ __launch_bounds__(512, 4) void roi_align_kernel(const T* __restrict__ fmap, int B, int H, int W, int C,
                                                         const float* __restrict__ rois, const int64_t* __restrict__ pairs,
                                                         int R, float scale, int P, int S, const float* __restrict__ add_ec,
                                                         T* __restrict__ out) {

@@ -136,7 +136,7 @@ def edge_csr(rel_inds, N, im_inds=None, graphs=None):
     csr = Csr((out_ptr, out_ids, in_ptr, in_ids, so, flags))
     if graphs is not None and im_inds is not None and E > 0:
         B = int(graphs[0])
-        csr.img_ptr = torch.empty(2 * (B + 1), dtype=torch.int32, device=dev)    # node offsets, then edge offsets
+        csr.img_ptr = torch.empty(2 * (B + 1) + 66 * B, dtype=torch.int32, device=dev)   # node offsets, edge offsets, per-graph out-list table
         _lib.call('sgg_graph_ptr', _p(im_inds, torch.int64), N, B, _p(out_ptr), _p(csr.img_ptr), _stream())
         csr.graphs = (B, int(graphs[1]), int(graphs[2]))
     return csr

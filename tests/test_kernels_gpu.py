@@ -507,7 +507,7 @@ def test_imp_sliced_vs_oracle_math(ops, H, sizes, dtype):
     assert ops.imp_sliced_ok(csr, H, dtype)
     np.testing.assert_array_equal(csr.img_ptr.cpu().numpy()[:len(sizes) + 1], np.concatenate(([0], np.cumsum(sizes))))
     per_graph = [int((rel[:, 0] == b).sum()) for b in range(len(sizes))]
-    np.testing.assert_array_equal(csr.img_ptr.cpu().numpy()[len(sizes) + 1:], np.concatenate(([0], np.cumsum(per_graph))))
+    np.testing.assert_array_equal(csr.img_ptr.cpu().numpy()[len(sizes) + 1:2 * len(sizes) + 2], np.concatenate(([0], np.cumsum(per_graph))))
     e_in, ctx2 = ops.imp_sliced(v_d, e_d, csr, nd, ed, cu(gb))
     exp_ein, exp_out, exp_in = _imp_expect(v, e, rel, gw, gb)
     tol = dict(atol=2e-5, rtol=1e-5) if dtype == torch.float32 else dict(atol=3e-2, rtol=1e-2)
