@@ -326,7 +326,7 @@ def main():
                              'frac': round(imp_gbs / HBM_PEAK_GBS, 4),
                              'traffic': pmc_traffic('imp_sliced_B8') if (B == 8 and args.dtype == 'bf16') else None,
                              'algorithmic_bytes': imp_bytes, 'avg_launch_ms': round(imp_ms, 5),
-                             'note': '16.8 MB per launch at B=8: 2.7 us at 6.3 TB/s, below launch + dependent-latency floor'},
+                             'note': '16.8 MB per launch at B=8: 2.7 us at 6.3 TB/s, below a launch plus two dependent memory latencies; see roofline_imp_large'},
             'roofline_imp_large': {'kernel': 'same kernel, %d images (%d edges) per launch' % (BL, 992 * BL), 'bound': 'hbm',
                                    'achieved': round(impL_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                    'frac': round(impL_gbs / HBM_PEAK_GBS, 4),
