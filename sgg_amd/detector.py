@@ -9,6 +9,7 @@ HOLD parameters -- the arithmetic runs in libsgg_hip.so.
 """
 import math
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -85,7 +86,8 @@ class Transform(object):
 
 
 def is_u8_image(im):
-    return im.dtype == torch.uint8 and im.dim() == 3 and im.shape[-1] == 3
+    """decoded image as the dataset keeps it: uint8 [h, w, 3], torch tensor or numpy array"""
+    return im.dtype in (torch.uint8, np.uint8) and im.ndim == 3 and im.shape[-1] == 3
 
 
 def image_hw(im):
@@ -150,6 +152,8 @@ class VGGDetector(nn.Module):
             x0.zero_()  # ragged batch: the pad region of a previous, larger image must be cleared
         for b, im in enumerate(images):
             if is_u8_image(im):
+                if isinstance(im, np.ndarray):
+                    im = torch.from_numpy(np.ascontiguousarray(im))
                 if not im.is_cuda:
                     im = im.to(device=dev, non_blocking=True)
                 ops.image_prep_u8(im.contiguous(), sizes[b][0], sizes[b][1], x0, b)

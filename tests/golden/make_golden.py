@@ -15,6 +15,9 @@ reference's source text is stored -- only data.  What is called, per file:
   eval_tail.npz    lib/surgery.py:17 filter_dets + the softmax/sort lines rel_model_stanford.py:187-204
   losses.npz       lib/losses.py:5,73
   recall.npz       lib/sgg_eval.py:14 BasicSceneGraphEvaluator (GC / no-GC / per-triplet, all modes), :420 mean recall, :481 eval_entry
+  vg_loader.npz    dataloaders/visual_genome.py:516 load_graphs (h5py.File replaced by an in-memory mapping with the VG-SGG.h5 keys),
+                   :662 load_info, :743 filter_dups, :377 VG.__getitem__ box / size arithmetic (synthetic PIL images),
+                   dataloaders/image_transforms.py:8 SquarePad
   freq_bias.npz    lib/get_dataset_counts.py:10 get_counts, lib/sparse_targets.py:7 FrequencyBias, and the use_bias block
                    sgg_models/rel_model_stanford.py:159-177 (executed on the reference's FrequencyBias module)
 """
@@ -394,6 +397,162 @@ def gold_recall():
     save('recall', **arrs)
 
 
+class _DS(object):
+    """An HDF5 dataset: indexing reads a fresh copy (the reference edits what it reads in place)."""
+
+    def __init__(self, a):
+        self.a = a
+        self.shape = a.shape
+
+    def __getitem__(self, idx):
+        return np.array(self.a[idx])
+
+
+class _H5(dict):
+    """Stand-in for h5py.File(path, 'r'): a mapping of datasets usable as a context manager."""
+
+    def __getitem__(self, k):
+        return _DS(dict.__getitem__(self, k))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def synthetic_vg_h5(seed=17, n_img=40, n_cls=12, n_pred=9):
+    """Arrays with the keys / dtypes / conventions of VG-SGG.h5 (boxes_1024 = xc, yc, w, h; relationships = GLOBAL box ids;
+    -1 first-indices for images without boxes / relations)."""
+    rng = np.random.RandomState(seed)
+    split = (rng.rand(n_img) < 0.3).astype(np.int32) * 2
+    boxes, labels, rels, preds = [], [], [], []
+    first_box, last_box, first_rel, last_rel = [], [], [], []
+    for i in range(n_img):
+        nb = 0 if i in (3, 11) else int(rng.randint(2, 9))
+        if nb == 0:
+            first_box.append(-1); last_box.append(-1); first_rel.append(-1); last_rel.append(-1)
+            continue
+        fb = len(labels)
+        xy = rng.uniform(40, 700, size=(nb, 2))
+        wh = rng.uniform(20, 300, size=(nb, 2))
+        boxes.append(np.concatenate((xy + wh / 2, wh), 1).astype(np.int32))
+        labels.extend(rng.randint(1, n_cls, size=nb))
+        first_box.append(fb); last_box.append(fb + nb - 1)
+        nr = 0 if i % 7 == 5 else int(rng.randint(1, 7))
+        if nr == 0:
+            first_rel.append(-1); last_rel.append(-1)
+            continue
+        fr = len(preds)
+        s = rng.randint(0, nb, size=nr)
+        o = (s + rng.randint(1, nb, size=nr)) % nb
+        if nr > 2:                                  # a duplicated pair with a different predicate (filter_dups)
+            s[-1], o[-1] = s[0], o[0]
+        rels.append(np.stack((s, o), 1) + fb)
+        preds.extend(rng.randint(1, n_pred, size=nr))
+        first_rel.append(fr); last_rel.append(fr + nr - 1)
+    return _H5({'split': split, 'img_to_first_box': np.array(first_box, np.int32), 'img_to_last_box': np.array(last_box, np.int32),
+                'img_to_first_rel': np.array(first_rel, np.int32), 'img_to_last_rel': np.array(last_rel, np.int32),
+                'boxes_1024': np.concatenate(boxes).astype(np.int32), 'labels': np.array(labels, np.int32)[:, None],
+                'relationships': np.concatenate(rels).astype(np.int32), 'predicates': np.array(preds, np.int32)[:, None]})
+
+
+LOADER_CASES = [
+    dict(mode='train'), dict(mode='test'), dict(mode='val', num_val_im=6), dict(mode='train', num_val_im=6),
+    dict(mode='train', filter_empty_rels=False), dict(mode='train', num_im=10),
+    dict(mode='train', min_graph_size=3, max_graph_size=6), dict(mode='train', filter_non_overlap=True),
+    dict(mode='test', training_triplets='set'), dict(mode='test', training_triplets='set', filter_zeroshots=False),
+    dict(mode='test', training_triplets='counts', n_shots=10), dict(mode='test', training_triplets='counts', n_shots=100),
+]
+
+
+def loader_triplets(h5):
+    """training-triplet collections in the two forms load_graphs accepts: a set of 'cls_pred_cls' strings (zero-shot filter)
+    and a {string: count} dict (few-shot filter), built from the train split of the same arrays."""
+    lab, rel, pred = h5['labels'][:, 0], h5['relationships'], h5['predicates'][:, 0]
+    counts = {}
+    for i in np.where((h5['split'] == 0) & (h5['img_to_first_rel'] >= 0))[0][::2]:
+        for r in range(h5['img_to_first_rel'][i], h5['img_to_last_rel'][i] + 1):
+            k = '{}_{}_{}'.format(lab[rel[r, 0]], pred[r], lab[rel[r, 1]])
+            counts[k] = counts.get(k, 0) + (1 if len(counts) % 3 else 12)
+    return set(counts), counts
+
+
+def gold_vg_loader():
+    import json
+    import tempfile
+    from PIL import Image
+    import torchvision.transforms as T
+
+    class _Stub(object):
+        def __init__(self, *a, **k):
+            pass
+    for n in ('Resize', 'Compose', 'ToTensor', 'Normalize'):
+        setattr(T, n, _Stub)                                   # names only: dataloaders/visual_genome.py:14 imports them
+    np.float, np.bool = float, bool
+    import dataloaders.visual_genome as vg
+    from dataloaders.image_transforms import SquarePad
+    h5 = synthetic_vg_h5()
+    arrs = {'h5_' + k: v for k, v in h5.items()}
+    tset, tcounts = loader_triplets(dict(h5.items()))
+    arrs['triplet_keys'] = np.array(sorted(tcounts))
+    arrs['triplet_counts'] = np.array([tcounts[k] for k in sorted(tcounts)])
+    vg.h5py.File = lambda path, mode='r': h5
+    for ci, case in enumerate(LOADER_CASES):
+        kw = dict(case)
+        if kw.get('training_triplets') == 'set':
+            kw['training_triplets'] = tset
+        elif kw.get('training_triplets') == 'counts':
+            kw['training_triplets'] = tcounts
+        mask, boxes, classes, rels = vg.load_graphs('unused.h5', **kw)
+        arrs['c%d_mask' % ci] = mask
+        arrs['c%d_n' % ci] = len(boxes)
+        for i in range(len(boxes)):
+            arrs['c%d_boxes_%d' % (ci, i)], arrs['c%d_classes_%d' % (ci, i)], arrs['c%d_rels_%d' % (ci, i)] = boxes[i], classes[i], rels[i]
+    # load_info
+    info = {'label_to_idx': {'dog': 2, 'cat': 1, 'tree': 3}, 'predicate_to_idx': {'on': 1, 'near': 3, 'has': 2}}
+    with tempfile.NamedTemporaryFile('w', suffix='.json', delete=False) as f:
+        json.dump(info, f)
+    c, p = vg.load_info(f.name)
+    arrs['info_classes'], arrs['info_predicates'] = np.array(c), np.array(p)
+    # filter_dups, deterministic form
+    gr = np.array([[0, 1, 3], [2, 1, 4], [0, 1, 5], [2, 1, 4], [1, 0, 2]])
+    arrs['dups_in'], arrs['dups_out'] = gr, vg.filter_dups(gr, random_edge=False)
+    # VG.__getitem__ box / size arithmetic on synthetic images (torch_detector True and False, flipped or not)
+    rng = np.random.RandomState(3)
+    sizes = [(50, 37), (37, 50), (40, 40), (102, 68)]          # small: the arithmetic only depends on (w, h)
+    n_entries = 0
+    for torch_detector in (True, False):
+        for (w, h) in sizes:
+            for flip in (False, True):
+                ds = vg.VG.__new__(vg.VG)
+                img = Image.fromarray(rng.randint(0, 255, size=(h, w, 3)).astype(np.uint8))
+                ds.images_dir, ds.filenames, ds.mode = '', ['x.png'], 'train' if flip else 'test'
+                nb = 5
+                xy = rng.uniform(0, 600, size=(nb, 2))
+                gt = np.concatenate((xy, xy + rng.uniform(10, 420, size=(nb, 2))), 1).astype(np.float32)   # BOX_SCALE space
+                ds.gt_boxes, ds.gt_classes = [gt], [rng.randint(1, 12, size=nb)]
+                ds.relationships = [np.array([[0, 1, 2], [3, 4, 1]])]
+                ds.torch_detector, ds.filter_duplicate_rels, ds.rpn_rois = torch_detector, False, None
+                ds.transform_pipeline = lambda im: torch.from_numpy(np.asarray(SquarePad()(im)).copy()).permute(2, 0, 1)
+                vg.Image.open = lambda path: img
+                entry = None
+                for seed in range(40):                        # np.random.random() > 0.5 decides the flip in train mode
+                    np.random.seed(seed)
+                    entry = ds[0]
+                    if entry['flipped'] == flip:
+                        break
+                assert entry['flipped'] == flip, (flip, entry['flipped'])
+                k = 'g%d_' % n_entries
+                arrs[k + 'wh'], arrs[k + 'torch_detector'], arrs[k + 'flip'] = np.array([w, h]), torch_detector, flip
+                arrs[k + 'img_in'], arrs[k + 'gt_in'] = np.asarray(img), gt
+                arrs[k + 'img_out'] = entry['img'].permute(1, 2, 0).numpy()
+                arrs[k + 'gt_out'], arrs[k + 'im_size'], arrs[k + 'scale'] = entry['gt_boxes'], np.array(entry['img_size'], dtype=np.float64), entry['scale']
+                n_entries += 1
+    arrs['n_entries'] = n_entries
+    save('vg_loader', **arrs)
+
+
 class _CountData(object):
     """The attributes lib/get_dataset_counts.py reads from a VG split (dataloaders/visual_genome.py:377-455)."""
 
@@ -481,3 +640,4 @@ if __name__ == '__main__':
     gold_losses()
     gold_recall()
     gold_freq_bias()
+    gold_vg_loader()

@@ -113,3 +113,46 @@ def test_val_batch_predicate_reweighting(model):
     np.testing.assert_allclose(rew['rel_scores'], want, rtol=1e-6)
     with pytest.raises(NotImplementedError):
         val_batch(model, 0, batch, ev(), 'sgcls', ds, [], [], vis=True)
+
+
+def test_val_epoch_over_vg_tables(model):
+    """f-2 + path + f-1 chained: VG-SGG tables -> sgg_amd.visual_genome.VG -> vg_collate -> HIP forward (u8 images, SquarePad on the GPU)
+    -> val_epoch; recalls equal the oracle evaluator on the same predictions and box scales (lib/eval.py:143-153)."""
+    import os
+    from sgg_amd.blob import vg_collate
+    from sgg_amd.evaluate import val_epoch
+    from sgg_amd.visual_genome import VG
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'vg_loader.npz'))
+    tables = {k[3:]: g[k] for k in g.files if k.startswith('h5_')}
+    rng = np.random.RandomState(2)
+    cache = {}
+    decode = lambda path: cache.setdefault(path, rng.randint(0, 255, size=(96, S, 3)).astype(np.uint8))
+    info = {'label_to_idx': {'c%d' % i: i for i in range(1, 151)}, 'predicate_to_idx': {'p%d' % i: i for i in range(1, 51)}}
+    ds = VG('test', tables, info, ['%d.jpg' % i for i in range(len(tables['split']))], num_val_im=0, decode=decode)
+
+    class Loader(object):
+        dataset = ds
+
+        def __iter__(self):
+            for i in range(len(ds)):
+                yield vg_collate([ds[i]], mode='rel', is_train=False)
+    results = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        entries = val_epoch('sgcls', model, Loader(), 'val_zs', None, None, save_scores=True, results=results)
+    assert len(entries['sgcls']) == len(ds) > 3
+    for mode in ('predcls', 'sgcls'):
+        per_k = {k: [] for k in KS}
+        for i, pr in enumerate(entries[mode]):
+            gt = {'gt_boxes': ds.gt_boxes[i] * (S / 1024.0), 'gt_classes': ds.gt_classes[i], 'gt_relations': ds.relationships[i]}
+            rec, _, _ = O.recall_entry(gt, pr, mode, False)
+            for k in KS:
+                per_k[k].append(rec[k])
+        for k in KS:
+            assert results['%s/val_zs_R@%d_GC' % (mode, k)] == pytest.approx(np.mean(per_k[k]), abs=1e-12)
+    # the two box scales agree (BOX_SCALE tables -> image scale on both sides): predicted boxes ARE the clipped GT boxes
+    hit = []
+    for i, pr in enumerate(entries['predcls']):
+        iou = O.box_iou(pr['pred_boxes'], ds.gt_boxes[i] * (S / 1024.0))
+        hit.extend(np.diag(iou) > 0.5)
+        np.testing.assert_array_equal(pr['pred_classes'], ds.gt_classes[i])
+    assert np.mean(hit) > 0.8

@@ -26,7 +26,8 @@ def main():
     dev = 'cuda:0'
     dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == 'bf16') else torch.float32
     shapes = [('fc6_edge', 7936, 4096, 25600), ('fc7_edge', 7936, 4096, 4096), ('unary', 7936, 512, 4096),
-              ('gru', 7936, 1536, 512), ('fc6_obj', 256, 4096, 25088), ('rel_fc', 7936, 51, 512)]
+              ('gru', 7936, 1536, 512), ('fc6_obj', 256, 4096, 25088), ('rel_fc', 7936, 51, 512),
+              ('sq4096', 4096, 4096, 4096), ('sq8192', 8192, 8192, 8192), ('fc6_8192', 8192, 4096, 25600)]
     for name, M, N, K in ([] if os.environ.get('CONV_ONLY') else shapes):
         A = torch.randn(M, K, device=dev).to(dt)
         W = (torch.randn(N, K, device=dev) / K ** 0.5).to(dt)
