@@ -90,13 +90,18 @@ int sgg_roi_align_fwd(const void* fmap, int B, int H, int W, int C, const float*
                       int R, float spatial_scale, int P, int sampling, const float* add_ec, void* out, int dtype,
                       void* stream);
 
-/* ---- a-5  union-mask raster: draw_union_boxes, lib/draw_rectangles/draw_rectangles.pyx:12-67 ----
- * rois f32[N,5], pairs i64[E,2] -> out f32[E,2,P,P] + offset (the caller's `- 0.5`, lib/get_union_boxes.py:67). */
-int sgg_union_rects_fwd(const float* rois, const int64_t* pairs, int E, int P, float offset, float* out, void* stream);
+/* ---- a-5  union-mask raster ----
+ * raster 0 (edge_model 'motifs', the default): draw_union_boxes, lib/draw_rectangles/draw_rectangles.pyx:12-67 -- coverage of
+ *   each box inside the pair's union box.  raster 1 (edge_model 'raw_boxes'): draw_union_boxes_grid,
+ *   lib/get_union_boxes.py:69-116 -- each box drawn in image coordinates normalised by im_wh f32[B,2] = (w, h) of its image
+ *   (rois[:,0] selects the row), through [P] F.grid_sample(ones, bilinear, zeros padding, align_corners=False).
+ * rois f32[N,5], pairs i64[E,2] -> out f32[E,2,P,P] + offset (the caller's `- 0.5`, lib/get_union_boxes.py:67,80). */
+int sgg_union_rects_fwd(const float* rois, const int64_t* pairs, int E, int P, float offset, float* out, int raster,
+                        const float* im_wh, void* stream);
 /* Same raster, emitted directly as the 4 stride-16 7x7 patches the (typo'd) conv stack reads
  * (lib/get_union_boxes.py:40-43,52): out[E*4, Kpad] with k = c*49+ky*7+kx, zero padded, raster-0.5 inside. */
-int sgg_union_rect_patches(const float* rois, const int64_t* pairs, int E, int P, void* out, int Kpad, int dtype,
-                           void* stream);
+int sgg_union_rect_patches(const float* rois, const int64_t* pairs, int E, int P, void* out, int Kpad, int raster,
+                           const float* im_wh, int dtype, void* stream);
 /* MaxPool2d(3,2,1) over the 2x2 map = max over 4 consecutive rows (lib/get_union_boxes.py:55). in[E*4,C] -> out[E,C] */
 int sgg_max4_rows(const void* in, void* out, int E, int C, int dtype, void* stream);
 /* x[r,c,p] += add[r,c] in place (lib/get_union_boxes.py:101 when the add is not fused in RoIAlign). */

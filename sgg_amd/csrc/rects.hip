@@ -42,28 +42,83 @@ __device__ __forceinline__ float coverage(const PairGeom& g, int i, int j, int k
     return __fmul_rn(xc, yc);
 }
 
+// edge_model 'raw_boxes' (lib/get_union_boxes.py:69-116): channel i is box i drawn in IMAGE coordinates normalised to [0,1]
+// (not relative to the union box): F.grid_sample (bilinear, zero padding, align_corners=False) of an all-ones P x P map at
+// x_k = (k/(P-1) - x0) / (x1 - x0) etc. (_boxes_to_grid, :119-157).  Sampling a constant map leaves the sum of the in-range
+// bilinear weights, separable in x and y: a soft-edged box mask.
+struct RawGeom {
+    float x0[2], y0[2], ww[2], hh[2];
+};
+
+__device__ __forceinline__ RawGeom raw_geom(const float* __restrict__ rois, const int64_t* __restrict__ pairs, long e,
+                                            const float* __restrict__ im_wh) {
+    RawGeom g;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float* r = rois + pairs[2 * e + i] * 5;
+        const int img = (int)r[0];
+        const float w = im_wh[2 * img], h = im_wh[2 * img + 1];
+        const float x0 = __fdiv_rn(r[1], w), y0 = __fdiv_rn(r[2], h), x1 = __fdiv_rn(r[3], w), y1 = __fdiv_rn(r[4], h);
+        g.x0[i] = x0;
+        g.y0[i] = y0;
+        g.ww[i] = __fsub_rn(x1, x0);
+        g.hh[i] = __fsub_rn(y1, y0);
+    }
+    return g;
+}
+
+// sum of the in-range bilinear weights along one axis for output index k of P: unnormalised source coordinate
+// ((g + 1) * P - 1) / 2 with g = 2 * ((k/(P-1) - lo) / extent) - 1
+__device__ __forceinline__ float axis_weight(int k, int P, float lo, float extent) {
+    const float t = __fdiv_rn(__fsub_rn(__fdiv_rn((float)k, (float)(P - 1)), lo), extent);
+    const float gcoord = __fsub_rn(__fmul_rn(t, 2.f), 1.f);
+    const float src = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(gcoord, 1.f), (float)P), 1.f), 0.5f);
+    const float f0 = floorf(src);
+    const float frac = __fsub_rn(src, f0);
+    float wsum = 0.f;
+    if (f0 >= 0.f && f0 <= (float)(P - 1)) wsum += 1.f - frac;
+    if (f0 + 1.f >= 0.f && f0 + 1.f <= (float)(P - 1)) wsum += frac;
+    return wsum;            // NaN coordinates (degenerate box) compare false everywhere: 0, like grid_sample's padding
+}
+
+__device__ __forceinline__ float coverage(const RawGeom& g, int i, int j, int k, int P) {
+    return __fmul_rn(axis_weight(k, P, g.x0[i], g.ww[i]), axis_weight(j, P, g.y0[i], g.hh[i]));
+}
+__device__ __forceinline__ float coverage(const PairGeom& g, int i, int j, int k, int) { return coverage(g, i, j, k); }
+
+template <bool RAW> struct GeomOf { typedef PairGeom type; };
+template <> struct GeomOf<true> { typedef RawGeom type; };
+template <bool RAW>
+__device__ __forceinline__ typename GeomOf<RAW>::type make_geom(const float* rois, const int64_t* pairs, long e, int P,
+                                                                 const float* im_wh) {
+    if constexpr (RAW) return raw_geom(rois, pairs, e, im_wh);
+    else return pair_geom(rois, pairs, e, P);
+}
+
 // a-5: out f32[E,2,P,P] (+offset).  One workgroup per pair; consecutive threads write consecutive pixels.
+template <bool RAW>
 __global__ __launch_bounds__(256) void union_rects_kernel(const float* __restrict__ rois, const int64_t* __restrict__ pairs,
-                                                          int P, float offset, float* __restrict__ out) {
+                                                          int P, float offset, float* __restrict__ out,
+                                                          const float* __restrict__ im_wh) {
     const long e = blockIdx.x;
-    const PairGeom g = pair_geom(rois, pairs, e, P);
+    const auto g = make_geom<RAW>(rois, pairs, e, P, im_wh);
     const int n = 2 * P * P;
     float* o = out + e * n;
     for (int t = threadIdx.x; t < n; t += 256) {
         const int i = t / (P * P), rem = t - i * P * P;
         const int j = rem / P, k = rem - j * P;
-        o[t] = __fadd_rn(coverage(g, i, j, k), offset);
+        o[t] = __fadd_rn(coverage(g, i, j, k, P), offset);
     }
 }
 
 // The conv stack of lib/get_union_boxes.py:51-59 uses stride 16 for BOTH convs (typo at :40-43), so the first conv
 // (k7,p3) reads only 2x2 windows at rows/cols {-3..3} and {13..19}.  Emit exactly those 4 patches per pair as
 // GEMM rows: out[(e*4 + oy*2+ox)][k = c*49 + ky*7 + kx], zero outside the raster, raster-0.5 inside.
-template <typename T>
+template <typename T, bool RAW>
 __global__ __launch_bounds__(256) void rect_patches_kernel(const float* __restrict__ rois, const int64_t* __restrict__ pairs,
-                                                           int P, T* __restrict__ out, int Kpad) {
+                                                           int P, T* __restrict__ out, int Kpad, const float* __restrict__ im_wh) {
     const long e = blockIdx.x;
-    const PairGeom g = pair_geom(rois, pairs, e, P);
+    const auto g = make_geom<RAW>(rois, pairs, e, P, im_wh);
     T* o = out + e * 4 * Kpad;
     for (int t = threadIdx.x; t < 4 * Kpad; t += 256) {
         const int pos = t / Kpad, k = t - pos * Kpad;
@@ -72,7 +127,7 @@ __global__ __launch_bounds__(256) void rect_patches_kernel(const float* __restri
             const int c = k / 49, r = k - c * 49;
             const int ky = r / 7, kx = r - ky * 7;
             const int j = (pos >> 1) * 16 - 3 + ky, kk = (pos & 1) * 16 - 3 + kx;
-            if (j >= 0 && j < P && kk >= 0 && kk < P) v = __fadd_rn(coverage(g, c, j, kk), -0.5f);
+            if (j >= 0 && j < P && kk >= 0 && kk < P) v = __fadd_rn(coverage(g, c, j, kk, P), -0.5f);
         }
         Elem<T>::st(o + t, v);
     }
@@ -122,26 +177,36 @@ __global__ __launch_bounds__(256) void bcast_add_kernel(T* __restrict__ x, const
 
 }  // namespace
 
-extern "C" int sgg_union_rects_fwd(const float* rois, const int64_t* pairs, int E, int P, float offset, float* out,
-                                   void* stream) {
+extern "C" int sgg_union_rects_fwd(const float* rois, const int64_t* pairs, int E, int P, float offset, float* out, int raster,
+                                   const float* im_wh, void* stream) {
     if (E == 0) return SGG_OK;
-    if (!rois || !pairs || !out || E < 0 || P <= 0) return SGG_ERR_ARG;
-    hipLaunchKernelGGL(union_rects_kernel, dim3(E), dim3(256), 0, (hipStream_t)stream, rois, pairs, P, offset, out);
+    if (!rois || !pairs || !out || E < 0 || P <= 0 || raster < 0 || raster > 1 || (raster == 1 && (!im_wh || P < 2))) return SGG_ERR_ARG;
+    if (raster)
+        hipLaunchKernelGGL(union_rects_kernel<true>, dim3(E), dim3(256), 0, (hipStream_t)stream, rois, pairs, P, offset, out, im_wh);
+    else
+        hipLaunchKernelGGL(union_rects_kernel<false>, dim3(E), dim3(256), 0, (hipStream_t)stream, rois, pairs, P, offset, out, im_wh);
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
 
-extern "C" int sgg_union_rect_patches(const float* rois, const int64_t* pairs, int E, int P, void* out, int Kpad,
-                                      int dtype, void* stream) {
+extern "C" int sgg_union_rect_patches(const float* rois, const int64_t* pairs, int E, int P, void* out, int Kpad, int raster,
+                                      const float* im_wh, int dtype, void* stream) {
     if (E == 0) return SGG_OK;
     // geometry of the typo'd stack: k7/p3/s16 must give a 2x2 map
-    if (!rois || !pairs || !out || E < 0 || Kpad < 98 || (P + 6 - 7) / 16 + 1 != 2) return SGG_ERR_ARG;
-    if (dtype == SGG_BF16)
-        hipLaunchKernelGGL(rect_patches_kernel<bf16_t>, dim3(E), dim3(256), 0, (hipStream_t)stream, rois, pairs, P, (bf16_t*)out, Kpad);
-    else if (dtype == SGG_F32)
-        hipLaunchKernelGGL(rect_patches_kernel<float>, dim3(E), dim3(256), 0, (hipStream_t)stream, rois, pairs, P, (float*)out, Kpad);
-    else
+    if (!rois || !pairs || !out || E < 0 || Kpad < 98 || (P + 6 - 7) / 16 + 1 != 2 || raster < 0 || raster > 1 || (raster == 1 && !im_wh))
+        return SGG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+#define SGG_PATCHES(T, RAW) hipLaunchKernelGGL((rect_patches_kernel<T, RAW>), dim3(E), dim3(256), 0, s, rois, pairs, P, (T*)out, Kpad, im_wh)
+    if (dtype == SGG_BF16) {
+        if (raster) SGG_PATCHES(bf16_t, true);
+        else SGG_PATCHES(bf16_t, false);
+    } else if (dtype == SGG_F32) {
+        if (raster) SGG_PATCHES(float, true);
+        else SGG_PATCHES(float, false);
+    } else {
         return SGG_ERR_DTYPE;
+    }
+#undef SGG_PATCHES
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

@@ -157,19 +157,29 @@ def roi_align(fmap_nhwc, rois, pairs=None, spatial_scale=1.0 / 16, P=7, sampling
 
 
 # ---------------------------------------------------------------- a-5 / a-6
-def union_rects(rois, pairs, P=27, offset=-0.5):
+def _im_wh(im_sizes, device):
+    """[(h, w), ...] per image (the transform's image_sizes) -> f32[B,2] = (w, h) on the device, for the 'raw_boxes' raster"""
+    if torch.is_tensor(im_sizes) and im_sizes.is_cuda:
+        return im_sizes.float().contiguous()
+    return torch.tensor([[float(s[1]), float(s[0])] for s in im_sizes], dtype=torch.float32).to(device, non_blocking=True)
+
+
+def union_rects(rois, pairs, P=27, offset=-0.5, im_sizes=None):
+    """im_sizes None: the 'motifs' raster (boxes inside their union box); given: the 'raw_boxes' raster (image coordinates)."""
     E = pairs.shape[0]
     out = torch.empty((E, 2, P, P), dtype=torch.float32, device=rois.device)
+    wh = _im_wh(im_sizes, rois.device) if im_sizes is not None else None
     _lib.call('sgg_union_rects_fwd', _p(rois, torch.float32), _p(pairs, torch.int64), E, P, float(offset), _p(out),
-              _stream())
+              0 if wh is None else 1, _p(wh), _stream())
     return out
 
 
-def union_rect_patches(rois, pairs, dtype, P=27, Kpad=128):
+def union_rect_patches(rois, pairs, dtype, P=27, Kpad=128, im_sizes=None):
     E = pairs.shape[0]
     out = torch.empty((E * 4, Kpad), dtype=dtype, device=rois.device)
-    _lib.call('sgg_union_rect_patches', _p(rois, torch.float32), _p(pairs, torch.int64), E, P, _p(out), Kpad, dt(dtype),
-              _stream())
+    wh = _im_wh(im_sizes, rois.device) if im_sizes is not None else None
+    _lib.call('sgg_union_rect_patches', _p(rois, torch.float32), _p(pairs, torch.int64), E, P, _p(out), Kpad,
+              0 if wh is None else 1, _p(wh), dt(dtype), _stream())
     return out
 
 

@@ -126,10 +126,10 @@ class RelModelStanford(RelModelBase):
         if self.training:
             # Dropout, batch-statistic BatchNorm and the autograd node of the whole head (sgg_amd/train.py)
             from .train import predict_train
-            return predict_train(self, nf, ef, rel_inds, rois, _im_inds, dropout_p=self.dropout_p, graphs=_graphs)
+            return predict_train(self, nf, ef, rel_inds, rois, _im_inds, dropout_p=self.dropout_p, graphs=_graphs, im_sizes=im_sizes)
         w = self.prepared()
         # :100  union_boxes(edge_feat, rois, rel_inds[:,1:]) -- conv(rects)[E,512]; the broadcast add rides in fc6's K
-        rect = self.union_boxes.rect_feat(rois, rel_inds[:, 1:].contiguous(), dtype)
+        rect = self.union_boxes.rect_feat(rois, rel_inds[:, 1:].contiguous(), dtype, im_sizes)
         # :103  obj_unary(roi_fmap_obj(node_feat)) -- three short-M GEMMs (256 rows), latency-bound: on the node lane's
         # stream they run under the edge MLP below instead of in front of it (message_pass keeps using that lane)
         def node_mlp():

@@ -118,7 +118,8 @@ class PredictFn(torch.autograd.Function):
         sv = {}
         # ---- rect conv, batch-statistics BatchNorm (lib/get_union_boxes.py:51-59)
         pairs = rel_inds[:, 1:].contiguous()
-        patches = ops.union_rect_patches(rois, pairs, dt, ub.pooling_size * 4 - 1, 128)           # [4E,128]
+        patches = ops.union_rect_patches(rois, pairs, dt, ub.pooling_size * 4 - 1, 128,
+                                         im_sizes=ub.raster_sizes(getattr(model, '_im_sizes_hint', None)))   # [4E,128]
         h1 = ops.gemm(patches, t['rc_w1'], t['rc_b1'], ops.ACT_RELU)                               # [4E,d2]
         bn1, bn2 = ub.conv[2], ub.conv[6]
         bn_sync = getattr(model, '_bn_sync', None)      # DP trainer: batch statistics over the rows of every rank
@@ -376,7 +377,8 @@ class PredictFn(torch.autograd.Function):
         return (None,) * 8 + tuple(grads)
 
 
-def predict_train(model, node_feat, edge_feat, rel_inds, rois, im_inds=None, seed=None, dropout_p=DROPOUT_P, graphs=None):
+def predict_train(model, node_feat, edge_feat, rel_inds, rois, im_inds=None, seed=None, dropout_p=DROPOUT_P, graphs=None,
+                  im_sizes=None):
     """Autograd-connected training forward of the head.  node_feat/edge_feat: [.,P,P,C]-contiguous (NHWC) tensors
     in the compute dtype."""
     N, E = node_feat.shape[0], edge_feat.shape[0]
@@ -385,5 +387,6 @@ def predict_train(model, node_feat, edge_feat, rel_inds, rois, im_inds=None, see
     named = dict(model.head_named_parameters())
     params = [named[n] for n in param_names(model)]
     model._graphs_hint = graphs     # host-side facts about the graphs (ops.edge_csr), read by PredictFn.forward
+    model._im_sizes_hint = im_sizes  # image sizes for the 'raw_boxes' raster (lib/get_union_boxes.py:71-78)
     return PredictFn.apply(model, node_feat.reshape(N, -1), edge_feat.reshape(E, -1), rois.float().contiguous(),
                            rel_inds.contiguous(), im_inds, seed, float(dropout_p), *params)

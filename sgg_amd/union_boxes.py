@@ -1,4 +1,4 @@
-"""UnionBoxesAndFeats (lib/get_union_boxes.py:16-101), edge_model='motifs', on the HIP path.
+"""UnionBoxesAndFeats (lib/get_union_boxes.py:16-116), edge_model 'motifs' (default) or 'raw_boxes', on the HIP path.
 
 The reference's conv stack is  Conv(2->d/2,k7,p3) ReLU BN MaxPool(3,2,1) Conv(d/2->d,k3,p1) ReLU BN  with BOTH convs
 at stride 16 (the `stide` typo, :40-43), so on the 27x27 raster it produces [E,d,1,1], broadcast-added over the 7x7
@@ -40,10 +40,10 @@ def fold_rect_conv(p, dtype, eps=1e-5):
                 d2=d2, d=d, k2=w2.shape[1])
 
 
-def rect_feat(rois, pairs, prep, dtype, P=27):
-    """rois f32[N,5], pairs i64[E,2] -> conv(rects)[E,d] in `dtype` (eval-mode BN)."""
+def rect_feat(rois, pairs, prep, dtype, P=27, im_sizes=None):
+    """rois f32[N,5], pairs i64[E,2] -> conv(rects)[E,d] in `dtype` (eval-mode BN).  im_sizes: given for edge_model 'raw_boxes'."""
     E = pairs.shape[0]
-    patches = ops.union_rect_patches(rois, pairs, dtype, P, prep['w1'].shape[1])            # [4E,128]
+    patches = ops.union_rect_patches(rois, pairs, dtype, P, prep['w1'].shape[1], im_sizes=im_sizes)   # [4E,128]
     h1 = torch.zeros((4 * E, prep['k2']), dtype=dtype, device=rois.device) if prep['k2'] != prep['d2'] else \
         torch.empty((4 * E, prep['k2']), dtype=dtype, device=rois.device)
     ops.gemm(patches, prep['w1'], prep['b1'], ops.ACT_RELU, dtype, post_scale=prep['s1'], post_shift=prep['t1'], out=h1)
@@ -56,8 +56,8 @@ class UnionBoxesAndFeats(nn.Module):
 
     def __init__(self, edge_model='motifs', pooling_size=7, stride=16, dim=256, concat=False, use_feats=True):
         super(UnionBoxesAndFeats, self).__init__()
-        if edge_model != 'motifs':
-            raise NotImplementedError(edge_model)  # 'raw_boxes' (grid_sample raster) is not on the BASELINE path
+        if edge_model not in ('motifs', 'raw_boxes'):     # lib/get_union_boxes.py:26-38
+            raise NotImplementedError(edge_model)
         if concat:
             raise NotImplementedError('concat=True')
         self.edge_model, self.pooling_size, self.stride, self.dim = edge_model, pooling_size, stride, dim
@@ -82,11 +82,19 @@ class UnionBoxesAndFeats(nn.Module):
             self._prep = dict(key=key, val=fold_rect_conv(sd, dtype, self.conv[2].eps))
         return self._prep['val']
 
-    def rect_feat(self, rois, union_inds, dtype):
+    def raster_sizes(self, im_sizes):
+        """what the raster kernels need besides the boxes: nothing for 'motifs', the image sizes for 'raw_boxes' (:71-78)"""
+        if self.edge_model == 'motifs':
+            return None
+        if im_sizes is None:
+            raise ValueError("edge_model 'raw_boxes' needs im_sizes")
+        return im_sizes
+
+    def rect_feat(self, rois, union_inds, dtype, im_sizes=None):
         if self.training:
             raise NotImplementedError('train-mode BatchNorm statistics of the rect conv are not on the HIP path yet')
         return rect_feat(rois.float().contiguous(), union_inds.contiguous(), self.prepared(dtype), dtype,
-                         self.pooling_size * 4 - 1)
+                         self.pooling_size * 4 - 1, im_sizes=self.raster_sizes(im_sizes))
 
     def forward(self, union_pools, rois, union_inds, im_sizes=None):
         """union_pools [E,dim,7,7] -> union_pools + conv(rects) (lib/get_union_boxes.py:101), a new tensor."""
@@ -94,7 +102,7 @@ class UnionBoxesAndFeats(nn.Module):
         x = union_pools
         if x.dtype not in (torch.float32, torch.bfloat16):
             x = x.float()
-        rf = self.rect_feat(rois, union_inds, x.dtype).float().contiguous()
+        rf = self.rect_feat(rois, union_inds, x.dtype, im_sizes).float().contiguous()
         x = x.contiguous().clone()
         ops.bcast_add_(x.view(E, C, -1), rf)
         return x

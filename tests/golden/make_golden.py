@@ -115,6 +115,29 @@ def gold_union_feats():
                      tag + '_rect_feat': (out - pools)[:, :, 0, 0]})
         for k, v in sd(m).items():
             arrs[tag + '_w_' + k] = v
+    # edge_model 'raw_boxes' (lib/get_union_boxes.py:69-80,105-116): boxes in image coordinates through grid_sample
+    from lib.get_union_boxes import draw_union_boxes_grid
+    n, dim = 9, 32
+    torch.manual_seed(3)
+    m = UnionBoxesAndFeats(pooling_size=7, stride=16, dim=dim, edge_model='raw_boxes')
+    randomize_bn(m, g)
+    m.eval()
+    im = np.array([0] * 5 + [1] * 4)
+    im_sizes = [(592, 400), (333, 592)]                      # (h, w) per image
+    boxes = rand_boxes(rng, n, hi=200, wmax=120, clip=330)
+    boxes[3] = [0, 0, 399, 591]                                # a box covering its whole image
+    boxes[6] = [10.5, 20.25, 12.0, 300.0]                      # thin
+    rois = np.concatenate((im[:, None].astype(np.float32), boxes), 1)
+    ui = np.array([(i, j) for i in range(n) for j in range(n) if i != j and im[i] == im[j]], dtype=np.int64)
+    pools = torch.randn(len(ui), dim, 7, 7, generator=g)
+    with torch.no_grad():
+        scale = torch.tensor([[im_sizes[i][1], im_sizes[i][0]] * 2 for i in im], dtype=torch.float32)
+        grid = draw_union_boxes_grid(torch.from_numpy(boxes) / scale, torch.from_numpy(ui), 27)
+        out = m(pools, torch.from_numpy(rois), torch.from_numpy(ui), im_sizes)
+    arrs.update({'raw_rois': rois, 'raw_union_inds': ui, 'raw_pools': pools, 'raw_out': out, 'raw_rects': grid,
+                 'raw_rect_feat': (out - pools)[:, :, 0, 0], 'raw_im_sizes': np.array(im_sizes)})
+    for k, v in sd(m).items():
+        arrs['raw_w_' + k] = v
     save('union_feats', **arrs)
 
 

@@ -327,6 +327,35 @@ def test_rect_feat_pipeline_vs_reference_golden(ops, golden, tag):
     np.testing.assert_allclose(rf.cpu().numpy(), g[tag + '_rect_feat'], atol=2e-5)
 
 
+def test_raw_boxes_raster_and_rect_feat_vs_reference_golden(ops, golden):
+    """edge_model 'raw_boxes' (lib/get_union_boxes.py:69-116): the grid_sample raster, the patches the conv stack reads from it,
+    and the module's eval forward, against vectors from the reference module."""
+    g = golden('union_feats')
+    ims = [tuple(int(v) for v in x) for x in g['raw_im_sizes']]
+    rois, ui = cu(g['raw_rois']), cu(g['raw_union_inds'])
+    r = ops.union_rects(rois, ui, 27, 0.0, im_sizes=ims)
+    np.testing.assert_allclose(r.cpu().numpy(), g['raw_rects'], atol=1e-5)
+    np.testing.assert_allclose(ops.union_rects(rois, ui, 27, -0.5, im_sizes=ims).cpu().numpy(), g['raw_rects'] - 0.5, atol=1e-5)
+    # patches = the 4 stride-16 7x7 windows of (raster - 0.5), zero outside
+    pat = ops.union_rect_patches(rois, ui, torch.float32, 27, 128, im_sizes=ims).cpu().numpy().reshape(len(g['raw_union_inds']), 4, 128)
+    padded = np.zeros((len(pat), 2, 27 + 6 + 16, 27 + 6 + 16), np.float32)
+    padded[:, :, 3:30, 3:30] = g['raw_rects'] - 0.5
+    for pos in range(4):
+        oy, ox = (pos >> 1) * 16, (pos & 1) * 16
+        np.testing.assert_allclose(pat[:, pos, :98], padded[:, :, oy:oy + 7, ox:ox + 7].reshape(len(pat), 98), atol=1e-5)
+    assert np.abs(pat[:, :, 98:]).max() == 0
+    from sgg_amd.union_boxes import UnionBoxesAndFeats
+    m = UnionBoxesAndFeats(pooling_size=7, stride=16, dim=32, edge_model='raw_boxes')
+    m.load_state_dict({k[len('raw_w_'):]: torch.from_numpy(g[k]) for k in g if k.startswith('raw_w_')}, strict=False)
+    m.to(DEV).eval()
+    out = m(cu(g['raw_pools']), rois, ui, ims)
+    np.testing.assert_allclose(out.cpu().numpy(), g['raw_out'], atol=5e-5)
+    with pytest.raises(ValueError):
+        m(cu(g['raw_pools']), rois, ui, None)                 # the image sizes are part of this raster
+    with pytest.raises(NotImplementedError):
+        UnionBoxesAndFeats(edge_model='boxes')
+
+
 # ----------------------------------------------------------------------------------------- RoIAlign
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_roi_align(ops, dtype):

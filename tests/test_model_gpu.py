@@ -203,3 +203,31 @@ def test_full_size_forward_fp32_matches_oracle_and_bf16_batch_is_sane():
     model.dropout_p = 0.5
     del model
     torch.cuda.empty_cache()
+
+
+def test_forward_raw_boxes_edge_model_matches_oracle():
+    """-edge_model raw_boxes (config.py:179 lists it next to the default 'motifs'): eval tuple in fp32 vs the oracle, and a train
+    step through the same raster."""
+    import sgg_amd
+    from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
+    from sgg_amd.trainer import Trainer
+    S = 160
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls', min_size=S, max_size=S, edge_model='raw_boxes'))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV).eval()
+    model.set_compute_dtype(torch.float32)
+    batch = synthetic_batch(B=2, S=S, n_boxes=6, n_fg=3, seed=12, ragged=True)
+    with torch.no_grad():
+        ref = O.forward_gtbox(batch[0], batch[3], batch[4], batch[5], sd, mode='sgcls', min_size=S, max_size=S, edge_model='raw_boxes')
+        plain = O.forward_gtbox(batch[0], batch[3], batch[4], batch[5], sd, mode='sgcls', min_size=S, max_size=S)
+        boxes, cls, scores, rels, pred_scores = model([batch])
+    assert float((ref['rel_dists'] - plain['rel_dists']).abs().max()) > 1e-3      # the two rasters do differ
+    rb, rc, rs, rr, rp = ref['dets']
+    np.testing.assert_array_equal(cls, rc)
+    np.testing.assert_allclose(scores, rs, atol=1e-3)
+    np.testing.assert_array_equal(rels, rr)
+    np.testing.assert_allclose(pred_scores, rp, atol=1e-3)
+    tr = Trainer(model, lr=1e-3)
+    l0 = float(tr.step(batch))
+    l1 = float(tr.step(batch))
+    assert np.isfinite(l0) and np.isfinite(l1)

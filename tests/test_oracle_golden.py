@@ -191,3 +191,15 @@ def test_freq_bias_oracle_equals_reference(golden):
             preds, out = O.freq_bias_apply(g['obj_dists'], g['rel_dists'], g['rel_inds'], g['table'], C, mode, g['gt_classes'], tb)
             np.testing.assert_array_equal(preds, g['preds_%s' % mode])
             np.testing.assert_allclose(out, g['out_%s_%d' % (mode, tb)], rtol=0, atol=1e-7)
+
+
+def test_raw_boxes_raster_and_feats(golden):
+    """edge_model 'raw_boxes': lib/get_union_boxes.py:69-116 (grid_sample raster) and the module's eval forward"""
+    g = golden('union_feats')
+    ims = [tuple(x) for x in g['raw_im_sizes']]
+    r = O.draw_union_boxes_grid(g['raw_rois'], g['raw_union_inds'], ims, 27)
+    np.testing.assert_allclose(r, g['raw_rects'], atol=1e-5)
+    assert r.min() == 0 and r.max() == 1 and ((r > 0) & (r < 1)).any()          # soft edges exist
+    p = {k[len('raw_w_'):]: torch.from_numpy(g[k]) for k in g.keys() if k.startswith('raw_w_')}
+    out = O.union_boxes_and_feats(g['raw_pools'], g['raw_rois'], g['raw_union_inds'], p, edge_model='raw_boxes', im_sizes=ims)
+    np.testing.assert_allclose(out.numpy(), g['raw_out'], atol=2e-5)
