@@ -14,16 +14,22 @@ from . import _lib, ops
 from .dist import GradBuckets, sum_over_ranks
 
 
-class FusedSGD(object):
+class FusedSGD(torch.optim.Optimizer):
     """torch.optim.SGD(momentum, weight_decay) + clip_grad_norm (lib/pytorch_misc.py:625-656) as HIP kernels.
-    Same parameter groups as get_optim (lib/pytorch_misc.py:135-144): names starting with 'roi_fmap' get lr/10."""
+
+    A `torch.optim.Optimizer` with the parameter groups of get_optim (lib/pytorch_misc.py:128-144: group 0 = names starting with
+    'roi_fmap' at lr/10, group 1 = the rest) and torch's per-parameter state ('momentum_buffer'), so that
+    `optim.lr_scheduler.MultiStepLR(optimizer, ...)` (:152-154), `get_smallest_lr`, `save_checkpoint` / `optimizer.load_state_dict(ckpt
+    ['optimizer'])` (:146-150, :218-227) work on it unchanged and optimiser checkpoints interchange with the reference's."""
 
     def __init__(self, named_params, lr, momentum=0.9, weight_decay=1e-4, clip=5.0):
-        self.groups = []
-        for n, p in named_params:
-            if p.requires_grad:
-                self.groups.append(dict(name=n, p=p, lr=lr / 10.0 if n.startswith('roi_fmap') else lr, buf=None))
-        self.momentum, self.weight_decay, self.clip = momentum, weight_decay, clip
+        named = [(n, p) for n, p in named_params if p.requires_grad]
+        fc = [p for n, p in named if n.startswith('roi_fmap')]
+        rest = [p for n, p in named if not n.startswith('roi_fmap')]
+        groups = ([{'params': fc, 'lr': lr / 10.0}] if fc else []) + ([{'params': rest}] if rest else [])
+        super(FusedSGD, self).__init__(groups, dict(lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay, nesterov=False))
+        self.name_of = {p: n for n, p in named}
+        self.clip = clip
         self.steps = 0
         self._norm = None
         self.on_update = None
@@ -31,56 +37,72 @@ class FusedSGD(object):
         self.shadow_of = None      # callable -> {param name: compute-dtype buffer the update should also write}
         self.wrote_shadow = []
 
-    def zero_grad(self):
-        for g in self.groups:
-            g['p'].grad = None
+    def params(self):
+        for g in self.param_groups:
+            for p in g['params']:
+                yield p
 
     @torch.no_grad()
-    def step(self, grad_scale=1.0, grads=None):
+    def step(self, grad_scale=1.0, grads=None, closure=None):
         """grads (optional): {param: tensor} overriding p.grad -- e.g. the bf16 buffers an all-reduce left behind, consumed
         directly (fp32 or bf16) instead of being copied back into fp32 .grad tensors."""
+        import numpy as np
         stream = torch.cuda.current_stream().cuda_stream
-        dev = self.groups[0]['p'].device
+        dev = next(self.params()).device
         if self._norm is None:
             self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._norm.zero_()
         grads = grads or {}
-        grad_of = lambda p: grads.get(p, p.grad)
-        live = [g for g in self.groups if grad_of(g['p']) is not None]
-        import numpy as np
-        first = any(g['buf'] is None for g in live)
-        if first and not all(g['buf'] is None for g in live):
-            raise RuntimeError('FusedSGD: a parameter received its first gradient after step 1 (unsupported)')
-        for g in live:
-            if g['buf'] is None:
-                g['buf'] = torch.empty_like(g['p'], dtype=torch.float32)
-        keep = [grad_of(g['p']).contiguous() for g in live]
+        live = []                                               # (param, gradient, lr)
+        mom, wd = None, None
+        for g in self.param_groups:
+            if g['dampening'] != 0 or g['nesterov']:
+                raise NotImplementedError('FusedSGD: dampening / nesterov')
+            mom = g['momentum'] if mom is None else mom
+            wd = g['weight_decay'] if wd is None else wd
+            if g['momentum'] != mom or g['weight_decay'] != wd:
+                raise NotImplementedError('FusedSGD: one momentum / weight decay for all groups (as get_optim builds them)')
+            for p in g['params']:
+                gr = grads.get(p, p.grad)
+                if gr is not None:
+                    live.append((p, gr.contiguous(), float(g['lr'])))
+        if not live:
+            return None
+        # torch's first step sets buf = d_p; a zero buffer gives the same number (mom * 0 + d_p), so parameters that meet their
+        # first gradient later -- or after a partial load_state_dict -- simply start from zeros
+        first = all('momentum_buffer' not in self.state[p] for p, _, _ in live)
+        for p, _, _ in live:
+            st = self.state[p]
+            if st.get('momentum_buffer') is None:
+                st['momentum_buffer'] = torch.empty_like(p, dtype=torch.float32) if first else torch.zeros_like(p, dtype=torch.float32)
         shadows = self.shadow_of() if self.shadow_of is not None else {}
         norm = self._norm.data_ptr() if self.clip and self.clip > 0 else None
         pending = []
         for dtype in (torch.float32, torch.bfloat16):          # gradients arrive fp32 (local) or bf16 (off the wire)
-            idx = [i for i, gr in enumerate(keep) if gr.dtype == dtype]
-            if not idx:
+            sel = [t for t in live if t[1].dtype == dtype]
+            if not sel:
                 continue
             arr = lambda vals: np.ascontiguousarray(np.array(vals, dtype=np.uint64))
-            gp = arr([keep[i].data_ptr() for i in idx])
-            pp = arr([live[i]['p'].data_ptr() for i in idx])
-            bp = arr([live[i]['buf'].data_ptr() for i in idx])
-            sh = [shadows.get(live[i]['name']) for i in idx]
+            gp = arr([gr.data_ptr() for _, gr, _ in sel])
+            pp = arr([p.data_ptr() for p, _, _ in sel])
+            bp = arr([self.state[p]['momentum_buffer'].data_ptr() for p, _, _ in sel])
+            sh = [shadows.get(self.name_of.get(p)) for p, _, _ in sel]
             sp = arr([t.data_ptr() if t is not None else 0 for t in sh])
-            nn = np.ascontiguousarray(np.array([keep[i].numel() for i in idx], dtype=np.int64))
-            lr = np.ascontiguousarray(np.array([live[i]['lr'] for i in idx], dtype=np.float32))
+            nn = np.ascontiguousarray(np.array([gr.numel() for _, gr, _ in sel], dtype=np.int64))
+            lr = np.ascontiguousarray(np.array([l for _, _, l in sel], dtype=np.float32))
             if norm is not None:
-                _lib.call('sgg_sqnorm_multi', gp.ctypes.data, nn.ctypes.data, len(idx), norm, ops.dt(keep[idx[0]]), stream)
-            pending.append((dtype, gp, pp, bp, sp, nn, lr, len(idx)))
-        for dtype, gp, pp, bp, sp, nn, lr, cnt in pending:  # every norm contribution lands before the first update
+                _lib.call('sgg_sqnorm_multi', gp.ctypes.data, nn.ctypes.data, len(sel), norm, ops.dt(sel[0][1]), stream)
+            pending.append((dtype, gp, pp, bp, sp, nn, lr, len(sel), sel))
+        for dtype, gp, pp, bp, sp, nn, lr, cnt, _keep in pending:  # every norm contribution lands before the first update
             _lib.call('sgg_sgd_multi', pp.ctypes.data, gp.ctypes.data, bp.ctypes.data, sp.ctypes.data, nn.ctypes.data,
-                      lr.ctypes.data, cnt, float(self.weight_decay), float(self.momentum), int(first), norm,
+                      lr.ctypes.data, cnt, float(wd), float(mom), int(first), norm,
                       float(self.clip or 0.0), float(grad_scale), ops.dt(dtype), int(self.max_blocks), stream)
-        self.wrote_shadow = [n for n in shadows if any(g['name'] == n for g in live)]
+        names = set(self.name_of.get(p) for p, _, _ in live)
+        self.wrote_shadow = [n for n in shadows if n in names]
         self.steps += 1
         if self.on_update is not None:
             self.on_update()   # parameters changed through raw pointers: tell the owner to refresh derived operands
+        return None
 
     def grad_norm(self):
         return float(self._norm.sqrt().item())
@@ -90,7 +112,7 @@ class Trainer(object):
     """One data-parallel train step.  `loss_type` as lib/losses.py ('baseline' is the reference default, config.py:184)."""
 
     def __init__(self, model, lr=1e-3, momentum=0.9, weight_decay=1e-4, clip=5.0, loss_type='baseline',
-                 comm_dtype=torch.bfloat16, force_dist=False, sync_bn=True, pipeline=False):
+                 comm_dtype=torch.bfloat16, force_dist=False, sync_bn=True, pipeline=False, loss_weights=(1, 1, 1)):
         self.model = model
         for n, p in model.named_parameters():
             if n.startswith('detector.'):
@@ -102,6 +124,7 @@ class Trainer(object):
             self.opt.shadow_of = model.shadow_buffers
         self.buckets = GradBuckets([p for _, p in named], comm_dtype=comm_dtype, force=force_dist)
         self.loss_type = loss_type
+        self.loss_weights = tuple(float(x) for x in loss_weights)      # (alpha, beta, gamma) of lib/losses.py:37 = conf.alpha/beta/gamma
         # pipeline=True: the optimiser update of step k (HBM-bound, ~1.1 ms) and the rebuild of the weight-derived operands
         # run on the side stream UNDER the frozen VGG forward of step k+1 (MFMA-bound, ~2 ms), which does not read the
         # weights being updated (main.py:62-63: the detector is frozen).  The head of step k+1 waits for the event.
@@ -142,7 +165,9 @@ class Trainer(object):
         labels = res.rel_labels[:, -1]
         rel_ce = F.cross_entropy(res.rel_dists, labels, reduction='none')
         n_obj, M = float(res.rm_obj_labels.shape[0]), float(labels.shape[0])
+        alpha, beta, gamma = self.loss_weights
         if self.loss_type == 'baseline':
+            assert alpha == beta == 1, ('wrong loss is used, use dnorm or dnorm-fgbg', alpha, beta)      # lib/losses.py:41
             if self.dist_on:
                 # global normalisers stay on the device (fill_ = a launch, no host round trip): a .tolist() here would
                 # stall the host between forward and backward on every rank
@@ -150,24 +175,24 @@ class Trainer(object):
                 t[0].fill_(n_obj)
                 t[1].fill_(M)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                return obj_ce / t[0] + rel_ce.sum() / t[1]
-            return obj_ce / n_obj + rel_ce.sum() / M                                 # lib/losses.py:41-42,74
+                return obj_ce / t[0] + gamma * rel_ce.sum() / t[1]
+            return obj_ce / n_obj + gamma * rel_ce.sum() / M                         # lib/losses.py:41-43,74
         fg = labels > 0
         m_fg, m_bg = float(fg.sum().item()), float((~fg).sum().item())
         if self.world > 1:
             n_obj, m_fg, m_bg = sum_over_ranks([n_obj, m_fg, m_bg], device=res.rel_dists.device)
         w = torch.ones_like(rel_ce)
         if m_fg > 0:
-            w[fg] = 1.0 / m_fg                                                        # :50
+            w[fg] = alpha / m_fg                                                      # :50-51
         if self.loss_type == 'dnorm':
             if m_bg > 0 and m_fg > 0:
-                w[~fg] = 1.0 / m_fg                                                   # :56
+                w[~fg] = beta / m_fg                                                  # :56-57
         elif self.loss_type == 'dnorm-fgbg':
             if m_bg > 0:
-                w[~fg] = 1.0 / m_bg                                                   # :59
+                w[~fg] = beta / m_bg                                                  # :59-60
         else:
             raise NotImplementedError(self.loss_type)
-        return obj_ce / n_obj + (rel_ce * w).sum()
+        return obj_ce / n_obj + (gamma * rel_ce * w).sum()                            # :62-63
 
     def _prefetch_operands(self):
         """The optimiser just changed the masters, so the derived operands (W^T copies for the dX GEMMs, W6sum, the GRU /
@@ -208,9 +233,9 @@ class Trainer(object):
         side = lane[0]
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for g in self.opt.groups:                      # gradients were allocated on the main stream: keep their memory
-                if g['p'].grad is not None:                # from being recycled there while the side stream reads it
-                    g['p'].grad.record_stream(side)
+            for p in self.opt.params():                    # gradients were allocated on the main stream: keep their memory
+                if p.grad is not None:                     # from being recycled there while the side stream reads it
+                    p.grad.record_stream(side)
             reduced = self.buckets.all_reduce(average=False) if self.dist_on else None
             for t in (reduced or {}).values():
                 t.record_stream(side)

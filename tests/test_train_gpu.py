@@ -149,12 +149,102 @@ def test_fused_sgd_matches_torch_sgd_with_global_norm_clip(env):
         p.grad = torch.zeros_like(p)
     hip_named[3][1].grad = None
     hip_opt.clip = 0.0
-    bufs = [g['buf'].clone() for g in hip_opt.groups]
+    bufs = [hip_opt.state[p]['momentum_buffer'].clone() for _, p in hip_named]
     hip_opt.step(grads=gb)
     for i, ((_, p), b0, m0) in enumerate(zip(hip_named, before, bufs)):
         gexp = (0.5 if i == 3 else 0.0) + wd * b0
         m1 = mom * m0 + gexp
         torch.testing.assert_close(p.detach(), b0 - (lr / 10 if i == 0 else lr) * m1, atol=1e-6, rtol=1e-5)
+
+
+def test_fused_sgd_is_a_torch_optimizer_scheduler_and_checkpoints_interchange(env):
+    """get_optim / save_checkpoint / load_checkpoint of lib/pytorch_misc.py:128-227 on FusedSGD: the reference's two parameter
+    groups, MultiStepLR driving their learning rates, and state_dict()s that load into torch.optim.SGD and back."""
+    from sgg_amd.trainer import FusedSGD
+    g = torch.Generator().manual_seed(3)
+    shapes = [(40, 33), (17,), (64, 8)]
+    names = ['roi_fmap.1.0.weight', 'obj_fc.bias', 'edge_gru.weight_ih']
+    init = [torch.randn(s, generator=g) for s in shapes]
+    hip = [(n, torch.nn.Parameter(t.clone().to(DEV))) for n, t in zip(names, init)]
+    ref = [(n, torch.nn.Parameter(t.clone())) for n, t in zip(names, init)]
+    lr, mom, wd = 0.1, 0.9, 1e-4
+    hopt = FusedSGD(hip, lr, mom, wd, clip=0.0)
+    ropt = torch.optim.SGD([{'params': [ref[0][1]], 'lr': lr / 10}, {'params': [ref[1][1], ref[2][1]]}], lr=lr, momentum=mom, weight_decay=wd)
+    assert isinstance(hopt, torch.optim.Optimizer) and [len(gr['params']) for gr in hopt.param_groups] == [1, 2]
+    assert [gr['lr'] for gr in hopt.param_groups] == [gr['lr'] for gr in ropt.param_groups]
+    hs = torch.optim.lr_scheduler.MultiStepLR(hopt, milestones=[2, 4], gamma=0.1)          # get_optim, :152-154
+    rs = torch.optim.lr_scheduler.MultiStepLR(ropt, milestones=[2, 4], gamma=0.1)
+
+    def both_step():
+        grads = [torch.randn(s, generator=g) for s in shapes]
+        for (_, p), gr in zip(ref, grads):
+            p.grad = gr.clone()
+        for (_, p), gr in zip(hip, grads):
+            p.grad = gr.clone().to(DEV)
+        ropt.step()
+        hopt.step()
+    for epoch in range(3):
+        both_step()
+        hs.step()
+        rs.step()
+        assert [gr['lr'] for gr in hopt.param_groups] == pytest.approx([gr['lr'] for gr in ropt.param_groups])
+    assert min(gr['lr'] for gr in hopt.param_groups) == pytest.approx(lr / 10 * 0.1)         # get_smallest_lr's view
+    for (_, a), (_, b) in zip(ref, hip):
+        torch.testing.assert_close(b.detach().cpu(), a.detach(), atol=1e-6, rtol=1e-5)
+    # checkpoint written by FusedSGD -> torch.optim.SGD (same group layout) and the other way round
+    sd_h, sd_r = hopt.state_dict(), ropt.state_dict()
+    assert sorted(sd_h['state']) == sorted(sd_r['state']) and all('momentum_buffer' in v for v in sd_h['state'].values())
+    ref2 = [(n, torch.nn.Parameter(p.detach().clone())) for n, p in ref]
+    hip2 = [(n, torch.nn.Parameter(p.detach().clone())) for n, p in hip]
+    ropt2 = torch.optim.SGD([{'params': [ref2[0][1]], 'lr': lr / 10}, {'params': [ref2[1][1], ref2[2][1]]}], lr=lr, momentum=mom, weight_decay=wd)
+    hopt2 = FusedSGD(hip2, lr, mom, wd, clip=0.0)
+    ropt2.load_state_dict({'state': {k: {'momentum_buffer': v['momentum_buffer'].cpu()} for k, v in sd_h['state'].items()},
+                           'param_groups': sd_h['param_groups']})
+    hopt2.load_state_dict(sd_r)
+    assert [gr['lr'] for gr in hopt2.param_groups] == pytest.approx([gr['lr'] for gr in ropt.param_groups])
+    grads = [torch.randn(s, generator=g) for s in shapes]
+    for (_, p), gr in zip(ref2, grads):
+        p.grad = gr.clone()
+    for (_, p), gr in zip(hip2, grads):
+        p.grad = gr.clone().to(DEV)
+    ropt2.step()
+    hopt2.step()
+    for (_, a), (_, b) in zip(ref2, hip2):
+        torch.testing.assert_close(b.detach().cpu(), a.detach(), atol=1e-6, rtol=1e-5)
+    # a parameter whose first gradient arrives late starts from a zero buffer (= torch's buf = d_p)
+    late = [('w', torch.nn.Parameter(torch.ones(8, device=DEV))), ('v', torch.nn.Parameter(torch.ones(8, device=DEV)))]
+    o = FusedSGD(late, 0.5, 0.9, 0.0, clip=0.0)
+    late[0][1].grad = torch.ones(8, device=DEV)
+    o.step()
+    late[0][1].grad = torch.ones(8, device=DEV)
+    late[1][1].grad = torch.ones(8, device=DEV)
+    o.step()
+    torch.testing.assert_close(late[0][1].detach(), torch.full((8,), 1 - 0.5 - 0.5 * 1.9, device=DEV))
+    torch.testing.assert_close(late[1][1].detach(), torch.full((8,), 0.5, device=DEV))
+
+
+@pytest.mark.parametrize('loss_type,weights', [('baseline', (1, 1, 0.5)), ('dnorm', (2.0, 0.5, 1.5)), ('dnorm-fgbg', (1.0, 3.0, 1.0))])
+def test_trainer_loss_weights_match_oracle(loss_type, weights):
+    """conf.alpha / beta / gamma (main.py:111): Trainer.losses against the oracle's edge_losses + node_losses (pinned by goldens)."""
+    from types import SimpleNamespace
+    from sgg_amd.trainer import Trainer
+    g = torch.Generator().manual_seed(9)
+    E, N = 60, 12
+    res = SimpleNamespace(rm_obj_dists=torch.randn(N, 151, generator=g).to(DEV), rm_obj_labels=torch.randint(1, 151, (N,), generator=g).to(DEV),
+                          rel_dists=torch.randn(E, 51, generator=g).to(DEV))
+    lab = torch.randint(0, 51, (E,), generator=g)
+    lab[torch.rand(E, generator=g) < 0.7] = 0
+    res.rel_labels = torch.stack((torch.zeros(E, dtype=torch.long),) * 3 + (lab,), 1).to(DEV)
+    tr = Trainer.__new__(Trainer)
+    tr.loss_type, tr.loss_weights, tr.dist_on, tr.world = loss_type, tuple(float(w) for w in weights), False, 1
+    got = float(tr.losses(res))
+    exp = O.edge_losses(res.rel_dists.cpu(), lab, loss_type, loss_weights=weights) + \
+        O.node_losses(res.rm_obj_dists.cpu(), res.rm_obj_labels.cpu())
+    assert got == pytest.approx(float(exp), rel=1e-5)
+    if loss_type == 'baseline':
+        tr.loss_weights = (2.0, 1.0, 1.0)
+        with pytest.raises(AssertionError):
+            tr.losses(res)
 
 
 def test_trainer_step_updates_weights_and_refreshes_operands(env):
@@ -363,6 +453,8 @@ def test_full_size_gradients_tn_path_equals_transposes_path():
         assert torch.isfinite(a).all() and torch.isfinite(c).all(), n
         scale = c.abs().max().item() + 1e-12
         # bf16 chains + float-atomic reduction order differ run to run by a few percent of the largest entry
-        assert (a - c).abs().max().item() <= 8e-2 * scale, (n, (a - c).abs().max().item(), scale)
+        # (the four one-element gate biases are sums of ~8000 signed terms that cancel to a few 1e-3: 25 % there)
+        tol = 0.25 if a.numel() <= 4 else 8e-2
+        assert (a - c).abs().max().item() <= tol * scale, (n, (a - c).abs().max().item(), scale)
     del model, tr
     torch.cuda.empty_cache()
