@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void gru_gate_kernel(const TG* __restrict__ gi
 constexpr int SL_THREADS = SGG_SL_THREADS;
 constexpr int SL_NMAX = 64;
 #ifndef SGG_SLICED_ABL
-#define SGG_SLICED_ABL 0   // kernel experiments only: 1 no phase 2, 2 no e_in stores
+#define SGG_SLICED_ABL 0   // kernel experiments only: 1 no phase 2, 2 no e_in stores, 5 clock stamps, 6 copy only
 #endif
 
 // 16 bytes of a row: 8 bf16 or 4 f32 channels
@@ -549,6 +549,10 @@ __global__ __launch_bounds__(SL_THREADS) void imp_sliced_kernel(const T* __restr
             for (int u = 0; u < U; ++u) {
                 const int el = kb + u;
                 const bool live = el < k1;       // lanes of a quad share `live`: the DPP broadcasts below stay inside a lane group
+#if SGG_SLICED_ABL == 6                          // experiment: the access pattern alone (row piece in, row piece out)
+                if (live) *reinterpret_cast<decltype(row[u].r)*>(e_in + (long)(e0 + el) * H + col) = row[u].r;
+                continue;
+#endif
                 // gate k: 0 sub_vert(v[s]), 1 obj_vert(v[o]), 2 out_edge(v[s]), 3 in_edge(v[o])  (rel_model_stanford.py:78-89)
                 float gate[GI];
 #pragma unroll
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(SL_THREADS) void imp_sliced_kernel(const T* __restr
     __syncthreads();
     SGG_TICK(5)
     // ---- phase 2: in-lists, from the parked pieces
-    if (has_node && SGG_SLICED_ABL != 1) {
+    if (has_node && SGG_SLICED_ABL != 1 && SGG_SLICED_ABL != 6) {
         const int beg = iptr[n], end = iptr[n + 1], ch = (end - beg + P - 1) / P;
         const int j0 = beg + part * ch, j1 = min(end, j0 + ch);
         float acc[CHL];

@@ -9,7 +9,8 @@ model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls')).to
 model.set_compute_dtype(torch.bfloat16)
 b = list(synthetic_batch(B=8, S=592, n_boxes=32, n_fg=6, seed=111))
 b[0] = [im.to(dev) for im in b[0]]
-b[3], b[4], b[5] = b[3].to(dev), b[4].to(dev), b[5].to(dev)
+from sgg_amd.rel_model_base import to_device_with_mirror
+b[3], b[4], b[5] = b[3].to(dev), to_device_with_mirror(b[4], dev), to_device_with_mirror(b[5], dev)
 b = tuple(b)
 tr = Trainer(model, lr=1e-3, pipeline=True)
 for _ in range(5):
