@@ -1,6 +1,8 @@
 """GPU parity of the TRAINING path: forward in model.train() (batch-statistic BatchNorm) and the gradients of every
 trainable parameter, HIP path vs torch autograd of the CPU oracle on identical inputs and weights (fp32 mode, dropout
 disabled because its RNG cannot be matched; Dropout itself is checked statistically)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -456,5 +458,60 @@ def test_full_size_gradients_tn_path_equals_transposes_path():
         # (the four one-element gate biases are sums of ~8000 signed terms that cancel to a few 1e-3: 25 % there)
         tol = 0.25 if a.numel() <= 4 else 8e-2
         assert (a - c).abs().max().item() <= tol * scale, (n, (a - c).abs().max().item(), scale)
+    del model, tr
+    torch.cuda.empty_cache()
+
+
+def test_full_size_bf16_gradients_close_to_fp32_mode():
+    """Benchmark-size forward + backward (8 images, dropout off) in fp32 storage / arithmetic and in bf16: losses agree and every
+    gradient tensor points the same way (cosine), i.e. the bf16 kernels at their real grid sizes compute the fp32 path's numbers
+    up to rounding -- fp32 mode itself is pinned to the oracle at small size (test_backward_fp32_matches_oracle_autograd)."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import sgg_amd
+    from sgg_amd.rel_model_base import to_device_with_mirror
+    from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
+    from sgg_amd.trainer import Trainer
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls')).to(DEV)
+    model.dropout_p = 0.0
+    b = list(synthetic_batch(B=8, S=592, n_boxes=32, n_fg=6, seed=302))
+    b[0] = [im.to(DEV) for im in b[0]]
+    b[3], b[4], b[5] = b[3].to(DEV), to_device_with_mirror(b[4], DEV), to_device_with_mirror(b[5], DEV)
+    b = tuple(b)
+    tr = Trainer(model, lr=1e-3)
+    out = {}
+    for dt in (torch.float32, torch.bfloat16):
+        model.set_compute_dtype(dt)
+        model.train()
+        res = model([b])
+        loss = tr.losses(res)
+        tr.opt.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        out[dt] = (float(loss), {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None},
+                   res.rel_dists.detach().float().clone(), res.rm_obj_dists.detach().float().clone())
+    l32, g32, rd32, od32 = out[torch.float32]
+    l16, g16, rd16, od16 = out[torch.bfloat16]
+    rel_rms = lambda a, c: float((a - c).pow(2).mean().sqrt() / a.pow(2).mean().sqrt())
+    stats = dict(loss=(l32, l16), rel=rel_rms(rd32, rd16), obj=rel_rms(od32, od16))
+    if os.environ.get('SGG_TEST_VERBOSE'):
+        print(stats)
+    assert abs(l32 - l16) < 0.02 * abs(l32), stats
+    assert stats['rel'] < 0.08 and stats['obj'] < 0.12, stats          # bf16 noise through VGG-16 + 3 IMP iterations, relative RMS
+    assert len(g32) == 40 and g32.keys() == g16.keys()
+    worst = []
+    for n in g32:
+        a, c = g32[n].flatten(), g16[n].flatten()
+        assert torch.isfinite(c).all(), n
+        if a.numel() < 64:
+            continue                                   # one-element gate biases: sums that cancel, no direction to compare
+        cos = float(torch.dot(a, c) / (a.norm() * c.norm() + 1e-30))
+        worst.append((cos, n))
+        ratio = float(c.norm() / (a.norm() + 1e-30))
+        assert 0.9 < ratio < 1.1, (n, ratio)
+    worst.sort()
+    if os.environ.get('SGG_TEST_VERBOSE'):
+        print(worst[:6])
+    assert worst[0][0] > 0.95, worst[:5]          # measured 0.977 (rect-conv tensors) .. 0.9999
     del model, tr
     torch.cuda.empty_cache()
