@@ -28,6 +28,31 @@ constexpr int STAGE = 512 * ROW;        // A 256 rows + W 256 rows = 32 KiB
 constexpr int NSTAGE = 4;
 constexpr int SMEM = NSTAGE * STAGE;    // 128 KiB
 
+// byte offset of K-tile kt inside its source rows and which of the two K segments it belongs to (uniform values)
+template <bool CONV>
+__device__ __forceinline__ long tile_koff(const GemmArgs& g, bool loads_a, int kt, int tpc, int esz, bool& seg2) {
+    seg2 = false;
+    if (loads_a) {
+        if constexpr (CONV) {
+            const int tap = kt / tpc, c0 = kt - tap * tpc;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            return ((long)(ky * (g.W + 2) + kx) * g.Cin) * esz + c0 * ROW;
+        } else {
+            seg2 = kt >= g.nt1;
+            return (long)(seg2 ? kt - g.nt1 : kt) * ROW;
+        }
+    }
+    seg2 = !CONV && g.W2 && kt >= g.nt1;
+    return (long)(seg2 ? kt - g.nt1 : kt) * ROW;
+}
+
+// a pointer the compiler can prove wave-uniform (SGPR pair): lets global_load_lds take its scalar-base + 32-bit lane offset form
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const unsigned long v = (unsigned long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long)hi << 32) | lo);
+}
+
 template <bool BF16, bool CONV>
 __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -61,26 +86,28 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
     }
     const int tpc = CONV ? (g.Cin * ESZ) / ROW : 1;
     const int lds_rows0 = (loads_a ? 0 : 256 * ROW) + (wave & 3) * 64 * ROW;
-
+    // DMA addressing that costs the issuing wave nothing but the instruction itself: global = SGPR base (uniform, advanced
+    // with scalar adds per K-tile) + a per-lane 32-bit offset that never changes + the instruction's immediate; the same
+    // immediate (j KiB) places piece j in LDS behind ONE M0 value per K-tile.  The immediate applies to both addresses, so
+    // the lane offset carries -j KiB (+3 KiB on the lane, -3 KiB on the base keep it unsigned).
+    const char* sbase = loads_a ? (CONV ? g.A : g.A) : g.Wt;
+    const char* sbase2 = loads_a ? g.A2 : g.W2;
+    // (named scalars, not arrays: indexed through a runtime choice they would be demoted to scratch memory)
+#define SGG_VO(j) (unsigned)(rp[j] - sbase) + 3072u - 1024u * j
+#define SGG_VO2(j) (rp2[j] ? (unsigned)(rp2[j] - sbase2) + 3072u - 1024u * j : 0u)
+    const unsigned vo_0 = SGG_VO(0), vo_1 = SGG_VO(1), vo_2 = SGG_VO(2), vo_3 = SGG_VO(3);
+    const unsigned vo2_0 = SGG_VO2(0), vo2_1 = SGG_VO2(1), vo2_2 = SGG_VO2(2), vo2_3 = SGG_VO2(3);
+#undef SGG_VO
+#undef SGG_VO2
     auto issue = [&](int kt) {
+        bool seg2;
+        const long koff = tile_koff<CONV>(g, loads_a, kt, tpc, ESZ, seg2);
+        const char* ub = uniform_ptr((seg2 ? sbase2 : sbase) + koff - 3072);      // the -3 KiB pairs with the +3 KiB inside vo_*
         char* dst = smem + (kt & (NSTAGE - 1)) * STAGE + lds_rows0;
-        long koff;
-        bool seg2 = false;
-        if (loads_a) {
-            if constexpr (CONV) {
-                const int tap = kt / tpc, c0 = kt - tap * tpc;
-                const int ky = tap / 3, kx = tap - ky * 3;
-                koff = ((long)(ky * (g.W + 2) + kx) * g.Cin) * ESZ + c0 * ROW;
-            } else {
-                seg2 = kt >= g.nt1;
-                koff = (long)(seg2 ? kt - g.nt1 : kt) * ROW;
-            }
-        } else {
-            seg2 = !CONV && g.W2 && kt >= g.nt1;
-            koff = (long)(seg2 ? kt - g.nt1 : kt) * ROW;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) glds16((seg2 ? rp2[j] : rp[j]) + koff, dst + j * 16 * ROW);
+        glds16_off<0>(ub + (seg2 ? vo2_0 : vo_0), dst);
+        glds16_off<1024>(ub + (seg2 ? vo2_1 : vo_1), dst);
+        glds16_off<2048>(ub + (seg2 ? vo2_2 : vo_2), dst);
+        glds16_off<3072>(ub + (seg2 ? vo2_3 : vo_3), dst);
     };
 
     // ---- fragment addressing: row = base + (lane&31); logical slot = 2*s + (lane>>5)
@@ -121,50 +148,54 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
         }
     };
 
-    // 16 MFMAs; the 4 DMA pieces of K-tile `pf` (or none if pf < 0) are issued between them, where the wave is
-    // matrix-pipe bound and has free issue slots (an LDS-DMA issue costs ~60 cycles there, 100-185 in a LOAD phase)
-    auto compute = [&](int pf) {
-        char* dst = nullptr;
-        long koff = 0;
-        bool seg2 = false;
-        if (pf >= 0) {
-            dst = smem + (pf & (NSTAGE - 1)) * STAGE + lds_rows0;
-            if (loads_a) {
-                if constexpr (CONV) {
-                    const int tap = pf / tpc, c0 = pf - tap * tpc;
-                    const int ky = tap / 3, kx = tap - ky * 3;
-                    koff = ((long)(ky * (g.W + 2) + kx) * g.Cin) * ESZ + c0 * ROW;
-                } else {
-                    seg2 = pf >= g.nt1;
-                    koff = (long)(seg2 ? pf - g.nt1 : pf) * ROW;
-                }
-            } else {
-                seg2 = !CONV && g.W2 && pf >= g.nt1;
-                koff = (long)(seg2 ? pf - g.nt1 : pf) * ROW;
-            }
-        }
+    // 16 MFMAs; the 4 DMA pieces of K-tile `pf` (DMA = false: none) are issued between them, where the wave is matrix-pipe
+    // bound and has free issue slots.  Everything a piece needs beyond the instruction itself is resolved BEFORE the first
+    // MFMA (uniform base in SGPRs, segment choice, M0): no branch, no vector ALU work and no M0 write sits between MFMAs.
+#define SGG_MFMA_PAIR(s, mi)                                                                                              \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                                                    \
+        if constexpr (BF16) {                                                                                             \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bf[ni][s]),                \
+                                                                  __builtin_bit_cast(bf16x8_t, af[mi][s]), acc[mi][ni], 0, 0, 0); \
+        } else {                                                                                                          \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(             \
+                __uint_as_float(bf[ni][s][c]), __uint_as_float(af[mi][s][c]), acc[mi][ni], 0, 0, 0);                      \
+        }                                                                                                                 \
+    }
+    auto compute_dma = [&](int pf) {
+        bool seg2;
+        const long koff = tile_koff<CONV>(g, loads_a, pf, tpc, ESZ, seg2);
+        const char* ub = uniform_ptr((seg2 ? sbase2 : sbase) + koff - 3072);
+        char* dst = smem + (pf & (NSTAGE - 1)) * STAGE + lds_rows0;
+        const unsigned o0 = seg2 ? vo2_0 : vo_0, o1 = seg2 ? vo2_1 : vo_1, o2 = seg2 ? vo2_2 : vo_2, o3 = seg2 ? vo2_3 : vo_3;
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    if constexpr (BF16) {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8_t, bf[ni][s]), __builtin_bit_cast(bf16x8_t, af[mi][s]), acc[mi][ni], 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                __uint_as_float(bf[ni][s][c]), __uint_as_float(af[mi][s][c]), acc[mi][ni], 0, 0, 0);
-                    }
-                }
-                if (s == 0 && pf >= 0) {   // after MFMA 2,4,6,8
-                    glds16((seg2 ? rp2[mi] : rp[mi]) + koff, dst + mi * 16 * ROW);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+        SGG_MFMA_PAIR(0, 0)
+        glds16_off<0>(ub + o0, dst);
+        __builtin_amdgcn_sched_barrier(0);
+        SGG_MFMA_PAIR(0, 1)
+        glds16_off<1024>(ub + o1, dst);
+        __builtin_amdgcn_sched_barrier(0);
+        SGG_MFMA_PAIR(0, 2)
+        glds16_off<2048>(ub + o2, dst);
+        __builtin_amdgcn_sched_barrier(0);
+        SGG_MFMA_PAIR(0, 3)
+        glds16_off<3072>(ub + o3, dst);
+        __builtin_amdgcn_sched_barrier(0);
+        SGG_MFMA_PAIR(1, 0)
+        SGG_MFMA_PAIR(1, 1)
+        SGG_MFMA_PAIR(1, 2)
+        SGG_MFMA_PAIR(1, 3)
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto compute_plain = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+        SGG_MFMA_PAIR(0, 0)
+        SGG_MFMA_PAIR(0, 1)
+        SGG_MFMA_PAIR(0, 2)
+        SGG_MFMA_PAIR(0, 3)
+        SGG_MFMA_PAIR(1, 0)
+        SGG_MFMA_PAIR(1, 1)
+        SGG_MFMA_PAIR(1, 2)
+        SGG_MFMA_PAIR(1, 3)
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -188,31 +219,50 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
     // Two s_barriers per K-tile (measured better than one: 1053 vs 1008 TFLOP/s on fc6 -- with a single barrier the
     // two waves of a SIMD drift into the same phase).  Tile kt+3 goes into the stage tile kt-1 occupied; its last
     // readers (group 1, LOAD kt-1) retired their ds_reads before the barrier that ended slot 2kt-1.
+    // The K loop is peeled: nt-3 steady iterations whose MFMA phase carries the DMA of tile kt+3, then the last three without
+    // any -- one copy of the MFMA block per loop, no branch inside a phase.
+    const int nsteady = max(nt - 3, 0);
     if (grp == 0) {
-        for (int kt = 0; kt < nt; ++kt) {
-            // slot 2kt : LOAD
+        for (int kt = 0; kt < nsteady; ++kt) {
+            load_frags(kt);                                  // slot 2kt : LOAD
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            compute_dma(kt + 3);                             // slot 2kt+1 : MFMA + DMA issue of tile kt+3
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vmcnt<8>();                                 // tile kt+1 landed; kt+2, kt+3 still in flight
+            __builtin_amdgcn_s_barrier();
+        }
+        for (int kt = nsteady; kt < nt; ++kt) {
             load_frags(kt);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
-            // slot 2kt+1 : MFMA (+ DMA issue of tile kt+3)
-            compute(kt + 3 < nt ? kt + 3 : -1);
+            compute_plain();
             __builtin_amdgcn_sched_barrier(0);
-            wait_tiles_in_flight(min(2, nt - 2 - kt));     // tile kt+1 landed; issued so far: .. kt+3
+            wait_tiles_in_flight(min(2, nt - 2 - kt));       // tile kt+1 landed; nothing issued after kt+3 <= nt-1
             __builtin_amdgcn_s_barrier();
         }
         __builtin_amdgcn_s_barrier();  // slot 2nt: group 1 finishes its last MFMA phase
     } else {
         __builtin_amdgcn_s_barrier();  // slot 0: idle
-        for (int kt = 0; kt < nt; ++kt) {
-            // slot 2kt+1 : LOAD
+        for (int kt = 0; kt < nsteady; ++kt) {
+            load_frags(kt);                                  // slot 2kt+1 : LOAD
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vmcnt<4>();                                 // tile kt+1 landed; issued so far: .. kt+2
+            __builtin_amdgcn_s_barrier();
+            compute_dma(kt + 3);                             // slot 2kt+2 : MFMA + DMA issue of tile kt+3
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        for (int kt = nsteady; kt < nt; ++kt) {
             load_frags(kt);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            wait_tiles_in_flight(min(1, nt - 2 - kt));     // tile kt+1 landed; issued so far: .. kt+2
+            wait_tiles_in_flight(min(1, nt - 2 - kt));
             __builtin_amdgcn_s_barrier();
-            // slot 2kt+2 : MFMA (+ DMA issue of tile kt+3)
-            compute(kt + 3 < nt ? kt + 3 : -1);
+            compute_plain();
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
         }

@@ -28,6 +28,12 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
     __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)l, 16, 0, 0);
 }
 
+// same, with an immediate offset that the hardware adds to BOTH the global and the LDS address
+template <int OFF>
+__device__ __forceinline__ void glds16_off(const char* g, char* l) {
+    __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)l, 16, OFF, 0);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
