@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
     const int y0 = ty * TILE, x0 = tx * TILE, n0 = cb * CN;
 
     // ---- DMA source pointers
-    const char* psrc[PI_W];
+    // per-lane 32-bit offsets against uniform bases: the LDS-DMA then takes its scalar-base form and costs no vector ALU work
+    unsigned psrc[PI_W];
 #pragma unroll
     for (int j = 0; j < PI_W; ++j) {
         const int instr = min(wave + j * NW, PI - 1);
@@ -76,25 +77,25 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
         const int py = r / PW, px = r - py * PW;
         const int gy = min(y0 + py, g.H + 1), gx = min(x0 + px, g.W + 1);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        psrc[j] = g.in + (((long)b * (g.H + 2) + gy) * (g.W + 2) + gx) * g.Cin * ESZ + chunk * 16;
+        psrc[j] = (unsigned)((((long)b * (g.H + 2) + gy) * (g.W + 2) + gx) * g.Cin * ESZ + chunk * 16);
     }
-    const char* wsrc[WI_W];
+    unsigned wsrc[WI_W];
 #pragma unroll
     for (int j = 0; j < WI_W; ++j) {
         const int r = (wave * WI_W + j) * 8 + (lane >> 3);   // row = output channel inside the block
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        wsrc[j] = g.w + (long)(n0 + r) * 9 * g.Cin * ESZ + chunk * 16;
+        wsrc[j] = (unsigned)((long)(n0 + r) * 9 * g.Cin * ESZ + chunk * 16);
     }
     auto stage_patch = [&](int chunk) {
-        const long koff = (long)chunk * RB;
+        const char* ub = uniform_ptr(g.in + (long)chunk * RB);
 #pragma unroll
         for (int j = 0; j < PI_W; ++j)
-            if (wave + j * NW < PI) glds16(psrc[j] + koff, patch + (wave + j * NW) * 8 * RB);
+            if (wave + j * NW < PI) glds16_su(ub, psrc[j], patch + (wave + j * NW) * 8 * RB);
     };
     auto stage_w = [&](int tap, int chunk, int buf) {
-        const long koff = ((long)tap * g.Cin) * ESZ + (long)chunk * RB;
+        const char* ub = uniform_ptr(g.w + ((long)tap * g.Cin) * ESZ + (long)chunk * RB);
 #pragma unroll
-        for (int j = 0; j < WI_W; ++j) glds16(wsrc[j] + koff, wbuf + buf * WSLAB_B + (wave * WI_W + j) * 8 * RB);
+        for (int j = 0; j < WI_W; ++j) glds16_su(ub, wsrc[j], wbuf + buf * WSLAB_B + (wave * WI_W + j) * 8 * RB);
     };
 
     // ---- fragment addressing

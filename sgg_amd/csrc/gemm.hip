@@ -45,10 +45,11 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
 
     // ---- per-lane source pointers (16-byte chunk of a 128-byte row, swizzled)
     const int lrow = lane >> 3;  // row inside an 8-row load
-    const char* arp[LA];
-    const char* arp2[LA];
-    const char* brp[LB];
-    const char* brp2[LB];
+    // per-lane 32-bit offsets against the uniform operand bases (glds16_su: scalar-base LDS-DMA, no vector ALU per piece)
+    unsigned arp[LA];
+    unsigned arp2[LA];
+    unsigned brp[LB];
+    unsigned brp2[LB];
 #pragma unroll
     for (int j = 0; j < LA; ++j) {
         const int r = (wave * LA + j) * 8 + lrow;
@@ -58,11 +59,11 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
             const int hw = g.H * g.W;
             const int b = m / hw, rem = m - b * hw;
             const int y = rem / g.W, x = rem - y * g.W;
-            arp[j] = g.A + ((long)(b * (g.H + 2) + y) * (g.W + 2) + x) * g.Cin * ESZ + chunk * 16;
-            arp2[j] = nullptr;
+            arp[j] = (unsigned)(((long)(b * (g.H + 2) + y) * (g.W + 2) + x) * g.Cin * ESZ + chunk * 16);
+            arp2[j] = 0;
         } else {
-            arp[j] = g.A + (long)m * g.lda_b + chunk * 16;
-            arp2[j] = g.A2 ? g.A2 + (long)m * g.lda2_b + chunk * 16 : nullptr;
+            arp[j] = (unsigned)((long)m * g.lda_b + chunk * 16);
+            arp2[j] = g.A2 ? (unsigned)((long)m * g.lda2_b + chunk * 16) : 0;
         }
     }
 #pragma unroll
@@ -70,8 +71,8 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
         const int r = (wave * LB + j) * 8 + lrow;
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
         const int n = min(n0 + r, g.N - 1);
-        brp[j] = g.Wt + (long)n * g.ldw_b + chunk * 16;
-        brp2[j] = (!CONV && g.W2) ? g.W2 + (long)n * g.ldw2_b + chunk * 16 : nullptr;
+        brp[j] = (unsigned)((long)n * g.ldw_b + chunk * 16);
+        brp2[j] = (!CONV && g.W2) ? (unsigned)((long)n * g.ldw2_b + chunk * 16) : 0;
     }
     const int tpc = CONV ? (g.Cin * ESZ) / ROWB : 1;  // k-tiles per conv tap
 
@@ -88,13 +89,13 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
             seg2 = kt >= g.nt1;
             koff = (long)(seg2 ? kt - g.nt1 : kt) * ROWB;
         }
+        const char* ua = uniform_ptr((seg2 ? g.A2 : g.A) + koff);
 #pragma unroll
-        for (int j = 0; j < LA; ++j)
-            glds16((seg2 ? arp2[j] : arp[j]) + koff, sa + (wave * LA + j) * 8 * ROWB);
+        for (int j = 0; j < LA; ++j) glds16_su(ua, seg2 ? arp2[j] : arp[j], sa + (wave * LA + j) * 8 * ROWB);
         const bool wseg2 = !CONV && g.W2 && kt >= g.nt1;
-        const long koffb = (long)(wseg2 ? kt - g.nt1 : kt) * ROWB;
+        const char* ub = uniform_ptr((wseg2 ? g.W2 : g.Wt) + (long)(wseg2 ? kt - g.nt1 : kt) * ROWB);
 #pragma unroll
-        for (int j = 0; j < LB; ++j) glds16((wseg2 ? brp2[j] : brp[j]) + koffb, sb + (wave * LB + j) * 8 * ROWB);
+        for (int j = 0; j < LB; ++j) glds16_su(ub, wseg2 ? brp2[j] : brp[j], sb + (wave * LB + j) * 8 * ROWB);
     };
 
     f32x16 acc[2][2];
@@ -221,26 +222,27 @@ __global__ __launch_bounds__(256) void mfma_tile_tn_kernel(const GemmArgs g) {
 
     // ---- DMA sources: instruction i of a half covers stage rows 8i..8i+7; lane -> (row 8i + lane/8, 16-byte chunk)
     const int lrow = lane >> 3;
-    const char* asrc[4];
-    const char* bsrc[4];
+    unsigned asrc[4];
+    unsigned bsrc[4];
     int ldst[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int idx = wave * 4 + j;               // 16 instructions per operand: half = idx / 8, row block = idx % 8
         const int half = idx >> 3, r = (idx & 7) * 8 + lrow;
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        asrc[j] = g.A + (long)r * g.lda_b + (long)(n0 + half * 64) * 2 + chunk * 16;
-        bsrc[j] = g.Wt + (long)r * g.ldw_b + (long)(k0 + half * 64) * 2 + chunk * 16;
+        asrc[j] = (unsigned)((long)r * g.lda_b + (long)(n0 + half * 64) * 2 + chunk * 16);
+        bsrc[j] = (unsigned)((long)r * g.ldw_b + (long)(k0 + half * 64) * 2 + chunk * 16);
         ldst[j] = half * HALF + (idx & 7) * 8 * ROWB;
     }
     auto stage = [&](int kt, int buf) {
         char* sa = smem + buf * STAGE;
         char* sb = sa + 2 * HALF;
-        const long roff_a = (long)kt * 64 * g.lda_b, roff_b = (long)kt * 64 * g.ldw_b;
+        const char* ua = uniform_ptr(g.A + (long)kt * 64 * g.lda_b);
+        const char* ub = uniform_ptr(g.Wt + (long)kt * 64 * g.ldw_b);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(asrc[j] + roff_a, sa + ldst[j]);
+        for (int j = 0; j < 4; ++j) glds16_su(ua, asrc[j], sa + ldst[j]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(bsrc[j] + roff_b, sb + ldst[j]);
+        for (int j = 0; j < 4; ++j) glds16_su(ub, bsrc[j], sb + ldst[j]);
     };
 
     f32x16 acc[2][2];
@@ -399,6 +401,10 @@ extern "C" int sgg_gemm(const void* A, int lda, const void* A2, int lda2, int K1
     if (W2 && (!A2 || (((uintptr_t)W2) & 15) || ldw2 < K - K1 || ldw < K1)) return SGG_ERR_ARG;
     if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)(A2 ? A2 : A)) & 15) return SGG_ERR_ARG;
     if (lda < K1 || (!W2 && ldw < K) || ldc < N || (A2 && lda2 < K - K1)) return SGG_ERR_ARG;
+    // the kernels address operand rows as (uniform base + 32-bit lane offset): every operand must span < 4 GiB
+    const long lim = 0xffff0000L;
+    if ((long)M * lda * esz > lim || (long)N * ldw * esz > lim || (A2 && (long)M * lda2 * esz > lim) || (W2 && (long)N * ldw2 * esz > lim))
+        return SGG_ERR_ARG;
     GemmArgs g{};
     g.A = (const char*)A; g.A2 = (const char*)A2; g.Wt = (const char*)W; g.W2 = (const char*)W2;
     g.lda_b = (long)lda * esz; g.lda2_b = (long)lda2 * esz; g.ldw_b = (long)ldw * esz; g.ldw2_b = (long)ldw2 * esz;
@@ -448,6 +454,7 @@ extern "C" int sgg_gemm_splitk(const void* A, int lda, const void* W, int ldw, c
     const int bke = ROWB / esz;
     if (!A || !W || !C || !workspace || M < 0 || N <= 0 || (N & 7) || K <= 0 || K % bke || splits < 1 || splits > K / bke) return SGG_ERR_ARG;
     if ((lda & 7) || (ldw & 7) || lda < K || ldw < K || (((uintptr_t)A | (uintptr_t)W) & 15)) return SGG_ERR_ARG;
+    if ((long)M * lda * esz > 0xffff0000L || (long)N * ldw * esz > 0xffff0000L) return SGG_ERR_ARG;   // 32-bit lane offsets
     GemmArgs g{};
     g.A = (const char*)A; g.Wt = (const char*)W;
     g.lda_b = (long)lda * esz; g.ldw_b = (long)ldw * esz;
@@ -478,6 +485,7 @@ extern "C" int sgg_gemm_tn(const void* A, int lda, const void* B, int ldb, void*
         ldc < K || ((lda | ldb | ldc) & 7) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) || splits < 1 ||
         splits > Mred / 64 || (splits > 1 && (!workspace || ldc != K)))
         return SGG_ERR_ARG;
+    if ((long)Mred * lda * 2 > 0xffff0000L || (long)Mred * ldb * 2 > 0xffff0000L) return SGG_ERR_ARG;   // 32-bit lane offsets
     GemmArgs g{};
     g.A = (const char*)A; g.Wt = (const char*)B;
     g.lda_b = (long)lda * 2; g.ldw_b = (long)ldb * 2;
@@ -518,6 +526,7 @@ extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias
     if (!in || !w || !out || B <= 0 || H <= 0 || W <= 0 || Cin % bke || Cout % 64 || (out_pad != 0 && out_pad != 1))
         return SGG_ERR_ARG;
     if ((long)B * H * W > 0x7fffffffL) return SGG_ERR_ARG;
+    if ((long)B * (H + 2) * (W + 2) * Cin * esz > 0xffff0000L || 9L * Cin * Cout * esz > 0xffff0000L) return SGG_ERR_ARG;   // 32-bit lane offsets
     {
         // wide-spatial layers: LDS-resident input patch kernel (conv_spatial.hip); small maps: implicit GEMM.
         // SGG_CONV_FORCE=gemm|spatial overrides (experiments only).

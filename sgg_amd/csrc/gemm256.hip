@@ -46,13 +46,6 @@ __device__ __forceinline__ long tile_koff(const GemmArgs& g, bool loads_a, int k
     return (long)(seg2 ? kt - g.nt1 : kt) * ROW;
 }
 
-// a pointer the compiler can prove wave-uniform (SGPR pair): lets global_load_lds take its scalar-base + 32-bit lane offset form
-__device__ __forceinline__ const char* uniform_ptr(const char* p) {
-    const unsigned long v = (unsigned long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (const char*)(((unsigned long)hi << 32) | lo);
-}
-
 template <bool BF16, bool CONV>
 __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -34,6 +34,20 @@ __device__ __forceinline__ void glds16_off(const char* g, char* l) {
     __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)l, 16, OFF, 0);
 }
 
+// a pointer the compiler can prove wave-uniform (SGPR pair): lets global_load_lds take its scalar-base + 32-bit lane offset form
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const unsigned long v = (unsigned long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long)hi << 32) | lo);
+}
+
+// LDS-DMA from (uniform base + per-lane 32-bit offset).  The empty asm pins the offset's zero-extension next to the load, where
+// instruction selection folds it into global_load_lds' scalar-base form (hoisted out of a loop it becomes a 64-bit VGPR add)
+__device__ __forceinline__ void glds16_su(const char* ubase, unsigned off, char* l) {
+    asm volatile("" : "+v"(off));
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(ubase + off), (lds_void_t*)l, 16, 0, 0);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
