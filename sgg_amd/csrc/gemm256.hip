@@ -32,6 +32,9 @@ constexpr int SMEM = NSTAGE * STAGE;    // 128 KiB
 template <bool CONV>
 __device__ __forceinline__ long tile_koff(const GemmArgs& g, bool loads_a, int kt, int tpc, int esz, bool& seg2) {
     seg2 = false;
+#ifdef SGG_GEMM_ABL_HOT   // experiment: every K-tile re-reads tile 0 (operands stay in L2): what the memory side costs
+    kt = 0;
+#endif
     if (loads_a) {
         if constexpr (CONV) {
             const int tap = kt / tpc, c0 = kt - tap * tpc;
