@@ -119,7 +119,10 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nchunk = (g.Cin * ESZ) / RB;
+#ifndef SGG_CONV_ABL
+#define SGG_CONV_ABL 0   // kernel experiments only: 1 no main loop (tile prologue + epilogue cost), 2 no output stores
+#endif
+    const int nchunk = SGG_CONV_ABL == 1 ? 0 : (g.Cin * ESZ) / RB;
     for (int ch = 0; ch < nchunk; ++ch) {
         if (ONEBAR && ch) __builtin_amdgcn_s_barrier();  // every wave is done with the previous patch and slab 0's buffer
         stage_patch(ch);
@@ -246,6 +249,7 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
             for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] + bias8[k], 0.f);
             const int op = g.out_pad;
             const long off = (((long)b * (g.H + 2 * op) + y + op) * (g.W + 2 * op) + x + op) * g.Cout + n;
+            if (SGG_CONV_ABL == 2) continue;
             if constexpr (BF16) store8(reinterpret_cast<bf16_t*>(g.out) + off, v);
             else store8(reinterpret_cast<float*>(g.out) + off, v);
         }
