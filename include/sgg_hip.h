@@ -47,6 +47,10 @@ int sgg_image_prep(const float* img_chw, int h, int w, int rh, int rw, float* ou
  * are fused in, so the host hands over 1 byte per sample instead of 4.  (rh,rw) = resized size of the S x S image. */
 int sgg_image_prep_u8(const uint8_t* img_hwc, int h0, int w0, int rh, int rw, float* out_nhwc4, int b, int Hp, int Wp,
                       void* stream);
+/* The whole batch in one launch: host arrays of n device image pointers and per-image (h0, w0) source sizes, (rh, rw) resized
+ * sizes and a u8 flag (1: decoded u8 [h0,w0,3] as sgg_image_prep_u8, 0: f32 [3,h0,w0] as sgg_image_prep); image k goes to plane k. */
+int sgg_image_prep_batch(const void* const* imgs, const int* h0, const int* w0, const int* rh, const int* rw,
+                         const unsigned char* is_u8, int n, float* out, int Hp, int Wp, void* stream);
 
 /* ---- a-2  VGG-16 features: [3P] vgg16.features minus the last pool, rel_model_base.py:92-93,184,310-312 ----
  * Activations live in zero-bordered NHWC buffers [B, H+2*pad, W+2*pad, C]. */
@@ -163,7 +167,8 @@ int sgg_imp_sliced_capacity(int H, int dtype);
 int sgg_imp_sliced_fwd(const void* v, const void* e, const int* so /*[E,2]*/, const int* out_ptr, const int* in_ptr,
                        const int* in_ids, const int* img_ptr, int B, int N, int E, int H, const float* node_dots,
                        const float* edge_dots, const float* gate_b, void* e_in, void* ctx2 /*[2,N,H]*/, int max_edges,
-                       int max_nodes, int dtype, void* stream);
+                       int max_nodes, int sum_ctx /*1: ctx2 is [N,H] = ctx_out + ctx_in (training keeps the sum)*/, int dtype,
+                       void* stream);
 /* img_ptr i32[2*(B+1) + 66*B]: img_ptr[b] = first node of graph b (im_inds i64[N] ascending), img_ptr[B] = N; then
  * img_ptr[B+1+b] = out_ptr[first node of b] = first edge of graph b (out_ptr from sgg_edge_csr, same stream, edges sorted);
  * then per graph 66 graph-relative out-list offsets of its nodes (entries past the last node repeat the edge count). */
@@ -223,8 +228,9 @@ int sgg_det_output(const float* boxes, const float* scores, const int* labels, c
 int sgg_dropout_fwd(void* x, int64_t n, float p, uint64_t seed, int dtype, void* stream);
 /* dx = dy * (y > 0) * scale : backward of ReLU (scale 1) / ReLU->Dropout (y = saved post-dropout output, scale 1/(1-p)) */
 int sgg_act_bwd(const void* dy, const void* y, void* dx, int64_t n, float scale, int g_dtype, int y_dtype, void* stream);
-/* out[N] = column sums of x[M,N] (row stride ld): bias gradients.  out zeroed by the callee. */
-int sgg_colsum(const void* x, int M, int N, int ld, float* out, int dtype, void* stream);
+/* out[N] = column sums of x[M,N] (row stride ld): bias gradients.  Accumulates with atomics: zero_out = 1 clears `out` first,
+ * zero_out = 0 expects the caller to hand over zeros (one cleared workspace for all the sums of a backward pass). */
+int sgg_colsum(const void* x, int M, int N, int ld, float* out, int zero_out, int dtype, void* stream);
 /* train-mode BatchNorm2d of the rect conv (lib/get_union_boxes.py:54,58) on row-major [rows, C] activations:
  * bn_stats: sums[2][C] = (sum x, sum x^2), zeroed by the callee; bn_finalize: batch mean / invstd, the affine
  * (scale, shift) and the running-stat update (momentum 0.01, unbiased var); bn_apply: y = x*scale+shift, optionally

@@ -22,6 +22,7 @@ SIGNATURES = {
     'sgg_build_info': [],
     'sgg_image_prep': [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     'sgg_image_prep_u8': [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
+    'sgg_image_prep_batch': [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P],
     'sgg_conv1_1': [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sgg_conv3x3_relu': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'sgg_maxpool2x2': [_P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -41,7 +42,7 @@ SIGNATURES = {
     'sgg_imp_fused_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     'sgg_gru_gate_fwd': [_P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _P],
     'sgg_imp_sliced_capacity': [_I, _I],
-    'sgg_imp_sliced_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    'sgg_imp_sliced_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sgg_graph_ptr': [_P, _I, _I, _P, _P, _P],
     'sgg_eval_tail': [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     'sgg_rpn_decode': [_P, _I, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P],
@@ -53,7 +54,7 @@ SIGNATURES = {
     'sgg_det_output': [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     'sgg_dropout_fwd': [_P, _L, _F, ctypes.c_uint64, _I, _P],
     'sgg_act_bwd': [_P, _P, _P, _L, _F, _I, _I, _P],
-    'sgg_colsum': [_P, _I, _I, _I, _P, _I, _P],
+    'sgg_colsum': [_P, _I, _I, _I, _P, _I, _I, _P],
     'sgg_bn_stats': [_P, _I, _I, _P, _I, _P],
     'sgg_bn_finalize': [_P, _I, _I, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],
     'sgg_bn_apply': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

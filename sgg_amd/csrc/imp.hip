@@ -427,7 +427,7 @@ __global__ __launch_bounds__(SL_THREADS) void imp_sliced_kernel(const T* __restr
                                                                 const int* __restrict__ img_ptr, int B, int N, int H,
                                                                 const float* __restrict__ ndots, const float* __restrict__ edots,
                                                                 const float* __restrict__ gb, T* __restrict__ e_in,
-                                                                T* __restrict__ ctx2, int EMAX) {
+                                                                T* __restrict__ ctx2, int EMAX, int sum_ctx) {
     constexpr int PIECE = LP * 16, CHL = 16 / (int)sizeof(T), GROUPS = SL_THREADS / LP;
     constexpr int U = 8;                         // edges in flight per lane group: their loads are issued before any is used
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -533,6 +533,9 @@ __global__ __launch_bounds__(SL_THREADS) void imp_sliced_kernel(const T* __restr
     __syncthreads();
     SGG_TICK(3)
     // ---- phase 1: out-lists
+    float out_sum[CHL];                           // sum_ctx: the node's finished ctx_out, kept for the single store after phase 2
+#pragma unroll
+    for (int j = 0; j < CHL; ++j) out_sum[j] = 0.f;
     if (has_node) {
         Piece16<T> vnp;
         vnp.r = *reinterpret_cast<const decltype(vnp.r)*>(vs + n * PIECE + sub * 16);
@@ -592,7 +595,12 @@ __global__ __launch_bounds__(SL_THREADS) void imp_sliced_kernel(const T* __restr
 #pragma unroll
             for (int j = 0; j < CHL; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
         }
-        if (part == 0) Piece16<T>::store(ctx2 + (long)(n0 + n) * H + col, acc);
+        if (sum_ctx) {
+#pragma unroll
+            for (int j = 0; j < CHL; ++j) out_sum[j] = acc[j];
+        } else if (part == 0) {
+            Piece16<T>::store(ctx2 + (long)(n0 + n) * H + col, acc);
+        }
     }
     SGG_TICK(4)
     __syncthreads();
@@ -627,7 +635,13 @@ __global__ __launch_bounds__(SL_THREADS) void imp_sliced_kernel(const T* __restr
 #pragma unroll
             for (int j = 0; j < CHL; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
         }
-        if (part == 0) Piece16<T>::store(ctx2 + ((long)N + n0 + n) * H + col, acc);
+        if (sum_ctx) {                            // training: ctx = ctx_out + ctx_in in one [N,H] tensor (it is an operand of d W_ih)
+#pragma unroll
+            for (int j = 0; j < CHL; ++j) acc[j] += out_sum[j];
+            if (part == 0) Piece16<T>::store(ctx2 + (long)(n0 + n) * H + col, acc);
+        } else if (part == 0) {
+            Piece16<T>::store(ctx2 + ((long)N + n0 + n) * H + col, acc);
+        }
     }
 #if SGG_SLICED_ABL == 5
     SGG_TICK(6)
@@ -748,7 +762,7 @@ __global__ void graph_ptr_kernel(const int64_t* __restrict__ im, int N, int B, c
 template <typename T, int LP>
 int launch_sliced(const void* v, const void* e, const int* so, const int* out_ptr, const int* in_ptr, const int* in_ids,
                   const int* img_ptr, int B, int N, int H, const float* ndots, const float* edots, const float* gb, void* e_in,
-                  void* ctx2, int max_edges, hipStream_t s) {
+                  void* ctx2, int max_edges, int sum_ctx, hipStream_t s) {
     auto k = imp_sliced_kernel<T, LP>;
     static bool configured = false;
     if (!configured) {
@@ -761,7 +775,7 @@ int launch_sliced(const void* v, const void* e, const int* so, const int* out_pt
     const int emax = (max(max_edges, 8) + 7) & ~7;
     const int S = H * (int)sizeof(T) / (LP * 16);
     hipLaunchKernelGGL(k, dim3(B * S), dim3(SL_THREADS), slice_lds_bytes<LP>(emax), s, (const T*)v, (const T*)e, so, out_ptr, in_ptr,
-                       in_ids, img_ptr, B, N, H, ndots, edots, gb, (T*)e_in, (T*)ctx2, emax);
+                       in_ids, img_ptr, B, N, H, ndots, edots, gb, (T*)e_in, (T*)ctx2, emax, sum_ctx);
     return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
 }
 }  // namespace
@@ -783,7 +797,7 @@ extern "C" int sgg_imp_sliced_capacity(int H, int dtype) {
 extern "C" int sgg_imp_sliced_fwd(const void* v, const void* e, const int* so, const int* out_ptr, const int* in_ptr,
                                   const int* in_ids, const int* img_ptr, int B, int N, int E, int H, const float* node_dots,
                                   const float* edge_dots, const float* gate_b, void* e_in, void* ctx2, int max_edges, int max_nodes,
-                                  int dtype, void* stream) {
+                                  int sum_ctx, int dtype, void* stream) {
     if (N == 0 || B == 0) return SGG_OK;
     if (!v || !e || !so || !out_ptr || !in_ptr || !in_ids || !img_ptr || !node_dots || !edge_dots || !gate_b || !e_in || !ctx2 ||
         N < 0 || E < 0 || B < 0 || H <= 0)
@@ -809,7 +823,7 @@ extern "C" int sgg_imp_sliced_fwd(const void* v, const void* e, const int* so, c
     }
 #define SGG_SLICED(T, LPV) \
     return launch_sliced<T, LPV>(v, e, so, out_ptr, in_ptr, in_ids, img_ptr, B, N, H, node_dots, edge_dots, gate_b, e_in, ctx2, \
-                                 max_edges, s)
+                                 max_edges, sum_ctx, s)
     if (dtype == SGG_BF16) {
         if (lp == 8) SGG_SLICED(bf16_t, 8);
         if (lp == 4) SGG_SLICED(bf16_t, 4);

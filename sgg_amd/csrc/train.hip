@@ -789,10 +789,12 @@ extern "C" int sgg_act_bwd(const void* dy, const void* y, void* dx, int64_t n, f
     return SGG_OK;
 }
 
-extern "C" int sgg_colsum(const void* x, int M, int N, int ld, float* out /*zeroed by the callee*/, int dtype, void* stream) {
+extern "C" int sgg_colsum(const void* x, int M, int N, int ld, float* out, int zero_out, int dtype, void* stream) {
     if (!out || N <= 0 || M < 0 || ld < N) return SGG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s) != hipSuccess) return SGG_ERR_LAUNCH;
+    // the kernel accumulates with atomics: `out` must start at zero -- zeroed here, or by the caller (zero_out = 0: e.g. a slice
+    // of one workspace cleared once for all the bias gradients of a backward pass, instead of a memset launch per call)
+    if (zero_out && hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s) != hipSuccess) return SGG_ERR_LAUNCH;
     if (M == 0) return SGG_OK;
     if (!x) return SGG_ERR_ARG;
     int rpb;

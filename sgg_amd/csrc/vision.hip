@@ -55,6 +55,47 @@ __global__ __launch_bounds__(256) void image_prep_kernel(const Src src, int h, i
     *reinterpret_cast<f32x4*>(out + (((long)b * (Hp + 2) + y + 1) * (Wp + 2) + x + 1) * 4) = o;
 }
 
+// Whole batch in one launch: blockIdx.z = image; per-image source / size parameters travel by value (<= PREP_MAX images).
+constexpr int PREP_MAX = 16;
+struct PrepTab {
+    const void* img[PREP_MAX];
+    int h0[PREP_MAX], w0[PREP_MAX], rh[PREP_MAX], rw[PREP_MAX];
+    unsigned char u8[PREP_MAX];
+};
+__global__ __launch_bounds__(256) void image_prep_batch_kernel(const PrepTab t, float* __restrict__ out, int b0, int Hp, int Wp) {
+    const int i = blockIdx.z, x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    const int rh = t.rh[i], rw = t.rw[i];
+    if (x >= rw || y >= rh) return;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    const int h0 = t.h0[i], w0 = t.w0[i];
+    const bool u8 = t.u8[i] != 0;
+    const int h = u8 ? max(h0, w0) : h0, w = u8 ? max(h0, w0) : w0;       // SquarePad: the transform sees a square
+    const SrcF32 sf{(const float*)t.img[i], h0, w0};
+    const SrcU8 su{(const unsigned char*)t.img[i], h0, w0};
+    auto at = [&](int c, int yy, int xx) { return u8 ? su.at(c, yy, xx) : sf.at(c, yy, xx); };
+    float v[3];
+    if (rh == h && rw == w) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (at(c, y, x) - mean[c]) / stdv[c];
+    } else {
+        const float sy = (float)h / (float)rh, sx = (float)w / (float)rw;
+        float fy = sy * ((float)y + 0.5f) - 0.5f, fx = sx * ((float)x + 0.5f) - 0.5f;
+        fy = fy < 0.f ? 0.f : fy;
+        fx = fx < 0.f ? 0.f : fx;
+        const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
+        const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float a = (at(c, y0, x0) - mean[c]) / stdv[c], bq = (at(c, y0, x1) - mean[c]) / stdv[c];
+            const float cq = (at(c, y1, x0) - mean[c]) / stdv[c], d = (at(c, y1, x1) - mean[c]) / stdv[c];
+            v[c] = hy * (hx * a + lx * bq) + ly * (hx * cq + lx * d);
+        }
+    }
+    f32x4 o = {v[0], v[1], v[2], 0.f};
+    *reinterpret_cast<f32x4*>(out + (((long)(b0 + i) * (Hp + 2) + y + 1) * (Wp + 2) + x + 1) * 4) = o;
+}
+
 // ------------------------------------------------------------------------------------------------
 // a-2  conv1_1 (3 -> 64, 3x3, pad 1) + ReLU, fp32 VALU (K = 27 is too thin for MFMA, the layer is
 // write-bound: 64 outputs per 27 inputs).  256 threads = 64 pixels x 4 groups of 16 output channels.
@@ -451,6 +492,26 @@ extern "C" int sgg_image_prep_u8(const uint8_t* img_hwc, int h0, int w0, int rh,
     dim3 grid((rw + 255) / 256, rh);
     hipLaunchKernelGGL(image_prep_kernel<SrcU8>, grid, dim3(256), 0, (hipStream_t)stream, SrcU8{img_hwc, h0, w0}, S, S, rh, rw, out, b, Hp, Wp);
     SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_image_prep_batch(const void* const* imgs, const int* h0, const int* w0, const int* rh, const int* rw,
+                                    const unsigned char* is_u8, int n, float* out, int Hp, int Wp, void* stream) {
+    if (!imgs || !h0 || !w0 || !rh || !rw || !is_u8 || !out || n < 0) return SGG_ERR_ARG;
+    for (int b0 = 0; b0 < n; b0 += PREP_MAX) {
+        const int m = n - b0 < PREP_MAX ? n - b0 : PREP_MAX;
+        PrepTab t{};
+        int mh = 0, mw = 0;
+        for (int i = 0; i < m; ++i) {
+            const int k = b0 + i;
+            if (!imgs[k] || h0[k] <= 0 || w0[k] <= 0 || rh[k] <= 0 || rw[k] <= 0 || rh[k] > Hp || rw[k] > Wp) return SGG_ERR_ARG;
+            t.img[i] = imgs[k]; t.h0[i] = h0[k]; t.w0[i] = w0[k]; t.rh[i] = rh[k]; t.rw[i] = rw[k]; t.u8[i] = is_u8[k];
+            mh = rh[k] > mh ? rh[k] : mh;
+            mw = rw[k] > mw ? rw[k] : mw;
+        }
+        hipLaunchKernelGGL(image_prep_batch_kernel, dim3((mw + 255) / 256, mh, m), dim3(256), 0, (hipStream_t)stream, t, out, b0, Hp, Wp);
+        SGG_CHECK_LAUNCH();
+    }
     return SGG_OK;
 }
 

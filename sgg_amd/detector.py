@@ -150,18 +150,19 @@ class VGGDetector(nn.Module):
         uniform = all(s == sizes[0] for s in sizes) and sizes[0] == (Hp, Wp)
         if not uniform:
             x0.zero_()  # ragged batch: the pad region of a previous, larger image must be cleared
-        for b, im in enumerate(images):
+        staged = []
+        for im in images:
             if is_u8_image(im):
                 if isinstance(im, np.ndarray):
                     im = torch.from_numpy(np.ascontiguousarray(im))
                 if not im.is_cuda:
                     im = im.to(device=dev, non_blocking=True)
-                ops.image_prep_u8(im.contiguous(), sizes[b][0], sizes[b][1], x0, b)
-                continue
-            im = im.squeeze()
-            if im.dtype != torch.float32 or not im.is_cuda:
-                im = im.to(device=dev, dtype=torch.float32, non_blocking=True)
-            ops.image_prep(im.contiguous(), sizes[b][0], sizes[b][1], x0, b)
+            else:
+                im = im.squeeze()
+                if im.dtype != torch.float32 or not im.is_cuda:
+                    im = im.to(device=dev, dtype=torch.float32, non_blocking=True)
+            staged.append(im)
+        ops.image_prep_batch(staged, sizes, x0)          # one launch for the batch (was one per image)
         H, W = Hp, Wp
         x, ci_layer, n_conv = x0, 0, len(ws)
         cfg = list(VGG16_CFG)

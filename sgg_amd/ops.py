@@ -62,6 +62,28 @@ def image_prep(img_chw, rh, rw, out_nhwc4, b):
               _stream())
 
 
+def image_prep_batch(images, sizes, out_nhwc4):
+    """All images of the batch in ONE launch.  images: device tensors, u8 [h,w,3] or f32 [3,h,w]; sizes[k] = (rh, rw) resized size."""
+    import numpy as np
+    n = len(images)
+    keep = [im.contiguous() for im in images]
+    for im in keep:
+        if not im.is_cuda:
+            raise RuntimeError('sgg_amd: tensor is not on the GPU (the HIP path has no CPU fallback)')
+    u8 = np.array([1 if im.dtype == torch.uint8 else 0 for im in keep], dtype=np.uint8)
+    for im, f in zip(keep, u8):
+        if not f and im.dtype != torch.float32:
+            raise TypeError('sgg_amd: image must be uint8 [h,w,3] or float32 [3,h,w]')
+    ptr = np.array([im.data_ptr() for im in keep], dtype=np.uint64)
+    h0 = np.array([im.shape[0] if f else im.shape[-2] for im, f in zip(keep, u8)], dtype=np.int32)
+    w0 = np.array([im.shape[1] if f else im.shape[-1] for im, f in zip(keep, u8)], dtype=np.int32)
+    rh = np.array([s[0] for s in sizes], dtype=np.int32)
+    rw = np.array([s[1] for s in sizes], dtype=np.int32)
+    Hp, Wp = out_nhwc4.shape[1] - 2, out_nhwc4.shape[2] - 2
+    _lib.call('sgg_image_prep_batch', ptr.ctypes.data, h0.ctypes.data, w0.ctypes.data, rh.ctypes.data, rw.ctypes.data,
+              u8.ctypes.data, n, _p(out_nhwc4, torch.float32), Hp, Wp, _stream())
+
+
 def conv1_1(x_nhwc4, w, bias, out):
     B, H, W = x_nhwc4.shape[0], x_nhwc4.shape[1] - 2, x_nhwc4.shape[2] - 2
     _lib.call('sgg_conv1_1', _p(x_nhwc4, torch.float32), _p(w, torch.float32), _p(bias, torch.float32), _p(out),
@@ -313,21 +335,23 @@ def imp_sliced_ok(csr, H, dtype):
     return g[1] <= 64 and g[2] <= cap
 
 
-def imp_sliced(v, e, csr, node_dots, edge_dots, gate_b, e_in=None, ctx2=None):
+def imp_sliced(v, e, csr, node_dots, edge_dots, gate_b, e_in=None, ctx2=None, ctx_sum=None):
     """One launch per IMP iteration, every edge row read once: -> (e_in [E,H], ctx2 [2,N,H]).  node_dots f32[N,4] /
-    edge_dots f32[E,4] come from gru_gate(dot_w=...)."""
+    edge_dots f32[E,4] come from gru_gate(dot_w=...).  ctx_sum (optional [N,H] output): the kernel stores ctx_out + ctx_in there
+    instead of the two halves (-> (e_in, ctx_sum))."""
     N, H = v.shape
     E = e.shape[0]
     out_ptr, out_ids, in_ptr, in_ids, so, flags = csr
     B, max_nodes, max_edges = csr.graphs
     if e_in is None:
         e_in = torch.empty_like(e)
-    if ctx2 is None:
+    if ctx_sum is None and ctx2 is None:
         ctx2 = torch.empty((2, N, H), dtype=v.dtype, device=v.device)
+    dst = ctx_sum if ctx_sum is not None else ctx2
     _lib.call('sgg_imp_sliced_fwd', _p(v), _p(e), _p(so), _p(out_ptr), _p(in_ptr), _p(in_ids), _p(csr.img_ptr), B, N, E, H,
-              _p(node_dots, torch.float32), _p(edge_dots, torch.float32), _p(gate_b, torch.float32), _p(e_in), _p(ctx2),
-              max_edges, max_nodes, dt(v), _stream())
-    return e_in, ctx2
+              _p(node_dots, torch.float32), _p(edge_dots, torch.float32), _p(gate_b, torch.float32), _p(e_in), _p(dst),
+              max_edges, max_nodes, 1 if ctx_sum is not None else 0, dt(v), _stream())
+    return e_in, dst
 
 
 def gru_gate(gi, gh, b_hh, h_prev, out_dtype, out=None, dot_w=None, dots=None):
@@ -401,10 +425,30 @@ def act_bwd(dy, y, scale=1.0):
     return dx
 
 
-def colsum(x):
+class ZeroPool(object):
+    """One zero-filled f32 workspace, carved into slices: the accumulate-with-atomics kernels (column sums = bias gradients) then
+    need one fill launch per backward pass instead of one memset per call."""
+
+    def __init__(self, nfloats, device):
+        self.buf = torch.zeros(nfloats, dtype=torch.float32, device=device)
+        self.used = 0
+
+    def take(self, n):
+        n_al = (n + 3) // 4 * 4                       # 16-byte aligned slices
+        if self.used + n_al > self.buf.numel():
+            return None
+        out = self.buf[self.used:self.used + n]
+        self.used += n_al
+        return out
+
+
+def colsum(x, pool=None):
     M, N = x.shape
-    out = torch.empty(N, dtype=torch.float32, device=x.device)
-    _lib.call('sgg_colsum', _p(x, rows_ok=True), M, N, x.stride(0), _p(out), dt(x), _stream())
+    out = pool.take(N) if pool is not None else None
+    zero = 0 if out is not None else 1
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=x.device)
+    _lib.call('sgg_colsum', _p(x, rows_ok=True), M, N, x.stride(0), _p(out), zero, dt(x), _stream())
     return out
 
 

@@ -46,13 +46,13 @@ def _pad_cols(x, mult, dtype):
 USE_TN = True      # tests flip this to cross-check the TN kernel against the transposes + NT path at benchmark grid sizes
 
 
-def tn_gemm(X, Y, out=None, want_colsum=False, out_dtype=torch.float32):
+def tn_gemm(X, Y, out=None, want_colsum=False, out_dtype=torch.float32, pool=None):
     """X[M,a]^T . Y[M,b] -> f32 [a,b]  (weight gradients).  Rows are zero-padded to a multiple of 64 by the transposes.
     want_colsum: also return colsum(X) (the bias gradient when X = dY), computed inside X's transpose pass."""
     if out is None and USE_TN and ops.gemm_tn_ok(X, Y):
         # bf16, aligned shapes: the TN kernel reads dY and X as they lie (no transposed copies); bias gradient = colsum(dY)
         dw = ops.gemm_tn(X, Y, out_dtype=out_dtype)
-        return (dw, ops.colsum(X)) if want_colsum else dw
+        return (dw, ops.colsum(X, pool)) if want_colsum else dw
     if want_colsum:
         xt, cs = ops.transpose(X, want_colsum=True)
         return ops.gemm(xt, ops.transpose(Y), out_dtype=out_dtype, out=out), cs
@@ -159,8 +159,13 @@ class PredictFn(torch.autograd.Function):
         # row-stacked inputs / states of the 4 calls of each GRU cell
         XN = torch.empty((4 * N, H), dtype=dt, device=dev)
         XE = torch.empty((4 * E, H), dtype=dt, device=dev)
-        HN = torch.empty((4 * N, H), dtype=dt, device=dev)     # block c = vert_c (hidden state entering call c+1)
-        HE = torch.empty((4 * E, H), dtype=dt, device=dev)
+        # block c = vert_c / edge_c (hidden state entering call c+1); one zero block in front makes the states ENTERING calls 0..3
+        # -- the X operand of the hidden-weight gradients -- a view of the same buffer (HNz[:4N]) instead of a concatenated copy
+        HNz = torch.empty((5 * N, H), dtype=dt, device=dev)
+        HEz = torch.empty((5 * E, H), dtype=dt, device=dev)
+        HNz[:N].zero_()
+        HEz[:E].zero_()
+        HN, HE = HNz[N:], HEz[E:]
         ops.gemm(x7, w['obj_unary'], w['obj_unary_b'], out=XN[:N])
         # ---- edges: relu(edge_unary(roi_fmap(edge_feat + conv(rects))))  (Linear ReLU Dropout Linear)
         _lib.set_tag('fc6_edge')
@@ -186,15 +191,15 @@ class PredictFn(torch.autograd.Function):
         for i in range(model.mp_iter):
             v_i, e_i = HN[i * N:(i + 1) * N], HE[i * E:(i + 1) * E]
             more = sliced and i + 1 < model.mp_iter
+            ctx_i = XN[(i + 1) * N:(i + 2) * N]                                # ctx = ctx_out + ctx_in (kept for d W_ih)
             if sliced:
                 dots = nd                                                       # saved for the backward
-                _, ctx2 = ops.imp_sliced(v_i, e_i, csr, nd, ed, imp.gate_b, e_in=XE[(i + 1) * E:(i + 2) * E])
+                ops.imp_sliced(v_i, e_i, csr, nd, ed, imp.gate_b, e_in=XE[(i + 1) * E:(i + 2) * E], ctx_sum=ctx_i)
             else:
                 dots = ops.imp_node_gate_dots(v_i, imp.gate_w)                  # saved for the backward
                 _, ctx2 = ops.imp_fused(v_i, e_i, rel_inds, csr, imp.gate_w_c, imp.gate_b, e_in=XE[(i + 1) * E:(i + 2) * E])
-            ctx_i = XN[(i + 1) * N:(i + 2) * N]                                # ctx = ctx_out + ctx_in (kept for d W_ih)
-            ctx_i.copy_(ctx2[0])
-            ops.add_(ctx_i, ctx2[1])
+                ctx_i.copy_(ctx2[0])
+                ops.add_(ctx_i, ctx2[1])
             a, b, ed = _gru_fwd(XE[(i + 1) * E:(i + 2) * E], e_i, imp.edge_gru_w_ih, imp.edge_gru_w_hh, imp.edge_gru_b_ih,
                                 imp.edge_gru_b_hh, dt, HE[(i + 1) * E:(i + 2) * E], we if more else None)
             gie.append(a); ghe.append(b)
@@ -207,7 +212,7 @@ class PredictFn(torch.autograd.Function):
         _lib.set_tag('heads')
         obj = ops.gemm(vT, w['obj_fc'], w['obj_fc_b'], out_dtype=torch.float32)
         rel = ops.gemm(eT, w['rel_fc'], w['rel_fc_b'], out_dtype=torch.float32)
-        sv.update(XN=XN, XE=XE, HN=HN, HE=HE, gin=gin, ghn=ghn, gie=gie, ghe=ghe, dots=dots_l, csr=csr, nf=nf, ef=ef,
+        sv.update(XN=XN, XE=XE, HN=HN, HE=HE, HNz=HNz, HEz=HEz, gin=gin, ghn=ghn, gie=gie, ghe=ghe, dots=dots_l, csr=csr, nf=nf, ef=ef,
                   rel_inds=rel_inds, N=N, E=E, H=H, dropout_p=dropout_p)
         _lib.set_tag('')
         ctx.model, ctx.sv = model, sv
@@ -222,6 +227,7 @@ class PredictFn(torch.autograd.Function):
         XN, XE, HN, HE = sv['XN'], sv['XE'], sv['HN'], sv['HE']
         dev = XN.device
         G = {}
+        pool = ops.ZeroPool(32768, dev)     # zeroed once: every bias-gradient column sum of this pass accumulates into a slice of it
         rows = lambda buf, c, n: buf[c * n:(c + 1) * n]
         # Data-parallel hooks (set by the trainer): a big gradient is handed over the moment it exists so that its
         # all-reduce overlaps the rest of the backward; with a bf16 wire the GEMM emits the wire dtype directly.
@@ -255,9 +261,9 @@ class PredictFn(torch.autograd.Function):
                     dYp = _pad_cols(dY, 128, dt)
                     if USE_TN and ops.gemm_tn_ok(dYp, X):
                         G[name + '.weight'] = ops.gemm_tn(dYp, X)[:n_out].contiguous()
-                        G[name + '.bias'] = ops.colsum(dYp)[:n_out].contiguous()
+                        G[name + '.bias'] = ops.colsum(dYp, pool)[:n_out].contiguous()
                         return
-                G[name + '.weight'], G[name + '.bias'] = tn_gemm(dY, X, want_colsum=True,
+                G[name + '.weight'], G[name + '.bias'] = tn_gemm(dY, X, want_colsum=True, pool=pool,
                                                                  out_dtype=big_dtype() if big else torch.float32)
                 if big:
                     hook(name + '.weight')
@@ -333,19 +339,18 @@ class PredictFn(torch.autograd.Function):
         hook('roi_fmap.1.0.weight')
         del x6t, d6t
         _lib.set_tag('bwd_mlp_obj')
-        G['roi_fmap_obj.0.weight'], G['roi_fmap_obj.0.bias'] = tn_gemm(d_p6, sv['nf'], want_colsum=True, out_dtype=big_dtype())
+        G['roi_fmap_obj.0.weight'], G['roi_fmap_obj.0.bias'] = tn_gemm(d_p6, sv['nf'], want_colsum=True, pool=pool, out_dtype=big_dtype())
         hook('roi_fmap_obj.0.weight')
         # ---- phase C: everything deferred, largest first (fc7 x2 carry their own hooks)
         for dw in deferred[::-1]:                      # fc7 node, unary node, fc7 edge, unary edge, heads
             dw()
         _lib.set_tag('bwd_imp')
         # GRU parameter gradients: one contraction over the 4 stacked calls; hidden state of call 0 is zero
-        HprevN = torch.cat((torch.zeros_like(HN[:N]), HN[:3 * N]), 0)
-        HprevE = torch.cat((torch.zeros_like(HE[:E]), HE[:3 * E]), 0)
-        G['edge_gru.weight_ih'], G['edge_gru.bias_ih'] = tn_gemm(dGIe, XE, want_colsum=True)
-        G['edge_gru.weight_hh'], G['edge_gru.bias_hh'] = tn_gemm(dGHe, HprevE, want_colsum=True)
-        G['node_gru.weight_ih'], G['node_gru.bias_ih'] = tn_gemm(dGIn, XN, want_colsum=True)
-        G['node_gru.weight_hh'], G['node_gru.bias_hh'] = tn_gemm(dGHn, HprevN, want_colsum=True)
+        HprevN, HprevE = sv['HNz'][:4 * N], sv['HEz'][:4 * E]
+        G['edge_gru.weight_ih'], G['edge_gru.bias_ih'] = tn_gemm(dGIe, XE, want_colsum=True, pool=pool)
+        G['edge_gru.weight_hh'], G['edge_gru.bias_hh'] = tn_gemm(dGHe, HprevE, want_colsum=True, pool=pool)
+        G['node_gru.weight_ih'], G['node_gru.bias_ih'] = tn_gemm(dGIn, XN, want_colsum=True, pool=pool)
+        G['node_gru.weight_hh'], G['node_gru.bias_hh'] = tn_gemm(dGHn, HprevN, want_colsum=True, pool=pool)
         ops.rank4_reduce_(da_all, HE[:T * E], d_gw, col0=H)         # e_i = rows i of HE, v_i = rows i of HN
         ops.rank4_reduce_(nsum_all, HN[:T * N], d_gw, col0=0)
         ops.rank4_reduce_(da_all, ones, d_gb)
@@ -358,7 +363,7 @@ class PredictFn(torch.autograd.Function):
         bn_sync = getattr(model, '_bn_sync', None)
         d_c2, db2, dg2 = ops.bn_bwd(d_rect, None, sv['h3'], sv['m2'], sv['is2'], t['rc_g2'], False, bn_sync)
         G['union_boxes.conv.6.weight'], G['union_boxes.conv.6.bias'] = dg2.clone(), db2.clone()
-        gw2, gb2 = tn_gemm(d_c2, sv['h2'], want_colsum=True)                       # [d, d2] centre tap
+        gw2, gb2 = tn_gemm(d_c2, sv['h2'], want_colsum=True, pool=pool)                       # [d, d2] centre tap
         full = torch.zeros(tuple(model.union_boxes.conv[4].weight.shape), dtype=torch.float32, device=dev)
         full[:, :, 1, 1] = gw2
         G['union_boxes.conv.4.weight'] = full
@@ -366,7 +371,7 @@ class PredictFn(torch.autograd.Function):
         d_h2 = ops.gemm(d_c2, t['rc_w2_t'])                                        # [E,d2]
         d_c1, db1, dg1 = ops.bn_bwd(d_h2, sv['arg'], sv['h1'], sv['m1'], sv['is1'], t['rc_g1'], True, bn_sync)
         G['union_boxes.conv.2.weight'], G['union_boxes.conv.2.bias'] = dg1.clone(), db1.clone()
-        gw1, gb1 = tn_gemm(d_c1, sv['patches'], want_colsum=True)                  # [d2,128]
+        gw1, gb1 = tn_gemm(d_c1, sv['patches'], want_colsum=True, pool=pool)                  # [d2,128]
         G['union_boxes.conv.0.weight'] = gw1[:, :98].reshape(tuple(model.union_boxes.conv[0].weight.shape)).contiguous()
         G['union_boxes.conv.0.bias'] = gb1
         _lib.set_tag('')
