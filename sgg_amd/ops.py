@@ -20,7 +20,14 @@ def dt(t):
         raise TypeError('sgg_amd: unsupported dtype %s (float32 / bfloat16 only)' % (t,))
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    """Raw handle of torch's current HIP stream on the current device.  The C accessor costs ~0.3 us; going through
+    torch.cuda.current_stream() builds a Stream object per call (~8 us x 60-450 calls per forward / train step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -19,7 +19,7 @@ import pickle
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, ops
 
 MAX_RECALL_K = 300                                   # lib/sgg_eval.py:12
 MODES = ('sgdet', 'sgcls', 'predcls')                # config.py:28
@@ -113,7 +113,7 @@ def match_cases(cases, iou_thresh=0.5, phrdet=False, want_pair_rank=False):
     p = lambda t: t.data_ptr() if t is not None and t.numel() else None
     _lib.call('sgg_recall_first_match', p(gt_trip), p(gt_box), p(gt_img), G, p(pred_trip), p(pred_box), pred_ptr.data_ptr(),
               len(cases), p(gt_pair), p(pred_pair) if want_pair_rank else None, float(iou_thresh), int(bool(phrdet)),
-              first.data_ptr(), p(pair_rank), torch.cuda.current_stream().cuda_stream)
+              first.data_ptr(), p(pair_rank), ops._stream())
     first = first.cpu().numpy().astype(np.int64)
     pr = pair_rank.cpu().numpy().astype(np.int64) if want_pair_rank else None
     out, off = [], 0

@@ -39,7 +39,7 @@ def _sort_desc(keys, seg_off, nseg, seg_len_hint=0):
     vals_tmp = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     vals_out = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     nbytes = ctypes.c_size_t(0)
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = ops._stream()
     _lib.call('sgg_segmented_sort_desc', None, None, None, None, n, nseg, None, seg_len_hint, None, ctypes.byref(nbytes), stream)
     temp = torch.empty(max(int(nbytes.value), 8), dtype=torch.uint8, device=dev)
     _lib.call('sgg_segmented_sort_desc', keys.data_ptr(), keys_out.data_ptr(), vals_tmp.data_ptr(), vals_out.data_ptr(), n,
@@ -55,7 +55,7 @@ def _nms(boxes, labels, valid, thresh, max_keep):
     keep_cnt = torch.empty(B, dtype=torch.int32, device=dev)
     _lib.call('sgg_nms', boxes.data_ptr(), labels.data_ptr() if labels is not None else None, valid.data_ptr(), B, n,
               float(thresh), max_keep, ws.data_ptr(), keep_idx.data_ptr(), keep_cnt.data_ptr(),
-              torch.cuda.current_stream().cuda_stream)
+              ops._stream())
     return keep_idx, keep_cnt
 
 
@@ -95,7 +95,7 @@ def detect(model, fmap, image_sizes, padded_hw, orig_sizes, spatial_scale):
     dt = model.compute_dtype
     dev = fmap.device
     B, Hf, Wf, Cf = fmap.shape
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = ops._stream()
     A, C = w['A'], w['C']
     img_hw = torch.tensor([[float(s[0]), float(s[1])] for s in image_sizes], dtype=torch.float32, device=dev)
     # ---- RPN head: 3x3 conv + ReLU, then the two 1x1 convs as one GEMM over pixels

@@ -47,7 +47,7 @@ class FusedSGD(torch.optim.Optimizer):
         """grads (optional): {param: tensor} overriding p.grad -- e.g. the bf16 buffers an all-reduce left behind, consumed
         directly (fp32 or bf16) instead of being copied back into fp32 .grad tensors."""
         import numpy as np
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = ops._stream()
         dev = next(self.params()).device
         if self._norm is None:
             self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
