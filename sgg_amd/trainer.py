@@ -136,6 +136,18 @@ class Trainer(object):
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         # force_dist: run the distributed code path on a 1-rank group too (tests exercise RCCL plumbing on one GPU)
         self.dist_on = self.world > 1 or (force_dist and dist.is_available() and dist.is_initialized())
+        self._local = {}          # one GPU: wire-dtype gradients of the big tensors, kept out of autograd for the optimiser
+        self._local_wire = comm_dtype if comm_dtype == torch.bfloat16 else None
+        if not self.dist_on and self._local_wire is not None:
+            by_name_l = dict(named)
+
+            def keep(name, grad):     # same hand-over as the data-parallel hook, without a collective: with bf16 compute the
+                p = by_name_l.get(name)   # weight-gradient GEMMs of fc6 / fc7 emit bf16 (fp32 accumulate, one rounding) and the
+                if p is not None and self.buckets.is_big(p):   # optimiser reads that -- 1-GPU and N-GPU steps see the same numbers,
+                    self._local[p] = grad                      # and 0.8 GB less is written and re-read per step
+                    return True
+                return False
+            self._keep = keep         # installed on the model only for the duration of step()'s backward
         if self.dist_on:
             by_name = dict(named)
 
@@ -236,7 +248,7 @@ class Trainer(object):
             for p in self.opt.params():                    # gradients were allocated on the main stream: keep their memory
                 if p.grad is not None:                     # from being recycled there while the side stream reads it
                     p.grad.record_stream(side)
-            reduced = self.buckets.all_reduce(average=False) if self.dist_on else None
+            reduced = self.buckets.all_reduce(average=False) if self.dist_on else dict(self._local)
             for t in (reduced or {}).values():
                 t.record_stream(side)
             self.opt.step(grads=reduced)
@@ -250,13 +262,22 @@ class Trainer(object):
         self.model.train()
         if not self._queued:
             self._prefetch_operands()
+        local = not self.dist_on and getattr(self, '_keep', None) is not None and self.model.compute_dtype == torch.bfloat16
+        if not self.dist_on:
+            self._local = {}
         res = self.model([batch])
         loss = self.losses(res)
         self.opt.zero_grad()
-        loss.backward()
+        if local:
+            self.model._grad_ready_hook, self.model._grad_wire_dtype = self._keep, self._local_wire
+        try:
+            loss.backward()
+        finally:
+            if local:
+                self.model._grad_ready_hook = self.model._grad_wire_dtype = None
         self._queued = self.pipeline and self._queue_update()
         if not self._queued:
-            reduced = self.buckets.all_reduce(average=False) if self.dist_on else None
+            reduced = self.buckets.all_reduce(average=False) if self.dist_on else dict(self._local)
             self.opt.step(grads=reduced)
         self.model.global_batch_iter = getattr(self.model, 'global_batch_iter', 0) + 1
         return loss.detach()
