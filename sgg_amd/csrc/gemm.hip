@@ -273,46 +273,62 @@ __global__ __launch_bounds__(256) void mfma_tile_tn_kernel(const GemmArgs g) {
         }
         __builtin_amdgcn_s_barrier();
         const unsigned sa = lds0 + buf * STAGE + wr * HALF, sb = lds0 + buf * STAGE + 2 * HALF + wc * HALF;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            // k-step s = stage rows 16s..16s+15 (s is a compile-time constant after unrolling: the offsets fold)
-            unsigned long long a_lo[2], a_hi[2], b_lo[2], b_hi[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int row = 16 * s + 2 * (2 * kg + h) + rsel;
-                    const int col = i * 32 + g16 * 16 + 4 * (p & 3);
-                    const unsigned off = row * ROWB + ((((col >> 3) ^ ((row >> 1) & 7)) << 4) | (((col >> 2) & 1) << 3));
-                    // outputs go STRAIGHT into the registers that the s_waitcnt below is tied to: no intermediate copy that
-                    // could be scheduled (and read stale data) before the wait
-                    if (h == 0) {
-                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a_lo[i]) : "v"(sa + off) : "memory");
-                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b_lo[i]) : "v"(sb + off) : "memory");
-                    } else {
-                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a_hi[i]) : "v"(sa + off) : "memory");
-                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b_hi[i]) : "v"(sb + off) : "memory");
-                    }
-                }
-            }
-            // the waitcnt TAKES the eight results as in/out operands: the compiler only sees register outputs of the asm reads
-            // and would otherwise be free to schedule a copy of them in front of this wait (it did, once two workgroups
-            // shared a CU and the copies were no longer coalesced away: garbage in, NaN out)
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(a_lo[0]), "+v"(a_lo[1]), "+v"(a_hi[0]), "+v"(a_hi[1]), "+v"(b_lo[0]), "+v"(b_lo[1]), "+v"(b_hi[0]),
-                           "+v"(b_hi[1])
-                         :
-                         : "memory");
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const u32x4 av = {(unsigned)a_lo[mi], (unsigned)(a_lo[mi] >> 32), (unsigned)a_hi[mi], (unsigned)(a_hi[mi] >> 32)};
-                    const u32x4 bv = {(unsigned)b_lo[ni], (unsigned)(b_lo[ni] >> 32), (unsigned)b_hi[ni], (unsigned)(b_hi[ni] >> 32)};
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bv), __builtin_bit_cast(bf16x8_t, av),
-                                                                         acc[mi][ni], 0, 0, 0);
-                }
-        }
+        // The four k-steps are software-pipelined inside the wave: the transposing reads of step s+1 are issued BEFORE the MFMAs of
+        // step s and waited for after them (two register sets), so LDS latency runs under the wave's own matrix work.
+        unsigned long long a_lo[2][2], a_hi[2][2], b_lo[2][2], b_hi[2][2];      // [set][i]
+#define SGG_TN_READ(SET, S)                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                          \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                                      \
+            const int row = 16 * (S) + 2 * (2 * kg + h) + rsel;                                                               \
+            const int col = i * 32 + g16 * 16 + 4 * (p & 3);                                                                  \
+            const unsigned off = row * ROWB + ((((col >> 3) ^ ((row >> 1) & 7)) << 4) | (((col >> 2) & 1) << 3));             \
+            if (h == 0) {                                                                                                     \
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a_lo[SET][i]) : "v"(sa + off) : "memory");                    \
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b_lo[SET][i]) : "v"(sb + off) : "memory");                    \
+            } else {                                                                                                          \
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a_hi[SET][i]) : "v"(sa + off) : "memory");                    \
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b_hi[SET][i]) : "v"(sb + off) : "memory");                    \
+            }                                                                                                                 \
+        }                                                                                                                     \
+    }
+        // the waitcnt TAKES the eight results of a set as in/out operands: the compiler only sees register outputs of the asm reads
+        // and would otherwise be free to schedule a use of them in front of this wait (it did, once two workgroups shared a CU)
+#define SGG_TN_WAIT(SET)                                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                       \
+                 : "+v"(a_lo[SET][0]), "+v"(a_lo[SET][1]), "+v"(a_hi[SET][0]), "+v"(a_hi[SET][1]), "+v"(b_lo[SET][0]),        \
+                   "+v"(b_lo[SET][1]), "+v"(b_hi[SET][0]), "+v"(b_hi[SET][1])                                                 \
+                 :                                                                                                            \
+                 : "memory");
+#define SGG_TN_MFMA(SET)                                                                                                      \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                      \
+        const u32x4 av = {(unsigned)a_lo[SET][mi], (unsigned)(a_lo[SET][mi] >> 32), (unsigned)a_hi[SET][mi],                  \
+                          (unsigned)(a_hi[SET][mi] >> 32)};                                                                   \
+        const u32x4 bv = {(unsigned)b_lo[SET][ni], (unsigned)(b_lo[SET][ni] >> 32), (unsigned)b_hi[SET][ni],                  \
+                          (unsigned)(b_hi[SET][ni] >> 32)};                                                                   \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bv), __builtin_bit_cast(bf16x8_t, av), \
+                                                             acc[mi][ni], 0, 0, 0);                                          \
+    }
+        SGG_TN_READ(0, 0)
+        SGG_TN_WAIT(0)
+        SGG_TN_READ(1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        SGG_TN_MFMA(0)
+        __builtin_amdgcn_sched_barrier(0);
+        SGG_TN_WAIT(1)
+        SGG_TN_READ(0, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        SGG_TN_MFMA(1)
+        __builtin_amdgcn_sched_barrier(0);
+        SGG_TN_WAIT(0)
+        SGG_TN_READ(1, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        SGG_TN_MFMA(0)
+        __builtin_amdgcn_sched_barrier(0);
+        SGG_TN_WAIT(1)
+        SGG_TN_MFMA(1)
+#undef SGG_TN_READ
+#undef SGG_TN_WAIT
+#undef SGG_TN_MFMA
         __builtin_amdgcn_s_barrier();
     }
 
