@@ -1,5 +1,6 @@
 """A short run of the randomised parity sweep (tools/fuzz_kernels.py): random ragged graphs through both IMP step kernels, random
-GEMM / TN-GEMM shapes, against dense torch fp32.  The long form is `python tools/fuzz_kernels.py 120` (614 + 617 + 617 cases pass)."""
+GEMM / TN-GEMM shapes, 3x3 convs (+ fused pool), RoIAlign incl. degenerate boxes, both rasters, pair indexing -- against dense torch
+fp32 / the oracle.  The long form is `python tools/fuzz_kernels.py 120` (~280 cases of each per 100 s, all passing in round 1)."""
 import os
 import sys
 
@@ -14,5 +15,5 @@ def test_fuzz_sweep_short():
         pytest.skip('no GPU')
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
     import fuzz_kernels
-    out = fuzz_kernels.run(budget=8.0, seed=12345)
-    assert min(out.values()) >= 5, out
+    out = fuzz_kernels.run(budget=10.0, seed=12345)
+    assert min(out.values()) >= 3, out

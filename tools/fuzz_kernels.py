@@ -9,7 +9,7 @@ from sgg_amd import ops
 dev = 'cuda:0'
 cu = lambda t: (torch.from_numpy(np.ascontiguousarray(t)) if isinstance(t, np.ndarray) else t.contiguous()).to(dev)
 rng = np.random.RandomState(0)
-stats = {'imp': 0, 'gemm': 0, 'tn': 0}
+stats = {'imp': 0, 'gemm': 0, 'tn': 0, 'conv': 0, 'roi': 0, 'raster': 0, 'pairs': 0}
 
 
 def fuzz_imp():
@@ -90,6 +90,98 @@ def fuzz_tn():
     stats['tn'] += 1
 
 
+def fuzz_conv():
+    """3x3 conv + ReLU (+ fused 2x2 max-pool): spatial LDS-patch kernel (maps >= 64) and implicit GEMM (small maps)"""
+    dtype = torch.bfloat16 if rng.rand() < 0.7 else torch.float32
+    B = int(rng.randint(1, 3))
+    H, W = int(rng.randint(6, 90)), int(rng.randint(6, 90))
+    if rng.rand() < 0.4:
+        H, W = H & ~1, W & ~1
+    Cin, Cout = int(rng.choice([64, 128])), int(rng.choice([64, 128, 256]))
+    g = torch.Generator().manual_seed(int(rng.randint(1 << 30)))
+    x = torch.randn(B, Cin, H, W, generator=g).to(dtype)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(dtype)
+    b = torch.randn(Cout, generator=g)
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), b, padding=1).relu()
+    xp = torch.zeros(B, H + 2, W + 2, Cin, dtype=dtype)
+    xp[:, 1:-1, 1:-1] = x.permute(0, 2, 3, 1)
+    tol = 2e-4 if dtype == torch.float32 else 4e-2
+    out = torch.zeros((B, H + 2, W + 2, Cout), dtype=dtype, device=dev)
+    ops.conv3x3_relu(cu(xp), cu(w.permute(0, 2, 3, 1)), cu(b), out, 1)
+    torch.testing.assert_close(out[:, 1:-1, 1:-1].float().cpu().permute(0, 3, 1, 2), ref, atol=tol, rtol=tol,
+                               msg=lambda m: 'conv B=%d %dx%d %d->%d %s: %s' % (B, H, W, Cin, Cout, dtype, m))
+    if H % 2 == 0 and W % 2 == 0 and ops.conv_pool_fusable(H, W, Cout):
+        got = torch.zeros((B, H // 2 + 2, W // 2 + 2, Cout), dtype=dtype, device=dev)
+        ops.conv3x3_relu(cu(xp), cu(w.permute(0, 2, 3, 1)), cu(b), got, 1, pool=True)
+        refp = torch.nn.functional.max_pool2d(out[:, 1:-1, 1:-1].float().permute(0, 3, 1, 2), 2)
+        torch.testing.assert_close(got[:, 1:-1, 1:-1].float().permute(0, 3, 1, 2), refp, atol=0, rtol=0)
+    stats['conv'] += 1
+
+
+def rand_boxes(n, S):
+    xy = rng.uniform(0, 0.7 * S, size=(n, 2))
+    wh = rng.uniform(1, 0.5 * S, size=(n, 2))
+    bx = np.concatenate((xy, np.minimum(xy + wh, S - 1)), 1).astype(np.float32)
+    if n > 2 and rng.rand() < 0.3:
+        bx[0, 2:] = bx[0, :2]                       # degenerate box
+        bx[1] = [0, 0, S - 1, S - 1]                # whole image
+    return bx
+
+
+def fuzz_roi():
+    dtype = torch.bfloat16 if rng.rand() < 0.5 else torch.float32
+    B, C = int(rng.randint(1, 4)), int(rng.choice([64, 128]))
+    Hf, Wf = int(rng.randint(5, 40)), int(rng.randint(5, 40))
+    N = int(rng.randint(2, 14))
+    fm = torch.from_numpy(rng.randn(B, C, Hf, Wf).astype(np.float32)).to(dtype)
+    boxes = rand_boxes(N, 16 * min(Hf, Wf))
+    im = np.sort(rng.randint(0, B, N)).astype(np.float32)
+    rois = np.concatenate((im[:, None], boxes), 1)
+    pairs = np.array([(i, j) for i in range(N) for j in range(N) if i != j and im[i] == im[j]], np.int64).reshape(-1, 2)
+    exp_n, exp_e = O.node_edge_features(fm.float().numpy(), rois, pairs if len(pairs) else np.zeros((0, 2), np.int64))
+    fmd = cu(fm.permute(0, 2, 3, 1).contiguous())
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    got = ops.roi_align(fmd, cu(rois))
+    np.testing.assert_allclose(got.float().cpu().numpy().reshape(exp_n.shape), exp_n, atol=tol, rtol=tol)
+    if len(pairs):
+        gote = ops.roi_align(fmd, cu(rois), cu(pairs))
+        np.testing.assert_allclose(gote.float().cpu().numpy().reshape(exp_e.shape), exp_e, atol=tol, rtol=tol)
+    stats['roi'] += 1
+
+
+def fuzz_raster():
+    N = int(rng.randint(2, 12))
+    B = int(rng.randint(1, 3))
+    S = float(rng.choice([100, 592, 1024]))
+    boxes = rand_boxes(N, S)
+    boxes[:, 2:] = np.maximum(boxes[:, 2:], boxes[:, :2] + 1)     # positive extent (a zero extent divides by zero in both)
+    im = np.sort(rng.randint(0, B, N)).astype(np.float32)
+    rois = np.concatenate((im[:, None], boxes), 1).astype(np.float32)
+    pairs = np.array([(i, j) for i in range(N) for j in range(N) if i != j and im[i] == im[j]], np.int64).reshape(-1, 2)
+    if not len(pairs):
+        return
+    pr = np.concatenate((rois[pairs[:, 0], 1:], rois[pairs[:, 1], 1:]), 1)
+    np.testing.assert_array_equal(ops.union_rects(cu(rois), cu(pairs), 27, 0.0).cpu().numpy(), O.draw_union_boxes(pr, 27))
+    sizes = [(int(S) + 10 * b, int(S) + 7) for b in range(B)]
+    np.testing.assert_allclose(ops.union_rects(cu(rois), cu(pairs), 27, 0.0, im_sizes=sizes).cpu().numpy(),
+                               O.draw_union_boxes_grid(rois, pairs, sizes, 27), atol=2e-5)
+    stats['raster'] += 1
+
+
+def fuzz_pairs():
+    B = int(rng.randint(1, 6))
+    sizes = [int(rng.randint(1, 12)) for _ in range(B)]
+    im = np.concatenate([np.full(n, b) for b, n in enumerate(sizes)]).astype(np.int64)
+    boxes = rand_boxes(len(im), 200)
+    for ov in (False, True):
+        exp = O.get_rel_inds_eval(im, boxes, ov)
+        out, cnt = ops.pair_index_eval(cu(im), cu(boxes) if ov else None, ov)
+        n = int(cnt.item())
+        if len(exp) and not (exp.shape == (1, 3) and n == 0):
+            np.testing.assert_array_equal(out[:n].cpu().numpy(), exp)
+    stats['pairs'] += 1
+
+
 def run(budget=60.0, seed=0):
     global rng
     rng = np.random.RandomState(seed)
@@ -100,6 +192,10 @@ def run(budget=60.0, seed=0):
         fuzz_imp()
         fuzz_gemm()
         fuzz_tn()
+        fuzz_conv()
+        fuzz_roi()
+        fuzz_raster()
+        fuzz_pairs()
     torch.cuda.synchronize()
     return dict(stats)
 
