@@ -466,6 +466,19 @@ __global__ __launch_bounds__(SL_THREADS) void imp_sliced_kernel(const T* __restr
     const int e0 = img_ptr[B + 1 + g], e1 = img_ptr[B + 2 + g], Ee = e1 - e0;
     const int i0 = e0;                           // edges are grouped by graph: the in-lists of earlier graphs hold e0 entries
     const long col = (long)slice * (PIECE / (int)sizeof(T)) + sub * CHL;        // this lane's first channel
+    if (Ee > EMAX || Nn > SL_NMAX) {
+        // the host's promise about this graph (edge_csr(graphs=...)) does not hold: nothing may be parked.  Poison the graph's
+        // outputs instead of corrupting LDS -- NaNs surface in the first loss / score that reads them.
+        float nanv[CHL];
+#pragma unroll
+        for (int j = 0; j < CHL; ++j) nanv[j] = __builtin_nanf("");
+        for (int k = grp; k < Ee; k += GROUPS) Piece16<T>::store(e_in + (long)(e0 + k) * H + col, nanv);
+        for (int k = grp; k < Nn; k += GROUPS) {
+            Piece16<T>::store(ctx2 + (long)(n0 + k) * H + col, nanv);
+            if (!sum_ctx) Piece16<T>::store(ctx2 + ((long)N + n0 + k) * H + col, nanv);
+        }
+        return;
+    }
     // the four gates of an edge are spread over the lanes of a quad: lane q makes gate q (LP >= 4), or gates q&1, (q&1)+2 (LP = 2)
     constexpr int GI = LP >= 4 ? 1 : 2;
     int gk[GI];

@@ -587,6 +587,12 @@ def test_imp_sliced_capacity_and_fallback(ops):
     torch.testing.assert_close(a[0], b[0], atol=2e-5, rtol=1e-5)
     torch.testing.assert_close(a[1], b[1], atol=2e-5, rtol=1e-5)
     assert all(torch.isfinite(t).all() for t in got)
+    # a hint that understates a graph (here: 132 edges promised as 40) must not corrupt anything silently: that graph's outputs are NaN
+    lie = ops.edge_csr(cu(rel), N, cu(im), graphs=(2, 12, 40))
+    nd, ed = cu(torch.zeros(N, 4)), cu(torch.zeros(E, 4))
+    e_in, ctx2 = ops.imp_sliced(v, e, lie, nd, ed, cu(torch.zeros(4)))
+    big = rel[:, 0] == 0                                  # graph 0 has 12 nodes / 132 edges, graph 1 has 9 / 72
+    assert torch.isnan(e_in[torch.from_numpy(big).to(DEV)]).all() and torch.isnan(ctx2[:, :12]).all()
 
 
 # ----------------------------------------------------------------------------------------- eval tail
