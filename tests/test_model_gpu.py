@@ -231,3 +231,18 @@ def test_forward_raw_boxes_edge_model_matches_oracle():
     l0 = float(tr.step(batch))
     l1 = float(tr.step(batch))
     assert np.isfinite(l0) and np.isfinite(l1)
+
+
+def test_get_scaled_boxes_matches_reference_formula(setup):
+    """rel_model_base.py:262-274 (the GAN / feature-extraction callers, main.py:137): per-image division by (w, h) and the <= 1 check"""
+    model, batch, ref, _ = setup
+    boxes = torch.tensor([[10., 20., 80., 90.], [0., 0., 159., 99.], [5., 5., 50., 60.]], device=DEV)
+    im_inds = torch.tensor([0, 0, 1], device=DEV)
+    im_sizes = [(100, 160), (80, 60)]                    # (h, w)
+    got = model.get_scaled_boxes(boxes, im_inds, im_sizes).cpu().numpy()
+    want = boxes.cpu().numpy().copy()
+    want[:2, [0, 2]] /= 160; want[:2, [1, 3]] /= 100
+    want[2, [0, 2]] /= 60; want[2, [1, 3]] /= 80
+    np.testing.assert_allclose(got, want, rtol=1e-6)
+    with pytest.raises(AssertionError):
+        model.get_scaled_boxes(boxes * 3, im_inds, im_sizes)
