@@ -93,6 +93,11 @@ int sgg_edge_csr(const int64_t* rel_inds /*[E,3]*/, int E, int N, const int64_t*
 int sgg_roi_align_fwd(const void* fmap, int B, int H, int W, int C, const float* rois, int Nroi, const int64_t* pairs,
                       int R, float spatial_scale, int P, int sampling, const float* add_ec, void* out, int dtype,
                       void* stream);
+/* Backward of the call above into the feature map (needed where fmap requires grad: the GAN feature-augmentation path,
+ * main.py:141): d_fmap f32[B,H,W,C] += RoIAlign^T(d_out[R,C,P,P]) -- float atomics, the caller zeroes d_fmap (or
+ * accumulates the node and the union-box call into one map).  Same rois / pairs / scale arguments as the forward. */
+int sgg_roi_align_bwd(const void* d_out, int B, int H, int W, int C, const float* rois, int Nroi, const int64_t* pairs, int R,
+                      float spatial_scale, int P, int sampling, float* d_fmap, int dtype, void* stream);
 
 /* ---- a-5  union-mask raster ----
  * raster 0 (edge_model 'motifs', the default): draw_union_boxes, lib/draw_rectangles/draw_rectangles.pyx:12-67 -- coverage of

@@ -476,6 +476,112 @@ __global__ __launch_bounds__(512, 4) void roi_align_kernel(const T* __restrict__
 
 }  // namespace
 
+namespace {
+// ------------------------------------------------------------------------------------------------
+// RoIAlign backward into the feature map (the GAN / feature-augmentation callers, where fmap requires grad: main.py:141; SURVEY
+// 8b lists it as `sgg_roi_align_bwd`).  Exact adjoint of roi_align_kernel: every (bin, sample, tap) of the forward adds
+// weight / S^2 * d_out[r, c, ph, pw] to d_fmap[b, y, x, c].  One workgroup per RoI, a lane owns 8 channels; float atomics on the
+// fp32 NHWC gradient map (RoIs of one image overlap).  d_out is the forward's layout [R, C, P, P] (T); d_fmap f32 [B,H,W,C].
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_bwd_kernel(const T* __restrict__ d_out, int B, int H, int W, int C,
+                                                            const float* __restrict__ rois, const int64_t* __restrict__ pairs, int R,
+                                                            float scale, int P, int S, float* __restrict__ d_fmap) {
+    __shared__ int s_lo[2][MAXS], s_hi[2][MAXS];
+    __shared__ float s_l[2][MAXS], s_h[2][MAXS];
+    __shared__ int s_b;
+    const int r = blockIdx.x, tid = threadIdx.x, PS = P * S;
+    if (tid < 2 * PS) {                       // the forward's sample table, verbatim
+        const int axis = tid / PS, k = tid - axis * PS;
+        float lo_c, hi_c, bi;
+        if (pairs) {
+            const float* a = rois + pairs[2 * (long)r] * 5;
+            const float* b = rois + pairs[2 * (long)r + 1] * 5;
+            bi = a[0];
+            lo_c = fminf(a[2 - axis], b[2 - axis]);
+            hi_c = fmaxf(a[4 - axis], b[4 - axis]);
+        } else {
+            const float* a = rois + (long)r * 5;
+            bi = a[0];
+            lo_c = a[2 - axis];
+            hi_c = a[4 - axis];
+        }
+        const int L = axis == 0 ? H : W;
+        const float start = lo_c * scale, end = hi_c * scale;
+        const float len = fmaxf(end - start, 1.0f);
+        const float bin = len / (float)P;
+        const int p = k / S, i = k - p * S;
+        float c = start + (float)p * bin + ((float)i + 0.5f) * bin / (float)S;
+        const bool valid = !(c < -1.0f || c > (float)L);
+        c = c <= 0.f ? 0.f : c;
+        int lo = (int)c, hi;
+        if (lo >= L - 1) {
+            hi = lo = L - 1;
+            c = (float)lo;
+        } else {
+            hi = lo + 1;
+        }
+        const float l = c - (float)lo;
+        s_lo[axis][k] = valid ? lo : 0;
+        s_hi[axis][k] = valid ? hi : 0;
+        s_l[axis][k] = l;
+        s_h[axis][k] = valid ? 1.f - l : -1.f;
+        if (tid == 0) s_b = min(max((int)bi, 0), B - 1);
+    }
+    __syncthreads();
+    float* gm = d_fmap + (long)s_b * H * W * C;
+    const float inv = 1.0f / (float)(S * S);
+    const int PP = P * P;
+    for (int c0 = tid * 8; c0 < C; c0 += 256 * 8) {
+        for (int bin = 0; bin < PP; ++bin) {
+            const int ph = bin / P, pw = bin - ph * P;
+            float g[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] = Elem<T>::ld(d_out + ((long)r * C + c0 + k) * PP + bin) * inv;
+            for (int iy = 0; iy < S; ++iy) {
+                const int ky = ph * S + iy;
+                const float hy = s_h[0][ky], ly = s_l[0][ky];
+                if (hy < 0.f) continue;
+                for (int ix = 0; ix < S; ++ix) {
+                    const int kx = pw * S + ix;
+                    const float hx = s_h[1][kx], lx = s_l[1][kx];
+                    if (hx < 0.f) continue;
+                    float* t00 = gm + ((long)s_lo[0][ky] * W + s_lo[1][kx]) * C + c0;
+                    float* t01 = gm + ((long)s_lo[0][ky] * W + s_hi[1][kx]) * C + c0;
+                    float* t10 = gm + ((long)s_hi[0][ky] * W + s_lo[1][kx]) * C + c0;
+                    float* t11 = gm + ((long)s_hi[0][ky] * W + s_hi[1][kx]) * C + c0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        atomicAdd(t00 + k, hy * hx * g[k]);
+                        atomicAdd(t01 + k, hy * lx * g[k]);
+                        atomicAdd(t10 + k, ly * hx * g[k]);
+                        atomicAdd(t11 + k, ly * lx * g[k]);
+                    }
+                }
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int sgg_roi_align_bwd(const void* d_out, int B, int H, int W, int C, const float* rois, int Nroi, const int64_t* pairs,
+                                 int R, float spatial_scale, int P, int sampling, float* d_fmap, int dtype, void* stream) {
+    if (R == 0) return SGG_OK;
+    if (!d_out || !rois || !d_fmap || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || R < 0 || P <= 0 || sampling <= 0 ||
+        P * sampling > MAXS || Nroi <= 0)
+        return SGG_ERR_ARG;
+    if (dtype == SGG_BF16)
+        hipLaunchKernelGGL(roi_align_bwd_kernel<bf16_t>, dim3(R), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)d_out, B, H, W, C, rois,
+                           pairs, R, spatial_scale, P, sampling, d_fmap);
+    else if (dtype == SGG_F32)
+        hipLaunchKernelGGL(roi_align_bwd_kernel<float>, dim3(R), dim3(256), 0, (hipStream_t)stream, (const float*)d_out, B, H, W, C, rois,
+                           pairs, R, spatial_scale, P, sampling, d_fmap);
+    else
+        return SGG_ERR_DTYPE;
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
 extern "C" int sgg_image_prep(const float* img, int h, int w, int rh, int rw, float* out, int b, int Hp, int Wp,
                               void* stream) {
     if (!img || !out || h <= 0 || w <= 0 || rh <= 0 || rw <= 0 || rh > Hp || rw > Wp || b < 0) return SGG_ERR_ARG;

@@ -185,6 +185,18 @@ def roi_align(fmap_nhwc, rois, pairs=None, spatial_scale=1.0 / 16, P=7, sampling
     return out
 
 
+def roi_align_bwd(d_out, fmap_shape, rois, pairs=None, spatial_scale=1.0 / 16, sampling=2, d_fmap=None):
+    """d_out [R,C,P,P] -> d_fmap f32 [B,H,W,C] (+= when given): the adjoint of roi_align (GAN path: fmap requires grad)."""
+    B, H, W, C = fmap_shape
+    R, P = d_out.shape[0], d_out.shape[-1]
+    if d_fmap is None:
+        d_fmap = torch.zeros((B, H, W, C), dtype=torch.float32, device=d_out.device)
+    _lib.call('sgg_roi_align_bwd', _p(d_out), B, H, W, C, _p(rois, torch.float32), rois.shape[0],
+              _p(pairs, torch.int64) if pairs is not None else None, R, float(spatial_scale), P, sampling, _p(d_fmap, torch.float32),
+              dt(d_out), _stream())
+    return d_fmap
+
+
 # ---------------------------------------------------------------- a-5 / a-6
 def _im_wh(im_sizes, device):
     """[(h, w), ...] per image (the transform's image_sizes) -> f32[B,2] = (w, h) on the device, for the 'raw_boxes' raster"""

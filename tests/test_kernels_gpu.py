@@ -327,6 +327,39 @@ def test_rect_feat_pipeline_vs_reference_golden(ops, golden, tag):
     np.testing.assert_allclose(rf.cpu().numpy(), g[tag + '_rect_feat'], atol=2e-5)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_roi_align_bwd_is_the_adjoint_of_the_forward(ops, dtype):
+    """sgg_roi_align_bwd: <g, RoIAlign(f)> == <RoIAlign^T(g), f> for random f, g (node boxes and fused union boxes, incl. boxes that
+    leave the map and a degenerate one) -- the forward itself is checked against the oracle in test_roi_align; plus a finite-
+    difference probe of single feature-map entries."""
+    rng = np.random.RandomState(9)
+    B, C, H, W, N = 2, 64, 20, 24, 9
+    f = torch.from_numpy(rng.randn(B, H, W, C).astype(np.float32))
+    xy = rng.uniform(0, 250, size=(N, 2))
+    boxes = np.concatenate((xy, xy + rng.uniform(12, 180, size=(N, 2))), 1).astype(np.float32)    # some stick out of the 384 x 320 image
+    boxes[0] = [50, 50, 50, 50]
+    im = np.sort(rng.randint(0, B, N)).astype(np.float32)
+    rois = np.concatenate((im[:, None], boxes), 1)
+    pairs = np.array([(i, j) for i in range(N) for j in range(N) if i != j and im[i] == im[j]], np.int64)
+    fd = cu(f)
+    for pr in (None, cu(pairs)):
+        y = ops.roi_align(fd, cu(rois), pr).float()
+        g = torch.from_numpy(rng.randn(*y.shape).astype(np.float32)).to(dtype)
+        gf = ops.roi_align_bwd(cu(g), (B, H, W, C), cu(rois), pr)
+        lhs = float((y.double().cpu() * g.double()).sum())
+        rhs = float((gf.double().cpu() * f.double()).sum())
+        assert abs(lhs - rhs) <= 2e-4 * (abs(lhs) + float((y.abs().double().cpu() * g.abs().double()).sum()) * 1e-3 + 1), (lhs, rhs)
+        # d <g, y> / d f[b,y,x,c] by central differences (RoIAlign is linear in f: the difference quotient is exact up to rounding)
+        for _ in range(3):
+            b_, y_, x_, c_ = int(rng.randint(B)), int(rng.randint(H)), int(rng.randint(W)), int(rng.randint(C))
+            fp = f.clone(); fp[b_, y_, x_, c_] += 1.0
+            yp = ops.roi_align(cu(fp), cu(rois), pr).float()
+            fdq = float(((yp - y).double().cpu() * g.double()).sum())
+            assert abs(fdq - float(gf[b_, y_, x_, c_])) <= 1e-3 * (1 + abs(fdq)), (fdq, float(gf[b_, y_, x_, c_]))
+    acc = ops.roi_align_bwd(cu(g), (B, H, W, C), cu(rois), cu(pairs), d_fmap=gf.clone())      # accumulates into a given map
+    torch.testing.assert_close(acc, 2 * gf, rtol=1e-5, atol=1e-5)
+
+
 def test_raw_boxes_raster_and_rect_feat_vs_reference_golden(ops, golden):
     """edge_model 'raw_boxes' (lib/get_union_boxes.py:69-116): the grid_sample raster, the patches the conv stack reads from it,
     and the module's eval forward, against vectors from the reference module."""
