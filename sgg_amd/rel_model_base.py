@@ -74,6 +74,29 @@ def to_rows(x, dtype):
     return x.view(R, -1)
 
 
+class _RoIFeatures(torch.autograd.Function):
+    """node + union-box RoIAlign as one differentiable op in `fmap` (callers that keep the feature map in the graph: the GAN
+    feature-augmentation path, main.py:141-149).  The hot path's fmap is detached (rel_model_stanford.py:131) and never gets here."""
+
+    @staticmethod
+    def forward(ctx, fmap, rois, union_inds, scale, P, dtype):
+        fm = to_nhwc(fmap.detach(), dtype)
+        node = ops.roi_align(fm, rois, None, scale, P, 2)
+        edge = ops.roi_align(fm, rois, union_inds, scale, P, 2)
+        ctx.save_for_backward(rois, union_inds)
+        ctx.meta = (tuple(fm.shape), scale, fmap.dtype)
+        return node, edge
+
+    @staticmethod
+    def backward(ctx, d_node, d_edge):
+        rois, union_inds = ctx.saved_tensors
+        shape, scale, in_dtype = ctx.meta
+        prep = lambda g: g.contiguous() if g.dtype in (torch.float32, torch.bfloat16) else g.float().contiguous()
+        d_fm = ops.roi_align_bwd(prep(d_node), shape, rois, None, scale)
+        ops.roi_align_bwd(prep(d_edge), shape, rois, union_inds, scale, d_fmap=d_fm)
+        return d_fm.permute(0, 3, 1, 2).to(in_dtype), None, None, None, None, None
+
+
 class RelModelBase(nn.Module):
     """RELATIONSHIPS (sgg_models/rel_model_base.py:22-123)."""
 
@@ -243,6 +266,8 @@ class RelModelBase(nn.Module):
         self.fmap_hw = (fm.shape[1], fm.shape[2])
         scale = self.spatial_scale(im_sizes) if im_sizes is not None else 1.0 / self.stride
         rois = rois.float().contiguous()
+        if fmap.requires_grad and torch.is_grad_enabled():
+            return _RoIFeatures.apply(fmap, rois, union_inds.contiguous(), scale, self.pool_sz, dtype)
         node = ops.roi_align(fm, rois, None, scale, self.pool_sz, 2)
         edge = ops.roi_align(fm, rois, union_inds.contiguous(), scale, self.pool_sz, 2)
         return node, edge

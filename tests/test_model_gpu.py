@@ -246,3 +246,31 @@ def test_get_scaled_boxes_matches_reference_formula(setup):
     np.testing.assert_allclose(got, want, rtol=1e-6)
     with pytest.raises(AssertionError):
         model.get_scaled_boxes(boxes * 3, im_inds, im_sizes)
+
+
+def test_node_edge_features_differentiable_in_fmap(setup):
+    """main.py:141-149 (GAN path): node_edge_features on a feature map that requires grad -- the gradient equals the adjoint applied to
+    the upstream gradients, and it flows on through predict()'s autograd node in training mode."""
+    model, batch, ref, _ = setup
+    from sgg_amd import ops
+    model.set_compute_dtype(torch.float32)
+    g = torch.Generator().manual_seed(2)
+    B, C, Hf = 2, 512, 10
+    fmap = torch.randn(B, C, Hf, Hf, generator=g).to(DEV).requires_grad_(True)
+    rois = torch.tensor([[0, 8., 8., 100., 90.], [0, 30., 20., 150., 140.], [1, 0., 0., 159., 159.], [1, 40., 60., 90., 120.]], device=DEV)
+    ui = torch.tensor([[0, 1], [1, 0], [2, 3], [3, 2]], device=DEV)
+    node, edge = model.node_edge_features(fmap, rois, ui, [(160, 160), (160, 160)])
+    assert node.requires_grad and edge.requires_grad
+    gn, ge = torch.randn(node.shape, generator=g).to(DEV), torch.randn(edge.shape, generator=g).to(DEV)
+    (node * gn).sum().backward(retain_graph=True)
+    d1 = fmap.grad.clone()
+    fmap.grad = None
+    ((node * gn).sum() + (edge * ge).sum()).backward()
+    shape = (B, Hf, Hf, C)
+    want = ops.roi_align_bwd(gn.contiguous(), shape, rois, None, 1.0 / 16)
+    torch.testing.assert_close(d1, want.permute(0, 3, 1, 2), rtol=1e-5, atol=1e-5)
+    ops.roi_align_bwd(ge.contiguous(), shape, rois, ui, 1.0 / 16, d_fmap=want)
+    torch.testing.assert_close(fmap.grad, want.permute(0, 3, 1, 2), rtol=1e-5, atol=1e-5)
+    with torch.no_grad():                                       # no graph requested: plain kernels, same numbers
+        n2, e2 = model.node_edge_features(fmap, rois, ui, [(160, 160), (160, 160)])
+    assert not n2.requires_grad and torch.equal(n2, node.detach()) and torch.equal(e2, edge.detach())
