@@ -70,7 +70,7 @@ def to_rows(x, dtype):
         x = x.float()
     x = x.contiguous()                      # no-op for the tensors RoIAlign produced
     if x.dtype != dtype:
-        x = ops.cast(x, dtype)
+        x = x.to(dtype) if (x.requires_grad and torch.is_grad_enabled()) else ops.cast(x, dtype)   # keep a caller's graph intact
     return x.view(R, -1)
 
 

@@ -379,7 +379,14 @@ class PredictFn(torch.autograd.Function):
         shapes = dict(model.head_named_parameters())
         # gradients already handed to the all-reduce in the wire dtype are not returned to autograd (no fp32 copy)
         grads = [None if n in handed else G[n].reshape(shapes[n].shape) for n in param_names(model)]
-        return (None,) * 8 + tuple(grads)
+        # gradients into the RoI features, only where a caller keeps them in the graph (GAN feature augmentation, main.py:145-149:
+        # predict() on generated features): dX of the two fc6 layers, [rows, 4096] . W6 -> [rows, C*P*P] in the reference's (c,ph,pw) order
+        d_nf = d_ef = None
+        if ctx.needs_input_grad[1]:
+            d_nf = ops.gemm(d_p6, ops.transpose(w['fc6_obj']), out_dtype=torch.float32)
+        if ctx.needs_input_grad[2]:
+            d_ef = ops.gemm(d_pre6, ops.transpose(w['fc6_edge']), out_dtype=torch.float32)
+        return (None, d_nf, d_ef) + (None,) * 5 + tuple(grads)
 
 
 def predict_train(model, node_feat, edge_feat, rel_inds, rois, im_inds=None, seed=None, dropout_p=DROPOUT_P, graphs=None,

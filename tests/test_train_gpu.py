@@ -515,3 +515,32 @@ def test_full_size_bf16_gradients_close_to_fp32_mode():
     assert worst[0][0] > 0.95, worst[:5]          # measured 0.977 (rect-conv tensors) .. 0.9999
     del model, tr
     torch.cuda.empty_cache()
+
+
+def test_predict_gradients_into_roi_features_match_oracle_autograd(env):
+    """main.py:145-149 (GAN path): predict() on RoI features that require grad -- d loss / d node_feat, d edge_feat against torch
+    autograd of the oracle (fp32, dropout off)."""
+    model, sd, batch = env
+    model.set_compute_dtype(torch.float32)
+    model.train()
+    model.dropout_p = 0.0
+    model.load_state_dict(sd)
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        res0 = model([tuple(batch)])
+    nf = res0.node_feat.detach().float().clone().requires_grad_(True)
+    ef = res0.edge_feat.detach().float().clone().requires_grad_(True)
+    od, rd = model.predict(nf, ef, res0.rel_inds, rois=res0.rois, im_sizes=res0.im_sizes, _im_inds=res0.im_inds.contiguous())
+    Wo, Wr = torch.randn(od.shape, generator=g), torch.randn(rd.shape, generator=g)
+    ((od * Wo.to(DEV)).sum() + (rd * Wr.to(DEV)).sum()).backward()
+    assert nf.grad is not None and ef.grad is not None and nf.grad.shape == nf.shape and ef.grad.shape == ef.shape
+    p = {k: v.clone() for k, v in sd.items()}
+    nfc, efc = nf.detach().cpu().requires_grad_(True), ef.detach().cpu().requires_grad_(True)
+    odc, rdc = O.predict(nfc, efc, res0.rel_inds.cpu().numpy(), res0.rois.cpu().numpy(), p, training=True)
+    ((odc * Wo).sum() + (rdc * Wr).sum()).backward()
+    for got, ref, name in ((nf.grad.cpu(), nfc.grad, 'node_feat'), (ef.grad.cpu(), efc.grad, 'edge_feat')):
+        scale = float(ref.abs().max()) + 1e-9
+        assert float((got - ref).abs().max()) / scale < 2e-3, (name, float((got - ref).abs().max()), scale)
+    model.zero_grad()
+    model.eval()
+    model.dropout_p = 0.5
