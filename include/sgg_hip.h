@@ -76,6 +76,15 @@ int sgg_pair_index_eval(const int64_t* im_inds, const float* boxes /*[N,4] or NU
                         int64_t* rel_inds, int cap, int* count, int* work, void* stream);
 int sgg_pair_index_train(const int64_t* im_inds, int N, const int64_t* gt_rels, int R, const int* img_first,
                          int64_t* rel_labels, int cap, int* count, int* work, void* stream);
+/* sgdet training: the tables lib/rel_assignments.py:60-76 builds per image, for the whole batch in one launch (the
+ * sampling that follows draws from numpy's RandomState in the reference and stays on the host, in that order).
+ * det_boxes f32[N,4], det_img i64[N], det_labels i64[N]; gt_boxes f32[G,4], gt_classes i64[G,2]=(img,cls).
+ * gt_iou f32[N,G]: box_iou(det, gt) in torchvision's fp32 operation order, -1 where the images differ;
+ * match u8[N,G] = same image & same class & IoU >= fg_thresh (:61); poss u8[N,N] = same image, both labels != 0 and
+ * 0 < IoU < 1 (filter_non_overlap, :66) or i != j (:69-71). */
+int sgg_rel_assign_tables(const float* det_boxes, const int64_t* det_img, const int64_t* det_labels, int N,
+                          const float* gt_boxes, const int64_t* gt_classes, int G, float fg_thresh,
+                          int filter_non_overlap, float* gt_iou, uint8_t* match, uint8_t* poss, void* stream);
 /* CSR lists of the edges by subject node (out_ptr/out_ids) and by object node (in_ptr/in_ids); edges keep ascending
  * order inside a node.  ptr i32[N+1], ids i32[E].  im_inds (optional, i64[N] node->image): when given, rel_inds must be
  * sorted by image (as both pair-index calls emit it) and only the node's own image segment is scanned.

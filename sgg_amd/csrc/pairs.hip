@@ -197,6 +197,48 @@ __global__ __launch_bounds__(64) void csr_kernel(const int64_t* __restrict__ rel
 
 __global__ void set_flag_kernel(int* flags) { flags[0] = 1; }
 
+// lib/rel_assignments.py:60-76, the tables the sampler reads: one thread per (detection, column); columns [0,G) are the
+// GT boxes (IoU + class/IoU match), columns [G,G+N) the other detections (relation candidates).  fp32 with torchvision
+// box_iou's operation order (the sampling probabilities are products of these IoUs, so they have to be the same bits).
+__device__ __forceinline__ float iou_f32(const float* a, const float* b) {
+    const float area_a = __fmul_rn(__fsub_rn(a[2], a[0]), __fsub_rn(a[3], a[1]));
+    const float area_b = __fmul_rn(__fsub_rn(b[2], b[0]), __fsub_rn(b[3], b[1]));
+    const float w = fmaxf(__fsub_rn(fminf(a[2], b[2]), fmaxf(a[0], b[0])), 0.f);
+    const float h = fmaxf(__fsub_rn(fminf(a[3], b[3]), fmaxf(a[1], b[1])), 0.f);
+    const float inter = __fmul_rn(w, h);
+    return __fdiv_rn(inter, __fsub_rn(__fadd_rn(area_a, area_b), inter));
+}
+
+__global__ __launch_bounds__(256) void rel_tables_kernel(const float* __restrict__ det, const int64_t* __restrict__ det_img,
+                                                         const int64_t* __restrict__ det_lab, const float* __restrict__ gt,
+                                                         const int64_t* __restrict__ gt_cls, int N, int G, float thr, int nonov,
+                                                         float* __restrict__ gt_iou, unsigned char* __restrict__ match,
+                                                         unsigned char* __restrict__ poss) {
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cols = G + N;
+    if (id >= (long)N * cols) return;
+    const int i = (int)(id / cols), c = (int)(id - (long)i * cols);
+    const int64_t img = det_img[i];
+    if (c < G) {
+        const bool same = gt_cls[2 * c] == img;
+        const float v = same ? iou_f32(det + 4 * i, gt + 4 * c) : -1.f;
+        gt_iou[(long)i * G + c] = v;
+        match[(long)i * G + c] = same && det_lab[i] == gt_cls[2 * c + 1] && v >= thr;          // :61
+    } else {
+        const int j = c - G;
+        bool ok = det_img[j] == img && det_lab[i] != 0 && det_lab[j] != 0;                      // :75-76
+        if (ok) {
+            if (nonov) {
+                const float v = iou_f32(det + 4 * i, det + 4 * j);
+                ok = v < 1.f && v > 0.f;                                                        // :66
+            } else {
+                ok = i != j;                                                                    // :69-71
+            }
+        }
+        poss[(long)i * N + j] = ok;
+    }
+}
+
 }  // namespace
 
 extern "C" int sgg_pair_index_eval(const int64_t* im_inds, const float* boxes, int N, int require_overlap,
@@ -237,6 +279,19 @@ extern "C" int sgg_edge_csr(const int64_t* rel_inds, int E, int N, const int64_t
     hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, s, out_ptr, N, (int*)nullptr);
     hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, s, in_ptr, N, (int*)nullptr);
     hipLaunchKernelGGL(csr_kernel<true>, dim3(2 * N), dim3(64), 0, s, rel_inds, E, N, im_inds, out_ptr, in_ptr, out_ids, in_ids, so, flags);
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_rel_assign_tables(const float* det_boxes, const int64_t* det_img, const int64_t* det_labels, int N,
+                                     const float* gt_boxes, const int64_t* gt_classes, int G, float fg_thresh,
+                                     int filter_non_overlap, float* gt_iou, uint8_t* match, uint8_t* poss, void* stream) {
+    if (N == 0) return SGG_OK;
+    if (!det_boxes || !det_img || !det_labels || !poss || N < 0 || G < 0 || (G > 0 && (!gt_boxes || !gt_classes || !gt_iou || !match)))
+        return SGG_ERR_ARG;
+    const long total = (long)N * (G + N);
+    hipLaunchKernelGGL(rel_tables_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, det_boxes, det_img,
+                       det_labels, gt_boxes, gt_classes, N, G, fg_thresh, filter_non_overlap, gt_iou, match, poss);
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

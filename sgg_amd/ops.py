@@ -141,6 +141,19 @@ def pair_index_train(im_inds, gt_rels, img_first, cap):
     return out, count
 
 
+def rel_assign_tables(det_boxes, det_img, det_labels, gt_boxes, gt_classes, fg_thresh=0.5, filter_non_overlap=True):
+    """lib/rel_assignments.py:60-76 for the whole batch -> (gt_iou f32[N,G], match u8[N,G], poss u8[N,N]) on the device."""
+    N, G = det_boxes.shape[0], gt_boxes.shape[0]
+    dev = det_boxes.device
+    gt_iou = torch.empty((N, G), dtype=torch.float32, device=dev)
+    match = torch.empty((N, G), dtype=torch.uint8, device=dev)
+    poss = torch.empty((N, N), dtype=torch.uint8, device=dev)
+    _lib.call('sgg_rel_assign_tables', _p(det_boxes, torch.float32), _p(det_img, torch.int64), _p(det_labels, torch.int64), N,
+              _p(gt_boxes, torch.float32) if G else None, _p(gt_classes, torch.int64) if G else None, G, float(fg_thresh),
+              int(bool(filter_non_overlap)), _p(gt_iou) if G else None, _p(match) if G else None, _p(poss), _stream())
+    return gt_iou, match, poss
+
+
 class Csr(tuple):
     """(out_ptr, out_ids, in_ptr, in_ids, so, flags) + what the sliced IMP kernel needs: `img_ptr` i32[B+1] (first node of each
     graph) and `graphs` = (B, max_nodes, max_edges) known on the host; both None when the caller gave no hint."""

@@ -183,7 +183,7 @@ class RelModelBase(nn.Module):
         self.detector.roi_heads.score_thresh = box_score_thresh  # rel_model_base.py:168-172
 
     def faster_rcnn(self, x, gt_boxes, gt_classes, gt_rels):
-        """rel_model_base.py:175-242: gt-box branch (predcls / sgcls) and the detector branch (sgdet, eval only)."""
+        """rel_model_base.py:175-242: gt-box branch (predcls / sgcls) and the detector branch (sgdet)."""
         if self.mode == 'sgdet':
             return self._faster_rcnn_sgdet(x, gt_classes)
         dtype = self.compute_dtype
@@ -225,8 +225,9 @@ class RelModelBase(nn.Module):
     def _faster_rcnn_sgdet(self, x, gt_classes):
         """rel_model_base.py:209-235: RPN + RoI heads (sgg_amd/sgdet.py), <= 50 detections per image."""
         from . import sgdet
-        if self.training:
-            raise NotImplementedError('SGDet training is documented as unsupported by the reference (README.md:214-218)')
+        # The detector is frozen (main.py:62-63) and always runs as an inference detector here, also under model.train():
+        # torchvision's RoIHeads in training mode returns losses and no detections, which is why the reference documents
+        # SGDet training as unsupported (README.md:214-218).  rm_obj_labels are the detector's labels, as at :221,:228.
         dtype = self.compute_dtype
         if gt_classes is not None and gt_classes.numel() > 0:
             ids = sorted(set(int(v) for v in gt_classes[:, 0].detach().to('cpu').tolist()))

@@ -4,6 +4,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 from .imp import GATES, ImpWeights, message_pass, node_lane
+from .rel_assignments import rel_assignments
 from .rel_model_base import RelModelBase, to_device_with_mirror, to_rows
 
 
@@ -182,8 +183,12 @@ class RelModelStanford(RelModelBase):
             result.fmap = result.fmap.detach()                                           # :131
             im_inds, boxes = result.im_inds, result.rm_box_priors
             if self.training and not hasattr(result, 'rel_labels'):
-                raise NotImplementedError('sgdet training (lib/rel_assignments.py) is documented as unsupported '
-                                          'by the reference (README.md:214-218)')
+                # :136-140.  (The reference tests `result.rel_labels is None` on a Result that has already dropped its None
+                # fields, lib/pytorch_misc.py:696-700; the intent -- sample relation labels for the detections -- is kept.)
+                assert self.mode == 'sgdet'
+                result.rel_labels = rel_assignments(im_inds.data, boxes.data, result.rm_obj_labels.data, gt_boxes.data,
+                                                    gt_classes.data, gt_rels.data, 0, filter_non_overlap=True,
+                                                    num_sample_per_gt=1)
             elif not hasattr(result, 'rel_labels'):
                 result.rel_labels = None
             rel_inds = self.get_rel_inds(result.rel_labels if self.training else None, im_inds, boxes,

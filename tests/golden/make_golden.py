@@ -12,6 +12,7 @@ reference's source text is stored -- only data.  What is called, per file:
   message_pass.npz sgg_models/rel_model_stanford.py:48        RelModelStanford.message_pass
   predict.npz      sgg_models/rel_model_stanford.py:97        RelModelStanford.predict
   pairs.npz        sgg_models/rel_model_base.py:143 get_rel_inds ; lib/proposal_assignments_gtbox.py:7
+  rel_assign.npz   lib/rel_assignments.py:12 rel_assignments (sgdet training), numpy global RNG seeded per case
   eval_tail.npz    lib/surgery.py:17 filter_dets + the softmax/sort lines rel_model_stanford.py:187-204
   losses.npz       lib/losses.py:5,73
   recall.npz       lib/sgg_eval.py:14 BasicSceneGraphEvaluator (GC / no-GC / per-triplet, all modes), :420 mean recall, :481 eval_entry
@@ -283,6 +284,66 @@ def gold_pairs():
                      tag + '_train_rel_inds': m.get_rel_inds(rl, tim, tb)})
         m.eval()
     save('pairs', **arrs)
+
+
+def gold_rel_assign():
+    """lib/rel_assignments.py:12 on jittered / relabelled / background detections around seeded GT graphs.  The function ends with
+    `.cuda(rpn_rois.get_device())` (:135): Tensor.cuda is made the identity for the duration of the call (no device here)."""
+    from lib.rel_assignments import rel_assignments
+    rng = np.random.RandomState(77)
+    arrs, cases = {}, []
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for tag, sizes, ndet in (('b1', (6,), (14,)), ('b3', (5, 9, 3), (20, 40, 2)), ('b2dense', (12, 12), (50, 50)), ('b2none', (4, 4), (6, 5))):
+            gt_im = np.concatenate([np.full(n, i, np.int64) for i, n in enumerate(sizes)])
+            gt_boxes = rand_boxes(rng, len(gt_im), wmin=40, wmax=220)
+            gt_cls = rng.randint(1, 151, size=len(gt_im))
+            gt_classes = np.stack((gt_im, gt_cls), 1).astype(np.int64)
+            rels, first = [], np.concatenate(([0], np.cumsum(sizes)))
+            for i, n in enumerate(sizes):
+                seen = set()
+                while len(seen) < min(2 * n, n * (n - 1)):
+                    a, b = rng.randint(n), rng.randint(n)
+                    if a != b:                                   # duplicates with different predicates are allowed (VG has them)
+                        seen.add((a, b, rng.randint(1, 51)))
+                rels += [(i, a, b, p) for a, b, p in sorted(seen)]
+            gt_rels = np.array(rels, dtype=np.int64)
+            det_im, det_boxes, det_lab = [], [], []
+            for i, (n, nd) in enumerate(zip(sizes, ndet)):
+                for _ in range(nd):
+                    g = first[i] + rng.randint(n)
+                    kind = rng.rand()
+                    if tag == 'b2none':                         # nothing matches: wrong labels everywhere
+                        box, lab = gt_boxes[g] + rng.uniform(-4, 4, 4), (gt_cls[g] % 150) + 1
+                    elif kind < 0.55:                           # a good detection of a GT box
+                        box, lab = gt_boxes[g] + rng.uniform(-8, 8, 4), gt_cls[g]
+                    elif kind < 0.65:                           # the GT box itself (IoU exactly 1 with it)
+                        box, lab = gt_boxes[g].copy(), gt_cls[g]
+                    elif kind < 0.8:                            # right place, wrong label
+                        box, lab = gt_boxes[g] + rng.uniform(-8, 8, 4), rng.randint(1, 151)
+                    elif kind < 0.9:                            # background label
+                        box, lab = gt_boxes[g] + rng.uniform(-30, 30, 4), 0
+                    else:                                       # somewhere else
+                        box, lab = rand_boxes(rng, 1)[0], rng.randint(1, 151)
+                    box = np.clip(box, 0, 591).astype(np.float32)
+                    box[2:] = np.maximum(box[2:], box[:2] + 2)
+                    det_im.append(i); det_boxes.append(box); det_lab.append(lab)
+            det_im = np.array(det_im, np.int64); det_boxes = np.stack(det_boxes).astype(np.float32); det_lab = np.array(det_lab, np.int64)
+            arrs.update({tag + '_im_inds': det_im, tag + '_boxes': det_boxes, tag + '_labels': det_lab, tag + '_gt_boxes': gt_boxes,
+                         tag + '_gt_classes': gt_classes, tag + '_gt_rels': gt_rels})
+            for k, (per_gt, nonov, seed) in enumerate(((1, True, 5), (4, True, 6), (1, False, 7), (4, False, 8), (1, True, 9))):
+                np.random.seed(seed)
+                out = rel_assignments(torch.from_numpy(det_im), torch.from_numpy(det_boxes), torch.from_numpy(det_lab),
+                                      torch.from_numpy(gt_boxes), torch.from_numpy(gt_classes), torch.from_numpy(gt_rels), 0,
+                                      filter_non_overlap=nonov, num_sample_per_gt=per_gt)
+                arrs['%s_out%d' % (tag, k)] = out
+                arrs['%s_cfg%d' % (tag, k)] = np.array([per_gt, int(nonov), seed], np.int64)
+            cases.append(tag)
+    finally:
+        torch.Tensor.cuda = real_cuda
+    arrs['cases'] = np.array(cases)
+    save('rel_assign', **arrs)
 
 
 def gold_eval_tail():
@@ -659,6 +720,7 @@ if __name__ == '__main__':
     gold_message_pass()
     gold_predict()
     gold_pairs()
+    gold_rel_assign()
     gold_eval_tail()
     gold_losses()
     gold_recall()

@@ -203,3 +203,18 @@ def test_raw_boxes_raster_and_feats(golden):
     p = {k[len('raw_w_'):]: torch.from_numpy(g[k]) for k in g.keys() if k.startswith('raw_w_')}
     out = O.union_boxes_and_feats(g['raw_pools'], g['raw_rois'], g['raw_union_inds'], p, edge_model='raw_boxes', im_sizes=ims)
     np.testing.assert_allclose(out.numpy(), g['raw_out'], atol=2e-5)
+
+
+def test_rel_assignments_oracle_equals_reference():
+    """lib/rel_assignments.py:12 (sgdet training): same numpy seed -> the same sampled rows, bit for bit, incl. the FG cap
+    (b2dense), images where nothing matches (b2none) and both filter_non_overlap settings."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'rel_assign.npz'))
+    for tag in g['cases']:
+        for k in range(5):
+            per_gt, nonov, seed = [int(v) for v in g['%s_cfg%d' % (tag, k)]]
+            np.random.seed(seed)
+            out = O.rel_assignments(g[tag + '_im_inds'], g[tag + '_boxes'], g[tag + '_labels'], g[tag + '_gt_boxes'],
+                                    g[tag + '_gt_classes'], g[tag + '_gt_rels'], 0, num_sample_per_gt=per_gt,
+                                    filter_non_overlap=bool(nonov))
+            np.testing.assert_array_equal(out, g['%s_out%d' % (tag, k)], err_msg='%s case %d' % (tag, k))

@@ -112,7 +112,41 @@ def test_sgdet_too_few_detections_raises_value_error(env):
         with torch.no_grad():
             model([batch])
     model.set_box_score_thresh(0.0)
+
+
+def test_sgdet_train_forward_samples_relations_like_the_reference_and_backpropagates(env):
+    """model.train() in sgdet mode (rel_model_stanford.py:136-140): relation labels sampled for the detections by
+    lib/rel_assignments.py (numpy-seeded, equal to the oracle's rows), logits on exactly those edges equal to the oracle's
+    train-mode predict, and gradients that match torch autograd of the oracle on the sampled (ragged, non-complete) graphs."""
+    model, sd, batch, ref, S = env
     model.train()
-    with pytest.raises(NotImplementedError):
-        model([batch])
-    model.eval()
+    model.dropout_p = 0.0
+    try:
+        np.random.seed(11)
+        res = model([batch])
+        det_lab = res.rm_obj_labels.cpu().numpy()
+        np.random.seed(11)
+        want = O.rel_assignments(res.im_inds.cpu().numpy(), res.rm_box_priors.cpu().numpy(), det_lab, batch[3].numpy(),
+                                 batch[4].numpy(), batch[5].numpy(), 0, filter_non_overlap=True, num_sample_per_gt=1)
+        np.testing.assert_array_equal(res.rel_labels.cpu().numpy(), want)
+        np.testing.assert_array_equal(res.rel_inds.cpu().numpy(), want[:, :3])
+        assert res.rel_dists.shape == (len(want), 51) and res.rm_obj_dists.shape == (len(det_lab), 151)
+        g = torch.Generator().manual_seed(0)
+        Wo, Wr = torch.randn(res.rm_obj_dists.shape, generator=g), torch.randn(res.rel_dists.shape, generator=g)
+        model.zero_grad()
+        ((res.rm_obj_dists * Wo.to(DEV)).sum() + (res.rel_dists * Wr.to(DEV)).sum()).backward()
+        from sgg_amd.train import param_names
+        pn = set(param_names(model))
+        p = {k: v.clone().requires_grad_(k in pn) for k, v in sd.items()}
+        od, rd = O.predict(res.node_feat.float().cpu().contiguous(), res.edge_feat.float().cpu().contiguous(), want[:, :3],
+                           res.rois.cpu().numpy(), p, training=True)
+        torch.testing.assert_close(res.rm_obj_dists.detach().cpu(), od.detach(), atol=1e-3, rtol=1e-3)
+        torch.testing.assert_close(res.rel_dists.detach().cpu(), rd.detach(), atol=1e-3, rtol=1e-3)
+        ((od * Wo).sum() + (rd * Wr).sum()).backward()
+        named = dict(model.named_parameters())
+        for n in param_names(model):
+            gref, got = p[n].grad, named[n].grad.cpu()
+            err = float((got - gref).abs().max()) / (float(gref.abs().max()) + 1e-6)
+            assert err < 2e-3, (n, err)
+    finally:
+        model.eval()
