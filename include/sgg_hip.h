@@ -338,6 +338,28 @@ int sgg_freq_bias_fwd(const void* obj_dists, int N, int C, const int64_t* gt_cla
                       int dtype, void* stream);
 int sgg_freq_bias_bwd(const float* d_out, const int32_t* row_idx, int E, int P, float* d_table, void* stream);
 
+/* ---- f-4 (next row, started)  GAN generator data movement: augment/layout.py, augment/graphconv.py ----
+ * boxes_to_layout (layout.py:33-71 with _boxes_to_grid :102-136 and _pool_samples :139-166), channels-last:
+ *   vecs [O,S,S,D] object patches (S = 0: [O,D] vectors, expanded to a constant 8x8 patch as at :57-58), boxes f32[O,4] in [0,1]
+ *   (x0,y0,x1,y1), obj_img i32[O] = image of each object, out [N,H,W,D] = per image the sum in ascending object order (avg = 1:
+ *   mean over the image's objects) of the bilinear (zeros padding, align_corners=False) resampling of every patch into its box.
+ *   bwd: d_vecs [O,S,S,D] (or [O,D]) from d_out [N,H,W,D]; counts i32[N] = objects per image (read only when avg = 1);
+ *   H, W <= 256. */
+int sgg_boxes_to_layout_fwd(const void* vecs, const float* boxes, const int* obj_img, int N, int O, int S, int D, int H, int W,
+                            int avg, void* out, int dtype, void* stream);
+int sgg_boxes_to_layout_bwd(const void* d_out, const float* boxes, const int* obj_img, const int* counts, int O, int S, int D,
+                            int H, int W, int avg, void* d_vecs, int dtype, void* stream);
+/* GraphTripleConv (graphconv.py:51-119): out[t] = [obj[s_t] | pred[t] | obj[o_t]] (:68-78), width 2*Din+De; edges i64[T,2]. */
+int sgg_triple_gather(const void* obj, const void* pred, const int64_t* edges, int T, int Din, int De, void* out, int dtype,
+                      void* stream);
+/* pooled[n] = sum of rows[t, 0:Hd] over triples with s_t = n + sum of rows[t, o_off:o_off+Hd] over triples with o_t = n, divided
+ * by the number of those triples when avg = 1 (clamped at 1) (:93-115); CSR lists as produced by sgg_edge_csr.
+ * bwd writes only the two Hd-wide column blocks of d_rows [T, ld]. */
+int sgg_triple_pool_fwd(const void* rows, int ld, int o_off, const int* out_ptr, const int* out_ids, const int* in_ptr,
+                        const int* in_ids, int O, int Hd, int avg, void* pooled, int dtype, void* stream);
+int sgg_triple_pool_bwd(const void* d_pooled, const int64_t* edges, const int* out_ptr, const int* in_ptr, int T, int Hd, int avg,
+                        int ld, int o_off, void* d_rows, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,11 @@ SIGNATURES = {
     'sgg_pair_index_eval': [_P, _P, _I, _I, _P, _I, _P, _P, _P],
     'sgg_pair_index_train': [_P, _I, _P, _I, _P, _P, _I, _P, _P, _P],
     'sgg_rel_assign_tables': [_P, _P, _P, _I, _P, _P, _I, _F, _I, _P, _P, _P, _P],
+    'sgg_boxes_to_layout_fwd': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    'sgg_boxes_to_layout_bwd': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    'sgg_triple_gather': [_P, _P, _P, _I, _I, _I, _P, _I, _P],
+    'sgg_triple_pool_fwd': [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P],
+    'sgg_triple_pool_bwd': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P],
     'sgg_edge_csr': [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],  # rel, E, N, im_inds, out_ptr, out_ids, in_ptr, in_ids, so, flags, stream
     'sgg_roi_align_fwd': [_P, _I, _I, _I, _I, _P, _I, _P, _I, _F, _I, _I, _P, _P, _I, _P],
     'sgg_roi_align_bwd': [_P, _I, _I, _I, _I, _P, _I, _P, _I, _F, _I, _I, _P, _I, _P],

@@ -12,6 +12,8 @@ reference's source text is stored -- only data.  What is called, per file:
   message_pass.npz sgg_models/rel_model_stanford.py:48        RelModelStanford.message_pass
   predict.npz      sgg_models/rel_model_stanford.py:97        RelModelStanford.predict
   pairs.npz        sgg_models/rel_model_base.py:143 get_rel_inds ; lib/proposal_assignments_gtbox.py:7
+  gan_ops.npz      augment/layout.py:33 boxes_to_layout (+ autograd gradient wrt the object features), augment/graphconv.py:17
+                   GraphTripleConv.forward (seeded weights) -- the gather / scatter steps of the GAN generator
   rel_assign.npz   lib/rel_assignments.py:12 rel_assignments (sgdet training), numpy global RNG seeded per case
   eval_tail.npz    lib/surgery.py:17 filter_dets + the softmax/sort lines rel_model_stanford.py:187-204
   losses.npz       lib/losses.py:5,73
@@ -344,6 +346,50 @@ def gold_rel_assign():
         torch.Tensor.cuda = real_cuda
     arrs['cases'] = np.array(cases)
     save('rel_assign', **arrs)
+
+
+def gold_gan_ops():
+    import warnings
+    from augment.graphconv import GraphTripleConv
+    from augment.layout import boxes_to_layout
+    warnings.simplefilter('ignore')                       # grid_sample's align_corners notice (default False since torch 1.3)
+    g = torch.Generator().manual_seed(91)
+    rng = np.random.RandomState(91)
+    arrs = {}
+    O_, D = 14, 8
+    img = np.sort(rng.randint(0, 3, size=O_)).astype(np.int64)
+    img[img == 1] = 2                                     # image 1 has no objects: its canvas stays zero
+    xy = rng.uniform(0, 0.6, size=(O_, 2)); wh = rng.uniform(0.08, 0.6, size=(O_, 2))
+    boxes = np.concatenate((xy, np.minimum(xy + wh, 1.0)), 1).astype(np.float32)
+    boxes[0] = (0, 0, 1, 1)                                # the whole canvas
+    boxes[1] = (0.5, 0.5, 0.52, 0.53)                      # smaller than one canvas cell
+    arrs.update(lay_boxes=boxes, lay_img=img)
+    for tag, shape in (('patch', (O_, D, 7, 7)), ('vec', (O_, D))):
+        v = torch.randn(*shape, generator=g)
+        arrs['lay_%s_in' % tag] = v
+        for hw in ((38, 38), (10, 14)):
+            for pool in ('sum', 'avg'):
+                vv = v.clone().requires_grad_(True)
+                out = boxes_to_layout(vv, torch.from_numpy(boxes), torch.from_numpy(img), hw[0], hw[1], pooling=pool)
+                up = torch.randn(out.shape, generator=g)
+                (out * up).sum().backward()
+                key = 'lay_%s_%dx%d_%s' % (tag, hw[0], hw[1], pool)
+                arrs.update({key + '_out': out, key + '_up': up, key + '_din': vv.grad})
+    # one scene-graph convolution layer, both final_nonlinearity settings (GraphTripleConvNet uses False for the last layer)
+    T, Din, De, Hd = 30, 12, 10, 16
+    edges = np.stack((rng.randint(0, O_, T), rng.randint(0, O_, T)), 1).astype(np.int64)
+    edges[edges[:, 0] == 5, 0] = 6                         # object 5 appears in no triple as a subject ...
+    edges[edges[:, 1] == 5, 1] = 6                         # ... nor as an object: count 0 -> clamp(min=1)
+    obj, pred = torch.randn(O_, Din, generator=g), torch.randn(T, De, generator=g)
+    arrs.update(gc_edges=edges, gc_obj=obj, gc_pred=pred, gc_hidden=np.int64(Hd))
+    for k, (final, pooling, dout) in enumerate(((True, 'avg', 16), (False, 'avg', 9), (True, 'sum', 16))):
+        torch.manual_seed(92 + k)
+        layer = GraphTripleConv(Din, input_edge_dim=De, output_dim=dout, hidden_dim=Hd, pooling=pooling,
+                                mlp_normalization='none', final_nonlinearity=final)
+        no, npred = layer(obj, pred, torch.from_numpy(edges))
+        arrs.update({'gc%d_%s' % (k, n): t for n, t in sd(layer).items()})
+        arrs.update({'gc%d_out_obj' % k: no, 'gc%d_out_pred' % k: npred, 'gc%d_cfg' % k: np.array([int(final), int(pooling == 'avg'), dout])})
+    save('gan_ops', **arrs)
 
 
 def gold_eval_tail():
@@ -721,6 +767,7 @@ if __name__ == '__main__':
     gold_predict()
     gold_pairs()
     gold_rel_assign()
+    gold_gan_ops()
     gold_eval_tail()
     gold_losses()
     gold_recall()

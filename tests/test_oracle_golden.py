@@ -218,3 +218,22 @@ def test_rel_assignments_oracle_equals_reference():
                                     g[tag + '_gt_classes'], g[tag + '_gt_rels'], 0, num_sample_per_gt=per_gt,
                                     filter_non_overlap=bool(nonov))
             np.testing.assert_array_equal(out, g['%s_out%d' % (tag, k)], err_msg='%s case %d' % (tag, k))
+
+
+def test_gan_ops_oracle_equals_reference():
+    """augment/layout.py:33 boxes_to_layout and augment/graphconv.py:17 GraphTripleConv vs the reference's outputs."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'gan_ops.npz'))
+    for tag in ('patch', 'vec'):
+        for hw in ((38, 38), (10, 14)):
+            for pool in ('sum', 'avg'):
+                key = 'lay_%s_%dx%d_%s' % (tag, hw[0], hw[1], pool)
+                out = O.boxes_to_layout(g['lay_%s_in' % tag], g['lay_boxes'], g['lay_img'], hw[0], hw[1], pool)
+                np.testing.assert_allclose(out, g[key + '_out'], atol=2e-5, err_msg=key)
+                assert np.abs(out[1]).max() == 0                 # the image without objects
+    for k in range(3):
+        final, avg, dout = [int(v) for v in g['gc%d_cfg' % k]]
+        p = {n[len('gc%d_' % k):]: g[n] for n in g.files if n.startswith('gc%d_net' % k)}
+        no, npred = O.graph_triple_conv(g['gc_obj'], g['gc_pred'], g['gc_edges'], p, int(g['gc_hidden']), 'avg' if avg else 'sum', bool(final))
+        np.testing.assert_allclose(no, g['gc%d_out_obj' % k], atol=2e-5)
+        np.testing.assert_allclose(npred, g['gc%d_out_pred' % k], atol=2e-5)
