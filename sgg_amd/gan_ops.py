@@ -113,3 +113,77 @@ def triple_pool(new_t_vecs, edges, num_objs, hidden_dim, o_off, pooling='avg'):
     """graphconv.py:93-115 on the net1 output itself: subject part = columns [0, H), object part = columns [o_off, o_off + H)."""
     assert pooling in ('sum', 'avg'), 'Invalid pooling "%s"' % pooling                               # :35
     return _TriplePool.apply(new_t_vecs, edges, num_objs, hidden_dim, o_off, pooling == 'avg')
+
+
+def build_mlp(dim_list, activation='relu', batch_norm='none', dropout=0, final_nonlinearity=True):
+    """graphconv.py:157-176: Linear [BatchNorm1d] [ReLU | LeakyReLU] ... with the reference's Sequential indices (checkpoints load).
+    The contractions here are plain library GEMMs; the HIP kernels of this module are the gather and the pooling."""
+    layers = []
+    for i in range(len(dim_list) - 1):
+        layers.append(torch.nn.Linear(dim_list[i], dim_list[i + 1]))
+        if i != len(dim_list) - 2 or final_nonlinearity:
+            if batch_norm == 'batch':
+                layers.append(torch.nn.BatchNorm1d(dim_list[i + 1]))
+            if activation == 'relu':
+                layers.append(torch.nn.ReLU())
+            elif activation == 'leakyrelu':
+                layers.append(torch.nn.LeakyReLU())
+        if dropout > 0:
+            layers.append(torch.nn.Dropout(p=dropout))
+    return torch.nn.Sequential(*layers)
+
+
+def _init_weights(module):
+    if isinstance(module, torch.nn.Linear):
+        torch.nn.init.kaiming_normal_(module.weight)                                                 # graphconv.py:11-14
+
+
+class GraphTripleConv(torch.nn.Module):
+    """augment/graphconv.py:17-119, one scene-graph convolution: same constructor, parameter names and outputs."""
+
+    def __init__(self, input_dim, input_edge_dim=None, output_dim=None, hidden_dim=512, pooling='avg', mlp_normalization='none',
+                 final_nonlinearity=True):
+        super(GraphTripleConv, self).__init__()
+        output_dim = input_dim if output_dim is None else output_dim
+        input_edge_dim = input_dim if input_edge_dim is None else input_edge_dim
+        self.input_dim, self.output_dim, self.hidden_dim = input_dim, output_dim, hidden_dim
+        self.final_nonlinearity = final_nonlinearity
+        assert pooling in ['sum', 'avg'], 'Invalid pooling "%s"' % pooling
+        self.pooling = pooling
+        self.net1 = build_mlp([2 * input_dim + input_edge_dim, hidden_dim, 2 * hidden_dim + output_dim],
+                              batch_norm=mlp_normalization, final_nonlinearity=final_nonlinearity)
+        self.net1.apply(_init_weights)
+        self.net2 = build_mlp([hidden_dim, hidden_dim, output_dim], batch_norm=mlp_normalization,
+                              final_nonlinearity=final_nonlinearity)
+        self.net2.apply(_init_weights)
+
+    def forward(self, obj_vecs, pred_vecs, edges):
+        """obj_vecs (O, Din), pred_vecs (T, De), edges (T, 2) -> new_obj_vecs (O, Dout), new_pred_vecs (T, Dout)"""
+        H, Dout = self.hidden_dim, self.output_dim
+        new_t = self.net1(triple_gather(obj_vecs, pred_vecs, edges))                                 # :68-79
+        if not self.final_nonlinearity:                                                              # :86-88
+            new_t = torch.cat((torch.relu(new_t[:, :H]), new_t[:, H:H + Dout], torch.relu(new_t[:, H + Dout:])), 1)
+        pooled = triple_pool(new_t, edges, obj_vecs.shape[0], H, H + Dout, self.pooling)             # :93-115
+        return self.net2(pooled), new_t[:, H:H + Dout]
+
+
+class GraphTripleConvNet(torch.nn.Module):
+    """augment/graphconv.py:120-153: a stack of scene-graph convolutions (`G_gcn` of augment/gan.py:109-115)."""
+
+    def __init__(self, input_dim, input_edge_dim=None, output_dim=None, num_layers=5, hidden_dim=512, pooling='avg',
+                 mlp_normalization='none'):
+        super(GraphTripleConvNet, self).__init__()
+        self.num_layers = num_layers
+        self.gconvs = torch.nn.ModuleList()
+        for i in range(num_layers):
+            self.gconvs.append(GraphTripleConv(input_dim if i == 0 else hidden_dim,
+                                               input_edge_dim=input_edge_dim if i == 0 else hidden_dim,
+                                               output_dim=output_dim if i == num_layers - 1 else hidden_dim,
+                                               hidden_dim=hidden_dim, pooling=pooling, mlp_normalization=mlp_normalization,
+                                               final_nonlinearity=i < num_layers - 1))
+
+    def forward(self, obj_vecs, pred_vecs, edges):
+        assert len(edges.shape) == 2 and edges.shape[1] == 2, edges.shape
+        for gconv in self.gconvs:
+            obj_vecs, pred_vecs = gconv(obj_vecs, pred_vecs, edges)
+        return obj_vecs, pred_vecs

@@ -389,6 +389,14 @@ def gold_gan_ops():
         no, npred = layer(obj, pred, torch.from_numpy(edges))
         arrs.update({'gc%d_%s' % (k, n): t for n, t in sd(layer).items()})
         arrs.update({'gc%d_out_obj' % k: no, 'gc%d_out_pred' % k: npred, 'gc%d_cfg' % k: np.array([int(final), int(pooling == 'avg'), dout])})
+    # the stacked network as augment/gan.py:109-115 builds it (reduced sizes), with and without BatchNorm1d (train-mode statistics)
+    from augment.graphconv import GraphTripleConvNet
+    for tag, norm in (('net', 'none'), ('netbn', 'batch')):
+        torch.manual_seed(97)
+        net = GraphTripleConvNet(Din, input_edge_dim=De, output_dim=20, num_layers=3, hidden_dim=Hd, pooling='avg', mlp_normalization=norm)
+        no, npred = net(obj, pred, torch.from_numpy(edges))
+        arrs.update({'%s_%s' % (tag, n): t for n, t in net.state_dict().items() if 'num_batches' not in n})
+        arrs.update({tag + '_out_obj': no, tag + '_out_pred': npred})
     save('gan_ops', **arrs)
 
 

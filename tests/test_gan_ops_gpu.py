@@ -108,3 +108,20 @@ def test_graph_triple_conv_layer_equals_reference(k):
     ((ro * u1).sum() + (rp * u2).sum()).backward()
     torch.testing.assert_close(obj.grad, obj2.grad, atol=2e-5, rtol=1e-4)
     torch.testing.assert_close(pred.grad, pred2.grad, atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize('tag,norm', [('net', 'none'), ('netbn', 'batch')])
+def test_graph_triple_conv_net_loads_reference_weights_and_matches(tag, norm):
+    """GraphTripleConvNet as augment/gan.py:109-115 builds it: the reference's state_dict loads by name (strict) and the outputs agree;
+    'batch' = BatchNorm1d in train mode (batch statistics), as the reference module was run."""
+    from sgg_amd.gan_ops import GraphTripleConvNet
+    net = GraphTripleConvNet(G['gc_obj'].shape[1], input_edge_dim=G['gc_pred'].shape[1], output_dim=20, num_layers=3,
+                             hidden_dim=int(G['gc_hidden']), pooling='avg', mlp_normalization=norm).to(DEV)
+    sd = {n[len(tag) + 1:]: torch.from_numpy(G[n]) for n in G.files if n.startswith(tag + '_gconvs')}
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all('num_batches' in m for m in missing), (missing, unexpected)
+    no, npred = net(_t(G['gc_obj']), _t(G['gc_pred']), _t(G['gc_edges']))
+    np.testing.assert_allclose(no.detach().cpu().numpy(), G[tag + '_out_obj'], atol=5e-5, rtol=1e-4)
+    np.testing.assert_allclose(npred.detach().cpu().numpy(), G[tag + '_out_pred'], atol=5e-5, rtol=1e-4)
+    (no.sum() + npred.sum()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
