@@ -254,6 +254,25 @@ def main():
         imp_old = {'B%d' % b_: round(imp_iter_ms(model, b_, tdtype, kind='fused'), 5) for b_ in (B, BL)}   # node-centric kernel, for comparison
         impL_bytes = (2.0 * (992 * BL + 32 * BL) * H) * s + 8.0 * 992 * BL
         impL_gbs = impL_bytes / (impL_ms * 1e-3) / 1e9
+        # context for the fraction: what a plain device-to-device copy moving the same number of bytes (half read, half written)
+        # reaches on this box, timed the same way (50 launches in one graph between two events)
+        src = torch.empty(int(impL_bytes) // 2, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        torch.cuda.synchronize()
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            for _ in range(50):
+                dst.copy_(src)
+        cg.replay()
+        torch.cuda.synchronize()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        cg.replay()
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbs = impL_bytes / (c0.elapsed_time(c1) / 50 * 1e-3) / 1e9
+        del src, dst, cg
         roi_ms = sum(v[0] * v[1] for (n, t), v in kt.items() if n == 'sgg_roi_align_fwd')
         roi_bytes = (E + N) * 25088.0 * s + B * 38 * 38 * 512.0 * s
         conv_ms = sum(v[0] * v[1] for (n, t), v in kt.items() if n in ('sgg_conv3x3_relu', 'sgg_conv1_1', 'sgg_maxpool2x2'))
@@ -332,7 +351,8 @@ def main():
                                    'frac': round(impL_gbs / HBM_PEAK_GBS, 4),
                                    'traffic': pmc_traffic('imp_sliced_B128') if args.dtype == 'bf16' else None,
                                    'algorithmic_bytes': impL_bytes, 'avg_launch_ms': round(impL_ms, 5),
-                                   'node_centric_kernel_ms': imp_old},
+                                   'node_centric_kernel_ms': imp_old,
+                                   'device_copy_same_bytes': {'GB/s': round(copy_gbs, 1), 'frac_of_copy': round(impL_gbs / copy_gbs, 4)}},
             'kernels': {'sum_kernel_ms_per_step': round(total_ms, 3),
                         'vgg16_ms': round(conv_ms, 3), 'vgg16_tflops': round(vgg_flop / (conv_ms * 1e-3) / 1e12, 1) if conv_ms else 0,
                         'roi_align_ms': round(roi_ms, 4), 'roi_align_GBs': round(roi_bytes / (roi_ms * 1e-3) / 1e9, 1) if roi_ms else 0,

@@ -12,7 +12,7 @@ from sgg_amd.synthetic import SyntheticData, init_weights  # noqa: E402
 model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls')).to('cuda:0').eval()
 for dtype, s in ((torch.bfloat16, 2), (torch.float32, 4)):
     model.set_compute_dtype(dtype)
-    for B in (8, 32, 128):
+    for B in [int(b) for b in os.environ.get("IMP_B", "8,32,128").split(",")]:
         algo = (2.0 * (992 * B + 32 * B) * 512) * s + 8.0 * 992 * B
         row = []
         for kind in ('sliced', 'fused'):
