@@ -102,7 +102,11 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const TI* __restrict__
     const int tid = threadIdx.x;
     const bool vin = ((ld_in & 7) == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
     const bool vout = ((ld_out & 7) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-    float v[8][8];
+    float v[8][8], a0v[8], a1v[8];
+    // a thread's eight pieces sit in one column block (c depends on tid & 15 only): its group index is computed once -- inside the
+    // guarded loop below the compiler may not hoist a division by a run-time value
+    const int c_h = c0 + (tid & 15) * 8;
+    const int cg_h = (add && group >= 8) ? c_h / group : 0, left_h = group - (c_h - cg_h * group);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int id = tid + q * 256, rr = id >> 4, cc = (id & 15) * 8;
@@ -113,16 +117,21 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const TI* __restrict__
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[q][k] = (r < R && c + k < C) ? Elem<TI>::ld(in + (long)r * ld_in + c + k) : 0.f;
         }
+        // the addends are requested together with the tile (an 8-element piece spans at most two groups: two loads), not after it
+        a0v[q] = a1v[q] = 0.f;
+        if (add && group >= 8 && r < R && c < C) {
+            a0v[q] = add[(long)r * ld_add + cg_h];
+            if (left_h < 8 && c + left_h < C) a1v[q] = add[(long)r * ld_add + cg_h + 1];
+        }
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int id = tid + q * 256, rr = id >> 4, cc = (id & 15) * 8;
         const int r = r0 + rr, c = c0 + cc;
         if (add && r < R && c < C) {
-            if (group >= 8) {   // an 8-element piece spans at most two groups: one division, two loads
-                const int cg = c / group, left = group - (c - cg * group);
-                const float a0 = add[(long)r * ld_add + cg];
-                const float a1 = (left < 8 && c + left < C) ? add[(long)r * ld_add + cg + 1] : 0.f;
+            if (group >= 8) {
+                const int left = left_h;
+                const float a0 = a0v[q], a1 = a1v[q];
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
                     if (c + k < C) v[q][k] += (k < left) ? a0 : a1;
