@@ -150,3 +150,25 @@ def test_sgdet_train_forward_samples_relations_like_the_reference_and_backpropag
             assert err < 2e-3, (n, err)
     finally:
         model.eval()
+
+
+def test_sgdet_trainer_steps_run_and_reduce_the_loss(env):
+    """main.py:100-120 in sgdet mode: a few optimiser steps on the sampled relation labels (numpy-seeded) lower the loss."""
+    import sgg_amd
+    from sgg_amd.synthetic import SyntheticData, init_weights
+    from sgg_amd.trainer import Trainer
+    _, sd, batch, ref, S = env
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgdet', min_size=S, max_size=S))
+    model.load_state_dict(sd)
+    model.to(DEV).set_compute_dtype(torch.float32)
+    model.set_box_score_thresh(0.0)
+    model.dropout_p = 0.0
+    tr = Trainer(model, lr=1e-3, pipeline=False)
+    dbatch = list(batch)
+    dbatch[0] = [im.to(DEV) for im in batch[0]]
+    losses = []
+    for _ in range(6):
+        np.random.seed(3)                      # the same sampled edges every step
+        losses.append(float(tr.step(tuple(dbatch))))
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses
