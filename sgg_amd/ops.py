@@ -252,7 +252,7 @@ def bcast_add_(x, add_rc):
 
 
 # ---------------------------------------------------------------- a-7
-def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None, post_shift=None, out=None, W2=None):
+def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None, post_shift=None, out=None, W2=None, splits=None):
     """act([A[M,K1] | A2[M,K2]] . [W | W2]^T + bias) * post_scale + post_shift -> [M,N].
     W is [N,K1+K2], or [N,K1] when the second K segment's weights are given separately as W2 [N,K2]."""
     M, K1 = A.shape
@@ -268,8 +268,10 @@ def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None
     # short-M, long-K contractions (fc6 on the object rows) do not fill the chip with output tiles: split K
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     kt = K // (64 if A.dtype == torch.bfloat16 else 32)
-    if A2 is None and tiles <= 96 and kt >= 64 and N % 8 == 0 and out.is_contiguous() and A.stride(0) >= K and W.stride(0) >= K:
-        splits = max(2, min(16, 512 // tiles, kt // 8))
+    can_split = A2 is None and N % 8 == 0 and out.is_contiguous() and A.stride(0) >= K and W.stride(0) >= K
+    if can_split and ((splits is None and tiles <= 96 and kt >= 64) or (splits is not None and splits > 1)):
+        if splits is None:
+            splits = max(2, min(16, 512 // tiles, kt // 8))
         ws = torch.empty((splits, M, N), dtype=torch.float32, device=A.device)
         _lib.call('sgg_gemm_splitk', _p(A, rows_ok=True), A.stride(0), _p(W, rows_ok=True), W.stride(0),
                   _p(bias, torch.float32) if bias is not None else None,
@@ -284,6 +286,30 @@ def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None
               _p(post_scale, torch.float32) if post_scale is not None else None,
               _p(post_shift, torch.float32) if post_shift is not None else None,
               _p(out, rows_ok=True), out.stride(0), M, N, K, act, dt(A), dt(out), _stream())
+    return out
+
+
+N_CU = 256     # MI355X
+
+
+def gemm_full_waves(A, W, out_dtype=None):
+    """A[M,K] . W[N,K]^T for the large weight-gradient contractions.  The ping-pong kernel runs one 256x256 tile per CU, so a tile
+    count just above a multiple of 256 costs a whole extra round for a few tiles (fc6 weight gradient: 16 x 98 = 1568 tiles = 6.125
+    rounds).  When the last round would be at most a quarter full and consists of whole tile columns, those columns are computed by a
+    split-K launch of the 128x128 kernel that fills the chip instead, and the main launch is an exact number of rounds."""
+    M, K = A.shape
+    N = W.shape[0]
+    tm, tn = M // 256, N // 256
+    rem = (tm * tn) % N_CU
+    kt = K // (64 if A.dtype == torch.bfloat16 else 32)
+    if M % 256 or N % 256 or tm * tn < 2 * N_CU or rem == 0 or rem > N_CU // 4 or rem % tm or kt < 64:   # short reductions: nothing to split
+        return gemm(A, W, out_dtype=out_dtype)
+    n1 = N - (rem // tm) * 256
+    out = torch.empty((M, N), dtype=out_dtype or A.dtype, device=A.device)
+    gemm(A, W[:n1], out=out[:, :n1])
+    tail_tiles = (M // 128) * ((N - n1) // 128)
+    tail = gemm(A, W[n1:], out_dtype=out.dtype, splits=max(2, min(8, (2 * N_CU) // tail_tiles, kt // 8)))
+    out[:, n1:].copy_(tail)
     return out
 
 

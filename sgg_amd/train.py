@@ -335,7 +335,7 @@ class PredictFn(torch.autograd.Function):
         else:
             x6t = ops.transpose(sv['ef'], add=sv['rect'].float() if sv['rect'].dtype != torch.float32 else sv['rect'], group=PP)
         d6t, G['roi_fmap.1.0.bias'] = ops.transpose(d_pre6, want_colsum=True)
-        G['roi_fmap.1.0.weight'] = ops.gemm(d6t, x6t, out_dtype=big_dtype())
+        G['roi_fmap.1.0.weight'] = ops.gemm_full_waves(d6t, x6t, out_dtype=big_dtype())
         hook('roi_fmap.1.0.weight')
         del x6t, d6t
         _lib.set_tag('bwd_mlp_obj')

@@ -686,3 +686,19 @@ def test_gemm_tn_matches_transposed_product(ops, shape, out_dtype):
     wide = torch.randn(Mred, N + 128, generator=g).to(torch.bfloat16)
     got = ops.gemm_tn(cu(wide)[:, 128:], cu(B), out_dtype=torch.float32, splits=1)
     torch.testing.assert_close(got.cpu(), wide[:, 128:].float().t() @ B.float(), atol=2e-3 * (Mred ** 0.5), rtol=1e-4)
+
+
+def test_gemm_full_waves_equals_one_launch():
+    """the fc6 weight-gradient shape (16 x 98 tiles = 6.125 rounds): full-round launch + split-K tail vs the single launch, and a
+    short reduction that must fall back to the single launch"""
+    from sgg_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for K in (7936, 128):
+        A = (torch.randn(4096, K, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+        W = (torch.randn(25088, K, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+        one = ops.gemm(A, W, out_dtype=torch.float32)
+        two = ops.gemm_full_waves(A, W, out_dtype=torch.float32)
+        assert two.shape == one.shape
+        # same products; the tail columns are summed in two K halves instead of one pass (fp32 accumulation order)
+        torch.testing.assert_close(two, one, atol=2e-3 * (K / 7936) ** 0.5 + 1e-5, rtol=1e-4)
+        assert torch.equal(two[:, :24576], one[:, :24576])
