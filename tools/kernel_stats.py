@@ -29,3 +29,12 @@ for (name, wgs), v in sorted(shapes.items(), key=lambda kv: -sum(kv[1])):
     if sum(v) / len(v) < 50:
         continue
     print('%-60s %10d %9d %12.1f %10.2f %10.2f %10.2f' % (name, wgs, len(v), sum(v), sum(v) / len(v), min(v), max(v)))
+
+# several contractions share a grid too (fc6 on the edges, K = 25600, and fc7, K = 4096, are both 496 workgroups of the ping-pong
+# kernel): the launches of at least 1 ms of such a row are listed on their own -- bench.py's `roofline` kernel is one of these rows
+print()
+print('%-60s %10s %9s %12s %10s %10s %10s' % ('launches >= 1000 us of a mixed row', 'workgroups', 'calls', 'total_us', 'avg_us', 'min_us', 'max_us'))
+for (name, wgs), v in sorted(shapes.items(), key=lambda kv: -sum(kv[1])):
+    big = [x for x in v if x >= 1000.0]
+    if big and len(big) < len(v):
+        print('%-60s %10d %9d %12.1f %10.2f %10.2f %10.2f' % (name, wgs, len(big), sum(big), sum(big) / len(big), min(big), max(big)))
