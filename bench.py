@@ -40,10 +40,84 @@ def parse():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--mode', default='train', choices=['train', 'infer'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-f32', action='store_true', help='skip the short exact-fp32 runs reported under "f32_mode"')
     ap.add_argument('--force-dist', action='store_true',
                     help='diagnostic: at 1 GPU, run the data-parallel code path on a 1-rank RCCL group')
     ap.add_argument('--cpu-images', type=int, default=8)
+    ap.add_argument('--dry', action='store_true',
+                    help='no GPU: check the launcher / rank environment with one gloo all-reduce and print the JSON skeleton')
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch(args):
+    """`python bench.py --gpus N` without a rank environment: start one child process per GPU (the contract of
+    torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), BEFORE this process has made any HIP or torch.cuda
+    call -- a process that has touched the GPU is never re-executed.  Rank 0 inherits stdout (its JSON line is the last thing
+    written there), the other ranks write to stderr.  Any non-zero exit ends the others and becomes this process's exit code."""
+    import signal
+    import subprocess
+    n = args.gpus
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr, start_new_session=True))
+    rc = 0
+    live = set(range(n))
+    try:
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write('[bench] rank %d exited with %d: stopping the other ranks\n' % (r, code))
+                    for o in live:                      # exactly the process groups started above, nothing by pattern
+                        try:
+                            os.killpg(procs[o].pid, signal.SIGTERM)
+                        except ProcessLookupError:
+                            pass
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for o in live:
+            try:
+                os.killpg(procs[o].pid, signal.SIGTERM)
+            except ProcessLookupError:
+                pass
+        rc = 130
+    return rc
+
+
+def dry_run(args, rank, world):
+    """Launcher check that needs no GPU: every rank joins a gloo group, one all-reduce, rank 0 prints the line's skeleton."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        if rank != 0:
+            os.dup2(2, 1)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        assert float(t.item()) == world * (world + 1) / 2.0, t
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({'metric': 'images/sec (whole node), VG SGCls IMP %s step' % args.mode, 'value': None, 'unit': 'images/s',
+                          'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'dry': True,
+                          'config': {'images_per_gpu': args.batch, 'global_batch': world * args.batch}}), flush=True)
 
 
 def kernel_times(step_fn, reps):
@@ -118,9 +192,21 @@ def imp_iter_ms(model, B, dtype, reps=50, kind='sliced'):
     return e0.elapsed_time(e1) / reps
 
 
-def cpu_baseline(n_images, seed):
-    """The oracle (a structural CPU restatement of the reference path, validated against the reference's own
-    outputs) timed on this box's host cores on a bounded sample of the same workload."""
+def cpu_model_name():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(n_images, seed, timed=3):
+    """the oracle (a structural CPU restatement of the reference path, validated against the reference's
+    own outputs by tests/golden) on this box's host cores, same synthetic batch as the GPU run: 1 warm-up + `timed` timed
+    forwards; (i) the full forward and (ii) the post-RoIAlign part (`predict`, comparable to BASELINE.md section 2)."""
     import torch
     import sgg_amd
     from oracle import sgg_oracle as O
@@ -128,24 +214,43 @@ def cpu_baseline(n_images, seed):
     model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls'))
     sd = model.state_dict()
     batch = synthetic_batch(B=n_images, S=592, n_boxes=32, n_fg=6, seed=seed)
-    cores = min(os.cpu_count() or 1, 32)      # measured on the GPU box: torch-CPU conv/GEMM is fastest at 32 threads (256 cores)
+    avail = os.cpu_count() or 1
+    cores = min(avail, 32)      # measured on the GPU box (256 hardware threads): torch-CPU conv/GEMM is fastest at 32 threads
     torch.set_num_threads(cores)
+    full, post = [], []
     with torch.no_grad():
-        t0 = time.time()
-        O.forward_gtbox(batch[0], batch[3], batch[4], batch[5], sd, mode='sgcls')
-        dt = time.time() - t0
+        for it in range(1 + timed):
+            t0 = time.time()
+            res = O.forward_gtbox(batch[0], batch[3], batch[4], batch[5], sd, mode='sgcls')
+            t1 = time.time()
+            O.predict(res['node_feat'], res['edge_feat'], res['rel_inds'], res['rois'], sd, im_sizes=res['im_sizes'])
+            t2 = time.time()
+            if it > 0:
+                full.append(t1 - t0)
+                post.append(t2 - t1)
+    dt, dp = sum(full) / len(full), sum(post) / len(post)
     return {'value': round(n_images / dt, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'sample': '1 forward of %d synthetic 592x592 images (32 boxes, 992 edges each), torch-CPU fp32 oracle, '
-                      '%.1f s' % (n_images, dt)}
+            'cpu_model': cpu_model_name(), 'host_threads_available': avail,
+            'post_roialign_images_per_s': round(n_images / dp, 4),
+            'sample': '1 warm-up + %d timed forwards of %d synthetic 592x592 images (32 boxes, 992 edges each, seed %d), torch-CPU fp32 '
+                      'oracle on %d threads: %.1f s per forward (min %.1f, max %.1f), of which predict() %.1f s'
+                      % (timed, n_images, seed, cores, dt, min(full), max(full), dp)}
 
 
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
+    host_group = None
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch(args))          # nothing above this line has touched the GPU
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        sys.exit('bench.py: --gpus %d but the rank environment says WORLD_SIZE=%d' % (args.gpus, world))
+    if args.dry:
+        return dry_run(args, rank, world)
+    import torch
+    import torch.distributed as dist
     if world > 1:
         if rank != 0:
             os.dup2(2, 1)      # only rank 0 owns stdout (the JSON line); anything other ranks print goes to stderr
@@ -153,6 +258,7 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local)
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        host_group = dist.new_group(backend='gloo')
     else:
         torch.cuda.set_device(0)
         if args.force_dist:
@@ -223,11 +329,10 @@ def main():
                 loss.backward()
                 trainer.opt.step()
             trainer.flush()
-            # rank 0 alone runs these extra steps: no collective may be issued (the other ranks wait at the barrier)
-            saved_hook, saved_bn, trainer.world = getattr(model, '_grad_ready_hook', None), getattr(model, '_bn_sync', None), 1
-            model._grad_ready_hook = model._bn_sync = None
-            kt = kernel_times(prof_step, reps=3)
-            model._grad_ready_hook, model._bn_sync, trainer.world = saved_hook, saved_bn, world
+            # rank 0 alone runs these extra steps: no collective may be issued (the other ranks wait at the host-side barrier
+            # below): the trainer is switched to its local form -- hooks, BatchNorm sync, loss normalisers (dist_on) and world
+            with trainer.local_only():
+                kt = kernel_times(prof_step, reps=3)
         else:
             kt = kernel_times(infer_step, reps=5)
         E, N, H = 992 * B, 32 * B, 512
@@ -362,12 +467,33 @@ def main():
             line['other_mode'] = other_line
         if pcie:
             line['pcie_inclusive'] = pcie
+        if world == 1 and not args.force_dist and args.dtype == 'bf16' and not args.no_f32:
+            # the reference computes in fp32: the same two steps in exact-fp32 mode (v_mfma_f32_32x32x2_f32, the mode the 1e-3 parity
+            # bar is checked in), short runs, reported beside the bf16 headline -- never `value`
+            if trainer is not None:
+                trainer.flush()
+            torch.cuda.synchronize()
+            model.set_compute_dtype(torch.float32)
+            t32 = Trainer(model, lr=1e-3, pipeline=trainer.pipeline if trainer is not None else True)
+            el_t = timed(lambda: t32.step(batch), 2, 5)
+            t32.flush()
+            el_i = timed(infer_step, 2, 5)
+            line['f32_mode'] = {'dtype': 'f32', 'train_images_per_s': round(B * 5 / el_t, 2), 'train_ms_per_step': round(1e3 * el_t / 5, 3),
+                                'infer_images_per_s': round(B * 5 / el_i, 2), 'infer_ms_per_step': round(1e3 * el_i / 5, 3),
+                                'mfma_peak_TFLOPs': MFMA_PEAK_TF['f32'], 'note': 'same workload, exact-fp32 MFMA; 2 warm-up + 5 timed steps each'}
+            del t32
+            model.set_compute_dtype(tdtype)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.cpu_images, 111)
     else:
         line = None
     if dist.is_initialized():
-        dist.barrier()
+        # the ranks that did not profile wait here on the HOST (gloo): an RCCL barrier would keep their GPUs spinning on
+        # rank 0's memory for the whole of its profiling pass
+        if host_group is not None:
+            dist.barrier(group=host_group)
+        else:
+            dist.barrier()
         dist.destroy_process_group()
     if line is not None:
         # RCCL prints its version banner through C stdio, which is block-buffered on a pipe and would otherwise be

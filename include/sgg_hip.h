@@ -30,7 +30,9 @@ enum {
     SGG_ERR_ARG = -1,      /* bad size / alignment / null pointer          -> ValueError  */
     SGG_ERR_DTYPE = -2,    /* unsupported element type                     -> TypeError   */
     SGG_ERR_LAUNCH = -3,   /* hipLaunch failed                             -> RuntimeError */
-    SGG_ERR_CAPACITY = -4  /* caller-provided output capacity too small    -> ValueError  */
+    SGG_ERR_CAPACITY = -4, /* caller-provided output capacity too small    -> ValueError  */
+    SGG_ERR_SPAN = -5      /* a GEMM / conv operand spans >= 4 GiB (the kernels address rows as uniform base + 32-bit lane offset):
+                              split the rows over several calls (sgg_amd.ops.gemm / conv3x3_relu do)  -> ValueError */
 };
 
 int sgg_abi_version(void);

@@ -89,7 +89,8 @@ _RESTYPE = {'sgg_build_info': c_char_p}
 _ERRORS = {-1: (ValueError, 'bad argument (size / alignment / null pointer)'),
            -2: (TypeError, 'unsupported element type'),
            -3: (RuntimeError, 'HIP kernel launch failed'),
-           -4: (ValueError, 'output capacity too small')}
+           -4: (ValueError, 'output capacity too small'),
+           -5: (ValueError, 'an operand spans >= 4 GiB (rows are addressed as base + 32-bit lane offset): split the rows over several calls')}
 
 _lib = None
 

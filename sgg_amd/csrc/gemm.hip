@@ -420,7 +420,7 @@ extern "C" int sgg_gemm(const void* A, int lda, const void* A2, int lda2, int K1
     // the kernels address operand rows as (uniform base + 32-bit lane offset): every operand must span < 4 GiB
     const long lim = 0xffff0000L;
     if ((long)M * lda * esz > lim || (long)N * ldw * esz > lim || (A2 && (long)M * lda2 * esz > lim) || (W2 && (long)N * ldw2 * esz > lim))
-        return SGG_ERR_ARG;
+        return SGG_ERR_SPAN;
     GemmArgs g{};
     g.A = (const char*)A; g.A2 = (const char*)A2; g.Wt = (const char*)W; g.W2 = (const char*)W2;
     g.lda_b = (long)lda * esz; g.lda2_b = (long)lda2 * esz; g.ldw_b = (long)ldw * esz; g.ldw2_b = (long)ldw2 * esz;
@@ -470,7 +470,7 @@ extern "C" int sgg_gemm_splitk(const void* A, int lda, const void* W, int ldw, c
     const int bke = ROWB / esz;
     if (!A || !W || !C || !workspace || M < 0 || N <= 0 || (N & 7) || K <= 0 || K % bke || splits < 1 || splits > K / bke) return SGG_ERR_ARG;
     if ((lda & 7) || (ldw & 7) || lda < K || ldw < K || (((uintptr_t)A | (uintptr_t)W) & 15)) return SGG_ERR_ARG;
-    if ((long)M * lda * esz > 0xffff0000L || (long)N * ldw * esz > 0xffff0000L) return SGG_ERR_ARG;   // 32-bit lane offsets
+    if ((long)M * lda * esz > 0xffff0000L || (long)N * ldw * esz > 0xffff0000L) return SGG_ERR_SPAN;   // 32-bit lane offsets
     GemmArgs g{};
     g.A = (const char*)A; g.Wt = (const char*)W;
     g.lda_b = (long)lda * esz; g.ldw_b = (long)ldw * esz;
@@ -501,7 +501,7 @@ extern "C" int sgg_gemm_tn(const void* A, int lda, const void* B, int ldb, void*
         ldc < K || ((lda | ldb | ldc) & 7) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) || splits < 1 ||
         splits > Mred / 64 || (splits > 1 && (!workspace || ldc != K)))
         return SGG_ERR_ARG;
-    if ((long)Mred * lda * 2 > 0xffff0000L || (long)Mred * ldb * 2 > 0xffff0000L) return SGG_ERR_ARG;   // 32-bit lane offsets
+    if ((long)Mred * lda * 2 > 0xffff0000L || (long)Mred * ldb * 2 > 0xffff0000L) return SGG_ERR_SPAN;   // 32-bit lane offsets
     GemmArgs g{};
     g.A = (const char*)A; g.Wt = (const char*)B;
     g.lda_b = (long)lda * 2; g.ldw_b = (long)ldb * 2;
@@ -542,7 +542,7 @@ extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias
     if (!in || !w || !out || B <= 0 || H <= 0 || W <= 0 || Cin % bke || Cout % 64 || (out_pad != 0 && out_pad != 1))
         return SGG_ERR_ARG;
     if ((long)B * H * W > 0x7fffffffL) return SGG_ERR_ARG;
-    if ((long)B * (H + 2) * (W + 2) * Cin * esz > 0xffff0000L || 9L * Cin * Cout * esz > 0xffff0000L) return SGG_ERR_ARG;   // 32-bit lane offsets
+    if ((long)B * (H + 2) * (W + 2) * Cin * esz > 0xffff0000L || 9L * Cin * Cout * esz > 0xffff0000L) return SGG_ERR_SPAN;   // 32-bit lane offsets
     {
         // wide-spatial layers: LDS-resident input patch kernel (conv_spatial.hip); small maps: implicit GEMM.
         // SGG_CONV_FORCE=gemm|spatial overrides (experiments only).

@@ -108,6 +108,12 @@ def conv3x3_relu(x, w, bias, out, out_pad, pool=False):
     B, H, W, Cin = x.shape[0], x.shape[1] - 2, x.shape[2] - 2, x.shape[3]
     Cout = w.shape[0]
     assert w.dtype == x.dtype == out.dtype
+    per_image = x.shape[1] * x.shape[2] * Cin * x.element_size()
+    if B * per_image > SPAN_LIMIT and B > 1:        # planes of 4 GiB or more (conv1_2 input above ~45 fp32 images): image blocks
+        step = max(1, SPAN_LIMIT // per_image)
+        for b0 in range(0, B, step):
+            conv3x3_relu(x[b0:b0 + step], w, bias, out[b0:b0 + step], out_pad, pool)
+        return
     _lib.call('sgg_conv3x3_relu', _p(x), _p(w), _p(bias, torch.float32), _p(out), out_pad, B, H, W, Cin, Cout, int(pool),
               dt(x), _stream())
 
@@ -265,6 +271,15 @@ def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None
     out_dtype = out_dtype or A.dtype
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    # the kernels address an operand's rows as (uniform base + 32-bit lane offset): an A operand of 4 GiB or more (fc6 on > 85 k
+    # edges in bf16, > 42 k in fp32) goes through in row blocks (SGG_ERR_SPAN is what the entry point returns otherwise)
+    row_bytes = max(A.stride(0) * A.element_size(), A2.stride(0) * A2.element_size() if A2 is not None else 0)
+    if M * row_bytes > SPAN_LIMIT and M > 1:
+        step = max(1, (SPAN_LIMIT // row_bytes) // 256 * 256 or SPAN_LIMIT // row_bytes)
+        for m0 in range(0, M, step):
+            m1 = min(M, m0 + step)
+            gemm(A[m0:m1], W, bias, act, out_dtype, A2[m0:m1] if A2 is not None else None, post_scale, post_shift, out[m0:m1], W2, splits)
+        return out
     # short-M, long-K contractions (fc6 on the object rows) do not fill the chip with output tiles: split K
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     kt = K // (64 if A.dtype == torch.bfloat16 else 32)
@@ -290,6 +305,7 @@ def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None
 
 
 N_CU = 256     # MI355X
+SPAN_LIMIT = 0xffff0000     # bytes one GEMM / conv operand may span (32-bit lane offsets, gemm.hip)
 
 
 def gemm_full_waves(A, W, out_dtype=None):

@@ -6,6 +6,7 @@ Layout note: the feature map is channels-last in memory and handed out as a [B,C
 [R,C,7,7] tensors exactly as in the reference (RoIAlign transposes through LDS), so fc6 weights are used un-permuted.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -322,6 +323,8 @@ class RelModelBase(nn.Module):
             else:
                 n = int(count.item())
                 max_edges = None
+            if __debug__ and os.environ.get('SGG_CHECK_COUNTS'):
+                assert n == int(count.item()), ('host-side row count differs from the device count', n, int(count.item()))
             rel_labels = out[:n]
             # sub-sampling (lib/proposal_assignments_gtbox.py:47-66): at most RELS_PER_IMG*0.25*num_im FG rows and
             # RELS_PER_IMG*num_im rows in total (or num_fg*sample_factor BG rows).  random_choose is a uniform random
@@ -331,11 +334,16 @@ class RelModelBase(nn.Module):
             sample_bg = num_im > 1 and sample_factor > -1
             num_bg = min(n_bg_all, int(num_fg * sample_factor) if sample_bg else int(self.RELS_PER_IMG * num_im) - num_fg)
             if num_fg < R or num_bg < n_bg_all:
+                # FG rows are recognised by their label: the reference samples fg_rels by identity (:28-35), which is the same set
+                # unless a GT relation carries predicate 0 (not a VG / GQA predicate id: those start at 1) -- such a row would
+                # count as background here.  The row counts are taken from the masks themselves, never from R / the host count,
+                # so the permutation always matches the rows it indexes.
                 is_fg = rel_labels[:, 3] > 0
                 keep = torch.ones(n, dtype=torch.bool, device=rel_labels.device)
-                for mask, want, have in ((is_fg, num_fg, R), (~is_fg, max(num_bg, 0), n_bg_all)):
+                for mask, want in ((is_fg, num_fg), (~is_fg, max(num_bg, 0))):
+                    pos = torch.nonzero(mask).view(-1)
+                    have = int(pos.numel())
                     if want < have:
-                        pos = torch.nonzero(mask).view(-1)
                         drop = pos[torch.randperm(have, device=pos.device)[want:]]
                         keep[drop] = False
                 rel_labels = rel_labels[keep].contiguous()

@@ -100,6 +100,10 @@ class FusedSGD(torch.optim.Optimizer):
         names = set(self.name_of.get(p) for p, _, _ in live)
         self.wrote_shadow = [n for n in shadows if n in names]
         self.steps += 1
+        # the kernels wrote through raw pointers: move every updated parameter's autograd version counter, so that anything keyed
+        # on (data_ptr, _version) -- model.prepared(), the bf16 shadows, the W^T copies of the backward -- sees the change even
+        # when this optimiser is used on its own (scheduler / checkpoint interchange) without a Trainer's on_update
+        torch.autograd.graph.increment_version([p for p, _, _ in live])
         if self.on_update is not None:
             self.on_update()   # parameters changed through raw pointers: tell the owner to refresh derived operands
         return None
@@ -164,6 +168,24 @@ class Trainer(object):
             # union_boxes.conv BatchNorm: statistics over the edges of the GLOBAL batch, i.e. the numbers a
             # single process would compute on the concatenated batch; sync_bn=False = replica-local statistics.
             model._bn_sync = (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)) if sync_bn else None
+
+    def local_only(self):
+        """Context manager: inside it the trainer and the model issue NO collective (gradient hooks, BatchNorm statistics,
+        loss normalisers, bucket all-reduce) -- for extra steps that one rank runs on its own, e.g. a profiling pass while the
+        other ranks wait.  Everything is restored on exit."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            m = self.model
+            saved = (getattr(m, '_grad_ready_hook', None), getattr(m, '_bn_sync', None), self.world, self.dist_on)
+            m._grad_ready_hook = m._bn_sync = None
+            self.world, self.dist_on = 1, False
+            try:
+                yield self
+            finally:
+                m._grad_ready_hook, m._bn_sync, self.world, self.dist_on = saved
+        return cm()
 
     def _bump(self):
         self.model.weights_version = getattr(self.model, 'weights_version', 0) + 1

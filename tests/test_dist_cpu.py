@@ -76,3 +76,148 @@ def test_shard_range_properties():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+# ------------------------------------------------------------------ the Trainer's data-parallel logic at world size 2
+class _Heads(torch.nn.Module):
+    """Stand-in for the model on the CPU: two linear heads over given features, returning what Trainer.losses reads."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(5)
+        self.obj_fc = torch.nn.Linear(6, 7)
+        self.rel_fc = torch.nn.Linear(6, 5)
+
+    def forward(self, xo, xr, obj_labels, rel_labels):
+        from sgg_amd.result import Result
+        return Result(rm_obj_dists=self.obj_fc(xo), rel_dists=self.rel_fc(xr), rm_obj_labels=obj_labels, rel_labels=rel_labels)
+
+
+def _split_batch():
+    """A global batch and a RAGGED split of it over two ranks: different object / edge / FG counts per rank; rank 1 of the
+    second case has no FG edge at all (the M_FG = 0 branch of lib/losses.py:50)."""
+    g = torch.Generator().manual_seed(9)
+    xo, xr = torch.randn(11, 6, generator=g), torch.randn(23, 6, generator=g)
+    ol = torch.randint(0, 7, (11,), generator=g)
+    pred = torch.randint(1, 5, (23,), generator=g)
+    cases = []
+    for n0, m0, fg in ((4, 9, torch.rand(23, generator=g) < 0.3), (7, 15, torch.arange(23) < 6)):
+        p = torch.where(fg, pred, torch.zeros_like(pred))
+        rl = torch.stack((torch.zeros(23, dtype=torch.long), torch.arange(23), torch.arange(23), p), 1)
+        cases.append((xo, xr, ol, rl, n0, m0))
+    return cases
+
+
+def _trainer_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from sgg_amd import dist as D
+    from sgg_amd.trainer import Trainer
+    D.init('gloo')
+    out = {}
+    for ci, (xo, xr, ol, rl, n0, m0) in enumerate(_split_batch()):
+        so, sr = (slice(0, n0), slice(0, m0)) if rank == 0 else (slice(n0, None), slice(m0, None))
+        for lt, lw in (('baseline', (1, 1, 0.5)), ('dnorm', (1.0, 0.7, 2.0)), ('dnorm-fgbg', (0.3, 1.5, 1.0))):
+            model = _Heads()
+            tr = Trainer(model, loss_type=lt, loss_weights=lw, comm_dtype=None)
+            assert tr.dist_on and tr.world == 2
+            loss = tr.losses(model(xo[so], xr[sr], ol[so], rl[sr]))
+            loss.backward()
+            grads = tr.buckets.all_reduce(average=False)            # SUM, as Trainer.step issues it
+            out[(ci, lt)] = (float(loss.detach()), {n: grads[p].tolist() for n, p in model.named_parameters()})
+    # a pass that ONE rank runs on its own (bench.py's profiling pass) must not issue a collective: rank 0 computes a loss
+    # inside local_only() while rank 1 goes straight to the barrier -- a stray all-reduce would pair with it and corrupt / hang
+    model = _Heads()
+    tr = Trainer(model, loss_type='baseline', comm_dtype=None)
+    xo, xr, ol, rl, n0, m0 = _split_batch()[0]
+    if rank == 0:
+        with tr.local_only():
+            assert not tr.dist_on and tr.world == 1 and model._grad_ready_hook is None and model._bn_sync is None
+            solo = float(tr.losses(model(xo[:n0], xr[:m0], ol[:n0], rl[:m0])).detach())
+        assert tr.dist_on and tr.world == 2 and model._grad_ready_hook is not None
+        out['solo'] = solo
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)                                              # the next collective both ranks issue must still pair up
+    out['after'] = float(t)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_losses_global_normalisers_world_size_2():
+    """lib/losses.py:34-63,74 on a split batch: per-rank losses with GLOBAL normalisers + all-reduce(SUM) of the gradients
+    = the single-process loss / gradient on the concatenated batch, for all three loss types (oracle restatement, pinned by
+    tests/golden/losses.npz)."""
+    from oracle import sgg_oracle as O
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0]['after'] == res[1]['after'] == 3.0
+    for ci, (xo, xr, ol, rl, n0, m0) in enumerate(_split_batch()):
+        for lt, lw in (('baseline', (1, 1, 0.5)), ('dnorm', (1.0, 0.7, 2.0)), ('dnorm-fgbg', (0.3, 1.5, 1.0))):
+            model = _Heads()
+            r = model(xo, xr, ol, rl)
+            ref = O.node_losses(r.rm_obj_dists, r.rm_obj_labels) + O.edge_losses(r.rel_dists, r.rel_labels[:, -1], lt, lw)
+            ref.backward()
+            l0, g0 = res[0][(ci, lt)]
+            l1, g1 = res[1][(ci, lt)]
+            assert abs(l0 + l1 - float(ref)) < 1e-5 * max(1.0, abs(float(ref))), (ci, lt, l0, l1, float(ref))
+            for n, p in model.named_parameters():
+                torch.testing.assert_close(torch.tensor(g0[n]), p.grad, atol=1e-6, rtol=1e-5)
+                torch.testing.assert_close(torch.tensor(g1[n]), p.grad, atol=1e-6, rtol=1e-5)
+    # the solo loss uses rank 0's LOCAL normalisers
+    xo, xr, ol, rl, n0, m0 = _split_batch()[0]
+    model = _Heads()
+    r = model(xo[:n0], xr[:m0], ol[:n0], rl[:m0])
+    ref = O.node_losses(r.rm_obj_dists, r.rm_obj_labels) + O.edge_losses(r.rel_dists, r.rel_labels[:, -1], 'baseline', (1, 1, 1))
+    assert abs(res[0]['solo'] - float(ref)) < 1e-5
+
+
+def test_bench_launcher_spawns_ranks_dry():
+    """`python bench.py --gpus 2 --dry` (no rank environment): the parent starts 2 ranks before touching the GPU, they form a
+    group, and rank 0's JSON line -- the last line on stdout -- says n_gpus 2.  A mismatch between --gpus and WORLD_SIZE fails."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry', '--steps', '4'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['steps'] == 4 and line['config']['global_batch'] == 16
+    bad = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--dry'], env=dict(env, WORLD_SIZE='2', RANK='0'),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and 'WORLD_SIZE' in bad.stderr
+    # the contract of torch.distributed.run (what the driver uses for N > 1) gives the same line
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--dry'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads([l for l in r.stdout.strip().splitlines() if l.startswith('{')][-1])['n_gpus'] == 2
+
+
+def test_bf16_wire_sum_error_bound_8_ranks():
+    """GradBuckets sums the big gradients in bf16 on the wire.  Bound for 8 ranks, worst case = a chain of 7 bf16 additions (ring
+    reduce-scatter: every hop adds two bf16 numbers and rounds): against the fp32 sum of the fp32 gradients the error stays
+    below 8 half-ulps of the LARGEST partial sum per element, and below 1 % of the gradient's norm overall."""
+    g = torch.Generator().manual_seed(3)
+    base = torch.randn(1 << 16, generator=g)                               # the common part of the ranks' gradients
+    grads = [base + 0.5 * torch.randn(1 << 16, generator=g) for _ in range(8)]
+    exact = torch.stack(grads).double().sum(0)
+    acc = grads[0].to(torch.bfloat16)
+    part = grads[0].double().abs()
+    for t in grads[1:]:
+        acc = acc + t.to(torch.bfloat16)                                   # bf16 + bf16 -> bf16 (one rounding per hop)
+        part = torch.maximum(part, acc.double().abs())
+    err = (acc.double() - exact).abs()
+    eps = 2.0 ** -8                                                        # bf16: 8 significand bits -> half-ulp = 2^-9 relative
+    assert bool((err <= 8 * eps * part + 1e-30).all())
+    assert float(err.norm() / exact.norm()) < 1e-2
