@@ -668,6 +668,312 @@ __global__ __launch_bounds__(SL_THREADS) void imp_sliced_kernel(const T* __restr
 #undef SGG_TICK
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent, software-pipelined form of the sliced step: the kernel the forward runs.
+//
+// Same unit of work as imp_sliced_kernel -- (graph, 64-byte slice of the rows) -- and the same arithmetic in the same
+// order, so the two are bit-identical.  What changes is WHEN memory is touched.  The short-lived form pays, per unit, three
+// dependent load levels (graph tables -> lists / vertex pieces -> edge rows) with nothing of its own in flight, then
+// computes, then stores: 70 us at B=128 for 43 us of traffic.  Here a workgroup is resident (<= 2 per CU) and walks its
+// XCD's units; while unit u is in its gate / accumulate phase (VALU + LDS), the loads of unit u+1 are already in flight:
+//
+//     iteration u:
+//       1. park B(u); barrier             lists / vertex pieces / vertex dots of u (loaded one iteration ago) into ITS copy of the
+//                                         small arrays (two copies, 4.7 KB each: stragglers of phase 2(u-1) still read the other)
+//       2. issue A(u+1)                   out-list range of this lane group's node in unit u+1
+//       3. phase 1(u)                     rows of u are in registers (issued one iteration ago): gates, e_in stores, park
+//       4. issue B(u+1), C(u+1)           small arrays and the first U edge rows of u+1 per lane group (+ scalar header of u+2)
+//       5. barrier;  phase 2(u) from LDS; ctx store          -- B(u+1), C(u+1) are in flight under all of this
+//
+// Two barriers per unit; the header (node / edge offsets) runs two units ahead on the scalar unit.
+template <int LP> constexpr int stream_small_bytes(int emax, int nmax) {
+    return emax * 2 + nmax * (LP * 16) + nmax * 16 + (nmax + 4) * 4;
+}
+template <int LP> constexpr int stream_lds_bytes(int emax, int nmax) {
+    return emax * (LP * 16 + 4) + 2 * stream_small_bytes<LP>(emax, nmax);
+}
+
+template <typename T, int LP>
+__global__ __launch_bounds__(SL_THREADS, SL_THREADS / 128) void imp_stream_kernel(
+    const T* __restrict__ v, const T* __restrict__ e, const int* __restrict__ so, const int* __restrict__ in_ptr,
+    const int* __restrict__ in_ids, const int* __restrict__ img_ptr, int B, int N, int H, const float* __restrict__ ndots,
+    const float* __restrict__ edots, const float* __restrict__ gb, T* __restrict__ e_in, T* __restrict__ ctx2, int EMAX, int NMAX,
+    int sum_ctx) {
+    constexpr int PIECE = LP * 16, CHL = 16 / (int)sizeof(T), GROUPS = SL_THREADS / LP;
+    constexpr int U = 8, INL = 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* stage = smem;                                                        // [EMAX][PIECE] parked row pieces
+    float* gin = reinterpret_cast<float*>(stage + (long)EMAX * PIECE);         // [EMAX] g_in of each edge
+    char* small0 = reinterpret_cast<char*>(gin + EMAX);
+    const int small_bytes = EMAX * 2 + NMAX * PIECE + NMAX * 16 + (NMAX + 4) * 4;
+    // copy `par` of the small arrays: in_loc u16[EMAX] | vs [NMAX][PIECE] | nd f32[NMAX][4] | iptr int[NMAX+4]
+    auto sm_inloc = [&](int par) { return reinterpret_cast<unsigned short*>(small0 + par * small_bytes); };
+    auto sm_vs = [&](int par) { return small0 + par * small_bytes + EMAX * 2; };
+    auto sm_nd = [&](int par) { return reinterpret_cast<float*>(small0 + par * small_bytes + EMAX * 2 + NMAX * PIECE); };
+    auto sm_iptr = [&](int par) { return reinterpret_cast<int*>(small0 + par * small_bytes + EMAX * 2 + NMAX * PIECE + NMAX * 16); };
+
+    const int S = H * (int)sizeof(T) / PIECE, units = B * S;
+    // this workgroup's units: XCD x (dispatch puts block b on XCD b % 8) owns a contiguous range of units, so that the
+    // slices of a graph -- which share its tables, dots and the other half of every 128-byte line -- meet in one L2
+    const int G = (int)gridDim.x, x = (int)blockIdx.x % 8, w = (int)blockIdx.x / 8;
+    const int wx = G / 8 + (x < G % 8 ? 1 : 0);
+    const int uq = units / 8, ur = units % 8;
+    const int cnt = uq + (x < ur ? 1 : 0), base = x * uq + min(x, ur);
+    if (w >= cnt) return;
+    const int tid = threadIdx.x, sub = tid % LP, grp = tid / LP;
+    constexpr int GI = LP >= 4 ? 1 : 2;
+    int gk[GI];
+    float bias[GI];
+#pragma unroll
+    for (int i = 0; i < GI; ++i) {
+        gk[i] = LP >= 4 ? (sub & 3) : (sub & 1) + 2 * i;
+        bias[i] = gb[gk[i]];
+    }
+
+    // ---- per-unit facts.  Header: offsets of the unit's graph (uniform -> scalar loads).
+    struct Hdr { int g, slice, n0, Nn, e0, Ee, bad; };
+    auto load_hdr = [&](int idx) {
+        Hdr h;
+        const int L = base + idx;
+        h.g = L / S;
+        h.slice = L - h.g * S;
+        h.n0 = img_ptr[h.g];
+        h.Nn = img_ptr[h.g + 1] - h.n0;
+        h.e0 = img_ptr[B + 1 + h.g];
+        h.Ee = img_ptr[B + 2 + h.g] - h.e0;
+        // the host's promise about this graph (edge_csr(graphs=...)) does not hold: nothing may be parked.  Its outputs are
+        // poisoned (below) and the unit runs as an empty graph.
+        h.bad = (h.Ee > EMAX || h.Nn > NMAX || h.Nn > SL_NMAX) ? 1 : 0;
+        return h;
+    };
+    // how the lane groups share the nodes of a graph: P groups per node (P a power of two, inside one wave)
+    struct Own { int P, part, n, has_node; long col; };
+    auto own_of = [&](const Hdr& h) {
+        Own o;
+        const int Nn = h.bad ? 0 : h.Nn;
+        int P = 1;
+        while (2 * P * LP <= 64 && 2 * P * Nn <= GROUPS) P *= 2;
+        o.P = P;
+        o.part = grp % P;
+        o.n = grp / P;
+        o.has_node = o.n < Nn;
+        o.col = (long)h.slice * (PIECE / (int)sizeof(T)) + sub * CHL;
+        return o;
+    };
+
+    // ---- prefetch registers
+    int a_ob = 0, a_oe = 0;                                  // A: this lane group's node's out-list range (graph-local)
+    u32x4 p_v = {0, 0, 0, 0};                                // B
+    f32x4 p_nd = {0, 0, 0, 0};
+    int p_ip = 0, p_in[INL];
+    Piece16<T> row[U];                                       // C
+    float de[U][GI];
+    int on[U];
+    int k0 = 0, k1 = 0;
+
+    auto issue_A = [&](const Hdr& h, const Own& o) {
+        const int* tab = img_ptr + 2 * (B + 1) + (long)h.g * (SL_NMAX + 2);
+        const int nc = min(o.n, SL_NMAX);
+        a_ob = tab[nc];
+        a_oe = tab[nc + 1];
+    };
+    auto issue_B = [&](const Hdr& h, const Own& o) {
+        const int Nn = h.bad ? 0 : h.Nn, Ee = h.bad ? 0 : h.Ee;
+        if (grp < Nn) p_v = *reinterpret_cast<const u32x4*>(v + (long)(h.n0 + grp) * H + o.col);
+        if (tid < Nn) p_nd = *reinterpret_cast<const f32x4*>(ndots + (long)(h.n0 + tid) * 4);
+        if (tid <= Nn) p_ip = in_ptr[h.n0 + tid] - h.e0;
+#pragma unroll
+        for (int q = 0; q < INL; ++q) p_in[q] = (tid + q * SL_THREADS < Ee) ? in_ids[h.e0 + tid + q * SL_THREADS] - h.e0 : 0;
+    };
+    auto park_B = [&](const Hdr& h, int par) {
+        const int Nn = h.bad ? 0 : h.Nn, Ee = h.bad ? 0 : h.Ee;
+        if (grp < Nn) *reinterpret_cast<u32x4*>(sm_vs(par) + grp * PIECE + sub * 16) = p_v;
+        if (tid < Nn) *reinterpret_cast<f32x4*>(sm_nd(par) + tid * 4) = p_nd;
+        if (tid <= Nn) sm_iptr(par)[tid] = p_ip;
+        unsigned short* in_loc = sm_inloc(par);
+#pragma unroll
+        for (int q = 0; q < INL; ++q)
+            if (tid + q * SL_THREADS < Ee) in_loc[tid + q * SL_THREADS] = (unsigned short)p_in[q];
+        for (int k = tid + INL * SL_THREADS; k < Ee; k += SL_THREADS) in_loc[k] = (unsigned short)(in_ids[h.e0 + k] - h.e0);
+    };
+    auto issue_rows = [&](const Hdr& h, const Own& o, int kb, int kend) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ec = h.e0 + max(min(kb + u, kend - 1), 0);
+            row[u].r = *reinterpret_cast<const decltype(row[u].r)*>(e + (long)ec * H + o.col);
+#pragma unroll
+            for (int i = 0; i < GI; ++i) de[u][i] = edots[(long)ec * 4 + gk[i]];
+            on[u] = so[2 * (long)ec + 1] - h.n0;
+        }
+    };
+    auto range_C = [&](const Hdr& h, const Own& o) {         // this lane group's part of its node's out-list
+        const int ob = o.has_node ? a_ob : 0, oe = o.has_node ? a_oe : 0;
+        const int chunk = (oe - ob + o.P - 1) / o.P;
+        k0 = ob + o.part * chunk;
+        k1 = min(oe, k0 + chunk);
+    };
+    auto poison = [&](const Hdr& h, const Own& o) {
+        float nanv[CHL];
+#pragma unroll
+        for (int j = 0; j < CHL; ++j) nanv[j] = __builtin_nanf("");
+        for (int k = grp; k < h.Ee; k += GROUPS) Piece16<T>::store(e_in + (long)(h.e0 + k) * H + o.col, nanv);
+        for (int k = grp; k < h.Nn; k += GROUPS) {
+            Piece16<T>::store(ctx2 + (long)(h.n0 + k) * H + o.col, nanv);
+            if (!sum_ctx) Piece16<T>::store(ctx2 + ((long)N + h.n0 + k) * H + o.col, nanv);
+        }
+    };
+
+    // ---- prologue: the first unit's chain is exposed once per workgroup
+    int idx = w, par = 0;
+    Hdr hc = load_hdr(idx);
+    Own oc = own_of(hc);
+    Hdr hn = hc;                                             // header of unit u+1 (valid when idx + wx < cnt)
+    if (idx + wx < cnt) hn = load_hdr(idx + wx);
+    issue_A(hc, oc);
+    issue_B(hc, oc);
+    range_C(hc, oc);
+    if (k0 < k1) issue_rows(hc, oc, k0, k1);
+
+    for (;;) {
+        const bool more = idx + wx < cnt;                    // uniform
+        park_B(hc, par);                                     // into this unit's copy: stragglers of the last unit's phase 2 read the other
+        if (hc.bad) poison(hc, oc);
+        __syncthreads();                                     // (1) small arrays of this unit visible; stage / gin free again
+        Own onx = oc;
+        if (more) {
+            onx = own_of(hn);
+            issue_A(hn, onx);
+        }
+        const char* vs = sm_vs(par);
+        const float* nd = sm_nd(par);
+        // ---- phase 1: out-lists
+        float out_sum[CHL];
+#pragma unroll
+        for (int j = 0; j < CHL; ++j) out_sum[j] = 0.f;
+        if (oc.has_node) {
+            const int n = oc.n;
+            Piece16<T> vnp;
+            vnp.r = *reinterpret_cast<const decltype(vnp.r)*>(vs + n * PIECE + sub * 16);
+            float vn[CHL], acc[CHL];
+            vnp.get(vn);
+#pragma unroll
+            for (int j = 0; j < CHL; ++j) acc[j] = 0.f;
+            float ndn[GI];
+#pragma unroll
+            for (int i = 0; i < GI; ++i) ndn[i] = nd[n * 4 + gk[i]];
+            for (int kb = k0; kb < k1; kb += U) {
+                if (kb != k0) issue_rows(hc, oc, kb, k1);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int el = kb + u;
+                    const bool live = el < k1;
+                    float gate[GI];
+#pragma unroll
+                    for (int i = 0; i < GI; ++i) {
+                        const float vd = (gk[i] & 1) ? nd[on[u] * 4 + gk[i]] : ndn[i];
+                        gate[i] = sigmoidf_(vd + de[u][i] + bias[i]);
+                    }
+                    float gs, go, gx;
+                    if constexpr (LP >= 4) {
+                        gs = quad_bcast<0x00>(gate[0]);
+                        go = quad_bcast<0x55>(gate[0]);
+                        gx = quad_bcast<0xAA>(gate[0]);
+                        if (live && sub == 3) gin[el] = gate[0];
+                    } else {
+                        gs = quad_bcast<0xA0>(gate[0]);
+                        go = quad_bcast<0xF5>(gate[0]);
+                        gx = quad_bcast<0xA0>(gate[1]);
+                        if (live && sub == 1) gin[el] = gate[1];
+                    }
+                    if (live) {
+                        *reinterpret_cast<decltype(row[u].r)*>(stage + (long)el * PIECE + sub * 16) = row[u].r;
+                        Piece16<T> vop;
+                        vop.r = *reinterpret_cast<const decltype(vop.r)*>(vs + on[u] * PIECE + sub * 16);
+                        float xx[CHL], yy[CHL], rr[CHL];
+                        row[u].get(xx);
+                        vop.get(yy);
+#pragma unroll
+                        for (int j = 0; j < CHL; ++j) {
+                            rr[j] = gs * vn[j] + go * yy[j];
+                            acc[j] = fmaf(gx, xx[j], acc[j]);
+                        }
+                        Piece16<T>::store(e_in + (long)(hc.e0 + el) * H + oc.col, rr);
+                    }
+                    if (u & 1) __builtin_amdgcn_sched_barrier(0);   // two edges at a time: eight interleaved cost 40 more VGPRs than the budget has
+                }
+            }
+            for (int off = LP; off < oc.P * LP; off <<= 1) {
+#pragma unroll
+                for (int j = 0; j < CHL; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+            }
+            if (sum_ctx) {
+#pragma unroll
+                for (int j = 0; j < CHL; ++j) out_sum[j] = acc[j];
+            } else if (oc.part == 0) {
+                Piece16<T>::store(ctx2 + (long)(hc.n0 + n) * H + oc.col, acc);
+            }
+        }
+        // ---- the next unit's rows go out now and fly under phase 2; its small arrays are parked in the other copy
+        Hdr hnn = hn;
+        if (more) {
+            issue_B(hn, onx);
+            range_C(hn, onx);
+            if (k0 < k1) issue_rows(hn, onx, k0, k1);
+            if (idx + 2 * wx < cnt) hnn = load_hdr(idx + 2 * wx);
+        }
+        __syncthreads();                                     // (2) parked pieces + g_in of this unit visible
+        // ---- phase 2: in-lists, from the parked pieces
+        if (oc.has_node) {
+            const int n = oc.n;
+            const int* iptr = sm_iptr(par);
+            const unsigned short* in_loc = sm_inloc(par);
+            const int beg = iptr[n], end = iptr[n + 1], ch = (end - beg + oc.P - 1) / oc.P;
+            const int j0 = beg + oc.part * ch, j1 = min(end, j0 + ch);
+            float acc[CHL];
+#pragma unroll
+            for (int j = 0; j < CHL; ++j) acc[j] = 0.f;
+            constexpr int U2 = 4;
+            for (int kb = j0; kb < j1; kb += U2) {
+                int el[U2];
+#pragma unroll
+                for (int u = 0; u < U2; ++u) el[u] = in_loc[min(kb + u, j1 - 1)];
+                Piece16<T> rw[U2];
+                float gv[U2];
+#pragma unroll
+                for (int u = 0; u < U2; ++u) {
+                    rw[u].r = *reinterpret_cast<const decltype(rw[u].r)*>(stage + (long)el[u] * PIECE + sub * 16);
+                    gv[u] = (kb + u < j1) ? gin[el[u]] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U2; ++u) {
+                    float xx[CHL];
+                    rw[u].get(xx);
+#pragma unroll
+                    for (int j = 0; j < CHL; ++j) acc[j] = fmaf(gv[u], xx[j], acc[j]);
+                }
+            }
+            for (int off = LP; off < oc.P * LP; off <<= 1) {
+#pragma unroll
+                for (int j = 0; j < CHL; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+            }
+            if (sum_ctx) {
+#pragma unroll
+                for (int j = 0; j < CHL; ++j) acc[j] += out_sum[j];
+                if (oc.part == 0) Piece16<T>::store(ctx2 + (long)(hc.n0 + n) * H + oc.col, acc);
+            } else if (oc.part == 0) {
+                Piece16<T>::store(ctx2 + ((long)N + hc.n0 + n) * H + oc.col, acc);
+            }
+        }
+        if (!more) break;
+        idx += wx;
+        par ^= 1;
+        hc = hn;
+        oc = onx;
+        hn = hnn;
+    }
+}
+
 }  // namespace
 
 #define SGG_DISPATCH_T(dtype, CALL_BF16, CALL_F32) \
@@ -791,6 +1097,30 @@ int launch_sliced(const void* v, const void* e, const int* so, const int* out_pt
                        in_ids, img_ptr, B, N, H, ndots, edots, gb, (T*)e_in, (T*)ctx2, emax, sum_ctx);
     return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
 }
+
+// persistent form: <= 2 resident workgroups per CU walk the units of their XCD (imp_stream_kernel)
+template <typename T, int LP>
+int launch_stream(const void* v, const void* e, const int* so, const int* in_ptr, const int* in_ids, const int* img_ptr, int B, int N,
+                  int H, const float* ndots, const float* edots, const float* gb, void* e_in, void* ctx2, int max_edges, int max_nodes,
+                  int sum_ctx, int max_wgs, hipStream_t s) {
+    auto k = imp_stream_kernel<T, LP>;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                stream_lds_bytes<LP>(SliceCfg<LP>::EMAX, SL_NMAX)) != hipSuccess)
+            return SGG_ERR_LAUNCH;
+        configured = true;
+    }
+    const int emax = (max(max_edges, 8) + 7) & ~7, nmax = (max(max_nodes, 8) + 7) & ~7;
+    const int lds = stream_lds_bytes<LP>(emax, nmax);
+    const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;       // register budget (<= 128 VGPRs) allows two 8-wave workgroups
+    const int S = H * (int)sizeof(T) / (LP * 16), units = B * S;
+    int grid = min(units, 256 * per_cu);
+    if (max_wgs > 0) grid = min(grid, max_wgs);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(SL_THREADS), lds, s, (const T*)v, (const T*)e, so, in_ptr, in_ids, img_ptr, B, N, H, ndots,
+                       edots, gb, (T*)e_in, (T*)ctx2, emax, nmax, sum_ctx);
+    return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
+}
 }  // namespace
 
 extern "C" int sgg_graph_ptr(const int64_t* im_inds, int N, int B, const int* out_ptr, int* img_ptr, void* stream) {
@@ -833,6 +1163,26 @@ extern "C" int sgg_imp_sliced_fwd(const void* v, const void* e, const int* so, c
         if ((f == 8 || f == 4 || f == 2) && row % (f * 16) == 0 &&
             max_edges <= (f == 8 ? SliceCfg<8>::EMAX : f == 4 ? SliceCfg<4>::EMAX : SliceCfg<2>::EMAX))
             lp = f;
+    }
+    // SGG_IMP_STREAM=0: the short-lived form (one workgroup per unit), kept as the cross-check of the persistent kernel;
+    // SGG_IMP_MAX_WGS=n caps the persistent grid (tests: several units per workgroup on small batches)
+    const char* st = getenv("SGG_IMP_STREAM");
+    if (st && st[0] == '1') {
+        const char* mw = getenv("SGG_IMP_MAX_WGS");
+        const int max_wgs = mw ? atoi(mw) : 0;
+#define SGG_STREAM(T, LPV) \
+    return launch_stream<T, LPV>(v, e, so, in_ptr, in_ids, img_ptr, B, N, H, node_dots, edge_dots, gate_b, e_in, ctx2, max_edges, \
+                                 max_nodes, sum_ctx, max_wgs, s)
+        if (dtype == SGG_BF16) {
+            if (lp == 8) SGG_STREAM(bf16_t, 8);
+            if (lp == 4) SGG_STREAM(bf16_t, 4);
+            SGG_STREAM(bf16_t, 2);
+        } else {
+            if (lp == 8) SGG_STREAM(float, 8);
+            if (lp == 4) SGG_STREAM(float, 4);
+            SGG_STREAM(float, 2);
+        }
+#undef SGG_STREAM
     }
 #define SGG_SLICED(T, LPV) \
     return launch_sliced<T, LPV>(v, e, so, out_ptr, in_ptr, in_ids, img_ptr, B, N, H, node_dots, edge_dots, gate_b, e_in, ctx2, \

@@ -56,3 +56,16 @@ def synthetic_batch(B=8, S=592, n_boxes=32, n_fg=6, seed=111, ragged=False):
     im_sizes = np.array([[S, S, 1.0]] * B)
     return (imgs, im_sizes, 0, torch.from_numpy(np.concatenate(boxes)), torch.from_numpy(np.concatenate(classes)),
             torch.from_numpy(np.array(rels, dtype=np.int64)), None, ['synthetic%d' % b for b in range(B)])
+
+
+def shard_batch(batch, lo, hi):
+    """Images [lo, hi) of a Blob-layout tuple as a batch of their own (image ids renumbered from 0): the shard rank r of a
+    data-parallel job holds when the global batch is `batch` (rank r takes images [r*B, (r+1)*B))."""
+    imgs, im_sizes, off, boxes, classes, rels, props, fns = batch
+    keep = (classes[:, 0] >= lo) & (classes[:, 0] < hi)
+    cls = classes[keep].clone()
+    cls[:, 0] -= lo
+    rk = (rels[:, 0] >= lo) & (rels[:, 0] < hi)
+    r = rels[rk].clone()
+    r[:, 0] -= lo
+    return (list(imgs[lo:hi]), im_sizes[lo:hi], off, boxes[keep].clone(), cls, r, props, list(fns[lo:hi]))

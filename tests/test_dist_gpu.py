@@ -1,0 +1,112 @@
+"""The data-parallel train step at WORLD SIZE 2 on one MI355X: two processes share cuda:0 and talk over gloo (RCCL refuses two
+ranks on one device; the collectives' semantics are the same).  Everything the N-GPU step does runs for real -- gradient hooks
+fired from inside the HIP backward, wire-dtype buffers written by the weight-gradient GEMMs, early all-reduces, the flat bucket,
+synchronised BatchNorm statistics (forward and backward), global loss normalisers, the fused optimiser reading the reduced
+buffers -- and the updated weights of BOTH ranks must equal what ONE process computes on the concatenated batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+S = 96
+NAMES = ['roi_fmap.1.0.weight', 'roi_fmap_obj.0.weight', 'roi_fmap.1.3.weight', 'roi_fmap_obj.3.weight', 'rel_fc.weight', 'obj_fc.bias',
+         'edge_gru.weight_ih', 'node_gru.weight_hh', 'union_boxes.conv.0.weight', 'union_boxes.conv.2.weight', 'union_boxes.conv.6.bias',
+         'sub_vert_w_fc.0.weight', 'edge_unary.weight']
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _global_batch():
+    from sgg_amd.synthetic import synthetic_batch
+    return synthetic_batch(B=4, S=S, n_boxes=7, n_fg=3, seed=21, ragged=True)     # 7, 4, 2, 2 boxes: ragged shards
+
+
+def _one_step(dtype, comm, batch, steps, opts):
+    """-> (losses, {name: updated weight as numpy}, running stats of the first BatchNorm)"""
+    import sgg_amd
+    from sgg_amd.synthetic import SyntheticData, init_weights
+    from sgg_amd.trainer import Trainer
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls', min_size=S, max_size=S)).to('cuda:0')
+    model.set_compute_dtype(dtype)
+    model.dropout_p = 0.0
+    tr = Trainer(model, lr=2e-2, comm_dtype=comm, **opts)
+    losses = [float(tr.step(batch)) for _ in range(steps)]
+    tr.flush()
+    torch.cuda.synchronize()
+    params = dict(model.named_parameters())
+    bn = model.union_boxes.conv[2]
+    return losses, {n: params[n].detach().float().cpu().numpy() for n in NAMES}, bn.running_mean.cpu().numpy(), tr
+
+
+def _worker(rank, world, port, cfg, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from sgg_amd.synthetic import shard_batch
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dtype, comm, steps, opts = cfg
+    g = _global_batch()
+    cut = 1 if rank == 0 else 4                    # rank 0: image 0 (7 boxes, 42 edges); rank 1: images 1..3 (4+2+2 boxes)
+    mine = shard_batch(g, 0 if rank == 0 else 1, cut)
+    losses, w, rm, tr = _one_step(dtype, comm, mine, steps, opts)
+    assert tr.dist_on and tr.world == 2
+    q.put((rank, losses, w, rm))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('cfg', [
+    (torch.float32, None, 1, dict(sync_bn=True)),                      # exact-fp32: pins the DP LOGIC against the concatenated batch
+    (torch.bfloat16, torch.bfloat16, 1, dict(sync_bn=True)),           # the benchmark's form: bf16 compute, bf16 on the wire
+    (torch.bfloat16, torch.bfloat16, 3, dict(sync_bn=True, pipeline=True)),   # + the update queued on the side stream
+], ids=['f32', 'bf16_wire', 'bf16_wire_pipelined'])
+def test_world_size_2_step_equals_single_process_on_concatenated_batch(cfg):
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    dtype, comm, steps, opts = cfg
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, cfg, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in procs:
+        r, losses, w, rm = q.get(timeout=600)
+        got[r] = (losses, w, rm)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ref_losses, ref_w, ref_rm, _ = _one_step(dtype, comm, _global_batch(), steps, {k: v for k, v in opts.items() if k != 'sync_bn'})
+    import sgg_amd
+    from sgg_amd.synthetic import SyntheticData, init_weights
+    w0 = {n: p.detach().float().numpy() for n, p in
+          init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls', min_size=S, max_size=S)).named_parameters() if n in NAMES}
+    exact = dtype == torch.float32
+    # per-rank losses are local sums over GLOBAL normalisers: they add up to the single-process loss
+    for k in range(steps):
+        tot = got[0][0][k] + got[1][0][k]
+        assert abs(tot - ref_losses[k]) <= (1e-4 if exact else 3e-2) * abs(ref_losses[k]), (k, tot, ref_losses[k])
+    tol = 2e-3 if exact else (0.06 if steps == 1 else 0.15)
+    for n in NAMES:
+        step = np.abs(ref_w[n] - w0[n]).max()
+        assert step > 0, n
+        for r in (0, 1):
+            diff = np.abs(got[r][1][n] - ref_w[n]).max()
+            assert diff <= tol * step + 1e-8, (n, r, float(step), float(diff))
+        # both ranks hold the same weights afterwards (same reduced gradients, same update)
+        np.testing.assert_allclose(got[0][1][n], got[1][1][n], rtol=0, atol=1e-6 * max(1.0, float(np.abs(ref_w[n]).max())))
+    # synchronised BatchNorm: every rank's running statistics are those of the concatenated batch
+    for r in (0, 1):
+        np.testing.assert_allclose(got[r][2], ref_rm, atol=1e-4 if exact else 2e-2)
