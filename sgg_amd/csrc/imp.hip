@@ -716,9 +716,9 @@ __global__ __launch_bounds__(SL_THREADS, SL_THREADS / 128) void imp_stream_kerne
     const int S = H * (int)sizeof(T) / PIECE, units = B * S;
     // this workgroup's units: XCD x (dispatch puts block b on XCD b % 8) owns a contiguous range of units, so that the
     // slices of a graph -- which share its tables, dots and the other half of every 128-byte line -- meet in one L2
-    const int G = (int)gridDim.x, x = (int)blockIdx.x % 8, w = (int)blockIdx.x / 8;
-    const int wx = G / 8 + (x < G % 8 ? 1 : 0);
-    const int uq = units / 8, ur = units % 8;
+    const int G = (int)gridDim.x, NX = min(G, 8), x = (int)blockIdx.x % NX, w = (int)blockIdx.x / NX;
+    const int wx = G / NX + (x < G % NX ? 1 : 0);
+    const int uq = units / NX, ur = units % NX;
     const int cnt = uq + (x < ur ? 1 : 0), base = x * uq + min(x, ur);
     if (w >= cnt) return;
     const int tid = threadIdx.x, sub = tid % LP, grp = tid / LP;
@@ -1098,6 +1098,342 @@ int launch_sliced(const void* v, const void* e, const int* so, const int* out_pt
     return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent LDS-DMA form of the sliced step (imp_dma_kernel): the kernel the forward runs.
+//
+// The row pieces of a unit have to sit in LDS anyway (phase 2 walks the in-lists over them), so they are fetched STRAIGHT into
+// LDS (`global_load_lds_dwordx4`: no VGPR round trip, no 13-cycle ds_write_b128 per piece) and both phases read them with
+// ds_read_b128.  One 16-wave workgroup per CU owns two staging buffers: while unit u is in its gate / accumulate phases, the
+// DMA of unit u+1 -- issued the moment the buffer is free -- is in flight.  Everything else a unit needs is fetched ONE
+// COALESCED ELEMENT PER THREAD (thread t <-> edge t: its four gate dots as one 16-byte load, its object node, its in-list
+// entry; thread t <-> node t: list offsets, vertex dots) one unit ahead into 16 registers and parked in LDS at the top of the
+// unit: clock stamps of the first version showed the vector-memory pipe (64 B/clk/CU, one wave-instruction at a time), not
+// HBM, to be what the waves queued on -- 256 four-byte gather instructions per unit for dots and node ids.  A wave waits for
+// memory ONCE per unit (`s_waitcnt vmcnt(0)` at the top of the iteration); phases 1 and 2 touch only LDS and issue stores.
+// Per unit: top wait -> barrier A (every wave has left the last unit) -> park -> barrier B -> issue DMA + fetches of the next
+// unit -> phase 1 (out-lists) -> phase 2 (in-lists), the two phases with NO barrier between them (g_in is recomputed).
+//
+// A node's lists are dealt to its P lane groups round-robin (entry k -> group k % P): at every step the P groups read P
+// consecutive staged rows (conflict-free; contiguous chunks put all of a wave's groups on the same banks).
+//
+// The DMA is issued from inline asm on purpose: hipcc treats a known LDS-DMA as an LDS write that may alias every later LDS
+// read and puts `s_waitcnt vmcnt(0)` in front of each, which would serialise unit u's phases behind unit u+1's DMA.  The
+// compiler's vmcnt bookkeeping therefore does not know about the DMA; that is harmless because every load is consumed after
+// the top wait, which is the builtin (the compiler's scoreboard sees the drain and adds no wait of its own).
+constexpr int DM_THREADS = 1024, DM_LP = 4, DM_PIECE = 64, DM_GROUPS = DM_THREADS / DM_LP, DM_U = 8;
+constexpr int DM_EMAX = DM_THREADS, DM_NMAX = SL_NMAX;     // one edge per thread for the coalesced fetches
+// vsb: bytes of one node's vertex piece in LDS (kept as f32: 128 with bf16 storage, 64 with f32)
+constexpr int dma_lds_bytes(int emax, int nmax, int vsb) {
+    return 2 * emax * DM_PIECE                 // staging buffers
+           + emax * 16 + emax + emax * 2       // gate dots, object node (u8), in-list entries (u16)
+           + nmax * vsb + nmax * 16 + 2 * (nmax + 4) * 4;   // vertex pieces (f32), vertex dots, out- / in-list offsets
+}
+constexpr int DM_LDS_MAX = 160 * 1024;
+static_assert(dma_lds_bytes(1008, 32, 128) <= DM_LDS_MAX, "imp_dma_kernel: LDS budget at the 32-box / 992-edge configuration");
+
+typedef __attribute__((address_space(3))) char lds_char_t;
+
+// 64 lanes x 16 bytes from per-lane global addresses into 1 KiB of LDS at `lds_base` (wave-uniform)
+__device__ __forceinline__ void dma16_to_lds(const void* gptr, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_base), "v"(gptr) : "memory");
+}
+
+#ifndef SGG_DMA_ABL
+#define SGG_DMA_ABL 0     // kernel experiments only: 1 copy only (staged piece in, piece out), 2 no e_in stores, 3 no DMA after the first unit
+#endif
+#ifdef SGG_DMA_TICKS     // kernel experiments only: clock stamps of the first 8 workgroups (one per XCD), wave 0, 16 units x 8 stamps
+__device__ long long g_dma_ticks[8 * 16 * 8];
+#define SGG_DTICK(i)                                                                                          \
+    if (blockIdx.x < 8 && threadIdx.x == 0 && unit_no < 16) g_dma_ticks[(blockIdx.x * 16 + unit_no) * 8 + (i)] = clock64();
+#else
+#define SGG_DTICK(i)
+#endif
+
+template <typename T>
+__global__ __launch_bounds__(DM_THREADS) void imp_dma_kernel(
+    const T* __restrict__ v, const T* __restrict__ e, const int* __restrict__ so, const int* __restrict__ in_ptr,
+    const int* __restrict__ in_ids, const int* __restrict__ img_ptr, int B, int N, int H, const float* __restrict__ ndots,
+    const float* __restrict__ edots, const float* __restrict__ gb, T* __restrict__ e_in, T* __restrict__ ctx2, int EMAX, int NMAX,
+    int sum_ctx) {
+    constexpr int LP = DM_LP, PIECE = DM_PIECE, CHL = 16 / (int)sizeof(T), GROUPS = DM_GROUPS, U = DM_U;
+    constexpr int VSB = CHL * 4 * LP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS map (EMAX a multiple of 16, NMAX of 8: every array 16-byte aligned)
+    char* const stage0 = smem;                                                       // [2][EMAX][64 B]
+    float* const dots = reinterpret_cast<float*>(stage0 + 2L * EMAX * PIECE);        // [EMAX][4] gate dots of every edge
+    unsigned char* const onl8 = reinterpret_cast<unsigned char*>(dots + 4L * EMAX);  // [EMAX] graph-local object node
+    char* const vs = reinterpret_cast<char*>(onl8 + EMAX);                            // [NMAX][VSB] vertex pieces as f32
+    float* const nd = reinterpret_cast<float*>(vs + NMAX * VSB);                      // [NMAX][4]
+    int* const optr = reinterpret_cast<int*>(nd + NMAX * 4);                          // [NMAX+4] out-list offsets (graph-local)
+    int* const iptr = optr + NMAX + 4;                                                // [NMAX+4] in-list offsets (graph-local)
+    unsigned short* const in_loc = reinterpret_cast<unsigned short*>(iptr + NMAX + 4);   // [EMAX] in-list entries (graph-local edge)
+    const unsigned stage_lds = (unsigned)(unsigned long)(lds_char_t*)smem;
+
+    const int S = H * (int)sizeof(T) / PIECE, units = B * S;
+    // this workgroup's units: XCD x (dispatch puts block b on XCD b % 8) owns a contiguous range of units, so that the
+    // slices of a graph -- which share its tables, dots and the other half of every 128-byte line -- meet in one L2
+    const int G = (int)gridDim.x, NX = min(G, 8), x = (int)blockIdx.x % NX, w = (int)blockIdx.x / NX;
+    const int wx = G / NX + (x < G % NX ? 1 : 0);
+    const int uq = units / NX, ur = units % NX;
+    const int cnt = uq + (x < ur ? 1 : 0), base = x * uq + min(x, ur);
+    if (w >= cnt) return;
+    const int tid = threadIdx.x, sub = tid % LP, grp = tid / LP, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gk = sub & 3;
+    const float bias = gb[gk];
+
+    struct Hdr { int g, slice, n0, Nn, e0, Ee; };          // Ee < 0: the host's promise about this graph is broken (see poison)
+    // (graph, slice) of unit `base + idx`, stepped from the last header loaded: no integer division on the per-unit path
+    int lg = base / S, lslice = base - lg * S, lidx = 0;
+    auto load_hdr = [&](int idx) {
+        Hdr h;
+        lslice += idx - lidx;
+        lidx = idx;
+        while (lslice >= S) {
+            lslice -= S;
+            ++lg;
+        }
+        h.g = lg;
+        h.slice = lslice;
+        h.n0 = img_ptr[h.g];
+        h.Nn = img_ptr[h.g + 1] - h.n0;
+        h.e0 = img_ptr[B + 1 + h.g];
+        h.Ee = img_ptr[B + 2 + h.g] - h.e0;
+        if (h.Ee > EMAX || h.Nn > NMAX || h.Nn > SL_NMAX) {              // nothing may be staged: outputs poisoned, unit runs empty
+            h.Nn = 0;
+            h.Ee = -1;
+        }
+        return h;
+    };
+    auto col_of = [&](const Hdr& h) { return (long)h.slice * (PIECE / (int)sizeof(T)) + sub * CHL; };   // this lane's first channel
+    auto issue_dma = [&](const Hdr& h, int par) {            // the unit's row pieces -> stage[par], 16 edges per wave-instruction
+        const int nch = (h.Ee + 15) >> 4;
+        const char* src = reinterpret_cast<const char*>(e + col_of(h));
+        for (int c = wv; c < nch; c += DM_THREADS / 64) {
+            const int el = min(c * 16 + (lane >> 2), h.Ee - 1);
+            dma16_to_lds(src + (long)(h.e0 + el) * H * (int)sizeof(T), stage_lds + (unsigned)(par * EMAX * PIECE + c * 1024));
+        }
+    };
+    // prefetch registers: thread t <-> edge t / node t of the NEXT unit.  Values stay raw (offsets are subtracted when they
+    // are parked): arithmetic on a loaded value would make the compiler wait for the load where it was issued.
+    f32x4 p_de = {0, 0, 0, 0}, p_nd = {0, 0, 0, 0};
+    u32x4 p_v = {0, 0, 0, 0};
+    // the four single-dword fetches live in ONE 128-bit register tuple: a lone VGPR with a load in flight can end up as the
+    // unused upper half of a broadcast operand pair of v_pk_fma_f32 (op_sel_hi = 0), and the compiler then waits for that load
+    // -- vmcnt(0), DMA included -- in the middle of a phase
+    u32x4 p_misc = {0, 0, 0, 0};                             // x: object node of edge t, y: in-list entry t, z: in-list offset, w: out-list offset
+    auto issue_small = [&](const Hdr& h) {
+        if (tid < h.Ee) {
+            p_de = *reinterpret_cast<const f32x4*>(edots + (long)(h.e0 + tid) * 4);
+            p_misc.x = (unsigned)so[2 * (long)(h.e0 + tid) + 1];
+            p_misc.y = (unsigned)in_ids[h.e0 + tid];
+        }
+        if (tid <= h.Nn) {
+            p_misc.z = (unsigned)in_ptr[h.n0 + tid];
+            p_misc.w = (unsigned)img_ptr[2 * (B + 1) + (long)h.g * (SL_NMAX + 2) + tid];   // graph-local already
+        }
+        if (tid < h.Nn) p_nd = *reinterpret_cast<const f32x4*>(ndots + (long)(h.n0 + tid) * 4);
+        if (grp < h.Nn) p_v = *reinterpret_cast<const u32x4*>(v + (long)(h.n0 + grp) * H + col_of(h));
+    };
+    auto park_small = [&](const Hdr& h) {
+        if (tid < h.Ee) {
+            *reinterpret_cast<f32x4*>(dots + 4 * tid) = p_de;
+            onl8[tid] = (unsigned char)((int)p_misc.x - h.n0);
+            in_loc[tid] = (unsigned short)((int)p_misc.y - h.e0);
+        }
+        if (tid <= h.Nn) {
+            iptr[tid] = (int)p_misc.z - h.e0;
+            optr[tid] = (int)p_misc.w;
+        }
+        if (tid < h.Nn) *reinterpret_cast<f32x4*>(nd + tid * 4) = p_nd;
+        if (grp < h.Nn) {                                  // unpacked once per unit: phase 1 reads a vertex piece per EDGE
+            Piece16<T> pv;
+            pv.r = __builtin_bit_cast(decltype(pv.r), p_v);
+            float f[CHL];
+            pv.get(f);
+            float* dst = reinterpret_cast<float*>(vs + grp * VSB) + sub * CHL;
+#pragma unroll
+            for (int j = 0; j < CHL; j += 4) *reinterpret_cast<f32x4*>(dst + j) = f32x4{f[j], f[j + 1], f[j + 2], f[j + 3]};
+        }
+    };
+    auto poison = [&](const Hdr& h) {                        // re-reads the raw offsets: the header was emptied
+        const int g = h.g;
+        const long col = col_of(h);
+        const int n0 = img_ptr[g], Nn = img_ptr[g + 1] - n0, e0 = img_ptr[B + 1 + g], Ee = img_ptr[B + 2 + g] - e0;
+        float nanv[CHL];
+#pragma unroll
+        for (int j = 0; j < CHL; ++j) nanv[j] = __builtin_nanf("");
+        for (int k = grp; k < Ee; k += GROUPS) Piece16<T>::store(e_in + (long)(e0 + k) * H + col, nanv);
+        for (int k = grp; k < Nn; k += GROUPS) {
+            Piece16<T>::store(ctx2 + (long)(n0 + k) * H + col, nanv);
+            if (!sum_ctx) Piece16<T>::store(ctx2 + ((long)N + n0 + k) * H + col, nanv);
+        }
+    };
+
+    // ---- prologue: header (scalar) -> DMA + per-thread fetches (one vector level) of the first unit, exposed once
+    int idx = w, par = 0;
+    Hdr hc = load_hdr(idx), hn = hc, hnn = hc;               // (headers are loaded in increasing unit order)
+    issue_dma(hc, 0);
+    issue_small(hc);
+    if (idx + wx < cnt) hn = load_hdr(idx + wx);
+    if (idx + 2 * wx < cnt) hnn = load_hdr(idx + 2 * wx);
+    int unit_no = 0;
+    (void)unit_no;
+    char* const e_in_c = reinterpret_cast<char*>(e_in);
+    const unsigned rowb = (unsigned)H * (unsigned)sizeof(T);
+
+    for (;;) {
+        const bool more = idx + wx < cnt;                                // uniform
+        SGG_DTICK(0)
+        // this unit's DMA and small fetches; last unit's stores.  The builtin (not asm): the compiler's own scoreboard must see
+        // the drain, or it waits again -- with counts that ignore the DMA -- at the first use of every prefetched register.
+        __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0) only
+        asm volatile("" ::: "memory");
+        SGG_DTICK(1)
+        __syncthreads();                                                 // (A) every wave has left the last unit: its small arrays are free
+        park_small(hc);
+        if (hc.Ee < 0) poison(hc);
+        __syncthreads();                                                 // (B) this unit's pieces + small arrays visible to all waves
+        SGG_DTICK(2)
+        if (more) {
+            if (SGG_DMA_ABL != 3) issue_dma(hn, par ^ 1);                // the other staging buffer: free since the last unit's phase 2
+            issue_small(hn);
+        }
+        SGG_DTICK(3)
+        const char* stage = stage0 + (long)par * EMAX * PIECE;
+        // lane groups per node (a power of two, inside one wave)
+        int P = 1, lgP = 0;
+        while (2 * P * LP <= 64 && 2 * P * hc.Nn <= GROUPS) {
+            P *= 2;
+            ++lgP;
+        }
+        const int part = grp & (P - 1), n = grp >> lgP;
+        const bool has_node = n < hc.Nn;
+        const long col = col_of(hc);
+        // ---- phase 1: out-lists
+        float out_sum[CHL];
+#pragma unroll
+        for (int j = 0; j < CHL; ++j) out_sum[j] = 0.f;
+        if (has_node) {
+            float vn[CHL], acc[CHL];
+            {
+                const float* src = reinterpret_cast<const float*>(vs + n * VSB) + sub * CHL;
+#pragma unroll
+                for (int j = 0; j < CHL; j += 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(src + j);
+                    vn[j] = t.x; vn[j + 1] = t.y; vn[j + 2] = t.z; vn[j + 3] = t.w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < CHL; ++j) acc[j] = 0.f;
+            const bool oddg = gk & 1;                        // gates 1 (obj_vert) and 3 (in_edge) look at v[o], 0 and 2 at v[s] = v[n]
+            const int ob = optr[n], oe = optr[n + 1];
+            // entries ob + part, ob + part + P, ...: `mine` of them
+            const int mine = (oe - ob - part + P - 1) >> lgP;
+            const unsigned eoff0 = (unsigned)(hc.e0 + ob + part) * rowb + (unsigned)col * (unsigned)sizeof(T);
+            for (int kb = 0; kb < mine; kb += U) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool live = kb + u < mine;     // lanes of a quad share `live`: the DPP broadcasts stay inside a lane group
+                    if (__builtin_amdgcn_ballot_w64(live) == 0) break;   // wave-uniform: no lane group of this wave has another edge
+                    const int el = live ? ob + part + ((kb + u) << lgP) : 0;
+#if SGG_DMA_ABL == 1                             // experiment: the access pattern alone (staged piece in, piece out)
+                    if (live) *reinterpret_cast<u32x4*>(e_in_c + (eoff0 + (unsigned)((kb + u) << lgP) * rowb)) = *reinterpret_cast<const u32x4*>(stage + el * PIECE + sub * 16);
+                    continue;
+#endif
+                    // gate k: 0 sub_vert(v[s]), 1 obj_vert(v[o]), 2 out_edge(v[s]), 3 in_edge(v[o])  (rel_model_stanford.py:78-89)
+                    const int o = onl8[el];
+                    const float vd = nd[(oddg ? o : n) * 4 + gk];
+                    const float gate = sigmoidf_(vd + dots[el * 4 + gk] + bias);
+                    const float gs = quad_bcast<0x00>(gate), go = quad_bcast<0x55>(gate), gx = quad_bcast<0xAA>(gate);
+                    if (live) {
+                        Piece16<T> rowp;
+                        rowp.r = *reinterpret_cast<const decltype(rowp.r)*>(stage + el * PIECE + sub * 16);
+                        float xx[CHL], yy[CHL], rr[CHL];
+                        rowp.get(xx);
+                        const float* vo = reinterpret_cast<const float*>(vs + o * VSB) + sub * CHL;
+#pragma unroll
+                        for (int j = 0; j < CHL; j += 4) {
+                            const f32x4 t = *reinterpret_cast<const f32x4*>(vo + j);
+                            yy[j] = t.x; yy[j + 1] = t.y; yy[j + 2] = t.z; yy[j + 3] = t.w;
+                        }
+#pragma unroll
+                        for (int j = 0; j < CHL; ++j) {
+                            rr[j] = gs * vn[j] + go * yy[j];
+                            acc[j] = fmaf(gx, xx[j], acc[j]);
+                        }
+                        if (SGG_DMA_ABL != 2) Piece16<T>::store(reinterpret_cast<T*>(e_in_c + (eoff0 + (unsigned)((kb + u) << lgP) * rowb)), rr);
+                    }
+                }
+            }
+            for (int off = LP; off < P * LP; off <<= 1) {
+#pragma unroll
+                for (int j = 0; j < CHL; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+            }
+            if (sum_ctx) {
+#pragma unroll
+                for (int j = 0; j < CHL; ++j) out_sum[j] = acc[j];
+            } else if (part == 0) {
+                Piece16<T>::store(ctx2 + (long)(hc.n0 + n) * H + col, acc);
+            }
+        }
+        SGG_DTICK(4)
+        SGG_DTICK(5)
+        SGG_DTICK(6)
+        // ---- phase 2: in-lists, from the staged pieces.  NO barrier in front of it: g_in of an in-edge is recomputed here from the
+        // parked dots (one exp + rcp per lane and edge) instead of being handed over through LDS by whichever wave owned the edge's
+        // subject -- the barrier cost more than the five instructions (clock stamps: waves idled a quarter of a unit at it).
+        if (has_node && SGG_DMA_ABL != 1) {
+            const int beg = iptr[n], end = iptr[n + 1];
+            const int mine = (end - beg - part + P - 1) >> lgP;
+            const float nb3 = nd[n * 4 + 3] + gb[3];        // in_edge gate: v[o] = v[n] for every edge of n's in-list
+            float acc[CHL];
+#pragma unroll
+            for (int j = 0; j < CHL; ++j) acc[j] = 0.f;
+            constexpr int U2 = 4;
+            for (int kb = 0; kb < mine; kb += U2) {
+                int el[U2];
+#pragma unroll
+                for (int u = 0; u < U2; ++u) el[u] = in_loc[beg + part + (min(kb + u, mine - 1) << lgP)];
+                Piece16<T> rw[U2];
+                float gv[U2];
+#pragma unroll
+                for (int u = 0; u < U2; ++u) {
+                    rw[u].r = *reinterpret_cast<const decltype(rw[u].r)*>(stage + el[u] * PIECE + sub * 16);
+                    gv[u] = dots[el[u] * 4 + 3];
+                }
+#pragma unroll
+                for (int u = 0; u < U2; ++u) {
+                    const float g3 = (kb + u < mine) ? sigmoidf_(gv[u] + nb3) : 0.f;
+                    float xx[CHL];
+                    rw[u].get(xx);
+#pragma unroll
+                    for (int j = 0; j < CHL; ++j) acc[j] = fmaf(g3, xx[j], acc[j]);
+                }
+            }
+            for (int off = LP; off < P * LP; off <<= 1) {
+#pragma unroll
+                for (int j = 0; j < CHL; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+            }
+            if (sum_ctx) {
+#pragma unroll
+                for (int j = 0; j < CHL; ++j) acc[j] += out_sum[j];
+                if (part == 0) Piece16<T>::store(ctx2 + (long)(hc.n0 + n) * H + col, acc);
+            } else if (part == 0) {
+                Piece16<T>::store(ctx2 + ((long)N + hc.n0 + n) * H + col, acc);
+            }
+        }
+        SGG_DTICK(7)
+        ++unit_no;
+        if (!more) break;
+        idx += wx;
+        par ^= 1;
+        hc = hn;
+        hn = hnn;
+        if (idx + 2 * wx < cnt) hnn = load_hdr(idx + 2 * wx);            // scalar loads (their own counter), two units ahead
+    }
+}
+
 // persistent form: <= 2 resident workgroups per CU walk the units of their XCD (imp_stream_kernel)
 template <typename T, int LP>
 int launch_stream(const void* v, const void* e, const int* so, const int* in_ptr, const int* in_ids, const int* img_ptr, int B, int N,
@@ -1121,7 +1457,35 @@ int launch_stream(const void* v, const void* e, const int* so, const int* in_ptr
                        edots, gb, (T*)e_in, (T*)ctx2, emax, nmax, sum_ctx);
     return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
 }
+
+// LDS-DMA form: one resident 16-wave workgroup per CU, two staging buffers (imp_dma_kernel)
+template <typename T>
+int launch_dma(const void* v, const void* e, const int* so, const int* in_ptr, const int* in_ids, const int* img_ptr, int B, int N,
+               int H, const float* ndots, const float* edots, const float* gb, void* e_in, void* ctx2, int max_edges, int max_nodes,
+               int sum_ctx, int max_wgs, hipStream_t s) {
+    auto k = imp_dma_kernel<T>;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                DM_LDS_MAX) != hipSuccess)
+            return SGG_ERR_LAUNCH;
+        configured = true;
+    }
+    const int emax = (max(max_edges, 16) + 15) & ~15, nmax = (max(max_nodes, 8) + 7) & ~7;
+    const int units = B * (H * (int)sizeof(T) / DM_PIECE);
+    int grid = min(units, 256);
+    if (max_wgs > 0) grid = min(grid, max_wgs);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(DM_THREADS), dma_lds_bytes(emax, nmax, sizeof(T) == 2 ? 128 : 64), s, (const T*)v, (const T*)e, so, in_ptr, in_ids,
+                       img_ptr, B, N, H, ndots, edots, gb, (T*)e_in, (T*)ctx2, emax, nmax, sum_ctx);
+    return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
+}
 }  // namespace
+
+#ifdef SGG_DMA_TICKS
+extern "C" int sgg_dbg_dma_ticks(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dma_ticks), sizeof(long long) * 8 * 16 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int sgg_graph_ptr(const int64_t* im_inds, int N, int B, const int* out_ptr, int* img_ptr, void* stream) {
     if (!im_inds || !img_ptr || !out_ptr || N < 0 || B < 0) return SGG_ERR_ARG;
@@ -1164,12 +1528,24 @@ extern "C" int sgg_imp_sliced_fwd(const void* v, const void* e, const int* so, c
             max_edges <= (f == 8 ? SliceCfg<8>::EMAX : f == 4 ? SliceCfg<4>::EMAX : SliceCfg<2>::EMAX))
             lp = f;
     }
-    // SGG_IMP_STREAM=0: the short-lived form (one workgroup per unit), kept as the cross-check of the persistent kernel;
-    // SGG_IMP_MAX_WGS=n caps the persistent grid (tests: several units per workgroup on small batches)
+    // Default: the persistent LDS-DMA kernel for graphs whose pieces fit two staging buffers; SGG_IMP_STREAM=0: the short-lived
+    // form (one workgroup per unit: larger graphs, and the cross-check of the persistent kernels); =1: the register-prefetch
+    // persistent form (experiment).  SGG_IMP_MAX_WGS=n caps the persistent grid (tests: several units per workgroup on small batches)
     const char* st = getenv("SGG_IMP_STREAM");
+    const char* mw = getenv("SGG_IMP_MAX_WGS");
+    const int max_wgs = mw ? atoi(mw) : 0;
+    // (graphs whose pieces do not fit two staging buffers, or whose e_in exceeds 32-bit byte offsets, take the short-lived form)
+    const bool dma_fits = row % DM_PIECE == 0 && max_nodes <= DM_NMAX && max_edges <= DM_EMAX &&
+                          dma_lds_bytes((max(max_edges, 16) + 15) & ~15, (max(max_nodes, 8) + 7) & ~7, dtype == SGG_BF16 ? 128 : 64) <= DM_LDS_MAX &&
+                          (long)E * row < 0xffff0000L;
+    if ((!st || st[0] == 'd') && dma_fits) {
+        if (dtype == SGG_BF16)
+            return launch_dma<bf16_t>(v, e, so, in_ptr, in_ids, img_ptr, B, N, H, node_dots, edge_dots, gate_b, e_in, ctx2, max_edges,
+                                      max_nodes, sum_ctx, max_wgs, s);
+        return launch_dma<float>(v, e, so, in_ptr, in_ids, img_ptr, B, N, H, node_dots, edge_dots, gate_b, e_in, ctx2, max_edges,
+                                 max_nodes, sum_ctx, max_wgs, s);
+    }
     if (st && st[0] == '1') {
-        const char* mw = getenv("SGG_IMP_MAX_WGS");
-        const int max_wgs = mw ? atoi(mw) : 0;
 #define SGG_STREAM(T, LPV) \
     return launch_stream<T, LPV>(v, e, so, in_ptr, in_ids, img_ptr, B, N, H, node_dots, edge_dots, gate_b, e_in, ctx2, max_edges, \
                                  max_nodes, sum_ctx, max_wgs, s)

@@ -583,6 +583,66 @@ def test_imp_sliced_vs_oracle_math(ops, H, sizes, dtype):
     torch.testing.assert_close(ctx2.float(), ctx2f.float(), **ctol)
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_imp_persistent_kernels_equal_short_lived_form(ops, dtype, monkeypatch):
+    """The persistent forms of the sliced IMP step (LDS-DMA kernel = default; register-prefetch kernel) do the same arithmetic as the
+    short-lived one-workgroup-per-unit kernel: identical e_in, ctx sums equal up to the association of their f32 terms, on ragged batches -- complete graphs of very
+    different sizes, a sampled edge list with a node that lost its out-edges, a two-node graph -- with the persistent grid capped
+    so that every workgroup walks SEVERAL units (prefetch across units, both staging buffers, both copies of the small arrays), and
+    in both output modes (ctx halves / summed ctx).  A broken capacity promise poisons that graph's outputs in every form."""
+    H = 128
+    g = torch.Generator().manual_seed(77)
+    for case, sizes in enumerate(([32, 5, 17, 2, 32, 9, 33, 3, 12], [32] * 12, [6, 2, 2])):
+        im = np.concatenate([np.full(n, b) for b, n in enumerate(sizes)]).astype(np.int64)
+        rel = O.get_rel_inds_eval(im)
+        if case == 0:
+            rng = np.random.RandomState(4)
+            drop = (rel[:, 0] == 2) & (rng.rand(len(rel)) < 0.35)          # graph 2: sampled list ...
+            drop |= (rel[:, 0] == 2) & (rel[:, 1] == im.tolist().index(2) + 4)   # ... and one node without out-edges
+            rel = rel[~drop]
+        N, E = len(im), len(rel)
+        per_graph = [int((rel[:, 0] == b).sum()) for b in range(len(sizes))]
+        v = cu(torch.randn(N, H, generator=g).to(dtype))
+        e = cu(torch.randn(E, H, generator=g).to(dtype))
+        nd, ed, gb = cu(torch.randn(N, 4, generator=g)), cu(torch.randn(E, 4, generator=g)), cu(torch.randn(4, generator=g))
+        csr = ops.edge_csr(cu(rel), N, cu(im), graphs=(len(sizes), max(sizes), max(per_graph)))
+        assert ops.imp_sliced_ok(csr, H, dtype)
+        monkeypatch.setenv('SGG_IMP_STREAM', '0')
+        monkeypatch.delenv('SGG_IMP_MAX_WGS', raising=False)
+        ref_ein, ref_ctx2 = ops.imp_sliced(v, e, csr, nd, ed, gb)
+        _, ref_sum = ops.imp_sliced(v, e, csr, nd, ed, gb, ctx_sum=torch.empty_like(v))
+        assert torch.isfinite(ref_ein.float()).all() and torch.isfinite(ref_ctx2.float()).all()
+        ctol = dict(atol=1e-4, rtol=1e-5) if dtype == torch.float32 else dict(atol=0.13, rtol=1.6e-2)   # 2 bf16 ulps
+        for form in ('d', '1'):
+            monkeypatch.setenv('SGG_IMP_STREAM', form)
+            first = None
+            for cap in ('', '1', '3', '8', '11'):
+                if cap:
+                    monkeypatch.setenv('SGG_IMP_MAX_WGS', cap)
+                else:
+                    monkeypatch.delenv('SGG_IMP_MAX_WGS', raising=False)
+                e_in, ctx2 = ops.imp_sliced(v, e, csr, nd, ed, gb)
+                _, csum = ops.imp_sliced(v, e, csr, nd, ed, gb, ctx_sum=torch.empty_like(v))
+                assert torch.equal(e_in, ref_ein), (case, form, cap)
+                # ctx: a node's list is cut into more parts by the 16-wave kernel (other association of the same f32 terms)
+                torch.testing.assert_close(ctx2.float(), ref_ctx2.float(), **ctol)
+                torch.testing.assert_close(csum.float(), ref_sum.float(), **ctol)
+                if first is None:
+                    first = (e_in, ctx2, csum)
+                else:                                                    # the same form is bit-reproducible for every grid size
+                    assert all(torch.equal(a, b) for a, b in zip(first, (e_in, ctx2, csum))), (case, form, cap)
+        # understated capacity (graph 0 promised as 40 edges): its outputs are NaN, the other graphs are untouched
+        if case == 2:
+            lie = ops.edge_csr(cu(rel), N, cu(im), graphs=(len(sizes), max(sizes), 8))
+            for form in ('d', '1', '0'):
+                monkeypatch.setenv('SGG_IMP_STREAM', form)
+                monkeypatch.setenv('SGG_IMP_MAX_WGS', '2')
+                e_in, ctx2 = ops.imp_sliced(v, e, lie, nd, ed, gb)
+                big = torch.from_numpy(rel[:, 0] == 0).to(DEV)
+                assert torch.isnan(e_in[big].float()).all() and torch.isnan(ctx2[:, :6].float()).all(), form
+                assert torch.equal(e_in[~big], ref_ein[~big]) and torch.equal(ctx2[:, 6:], ref_ctx2[:, 6:]), form
+
+
 def test_imp_sliced_capacity_and_fallback(ops):
     """Graphs the staging area cannot hold are refused by the C entry (SGG_ERR_CAPACITY -> ValueError) and by imp_sliced_ok;
     message_pass then runs the node-centric kernel and gives the same result as without the hint."""

@@ -1,0 +1,70 @@
+"""IMP sliced-step kernels without the model: random states on complete 32-node graphs, hipGraph-replay timing of each form;
+with a library built with -DSGG_DMA_TICKS (SGG_HIP_LIB=...), prints the per-unit phase stamps of the LDS-DMA kernel.
+    python tools/exp/imp_micro.py [B ...]      env: IMP_FORMS=d,1,0  IMP_DTYPE=bf16|f32"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from sgg_amd import _lib, ops  # noqa: E402
+
+dev = 'cuda:0'
+dtype = torch.float32 if os.environ.get('IMP_DTYPE') == 'f32' else torch.bfloat16
+s = 2 if dtype == torch.bfloat16 else 4
+H, n = int(os.environ.get('IMP_H', '512')), 32
+forms = os.environ.get('IMP_FORMS', 'd,0').split(',')
+Bs = [int(b) for b in sys.argv[1:]] or [8, 128]
+for B in Bs:
+    N, E = n * B, n * (n - 1) * B
+    im = torch.arange(B, device=dev).repeat_interleave(n)
+    rel, _ = ops.pair_index_eval(im)
+    rel = rel[:E]
+    csr = ops.edge_csr(rel, N, im, graphs=(B, n, n * (n - 1)))
+    g = torch.Generator().manual_seed(1)
+    v = torch.randn(N, H, generator=g).to(dev).to(dtype)
+    e = torch.randn(E, H, generator=g).to(dev).to(dtype)
+    nd, ed, gb = torch.randn(N, 4, generator=g).to(dev), torch.randn(E, 4, generator=g).to(dev), torch.randn(4, generator=g).to(dev)
+    e_in, ctx2 = torch.empty_like(e), torch.empty((2, N, H), dtype=dtype, device=dev)
+    algo = (2.0 * (E + N) * H) * s + 8.0 * E
+    row = []
+    for form in forms:
+        os.environ['SGG_IMP_STREAM'] = form
+        launch = lambda: ops.imp_sliced(v, e, csr, nd, ed, gb, e_in, ctx2)
+        for _ in range(3):
+            launch()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(50):
+                launch()
+        graph.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 50
+        row.append('%s %7.2f us %5.0f GB/s %.3f' % (form, ms * 1e3, algo / ms / 1e6, algo / ms / 1e6 / 8000))
+    print('B=%3d' % B, ' | '.join(row), flush=True)
+    lib = _lib.load()
+    if hasattr(lib, 'sgg_dbg_dma_ticks') and 'd' in forms:
+        os.environ['SGG_IMP_STREAM'] = 'd'
+        ops.imp_sliced(v, e, csr, nd, ed, gb, e_in, ctx2)
+        torch.cuda.synchronize()
+        buf = np.zeros(8 * 16 * 8, dtype=np.int64)
+        lib.sgg_dbg_dma_ticks.argtypes = [ctypes.c_void_p]
+        assert lib.sgg_dbg_dma_ticks(buf.ctypes.data) == 0
+        t = buf.reshape(8, 16, 8)
+        units = int(min(16, max(1, (B * (H * s // 64) + 255) // 256)))
+        names = ['top-wait', 'barA+park+barB', 'dma+fetch issue', 'phase1', '-', '-', 'phase2', 'loop-tail']
+        for blk in (0, 3):
+            print(' block %d (stamps of wave 0; clock64 ticks), %d units' % (blk, units))
+            for u in range(units):
+                d = np.diff(t[blk, u])
+                nxt = t[blk, u + 1, 0] - t[blk, u, 7] if u + 1 < units else 0
+                print('   unit %2d: ' % u + '  '.join('%s %5d' % (nm, x) for nm, x in zip(names, list(d) + [nxt])) + '   total %d' % (t[blk, u, 7] - t[blk, u, 0]))
+    os.environ.pop('SGG_IMP_STREAM', None)

@@ -1,4 +1,6 @@
-"""IMP step kernels (sliced vs node-centric) at B = 8 and 128 images of 32 boxes: us per launch, algorithmic GB/s."""
+"""IMP step kernels at B = 8 / 32 / 128 images of 32 boxes: us per launch and algorithmic GB/s for the persistent LDS-DMA kernel
+(what the forward runs), the register-prefetch persistent kernel, the short-lived one-workgroup-per-unit kernel and the node-centric
+kernel.  IMP_B=8,128 selects batch sizes; IMP_FORMS=d,1,0,fused selects forms."""
 import os
 import sys
 
@@ -10,12 +12,17 @@ import sgg_amd  # noqa: E402
 from sgg_amd.synthetic import SyntheticData, init_weights  # noqa: E402
 
 model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls')).to('cuda:0').eval()
+names = {'d': 'dma', '1': 'stream', '0': 'short', 'fused': 'node-centric'}
+forms = os.environ.get('IMP_FORMS', 'd,1,0,fused').split(',')
 for dtype, s in ((torch.bfloat16, 2), (torch.float32, 4)):
     model.set_compute_dtype(dtype)
-    for B in [int(b) for b in os.environ.get("IMP_B", "8,32,128").split(",")]:
+    for B in [int(b) for b in os.environ.get('IMP_B', '8,32,128').split(',')]:
         algo = (2.0 * (992 * B + 32 * B) * 512) * s + 8.0 * 992 * B
         row = []
-        for kind in ('sliced', 'fused'):
-            ms = bench.imp_iter_ms(model, B, dtype, kind=kind)
-            row.append('%s %7.2f us %6.0f GB/s' % (kind, ms * 1e3, algo / ms / 1e6))
-        print(str(dtype).split('.')[-1], 'B=%3d' % B, ' | '.join(row))
+        for form in forms:
+            if form != 'fused':
+                os.environ['SGG_IMP_STREAM'] = form
+            ms = bench.imp_iter_ms(model, B, dtype, kind='fused' if form == 'fused' else 'sliced')
+            row.append('%s %7.2f us %5.0f GB/s %.3f' % (names[form], ms * 1e3, algo / ms / 1e6, algo / ms / 1e6 / 8000))
+        os.environ.pop('SGG_IMP_STREAM', None)
+        print(str(dtype).split('.')[-1], 'B=%3d' % B, ' | '.join(row), flush=True)
