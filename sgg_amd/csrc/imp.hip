@@ -1101,35 +1101,50 @@ int launch_sliced(const void* v, const void* e, const int* so, const int* out_pt
 // ---------------------------------------------------------------------------------------------------------------------
 // Persistent LDS-DMA form of the sliced step (imp_dma_kernel): the kernel the forward runs.
 //
-// The row pieces of a unit have to sit in LDS anyway (phase 2 walks the in-lists over them), so they are fetched STRAIGHT into
-// LDS (`global_load_lds_dwordx4`: no VGPR round trip, no 13-cycle ds_write_b128 per piece) and both phases read them with
-// ds_read_b128.  One 16-wave workgroup per CU owns two staging buffers: while unit u is in its gate / accumulate phases, the
-// DMA of unit u+1 -- issued the moment the buffer is free -- is in flight.  Everything else a unit needs is fetched ONE
-// COALESCED ELEMENT PER THREAD (thread t <-> edge t: its four gate dots as one 16-byte load, its object node, its in-list
-// entry; thread t <-> node t: list offsets, vertex dots) one unit ahead into 16 registers and parked in LDS at the top of the
-// unit: clock stamps of the first version showed the vector-memory pipe (64 B/clk/CU, one wave-instruction at a time), not
-// HBM, to be what the waves queued on -- 256 four-byte gather instructions per unit for dots and node ids.  A wave waits for
-// memory ONCE per unit (`s_waitcnt vmcnt(0)` at the top of the iteration); phases 1 and 2 touch only LDS and issue stores.
-// Per unit: top wait -> barrier A (every wave has left the last unit) -> park -> barrier B -> issue DMA + fetches of the next
-// unit -> phase 1 (out-lists) -> phase 2 (in-lists), the two phases with NO barrier between them (g_in is recomputed).
+// What bounds the step (measured on MI355X, DESIGN.md "IMP step"):
+//   * the REQUEST size.  A workgroup that owns a W-byte column slice of a graph's edge rows moves W bytes per memory request;
+//     the chip retires about the same number of requests per second whatever their size, so 64-byte pieces (half a cache
+//     line) stream at 3.3 TB/s, 128-byte pieces (full lines) at 5.3 TB/s, 256-byte pieces at 5.6 TB/s
+//     (tools/exp/piece_bw.hip).  The short-lived kernel above (64-byte pieces) was AT its pattern's ceiling.
+//   * VALU instructions.  With 64-byte units every lane did 4 edges per unit and then paid the unit's fixed costs again;
+//     gates were recomputed by each of a graph's 16 slices, per lane.
+//   * the vector-memory pipe of the CU takes one wave-instruction at a time: 4-byte gathers (gate dots, node ids) queue it up.
+// Hence: the unit is (graph, 128-byte slice) whenever that still gives every CU a unit (64-byte slices for small batches).
+// A unit's row pieces do not fit LDS twice at 128 bytes (992 x 128 B = 124 KB), so a unit is cut into BATCHES of consecutive
+// edges and the two staging buffers alternate between batches: while batch b is in its gate / accumulate phases, the DMA of
+// batch b+1 -- or of the next unit's first batch -- is in flight (`global_load_lds_dwordx4`: straight into LDS, no VGPR round
+// trip; both phases read the staged pieces with ds_read_b128).  A lane group owns one node for the whole unit: it walks the part
+// of the node's out-list that lies in the batch (phase 1: e_in rows, sum g_out e) and, with a cursor, the part of its in-list
+// that does (phase 2: sum g_in e over the staged pieces); both sums stay in registers until the unit ends.
+// Everything else a unit needs is fetched ONE COALESCED ELEMENT PER THREAD (thread t <-> edge t: its four gate dots as one
+// 16-byte load, (subject, object), in-list entry; thread t <-> node t: list offsets, vertex dots) one unit ahead into
+// registers; at the start of the unit thread t turns the dots of edge t into its four GATES (once per unit instead of once per
+// lane and edge) and parks them in LDS.  A wave waits for memory ONCE per batch (`s_waitcnt vmcnt(0)` at its top).
 //
 // A node's lists are dealt to its P lane groups round-robin (entry k -> group k % P): at every step the P groups read P
 // consecutive staged rows (conflict-free; contiguous chunks put all of a wave's groups on the same banks).
 //
 // The DMA is issued from inline asm on purpose: hipcc treats a known LDS-DMA as an LDS write that may alias every later LDS
-// read and puts `s_waitcnt vmcnt(0)` in front of each, which would serialise unit u's phases behind unit u+1's DMA.  The
+// read and puts `s_waitcnt vmcnt(0)` in front of each, which would serialise batch b's phases behind batch b+1's DMA.  The
 // compiler's vmcnt bookkeeping therefore does not know about the DMA; that is harmless because every load is consumed after
-// the top wait, which is the builtin (the compiler's scoreboard sees the drain and adds no wait of its own).
-constexpr int DM_THREADS = 1024, DM_LP = 4, DM_PIECE = 64, DM_GROUPS = DM_THREADS / DM_LP, DM_U = 8;
+// a top wait, which is the builtin (the compiler's scoreboard sees the drain and adds no wait of its own).
+constexpr int DM_THREADS = 1024;
 constexpr int DM_EMAX = DM_THREADS, DM_NMAX = SL_NMAX;     // one edge per thread for the coalesced fetches
-// vsb: bytes of one node's vertex piece in LDS (kept as f32: 128 with bf16 storage, 64 with f32)
-constexpr int dma_lds_bytes(int emax, int nmax, int vsb) {
-    return 2 * emax * DM_PIECE                 // staging buffers
-           + emax * 16 + emax + emax * 2       // gate dots, object node (u8), in-list entries (u16)
-           + nmax * vsb + nmax * 16 + 2 * (nmax + 4) * 4;   // vertex pieces (f32), vertex dots, out- / in-list offsets
-}
 constexpr int DM_LDS_MAX = 160 * 1024;
-static_assert(dma_lds_bytes(1008, 32, 128) <= DM_LDS_MAX, "imp_dma_kernel: LDS budget at the 32-box / 992-edge configuration");
+// LDS that does not depend on the batch size.  vsb: bytes of one node's vertex piece as f32
+constexpr int dma_fixed_bytes(int emax, int nmax, int vsb, bool sum_ctx) {
+    return emax * 16 + emax + emax * 2                     // gates f32[emax][4], object node u8, in-list entries u16
+           + nmax * vsb + nmax * 16 + 2 * (nmax + 4) * 4   // vertex pieces (f32), vertex dots, out- / in-list offsets
+           + (sum_ctx ? nmax * vsb : 0);                   // ctx_out pieces waiting for ctx_in (one summed ctx tensor: training)
+}
+// edges per batch (multiple of 16, at most emax): two staging buffers of `eb` pieces must fit beside the fixed part
+constexpr int dma_batch_edges(int emax, int nmax, int vsb, int piece, bool sum_ctx) {
+    const int room = (DM_LDS_MAX - dma_fixed_bytes(emax, nmax, vsb, sum_ctx)) / (2 * piece);
+    const int eb = room < emax ? (room & ~15) : emax;
+    return eb < 16 ? 0 : eb;
+}
+static_assert(dma_batch_edges(1008, 32, 256, 128, true) >= 496, "imp_dma_kernel: a 992-edge graph must go through in two 128-byte batches");
+static_assert(dma_batch_edges(1008, 32, 128, 64, true) == 1008, "imp_dma_kernel: ... and in one 64-byte batch");
 
 typedef __attribute__((address_space(3))) char lds_char_t;
 
@@ -1139,7 +1154,7 @@ __device__ __forceinline__ void dma16_to_lds(const void* gptr, unsigned lds_base
 }
 
 #ifndef SGG_DMA_ABL
-#define SGG_DMA_ABL 0     // kernel experiments only: 1 copy only (staged piece in, piece out), 2 no e_in stores, 3 no DMA after the first unit
+#define SGG_DMA_ABL 0     // kernel experiments only: 1 copy only (staged piece in, piece out), 2 no e_in stores, 3 no DMA after the first batch
 #endif
 #ifdef SGG_DMA_TICKS     // kernel experiments only: clock stamps of the first 8 workgroups (one per XCD), wave 0, 16 units x 8 stamps
 __device__ long long g_dma_ticks[8 * 16 * 8];
@@ -1149,29 +1164,30 @@ __device__ long long g_dma_ticks[8 * 16 * 8];
 #define SGG_DTICK(i)
 #endif
 
-template <typename T>
+template <typename T, int LP>
 __global__ __launch_bounds__(DM_THREADS) void imp_dma_kernel(
     const T* __restrict__ v, const T* __restrict__ e, const int* __restrict__ so, const int* __restrict__ in_ptr,
     const int* __restrict__ in_ids, const int* __restrict__ img_ptr, int B, int N, int H, const float* __restrict__ ndots,
     const float* __restrict__ edots, const float* __restrict__ gb, T* __restrict__ e_in, T* __restrict__ ctx2, int EMAX, int NMAX,
-    int sum_ctx) {
-    constexpr int LP = DM_LP, PIECE = DM_PIECE, CHL = 16 / (int)sizeof(T), GROUPS = DM_GROUPS, U = DM_U;
-    constexpr int VSB = CHL * 4 * LP;
+    int EB, int sum_ctx) {
+    constexpr int PIECE = LP * 16, CHL = 16 / (int)sizeof(T), GROUPS = DM_THREADS / LP, U = 2, EPW = 64 / LP;
+    constexpr int VSB = CHL * 4 * LP;                      // a node's vertex piece as f32
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS map (EMAX a multiple of 16, NMAX of 8: every array 16-byte aligned)
-    char* const stage0 = smem;                                                       // [2][EMAX][64 B]
-    float* const dots = reinterpret_cast<float*>(stage0 + 2L * EMAX * PIECE);        // [EMAX][4] gate dots of every edge
-    unsigned char* const onl8 = reinterpret_cast<unsigned char*>(dots + 4L * EMAX);  // [EMAX] graph-local object node
+    // LDS map (EMAX, EB multiples of 16, NMAX of 8: every array 16-byte aligned)
+    char* const stage0 = smem;                                                       // [2][EB][PIECE]
+    float* const gates = reinterpret_cast<float*>(stage0 + 2L * EB * PIECE);         // [EMAX][4]  sub_vert, obj_vert, out_edge, in_edge
+    unsigned char* const onl8 = reinterpret_cast<unsigned char*>(gates + 4L * EMAX); // [EMAX] graph-local object node
     char* const vs = reinterpret_cast<char*>(onl8 + EMAX);                            // [NMAX][VSB] vertex pieces as f32
     float* const nd = reinterpret_cast<float*>(vs + NMAX * VSB);                      // [NMAX][4]
     int* const optr = reinterpret_cast<int*>(nd + NMAX * 4);                          // [NMAX+4] out-list offsets (graph-local)
     int* const iptr = optr + NMAX + 4;                                                // [NMAX+4] in-list offsets (graph-local)
     unsigned short* const in_loc = reinterpret_cast<unsigned short*>(iptr + NMAX + 4);   // [EMAX] in-list entries (graph-local edge)
+    char* const osum = reinterpret_cast<char*>(in_loc + EMAX);                        // [NMAX][VSB] ctx_out pieces (f32), sum_ctx only
     const unsigned stage_lds = (unsigned)(unsigned long)(lds_char_t*)smem;
 
     const int S = H * (int)sizeof(T) / PIECE, units = B * S;
     // this workgroup's units: XCD x (dispatch puts block b on XCD b % 8) owns a contiguous range of units, so that the
-    // slices of a graph -- which share its tables, dots and the other half of every 128-byte line -- meet in one L2
+    // slices of a graph -- which share its tables and dots -- meet in one L2
     const int G = (int)gridDim.x, NX = min(G, 8), x = (int)blockIdx.x % NX, w = (int)blockIdx.x / NX;
     const int wx = G / NX + (x < G % NX ? 1 : 0);
     const int uq = units / NX, ur = units % NX;
@@ -1179,8 +1195,7 @@ __global__ __launch_bounds__(DM_THREADS) void imp_dma_kernel(
     if (w >= cnt) return;
     const int tid = threadIdx.x, sub = tid % LP, grp = tid / LP, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int gk = sub & 3;
-    const float bias = gb[gk];
+    const float b0 = gb[0], b1 = gb[1], b2 = gb[2], b3 = gb[3];
 
     struct Hdr { int g, slice, n0, Nn, e0, Ee; };          // Ee < 0: the host's promise about this graph is broken (see poison)
     // (graph, slice) of unit `base + idx`, stepped from the last header loaded: no integer division on the per-unit path
@@ -1195,10 +1210,19 @@ __global__ __launch_bounds__(DM_THREADS) void imp_dma_kernel(
         }
         h.g = lg;
         h.slice = lslice;
-        h.n0 = img_ptr[h.g];
-        h.Nn = img_ptr[h.g + 1] - h.n0;
-        h.e0 = img_ptr[B + 1 + h.g];
-        h.Ee = img_ptr[B + 2 + h.g] - h.e0;
+        // scalar loads by hand: with asm memory clobbers around (the waits), the compiler no longer proves the table unclobbered
+        // and would fetch it with VECTOR loads -- whose vmcnt wait drains every store in flight
+        {
+            const int* pn = img_ptr + h.g;
+            const int* pe = img_ptr + (B + 1 + h.g);
+            u32x2 nn, ee;
+            asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(nn), "=&s"(ee) : "s"(pn), "s"(pe) : "memory");
+            h.n0 = (int)nn.x;
+            h.Nn = (int)nn.y - h.n0;
+            h.e0 = (int)ee.x;
+            h.Ee = (int)ee.y - h.e0;
+        }
         if (h.Ee > EMAX || h.Nn > NMAX || h.Nn > SL_NMAX) {              // nothing may be staged: outputs poisoned, unit runs empty
             h.Nn = 0;
             h.Ee = -1;
@@ -1206,44 +1230,67 @@ __global__ __launch_bounds__(DM_THREADS) void imp_dma_kernel(
         return h;
     };
     auto col_of = [&](const Hdr& h) { return (long)h.slice * (PIECE / (int)sizeof(T)) + sub * CHL; };   // this lane's first channel
-    auto issue_dma = [&](const Hdr& h, int par) {            // the unit's row pieces -> stage[par], 16 edges per wave-instruction
-        const int nch = (h.Ee + 15) >> 4;
+    // rows [lo, hi) (graph-local) of the unit -> staging buffer `par`: EPW edges per wave-instruction, one full piece per edge
+    auto issue_dma = [&](const Hdr& h, int lo, int hi, int par) {
+        const int nch = (hi - lo + EPW - 1) / EPW;
         const char* src = reinterpret_cast<const char*>(e + col_of(h));
         for (int c = wv; c < nch; c += DM_THREADS / 64) {
-            const int el = min(c * 16 + (lane >> 2), h.Ee - 1);
-            dma16_to_lds(src + (long)(h.e0 + el) * H * (int)sizeof(T), stage_lds + (unsigned)(par * EMAX * PIECE + c * 1024));
+            const int el = min(lo + c * EPW + lane / LP, hi - 1);
+            dma16_to_lds(src + (long)(h.e0 + el) * H * (int)sizeof(T), stage_lds + (unsigned)(par * EB * PIECE + c * 1024));
         }
     };
     // prefetch registers: thread t <-> edge t / node t of the NEXT unit.  Values stay raw (offsets are subtracted when they
     // are parked): arithmetic on a loaded value would make the compiler wait for the load where it was issued.
+    // The single-dword fetches live in 128-bit register tuples: a lone VGPR with a load in flight can end up as the unused
+    // upper half of a broadcast operand pair of v_pk_fma_f32 (op_sel_hi = 0), and the compiler then waits for that load --
+    // vmcnt(0), DMA included -- in the middle of a phase.
+    //
+    // These loads are issued from inline asm as well, for the sake of the WAIT at the top of a batch: vmcnt counts loads and
+    // stores in issue order, and between the fetches and the wait a wave issues its e_in stores.  `s_waitcnt vmcnt(0)` would
+    // drain those stores too (clock stamps: 3.5k cycles per batch top, a fifth of the kernel); `s_waitcnt vmcnt(k)` with k =
+    // the number of store instructions this wave issued since its last load returns as soon as the loads have landed.  The
+    // compiler cannot emit that wait (it sees stores in loops) and, if it knew of the loads, would add waits of its own -- so it
+    // does not know of them.  Consequence: nothing may read these registers between the asm load and the asm wait; they are
+    // read-write operands of the loads ("+v"), so the loop-carried variable and the load destination are one register.
     f32x4 p_de = {0, 0, 0, 0}, p_nd = {0, 0, 0, 0};
     u32x4 p_v = {0, 0, 0, 0};
-    // the four single-dword fetches live in ONE 128-bit register tuple: a lone VGPR with a load in flight can end up as the
-    // unused upper half of a broadcast operand pair of v_pk_fma_f32 (op_sel_hi = 0), and the compiler then waits for that load
-    // -- vmcnt(0), DMA included -- in the middle of a phase
-    u32x4 p_misc = {0, 0, 0, 0};                             // x: object node of edge t, y: in-list entry t, z: in-list offset, w: out-list offset
+    u32x2 p_so = {0, 0};                                     // (subject, object) of edge t, global ids
+    unsigned p_in = 0, p_ip = 0, p_op = 0;                   // in-list entry t; in-list / out-list offset of node t
+    // (addresses are 32-bit byte offsets from the scalar table pointers: per-lane 64-bit pointers, which the compiler would
+    // keep across the loop, cost 14 VGPRs -- and spills whose reloads are vector-memory operations with waits of their own)
     auto issue_small = [&](const Hdr& h) {
         if (tid < h.Ee) {
-            p_de = *reinterpret_cast<const f32x4*>(edots + (long)(h.e0 + tid) * 4);
-            p_misc.x = (unsigned)so[2 * (long)(h.e0 + tid) + 1];
-            p_misc.y = (unsigned)in_ids[h.e0 + tid];
+            const unsigned et = (unsigned)(h.e0 + tid);
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(p_de) : "v"(et * 16u), "s"(edots) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(p_so) : "v"(et * 8u), "s"(so) : "memory");
+            asm volatile("global_load_dword %0, %1, %2" : "+v"(p_in) : "v"(et * 4u), "s"(in_ids) : "memory");
         }
         if (tid <= h.Nn) {
-            p_misc.z = (unsigned)in_ptr[h.n0 + tid];
-            p_misc.w = (unsigned)img_ptr[2 * (B + 1) + (long)h.g * (SL_NMAX + 2) + tid];   // graph-local already
+            asm volatile("global_load_dword %0, %1, %2" : "+v"(p_ip) : "v"((unsigned)(h.n0 + tid) * 4u), "s"(in_ptr) : "memory");
+            asm volatile("global_load_dword %0, %1, %2" : "+v"(p_op) : "v"((unsigned)(2 * (B + 1) + h.g * (SL_NMAX + 2) + tid) * 4u), "s"(img_ptr) : "memory");
         }
-        if (tid < h.Nn) p_nd = *reinterpret_cast<const f32x4*>(ndots + (long)(h.n0 + tid) * 4);
-        if (grp < h.Nn) p_v = *reinterpret_cast<const u32x4*>(v + (long)(h.n0 + grp) * H + col_of(h));
+        if (tid < h.Nn) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(p_nd) : "v"((unsigned)(h.n0 + tid) * 16u), "s"(ndots) : "memory");
+        if (grp < h.Nn)
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(p_v) : "v"((unsigned)(((long)(h.n0 + grp) * H + col_of(h)) * (long)sizeof(T))), "s"(v) : "memory");
+    };
+    // wait until at most k vector-memory operations of this wave are outstanding, k = min(stores issued since the last load, 15)
+    auto wait_loads = [&](int nst) {
+        switch (min(nst, 15)) {
+#define SGG_W(K) case K: asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory"); break;
+            SGG_W(0) SGG_W(1) SGG_W(2) SGG_W(3) SGG_W(4) SGG_W(5) SGG_W(6) SGG_W(7) SGG_W(8) SGG_W(9) SGG_W(10) SGG_W(11) SGG_W(12)
+            SGG_W(13) SGG_W(14)
+#undef SGG_W
+            default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        }
     };
     auto park_small = [&](const Hdr& h) {
         if (tid < h.Ee) {
-            *reinterpret_cast<f32x4*>(dots + 4 * tid) = p_de;
-            onl8[tid] = (unsigned char)((int)p_misc.x - h.n0);
-            in_loc[tid] = (unsigned short)((int)p_misc.y - h.e0);
+            onl8[tid] = (unsigned char)((int)p_so.y - h.n0);
+            in_loc[tid] = (unsigned short)((int)p_in - h.e0);
         }
         if (tid <= h.Nn) {
-            iptr[tid] = (int)p_misc.z - h.e0;
-            optr[tid] = (int)p_misc.w;
+            iptr[tid] = (int)p_ip - h.e0;
+            optr[tid] = (int)p_op;
         }
         if (tid < h.Nn) *reinterpret_cast<f32x4*>(nd + tid * 4) = p_nd;
         if (grp < h.Nn) {                                  // unpacked once per unit: phase 1 reads a vertex piece per EDGE
@@ -1256,10 +1303,26 @@ __global__ __launch_bounds__(DM_THREADS) void imp_dma_kernel(
             for (int j = 0; j < CHL; j += 4) *reinterpret_cast<f32x4*>(dst + j) = f32x4{f[j], f[j + 1], f[j + 2], f[j + 3]};
         }
     };
+    // thread t: the four gates of edge t (rel_model_stanford.py:78-89), from its dots (registers) and the parked vertex dots
+    auto make_gates = [&](const Hdr& h) {
+        if (tid < h.Ee) {
+            const int sl = (int)p_so.x - h.n0, ol = (int)p_so.y - h.n0;
+            const f32x4 ns = *reinterpret_cast<const f32x4*>(nd + sl * 4), no = *reinterpret_cast<const f32x4*>(nd + ol * 4);
+            f32x4 gt;
+            gt.x = sigmoidf_(ns.x + p_de.x + b0);            // sub_vert (v[s])
+            gt.y = sigmoidf_(no.y + p_de.y + b1);            // obj_vert (v[o])
+            gt.z = sigmoidf_(ns.z + p_de.z + b2);            // out_edge (v[s])
+            gt.w = sigmoidf_(no.w + p_de.w + b3);            // in_edge  (v[o])
+            *reinterpret_cast<f32x4*>(gates + 4 * tid) = gt;
+        }
+    };
     auto poison = [&](const Hdr& h) {                        // re-reads the raw offsets: the header was emptied
         const int g = h.g;
         const long col = col_of(h);
-        const int n0 = img_ptr[g], Nn = img_ptr[g + 1] - n0, e0 = img_ptr[B + 1 + g], Ee = img_ptr[B + 2 + g] - e0;
+        u32x2 nn, ee;
+        asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(nn), "=&s"(ee) : "s"(img_ptr + g), "s"(img_ptr + (B + 1 + g)) : "memory");
+        const int n0 = (int)nn.x, Nn = (int)nn.y - n0, e0 = (int)ee.x, Ee = (int)ee.y - e0;
         float nanv[CHL];
 #pragma unroll
         for (int j = 0; j < CHL; ++j) nanv[j] = __builtin_nanf("");
@@ -1272,12 +1335,11 @@ __global__ __launch_bounds__(DM_THREADS) void imp_dma_kernel(
 
     // ---- prologue: header (scalar) -> DMA + per-thread fetches (one vector level) of the first unit, exposed once
     int idx = w, par = 0;
-    Hdr hc = load_hdr(idx), hn = hc, hnn = hc;               // (headers are loaded in increasing unit order)
-    issue_dma(hc, 0);
+    Hdr hc = load_hdr(idx), hn = hc;                         // (headers are loaded in increasing unit order)
+    issue_dma(hc, 0, min(EB, hc.Ee), 0);
     issue_small(hc);
     if (idx + wx < cnt) hn = load_hdr(idx + wx);
-    if (idx + 2 * wx < cnt) hnn = load_hdr(idx + 2 * wx);
-    int unit_no = 0;
+    int unit_no = 0, nst = 0;                                // nst: store instructions this wave issued since its last load
     (void)unit_no;
     char* const e_in_c = reinterpret_cast<char*>(e_in);
     const unsigned rowb = (unsigned)H * (unsigned)sizeof(T);
@@ -1285,152 +1347,231 @@ __global__ __launch_bounds__(DM_THREADS) void imp_dma_kernel(
     for (;;) {
         const bool more = idx + wx < cnt;                                // uniform
         SGG_DTICK(0)
-        // this unit's DMA and small fetches; last unit's stores.  The builtin (not asm): the compiler's own scoreboard must see
-        // the drain, or it waits again -- with counts that ignore the DMA -- at the first use of every prefetched register.
-        __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0) only
-        asm volatile("" ::: "memory");
-        SGG_DTICK(1)
+        wait_loads(nst);                                                 // this unit's first batch and small fetches have landed
+        nst = 0;
         __syncthreads();                                                 // (A) every wave has left the last unit: its small arrays are free
         park_small(hc);
         if (hc.Ee < 0) poison(hc);
-        __syncthreads();                                                 // (B) this unit's pieces + small arrays visible to all waves
-        SGG_DTICK(2)
-        if (more) {
-            if (SGG_DMA_ABL != 3) issue_dma(hn, par ^ 1);                // the other staging buffer: free since the last unit's phase 2
-            issue_small(hn);
+        __syncthreads();                                                 // (B) vertex dots parked
+        make_gates(hc);
+        __syncthreads();                                                 // (C) gates, lists, vertex pieces and the first batch visible to all waves
+        // ---- lane groups per node (powers of two, inside one wave).  Phase 2 (in-lists: every node has entries in every batch)
+        // deals ALL nodes to the lane groups for the whole unit; phase 1 (out-lists: a batch holds the out-lists of ITS nodes
+        // only) deals the batch's nodes to all lane groups, batch by batch -- otherwise half the waves would idle in every batch.
+        int P2 = 1, lgP2 = 0;
+        while (2 * P2 * LP <= 64 && 2 * P2 * hc.Nn <= GROUPS) {
+            P2 *= 2;
+            ++lgP2;
         }
-        SGG_DTICK(3)
-        const char* stage = stage0 + (long)par * EMAX * PIECE;
-        // lane groups per node (a power of two, inside one wave)
-        int P = 1, lgP = 0;
-        while (2 * P * LP <= 64 && 2 * P * hc.Nn <= GROUPS) {
-            P *= 2;
-            ++lgP;
-        }
-        const int part = grp & (P - 1), n = grp >> lgP;
-        const bool has_node = n < hc.Nn;
+        const int part2 = grp & (P2 - 1), n2 = grp >> lgP2;
+        const bool has2 = n2 < hc.Nn;
         const long col = col_of(hc);
-        // ---- phase 1: out-lists
-        float out_sum[CHL];
+        float acc_i[CHL];
 #pragma unroll
-        for (int j = 0; j < CHL; ++j) out_sum[j] = 0.f;
-        if (has_node) {
-            float vn[CHL], acc[CHL];
-            {
-                const float* src = reinterpret_cast<const float*>(vs + n * VSB) + sub * CHL;
+        for (int j = 0; j < CHL; ++j) acc_i[j] = 0.f;
+        int ib = 0, mine_i = 0, ki = 0;                                  // my entries of the in-list: ib + k P2, k < mine_i
+        if (has2) {
+            ib = iptr[n2] + part2;
+            mine_i = (iptr[n2 + 1] - ib + P2 - 1) >> lgP2;
+        }
+        const unsigned eoff0 = (unsigned)hc.e0 * rowb + (unsigned)col * (unsigned)sizeof(T);
+        const int Ee = max(hc.Ee, 0);
+        bool first_batch = true;
+        // batches are node-aligned: nodes [nlo, nhi), edges [optr[nlo], optr[nhi]) <= EB (a node has < 64 out-edges <= EB).
+        // The first batch of a unit was fetched before its lists were known: edges [0, min(EB, Ee)), a superset of its node range.
+        int nlo = 0;
+        for (;;) {
+            int nhi = nlo;
+            const int blo = __builtin_amdgcn_readfirstlane(optr[nlo]);
+            int bhi = blo;
+            while (nhi < hc.Nn) {
+                const int nx = __builtin_amdgcn_readfirstlane(optr[nhi + 1]);
+                if (nx - blo > EB) break;
+                bhi = nx;
+                ++nhi;
+            }
+            const bool last = nhi >= hc.Nn;
+            if (last) bhi = Ee;                                          // (edges past the last node's list do not exist; keeps the cursors simple)
+            SGG_DTICK(1)
+            if (!first_batch) {
+                wait_loads(nst);                                         // this batch's DMA (my part of it)
+                nst = 0;
+                __syncthreads();                                         // (D) batch visible; every wave has left the last batch
+            }
+            // the other staging buffer is free: next batch of this unit, or the first batch of the next unit
+            if (SGG_DMA_ABL != 3) {
+                if (!last) {
+                    int mhi = nhi;
+                    int ehi = bhi;
+                    while (mhi < hc.Nn) {
+                        const int nx = __builtin_amdgcn_readfirstlane(optr[mhi + 1]);
+                        if (nx - bhi > EB) break;
+                        ehi = nx;
+                        ++mhi;
+                    }
+                    if (mhi >= hc.Nn) ehi = Ee;
+                    issue_dma(hc, bhi, ehi, par ^ 1);
+                } else if (more) {
+                    issue_dma(hn, 0, min(EB, hn.Ee), par ^ 1);
+                }
+            }
+            SGG_DTICK(2)
+            if (first_batch && more) issue_small(hn);                    // consumed after the next unit's top wait
+            first_batch = false;
+            SGG_DTICK(3)
+            const int soff = (par * EB - blo) * PIECE + sub * 16;         // this lane's 16 bytes of graph-local edge el: stage0 + soff + el * PIECE
+            // ---- phase 1: the out-lists of nodes [nlo, nhi), all lane groups
+            auto phase1 = [&]() {
+                const int nb = nhi - nlo;
+                int P1 = 1, lgP1 = 0;
+                while (2 * P1 * LP <= 64 && 2 * P1 * nb <= GROUPS) {
+                    P1 *= 2;
+                    ++lgP1;
+                }
+                const int part1 = grp & (P1 - 1), n1 = nlo + (grp >> lgP1);
+                if (n1 < nhi) {
+                    float vn[CHL], acc_o[CHL];
+                    const float* src = reinterpret_cast<const float*>(vs + n1 * VSB) + sub * CHL;
+#pragma unroll
+                    for (int j = 0; j < CHL; j += 4) {
+                        const f32x4 t = *reinterpret_cast<const f32x4*>(src + j);
+                        vn[j] = t.x; vn[j + 1] = t.y; vn[j + 2] = t.z; vn[j + 3] = t.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < CHL; ++j) acc_o[j] = 0.f;
+                    const int ob = optr[n1] + part1;                     // my entries: ob + k P1, k < mine_o
+                    const int mine_o = (optr[n1 + 1] - ob + P1 - 1) >> lgP1;
+                    for (int kb = 0;; kb += U) {
+                        if (__builtin_amdgcn_ballot_w64(kb < mine_o) == 0) break;   // wave-uniform
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const bool live = kb + u < mine_o;
+                            if (__builtin_amdgcn_ballot_w64(live) == 0) break;      // wave-uniform
+                            ++nst;                           // one e_in store instruction per wave and step (uniform count)
+                            if (live) {
+                                const int el = ob + ((kb + u) << lgP1);
+#if SGG_DMA_ABL == 1                             // experiment: the access pattern alone (staged piece in, piece out)
+                                *reinterpret_cast<u32x4*>(e_in_c + (eoff0 + (unsigned)el * rowb)) = *reinterpret_cast<const u32x4*>(stage0 + (soff + el * PIECE));
+                                continue;
+#endif
+                                const f32x4 gt = *reinterpret_cast<const f32x4*>(gates + el * 4);
+                                const int o = onl8[el];
+                                Piece16<T> rowp;
+                                rowp.r = *reinterpret_cast<const decltype(rowp.r)*>(stage0 + (soff + el * PIECE));
+                                float xx[CHL], yy[CHL], rr[CHL];
+                                rowp.get(xx);
+                                const float* vo = reinterpret_cast<const float*>(vs + o * VSB) + sub * CHL;
+#pragma unroll
+                                for (int j = 0; j < CHL; j += 4) {
+                                    const f32x4 t = *reinterpret_cast<const f32x4*>(vo + j);
+                                    yy[j] = t.x; yy[j + 1] = t.y; yy[j + 2] = t.z; yy[j + 3] = t.w;
+                                }
+#pragma unroll
+                                for (int j = 0; j < CHL; ++j) {
+                                    rr[j] = gt.x * vn[j] + gt.y * yy[j];
+                                    acc_o[j] = fmaf(gt.z, xx[j], acc_o[j]);
+                                }
+                                if (SGG_DMA_ABL != 2) Piece16<T>::store(reinterpret_cast<T*>(e_in_c + (eoff0 + (unsigned)el * rowb)), rr);
+                            }
+                        }
+                    }
+                    // a node's out-list lies inside its batch: ctx_out is complete
+                    for (int off = LP; off < P1 * LP; off <<= 1) {
+#pragma unroll
+                        for (int j = 0; j < CHL; ++j) acc_o[j] += __shfl_xor(acc_o[j], off, 64);
+                    }
+                    if (part1 == 0) {
+                        if (sum_ctx) {                                   // meets ctx_in at the end of the unit (other lanes own it there)
+                            float* dst = reinterpret_cast<float*>(osum + n1 * VSB) + sub * CHL;
+#pragma unroll
+                            for (int j = 0; j < CHL; j += 4) *reinterpret_cast<f32x4*>(dst + j) = f32x4{acc_o[j], acc_o[j + 1], acc_o[j + 2], acc_o[j + 3]};
+                        } else {
+                            Piece16<T>::store(ctx2 + (long)(hc.n0 + n1) * H + col, acc_o);
+                        }
+                    }
+                }
+            };
+            // ---- phase 2: my in-list entries inside this batch (in-lists ascend in edge id: a cursor), from the staged pieces
+            auto phase2 = [&]() {
+            if (has2 && SGG_DMA_ABL != 1) {
+                constexpr int U2 = 2;
+                for (;;) {
+                    int el[U2];
+                    bool lv[U2];
+#pragma unroll
+                    for (int u = 0; u < U2; ++u) {
+                        el[u] = in_loc[ib + (min(ki + u, max(mine_i - 1, 0)) << lgP2)];
+                        lv[u] = ki + u < mine_i && el[u] < bhi;
+                    }
+                    // (entries ascend: once one is outside the batch, so are the later ones)
+                    if (__builtin_amdgcn_ballot_w64(lv[0]) == 0) break;
+                    int done = 0;
+#pragma unroll
+                    for (int u = 0; u < U2; ++u) {
+                        if (lv[u]) {
+                            const float g3 = gates[el[u] * 4 + 3];
+                            Piece16<T> rw;
+                            rw.r = *reinterpret_cast<const decltype(rw.r)*>(stage0 + (soff + el[u] * PIECE));
+                            float xx[CHL];
+                            rw.get(xx);
+#pragma unroll
+                            for (int j = 0; j < CHL; ++j) acc_i[j] = fmaf(g3, xx[j], acc_i[j]);
+                            ++done;
+                        }
+                    }
+                    ki += done;
+                    if (__builtin_amdgcn_ballot_w64(done == U2) == 0) break;
+                }
+            }
+            };
+            // the two phases are independent.  Half the waves of every SIMD run them in the other order: phase 1 issues the stores
+            // (and stalls on the memory pipe), phase 2 is LDS + VALU only -- in lockstep, all 16 waves queued on the store path at once
+            if ((wv >> 2) & 1) {
+                phase2();
+                SGG_DTICK(4)
+                phase1();
+            } else {
+                phase1();
+                SGG_DTICK(4)
+                phase2();
+            }
+            SGG_DTICK(5)
+            par ^= 1;
+            ++unit_no;                                                   // (stamps are per batch)
+            if (last) break;
+            nlo = nhi;
+        }
+        // ---- unit done: the P2 partial in-sums of a node meet, one store per node
+        if (has2) {
+            for (int off = LP; off < P2 * LP; off <<= 1) {
+#pragma unroll
+                for (int j = 0; j < CHL; ++j) acc_i[j] += __shfl_xor(acc_i[j], off, 64);
+            }
+            if (part2 == 0) {
+                if (sum_ctx) {
+                    // osum[n2] was written by other lanes before barrier (D) of a later batch or -- last batch -- in this very
+                    // phase: make it visible first (below)
+                } else {
+                    Piece16<T>::store(ctx2 + ((long)N + hc.n0 + n2) * H + col, acc_i);
+                }
+            }
+        }
+        if (sum_ctx) {
+            __syncthreads();                                             // (E) every ctx_out piece of the unit is in osum
+            if (has2 && part2 == 0) {
+                const float* src = reinterpret_cast<const float*>(osum + n2 * VSB) + sub * CHL;
 #pragma unroll
                 for (int j = 0; j < CHL; j += 4) {
                     const f32x4 t = *reinterpret_cast<const f32x4*>(src + j);
-                    vn[j] = t.x; vn[j + 1] = t.y; vn[j + 2] = t.z; vn[j + 3] = t.w;
+                    acc_i[j] += t.x; acc_i[j + 1] += t.y; acc_i[j + 2] += t.z; acc_i[j + 3] += t.w;
                 }
-            }
-#pragma unroll
-            for (int j = 0; j < CHL; ++j) acc[j] = 0.f;
-            const bool oddg = gk & 1;                        // gates 1 (obj_vert) and 3 (in_edge) look at v[o], 0 and 2 at v[s] = v[n]
-            const int ob = optr[n], oe = optr[n + 1];
-            // entries ob + part, ob + part + P, ...: `mine` of them
-            const int mine = (oe - ob - part + P - 1) >> lgP;
-            const unsigned eoff0 = (unsigned)(hc.e0 + ob + part) * rowb + (unsigned)col * (unsigned)sizeof(T);
-            for (int kb = 0; kb < mine; kb += U) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const bool live = kb + u < mine;     // lanes of a quad share `live`: the DPP broadcasts stay inside a lane group
-                    if (__builtin_amdgcn_ballot_w64(live) == 0) break;   // wave-uniform: no lane group of this wave has another edge
-                    const int el = live ? ob + part + ((kb + u) << lgP) : 0;
-#if SGG_DMA_ABL == 1                             // experiment: the access pattern alone (staged piece in, piece out)
-                    if (live) *reinterpret_cast<u32x4*>(e_in_c + (eoff0 + (unsigned)((kb + u) << lgP) * rowb)) = *reinterpret_cast<const u32x4*>(stage + el * PIECE + sub * 16);
-                    continue;
-#endif
-                    // gate k: 0 sub_vert(v[s]), 1 obj_vert(v[o]), 2 out_edge(v[s]), 3 in_edge(v[o])  (rel_model_stanford.py:78-89)
-                    const int o = onl8[el];
-                    const float vd = nd[(oddg ? o : n) * 4 + gk];
-                    const float gate = sigmoidf_(vd + dots[el * 4 + gk] + bias);
-                    const float gs = quad_bcast<0x00>(gate), go = quad_bcast<0x55>(gate), gx = quad_bcast<0xAA>(gate);
-                    if (live) {
-                        Piece16<T> rowp;
-                        rowp.r = *reinterpret_cast<const decltype(rowp.r)*>(stage + el * PIECE + sub * 16);
-                        float xx[CHL], yy[CHL], rr[CHL];
-                        rowp.get(xx);
-                        const float* vo = reinterpret_cast<const float*>(vs + o * VSB) + sub * CHL;
-#pragma unroll
-                        for (int j = 0; j < CHL; j += 4) {
-                            const f32x4 t = *reinterpret_cast<const f32x4*>(vo + j);
-                            yy[j] = t.x; yy[j + 1] = t.y; yy[j + 2] = t.z; yy[j + 3] = t.w;
-                        }
-#pragma unroll
-                        for (int j = 0; j < CHL; ++j) {
-                            rr[j] = gs * vn[j] + go * yy[j];
-                            acc[j] = fmaf(gx, xx[j], acc[j]);
-                        }
-                        if (SGG_DMA_ABL != 2) Piece16<T>::store(reinterpret_cast<T*>(e_in_c + (eoff0 + (unsigned)((kb + u) << lgP) * rowb)), rr);
-                    }
-                }
-            }
-            for (int off = LP; off < P * LP; off <<= 1) {
-#pragma unroll
-                for (int j = 0; j < CHL; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
-            }
-            if (sum_ctx) {
-#pragma unroll
-                for (int j = 0; j < CHL; ++j) out_sum[j] = acc[j];
-            } else if (part == 0) {
-                Piece16<T>::store(ctx2 + (long)(hc.n0 + n) * H + col, acc);
+                Piece16<T>::store(ctx2 + (long)(hc.n0 + n2) * H + col, acc_i);
             }
         }
-        SGG_DTICK(4)
-        SGG_DTICK(5)
-        SGG_DTICK(6)
-        // ---- phase 2: in-lists, from the staged pieces.  NO barrier in front of it: g_in of an in-edge is recomputed here from the
-        // parked dots (one exp + rcp per lane and edge) instead of being handed over through LDS by whichever wave owned the edge's
-        // subject -- the barrier cost more than the five instructions (clock stamps: waves idled a quarter of a unit at it).
-        if (has_node && SGG_DMA_ABL != 1) {
-            const int beg = iptr[n], end = iptr[n + 1];
-            const int mine = (end - beg - part + P - 1) >> lgP;
-            const float nb3 = nd[n * 4 + 3] + gb[3];        // in_edge gate: v[o] = v[n] for every edge of n's in-list
-            float acc[CHL];
-#pragma unroll
-            for (int j = 0; j < CHL; ++j) acc[j] = 0.f;
-            constexpr int U2 = 4;
-            for (int kb = 0; kb < mine; kb += U2) {
-                int el[U2];
-#pragma unroll
-                for (int u = 0; u < U2; ++u) el[u] = in_loc[beg + part + (min(kb + u, mine - 1) << lgP)];
-                Piece16<T> rw[U2];
-                float gv[U2];
-#pragma unroll
-                for (int u = 0; u < U2; ++u) {
-                    rw[u].r = *reinterpret_cast<const decltype(rw[u].r)*>(stage + el[u] * PIECE + sub * 16);
-                    gv[u] = dots[el[u] * 4 + 3];
-                }
-#pragma unroll
-                for (int u = 0; u < U2; ++u) {
-                    const float g3 = (kb + u < mine) ? sigmoidf_(gv[u] + nb3) : 0.f;
-                    float xx[CHL];
-                    rw[u].get(xx);
-#pragma unroll
-                    for (int j = 0; j < CHL; ++j) acc[j] = fmaf(g3, xx[j], acc[j]);
-                }
-            }
-            for (int off = LP; off < P * LP; off <<= 1) {
-#pragma unroll
-                for (int j = 0; j < CHL; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
-            }
-            if (sum_ctx) {
-#pragma unroll
-                for (int j = 0; j < CHL; ++j) acc[j] += out_sum[j];
-                if (part == 0) Piece16<T>::store(ctx2 + (long)(hc.n0 + n) * H + col, acc);
-            } else if (part == 0) {
-                Piece16<T>::store(ctx2 + ((long)N + hc.n0 + n) * H + col, acc);
-            }
-        }
-        SGG_DTICK(7)
-        ++unit_no;
         if (!more) break;
         idx += wx;
-        par ^= 1;
         hc = hn;
-        hn = hnn;
-        if (idx + 2 * wx < cnt) hnn = load_hdr(idx + 2 * wx);            // scalar loads (their own counter), two units ahead
+        if (idx + wx < cnt) hn = load_hdr(idx + wx);                     // scalar loads, one unit ahead
     }
 }
 
@@ -1459,24 +1600,23 @@ int launch_stream(const void* v, const void* e, const int* so, const int* in_ptr
 }
 
 // LDS-DMA form: one resident 16-wave workgroup per CU, two staging buffers (imp_dma_kernel)
-template <typename T>
+template <typename T, int LP>
 int launch_dma(const void* v, const void* e, const int* so, const int* in_ptr, const int* in_ids, const int* img_ptr, int B, int N,
-               int H, const float* ndots, const float* edots, const float* gb, void* e_in, void* ctx2, int max_edges, int max_nodes,
+               int H, const float* ndots, const float* edots, const float* gb, void* e_in, void* ctx2, int emax, int nmax, int eb,
                int sum_ctx, int max_wgs, hipStream_t s) {
-    auto k = imp_dma_kernel<T>;
+    auto k = imp_dma_kernel<T, LP>;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                DM_LDS_MAX) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS_MAX) != hipSuccess)
             return SGG_ERR_LAUNCH;
         configured = true;
     }
-    const int emax = (max(max_edges, 16) + 15) & ~15, nmax = (max(max_nodes, 8) + 7) & ~7;
-    const int units = B * (H * (int)sizeof(T) / DM_PIECE);
+    const int piece = LP * 16, vsb = 64 * LP / (int)sizeof(T);
+    const int units = B * (H * (int)sizeof(T) / piece);
     int grid = min(units, 256);
     if (max_wgs > 0) grid = min(grid, max_wgs);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(DM_THREADS), dma_lds_bytes(emax, nmax, sizeof(T) == 2 ? 128 : 64), s, (const T*)v, (const T*)e, so, in_ptr, in_ids,
-                       img_ptr, B, N, H, ndots, edots, gb, (T*)e_in, (T*)ctx2, emax, nmax, sum_ctx);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(DM_THREADS), 2 * eb * piece + dma_fixed_bytes(emax, nmax, vsb, sum_ctx != 0), s, (const T*)v, (const T*)e,
+                       so, in_ptr, in_ids, img_ptr, B, N, H, ndots, edots, gb, (T*)e_in, (T*)ctx2, emax, nmax, eb, sum_ctx);
     return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
 }
 }  // namespace
@@ -1528,22 +1668,40 @@ extern "C" int sgg_imp_sliced_fwd(const void* v, const void* e, const int* so, c
             max_edges <= (f == 8 ? SliceCfg<8>::EMAX : f == 4 ? SliceCfg<4>::EMAX : SliceCfg<2>::EMAX))
             lp = f;
     }
-    // Default: the persistent LDS-DMA kernel for graphs whose pieces fit two staging buffers; SGG_IMP_STREAM=0: the short-lived
-    // form (one workgroup per unit: larger graphs, and the cross-check of the persistent kernels); =1: the register-prefetch
-    // persistent form (experiment).  SGG_IMP_MAX_WGS=n caps the persistent grid (tests: several units per workgroup on small batches)
+    // Default: the short-lived form (one workgroup per unit, two per CU) -- still the fastest measured (DESIGN.md "IMP step").
+    // SGG_IMP_STREAM=d: the persistent LDS-DMA kernel (128-byte pieces, batches, gates once per unit); =1: the register-prefetch
+    // persistent form.  Both are kept as measured experiments and as cross-checks of the default (tests/test_kernels_gpu.py).
+    // SGG_IMP_MAX_WGS=n caps the persistent grid (tests: several units per workgroup on small batches).
     const char* st = getenv("SGG_IMP_STREAM");
     const char* mw = getenv("SGG_IMP_MAX_WGS");
     const int max_wgs = mw ? atoi(mw) : 0;
-    // (graphs whose pieces do not fit two staging buffers, or whose e_in exceeds 32-bit byte offsets, take the short-lived form)
-    const bool dma_fits = row % DM_PIECE == 0 && max_nodes <= DM_NMAX && max_edges <= DM_EMAX &&
-                          dma_lds_bytes((max(max_edges, 16) + 15) & ~15, (max(max_nodes, 8) + 7) & ~7, dtype == SGG_BF16 ? 128 : 64) <= DM_LDS_MAX &&
-                          (long)E * row < 0xffff0000L;
-    if ((!st || st[0] == 'd') && dma_fits) {
-        if (dtype == SGG_BF16)
-            return launch_dma<bf16_t>(v, e, so, in_ptr, in_ids, img_ptr, B, N, H, node_dots, edge_dots, gate_b, e_in, ctx2, max_edges,
-                                      max_nodes, sum_ctx, max_wgs, s);
-        return launch_dma<float>(v, e, so, in_ptr, in_ids, img_ptr, B, N, H, node_dots, edge_dots, gate_b, e_in, ctx2, max_edges,
-                                 max_nodes, sum_ctx, max_wgs, s);
+    // (graphs above one edge per thread, or whose e_in exceeds 32-bit byte offsets, take the short-lived form)
+    if (st && st[0] == 'd' && row % 64 == 0 && max_nodes <= DM_NMAX && max_edges <= DM_EMAX && (long)E * row < 0xffff0000L) {
+        const int emax = (max(max_edges, 16) + 15) & ~15, nmax = (max(max_nodes, 8) + 7) & ~7;
+        const int tsz = dtype == SGG_BF16 ? 2 : 4;
+        // 128-byte pieces (full cache lines: 5.3 TB/s against 3.3 for half lines) when that still gives every CU a unit;
+        // SGG_IMP_PIECE=64|128 overrides (experiments, tests)
+        const char* pc = getenv("SGG_IMP_PIECE");
+        int piece = (row % 128 == 0 && (long)B * (row / 128) >= 256) ? 128 : 64;
+        if (pc && atoi(pc) == 64) piece = 64;
+        if (pc && atoi(pc) == 128 && row % 128 == 0) piece = 128;
+        const char* ebs = getenv("SGG_IMP_EB");     // tests: small batches (several per unit on small graphs)
+        for (; piece >= 64; piece -= 64) {
+            int eb = dma_batch_edges(emax, nmax, 4 * piece / tsz, piece, sum_ctx != 0);
+            if (eb < 64) continue;                  // a batch holds whole out-lists (< 64 edges each)
+            if (ebs && atoi(ebs) >= 64) eb = min(eb, atoi(ebs) & ~15);
+#define SGG_DMA(T, LPV) \
+    return launch_dma<T, LPV>(v, e, so, in_ptr, in_ids, img_ptr, B, N, H, node_dots, edge_dots, gate_b, e_in, ctx2, emax, nmax, eb, \
+                              sum_ctx, max_wgs, s)
+            if (dtype == SGG_BF16) {
+                if (piece == 128) SGG_DMA(bf16_t, 8);
+                SGG_DMA(bf16_t, 4);
+            } else {
+                if (piece == 128) SGG_DMA(float, 8);
+                SGG_DMA(float, 4);
+            }
+#undef SGG_DMA
+        }
     }
     if (st && st[0] == '1') {
 #define SGG_STREAM(T, LPV) \

@@ -613,8 +613,15 @@ def test_imp_persistent_kernels_equal_short_lived_form(ops, dtype, monkeypatch):
         _, ref_sum = ops.imp_sliced(v, e, csr, nd, ed, gb, ctx_sum=torch.empty_like(v))
         assert torch.isfinite(ref_ein.float()).all() and torch.isfinite(ref_ctx2.float()).all()
         ctol = dict(atol=1e-4, rtol=1e-5) if dtype == torch.float32 else dict(atol=0.13, rtol=1.6e-2)   # 2 bf16 ulps
-        for form in ('d', '1'):
+        # (form, piece bytes, edges per batch): the LDS-DMA kernel with half-line and full-line pieces, one batch per unit and
+        # several (small batches: lists of one node straddle batch boundaries, the in-list cursors advance across them)
+        for form, piece, eb in (('d', '64', ''), ('d', '128', ''), ('d', '128', '80'), ('d', '64', '64'), ('1', '', '')):
             monkeypatch.setenv('SGG_IMP_STREAM', form)
+            for k_, v_ in (('SGG_IMP_PIECE', piece), ('SGG_IMP_EB', eb)):
+                if v_:
+                    monkeypatch.setenv(k_, v_)
+                else:
+                    monkeypatch.delenv(k_, raising=False)
             first = None
             for cap in ('', '1', '3', '8', '11'):
                 if cap:
@@ -623,17 +630,19 @@ def test_imp_persistent_kernels_equal_short_lived_form(ops, dtype, monkeypatch):
                     monkeypatch.delenv('SGG_IMP_MAX_WGS', raising=False)
                 e_in, ctx2 = ops.imp_sliced(v, e, csr, nd, ed, gb)
                 _, csum = ops.imp_sliced(v, e, csr, nd, ed, gb, ctx_sum=torch.empty_like(v))
-                assert torch.equal(e_in, ref_ein), (case, form, cap)
+                assert torch.equal(e_in, ref_ein), (case, form, piece, eb, cap)
                 # ctx: a node's list is cut into more parts by the 16-wave kernel (other association of the same f32 terms)
                 torch.testing.assert_close(ctx2.float(), ref_ctx2.float(), **ctol)
                 torch.testing.assert_close(csum.float(), ref_sum.float(), **ctol)
                 if first is None:
                     first = (e_in, ctx2, csum)
                 else:                                                    # the same form is bit-reproducible for every grid size
-                    assert all(torch.equal(a, b) for a, b in zip(first, (e_in, ctx2, csum))), (case, form, cap)
+                    assert all(torch.equal(a, b) for a, b in zip(first, (e_in, ctx2, csum))), (case, form, piece, eb, cap)
         # understated capacity (graph 0 promised as 40 edges): its outputs are NaN, the other graphs are untouched
         if case == 2:
             lie = ops.edge_csr(cu(rel), N, cu(im), graphs=(len(sizes), max(sizes), 8))
+            monkeypatch.delenv('SGG_IMP_PIECE', raising=False)
+            monkeypatch.delenv('SGG_IMP_EB', raising=False)
             for form in ('d', '1', '0'):
                 monkeypatch.setenv('SGG_IMP_STREAM', form)
                 monkeypatch.setenv('SGG_IMP_MAX_WGS', '2')

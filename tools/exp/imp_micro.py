@@ -59,12 +59,17 @@ for B in Bs:
         lib.sgg_dbg_dma_ticks.argtypes = [ctypes.c_void_p]
         assert lib.sgg_dbg_dma_ticks(buf.ctypes.data) == 0
         t = buf.reshape(8, 16, 8)
-        units = int(min(16, max(1, (B * (H * s // 64) + 255) // 256)))
-        names = ['top-wait', 'barA+park+barB', 'dma+fetch issue', 'phase1', '-', '-', 'phase2', 'loop-tail']
+        # stamps per BATCH: 0 unit top (first batch of a unit only), 1 batch top, 2 after wait + barrier(s) + DMA issue, 3 after small-fetch issue,
+        # 4 after phase 1, 5 after phase 2
         for blk in (0, 3):
-            print(' block %d (stamps of wave 0; clock64 ticks), %d units' % (blk, units))
-            for u in range(units):
-                d = np.diff(t[blk, u])
-                nxt = t[blk, u + 1, 0] - t[blk, u, 7] if u + 1 < units else 0
-                print('   unit %2d: ' % u + '  '.join('%s %5d' % (nm, x) for nm, x in zip(names, list(d) + [nxt])) + '   total %d' % (t[blk, u, 7] - t[blk, u, 0]))
+            print(' block %d (wave 0; clock64 ticks per batch)' % blk)
+            prev_end = None
+            for u in range(16):
+                r = t[blk, u]
+                if r[5] == 0:
+                    break
+                gap = (r[1] - prev_end) if prev_end is not None else 0
+                print('   batch %2d: since-last-batch-end %6d | wait+bar+dma-issue %6d  small-issue %5d  phase1 %6d  phase2 %6d   | batch total %6d' %
+                      (u, gap, r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4], r[5] - r[1]))
+                prev_end = r[5]
     os.environ.pop('SGG_IMP_STREAM', None)

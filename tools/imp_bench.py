@@ -13,7 +13,7 @@ from sgg_amd.synthetic import SyntheticData, init_weights  # noqa: E402
 
 model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls')).to('cuda:0').eval()
 names = {'d': 'dma', '1': 'stream', '0': 'short', 'fused': 'node-centric'}
-forms = os.environ.get('IMP_FORMS', 'd,1,0,fused').split(',')
+forms = os.environ.get('IMP_FORMS', '0,d,1,fused').split(',')
 for dtype, s in ((torch.bfloat16, 2), (torch.float32, 4)):
     model.set_compute_dtype(dtype)
     for B in [int(b) for b in os.environ.get('IMP_B', '8,32,128').split(',')]:
