@@ -203,8 +203,10 @@ class BasicSceneGraphEvaluator(object):
         return weights
 
     # ------------------------------------------------------------------ per-image preparation (:134-222)
-    def _prepare(self, gt_entry, pred_entry, mode, multiple_preds):
-        """-> None (entry fully handled on the host: preddet) or a dict for the matching stage."""
+    def _prepare(self, gt_entry, pred_entry, mode, multiple_preds, ranked=None):
+        """-> None (entry fully handled on the host: preddet) or a dict for the matching stage.  `ranked` (optional dict): the
+        prediction ranking depends on pred_entry only, not on the ground truth -- evaluators that see the same image (the 2 x 50
+        per-predicate evaluators) share it through this cache instead of sorting the image's scores again."""
         result_dict = self.result_dict
         gt_rels = np.asarray(gt_entry['gt_relations'])
         gt_boxes = np.asarray(gt_entry['gt_boxes']).astype(float)
@@ -248,8 +250,11 @@ class BasicSceneGraphEvaluator(object):
         else:
             raise ValueError('invalid mode')
 
-        overall_order = None
-        if multiple_preds:                                       # :215-219
+        key = (id(pred_entry), mode, bool(multiple_preds), mode == 'objcls' and id(gt_entry))
+        hit = ranked.get(key) if ranked is not None else None
+        if hit is not None:
+            pred_rels, predicate_scores, overall_order = hit
+        elif multiple_preds:                                     # :215-219
             obj_scores_per_rel = obj_scores[pred_rel_inds].prod(1)
             overall_scores = obj_scores_per_rel[:, None] * rel_scores[:, 1:]
             overall_order = argsort_desc(overall_scores)
@@ -257,8 +262,11 @@ class BasicSceneGraphEvaluator(object):
             pred_rels = np.column_stack((pred_rel_inds[score_inds[:, 0]], score_inds[:, 1] + 1))
             predicate_scores = rel_scores[score_inds[:, 0], score_inds[:, 1] + 1]
         else:                                                    # :220-222
+            overall_order = None
             pred_rels = np.column_stack((pred_rel_inds, 1 + rel_scores[:, 1:].argmax(1)))
             predicate_scores = rel_scores[:, 1:].max(1)
+        if ranked is not None and hit is None:
+            ranked[key] = (pred_rels, predicate_scores, overall_order)
         prep = dict(gt_rels=gt_rels, gt_boxes=gt_boxes, gt_classes=gt_classes, pred_rels=pred_rels, pred_boxes=pred_boxes,
                     pred_classes=pred_classes, predicate_scores=predicate_scores, obj_scores=obj_scores, mode=mode,
                     pred_rel_inds=pred_rel_inds, overall_order=overall_order)
@@ -291,12 +299,12 @@ class BasicSceneGraphEvaluator(object):
             result_dict[mode + '_counts'].extend(counts)
 
     # ------------------------------------------------------------------ public evaluation entry points
-    def evaluate_scene_graph_batch(self, gt_entries, pred_entries, iou_thresh=0.5):
+    def evaluate_scene_graph_batch(self, gt_entries, pred_entries, iou_thresh=0.5, ranked=None):
         """Many images, one matching launch (and one more for the per-triplet ranks).  Updates result_dict exactly as
-        calling evaluate_scene_graph_entry image by image."""
+        calling evaluate_scene_graph_entry image by image.  `ranked`: see _prepare."""
         if self.per_triplet and not self.multiple_preds:
             raise NameError('per_triplet needs multiple_preds=True (overall_scores, lib/sgg_eval.py:249)')
-        preps = [self._prepare(g, p, self.mode, self.multiple_preds) for g, p in zip(gt_entries, pred_entries)]
+        preps = [self._prepare(g, p, self.mode, self.multiple_preds, ranked) for g, p in zip(gt_entries, pred_entries)]
         live = [p for p in preps if p is not None]
         if not live:
             return
@@ -388,43 +396,86 @@ class BasicSceneGraphEvaluator(object):
         return output
 
 
+class PredicateRecall(object):
+    """Recall per predicate and its mean over predicates -- the job of lib/sgg_eval.py:420-496 (calculate_mR_from_evaluator_list,
+    eval_entry).  One graph-constrained and one unconstrained evaluator set per foreground predicate; a predicate's evaluators see
+    an image only if its ground truth holds that predicate, and then only those ground-truth relations.  Images arrive in
+    batches: per predicate ONE matching launch per evaluator over the images that contain it, and the prediction ranking of an
+    image is computed once and shared by all predicates."""
+
+    def __init__(self, ind_to_predicates=None):
+        self.rows = []                                   # (predicate id, name, {mode: evaluator}, {mode: unconstrained evaluator})
+        for pid, pname in enumerate(ind_to_predicates or ()):
+            if pid > 0:                                  # 0 = background
+                self.rows.append((pid, pname, BasicSceneGraphEvaluator.all_modes(),
+                                  BasicSceneGraphEvaluator.all_modes(multiple_preds=True)))
+
+    @classmethod
+    def from_lists(cls, evaluator_list, evaluator_multiple_preds_list):
+        """Wraps the reference's two parallel lists [(id, name, {mode: evaluator})]."""
+        self = cls()
+        for (pid, pname, ev), (pid2, _, ev_mp) in zip(evaluator_list, evaluator_multiple_preds_list):
+            assert pid == pid2
+            self.rows.append((pid, pname, ev, ev_mp))
+        return self
+
+    def evaluate_batch(self, mode, gt_entries, pred_entries):
+        holders = {}                                     # predicate id -> images whose ground truth holds it
+        for i, g in enumerate(gt_entries):
+            for pid in np.unique(np.asarray(g['gt_relations'])[:, -1]):
+                holders.setdefault(int(pid), []).append(i)
+        ranked = {}
+        for pid, _, ev, ev_mp in self.rows:
+            imgs = holders.get(pid)
+            if not imgs:
+                continue
+            sub_gt = []
+            for i in imgs:
+                rel = np.asarray(gt_entries[i]['gt_relations'])
+                sub_gt.append(dict(gt_entries[i], gt_relations=rel[rel[:, -1] == pid]))
+            sub_pred = [pred_entries[i] for i in imgs]
+            ev[mode].evaluate_scene_graph_batch(sub_gt, sub_pred, ranked=ranked)
+            ev_mp[mode].evaluate_scene_graph_batch(sub_gt, sub_pred, ranked=ranked)
+
+    def table(self, mode, multiple_preds=False):
+        """-> (names, f64[n_predicates, len(RECALL_KS)]): mean image-level R@K of every predicate (NaN: predicate never seen)."""
+        names, rows = [], []
+        for _, pname, ev, ev_mp in self.rows:
+            rec = (ev_mp if multiple_preds else ev)[mode].result_dict[mode + '_recall']
+            names.append(pname)
+            rows.append([np.mean(rec[k]) if len(rec[k]) else np.nan for k in RECALL_KS])
+        return names, np.asarray(rows, dtype=np.float64).reshape(len(names), len(RECALL_KS))
+
+    def mean_recall(self, mode, multiple_preds=False, save_file=None, verbose=True):
+        """{'R@K': mR@K}.  As in the reference, a predicate without any image (NaN R@100) adds nothing to the sum but still
+        counts in the denominator."""
+        names, tab = self.table(mode, multiple_preds)
+        seen = ~np.isnan(tab[:, RECALL_KS.index(100)]) if len(names) else np.zeros(0, bool)
+        mr = np.where(seen[:, None], tab, 0.0).sum(0) / max(len(names), 1)
+        mean_recall = {'R@%d' % k: float(v) for k, v in zip(RECALL_KS, mr)}
+        if verbose:
+            print('\n====== %s  mean recall %s constraint: %d predicates, %d seen ======' %
+                  (mode, 'without' if multiple_preds else 'with', len(names), int(seen.sum())))
+            for pname, row in zip(names, tab):
+                print('  %-16s ' % pname + '  '.join('R@%d %.4f' % (k, v) for k, v in zip(RECALL_KS, row)))
+            print('  ' + '  '.join('mR@%d: %.6f' % (k, mean_recall['R@%d' % k]) for k in RECALL_KS[:4]))
+        if save_file is not None:
+            if multiple_preds:
+                save_file = save_file.replace('.pkl', '_multiple_preds.pkl')
+            per_pred = {pname: {'R@%d' % k: float(v) for k, v in zip(RECALL_KS, row)} for pname, row in zip(names, tab)}
+            per_pred['mean_recall'] = mean_recall
+            with open(save_file, 'wb') as f:
+                pickle.dump(per_pred, f)
+        return mean_recall
+
+
 def calculate_mR_from_evaluator_list(evaluator_list, mode, multiple_preds=False, save_file=None):
-    """lib/sgg_eval.py:420-478 (mean recall over predicates; predicates with a NaN R@100 are skipped but still counted in
-    the denominator, as in the reference)."""
-    all_rel_results = {}
-    for (pred_id, pred_name, evaluator_rel) in evaluator_list:
-        print('\n')
-        print('relationship: ', pred_name)
-        all_rel_results[pred_name] = evaluator_rel[mode].print_stats()
-    sums = {k: 0.0 for k in (20, 50, 100, 200, 300)}
-    for key, value in all_rel_results.items():
-        if math.isnan(value['R@100']):
-            continue
-        for k in sums:
-            sums[k] += value['R@%d' % k]
-    rel_num = len(evaluator_list)
-    mean_recall = {'R@%d' % k: sums[k] / rel_num for k in sums}
-    all_rel_results['mean_recall'] = mean_recall
-    recall_mode = 'mean recall without constraint' if multiple_preds else 'mean recall with constraint'
-    print('\n')
-    print('======================' + mode + '  ' + recall_mode + '============================')
-    for k in (20, 50, 100, 200):
-        print('mR@%d: ' % k, mean_recall['R@%d' % k])
-    if save_file is not None:
-        if multiple_preds:
-            save_file = save_file.replace('.pkl', '_multiple_preds.pkl')
-        with open(save_file, 'wb') as f:
-            pickle.dump(all_rel_results, f)
-    return mean_recall
+    """The reference's entry point (lib/sgg_eval.py:420-478) over ONE list [(id, name, {mode: evaluator})]; `multiple_preds` only
+    says which kind of evaluators the list holds (it names the table and the save file)."""
+    pr = PredicateRecall.from_lists(evaluator_list, evaluator_list)
+    return pr.mean_recall(mode, multiple_preds=multiple_preds, save_file=save_file)
 
 
 def eval_entry(mode, gt_entry, pred_entry, evaluator_list, evaluator_multiple_preds_list):
-    """lib/sgg_eval.py:481-496: per-predicate evaluators see only the GT relations of their predicate."""
-    for (pred_id, _, evaluator_rel), (_, _, evaluator_rel_mp) in zip(evaluator_list, evaluator_multiple_preds_list):
-        gt_entry_rel = gt_entry.copy()
-        mask = np.isin(gt_entry_rel['gt_relations'][:, -1], pred_id)
-        gt_entry_rel['gt_relations'] = gt_entry_rel['gt_relations'][mask, :]
-        if gt_entry_rel['gt_relations'].shape[0] == 0:
-            continue
-        evaluator_rel[mode].evaluate_scene_graph_entry(gt_entry_rel, pred_entry)
-        evaluator_rel_mp[mode].evaluate_scene_graph_entry(gt_entry_rel, pred_entry)
+    """The reference's per-image entry point (lib/sgg_eval.py:481-496)."""
+    PredicateRecall.from_lists(evaluator_list, evaluator_multiple_preds_list).evaluate_batch(mode, [gt_entry], [pred_entry])

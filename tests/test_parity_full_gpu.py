@@ -1,0 +1,217 @@
+"""Parity of the BENCHMARKED configuration (bf16 compute) against the fp32 CPU oracle, with explicit numbers:
+
+ (i)  logits of the bench batch -- 8 x 592x592 frames, 32 boxes and 992 edges each, seed 111, bf16 -- against
+      oracle.forward_gtbox on the same inputs and weights: max / mean absolute error reported and bounded (the fp32 mode's 1e-3
+      bar is tests/test_model_gpu.py's; this is the bound the bf16 headline runs under);
+ (ii) R@K of the HIP forward (bf16 and fp32) against R@K of the ORACLE forward -- three forwards, one evaluator each -- on 2 048
+      ground-truth triplets (one triplet = 0.05 points), with a head trained until its softmaxes mean something (R@50 ~ 40 %): the
+      north star's +-0.1 on R@50 holds exactly in fp32 mode and for graph-constrained R@K in bf16 mode; bf16's unconstrained R@K is
+      bounded at 0.5 points (observed 0.34) and says so.
+Both write what they measured to gpurun_out/ (copied to profiles/ by the round's author)."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sgg_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _dump(name, payload):
+    out = os.path.join(ROOT, 'gpurun_out')
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, name), 'w') as f:
+            json.dump(payload, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _logits(model, batch):
+    """(obj_dists, rel_dists, rel_inds) of the eval forward, before the tail."""
+    dev = model.rel_fc.weight.device
+    with torch.no_grad():
+        res = model.faster_rcnn(batch[0], batch[3].to(dev), batch[4].to(dev), None)
+        rel_inds = model.get_rel_inds(None, res.im_inds, res.rm_box_priors)
+        rois = torch.cat((res.im_inds[:, None].float(), res.rm_box_priors), 1)
+        nf, ef = model.node_edge_features(res.fmap, rois, rel_inds[:, 1:], res.im_sizes)
+        od, rd = model.predict(nf, ef, rel_inds, rois, res.im_sizes, _im_inds=res.im_inds.contiguous())
+    return od.float().cpu().numpy(), rd.float().cpu().numpy(), rel_inds.cpu().numpy()
+
+
+# bounds of (i): about twice what was observed on MI355X (profiles/r02_parity_bench_config.json: obj max 0.42 / mean 0.059, rel max
+# 0.097 / mean 0.018, against logits of magnitude <= 3.9 / 2.4 with the He-initialised random weights of the bench; fp32 mode:
+# 7.5e-5 / 1.8e-5).  The object logits carry more error than the relation logits: a node's context is a sum of 62 gated edge rows
+# that is stored in bf16 (one rounding of a value ~8x the size of its terms) before it enters the node GRU, three times over.
+BF16_MAX_ABS = {'obj': 0.85, 'rel': 0.2}
+BF16_MEAN_ABS = {'obj': 0.12, 'rel': 0.04}
+
+
+def test_bench_config_bf16_logits_within_stated_tolerance():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import sgg_amd
+    from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls'))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV).eval()
+    batch = synthetic_batch(B=8, S=592, n_boxes=32, n_fg=6, seed=111)          # bench.py's rank-0 batch
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    t0 = time.time()
+    with torch.no_grad():
+        ref = O.forward_gtbox(batch[0], batch[3], batch[4], batch[5], sd, mode='sgcls')
+    t_ref = time.time() - t0
+    ref_od, ref_rd = ref['rm_obj_dists'].numpy(), ref['rel_dists'].numpy()
+    report = {'config': '8 x 592x592, 32 boxes, 992 edges per image, seed 111', 'oracle_seconds': round(t_ref, 1)}
+    for name, dt in (('f32', torch.float32), ('bf16', torch.bfloat16)):
+        model.set_compute_dtype(dt)
+        od, rd, rel_inds = _logits(model, batch)
+        np.testing.assert_array_equal(rel_inds, ref['rel_inds'])
+        assert od.shape == (256, 151) and rd.shape == (7936, 51)
+        e_o, e_r = np.abs(od - ref_od), np.abs(rd - ref_rd)
+        report[name] = {'obj_max_abs': float(e_o.max()), 'obj_mean_abs': float(e_o.mean()), 'rel_max_abs': float(e_r.max()),
+                        'rel_mean_abs': float(e_r.mean()), 'obj_logit_absmax': float(np.abs(ref_od).max()),
+                        'rel_logit_absmax': float(np.abs(ref_rd).max()),
+                        'obj_argmax_agreement': float((od[:, 1:].argmax(1) == ref_od[:, 1:].argmax(1)).mean()),
+                        'rel_argmax_agreement': float((rd[:, 1:].argmax(1) == ref_rd[:, 1:].argmax(1)).mean())}
+    _dump('r02_parity_bench_config.json', report)
+    print(json.dumps(report, indent=1))
+    f32, b16 = report['f32'], report['bf16']
+    assert f32['obj_max_abs'] <= 1e-3 and f32['rel_max_abs'] <= 1e-3, f32                 # the north star's fp32 bar, at full size
+    assert b16['obj_max_abs'] <= BF16_MAX_ABS['obj'] and b16['rel_max_abs'] <= BF16_MAX_ABS['rel'], b16
+    assert b16['obj_mean_abs'] <= BF16_MEAN_ABS['obj'] and b16['rel_mean_abs'] <= BF16_MEAN_ABS['rel'], b16
+
+
+# ------------------------------------------------------------------------------------------------- (ii) recall parity
+S_R, NB_R, NREL_R, NCLS_R = 320, 16, 32, 24
+
+
+def _colour(c):
+    return torch.tensor([(c * 37) % 256, (c * 91) % 256, (c * 53) % 256], dtype=torch.float32) / 255.0
+
+
+def _painted_batch(seed, B):
+    """Images a head can learn from: every box painted with its class's colour on a grey canvas, the predicate of a relation a
+    function of the two classes (uniform noise through a frozen random VGG gives every box the same features)."""
+    rng = np.random.RandomState(seed)
+    imgs, boxes, classes, rels = [], [], [], []
+    for b in range(B):
+        img = torch.full((3, S_R, S_R), 0.5) + 0.02 * torch.from_numpy(rng.randn(3, S_R, S_R).astype(np.float32))
+        xy = rng.uniform(0, S_R - 90, size=(NB_R, 2))
+        wh = rng.uniform(30, 85, size=(NB_R, 2))
+        bx = np.concatenate((xy, xy + wh), 1).astype(np.float32)
+        cls = rng.randint(1, NCLS_R + 1, size=NB_R)
+        for k in range(NB_R):
+            x1, y1, x2, y2 = [int(v) for v in bx[k]]
+            img[:, y1:y2, x1:x2] = _colour(int(cls[k]))[:, None, None]
+        seen = set()
+        while len(seen) < NREL_R:
+            s_, o_ = rng.randint(NB_R), rng.randint(NB_R)
+            if s_ != o_ and (s_, o_) not in seen:
+                seen.add((s_, o_))
+                rels.append((b, s_, o_, 1 + (int(cls[s_]) * 7 + int(cls[o_]) * 3) % 50))
+        imgs.append(img.clamp(0, 1))
+        boxes.append(bx)
+        classes.append(np.stack((np.full(NB_R, b), cls), 1).astype(np.int64))
+    return [imgs, np.array([[S_R, S_R, 1.0]] * B), 0, torch.from_numpy(np.concatenate(boxes)), torch.from_numpy(np.concatenate(classes)),
+            torch.from_numpy(np.array(rels, dtype=np.int64)), None, ['img%d_%d' % (seed, b) for b in range(B)]]
+
+
+def _single(b, i):
+    sel = b[4][:, 0] == i
+    cls = b[4][sel].clone()
+    cls[:, 0] = 0
+    rel = b[5][b[5][:, 0] == i].clone()
+    rel[:, 0] = 0
+    return ([b[0][i]], b[1][i:i + 1], 0, b[3][sel].clone(), cls, rel, None, [b[7][i]])
+
+
+def test_recall_of_hip_forward_equals_recall_of_oracle_forward():
+    """Three independent forwards per image (HIP bf16, HIP fp32, CPU oracle fp32), each scored by its own evaluator; 64 images x 32
+    GT relations = 2 048 triplets per table, sgcls and predcls, graph-constrained and not."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import sgg_amd
+    from sgg_amd.recall import BasicSceneGraphEvaluator
+    from sgg_amd.rel_model_base import to_device_with_mirror
+    from sgg_amd.synthetic import SyntheticData, init_weights
+    from sgg_amd.trainer import Trainer
+    B, steps = 8, int(os.environ.get('SGG_PARITY_STEPS', '800'))
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls', min_size=S_R, max_size=S_R)).to(DEV)
+    model.set_compute_dtype(torch.bfloat16)
+    model.dropout_p = 0.0
+    train_set = [_painted_batch(900 + s, B) for s in range(4)]
+
+    def on_dev(b):
+        b = list(b)
+        b[0] = [im.to(DEV) for im in b[0]]
+        b[3], b[4], b[5] = b[3].to(DEV), to_device_with_mirror(b[4], DEV), to_device_with_mirror(b[5], DEV)
+        return tuple(b)
+    dev_set = [on_dev(b) for b in train_set]
+    tr = Trainer(model, lr=0.02, pipeline=True)
+    for it in range(steps):
+        loss = tr.step(dev_set[it % len(dev_set)])
+    tr.flush()
+    torch.cuda.synchronize()
+    final_loss = float(loss)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    model.eval()
+    model.dropout_p = 0.5
+    held = [_painted_batch(5000 + s, B) for s in range(4)]
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    KS = (20, 50, 100)
+    paths = ('hip_bf16', 'hip_fp32', 'oracle_fp32')
+    evs = {(m, w, mp): BasicSceneGraphEvaluator(m, multiple_preds=mp) for m in ('sgcls', 'predcls') for w in paths for mp in (False, True)}
+    gts = {m: [] for m in ('sgcls', 'predcls')}
+    preds = {(m, w): [] for m in ('sgcls', 'predcls') for w in paths}
+    n_trip = 0
+    for b in train_set + held:
+        for i in range(B):
+            one = _single(b, i)
+            gt = {'gt_boxes': one[3].numpy(), 'gt_classes': one[4][:, 1].numpy(), 'gt_relations': one[5][:, 1:].numpy()}
+            n_trip += len(gt['gt_relations'])
+            with torch.no_grad():
+                ref = O.forward_gtbox(one[0], one[3], one[4], one[5], sd, mode='sgcls', min_size=S_R, max_size=S_R)
+            for mode in ('sgcls', 'predcls'):
+                model.mode = mode
+                outs = {}
+                with torch.no_grad():
+                    for name, dt in (('hip_bf16', torch.bfloat16), ('hip_fp32', torch.float32)):
+                        model.set_compute_dtype(dt)
+                        outs[name] = model([one])
+                    outs['oracle_fp32'] = ref['dets'] if mode == 'sgcls' else O.eval_tail(
+                        ref['rm_obj_dists'], ref['rel_dists'], ref['rel_inds'], one[3].numpy(), 'predcls', one[4][:, 1].numpy())
+                gts[mode].append(gt)
+                for name, (boxes, objs, scores, rels, pscores) in outs.items():
+                    preds[(mode, name)].append({'pred_boxes': boxes, 'pred_classes': objs, 'pred_rel_inds': rels, 'obj_scores': scores,
+                                                'rel_scores': pscores})
+    model.mode = 'sgcls'
+    assert n_trip >= 2000
+    table = {}
+    for (mode, name, mp), ev in evs.items():
+        ev.evaluate_scene_graph_batch(gts[mode], preds[(mode, name)])
+        table['%s %s %s' % (mode, name, 'noGC' if mp else 'GC')] = {('R@%d' % k): 100 * float(np.mean(ev.result_dict[mode + '_recall'][k])) for k in KS}
+    worst = {}
+    for name in ('hip_bf16', 'hip_fp32'):
+        for g in ('GC', 'noGC'):
+            worst['%s %s' % (name, g)] = max(abs(table['%s %s %s' % (m, name, g)]['R@%d' % k] - table['%s oracle_fp32 %s' % (m, g)]['R@%d' % k])
+                                             for m in ('sgcls', 'predcls') for k in KS)
+    report = {'gt_triplets': n_trip, 'images': len(gts['sgcls']), 'train_steps': steps, 'final_loss': final_loss, 'recall_percent': table,
+              'largest_abs_difference_to_oracle_points': worst, 'one_triplet_is_points': 100.0 / n_trip}
+    _dump('r02_recall_parity.json', report)
+    print(json.dumps(report, indent=1))
+    r50 = table['sgcls oracle_fp32 GC']['R@50']
+    assert 5.0 < r50 < 95.0, 'recall at the floor / ceiling: the comparison would not discriminate'
+    # fp32 mode (what the north star's parity clause is stated in): within +-0.1 everywhere -- observed: identical in all 12 cells
+    assert worst['hip_fp32 GC'] <= 0.1 and worst['hip_fp32 noGC'] <= 0.1, worst
+    # bf16 mode (what the headline throughput runs in): graph-constrained R@K -- the VG headline metric -- within +-0.1 (observed
+    # 0.05 = one triplet of 2 048); the graph-UNconstrained ranking puts every (pair, predicate) score of an image in one order and
+    # is decided by near-ties that bf16 rounding flips: observed up to 0.34 points (7 triplets), bounded at 0.5 and reported
+    assert worst['hip_bf16 GC'] <= 0.1, worst
+    assert worst['hip_bf16 noGC'] <= 0.5, worst
