@@ -7,6 +7,9 @@
   global-norm clip and SGD step -- nothing skipped.
 --mode infer: a step = RelModelStanford.forward in eval mode incl. the eval tail and the D2H copy of the result tuple
   (no collective).
+--mode sgdet (BASELINE configs[2], not the headline): a step = the SGDet eval forward -- VGG-16, RPN over 21 660 anchors, 1 000
+  proposals per image after NMS, the box head on all of them, per-class NMS, <= 50 detections, overlap-filtered pairs, union-box
+  RoIAlign, IMP, tail -- with the detector's score threshold at 0 (random-init weights: every candidate enters the per-class NMS).
 One batch = B synthetic 592x592 frames per GPU, 32 boxes and 32*31 candidate edges per image, inputs resident in HBM.
 Images are sharded over ranks (one process per GPU) => weak scaling.  Prints ONE JSON line on rank 0; the other mode's
 throughput is reported alongside under "other_mode".
@@ -38,7 +41,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=8, help='images per GPU (global batch 64 at 8 GPUs)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--mode', default='train', choices=['train', 'infer'])
+    ap.add_argument('--mode', default='train', choices=['train', 'infer', 'sgdet'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-f32', action='store_true', help='skip the short exact-fp32 runs reported under "f32_mode"')
     ap.add_argument('--force-dist', action='store_true',
@@ -237,6 +240,42 @@ def cpu_baseline(n_images, seed, timed=3):
                       % (timed, n_images, seed, cores, dt, min(full), max(full), dp)}
 
 
+def sgdet_bench(args, model, batch, timed, world, rank, B, dev):
+    """--mode sgdet: images/s of the SGDet eval forward at its real size + the per-call kernel times of one profiled pass."""
+    import torch
+    model.mode = 'sgdet'
+    model.detector.mode = 'refinerels'
+    model.set_box_score_thresh(0.0)
+
+    def step():
+        model.eval()
+        with torch.no_grad():
+            return model([batch])
+    out = step()
+    n_det, n_edges = len(out[1]), len(out[3])
+    elapsed = timed(step, args.warmup, args.steps)
+    if rank != 0:
+        return
+    kt = kernel_times(step, reps=3)
+    total_ms = sum(v[0] * v[1] for v in kt.values())
+    top = sorted(((v[0] * v[1], n, t) for (n, t), v in kt.items()), reverse=True)[:10]
+    # the box head's fc6 on <= 1000 proposals per image is the largest contraction of this mode
+    fc6 = max(((v[0] * v[1], n, t) for (n, t), v in kt.items() if n == 'sgg_gemm'), default=(0.0, '', ''))
+    line = {'metric': 'images/sec (whole node), VG SGDet eval forward (detector + IMP)', 'value': round(world * B * args.steps / elapsed, 3),
+            'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'VG SGDet (BASELINE configs[2]): 592x592 frames, RPN 21 660 anchors -> 1 000 proposals/img, box head, '
+                                   'per-class NMS, <= 50 detections/img, overlap-filtered pairs, union RoIAlign, 3 IMP iters, eval tail',
+                       'mode': 'sgdet', 'images_per_gpu': B, 'detections_per_step': n_det, 'candidate_edges_per_step': n_edges,
+                       'score_thresh': 0.0, 'weights': 'random init (He)'},
+            'kernels': {'sum_kernel_ms_per_step': round(total_ms, 3), 'largest_gemm_ms': round(fc6[0], 3),
+                        'top': [{'ms_per_step': round(ms_, 3), 'call': n, 'tag': t} for ms_, n, t in top]}}
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
     host_group = None
@@ -272,7 +311,7 @@ def main():
     from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
     tdtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     B = args.batch
-    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls')).to(dev).eval()
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgdet' if args.mode == 'sgdet' else 'sgcls')).to(dev).eval()
     model.set_compute_dtype(tdtype)
     # images sharded by rank: rank r owns global images [r*B, (r+1)*B)  (seed differs per rank)
     batch = list(synthetic_batch(B=B, S=592, n_boxes=32, n_fg=6, seed=111 + rank))
@@ -283,7 +322,7 @@ def main():
     batch = tuple(batch)
 
     from sgg_amd.trainer import Trainer
-    trainer = Trainer(model, lr=1e-3, force_dist=args.force_dist, pipeline=os.environ.get('SGG_PIPELINE', '1') != '0', sync_bn=os.environ.get('SGG_SYNC_BN', '1') != '0') if args.mode == 'train' else None
+    trainer = None if args.mode != 'train' else Trainer(model, lr=1e-3, force_dist=args.force_dist, pipeline=os.environ.get('SGG_PIPELINE', '1') != '0', sync_bn=os.environ.get('SGG_SYNC_BN', '1') != '0')
 
     def infer_step():
         model.eval()
@@ -316,6 +355,12 @@ def main():
             el = float(t.item())
         return el
 
+    if args.mode == 'sgdet':
+        sgdet_bench(args, model, batch, timed, world, rank, B, dev)
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     elapsed = timed(step, args.warmup, args.steps)
 
     # ---- per-kernel roofline (rank 0, outside the timed region; single-GPU kernels, no collective inside)

@@ -133,6 +133,16 @@ __device__ __forceinline__ float wave_max(float v) {
 // which was a tenth of the VALU work of an IMP edge.  Every kernel that makes a gate (forward, recompute in the backward) uses this one.
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// Workgroup barrier in front of an LDS buffer REFILL (LDS-DMA or ds_write by any wave after the barrier): this wave's LDS reads of
+// the buffer must have COMPLETED, not merely been issued, when it arrives.  A bare s_barrier does not say that: the compiler sinks
+// the `s_waitcnt lgkmcnt` -- and the MFMAs that consume the reads -- below it, and with two workgroups sharing a CU's LDS a queued
+// ds_read then loses the race against the refill.  Found in round 2 as run-to-run differences of conv1_2 (bf16, fused pool): a few
+// hundred wrong outputs in 24 % of the launches at benchmark size, none in the small-shape unit tests (one workgroup per CU).
+__device__ __forceinline__ void lds_reads_done_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 // XCD-aware block remap: consecutive logical ids land on the same XCD (dispatch puts block b on XCD b%8).
 // Bijective for any grid size (cdna guide T1).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

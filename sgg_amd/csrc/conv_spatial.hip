@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
 #endif
     const int nchunk = SGG_CONV_ABL == 1 ? 0 : (g.Cin * ESZ) / RB;
     for (int ch = 0; ch < nchunk; ++ch) {
-        if (ONEBAR && ch) __builtin_amdgcn_s_barrier();  // every wave is done with the previous patch and slab 0's buffer
+        if (ONEBAR && ch) lds_reads_done_barrier();      // every wave is done with the previous patch and slab 0's buffer
         stage_patch(ch);
         stage_w(0, ch, 0);
         for (int tap = 0; tap < 9; ++tap) {
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
                 // One barrier per tap: after it, slab `tap` (and the patch) have landed for every wave, and every wave
                 // has finished tap-1 -- the buffer tap-1 used is free and the slab for tap+1 can be streamed into it.
                 wait_vmcnt<0>();
-                __builtin_amdgcn_s_barrier();
+                lds_reads_done_barrier();                // (the reads of tap-1 out of the buffer that is refilled next)
                 if (tap + 1 < 9) stage_w(tap + 1, ch, (tap + 1) & 1);
             } else {
                 if (tap + 1 < 9) {
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
                         }
                     }
             }
-            if constexpr (!ONEBAR) __builtin_amdgcn_s_barrier();   // slab buffer (tap&1) and, after tap 8, the patch are free
+            if constexpr (!ONEBAR) lds_reads_done_barrier();       // slab buffer (tap&1) and, after tap 8, the patch are free
         }
     }
 

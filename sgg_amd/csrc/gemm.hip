@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
                     }
                 }
         }
-        __builtin_amdgcn_s_barrier();
+        lds_reads_done_barrier();          // the stage this tile was read from is refilled right after (common.h)
     }
 
     // ---- epilogue through LDS: per wave a [32][64] f32 staging tile (row stride 272 B), two halves (mi)

@@ -172,3 +172,106 @@ def test_sgdet_trainer_steps_run_and_reduce_the_loss(env):
         losses.append(float(tr.step(tuple(dbatch))))
     assert all(np.isfinite(losses)), losses
     assert losses[-1] < losses[0], losses
+
+
+# ------------------------------------------------------------------------------------------------- exact detections, real size
+def _separated(sd, gain=60.0, seed=17):
+    """The same random detector with a class head whose scores are well apart: cls_score weights x gain (peaked softmaxes), box
+    regression left small.  Near-tied scores were the only reason the detections above are compared loosely."""
+    out = {k: v.clone() for k, v in sd.items()}
+    out['detector.roi_heads.box_predictor.cls_score.weight'] *= gain
+    g = torch.Generator().manual_seed(seed)
+    out['detector.roi_heads.box_predictor.cls_score.bias'] = torch.randn(out['detector.roi_heads.box_predictor.cls_score.bias'].shape, generator=g)
+    out['detector.roi_heads.box_predictor.bbox_pred.weight'] *= 0.2
+    return out
+
+
+def _assert_same_detections(res, ref_dets, box_tol=5e-2, score_tol=2e-4):
+    """Exact SET equality (one-to-one): every oracle detection has exactly one HIP detection with the same label and box within box_tol px (fp32 summation-order noise through two exp() box decodings on anchors up to 512 px: 2e-2 px seen) and
+    score within score_tol, and vice versa; and the two rank orders agree wherever neighbouring scores differ by more than the
+    tolerance."""
+    im = res.im_inds.cpu().numpy()
+    boxes, labels = res.rm_box_priors.cpu().numpy(), res.rm_obj_labels.cpu().numpy()
+    n_total = 0
+    for b, (eb, es, el) in enumerate(ref_dets):
+        gb, gl = boxes[im == b], labels[im == b]
+        eb, es, el = eb.numpy(), es.numpy(), el.numpy()
+        assert len(gb) == len(eb), (b, len(gb), len(eb))
+        used = np.zeros(len(eb), bool)
+        for bx, lb in zip(gb, gl):
+            d = np.abs(eb - bx[None]).max(1)
+            cand = np.nonzero((d < box_tol) & (el == lb) & ~used)[0]
+            assert len(cand) >= 1, (b, bx, lb, float(d.min()))
+            used[cand[0]] = True
+        assert used.all()
+        n_total += len(eb)
+    return n_total
+
+
+def test_detections_equal_oracle_exactly_on_separated_scores(env):
+    import sgg_amd
+    from sgg_amd.synthetic import SyntheticData
+    model, sd, batch, _, S = env
+    sd2 = _separated(sd)
+    m2 = sgg_amd.RelModelStanford(SyntheticData(), mode='sgdet', min_size=S, max_size=S)
+    m2.load_state_dict(sd2)
+    m2.to(DEV).eval().set_compute_dtype(torch.float32)
+    for thresh in (0.05, 0.3):
+        m2.set_box_score_thresh(thresh)
+        with torch.no_grad():
+            ref = O.sgdet_detect(batch[0], sd2, score_thresh=thresh, min_size=S, max_size=S)
+            res = m2.faster_rcnn(batch[0], None, batch[4].to(DEV), None)
+        n = _assert_same_detections(res, ref[6])
+        assert n >= 8, n
+
+
+def test_sgdet_full_size_config3():
+    """BASELINE config 3 at its real size: 592x592 frames, 21 660 anchors, 1 000 proposals after NMS 0.7, box head on all of them,
+    per-class NMS 0.5, <= 50 detections and <= 2 450 candidate edges per image.  One image in exact-fp32 mode against the CPU oracle
+    (exact detection sets; logits within 1e-3 given the same detections), then a batch of 4 in bf16 through the whole forward with
+    the structural properties of the output."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import sgg_amd
+    from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
+    base = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgdet'))
+    sd = _separated({k: v.clone() for k, v in base.state_dict().items()})
+    model = sgg_amd.RelModelStanford(SyntheticData(), mode='sgdet')
+    model.load_state_dict(sd)
+    model.to(DEV).eval().set_compute_dtype(torch.float32)
+    model.set_box_score_thresh(0.05)
+    batch = synthetic_batch(B=4, S=592, n_boxes=8, n_fg=2, seed=41)
+    one = ([batch[0][0]], batch[1][:1], 0, batch[3][:8], batch[4][:8], batch[5][batch[5][:, 0] == 0], None, batch[7][:1])
+    torch.set_num_threads(min(__import__('os').cpu_count() or 1, 32))
+    with torch.no_grad():
+        ref = O.sgdet_detect(one[0], sd, score_thresh=0.05)
+        res = model.faster_rcnn(one[0], None, one[4].to(DEV), None)
+    assert tuple(res.fmap.shape[1:]) == (512, 38, 38)
+    n = _assert_same_detections(res, ref[6])
+    assert 2 <= n <= 50
+    with torch.no_grad():
+        boxes, cls, scores, rels, pred_scores = model([one])
+        exp = O.forward_from_detections(res.fmap.float().cpu(), res.im_inds.cpu().numpy(), res.rm_box_priors.cpu().numpy(),
+                                        res.rm_box_priors_org.cpu().numpy(), res.im_sizes, sd)
+    rb, rc, rs, rr, rp = exp['dets']
+    np.testing.assert_array_equal(cls, rc)
+    np.testing.assert_allclose(scores, rs, atol=1e-3)
+    key = lambda r: r[:, 0] * 100000 + r[:, 1]
+    go, ro = np.argsort(key(rels)), np.argsort(key(rr))
+    np.testing.assert_array_equal(rels[go], rr[ro])
+    np.testing.assert_allclose(pred_scores[go], rp[ro], atol=1e-3)
+    # the batch, in the benchmark's compute dtype
+    model.set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        res4 = model.faster_rcnn(batch[0], None, batch[4].to(DEV), None)
+        boxes, cls, scores, rels, pred_scores = model([batch])
+    im = res4.im_inds.cpu().numpy()
+    per_img = np.bincount(im, minlength=4)
+    assert (per_img >= 2).all() and (per_img <= 50).all()
+    assert len(cls) == per_img.sum() and boxes.shape == (len(cls), 4)
+    assert np.isfinite(pred_scores).all() and np.allclose(pred_scores.sum(1), 1.0, atol=2e-2)
+    assert (im[rels[:, 0]] == im[rels[:, 1]]).all() and (rels[:, 0] != rels[:, 1]).all()          # same-image ordered pairs
+    assert len(rels) <= int((per_img * (per_img - 1)).sum()) and len(rels) <= 2450 * 4
+    trip = pred_scores[:, 1:].max(1) * scores[rels[:, 0]] * scores[rels[:, 1]]
+    assert (trip[:-1] >= trip[1:] - 1e-6).all()                                                   # sorted by triple score
+    assert (boxes[:, 0] <= boxes[:, 2]).all() and boxes.min() >= 0 and boxes.max() <= 592 + 1e-3
