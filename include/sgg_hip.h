@@ -244,6 +244,11 @@ int sgg_det_output(const float* boxes, const float* scores, const int* labels, c
 int sgg_dropout_fwd(void* x, int64_t n, float p, uint64_t seed, int dtype, void* stream);
 /* dx = dy * (y > 0) * scale : backward of ReLU (scale 1) / ReLU->Dropout (y = saved post-dropout output, scale 1/(1-p)) */
 int sgg_act_bwd(const void* dy, const void* y, void* dx, int64_t n, float scale, int g_dtype, int y_dtype, void* stream);
+/* Cross-entropy of logits f32[M,C] (row stride ld) against labels i64 (element stride label_stride), 'baseline' form of
+ * lib/losses.py:41-43,74: loss[0] += weight / norm[0] * sum_rows CE (float atomic: zero `loss` first; `norm` on the device), and
+ * grad[M,ldg] (g_dtype, columns >= C zero) = d loss / d logits -- one launch for what F.cross_entropy + autograd do in ~12. */
+int sgg_ce_fwd_bwd(const float* logits, int ld, const int64_t* labels, int label_stride, int M, int C, const float* norm,
+                   float weight, float* loss, void* grad, int ldg, int g_dtype, void* stream);
 /* out[N] = column sums of x[M,N] (row stride ld): bias gradients.  Accumulates with atomics: zero_out = 1 clears `out` first,
  * zero_out = 0 expects the caller to hand over zeros (one cleared workspace for all the sums of a backward pass). */
 int sgg_colsum(const void* x, int M, int N, int ld, float* out, int zero_out, int dtype, void* stream);

@@ -61,6 +61,7 @@ SIGNATURES = {
     'sgg_det_output': [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     'sgg_dropout_fwd': [_P, _L, _F, ctypes.c_uint64, _I, _P],
     'sgg_act_bwd': [_P, _P, _P, _L, _F, _I, _I, _P],
+    'sgg_ce_fwd_bwd': [_P, _I, _P, _I, _I, _I, _P, _F, _P, _P, _I, _I, _P],
     'sgg_colsum': [_P, _I, _I, _I, _P, _I, _I, _P],
     'sgg_bn_stats': [_P, _I, _I, _P, _I, _P],
     'sgg_bn_finalize': [_P, _I, _I, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],

@@ -756,6 +756,64 @@ inline int split_rows(int M, int& rows_per_block) {
 #define DISPATCH2(dtype, BF, F32) \
     if ((dtype) == SGG_BF16) { BF; } else if ((dtype) == SGG_F32) { F32; } else return SGG_ERR_DTYPE;
 
+namespace {
+// ------------------------------------------------------------------------------------------------
+// Cross-entropy of a logit matrix, loss and gradient in ONE launch (lib/losses.py:41-43,74 -- the 'baseline' form: summed CE of the
+// rows divided by a batch-level normaliser).  One wave per row: max, sum of exponentials, -log p[label]; the gradient
+// (softmax - onehot) * weight / norm is written in the dtype the backward's GEMMs take, zero-padded to `ldg` columns (the heads are
+// 151 / 51 wide, the GEMMs want multiples of 64: no separate pad + cast passes).  `norm` lives on the device (a data-parallel step
+// all-reduces it), the loss is accumulated with one float atomic per row block.
+// torch's own path for the two heads is ~25 tiny launches per step (log_softmax, nll, their backwards, casts, pads).
+// ------------------------------------------------------------------------------------------------
+template <typename TG>
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels,
+                                                         int label_stride, int M, int C, const float* __restrict__ norm, float weight,
+                                                         float* __restrict__ loss, TG* __restrict__ grad, int ldg) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    __shared__ float part[4];
+    float mine = 0.f;
+    if (row < M) {
+        const float* x = logits + (long)row * ld;
+        float mx = -3.0e38f;
+        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, x[c]);
+        mx = wave_max(mx);
+        float se = 0.f;
+        for (int c = lane; c < C; c += 64) se += __expf(x[c] - mx);
+        se = wave_sum(se);
+        const int lab = (int)labels[(long)row * label_stride];
+        const float scale = weight / norm[0];
+        const float lse = mx + __logf(se);
+        if (lane == 0) mine = (lse - x[lab]) * scale;
+        TG* g = grad + (long)row * ldg;
+        for (int c = lane; c < ldg; c += 64) {
+            float v = 0.f;
+            if (c < C) v = (__expf(x[c] - lse) - (c == lab ? 1.f : 0.f)) * scale;
+            Elem<TG>::st(g + c, v);
+        }
+    }
+    if (lane == 0) part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, part[0] + part[1] + part[2] + part[3]);
+}
+}  // namespace
+
+// loss[0] += weight / norm[0] * sum_rows CE(logits[row], labels[row * label_stride]);  grad[M, ldg] = d loss / d logits (zero-padded)
+extern "C" int sgg_ce_fwd_bwd(const float* logits, int ld, const int64_t* labels, int label_stride, int M, int C, const float* norm,
+                              float weight, float* loss, void* grad, int ldg, int g_dtype, void* stream) {
+    if (M == 0) return SGG_OK;
+    if (!logits || !labels || !norm || !loss || !grad || M < 0 || C <= 0 || ld < C || ldg < C || label_stride <= 0) return SGG_ERR_ARG;
+    const dim3 grid((M + 3) / 4), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (g_dtype == SGG_BF16)
+        hipLaunchKernelGGL(ce_fwd_bwd_kernel<bf16_t>, grid, blk, 0, s, logits, ld, labels, label_stride, M, C, norm, weight, loss, (bf16_t*)grad, ldg);
+    else if (g_dtype == SGG_F32)
+        hipLaunchKernelGGL(ce_fwd_bwd_kernel<float>, grid, blk, 0, s, logits, ld, labels, label_stride, M, C, norm, weight, loss, (float*)grad, ldg);
+    else
+        return SGG_ERR_DTYPE;
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
 extern "C" int sgg_dropout_fwd(void* x, int64_t n, float p, uint64_t seed, int dtype, void* stream) {
     if (n == 0) return SGG_OK;
     if (!x || n < 0 || (n & 7) || !(p >= 0.f && p < 1.f)) return SGG_ERR_ARG;

@@ -499,6 +499,16 @@ def act_bwd(dy, y, scale=1.0):
     return dx
 
 
+def ce_fwd_bwd(logits, labels, norm, weight, loss, grad):
+    """loss[0] += weight / norm[0] * sum CE(logits, labels); grad [M, ldg] (bf16 / f32, zero-padded columns) = d loss / d logits.
+    logits f32 [M,C]; labels i64, any 1-D view (e.g. a column of rel_labels); norm, loss: f32 device scalars."""
+    M, C = logits.shape
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1 and labels.dtype == torch.int64 and labels.dim() == 1
+    assert grad.shape[0] == M and grad.shape[1] >= C and grad.stride(1) == 1
+    _lib.call('sgg_ce_fwd_bwd', logits.data_ptr(), logits.stride(0), labels.data_ptr(), labels.stride(0), M, C, norm.data_ptr(),
+              float(weight), loss.data_ptr(), grad.data_ptr(), grad.stride(0), dt(grad), _stream())
+
+
 class ZeroPool(object):
     """One zero-filled f32 workspace, carved into slices: the accumulate-with-atomics kernels (column sums = bias gradients) then
     need one fill launch per backward pass instead of one memset per call."""

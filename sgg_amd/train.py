@@ -251,31 +251,45 @@ class PredictFn(torch.autograd.Function):
         # that it runs while the fc6 all-reduces occupy the links.
         deferred = []
 
-        def lin_bwd(dY, X, Wt, name, tag, want_dx=True, big=False):
-            """Y = X W^T + b : returns dX now; dW (f32 [N,K]) and db are computed in phase C."""
+        def lin_bwd(dY, X, Wt, name, tag, want_dx=True, big=False, n_out=None):
+            """Y = X W^T + b : returns dX now; dW (f32 [N,K]) and db are computed in phase C.  n_out: dY arrives already
+            zero-padded to a multiple of 128 columns (the fused loss kernel writes it so) and only its first n_out are real."""
+            prepadded = n_out is not None
             def dw():
                 _lib.set_tag(tag)
-                n_out = dY.shape[1]
-                if n_out % 128 and dt == torch.bfloat16 and not big:
+                n_out = dY.shape[1] if not prepadded else n_out_
+                if (n_out % 128 or prepadded) and dt == torch.bfloat16 and not big:
                     # narrow heads (151 / 51 outputs): zero-pad dY to 128 columns so that the TN kernel takes it
-                    dYp = _pad_cols(dY, 128, dt)
+                    dYp = dY if prepadded else _pad_cols(dY, 128, dt)
                     if USE_TN and ops.gemm_tn_ok(dYp, X):
                         G[name + '.weight'] = ops.gemm_tn(dYp, X)[:n_out].contiguous()
                         G[name + '.bias'] = ops.colsum(dYp, pool)[:n_out].contiguous()
                         return
-                G[name + '.weight'], G[name + '.bias'] = tn_gemm(dY, X, want_colsum=True, pool=pool,
+                dYr = dY[:, :n_out].contiguous() if prepadded else dY
+                G[name + '.weight'], G[name + '.bias'] = tn_gemm(dYr, X, want_colsum=True, pool=pool,
                                                                  out_dtype=big_dtype() if big else torch.float32)
                 if big:
                     hook(name + '.weight')
+            n_out_ = n_out
             deferred.append(dw)
-            return ops.gemm(_pad_cols(dY, 64, dt), Wt) if want_dx else None
+            if not want_dx:
+                return None
+            if prepadded:                                   # W^T is padded to a multiple of 64 columns: a strided view of dY matches it
+                return ops.gemm(dY[:, :Wt.shape[1]], Wt)
+            return ops.gemm(_pad_cols(dY, 64, dt), Wt)
 
         # ---- phase A
         _lib.set_tag('bwd_heads')
-        d_obj = d_obj.contiguous().to(dt) if d_obj.dtype != dt else d_obj.contiguous()
-        d_rel = d_rel.contiguous().to(dt) if d_rel.dtype != dt else d_rel.contiguous()
-        d_v = lin_bwd(d_obj, rows(HN, T, N), t['obj_fc_t'], 'obj_fc', 'bwd_heads')
-        d_e = lin_bwd(d_rel, rows(HE, T, E), t['rel_fc_t'], 'rel_fc', 'bwd_heads')
+        pre = getattr(model, '_logit_grads', None)       # Trainer's fused loss: (d_obj [N,256], d_rel [E,128]) in dt, zero-padded
+        model._logit_grads = None
+        if pre is not None and dt == torch.bfloat16 and pre[0].dtype == dt and pre[0].shape[0] == N and pre[1].shape[0] == E:
+            d_v = lin_bwd(pre[0], rows(HN, T, N), t['obj_fc_t'], 'obj_fc', 'bwd_heads', n_out=d_obj.shape[1])
+            d_e = lin_bwd(pre[1], rows(HE, T, E), t['rel_fc_t'], 'rel_fc', 'bwd_heads', n_out=d_rel.shape[1])
+        else:
+            d_obj = d_obj.contiguous().to(dt) if d_obj.dtype != dt else d_obj.contiguous()
+            d_rel = d_rel.contiguous().to(dt) if d_rel.dtype != dt else d_rel.contiguous()
+            d_v = lin_bwd(d_obj, rows(HN, T, N), t['obj_fc_t'], 'obj_fc', 'bwd_heads')
+            d_e = lin_bwd(d_rel, rows(HE, T, E), t['rel_fc_t'], 'rel_fc', 'bwd_heads')
         # IMP backward (rel_model_stanford.py:74-92 in reverse)
         _lib.set_tag('bwd_imp')
         dGIn = torch.empty((4 * N, 3 * H), dtype=dt, device=dev)
@@ -283,7 +297,7 @@ class PredictFn(torch.autograd.Function):
         dGIe = torch.empty((4 * E, 3 * H), dtype=dt, device=dev)
         dGHe = torch.empty((4 * E, 3 * H), dtype=dt, device=dev)
         d_gw = torch.zeros((4, 2 * H), dtype=torch.float32, device=dev)
-        d_gb = torch.zeros((4, 1), dtype=torch.float32, device=dev)
+        d_gb = torch.zeros((4, 4), dtype=torch.float32, device=dev)     # column 0 of a 16-byte row per gate: the views handed on stay aligned
         ones = torch.ones((T * E, 1), dtype=dt, device=dev)
         # gate-side partials of all iterations, stacked like HN / HE so that the gate-weight gradients are three
         # contractions over 3E / 3N rows in phase C instead of nine small ones
@@ -354,15 +368,15 @@ class PredictFn(torch.autograd.Function):
         ops.rank4_reduce_(da_all, HE[:T * E], d_gw, col0=H)         # e_i = rows i of HE, v_i = rows i of HN
         ops.rank4_reduce_(nsum_all, HN[:T * N], d_gw, col0=0)
         ops.rank4_reduce_(da_all, ones, d_gb)
-        for k, g in enumerate(GATES):
-            G[g + '.0.weight'] = d_gw[k:k + 1].clone()
-            G[g + '.0.bias'] = d_gb[k].clone()
+        for k, g in enumerate(GATES):                       # views of the two accumulators (nothing writes them after this point)
+            G[g + '.0.weight'] = d_gw[k:k + 1]
+            G[g + '.0.bias'] = d_gb[k, :1]
         _lib.set_tag('bwd_rect')
         d_rect = ops.gemm(d_pre6, t['w6sum_t'])                                    # [E,C]
         # rect conv backward (BatchNorm with batch statistics)
         bn_sync = getattr(model, '_bn_sync', None)
         d_c2, db2, dg2 = ops.bn_bwd(d_rect, None, sv['h3'], sv['m2'], sv['is2'], t['rc_g2'], False, bn_sync)
-        G['union_boxes.conv.6.weight'], G['union_boxes.conv.6.bias'] = dg2.clone(), db2.clone()
+        G['union_boxes.conv.6.weight'], G['union_boxes.conv.6.bias'] = dg2, db2
         gw2, gb2 = tn_gemm(d_c2, sv['h2'], want_colsum=True, pool=pool)                       # [d, d2] centre tap
         full = torch.zeros(tuple(model.union_boxes.conv[4].weight.shape), dtype=torch.float32, device=dev)
         full[:, :, 1, 1] = gw2
@@ -370,7 +384,7 @@ class PredictFn(torch.autograd.Function):
         G['union_boxes.conv.4.bias'] = gb2
         d_h2 = ops.gemm(d_c2, t['rc_w2_t'])                                        # [E,d2]
         d_c1, db1, dg1 = ops.bn_bwd(d_h2, sv['arg'], sv['h1'], sv['m1'], sv['is1'], t['rc_g1'], True, bn_sync)
-        G['union_boxes.conv.2.weight'], G['union_boxes.conv.2.bias'] = dg1.clone(), db1.clone()
+        G['union_boxes.conv.2.weight'], G['union_boxes.conv.2.bias'] = dg1, db1
         gw1, gb1 = tn_gemm(d_c1, sv['patches'], want_colsum=True, pool=pool)                  # [d2,128]
         G['union_boxes.conv.0.weight'] = gw1[:, :98].reshape(tuple(model.union_boxes.conv[0].weight.shape)).contiguous()
         G['union_boxes.conv.0.bias'] = gb1

@@ -134,6 +134,8 @@ class Trainer(object):
         # weights being updated (main.py:62-63: the detector is frozen).  The head of step k+1 waits for the event.
         # Every update still happens, in order; read parameters through flush() in this mode.
         self.pipeline = pipeline
+        self.fused_loss = True          # step(): loss + logit gradients by sgg_ce_fwd_bwd where it applies (tests flip it to compare)
+        self._norm_cache = {}
         if pipeline:
             self.opt.max_blocks = 256      # leave wave slots for the VGG forward running beside the update
         self._queued = False
@@ -228,6 +230,34 @@ class Trainer(object):
             raise NotImplementedError(self.loss_type)
         return obj_ce / n_obj + (gamma * rel_ce * w).sum()                            # :62-63
 
+    def _fused_losses(self, res):
+        """'baseline' losses and their logit gradients in two launches (sgg_ce_fwd_bwd) instead of torch's ~25: returns the loss
+        (device scalar, no autograd graph) after leaving the zero-padded compute-dtype gradients where PredictFn.backward
+        picks them up (model._logit_grads).  Same numbers as losses() + autograd: sum CE / global normaliser."""
+        m = self.model
+        dev = res.rel_dists.device
+        N, E = res.rm_obj_dists.shape[0], res.rel_dists.shape[0]
+        key = (N, E)
+        if self.dist_on:
+            norm = torch.empty(2, dtype=torch.float32, device=dev)
+            norm[0].fill_(float(N))
+            norm[1].fill_(float(E))
+            dist.all_reduce(norm, op=dist.ReduceOp.SUM)
+        else:
+            norm = self._norm_cache.get(key)
+            if norm is None:
+                norm = self._norm_cache[key] = torch.tensor([float(N), float(E)], dtype=torch.float32, device=dev)
+        dt_ = m.compute_dtype
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        d_obj = torch.empty((N, 256), dtype=dt_, device=dev)           # 151 -> 256, 51 -> 128: what the TN weight-gradient kernel takes
+        d_rel = torch.empty((E, 128), dtype=dt_, device=dev)
+        alpha, beta, gamma = self.loss_weights
+        assert alpha == beta == 1, ('wrong loss is used, use dnorm or dnorm-fgbg', alpha, beta)          # lib/losses.py:41
+        ops.ce_fwd_bwd(res.rm_obj_dists.detach(), res.rm_obj_labels, norm[0:1], 1.0, loss, d_obj)
+        ops.ce_fwd_bwd(res.rel_dists.detach(), res.rel_labels[:, -1], norm[1:2], gamma, loss, d_rel)
+        m._logit_grads = (d_obj, d_rel)
+        return loss[0]
+
     def _prefetch_operands(self):
         """The optimiser just changed the masters, so the derived operands (W^T copies for the dX GEMMs, W6sum, the GRU /
         rect-conv operands: ~0.3 ms of HBM-bound transposes and casts) must be rebuilt.  They are rebuilt on the node
@@ -288,13 +318,22 @@ class Trainer(object):
         if not self.dist_on:
             self._local = {}
         res = self.model([batch])
-        loss = self.losses(res)
+        # the fused loss covers what the benchmark runs: 'baseline' CE, bf16 compute, logits straight out of predict()
+        fused = (self.fused_loss and self.loss_type == 'baseline' and self.model.compute_dtype == torch.bfloat16 and
+                 not getattr(self.model, 'use_bias', False) and res.rm_obj_dists.shape[1] <= 256 and res.rel_dists.shape[1] <= 128)
+        loss = self._fused_losses(res) if fused else self.losses(res)
         self.opt.zero_grad()
         if local:
             self.model._grad_ready_hook, self.model._grad_wire_dtype = self._keep, self._local_wire
         try:
-            loss.backward()
+            if fused:
+                # the real gradients wait in model._logit_grads; autograd only needs placeholders of the outputs' shape (no launch)
+                torch.autograd.backward([res.rm_obj_dists, res.rel_dists],
+                                        [torch.empty_like(res.rm_obj_dists), torch.empty_like(res.rel_dists)])
+            else:
+                loss.backward()
         finally:
+            self.model._logit_grads = None
             if local:
                 self.model._grad_ready_hook = self.model._grad_wire_dtype = None
         self._queued = self.pipeline and self._queue_update()

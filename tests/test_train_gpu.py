@@ -544,3 +544,44 @@ def test_predict_gradients_into_roi_features_match_oracle_autograd(env):
     model.zero_grad()
     model.eval()
     model.dropout_p = 0.5
+
+
+def test_fused_cross_entropy_equals_torch_losses_and_autograd(env):
+    """sgg_ce_fwd_bwd (loss + logit gradients in one launch per head, padded compute-dtype gradients handed straight to the
+    backward) against F.cross_entropy + autograd: the kernel's numbers on random logits, then one whole train step either way."""
+    from sgg_amd import ops
+    from sgg_amd.trainer import Trainer
+    g = torch.Generator().manual_seed(4)
+    for M, C, ldg in ((37, 151, 256), (1000, 51, 128), (5, 7, 64)):
+        logits = (torch.randn(M, C, generator=g) * 3).to(DEV)
+        labels = torch.randint(0, C, (M, 4), generator=g).to(DEV)
+        norm = torch.tensor([float(M) * 1.7], device=DEV)
+        for gdt in (torch.float32, torch.bfloat16):
+            loss = torch.zeros(1, device=DEV)
+            grad = torch.full((M, ldg), 7.0, dtype=gdt, device=DEV)
+            ops.ce_fwd_bwd(logits, labels[:, -1], norm, 0.6, loss, grad)
+            x = logits.clone().requires_grad_(True)
+            ref = 0.6 * torch.nn.functional.cross_entropy(x, labels[:, -1], reduction='sum') / norm[0]
+            ref.backward()
+            assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+            tol = dict(atol=1e-6, rtol=1e-5) if gdt == torch.float32 else dict(atol=2e-3, rtol=1e-2)
+            torch.testing.assert_close(grad[:, :C].float(), x.grad, **tol)
+            assert float(grad[:, C:].float().abs().max()) == 0.0 if ldg > C else True
+    model, sd, batch = env
+    model.set_compute_dtype(torch.bfloat16)
+    model.dropout_p = 0.0
+    out = {}
+    for fused in (False, True):
+        model.load_state_dict(sd)
+        tr = Trainer(model, lr=2e-2)
+        tr.fused_loss = fused
+        losses = [float(tr.step(tuple(batch))) for _ in range(2)]
+        out[fused] = (losses, {n: p.detach().float().cpu().clone() for n, p in model.named_parameters() if not n.startswith('detector.')})
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=2e-3)
+    for n, w_ref in out[False][1].items():
+        w0 = sd[n].float()
+        step = (w_ref - w0).abs().max()
+        diff = (w_ref - out[True][1][n]).abs().max()
+        assert diff <= 0.08 * step + 1e-7, (n, float(step), float(diff))
+    model.dropout_p = 0.5
+    model.eval()
