@@ -185,6 +185,15 @@ int sgg_imp_sliced_fwd(const void* v, const void* e, const int* so /*[E,2]*/, co
                        const float* edge_dots, const float* gate_b, void* e_in, void* ctx2 /*[2,N,H]*/, int max_edges,
                        int max_nodes, int sum_ctx /*1: ctx2 is [N,H] = ctx_out + ctx_in (training keeps the sum)*/, int dtype,
                        void* stream);
+/* The split step.  e_in[e] = g_sub(e) v[s(e)] + g_obj(e) v[o(e)] does not read the edge rows (they enter through edge_dots only), so
+ * the step is a WRITE stream -- sgg_imp_edge_in_fwd: any edge list, no graph structure; it also leaves the read stream's two gates of
+ * every edge, gates_oi f32[E,2] = (g_out, g_in) (rel_model_stanford.py:86-89), when gates_oi is not NULL -- and a READ stream --
+ * sgg_imp_ctx_fwd: ctx2 as in sgg_imp_sliced_fwd from the edge rows and gates_oi, same requirements on the graphs;
+ * SGG_ERR_CAPACITY when a graph has more than 1024 edges / 64 nodes or rows are not a multiple of 64 bytes. */
+int sgg_imp_edge_in_fwd(const void* v, const int* so /*[E,2]*/, const float* node_dots, const float* edge_dots, const float* gate_b,
+                        void* e_in, float* gates_oi /*[E,2] or NULL*/, int E, int H, int dtype, void* stream);
+int sgg_imp_ctx_fwd(const void* e, const float* gates_oi /*[E,2]*/, const int* in_ptr, const int* in_ids, const int* img_ptr, int B, int N,
+                    int E, int H, void* ctx2 /*[2,N,H] or [N,H]*/, int max_edges, int max_nodes, int sum_ctx, int dtype, void* stream);
 /* img_ptr i32[2*(B+1) + 66*B]: img_ptr[b] = first node of graph b (im_inds i64[N] ascending), img_ptr[B] = N; then
  * img_ptr[B+1+b] = out_ptr[first node of b] = first edge of graph b (out_ptr from sgg_edge_csr, same stream, edges sorted);
  * then per graph 66 graph-relative out-list offsets of its nodes (entries past the last node repeat the edge count). */

@@ -50,6 +50,8 @@ SIGNATURES = {
     'sgg_gru_gate_fwd': [_P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _P],
     'sgg_imp_sliced_capacity': [_I, _I],
     'sgg_imp_sliced_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'sgg_imp_edge_in_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    'sgg_imp_ctx_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P],
     'sgg_graph_ptr': [_P, _I, _I, _P, _P, _P],
     'sgg_eval_tail': [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     'sgg_rpn_decode': [_P, _I, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P],

@@ -1164,7 +1164,7 @@ __device__ long long g_dma_ticks[8 * 16 * 8];
 #define SGG_DTICK(i)
 #endif
 
-template <typename T, int LP>
+template <typename T, int LP, bool EIN>
 __global__ __launch_bounds__(DM_THREADS) void imp_dma_kernel(
     const T* __restrict__ v, const T* __restrict__ e, const int* __restrict__ so, const int* __restrict__ in_ptr,
     const int* __restrict__ in_ids, const int* __restrict__ img_ptr, int B, int N, int H, const float* __restrict__ ndots,
@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(DM_THREADS) void imp_dma_kernel(
             asm volatile("global_load_dword %0, %1, %2" : "+v"(p_op) : "v"((unsigned)(2 * (B + 1) + h.g * (SL_NMAX + 2) + tid) * 4u), "s"(img_ptr) : "memory");
         }
         if (tid < h.Nn) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(p_nd) : "v"((unsigned)(h.n0 + tid) * 16u), "s"(ndots) : "memory");
-        if (grp < h.Nn)
+        if (EIN && grp < h.Nn)
             asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(p_v) : "v"((unsigned)(((long)(h.n0 + grp) * H + col_of(h)) * (long)sizeof(T))), "s"(v) : "memory");
     };
     // wait until at most k vector-memory operations of this wave are outstanding, k = min(stores issued since the last load, 15)
@@ -1293,7 +1293,7 @@ __global__ __launch_bounds__(DM_THREADS) void imp_dma_kernel(
             optr[tid] = (int)p_op;
         }
         if (tid < h.Nn) *reinterpret_cast<f32x4*>(nd + tid * 4) = p_nd;
-        if (grp < h.Nn) {                                  // unpacked once per unit: phase 1 reads a vertex piece per EDGE
+        if (EIN && grp < h.Nn) {                           // unpacked once per unit: phase 1 reads a vertex piece per EDGE
             Piece16<T> pv;
             pv.r = __builtin_bit_cast(decltype(pv.r), p_v);
             float f[CHL];
@@ -1326,7 +1326,8 @@ __global__ __launch_bounds__(DM_THREADS) void imp_dma_kernel(
         float nanv[CHL];
 #pragma unroll
         for (int j = 0; j < CHL; ++j) nanv[j] = __builtin_nanf("");
-        for (int k = grp; k < Ee; k += GROUPS) Piece16<T>::store(e_in + (long)(e0 + k) * H + col, nanv);
+        if (EIN)
+            for (int k = grp; k < Ee; k += GROUPS) Piece16<T>::store(e_in + (long)(e0 + k) * H + col, nanv);
         for (int k = grp; k < Nn; k += GROUPS) {
             Piece16<T>::store(ctx2 + (long)(n0 + k) * H + col, nanv);
             if (!sum_ctx) Piece16<T>::store(ctx2 + ((long)N + n0 + k) * H + col, nanv);
@@ -1431,14 +1432,16 @@ __global__ __launch_bounds__(DM_THREADS) void imp_dma_kernel(
                 const int part1 = grp & (P1 - 1), n1 = nlo + (grp >> lgP1);
                 if (n1 < nhi) {
                     float vn[CHL], acc_o[CHL];
-                    const float* src = reinterpret_cast<const float*>(vs + n1 * VSB) + sub * CHL;
 #pragma unroll
-                    for (int j = 0; j < CHL; j += 4) {
-                        const f32x4 t = *reinterpret_cast<const f32x4*>(src + j);
-                        vn[j] = t.x; vn[j + 1] = t.y; vn[j + 2] = t.z; vn[j + 3] = t.w;
+                    for (int j = 0; j < CHL; ++j) vn[j] = acc_o[j] = 0.f;
+                    if constexpr (EIN) {
+                        const float* src = reinterpret_cast<const float*>(vs + n1 * VSB) + sub * CHL;
+#pragma unroll
+                        for (int j = 0; j < CHL; j += 4) {
+                            const f32x4 t = *reinterpret_cast<const f32x4*>(src + j);
+                            vn[j] = t.x; vn[j + 1] = t.y; vn[j + 2] = t.z; vn[j + 3] = t.w;
+                        }
                     }
-#pragma unroll
-                    for (int j = 0; j < CHL; ++j) acc_o[j] = 0.f;
                     const int ob = optr[n1] + part1;                     // my entries: ob + k P1, k < mine_o
                     const int mine_o = (optr[n1 + 1] - ob + P1 - 1) >> lgP1;
                     for (int kb = 0;; kb += U) {
@@ -1447,31 +1450,38 @@ __global__ __launch_bounds__(DM_THREADS) void imp_dma_kernel(
                         for (int u = 0; u < U; ++u) {
                             const bool live = kb + u < mine_o;
                             if (__builtin_amdgcn_ballot_w64(live) == 0) break;      // wave-uniform
-                            ++nst;                           // one e_in store instruction per wave and step (uniform count)
+                            if (EIN) ++nst;                  // one e_in store instruction per wave and step (uniform count)
                             if (live) {
                                 const int el = ob + ((kb + u) << lgP1);
 #if SGG_DMA_ABL == 1                             // experiment: the access pattern alone (staged piece in, piece out)
                                 *reinterpret_cast<u32x4*>(e_in_c + (eoff0 + (unsigned)el * rowb)) = *reinterpret_cast<const u32x4*>(stage0 + (soff + el * PIECE));
                                 continue;
 #endif
-                                const f32x4 gt = *reinterpret_cast<const f32x4*>(gates + el * 4);
-                                const int o = onl8[el];
                                 Piece16<T> rowp;
                                 rowp.r = *reinterpret_cast<const decltype(rowp.r)*>(stage0 + (soff + el * PIECE));
-                                float xx[CHL], yy[CHL], rr[CHL];
+                                float xx[CHL];
                                 rowp.get(xx);
-                                const float* vo = reinterpret_cast<const float*>(vs + o * VSB) + sub * CHL;
+                                if constexpr (EIN) {
+                                    const f32x4 gt = *reinterpret_cast<const f32x4*>(gates + el * 4);
+                                    const int o = onl8[el];
+                                    float yy[CHL], rr[CHL];
+                                    const float* vo = reinterpret_cast<const float*>(vs + o * VSB) + sub * CHL;
 #pragma unroll
-                                for (int j = 0; j < CHL; j += 4) {
-                                    const f32x4 t = *reinterpret_cast<const f32x4*>(vo + j);
-                                    yy[j] = t.x; yy[j + 1] = t.y; yy[j + 2] = t.z; yy[j + 3] = t.w;
-                                }
+                                    for (int j = 0; j < CHL; j += 4) {
+                                        const f32x4 t = *reinterpret_cast<const f32x4*>(vo + j);
+                                        yy[j] = t.x; yy[j + 1] = t.y; yy[j + 2] = t.z; yy[j + 3] = t.w;
+                                    }
 #pragma unroll
-                                for (int j = 0; j < CHL; ++j) {
-                                    rr[j] = gt.x * vn[j] + gt.y * yy[j];
-                                    acc_o[j] = fmaf(gt.z, xx[j], acc_o[j]);
+                                    for (int j = 0; j < CHL; ++j) {
+                                        rr[j] = gt.x * vn[j] + gt.y * yy[j];
+                                        acc_o[j] = fmaf(gt.z, xx[j], acc_o[j]);
+                                    }
+                                    if (SGG_DMA_ABL != 2) Piece16<T>::store(reinterpret_cast<T*>(e_in_c + (eoff0 + (unsigned)el * rowb)), rr);
+                                } else {                     // ctx only: e_in is made by imp_edge_in_kernel, which never reads the edge rows
+                                    const float gz = gates[el * 4 + 2];
+#pragma unroll
+                                    for (int j = 0; j < CHL; ++j) acc_o[j] = fmaf(gz, xx[j], acc_o[j]);
                                 }
-                                if (SGG_DMA_ABL != 2) Piece16<T>::store(reinterpret_cast<T*>(e_in_c + (eoff0 + (unsigned)el * rowb)), rr);
                             }
                         }
                     }
@@ -1575,6 +1585,457 @@ __global__ __launch_bounds__(DM_THREADS) void imp_dma_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The node half of the step on its own (imp_ctx_kernel): ctx_out[n] = sum over n's out-edges of g_out e, ctx_in[n] = sum over its
+// in-edges of g_in e -- a READ stream (every edge row once) with two small outputs.  Same unit as imp_dma_kernel -- (graph, PIECE-byte
+// slice of the rows), the slice's pieces staged in LDS so that the in-lists can walk them -- but
+//  * the staging is a RING of NBUF buffers of EB consecutive edges and the DMA runs NBUF-1 chunks ahead of the compute, ACROSS unit
+//    boundaries (a chunk is an edge range: its extent follows from the graph header alone).  imp_dma_kernel kept one batch in
+//    flight and issued the next only after the barrier that followed the landing of the last;
+//  * NOTHING a load returns lives in a register across other code: the per-unit small arrays (the two gates of every edge --
+//    made by the write stream, imp_edge_in_kernel -- the in-list entries, the list offsets) go global -> LDS by DMA as well, into
+//    one of two sets, one unit ahead.  imp_dma_kernel fetches them with asm loads into registers that the compiler believes
+//    defined at issue; under register pressure it may copy such a register before the data lands (seen here: wrong sums and
+//    memory faults that came and went with unrelated code changes);
+//  * out-lists: a chunk's rows belong to few nodes (8 of 32 on a complete 32-node graph), so ALL lane groups share those nodes
+//    (Pc parts per node), the parts meet in the wave and one lane group per node and chunk adds to the node's running sum in
+//    LDS; in-lists: a lane group owns (node, part) for the whole unit and walks its entries with a cursor (ascending edge ids).
+// Waits are counted: a wave tracks how many vector-memory operations it has issued (`ci`, exact for DMA, stores not counted: an
+// under-count) and the value of that counter after each thing it will wait for; `s_waitcnt vmcnt(ci - mark)` returns as soon as
+// that thing -- and, in issue order, everything older -- has landed, whatever was issued later.
+constexpr int CX_NBUF = 4, CX_MAXCHUNKS = 64, CX_PTRS = 128;
+constexpr int ctx_epad(int emax) { return (emax + 63) & ~63; }
+// LDS beside the ring.  osb: bytes of one node's running out-sum (its piece as f32)
+constexpr int ctx_fixed_bytes(int emax, int nmax, int osb) {
+    return 2 * (3 * ctx_epad(emax) * 4 + 2 * CX_PTRS * 4)      // two sets of: g_out, g_in, in-list entries (per edge), out- / in-list offsets
+           + 2 * CX_MAXCHUNKS * 4 + nmax * osb;                 // node range of every chunk, running out-sums
+}
+// edges per chunk: a multiple of the edges one DMA instruction moves (64 lanes x 16 bytes)
+constexpr int ctx_chunk_edges(int emax, int nmax, int osb, int piece) {
+    const int epw = 1024 / piece;
+    const int room = (DM_LDS_MAX - ctx_fixed_bytes(emax, nmax, osb)) / (CX_NBUF * piece);
+    const int eb = room < emax ? room / epw * epw : (emax + epw - 1) / epw * epw;
+    return eb < 16 ? 0 : eb;
+}
+static_assert(ctx_chunk_edges(992, 32, 256, 128) >= 248, "imp_ctx_kernel: a 992-edge graph goes through in four chunks of 128-byte pieces");
+static_assert(ctx_chunk_edges(992, 32, 128, 64) >= 496, "imp_ctx_kernel: ... and in two of 64-byte pieces");
+
+// 64 lanes x 4 bytes from per-lane global addresses into 256 bytes of LDS at `lds_base` (wave-uniform)
+__device__ __forceinline__ void dma4_to_lds(const void* gptr, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_base), "v"(gptr) : "memory");
+}
+
+template <typename T, int LP>
+__global__ __launch_bounds__(DM_THREADS) void imp_ctx_kernel(
+    const T* __restrict__ e, const float* __restrict__ gates_oi, const int* __restrict__ in_ptr, const int* __restrict__ in_ids,
+    const int* __restrict__ img_ptr, int B, int N, int H, T* __restrict__ ctx2, int EMAX, int NMAX, int EB, int sum_ctx) {
+    constexpr int PIECE = LP * 16, CHL = 16 / (int)sizeof(T), CHAN = PIECE / (int)sizeof(T), GROUPS = DM_THREADS / LP, EPW = 64 / LP;
+    constexpr int NBUF = CX_NBUF, U = 2, UO = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int EPAD = ctx_epad(EMAX), SETW = 3 * EPAD + 2 * CX_PTRS;                  // words of one set of small arrays
+    char* const ring = smem;                                                          // [NBUF][EB][PIECE]
+    int* const sets = reinterpret_cast<int*>(ring + (long)NBUF * EB * PIECE);        // [2][SETW]: g_out[EPAD] g_in[EPAD] in[EPAD] optr[] iptr[]
+    int* const cna = sets + 2 * SETW;                                                 // [CX_MAXCHUNKS] first / last node whose out-list
+    int* const cnb = cna + CX_MAXCHUNKS;                                              //                touches the chunk
+    float* const osum = reinterpret_cast<float*>(cnb + CX_MAXCHUNKS);                 // [NMAX][CHAN] running out-sums (f32)
+    const unsigned ring_lds = (unsigned)(unsigned long)(lds_char_t*)smem;
+    const unsigned sets_lds = ring_lds + (unsigned)(NBUF * EB * PIECE);
+
+    const int S = H * (int)sizeof(T) / PIECE, units = B * S;
+    const int G = (int)gridDim.x, NX = min(G, 8), x = (int)blockIdx.x % NX, w = (int)blockIdx.x / NX;
+    const int wx = G / NX + (x < G % NX ? 1 : 0);
+    const int uq = units / NX, ur = units % NX;
+    const int cnt = uq + (x < ur ? 1 : 0), base = x * uq + min(x, ur);
+    if (w >= cnt) return;
+    const int nunits = (cnt - w + wx - 1) / wx;                 // units of this workgroup: ordinals 0 .. nunits-1, unit index w + k wx
+    const int tid = threadIdx.x, sub = tid % LP, grp = tid / LP, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    struct Hdr { int g, slice, n0, Nn, e0, Ee; };              // Ee < 0: the host's promise about this graph is broken (outputs poisoned)
+    int lg = base / S, lslice = base - lg * S, lidx = 0;
+    auto load_hdr = [&](int k) __attribute__((always_inline)) { // header of ordinal k (loaded in increasing order)
+        Hdr h;
+        const int idx = w + k * wx;
+        lslice += idx - lidx;
+        lidx = idx;
+        while (lslice >= S) {
+            lslice -= S;
+            ++lg;
+        }
+        h.g = lg;
+        h.slice = lslice;
+        u32x2 nn, ee;
+        asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(nn), "=&s"(ee) : "s"(img_ptr + h.g), "s"(img_ptr + (B + 1 + h.g)) : "memory");
+        h.n0 = (int)nn.x;
+        h.Nn = (int)nn.y - h.n0;
+        h.e0 = (int)ee.x;
+        h.Ee = (int)ee.y - h.e0;
+        if (h.Ee > EMAX || h.Nn > NMAX || h.Nn > SL_NMAX) {
+            h.Nn = 0;
+            h.Ee = -1;
+        }
+        return h;
+    };
+    auto col_of = [&](const Hdr& h) __attribute__((always_inline)) { return (long)h.slice * CHAN + sub * CHL; };
+    int ci = 0;                                                  // DMA operations this wave has issued
+    // rows [lo, hi) (graph-local) of h's slice -> ring buffer rb
+    auto issue_dma = [&](const Hdr& h, int lo, int hi, int rb) __attribute__((always_inline)) {
+        const int nch = (hi - lo + EPW - 1) / EPW;
+        const char* src = reinterpret_cast<const char*>(e + col_of(h));
+        for (int c = wv; c < nch; c += DM_THREADS / 64) {
+            const int el = min(lo + c * EPW + lane / LP, hi - 1);
+            dma16_to_lds(src + (long)(h.e0 + el) * H * (int)sizeof(T),
+                         __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)(rb * EB * PIECE + c * 1024)));
+            ++ci;
+        }
+    };
+    auto wait_mark = [&](int mark) __attribute__((always_inline)) {   // everything issued up to `mark` has landed
+        switch (min(ci - mark, 15)) {
+#define SGG_W(K) case K: asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory"); break;
+            SGG_W(0) SGG_W(1) SGG_W(2) SGG_W(3) SGG_W(4) SGG_W(5) SGG_W(6) SGG_W(7) SGG_W(8) SGG_W(9) SGG_W(10) SGG_W(11) SGG_W(12)
+            SGG_W(13) SGG_W(14)
+#undef SGG_W
+            default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        }
+    };
+    // the small arrays of h's graph -> set q: lane t of the workgroup <-> edge t / list offset t
+    auto issue_small = [&](const Hdr& h, int q) __attribute__((always_inline)) {
+        const unsigned set_lds = sets_lds + (unsigned)(q * SETW * 4);
+        if (wv * 64 < h.Ee) {
+            const long et = h.e0 + min(tid, h.Ee - 1);
+            dma4_to_lds(gates_oi + 2 * et, __builtin_amdgcn_readfirstlane(set_lds + (unsigned)(wv * 256)));
+            dma4_to_lds(gates_oi + 2 * et + 1, __builtin_amdgcn_readfirstlane(set_lds + (unsigned)((EPAD + wv * 64) * 4)));
+            dma4_to_lds(in_ids + et, __builtin_amdgcn_readfirstlane(set_lds + (unsigned)((2 * EPAD + wv * 64) * 4)));
+            ci += 3;
+        }
+        if (wv * 64 <= h.Nn && h.Ee >= 0) {
+            const int t = min(tid, h.Nn);
+            dma4_to_lds(img_ptr + (2 * (B + 1) + h.g * (SL_NMAX + 2) + t), __builtin_amdgcn_readfirstlane(set_lds + (unsigned)((3 * EPAD + wv * 64) * 4)));
+            dma4_to_lds(in_ptr + (h.n0 + t), __builtin_amdgcn_readfirstlane(set_lds + (unsigned)((3 * EPAD + CX_PTRS + wv * 64) * 4)));
+            ci += 2;
+        }
+    };
+    auto poison = [&](const Hdr& h) __attribute__((always_inline)) {
+        u32x2 nn;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(nn) : "s"(img_ptr + __builtin_amdgcn_readfirstlane(h.g)) : "memory");
+        const int n0 = (int)nn.x, Nn = (int)nn.y - n0;
+        const long col = col_of(h);
+        float nanv[CHL];
+#pragma unroll
+        for (int j = 0; j < CHL; ++j) nanv[j] = __builtin_nanf("");
+        for (int k = grp; k < Nn; k += GROUPS) {
+            Piece16<T>::store(ctx2 + (long)(n0 + k) * H + col, nanv);
+            if (!sum_ctx) Piece16<T>::store(ctx2 + ((long)N + n0 + k) * H + col, nanv);
+        }
+    };
+    auto chunks_of = [&](const Hdr& h) __attribute__((always_inline)) { return h.Ee > 0 ? (h.Ee + EB - 1) / EB : 1; };
+
+    // ---- headers of the consumer's unit and the two after it (the producer runs at most NBUF-1 chunks ahead)
+    Hdr h0 = load_hdr(0), h1 = h0, h2 = h0;
+    if (nunits > 1) h1 = load_hdr(1);
+    if (nunits > 2) h2 = load_hdr(2);
+    int loaded = min(nunits, 3);
+    // producer position: unit ordinal pu, chunk pb; ring slot pr
+    int pu = 0, pb = 0, pr = 0, issued_chunks = 0;
+    static_assert(NBUF == 4, "four ring slots, four marks");
+    int mk0 = 0, mk1 = 0, mk2 = 0, mk3 = 0;                      // ci after the DMA of the chunk in ring slot r was issued
+    auto mark_of = [&](int r) __attribute__((always_inline)) { return r == 0 ? mk0 : r == 1 ? mk1 : r == 2 ? mk2 : mk3; };
+    int cu = 0;                                                  // consumer unit ordinal
+    auto hdr_rel = [&](int rel) __attribute__((always_inline)) {   // field by field: a selected struct copy would put the headers in scratch
+        Hdr h;
+        h.g = rel == 0 ? h0.g : rel == 1 ? h1.g : h2.g;
+        h.slice = rel == 0 ? h0.slice : rel == 1 ? h1.slice : h2.slice;
+        h.n0 = rel == 0 ? h0.n0 : rel == 1 ? h1.n0 : h2.n0;
+        h.Nn = rel == 0 ? h0.Nn : rel == 1 ? h1.Nn : h2.Nn;
+        h.e0 = rel == 0 ? h0.e0 : rel == 1 ? h1.e0 : h2.e0;
+        h.Ee = rel == 0 ? h0.Ee : rel == 1 ? h1.Ee : h2.Ee;
+        return h;
+    };
+    auto produce = [&]() __attribute__((always_inline)) {       // issue the DMA of the next chunk, if there is one within reach
+        if (pu >= nunits || pu - cu > 2) return false;
+        const Hdr hp = hdr_rel(pu - cu);
+        const int lo = pb * EB, hi = min(lo + EB, max(hp.Ee, 0));
+        if (SGG_DMA_ABL != 3 || issued_chunks == 0) issue_dma(hp, lo, hi, pr);
+        mk0 = pr == 0 ? ci : mk0;
+        mk1 = pr == 1 ? ci : mk1;
+        mk2 = pr == 2 ? ci : mk2;
+        mk3 = pr == 3 ? ci : mk3;
+        pr = pr + 1 == NBUF ? 0 : pr + 1;
+        ++issued_chunks;
+        if (++pb >= chunks_of(hp)) {
+            pb = 0;
+            ++pu;
+        }
+        return true;
+    };
+    int mark_small;
+    issue_small(h0, 0);
+    mark_small = ci;
+    for (int d = 0; d < NBUF - 1; ++d) produce();
+    for (int k = tid; k < NMAX * CHAN; k += DM_THREADS) osum[k] = 0.f;   // published by the first unit's barrier (B)
+    if (tid < CX_MAXCHUNKS) {
+        cna[tid] = 0x7fffffff;
+        cnb[tid] = -1;
+    }
+    int cr = 0, consumed = 0;                                    // consumer ring slot, chunks consumed
+
+    for (cu = 0; cu < nunits; ++cu) {
+        const Hdr hc = h0;
+        const int q = cu & 1;
+        const float* const g_out = reinterpret_cast<const float*>(sets + q * SETW);
+        const float* const g_in = g_out + EPAD;
+        const int* const in_raw = sets + q * SETW + 2 * EPAD;    // global edge ids
+        const int* const optr = in_raw + EPAD;                   // graph-local
+        const int* const iptr = optr + CX_PTRS;                  // global positions
+        // ---- unit start: its small arrays and first chunk have landed (this wave's parts)
+        { [[maybe_unused]] const int unit_no = consumed; SGG_DTICK(0) }
+        wait_mark(max(mark_small, mark_of(cr)));
+        if (hc.Ee < 0) poison(hc);
+        __syncthreads();                                         // (B) ... and every wave's
+        if (tid < hc.Nn) {                                       // thread t: node t tells the chunks its out-list touches
+            const int a = optr[tid], bnd = optr[tid + 1];
+            if (bnd > a)
+                for (int c = a / EB; c <= (bnd - 1) / EB; ++c) {
+                    atomicMin(&cna[c], tid);
+                    atomicMax(&cnb[c], tid);
+                }
+        }
+        __syncthreads();                                         // (C) chunk -> node ranges
+        if (cu + 1 < nunits) {
+            issue_small(h1, q ^ 1);                              // the next unit's: that set was the last unit's (all waves passed its E)
+            mark_small = ci;
+        }
+        // in-lists: a lane group owns (node n, part) for the whole unit
+        int P = 1, lgP = 0;
+        while (2 * P * LP <= 64 && 2 * P * hc.Nn <= GROUPS) {
+            P *= 2;
+            ++lgP;
+        }
+        const int part = grp & (P - 1), n = grp >> lgP;
+        const bool has = n < hc.Nn;
+        const long col = col_of(hc);
+        float acc_i[CHL];
+#pragma unroll
+        for (int j = 0; j < CHL; ++j) acc_i[j] = 0.f;
+        int ib = 0, mine_i = 0, ki = 0;
+        if (has) {
+            ib = iptr[n] - hc.e0 + part;
+            mine_i = (iptr[n + 1] - hc.e0 - ib + P - 1) >> lgP;
+        }
+        const int nchunks = chunks_of(hc);
+        for (int cb = 0; cb < nchunks; ++cb) {
+            const int blo = cb * EB, bhi = min(blo + EB, max(hc.Ee, 0));
+            [[maybe_unused]] const int unit_no = consumed;
+            if (cb > 0) {
+                SGG_DTICK(0)
+                wait_mark(mark_of(cr));                          // this chunk's DMA (my part of it)
+                __syncthreads();                                 // (D) chunk visible; every wave has left the last chunk
+            }
+            SGG_DTICK(1)
+            while (issued_chunks - consumed < NBUF && produce()) {}   // the ring slot of the last chunk is free: one more chunk ahead
+            SGG_DTICK(2)
+            const int soff = (cr * EB - blo) * PIECE + sub * 16; // this lane's 16 bytes of graph-local edge el: ring + soff + el * PIECE
+            if (SGG_DMA_ABL != 4 && bhi > blo) {
+                // ---- out-lists: the chunk's rows belong to the nodes na .. nb
+                const int na = __builtin_amdgcn_readfirstlane(cna[cb]), nb = __builtin_amdgcn_readfirstlane(cnb[cb]);
+                int Pc = 1, lgPc = 0;
+                while (2 * Pc * LP <= 64 && 2 * Pc * (nb - na + 1) <= GROUPS) {
+                    Pc *= 2;
+                    ++lgPc;
+                }
+                for (int nc = na + (grp >> lgPc); nc <= nb; nc += GROUPS >> lgPc) {
+                    const int pc = grp & (Pc - 1);
+                    const int a = max(optr[nc], blo) + pc, bnd = min(optr[nc + 1], bhi);
+                    float acc_o[CHL];
+#pragma unroll
+                    for (int j = 0; j < CHL; ++j) acc_o[j] = 0.f;
+                    for (int el0 = a; el0 < bnd; el0 += UO << lgPc) {
+                        Piece16<T> rowp[UO];
+                        float gz[UO];
+#pragma unroll
+                        for (int u = 0; u < UO; ++u) {
+                            const int el = min(el0 + (u << lgPc), bhi - 1);
+                            gz[u] = el0 + (u << lgPc) < bnd ? g_out[el] : 0.f;
+                            rowp[u].r = *reinterpret_cast<const decltype(rowp[u].r)*>(ring + (soff + el * PIECE));
+                        }
+#pragma unroll
+                        for (int u = 0; u < UO; ++u) {
+                            float xx[CHL];
+                            rowp[u].get(xx);
+#pragma unroll
+                            for (int j = 0; j < CHL; ++j) acc_o[j] = fmaf(gz[u], xx[j], acc_o[j]);
+                        }
+                    }
+                    for (int off = LP; off < Pc * LP; off <<= 1) {
+#pragma unroll
+                        for (int j = 0; j < CHL; ++j) acc_o[j] += __shfl_xor(acc_o[j], off, 64);
+                    }
+                    if (pc == 0) {
+                        float* dst = osum + nc * CHAN + sub * CHL;
+#pragma unroll
+                        for (int j = 0; j < CHL; j += 4) {
+                            f32x4 t = *reinterpret_cast<const f32x4*>(dst + j);
+                            t.x += acc_o[j];
+                            t.y += acc_o[j + 1];
+                            t.z += acc_o[j + 2];
+                            t.w += acc_o[j + 3];
+                            *reinterpret_cast<f32x4*>(dst + j) = t;
+                        }
+                    }
+                }
+                SGG_DTICK(3)
+                // ---- in-list entries inside [blo, bhi) (ascending edge ids: a cursor)
+                if (has) {
+                    for (;;) {
+                        int done = 0;
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int el = in_raw[ib + (min(ki + u, max(mine_i - 1, 0)) << lgP)] - hc.e0;
+                            if (ki + u < mine_i && el < bhi && done == u) {
+                                const float gw = g_in[el];
+                                Piece16<T> rw;
+                                rw.r = *reinterpret_cast<const decltype(rw.r)*>(ring + (soff + el * PIECE));
+                                float xx[CHL];
+                                rw.get(xx);
+#pragma unroll
+                                for (int j = 0; j < CHL; ++j) acc_i[j] = fmaf(gw, xx[j], acc_i[j]);
+                                ++done;
+                            }
+                        }
+                        ki += done;
+                        if (__builtin_amdgcn_ballot_w64(done == U) == 0) break;
+                    }
+                }
+            }
+            SGG_DTICK(4)
+            cr = cr + 1 == NBUF ? 0 : cr + 1;
+            ++consumed;
+        }
+        { [[maybe_unused]] const int unit_no = consumed - 1; SGG_DTICK(5) }
+        __syncthreads();                                         // (E) every wave has left the unit: the running out-sums are final
+        if (tid < CX_MAXCHUNKS) {                                // for the next unit (read again only after its barrier C)
+            cna[tid] = 0x7fffffff;
+            cnb[tid] = -1;
+        }
+        // ---- unit done: the P in-sum parts of a node meet; the node's owner takes (and clears) its out-sum; one store per sum
+        if (has) {
+            for (int off = LP; off < P * LP; off <<= 1) {
+#pragma unroll
+                for (int j = 0; j < CHL; ++j) acc_i[j] += __shfl_xor(acc_i[j], off, 64);
+            }
+            if (part == 0) {
+                float acc_o[CHL];
+                float* src = osum + n * CHAN + sub * CHL;
+#pragma unroll
+                for (int j = 0; j < CHL; j += 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(src + j);
+                    acc_o[j] = t.x;
+                    acc_o[j + 1] = t.y;
+                    acc_o[j + 2] = t.z;
+                    acc_o[j + 3] = t.w;
+                    *reinterpret_cast<f32x4*>(src + j) = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                if (sum_ctx) {
+#pragma unroll
+                    for (int j = 0; j < CHL; ++j) acc_o[j] += acc_i[j];
+                    Piece16<T>::store(ctx2 + (long)(hc.n0 + n) * H + col, acc_o);
+                } else {
+                    Piece16<T>::store(ctx2 + (long)(hc.n0 + n) * H + col, acc_o);
+                    Piece16<T>::store(ctx2 + ((long)N + hc.n0 + n) * H + col, acc_i);
+                }
+            }
+        }
+        { [[maybe_unused]] const int unit_no = consumed - 1; SGG_DTICK(6) }
+        // headers slide: the consumer moves to the next unit
+        h0 = h1;
+        h1 = h2;
+        if (loaded < nunits) {
+            h2 = load_hdr(loaded);
+            ++loaded;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The edge half of the step on its own:  e_in[e] = g_sub(e) v[s(e)] + g_obj(e) v[o(e)]   (rel_model_stanford.py:78-81).
+// The edge ROW is not an input: it enters only through its two gate dot products, which the GRU gate kernel already left in
+// edots.  So the step splits into a WRITE stream (this kernel: E rows out, the L2-resident vertex rows in) and a READ stream
+// (imp_ctx_kernel: E rows in, two weighted sums per node out) with nothing in common but the gates -- each
+// streams whole rows / full cache lines in one direction, and the two can run side by side (the forward puts the read stream on
+// the node lane's stream, in front of the node GRU that consumes it).  Any edge list: no graph structure is used.
+// A wave owns `rpw` consecutive rows: lane l makes the two gates of row l (coalesced 8-byte / 16-byte fetches), then the rows are
+// written one per step, (s, o, g_sub, g_obj) broadcast with v_readlane; the subject's piece stays in registers while s repeats.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void imp_edge_in_kernel(const T* __restrict__ v, const int* __restrict__ so,
+                                                          const float* __restrict__ ndots, const float* __restrict__ edots,
+                                                          const float* __restrict__ gb, T* __restrict__ e_in,
+                                                          float* __restrict__ gates_oi, int E, int H, int rpw) {
+    constexpr int CHL = 16 / (int)sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long base = wid * rpw;
+    if (base >= E) return;
+    const int nrows = (int)min((long)rpw, (long)E - base);
+    int s_l = 0, o_l = 0;
+    float gs_l = 0.f, go_l = 0.f;
+    if (lane < nrows) {
+        const long e = base + lane;
+        const u32x2 p = *reinterpret_cast<const u32x2*>(so + 2 * e);
+        s_l = (int)p.x;
+        o_l = (int)p.y;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(edots + 4 * e);
+        const f32x4 ns = *reinterpret_cast<const f32x4*>(ndots + 4 * (long)s_l), no = *reinterpret_cast<const f32x4*>(ndots + 4 * (long)o_l);
+        gs_l = sigmoidf_(ns.x + d.x + gb[0]);
+        go_l = sigmoidf_(no.y + d.y + gb[1]);
+        if (gates_oi) {                                       // the read stream's two gates of this row (rel_model_stanford.py:86-89)
+            f32x2_t gt;
+            gt.x = sigmoidf_(ns.z + d.z + gb[2]);             // out_edge (v[s])
+            gt.y = sigmoidf_(no.w + d.w + gb[3]);             // in_edge  (v[o])
+            *reinterpret_cast<f32x2_t*>(gates_oi + 2 * e) = gt;
+        }
+    }
+    const int CPR = H / CHL;                                  // 16-byte pieces per row
+    for (int c = lane; c < CPR; c += 64) {
+        const long col = (long)c * CHL;
+        int prev_s = -1;
+        float vs_[CHL];
+#pragma unroll
+        for (int j = 0; j < CHL; ++j) vs_[j] = 0.f;
+        constexpr int UR = 4;                                 // object pieces in flight
+        for (int j0 = 0; j0 < nrows; j0 += UR) {
+            Piece16<T> po[UR];
+            int sj[UR];
+            float gsj[UR], goj[UR];
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                const int j = min(j0 + u, nrows - 1);
+                sj[u] = __builtin_amdgcn_readlane(s_l, j);
+                const int oj = __builtin_amdgcn_readlane(o_l, j);
+                gsj[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gs_l), j));
+                goj[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(go_l), j));
+                po[u].r = *reinterpret_cast<const decltype(po[u].r)*>(v + (long)oj * H + col);
+            }
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                if (j0 + u >= nrows) break;                  // wave-uniform
+                if (sj[u] != prev_s) {                       // wave-uniform: edges come sorted by subject
+                    Piece16<T> ps;
+                    ps.r = *reinterpret_cast<const decltype(ps.r)*>(v + (long)sj[u] * H + col);
+                    ps.get(vs_);
+                    prev_s = sj[u];
+                }
+                float yy[CHL], rr[CHL];
+                po[u].get(yy);
+#pragma unroll
+                for (int q = 0; q < CHL; ++q) rr[q] = gsj[u] * vs_[q] + goj[u] * yy[q];
+                Piece16<T>::store(e_in + (base + j0 + u) * H + col, rr);
+            }
+        }
+    }
+}
+
 // persistent form: <= 2 resident workgroups per CU walk the units of their XCD (imp_stream_kernel)
 template <typename T, int LP>
 int launch_stream(const void* v, const void* e, const int* so, const int* in_ptr, const int* in_ids, const int* img_ptr, int B, int N,
@@ -1600,11 +2061,11 @@ int launch_stream(const void* v, const void* e, const int* so, const int* in_ptr
 }
 
 // LDS-DMA form: one resident 16-wave workgroup per CU, two staging buffers (imp_dma_kernel)
-template <typename T, int LP>
+template <typename T, int LP, bool EIN>
 int launch_dma(const void* v, const void* e, const int* so, const int* in_ptr, const int* in_ids, const int* img_ptr, int B, int N,
                int H, const float* ndots, const float* edots, const float* gb, void* e_in, void* ctx2, int emax, int nmax, int eb,
                int sum_ctx, int max_wgs, hipStream_t s) {
-    auto k = imp_dma_kernel<T, LP>;
+    auto k = imp_dma_kernel<T, LP, EIN>;
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS_MAX) != hipSuccess)
@@ -1632,6 +2093,122 @@ extern "C" int sgg_graph_ptr(const int64_t* im_inds, int N, int B, const int* ou
     hipLaunchKernelGGL(graph_ptr_kernel, dim3((B + 256) / 256), dim3(256), 0, (hipStream_t)stream, im_inds, N, B, out_ptr, img_ptr);
     SGG_CHECK_LAUNCH();
     return SGG_OK;
+}
+
+namespace {
+// LDS-DMA kernel, with e_in (one kernel for the whole step) or without (the read stream of the split step).  Returns 1 when the
+// graphs do not fit it (above one edge per thread, rows not a multiple of 64 bytes, e_in beyond 32-bit byte offsets).
+int dma_dispatch(const void* v, const void* e, const int* so, const int* in_ptr, const int* in_ids, const int* img_ptr,
+                 int B, int N, int E, int H, const float* node_dots, const float* edge_dots, const float* gate_b, void* e_in, void* ctx2,
+                 int max_edges, int max_nodes, int sum_ctx, int dtype, int max_wgs, hipStream_t s) {
+    const int tsz = dtype == SGG_BF16 ? 2 : 4;
+    const int row = H * tsz;
+    if (row % 64 || max_nodes > DM_NMAX || max_edges > DM_EMAX || (long)E * row >= 0xffff0000L) return 1;
+    const int emax = (max(max_edges, 16) + 15) & ~15, nmax = (max(max_nodes, 8) + 7) & ~7;
+    // 128-byte pieces (full cache lines: 5.3 TB/s against 3.3 for half lines) when that still gives every CU a unit;
+    // SGG_IMP_PIECE=64|128 overrides (experiments, tests)
+    const char* pc = getenv("SGG_IMP_PIECE");
+    int piece = (row % 128 == 0 && (long)B * (row / 128) >= 256) ? 128 : 64;
+    if (pc && atoi(pc) == 64) piece = 64;
+    if (pc && atoi(pc) == 128 && row % 128 == 0) piece = 128;
+    const char* ebs = getenv("SGG_IMP_EB");     // tests: small batches (several per unit on small graphs)
+    for (; piece >= 64; piece -= 64) {
+        int eb = dma_batch_edges(emax, nmax, 4 * piece / tsz, piece, sum_ctx != 0);
+        if (eb < 64) continue;                  // a batch holds whole out-lists (< 64 edges each)
+        if (ebs && atoi(ebs) >= 64) eb = min(eb, atoi(ebs) & ~15);
+#define SGG_DMA(T, LPV)                                                                                                      \
+    return launch_dma<T, LPV, true>(v, e, so, in_ptr, in_ids, img_ptr, B, N, H, node_dots, edge_dots, gate_b, e_in, ctx2, emax, nmax, \
+                                    eb, sum_ctx, max_wgs, s)
+        if (dtype == SGG_BF16) {
+            if (piece == 128) SGG_DMA(bf16_t, 8);
+            SGG_DMA(bf16_t, 4);
+        } else {
+            if (piece == 128) SGG_DMA(float, 8);
+            SGG_DMA(float, 4);
+        }
+#undef SGG_DMA
+    }
+    return 1;
+}
+}  // namespace
+
+namespace {
+template <typename T, int LP>
+int launch_ctx(const void* e, const float* gates_oi, const int* in_ptr, const int* in_ids, const int* img_ptr, int B, int N, int H,
+               void* ctx2, int emax, int nmax, int eb, int sum_ctx, int max_wgs, hipStream_t s) {
+    auto k = imp_ctx_kernel<T, LP>;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS_MAX) != hipSuccess)
+            return SGG_ERR_LAUNCH;
+        configured = true;
+    }
+    const int piece = LP * 16;
+    const int units = B * (H * (int)sizeof(T) / piece);
+    int grid = min(units, 256);
+    if (max_wgs > 0) grid = min(grid, max_wgs);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(DM_THREADS), CX_NBUF * eb * piece + ctx_fixed_bytes(emax, nmax, 4 * piece / (int)sizeof(T)), s,
+                       (const T*)e, gates_oi, in_ptr, in_ids, img_ptr, B, N, H, (T*)ctx2, emax, nmax, eb, sum_ctx);
+    return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
+}
+
+// the ring-buffered read stream; 1 when the graphs do not fit it (as dma_dispatch)
+int ctx_dispatch(const void* e, const float* gates_oi, const int* in_ptr, const int* in_ids, const int* img_ptr, int B, int N, int E, int H,
+                 void* ctx2, int max_edges, int max_nodes, int sum_ctx, int dtype, int max_wgs, hipStream_t s) {
+    const int tsz = dtype == SGG_BF16 ? 2 : 4;
+    const int row = H * tsz;
+    if (row % 64 || max_nodes > DM_NMAX || max_edges > DM_EMAX) return 1;
+    const int emax = (max(max_edges, 16) + 15) & ~15, nmax = (max(max_nodes, 8) + 7) & ~7;
+    const char* pc = getenv("SGG_IMP_PIECE");
+    int piece = (row % 128 == 0 && (long)B * (row / 128) >= 256) ? 128 : 64;
+    if (pc && atoi(pc) == 64) piece = 64;
+    if (pc && atoi(pc) == 128 && row % 128 == 0) piece = 128;
+    int eb = ctx_chunk_edges(emax, nmax, 4 * piece / tsz, piece);
+    if (eb < 16) return 1;
+    const char* ebs = getenv("SGG_IMP_EB");     // tests: small chunks (many per unit on small graphs)
+    if (ebs && atoi(ebs) >= 16) eb = min(eb, atoi(ebs) & ~15);
+#define SGG_CTX(T, LPV) \
+    return launch_ctx<T, LPV>(e, gates_oi, in_ptr, in_ids, img_ptr, B, N, H, ctx2, emax, nmax, eb, sum_ctx, max_wgs, s)
+    if (dtype == SGG_BF16) {
+        if (piece == 128) SGG_CTX(bf16_t, 8);
+        SGG_CTX(bf16_t, 4);
+    } else {
+        if (piece == 128) SGG_CTX(float, 8);
+        SGG_CTX(float, 4);
+    }
+#undef SGG_CTX
+}
+}  // namespace
+
+// ---- the split step (what the forward runs): a write stream and a read stream that share nothing but the gate dot products
+extern "C" int sgg_imp_edge_in_fwd(const void* v, const int* so, const float* node_dots, const float* edge_dots, const float* gate_b,
+                                   void* e_in, float* gates_oi, int E, int H, int dtype, void* stream) {
+    if (E == 0) return SGG_OK;
+    if (!v || !so || !node_dots || !edge_dots || !gate_b || !e_in || E < 0 || H <= 0) return SGG_ERR_ARG;
+    if (dtype != SGG_BF16 && dtype != SGG_F32) return SGG_ERR_DTYPE;
+    if ((H * (dtype == SGG_BF16 ? 2 : 4)) % 16) return SGG_ERR_ARG;
+    // rows per wave: enough waves to fill the chip (256 CUs x 8) on small batches, 64-row batches on large ones
+    int rpw = (int)(((long)E + 2047) / 2048);
+    rpw = rpw < 4 ? 4 : rpw > 64 ? 64 : rpw;
+    const long waves = ((long)E + rpw - 1) / rpw;
+    const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    SGG_DISPATCH_T(dtype,
+        hipLaunchKernelGGL(imp_edge_in_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)v, so, node_dots, edge_dots, gate_b, (bf16_t*)e_in, gates_oi, E, H, rpw),
+        hipLaunchKernelGGL(imp_edge_in_kernel<float>, grid, blk, 0, s, (const float*)v, so, node_dots, edge_dots, gate_b, (float*)e_in, gates_oi, E, H, rpw));
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_imp_ctx_fwd(const void* e, const float* gates_oi, const int* in_ptr, const int* in_ids, const int* img_ptr, int B, int N,
+                               int E, int H, void* ctx2, int max_edges, int max_nodes, int sum_ctx, int dtype, void* stream) {
+    if (N == 0 || B == 0) return SGG_OK;
+    if (!e || !gates_oi || !in_ptr || !in_ids || !img_ptr || !ctx2 || N < 0 || E < 0 || B < 0 || H <= 0) return SGG_ERR_ARG;
+    if (dtype != SGG_BF16 && dtype != SGG_F32) return SGG_ERR_DTYPE;
+    const char* mw = getenv("SGG_IMP_MAX_WGS");
+    const int rc = ctx_dispatch(e, gates_oi, in_ptr, in_ids, img_ptr, B, N, E, H, ctx2, max_edges, max_nodes, sum_ctx, dtype,
+                                mw ? atoi(mw) : 0, (hipStream_t)stream);
+    return rc == 1 ? SGG_ERR_CAPACITY : rc;
 }
 
 // largest per-graph edge count the sliced kernel takes at this row width (0: rows too narrow for any slicing)
@@ -1669,39 +2246,16 @@ extern "C" int sgg_imp_sliced_fwd(const void* v, const void* e, const int* so, c
             lp = f;
     }
     // Default: the short-lived form (one workgroup per unit, two per CU) -- still the fastest measured (DESIGN.md "IMP step").
-    // SGG_IMP_STREAM=d: the persistent LDS-DMA kernel (128-byte pieces, batches, gates once per unit); =1: the register-prefetch
-    // persistent form.  Both are kept as measured experiments and as cross-checks of the default (tests/test_kernels_gpu.py).
+    // SGG_IMP_STREAM=d: the persistent LDS-DMA kernel doing both halves (128-byte pieces, batches, gates once per unit); =1: the register-prefetch persistent form.
+    // Kept as measured experiments and as cross-checks of each other (tests/test_kernels_gpu.py).
     // SGG_IMP_MAX_WGS=n caps the persistent grid (tests: several units per workgroup on small batches).
     const char* st = getenv("SGG_IMP_STREAM");
     const char* mw = getenv("SGG_IMP_MAX_WGS");
     const int max_wgs = mw ? atoi(mw) : 0;
-    // (graphs above one edge per thread, or whose e_in exceeds 32-bit byte offsets, take the short-lived form)
-    if (st && st[0] == 'd' && row % 64 == 0 && max_nodes <= DM_NMAX && max_edges <= DM_EMAX && (long)E * row < 0xffff0000L) {
-        const int emax = (max(max_edges, 16) + 15) & ~15, nmax = (max(max_nodes, 8) + 7) & ~7;
-        const int tsz = dtype == SGG_BF16 ? 2 : 4;
-        // 128-byte pieces (full cache lines: 5.3 TB/s against 3.3 for half lines) when that still gives every CU a unit;
-        // SGG_IMP_PIECE=64|128 overrides (experiments, tests)
-        const char* pc = getenv("SGG_IMP_PIECE");
-        int piece = (row % 128 == 0 && (long)B * (row / 128) >= 256) ? 128 : 64;
-        if (pc && atoi(pc) == 64) piece = 64;
-        if (pc && atoi(pc) == 128 && row % 128 == 0) piece = 128;
-        const char* ebs = getenv("SGG_IMP_EB");     // tests: small batches (several per unit on small graphs)
-        for (; piece >= 64; piece -= 64) {
-            int eb = dma_batch_edges(emax, nmax, 4 * piece / tsz, piece, sum_ctx != 0);
-            if (eb < 64) continue;                  // a batch holds whole out-lists (< 64 edges each)
-            if (ebs && atoi(ebs) >= 64) eb = min(eb, atoi(ebs) & ~15);
-#define SGG_DMA(T, LPV) \
-    return launch_dma<T, LPV>(v, e, so, in_ptr, in_ids, img_ptr, B, N, H, node_dots, edge_dots, gate_b, e_in, ctx2, emax, nmax, eb, \
-                              sum_ctx, max_wgs, s)
-            if (dtype == SGG_BF16) {
-                if (piece == 128) SGG_DMA(bf16_t, 8);
-                SGG_DMA(bf16_t, 4);
-            } else {
-                if (piece == 128) SGG_DMA(float, 8);
-                SGG_DMA(float, 4);
-            }
-#undef SGG_DMA
-        }
+    if (st && st[0] == 'd') {
+        const int rc = dma_dispatch(v, e, so, in_ptr, in_ids, img_ptr, B, N, E, H, node_dots, edge_dots, gate_b, e_in, ctx2, max_edges,
+                                    max_nodes, sum_ctx, dtype, max_wgs, s);
+        if (rc != 1) return rc;                      // 1: these graphs do not fit the LDS-DMA kernel -> short-lived form below
     }
     if (st && st[0] == '1') {
 #define SGG_STREAM(T, LPV) \

@@ -415,6 +415,8 @@ def imp_sliced(v, e, csr, node_dots, edge_dots, gate_b, e_in=None, ctx2=None, ct
     instead of the two halves (-> (e_in, ctx_sum))."""
     N, H = v.shape
     E = e.shape[0]
+    if os.environ.get('SGG_IMP_STREAM') == 's' and imp_split_ok(csr, H, v.dtype):     # kernel experiments / cross-checks
+        return imp_split(v, e, csr, node_dots, edge_dots, gate_b, e_in=e_in, ctx2=ctx2, ctx_sum=ctx_sum)
     out_ptr, out_ids, in_ptr, in_ids, so, flags = csr
     B, max_nodes, max_edges = csr.graphs
     if e_in is None:
@@ -426,6 +428,49 @@ def imp_sliced(v, e, csr, node_dots, edge_dots, gate_b, e_in=None, ctx2=None, ct
               _p(node_dots, torch.float32), _p(edge_dots, torch.float32), _p(gate_b, torch.float32), _p(e_in), _p(dst),
               max_edges, max_nodes, 1 if ctx_sum is not None else 0, dt(v), _stream())
     return e_in, dst
+
+
+def imp_split_ok(csr, H, dtype):
+    """True when the split step's read stream (sgg_imp_ctx_fwd) takes these graphs: one edge per thread of its workgroup."""
+    g = getattr(csr, 'graphs', None)
+    return imp_sliced_ok(csr, H, dtype) and g[2] <= 1024 and (H * (2 if dtype == torch.bfloat16 else 4)) % 64 == 0
+
+
+def imp_edge_in(v, csr, node_dots, edge_dots, gate_b, E, e_in=None, gates_oi=None):
+    """The write stream of the split step: e_in[e] = g_sub v[s] + g_obj v[o] -> [E,H] (the edge rows are not an input); with
+    gates_oi (f32 [E,2]) it also leaves (g_out, g_in) of every edge for the read stream (imp_ctx)."""
+    N, H = v.shape
+    so = csr[4]
+    if e_in is None:
+        e_in = torch.empty((E, H), dtype=v.dtype, device=v.device)
+    _lib.call('sgg_imp_edge_in_fwd', _p(v), _p(so), _p(node_dots, torch.float32), _p(edge_dots, torch.float32), _p(gate_b, torch.float32),
+              _p(e_in), _p(gates_oi, torch.float32) if gates_oi is not None else None, E, H, dt(v), _stream())
+    return e_in
+
+
+def imp_ctx(e, csr, N, gates_oi, ctx2=None, ctx_sum=None):
+    """The read stream of the split step: ctx2 [2,N,H] = (sum over out-edges g_out e, sum over in-edges g_in e), or their sum in
+    ctx_sum [N,H]; gates_oi f32 [E,2] from imp_edge_in."""
+    E, H = e.shape
+    out_ptr, out_ids, in_ptr, in_ids, so, flags = csr
+    B, max_nodes, max_edges = csr.graphs
+    if gates_oi.shape != (E, 2):
+        raise ValueError('imp_ctx: gates_oi must be f32 [E,2]')
+    if ctx_sum is None and ctx2 is None:
+        ctx2 = torch.empty((2, N, H), dtype=e.dtype, device=e.device)
+    dst = ctx_sum if ctx_sum is not None else ctx2
+    _lib.call('sgg_imp_ctx_fwd', _p(e), _p(gates_oi, torch.float32), _p(in_ptr), _p(in_ids), _p(csr.img_ptr), B, N, E, H, _p(dst), max_edges,
+              max_nodes, 1 if ctx_sum is not None else 0, dt(e), _stream())
+    return dst
+
+
+def imp_split(v, e, csr, node_dots, edge_dots, gate_b, e_in=None, ctx2=None, ctx_sum=None, gates_oi=None):
+    """One IMP step as its write stream followed by its read stream; same results as imp_sliced."""
+    E = e.shape[0]
+    if gates_oi is None:
+        gates_oi = torch.empty((E, 2), dtype=torch.float32, device=e.device)
+    e_in = imp_edge_in(v, csr, node_dots, edge_dots, gate_b, E, e_in=e_in, gates_oi=gates_oi)
+    return e_in, imp_ctx(e, csr, v.shape[0], gates_oi, ctx2=ctx2, ctx_sum=ctx_sum)
 
 
 def gru_gate(gi, gh, b_hh, h_prev, out_dtype, out=None, dot_w=None, dots=None):

@@ -592,7 +592,7 @@ def test_imp_persistent_kernels_equal_short_lived_form(ops, dtype, monkeypatch):
     in both output modes (ctx halves / summed ctx).  A broken capacity promise poisons that graph's outputs in every form."""
     H = 128
     g = torch.Generator().manual_seed(77)
-    for case, sizes in enumerate(([32, 5, 17, 2, 32, 9, 33, 3, 12], [32] * 12, [6, 2, 2])):
+    for case, sizes in enumerate(([32, 5, 17, 2, 32, 9, 31, 3, 12], [32] * 12, [6, 2, 2], [33, 4])):
         im = np.concatenate([np.full(n, b) for b, n in enumerate(sizes)]).astype(np.int64)
         rel = O.get_rel_inds_eval(im)
         if case == 0:
@@ -615,7 +615,7 @@ def test_imp_persistent_kernels_equal_short_lived_form(ops, dtype, monkeypatch):
         ctol = dict(atol=1e-4, rtol=1e-5) if dtype == torch.float32 else dict(atol=0.13, rtol=1.6e-2)   # 2 bf16 ulps
         # (form, piece bytes, edges per batch): the LDS-DMA kernel with half-line and full-line pieces, one batch per unit and
         # several (small batches: lists of one node straddle batch boundaries, the in-list cursors advance across them)
-        for form, piece, eb in (('d', '64', ''), ('d', '128', ''), ('d', '128', '80'), ('d', '64', '64'), ('1', '', '')):
+        for form, piece, eb in (('d', '64', ''), ('d', '128', ''), ('d', '128', '80'), ('d', '64', '64'), ('s', '128', ''), ('s', '64', '80'), ('s', '128', '32'), ('s', '64', '16'), ('1', '', '')):
             monkeypatch.setenv('SGG_IMP_STREAM', form)
             for k_, v_ in (('SGG_IMP_PIECE', piece), ('SGG_IMP_EB', eb)):
                 if v_:
@@ -632,12 +632,31 @@ def test_imp_persistent_kernels_equal_short_lived_form(ops, dtype, monkeypatch):
                 _, csum = ops.imp_sliced(v, e, csr, nd, ed, gb, ctx_sum=torch.empty_like(v))
                 assert torch.equal(e_in, ref_ein), (case, form, piece, eb, cap)
                 # ctx: a node's list is cut into more parts by the 16-wave kernel (other association of the same f32 terms)
-                torch.testing.assert_close(ctx2.float(), ref_ctx2.float(), **ctol)
-                torch.testing.assert_close(csum.float(), ref_sum.float(), **ctol)
+                where = lambda m: '%s %s' % (m, (case, form, piece, eb, cap))  # noqa: E731
+                torch.testing.assert_close(ctx2.float(), ref_ctx2.float(), msg=where, **ctol)
+                torch.testing.assert_close(csum.float(), ref_sum.float(), msg=where, **ctol)
                 if first is None:
                     first = (e_in, ctx2, csum)
                 else:                                                    # the same form is bit-reproducible for every grid size
                     assert all(torch.equal(a, b) for a, b in zip(first, (e_in, ctx2, csum))), (case, form, piece, eb, cap)
+        # the split step through its own entry points (what the forward calls): write stream and read stream, any order
+        for k_ in ('SGG_IMP_STREAM', 'SGG_IMP_PIECE', 'SGG_IMP_EB', 'SGG_IMP_MAX_WGS'):
+            monkeypatch.delenv(k_, raising=False)
+        assert ops.imp_split_ok(csr, H, dtype) == (case < 3)      # case 3: 1056 edges > one per thread -> the forms above fell back
+        if case == 3:
+            with pytest.raises(ValueError):
+                ops.imp_ctx(e, csr, N, torch.zeros((E, 2), device=DEV))
+            continue
+        gates = torch.full((E, 2), float('nan'), device=DEV)
+        ein_a = ops.imp_edge_in(v, csr, nd, ed, gb, E, gates_oi=gates)
+        rs, ro = (torch.from_numpy(rel[:, k_].astype(np.int64)).to(DEV) for k_ in (1, 2))
+        torch.testing.assert_close(gates, torch.sigmoid(torch.stack([nd[rs, 2] + ed[:, 2] + gb[2], nd[ro, 3] + ed[:, 3] + gb[3]], 1)),
+                                   atol=2e-6, rtol=2e-6)
+        ctx_b = ops.imp_ctx(e, csr, N, gates)
+        sum_b = ops.imp_ctx(e, csr, N, gates, ctx_sum=torch.empty_like(v))
+        assert torch.equal(ein_a, ref_ein) and torch.equal(ops.imp_edge_in(v, csr, nd, ed, gb, E), ref_ein), case
+        torch.testing.assert_close(ctx_b.float(), ref_ctx2.float(), **ctol)
+        torch.testing.assert_close(sum_b.float(), ref_sum.float(), **ctol)
         # understated capacity (graph 0 promised as 40 edges): its outputs are NaN, the other graphs are untouched
         if case == 2:
             lie = ops.edge_csr(cu(rel), N, cu(im), graphs=(len(sizes), max(sizes), 8))

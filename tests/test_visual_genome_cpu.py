@@ -39,15 +39,18 @@ def test_load_graphs_equals_reference(ci):
         assert boxes[i].dtype == G['c%d_boxes_%d' % (ci, i)].dtype
 
 
-def test_load_graphs_rejects_unknown_mode_and_paths_without_h5py():
+def test_load_graphs_rejects_unknown_mode_and_missing_files(tmp_path):
+    """.h5 paths are opened by the package's own reader (sgg_amd.hdf5_lite, no h5py): a missing file and a file that is not HDF5
+    are both errors, not empty splits."""
     from sgg_amd.visual_genome import load_graphs
     with pytest.raises(ValueError):
         load_graphs(tables(), mode='trainval')
-    try:
-        import h5py  # noqa: F401
-    except ImportError:
-        with pytest.raises(ImportError):
-            load_graphs('/nonexistent/VG-SGG.h5')
+    with pytest.raises(OSError):
+        load_graphs('/nonexistent/VG-SGG.h5')
+    bad = tmp_path / 'not_hdf5.h5'
+    bad.write_bytes(b'plain text, no superblock' * 64)
+    with pytest.raises((OSError, ValueError)):
+        load_graphs(str(bad))
 
 
 def test_info_dups_filenames(tmp_path):

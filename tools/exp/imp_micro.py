@@ -30,9 +30,25 @@ for B in Bs:
     e_in, ctx2 = torch.empty_like(e), torch.empty((2, N, H), dtype=dtype, device=dev)
     algo = (2.0 * (E + N) * H) * s + 8.0 * E
     row = []
+    side = torch.cuda.Stream()
+    ev0, ev1 = torch.cuda.Event(), torch.cuda.Event()
+
+    def par():                      # the split step on two streams: write stream here, read stream on the side
+        cur = torch.cuda.current_stream()
+        ev0.record(cur)
+        side.wait_event(ev0)
+        with torch.cuda.stream(side):
+            ops.imp_ctx(e, csr, N, gates, ctx2=ctx2)
+            ev1.record(side)
+        ops.imp_edge_in(v, csr, nd, ed, gb, E, e_in=e_in)
+        cur.wait_event(ev1)
+    gates = torch.empty((E, 2), device=dev)
+    ops.imp_edge_in(v, csr, nd, ed, gb, E, e_in=e_in, gates_oi=gates)
     for form in forms:
-        os.environ['SGG_IMP_STREAM'] = form
-        launch = lambda: ops.imp_sliced(v, e, csr, nd, ed, gb, e_in, ctx2)
+        os.environ['SGG_IMP_STREAM'] = form if form not in ('A', 'B', 'par') else '0'
+        launch = {'A': lambda: ops.imp_edge_in(v, csr, nd, ed, gb, E, e_in=e_in, gates_oi=gates), 'B': lambda: ops.imp_ctx(e, csr, N, gates, ctx2=ctx2),
+                  's': lambda: ops.imp_split(v, e, csr, nd, ed, gb, e_in=e_in, ctx2=ctx2, gates_oi=gates),
+                  'par': par}.get(form, lambda: ops.imp_sliced(v, e, csr, nd, ed, gb, e_in, ctx2))
         for _ in range(3):
             launch()
         torch.cuda.synchronize()
@@ -50,6 +66,18 @@ for B in Bs:
         ms = e0.elapsed_time(e1) / 50
         row.append('%s %7.2f us %5.0f GB/s %.3f' % (form, ms * 1e3, algo / ms / 1e6, algo / ms / 1e6 / 8000))
     print('B=%3d' % B, ' | '.join(row), flush=True)
+    if os.environ.get('IMP_EAGER'):                     # no graph: do the two streams of 'par' overlap on the device?
+        for name, fn in (('s', lambda: ops.imp_split(v, e, csr, nd, ed, gb, e_in=e_in, ctx2=ctx2, gates_oi=gates)), ('par', par)):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(200):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            print('   eager %s: %.2f us per step' % (name, e0.elapsed_time(e1) * 5))
     lib = _lib.load()
     if hasattr(lib, 'sgg_dbg_dma_ticks') and 'd' in forms:
         os.environ['SGG_IMP_STREAM'] = 'd'
@@ -72,4 +100,22 @@ for B in Bs:
                 print('   batch %2d: since-last-batch-end %6d | wait+bar+dma-issue %6d  small-issue %5d  phase1 %6d  phase2 %6d   | batch total %6d' %
                       (u, gap, r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4], r[5] - r[1]))
                 prev_end = r[5]
+    if hasattr(lib, 'sgg_dbg_dma_ticks') and 'B' in forms:
+        ops.imp_ctx(e, csr, N, gates, ctx2=ctx2)
+        torch.cuda.synchronize()
+        buf = np.zeros(8 * 16 * 8, dtype=np.int64)
+        lib.sgg_dbg_dma_ticks.argtypes = [ctypes.c_void_p]
+        assert lib.sgg_dbg_dma_ticks(buf.ctypes.data) == 0
+        t = buf.reshape(8, 16, 8)
+        for blk in (0, 3):
+            print(' block %d (wave 0; clock64 ticks per CHUNK of the read stream)' % blk)
+            prev_end = None
+            for u in range(16):
+                r = t[blk, u]
+                if r[4] == 0:
+                    break
+                gap = (r[0] - prev_end) if prev_end is not None else 0
+                print('   chunk %2d: gap %6d | wait+barrier(s) %6d  dma-issue %5d  out-lists %6d  in-lists %6d | unit end: wait E %6d  sums+stores %6d' %
+                      (u, gap, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], (r[5] - r[4]) if r[5] else 0, (r[6] - r[5]) if r[6] else 0))
+                prev_end = r[6] if r[6] else r[4]
     os.environ.pop('SGG_IMP_STREAM', None)
