@@ -1099,52 +1099,25 @@ int launch_sliced(const void* v, const void* e, const int* so, const int* out_pt
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Persistent LDS-DMA form of the sliced step (imp_dma_kernel): the kernel the forward runs.
+// Persistent LDS-DMA kernels (the read stream of the split step, imp_ctx_kernel below).
 //
 // What bounds the step (measured on MI355X, DESIGN.md "IMP step"):
 //   * the REQUEST size.  A workgroup that owns a W-byte column slice of a graph's edge rows moves W bytes per memory request;
 //     the chip retires about the same number of requests per second whatever their size, so 64-byte pieces (half a cache
 //     line) stream at 3.3 TB/s, 128-byte pieces (full lines) at 5.3 TB/s, 256-byte pieces at 5.6 TB/s
-//     (tools/exp/piece_bw.hip).  The short-lived kernel above (64-byte pieces) was AT its pattern's ceiling.
-//   * VALU instructions.  With 64-byte units every lane did 4 edges per unit and then paid the unit's fixed costs again;
-//     gates were recomputed by each of a graph's 16 slices, per lane.
-//   * the vector-memory pipe of the CU takes one wave-instruction at a time: 4-byte gathers (gate dots, node ids) queue it up.
-// Hence: the unit is (graph, 128-byte slice) whenever that still gives every CU a unit (64-byte slices for small batches).
-// A unit's row pieces do not fit LDS twice at 128 bytes (992 x 128 B = 124 KB), so a unit is cut into BATCHES of consecutive
-// edges and the two staging buffers alternate between batches: while batch b is in its gate / accumulate phases, the DMA of
-// batch b+1 -- or of the next unit's first batch -- is in flight (`global_load_lds_dwordx4`: straight into LDS, no VGPR round
-// trip; both phases read the staged pieces with ds_read_b128).  A lane group owns one node for the whole unit: it walks the part
-// of the node's out-list that lies in the batch (phase 1: e_in rows, sum g_out e) and, with a cursor, the part of its in-list
-// that does (phase 2: sum g_in e over the staged pieces); both sums stay in registers until the unit ends.
-// Everything else a unit needs is fetched ONE COALESCED ELEMENT PER THREAD (thread t <-> edge t: its four gate dots as one
-// 16-byte load, (subject, object), in-list entry; thread t <-> node t: list offsets, vertex dots) one unit ahead into
-// registers; at the start of the unit thread t turns the dots of edge t into its four GATES (once per unit instead of once per
-// lane and edge) and parks them in LDS.  A wave waits for memory ONCE per batch (`s_waitcnt vmcnt(0)` at its top).
-//
-// A node's lists are dealt to its P lane groups round-robin (entry k -> group k % P): at every step the P groups read P
-// consecutive staged rows (conflict-free; contiguous chunks put all of a wave's groups on the same banks).
+//     (tools/exp/piece_bw.hip).  The short-lived kernel above (64-byte pieces) is AT its pattern's ceiling.
+//   * VALU instructions: every wave of a 16-wave workgroup walks the same instruction stream, 4 cycles per wave instruction
+//     and SIMD, four waves per SIMD.
+// A one-kernel persistent form with 128-byte pieces (imp_dma_kernel: two 496-edge batches per unit, gates once per unit,
+// small arrays prefetched into registers by asm loads) measured 70-85 us at B=128 and was removed: its asm loads returned into
+// registers that the compiler believed defined at issue -- legal only while the register allocator never copies them, which
+// it started to do as soon as register pressure rose (DESIGN.md "IMP step").
 //
 // The DMA is issued from inline asm on purpose: hipcc treats a known LDS-DMA as an LDS write that may alias every later LDS
-// read and puts `s_waitcnt vmcnt(0)` in front of each, which would serialise batch b's phases behind batch b+1's DMA.  The
-// compiler's vmcnt bookkeeping therefore does not know about the DMA; that is harmless because every load is consumed after
-// a top wait, which is the builtin (the compiler's scoreboard sees the drain and adds no wait of its own).
+// read and puts `s_waitcnt vmcnt(0)` in front of each, which would serialise a chunk's compute behind the next chunk's DMA.
 constexpr int DM_THREADS = 1024;
 constexpr int DM_EMAX = DM_THREADS, DM_NMAX = SL_NMAX;     // one edge per thread for the coalesced fetches
 constexpr int DM_LDS_MAX = 160 * 1024;
-// LDS that does not depend on the batch size.  vsb: bytes of one node's vertex piece as f32
-constexpr int dma_fixed_bytes(int emax, int nmax, int vsb, bool sum_ctx) {
-    return emax * 16 + emax + emax * 2                     // gates f32[emax][4], object node u8, in-list entries u16
-           + nmax * vsb + nmax * 16 + 2 * (nmax + 4) * 4   // vertex pieces (f32), vertex dots, out- / in-list offsets
-           + (sum_ctx ? nmax * vsb : 0);                   // ctx_out pieces waiting for ctx_in (one summed ctx tensor: training)
-}
-// edges per batch (multiple of 16, at most emax): two staging buffers of `eb` pieces must fit beside the fixed part
-constexpr int dma_batch_edges(int emax, int nmax, int vsb, int piece, bool sum_ctx) {
-    const int room = (DM_LDS_MAX - dma_fixed_bytes(emax, nmax, vsb, sum_ctx)) / (2 * piece);
-    const int eb = room < emax ? (room & ~15) : emax;
-    return eb < 16 ? 0 : eb;
-}
-static_assert(dma_batch_edges(1008, 32, 256, 128, true) >= 496, "imp_dma_kernel: a 992-edge graph must go through in two 128-byte batches");
-static_assert(dma_batch_edges(1008, 32, 128, 64, true) == 1008, "imp_dma_kernel: ... and in one 64-byte batch");
 
 typedef __attribute__((address_space(3))) char lds_char_t;
 
@@ -1154,7 +1127,7 @@ __device__ __forceinline__ void dma16_to_lds(const void* gptr, unsigned lds_base
 }
 
 #ifndef SGG_DMA_ABL
-#define SGG_DMA_ABL 0     // kernel experiments only: 1 copy only (staged piece in, piece out), 2 no e_in stores, 3 no DMA after the first batch
+#define SGG_DMA_ABL 0     // kernel experiments only (imp_ctx_kernel): 3 no DMA after the first chunk, 4 DMA and barriers only (no sums)
 #endif
 #ifdef SGG_DMA_TICKS     // kernel experiments only: clock stamps of the first 8 workgroups (one per XCD), wave 0, 16 units x 8 stamps
 __device__ long long g_dma_ticks[8 * 16 * 8];
@@ -1164,439 +1137,17 @@ __device__ long long g_dma_ticks[8 * 16 * 8];
 #define SGG_DTICK(i)
 #endif
 
-template <typename T, int LP, bool EIN>
-__global__ __launch_bounds__(DM_THREADS) void imp_dma_kernel(
-    const T* __restrict__ v, const T* __restrict__ e, const int* __restrict__ so, const int* __restrict__ in_ptr,
-    const int* __restrict__ in_ids, const int* __restrict__ img_ptr, int B, int N, int H, const float* __restrict__ ndots,
-    const float* __restrict__ edots, const float* __restrict__ gb, T* __restrict__ e_in, T* __restrict__ ctx2, int EMAX, int NMAX,
-    int EB, int sum_ctx) {
-    constexpr int PIECE = LP * 16, CHL = 16 / (int)sizeof(T), GROUPS = DM_THREADS / LP, U = 2, EPW = 64 / LP;
-    constexpr int VSB = CHL * 4 * LP;                      // a node's vertex piece as f32
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS map (EMAX, EB multiples of 16, NMAX of 8: every array 16-byte aligned)
-    char* const stage0 = smem;                                                       // [2][EB][PIECE]
-    float* const gates = reinterpret_cast<float*>(stage0 + 2L * EB * PIECE);         // [EMAX][4]  sub_vert, obj_vert, out_edge, in_edge
-    unsigned char* const onl8 = reinterpret_cast<unsigned char*>(gates + 4L * EMAX); // [EMAX] graph-local object node
-    char* const vs = reinterpret_cast<char*>(onl8 + EMAX);                            // [NMAX][VSB] vertex pieces as f32
-    float* const nd = reinterpret_cast<float*>(vs + NMAX * VSB);                      // [NMAX][4]
-    int* const optr = reinterpret_cast<int*>(nd + NMAX * 4);                          // [NMAX+4] out-list offsets (graph-local)
-    int* const iptr = optr + NMAX + 4;                                                // [NMAX+4] in-list offsets (graph-local)
-    unsigned short* const in_loc = reinterpret_cast<unsigned short*>(iptr + NMAX + 4);   // [EMAX] in-list entries (graph-local edge)
-    char* const osum = reinterpret_cast<char*>(in_loc + EMAX);                        // [NMAX][VSB] ctx_out pieces (f32), sum_ctx only
-    const unsigned stage_lds = (unsigned)(unsigned long)(lds_char_t*)smem;
-
-    const int S = H * (int)sizeof(T) / PIECE, units = B * S;
-    // this workgroup's units: XCD x (dispatch puts block b on XCD b % 8) owns a contiguous range of units, so that the
-    // slices of a graph -- which share its tables and dots -- meet in one L2
-    const int G = (int)gridDim.x, NX = min(G, 8), x = (int)blockIdx.x % NX, w = (int)blockIdx.x / NX;
-    const int wx = G / NX + (x < G % NX ? 1 : 0);
-    const int uq = units / NX, ur = units % NX;
-    const int cnt = uq + (x < ur ? 1 : 0), base = x * uq + min(x, ur);
-    if (w >= cnt) return;
-    const int tid = threadIdx.x, sub = tid % LP, grp = tid / LP, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float b0 = gb[0], b1 = gb[1], b2 = gb[2], b3 = gb[3];
-
-    struct Hdr { int g, slice, n0, Nn, e0, Ee; };          // Ee < 0: the host's promise about this graph is broken (see poison)
-    // (graph, slice) of unit `base + idx`, stepped from the last header loaded: no integer division on the per-unit path
-    int lg = base / S, lslice = base - lg * S, lidx = 0;
-    auto load_hdr = [&](int idx) {
-        Hdr h;
-        lslice += idx - lidx;
-        lidx = idx;
-        while (lslice >= S) {
-            lslice -= S;
-            ++lg;
-        }
-        h.g = lg;
-        h.slice = lslice;
-        // scalar loads by hand: with asm memory clobbers around (the waits), the compiler no longer proves the table unclobbered
-        // and would fetch it with VECTOR loads -- whose vmcnt wait drains every store in flight
-        {
-            const int* pn = img_ptr + h.g;
-            const int* pe = img_ptr + (B + 1 + h.g);
-            u32x2 nn, ee;
-            asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&s"(nn), "=&s"(ee) : "s"(pn), "s"(pe) : "memory");
-            h.n0 = (int)nn.x;
-            h.Nn = (int)nn.y - h.n0;
-            h.e0 = (int)ee.x;
-            h.Ee = (int)ee.y - h.e0;
-        }
-        if (h.Ee > EMAX || h.Nn > NMAX || h.Nn > SL_NMAX) {              // nothing may be staged: outputs poisoned, unit runs empty
-            h.Nn = 0;
-            h.Ee = -1;
-        }
-        return h;
-    };
-    auto col_of = [&](const Hdr& h) { return (long)h.slice * (PIECE / (int)sizeof(T)) + sub * CHL; };   // this lane's first channel
-    // rows [lo, hi) (graph-local) of the unit -> staging buffer `par`: EPW edges per wave-instruction, one full piece per edge
-    auto issue_dma = [&](const Hdr& h, int lo, int hi, int par) {
-        const int nch = (hi - lo + EPW - 1) / EPW;
-        const char* src = reinterpret_cast<const char*>(e + col_of(h));
-        for (int c = wv; c < nch; c += DM_THREADS / 64) {
-            const int el = min(lo + c * EPW + lane / LP, hi - 1);
-            dma16_to_lds(src + (long)(h.e0 + el) * H * (int)sizeof(T), stage_lds + (unsigned)(par * EB * PIECE + c * 1024));
-        }
-    };
-    // prefetch registers: thread t <-> edge t / node t of the NEXT unit.  Values stay raw (offsets are subtracted when they
-    // are parked): arithmetic on a loaded value would make the compiler wait for the load where it was issued.
-    // The single-dword fetches live in 128-bit register tuples: a lone VGPR with a load in flight can end up as the unused
-    // upper half of a broadcast operand pair of v_pk_fma_f32 (op_sel_hi = 0), and the compiler then waits for that load --
-    // vmcnt(0), DMA included -- in the middle of a phase.
-    //
-    // These loads are issued from inline asm as well, for the sake of the WAIT at the top of a batch: vmcnt counts loads and
-    // stores in issue order, and between the fetches and the wait a wave issues its e_in stores.  `s_waitcnt vmcnt(0)` would
-    // drain those stores too (clock stamps: 3.5k cycles per batch top, a fifth of the kernel); `s_waitcnt vmcnt(k)` with k =
-    // the number of store instructions this wave issued since its last load returns as soon as the loads have landed.  The
-    // compiler cannot emit that wait (it sees stores in loops) and, if it knew of the loads, would add waits of its own -- so it
-    // does not know of them.  Consequence: nothing may read these registers between the asm load and the asm wait; they are
-    // read-write operands of the loads ("+v"), so the loop-carried variable and the load destination are one register.
-    f32x4 p_de = {0, 0, 0, 0}, p_nd = {0, 0, 0, 0};
-    u32x4 p_v = {0, 0, 0, 0};
-    u32x2 p_so = {0, 0};                                     // (subject, object) of edge t, global ids
-    unsigned p_in = 0, p_ip = 0, p_op = 0;                   // in-list entry t; in-list / out-list offset of node t
-    // (addresses are 32-bit byte offsets from the scalar table pointers: per-lane 64-bit pointers, which the compiler would
-    // keep across the loop, cost 14 VGPRs -- and spills whose reloads are vector-memory operations with waits of their own)
-    auto issue_small = [&](const Hdr& h) {
-        if (tid < h.Ee) {
-            const unsigned et = (unsigned)(h.e0 + tid);
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(p_de) : "v"(et * 16u), "s"(edots) : "memory");
-            asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(p_so) : "v"(et * 8u), "s"(so) : "memory");
-            asm volatile("global_load_dword %0, %1, %2" : "+v"(p_in) : "v"(et * 4u), "s"(in_ids) : "memory");
-        }
-        if (tid <= h.Nn) {
-            asm volatile("global_load_dword %0, %1, %2" : "+v"(p_ip) : "v"((unsigned)(h.n0 + tid) * 4u), "s"(in_ptr) : "memory");
-            asm volatile("global_load_dword %0, %1, %2" : "+v"(p_op) : "v"((unsigned)(2 * (B + 1) + h.g * (SL_NMAX + 2) + tid) * 4u), "s"(img_ptr) : "memory");
-        }
-        if (tid < h.Nn) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(p_nd) : "v"((unsigned)(h.n0 + tid) * 16u), "s"(ndots) : "memory");
-        if (EIN && grp < h.Nn)
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(p_v) : "v"((unsigned)(((long)(h.n0 + grp) * H + col_of(h)) * (long)sizeof(T))), "s"(v) : "memory");
-    };
-    // wait until at most k vector-memory operations of this wave are outstanding, k = min(stores issued since the last load, 15)
-    auto wait_loads = [&](int nst) {
-        switch (min(nst, 15)) {
-#define SGG_W(K) case K: asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory"); break;
-            SGG_W(0) SGG_W(1) SGG_W(2) SGG_W(3) SGG_W(4) SGG_W(5) SGG_W(6) SGG_W(7) SGG_W(8) SGG_W(9) SGG_W(10) SGG_W(11) SGG_W(12)
-            SGG_W(13) SGG_W(14)
-#undef SGG_W
-            default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-        }
-    };
-    auto park_small = [&](const Hdr& h) {
-        if (tid < h.Ee) {
-            onl8[tid] = (unsigned char)((int)p_so.y - h.n0);
-            in_loc[tid] = (unsigned short)((int)p_in - h.e0);
-        }
-        if (tid <= h.Nn) {
-            iptr[tid] = (int)p_ip - h.e0;
-            optr[tid] = (int)p_op;
-        }
-        if (tid < h.Nn) *reinterpret_cast<f32x4*>(nd + tid * 4) = p_nd;
-        if (EIN && grp < h.Nn) {                           // unpacked once per unit: phase 1 reads a vertex piece per EDGE
-            Piece16<T> pv;
-            pv.r = __builtin_bit_cast(decltype(pv.r), p_v);
-            float f[CHL];
-            pv.get(f);
-            float* dst = reinterpret_cast<float*>(vs + grp * VSB) + sub * CHL;
-#pragma unroll
-            for (int j = 0; j < CHL; j += 4) *reinterpret_cast<f32x4*>(dst + j) = f32x4{f[j], f[j + 1], f[j + 2], f[j + 3]};
-        }
-    };
-    // thread t: the four gates of edge t (rel_model_stanford.py:78-89), from its dots (registers) and the parked vertex dots
-    auto make_gates = [&](const Hdr& h) {
-        if (tid < h.Ee) {
-            const int sl = (int)p_so.x - h.n0, ol = (int)p_so.y - h.n0;
-            const f32x4 ns = *reinterpret_cast<const f32x4*>(nd + sl * 4), no = *reinterpret_cast<const f32x4*>(nd + ol * 4);
-            f32x4 gt;
-            gt.x = sigmoidf_(ns.x + p_de.x + b0);            // sub_vert (v[s])
-            gt.y = sigmoidf_(no.y + p_de.y + b1);            // obj_vert (v[o])
-            gt.z = sigmoidf_(ns.z + p_de.z + b2);            // out_edge (v[s])
-            gt.w = sigmoidf_(no.w + p_de.w + b3);            // in_edge  (v[o])
-            *reinterpret_cast<f32x4*>(gates + 4 * tid) = gt;
-        }
-    };
-    auto poison = [&](const Hdr& h) {                        // re-reads the raw offsets: the header was emptied
-        const int g = h.g;
-        const long col = col_of(h);
-        u32x2 nn, ee;
-        asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(nn), "=&s"(ee) : "s"(img_ptr + g), "s"(img_ptr + (B + 1 + g)) : "memory");
-        const int n0 = (int)nn.x, Nn = (int)nn.y - n0, e0 = (int)ee.x, Ee = (int)ee.y - e0;
-        float nanv[CHL];
-#pragma unroll
-        for (int j = 0; j < CHL; ++j) nanv[j] = __builtin_nanf("");
-        if (EIN)
-            for (int k = grp; k < Ee; k += GROUPS) Piece16<T>::store(e_in + (long)(e0 + k) * H + col, nanv);
-        for (int k = grp; k < Nn; k += GROUPS) {
-            Piece16<T>::store(ctx2 + (long)(n0 + k) * H + col, nanv);
-            if (!sum_ctx) Piece16<T>::store(ctx2 + ((long)N + n0 + k) * H + col, nanv);
-        }
-    };
-
-    // ---- prologue: header (scalar) -> DMA + per-thread fetches (one vector level) of the first unit, exposed once
-    int idx = w, par = 0;
-    Hdr hc = load_hdr(idx), hn = hc;                         // (headers are loaded in increasing unit order)
-    issue_dma(hc, 0, min(EB, hc.Ee), 0);
-    issue_small(hc);
-    if (idx + wx < cnt) hn = load_hdr(idx + wx);
-    int unit_no = 0, nst = 0;                                // nst: store instructions this wave issued since its last load
-    (void)unit_no;
-    char* const e_in_c = reinterpret_cast<char*>(e_in);
-    const unsigned rowb = (unsigned)H * (unsigned)sizeof(T);
-
-    for (;;) {
-        const bool more = idx + wx < cnt;                                // uniform
-        SGG_DTICK(0)
-        wait_loads(nst);                                                 // this unit's first batch and small fetches have landed
-        nst = 0;
-        __syncthreads();                                                 // (A) every wave has left the last unit: its small arrays are free
-        park_small(hc);
-        if (hc.Ee < 0) poison(hc);
-        __syncthreads();                                                 // (B) vertex dots parked
-        make_gates(hc);
-        __syncthreads();                                                 // (C) gates, lists, vertex pieces and the first batch visible to all waves
-        // ---- lane groups per node (powers of two, inside one wave).  Phase 2 (in-lists: every node has entries in every batch)
-        // deals ALL nodes to the lane groups for the whole unit; phase 1 (out-lists: a batch holds the out-lists of ITS nodes
-        // only) deals the batch's nodes to all lane groups, batch by batch -- otherwise half the waves would idle in every batch.
-        int P2 = 1, lgP2 = 0;
-        while (2 * P2 * LP <= 64 && 2 * P2 * hc.Nn <= GROUPS) {
-            P2 *= 2;
-            ++lgP2;
-        }
-        const int part2 = grp & (P2 - 1), n2 = grp >> lgP2;
-        const bool has2 = n2 < hc.Nn;
-        const long col = col_of(hc);
-        float acc_i[CHL];
-#pragma unroll
-        for (int j = 0; j < CHL; ++j) acc_i[j] = 0.f;
-        int ib = 0, mine_i = 0, ki = 0;                                  // my entries of the in-list: ib + k P2, k < mine_i
-        if (has2) {
-            ib = iptr[n2] + part2;
-            mine_i = (iptr[n2 + 1] - ib + P2 - 1) >> lgP2;
-        }
-        const unsigned eoff0 = (unsigned)hc.e0 * rowb + (unsigned)col * (unsigned)sizeof(T);
-        const int Ee = max(hc.Ee, 0);
-        bool first_batch = true;
-        // batches are node-aligned: nodes [nlo, nhi), edges [optr[nlo], optr[nhi]) <= EB (a node has < 64 out-edges <= EB).
-        // The first batch of a unit was fetched before its lists were known: edges [0, min(EB, Ee)), a superset of its node range.
-        int nlo = 0;
-        for (;;) {
-            int nhi = nlo;
-            const int blo = __builtin_amdgcn_readfirstlane(optr[nlo]);
-            int bhi = blo;
-            while (nhi < hc.Nn) {
-                const int nx = __builtin_amdgcn_readfirstlane(optr[nhi + 1]);
-                if (nx - blo > EB) break;
-                bhi = nx;
-                ++nhi;
-            }
-            const bool last = nhi >= hc.Nn;
-            if (last) bhi = Ee;                                          // (edges past the last node's list do not exist; keeps the cursors simple)
-            SGG_DTICK(1)
-            if (!first_batch) {
-                wait_loads(nst);                                         // this batch's DMA (my part of it)
-                nst = 0;
-                __syncthreads();                                         // (D) batch visible; every wave has left the last batch
-            }
-            // the other staging buffer is free: next batch of this unit, or the first batch of the next unit
-            if (SGG_DMA_ABL != 3) {
-                if (!last) {
-                    int mhi = nhi;
-                    int ehi = bhi;
-                    while (mhi < hc.Nn) {
-                        const int nx = __builtin_amdgcn_readfirstlane(optr[mhi + 1]);
-                        if (nx - bhi > EB) break;
-                        ehi = nx;
-                        ++mhi;
-                    }
-                    if (mhi >= hc.Nn) ehi = Ee;
-                    issue_dma(hc, bhi, ehi, par ^ 1);
-                } else if (more) {
-                    issue_dma(hn, 0, min(EB, hn.Ee), par ^ 1);
-                }
-            }
-            SGG_DTICK(2)
-            if (first_batch && more) issue_small(hn);                    // consumed after the next unit's top wait
-            first_batch = false;
-            SGG_DTICK(3)
-            const int soff = (par * EB - blo) * PIECE + sub * 16;         // this lane's 16 bytes of graph-local edge el: stage0 + soff + el * PIECE
-            // ---- phase 1: the out-lists of nodes [nlo, nhi), all lane groups
-            auto phase1 = [&]() {
-                const int nb = nhi - nlo;
-                int P1 = 1, lgP1 = 0;
-                while (2 * P1 * LP <= 64 && 2 * P1 * nb <= GROUPS) {
-                    P1 *= 2;
-                    ++lgP1;
-                }
-                const int part1 = grp & (P1 - 1), n1 = nlo + (grp >> lgP1);
-                if (n1 < nhi) {
-                    float vn[CHL], acc_o[CHL];
-#pragma unroll
-                    for (int j = 0; j < CHL; ++j) vn[j] = acc_o[j] = 0.f;
-                    if constexpr (EIN) {
-                        const float* src = reinterpret_cast<const float*>(vs + n1 * VSB) + sub * CHL;
-#pragma unroll
-                        for (int j = 0; j < CHL; j += 4) {
-                            const f32x4 t = *reinterpret_cast<const f32x4*>(src + j);
-                            vn[j] = t.x; vn[j + 1] = t.y; vn[j + 2] = t.z; vn[j + 3] = t.w;
-                        }
-                    }
-                    const int ob = optr[n1] + part1;                     // my entries: ob + k P1, k < mine_o
-                    const int mine_o = (optr[n1 + 1] - ob + P1 - 1) >> lgP1;
-                    for (int kb = 0;; kb += U) {
-                        if (__builtin_amdgcn_ballot_w64(kb < mine_o) == 0) break;   // wave-uniform
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const bool live = kb + u < mine_o;
-                            if (__builtin_amdgcn_ballot_w64(live) == 0) break;      // wave-uniform
-                            if (EIN) ++nst;                  // one e_in store instruction per wave and step (uniform count)
-                            if (live) {
-                                const int el = ob + ((kb + u) << lgP1);
-#if SGG_DMA_ABL == 1                             // experiment: the access pattern alone (staged piece in, piece out)
-                                *reinterpret_cast<u32x4*>(e_in_c + (eoff0 + (unsigned)el * rowb)) = *reinterpret_cast<const u32x4*>(stage0 + (soff + el * PIECE));
-                                continue;
-#endif
-                                Piece16<T> rowp;
-                                rowp.r = *reinterpret_cast<const decltype(rowp.r)*>(stage0 + (soff + el * PIECE));
-                                float xx[CHL];
-                                rowp.get(xx);
-                                if constexpr (EIN) {
-                                    const f32x4 gt = *reinterpret_cast<const f32x4*>(gates + el * 4);
-                                    const int o = onl8[el];
-                                    float yy[CHL], rr[CHL];
-                                    const float* vo = reinterpret_cast<const float*>(vs + o * VSB) + sub * CHL;
-#pragma unroll
-                                    for (int j = 0; j < CHL; j += 4) {
-                                        const f32x4 t = *reinterpret_cast<const f32x4*>(vo + j);
-                                        yy[j] = t.x; yy[j + 1] = t.y; yy[j + 2] = t.z; yy[j + 3] = t.w;
-                                    }
-#pragma unroll
-                                    for (int j = 0; j < CHL; ++j) {
-                                        rr[j] = gt.x * vn[j] + gt.y * yy[j];
-                                        acc_o[j] = fmaf(gt.z, xx[j], acc_o[j]);
-                                    }
-                                    if (SGG_DMA_ABL != 2) Piece16<T>::store(reinterpret_cast<T*>(e_in_c + (eoff0 + (unsigned)el * rowb)), rr);
-                                } else {                     // ctx only: e_in is made by imp_edge_in_kernel, which never reads the edge rows
-                                    const float gz = gates[el * 4 + 2];
-#pragma unroll
-                                    for (int j = 0; j < CHL; ++j) acc_o[j] = fmaf(gz, xx[j], acc_o[j]);
-                                }
-                            }
-                        }
-                    }
-                    // a node's out-list lies inside its batch: ctx_out is complete
-                    for (int off = LP; off < P1 * LP; off <<= 1) {
-#pragma unroll
-                        for (int j = 0; j < CHL; ++j) acc_o[j] += __shfl_xor(acc_o[j], off, 64);
-                    }
-                    if (part1 == 0) {
-                        if (sum_ctx) {                                   // meets ctx_in at the end of the unit (other lanes own it there)
-                            float* dst = reinterpret_cast<float*>(osum + n1 * VSB) + sub * CHL;
-#pragma unroll
-                            for (int j = 0; j < CHL; j += 4) *reinterpret_cast<f32x4*>(dst + j) = f32x4{acc_o[j], acc_o[j + 1], acc_o[j + 2], acc_o[j + 3]};
-                        } else {
-                            Piece16<T>::store(ctx2 + (long)(hc.n0 + n1) * H + col, acc_o);
-                        }
-                    }
-                }
-            };
-            // ---- phase 2: my in-list entries inside this batch (in-lists ascend in edge id: a cursor), from the staged pieces
-            auto phase2 = [&]() {
-            if (has2 && SGG_DMA_ABL != 1) {
-                constexpr int U2 = 2;
-                for (;;) {
-                    int el[U2];
-                    bool lv[U2];
-#pragma unroll
-                    for (int u = 0; u < U2; ++u) {
-                        el[u] = in_loc[ib + (min(ki + u, max(mine_i - 1, 0)) << lgP2)];
-                        lv[u] = ki + u < mine_i && el[u] < bhi;
-                    }
-                    // (entries ascend: once one is outside the batch, so are the later ones)
-                    if (__builtin_amdgcn_ballot_w64(lv[0]) == 0) break;
-                    int done = 0;
-#pragma unroll
-                    for (int u = 0; u < U2; ++u) {
-                        if (lv[u]) {
-                            const float g3 = gates[el[u] * 4 + 3];
-                            Piece16<T> rw;
-                            rw.r = *reinterpret_cast<const decltype(rw.r)*>(stage0 + (soff + el[u] * PIECE));
-                            float xx[CHL];
-                            rw.get(xx);
-#pragma unroll
-                            for (int j = 0; j < CHL; ++j) acc_i[j] = fmaf(g3, xx[j], acc_i[j]);
-                            ++done;
-                        }
-                    }
-                    ki += done;
-                    if (__builtin_amdgcn_ballot_w64(done == U2) == 0) break;
-                }
-            }
-            };
-            // the two phases are independent.  Half the waves of every SIMD run them in the other order: phase 1 issues the stores
-            // (and stalls on the memory pipe), phase 2 is LDS + VALU only -- in lockstep, all 16 waves queued on the store path at once
-            if ((wv >> 2) & 1) {
-                phase2();
-                SGG_DTICK(4)
-                phase1();
-            } else {
-                phase1();
-                SGG_DTICK(4)
-                phase2();
-            }
-            SGG_DTICK(5)
-            par ^= 1;
-            ++unit_no;                                                   // (stamps are per batch)
-            if (last) break;
-            nlo = nhi;
-        }
-        // ---- unit done: the P2 partial in-sums of a node meet, one store per node
-        if (has2) {
-            for (int off = LP; off < P2 * LP; off <<= 1) {
-#pragma unroll
-                for (int j = 0; j < CHL; ++j) acc_i[j] += __shfl_xor(acc_i[j], off, 64);
-            }
-            if (part2 == 0) {
-                if (sum_ctx) {
-                    // osum[n2] was written by other lanes before barrier (D) of a later batch or -- last batch -- in this very
-                    // phase: make it visible first (below)
-                } else {
-                    Piece16<T>::store(ctx2 + ((long)N + hc.n0 + n2) * H + col, acc_i);
-                }
-            }
-        }
-        if (sum_ctx) {
-            __syncthreads();                                             // (E) every ctx_out piece of the unit is in osum
-            if (has2 && part2 == 0) {
-                const float* src = reinterpret_cast<const float*>(osum + n2 * VSB) + sub * CHL;
-#pragma unroll
-                for (int j = 0; j < CHL; j += 4) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(src + j);
-                    acc_i[j] += t.x; acc_i[j + 1] += t.y; acc_i[j + 2] += t.z; acc_i[j + 3] += t.w;
-                }
-                Piece16<T>::store(ctx2 + (long)(hc.n0 + n2) * H + col, acc_i);
-            }
-        }
-        if (!more) break;
-        idx += wx;
-        hc = hn;
-        if (idx + wx < cnt) hn = load_hdr(idx + wx);                     // scalar loads, one unit ahead
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // The node half of the step on its own (imp_ctx_kernel): ctx_out[n] = sum over n's out-edges of g_out e, ctx_in[n] = sum over its
-// in-edges of g_in e -- a READ stream (every edge row once) with two small outputs.  Same unit as imp_dma_kernel -- (graph, PIECE-byte
-// slice of the rows), the slice's pieces staged in LDS so that the in-lists can walk them -- but
+// in-edges of g_in e -- a READ stream (every edge row once) with two small outputs.  The unit is (graph, PIECE-byte slice of the
+// rows), the slice's pieces staged in LDS so that the in-lists can walk them:
 //  * the staging is a RING of NBUF buffers of EB consecutive edges and the DMA runs NBUF-1 chunks ahead of the compute, ACROSS unit
-//    boundaries (a chunk is an edge range: its extent follows from the graph header alone).  imp_dma_kernel kept one batch in
-//    flight and issued the next only after the barrier that followed the landing of the last;
+//    boundaries (a chunk is an edge range: its extent follows from the graph header alone);
 //  * NOTHING a load returns lives in a register across other code: the per-unit small arrays (the two gates of every edge --
 //    made by the write stream, imp_edge_in_kernel -- the in-list entries, the list offsets) go global -> LDS by DMA as well, into
-//    one of two sets, one unit ahead.  imp_dma_kernel fetches them with asm loads into registers that the compiler believes
-//    defined at issue; under register pressure it may copy such a register before the data lands (seen here: wrong sums and
-//    memory faults that came and went with unrelated code changes);
+//    one of two sets, one unit ahead.  (Asm loads into registers that the compiler believes defined at issue are only safe while
+//    the register allocator never copies such a register before the data lands; under pressure it does -- seen here as wrong
+//    sums and memory faults that came and went with unrelated code changes.);
 //  * out-lists: a chunk's rows belong to few nodes (8 of 32 on a complete 32-node graph), so ALL lane groups share those nodes
 //    (Pc parts per node), the parts meet in the wave and one lane group per node and chunk adds to the node's running sum in
 //    LDS; in-lists: a lane group owns (node, part) for the whole unit and walks its entries with a cursor (ascending edge ids).
@@ -2060,26 +1611,6 @@ int launch_stream(const void* v, const void* e, const int* so, const int* in_ptr
     return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
 }
 
-// LDS-DMA form: one resident 16-wave workgroup per CU, two staging buffers (imp_dma_kernel)
-template <typename T, int LP, bool EIN>
-int launch_dma(const void* v, const void* e, const int* so, const int* in_ptr, const int* in_ids, const int* img_ptr, int B, int N,
-               int H, const float* ndots, const float* edots, const float* gb, void* e_in, void* ctx2, int emax, int nmax, int eb,
-               int sum_ctx, int max_wgs, hipStream_t s) {
-    auto k = imp_dma_kernel<T, LP, EIN>;
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS_MAX) != hipSuccess)
-            return SGG_ERR_LAUNCH;
-        configured = true;
-    }
-    const int piece = LP * 16, vsb = 64 * LP / (int)sizeof(T);
-    const int units = B * (H * (int)sizeof(T) / piece);
-    int grid = min(units, 256);
-    if (max_wgs > 0) grid = min(grid, max_wgs);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(DM_THREADS), 2 * eb * piece + dma_fixed_bytes(emax, nmax, vsb, sum_ctx != 0), s, (const T*)v, (const T*)e,
-                       so, in_ptr, in_ids, img_ptr, B, N, H, ndots, edots, gb, (T*)e_in, (T*)ctx2, emax, nmax, eb, sum_ctx);
-    return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
-}
 }  // namespace
 
 #ifdef SGG_DMA_TICKS
@@ -2094,43 +1625,6 @@ extern "C" int sgg_graph_ptr(const int64_t* im_inds, int N, int B, const int* ou
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
-
-namespace {
-// LDS-DMA kernel, with e_in (one kernel for the whole step) or without (the read stream of the split step).  Returns 1 when the
-// graphs do not fit it (above one edge per thread, rows not a multiple of 64 bytes, e_in beyond 32-bit byte offsets).
-int dma_dispatch(const void* v, const void* e, const int* so, const int* in_ptr, const int* in_ids, const int* img_ptr,
-                 int B, int N, int E, int H, const float* node_dots, const float* edge_dots, const float* gate_b, void* e_in, void* ctx2,
-                 int max_edges, int max_nodes, int sum_ctx, int dtype, int max_wgs, hipStream_t s) {
-    const int tsz = dtype == SGG_BF16 ? 2 : 4;
-    const int row = H * tsz;
-    if (row % 64 || max_nodes > DM_NMAX || max_edges > DM_EMAX || (long)E * row >= 0xffff0000L) return 1;
-    const int emax = (max(max_edges, 16) + 15) & ~15, nmax = (max(max_nodes, 8) + 7) & ~7;
-    // 128-byte pieces (full cache lines: 5.3 TB/s against 3.3 for half lines) when that still gives every CU a unit;
-    // SGG_IMP_PIECE=64|128 overrides (experiments, tests)
-    const char* pc = getenv("SGG_IMP_PIECE");
-    int piece = (row % 128 == 0 && (long)B * (row / 128) >= 256) ? 128 : 64;
-    if (pc && atoi(pc) == 64) piece = 64;
-    if (pc && atoi(pc) == 128 && row % 128 == 0) piece = 128;
-    const char* ebs = getenv("SGG_IMP_EB");     // tests: small batches (several per unit on small graphs)
-    for (; piece >= 64; piece -= 64) {
-        int eb = dma_batch_edges(emax, nmax, 4 * piece / tsz, piece, sum_ctx != 0);
-        if (eb < 64) continue;                  // a batch holds whole out-lists (< 64 edges each)
-        if (ebs && atoi(ebs) >= 64) eb = min(eb, atoi(ebs) & ~15);
-#define SGG_DMA(T, LPV)                                                                                                      \
-    return launch_dma<T, LPV, true>(v, e, so, in_ptr, in_ids, img_ptr, B, N, H, node_dots, edge_dots, gate_b, e_in, ctx2, emax, nmax, \
-                                    eb, sum_ctx, max_wgs, s)
-        if (dtype == SGG_BF16) {
-            if (piece == 128) SGG_DMA(bf16_t, 8);
-            SGG_DMA(bf16_t, 4);
-        } else {
-            if (piece == 128) SGG_DMA(float, 8);
-            SGG_DMA(float, 4);
-        }
-#undef SGG_DMA
-    }
-    return 1;
-}
-}  // namespace
 
 namespace {
 template <typename T, int LP>
@@ -2152,7 +1646,7 @@ int launch_ctx(const void* e, const float* gates_oi, const int* in_ptr, const in
     return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
 }
 
-// the ring-buffered read stream; 1 when the graphs do not fit it (as dma_dispatch)
+// the ring-buffered read stream; 1 when the graphs do not fit it (above one edge per thread, rows not a multiple of 64 bytes)
 int ctx_dispatch(const void* e, const float* gates_oi, const int* in_ptr, const int* in_ids, const int* img_ptr, int B, int N, int E, int H,
                  void* ctx2, int max_edges, int max_nodes, int sum_ctx, int dtype, int max_wgs, hipStream_t s) {
     const int tsz = dtype == SGG_BF16 ? 2 : 4;
@@ -2246,17 +1740,11 @@ extern "C" int sgg_imp_sliced_fwd(const void* v, const void* e, const int* so, c
             lp = f;
     }
     // Default: the short-lived form (one workgroup per unit, two per CU) -- still the fastest measured (DESIGN.md "IMP step").
-    // SGG_IMP_STREAM=d: the persistent LDS-DMA kernel doing both halves (128-byte pieces, batches, gates once per unit); =1: the register-prefetch persistent form.
-    // Kept as measured experiments and as cross-checks of each other (tests/test_kernels_gpu.py).
+    // SGG_IMP_STREAM=1: the register-prefetch persistent form, kept as a measured experiment and a cross-check (tests/test_kernels_gpu.py).
     // SGG_IMP_MAX_WGS=n caps the persistent grid (tests: several units per workgroup on small batches).
     const char* st = getenv("SGG_IMP_STREAM");
     const char* mw = getenv("SGG_IMP_MAX_WGS");
     const int max_wgs = mw ? atoi(mw) : 0;
-    if (st && st[0] == 'd') {
-        const int rc = dma_dispatch(v, e, so, in_ptr, in_ids, img_ptr, B, N, E, H, node_dots, edge_dots, gate_b, e_in, ctx2, max_edges,
-                                    max_nodes, sum_ctx, dtype, max_wgs, s);
-        if (rc != 1) return rc;                      // 1: these graphs do not fit the LDS-DMA kernel -> short-lived form below
-    }
     if (st && st[0] == '1') {
 #define SGG_STREAM(T, LPV) \
     return launch_stream<T, LPV>(v, e, so, in_ptr, in_ids, img_ptr, B, N, H, node_dots, edge_dots, gate_b, e_in, ctx2, max_edges, \

@@ -1,6 +1,6 @@
 """IMP sliced-step kernels without the model: random states on complete 32-node graphs, hipGraph-replay timing of each form;
-with a library built with -DSGG_DMA_TICKS (SGG_HIP_LIB=...), prints the per-unit phase stamps of the LDS-DMA kernel.
-    python tools/exp/imp_micro.py [B ...]      env: IMP_FORMS=d,1,0  IMP_DTYPE=bf16|f32"""
+with a library built with -DSGG_DMA_TICKS (SGG_HIP_LIB=...), prints the per-chunk phase stamps of the read stream.
+    python tools/exp/imp_micro.py [B ...]      env: IMP_FORMS=0,s,A,B,par,1  IMP_DTYPE=bf16|f32  IMP_EAGER=1"""
 import ctypes
 import os
 import sys
@@ -15,7 +15,7 @@ dev = 'cuda:0'
 dtype = torch.float32 if os.environ.get('IMP_DTYPE') == 'f32' else torch.bfloat16
 s = 2 if dtype == torch.bfloat16 else 4
 H, n = int(os.environ.get('IMP_H', '512')), 32
-forms = os.environ.get('IMP_FORMS', 'd,0').split(',')
+forms = os.environ.get('IMP_FORMS', '0,s,A,B').split(',')
 Bs = [int(b) for b in sys.argv[1:]] or [8, 128]
 for B in Bs:
     N, E = n * B, n * (n - 1) * B
@@ -79,27 +79,6 @@ for B in Bs:
             torch.cuda.synchronize()
             print('   eager %s: %.2f us per step' % (name, e0.elapsed_time(e1) * 5))
     lib = _lib.load()
-    if hasattr(lib, 'sgg_dbg_dma_ticks') and 'd' in forms:
-        os.environ['SGG_IMP_STREAM'] = 'd'
-        ops.imp_sliced(v, e, csr, nd, ed, gb, e_in, ctx2)
-        torch.cuda.synchronize()
-        buf = np.zeros(8 * 16 * 8, dtype=np.int64)
-        lib.sgg_dbg_dma_ticks.argtypes = [ctypes.c_void_p]
-        assert lib.sgg_dbg_dma_ticks(buf.ctypes.data) == 0
-        t = buf.reshape(8, 16, 8)
-        # stamps per BATCH: 0 unit top (first batch of a unit only), 1 batch top, 2 after wait + barrier(s) + DMA issue, 3 after small-fetch issue,
-        # 4 after phase 1, 5 after phase 2
-        for blk in (0, 3):
-            print(' block %d (wave 0; clock64 ticks per batch)' % blk)
-            prev_end = None
-            for u in range(16):
-                r = t[blk, u]
-                if r[5] == 0:
-                    break
-                gap = (r[1] - prev_end) if prev_end is not None else 0
-                print('   batch %2d: since-last-batch-end %6d | wait+bar+dma-issue %6d  small-issue %5d  phase1 %6d  phase2 %6d   | batch total %6d' %
-                      (u, gap, r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4], r[5] - r[1]))
-                prev_end = r[5]
     if hasattr(lib, 'sgg_dbg_dma_ticks') and 'B' in forms:
         ops.imp_ctx(e, csr, N, gates, ctx2=ctx2)
         torch.cuda.synchronize()

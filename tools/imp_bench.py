@@ -1,6 +1,6 @@
-"""IMP step kernels at B = 8 / 32 / 128 images of 32 boxes: us per launch and algorithmic GB/s for the persistent LDS-DMA kernel
-(what the forward runs), the register-prefetch persistent kernel, the short-lived one-workgroup-per-unit kernel and the node-centric
-kernel.  IMP_B=8,128 selects batch sizes; IMP_FORMS=d,1,0,fused selects forms."""
+"""IMP step kernels at B = 8 / 32 / 128 images of 32 boxes: us per launch and algorithmic GB/s for the short-lived
+one-workgroup-per-unit kernel (what the forward runs), the split step (write stream + LDS-DMA read stream), the register-prefetch
+persistent kernel and the node-centric kernel.  IMP_B=8,128 selects batch sizes; IMP_FORMS=0,s,1,fused selects forms."""
 import os
 import sys
 
@@ -12,8 +12,8 @@ import sgg_amd  # noqa: E402
 from sgg_amd.synthetic import SyntheticData, init_weights  # noqa: E402
 
 model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls')).to('cuda:0').eval()
-names = {'d': 'dma', '1': 'stream', '0': 'short', 'fused': 'node-centric'}
-forms = os.environ.get('IMP_FORMS', '0,d,1,fused').split(',')
+names = {'s': 'split', '1': 'stream', '0': 'short', 'fused': 'node-centric'}
+forms = os.environ.get('IMP_FORMS', '0,s,1,fused').split(',')
 for dtype, s in ((torch.bfloat16, 2), (torch.float32, 4)):
     model.set_compute_dtype(dtype)
     for B in [int(b) for b in os.environ.get('IMP_B', '8,32,128').split(',')]:
