@@ -6,6 +6,8 @@
     all-reduce(SUM) of the 247.75 M gradients over RCCL   # sgg_amd/dist.py
     global-norm clip (5.0) + SGD(momentum 0.9, wd 1e-4, LR/10 for roi_fmap*)   # fused HIP kernels, no host sync
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -137,7 +139,7 @@ class Trainer(object):
         self.fused_loss = True          # step(): loss + logit gradients by sgg_ce_fwd_bwd where it applies (tests flip it to compare)
         self._norm_cache = {}
         if pipeline:
-            self.opt.max_blocks = 256      # leave wave slots for the VGG forward running beside the update
+            self.opt.max_blocks = int(os.environ.get('SGG_OPT_BLOCKS', '256'))   # leave wave slots for the VGG forward running beside the update
         self._queued = False
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         # force_dist: run the distributed code path on a 1-rank group too (tests exercise RCCL plumbing on one GPU)
