@@ -482,8 +482,11 @@ def main():
                                    ('train step: fwd + losses + bwd + grad all-reduce + clip + SGD' if args.mode == 'train'
                                     else 'eval forward incl. eval tail'),
                        'mode': args.mode, 'images_per_gpu': B, 'global_batch': world * B,
-                       'parallelism': 'image-sharded dp%d, %s' % (world, 'RCCL gradient all-reduce (bf16 on the wire)'
-                                                                  if args.mode == 'train' else 'no collective'),
+                       'parallelism': 'image-sharded dp%d, %s' % (
+                           world, 'no collective' if args.mode != 'train' else
+                           ('RCCL, bf16 on the wire: fc6 / fc7 gradients reduce-scattered, clip + SGD on 1/%d of their fp32 masters per rank, '
+                            'updated bf16 operands all-gathered; the other tensors all-reduced' % world)
+                           if (trainer is not None and trainer.shard_optimizer) else 'RCCL gradient all-reduce (bf16 on the wire)'),
                        'weights': 'random init (He), frozen VGG16 + trainable IMP head (247.75 M params)',
                        'pipeline': 'optimiser update of step k runs on a side stream under the frozen VGG forward of step k+1 (every update inside the timed region)'},
             'roofline': {'kernel': '256x256 ping-pong MFMA kernel (+ the 128x128 split-K launch that replaces a nearly empty last round), %s' % desc, 'bound': 'mfma', 'achieved': round(tf, 2), 'peak': peak,

@@ -61,24 +61,50 @@ class GradBuckets(object):
     the links (the sum is still applied to fp32 master gradients).  All collectives are issued asynchronously and
     waited for together."""
 
-    def __init__(self, params, big_bytes=8 << 20, comm_dtype=None, force=False):
+    def __init__(self, params, big_bytes=8 << 20, comm_dtype=None, force=False, shard=False):
         self.params = [p for p in params if p.requires_grad]
         self.comm_dtype = comm_dtype
         self.big = [p for p in self.params if p.numel() * p.element_size() >= big_bytes]
         self.small = [p for p in self.params if p.numel() * p.element_size() < big_bytes]
         self.force = force    # also run on a 1-rank group (tests)
-        self._early = {}      # param -> (wire buffer, work handle): all-reduces launched from inside the backward
+        self._early = {}      # param -> (wire buffer, work handle): collectives launched from inside the backward
+        self._keepalive = []
+        # shard=True: the big tensors are REDUCE-SCATTERED instead of all-reduced -- rank r receives the summed gradient of its
+        # contiguous 1/world of every big tensor only, the optimiser updates that part of the fp32 master / momentum, and the
+        # updated compute-dtype operand is all-gathered (FusedSGD.step).  Same bytes on the links as the all-reduce (a ring
+        # all-reduce IS a reduce-scatter + an all-gather), 1/world of the optimiser's HBM traffic per rank.
+        self.shard = shard
 
     def is_big(self, p):
         return any(p is q for q in self.big)
 
+    def shard_of(self, p):
+        """(lo, hi) element range of `p` (flattened) this rank owns, or None when `p` is not sharded."""
+        if not self.shard or not self.is_big(p) or not (dist.is_available() and dist.is_initialized()):
+            return None
+        world, rank = dist.get_world_size(), dist.get_rank()
+        n = p.numel()
+        if world == 1 or n % (world * 8):          # equal parts whose starts stay 16-byte aligned in every dtype used
+            return None
+        return rank * (n // world), (rank + 1) * (n // world)
+
+    def _reduce(self, p, buf):
+        """-> (tensor the optimiser will read, work handle)"""
+        rng = self.shard_of(p)
+        if rng is None:
+            return buf, dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+        out = torch.empty(rng[1] - rng[0], dtype=buf.dtype, device=buf.device)
+        work = dist.reduce_scatter_tensor(out, buf.reshape(-1), op=dist.ReduceOp.SUM, async_op=True)
+        self._keepalive.append(buf)                # the input must outlive the collective
+        return out, work
+
     def start(self, p, grad):
-        """Launch the all-reduce of one big gradient as soon as the backward has produced it (overlaps the rest of the
-        backward); `all_reduce` later waits for it instead of issuing it."""
+        """Launch the all-reduce (reduce-scatter when sharded) of one big gradient as soon as the backward has produced it
+        (overlaps the rest of the backward); `all_reduce` later waits for it instead of issuing it."""
         if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not self.force):
             return
         buf = grad.to(self.comm_dtype) if (self.comm_dtype is not None and self.comm_dtype != grad.dtype) else grad
-        self._early[p] = (buf, dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+        self._early[p] = self._reduce(p, buf.contiguous())
 
     def all_reduce(self, average=True):
         """average=True: p.grad of every parameter holds the mean gradient afterwards (returns {}).
@@ -88,6 +114,8 @@ class GradBuckets(object):
         if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not self.force):
             return {}
         world = dist.get_world_size()
+        if average and self.shard:
+            raise ValueError('GradBuckets: average=True writes whole gradients back into p.grad; a sharded reduction leaves parts')
         direct = {}
         works, bufs = [], []
         for p in self.big:
@@ -102,8 +130,9 @@ class GradBuckets(object):
                 p.grad = torch.zeros_like(p)
             g = p.grad
             buf = g.to(self.comm_dtype) if (self.comm_dtype is not None and self.comm_dtype != g.dtype) else g
+            buf, work = self._reduce(p, buf.contiguous())
             bufs.append((p, buf))
-            works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+            works.append(work)
         # small tensors: one flat fp32 bucket, every slot padded to 4 elements so that views into it stay 16-byte aligned
         pieces, offs, off = [], [], 0
         for p in self.small:
@@ -119,6 +148,7 @@ class GradBuckets(object):
             works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
         for w in works:
             w.wait()
+        self._keepalive = []
         for p, buf in bufs:
             if buf is not p.grad:
                 if average:

@@ -55,7 +55,8 @@ class RelModelStanford(RelModelBase):
         w['fc6_obj'] = self._shadow_cast('roi_fmap_obj.0.weight', self.roi_fmap_obj[0].weight)
         w6e = f(self.roi_fmap[1][0].weight)
         w['fc6_edge'] = self._shadow_cast('roi_fmap.1.0.weight', w6e)   # [4096, 25088], K order (c,ph,pw) as in the reference
-        w['fc6_edge_sum'] = ops.group_sum(w6e, C, PP, dtype)       # [4096, 512]
+        gs = getattr(self, '_sharded_group_sum', None)             # a trainer with a sharded optimiser: sums of this rank's rows, gathered
+        w['fc6_edge_sum'] = (gs or ops.group_sum)(w6e, C, PP, dtype)    # [4096, 512]
         for name, pname, mod in (('fc7_obj', 'roi_fmap_obj.3', self.roi_fmap_obj[3]),
                                  ('fc7_edge', 'roi_fmap.1.3', self.roi_fmap[1][3]),
                                  ('obj_unary', 'obj_unary', self.obj_unary), ('edge_unary', 'edge_unary', self.edge_unary),

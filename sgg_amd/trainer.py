@@ -34,6 +34,9 @@ class FusedSGD(torch.optim.Optimizer):
         self.clip = clip
         self.steps = 0
         self._norm = None
+        self._norm_parts = None
+        self.stale_masters = {}    # sharded data-parallel steps: {param: (lo, hi)} whose fp32 master is current only in [lo, hi)
+        self.momentum_parts = {}   # ... and whose momentum buffer is
         self.on_update = None
         self.max_blocks = 0        # workgroups of the update kernel (0: library default); the pipelined trainer lowers it
         self.shadow_of = None      # callable -> {param name: compute-dtype buffer the update should also write}
@@ -45,9 +48,14 @@ class FusedSGD(torch.optim.Optimizer):
                 yield p
 
     @torch.no_grad()
-    def step(self, grad_scale=1.0, grads=None, closure=None):
+    def step(self, grad_scale=1.0, grads=None, closure=None, shards=None):
         """grads (optional): {param: tensor} overriding p.grad -- e.g. the bf16 buffers an all-reduce left behind, consumed
-        directly (fp32 or bf16) instead of being copied back into fp32 .grad tensors."""
+        directly (fp32 or bf16) instead of being copied back into fp32 .grad tensors.
+        shards (optional, data-parallel): {param: (lo, hi)} -- grads[param] is the reduce-scattered gradient of elements
+        [lo, hi) of the flattened parameter only (GradBuckets(shard=True)).  This rank updates that part of the fp32 master and
+        of the momentum buffer; the squared norms of the parts are summed over the ranks for the clip; the updated operand (the
+        bf16 shadow when there is one, else the fp32 parameter itself) is all-gathered in place.  The fp32 master outside
+        [lo, hi) is then STALE on this rank until gather_masters()."""
         import numpy as np
         stream = ops._stream()
         dev = next(self.params()).device
@@ -55,6 +63,7 @@ class FusedSGD(torch.optim.Optimizer):
             self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._norm.zero_()
         grads = grads or {}
+        shards = {p: r for p, r in (shards or {}).items() if r is not None}
         live = []                                               # (param, gradient, lr)
         mom, wd = None, None
         for g in self.param_groups:
@@ -79,26 +88,48 @@ class FusedSGD(torch.optim.Optimizer):
                 st['momentum_buffer'] = torch.empty_like(p, dtype=torch.float32) if first else torch.zeros_like(p, dtype=torch.float32)
         shadows = self.shadow_of() if self.shadow_of is not None else {}
         norm = self._norm.data_ptr() if self.clip and self.clip > 0 else None
+        for p, gr, _ in live:
+            if p in shards and gr.numel() != shards[p][1] - shards[p][0]:
+                raise ValueError('FusedSGD: the gradient of a sharded parameter must be its [lo, hi) part')
+        if shards and norm is not None and self._norm_parts is None:
+            self._norm_parts = torch.zeros(1, dtype=torch.float32, device=dev)
         pending = []
-        for dtype in (torch.float32, torch.bfloat16):          # gradients arrive fp32 (local) or bf16 (off the wire)
-            sel = [t for t in live if t[1].dtype == dtype]
-            if not sel:
-                continue
-            arr = lambda vals: np.ascontiguousarray(np.array(vals, dtype=np.uint64))
-            gp = arr([gr.data_ptr() for _, gr, _ in sel])
-            pp = arr([p.data_ptr() for p, _, _ in sel])
-            bp = arr([self.state[p]['momentum_buffer'].data_ptr() for p, _, _ in sel])
-            sh = [shadows.get(self.name_of.get(p)) for p, _, _ in sel]
-            sp = arr([t.data_ptr() if t is not None else 0 for t in sh])
-            nn = np.ascontiguousarray(np.array([gr.numel() for _, gr, _ in sel], dtype=np.int64))
-            lr = np.ascontiguousarray(np.array([l for _, _, l in sel], dtype=np.float32))
-            if norm is not None:
-                _lib.call('sgg_sqnorm_multi', gp.ctypes.data, nn.ctypes.data, len(sel), norm, ops.dt(sel[0][1]), stream)
-            pending.append((dtype, gp, pp, bp, sp, nn, lr, len(sel), sel))
+        for part in (False, True):                              # whole tensors first, then this rank's parts of the sharded ones
+            for dtype in (torch.float32, torch.bfloat16):      # gradients arrive fp32 (local) or bf16 (off the wire)
+                sel = [t for t in live if t[1].dtype == dtype and (t[0] in shards) == part]
+                if not sel:
+                    continue
+                arr = lambda vals: np.ascontiguousarray(np.array(vals, dtype=np.uint64))
+                lo = [shards[p][0] if part else 0 for p, _, _ in sel]
+                gp = arr([gr.data_ptr() for _, gr, _ in sel])
+                pp = arr([p.data_ptr() + 4 * o for (p, _, _), o in zip(sel, lo)])
+                bp = arr([self.state[p]['momentum_buffer'].data_ptr() + 4 * o for (p, _, _), o in zip(sel, lo)])
+                sh = [shadows.get(self.name_of.get(p)) for p, _, _ in sel]
+                sp = arr([t.data_ptr() + t.element_size() * o if t is not None else 0 for t, o in zip(sh, lo)])
+                nn = np.ascontiguousarray(np.array([gr.numel() for _, gr, _ in sel], dtype=np.int64))
+                lr = np.ascontiguousarray(np.array([l for _, _, l in sel], dtype=np.float32))
+                if norm is not None:
+                    acc = self._norm_parts.data_ptr() if part else norm
+                    _lib.call('sgg_sqnorm_multi', gp.ctypes.data, nn.ctypes.data, len(sel), acc, ops.dt(sel[0][1]), stream)
+                pending.append((dtype, gp, pp, bp, sp, nn, lr, len(sel), sel))
+        if shards and norm is not None:                         # the parts' squared norms of all ranks join the replicated ones
+            import torch.distributed as dist
+            dist.all_reduce(self._norm_parts, op=dist.ReduceOp.SUM)
+            self._norm.add_(self._norm_parts)
+            self._norm_parts.zero_()
         for dtype, gp, pp, bp, sp, nn, lr, cnt, _keep in pending:  # every norm contribution lands before the first update
             _lib.call('sgg_sgd_multi', pp.ctypes.data, gp.ctypes.data, bp.ctypes.data, sp.ctypes.data, nn.ctypes.data,
                       lr.ctypes.data, cnt, float(wd), float(mom), int(first), norm,
                       float(self.clip or 0.0), float(grad_scale), ops.dt(dtype), int(self.max_blocks), stream)
+        if shards:                                              # every rank gets every part of the updated operands
+            import torch.distributed as dist
+            for p, _, _ in live:
+                if p in shards:
+                    sh = shadows.get(self.name_of.get(p))
+                    full = (sh if sh is not None else p.data).view(-1)
+                    dist.all_gather_into_tensor(full, full[shards[p][0]:shards[p][1]])
+            self.stale_masters = {p: shards[p] for p, _, _ in live if p in shards and shadows.get(self.name_of.get(p)) is not None}
+            self.momentum_parts = {p: shards[p] for p, _, _ in live if p in shards}
         names = set(self.name_of.get(p) for p, _, _ in live)
         self.wrote_shadow = [n for n in shadows if n in names]
         self.steps += 1
@@ -113,12 +144,32 @@ class FusedSGD(torch.optim.Optimizer):
     def grad_norm(self):
         return float(self._norm.sqrt().item())
 
+    @torch.no_grad()
+    def gather_masters(self, momentum=True):
+        """After sharded steps: all-gather the fp32 masters (and momentum buffers) whose other parts went stale on this rank,
+        so that checkpoints, fp32-mode forwards and `state_dict()` see whole tensors again.  A collective: every rank calls it."""
+        import torch.distributed as dist
+        for p, (lo, hi) in self.stale_masters.items():
+            flat = p.data.view(-1)
+            dist.all_gather_into_tensor(flat, flat[lo:hi])
+        if momentum:
+            for p, (lo, hi) in self.momentum_parts.items():
+                buf = self.state[p].get('momentum_buffer')
+                if buf is not None:
+                    flat = buf.view(-1)
+                    dist.all_gather_into_tensor(flat, flat[lo:hi])
+            self.momentum_parts = {}
+        if self.stale_masters:
+            torch.autograd.graph.increment_version(list(self.stale_masters))
+        self.stale_masters = {}
+
 
 class Trainer(object):
     """One data-parallel train step.  `loss_type` as lib/losses.py ('baseline' is the reference default, config.py:184)."""
 
     def __init__(self, model, lr=1e-3, momentum=0.9, weight_decay=1e-4, clip=5.0, loss_type='baseline',
-                 comm_dtype=torch.bfloat16, force_dist=False, sync_bn=True, pipeline=False, loss_weights=(1, 1, 1)):
+                 comm_dtype=torch.bfloat16, force_dist=False, sync_bn=True, pipeline=False, loss_weights=(1, 1, 1),
+                 shard_optimizer=None):
         self.model = model
         for n, p in model.named_parameters():
             if n.startswith('detector.'):
@@ -128,7 +179,17 @@ class Trainer(object):
         self.opt.on_update = self._bump
         if hasattr(model, 'shadow_buffers'):
             self.opt.shadow_of = model.shadow_buffers
-        self.buckets = GradBuckets([p for _, p in named], comm_dtype=comm_dtype, force=force_dist)
+        # shard_optimizer (default: on when there is more than one rank; SGG_SHARD_OPT=0 turns it off): the four tensors that are
+        # 97 % of the parameters (fc6 x2, fc7 x2) are reduce-scattered, each rank runs clip + SGD on its 1/world of their fp32
+        # masters and momenta, and the updated compute-dtype operands are all-gathered -- the bytes of the all-reduce on the
+        # links, 1/world of the 5 GB optimiser pass per rank.  fp32 masters are whole again after flush().
+        n_ranks = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if shard_optimizer is None:
+            shard_optimizer = n_ranks > 1 and os.environ.get('SGG_SHARD_OPT', '1') != '0'
+        self.shard_optimizer = bool(shard_optimizer) and n_ranks > 1
+        self.buckets = GradBuckets([p for _, p in named], comm_dtype=comm_dtype, force=force_dist, shard=self.shard_optimizer)
+        if self.shard_optimizer:
+            model._sharded_group_sum = self._group_sum_of_parts
         self.loss_type = loss_type
         self.loss_weights = tuple(float(x) for x in loss_weights)      # (alpha, beta, gamma) of lib/losses.py:37 = conf.alpha/beta/gamma
         # pipeline=True: the optimiser update of step k (HBM-bound, ~1.1 ms) and the rebuild of the weight-derived operands
@@ -183,13 +244,37 @@ class Trainer(object):
         def cm():
             m = self.model
             saved = (getattr(m, '_grad_ready_hook', None), getattr(m, '_bn_sync', None), self.world, self.dist_on)
-            m._grad_ready_hook = m._bn_sync = None
+            saved_sh = (getattr(m, '_sharded_group_sum', None), self.opt.stale_masters, self.opt.momentum_parts)
+            m._grad_ready_hook = m._bn_sync = m._sharded_group_sum = None
             self.world, self.dist_on = 1, False
+            # (with a sharded optimiser the fp32 masters this rank does not own are stale in here: fine for timing, not for results)
+            self.opt.stale_masters, self.opt.momentum_parts = {}, {}
             try:
                 yield self
             finally:
                 m._grad_ready_hook, m._bn_sync, self.world, self.dist_on = saved
+                m._sharded_group_sum, self.opt.stale_masters, self.opt.momentum_parts = saved_sh
         return cm()
+
+    def _group_sum_of_parts(self, w6e, C, PP, dtype):
+        """W6sum (model.prepared()) when this rank's fp32 master of fc6 is current only in its own rows: every rank sums its rows,
+        the [rows, C] results are all-gathered -- the numbers of the whole-tensor sum.  A collective: prepared() runs at the same
+        points of the step on every rank."""
+        p = dict(self.model.named_parameters()).get('roi_fmap.1.0.weight')
+        rng = self.opt.stale_masters.get(p) if p is not None else None
+        if rng is None:
+            return ops.group_sum(w6e, C, PP, dtype)
+        rows, K = w6e.shape
+        lo, hi = rng
+        if lo % K or hi % K:
+            raise ValueError('sharded optimiser: the parts of fc6 must be whole rows (world size must divide %d)' % rows)
+        part = ops.group_sum(w6e[lo // K:hi // K], C, PP, dtype)
+        full = torch.empty((rows, part.shape[1]), dtype=part.dtype, device=part.device)
+        dist.all_gather_into_tensor(full.view(-1), part.reshape(-1))
+        return full
+
+    def _shards(self, reduced):
+        return {p: self.buckets.shard_of(p) for p in reduced} if self.shard_optimizer else None
 
     def _bump(self):
         self.model.weights_version = getattr(self.model, 'weights_version', 0) + 1
@@ -281,10 +366,13 @@ class Trainer(object):
         self.model._operands_ready = ev
 
     def flush(self):
-        """Make the current stream wait for a queued optimiser update (pipeline mode) before parameters are read."""
+        """Make the current stream wait for a queued optimiser update (pipeline mode) before parameters are read; with a sharded
+        optimiser also gather the fp32 masters and momentum buffers (a collective: every rank calls flush())."""
         ev = getattr(self.model, '_operands_ready', None)
         if ev is not None:
             torch.cuda.current_stream(next(self.model.parameters()).device).wait_event(ev)
+        if self.dist_on and (self.opt.stale_masters or self.opt.momentum_parts):
+            self.opt.gather_masters()
 
     def _queue_update(self):
         """pipeline mode: wait for the gradient all-reduce, optimiser step and operand rebuild, all on the side stream
@@ -305,7 +393,7 @@ class Trainer(object):
             reduced = self.buckets.all_reduce(average=False) if self.dist_on else dict(self._local)
             for t in (reduced or {}).values():
                 t.record_stream(side)
-            self.opt.step(grads=reduced)
+            self.opt.step(grads=reduced, shards=self._shards(reduced) if self.dist_on else None)
             train_weights(self.model)
             ev = torch.cuda.Event()
             ev.record(side)
@@ -341,6 +429,6 @@ class Trainer(object):
         self._queued = self.pipeline and self._queue_update()
         if not self._queued:
             reduced = self.buckets.all_reduce(average=False) if self.dist_on else dict(self._local)
-            self.opt.step(grads=reduced)
+            self.opt.step(grads=reduced, shards=self._shards(reduced) if self.dist_on else None)
         self.model.global_batch_iter = getattr(self.model, 'global_batch_iter', 0) + 1
         return loss.detach()

@@ -41,6 +41,27 @@ def _worker(rank, world, port, q):
     summed = [(direct[p] if p in direct else p.grad).float() for p in lin.parameters()]
     ok = len(direct) == 4 and all(torch.allclose(s, a * 2, atol=1e-6) for s, a in zip(summed, avg))
     ok = ok and all(t.data_ptr() % 16 == 0 for t in direct.values())     # bucket views stay 16-byte aligned (3-element bias)
+    # sharded form: the big tensor (Linear(8,16).weight: 128 elements) is reduce-scattered -- each rank gets the summed gradient
+    # of ITS half only, early-started or not; the small ones still arrive whole; a tensor that does not split evenly is all-reduced
+    for early in (True, False):
+        for p, g in zip(lin.parameters(), local):
+            p.grad = g.clone()
+        gs = D.GradBuckets(lin.parameters(), big_bytes=256, shard=True)
+        ok = ok and gs.shard_of(first) == (64 * r, 64 * (r + 1)) and all(gs.shard_of(p) is None for p in list(lin.parameters())[1:])
+        if early:
+            gs.start(first, first.grad)
+        part = gs.all_reduce(average=False)
+        ok = ok and part[first].shape == (64,) and torch.allclose(part[first], (avg[0] * 2).reshape(-1)[64 * r:64 * (r + 1)], atol=1e-6)
+        ok = ok and all(torch.allclose(part[p].float(), a * 2, atol=1e-6) for p, a in list(zip(lin.parameters(), avg))[1:])
+    odd = torch.nn.Parameter(torch.ones(100))                              # 100 elements do not split into 2 x (multiple of 8)
+    odd.grad = torch.full((100,), float(r + 1))
+    go = D.GradBuckets([odd], big_bytes=256, shard=True)
+    ok = ok and go.shard_of(odd) is None and torch.allclose(go.all_reduce(average=False).get(odd, odd.grad), torch.full((100,), 3.0))
+    try:
+        gs.all_reduce(average=True)
+        ok = False
+    except ValueError:
+        pass
     q.put((r, (lo, hi), mx, tot, [g.tolist() for g in local], [g.tolist() for g in avg], ok))
     dist.barrier()
     dist.destroy_process_group()

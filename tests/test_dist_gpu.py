@@ -60,7 +60,11 @@ def _worker(rank, world, port, cfg, q):
     cut = 1 if rank == 0 else 4                    # rank 0: image 0 (7 boxes, 42 edges); rank 1: images 1..3 (4+2+2 boxes)
     mine = shard_batch(g, 0 if rank == 0 else 1, cut)
     losses, w, rm, tr = _one_step(dtype, comm, mine, steps, opts)
-    assert tr.dist_on and tr.world == 2
+    assert tr.dist_on and tr.world == 2 and tr.shard_optimizer == opts.get('shard_optimizer', True)
+    if tr.shard_optimizer:                         # fc6 x2, fc7 x2 (and the two 8 MiB unary weights) went through reduce-scatter: this rank updated its half
+        big = [p for p in tr.buckets.big]
+        assert len(big) >= 4 and all(tr.buckets.shard_of(p) == (rank * p.numel() // 2, (rank + 1) * p.numel() // 2) for p in big)
+        assert not tr.opt.stale_masters and not tr.opt.momentum_parts          # flush() gathered masters and momenta
     q.put((rank, losses, w, rm))
     dist.barrier()
     dist.destroy_process_group()
@@ -70,7 +74,11 @@ def _worker(rank, world, port, cfg, q):
     (torch.float32, None, 1, dict(sync_bn=True)),                      # exact-fp32: pins the DP LOGIC against the concatenated batch
     (torch.bfloat16, torch.bfloat16, 1, dict(sync_bn=True)),           # the benchmark's form: bf16 compute, bf16 on the wire
     (torch.bfloat16, torch.bfloat16, 3, dict(sync_bn=True, pipeline=True)),   # + the update queued on the side stream
-], ids=['f32', 'bf16_wire', 'bf16_wire_pipelined'])
+    # the three above run the SHARDED optimiser (the default for more than one rank: reduce-scatter, SGD on this rank's half of
+    # fc6 / fc7, all-gather of the updated operands, masters gathered by flush()); the plain all-reduce form:
+    (torch.float32, None, 1, dict(sync_bn=True, shard_optimizer=False)),
+    (torch.bfloat16, torch.bfloat16, 3, dict(sync_bn=True, pipeline=True, shard_optimizer=False)),
+], ids=['f32', 'bf16_wire', 'bf16_wire_pipelined', 'f32_allreduce', 'bf16_wire_pipelined_allreduce'])
 def test_world_size_2_step_equals_single_process_on_concatenated_batch(cfg):
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
@@ -81,14 +89,25 @@ def test_world_size_2_step_equals_single_process_on_concatenated_batch(cfg):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, cfg, q)) for r in range(2)]
     for p in procs:
         p.start()
+    import queue
+    import time
     got = {}
-    for _ in procs:
-        r, losses, w, rm = q.get(timeout=600)
-        got[r] = (losses, w, rm)
+    t0 = time.time()
+    while len(got) < len(procs):
+        try:
+            r, losses, w, rm = q.get(timeout=5)
+            got[r] = (losses, w, rm)
+        except queue.Empty:                        # a rank that died will never answer: fail now, not after the full timeout
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > 600:
+                for p in procs:
+                    p.kill()
+                pytest.fail('a rank exited with %s (or the step timed out)' % dead)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    ref_losses, ref_w, ref_rm, _ = _one_step(dtype, comm, _global_batch(), steps, {k: v for k, v in opts.items() if k != 'sync_bn'})
+    ref_losses, ref_w, ref_rm, _ = _one_step(dtype, comm, _global_batch(), steps,
+                                            {k: v for k, v in opts.items() if k not in ('sync_bn', 'shard_optimizer')})
     import sgg_amd
     from sgg_amd.synthetic import SyntheticData, init_weights
     w0 = {n: p.detach().float().numpy() for n, p in
