@@ -84,8 +84,8 @@ class GradBuckets(object):
             return None
         world, rank = dist.get_world_size(), dist.get_rank()
         n = p.numel()
-        if world == 1 or n % (world * 8):          # equal parts whose starts stay 16-byte aligned in every dtype used
-            return None
+        if (world == 1 and not self.force) or n % (world * 8):   # equal parts whose starts stay 16-byte aligned in every dtype used
+            return None                            # (force: a 1-rank group still goes through the collectives -- tests)
         return rank * (n // world), (rank + 1) * (n // world)
 
     def _reduce(self, p, buf):

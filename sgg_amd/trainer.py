@@ -186,7 +186,7 @@ class Trainer(object):
         n_ranks = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         if shard_optimizer is None:
             shard_optimizer = n_ranks > 1 and os.environ.get('SGG_SHARD_OPT', '1') != '0'
-        self.shard_optimizer = bool(shard_optimizer) and n_ranks > 1
+        self.shard_optimizer = bool(shard_optimizer) and (n_ranks > 1 or (force_dist and dist.is_available() and dist.is_initialized()))
         self.buckets = GradBuckets([p for _, p in named], comm_dtype=comm_dtype, force=force_dist, shard=self.shard_optimizer)
         if self.shard_optimizer:
             model._sharded_group_sum = self._group_sum_of_parts

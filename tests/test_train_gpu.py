@@ -275,7 +275,8 @@ def test_trainer_step_updates_weights_and_refreshes_operands(env):
 def test_trainer_distributed_path_on_one_rank_matches_local(env):
     """The DP code path (hooks from inside the backward, bf16 wire buffers written by the GEMMs, RCCL all-reduce, the
     optimiser consuming the wire buffers) on a 1-rank RCCL group must reproduce the local step up to bf16 rounding of
-    the big gradients."""
+    the big gradients -- in the all-reduce form and in the sharded form (RCCL reduce-scatter, update of this rank's part,
+    in-place RCCL all-gather of the bf16 operands, masters gathered by flush())."""
     import os
     import torch.distributed as dist
     from sgg_amd.trainer import Trainer
@@ -290,28 +291,38 @@ def test_trainer_distributed_path_on_one_rank_matches_local(env):
         names = ['roi_fmap.1.0.weight', 'roi_fmap_obj.0.weight', 'roi_fmap.1.3.weight', 'rel_fc.weight',
                  'edge_gru.weight_ih', 'union_boxes.conv.0.weight']
         out = {}
-        for mode in ('local', 'dist'):
+        for mode in ('local', 'dist', 'dist_sharded'):
             model.load_state_dict(sd)
-            tr = Trainer(model, lr=2e-2, force_dist=(mode == 'dist'))
-            assert tr.dist_on == (mode == 'dist')
+            tr = Trainer(model, lr=2e-2, force_dist=(mode != 'local'), shard_optimizer=(mode == 'dist_sharded'))
+            assert tr.dist_on == (mode != 'local') and tr.shard_optimizer == (mode == 'dist_sharded')
             loss = float(tr.step(tuple(batch)))
             params = dict(model.named_parameters())
+            if mode == 'dist_sharded':
+                big = params['roi_fmap.1.0.weight']
+                assert tr.buckets.shard_of(big) == (0, big.numel()) and tr.opt.momentum_parts
+                w = model.prepared()                    # the gathered shadow is the cast of the updated master
+                assert torch.equal(w['fc6_edge'], big.detach().to(torch.bfloat16))
+            tr.flush()
+            assert not tr.opt.stale_masters and not tr.opt.momentum_parts
             out[mode] = (loss, {n: params[n].detach().float().cpu().clone() for n in names})
-            if mode == 'dist':
+            if mode != 'local':
                 hooked = ('roi_fmap.1.0.weight', 'roi_fmap_obj.0.weight', 'roi_fmap.1.3.weight', 'roi_fmap_obj.3.weight')
                 assert all(tr.buckets.is_big(params[n]) for n in hooked)
                 assert all(params[n].grad is None for n in hooked)   # handed over in bf16, never materialised in fp32
-        assert abs(out['local'][0] - out['dist'][0]) < 1e-5
+        assert abs(out['local'][0] - out['dist'][0]) < 1e-5 and abs(out['local'][0] - out['dist_sharded'][0]) < 1e-5
         for n in names:
             w0 = sd[n].float()
             step = (out['local'][1][n] - w0).abs().max()
             diff = (out['local'][1][n] - out['dist'][1][n]).abs().max()
             assert step > 0 and diff <= 2e-2 * step + 1e-9, (n, float(step), float(diff))
+            # one rank: the part IS the tensor; only the order in which the squared norms meet (atomics, two accumulators) differs
+            assert (out['dist'][1][n] - out['dist_sharded'][1][n]).abs().max() <= 1e-4 * step, n
     finally:
         dist.destroy_process_group()
         model._grad_ready_hook = None
         model._grad_wire_dtype = None
         model._bn_sync = None
+        model._sharded_group_sum = None
         model.dropout_p = 0.5
         model.eval()
 
