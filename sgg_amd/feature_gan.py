@@ -1,0 +1,352 @@
+"""The GAN feature-augmentation model of BASELINE config 5 behind the reference's interface: `GAN`
+(augment/gan.py:17-259: constructor arguments, parameter names -- the reference's `state_dict()` loads by name -- `forward`,
+`loss`, `loss_fn`), `dummy_nodes` (augment/gan.py:262-289), `RefinementNetwork` / `RefinementModule` (augment/crn.py:64-142).
+
+What runs where.  The generator's data movement is this package's HIP code: the scene-graph convolutions gather / pool through
+`triple_gather` / `triple_pool`, and the per-object 7x7 patches are resampled onto the 38x38 canvas and summed per image by the
+one-launch `boxes_to_layout` kernel (sgg_amd/gan_ops.py, csrc/gan.hip), each with its adjoint, so the whole model trains.  The small
+dense layers around them -- the Linear layers of the graph convolutions, the 3x3 / 1x1 convolutions on 7x7 patches, the cascaded
+refinement network on the 38x38 canvas, the three spectral-norm discriminators -- are plain library layers (torch.nn on ROCm:
+MIOpen / hipBLASLt), as the reference runs them through cuDNN: they are dense library shapes with no gather in them, and
+nothing on the SGCls hot path depends on them.  `features.hdf5` (the `vis_cond` file of real per-class 512x7x7 features) is read
+by sgg_amd/hdf5_lite.py.
+
+Not carried: the GloVe tables (`lib/word_vectors.py`; `embed_objs` is only used by the scene-graph perturbations of
+augment/sg_perturb.py, and `init_embed` "led to worse results" and is off in the reference): pass `embed_objs=` / `embed_rels=`
+tensors if you have them, otherwise the attributes stay None and `init_embed=True` raises.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn import functional as F
+from torch.nn.functional import binary_cross_entropy_with_logits as BCE
+from torch.nn.utils import spectral_norm
+
+from .gan_ops import GraphTripleConvNet, boxes_to_layout
+
+
+# ------------------------------------------------------------------------------------------------ augment/crn.py
+def get_normalization_2d(channels, normalization):
+    """augment/crn.py:38-46"""
+    if normalization == 'instance':
+        return nn.InstanceNorm2d(channels)
+    if normalization == 'batch':
+        return nn.BatchNorm2d(channels)
+    if normalization == 'none':
+        return None
+    raise ValueError('Unrecognized normalization type "%s"' % normalization)
+
+
+def get_activation(name):
+    """augment/crn.py:49-62: 'relu', 'leakyrelu', 'leakyrelu-<slope>' -- and, as there, EVERY name ends up a LeakyReLU (the
+    reference overwrites `name` before the lookup); the slope defaults to torch's 0.01."""
+    kwargs = {}
+    if name.lower().startswith('leakyrelu') and '-' in name:
+        kwargs = {'negative_slope': float(name.split('-')[1])}
+    return nn.LeakyReLU(**kwargs)
+
+
+class RefinementModule(nn.Module):
+    """augment/crn.py:64-94: conv3x3 -> norm -> act -> conv3x3 -> norm -> act on [layout pooled to the feature size | features]."""
+
+    def __init__(self, layout_dim, input_dim, output_dim, normalization='instance', activation='leakyrelu'):
+        super(RefinementModule, self).__init__()
+        layers = [nn.Conv2d(layout_dim + input_dim, output_dim, kernel_size=3, padding=1),
+                  get_normalization_2d(output_dim, normalization), get_activation(activation),
+                  nn.Conv2d(output_dim, output_dim, kernel_size=3, padding=1),
+                  get_normalization_2d(output_dim, normalization), get_activation(activation)]
+        layers = [layer for layer in layers if layer is not None]
+        for layer in layers:
+            if isinstance(layer, nn.Conv2d):
+                nn.init.kaiming_normal_(layer.weight)
+        self.net = nn.Sequential(*layers)
+
+    def forward(self, layout, feats):
+        HH, H = layout.shape[2], feats.shape[2]
+        assert HH >= H
+        if HH > H:
+            layout = F.adaptive_avg_pool2d(layout, output_size=H)
+        return self.net(torch.cat([layout, feats], dim=1))
+
+
+class RefinementNetwork(nn.Module):
+    """augment/crn.py:97-142: a cascade over len(dims)-1 scales, coarse to fine, the output has the layout's size."""
+
+    def __init__(self, dims, normalization='instance', activation='leakyrelu'):
+        super(RefinementNetwork, self).__init__()
+        layout_dim = dims[0]
+        self.refinement_modules = nn.ModuleList()
+        for i in range(1, len(dims)):
+            self.refinement_modules.append(RefinementModule(layout_dim, 1 if i == 1 else dims[i - 1], dims[i],
+                                                            normalization=normalization, activation=activation))
+        self.output_conv = nn.Sequential(nn.Conv2d(dims[-1], dims[-1], kernel_size=3, padding=1))
+        nn.init.kaiming_normal_(self.output_conv[0].weight)
+
+    def forward(self, layout):
+        N, _, H, W = layout.shape
+        self.layout = layout
+        input_H, input_W = H, W
+        for _ in range(len(self.refinement_modules)):
+            input_H //= 2
+            input_W //= 2
+        assert input_H != 0 and input_W != 0
+        feats = torch.zeros(N, 1, input_H, input_W, dtype=layout.dtype, device=layout.device)
+        last = len(self.refinement_modules) - 1
+        for i, mod in enumerate(self.refinement_modules):
+            # (38 -> 4 -> 8 -> 16 -> 38: the last step goes to the layout's own size, not x2)
+            feats = F.interpolate(feats, size=(H, W), mode='nearest') if i == last else F.interpolate(feats, scale_factor=2, mode='nearest')
+            feats = mod(layout, feats)
+        return self.output_conv(feats)
+
+
+# ------------------------------------------------------------------------------------------------ augment/gan.py
+def dummy_nodes(gt_objs, gt_boxes, gt_rels):
+    """augment/gan.py:262-289: one dummy node (class 0, box [0,0,1,1]) per image, connected both ways to every object of the image
+    with predicate 0; node indices become global over the batch (dummies included).  gt_objs i64[N,2] (image, class), gt_boxes
+    [N,4], gt_rels i64[T,4] (image, subject, object, predicate) with image-LOCAL subject / object indices, both sorted by image.
+    No per-object loop: segment offsets and index arithmetic on the device the inputs live on."""
+    dev = gt_objs.device
+    im_o, im_r = gt_objs[:, 0], gt_rels[:, 0]
+    B = int(im_o.max().item()) + 1 if gt_objs.shape[0] else 0
+    n = torch.bincount(im_o, minlength=B)                                   # objects per image
+    t = torch.bincount(im_r, minlength=B)                                   # relations per image
+    if B == 0 or int((n == 0).sum()) or int((t == 0).sum()) or im_r.shape[0] == 0 or int(im_r.max()) >= B:
+        raise IndexError('dummy_nodes: every image 0..B-1 needs at least one object and one relation (the reference indexes its '
+                         'per-image relation list by image id)')
+    N = gt_objs.shape[0]
+    off = torch.cumsum(n + 1, 0) - (n + 1)                                  # first new node id of every image
+    # nodes: image i's objects, then its dummy
+    new_pos = torch.arange(N, device=dev) + im_o                           # an object moves down by the dummies of earlier images
+    dummy_pos = off + n
+    objs = gt_objs.new_zeros((N + B, 2))
+    objs[new_pos] = gt_objs
+    objs[dummy_pos, 0] = torch.arange(B, device=dev, dtype=gt_objs.dtype)
+    boxes = gt_boxes.new_zeros((N + B, 4))
+    boxes[new_pos] = gt_boxes
+    boxes[dummy_pos] = torch.tensor([0, 0, 1, 1], dtype=gt_boxes.dtype, device=dev)
+    # relations: image i's own (indices + off[i]), then dummy -> object k, then object k -> dummy
+    T = gt_rels.shape[0]
+    r_off = torch.cumsum(t + 2 * n, 0) - (t + 2 * n)                        # first new relation row of every image
+    t_start = torch.cumsum(t, 0) - t
+    rels = gt_rels.new_zeros((T + 2 * N, 4))
+    own = r_off[im_r] + (torch.arange(T, device=dev) - t_start[im_r])
+    rels[own] = gt_rels
+    rels[own, 1] += off[im_r]
+    rels[own, 2] += off[im_r]
+    k = torch.arange(N, device=dev) - (torch.cumsum(n, 0) - n)[im_o]        # local object index
+    out_rows = r_off[im_o] + t[im_o] + k
+    in_rows = out_rows + n[im_o]
+    dummy_of = (off + n)[im_o]
+    rels[out_rows, 0] = im_o
+    rels[out_rows, 1] = dummy_of
+    rels[out_rows, 2] = off[im_o] + k
+    rels[in_rows, 0] = im_o
+    rels[in_rows, 1] = off[im_o] + k
+    rels[in_rows, 2] = dummy_of
+    return objs, boxes, rels
+
+
+class GAN(nn.Module):
+    """augment/gan.py:17-259.  Generator: class / predicate embeddings -> scene-graph convolutions (G_gcn) -> per-object 32x7x7
+    features -> G_node (two 3x3 convs) [-> concatenated with real 512x7x7 features of the same class when `vis_cond` names a
+    features.hdf5] -> G_proj (1x1) -> boxes_to_layout onto the fmap_sz^2 canvas -> cascaded refinement -> ReLU = a fake
+    512 x fmap_sz x fmap_sz detector feature map.  Discriminators: D_nodes / D_edges on class-conditioned 7x7 RoI features,
+    D_global on the feature map."""
+
+    def __init__(self, obj_classes, rel_classes, embed_dim=200, hidden_dim=64, n_ch=512, pool_sz=7, fmap_sz=38,
+                 losses=('D', 'G', 'rec'), SN=True, BN=True, n_layers_G=5, vis_cond=None, init_embed=False, largeD=False,
+                 data_dir='', device='cuda', embed_objs=None, embed_rels=None):
+        super(GAN, self).__init__()
+        self.obj_classes, self.rel_classes = obj_classes, rel_classes
+        self.embed_dim, self.n_ch, self.pool_sz, self.fmap_sz = embed_dim, n_ch, pool_sz, fmap_sz
+        self.obj_dim = pool_sz ** 2 * n_ch
+        self.losses, self.SN, self.BN, self.vis_cond, self.largeD, self.device = losses, SN, BN, vis_cond, largeD, device
+        self.h5_data = None
+        if vis_cond is not None:
+            from .hdf5_lite import File
+            self.h5_data = File(vis_cond)
+
+        self.G_obj_embed = nn.Embedding(len(obj_classes), embed_dim)
+        self.G_rel_embed = nn.Embedding(len(rel_classes), embed_dim)
+
+        # Discriminators as layer tables: (out channels, kernel) per convolution, all without padding; 'A' = LeakyReLU(0.2),
+        # 'R' = ReLU, 'P' / 'Pc' = AvgPool2d(2) / with ceil_mode.  Positions that the reference fills with nn.Identity() when an
+        # option is off keep an Identity here too: the Sequential indices are part of the state_dict keys.
+        def stack(n_in, table):
+            mods = []
+            for item in table:
+                if item is None:
+                    mods.append(nn.Identity())
+                elif item == 'A':
+                    mods.append(nn.LeakyReLU(0.2))
+                elif item == 'R':
+                    mods.append(nn.ReLU())
+                elif item in ('P', 'Pc'):
+                    mods.append(nn.AvgPool2d(2, ceil_mode=item == 'Pc'))
+                else:
+                    n_out, ks = item
+                    c = nn.Conv2d(n_in, n_out, kernel_size=ks, padding=0)
+                    mods.append(spectral_norm(c) if SN else c)
+                    n_in = n_out
+            return nn.Sequential(*(mods + [nn.Flatten()]))
+
+        # RoI features (n_ch + classes) x 7 x 7 -> 5x5 -> 3x3 -> 3x3 -> one logit
+        roi_table = [(n_ch // 2, 3), 'R', (n_ch // 4, 3), 'R', (n_ch // 8, 1), 'R', (1, 3)]
+        self.D_nodes = stack(n_ch + len(obj_classes), roi_table)
+        self.D_edges = stack(n_ch + len(rel_classes), roi_table)
+        # feature map n_ch x 38 x 38 -> 36 -> (pool) 18 -> 16 -> (pool) 8 -> 6 -> (pool) 3 -> one logit; largeD adds a 1x1 layer per scale
+        wide = lambda c: [(c, 1), 'A'] if largeD else [None, None]                                       # noqa: E731
+        self.D_global = stack(n_ch, [(n_ch // 2, 3), 'A'] + wide(n_ch // 2) + ['Pc' if fmap_sz > 24 else None] +
+                              [(n_ch // 2, 3), 'A'] + wide(n_ch // 2) + ['P'] +
+                              [(n_ch // 4, 3), 'A'] + wide(n_ch // 4) + ['P', (1, 3)])
+
+        self.G_gcn = GraphTripleConvNet(input_dim=embed_dim + 4, input_edge_dim=embed_dim,
+                                        output_dim=hidden_dim // 2 * pool_sz * pool_sz, num_layers=n_layers_G,
+                                        hidden_dim=hidden_dim, pooling='avg', mlp_normalization='batch' if BN else 'none')
+        self.G_node = nn.Sequential(nn.Conv2d(hidden_dim // 2, hidden_dim, kernel_size=3, padding=1), nn.ReLU(),
+                                    nn.Conv2d(hidden_dim, hidden_dim, kernel_size=3, padding=1), nn.ReLU())
+        self.G_proj = nn.Conv2d(hidden_dim + int(vis_cond is not None) * n_ch, hidden_dim, kernel_size=1)
+        self.G_refine = RefinementNetwork(dims=(hidden_dim, n_ch // 4, n_ch // 2, n_ch), normalization='batch',
+                                          activation='leakyrelu-0.2')
+
+        norm = lambda e: None if e is None else (e / torch.norm(e, 2, dim=1, keepdim=True)).to(device)   # noqa: E731
+        self.embed_objs, self.embed_rels = norm(embed_objs), norm(embed_rels)
+        if init_embed:
+            if self.embed_objs is None or self.embed_rels is None:
+                raise ValueError('GAN(init_embed=True) needs embed_objs= / embed_rels= (the GloVe tables are not carried)')
+            assert self.G_obj_embed.weight.shape == self.embed_objs.shape and self.G_rel_embed.weight.shape == self.embed_rels.shape
+            self.G_obj_embed.weight.data = self.embed_objs.clone()
+            self.G_rel_embed.weight.data = self.embed_rels.clone()
+
+    # targets of the discriminator losses: made at the size asked for (the reference slices two preallocated 50000-row vectors)
+    def y_real(self, n):
+        return torch.ones((n, 1), device=self.device)
+
+    def y_fake(self, n):
+        return torch.zeros((n, 1), device=self.device)
+
+    def loss_fn(self, predictions, is_fake=True, updateD=False):
+        """augment/gan.py:162-171"""
+        if updateD:
+            return BCE(predictions, self.y_fake(len(predictions)) if is_fake else self.y_real(len(predictions)))
+        assert is_fake
+        return BCE(predictions, self.y_real(len(predictions)))
+
+    def sample_real_features(self, classes):
+        """augment/gan.py:193-199: one random real 512x7x7 feature of each object's class out of features.hdf5 (numpy's global RNG,
+        one `permutation(n)[0]` draw per object, as there)."""
+        feats = []
+        for cls in classes.tolist():
+            assert cls > 0, 'background objects are not expected here'
+            dset = self.h5_data[self.obj_classes[cls]]
+            ind = int(np.random.permutation(dset.shape[0])[0])
+            feats.append(torch.from_numpy(np.asarray(dset[ind])).view(1, self.n_ch, self.pool_sz, self.pool_sz))
+        return torch.cat(feats)
+
+    def forward(self, gt_objects, boxes_scaled, gt_rels):
+        """augment/gan.py:174-208 -> fake feature maps [B, n_ch, fmap_sz, fmap_sz]"""
+        gt_objects, boxes_scaled, gt_rels = dummy_nodes(gt_objects, boxes_scaled, gt_rels)
+        obj_vecs = self.G_obj_embed(gt_objects[:, -1])
+        pred_vecs = self.G_rel_embed(gt_rels[:, -1])
+        obj_fg = torch.nonzero(gt_objects[:, -1]).view(-1)
+        nodes_fake = self.G_gcn(torch.cat((obj_vecs, boxes_scaled), dim=1), pred_vecs, gt_rels[:, 1:3])[0][obj_fg]
+        n_obj = len(obj_fg)
+        gt_objects, boxes = gt_objects[obj_fg], boxes_scaled[obj_fg]
+        assert len(nodes_fake) == len(gt_objects) == len(boxes), (nodes_fake.shape, gt_objects.shape, boxes.shape)
+        nodes_fake = self.G_node(nodes_fake.view(n_obj, -1, self.pool_sz, self.pool_sz))
+        if self.h5_data is not None:
+            vis = self.sample_real_features(gt_objects[:, -1].detach().cpu())
+            nodes_fake = torch.cat((vis.to(nodes_fake), nodes_fake), dim=1)
+        layout = boxes_to_layout(self.G_proj(nodes_fake), boxes, gt_objects[:, 0], self.fmap_sz, self.fmap_sz, pooling='sum')
+        return F.relu(self.G_refine(layout))
+
+    def loss(self, features_real=None, features_fake=None, is_nodes=False, updateD=False, labels_fake=None, labels_real=None,
+             is_fmaps=False):
+        """augment/gan.py:211-259 -> {'D_obj' | 'D_rel' | 'D_fmap' | 'G_obj' | 'G_rel' | 'G_fmap': loss} (or {} when the side is off)"""
+        if updateD and 'D' not in self.losses:
+            return {}
+        if not updateD and 'G' not in self.losses:
+            return {}
+        if not is_fmaps:
+            def conditioned(feats, labels, n_classes):                     # class one-hot planes appended to the 7x7 features
+                n = len(feats)
+                y = torch.zeros(n, n_classes, device=feats.device, dtype=feats.dtype).scatter_(1, labels.view(-1, 1), 1)
+                return y[:, :, None, None].expand(n, -1, self.pool_sz, self.pool_sz)
+            n_classes = len(self.obj_classes if is_nodes else self.rel_classes)
+            n_fake = len(features_fake)
+            y_fill_fake = conditioned(features_fake, labels_fake, n_classes)
+            features_fake = torch.cat([features_fake.view(n_fake, -1, self.pool_sz, self.pool_sz), y_fill_fake], 1)
+            if updateD:
+                n_real = len(features_real)
+                y_fill_real = y_fill_fake.clone() if labels_real is None else conditioned(features_real, labels_real, n_classes)
+                features_real = torch.cat([features_real.view(n_real, -1, self.pool_sz, self.pool_sz), y_fill_real], 1)
+        fn = self.D_global if is_fmaps else (self.D_nodes if is_nodes else self.D_edges)
+        if not updateD:
+            assert labels_real is None and features_real is None, 'do not need real labels/features in case of G update'
+        real_loss = self.loss_fn(fn(features_real.detach()), is_fake=False, updateD=True) if updateD else 0
+        fake_loss = self.loss_fn(fn(features_fake.detach() if updateD else features_fake), is_fake=True, updateD=updateD)
+        key = '_'.join(('D' if updateD else 'G', 'fmap' if is_fmaps else ('obj' if is_nodes else 'rel')))
+        return {key: real_loss + fake_loss}
+
+
+# ------------------------------------------------------------------------------------------------ main.py:124-194
+def gan_train_step(sgg_model, gan, res, gt_boxes, gt_objects, gt_rels, optimizer, G_optimizer, D_optimizer, *, ganw=1.0,
+                   attachG=False, ganlosses=('D', 'G', 'rec'), loss_type='baseline', loss_weights=(1, 1, 1), clip=5.0,
+                   gt_objects_fake=None):
+    """The GAN part of one training iteration -- what main.py:124-194 does after the SGG model's own update, with the same calls in
+    the same order: generate feature maps from the (perturbed) scene graph, extract node / edge features from them with the SGG
+    model's RoIAlign (differentiable into the maps: sgg_roi_align_bwd), classify them with the SGG head, update G (adversarial +
+    reconstruction losses; the SGG model too when 'rec' is on), then update D on real vs generated features.
+    `res` is the Result of the SGG model's training forward on the same batch.  -> {loss name: value} as main.py logs them.
+    gt_objects_fake: the perturbed objects (augment/sg_perturb.py, not carried); default = the real ones (`-perturb` off)."""
+    from .trainer import Trainer
+    gan.train()
+    if gt_objects_fake is None:
+        gt_objects_fake = gt_objects.clone()
+    fmaps = gan(gt_objects_fake, sgg_model.get_scaled_boxes(gt_boxes, res.im_inds, res.im_sizes_org), gt_rels)
+    nodes_fake, edges_fake = sgg_model.node_edge_features(fmaps, res.rois, res.rel_inds[:, 1:], res.im_sizes)
+    obj_fake, rel_fake = sgg_model.predict(nodes_fake if attachG else nodes_fake.detach(), edges_fake if attachG else edges_fake.detach(),
+                                           res.rel_inds, rois=res.rois, im_sizes=res.im_sizes)
+    # ---- generator (main.py:151-176)
+    optimizer.zero_grad()
+    G_optimizer.zero_grad()
+    losses = {}
+    losses_G = {}
+    losses_G.update(gan.loss(features_fake=nodes_fake, is_nodes=True, labels_fake=gt_objects_fake[:, -1]))
+    losses_G.update(gan.loss(features_fake=edges_fake, labels_fake=res.rel_labels[:, -1]))
+    losses_G.update(gan.loss(features_fake=fmaps, is_fmaps=True))
+    losses_G = {k: ganw * v for k, v in losses_G.items()}
+    if 'rec' in ganlosses:
+        class _R(object):        # the loss code of the trainer takes a Result-shaped object
+            pass
+        r = _R()
+        r.rm_obj_dists, r.rm_obj_labels, r.rel_dists, r.rel_labels = obj_fake, gt_objects_fake[:, -1], rel_fake, res.rel_labels
+        rec = Trainer.losses(_LossCfg(loss_type, loss_weights), r)
+        losses_G['rec'] = rec                                    # node + edge reconstruction losses (main.py:163-170), summed
+    if losses_G:
+        sum(losses_G.values()).backward()
+        if 'rec' in ganlosses:
+            if clip:
+                torch.nn.utils.clip_grad_norm_([p for p in sgg_model.parameters() if p.grad is not None], clip)
+            optimizer.step()
+        G_optimizer.step()
+        losses.update(losses_G)
+    # ---- discriminators (main.py:178-191)
+    D_optimizer.zero_grad()
+    losses_D = {}
+    losses_D.update(gan.loss(res.node_feat, nodes_fake, is_nodes=True, updateD=True, labels_fake=gt_objects_fake[:, -1], labels_real=gt_objects[:, -1]))
+    losses_D.update(gan.loss(res.edge_feat, edges_fake, updateD=True, labels_fake=res.rel_labels[:, -1]))
+    losses_D.update(gan.loss(res.fmap, fmaps, updateD=True, is_fmaps=True))
+    losses_D = {k: ganw * v for k, v in losses_D.items()}
+    if losses_D:
+        sum(losses_D.values()).backward()
+        D_optimizer.step()
+        losses.update(losses_D)
+    return {k: v.detach() for k, v in losses.items()}
+
+
+class _LossCfg(object):
+    """what Trainer.losses reads from `self` (loss form and weights; one process)"""
+
+    def __init__(self, loss_type, loss_weights):
+        self.loss_type, self.loss_weights, self.dist_on, self.world = loss_type, tuple(float(x) for x in loss_weights), False, 1

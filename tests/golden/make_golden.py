@@ -21,6 +21,9 @@ reference's source text is stored -- only data.  What is called, per file:
   vg_loader.npz    dataloaders/visual_genome.py:516 load_graphs (h5py.File replaced by an in-memory mapping with the VG-SGG.h5 keys),
                    :662 load_info, :743 filter_dups, :377 VG.__getitem__ box / size arithmetic (synthetic PIL images),
                    dataloaders/image_transforms.py:8 SquarePad
+  gan_model.npz    augment/gan.py:17 GAN (reduced widths, seeded weights; GloVe loader replaced by random vectors): dummy_nodes :262,
+                   forward :174 (train-mode BatchNorm), loss :211 for the six D / G cases in a fixed order (spectral-norm power
+                   iterations advance per call), gradients of the G_fmap loss wrt three generator parameters
   freq_bias.npz    lib/get_dataset_counts.py:10 get_counts, lib/sparse_targets.py:7 FrequencyBias, and the use_bias block
                    sgg_models/rel_model_stanford.py:159-177 (executed on the reference's FrequencyBias module)
 """
@@ -346,6 +349,65 @@ def gold_rel_assign():
         torch.Tensor.cuda = real_cuda
     arrs['cases'] = np.array(cases)
     save('rel_assign', **arrs)
+
+
+def gold_gan_model():
+    import warnings
+    import augment.gan as RG
+    warnings.simplefilter('ignore')
+    obj_classes = ['__background__'] + ['obj%d' % i for i in range(1, 9)]
+    rel_classes = ['__background__'] + ['rel%d' % i for i in range(1, 5)]
+    RG.obj_edge_vectors = lambda names, wv_dir='', wv_dim=300, word_vectors=None, avg_words=False: (torch.randn(len(names), wv_dim), None)
+    torch.manual_seed(123)
+    gan = RG.GAN(obj_classes, rel_classes, embed_dim=12, hidden_dim=16, n_ch=32, pool_sz=7, fmap_sz=38, n_layers_G=3, device='cpu')
+    gan.train()
+    arrs = {'w_' + k: v for k, v in sd(gan).items()}
+    rng = np.random.RandomState(5)
+    n_per = [4, 2, 5]
+    objs, boxes, rels = [], [], []
+    for im, n in enumerate(n_per):
+        objs += [(im, int(c)) for c in rng.randint(1, len(obj_classes), size=n)]
+        xy = rng.uniform(0, 0.55, size=(n, 2)); wh = rng.uniform(0.1, 0.45, size=(n, 2))
+        boxes.append(np.concatenate((xy, np.minimum(xy + wh, 1.0)), 1))
+        t = rng.randint(1, 2 * n)
+        for _ in range(t):
+            s_, o_ = rng.choice(n, 2, replace=False)
+            rels.append((im, int(s_), int(o_), int(rng.randint(1, len(rel_classes)))))
+    gt_objs = torch.tensor(objs, dtype=torch.int64)
+    gt_boxes = torch.from_numpy(np.concatenate(boxes).astype(np.float32))
+    gt_rels = torch.tensor(sorted(rels), dtype=torch.int64)
+    arrs.update(in_objs=gt_objs, in_boxes=gt_boxes, in_rels=gt_rels)
+    d_objs, d_boxes, d_rels = RG.dummy_nodes(gt_objs, gt_boxes, gt_rels)
+    arrs.update(dummy_objs=d_objs, dummy_boxes=d_boxes, dummy_rels=d_rels)
+    fmap = gan(gt_objs, gt_boxes, gt_rels)
+    arrs['fmap_fake'] = fmap
+    g = torch.Generator().manual_seed(6)
+    n_obj, n_rel = len(gt_objs), 9
+    f_real_o, f_fake_o = torch.randn(n_obj, 32 * 49, generator=g), torch.randn(n_obj, 32 * 49, generator=g)
+    f_real_r, f_fake_r = torch.randn(n_rel + 2, 32, 7, 7, generator=g), torch.randn(n_rel, 32, 7, 7, generator=g)
+    lab_o = gt_objs[:, 1].clone()
+    lab_r_fake = torch.from_numpy(rng.randint(0, len(rel_classes), size=n_rel)).long()
+    lab_r_real = torch.from_numpy(rng.randint(0, len(rel_classes), size=n_rel + 2)).long()
+    fmap_real = torch.randn(3, 32, 38, 38, generator=g).relu()
+    arrs.update(f_real_o=f_real_o, f_fake_o=f_fake_o, f_real_r=f_real_r, f_fake_r=f_fake_r, lab_o=lab_o, lab_r_fake=lab_r_fake,
+                lab_r_real=lab_r_real, fmap_real=fmap_real)
+    # fixed order of calls: every call advances the spectral-norm vectors of the discriminator it uses
+    out = {}
+    out.update(gan.loss(f_real_o, f_fake_o, is_nodes=True, updateD=True, labels_fake=lab_o))                       # D_obj (real labels = fake labels)
+    out.update(gan.loss(f_real_r, f_fake_r, is_nodes=False, updateD=True, labels_fake=lab_r_fake, labels_real=lab_r_real))   # D_rel
+    out.update(gan.loss(fmap_real, fmap, updateD=True, is_fmaps=True))                                             # D_fmap
+    out.update(gan.loss(features_fake=f_fake_o, is_nodes=True, labels_fake=lab_o))                                  # G_obj
+    out.update(gan.loss(features_fake=f_fake_r, is_nodes=False, labels_fake=lab_r_fake))                            # G_rel
+    g_fmap = gan.loss(features_fake=fmap, is_fmaps=True)                                                            # G_fmap
+    out.update(g_fmap)
+    for k, v in out.items():
+        arrs['loss_' + k] = v
+    names = ['G_obj_embed.weight', 'G_proj.weight', 'G_refine.refinement_modules.0.net.0.weight', 'G_gcn.gconvs.0.net1.0.weight']
+    params = dict(gan.named_parameters())
+    grads = torch.autograd.grad(g_fmap['G_fmap'], [params[n] for n in names])
+    for n, gr in zip(names, grads):
+        arrs['grad_' + n] = gr
+    save('gan_model', **arrs)
 
 
 def gold_gan_ops():
@@ -776,6 +838,7 @@ if __name__ == '__main__':
     gold_pairs()
     gold_rel_assign()
     gold_gan_ops()
+    gold_gan_model()
     gold_eval_tail()
     gold_losses()
     gold_recall()
