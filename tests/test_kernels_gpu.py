@@ -360,6 +360,30 @@ def test_roi_align_bwd_is_the_adjoint_of_the_forward(ops, dtype):
     torch.testing.assert_close(acc, 2 * gf, rtol=1e-5, atol=1e-5)
 
 
+def test_roi_align_bwd_equals_the_transposed_oracle_operator(ops):
+    """An oracle gradient for sgg_roi_align_bwd that does not come from the HIP forward: RoIAlign is linear in the feature map, so
+    the ORACLE's forward applied to the unit maps gives the operator A column by column (one 6x7 map, [R*49, 42]); the gradient is
+    A^T g.  Node boxes and fused union boxes; boxes that leave the map, a degenerate box, a box over the whole map."""
+    rng = np.random.RandomState(31)
+    H, W, C = 6, 7, 8
+    boxes = np.array([[10, 8, 70, 60], [0, 0, 111, 95], [40, 40, 40, 40], [60, 30, 150, 130], [-20, -10, 30, 50]], np.float32)
+    rois = np.concatenate((np.zeros((len(boxes), 1), np.float32), boxes), 1)
+    pairs = np.array([(0, 1), (1, 0), (2, 3), (4, 0), (3, 4)], np.int64)
+    union = np.concatenate((np.zeros((len(pairs), 1), np.float32), np.minimum(boxes[pairs[:, 0], :2], boxes[pairs[:, 1], :2]),
+                            np.maximum(boxes[pairs[:, 0], 2:], boxes[pairs[:, 1], 2:])), 1)
+    for pr, rr in ((None, rois), (cu(pairs), union)):
+        R = len(rr)
+        A = np.zeros((R * 49, H * W), np.float64)
+        for k in range(H * W):
+            e = np.zeros((1, 1, H, W), np.float32)
+            e.reshape(-1)[k] = 1.0
+            A[:, k] = O.roi_align(e, rr).reshape(-1)
+        g = rng.randn(R, C, 7, 7).astype(np.float32)
+        want = np.einsum('rk,rc->kc', A, g.transpose(0, 2, 3, 1).reshape(R * 49, C).astype(np.float64)).reshape(1, H, W, C)
+        got = ops.roi_align_bwd(cu(torch.from_numpy(g)), (1, H, W, C), cu(rois), pr).double().cpu().numpy()
+        np.testing.assert_allclose(got, want, atol=2e-5 * max(1.0, np.abs(want).max()))
+
+
 def test_raw_boxes_raster_and_rect_feat_vs_reference_golden(ops, golden):
     """edge_model 'raw_boxes' (lib/get_union_boxes.py:69-116): the grid_sample raster, the patches the conv stack reads from it,
     and the module's eval forward, against vectors from the reference module."""
