@@ -194,6 +194,19 @@ int sgg_imp_edge_in_fwd(const void* v, const int* so /*[E,2]*/, const float* nod
                         void* e_in, float* gates_oi /*[E,2] or NULL*/, int E, int H, int dtype, void* stream);
 int sgg_imp_ctx_fwd(const void* e, const float* gates_oi /*[E,2]*/, const int* in_ptr, const int* in_ids, const int* img_ptr, int B, int N,
                     int E, int H, void* ctx2 /*[2,N,H] or [N,H]*/, int max_edges, int max_nodes, int sum_ctx, int dtype, void* stream);
+/* ---- glue of the ResNet-50-FPN feature extractor (GQA configuration: sgg_models/rel_model_base.py:58-81; the convolutions themselves
+ * run on sgg_gemm / sgg_conv3x3_relu).  NHWC, C a multiple of 8 except where noted.
+ * sgg_im2col: patch matrix of a k x k / stride / pad convolution, row = output pixel, columns (ky, kx, c) zero-filled to Kp; src is a
+ *   plane [B, H+2 src_pad, W+2 src_pad, Ca] of which the first C channels are used (any C; f32 -> bf16 conversion allowed).
+ * sgg_maxpool3x3s2: MaxPool2d(3, stride 2, padding 1) on [B,H,W,C] -> [B,(H-1)/2+1,(W-1)/2+1,C].
+ * sgg_plane_copy: dst[b,y,x,:] = src[b, y*stride, x*stride, :] between planes with borders src_pad / dst_pad (interiors only).
+ * sgg_add_relu: y = max(y + x, 0). */
+int sgg_im2col(const void* src, int B, int H, int W, int Ca, int C, int src_pad, int k, int stride, int pad, int Ho, int Wo, void* dst,
+               int Kp, int src_dtype, int dst_dtype, void* stream);
+int sgg_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C, int dtype, void* stream);
+int sgg_plane_copy(const void* src, int Hs, int Ws, int src_pad, void* dst, int Hd, int Wd, int dst_pad, int B, int C, int stride, int dtype,
+                   void* stream);
+int sgg_add_relu(void* y, const void* x, int64_t n, int dtype, void* stream);
 /* img_ptr i32[2*(B+1) + 66*B]: img_ptr[b] = first node of graph b (im_inds i64[N] ascending), img_ptr[B] = N; then
  * img_ptr[B+1+b] = out_ptr[first node of b] = first edge of graph b (out_ptr from sgg_edge_csr, same stream, edges sorted);
  * then per graph 66 graph-relative out-list offsets of its nodes (entries past the last node repeat the edge count). */

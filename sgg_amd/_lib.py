@@ -53,6 +53,10 @@ SIGNATURES = {
     'sgg_imp_edge_in_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     'sgg_imp_ctx_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P],
     'sgg_graph_ptr': [_P, _I, _I, _P, _P, _P],
+    'sgg_im2col': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P],
+    'sgg_maxpool3x3s2': [_P, _P, _I, _I, _I, _I, _I, _P],
+    'sgg_plane_copy': [_P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    'sgg_add_relu': [_P, _P, _L, _I, _P],
     'sgg_eval_tail': [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     'sgg_rpn_decode': [_P, _I, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P],
     'sgg_segmented_sort_desc': [_P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P],

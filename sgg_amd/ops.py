@@ -689,3 +689,40 @@ def group_sum(w, C, group, dtype):
 def add_(y, x):
     _lib.call('sgg_add', _p(y), _p(x), y.numel(), dt(y), dt(x), _stream())
     return y
+
+
+# ---------------------------------------------------------------- ResNet-50-FPN glue (GQA configuration)
+def im2col(x, k, stride, pad, src_pad=0, C=None, Kp=None, dtype=None):
+    """Patch matrix of a k x k / stride / pad convolution: x [B, H+2 src_pad, W+2 src_pad, Ca] -> ([B*Ho*Wo, Kp], Ho, Wo); columns
+    (ky, kx, c) over the first C channels, zero-filled to Kp (default: the next multiple of 64)."""
+    B, H, W, Ca = x.shape[0], x.shape[1] - 2 * src_pad, x.shape[2] - 2 * src_pad, x.shape[3]
+    C = Ca if C is None else C
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    Kp = (k * k * C + 63) // 64 * 64 if Kp is None else Kp
+    out = torch.empty((B * Ho * Wo, Kp), dtype=dtype or x.dtype, device=x.device)
+    _lib.call('sgg_im2col', _p(x), B, H, W, Ca, C, src_pad, k, stride, pad, Ho, Wo, _p(out), Kp, dt(x), dt(out), _stream())
+    return out, Ho, Wo
+
+
+def maxpool3x3s2(x):
+    """MaxPool2d(3, stride=2, padding=1) on NHWC [B,H,W,C]."""
+    B, H, W, C = x.shape
+    out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=x.dtype, device=x.device)
+    _lib.call('sgg_maxpool3x3s2', _p(x), _p(out), B, H, W, C, dt(x), _stream())
+    return out
+
+
+def plane_copy(x, out, src_pad=0, dst_pad=0, stride=1):
+    """out[b,y,x,:] = x[b, y*stride, x*stride, :] between NHWC planes with borders src_pad / dst_pad (only interiors are written)."""
+    B, C = x.shape[0], x.shape[3]
+    assert out.shape[0] == B and out.shape[3] == C and out.dtype == x.dtype
+    _lib.call('sgg_plane_copy', _p(x), x.shape[1] - 2 * src_pad, x.shape[2] - 2 * src_pad, src_pad, _p(out), out.shape[1] - 2 * dst_pad,
+              out.shape[2] - 2 * dst_pad, dst_pad, B, C, stride, dt(x), _stream())
+    return out
+
+
+def add_relu_(y, x):
+    """y = max(y + x, 0) in place"""
+    assert y.shape == x.shape and y.dtype == x.dtype
+    _lib.call('sgg_add_relu', _p(y), _p(x), y.numel(), dt(y), _stream())
+    return y

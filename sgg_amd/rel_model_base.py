@@ -127,8 +127,15 @@ class RelModelBase(nn.Module):
             self.roi_fmap = nn.Sequential(nn.Flatten(), cls)
             self.roi_fmap_obj = make_vgg_classifier(512 * self.pool_sz ** 2, self.obj_dim)
         elif self.backbone == 'resnet50':
-            # GQA / Mask-R-CNN-R50-FPN detector (rel_model_base.py:58-81): SURVEY 8f-4, not on this path
-            raise NotImplementedError('backbone resnet50 is outside the MI355X hot path (SURVEY 8f-4)')
+            # GQA / Mask-R-CNN-R50-FPN detector (rel_model_base.py:58-81): sgg_amd/resnet_fpn.py
+            from .resnet_fpn import ResNet50FPNDetector, make_box_head
+            self.obj_dim = 1024
+            self.fmap_sz = 21
+            min_size = 1333 if min_size is None else min_size
+            max_size = 1333 if max_size is None else max_size
+            self.detector = ResNet50FPNDetector(len(self.classes), min_size, max_size, self.pool_sz, self.obj_dim)
+            self.roi_fmap = make_box_head(self.pool_sz, self.obj_dim)            # :78-79 deep copies of the detector's TwoMLPHead
+            self.roi_fmap_obj = make_box_head(self.pool_sz, self.obj_dim)
         else:
             raise NotImplementedError(self.backbone)
         self.edge_dim = self.detector.backbone.out_channels
@@ -141,6 +148,17 @@ class RelModelBase(nn.Module):
         self.compute_dtype = torch.bfloat16
         self._prep = {}
         self._shadow, self._shadow_tags = {}, {}     # compute-dtype weight copies (rel_model_stanford._shadow_cast)
+
+    def fc_layers(self):
+        """The four big Linear layers of the RoI feature heads under the names their parameters have in the reference's state_dict
+        -- {'fc6_edge' | 'fc7_edge' | 'fc6_obj' | 'fc7_obj': (parameter-name prefix, module)} -- and whether the edge branch's fc7 is
+        followed by a ReLU: vgg16 keeps the VGG classifier (roi_fmap = Flatten + [fc6, ReLU, Dropout, fc7]: no ReLU after fc7,
+        rel_model_base.py:110-111), resnet50 copies the detector's TwoMLPHead (relu(fc7), :78-80)."""
+        if self.backbone == 'resnet50':
+            return {'fc6_edge': ('roi_fmap.fc6', self.roi_fmap.fc6), 'fc7_edge': ('roi_fmap.fc7', self.roi_fmap.fc7),
+                    'fc6_obj': ('roi_fmap_obj.fc6', self.roi_fmap_obj.fc6), 'fc7_obj': ('roi_fmap_obj.fc7', self.roi_fmap_obj.fc7)}, True
+        return {'fc6_edge': ('roi_fmap.1.0', self.roi_fmap[1][0]), 'fc7_edge': ('roi_fmap.1.3', self.roi_fmap[1][3]),
+                'fc6_obj': ('roi_fmap_obj.0', self.roi_fmap_obj[0]), 'fc7_obj': ('roi_fmap_obj.3', self.roi_fmap_obj[3])}, False
 
     # ------------------------------------------------------------------ reference API
     @property
@@ -226,6 +244,8 @@ class RelModelBase(nn.Module):
     def _faster_rcnn_sgdet(self, x, gt_classes):
         """rel_model_base.py:209-235: RPN + RoI heads (sgg_amd/sgdet.py), <= 50 detections per image."""
         from . import sgdet
+        if self.backbone != 'vgg16':
+            raise NotImplementedError('sgdet with backbone %s (RPN over five pyramid levels, multi-level RoIAlign) is not built' % self.backbone)
         # The detector is frozen (main.py:62-63) and always runs as an inference detector here, also under model.train():
         # torchvision's RoIHeads in training mode returns losses and no detections, which is why the reference documents
         # SGDet training as unsupported (README.md:214-218).  rm_obj_labels are the detector's labels, as at :221,:228.

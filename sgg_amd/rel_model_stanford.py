@@ -52,19 +52,19 @@ class RelModelStanford(RelModelBase):
         C, PP = self.edge_dim, self.pool_sz ** 2
         f = lambda t: t.detach().float().contiguous()
         w = {}
-        w['fc6_obj'] = self._shadow_cast('roi_fmap_obj.0.weight', self.roi_fmap_obj[0].weight)
-        w6e = f(self.roi_fmap[1][0].weight)
-        w['fc6_edge'] = self._shadow_cast('roi_fmap.1.0.weight', w6e)   # [4096, 25088], K order (c,ph,pw) as in the reference
+        fc, _ = self.fc_layers()
+        w['fc6_obj'] = self._shadow_cast(fc['fc6_obj'][0] + '.weight', fc['fc6_obj'][1].weight)
+        w6e = f(fc['fc6_edge'][1].weight)
+        w['fc6_edge'] = self._shadow_cast(fc['fc6_edge'][0] + '.weight', w6e)   # [obj_dim, C*49], K order (c,ph,pw) as in the reference
         gs = getattr(self, '_sharded_group_sum', None)             # a trainer with a sharded optimiser: sums of this rank's rows, gathered
-        w['fc6_edge_sum'] = (gs or ops.group_sum)(w6e, C, PP, dtype)    # [4096, 512]
-        for name, pname, mod in (('fc7_obj', 'roi_fmap_obj.3', self.roi_fmap_obj[3]),
-                                 ('fc7_edge', 'roi_fmap.1.3', self.roi_fmap[1][3]),
+        w['fc6_edge_sum'] = (gs or ops.group_sum)(w6e, C, PP, dtype)    # [obj_dim, C]
+        for name, pname, mod in (('fc7_obj',) + fc['fc7_obj'], ('fc7_edge',) + fc['fc7_edge'],
                                  ('obj_unary', 'obj_unary', self.obj_unary), ('edge_unary', 'edge_unary', self.edge_unary),
                                  ('obj_fc', 'obj_fc', self.obj_fc), ('rel_fc', 'rel_fc', self.rel_fc)):
             w[name] = self._shadow_cast(pname + '.weight', mod.weight)
             w[name + '_b'] = f(mod.bias)
-        w['fc6_obj_b'] = f(self.roi_fmap_obj[0].bias)
-        w['fc6_edge_b'] = f(self.roi_fmap[1][0].bias)
+        w['fc6_obj_b'] = f(fc['fc6_obj'][1].bias)
+        w['fc6_edge_b'] = f(fc['fc6_edge'][1].bias)
         sd = {k: v for k, v in self.head_named_parameters() if 'gru' in k or 'w_fc' in k}
         w['imp'] = ImpWeights.from_state(sd, dtype)
         self._prep = dict(key=key, val=w)
@@ -72,8 +72,6 @@ class RelModelStanford(RelModelBase):
 
     # Compute-dtype copies of the plain-cast weights live in stable buffers: the fused optimiser writes them in its
     # update pass (sgg_sgd_multi `shadow`), so a train step never re-reads 1 GB of fp32 masters just to cast them.
-    _SHADOWED = ('roi_fmap_obj.0.weight', 'roi_fmap.1.0.weight', 'roi_fmap_obj.3.weight', 'roi_fmap.1.3.weight',
-                 'obj_unary.weight', 'edge_unary.weight', 'obj_fc.weight', 'rel_fc.weight')
 
     def _shadow_tag(self, p):
         return (getattr(self, 'weights_version', 0), p.data_ptr(), p._version)
@@ -126,6 +124,9 @@ class RelModelStanford(RelModelBase):
         nf = to_rows(node_feat.view(N, -1, self.pool_sz, self.pool_sz), dtype)
         ef = to_rows(edge_feat.view(E, -1, self.pool_sz, self.pool_sz), dtype)
         if self.training:
+            if self.backbone != 'vgg16':
+                raise NotImplementedError('training the head with backbone %s: the autograd node of sgg_amd/train.py is written for the '
+                                          'VGG classifier heads (dropout, no ReLU after the edge fc7)' % self.backbone)
             # Dropout, batch-statistic BatchNorm and the autograd node of the whole head (sgg_amd/train.py)
             from .train import predict_train
             return predict_train(self, nf, ef, rel_inds, rois, _im_inds, dropout_p=self.dropout_p, graphs=_graphs, im_sizes=im_sizes)
@@ -154,7 +155,7 @@ class RelModelStanford(RelModelBase):
         _lib.set_tag('fc6_edge')
         y = ops.gemm(ef, w['fc6_edge'], w['fc6_edge_b'], ops.ACT_RELU, A2=rect, W2=w['fc6_edge_sum'])
         _lib.set_tag('fc7_edge')
-        y = ops.gemm(y, w['fc7_edge'], w['fc7_edge_b'])
+        y = ops.gemm(y, w['fc7_edge'], w['fc7_edge_b'], ops.ACT_RELU if self.fc_layers()[1] else ops.ACT_NONE)
         _lib.set_tag('unary')
         rel_rep = ops.gemm(y, w['edge_unary'], w['edge_unary_b'], ops.ACT_RELU)
         # :105

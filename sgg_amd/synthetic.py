@@ -21,7 +21,8 @@ def init_weights(model, seed=111):
             if isinstance(m, (nn.Conv2d, nn.Linear)):
                 fan_in = m.weight[0].numel()
                 m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (2.0 / fan_in) ** 0.5)
-                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.05)
+                if m.bias is not None:
+                    m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.05)
             elif isinstance(m, nn.GRUCell):
                 for p in m.parameters():
                     p.copy_(torch.randn(p.shape, generator=g) * (1.0 / m.hidden_size) ** 0.5)

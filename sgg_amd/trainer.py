@@ -260,7 +260,7 @@ class Trainer(object):
         """W6sum (model.prepared()) when this rank's fp32 master of fc6 is current only in its own rows: every rank sums its rows,
         the [rows, C] results are all-gathered -- the numbers of the whole-tensor sum.  A collective: prepared() runs at the same
         points of the step on every rank."""
-        p = dict(self.model.named_parameters()).get('roi_fmap.1.0.weight')
+        p = self.model.fc_layers()[0]['fc6_edge'][1].weight
         rng = self.opt.stale_masters.get(p) if p is not None else None
         if rng is None:
             return ops.group_sum(w6e, C, PP, dtype)

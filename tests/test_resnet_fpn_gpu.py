@@ -1,0 +1,143 @@
+"""ResNet-50-FPN front end of the GQA configuration (sgg_models/rel_model_base.py:58-81) on the HIP path against the
+oracle's restatement of torchvision's backbone ([3P] unpinned), and its glue kernels against plain torch ops."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+import sgg_oracle as O  # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def seeded_detector(seed=0):
+    """random He-scaled convolutions, non-trivial frozen BatchNorm buffers"""
+    from sgg_amd.resnet_fpn import FrozenBatchNorm2d, ResNet50FPNDetector
+    torch.manual_seed(seed)
+    det = ResNet50FPNDetector(num_classes=12)
+    for m in det.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.kaiming_normal_(m.weight, nonlinearity='relu')
+            if m.bias is not None:
+                torch.nn.init.normal_(m.bias, std=0.1)
+        elif isinstance(m, FrozenBatchNorm2d):
+            m.weight.uniform_(0.4, 0.9)
+            m.bias.normal_(0, 0.1)
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    return det
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_glue_kernels_equal_torch(dtype):
+    from sgg_amd import ops
+    g = torch.Generator().manual_seed(3)
+    tol = dict(atol=0, rtol=0)
+    x = torch.randn(2, 11, 14, 16, generator=g).to(DEV).to(dtype)                   # NHWC rows
+    nchw = lambda t: t.permute(0, 3, 1, 2).float()                                   # noqa: E731
+    torch.testing.assert_close(nchw(ops.maxpool3x3s2(x)), F.max_pool2d(nchw(x), 3, 2, 1), **tol)
+    y = torch.randn(2, 11, 14, 16, generator=g).to(DEV).to(dtype)
+    torch.testing.assert_close(ops.add_relu_(y.clone(), x).float(), (y.float() + x.float()).clamp(min=0).to(dtype).float(), **tol)
+    # rows -> zero-bordered plane, stride-2 sub-sampling
+    pl = torch.zeros(2, 13, 16, 16, dtype=dtype, device=DEV)
+    ops.plane_copy(x, pl, dst_pad=1)
+    assert torch.equal(pl[:, 1:-1, 1:-1], x) and pl[:, 0].abs().max() == 0 and pl[:, :, 0].abs().max() == 0 and pl[:, -1].abs().max() == 0
+    sub = ops.plane_copy(x, torch.empty(2, 6, 7, 16, dtype=dtype, device=DEV), stride=2)
+    assert torch.equal(sub, x[:, ::2, ::2])
+    assert torch.equal(ops.plane_copy(pl, torch.empty(2, 6, 7, 16, dtype=dtype, device=DEV), src_pad=1, stride=2), x[:, ::2, ::2])
+    # patch matrices: 3x3 / 2 / 1 on a bordered plane; 7x7 / 2 / 3 on the 4-channel f32 image plane (3 channels used, f32 -> dtype)
+    for k, s, p_ in ((3, 2, 1), (3, 1, 1)):
+        cols, Ho, Wo = ops.im2col(pl, k, s, p_, src_pad=1)
+        ref = F.unfold(nchw(x), k, padding=p_, stride=s)                                   # [B, C*k*k, L], (c, ky, kx) order
+        ref = ref.view(2, 16, k * k, Ho * Wo).permute(0, 3, 2, 1).reshape(2 * Ho * Wo, k * k * 16)
+        assert cols.shape == (2 * Ho * Wo, 192) and cols[:, 144:].abs().max() == 0
+        torch.testing.assert_close(cols[:, :144].float(), ref, **tol)
+    img = torch.zeros(2, 21, 26, 4, device=DEV)
+    img[:, 1:-1, 1:-1, :3] = torch.randn(2, 19, 24, 3, generator=g).to(DEV)
+    cols, Ho, Wo = ops.im2col(img, 7, 2, 3, src_pad=1, C=3, Kp=192, dtype=dtype)
+    ref = F.unfold(img[:, 1:-1, 1:-1, :3].permute(0, 3, 1, 2), 7, padding=3, stride=2).view(2, 3, 49, Ho * Wo).permute(0, 3, 2, 1).reshape(-1, 147)
+    assert (Ho, Wo) == (10, 12) and cols[:, 147:].abs().max() == 0
+    torch.testing.assert_close(cols[:, :147].float(), ref.to(dtype).float(), **tol)
+
+
+def test_state_dict_names_are_torchvisions():
+    from sgg_amd.resnet_fpn import ResNet50FPNDetector
+    keys = set(ResNet50FPNDetector(num_classes=1704).state_dict())
+    for k in ('backbone.body.conv1.weight', 'backbone.body.bn1.running_var', 'backbone.body.layer1.0.downsample.0.weight',
+              'backbone.body.layer1.0.downsample.1.running_mean', 'backbone.body.layer3.5.conv2.weight', 'backbone.body.layer4.2.bn3.bias',
+              'backbone.fpn.inner_blocks.0.weight', 'backbone.fpn.layer_blocks.3.bias', 'rpn.head.conv.weight', 'rpn.head.cls_logits.bias',
+              'roi_heads.box_head.fc6.weight', 'roi_heads.box_head.fc7.bias', 'roi_heads.box_predictor.cls_score.weight',
+              'roi_heads.box_predictor.bbox_pred.bias', 'roi_heads.mask_head.mask_fcn4.weight'):
+        assert k in keys, k
+    assert not any('num_batches_tracked' in k for k in keys)
+    sd = ResNet50FPNDetector(num_classes=1704).state_dict()
+    assert sd['roi_heads.box_head.fc6.weight'].shape == (1024, 256 * 49) and sd['roi_heads.box_predictor.cls_score.weight'].shape == (1704, 1024)
+    assert sd['rpn.head.cls_logits.weight'].shape[0] == 3 and len([k for k in keys if k.startswith('backbone.body.') and k.endswith('conv2.weight')]) == 16
+
+
+@pytest.mark.parametrize('dtype,size', [(torch.float32, (96, 128)), (torch.float32, (70, 50)), (torch.bfloat16, (96, 128))])
+def test_pool_level_feature_map_matches_oracle(dtype, size):
+    """transform (no resize / resize + pad, two images of different sizes) -> ResNet-50 -> FPN top level -> LastLevelMaxPool"""
+    det = seeded_detector(1).to(DEV)
+    det.transform.min_size, det.transform.max_size = 96, 128
+    g = torch.Generator().manual_seed(5)
+    images = [torch.rand(3, *size, generator=g), torch.rand(3, size[0] - 12, size[1] - 20, generator=g)]
+    fmap, sizes, padded = det.features(images, dtype)
+    batch, osizes, _ = O.transform(images, None, 96, 128)
+    assert list(map(tuple, osizes)) == list(map(tuple, sizes)) and tuple(batch.shape[2:]) == tuple(padded)
+    sd = {'detector.' + k: v.cpu() for k, v in det.state_dict().items()}
+    want = O.resnet50_fpn_pool(batch, sd)                                             # [B,256,h,w]
+    got = fmap.float().cpu().permute(0, 3, 1, 2)
+    assert got.shape == want.shape and want.abs().max() > 0.05
+    err = (got - want).abs().max().item() / want.abs().max().item()
+    assert err <= (2e-4 if dtype == torch.float32 else 6e-2), err
+
+
+def test_relation_model_with_resnet50_backbone_matches_oracle():
+    """RelModelStanford(backbone='resnet50') (the GQA configuration, rel_model_base.py:58-81): obj_dim 1024, 256-channel 'pool'-level
+    feature map at stride 64, TwoMLPHead RoI heads (ReLU after the edge branch's fc7 too); eval forward in exact-fp32 mode against the
+    oracle chain (transform -> ResNet-50-FPN -> RoIAlign at 1/64 -> heads -> message passing -> eval tail)."""
+    import sgg_amd
+    from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
+    from sgg_amd.resnet_fpn import FrozenBatchNorm2d
+    torch.manual_seed(2)
+    S = 256
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls', backbone='resnet50', min_size=S, max_size=S))
+    for m in model.modules():
+        if isinstance(m, FrozenBatchNorm2d):
+            m.weight.uniform_(0.5, 1.0)
+            m.running_var.uniform_(0.6, 1.4)
+            m.running_mean.normal_(0, 0.1)
+    assert model.obj_dim == 1024 and model.edge_dim == 256 and model.fmap_sz == 21
+    sd = model.state_dict()
+    for k, shape in (('roi_fmap.fc6.weight', (1024, 256 * 49)), ('roi_fmap_obj.fc7.weight', (1024, 1024)), ('obj_unary.weight', (512, 1024)),
+                     ('union_boxes.conv.4.weight', (256, 128, 3, 3)), ('detector.backbone.fpn.layer_blocks.3.weight', (256, 256, 3, 3))):
+        assert tuple(sd[k].shape) == shape, (k, tuple(sd[k].shape))
+    model.to(DEV).eval()
+    model.set_compute_dtype(torch.float32)
+    batch = synthetic_batch(B=2, S=S, n_boxes=5, n_fg=3, seed=4)
+    dev_batch = tuple(t_.to(DEV) if isinstance(t_, torch.Tensor) else t_ for t_ in batch)
+    with torch.no_grad():
+        dets = model([dev_batch])
+    p = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    ref = O.forward_gtbox(batch[0], batch[3].numpy(), batch[4].numpy(), batch[5].numpy(), p, mode='sgcls', min_size=S, max_size=S)
+    assert ref['fmap'].shape[1] == 256 and ref['fmap'].shape[-1] == 4            # 256 / 64
+    boxes, obj_classes, obj_scores, rels, pred_scores = dets
+    rb, rc, rs, rr, rp = ref['dets']
+    np.testing.assert_array_equal(obj_classes, rc)
+    np.testing.assert_allclose(obj_scores, rs, atol=1e-3)
+    np.testing.assert_array_equal(rels[:20], rr[:20])
+    np.testing.assert_allclose(pred_scores[:20], rp[:20], atol=1e-3)
+    # sgdet with this backbone and training of the head are not built: say so instead of running something else
+    model.mode = 'sgdet'
+    with pytest.raises(NotImplementedError):
+        model([dev_batch])
+    model.mode = 'sgcls'
+    model.train()
+    with pytest.raises(NotImplementedError):
+        model([dev_batch])

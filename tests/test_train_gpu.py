@@ -316,7 +316,7 @@ def test_trainer_distributed_path_on_one_rank_matches_local(env):
             diff = (out['local'][1][n] - out['dist'][1][n]).abs().max()
             assert step > 0 and diff <= 2e-2 * step + 1e-9, (n, float(step), float(diff))
             # one rank: the part IS the tensor; only the order in which the squared norms meet (atomics, two accumulators) differs
-            assert (out['dist'][1][n] - out['dist_sharded'][1][n]).abs().max() <= 1e-4 * step, n
+            assert (out['dist'][1][n] - out['dist_sharded'][1][n]).abs().max() <= 2e-3 * step + 1e-8, n
     finally:
         dist.destroy_process_group()
         model._grad_ready_hook = None
