@@ -124,12 +124,11 @@ class RelModelStanford(RelModelBase):
         nf = to_rows(node_feat.view(N, -1, self.pool_sz, self.pool_sz), dtype)
         ef = to_rows(edge_feat.view(E, -1, self.pool_sz, self.pool_sz), dtype)
         if self.training:
-            if self.backbone != 'vgg16':
-                raise NotImplementedError('training the head with backbone %s: the autograd node of sgg_amd/train.py is written for the '
-                                          'VGG classifier heads (dropout, no ReLU after the edge fc7)' % self.backbone)
-            # Dropout, batch-statistic BatchNorm and the autograd node of the whole head (sgg_amd/train.py)
+            # Dropout, batch-statistic BatchNorm and the autograd node of the whole head (sgg_amd/train.py); the TwoMLPHead copies of
+            # the resnet50 configuration have no Dropout layers (the VGG classifier's sit after fc6 and fc7)
             from .train import predict_train
-            return predict_train(self, nf, ef, rel_inds, rois, _im_inds, dropout_p=self.dropout_p, graphs=_graphs, im_sizes=im_sizes)
+            return predict_train(self, nf, ef, rel_inds, rois, _im_inds, dropout_p=self.dropout_p if self.backbone == 'vgg16' else 0.0,
+                                 graphs=_graphs, im_sizes=im_sizes)
         w = self.prepared()
         # :100  union_boxes(edge_feat, rois, rel_inds[:,1:]) -- conv(rects)[E,512]; the broadcast add rides in fc6's K
         rect = self.union_boxes.rect_feat(rois, rel_inds[:, 1:].contiguous(), dtype, im_sizes)

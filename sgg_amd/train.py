@@ -20,9 +20,9 @@ DROPOUT_P = 0.5  # nn.Dropout() default in torchvision's VGG classifier
 
 
 def param_names(model):
-    names = ['roi_fmap.1.0.weight', 'roi_fmap.1.0.bias', 'roi_fmap.1.3.weight', 'roi_fmap.1.3.bias',
-             'roi_fmap_obj.0.weight', 'roi_fmap_obj.0.bias', 'roi_fmap_obj.3.weight', 'roi_fmap_obj.3.bias',
-             'union_boxes.conv.0.weight', 'union_boxes.conv.0.bias', 'union_boxes.conv.2.weight',
+    fc, _ = model.fc_layers()        # the four big Linear layers under their own names (VGG classifier / TwoMLPHead copies)
+    names = [fc[k][0] + sfx for k in ('fc6_edge', 'fc7_edge', 'fc6_obj', 'fc7_obj') for sfx in ('.weight', '.bias')]
+    names += ['union_boxes.conv.0.weight', 'union_boxes.conv.0.bias', 'union_boxes.conv.2.weight',
              'union_boxes.conv.2.bias', 'union_boxes.conv.4.weight', 'union_boxes.conv.4.bias',
              'union_boxes.conv.6.weight', 'union_boxes.conv.6.bias', 'rel_fc.weight', 'rel_fc.bias', 'obj_fc.weight',
              'obj_fc.bias', 'obj_unary.weight', 'obj_unary.bias', 'edge_unary.weight', 'edge_unary.bias']
@@ -173,7 +173,8 @@ class PredictFn(torch.autograd.Function):
         _lib.set_tag('mlp')
         if dropout_p > 0:
             ops.dropout_(y6, dropout_p, seed * 4 + 3)
-        y7 = ops.gemm(y6, w['fc7_edge'], w['fc7_edge_b'])
+        edge_relu7 = model.fc_layers()[1]          # TwoMLPHead copies (resnet50): ReLU after the edge branch's fc7 as well
+        y7 = ops.gemm(y6, w['fc7_edge'], w['fc7_edge_b'], ops.ACT_RELU if edge_relu7 else ops.ACT_NONE)
         ops.gemm(y7, w['edge_unary'], w['edge_unary_b'], ops.ACT_RELU, out=XE[:E])
         sv.update(x6=x6, x7=x7, y6=y6, y7=y7)
         # ---- message passing (rel_model_stanford.py:68-94)
@@ -332,13 +333,17 @@ class PredictFn(torch.autograd.Function):
         C, PP = model.edge_dim, model.pool_sz ** 2
         _lib.set_tag('bwd_mlp')
         d_u = ops.act_bwd(d_rel_rep, rows(XE, 0, E))                               # relu(edge_unary)
+        fc, edge_relu7 = model.fc_layers()
+        n6e, n7e, n6o, n7o = (fc[k][0] for k in ('fc6_edge', 'fc7_edge', 'fc6_obj', 'fc7_obj'))
         d_y7 = lin_bwd(d_u, sv['y7'], t['edge_unary_t'], 'edge_unary', 'bwd_mlp')
-        d_y6 = lin_bwd(d_y7, sv['y6'], t['fc7_edge_t'], 'roi_fmap.1.3', 'bwd_mlp', big=True)
+        if edge_relu7:
+            d_y7 = ops.act_bwd(d_y7, sv['y7'])
+        d_y6 = lin_bwd(d_y7, sv['y6'], t['fc7_edge_t'], n7e, 'bwd_mlp', big=True)
         d_pre6 = ops.act_bwd(d_y6, sv['y6'], ds)                                   # dropout + relu
         _lib.set_tag('bwd_mlp_obj')
         d_x7 = lin_bwd(d_obj_rep, sv['x7'], t['obj_unary_t'], 'obj_unary', 'bwd_mlp_obj')
         d_p7 = ops.act_bwd(d_x7, sv['x7'], ds)
-        d_x6 = lin_bwd(d_p7, sv['x6'], t['fc7_obj_t'], 'roi_fmap_obj.3', 'bwd_mlp_obj', big=True)
+        d_x6 = lin_bwd(d_p7, sv['x6'], t['fc7_obj_t'], n7o, 'bwd_mlp_obj', big=True)
         d_p6 = ops.act_bwd(d_x6, sv['x6'], ds)
         # ---- phase B: the two fc6 weight gradients
         _lib.set_tag('bwd_fc6_edge_dW')
@@ -348,13 +353,13 @@ class PredictFn(torch.autograd.Function):
             x6t = sv['x6t']
         else:
             x6t = ops.transpose(sv['ef'], add=sv['rect'].float() if sv['rect'].dtype != torch.float32 else sv['rect'], group=PP)
-        d6t, G['roi_fmap.1.0.bias'] = ops.transpose(d_pre6, want_colsum=True)
-        G['roi_fmap.1.0.weight'] = ops.gemm_full_waves(d6t, x6t, out_dtype=big_dtype())
-        hook('roi_fmap.1.0.weight')
+        d6t, G[n6e + '.bias'] = ops.transpose(d_pre6, want_colsum=True)
+        G[n6e + '.weight'] = ops.gemm_full_waves(d6t, x6t, out_dtype=big_dtype())
+        hook(n6e + '.weight')
         del x6t, d6t
         _lib.set_tag('bwd_mlp_obj')
-        G['roi_fmap_obj.0.weight'], G['roi_fmap_obj.0.bias'] = tn_gemm(d_p6, sv['nf'], want_colsum=True, pool=pool, out_dtype=big_dtype())
-        hook('roi_fmap_obj.0.weight')
+        G[n6o + '.weight'], G[n6o + '.bias'] = tn_gemm(d_p6, sv['nf'], want_colsum=True, pool=pool, out_dtype=big_dtype())
+        hook(n6o + '.weight')
         # ---- phase C: everything deferred, largest first (fc7 x2 carry their own hooks)
         for dw in deferred[::-1]:                      # fc7 node, unary node, fc7 edge, unary edge, heads
             dw()

@@ -133,11 +133,35 @@ def test_relation_model_with_resnet50_backbone_matches_oracle():
     np.testing.assert_allclose(obj_scores, rs, atol=1e-3)
     np.testing.assert_array_equal(rels[:20], rr[:20])
     np.testing.assert_allclose(pred_scores[:20], rp[:20], atol=1e-3)
-    # sgdet with this backbone and training of the head are not built: say so instead of running something else
+    # sgdet with this backbone is not built: say so instead of running something else
     model.mode = 'sgdet'
     with pytest.raises(NotImplementedError):
         model([dev_batch])
     model.mode = 'sgcls'
+    # ---- training forward and the gradients of every head parameter against torch autograd of the oracle (TwoMLPHead layout:
+    # no Dropout, ReLU after the edge branch's fc7), then one Trainer step in bf16
+    from sgg_amd.train import param_names
     model.train()
-    with pytest.raises(NotImplementedError):
-        model([dev_batch])
+    res = model([dev_batch])
+    g = torch.Generator().manual_seed(0)
+    Wo, Wr = torch.randn(res.rm_obj_dists.shape, generator=g), torch.randn(res.rel_dists.shape, generator=g)
+    model.zero_grad()
+    ((res.rm_obj_dists * Wo.to(DEV)).sum() + (res.rel_dists * Wr.to(DEV)).sum()).backward()
+    names = param_names(model)
+    assert names[:4] == ['roi_fmap.fc6.weight', 'roi_fmap.fc6.bias', 'roi_fmap.fc7.weight', 'roi_fmap.fc7.bias'] and len(names) == 40
+    pq = {k: v.clone().requires_grad_(k in set(names)) for k, v in p.items()}
+    od, rd = O.predict(res.node_feat.float().cpu().contiguous(), res.edge_feat.float().cpu().contiguous(), res.rel_inds.cpu().numpy(),
+                       res.rois.cpu().numpy(), pq, training=True)
+    torch.testing.assert_close(res.rm_obj_dists.detach().cpu(), od.detach(), atol=1e-3, rtol=1e-3)
+    torch.testing.assert_close(res.rel_dists.detach().cpu(), rd.detach(), atol=1e-3, rtol=1e-3)
+    ((od * Wo).sum() + (rd * Wr).sum()).backward()
+    named = dict(model.named_parameters())
+    for n in names:
+        ref, got = pq[n].grad, named[n].grad.cpu()
+        err = float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-6)
+        assert got.shape == ref.shape and err < 2e-3, (n, err)
+    from sgg_amd.trainer import Trainer
+    model.set_compute_dtype(torch.bfloat16)
+    tr = Trainer(model, lr=1e-3)
+    losses = [float(tr.step(dev_batch)) for _ in range(4)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
