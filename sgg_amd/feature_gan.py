@@ -267,6 +267,10 @@ class GAN(nn.Module):
             return {}
         if not updateD and 'G' not in self.losses:
             return {}
+        # the SGG model may run in bf16 (its RoI features and feature maps then arrive in bf16); the discriminators are fp32 layers
+        wd = self.D_global[0].bias.dtype
+        features_fake = features_fake.to(wd) if features_fake is not None else None
+        features_real = features_real.to(wd) if features_real is not None else None
         if not is_fmaps:
             def conditioned(feats, labels, n_classes):                     # class one-hot planes appended to the 7x7 features
                 n = len(feats)

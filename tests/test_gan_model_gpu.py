@@ -104,3 +104,34 @@ def test_gan_training_iteration_with_the_sgg_model():
     losses2 = gan_train_step(model, gan, res, gt_boxes, gt_objects, gt_rels, optimizer, G_optimizer, D_optimizer, ganw=1.0,
                              ganlosses=('D', 'G'))
     assert sorted(losses2) == ['D_fmap', 'D_obj', 'D_rel', 'G_fmap', 'G_obj', 'G_rel'] and all(torch.isfinite(v) for v in losses2.values())
+
+
+def test_gqa_configuration_iteration_resnet50_backbone_and_gan():
+    """BASELINE configs[4] in one process: the GQA form of the model (backbone='resnet50': 1333-pixel images, 256 x 21 x 21 'pool'-level
+    feature map, TwoMLPHead RoI heads) with the GAN sized from it (n_ch 256, fmap_sz 21: D_global then skips its first pooling), one
+    SGG forward + one GAN iteration of main.py:124-194."""
+    import sgg_amd
+    from sgg_amd.feature_gan import GAN, gan_train_step
+    from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
+    torch.manual_seed(5)
+    data = SyntheticData()
+    model = init_weights(sgg_amd.RelModelStanford(data, mode='sgcls', backbone='resnet50')).to(DEV)
+    for n, p in model.named_parameters():
+        if n.startswith('detector.'):
+            p.requires_grad = False
+    gan = GAN(data.ind_to_classes, data.ind_to_predicates, n_ch=model.edge_dim, pool_sz=model.pool_sz, fmap_sz=model.fmap_sz,
+              n_layers_G=2, device=DEV).to(DEV)
+    assert (model.edge_dim, model.fmap_sz, model.obj_dim) == (256, 21, 1024) and isinstance(gan.D_global[4], torch.nn.Identity)
+    batch = synthetic_batch(B=1, S=1333, n_boxes=5, n_fg=4, seed=12)
+    dev_batch = tuple(t_.to(DEV) if isinstance(t_, torch.Tensor) else t_ for t_ in batch)
+    model.train()
+    res = model([dev_batch])
+    assert tuple(res.fmap.shape) == (1, 256, 21, 21) and res.node_feat.shape[1:] == (256, 7, 7)
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-3, momentum=0.9)
+    G_opt = torch.optim.Adam([p for n, p in gan.named_parameters() if n.startswith('G_')], lr=1e-4)
+    D_opt = torch.optim.Adam([p for n, p in gan.named_parameters() if n.startswith('D_')], lr=1e-4)
+    g0 = gan.G_proj.weight.detach().clone()
+    w0 = model.roi_fmap.fc6.weight.detach().clone()
+    losses = gan_train_step(model, gan, res, dev_batch[3].clone(), dev_batch[4].clone(), dev_batch[5].clone(), opt, G_opt, D_opt)
+    assert sorted(losses) == ['D_fmap', 'D_obj', 'D_rel', 'G_fmap', 'G_obj', 'G_rel', 'rec'] and all(torch.isfinite(v) for v in losses.values())
+    assert not torch.equal(g0, gan.G_proj.weight.detach()) and not torch.equal(w0, model.roi_fmap.fc6.weight.detach())
