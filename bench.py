@@ -143,12 +143,14 @@ def kernel_times(step_fn, reps):
 
 
 def pmc_traffic(key):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_r01.json), or None."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'pmc_r01.json')) as f:
-            return json.load(f)[key]['traffic_bytes']
-    except Exception:
-        return None
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_r02.json, else round 1's), or None."""
+    for name in ('pmc_r02.json', 'pmc_r01.json'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                return json.load(f)[key]['traffic_bytes']
+        except Exception:
+            continue
+    return None
 
 
 def imp_iter_ms(model, B, dtype, reps=50, kind='sliced'):
