@@ -545,9 +545,12 @@ extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias
     if ((long)B * (H + 2) * (W + 2) * Cin * esz > 0xffff0000L || 9L * Cin * Cout * esz > 0xffff0000L) return SGG_ERR_SPAN;   // 32-bit lane offsets
     {
         // wide-spatial layers: LDS-resident input patch kernel (conv_spatial.hip); small maps: implicit GEMM.
-        // SGG_CONV_FORCE=gemm|spatial overrides (experiments only).
+        // SGG_CONV_FORCE=gemm|spatial|old overrides (experiments only).
         static const char* force = getenv("SGG_CONV_FORCE");
-        const bool want = force ? (force[0] == 's') : (H >= 64 && W >= 64);   // measured: conv1_2..conv4_3 faster here, conv5 (38x38) on the implicit GEMM
+        // measured (round 2, after the scalar-base DMA went into every kernel; TFLOP/s spatial vs implicit GEMM at B=8): conv1_2 620 / 477,
+        // conv2_1 594 / 558, conv2_2 781 / 750, conv3_1 749 / 826, conv3_2 881 / 981, conv4_1 781 / 795, conv4_2 849 / 890, conv5 713 / 688
+        // (conv5: 37x37 there, 38x38 in the detector): the narrow layers on the patch kernel, the >= 256-channel ones on the GEMM
+        const bool want = force ? (force[0] == 's' || (force[0] == 'o' && H >= 64 && W >= 64)) : (H >= 64 && W >= 64 && Cout < 256);   // 'o': round 1's rule
         if (pool && ((H | W) & 1)) return SGG_ERR_ARG;
         if (want || pool) {
             const int rc = sgg_launch_conv_spatial(in, w, bias, out, out_pad, B, H, W, Cin, Cout, dtype == SGG_BF16, pool, (hipStream_t)stream);
