@@ -522,15 +522,17 @@ def main():
             # bar is checked in), short runs, reported beside the bf16 headline -- never `value`
             if trainer is not None:
                 trainer.flush()
+                trainer.opt.state.clear()            # the bf16 run is over: its 1 GB of momentum buffers goes back to the allocator
             torch.cuda.synchronize()
             model.set_compute_dtype(torch.float32)
+            torch.cuda.empty_cache()                 # fp32 activations are twice the size: let the allocator start from whole blocks
             t32 = Trainer(model, lr=1e-3, pipeline=trainer.pipeline if trainer is not None else True)
-            el_t = timed(lambda: t32.step(batch), 2, 5)
+            el_t = timed(lambda: t32.step(batch), 4, 5)
             t32.flush()
             el_i = timed(infer_step, 2, 5)
             line['f32_mode'] = {'dtype': 'f32', 'train_images_per_s': round(B * 5 / el_t, 2), 'train_ms_per_step': round(1e3 * el_t / 5, 3),
                                 'infer_images_per_s': round(B * 5 / el_i, 2), 'infer_ms_per_step': round(1e3 * el_i / 5, 3),
-                                'mfma_peak_TFLOPs': MFMA_PEAK_TF['f32'], 'note': 'same workload, exact-fp32 MFMA; 2 warm-up + 5 timed steps each'}
+                                'mfma_peak_TFLOPs': MFMA_PEAK_TF['f32'], 'note': 'same workload, exact-fp32 MFMA; 4 (train) / 2 (inference) warm-up + 5 timed steps'}
             del t32
             model.set_compute_dtype(tdtype)
         if world == 1 and not args.no_cpu_baseline:
