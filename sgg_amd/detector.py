@@ -147,9 +147,13 @@ class VGGDetector(nn.Module):
         B = len(images)
         ws = self.prepared(dtype)
         x0 = self._buf('img', (B, Hp + 2, Wp + 2, 4), torch.float32, dev, True)
-        uniform = all(s == sizes[0] for s in sizes) and sizes[0] == (Hp, Wp)
-        if not uniform:
-            x0.zero_()  # ragged batch: the pad region of a previous, larger image must be cleared
+        # the prep kernel writes image interiors only: the pad region of a previous, LARGER image in the same slot must be cleared --
+        # i.e. only when the per-image sizes differ from the last call's on this (cached) plane
+        sig = (tuple(sizes), x0.data_ptr())
+        if getattr(self, '_x0_sig', None) != sig:
+            if getattr(self, '_x0_sig', None) is not None:
+                x0.zero_()
+            self._x0_sig = sig
         staged = []
         for im in images:
             if is_u8_image(im):
