@@ -188,12 +188,14 @@ int sgg_imp_sliced_fwd(const void* v, const void* e, const int* so /*[E,2]*/, co
 /* The split step.  e_in[e] = g_sub(e) v[s(e)] + g_obj(e) v[o(e)] does not read the edge rows (they enter through edge_dots only), so
  * the step is a WRITE stream -- sgg_imp_edge_in_fwd: any edge list, no graph structure; it also leaves the read stream's two gates of
  * every edge, gates_oi f32[E,2] = (g_out, g_in) (rel_model_stanford.py:86-89), when gates_oi is not NULL -- and a READ stream --
- * sgg_imp_ctx_fwd: ctx2 as in sgg_imp_sliced_fwd from the edge rows and gates_oi, same requirements on the graphs;
+ * sgg_imp_ctx_fwd: ctx2 as in sgg_imp_sliced_fwd from the edge rows and gates_oi, same requirements on the graphs (with `so`, bf16 rows
+ * and graphs of <= 32 nodes the sums run as a gate-matrix product on the matrix cores, gates rounded to bf16);
  * SGG_ERR_CAPACITY when a graph has more than 1024 edges / 64 nodes or rows are not a multiple of 64 bytes. */
 int sgg_imp_edge_in_fwd(const void* v, const int* so /*[E,2]*/, const float* node_dots, const float* edge_dots, const float* gate_b,
                         void* e_in, float* gates_oi /*[E,2] or NULL*/, int E, int H, int dtype, void* stream);
-int sgg_imp_ctx_fwd(const void* e, const float* gates_oi /*[E,2]*/, const int* in_ptr, const int* in_ids, const int* img_ptr, int B, int N,
-                    int E, int H, void* ctx2 /*[2,N,H] or [N,H]*/, int max_edges, int max_nodes, int sum_ctx, int dtype, void* stream);
+int sgg_imp_ctx_fwd(const void* e, const float* gates_oi /*[E,2]*/, const int* so /*[E,2] or NULL*/, const int* in_ptr, const int* in_ids,
+                    const int* img_ptr, int B, int N, int E, int H, void* ctx2 /*[2,N,H] or [N,H]*/, int max_edges, int max_nodes, int sum_ctx,
+                    int dtype, void* stream);
 /* ---- glue of the ResNet-50-FPN feature extractor (GQA configuration: sgg_models/rel_model_base.py:58-81; the convolutions themselves
  * run on sgg_gemm / sgg_conv3x3_relu).  NHWC, C a multiple of 8 except where noted.
  * sgg_im2col: patch matrix of a k x k / stride / pad convolution, row = output pixel, columns (ky, kx, c) zero-filled to Kp; src is a

@@ -1509,6 +1509,349 @@ __global__ __launch_bounds__(DM_THREADS) void imp_ctx_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The read stream as a block-sparse matrix product on the matrix cores (imp_ctx_mfma_kernel; bf16, graphs of <= 32 nodes).
+//   ctx_out[n, :] = sum_e G_out[n, e] R[e, :],  G_out[n, e] = g_out(e) [s(e) == n]        ctx_in likewise with g_in, o(e)
+// R = the unit's row pieces [edges x 64 channels] in the LDS ring exactly as imp_ctx_kernel stages them (same DMA ring, same counted
+// waits, the small arrays by DMA one unit ahead); the VALU gather / unpack / FMA / cross-lane reduction loops -- ~340 wave
+// instructions per 248-row chunk, which is what bounds that kernel -- become v_mfma_f32_16x16x32_bf16: K = 32 edges per step, the
+// B fragment (edges x 16 channels: the reduction index is the SLOW axis in LDS) comes out through ds_read_b64_tr_b16, the A fragment
+// (16 nodes x 32 edges of the gate matrix) is built in registers from the edge's gate and node id: 8 compares + selects per lane.
+// No lists are walked: graph structure enters only through (s, o) of every edge, so any edge order inside a graph works.
+// Roles of the 16 waves: (sum: out / in) x (node tile: 0-15 / 16-31) x (K quarter: every fourth 32-edge step); a wave builds each
+// of its A fragments ONCE and multiplies it with all four 16-channel tiles (four 16x16 accumulators, kept for the whole unit); at
+// the end of the unit the K quarters (and, for the summed ctx of the training step, the two sums) meet through the ring slot that
+// was consumed last.
+// Measured at B=128 (127 MB of rows): 40 us -- the list-walking kernel above: 51, DMA and barriers alone: 31-32.  On the way:
+// K halves x channel halves as wave roles (every A fragment built by two waves), f32 gates and 32-bit node ids read by every lane
+// (64 bytes per lane and K step, 16 lanes reading the same bytes), swizzle key (row >> 1) & 7 (two-way conflicts of the transposing
+// reads): 46-48 us, bound by the LDS pipe (3000 of its cycles per 256-row chunk).  What is left at 40 us: ~110 wave instructions per
+// wave and chunk (VALU issue, 1800 cycles per chunk), 3 barriers + 2 LDS round trips at the end of every unit (3700 cycles), the
+// conversion pass at its start.
+// Gates enter the product as bf16 (relative error <= 2^-9 per term, below the bf16 rounding of the output): a pass at the start of a
+// unit turns the raw per-edge arrays (f32 gates, 32-bit global node ids, DMA'd one unit ahead) into bf16 gates and byte node ids.
+// Rows are swizzled on the DMA's source side, slot' = slot ^ mf_key(row), so that the 16 rows one transposing read touches spread
+// over the banks (with the plain key (row >> 1) & 7 they fell on 4 keys: two-way conflicts, 64 instead of 32 LDS cycles per K step).
+typedef __attribute__((ext_vector_type(8))) __bf16 mf_bf16x8;
+typedef __attribute__((ext_vector_type(4))) short mf_s16x4;
+typedef __attribute__((ext_vector_type(8))) short mf_s16x8;
+typedef __attribute__((address_space(3))) mf_s16x4 mf_lds_s16x4;
+constexpr int MF_NBUF = 4, MF_NODES = 32;
+constexpr int mfma_set_words(int emax) { return 4 * ctx_epad(emax); }                // raw: g_out, g_in, subject id, object id per edge
+constexpr int mfma_fixed_bytes(int emax) { return mfma_set_words(emax) * 4 + 6 * ctx_epad(emax); }   // + packed: 2 x bf16 gates, 2 x byte ids
+constexpr int mfma_chunk_edges(int emax) {
+    const int room = (DM_LDS_MAX - mfma_fixed_bytes(emax)) / (MF_NBUF * 128);
+    const int need = (emax + 31) / 32 * 32;
+    return (room < need ? room : need) / 32 * 32;
+}
+static_assert(mfma_chunk_edges(992) == 256, "imp_ctx_mfma_kernel: a 992-edge graph goes through in four 256-row chunks");
+
+// swizzle key of a chunk-local row: the 16 rows one transposing read touches (4 K blocks x 4 rows) get 8 distinct keys per row parity
+__device__ __forceinline__ int mf_key(int r) { return ((r >> 1) ^ ((r >> 3) & 3)) & 7; }
+
+__device__ __forceinline__ void dma16_to_lds_s(const void* sbase, unsigned voff, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_base), "v"(voff), "s"(sbase) : "memory");
+}
+
+__global__ __launch_bounds__(DM_THREADS) void imp_ctx_mfma_kernel(
+    const bf16_t* __restrict__ e, const float* __restrict__ gates_oi, const int* __restrict__ so, const int* __restrict__ img_ptr, int B,
+    int N, int H, bf16_t* __restrict__ ctx2, int EMAX, int EB, int sum_ctx) {
+    constexpr int PIECE = 128, CHAN = 64, NBUF = MF_NBUF;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int EPAD = ctx_epad(EMAX), SETW = 4 * EPAD;
+    char* const ring = smem;                                                          // [NBUF][EB][128 B], rows swizzled
+    int* const sets = reinterpret_cast<int*>(ring + (long)NBUF * EB * PIECE);        // raw [4][EPAD]: g_out, g_in (f32), subject, object (global ids)
+    // what the K steps read, made from the raw arrays at the start of a unit: gates as bf16 (what the A fragment holds anyway) and
+    // node ids as bytes (graph-local; 0xff = no node): 24 instead of 64 bytes per lane and K step
+    unsigned short* const gbf = reinterpret_cast<unsigned short*>(sets + SETW);       // [2][EPAD] bf16 g_out | g_in
+    unsigned char* const nid = reinterpret_cast<unsigned char*>(gbf + 2 * EPAD);      // [2][EPAD] subject | object
+    const unsigned ring_lds = (unsigned)(unsigned long)(lds_char_t*)smem;
+    const unsigned sets_lds = ring_lds + (unsigned)(NBUF * EB * PIECE);
+
+    const int S = H * 2 / PIECE, units = B * S;
+    const int G = (int)gridDim.x, NX = min(G, 8), x = (int)blockIdx.x % NX, w = (int)blockIdx.x / NX;
+    const int wx = G / NX + (x < G % NX ? 1 : 0);
+    const int uq = units / NX, ur = units % NX;
+    const int cnt = uq + (x < ur ? 1 : 0), base = x * uq + min(x, ur);
+    if (w >= cnt) return;
+    const int nunits = (cnt - w + wx - 1) / wx;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = wv >> 3, mt = (wv >> 2) & 1, kq = wv & 3;                          // this wave's role
+    const int nks = EB / 32;                                                           // 32-edge K steps per chunk
+
+    struct Hdr { int g, slice, n0, Nn, e0, Ee, nch; };         // Ee < 0: the host's promise about this graph is broken (outputs poisoned); nch chunks
+    int lg = base / S, lslice = base - lg * S, lidx = 0;
+    auto load_hdr = [&](int k) __attribute__((always_inline)) {
+        Hdr h;
+        const int idx = w + k * wx;
+        lslice += idx - lidx;
+        lidx = idx;
+        while (lslice >= S) {
+            lslice -= S;
+            ++lg;
+        }
+        h.g = lg;
+        h.slice = lslice;
+        u32x2 nn, ee;
+        asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(nn), "=&s"(ee) : "s"(img_ptr + h.g), "s"(img_ptr + (B + 1 + h.g)) : "memory");
+        h.n0 = (int)nn.x;
+        h.Nn = (int)nn.y - h.n0;
+        h.e0 = (int)ee.x;
+        h.Ee = (int)ee.y - h.e0;
+        if (h.Ee > EMAX || h.Nn > MF_NODES) {
+            h.Nn = 0;
+            h.Ee = -1;
+        }
+        h.nch = h.Ee > 0 ? (h.Ee + EB - 1) / EB : 1;             // (the only division: once per header)
+        return h;
+    };
+    int ci = 0;                                                  // DMA operations this wave has issued
+    // rows [lo, hi) (graph-local) of h's slice -> ring buffer rb: lane = (row of the instruction's 8, physical 16-byte slot)
+    const int l_row = lane >> 3, l_slot = lane & 7;
+    auto issue_dma = [&](const Hdr& h, int lo, int hi, int rb) __attribute__((always_inline)) {
+        // whole 32-row K steps: the rows past the last edge repeat it (finite data under the gate matrix's zeros -- the slot may
+        // hold the f32 partial sums of the last unit's reduction, which read as bf16 can be NaN)
+        const int nch = (hi - lo + 31) / 32 * 4;
+        const char* sb = reinterpret_cast<const char*>(e) + ((long)h.e0 * H + (long)h.slice * CHAN) * 2;      // uniform
+        for (int c = wv; c < nch; c += DM_THREADS / 64) {
+            const int r = c * 8 + l_row;                                       // chunk-local row
+            const int el = min(lo + r, hi - 1);
+            const unsigned voff = (unsigned)el * (unsigned)(H * 2) + (unsigned)((l_slot ^ mf_key(r)) << 4);
+            dma16_to_lds_s(sb, voff, __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)(rb * EB * PIECE + c * 1024)));
+            ++ci;
+        }
+    };
+    auto wait_mark = [&](int mark) __attribute__((always_inline)) {
+        switch (min(ci - mark, 15)) {
+#define SGG_W(K) case K: asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory"); break;
+            SGG_W(0) SGG_W(1) SGG_W(2) SGG_W(3) SGG_W(4) SGG_W(5) SGG_W(6) SGG_W(7) SGG_W(8) SGG_W(9) SGG_W(10) SGG_W(11) SGG_W(12)
+            SGG_W(13) SGG_W(14)
+#undef SGG_W
+            default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        }
+    };
+    // the four per-edge arrays of h's graph -> set q: lane t of the workgroup <-> edge t
+    auto issue_small = [&](const Hdr& h) __attribute__((always_inline)) {
+        if (wv * 64 < h.Ee) {
+            const unsigned set_lds = sets_lds;
+            const long et = h.e0 + min(tid, h.Ee - 1);
+            dma4_to_lds(gates_oi + 2 * et, __builtin_amdgcn_readfirstlane(set_lds + (unsigned)(wv * 256)));
+            dma4_to_lds(gates_oi + 2 * et + 1, __builtin_amdgcn_readfirstlane(set_lds + (unsigned)((EPAD + wv * 64) * 4)));
+            dma4_to_lds(so + 2 * et, __builtin_amdgcn_readfirstlane(set_lds + (unsigned)((2 * EPAD + wv * 64) * 4)));
+            dma4_to_lds(so + 2 * et + 1, __builtin_amdgcn_readfirstlane(set_lds + (unsigned)((3 * EPAD + wv * 64) * 4)));
+            ci += 4;
+        }
+    };
+
+    Hdr h0 = load_hdr(0), h1 = h0, h2 = h0;
+    if (nunits > 1) h1 = load_hdr(1);
+    if (nunits > 2) h2 = load_hdr(2);
+    int loaded = min(nunits, 3);
+    int pu = 0, pb = 0, pr = 0, issued_chunks = 0;
+    int mk0 = 0, mk1 = 0, mk2 = 0, mk3 = 0;
+    auto mark_of = [&](int r) __attribute__((always_inline)) { return r == 0 ? mk0 : r == 1 ? mk1 : r == 2 ? mk2 : mk3; };
+    int cu = 0;
+    auto hdr_rel = [&](int rel) __attribute__((always_inline)) {
+        Hdr h;
+        h.g = rel == 0 ? h0.g : rel == 1 ? h1.g : h2.g;
+        h.slice = rel == 0 ? h0.slice : rel == 1 ? h1.slice : h2.slice;
+        h.n0 = rel == 0 ? h0.n0 : rel == 1 ? h1.n0 : h2.n0;
+        h.Nn = rel == 0 ? h0.Nn : rel == 1 ? h1.Nn : h2.Nn;
+        h.e0 = rel == 0 ? h0.e0 : rel == 1 ? h1.e0 : h2.e0;
+        h.Ee = rel == 0 ? h0.Ee : rel == 1 ? h1.Ee : h2.Ee;
+        h.nch = rel == 0 ? h0.nch : rel == 1 ? h1.nch : h2.nch;
+        return h;
+    };
+    auto produce = [&]() __attribute__((always_inline)) {
+        if (pu >= nunits || pu - cu > 2) return false;
+        const Hdr hp = hdr_rel(pu - cu);
+        const int lo = pb * EB, hi = min(lo + EB, max(hp.Ee, 0));
+        if (SGG_DMA_ABL != 3 || issued_chunks == 0) issue_dma(hp, lo, hi, pr);
+        mk0 = pr == 0 ? ci : mk0;
+        mk1 = pr == 1 ? ci : mk1;
+        mk2 = pr == 2 ? ci : mk2;
+        mk3 = pr == 3 ? ci : mk3;
+        pr = pr + 1 == NBUF ? 0 : pr + 1;
+        ++issued_chunks;
+        if (++pb >= hp.nch) {
+            pb = 0;
+            ++pu;
+        }
+        return true;
+    };
+    // stale LDS must never meet a zero of the gate matrix as NaN / Inf: clear the ring once; node ids that cannot match
+    for (int k = tid; k < NBUF * EB * PIECE / 16; k += DM_THREADS) reinterpret_cast<u32x4*>(ring)[k] = u32x4{0, 0, 0, 0};
+    __syncthreads();
+    int mark_small;
+    issue_small(h0);
+    mark_small = ci;
+    for (int d = 0; d < NBUF - 1; ++d) produce();
+    int cr = 0, consumed = 0;
+
+    // lane constants of the fragments
+    const int m16 = lane & 15, kb = lane >> 4;
+    // transposing read: lane (kb, q16): row j = q16 >> 2 of its K block, column group cg = q16 & 3 (4 channels)
+    const int tj = m16 >> 2, tcg = m16 & 3;
+    unsigned boff[4][2];                                         // [16-channel tile][rows 0-3 / 4-7 of the K block], ks = 0
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int r = kb * 8 + hlf * 4 + tj;                 // (ks * 32 does not enter the swizzle key)
+            const int slot = (t * 2 + (tcg >> 1)) ^ mf_key(r);
+            boff[t][hlf] = (unsigned)(r * PIECE + slot * 16 + (tcg & 1) * 8);
+        }
+
+    for (cu = 0; cu < nunits; ++cu) {
+        const Hdr hc = h0;
+        { [[maybe_unused]] const int unit_no = consumed; SGG_DTICK(0) }
+        wait_mark(max(mark_small, mark_of(cr)));
+        __syncthreads();                                         // (B) this unit's raw per-edge arrays and first chunk, every wave's parts
+        {   // thread t: edge t -> bf16 gates, byte node ids (every wave has left the last unit: the packed arrays are free)
+            const float* graw = reinterpret_cast<const float*>(sets);
+            const bool live = tid < hc.Ee;
+            gbf[tid] = live ? (unsigned short)(pack_bf16x2(graw[tid], 0.f) & 0xffffu) : (unsigned short)0;
+            gbf[EPAD + tid] = live ? (unsigned short)(pack_bf16x2(graw[EPAD + tid], 0.f) & 0xffffu) : (unsigned short)0;
+            nid[tid] = live ? (unsigned char)(sets[2 * EPAD + tid] - hc.n0) : (unsigned char)0xff;
+            nid[EPAD + tid] = live ? (unsigned char)(sets[3 * EPAD + tid] - hc.n0) : (unsigned char)0xff;
+        }
+        __syncthreads();                                         // (C) packed arrays visible; the raw arrays are free
+        if (cu + 1 < nunits) {
+            issue_small(h1);                                     // the next unit's raw arrays
+            mark_small = ci;
+        }
+        const unsigned short* const gate = gbf + dir * EPAD;     // g_out | g_in
+        const unsigned char* const node = nid + dir * EPAD;      // subject | object
+        const unsigned target = (unsigned)(mt * 16 + m16);       // this lane's node (graph-local; ids of real edges are < Nn, padding is 0xff)
+        f32x4 acc[2][4];                                         // [step parity][channel tile]
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nchunks = hc.nch;
+        int last_slot = cr;
+        for (int cb = 0; cb < nchunks; ++cb) {
+            const int blo = cb * EB, bhi = min(blo + EB, max(hc.Ee, 0));
+            [[maybe_unused]] const int unit_no = consumed;
+            if (cb > 0) {
+                SGG_DTICK(0)
+                wait_mark(mark_of(cr));
+                __syncthreads();                                 // (D) chunk visible; every wave has left the last chunk
+            }
+            SGG_DTICK(1)
+            if (issued_chunks - consumed < NBUF) produce();
+            SGG_DTICK(2)
+            const lds_char_t* const slot_lds = (const lds_char_t*)(ring + cr * EB * PIECE);
+            // one 32-edge K step: A fragment = 16 nodes x 32 edges of the gate matrix (lane: node m16, K block kb: 8 edges), B
+            // fragments = 32 edges x 16 channels for this wave's two channel tiles through the transposing read (compiler-visible
+            // builtins: it hoists the reads of the next step above this step's arithmetic and places the waits itself)
+            auto kstep = [&](int ks, f32x4 (&c)[4]) __attribute__((always_inline)) {
+                const int el0 = blo + ks * 32 + kb * 8;          // this lane's 8 edges (16-byte / 8-byte aligned in the packed arrays)
+                const u32x4 g8 = *reinterpret_cast<const u32x4*>(gate + el0);
+                const u32x2 n8 = *reinterpret_cast<const u32x2*>(node + el0);
+                const lds_char_t* sl = slot_lds + ks * 32 * PIECE;
+                mf_s16x4 b[4][2];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    b[t][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((mf_lds_s16x4*)(sl + boff[t][0]));
+                    b[t][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((mf_lds_s16x4*)(sl + boff[t][1]));
+                }
+                // A fragment element j = gate j where byte j of the ids is this lane's node, else 0: a byte compare and a half-word
+                // select per element, straight into the packed bf16 registers (SDWA operand selects: no unpacking, no conversion)
+                u32x4 ap = {0u, 0u, 0u, 0u};
+                const unsigned zero = 0u;
+#define SGG_AEL(IDS, J, AP, GP, HW)                                                                                   \
+    asm("v_cmp_eq_u32_sdwa vcc, %2, %3 src0_sel:BYTE_" #J " src1_sel:DWORD\n\t"                                         \
+        "v_cndmask_b32_sdwa %0, %4, %1, vcc dst_sel:WORD_" #HW " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:WORD_" #HW \
+        : "+v"(AP) : "v"(GP), "v"(IDS), "v"(target), "v"(zero) : "vcc")
+                SGG_AEL(n8.x, 0, ap.x, g8.x, 0); SGG_AEL(n8.x, 1, ap.x, g8.x, 1);
+                SGG_AEL(n8.x, 2, ap.y, g8.y, 0); SGG_AEL(n8.x, 3, ap.y, g8.y, 1);
+                SGG_AEL(n8.y, 0, ap.z, g8.z, 0); SGG_AEL(n8.y, 1, ap.z, g8.z, 1);
+                SGG_AEL(n8.y, 2, ap.w, g8.w, 0); SGG_AEL(n8.y, 3, ap.w, g8.w, 1);
+#undef SGG_AEL
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const mf_s16x8 bp = __builtin_shufflevector(b[t][0], b[t][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    c[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, ap), __builtin_bit_cast(mf_bf16x8, bp), c[t], 0, 0, 0);
+                }
+            };
+            // this wave's K steps of the chunk: every fourth one; two per turn on separate accumulators
+            for (int ks = kq; SGG_DMA_ABL != 4 && ks < nks && blo + ks * 32 < bhi; ks += 8) {
+                kstep(ks, acc[0]);
+                if (ks + 4 < nks && blo + (ks + 4) * 32 < bhi) kstep(ks + 4, acc[1]);
+            }
+            SGG_DTICK(3)
+            SGG_DTICK(4)
+            last_slot = cr;
+            cr = cr + 1 == NBUF ? 0 : cr + 1;
+            ++consumed;
+        }
+        // ---- unit done: the four K quarters (and, for the summed ctx, the two sums) meet through the ring slot consumed last.
+        // The slot holds 8 x 4 KiB partial tiles: quarters 2 and 3 write, 0 and 1 add; 1 writes its sum back over what it read, 0 adds.
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[0][t] += acc[1][t];
+        { [[maybe_unused]] const int unit_no = consumed - 1; SGG_DTICK(5) }
+        lds_reads_done_barrier();                                // (E1) every wave has left the unit's last chunk
+        // [8 regions][16 registers][64 lanes] f32 = 32 KiB: the slot itself when it is that large (256-row chunks), else a region of
+        // its own behind the sets
+        float* const scratch = EB * PIECE >= 32768 ? reinterpret_cast<float*>(ring + last_slot * EB * PIECE)
+                                                   : reinterpret_cast<float*>(smem + NBUF * EB * PIECE + ((SETW * 4 + 6 * EPAD + 15) & ~15));
+        auto region = [&](int d, int m, int h) __attribute__((always_inline)) {
+            return reinterpret_cast<f32x4*>(scratch + ((d * 2 + m) * 2 + h) * 1024) + lane;        // [4 tiles][64 lanes] x 16 bytes
+        };
+        auto put = [&](f32x4* d) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) d[t * 64] = acc[0][t];
+        };
+        auto add = [&](const f32x4* d) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[0][t] += d[t * 64];
+        };
+        if (kq >= 2) put(region(dir, mt, kq - 2));
+        __syncthreads();                                         // (R1)
+        if (kq < 2) add(region(dir, mt, kq));
+        if (kq == 1) put(region(dir, mt, 1));                    // (only this wave read that region)
+        __syncthreads();                                         // (R2)
+        if (kq == 0) add(region(dir, mt, 1));
+        if (sum_ctx) {
+            if (kq == 0 && dir == 1) put(region(1, mt, 0));      // (read by this wave alone in round 1)
+            __syncthreads();                                     // (R3)
+            if (kq == 0 && dir == 0) add(region(1, mt, 0));
+        }
+        if (kq == 0 && (dir == 0 || !sum_ctx) && hc.Ee >= 0) {
+            // lane: channel m16 of each 16-channel tile, nodes kb*4 + i of this wave's node tile
+            bf16_t* out = ctx2 + ((long)(dir && !sum_ctx ? N : 0) + hc.n0 + mt * 16 + kb * 4) * H + hc.slice * CHAN + m16;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float v[4] = {acc[0][t].x, acc[0][t].y, acc[0][t].z, acc[0][t].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (mt * 16 + kb * 4 + i < hc.Nn) out[(long)i * H + t * 16] = f32_to_bf16(v[i]);
+            }
+        }
+        if (hc.Ee < 0) {                                         // broken promise: this graph's slice of the outputs is NaN
+            u32x2 nn;
+            asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(nn) : "s"(img_ptr + __builtin_amdgcn_readfirstlane(hc.g)) : "memory");
+            const int n0 = (int)nn.x, Nn = (int)nn.y - n0;
+            for (int k = tid; k < Nn * CHAN; k += DM_THREADS) {
+                const long o = (long)(n0 + k / CHAN) * H + hc.slice * CHAN + k % CHAN;
+                ctx2[o] = f32_to_bf16(__builtin_nanf(""));
+                if (!sum_ctx) ctx2[(long)N * H + o] = f32_to_bf16(__builtin_nanf(""));
+            }
+        }
+        { [[maybe_unused]] const int unit_no = consumed - 1; SGG_DTICK(6) }
+        // (the scratch slot is refilled by a DMA only after the next unit's barrier (B): every reader has consumed its reads by then)
+        h0 = h1;
+        h1 = h2;
+        if (loaded < nunits) {
+            h2 = load_hdr(loaded);
+            ++loaded;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The edge half of the step on its own:  e_in[e] = g_sub(e) v[s(e)] + g_obj(e) v[o(e)]   (rel_model_stanford.py:78-81).
 // The edge ROW is not an input: it enters only through its two gate dot products, which the GRU gate kernel already left in
 // edots.  So the step splits into a WRITE stream (this kernel: E rows out, the L2-resident vertex rows in) and a READ stream
@@ -1646,6 +1989,32 @@ int launch_ctx(const void* e, const float* gates_oi, const int* in_ptr, const in
     return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
 }
 
+// the matrix-core read stream (bf16, <= 32 nodes and <= 1024 edges per graph, rows a multiple of 128 bytes); 1 when it does not apply
+int ctx_mfma_dispatch(const void* e, const float* gates_oi, const int* so, const int* img_ptr, int B, int N, int H, void* ctx2, int max_edges,
+                      int max_nodes, int sum_ctx, int dtype, int max_wgs, hipStream_t s) {
+    if (dtype != SGG_BF16 || !so || max_nodes > MF_NODES || max_edges > DM_EMAX || (H * 2) % 128) return 1;
+    const int emax = (max(max_edges, 32) + 31) & ~31;
+    int eb = mfma_chunk_edges(emax);
+    const char* ebs = getenv("SGG_IMP_EB");     // tests: small chunks (many per unit on small graphs)
+    if (ebs && atoi(ebs) >= 32) eb = min(eb, atoi(ebs) & ~31);
+    if (eb < 32) return 1;
+    auto k = imp_ctx_mfma_kernel;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS_MAX) != hipSuccess)
+            return SGG_ERR_LAUNCH;
+        configured = true;
+    }
+    const int units = B * (H * 2 / 128);
+    int grid = min(units, 256);
+    if (max_wgs > 0) grid = min(grid, max_wgs);
+    const int smem = MF_NBUF * eb * 128 + mfma_fixed_bytes(emax) + (eb * 128 >= 32768 ? 0 : 32768 + 16);
+    if (smem > DM_LDS_MAX) return 1;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(DM_THREADS), smem, s, (const bf16_t*)e, gates_oi, so, img_ptr, B, N, H, (bf16_t*)ctx2, emax, eb,
+                       sum_ctx);
+    return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
+}
+
 // the ring-buffered read stream; 1 when the graphs do not fit it (above one edge per thread, rows not a multiple of 64 bytes)
 int ctx_dispatch(const void* e, const float* gates_oi, const int* in_ptr, const int* in_ids, const int* img_ptr, int B, int N, int E, int H,
                  void* ctx2, int max_edges, int max_nodes, int sum_ctx, int dtype, int max_wgs, hipStream_t s) {
@@ -1694,14 +2063,19 @@ extern "C" int sgg_imp_edge_in_fwd(const void* v, const int* so, const float* no
     return SGG_OK;
 }
 
-extern "C" int sgg_imp_ctx_fwd(const void* e, const float* gates_oi, const int* in_ptr, const int* in_ids, const int* img_ptr, int B, int N,
-                               int E, int H, void* ctx2, int max_edges, int max_nodes, int sum_ctx, int dtype, void* stream) {
+extern "C" int sgg_imp_ctx_fwd(const void* e, const float* gates_oi, const int* so, const int* in_ptr, const int* in_ids, const int* img_ptr,
+                               int B, int N, int E, int H, void* ctx2, int max_edges, int max_nodes, int sum_ctx, int dtype, void* stream) {
     if (N == 0 || B == 0) return SGG_OK;
     if (!e || !gates_oi || !in_ptr || !in_ids || !img_ptr || !ctx2 || N < 0 || E < 0 || B < 0 || H <= 0) return SGG_ERR_ARG;
     if (dtype != SGG_BF16 && dtype != SGG_F32) return SGG_ERR_DTYPE;
     const char* mw = getenv("SGG_IMP_MAX_WGS");
-    const int rc = ctx_dispatch(e, gates_oi, in_ptr, in_ids, img_ptr, B, N, E, H, ctx2, max_edges, max_nodes, sum_ctx, dtype,
-                                mw ? atoi(mw) : 0, (hipStream_t)stream);
+    const char* form = getenv("SGG_IMP_CTX");   // kernel experiments / cross-checks: "valu" = the list-walking kernel for every graph
+    int rc = 1;
+    if (!(form && form[0] == 'v'))              // bf16 graphs of <= 32 nodes with (s, o) given: the gate-matrix product on the matrix cores
+        rc = ctx_mfma_dispatch(e, gates_oi, so, img_ptr, B, N, H, ctx2, max_edges, max_nodes, sum_ctx, dtype, mw ? atoi(mw) : 0, (hipStream_t)stream);
+    if (rc == 1)
+        rc = ctx_dispatch(e, gates_oi, in_ptr, in_ids, img_ptr, B, N, E, H, ctx2, max_edges, max_nodes, sum_ctx, dtype, mw ? atoi(mw) : 0,
+                          (hipStream_t)stream);
     return rc == 1 ? SGG_ERR_CAPACITY : rc;
 }
 

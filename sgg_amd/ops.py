@@ -459,8 +459,8 @@ def imp_ctx(e, csr, N, gates_oi, ctx2=None, ctx_sum=None):
     if ctx_sum is None and ctx2 is None:
         ctx2 = torch.empty((2, N, H), dtype=e.dtype, device=e.device)
     dst = ctx_sum if ctx_sum is not None else ctx2
-    _lib.call('sgg_imp_ctx_fwd', _p(e), _p(gates_oi, torch.float32), _p(in_ptr), _p(in_ids), _p(csr.img_ptr), B, N, E, H, _p(dst), max_edges,
-              max_nodes, 1 if ctx_sum is not None else 0, dt(e), _stream())
+    _lib.call('sgg_imp_ctx_fwd', _p(e), _p(gates_oi, torch.float32), _p(so), _p(in_ptr), _p(in_ids), _p(csr.img_ptr), B, N, E, H, _p(dst),
+              max_edges, max_nodes, 1 if ctx_sum is not None else 0, dt(e), _stream())
     return dst
 
 

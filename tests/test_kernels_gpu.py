@@ -617,7 +617,7 @@ def test_imp_persistent_kernels_equal_short_lived_form(ops, dtype, monkeypatch):
     output modes (ctx halves / summed ctx).  A broken capacity promise poisons that graph's outputs in every form."""
     H = 128
     g = torch.Generator().manual_seed(77)
-    for case, sizes in enumerate(([32, 5, 17, 2, 32, 9, 31, 3, 12], [32] * 12, [6, 2, 2], [33, 4])):
+    for case, sizes in enumerate(([32, 5, 17, 2, 32, 9, 31, 3, 12], [32] * 12, [8, 2, 2], [33, 4])):
         im = np.concatenate([np.full(n, b) for b, n in enumerate(sizes)]).astype(np.int64)
         rel = O.get_rel_inds_eval(im)
         if case == 0:
@@ -640,9 +640,12 @@ def test_imp_persistent_kernels_equal_short_lived_form(ops, dtype, monkeypatch):
         ctol = dict(atol=1e-4, rtol=1e-5) if dtype == torch.float32 else dict(atol=0.13, rtol=1.6e-2)   # 2 bf16 ulps
         # (form, piece bytes, edges per chunk): the read stream with half-line and full-line pieces, few chunks per unit and
         # many (small chunks: lists of one node straddle chunk boundaries, the in-list cursors advance across them)
-        for form, piece, eb in (('s', '64', ''), ('s', '128', ''), ('s', '128', '80'), ('s', '64', '64'), ('s', '128', '32'), ('s', '64', '16'), ('1', '', '')):
+        # ctx '' = the read stream's default (bf16 graphs of <= 32 nodes: the gate-matrix product on the matrix cores), 'v' = its
+        # list-walking VALU kernel for every graph
+        for form, piece, eb, ctxf in (('s', '', '', ''), ('s', '', '64', ''), ('s', '', '32', ''), ('s', '64', '', 'v'), ('s', '128', '', 'v'),
+                                      ('s', '128', '80', 'v'), ('s', '64', '64', 'v'), ('s', '128', '32', 'v'), ('s', '64', '16', 'v'), ('1', '', '', '')):
             monkeypatch.setenv('SGG_IMP_STREAM', form)
-            for k_, v_ in (('SGG_IMP_PIECE', piece), ('SGG_IMP_EB', eb)):
+            for k_, v_ in (('SGG_IMP_PIECE', piece), ('SGG_IMP_EB', eb), ('SGG_IMP_CTX', ctxf)):
                 if v_:
                     monkeypatch.setenv(k_, v_)
                 else:
@@ -657,7 +660,7 @@ def test_imp_persistent_kernels_equal_short_lived_form(ops, dtype, monkeypatch):
                 _, csum = ops.imp_sliced(v, e, csr, nd, ed, gb, ctx_sum=torch.empty_like(v))
                 assert torch.equal(e_in, ref_ein), (case, form, piece, eb, cap)
                 # ctx: a node's list is cut into more parts by the 16-wave kernel (other association of the same f32 terms)
-                where = lambda m: '%s %s' % (m, (case, form, piece, eb, cap))  # noqa: E731
+                where = lambda m: '%s %s' % (m, (case, form, piece, eb, ctxf, cap))  # noqa: E731
                 torch.testing.assert_close(ctx2.float(), ref_ctx2.float(), msg=where, **ctol)
                 torch.testing.assert_close(csum.float(), ref_sum.float(), msg=where, **ctol)
                 if first is None:
@@ -665,7 +668,7 @@ def test_imp_persistent_kernels_equal_short_lived_form(ops, dtype, monkeypatch):
                 else:                                                    # the same form is bit-reproducible for every grid size
                     assert all(torch.equal(a, b) for a, b in zip(first, (e_in, ctx2, csum))), (case, form, piece, eb, cap)
         # the split step through its own entry points (what the forward calls): write stream and read stream, any order
-        for k_ in ('SGG_IMP_STREAM', 'SGG_IMP_PIECE', 'SGG_IMP_EB', 'SGG_IMP_MAX_WGS'):
+        for k_ in ('SGG_IMP_STREAM', 'SGG_IMP_PIECE', 'SGG_IMP_EB', 'SGG_IMP_MAX_WGS', 'SGG_IMP_CTX'):
             monkeypatch.delenv(k_, raising=False)
         assert ops.imp_split_ok(csr, H, dtype) == (case < 3)      # case 3: 1056 edges > one per thread -> the forms above fell back
         if case == 3:
@@ -682,7 +685,7 @@ def test_imp_persistent_kernels_equal_short_lived_form(ops, dtype, monkeypatch):
         assert torch.equal(ein_a, ref_ein) and torch.equal(ops.imp_edge_in(v, csr, nd, ed, gb, E), ref_ein), case
         torch.testing.assert_close(ctx_b.float(), ref_ctx2.float(), **ctol)
         torch.testing.assert_close(sum_b.float(), ref_sum.float(), **ctol)
-        # understated capacity (graph 0 promised as 40 edges): its outputs are NaN, the other graphs are untouched
+        # understated capacity (graph 0 has 56 edges, promised: 8): its outputs are NaN, the other graphs are untouched
         if case == 2:
             lie = ops.edge_csr(cu(rel), N, cu(im), graphs=(len(sizes), max(sizes), 8))
             monkeypatch.delenv('SGG_IMP_PIECE', raising=False)
@@ -692,13 +695,13 @@ def test_imp_persistent_kernels_equal_short_lived_form(ops, dtype, monkeypatch):
                 monkeypatch.setenv('SGG_IMP_MAX_WGS', '2')
                 e_in, ctx2 = ops.imp_sliced(v, e, lie, nd, ed, gb)
                 big = torch.from_numpy(rel[:, 0] == 0).to(DEV)
-                assert torch.isnan(ctx2[:, :6].float()).all(), form
+                assert torch.isnan(ctx2[:, :8].float()).all(), form
                 if form == 's':                                          # the write stream uses no graph structure: nothing to break
                     assert torch.equal(e_in, ref_ein)
-                    torch.testing.assert_close(ctx2[:, 6:].float(), ref_ctx2[:, 6:].float(), **ctol)
+                    torch.testing.assert_close(ctx2[:, 8:].float(), ref_ctx2[:, 8:].float(), **ctol)
                 else:
                     assert torch.isnan(e_in[big].float()).all(), form
-                    assert torch.equal(e_in[~big], ref_ein[~big]) and torch.equal(ctx2[:, 6:], ref_ctx2[:, 6:]), form
+                    assert torch.equal(e_in[~big], ref_ein[~big]) and torch.equal(ctx2[:, 8:], ref_ctx2[:, 8:]), form
 
 
 def test_imp_sliced_capacity_and_fallback(ops):
