@@ -156,7 +156,8 @@ def pmc_traffic(key):
 def imp_iter_ms(model, B, dtype, reps=50, kind='sliced'):
     """Average duration of ONE IMP gather/gate/scatter launch on a complete 32-box/image graph of B images: `reps` launches
     back-to-back between two HIP events on the launch stream (outputs pre-allocated).  kind: 'sliced' (the kernel the forward
-    runs: every edge row read once, gate dot products supplied by the GRU gate kernels) or 'fused' (node-centric, any graph)."""
+    runs: every edge row read once, gate dot products supplied by the GRU gate kernels), 'fused' (node-centric, any graph),
+    'write' / 'read' (the two kernels of the split step: sgg_imp_edge_in_fwd, sgg_imp_ctx_fwd)."""
     import torch
     from sgg_amd import ops
     dev = model.rel_fc.weight.device
@@ -171,11 +172,17 @@ def imp_iter_ms(model, B, dtype, reps=50, kind='sliced'):
     e = torch.randn(E, H, generator=g).to(dev).to(dtype)
     imp = model.prepared()['imp']
     e_in, ctx2 = torch.empty_like(e), torch.empty((2, N, H), dtype=dtype, device=dev)
-    if kind == 'sliced':
+    if kind in ('sliced', 'write', 'read'):
         assert ops.imp_sliced_ok(csr, H, dtype)
         nd = (v.float() @ imp.gate_w[:, :H].t()).contiguous()     # what sgg_gru_gate_fwd's dot epilogue hands over
         ed = (e.float() @ imp.gate_w[:, H:].t()).contiguous()
-        launch = lambda: ops.imp_sliced(v, e, csr, nd, ed, imp.gate_b, e_in, ctx2)
+        if kind == 'sliced':
+            launch = lambda: ops.imp_sliced(v, e, csr, nd, ed, imp.gate_b, e_in, ctx2)
+        else:                 # the two halves of the split step (opt-in entry points): write stream (e_in + gates), read stream (ctx)
+            gates = torch.empty((E, 2), dtype=torch.float32, device=dev)
+            ops.imp_edge_in(v, csr, nd, ed, imp.gate_b, E, e_in=e_in, gates_oi=gates)
+            launch = (lambda: ops.imp_edge_in(v, csr, nd, ed, imp.gate_b, E, e_in=e_in, gates_oi=gates)) if kind == 'write' else \
+                (lambda: ops.imp_ctx(e, csr, N, gates, ctx2=ctx2))
     else:
         launch = lambda: ops.imp_fused(v, e, rel, csr, imp.gate_w_c, imp.gate_b, e_in, ctx2)
     for _ in range(3):
@@ -404,6 +411,9 @@ def main():
         BL = 128                                                 # same kernel on a graph that fills the chip
         impL_ms = imp_iter_ms(model, BL, tdtype)
         imp_old = {'B%d' % b_: round(imp_iter_ms(model, b_, tdtype, kind='fused'), 5) for b_ in (B, BL)}   # node-centric kernel, for comparison
+        # the split step's two kernels (opt-in entry points), same graphs, for comparison
+        imp_split = {'B%d' % b_: {k_: round(imp_iter_ms(model, b_, tdtype, kind=k_), 5) for k_ in ('write', 'read')} for b_ in (B, BL)} \
+            if tdtype == torch.bfloat16 else None
         impL_bytes = (2.0 * (992 * BL + 32 * BL) * H) * s + 8.0 * 992 * BL
         impL_gbs = impL_bytes / (impL_ms * 1e-3) / 1e9
         # context for the fraction: what a plain device-to-device copy moving the same number of bytes (half read, half written)
@@ -506,7 +516,7 @@ def main():
                                    'frac': round(impL_gbs / HBM_PEAK_GBS, 4),
                                    'traffic': pmc_traffic('imp_sliced_B128') if args.dtype == 'bf16' else None,
                                    'algorithmic_bytes': impL_bytes, 'avg_launch_ms': round(impL_ms, 5),
-                                   'node_centric_kernel_ms': imp_old,
+                                   'node_centric_kernel_ms': imp_old, 'split_step_kernels_ms': imp_split,
                                    'device_copy_same_bytes': {'GB/s': round(copy_gbs, 1), 'frac_of_copy': round(impL_gbs / copy_gbs, 4)}},
             'kernels': {'sum_kernel_ms_per_step': round(total_ms, 3),
                         'vgg16_ms': round(conv_ms, 3), 'vgg16_tflops': round(vgg_flop / (conv_ms * 1e-3) / 1e12, 1) if conv_ms else 0,
