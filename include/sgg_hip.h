@@ -209,6 +209,11 @@ int sgg_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C, int 
 int sgg_plane_copy(const void* src, int Hs, int Ws, int src_pad, void* dst, int Hd, int Wd, int dst_pad, int B, int C, int stride, int dtype,
                    void* stream);
 int sgg_add_relu(void* y, const void* x, int64_t n, int dtype, void* stream);
+/* The whole step in one launch of the matrix-core kernel (bf16, graphs of <= 32 nodes / <= 1024 edges, rows a multiple of 128 bytes;
+ * SGG_ERR_CAPACITY otherwise): gates from node_dots / edge_dots / gate_b, e_in, ctx2 as sgg_imp_sliced_fwd (ctx sums with bf16 gates). */
+int sgg_imp_step_fwd(const void* v, const void* e, const int* so /*[E,2]*/, const int* img_ptr, int B, int N, int E, int H,
+                     const float* node_dots, const float* edge_dots, const float* gate_b, void* e_in, void* ctx2, int max_edges, int max_nodes,
+                     int sum_ctx, int dtype, void* stream);
 /* img_ptr i32[2*(B+1) + 66*B]: img_ptr[b] = first node of graph b (im_inds i64[N] ascending), img_ptr[B] = N; then
  * img_ptr[B+1+b] = out_ptr[first node of b] = first edge of graph b (out_ptr from sgg_edge_csr, same stream, edges sorted);
  * then per graph 66 graph-relative out-list offsets of its nodes (entries past the last node repeat the edge count). */

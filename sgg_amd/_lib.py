@@ -52,6 +52,7 @@ SIGNATURES = {
     'sgg_imp_sliced_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sgg_imp_edge_in_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     'sgg_imp_ctx_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P],
+    'sgg_imp_step_fwd': [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sgg_graph_ptr': [_P, _I, _I, _P, _P, _P],
     'sgg_im2col': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     'sgg_maxpool3x3s2': [_P, _P, _I, _I, _I, _I, _I, _P],

@@ -1289,7 +1289,6 @@ __global__ __launch_bounds__(DM_THREADS) void imp_ctx_kernel(
     int loaded = min(nunits, 3);
     // producer position: unit ordinal pu, chunk pb; ring slot pr
     int pu = 0, pb = 0, pr = 0, issued_chunks = 0;
-    static_assert(NBUF == 4, "four ring slots, four marks");
     int mk0 = 0, mk1 = 0, mk2 = 0, mk3 = 0;                      // ci after the DMA of the chunk in ring slot r was issued
     auto mark_of = [&](int r) __attribute__((always_inline)) { return r == 0 ? mk0 : r == 1 ? mk1 : r == 2 ? mk2 : mk3; };
     int cu = 0;                                                  // consumer unit ordinal
@@ -1535,9 +1534,18 @@ typedef __attribute__((ext_vector_type(8))) __bf16 mf_bf16x8;
 typedef __attribute__((ext_vector_type(4))) short mf_s16x4;
 typedef __attribute__((ext_vector_type(8))) short mf_s16x8;
 typedef __attribute__((address_space(3))) mf_s16x4 mf_lds_s16x4;
-constexpr int MF_NBUF = 4, MF_NODES = 32;
+constexpr int MF_NBUF = 4, MF_NBUF_STEP = 3, MF_NODES = 32;
 constexpr int mfma_set_words(int emax) { return 4 * ctx_epad(emax); }                // raw: g_out, g_in, subject id, object id per edge
 constexpr int mfma_fixed_bytes(int emax) { return mfma_set_words(emax) * 4 + 6 * ctx_epad(emax); }   // + packed: 2 x bf16 gates, 2 x byte ids
+// whole-step form: raw = 4 dots + 2 ids per edge; packed + g_sub, g_obj (f32); vertex dots (one 1 KiB DMA); two copies of 32 vertex pieces
+constexpr int mfma_fixed_bytes_step(int emax) { return 6 * ctx_epad(emax) * 4 + 6 * ctx_epad(emax) + 8 * ctx_epad(emax) + 1024 + 2 * MF_NODES * 128; }
+constexpr int mfma_chunk_edges_step(int emax) {
+    const int room = (DM_LDS_MAX - mfma_fixed_bytes_step(emax)) / (MF_NBUF_STEP * 128);
+    const int need = (emax + 31) / 32 * 32;
+    const int eb = (room < need ? room : need) / 32 * 32;
+    return eb > 256 ? 256 : eb;                               // 8 K steps per chunk: two for each of the four K-quarter waves
+}
+static_assert(mfma_chunk_edges_step(992) == 256, "imp_ctx_mfma_kernel<STEP>: a 992-edge graph goes through in four 256-row chunks");
 constexpr int mfma_chunk_edges(int emax) {
     const int room = (DM_LDS_MAX - mfma_fixed_bytes(emax)) / (MF_NBUF * 128);
     const int need = (emax + 31) / 32 * 32;
@@ -1552,18 +1560,28 @@ __device__ __forceinline__ void dma16_to_lds_s(const void* sbase, unsigned voff,
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_base), "v"(voff), "s"(sbase) : "memory");
 }
 
+template <bool STEP>
 __global__ __launch_bounds__(DM_THREADS) void imp_ctx_mfma_kernel(
     const bf16_t* __restrict__ e, const float* __restrict__ gates_oi, const int* __restrict__ so, const int* __restrict__ img_ptr, int B,
-    int N, int H, bf16_t* __restrict__ ctx2, int EMAX, int EB, int sum_ctx) {
-    constexpr int PIECE = 128, CHAN = 64, NBUF = MF_NBUF;
+    int N, int H, bf16_t* __restrict__ ctx2, int EMAX, int EB, int sum_ctx,
+    // STEP (the whole IMP step in this kernel): vertex rows, the gate dot products and bias, the edge-input rows to write
+    const bf16_t* __restrict__ v, const float* __restrict__ ndots, const float* __restrict__ edots, const float* __restrict__ gb,
+    bf16_t* __restrict__ e_in) {
+    constexpr int PIECE = 128, CHAN = 64, NBUF = STEP ? MF_NBUF_STEP : MF_NBUF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int EPAD = ctx_epad(EMAX), SETW = 4 * EPAD;
+    const int EPAD = ctx_epad(EMAX), SETW = (STEP ? 6 : 4) * EPAD;
     char* const ring = smem;                                                          // [NBUF][EB][128 B], rows swizzled
-    int* const sets = reinterpret_cast<int*>(ring + (long)NBUF * EB * PIECE);        // raw [4][EPAD]: g_out, g_in (f32), subject, object (global ids)
+    // raw per-edge arrays as the DMA leaves them: g_out, g_in (f32), subject, object (global ids) [4][EPAD]; STEP: the edge's four
+    // gate dot products [EPAD][4] f32, then subject, object
+    int* const sets = reinterpret_cast<int*>(ring + (long)NBUF * EB * PIECE);
     // what the K steps read, made from the raw arrays at the start of a unit: gates as bf16 (what the A fragment holds anyway) and
     // node ids as bytes (graph-local; 0xff = no node): 24 instead of 64 bytes per lane and K step
     unsigned short* const gbf = reinterpret_cast<unsigned short*>(sets + SETW);       // [2][EPAD] bf16 g_out | g_in
     unsigned char* const nid = reinterpret_cast<unsigned char*>(gbf + 2 * EPAD);      // [2][EPAD] subject | object
+    // STEP only: g_sub | g_obj (f32: the edge inputs are exact), the graph's vertex dots, two copies of its vertex pieces (this slice)
+    float* const gso = reinterpret_cast<float*>(nid + 2 * EPAD);                      // [2][EPAD]
+    float* const ndl = gso + 2 * EPAD;                                                // [64][4] (one DMA instruction: 64 lanes x 16 bytes)
+    char* const vsb = reinterpret_cast<char*>(ndl + 256);                             // [2][MF_NODES][128 B]
     const unsigned ring_lds = (unsigned)(unsigned long)(lds_char_t*)smem;
     const unsigned sets_lds = ring_lds + (unsigned)(NBUF * EB * PIECE);
 
@@ -1632,15 +1650,37 @@ __global__ __launch_bounds__(DM_THREADS) void imp_ctx_mfma_kernel(
         }
     };
     // the four per-edge arrays of h's graph -> set q: lane t of the workgroup <-> edge t
-    auto issue_small = [&](const Hdr& h) __attribute__((always_inline)) {
+    // the per-edge arrays of h's graph -> raw: lane t of the workgroup <-> edge t (STEP: also the vertex dots, and the vertex pieces
+    // of h's slice into copy `vq`)
+    auto issue_small = [&](const Hdr& h, int vq) __attribute__((always_inline)) {
         if (wv * 64 < h.Ee) {
-            const unsigned set_lds = sets_lds;
             const long et = h.e0 + min(tid, h.Ee - 1);
-            dma4_to_lds(gates_oi + 2 * et, __builtin_amdgcn_readfirstlane(set_lds + (unsigned)(wv * 256)));
-            dma4_to_lds(gates_oi + 2 * et + 1, __builtin_amdgcn_readfirstlane(set_lds + (unsigned)((EPAD + wv * 64) * 4)));
-            dma4_to_lds(so + 2 * et, __builtin_amdgcn_readfirstlane(set_lds + (unsigned)((2 * EPAD + wv * 64) * 4)));
-            dma4_to_lds(so + 2 * et + 1, __builtin_amdgcn_readfirstlane(set_lds + (unsigned)((3 * EPAD + wv * 64) * 4)));
-            ci += 4;
+            if constexpr (STEP) {
+                dma16_to_lds(edots + 4 * et, __builtin_amdgcn_readfirstlane(sets_lds + (unsigned)(wv * 1024)));
+                dma4_to_lds(so + 2 * et, __builtin_amdgcn_readfirstlane(sets_lds + (unsigned)((4 * EPAD + wv * 64) * 4)));
+                dma4_to_lds(so + 2 * et + 1, __builtin_amdgcn_readfirstlane(sets_lds + (unsigned)((5 * EPAD + wv * 64) * 4)));
+                ci += 3;
+            } else {
+                dma4_to_lds(gates_oi + 2 * et, __builtin_amdgcn_readfirstlane(sets_lds + (unsigned)(wv * 256)));
+                dma4_to_lds(gates_oi + 2 * et + 1, __builtin_amdgcn_readfirstlane(sets_lds + (unsigned)((EPAD + wv * 64) * 4)));
+                dma4_to_lds(so + 2 * et, __builtin_amdgcn_readfirstlane(sets_lds + (unsigned)((2 * EPAD + wv * 64) * 4)));
+                dma4_to_lds(so + 2 * et + 1, __builtin_amdgcn_readfirstlane(sets_lds + (unsigned)((3 * EPAD + wv * 64) * 4)));
+                ci += 4;
+            }
+        }
+        if constexpr (STEP) {
+            if (h.Ee >= 0 && h.Nn > 0) {
+                const unsigned ndl_lds = (unsigned)(unsigned long)(lds_char_t*)ndl;
+                if (wv == 0) {                                   // vertex dots: lane n <-> node n
+                    dma16_to_lds(ndots + 4L * (h.n0 + min(lane, h.Nn - 1)), __builtin_amdgcn_readfirstlane(ndl_lds));
+                    ++ci;
+                } else if (wv <= MF_NODES / 8) {                 // vertex pieces: 8 nodes x 128 bytes per instruction
+                    const int n = min((wv - 1) * 8 + (lane >> 3), h.Nn - 1);
+                    dma16_to_lds(reinterpret_cast<const char*>(v) + ((long)(h.n0 + n) * H + (long)h.slice * CHAN) * 2 + (lane & 7) * 16,
+                                 __builtin_amdgcn_readfirstlane(ndl_lds + 1024u + (unsigned)(vq * MF_NODES * PIECE + (wv - 1) * 1024)));
+                    ++ci;
+                }
+            }
         }
     };
 
@@ -1684,7 +1724,7 @@ __global__ __launch_bounds__(DM_THREADS) void imp_ctx_mfma_kernel(
     for (int k = tid; k < NBUF * EB * PIECE / 16; k += DM_THREADS) reinterpret_cast<u32x4*>(ring)[k] = u32x4{0, 0, 0, 0};
     __syncthreads();
     int mark_small;
-    issue_small(h0);
+    issue_small(h0, 0);
     mark_small = ci;
     for (int d = 0; d < NBUF - 1; ++d) produce();
     int cr = 0, consumed = 0;
@@ -1708,7 +1748,20 @@ __global__ __launch_bounds__(DM_THREADS) void imp_ctx_mfma_kernel(
         { [[maybe_unused]] const int unit_no = consumed; SGG_DTICK(0) }
         wait_mark(max(mark_small, mark_of(cr)));
         __syncthreads();                                         // (B) this unit's raw per-edge arrays and first chunk, every wave's parts
-        {   // thread t: edge t -> bf16 gates, byte node ids (every wave has left the last unit: the packed arrays are free)
+        if (tid >= EPAD) {
+            // (the per-edge arrays hold EPAD entries: small graphs leave most threads without an edge)
+        } else if constexpr (STEP) {   // thread t: edge t -> its four gates (rel_model_stanford.py:78-89), byte node ids
+            const bool live = tid < hc.Ee;
+            const int sl = live ? sets[4 * EPAD + tid] - hc.n0 : 0, ol = live ? sets[5 * EPAD + tid] - hc.n0 : 0;
+            const f32x4 de = reinterpret_cast<const f32x4*>(sets)[tid];
+            const f32x4 ns = reinterpret_cast<const f32x4*>(ndl)[sl], no = reinterpret_cast<const f32x4*>(ndl)[ol];
+            gso[tid] = sigmoidf_(ns.x + de.x + gb[0]);                               // sub_vert (v[s])
+            gso[EPAD + tid] = sigmoidf_(no.y + de.y + gb[1]);                        // obj_vert (v[o])
+            gbf[tid] = live ? (unsigned short)(pack_bf16x2(sigmoidf_(ns.z + de.z + gb[2]), 0.f) & 0xffffu) : (unsigned short)0;          // out_edge
+            gbf[EPAD + tid] = live ? (unsigned short)(pack_bf16x2(sigmoidf_(no.w + de.w + gb[3]), 0.f) & 0xffffu) : (unsigned short)0;   // in_edge
+            nid[tid] = live ? (unsigned char)sl : (unsigned char)0xff;
+            nid[EPAD + tid] = live ? (unsigned char)ol : (unsigned char)0xff;
+        } else {   // thread t: edge t -> bf16 gates, byte node ids (every wave has left the last unit: the packed arrays are free)
             const float* graw = reinterpret_cast<const float*>(sets);
             const bool live = tid < hc.Ee;
             gbf[tid] = live ? (unsigned short)(pack_bf16x2(graw[tid], 0.f) & 0xffffu) : (unsigned short)0;
@@ -1718,7 +1771,7 @@ __global__ __launch_bounds__(DM_THREADS) void imp_ctx_mfma_kernel(
         }
         __syncthreads();                                         // (C) packed arrays visible; the raw arrays are free
         if (cu + 1 < nunits) {
-            issue_small(h1);                                     // the next unit's raw arrays
+            issue_small(h1, (cu + 1) & 1);                       // the next unit's raw arrays (and the other copy of the vertex pieces)
             mark_small = ci;
         }
         const unsigned short* const gate = gbf + dir * EPAD;     // g_out | g_in
@@ -1734,6 +1787,24 @@ __global__ __launch_bounds__(DM_THREADS) void imp_ctx_mfma_kernel(
         for (int cb = 0; cb < nchunks; ++cb) {
             const int blo = cb * EB, bhi = min(blo + EB, max(hc.Ee, 0));
             [[maybe_unused]] const int unit_no = consumed;
+            if constexpr (STEP) {
+                // the edge inputs of this chunk's edges, e_in = g_sub v[s] + g_obj v[o] (rel_model_stanford.py:78-81): they need no edge
+                // row, so they are made while the chunk's DMA is still landing.  Lane group (8 lanes x 16 bytes) <-> row piece.
+                const char* vq = vsb + (cu & 1) * MF_NODES * PIECE + (tid & 7) * 16;
+                for (int r = blo + (tid >> 3); r < bhi; r += DM_THREADS / 8) {
+                    const float gs = gso[r], go = gso[EPAD + r];
+                    Piece16<bf16_t> ps, po;
+                    ps.r = *reinterpret_cast<const u32x4*>(vq + nid[r] * PIECE);
+                    po.r = *reinterpret_cast<const u32x4*>(vq + nid[EPAD + r] * PIECE);
+                    float vn[8], yy[8], rr[8];
+                    ps.get(vn);
+                    po.get(yy);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) rr[j] = gs * vn[j] + go * yy[j];
+                    store8(e_in + ((long)(hc.e0 + r) * H + hc.slice * CHAN + (tid & 7) * 8), rr);
+                }
+                for (int r0 = blo + wv * 8; r0 < bhi; r0 += DM_THREADS / 8) ++ci;      // this wave's store instructions (vmcnt counts them)
+            }
             if (cb > 0) {
                 SGG_DTICK(0)
                 wait_mark(mark_of(cr));
@@ -1795,8 +1866,9 @@ __global__ __launch_bounds__(DM_THREADS) void imp_ctx_mfma_kernel(
         lds_reads_done_barrier();                                // (E1) every wave has left the unit's last chunk
         // [8 regions][16 registers][64 lanes] f32 = 32 KiB: the slot itself when it is that large (256-row chunks), else a region of
         // its own behind the sets
+        char* const fixed_end = STEP ? vsb + 2 * MF_NODES * PIECE : reinterpret_cast<char*>(nid + 2 * EPAD);
         float* const scratch = EB * PIECE >= 32768 ? reinterpret_cast<float*>(ring + last_slot * EB * PIECE)
-                                                   : reinterpret_cast<float*>(smem + NBUF * EB * PIECE + ((SETW * 4 + 6 * EPAD + 15) & ~15));
+                                                   : reinterpret_cast<float*>(smem + (((fixed_end - smem) + 15) & ~15L));
         auto region = [&](int d, int m, int h) __attribute__((always_inline)) {
             return reinterpret_cast<f32x4*>(scratch + ((d * 2 + m) * 2 + h) * 1024) + lane;        // [4 tiles][64 lanes] x 16 bytes
         };
@@ -1838,6 +1910,13 @@ __global__ __launch_bounds__(DM_THREADS) void imp_ctx_mfma_kernel(
                 const long o = (long)(n0 + k / CHAN) * H + hc.slice * CHAN + k % CHAN;
                 ctx2[o] = f32_to_bf16(__builtin_nanf(""));
                 if (!sum_ctx) ctx2[(long)N * H + o] = f32_to_bf16(__builtin_nanf(""));
+            }
+            if constexpr (STEP) {
+                u32x2 ee;
+                asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(ee) : "s"(img_ptr + (B + 1 + __builtin_amdgcn_readfirstlane(hc.g))) : "memory");
+                const int e0 = (int)ee.x, Ee = (int)ee.y - e0;
+                for (long k = tid; k < (long)Ee * CHAN; k += DM_THREADS)
+                    e_in[(e0 + k / CHAN) * H + hc.slice * CHAN + k % CHAN] = f32_to_bf16(__builtin_nanf(""));
             }
         }
         { [[maybe_unused]] const int unit_no = consumed - 1; SGG_DTICK(6) }
@@ -1989,29 +2068,32 @@ int launch_ctx(const void* e, const float* gates_oi, const int* in_ptr, const in
     return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
 }
 
-// the matrix-core read stream (bf16, <= 32 nodes and <= 1024 edges per graph, rows a multiple of 128 bytes); 1 when it does not apply
-int ctx_mfma_dispatch(const void* e, const float* gates_oi, const int* so, const int* img_ptr, int B, int N, int H, void* ctx2, int max_edges,
-                      int max_nodes, int sum_ctx, int dtype, int max_wgs, hipStream_t s) {
+// the matrix-core read stream / whole step (bf16, <= 32 nodes and <= 1024 edges per graph, rows a multiple of 128 bytes); 1 when it
+// does not apply.  step: v, node_dots, edge_dots, gate_b, e_in given -> the kernel also makes the gates and the edge inputs.
+int ctx_mfma_dispatch(bool step, const void* e, const float* gates_oi, const int* so, const int* img_ptr, int B, int N, int H, void* ctx2,
+                      int max_edges, int max_nodes, int sum_ctx, int dtype, int max_wgs, hipStream_t s, const void* v = nullptr,
+                      const float* node_dots = nullptr, const float* edge_dots = nullptr, const float* gate_b = nullptr, void* e_in = nullptr) {
     if (dtype != SGG_BF16 || !so || max_nodes > MF_NODES || max_edges > DM_EMAX || (H * 2) % 128) return 1;
     const int emax = (max(max_edges, 32) + 31) & ~31;
-    int eb = mfma_chunk_edges(emax);
+    int eb = step ? mfma_chunk_edges_step(emax) : mfma_chunk_edges(emax);
     const char* ebs = getenv("SGG_IMP_EB");     // tests: small chunks (many per unit on small graphs)
     if (ebs && atoi(ebs) >= 32) eb = min(eb, atoi(ebs) & ~31);
     if (eb < 32) return 1;
-    auto k = imp_ctx_mfma_kernel;
-    static bool configured = false;
-    if (!configured) {
+    auto k = step ? imp_ctx_mfma_kernel<true> : imp_ctx_mfma_kernel<false>;
+    static bool configured[2] = {false, false};
+    if (!configured[step]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS_MAX) != hipSuccess)
             return SGG_ERR_LAUNCH;
-        configured = true;
+        configured[step] = true;
     }
     const int units = B * (H * 2 / 128);
     int grid = min(units, 256);
     if (max_wgs > 0) grid = min(grid, max_wgs);
-    const int smem = MF_NBUF * eb * 128 + mfma_fixed_bytes(emax) + (eb * 128 >= 32768 ? 0 : 32768 + 16);
+    const int smem = (step ? MF_NBUF_STEP : MF_NBUF) * eb * 128 + (step ? mfma_fixed_bytes_step(emax) : mfma_fixed_bytes(emax)) +
+                     (eb * 128 >= 32768 ? 0 : 32768 + 16);
     if (smem > DM_LDS_MAX) return 1;
     hipLaunchKernelGGL(k, dim3(grid), dim3(DM_THREADS), smem, s, (const bf16_t*)e, gates_oi, so, img_ptr, B, N, H, (bf16_t*)ctx2, emax, eb,
-                       sum_ctx);
+                       sum_ctx, (const bf16_t*)v, node_dots, edge_dots, gate_b, (bf16_t*)e_in);
     return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
 }
 
@@ -2072,10 +2154,26 @@ extern "C" int sgg_imp_ctx_fwd(const void* e, const float* gates_oi, const int* 
     const char* form = getenv("SGG_IMP_CTX");   // kernel experiments / cross-checks: "valu" = the list-walking kernel for every graph
     int rc = 1;
     if (!(form && form[0] == 'v'))              // bf16 graphs of <= 32 nodes with (s, o) given: the gate-matrix product on the matrix cores
-        rc = ctx_mfma_dispatch(e, gates_oi, so, img_ptr, B, N, H, ctx2, max_edges, max_nodes, sum_ctx, dtype, mw ? atoi(mw) : 0, (hipStream_t)stream);
+        rc = ctx_mfma_dispatch(false, e, gates_oi, so, img_ptr, B, N, H, ctx2, max_edges, max_nodes, sum_ctx, dtype, mw ? atoi(mw) : 0, (hipStream_t)stream);
     if (rc == 1)
         rc = ctx_dispatch(e, gates_oi, in_ptr, in_ids, img_ptr, B, N, E, H, ctx2, max_edges, max_nodes, sum_ctx, dtype, mw ? atoi(mw) : 0,
                           (hipStream_t)stream);
+    return rc == 1 ? SGG_ERR_CAPACITY : rc;
+}
+
+// One launch for the whole step on the matrix-core kernel: gates from the dot products, e_in = g_sub v[s] + g_obj v[o], the two context
+// sums.  bf16, graphs of <= 32 nodes / <= 1024 edges, rows a multiple of 128 bytes: SGG_ERR_CAPACITY otherwise.
+extern "C" int sgg_imp_step_fwd(const void* v, const void* e, const int* so, const int* img_ptr, int B, int N, int E, int H,
+                                const float* node_dots, const float* edge_dots, const float* gate_b, void* e_in, void* ctx2, int max_edges,
+                                int max_nodes, int sum_ctx, int dtype, void* stream) {
+    if (N == 0 || B == 0) return SGG_OK;
+    if (!v || !e || !so || !img_ptr || !node_dots || !edge_dots || !gate_b || !e_in || !ctx2 || N < 0 || E < 0 || B < 0 || H <= 0)
+        return SGG_ERR_ARG;
+    if (dtype != SGG_BF16 && dtype != SGG_F32) return SGG_ERR_DTYPE;
+    if ((long)E * H * 2 >= 0xffff0000L) return SGG_ERR_SPAN;
+    const char* mw = getenv("SGG_IMP_MAX_WGS");
+    const int rc = ctx_mfma_dispatch(true, e, nullptr, so, img_ptr, B, N, H, ctx2, max_edges, max_nodes, sum_ctx, dtype, mw ? atoi(mw) : 0,
+                                     (hipStream_t)stream, v, node_dots, edge_dots, gate_b, e_in);
     return rc == 1 ? SGG_ERR_CAPACITY : rc;
 }
 

@@ -417,6 +417,8 @@ def imp_sliced(v, e, csr, node_dots, edge_dots, gate_b, e_in=None, ctx2=None, ct
     E = e.shape[0]
     if os.environ.get('SGG_IMP_STREAM') == 's' and imp_split_ok(csr, H, v.dtype):     # kernel experiments / cross-checks
         return imp_split(v, e, csr, node_dots, edge_dots, gate_b, e_in=e_in, ctx2=ctx2, ctx_sum=ctx_sum)
+    if os.environ.get('SGG_IMP_STREAM') == 'm' and imp_step_ok(csr, H, v.dtype):
+        return imp_step(v, e, csr, node_dots, edge_dots, gate_b, e_in=e_in, ctx2=ctx2, ctx_sum=ctx_sum)
     out_ptr, out_ids, in_ptr, in_ids, so, flags = csr
     B, max_nodes, max_edges = csr.graphs
     if e_in is None:
@@ -462,6 +464,28 @@ def imp_ctx(e, csr, N, gates_oi, ctx2=None, ctx_sum=None):
     _lib.call('sgg_imp_ctx_fwd', _p(e), _p(gates_oi, torch.float32), _p(so), _p(in_ptr), _p(in_ids), _p(csr.img_ptr), B, N, E, H, _p(dst),
               max_edges, max_nodes, 1 if ctx_sum is not None else 0, dt(e), _stream())
     return dst
+
+
+def imp_step_ok(csr, H, dtype):
+    """True when the one-launch matrix-core step (sgg_imp_step_fwd) takes these graphs"""
+    g = getattr(csr, 'graphs', None)
+    return imp_sliced_ok(csr, H, dtype) and dtype == torch.bfloat16 and g[1] <= 32 and g[2] <= 1024 and (H * 2) % 128 == 0
+
+
+def imp_step(v, e, csr, node_dots, edge_dots, gate_b, e_in=None, ctx2=None, ctx_sum=None):
+    """The whole IMP step on the matrix-core kernel: -> (e_in [E,H], ctx2 [2,N,H]) or (e_in, ctx_sum [N,H]); same contract as imp_sliced."""
+    N, H = v.shape
+    E = e.shape[0]
+    so = csr[4]
+    B, max_nodes, max_edges = csr.graphs
+    if e_in is None:
+        e_in = torch.empty_like(e)
+    if ctx_sum is None and ctx2 is None:
+        ctx2 = torch.empty((2, N, H), dtype=v.dtype, device=v.device)
+    dst = ctx_sum if ctx_sum is not None else ctx2
+    _lib.call('sgg_imp_step_fwd', _p(v), _p(e), _p(so), _p(csr.img_ptr), B, N, E, H, _p(node_dots, torch.float32), _p(edge_dots, torch.float32),
+              _p(gate_b, torch.float32), _p(e_in), _p(dst), max_edges, max_nodes, 1 if ctx_sum is not None else 0, dt(v), _stream())
+    return e_in, dst
 
 
 def imp_split(v, e, csr, node_dots, edge_dots, gate_b, e_in=None, ctx2=None, ctx_sum=None, gates_oi=None):

@@ -45,9 +45,10 @@ for B in Bs:
     gates = torch.empty((E, 2), device=dev)
     ops.imp_edge_in(v, csr, nd, ed, gb, E, e_in=e_in, gates_oi=gates)
     for form in forms:
-        os.environ['SGG_IMP_STREAM'] = form if form not in ('A', 'B', 'par') else '0'
+        os.environ['SGG_IMP_STREAM'] = form if form not in ('A', 'B', 'par', 'm') else '0'
         launch = {'A': lambda: ops.imp_edge_in(v, csr, nd, ed, gb, E, e_in=e_in, gates_oi=gates), 'B': lambda: ops.imp_ctx(e, csr, N, gates, ctx2=ctx2),
                   's': lambda: ops.imp_split(v, e, csr, nd, ed, gb, e_in=e_in, ctx2=ctx2, gates_oi=gates),
+                  'm': lambda: ops.imp_step(v, e, csr, nd, ed, gb, e_in=e_in, ctx2=ctx2),
                   'par': par}.get(form, lambda: ops.imp_sliced(v, e, csr, nd, ed, gb, e_in, ctx2))
         for _ in range(3):
             launch()
