@@ -172,12 +172,14 @@ def imp_iter_ms(model, B, dtype, reps=50, kind='sliced'):
     e = torch.randn(E, H, generator=g).to(dev).to(dtype)
     imp = model.prepared()['imp']
     e_in, ctx2 = torch.empty_like(e), torch.empty((2, N, H), dtype=dtype, device=dev)
-    if kind in ('sliced', 'write', 'read'):
+    if kind in ('sliced', 'write', 'read', 'step_mfma'):
         assert ops.imp_sliced_ok(csr, H, dtype)
         nd = (v.float() @ imp.gate_w[:, :H].t()).contiguous()     # what sgg_gru_gate_fwd's dot epilogue hands over
         ed = (e.float() @ imp.gate_w[:, H:].t()).contiguous()
         if kind == 'sliced':
             launch = lambda: ops.imp_sliced(v, e, csr, nd, ed, imp.gate_b, e_in, ctx2)
+        elif kind == 'step_mfma':   # the whole step in one launch of the matrix-core kernel (opt-in entry point sgg_imp_step_fwd)
+            launch = lambda: ops.imp_step(v, e, csr, nd, ed, imp.gate_b, e_in, ctx2)
         else:                 # the two halves of the split step (opt-in entry points): write stream (e_in + gates), read stream (ctx)
             gates = torch.empty((E, 2), dtype=torch.float32, device=dev)
             ops.imp_edge_in(v, csr, nd, ed, imp.gate_b, E, e_in=e_in, gates_oi=gates)
@@ -411,8 +413,8 @@ def main():
         BL = 128                                                 # same kernel on a graph that fills the chip
         impL_ms = imp_iter_ms(model, BL, tdtype)
         imp_old = {'B%d' % b_: round(imp_iter_ms(model, b_, tdtype, kind='fused'), 5) for b_ in (B, BL)}   # node-centric kernel, for comparison
-        # the split step's two kernels (opt-in entry points), same graphs, for comparison
-        imp_split = {'B%d' % b_: {k_: round(imp_iter_ms(model, b_, tdtype, kind=k_), 5) for k_ in ('write', 'read')} for b_ in (B, BL)} \
+        # the split step's two kernels and the one-launch matrix-core step (opt-in entry points), same graphs
+        imp_split = {'B%d' % b_: {k_: round(imp_iter_ms(model, b_, tdtype, kind=k_), 5) for k_ in ('write', 'read', 'step_mfma')} for b_ in (B, BL)} \
             if tdtype == torch.bfloat16 else None
         impL_bytes = (2.0 * (992 * BL + 32 * BL) * H) * s + 8.0 * 992 * BL
         impL_gbs = impL_bytes / (impL_ms * 1e-3) / 1e9

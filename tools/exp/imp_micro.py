@@ -80,8 +80,11 @@ for B in Bs:
             torch.cuda.synchronize()
             print('   eager %s: %.2f us per step' % (name, e0.elapsed_time(e1) * 5))
     lib = _lib.load()
-    if hasattr(lib, 'sgg_dbg_dma_ticks') and 'B' in forms:
-        ops.imp_ctx(e, csr, N, gates, ctx2=ctx2)
+    if hasattr(lib, 'sgg_dbg_dma_ticks') and ('B' in forms or 'm' in forms):
+        if 'm' in forms:
+            ops.imp_step(v, e, csr, nd, ed, gb, e_in=e_in, ctx2=ctx2)
+        else:
+            ops.imp_ctx(e, csr, N, gates, ctx2=ctx2)
         torch.cuda.synchronize()
         buf = np.zeros(8 * 16 * 8, dtype=np.int64)
         lib.sgg_dbg_dma_ticks.argtypes = [ctypes.c_void_p]
