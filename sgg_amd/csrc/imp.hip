@@ -1720,9 +1720,7 @@ __global__ __launch_bounds__(DM_THREADS) void imp_ctx_mfma_kernel(
         }
         return true;
     };
-    // stale LDS must never meet a zero of the gate matrix as NaN / Inf: clear the ring once; node ids that cannot match
-    for (int k = tid; k < NBUF * EB * PIECE / 16; k += DM_THREADS) reinterpret_cast<u32x4*>(ring)[k] = u32x4{0, 0, 0, 0};
-    __syncthreads();
+    // (stale LDS never meets a zero of the gate matrix: every 32-row K step that is read was filled whole by issue_dma)
     int mark_small;
     issue_small(h0, 0);
     mark_small = ci;
