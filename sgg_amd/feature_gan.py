@@ -11,8 +11,8 @@ MIOpen / hipBLASLt), as the reference runs them through cuDNN: they are dense li
 nothing on the SGCls hot path depends on them.  `features.hdf5` (the `vis_cond` file of real per-class 512x7x7 features) is read
 by sgg_amd/hdf5_lite.py.
 
-Not carried: the GloVe tables (`lib/word_vectors.py`; `embed_objs` is only used by the scene-graph perturbations of
-augment/sg_perturb.py, and `init_embed` "led to worse results" and is off in the reference): pass `embed_objs=` / `embed_rels=`
+Not carried: the GloVe tables (`lib/word_vectors.py`; `embed_objs` is only used by the scene-graph perturbations
+(sgg_amd/sg_perturb.py), and `init_embed` "led to worse results" and is off in the reference): pass `embed_objs=` / `embed_rels=`
 tensors if you have them, otherwise the attributes stay None and `init_embed=True` raises.
 """
 import numpy as np
@@ -302,7 +302,8 @@ def gan_train_step(sgg_model, gan, res, gt_boxes, gt_objects, gt_rels, optimizer
     model's RoIAlign (differentiable into the maps: sgg_roi_align_bwd), classify them with the SGG head, update G (adversarial +
     reconstruction losses; the SGG model too when 'rec' is on), then update D on real vs generated features.
     `res` is the Result of the SGG model's training forward on the same batch.  -> {loss name: value} as main.py logs them.
-    gt_objects_fake: the perturbed objects (augment/sg_perturb.py, not carried); default = the real ones (`-perturb` off)."""
+    gt_objects_fake: the perturbed objects, `sgg_amd.sg_perturb.SceneGraphPerturb(...).perturb(gt_objects.clone(), gt_rels.clone())`
+    (main.py:131-134); default = the real ones (`-perturb` off)."""
     from .trainer import Trainer
     gan.train()
     if gt_objects_fake is None:

@@ -235,6 +235,15 @@ class VG(object):
             for s, o, p in rels:
                 key = '{}_{}_{}'.format(cls[s], p, cls[o])
                 self.triplet_counts[key] = self.triplet_counts.get(key, 0) + 1
+        if mode == 'train':
+            # what the scene-graph perturbations consult (visual_genome.py:211-227, augment/sg_perturb.py): for "subject predicate"
+            # the objects seen with it, for "predicate object" the subjects, each with the count of the whole triplet; first-seen order
+            self.subj_pred_pairs, self.pred_obj_pairs = {}, {}
+            for cls, rels in zip(self.gt_classes, self.relationships):
+                for s, o, p in rels:
+                    count = self.triplet_counts['{}_{}_{}'.format(cls[s], p, cls[o])]
+                    self.subj_pred_pairs.setdefault('{}_{}'.format(cls[s], p), {})[cls[o]] = count
+                    self.pred_obj_pairs.setdefault('{}_{}'.format(p, cls[o]), {})[cls[s]] = count
 
     @property
     def is_train(self):

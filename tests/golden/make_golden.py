@@ -24,6 +24,8 @@ reference's source text is stored -- only data.  What is called, per file:
   gan_model.npz    augment/gan.py:17 GAN (reduced widths, seeded weights; GloVe loader replaced by random vectors): dummy_nodes :262,
                    forward :174 (train-mode BatchNorm), loss :211 for the six D / G cases in a fixed order (spectral-norm power
                    iterations advance per call), gradients of the G_fmap loss wrt three generator parameters
+  sg_perturb.npz   augment/sg_perturb.py:7 SceneGraphPerturb.perturb ('rand', 'neigh', 'graphn' with and without the semantic hop; numpy and
+                   torch generators seeded per case), on synthetic graphs and synthetic training statistics
   freq_bias.npz    lib/get_dataset_counts.py:10 get_counts, lib/sparse_targets.py:7 FrequencyBias, and the use_bias block
                    sgg_models/rel_model_stanford.py:159-177 (executed on the reference's FrequencyBias module)
 """
@@ -408,6 +410,43 @@ def gold_gan_model():
     for n, gr in zip(names, grads):
         arrs['grad_' + n] = gr
     save('gan_model', **arrs)
+
+
+def gold_sg_perturb():
+    if not hasattr(np, 'Inf'):
+        np.Inf = np.inf                  # the reference spells it the NumPy-1 way (augment/sg_perturb.py:124,181); same value
+    from augment.sg_perturb import SceneGraphPerturb
+    rng = np.random.RandomState(17)
+    C, P = 12, 6
+    embed = torch.randn(C, 10, generator=torch.Generator().manual_seed(3))
+    embed = embed / embed.norm(2, dim=1, keepdim=True)
+    # a batch of 3 images
+    objs, rels = [], []
+    for im, n in enumerate((6, 3, 8)):
+        cls = rng.randint(1, C, size=n)
+        objs += [(im, int(c)) for c in cls]
+        pairs = [(a, b) for a in range(n) for b in range(n) if a != b]
+        for k in rng.choice(len(pairs), size=min(len(pairs), 2 * n), replace=False):
+            rels.append((im, pairs[k][0], pairs[k][1], int(rng.randint(0, P))))          # predicate 0 = background rows too
+    gt_obj = torch.tensor(objs, dtype=torch.int64)
+    gt_rels = torch.tensor(sorted(rels), dtype=torch.int64)
+    # synthetic training statistics in the dataset's form: {"s_p": {o: count}}, {"p_o": {s: count}}
+    subj_pred, pred_obj, rows = {}, {}, []
+    for _ in range(400):
+        s_, p_, o_, cnt = int(rng.randint(1, C)), int(rng.randint(1, P)), int(rng.randint(1, C)), int(rng.randint(1, 40))
+        subj_pred.setdefault('{}_{}'.format(s_, p_), {})[o_] = cnt
+        pred_obj.setdefault('{}_{}'.format(p_, o_), {})[s_] = cnt
+        rows.append((s_, p_, o_, cnt))
+    arrs = dict(embed=embed, gt_obj=gt_obj, gt_rels=gt_rels, stats_rows=np.array(rows, dtype=np.int64))
+    cases = [('rand', dict(L=0.5)), ('neigh', dict(L=0.3, topk=3)), ('graphn', dict(L=0.5, topk=0, alpha=2)),
+             ('graphn', dict(L=1.0, topk=4, alpha=1)), ('rand', dict(L=0.2, uniform=True)), ('graphn', dict(L=0.4, topk=2, alpha=5, degree_smoothing=0.5))]
+    for k, (method, kw) in enumerate(cases):
+        sgp = SceneGraphPerturb(method=method, embed_objs=embed.clone(), subj_pred_obj_pairs=(subj_pred, pred_obj), **kw)
+        for rep in range(3):
+            np.random.seed(100 * k + rep)
+            torch.manual_seed(100 * k + rep)
+            arrs['case%d_rep%d' % (k, rep)] = sgp.perturb(gt_obj.clone(), gt_rels.clone())
+    save('sg_perturb', **arrs)
 
 
 def gold_gan_ops():
@@ -839,6 +878,7 @@ if __name__ == '__main__':
     gold_rel_assign()
     gold_gan_ops()
     gold_gan_model()
+    gold_sg_perturb()
     gold_eval_tail()
     gold_losses()
     gold_recall()

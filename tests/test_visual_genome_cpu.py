@@ -108,6 +108,15 @@ def test_dataset_items_feed_the_blob():
     assert gt_boxes.shape[0] == gt_classes.shape[0] == len(ds.gt_classes[0]) + len(ds.gt_classes[1])
     train = VG('train', t, info, ['%d.jpg' % i for i in range(n_img)], num_val_im=6, decode=decode)
     assert len(train) == int(np.sum(train.split_mask)) > 0 and train.filter_duplicate_rels
+    # the statistics the scene-graph perturbations consult (visual_genome.py:211-227): every (subject, predicate) -> {object: count of
+    # the whole triplet}, every (predicate, object) -> {subject: count}; together they hold every training triplet exactly once
+    assert not hasattr(ds, 'subj_pred_pairs')                     # train mode only
+    n_sp = sum(len(v) for v in train.subj_pred_pairs.values())
+    assert n_sp == sum(len(v) for v in train.pred_obj_pairs.values()) == len(train.triplet_counts) > 0
+    for pair, objs in train.subj_pred_pairs.items():
+        for o, count in objs.items():
+            s_, p_ = pair.split('_')
+            assert train.triplet_counts['%s_%s_%s' % (s_, p_, o)] == count == train.pred_obj_pairs['%s_%s' % (p_, o)][int(s_)]
     np.random.seed(1)
     e = train[0]
     assert len(set(map(tuple, e['gt_relations'][:, :2]))) == len(e['gt_relations'])     # duplicates filtered in training
