@@ -157,7 +157,8 @@ def imp_iter_ms(model, B, dtype, reps=50, kind='sliced'):
     """Average duration of ONE IMP gather/gate/scatter launch on a complete 32-box/image graph of B images: `reps` launches
     back-to-back between two HIP events on the launch stream (outputs pre-allocated).  kind: 'sliced' (the kernel the forward
     runs: every edge row read once, gate dot products supplied by the GRU gate kernels), 'fused' (node-centric, any graph),
-    'write' / 'read' (the two kernels of the split step: sgg_imp_edge_in_fwd, sgg_imp_ctx_fwd)."""
+    'write' / 'read' (the two kernels of the split step: sgg_imp_edge_in_fwd, sgg_imp_ctx_fwd), 'step_mfma' (sgg_imp_step_fwd),
+    'sliced_kernel' (imp_sliced_kernel at any size)."""
     import torch
     from sgg_amd import ops
     dev = model.rel_fc.weight.device
@@ -172,12 +173,19 @@ def imp_iter_ms(model, B, dtype, reps=50, kind='sliced'):
     e = torch.randn(E, H, generator=g).to(dev).to(dtype)
     imp = model.prepared()['imp']
     e_in, ctx2 = torch.empty_like(e), torch.empty((2, N, H), dtype=dtype, device=dev)
-    if kind in ('sliced', 'write', 'read', 'step_mfma'):
+    if kind in ('sliced', 'sliced_kernel', 'write', 'read', 'step_mfma'):
         assert ops.imp_sliced_ok(csr, H, dtype)
         nd = (v.float() @ imp.gate_w[:, :H].t()).contiguous()     # what sgg_gru_gate_fwd's dot epilogue hands over
         ed = (e.float() @ imp.gate_w[:, H:].t()).contiguous()
-        if kind == 'sliced':
+        if kind == 'sliced':          # what the forward launches for these graphs (ops.imp_sliced routes by size)
             launch = lambda: ops.imp_sliced(v, e, csr, nd, ed, imp.gate_b, e_in, ctx2)
+        elif kind == 'sliced_kernel':  # imp_sliced_kernel itself
+            def launch():
+                os.environ['SGG_IMP_STREAM'] = '0'
+                try:
+                    ops.imp_sliced(v, e, csr, nd, ed, imp.gate_b, e_in, ctx2)
+                finally:
+                    del os.environ['SGG_IMP_STREAM']
         elif kind == 'step_mfma':   # the whole step in one launch of the matrix-core kernel (opt-in entry point sgg_imp_step_fwd)
             launch = lambda: ops.imp_step(v, e, csr, nd, ed, imp.gate_b, e_in, ctx2)
         else:                 # the two halves of the split step (opt-in entry points): write stream (e_in + gates), read stream (ctx)
@@ -412,9 +420,15 @@ def main():
         imp_gbs = imp_bytes / (imp_ms * 1e-3) / 1e9 if imp_ms else 0.0
         BL = 128                                                 # same kernel on a graph that fills the chip
         impL_ms = imp_iter_ms(model, BL, tdtype)
+        from sgg_amd import _lib as _sgg_lib
+        step_units = _sgg_lib.load().sgg_imp_step_min_units()
+        impL_step = tdtype == torch.bfloat16 and BL * (H // 64) >= step_units and os.environ.get('SGG_IMP_STREAM') is None
+        impL_kernel = ('imp_ctx_mfma_kernel<STEP> (persistent one-launch step: gates + edge inputs + block-sparse gate-matrix product on '
+                       'the matrix cores; sgg_imp_sliced_fwd hands >= %d (graph, slice) units to it)' % step_units) if impL_step \
+            else 'imp_sliced_kernel'
         imp_old = {'B%d' % b_: round(imp_iter_ms(model, b_, tdtype, kind='fused'), 5) for b_ in (B, BL)}   # node-centric kernel, for comparison
         # the split step's two kernels and the one-launch matrix-core step (opt-in entry points), same graphs
-        imp_split = {'B%d' % b_: {k_: round(imp_iter_ms(model, b_, tdtype, kind=k_), 5) for k_ in ('write', 'read', 'step_mfma')} for b_ in (B, BL)} \
+        imp_split = {'B%d' % b_: {k_: round(imp_iter_ms(model, b_, tdtype, kind=k_), 5) for k_ in ('write', 'read', 'step_mfma', 'sliced_kernel')} for b_ in (B, BL)} \
             if tdtype == torch.bfloat16 else None
         impL_bytes = (2.0 * (992 * BL + 32 * BL) * H) * s + 8.0 * 992 * BL
         impL_gbs = impL_bytes / (impL_ms * 1e-3) / 1e9
@@ -513,10 +527,10 @@ def main():
                              'traffic': pmc_traffic('imp_sliced_B8') if (B == 8 and args.dtype == 'bf16') else None,
                              'algorithmic_bytes': imp_bytes, 'avg_launch_ms': round(imp_ms, 5),
                              'note': '16.8 MB per launch at B=8: 2.7 us at 6.3 TB/s, below a launch plus two dependent memory latencies; see roofline_imp_large'},
-            'roofline_imp_large': {'kernel': 'same kernel, %d images (%d edges) per launch' % (BL, 992 * BL), 'bound': 'hbm',
+            'roofline_imp_large': {'kernel': 'the IMP launch of the forward at %d images (%d edges): %s' % (BL, 992 * BL, impL_kernel), 'bound': 'hbm',
                                    'achieved': round(impL_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                    'frac': round(impL_gbs / HBM_PEAK_GBS, 4),
-                                   'traffic': pmc_traffic('imp_sliced_B128') if args.dtype == 'bf16' else None,
+                                   'traffic': pmc_traffic('imp_step_mfma_B128' if impL_step else 'imp_sliced_B128') if args.dtype == 'bf16' else None,
                                    'algorithmic_bytes': impL_bytes, 'avg_launch_ms': round(impL_ms, 5),
                                    'node_centric_kernel_ms': imp_old, 'split_step_kernels_ms': imp_split,
                                    'device_copy_same_bytes': {'GB/s': round(copy_gbs, 1), 'frac_of_copy': round(impL_gbs / copy_gbs, 4)}},

@@ -178,8 +178,10 @@ int sgg_imp_fused_fwd(const void* v, const void* e, const int* so /*[E,2]*/, con
  * (sgg_gru_gate_fwd's dot outputs, vertex / edge halves of gate_w), e_in pieces stream out, ctx2 halves are reduced from
  * LDS.  Requires: rel_inds sorted by (graph, subject) (both pair-index calls emit that; out-lists are then ranges), nodes
  * grouped by graph with img_ptr from sgg_graph_ptr, every graph with <= max_nodes <= 64 nodes and <= max_edges edges
- * (SGG_ERR_CAPACITY above sgg_imp_sliced_capacity(H, dtype)).  Same outputs as sgg_imp_fused_fwd. */
+ * (SGG_ERR_CAPACITY above sgg_imp_sliced_capacity(H, dtype)).  Same outputs as sgg_imp_fused_fwd.  Launches of at least
+ * sgg_imp_step_min_units() units (B graphs x H/64 slices) of bf16 graphs with <= 32 nodes run as sgg_imp_step_fwd (below). */
 int sgg_imp_sliced_capacity(int H, int dtype);
+int sgg_imp_step_min_units(void);
 int sgg_imp_sliced_fwd(const void* v, const void* e, const int* so /*[E,2]*/, const int* out_ptr, const int* in_ptr,
                        const int* in_ids, const int* img_ptr, int B, int N, int E, int H, const float* node_dots,
                        const float* edge_dots, const float* gate_b, void* e_in, void* ctx2 /*[2,N,H]*/, int max_edges,

@@ -49,6 +49,7 @@ SIGNATURES = {
     'sgg_imp_fused_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     'sgg_gru_gate_fwd': [_P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _P],
     'sgg_imp_sliced_capacity': [_I, _I],
+    'sgg_imp_step_min_units': [],
     'sgg_imp_sliced_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sgg_imp_edge_in_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     'sgg_imp_ctx_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P],

@@ -1741,37 +1741,43 @@ __global__ __launch_bounds__(DM_THREADS) void imp_ctx_mfma_kernel(
             boff[t][hlf] = (unsigned)(r * PIECE + slot * 16 + (tcg & 1) * 8);
         }
 
+    // thread t: edge t of unit hx -> what the K steps (and, STEP, the edge inputs) read.  Reads the raw arrays this thread's own wave
+    // DMA'd (and the vertex dots wave 0 DMA'd): the caller has waited for them and, for the dots, passed a barrier.
+    auto convert = [&](const Hdr& hx) __attribute__((always_inline)) {
+        if (tid >= EPAD) {
+        // (the per-edge arrays hold EPAD entries: small graphs leave most threads without an edge)
+    } else if constexpr (STEP) {   // thread t: edge t -> its four gates (rel_model_stanford.py:78-89), byte node ids
+        const bool live = tid < hx.Ee;
+        const int sl = live ? sets[4 * EPAD + tid] - hx.n0 : 0, ol = live ? sets[5 * EPAD + tid] - hx.n0 : 0;
+        const f32x4 de = reinterpret_cast<const f32x4*>(sets)[tid];
+        const f32x4 ns = reinterpret_cast<const f32x4*>(ndl)[sl], no = reinterpret_cast<const f32x4*>(ndl)[ol];
+        gso[tid] = sigmoidf_(ns.x + de.x + gb[0]);                               // sub_vert (v[s])
+        gso[EPAD + tid] = sigmoidf_(no.y + de.y + gb[1]);                        // obj_vert (v[o])
+        gbf[tid] = live ? (unsigned short)(pack_bf16x2(sigmoidf_(ns.z + de.z + gb[2]), 0.f) & 0xffffu) : (unsigned short)0;          // out_edge
+        gbf[EPAD + tid] = live ? (unsigned short)(pack_bf16x2(sigmoidf_(no.w + de.w + gb[3]), 0.f) & 0xffffu) : (unsigned short)0;   // in_edge
+        nid[tid] = live ? (unsigned char)sl : (unsigned char)0xff;
+        nid[EPAD + tid] = live ? (unsigned char)ol : (unsigned char)0xff;
+    } else {   // thread t: edge t -> bf16 gates, byte node ids (every wave has left the last unit: the packed arrays are free)
+        const float* graw = reinterpret_cast<const float*>(sets);
+        const bool live = tid < hx.Ee;
+        gbf[tid] = live ? (unsigned short)(pack_bf16x2(graw[tid], 0.f) & 0xffffu) : (unsigned short)0;
+        gbf[EPAD + tid] = live ? (unsigned short)(pack_bf16x2(graw[EPAD + tid], 0.f) & 0xffffu) : (unsigned short)0;
+        nid[tid] = live ? (unsigned char)(sets[2 * EPAD + tid] - hx.n0) : (unsigned char)0xff;
+        nid[EPAD + tid] = live ? (unsigned char)(sets[3 * EPAD + tid] - hx.n0) : (unsigned char)0xff;
+    }
+    };
+    // ---- first unit: its small arrays -> packed; then the second unit's small arrays are requested
+    wait_mark(mark_small);
+    __syncthreads();
+    convert(h0);
+    __syncthreads();
+    if (nunits > 1) {
+        issue_small(h1, 1);
+        mark_small = ci;
+    }
+
     for (cu = 0; cu < nunits; ++cu) {
         const Hdr hc = h0;
-        { [[maybe_unused]] const int unit_no = consumed; SGG_DTICK(0) }
-        wait_mark(max(mark_small, mark_of(cr)));
-        __syncthreads();                                         // (B) this unit's raw per-edge arrays and first chunk, every wave's parts
-        if (tid >= EPAD) {
-            // (the per-edge arrays hold EPAD entries: small graphs leave most threads without an edge)
-        } else if constexpr (STEP) {   // thread t: edge t -> its four gates (rel_model_stanford.py:78-89), byte node ids
-            const bool live = tid < hc.Ee;
-            const int sl = live ? sets[4 * EPAD + tid] - hc.n0 : 0, ol = live ? sets[5 * EPAD + tid] - hc.n0 : 0;
-            const f32x4 de = reinterpret_cast<const f32x4*>(sets)[tid];
-            const f32x4 ns = reinterpret_cast<const f32x4*>(ndl)[sl], no = reinterpret_cast<const f32x4*>(ndl)[ol];
-            gso[tid] = sigmoidf_(ns.x + de.x + gb[0]);                               // sub_vert (v[s])
-            gso[EPAD + tid] = sigmoidf_(no.y + de.y + gb[1]);                        // obj_vert (v[o])
-            gbf[tid] = live ? (unsigned short)(pack_bf16x2(sigmoidf_(ns.z + de.z + gb[2]), 0.f) & 0xffffu) : (unsigned short)0;          // out_edge
-            gbf[EPAD + tid] = live ? (unsigned short)(pack_bf16x2(sigmoidf_(no.w + de.w + gb[3]), 0.f) & 0xffffu) : (unsigned short)0;   // in_edge
-            nid[tid] = live ? (unsigned char)sl : (unsigned char)0xff;
-            nid[EPAD + tid] = live ? (unsigned char)ol : (unsigned char)0xff;
-        } else {   // thread t: edge t -> bf16 gates, byte node ids (every wave has left the last unit: the packed arrays are free)
-            const float* graw = reinterpret_cast<const float*>(sets);
-            const bool live = tid < hc.Ee;
-            gbf[tid] = live ? (unsigned short)(pack_bf16x2(graw[tid], 0.f) & 0xffffu) : (unsigned short)0;
-            gbf[EPAD + tid] = live ? (unsigned short)(pack_bf16x2(graw[EPAD + tid], 0.f) & 0xffffu) : (unsigned short)0;
-            nid[tid] = live ? (unsigned char)(sets[2 * EPAD + tid] - hc.n0) : (unsigned char)0xff;
-            nid[EPAD + tid] = live ? (unsigned char)(sets[3 * EPAD + tid] - hc.n0) : (unsigned char)0xff;
-        }
-        __syncthreads();                                         // (C) packed arrays visible; the raw arrays are free
-        if (cu + 1 < nunits) {
-            issue_small(h1, (cu + 1) & 1);                       // the next unit's raw arrays (and the other copy of the vertex pieces)
-            mark_small = ci;
-        }
         const unsigned short* const gate = gbf + dir * EPAD;     // g_out | g_in
         const unsigned char* const node = nid + dir * EPAD;      // subject | object
         const unsigned target = (unsigned)(mt * 16 + m16);       // this lane's node (graph-local; ids of real edges are < Nn, padding is 0xff)
@@ -1803,11 +1809,9 @@ __global__ __launch_bounds__(DM_THREADS) void imp_ctx_mfma_kernel(
                 }
                 for (int r0 = blo + wv * 8; r0 < bhi; r0 += DM_THREADS / 8) ++ci;      // this wave's store instructions (vmcnt counts them)
             }
-            if (cb > 0) {
-                SGG_DTICK(0)
-                wait_mark(mark_of(cr));
-                __syncthreads();                                 // (D) chunk visible; every wave has left the last chunk
-            }
+            SGG_DTICK(0)
+            wait_mark(mark_of(cr));
+            __syncthreads();                                     // (D) chunk visible; every wave has left the last chunk (and unit)
             SGG_DTICK(1)
             if (issued_chunks - consumed < NBUF) produce();
             SGG_DTICK(2)
@@ -1856,38 +1860,49 @@ __global__ __launch_bounds__(DM_THREADS) void imp_ctx_mfma_kernel(
             cr = cr + 1 == NBUF ? 0 : cr + 1;
             ++consumed;
         }
-        // ---- unit done: the four K quarters (and, for the summed ctx, the two sums) meet through the ring slot consumed last.
-        // The slot holds 8 x 4 KiB partial tiles: quarters 2 and 3 write, 0 and 1 add; 1 writes its sum back over what it read, 0 adds.
+        // ---- unit done: the four K quarters (and, for the summed ctx, the two sums) meet through LDS
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[0][t] += acc[1][t];
         { [[maybe_unused]] const int unit_no = consumed - 1; SGG_DTICK(5) }
         lds_reads_done_barrier();                                // (E1) every wave has left the unit's last chunk
-        // [8 regions][16 registers][64 lanes] f32 = 32 KiB: the slot itself when it is that large (256-row chunks), else a region of
-        // its own behind the sets
         char* const fixed_end = STEP ? vsb + 2 * MF_NODES * PIECE : reinterpret_cast<char*>(nid + 2 * EPAD);
-        float* const scratch = EB * PIECE >= 32768 ? reinterpret_cast<float*>(ring + last_slot * EB * PIECE)
-                                                   : reinterpret_cast<float*>(smem + (((fixed_end - smem) + 15) & ~15L));
-        auto region = [&](int d, int m, int h) __attribute__((always_inline)) {
-            return reinterpret_cast<f32x4*>(scratch + ((d * 2 + m) * 2 + h) * 1024) + lane;        // [4 tiles][64 lanes] x 16 bytes
-        };
-        auto put = [&](f32x4* d) __attribute__((always_inline)) {
+        auto put_to = [&](f32x4* d) __attribute__((always_inline)) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) d[t * 64] = acc[0][t];
         };
-        auto add = [&](const f32x4* d) __attribute__((always_inline)) {
+        auto add_from = [&](const f32x4* d) __attribute__((always_inline)) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[0][t] += d[t * 64];
         };
-        if (kq >= 2) put(region(dir, mt, kq - 2));
-        __syncthreads();                                         // (R1)
-        if (kq < 2) add(region(dir, mt, kq));
-        if (kq == 1) put(region(dir, mt, 1));                    // (only this wave read that region)
-        __syncthreads();                                         // (R2)
-        if (kq == 0) add(region(dir, mt, 1));
-        if (sum_ctx) {
-            if (kq == 0 && dir == 1) put(region(1, mt, 0));      // (read by this wave alone in round 1)
-            __syncthreads();                                     // (R3)
-            if (kq == 0 && dir == 0) add(region(1, mt, 0));
+        {
+            // [8 regions][16 registers][64 lanes] f32 = 32 KiB: the ring slot consumed last when it is that large (256-row chunks),
+            // else a region of its own behind the sets.  Quarters 2 and 3 write, 0 and 1 add; 1 writes its sum back over what it
+            // read, 0 adds.  The next unit's conversion pass rides in the shadow of the rounds: its raw arrays are waited for before
+            // (R1) -- which also publishes the vertex dots wave 0 fetched --, the pass runs between (R1) and (R2), and (R2) publishes
+            // its results (the packed arrays have been free since (E1)); then the raw arrays go to the DMA of the unit after next.
+            // (Tried: a 16 KiB region of its own + a chain 3 -> 2 -> 1 -> 0, so that the slot is refilled at (E1) already: same time.)
+            float* const scratch = EB * PIECE >= 32768 ? reinterpret_cast<float*>(ring + last_slot * EB * PIECE)
+                                                       : reinterpret_cast<float*>(smem + (((fixed_end - smem) + 15) & ~15L));
+            auto region = [&](int d, int m, int h) __attribute__((always_inline)) {
+                return reinterpret_cast<f32x4*>(scratch + ((d * 2 + m) * 2 + h) * 1024) + lane;    // [4 tiles][64 lanes] x 16 bytes
+            };
+            if (kq >= 2) put_to(region(dir, mt, kq - 2));
+            if (cu + 1 < nunits) wait_mark(mark_small);
+            __syncthreads();                                     // (R1)
+            if (kq < 2) add_from(region(dir, mt, kq));
+            if (kq == 1) put_to(region(dir, mt, 1));             // (only this wave read that region)
+            if (cu + 1 < nunits) convert(h1);
+            __syncthreads();                                     // (R2)
+            if (cu + 2 < nunits) {
+                issue_small(h2, cu & 1);                         // (the vertex-piece copy this unit used)
+                mark_small = ci;
+            }
+            if (kq == 0) add_from(region(dir, mt, 1));
+            if (sum_ctx) {
+                if (kq == 0 && dir == 1) put_to(region(1, mt, 0));   // (read by this wave alone in round 1)
+                __syncthreads();                                 // (R3)
+                if (kq == 0 && dir == 0) add_from(region(1, mt, 0));
+            }
         }
         if (kq == 0 && (dir == 0 || !sum_ctx) && hc.Ee >= 0) {
             // lane: channel m16 of each 16-channel tile, nodes kb*4 + i of this wave's node tile
@@ -1918,7 +1933,7 @@ __global__ __launch_bounds__(DM_THREADS) void imp_ctx_mfma_kernel(
             }
         }
         { [[maybe_unused]] const int unit_no = consumed - 1; SGG_DTICK(6) }
-        // (the scratch slot is refilled by a DMA only after the next unit's barrier (B): every reader has consumed its reads by then)
+        // (the scratch slot is refilled by a DMA only after the next unit's first barrier (D): every reader has consumed its reads by then)
         h0 = h1;
         h1 = h2;
         if (loaded < nunits) {
@@ -2175,6 +2190,11 @@ extern "C" int sgg_imp_step_fwd(const void* v, const void* e, const int* so, con
     return rc == 1 ? SGG_ERR_CAPACITY : rc;
 }
 
+// (graph, 64-channel slice) units from which sgg_imp_sliced_fwd hands bf16 graphs of <= 32 nodes to the persistent matrix-core step
+// (256 workgroups, one per CU: four units each; measured on complete 32-node graphs: 96 images even, 128 images 64 against 72-75 us)
+constexpr int IMP_STEP_MIN_UNITS = 1024;
+extern "C" int sgg_imp_step_min_units(void) { return IMP_STEP_MIN_UNITS; }
+
 // largest per-graph edge count the sliced kernel takes at this row width (0: rows too narrow for any slicing)
 extern "C" int sgg_imp_sliced_capacity(int H, int dtype) {
     const int row = H * (dtype == SGG_BF16 ? 2 : 4);
@@ -2209,12 +2229,19 @@ extern "C" int sgg_imp_sliced_fwd(const void* v, const void* e, const int* so, c
             max_edges <= (f == 8 ? SliceCfg<8>::EMAX : f == 4 ? SliceCfg<4>::EMAX : SliceCfg<2>::EMAX))
             lp = f;
     }
-    // Default: the short-lived form (one workgroup per unit, two per CU) -- still the fastest measured (DESIGN.md "IMP step").
-    // SGG_IMP_STREAM=1: the register-prefetch persistent form, kept as a measured experiment and a cross-check (tests/test_kernels_gpu.py).
-    // SGG_IMP_MAX_WGS=n caps the persistent grid (tests: several units per workgroup on small batches).
+    // Default: the short-lived form (one workgroup per unit, two per CU) -- the fastest measured up to a few hundred units; from
+    // IMP_STEP_MIN_UNITS (graph, 64-channel slice) units on, bf16 graphs of <= 32 nodes go to the persistent matrix-core step
+    // (imp_ctx_mfma_kernel<STEP>, the kernel behind sgg_imp_step_fwd; DESIGN.md "IMP step").
+    // SGG_IMP_STREAM=0: never route; =1: the register-prefetch persistent form, kept as a measured experiment and a cross-check
+    // (tests/test_kernels_gpu.py).  SGG_IMP_MAX_WGS=n caps the persistent grids (tests: several units per workgroup on small batches).
     const char* st = getenv("SGG_IMP_STREAM");
     const char* mw = getenv("SGG_IMP_MAX_WGS");
     const int max_wgs = mw ? atoi(mw) : 0;
+    if (!st && dtype == SGG_BF16 && row % 128 == 0 && (long)B * (row / 128) >= IMP_STEP_MIN_UNITS && (long)E * row < 0xffff0000L) {
+        const int rc = ctx_mfma_dispatch(true, e, nullptr, so, img_ptr, B, N, H, ctx2, max_edges, max_nodes, sum_ctx, dtype, max_wgs, s, v,
+                                         node_dots, edge_dots, gate_b, e_in);
+        if (rc != 1) return rc;                              // 1: these graphs do not fit it
+    }
     if (st && st[0] == '1') {
 #define SGG_STREAM(T, LPV) \
     return launch_stream<T, LPV>(v, e, so, in_ptr, in_ids, img_ptr, B, N, H, node_dots, edge_dots, gate_b, e_in, ctx2, max_edges, \

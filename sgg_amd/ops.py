@@ -410,14 +410,16 @@ def imp_sliced_ok(csr, H, dtype):
 
 
 def imp_sliced(v, e, csr, node_dots, edge_dots, gate_b, e_in=None, ctx2=None, ctx_sum=None):
-    """One launch per IMP iteration, every edge row read once: -> (e_in [E,H], ctx2 [2,N,H]).  node_dots f32[N,4] /
+    """One launch per IMP iteration, every edge row read once: -> (e_in [E,H], ctx2 [2,N,H]) -- imp_sliced_kernel, or from
+    sgg_imp_step_min_units() units on (bf16, <= 32 nodes per graph) the persistent matrix-core step.  node_dots f32[N,4] /
     edge_dots f32[E,4] come from gru_gate(dot_w=...).  ctx_sum (optional [N,H] output): the kernel stores ctx_out + ctx_in there
     instead of the two halves (-> (e_in, ctx_sum))."""
     N, H = v.shape
     E = e.shape[0]
-    if os.environ.get('SGG_IMP_STREAM') == 's' and imp_split_ok(csr, H, v.dtype):     # kernel experiments / cross-checks
+    form = os.environ.get('SGG_IMP_STREAM')       # kernel experiments / cross-checks: 's' split step, 'm' matrix-core step at any size
+    if form == 's' and imp_split_ok(csr, H, v.dtype):
         return imp_split(v, e, csr, node_dots, edge_dots, gate_b, e_in=e_in, ctx2=ctx2, ctx_sum=ctx_sum)
-    if os.environ.get('SGG_IMP_STREAM') == 'm' and imp_step_ok(csr, H, v.dtype):
+    if form == 'm' and imp_step_ok(csr, H, v.dtype):
         return imp_step(v, e, csr, node_dots, edge_dots, gate_b, e_in=e_in, ctx2=ctx2, ctx_sum=ctx_sum)
     out_ptr, out_ids, in_ptr, in_ids, so, flags = csr
     B, max_nodes, max_edges = csr.graphs

@@ -607,6 +607,54 @@ def test_imp_sliced_vs_oracle_math(ops, H, sizes, dtype):
     torch.testing.assert_close(ctx2.float(), ctx2f.float(), **ctol)
 
 
+def test_imp_sliced_hands_large_launches_to_the_matrix_core_step(ops, monkeypatch):
+    """sgg_imp_sliced_fwd routes by size: from sgg_imp_step_min_units() (graph, slice) units on, bf16 graphs of <= 32 nodes run as the
+    persistent matrix-core step -- bit-equal to calling that step directly, e_in bit-equal to the sliced kernel and the ctx sums
+    within 2 bf16 ulps of it; one graph too wide for the step (33 nodes) sends the whole launch back to the sliced kernel."""
+    from sgg_amd import _lib
+    H = 128
+    units = _lib.load().sgg_imp_step_min_units()
+    assert units == 1024
+    g = torch.Generator().manual_seed(5)
+    rng = np.random.RandomState(5)
+    for wide in (False, True):
+        sizes = [int(n) for n in rng.randint(2, 8, size=units // (H // 64))]
+        if wide:
+            sizes[7] = 33
+        im = np.concatenate([np.full(n, b) for b, n in enumerate(sizes)]).astype(np.int64)
+        rel = O.get_rel_inds_eval(im)
+        N, E = len(im), len(rel)
+        v = cu(torch.randn(N, H, generator=g).to(torch.bfloat16))
+        e = cu(torch.randn(E, H, generator=g).to(torch.bfloat16))
+        nd, ed, gb = cu(torch.randn(N, 4, generator=g)), cu(torch.randn(E, 4, generator=g)), cu(torch.randn(4, generator=g))
+        csr = ops.edge_csr(cu(rel), N, cu(im), graphs=(len(sizes), max(sizes), max(n * (n - 1) for n in sizes)))
+        out = {}
+        for form in ('0', None, 'm'):
+            if form is None:
+                monkeypatch.delenv('SGG_IMP_STREAM', raising=False)
+            else:
+                monkeypatch.setenv('SGG_IMP_STREAM', form)
+            out[form] = ops.imp_sliced(v, e, csr, nd, ed, gb)
+        monkeypatch.delenv('SGG_IMP_STREAM', raising=False)
+        assert torch.equal(out[None][0], out['0'][0])
+        torch.testing.assert_close(out[None][1].float(), out['0'][1].float(), atol=0.13, rtol=1.6e-2)
+        if wide:                                               # ('m' fell back as well: imp_step_ok is false)
+            assert all(torch.equal(out[None][i], out['0'][i]) for i in (0, 1))
+        else:
+            assert all(torch.equal(out[None][i], out['m'][i]) for i in (0, 1))
+            assert not torch.equal(out[None][1], out['0'][1])  # (bf16 gates in the product: not the sliced kernel's bits)
+        # one unit fewer: the sliced kernel
+        keep = len(sizes) - 1
+        im2 = im[im < keep]
+        rel2 = O.get_rel_inds_eval(im2)
+        csr2 = ops.edge_csr(cu(rel2), len(im2), cu(im2), graphs=(keep, max(sizes[:keep]), max(n * (n - 1) for n in sizes[:keep])))
+        a = ops.imp_sliced(v[:len(im2)], e[:len(rel2)], csr2, nd[:len(im2)], ed[:len(rel2)], gb)
+        monkeypatch.setenv('SGG_IMP_STREAM', '0')
+        b = ops.imp_sliced(v[:len(im2)], e[:len(rel2)], csr2, nd[:len(im2)], ed[:len(rel2)], gb)
+        monkeypatch.delenv('SGG_IMP_STREAM', raising=False)
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
 def test_imp_persistent_kernels_equal_short_lived_form(ops, dtype, monkeypatch):
     """The other forms of the sliced IMP step -- the split step (write stream + ring-buffered LDS-DMA read stream, 's') and the

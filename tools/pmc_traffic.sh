@@ -30,6 +30,8 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
             key = 'fc6_dW_gemm'
         elif 'imp_sliced_kernel' in k:
             key = 'imp_sliced_B8' if wgs <= 256 else 'imp_sliced_B128'
+        elif 'imp_ctx_mfma_kernel<true>' in k or 'imp_ctx_mfma_kernel<1>' in k:
+            key = 'imp_step_mfma_B128'
         if key:
             res.setdefault(key, {})[c + '_KiB_avg'] = sum(v) / len(v)
             res[key]['launches'] = len(v)
