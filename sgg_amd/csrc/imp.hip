@@ -1127,7 +1127,7 @@ __device__ __forceinline__ void dma16_to_lds(const void* gptr, unsigned lds_base
 }
 
 #ifndef SGG_DMA_ABL
-#define SGG_DMA_ABL 0     // kernel experiments only (imp_ctx_kernel): 3 no DMA after the first chunk, 4 DMA and barriers only (no sums)
+#define SGG_DMA_ABL 0     // kernel experiments only (imp_ctx_kernel): 3 no DMA after the first chunk, 4 DMA and barriers only (no sums), 5 no edge inputs (STEP)
 #endif
 #ifdef SGG_DMA_TICKS     // kernel experiments only: clock stamps of the first 8 workgroups (one per XCD), wave 0, 16 units x 8 stamps
 __device__ long long g_dma_ticks[8 * 16 * 8];
@@ -1791,7 +1791,7 @@ __global__ __launch_bounds__(DM_THREADS) void imp_ctx_mfma_kernel(
         for (int cb = 0; cb < nchunks; ++cb) {
             const int blo = cb * EB, bhi = min(blo + EB, max(hc.Ee, 0));
             [[maybe_unused]] const int unit_no = consumed;
-            if constexpr (STEP) {
+            if constexpr (STEP && SGG_DMA_ABL != 5) {
                 // the edge inputs of this chunk's edges, e_in = g_sub v[s] + g_obj v[o] (rel_model_stanford.py:78-81): they need no edge
                 // row, so they are made while the chunk's DMA is still landing.  Lane group (8 lanes x 16 bytes) <-> row piece.
                 const char* vq = vsb + (cu & 1) * MF_NODES * PIECE + (tid & 7) * 16;
