@@ -38,10 +38,10 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WN, wc = wave % WN;
 
-    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    const int tilesM = (g.M - g.m_base + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
     int tm, tn;
     tile_coords(blockIdx.x, tilesM, tilesN, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = g.m_base + tm * BM, n0 = tn * BN;
 
     // ---- per-lane source pointers (16-byte chunk of a 128-byte row, swizzled)
     const int lrow = lane >> 3;  // row inside an 8-row load
@@ -370,7 +370,7 @@ int launch(const GemmArgs& g, hipStream_t s, int splits = 1) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int smem = 2 * (BM + BN) * ROWB;
     static_assert(smem >= 4 * 32 * 272, "epilogue staging fits");
-    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    const int tilesM = (g.M - g.m_base + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
     auto k = mfma_tile_kernel<BF16, WM, WN, CONV>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -385,12 +385,32 @@ int launch(const GemmArgs& g, hipStream_t s, int splits = 1) {
 
 // Kernel choice: the 256x256 ping-pong kernel when the problem fills the chip with 256-wide tiles
 // (N >= 256, M large); 256x64 tiles for narrow N; 128x128 otherwise.  SGG_GEMM_FORCE=128 disables the big kernel.
+constexpr int N_CU_CHIP = 256;   // MI355X: one 256x256 ping-pong tile per CU and round
 template <bool CONV>
 int dispatch(GemmArgs g, bool bf16, hipStream_t s) {
     static const char* force = getenv("SGG_GEMM_FORCE");
     const bool allow256 = !(force && force[0] == '1' && force[1] == '2');
     const long tiles256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
     if (allow256 && g.N >= 256 && tiles256 >= 128) {
+        if constexpr (CONV) {
+            // One 256x256 tile per CU and round: a tile count a little above a multiple of the CU count costs a whole round for a few
+            // tiles (conv4_1 / conv4_2 at 8 frames: 172 x 2 = 344 tiles = 1.34 rounds).  When the last round would be less than
+            // half full and is made of whole tile rows, those pixels go to the 128x128 kernel (two workgroups per CU: 4 x rem tiles
+            // fill the chip once at most) and the main launch is an exact number of rounds.  Same K order in both kernels.
+            static const char* notail = getenv("SGG_CONV_NOTAIL");
+            const int tN = (g.N + 255) / 256;
+            const long rem = tiles256 % N_CU_CHIP;
+            if (bf16 && !notail && g.m_base == 0 && tiles256 > N_CU_CHIP && rem > 0 && rem <= 112 && (tiles256 - rem) % tN == 0) {
+                GemmArgs tail = g;
+                tail.m_base = (int)((tiles256 - rem) / tN) * 256;
+                g.M = tail.m_base;
+                g.nt *= 2;
+                g.nt1 *= 2;
+                const int rc = sgg_launch_pingpong(g, bf16, CONV, s);
+                if (rc != SGG_OK) return rc;
+                return launch<true, 2, 2, CONV>(tail, s);
+            }
+        }
         g.nt *= 2;   // 64-byte K-tiles
         g.nt1 *= 2;
         return sgg_launch_pingpong(g, bf16, CONV, s);

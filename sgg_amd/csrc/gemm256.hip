@@ -57,10 +57,10 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, q = wave & 3;  // grp: which half of M; q: which 64-wide N slab
 
-    const int tilesM = (g.M + 255) / 256, tilesN = (g.N + 255) / 256;
+    const int tilesM = (g.M - g.m_base + 255) / 256, tilesN = (g.N + 255) / 256;
     int tm, tn;
     tile_coords(blockIdx.x, tilesM, tilesN, tm, tn);
-    const int m0 = tm * 256, n0 = tn * 256;
+    const int m0 = g.m_base + tm * 256, n0 = tn * 256;
 
     // ---- DMA duty: waves 0-3 stage the A rows, waves 4-7 the W rows; 4 instructions of 16 rows each
     const bool loads_a = wave < 4;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
 
 template <bool BF16, bool CONV>
 int launch256(const GemmArgs& g, hipStream_t s) {
-    const int tilesM = (g.M + 255) / 256, tilesN = (g.N + 255) / 256;
+    const int tilesM = (g.M - g.m_base + 255) / 256, tilesN = (g.N + 255) / 256;
     auto k = mfma_pingpong_kernel<BF16, CONV>;
     static bool attr_done = false;
     if (!attr_done) {

@@ -19,6 +19,7 @@ struct GemmArgs {
     char* C;
     long ldc;  // elements
     int M, N, act, out_bf16;
+    int m_base;                 // first output row of this launch (rows [m_base, M): a launch may cover the tail of a problem only)
     long splitk_stride;         // bytes between the fp32 partial outputs of consecutive K splits (gridDim.y > 1)
     // conv mode: A is a zero-bordered NHWC plane [B,H+2,W+2,Cin]; C is [B,H+2p,W+2p,N]
     int H, W, Cin, out_pad;
