@@ -405,9 +405,21 @@ def main():
         get = lambda name, tag: kt.get((name, tag), (0.0, 0))
         per_step = lambda name, tag: get(name, tag)[0] * get(name, tag)[1]
         # the two largest contractions: fc6 on edges forward, and its weight gradient in training
-        cands = {'fc6_edge': ('fc6 on edges, forward: [%d x 25600] . [4096 x 25600]^T' % E, 2.0 * E * 4096 * 25600),
-                 'bwd_fc6_edge_dW': ('fc6 weight gradient: [4096 x %d] . [25088 x %d]^T (the rect term rides in the transpose)' % (E, E),
-                                     2.0 * E * 4096 * 25088)}
+        # The forward pools every unordered box pair once (sgg_amd/pairing.py): on these complete graphs the long contraction runs on
+        # U = E / 2 rows.  `achieved` counts the FLOPs the kernel EXECUTES; the reference's per-edge algorithm (2 E 4096 25600
+        # per image batch) is reported beside it as `reference_algorithm_tflops`.
+        paired = os.environ.get('SGG_EDGE_PAIRS', '1') != '0'
+        U = E // 2 if paired else E
+        if paired:
+            cands = {'fc6_edge': ('fc6 on the unordered box pairs, forward: [%d x 25088] . [4096 x 25088]^T (f32 out; the per-edge rect '
+                                  'term, bias and ReLU follow in a K = 512 launch)' % U, 2.0 * U * 4096 * 25088),
+                     'bwd_fc6_edge_dW': ('fc6 weight gradient over the unordered pairs: [4096 x %d] . [25088 x %d]^T' % (U, U),
+                                         2.0 * U * 4096 * 25088)}
+        else:
+            cands = {'fc6_edge': ('fc6 on edges, forward: [%d x 25600] . [4096 x 25600]^T' % E, 2.0 * E * 4096 * 25600),
+                     'bwd_fc6_edge_dW': ('fc6 weight gradient: [4096 x %d] . [25088 x %d]^T (the rect term rides in the transpose)' % (E, E),
+                                         2.0 * E * 4096 * 25088)}
+        ref_flop = {'fc6_edge': 2.0 * E * 4096 * 25600, 'bwd_fc6_edge_dW': 2.0 * E * 4096 * 25088}
         best = None
         for tag, (desc, flop) in cands.items():
             ms = per_step('sgg_gemm', tag) + per_step('sgg_gemm_splitk', tag)   # a contraction may be issued as a full-round launch + a split-K tail
@@ -520,7 +532,11 @@ def main():
             'roofline': {'kernel': '256x256 ping-pong MFMA kernel (+ the 128x128 split-K launch that replaces a nearly empty last round), %s' % desc, 'bound': 'mfma', 'achieved': round(tf, 2), 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': round(tf / peak, 4),
                          'traffic': pmc_traffic('fc6_edge_gemm' if tag == 'fc6_edge' else 'fc6_dW_gemm') if (B == 8 and args.dtype == 'bf16') else None,
-                         'ms_per_step': round(ms, 4)},
+                         'ms_per_step': round(ms, 4), 'executed_flop': flop,
+                         'reference_algorithm_tflops': round(ref_flop[tag] / (ms * 1e-3) / 1e12, 2),
+                         'note': ('achieved = FLOPs the launch executes / its time; the reference runs this contraction on every EDGE '
+                                  '(SURVEY 8(d)), here it runs once per unordered box pair: reference_algorithm_tflops prices the '
+                                  'reference\'s FLOPs over the same time') if paired else None},
             'roofline_imp': {'kernel': 'imp_sliced_kernel (gather + 4 gates + scatter, every edge row read once), one launch per IMP iteration', 'bound': 'hbm',
                              'achieved': round(imp_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                              'frac': round(imp_gbs / HBM_PEAK_GBS, 4),

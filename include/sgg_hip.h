@@ -198,6 +198,22 @@ int sgg_imp_edge_in_fwd(const void* v, const int* so /*[E,2]*/, const float* nod
 int sgg_imp_ctx_fwd(const void* e, const float* gates_oi /*[E,2]*/, const int* so /*[E,2] or NULL*/, const int* in_ptr, const int* in_ids,
                     const int* img_ptr, int B, int N, int E, int H, void* ctx2 /*[2,N,H] or [N,H]*/, int max_edges, int max_nodes, int sum_ctx,
                     int dtype, void* stream);
+/* ---- unordered box pairs (edge_pairs.hip).  The union box of (subject, object) and (object, subject) is one box: its RoIAlign row and
+ * the long part of fc6 on it (sgg_models/rel_model_base.py:245-260, rel_model_stanford.py:104 compute both per edge) are computed
+ * once per unordered pair {i < j} of an image, slot u = ubase[img] + i (2n - i - 1) / 2 + (j - i - 1) (image-local i, j; n boxes).
+ * pair_slots: rel_inds i64[E,3] (image, subject, object: global box indices) + per-image first box / first slot / box count ->
+ *   e2u i32[E] (slot of every edge) and u2e i32[U,2] (the at most two edges of every slot, -1 = none; filled in arrival order);
+ *   ucount i32[U] is scratch; *flag: bit 0 = an edge outside its image's boxes, bit 1 = more than two edges on a pair.
+ * gemm_addrows: sgg_gemm with an f32 row add_rows[add_idx[m]] (add_idx NULL: row m) added before bias and activation.
+ * transpose_pairsum: out [C, ld_out] (x's element type) with out[c][u] = x[a][c] + x[b][c], (a, b) = u2e[u] in ascending order; columns >= U are 0.
+ * group_bcast_add: y[m][c * group + p] += r[m][c]  (the rect term's share of fc6's weight gradient). */
+int sgg_pair_slots(const int64_t* rel_inds, const int* first, const int* ubase, const int* cnt, int E, int B, int U, int* e2u, int* u2e,
+                   int* ucount, int* flag, void* stream);
+int sgg_gemm_addrows(const void* A, int lda, const void* W, int ldw, const float* bias, const float* add_rows, int ld_add,
+                     const int* add_idx, void* C, int ldc, int M, int N, int K, int act, int in_dtype, int out_dtype, void* stream);
+int sgg_transpose_pairsum(const void* x, int64_t ldx, const int* u2e, void* out, int64_t ld_out, int U, int C, int dtype, void* stream);
+int sgg_group_bcast_add(void* y, int64_t ldy, const float* r, int64_t ldr, int M, int C, int group, int dtype, void* stream);
+
 /* ---- glue of the ResNet-50-FPN feature extractor (GQA configuration: sgg_models/rel_model_base.py:58-81; the convolutions themselves
  * run on sgg_gemm / sgg_conv3x3_relu).  NHWC, C a multiple of 8 except where noted.
  * sgg_im2col: patch matrix of a k x k / stride / pad convolution, row = output pixel, columns (ky, kx, c) zero-filled to Kp; src is a

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
             const f32x4 lo = *reinterpret_cast<const f32x4*>(est + rl * ESTRIDE + cl * 4);
             const f32x4 hi = *reinterpret_cast<const f32x4*>(est + rl * ESTRIDE + cl * 4 + 16);
             v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-            epilogue_store8(ge, cv, v, n, out_offset<CONV>(g, m, n), vec_ok);
+            epilogue_store8(ge, cv, v, m, n, out_offset<CONV>(g, m, n), vec_ok);
         }
     }
 }
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void mfma_tile_tn_kernel(const GemmArgs g) {
             const f32x4 lo = *reinterpret_cast<const f32x4*>(est + rl * ESTRIDE + cl * 4);
             const f32x4 hi = *reinterpret_cast<const f32x4*>(est + rl * ESTRIDE + cl * 4 + 16);
             v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-            epilogue_store8(ge, cv, v, n, (long)m * g.ldc + n, true);
+            epilogue_store8(ge, cv, v, m, n, (long)m * g.ldc + n, true);
         }
     }
 }
@@ -422,9 +422,9 @@ int dispatch(GemmArgs g, bool bf16, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int sgg_gemm(const void* A, int lda, const void* A2, int lda2, int K1, const void* W, int ldw, const void* W2,
-                        int ldw2, const float* bias, const float* post_scale, const float* post_shift, void* C, int ldc, int M,
-                        int N, int K, int act, int in_dtype, int out_dtype, void* stream) {
+static int gemm_impl(const void* A, int lda, const void* A2, int lda2, int K1, const void* W, int ldw, const void* W2,
+                     int ldw2, const float* bias, const float* post_scale, const float* post_shift, void* C, int ldc, int M,
+                     int N, int K, int act, int in_dtype, int out_dtype, const float* add_rows, int ld_add, const int* add_idx, void* stream) {
     if (in_dtype != SGG_F32 && in_dtype != SGG_BF16) return SGG_ERR_DTYPE;
     if (out_dtype != SGG_F32 && out_dtype != SGG_BF16) return SGG_ERR_DTYPE;
     if (M == 0 || N == 0) return SGG_OK;
@@ -447,7 +447,26 @@ extern "C" int sgg_gemm(const void* A, int lda, const void* A2, int lda2, int K1
     g.nt1 = K1 / bke; g.nt = K / bke;
     g.bias = bias; g.pscale = post_scale; g.pshift = post_shift;
     g.C = (char*)C; g.ldc = ldc; g.M = M; g.N = N; g.act = act; g.out_bf16 = out_dtype == SGG_BF16;
+    g.add_rows = add_rows; g.add_idx = add_idx; g.ld_add = ld_add;
     return dispatch<false>(g, in_dtype == SGG_BF16, (hipStream_t)stream);
+}
+
+extern "C" int sgg_gemm(const void* A, int lda, const void* A2, int lda2, int K1, const void* W, int ldw, const void* W2,
+                        int ldw2, const float* bias, const float* post_scale, const float* post_shift, void* C, int ldc, int M,
+                        int N, int K, int act, int in_dtype, int out_dtype, void* stream) {
+    return gemm_impl(A, lda, A2, lda2, K1, W, ldw, W2, ldw2, bias, post_scale, post_shift, C, ldc, M, N, K, act, in_dtype, out_dtype, nullptr, 0,
+                     nullptr, stream);
+}
+
+// C = act(A . W^T + add_rows[add_idx[m]] + bias): sgg_gemm with a gathered f32 row added to every output row before the bias and the
+// activation (add_idx NULL: row m itself).  Used where a long contraction is shared by several output rows (fc6 on the unordered box
+// pairs, once; this call adds it to the per-edge rect term of both directions).
+extern "C" int sgg_gemm_addrows(const void* A, int lda, const void* W, int ldw, const float* bias, const float* add_rows, int ld_add,
+                                const int* add_idx, void* C, int ldc, int M, int N, int K, int act, int in_dtype, int out_dtype,
+                                void* stream) {
+    if (!add_rows || ld_add < N) return SGG_ERR_ARG;
+    return gemm_impl(A, lda, nullptr, 0, K, W, ldw, nullptr, 0, bias, nullptr, nullptr, C, ldc, M, N, K, act, in_dtype, out_dtype, add_rows,
+                     ld_add, add_idx, stream);
 }
 
 namespace {

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
             const f32x4 lo = *reinterpret_cast<const f32x4*>(est + rl * ESTRIDE + cl * 4);
             const f32x4 hi = *reinterpret_cast<const f32x4*>(est + rl * ESTRIDE + cl * 4 + 16);
             v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-            epilogue_store8(g, cv, v, n, out_offset<CONV>(g, m, n), vec_ok);
+            epilogue_store8(g, cv, v, m, n, out_offset<CONV>(g, m, n), vec_ok);
         }
     }
 }

@@ -19,6 +19,10 @@ struct GemmArgs {
     char* C;
     long ldc;  // elements
     int M, N, act, out_bf16;
+    // optional gathered-row addend of the pre-activation: += add_rows[(add_idx ? add_idx[m] : m) * ld_add + n]  (f32)
+    const float* add_rows;
+    const int* add_idx;
+    long ld_add;
     int m_base;                 // first output row of this launch (rows [m_base, M): a launch may cover the tail of a problem only)
     long splitk_stride;         // bytes between the fp32 partial outputs of consecutive K splits (gridDim.y > 1)
     // conv mode: A is a zero-bordered NHWC plane [B,H+2,W+2,Cin]; C is [B,H+2p,W+2p,N]
@@ -98,8 +102,19 @@ __device__ __forceinline__ ChanVec8 load_chanvec8(const GemmArgs& g, int n) {
 }
 
 // bias -> act -> per-channel affine on 8 consecutive n, then store (vector when aligned and full)
-__device__ __forceinline__ void epilogue_store8(const GemmArgs& g, const ChanVec8& c, float (&v)[8], int n, long off, bool vec_ok) {
+__device__ __forceinline__ void epilogue_store8(const GemmArgs& g, const ChanVec8& c, float (&v)[8], int m, int n, long off, bool vec_ok) {
     const int nv = min(8, g.N - n);
+    if (g.add_rows) {
+        const float* r = g.add_rows + (long)(g.add_idx ? g.add_idx[m] : m) * g.ld_add + n;
+        if (nv == 8 && ((reinterpret_cast<uintptr_t>(r) & 15) == 0)) {
+            float t[8];
+            load8(r, t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += t[k];
+        } else {
+            for (int k = 0; k < nv; ++k) v[k] += r[k];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         float t = v[k] + c.bias[k];

@@ -304,6 +304,52 @@ def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None
     return out
 
 
+def gemm_addrows(A, W, bias, add_rows, add_idx=None, act=ACT_NONE, out_dtype=None, out=None):
+    """act(A[M,K] . W[N,K]^T + add_rows[add_idx[m]] + bias) -> [M,N]; add_rows f32 [R,N], add_idx i32 [M] (None: row m)."""
+    M, K = A.shape
+    N = W.shape[0]
+    assert A.dtype == W.dtype and tuple(W.shape) == (N, K) and add_rows.dtype == torch.float32 and add_rows.shape[1] == N
+    assert add_idx is None or (add_idx.dtype == torch.int32 and add_idx.numel() == M)
+    out_dtype = out_dtype or A.dtype
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    _lib.call('sgg_gemm_addrows', _p(A, rows_ok=True), A.stride(0), _p(W, rows_ok=True), W.stride(0),
+              _p(bias, torch.float32) if bias is not None else None, _p(add_rows, torch.float32, rows_ok=True), add_rows.stride(0),
+              _p(add_idx, torch.int32) if add_idx is not None else None, _p(out, rows_ok=True), out.stride(0), M, N, K, act, dt(A), dt(out),
+              _stream())
+    return out
+
+
+def pair_slots(rel_inds, first, ubase, cnt, U):
+    """rel_inds i64[E,3] + per-image tables (i32[B]) -> (e2u i32[E], u2e i32[U,2], flag i32[1]); see include/sgg_hip.h"""
+    E, B = rel_inds.shape[0], first.numel()
+    dev = rel_inds.device
+    e2u = torch.empty(E, dtype=torch.int32, device=dev)
+    u2e = torch.empty((U, 2), dtype=torch.int32, device=dev)
+    scratch = torch.empty(U + 1, dtype=torch.int32, device=dev)
+    _lib.call('sgg_pair_slots', _p(rel_inds, torch.int64), _p(first, torch.int32), _p(ubase, torch.int32), _p(cnt, torch.int32), E, B, U,
+              _p(e2u), _p(u2e), scratch.data_ptr(), scratch.data_ptr() + 4 * U, _stream())
+    return e2u, u2e, scratch[U:]
+
+
+def transpose_pairsum(x, u2e, pad_to=64):
+    """x [E,C] (bf16 / f32, row-strided ok), u2e i32[U,2] -> [C, Up] in x's dtype: column u = the sum of the pair's edge rows (zero padded)"""
+    U, C = u2e.shape[0], x.shape[1]
+    Up = (U + pad_to - 1) // pad_to * pad_to
+    out = torch.empty((C, Up), dtype=x.dtype, device=x.device)
+    _lib.call('sgg_transpose_pairsum', _p(x, rows_ok=True), x.stride(0), _p(u2e, torch.int32), _p(out), Up, U, C, dt(x), _stream())
+    return out
+
+
+def group_bcast_add_(y, r, group):
+    """y[m, c*group + p] += r[m, c]   (y bf16 / f32 [M, C*group], r f32 [M, C])"""
+    M, C = r.shape
+    assert y.shape[0] == M and y.shape[1] == C * group and r.dtype == torch.float32
+    _lib.call('sgg_group_bcast_add', _p(y, rows_ok=True), y.stride(0), _p(r, torch.float32, rows_ok=True), r.stride(0), M, C, group, dt(y),
+              _stream())
+    return y
+
+
 N_CU = 256     # MI355X
 SPAN_LIMIT = 0xffff0000     # bytes one GEMM / conv operand may span (32-bit lane offsets, gemm.hip)
 
@@ -318,7 +364,7 @@ def gemm_full_waves(A, W, out_dtype=None):
     tm, tn = M // 256, N // 256
     rem = (tm * tn) % N_CU
     kt = K // (64 if A.dtype == torch.bfloat16 else 32)
-    if M % 256 or N % 256 or tm * tn < 2 * N_CU or rem == 0 or rem > N_CU // 4 or rem % tm or kt < 64:   # short reductions: nothing to split
+    if M % 256 or N % 256 or tm * tn < 2 * N_CU or rem == 0 or rem > N_CU // 4 or rem % tm or kt < 32:   # short reductions: nothing to split
         return gemm(A, W, out_dtype=out_dtype)
     n1 = N - (rem // tm) * 256
     out = torch.empty((M, N), dtype=out_dtype or A.dtype, device=A.device)

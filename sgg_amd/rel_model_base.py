@@ -234,6 +234,7 @@ class RelModelBase(nn.Module):
         result.fmap = as_nchw_view(fmap)
         result.rois = torch.cat((im_inds.float()[:, None], priors), 1)
         result._num_pairs = sum((e - s) * (e - s - 1) for _, s, e in segs)   # host-side count (private)
+        result._segs = segs                                                    # (image, first box, end box): host-side (private)
         # host-side facts about the graphs (private): (images, most nodes, most candidate edges in one image).  In training
         # gt_labels knows the exact rows per image (duplicate FG relations add rows) when the batch has a host mirror.
         worst = getattr(rel_labels, '_sgg_max_edges', None) if rel_labels is not None else \
@@ -280,8 +281,10 @@ class RelModelBase(nn.Module):
         result.rois = torch.cat((im_inds.float()[:, None], result.rm_box_priors), 1)
         return result
 
-    def node_edge_features(self, fmap, rois, union_inds, im_sizes):
-        """rel_model_base.py:245-260: RoIAlign of the boxes and of the pair union boxes (union fused in-kernel)."""
+    def node_edge_features(self, fmap, rois, union_inds, im_sizes, _pairing=None):
+        """rel_model_base.py:245-260: RoIAlign of the boxes and of the pair union boxes (union fused in-kernel).
+        _pairing (sgg_amd/pairing.py, only forward() passes it): pool every unordered pair once; the edge features come back as a
+        PairedEdgeFeat ([U,C,P,P] rows + the edge -> row map; `.dense()` = the [E,C,P,P] tensor)."""
         assert union_inds.shape[1] == 2, union_inds.shape
         dtype = self.compute_dtype
         fm = to_nhwc(fmap, dtype)
@@ -291,6 +294,9 @@ class RelModelBase(nn.Module):
         if fmap.requires_grad and torch.is_grad_enabled():
             return _RoIFeatures.apply(fmap, rois, union_inds.contiguous(), scale, self.pool_sz, dtype)
         node = ops.roi_align(fm, rois, None, scale, self.pool_sz, 2)
+        if _pairing is not None:
+            from .pairing import PairedEdgeFeat
+            return node, PairedEdgeFeat(ops.roi_align(fm, rois, _pairing.pairs, scale, self.pool_sz, 2), _pairing)
         edge = ops.roi_align(fm, rois, union_inds.contiguous(), scale, self.pool_sz, 2)
         return node, edge
 
@@ -340,6 +346,12 @@ class RelModelBase(nn.Module):
                     for im, _, _, _ in rels_host.tolist():
                         per_im[im] += 1
                     max_edges = max(per_im.values())
+                    # most rows on one unordered box pair (sgg_amd/pairing.py keeps two): each direction has one row, or one per
+                    # FG relation on it
+                    fg_rows = {}
+                    for im, s_, o_, _ in rels_host.tolist():
+                        fg_rows[(im, s_, o_)] = fg_rows.get((im, s_, o_), 0) + 1
+                    max_per_pair = max([2] + [c + max(1, fg_rows.get((im, o_, s_), 0)) for (im, s_, o_), c in fg_rows.items()])
             else:
                 n = int(count.item())
                 max_edges = None
@@ -369,6 +381,7 @@ class RelModelBase(nn.Module):
                 rel_labels = rel_labels[keep].contiguous()
             if max_edges is not None:
                 rel_labels._sgg_max_edges = max_edges       # sub-sampling only removes rows: still an upper bound
+                rel_labels._sgg_max_per_pair = max_per_pair
             obj_labels = gt_classes[:, 1].contiguous()
         else:
             obj_labels = gt_classes[:, 1]

@@ -1,9 +1,12 @@
 """RelModelStanford (IMP) on the HIP path -- mirror of sgg_models/rel_model_stanford.py."""
+import os
+
 import torch
 import torch.nn as nn
 
 from . import _lib, ops
 from .imp import GATES, ImpWeights, message_pass, node_lane
+from .pairing import PairedEdgeFeat, make_pairing
 from .rel_assignments import rel_assignments
 from .rel_model_base import RelModelBase, to_device_with_mirror, to_rows
 
@@ -122,13 +125,17 @@ class RelModelStanford(RelModelBase):
         N, E = node_feat.shape[0], edge_feat.shape[0]
         rel_inds = rel_inds.contiguous()
         nf = to_rows(node_feat.view(N, -1, self.pool_sz, self.pool_sz), dtype)
-        ef = to_rows(edge_feat.view(E, -1, self.pool_sz, self.pool_sz), dtype)
+        paired = edge_feat.pairing if isinstance(edge_feat, PairedEdgeFeat) else None
+        if paired is not None:       # rows of the unordered pairs [U, C*P*P]; e2u maps the edges onto them
+            ef = to_rows(edge_feat.rows.view(paired.U, -1, self.pool_sz, self.pool_sz), dtype)
+        else:
+            ef = to_rows(edge_feat.view(E, -1, self.pool_sz, self.pool_sz), dtype)
         if self.training:
             # Dropout, batch-statistic BatchNorm and the autograd node of the whole head (sgg_amd/train.py); the TwoMLPHead copies of
             # the resnet50 configuration have no Dropout layers (the VGG classifier's sit after fc6 and fc7)
             from .train import predict_train
             return predict_train(self, nf, ef, rel_inds, rois, _im_inds, dropout_p=self.dropout_p if self.backbone == 'vgg16' else 0.0,
-                                 graphs=_graphs, im_sizes=im_sizes)
+                                 graphs=_graphs, im_sizes=im_sizes, pairing=paired)
         w = self.prepared()
         # :100  union_boxes(edge_feat, rois, rel_inds[:,1:]) -- conv(rects)[E,512]; the broadcast add rides in fc6's K
         rect = self.union_boxes.rect_feat(rois, rel_inds[:, 1:].contiguous(), dtype, im_sizes)
@@ -152,7 +159,12 @@ class RelModelStanford(RelModelBase):
                 obj_rep = node_mlp()                                 # consumed on the same stream by message_pass
         # :104  relu(edge_unary(roi_fmap(edge_feat)))
         _lib.set_tag('fc6_edge')
-        y = ops.gemm(ef, w['fc6_edge'], w['fc6_edge_b'], ops.ACT_RELU, A2=rect, W2=w['fc6_edge_sum'])
+        if paired is not None:       # the long contraction once per unordered pair (f32), then per edge: + rect term + bias, ReLU
+            yu = ops.gemm(ef, w['fc6_edge'], out_dtype=torch.float32)
+            _lib.set_tag('fc6_edge_rect')
+            y = ops.gemm_addrows(rect, w['fc6_edge_sum'], w['fc6_edge_b'], yu, paired.e2u, ops.ACT_RELU)
+        else:
+            y = ops.gemm(ef, w['fc6_edge'], w['fc6_edge_b'], ops.ACT_RELU, A2=rect, W2=w['fc6_edge_sum'])
         _lib.set_tag('fc7_edge')
         y = ops.gemm(y, w['fc7_edge'], w['fc7_edge_b'], ops.ACT_RELU if self.fc_layers()[1] else ops.ACT_NONE)
         _lib.set_tag('unary')
@@ -196,8 +208,14 @@ class RelModelStanford(RelModelBase):
                                          _num=getattr(result, '_num_pairs', None))       # :144
             result.rel_inds = rel_inds
             rois = torch.cat((im_inds[:, None].float(), boxes), 1)                       # :146
+            # every unordered box pair pooled (and, in predict, sent through fc6's long contraction) once: sgg_amd/pairing.py
+            pairing = None
+            if getattr(result, '_segs', None) is not None and os.environ.get('SGG_EDGE_PAIRS', '1') != '0':
+                # (training: the sampled rows may repeat an ordered pair -- only a host mirror of gt_rels can rule that out)
+                pairing = make_pairing(rel_inds, result._segs, getattr(result.rel_labels, '_sgg_max_per_pair', 3)
+                                       if self.training and result.rel_labels is not None else 2)
             result.node_feat, result.edge_feat = self.node_edge_features(
-                result.fmap, rois, rel_inds[:, 1:], im_sizes=result.im_sizes)            # :148
+                result.fmap, rois, rel_inds[:, 1:], im_sizes=result.im_sizes, _pairing=pairing)   # :148
         result.rm_obj_dists, result.rel_dists = self.predict(result.node_feat, result.edge_feat, rel_inds,
                                                              rois=rois, im_sizes=result.im_sizes,
                                                              _im_inds=im_inds.contiguous(),
@@ -208,6 +226,8 @@ class RelModelStanford(RelModelBase):
                 gt_classes=gt_classes[:, 1].contiguous() if self.mode == 'predcls' else None, replace=self.test_bias)
         if self.training:
             result.rois = rois
+            if pairing is not None and __debug__ and os.environ.get('SGG_CHECK_COUNTS'):
+                assert int(pairing.flag.item()) == 0, ('edge list outside the promise made to the pair tables', int(pairing.flag.item()))
             return result                                                                # :179-181
         if self.mode == 'predcls':
             gt = gt_classes[:, 1].contiguous()                                           # :184-185
@@ -221,5 +241,7 @@ class RelModelStanford(RelModelBase):
         if bboxes.dim() != 2:
             raise ValueError('Boxes needs to be [num_box, 4] but its {}'.format(bboxes.size()))
         # lib/surgery.py:49-55: host numpy copies
-        return (bboxes.cpu().numpy(), obj_preds.cpu().numpy(), obj_scores.cpu().numpy(), rels.cpu().numpy(),
-                pred_scores.cpu().numpy())
+        out = (bboxes.cpu().numpy(), obj_preds.cpu().numpy(), obj_scores.cpu().numpy(), rels.cpu().numpy(), pred_scores.cpu().numpy())
+        if pairing is not None and int(pairing.flag.item()) != 0:      # (the copies above have synchronised already)
+            raise RuntimeError('sgg_amd: the relation list does not fit the unordered-pair tables (flag %d)' % int(pairing.flag.item()))
+        return out

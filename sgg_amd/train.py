@@ -112,7 +112,10 @@ class PredictFn(torch.autograd.Function):
             model._operands_ready = None
         w = train_weights(model)
         t, imp, dt = w['train'], w['imp'], model.compute_dtype
-        N, E, H = nf.shape[0], ef.shape[0], model.hidden_dim
+        N, E, H = nf.shape[0], rel_inds.shape[0], model.hidden_dim
+        paired = getattr(model, '_pairing_hint', None)   # ef holds the rows of the unordered box pairs (sgg_amd/pairing.py)
+        model._pairing_hint = None
+        assert ef.shape[0] == (paired.U if paired is not None else E), (ef.shape, E)
         ub = model.union_boxes
         dev = nf.device
         sv = {}
@@ -143,7 +146,10 @@ class PredictFn(torch.autograd.Function):
             side.wait_event(ev_main)                                 # ef and rect are ready
             with torch.cuda.stream(side):
                 PPs = model.pool_sz ** 2
-                sv['x6t'] = ops.transpose(ef, add=rect.float() if rect.dtype != torch.float32 else rect, group=PPs)
+                if paired is not None:      # the rect term does not ride here: it differs between a pair's two edges (backward)
+                    sv['x6t'] = ops.transpose(ef)
+                else:
+                    sv['x6t'] = ops.transpose(ef, add=rect.float() if rect.dtype != torch.float32 else rect, group=PPs)
                 ev = torch.cuda.Event()
                 ev.record(side)
             sv['x6t_ready'] = ev
@@ -169,7 +175,13 @@ class PredictFn(torch.autograd.Function):
         ops.gemm(x7, w['obj_unary'], w['obj_unary_b'], out=XN[:N])
         # ---- edges: relu(edge_unary(roi_fmap(edge_feat + conv(rects))))  (Linear ReLU Dropout Linear)
         _lib.set_tag('fc6_edge')
-        y6 = ops.gemm(ef, w['fc6_edge'], w['fc6_edge_b'], ops.ACT_RELU, A2=rect, W2=w['fc6_edge_sum'])
+        if paired is not None:       # the long contraction once per unordered pair (f32), then per edge: + rect term + bias, ReLU
+            yu = ops.gemm(ef, w['fc6_edge'], out_dtype=torch.float32)
+            _lib.set_tag('fc6_edge_rect')
+            y6 = ops.gemm_addrows(rect, w['fc6_edge_sum'], w['fc6_edge_b'], yu, paired.e2u, ops.ACT_RELU)
+            del yu
+        else:
+            y6 = ops.gemm(ef, w['fc6_edge'], w['fc6_edge_b'], ops.ACT_RELU, A2=rect, W2=w['fc6_edge_sum'])
         _lib.set_tag('mlp')
         if dropout_p > 0:
             ops.dropout_(y6, dropout_p, seed * 4 + 3)
@@ -213,7 +225,7 @@ class PredictFn(torch.autograd.Function):
         _lib.set_tag('heads')
         obj = ops.gemm(vT, w['obj_fc'], w['obj_fc_b'], out_dtype=torch.float32)
         rel = ops.gemm(eT, w['rel_fc'], w['rel_fc_b'], out_dtype=torch.float32)
-        sv.update(XN=XN, XE=XE, HN=HN, HE=HE, HNz=HNz, HEz=HEz, gin=gin, ghn=ghn, gie=gie, ghe=ghe, dots=dots_l, csr=csr, nf=nf, ef=ef,
+        sv.update(paired=paired, XN=XN, XE=XE, HN=HN, HE=HE, HNz=HNz, HEz=HEz, gin=gin, ghn=ghn, gie=gie, ghe=ghe, dots=dots_l, csr=csr, nf=nf, ef=ef,
                   rel_inds=rel_inds, N=N, E=E, H=H, dropout_p=dropout_p)
         _lib.set_tag('')
         ctx.model, ctx.sv = model, sv
@@ -348,13 +360,25 @@ class PredictFn(torch.autograd.Function):
         # ---- phase B: the two fc6 weight gradients
         _lib.set_tag('bwd_fc6_edge_dW')
         # d W6[n,(c,p)] = sum_e d_pre6[e,n] * (edge_feat[e,c,p] + rect[e,c]): the folded term rides in the transpose
+        paired = sv['paired']
         if 'x6t' in sv:
             torch.cuda.current_stream(dev).wait_event(sv['x6t_ready'])
             x6t = sv['x6t']
+        elif paired is not None:
+            x6t = ops.transpose(sv['ef'])
         else:
             x6t = ops.transpose(sv['ef'], add=sv['rect'].float() if sv['rect'].dtype != torch.float32 else sv['rect'], group=PP)
-        d6t, G[n6e + '.bias'] = ops.transpose(d_pre6, want_colsum=True)
-        G[n6e + '.weight'] = ops.gemm_full_waves(d6t, x6t, out_dtype=big_dtype())
+        if paired is not None:
+            # rows of the unordered pairs: d W6[n,(c,p)] = sum_u (d_pre6[e1(u),n] + d_pre6[e2(u),n]) pooled[u,c,p]  +  (sum_e d_pre6[e,n] rect[e,c])
+            # broadcast over p -- the second term is the gradient through W6's group sums (the folded rect term of the forward)
+            d6t = ops.transpose_pairsum(d_pre6, paired.u2e)
+            G[n6e + '.bias'] = ops.colsum(d_pre6, pool)
+            gw6 = ops.gemm_full_waves(d6t, x6t, out_dtype=big_dtype())
+            ops.group_bcast_add_(gw6, tn_gemm(d_pre6, sv['rect']), PP)
+            G[n6e + '.weight'] = gw6
+        else:
+            d6t, G[n6e + '.bias'] = ops.transpose(d_pre6, want_colsum=True)
+            G[n6e + '.weight'] = ops.gemm_full_waves(d6t, x6t, out_dtype=big_dtype())
         hook(n6e + '.weight')
         del x6t, d6t
         _lib.set_tag('bwd_mlp_obj')
@@ -404,20 +428,23 @@ class PredictFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             d_nf = ops.gemm(d_p6, ops.transpose(w['fc6_obj']), out_dtype=torch.float32)
         if ctx.needs_input_grad[2]:
+            if paired is not None:
+                raise NotImplementedError('gradient into pair-pooled edge features (pass dense edge features to predict())')
             d_ef = ops.gemm(d_pre6, ops.transpose(w['fc6_edge']), out_dtype=torch.float32)
         return (None, d_nf, d_ef) + (None,) * 5 + tuple(grads)
 
 
 def predict_train(model, node_feat, edge_feat, rel_inds, rois, im_inds=None, seed=None, dropout_p=DROPOUT_P, graphs=None,
-                  im_sizes=None):
+                  im_sizes=None, pairing=None):
     """Autograd-connected training forward of the head.  node_feat/edge_feat: [.,P,P,C]-contiguous (NHWC) tensors
     in the compute dtype."""
-    N, E = node_feat.shape[0], edge_feat.shape[0]
+    N, E = node_feat.shape[0], edge_feat.shape[0]      # (E: rows of edge_feat -- the unordered pairs when `pairing` is given)
     if seed is None:
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
     named = dict(model.head_named_parameters())
     params = [named[n] for n in param_names(model)]
     model._graphs_hint = graphs     # host-side facts about the graphs (ops.edge_csr), read by PredictFn.forward
     model._im_sizes_hint = im_sizes  # image sizes for the 'raw_boxes' raster (lib/get_union_boxes.py:71-78)
+    model._pairing_hint = pairing    # sgg_amd/pairing.py: edge_feat holds one row per unordered box pair
     return PredictFn.apply(model, node_feat.reshape(N, -1), edge_feat.reshape(E, -1), rois.float().contiguous(),
                            rel_inds.contiguous(), im_inds, seed, float(dropout_p), *params)

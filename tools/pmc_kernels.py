@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Runs the two roofline kernels in isolation (for rocprofv3 --pmc passes): the fc6-on-edges GEMM and the fused IMP
-gather/gate/scatter at B=8 and B=128.  Usage under the profiler:
+"""Runs the roofline kernels in isolation (for rocprofv3 --pmc passes): the fc6 GEMM on the unordered box pairs (forward and weight
+gradient, B=8: 3968 pairs) and the IMP gather/gate/scatter step at B=8 and B=128.  Usage under the profiler:
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d out -o fetch -- python3 tools/pmc_kernels.py
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d out -o write -- python3 tools/pmc_kernels.py
 """
@@ -15,24 +15,20 @@ from sgg_amd import ops  # noqa: E402
 dev = 'cuda:0'
 g = torch.Generator().manual_seed(0)
 dt = torch.bfloat16
-# fc6 on edges
-M, N, K1, K2 = 7936, 4096, 25088, 512
+# fc6 on the unordered box pairs (sgg_amd/pairing.py): [U, 25088] . [4096, 25088]^T, f32 out
+M, N, K1 = 3968, 4096, 25088
 A = torch.randn(M, K1, generator=g).to(dev).to(dt).relu()
-A2 = torch.randn(M, K2, generator=g).to(dev).to(dt)
 W = (torch.randn(N, K1, generator=g) / 160).to(dev).to(dt)
-W2 = (torch.randn(N, K2, generator=g) / 160).to(dev).to(dt)
-b = torch.randn(N, generator=g).to(dev)
-out = torch.empty(M, N, device=dev, dtype=dt)
+out = torch.empty(M, N, device=dev, dtype=torch.float32)
 for _ in range(3):
-    ops.gemm(A, W, b, ops.ACT_RELU, A2=A2, W2=W2, out=out)
+    ops.gemm(A, W, out=out, out_dtype=torch.float32)
 torch.cuda.synchronize()
-# fc6 weight gradient (the train step's largest contraction): dW[4096, 25088] = d_pre6^T [4096, 7936] . x6^T [25088, 7936]^T, fp32 out
-Mg, Ng, Kg = 4096, 25088, 7936
+# its weight gradient (the train step's largest contraction): dW[4096, 25088] = (pair-summed d_pre6)^T [4096, U] . pooled^T [25088, U]^T
+Mg, Ng, Kg = 4096, 25088, 3968
 At = (torch.randn(Mg, Kg, generator=g) / 50).to(dev).to(dt)
 Bt = torch.randn(Ng, Kg, generator=g).to(dev).to(dt).relu()
-dW = torch.empty(Mg, Ng, device=dev, dtype=torch.float32)
 for _ in range(3):
-    ops.gemm(At, Bt, out_dtype=torch.float32, out=dW)
+    dW = ops.gemm_full_waves(At, Bt, out_dtype=dt)
 torch.cuda.synchronize()
 del At, Bt, dW
 # IMP fused

@@ -24,7 +24,7 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
         agg[(r['Kernel_Name'], wgs)].append(float(r['Counter_Value']))
     for (k, wgs), v in agg.items():
         key = None
-        if 'mfma_pingpong_kernel' in k and wgs == 496:
+        if 'mfma_pingpong_kernel' in k and wgs == 256:
             key = 'fc6_edge_gemm'
         elif 'mfma_pingpong_kernel' in k and wgs >= 1500:
             key = 'fc6_dW_gemm'
