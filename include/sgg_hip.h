@@ -206,13 +206,16 @@ int sgg_imp_ctx_fwd(const void* e, const float* gates_oi /*[E,2]*/, const int* s
  *   ucount i32[U] is scratch; *flag: bit 0 = an edge outside its image's boxes, bit 1 = more than two edges on a pair.
  * gemm_addrows: sgg_gemm with an f32 row add_rows[add_idx[m]] (add_idx NULL: row m) added before bias and activation.
  * transpose_pairsum: out [C, ld_out] (x's element type) with out[c][u] = x[a][c] + x[b][c], (a, b) = u2e[u] in ascending order; columns >= U are 0.
- * group_bcast_add: y[m][c * group + p] += r[m][c]  (the rect term's share of fc6's weight gradient). */
+ * group_bcast_add: y[m][j] += r[m][(j + col0) / group], j < ncol  (the rect term's share of fc6's weight gradient);
+ * gemm_groupadd: the same addend in the epilogue of sgg_gemm (no bias, no activation). */
 int sgg_pair_slots(const int64_t* rel_inds, const int* first, const int* ubase, const int* cnt, int E, int B, int U, int* e2u, int* u2e,
                    int* ucount, int* flag, void* stream);
 int sgg_gemm_addrows(const void* A, int lda, const void* W, int ldw, const float* bias, const float* add_rows, int ld_add,
                      const int* add_idx, void* C, int ldc, int M, int N, int K, int act, int in_dtype, int out_dtype, void* stream);
 int sgg_transpose_pairsum(const void* x, int64_t ldx, const int* u2e, void* out, int64_t ld_out, int U, int C, int dtype, void* stream);
-int sgg_group_bcast_add(void* y, int64_t ldy, const float* r, int64_t ldr, int M, int C, int group, int dtype, void* stream);
+int sgg_group_bcast_add(void* y, int64_t ldy, const float* r, int64_t ldr, int M, int ncol, int group, int col0, int dtype, void* stream);
+int sgg_gemm_groupadd(const void* A, int lda, const void* W, int ldw, const float* gadd, int ld_gadd, int group, int col0, void* C, int ldc,
+                      int M, int N, int K, int in_dtype, int out_dtype, void* stream);
 
 /* ---- glue of the ResNet-50-FPN feature extractor (GQA configuration: sgg_models/rel_model_base.py:58-81; the convolutions themselves
  * run on sgg_gemm / sgg_conv3x3_relu).  NHWC, C a multiple of 8 except where noted.

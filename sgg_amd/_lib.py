@@ -90,7 +90,8 @@ SIGNATURES = {
     'sgg_pair_slots': [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     'sgg_gemm_addrows': [_P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'sgg_transpose_pairsum': [_P, _L, _P, _P, _L, _I, _I, _I, _P],
-    'sgg_group_bcast_add': [_P, _L, _P, _L, _I, _I, _I, _I, _P],
+    'sgg_group_bcast_add': [_P, _L, _P, _L, _I, _I, _I, _I, _I, _P],
+    'sgg_gemm_groupadd': [_P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     'sgg_add': [_P, _P, _L, _I, _I, _P],
     'sgg_sqnorm_acc': [_P, _L, _P, _I, _P],
     'sgg_sgd_step': [_P, _P, _P, _L, _F, _F, _F, _I, _P, _F, _F, _I, _P],

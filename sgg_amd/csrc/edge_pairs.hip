@@ -57,12 +57,11 @@ __global__ __launch_bounds__(256) void transpose_pairsum_kernel(const T* __restr
     }
 }
 
-// y[m][c * group + p] += r[m][c]
+// y[m][j] += r[m][(j + col0) / group],  j < ncol
 template <typename T>
 __global__ __launch_bounds__(256) void group_bcast_add_kernel(T* __restrict__ y, long ldy, const float* __restrict__ r, long ldr, int M,
-                                                              int C, int group) {
+                                                              int ncol, int group, int col0) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const int ncol = C * group;
     const long per_row = (ncol + 7) / 8;
     const int m = (int)(i / per_row), j0 = (int)(i - (long)m * per_row) * 8;
     if (m >= M) return;
@@ -72,10 +71,10 @@ __global__ __launch_bounds__(256) void group_bcast_add_kernel(T* __restrict__ y,
         float v[8];
         load8(p, v);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] += rr[(j0 + k) / group];
+        for (int k = 0; k < 8; ++k) v[k] += rr[(j0 + k + col0) / group];
         store8(p, v);
     } else {
-        for (int k = 0; k < 8 && j0 + k < ncol; ++k) Elem<T>::st(p + k, Elem<T>::ld(p + k) + rr[(j0 + k) / group]);
+        for (int k = 0; k < 8 && j0 + k < ncol; ++k) Elem<T>::st(p + k, Elem<T>::ld(p + k) + rr[(j0 + k + col0) / group]);
     }
 }
 }  // namespace
@@ -110,16 +109,17 @@ extern "C" int sgg_transpose_pairsum(const void* x, int64_t ldx, const int* u2e,
     return SGG_OK;
 }
 
-extern "C" int sgg_group_bcast_add(void* y, int64_t ldy, const float* r, int64_t ldr, int M, int C, int group, int dtype, void* stream) {
-    if (M == 0 || C == 0) return SGG_OK;
-    if (!y || !r || M < 0 || C < 0 || group <= 0 || ldy < (int64_t)C * group || ldr < C) return SGG_ERR_ARG;
-    const long per_row = ((long)C * group + 7) / 8;
+extern "C" int sgg_group_bcast_add(void* y, int64_t ldy, const float* r, int64_t ldr, int M, int ncol, int group, int col0, int dtype,
+                                   void* stream) {
+    if (M == 0 || ncol == 0) return SGG_OK;
+    if (!y || !r || M < 0 || ncol < 0 || group <= 0 || col0 < 0 || ldy < ncol || ldr * group < (int64_t)ncol + col0) return SGG_ERR_ARG;
+    const long per_row = ((long)ncol + 7) / 8;
     const dim3 grid((unsigned)((per_row * M + 255) / 256)), blk(256);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == SGG_BF16)
-        hipLaunchKernelGGL(group_bcast_add_kernel<bf16_t>, grid, blk, 0, s, (bf16_t*)y, (long)ldy, r, (long)ldr, M, C, group);
+        hipLaunchKernelGGL(group_bcast_add_kernel<bf16_t>, grid, blk, 0, s, (bf16_t*)y, (long)ldy, r, (long)ldr, M, ncol, group, col0);
     else if (dtype == SGG_F32)
-        hipLaunchKernelGGL(group_bcast_add_kernel<float>, grid, blk, 0, s, (float*)y, (long)ldy, r, (long)ldr, M, C, group);
+        hipLaunchKernelGGL(group_bcast_add_kernel<float>, grid, blk, 0, s, (float*)y, (long)ldy, r, (long)ldr, M, ncol, group, col0);
     else
         return SGG_ERR_DTYPE;
     SGG_CHECK_LAUNCH();

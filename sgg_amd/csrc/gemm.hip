@@ -424,7 +424,8 @@ int dispatch(GemmArgs g, bool bf16, hipStream_t s) {
 
 static int gemm_impl(const void* A, int lda, const void* A2, int lda2, int K1, const void* W, int ldw, const void* W2,
                      int ldw2, const float* bias, const float* post_scale, const float* post_shift, void* C, int ldc, int M,
-                     int N, int K, int act, int in_dtype, int out_dtype, const float* add_rows, int ld_add, const int* add_idx, void* stream) {
+                     int N, int K, int act, int in_dtype, int out_dtype, const float* add_rows, int ld_add, const int* add_idx, void* stream,
+                     const float* gadd = nullptr, int ld_gadd = 0, int ggroup = 1, int gcol0 = 0) {
     if (in_dtype != SGG_F32 && in_dtype != SGG_BF16) return SGG_ERR_DTYPE;
     if (out_dtype != SGG_F32 && out_dtype != SGG_BF16) return SGG_ERR_DTYPE;
     if (M == 0 || N == 0) return SGG_OK;
@@ -448,6 +449,7 @@ static int gemm_impl(const void* A, int lda, const void* A2, int lda2, int K1, c
     g.bias = bias; g.pscale = post_scale; g.pshift = post_shift;
     g.C = (char*)C; g.ldc = ldc; g.M = M; g.N = N; g.act = act; g.out_bf16 = out_dtype == SGG_BF16;
     g.add_rows = add_rows; g.add_idx = add_idx; g.ld_add = ld_add;
+    g.gadd = gadd; g.ld_gadd = ld_gadd; g.ggroup = ggroup; g.gcol0 = gcol0;
     return dispatch<false>(g, in_dtype == SGG_BF16, (hipStream_t)stream);
 }
 
@@ -467,6 +469,15 @@ extern "C" int sgg_gemm_addrows(const void* A, int lda, const void* W, int ldw, 
     if (!add_rows || ld_add < N) return SGG_ERR_ARG;
     return gemm_impl(A, lda, nullptr, 0, K, W, ldw, nullptr, 0, bias, nullptr, nullptr, C, ldc, M, N, K, act, in_dtype, out_dtype, add_rows,
                      ld_add, add_idx, stream);
+}
+
+// C[m][n] = A . W^T + gadd[m][(n + col0) / group]: sgg_gemm with one f32 addend per output row and group of `group` consecutive
+// columns (fc6's weight gradient on the unordered pairs: the rect term's share, constant over the 49 positions of a channel).
+extern "C" int sgg_gemm_groupadd(const void* A, int lda, const void* W, int ldw, const float* gadd, int ld_gadd, int group, int col0,
+                                 void* C, int ldc, int M, int N, int K, int in_dtype, int out_dtype, void* stream) {
+    if (!gadd || group <= 0 || col0 < 0 || (long)ld_gadd * group < (long)N + col0) return SGG_ERR_ARG;
+    return gemm_impl(A, lda, nullptr, 0, K, W, ldw, nullptr, 0, nullptr, nullptr, nullptr, C, ldc, M, N, K, SGG_ACT_NONE, in_dtype, out_dtype,
+                     nullptr, 0, nullptr, stream, gadd, ld_gadd, group, col0);
 }
 
 namespace {

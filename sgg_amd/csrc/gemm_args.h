@@ -23,6 +23,10 @@ struct GemmArgs {
     const float* add_rows;
     const int* add_idx;
     long ld_add;
+    // optional group-broadcast addend: += gadd[m * ld_gadd + (n + gcol0) / ggroup]  (f32; one value per output row and column group)
+    const float* gadd;
+    long ld_gadd;
+    int ggroup, gcol0;
     int m_base;                 // first output row of this launch (rows [m_base, M): a launch may cover the tail of a problem only)
     long splitk_stride;         // bytes between the fp32 partial outputs of consecutive K splits (gridDim.y > 1)
     // conv mode: A is a zero-bordered NHWC plane [B,H+2,W+2,Cin]; C is [B,H+2p,W+2p,N]
@@ -114,6 +118,11 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& g, const ChanVec
         } else {
             for (int k = 0; k < nv; ++k) v[k] += r[k];
         }
+    }
+    if (g.gadd) {
+        const float* r = g.gadd + (long)m * g.ld_gadd;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += r[(n + k + g.gcol0) / g.ggroup];     // (columns past N: computed, never stored)
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {

@@ -341,12 +341,12 @@ def transpose_pairsum(x, u2e, pad_to=64):
     return out
 
 
-def group_bcast_add_(y, r, group):
-    """y[m, c*group + p] += r[m, c]   (y bf16 / f32 [M, C*group], r f32 [M, C])"""
+def group_bcast_add_(y, r, group, col0=0):
+    """y[m, j] += r[m, (j + col0) // group]   (y bf16 / f32 [M, ncol], r f32 [M, C])"""
     M, C = r.shape
-    assert y.shape[0] == M and y.shape[1] == C * group and r.dtype == torch.float32
-    _lib.call('sgg_group_bcast_add', _p(y, rows_ok=True), y.stride(0), _p(r, torch.float32, rows_ok=True), r.stride(0), M, C, group, dt(y),
-              _stream())
+    assert y.shape[0] == M and y.shape[1] + col0 <= C * group and r.dtype == torch.float32
+    _lib.call('sgg_group_bcast_add', _p(y, rows_ok=True), y.stride(0), _p(r, torch.float32, rows_ok=True), r.stride(0), M, y.shape[1], group,
+              col0, dt(y), _stream())
     return y
 
 
@@ -354,23 +354,36 @@ N_CU = 256     # MI355X
 SPAN_LIMIT = 0xffff0000     # bytes one GEMM / conv operand may span (32-bit lane offsets, gemm.hip)
 
 
-def gemm_full_waves(A, W, out_dtype=None):
+def gemm_full_waves(A, W, out_dtype=None, gadd=None):
     """A[M,K] . W[N,K]^T for the large weight-gradient contractions.  The ping-pong kernel runs one 256x256 tile per CU, so a tile
     count just above a multiple of 256 costs a whole extra round for a few tiles (fc6 weight gradient: 16 x 98 = 1568 tiles = 6.125
     rounds).  When the last round would be at most a quarter full and consists of whole tile columns, those columns are computed by a
-    split-K launch of the 128x128 kernel that fills the chip instead, and the main launch is an exact number of rounds."""
+    split-K launch of the 128x128 kernel that fills the chip instead, and the main launch is an exact number of rounds.
+    gadd = (r f32 [M, N / group], group): out[m, n] += r[m, n // group], in the GEMM's epilogue."""
     M, K = A.shape
     N = W.shape[0]
     tm, tn = M // 256, N // 256
     rem = (tm * tn) % N_CU
     kt = K // (64 if A.dtype == torch.bfloat16 else 32)
+
+    def main(Wp, out, col0=0):
+        if gadd is None:
+            return gemm(A, Wp, out=out, out_dtype=out_dtype)
+        r, group = gadd
+        if out is None:
+            out = torch.empty((M, Wp.shape[0]), dtype=out_dtype or A.dtype, device=A.device)
+        _lib.call('sgg_gemm_groupadd', _p(A, rows_ok=True), A.stride(0), _p(Wp, rows_ok=True), Wp.stride(0), _p(r, torch.float32, rows_ok=True),
+                  r.stride(0), group, col0, _p(out, rows_ok=True), out.stride(0), M, Wp.shape[0], K, dt(A), dt(out), _stream())
+        return out
     if M % 256 or N % 256 or tm * tn < 2 * N_CU or rem == 0 or rem > N_CU // 4 or rem % tm or kt < 32:   # short reductions: nothing to split
-        return gemm(A, W, out_dtype=out_dtype)
+        return main(W, None)
     n1 = N - (rem // tm) * 256
     out = torch.empty((M, N), dtype=out_dtype or A.dtype, device=A.device)
-    gemm(A, W[:n1], out=out[:, :n1])
+    main(W[:n1], out[:, :n1])
     tail_tiles = (M // 128) * ((N - n1) // 128)
     tail = gemm(A, W[n1:], out_dtype=out.dtype, splits=max(2, min(8, (2 * N_CU) // tail_tiles, kt // 8)))
+    if gadd is not None:
+        group_bcast_add_(tail, gadd[0], gadd[1], col0=n1)
     out[:, n1:].copy_(tail)
     return out
 

@@ -373,9 +373,7 @@ class PredictFn(torch.autograd.Function):
             # broadcast over p -- the second term is the gradient through W6's group sums (the folded rect term of the forward)
             d6t = ops.transpose_pairsum(d_pre6, paired.u2e)
             G[n6e + '.bias'] = ops.colsum(d_pre6, pool)
-            gw6 = ops.gemm_full_waves(d6t, x6t, out_dtype=big_dtype())
-            ops.group_bcast_add_(gw6, tn_gemm(d_pre6, sv['rect']), PP)
-            G[n6e + '.weight'] = gw6
+            G[n6e + '.weight'] = ops.gemm_full_waves(d6t, x6t, out_dtype=big_dtype(), gadd=(tn_gemm(d_pre6, sv['rect']), PP))
         else:
             d6t, G[n6e + '.bias'] = ops.transpose(d_pre6, want_colsum=True)
             G[n6e + '.weight'] = ops.gemm_full_waves(d6t, x6t, out_dtype=big_dtype())

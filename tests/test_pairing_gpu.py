@@ -116,6 +116,29 @@ def test_pair_kernels(dtype):
     got = ops.group_bcast_add_(cu(y).clone(), cu(r), grp)
     ref = (y.float() + r.repeat_interleave(grp, 1)).to(dtype)
     torch.testing.assert_close(got.cpu().float(), ref.float(), atol=0, rtol=0)
+    got = ops.group_bcast_add_(cu(y[:, :100]).clone(), cu(r), grp, col0=30)     # a column slice: groups counted from column 30
+    ref = (y[:, :100].float() + r.repeat_interleave(grp, 1)[:, 30:130]).to(dtype)
+    torch.testing.assert_close(got.cpu().float(), ref.float(), atol=0, rtol=0)
+
+
+def test_weight_gradient_gemm_with_group_addend_in_its_epilogue():
+    """gemm_full_waves(gadd=...): whole rounds of the ping-pong kernel with the addend in the epilogue + the split-K tail columns with
+    the addend applied afterwards = GEMM + broadcast add"""
+    from sgg_amd import ops
+    g = torch.Generator().manual_seed(8)
+    M, K, grp = 512, 2048, 49
+    for N in (66048, 1024):                 # 516 tiles: 2 rounds + 4 tiles of tail; 8 tiles: one launch
+        A = (torch.randn(M, K, generator=g) / 8).to(torch.bfloat16)
+        W = (torch.randn(N, K, generator=g) / 8).to(torch.bfloat16)
+        C = (N + grp - 1) // grp
+        r = torch.randn(M, C, generator=g)
+        out = ops.gemm_full_waves(cu(A), cu(W), out_dtype=torch.float32, gadd=(cu(r), grp))
+        plain = ops.gemm_full_waves(cu(A), cu(W), out_dtype=torch.float32)
+        ref = plain.cpu() + r.repeat_interleave(grp, 1)[:, :N]
+        torch.testing.assert_close(out.cpu(), ref, atol=1e-4, rtol=1e-5)
+        n4 = min(N, 4096)
+        chk = A[:64].float() @ W[:n4].float().t() + r[:64].repeat_interleave(grp, 1)[:, :n4]
+        torch.testing.assert_close(out[:64, :n4].cpu(), chk, atol=2e-2, rtol=2e-3)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
