@@ -398,9 +398,11 @@ int dispatch(GemmArgs g, bool bf16, hipStream_t s) {
             // half full and is made of whole tile rows, those pixels go to the 128x128 kernel (two workgroups per CU: 4 x rem tiles
             // fill the chip once at most) and the main launch is an exact number of rounds.  Same K order in both kernels.
             static const char* notail = getenv("SGG_CONV_NOTAIL");
+            static const char* tmax = getenv("SGG_CONV_TAIL_MAX");        // experiments: largest last round (tiles) that becomes a tail
+            const long tail_max = tmax ? atol(tmax) : 112;
             const int tN = (g.N + 255) / 256;
             const long rem = tiles256 % N_CU_CHIP;
-            if (bf16 && !notail && g.m_base == 0 && tiles256 > N_CU_CHIP && rem > 0 && rem <= 112 && (tiles256 - rem) % tN == 0) {
+            if (bf16 && !notail && g.m_base == 0 && tiles256 > N_CU_CHIP && rem > 0 && rem <= tail_max && (tiles256 - rem) % tN == 0) {
                 GemmArgs tail = g;
                 tail.m_base = (int)((tiles256 - rem) / tN) * 256;
                 g.M = tail.m_base;
