@@ -77,11 +77,16 @@ class PairedEdgeFeat(object):
         return torch.Size((self.pairing.E,) + tuple(self.rows.shape[1:]))
 
     def __getattr__(self, name):
-        if name.startswith('__'):
+        if name.startswith('__') or name in ('rows', 'pairing', '_dense'):     # (copy / pickle probe an object before __init__ ran)
             raise AttributeError(name)
         return getattr(self.dense(), name)
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
-        conv = lambda a: a.dense() if isinstance(a, PairedEdgeFeat) else a   # noqa: E731
-        return func(*[conv(a) for a in args], **{k: conv(v) for k, v in (kwargs or {}).items()})
+        def conv(a):
+            if isinstance(a, PairedEdgeFeat):
+                return a.dense()
+            if isinstance(a, (tuple, list)):
+                return type(a)(conv(x) for x in a)
+            return a
+        return func(*conv(tuple(args)), **{k: conv(v) for k, v in (kwargs or {}).items()})
