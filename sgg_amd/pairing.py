@@ -59,6 +59,35 @@ def make_pairing(rel_inds, segs, max_per_pair=2):
     return EdgePairing(pairs, e2u, u2e, flag, U, E)
 
 
+def make_pairing_symmetric(rel_inds, n_boxes, min_edges=256):
+    """Pairing for a SYMMETRIC edge list -- (s, o) present iff (o, s) is -- sorted by (subject, object), e.g. the overlap-filtered
+    pairs of get_rel_inds in eval mode (IoU is symmetric): the U = E / 2 edges with s < o are the slots, in list order; every other
+    edge finds its partner by binary search.  Device-side torch index arithmetic, no host synchronisation: E is the only size needed.
+    A list that breaks the promise sets `flag` (checked where the forward synchronises anyway)."""
+    E = rel_inds.shape[0]
+    if E < min_edges or E % 2:
+        return None
+    U = E // 2
+    dev = rel_inds.device
+    s, o = rel_inds[:, 1], rel_inds[:, 2]
+    prim = s < o
+    order = torch.sort((~prim).to(torch.uint8), stable=True).indices          # the edges with s < o first, both halves in list order
+    prim_idx, rev_idx = order[:U], order[U:]
+    keys = s * n_boxes + o                                                     # ascending along the list
+    tgt = o[rev_idx] * n_boxes + s[rev_idx]
+    pos = torch.searchsorted(keys, tgt).clamp_(max=E - 1)                      # the partner (o, s) of every edge with s > o
+    slot_of = torch.cumsum(prim, 0, dtype=torch.int32) - 1                      # slot of an edge with s < o
+    part = slot_of[pos].clamp_(0, U - 1)
+    e2u = torch.empty(E, dtype=torch.int32, device=dev)
+    e2u[prim_idx] = torch.arange(U, dtype=torch.int32, device=dev)
+    e2u[rev_idx] = part
+    u2e = torch.full((U, 2), -1, dtype=torch.int32, device=dev)
+    u2e[:, 0] = prim_idx.to(torch.int32)
+    u2e[part.long(), 1] = rev_idx.to(torch.int32)
+    bad = (prim.sum() != U) | (keys[pos] != tgt).any() | (u2e[:, 1] < 0).any()
+    return EdgePairing(rel_inds[prim_idx][:, 1:3].contiguous(), e2u, u2e, bad.to(torch.int32).view(1), U, E)
+
+
 class PairedEdgeFeat(object):
     """The edge features as [U,C,P,P] pooled rows of the unordered pairs + the edge -> slot map; `dense()` is the reference's
     [E,C,P,P] tensor.  Behaves as that tensor wherever torch functions or tensor attributes are applied to it."""

@@ -6,7 +6,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 from .imp import GATES, ImpWeights, message_pass, node_lane
-from .pairing import PairedEdgeFeat, make_pairing
+from .pairing import PairedEdgeFeat, make_pairing, make_pairing_symmetric
 from .rel_assignments import rel_assignments
 from .rel_model_base import RelModelBase, to_device_with_mirror, to_rows
 
@@ -214,6 +214,9 @@ class RelModelStanford(RelModelBase):
                 # (training: the sampled rows may repeat an ordered pair -- only a host mirror of gt_rels can rule that out)
                 pairing = make_pairing(rel_inds, result._segs, getattr(result.rel_labels, '_sgg_max_per_pair', 3)
                                        if self.training and result.rel_labels is not None else 2)
+            elif not self.training and self.mode == 'sgdet' and os.environ.get('SGG_EDGE_PAIRS', '1') != '0':
+                # detections: the overlap-filtered list of get_rel_inds is symmetric and sorted -- half of its edges are the pairs
+                pairing = make_pairing_symmetric(rel_inds, rois.shape[0])
             result.node_feat, result.edge_feat = self.node_edge_features(
                 result.fmap, rois, rel_inds[:, 1:], im_sizes=result.im_sizes, _pairing=pairing)   # :148
         result.rm_obj_dists, result.rel_dists = self.predict(result.node_feat, result.edge_feat, rel_inds,

@@ -35,3 +35,39 @@ def test_paired_edge_feat_behaves_like_the_dense_tensor():
     assert torch.equal(torch.relu(torch.sub(ef, 5)), torch.relu(dense - 5))
     c = copy.copy(ef)                                                        # no attribute recursion before __init__
     assert torch.equal(c.dense(), dense)
+
+
+def test_symmetric_sparse_lists():
+    """make_pairing_symmetric: overlap-filtered style lists ((s,o) present iff (o,s)), sorted by (subject, object)"""
+    from sgg_amd.pairing import make_pairing_symmetric
+    rng = np.random.RandomState(3)
+    counts = [9, 30, 4, 17]
+    rows, first = [], 0
+    for b, n in enumerate(counts):
+        keep = np.triu(rng.rand(n, n) < 0.4, 1)
+        keep = keep | keep.T
+        for s in range(n):
+            for o in range(n):
+                if keep[s, o]:
+                    rows.append((b, first + s, first + o))
+        first += n
+    rel = torch.tensor(rows, dtype=torch.int64)
+    pm = make_pairing_symmetric(rel, first, min_edges=2)
+    E = len(rows)
+    assert pm is not None and pm.E == E and pm.U == E // 2 and int(pm.flag.item()) == 0
+    pairs, e2u, u2e = pm.pairs.numpy(), pm.e2u.numpy(), pm.u2e.numpy()
+    assert (pairs[:, 0] < pairs[:, 1]).all() and len({tuple(p) for p in pairs.tolist()}) == pm.U
+    reln = rel.numpy()
+    np.testing.assert_array_equal(pairs[e2u], np.stack((reln[:, 1:].min(1), reln[:, 1:].max(1)), 1))
+    for u in range(pm.U):
+        a, b = u2e[u]
+        assert a != b and e2u[a] == u and e2u[b] == u and reln[a, 1] < reln[a, 2] and reln[b, 1] > reln[b, 2]
+    # slots follow the list order of the edges with s < o
+    assert (np.diff(u2e[:, 0]) > 0).all()
+    # odd or short lists: per-edge path; a list that is not symmetric raises the flag (indices stay in range)
+    assert make_pairing_symmetric(rel[:-1], first, min_edges=2) is None
+    assert make_pairing_symmetric(rel[:10], first) is None
+    broken = torch.cat((rel[:3], rel[5:], rel[-2:]))          # two edges lost their partners
+    pb = make_pairing_symmetric(broken[:(len(broken) // 2) * 2], first, min_edges=2)
+    assert pb is not None and int(pb.flag.item()) != 0
+    assert int(pb.e2u.min()) >= 0 and int(pb.e2u.max()) < pb.U
