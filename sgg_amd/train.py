@@ -165,13 +165,10 @@ class PredictFn(torch.autograd.Function):
         # row-stacked inputs / states of the 4 calls of each GRU cell
         XN = torch.empty((4 * N, H), dtype=dt, device=dev)
         XE = torch.empty((4 * E, H), dtype=dt, device=dev)
-        # block c = vert_c / edge_c (hidden state entering call c+1); one zero block in front makes the states ENTERING calls 0..3
-        # -- the X operand of the hidden-weight gradients -- a view of the same buffer (HNz[:4N]) instead of a concatenated copy
-        HNz = torch.empty((5 * N, H), dtype=dt, device=dev)
-        HEz = torch.empty((5 * E, H), dtype=dt, device=dev)
-        HNz[:N].zero_()
-        HEz[:E].zero_()
-        HN, HE = HNz[N:], HEz[E:]
+        # block c = vert_c / edge_c: the hidden state LEAVING call c = entering call c+1.  (The state entering call 0 is zero: that
+        # call adds nothing to the hidden-weight gradients, whose contractions therefore run over the rows of calls 1..3 only.)
+        HN = torch.empty((4 * N, H), dtype=dt, device=dev)
+        HE = torch.empty((4 * E, H), dtype=dt, device=dev)
         ops.gemm(x7, w['obj_unary'], w['obj_unary_b'], out=XN[:N])
         # ---- edges: relu(edge_unary(roi_fmap(edge_feat + conv(rects))))  (Linear ReLU Dropout Linear)
         _lib.set_tag('fc6_edge')
@@ -225,7 +222,7 @@ class PredictFn(torch.autograd.Function):
         _lib.set_tag('heads')
         obj = ops.gemm(vT, w['obj_fc'], w['obj_fc_b'], out_dtype=torch.float32)
         rel = ops.gemm(eT, w['rel_fc'], w['rel_fc_b'], out_dtype=torch.float32)
-        sv.update(paired=paired, XN=XN, XE=XE, HN=HN, HE=HE, HNz=HNz, HEz=HEz, gin=gin, ghn=ghn, gie=gie, ghe=ghe, dots=dots_l, csr=csr, nf=nf, ef=ef,
+        sv.update(paired=paired, XN=XN, XE=XE, HN=HN, HE=HE, gin=gin, ghn=ghn, gie=gie, ghe=ghe, dots=dots_l, csr=csr, nf=nf, ef=ef,
                   rel_inds=rel_inds, N=N, E=E, H=H, dropout_p=dropout_p)
         _lib.set_tag('')
         ctx.model, ctx.sv = model, sv
@@ -387,11 +384,12 @@ class PredictFn(torch.autograd.Function):
             dw()
         _lib.set_tag('bwd_imp')
         # GRU parameter gradients: one contraction over the 4 stacked calls; hidden state of call 0 is zero
-        HprevN, HprevE = sv['HNz'][:4 * N], sv['HEz'][:4 * E]
         G['edge_gru.weight_ih'], G['edge_gru.bias_ih'] = tn_gemm(dGIe, XE, want_colsum=True, pool=pool)
-        G['edge_gru.weight_hh'], G['edge_gru.bias_hh'] = tn_gemm(dGHe, HprevE, want_colsum=True, pool=pool)
+        G['edge_gru.weight_hh'] = tn_gemm(dGHe[E:], HE[:3 * E])              # states entering calls 1..3 (call 0: zero state)
+        G['edge_gru.bias_hh'] = ops.colsum(dGHe, pool)                          # b_hh acts in every call
         G['node_gru.weight_ih'], G['node_gru.bias_ih'] = tn_gemm(dGIn, XN, want_colsum=True, pool=pool)
-        G['node_gru.weight_hh'], G['node_gru.bias_hh'] = tn_gemm(dGHn, HprevN, want_colsum=True, pool=pool)
+        G['node_gru.weight_hh'] = tn_gemm(dGHn[N:], HN[:3 * N])
+        G['node_gru.bias_hh'] = ops.colsum(dGHn, pool)
         ops.rank4_reduce_(da_all, HE[:T * E], d_gw, col0=H)         # e_i = rows i of HE, v_i = rows i of HN
         ops.rank4_reduce_(nsum_all, HN[:T * N], d_gw, col0=0)
         ops.rank4_reduce_(da_all, ones, d_gb)

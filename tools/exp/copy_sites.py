@@ -15,8 +15,11 @@ from sgg_amd.trainer import Trainer  # noqa: E402
 dev = 'cuda:0'
 model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls')).to(dev)
 model.set_compute_dtype(torch.bfloat16)
-b = synthetic_batch()
-batch = ([im.to(dev) for im in b[0]],) + tuple(t.to(dev) if isinstance(t, torch.Tensor) else t for t in b[1:])
+from sgg_amd.rel_model_base import to_device_with_mirror  # noqa: E402
+b = list(synthetic_batch(B=8, S=592, n_boxes=32, n_fg=6, seed=111))
+b[0] = [im.to(dev) for im in b[0]]
+b[3], b[4], b[5] = b[3].to(dev), to_device_with_mirror(b[4], dev), to_device_with_mirror(b[5], dev)
+batch = tuple(b)
 tr = Trainer(model, lr=1e-3, pipeline=True)
 for _ in range(4):
     tr.step(batch)
@@ -61,6 +64,14 @@ wrap(torch.Tensor, 'fill_', lambda a, k, o: nbytes(a[0]))
 wrap(torch, 'cat', lambda a, k, o: nbytes(o))
 wrap(torch, 'zeros', lambda a, k, o: nbytes(o))
 wrap(torch, 'zeros_like', lambda a, k, o: nbytes(o))
+wrap(torch, 'ones', lambda a, k, o: nbytes(o))
+wrap(torch, 'full', lambda a, k, o: nbytes(o))
+wrap(torch, 'tensor', lambda a, k, o: nbytes(o))
+wrap(torch, 'arange', lambda a, k, o: nbytes(o))
+wrap(torch.Tensor, 'long', lambda a, k, o: nbytes(o) if o.data_ptr() != a[0].data_ptr() else 0)
+wrap(torch.Tensor, 'int', lambda a, k, o: nbytes(o) if o.data_ptr() != a[0].data_ptr() else 0)
+wrap(torch.Tensor, 'add_', lambda a, k, o: nbytes(a[0]))
+wrap(torch.Tensor, '__getitem__', lambda a, k, o: nbytes(o) if isinstance(o, torch.Tensor) and o._base is None and o.data_ptr() != a[0].data_ptr() else 0)
 on[0] = True
 for _ in range(2):
     tr.step(batch)
@@ -68,5 +79,5 @@ on[0] = False
 torch.cuda.synchronize()
 rows = sorted(log.items(), key=lambda kv: -kv[1][1])
 print('per step: %.1f calls, %.1f MB' % (sum(v[0] for _, v in rows) / 2, sum(v[1] for _, v in rows) / 2e6))
-for (name, where), (n, nb) in rows[:40]:
+for (name, where), (n, nb) in rows[:70]:
     print('%5.1f/step %9.2f MB/step  %-11s %s' % (n / 2, nb / 2e6, name, where))
