@@ -243,8 +243,17 @@ class RelModelStanford(RelModelBase):
         bboxes = result.rm_box_priors_org                                                # :199
         if bboxes.dim() != 2:
             raise ValueError('Boxes needs to be [num_box, 4] but its {}'.format(bboxes.size()))
-        # lib/surgery.py:49-55: host numpy copies
-        out = (bboxes.cpu().numpy(), obj_preds.cpu().numpy(), obj_scores.cpu().numpy(), rels.cpu().numpy(), pred_scores.cpu().numpy())
-        if pairing is not None and int(pairing.flag.item()) != 0:      # (the copies above have synchronised already)
-            raise RuntimeError('sgg_amd: the relation list does not fit the unordered-pair tables (flag %d)' % int(pairing.flag.item()))
-        return out
+        # lib/surgery.py:49-55: host numpy copies -- ONE device->host transfer (five blocking copies otherwise): the outputs are laid
+        # end to end in a byte buffer, widest element type first (so that every piece is aligned for its dtype), and viewed back
+        outs = [bboxes, obj_preds, obj_scores, rels, pred_scores] + ([pairing.flag] if pairing is not None else [])
+        order = sorted(range(len(outs)), key=lambda i: -outs[i].element_size())
+        host = torch.cat([outs[i].contiguous().view(-1).view(torch.uint8) for i in order]).cpu().numpy()
+        pieces, off = [None] * len(outs), 0
+        for i in order:
+            t = outs[i]
+            nb = t.numel() * t.element_size()
+            pieces[i] = host[off:off + nb].view(torch.zeros(0, dtype=t.dtype).numpy().dtype).reshape(tuple(t.shape))
+            off += nb
+        if pairing is not None and int(pieces[5][0]) != 0:
+            raise RuntimeError('sgg_amd: the relation list does not fit the unordered-pair tables (flag %d)' % int(pieces[5][0]))
+        return tuple(pieces[:5])
