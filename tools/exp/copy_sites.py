@@ -21,8 +21,12 @@ b[0] = [im.to(dev) for im in b[0]]
 b[3], b[4], b[5] = b[3].to(dev), to_device_with_mirror(b[4], dev), to_device_with_mirror(b[5], dev)
 batch = tuple(b)
 tr = Trainer(model, lr=1e-3, pipeline=True)
+INFER = len(sys.argv) > 1 and sys.argv[1] == 'infer'
+if INFER:
+    model.eval()
+run = (lambda: model([batch])) if INFER else (lambda: tr.step(batch))
 for _ in range(4):
-    tr.step(batch)
+    run()
 torch.cuda.synchronize()
 log = collections.defaultdict(lambda: [0, 0])
 on = [False]
@@ -74,7 +78,7 @@ wrap(torch.Tensor, 'add_', lambda a, k, o: nbytes(a[0]))
 wrap(torch.Tensor, '__getitem__', lambda a, k, o: nbytes(o) if isinstance(o, torch.Tensor) and o._base is None and o.data_ptr() != a[0].data_ptr() else 0)
 on[0] = True
 for _ in range(2):
-    tr.step(batch)
+    run()
 on[0] = False
 torch.cuda.synchronize()
 rows = sorted(log.items(), key=lambda kv: -kv[1][1])
