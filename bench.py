@@ -522,6 +522,10 @@ def main():
                                    ('train step: fwd + losses + bwd + grad all-reduce + clip + SGD' if args.mode == 'train'
                                     else 'eval forward incl. eval tail'),
                        'mode': args.mode, 'images_per_gpu': B, 'global_batch': world * B,
+                       'edge_branch': ('union-box RoIAlign and fc6 K=25088 computed once per UNORDERED box pair (%d pairs for %d edges per '
+                                       'GPU and step), per-edge rect term added after; same outputs as the per-edge computation '
+                                       '(SGG_EDGE_PAIRS=0)' % (992 * B // 2, 992 * B)) if os.environ.get('SGG_EDGE_PAIRS', '1') != '0'
+                       else 'per edge, as in the reference',
                        'parallelism': 'image-sharded dp%d, %s' % (
                            world, 'no collective' if args.mode != 'train' else
                            ('RCCL, bf16 on the wire: fc6 / fc7 gradients reduce-scattered, clip + SGD on 1/%d of their fp32 masters per rank, '
