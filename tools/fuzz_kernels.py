@@ -9,7 +9,7 @@ from sgg_amd import ops
 dev = 'cuda:0'
 cu = lambda t: (torch.from_numpy(np.ascontiguousarray(t)) if isinstance(t, np.ndarray) else t.contiguous()).to(dev)
 rng = np.random.RandomState(0)
-stats = {'imp': 0, 'gemm': 0, 'tn': 0, 'conv': 0, 'roi': 0, 'raster': 0, 'pairs': 0}
+stats = {'imp': 0, 'gemm': 0, 'tn': 0, 'conv': 0, 'roi': 0, 'raster': 0, 'pairs': 0, 'unordered': 0}
 
 
 def fuzz_imp():
@@ -114,7 +114,9 @@ def fuzz_conv():
         got = torch.zeros((B, H // 2 + 2, W // 2 + 2, Cout), dtype=dtype, device=dev)
         ops.conv3x3_relu(cu(xp), cu(w.permute(0, 2, 3, 1)), cu(b), got, 1, pool=True)
         refp = torch.nn.functional.max_pool2d(out[:, 1:-1, 1:-1].float().permute(0, 3, 1, 2), 2)
-        torch.testing.assert_close(got[:, 1:-1, 1:-1].float().permute(0, 3, 1, 2), refp, atol=0, rtol=0)
+        # (the unpooled map may come from the implicit-GEMM kernel -- another summation order than the patch kernel's: one bf16 ulp)
+        exact = Cout < 256 or dtype == torch.float32 and False
+        torch.testing.assert_close(got[:, 1:-1, 1:-1].float().permute(0, 3, 1, 2), refp, atol=0 if exact else tol, rtol=0 if exact else tol)
     stats['conv'] += 1
 
 
@@ -182,6 +184,56 @@ def fuzz_pairs():
     stats['pairs'] += 1
 
 
+def fuzz_unordered():
+    """the unordered-pair tables (closed form on complete / thinned lists, symmetric sparse lists) and the kernels around them"""
+    from sgg_amd.pairing import make_pairing, make_pairing_symmetric
+    counts = [int(rng.randint(1, 14)) for _ in range(int(rng.randint(1, 6)))]
+    rows, segs, first = [], [], 0
+    sym = rng.rand() < 0.5
+    dropm = None
+    for b, n in enumerate(counts):
+        keep = np.triu(rng.rand(n, n) < rng.uniform(0.3, 1.0), 1)
+        keep = keep | keep.T
+        for s_ in range(n):
+            for o_ in range(n):
+                if s_ != o_ and (keep[s_, o_] if sym else rng.rand() < 0.9):
+                    rows.append((b, first + s_, first + o_))
+        segs.append((b, first, first + n))
+        first += n
+    if len(rows) < 4:
+        return
+    rel = np.array(rows, dtype=np.int64)
+    pm = make_pairing_symmetric(cu(rel), first, min_edges=2) if sym else make_pairing(cu(rel), segs)
+    if pm is None:
+        return
+    assert int(pm.flag.item()) == 0
+    pairs, e2u, u2e = pm.pairs.cpu().numpy(), pm.e2u.cpu().numpy(), pm.u2e.cpu().numpy()
+    np.testing.assert_array_equal(pairs[e2u], np.stack((rel[:, 1:].min(1), rel[:, 1:].max(1)), 1))
+    cnt = np.bincount(e2u, minlength=pm.U)
+    np.testing.assert_array_equal((u2e >= 0).sum(1), cnt)
+    for u in range(pm.U):
+        for e_ in u2e[u]:
+            assert e_ < 0 or e2u[e_] == u
+    # pair-sum transpose + gathered-row GEMM on these tables
+    dtype = torch.bfloat16 if rng.rand() < 0.6 else torch.float32
+    g = torch.Generator().manual_seed(int(rng.randint(1 << 30)))
+    C = int(rng.choice([64, 192, 256]))
+    x = torch.randn(len(rel), C, generator=g).to(dtype)
+    out = ops.transpose_pairsum(cu(x), pm.u2e)
+    ref = torch.zeros(pm.U, C)
+    ref.index_add_(0, torch.from_numpy(e2u).long(), x.float())
+    torch.testing.assert_close(out[:, :pm.U].float().cpu().t(), ref.to(dtype).float(), atol=2e-2 if dtype == torch.bfloat16 else 1e-5, rtol=1e-2)
+    K, N = 64 * int(rng.randint(1, 5)), 64 * int(rng.randint(1, 9))
+    A = torch.randn(len(rel), K, generator=g).to(dtype)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype)
+    b = torch.randn(N, generator=g)
+    yu = torch.randn(pm.U, N, generator=g)
+    got = ops.gemm_addrows(cu(A), cu(W), cu(b), cu(yu), pm.e2u, ops.ACT_RELU, out_dtype=torch.float32)
+    exp = torch.relu(A.float() @ W.float().t() + yu[torch.from_numpy(e2u).long()] + b)
+    torch.testing.assert_close(got.cpu(), exp, atol=3e-2 if dtype == torch.bfloat16 else 3e-4, rtol=2e-2 if dtype == torch.bfloat16 else 1e-4)
+    stats['unordered'] += 1
+
+
 def run(budget=60.0, seed=0):
     global rng
     rng = np.random.RandomState(seed)
@@ -196,6 +248,7 @@ def run(budget=60.0, seed=0):
         fuzz_roi()
         fuzz_raster()
         fuzz_pairs()
+        fuzz_unordered()
     torch.cuda.synchronize()
     return dict(stats)
 
