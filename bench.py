@@ -563,6 +563,24 @@ def main():
             line['other_mode'] = other_line
         if pcie:
             line['pcie_inclusive'] = pcie
+        if world == 1 and not args.force_dist and args.dtype == 'bf16' and not args.no_f32 and os.environ.get('SGG_EDGE_PAIRS', '1') != '0' \
+                and args.mode in ('train', 'infer'):
+            # the same steps with the edge branch computed PER EDGE, as the reference does (SGG_EDGE_PAIRS=0): short runs beside the headline
+            os.environ['SGG_EDGE_PAIRS'] = '0'
+            try:
+                if trainer is not None:
+                    el_pe = timed(lambda: trainer.step(batch), 3, 8)
+                    trainer.flush()
+                else:
+                    el_pe = None
+                el_pi = timed(infer_step, 2, 8)
+            finally:
+                del os.environ['SGG_EDGE_PAIRS']
+            line['per_edge_branch'] = {'infer_images_per_s': round(B * 8 / el_pi, 2), 'infer_ms_per_step': round(1e3 * el_pi / 8, 3),
+                                       'note': 'same workload with RoIAlign and fc6 run on every edge as in the reference (SGG_EDGE_PAIRS=0); '
+                                               '3 (train) / 2 (inference) warm-up + 8 timed steps; never `value`'}
+            if el_pe is not None:
+                line['per_edge_branch'].update(train_images_per_s=round(B * 8 / el_pe, 2), train_ms_per_step=round(1e3 * el_pe / 8, 3))
         if world == 1 and not args.force_dist and args.dtype == 'bf16' and not args.no_f32:
             # the reference computes in fp32: the same two steps in exact-fp32 mode (v_mfma_f32_32x32x2_f32, the mode the 1e-3 parity
             # bar is checked in), short runs, reported beside the bf16 headline -- never `value`
