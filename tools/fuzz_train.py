@@ -85,7 +85,12 @@ for case in range(cases):
             efe = O.union_boxes_and_feats(res.edge_feat.float().cpu(), res.rois.cpu().numpy(), res.rel_inds.cpu().numpy()[:, 1:], up, training=True)
             z6 = efe.reshape(efe.shape[0], -1) @ sd['roi_fmap.1.0.weight'].t() + sd['roi_fmap.1.0.bias']
             zn = res.node_feat.float().cpu().reshape(res.node_feat.shape[0], -1) @ sd['roi_fmap_obj.0.weight'].t() + sd['roi_fmap_obj.0.bias']
-        kinks = int((z6.abs() < 2e-5).sum()) + int((zn.abs() < 2e-5).sum())
+            # ... and the second Linear of each branch (its ReLU feeds the next layer in the node branch; TwoMLPHead copies also in the edge branch)
+            z7n = torch.relu(zn) @ sd['roi_fmap_obj.3.weight'].t() + sd['roi_fmap_obj.3.bias']
+            z7e = torch.relu(z6) @ sd['roi_fmap.1.3.weight'].t() + sd['roi_fmap.1.3.bias']
+        kinks = int((z6.abs() < 2e-5).sum()) + int((zn.abs() < 2e-5).sum()) + int((z7n.abs() < 2e-5).sum())
+        print('  fc7 pre-activations within 2e-5 of zero: nodes %d (min |z| %.1e), edges %d (min |z| %.1e; no ReLU after it in the VGG head)' % (
+            int((z7n.abs() < 2e-5).sum()), float(z7n.abs().min()), int((z7e.abs() < 2e-5).sum()), float(z7e.abs().min())))
         print('  fc6 pre-activations within 2e-5 of zero: edges %d (min |z| %.1e), nodes %d (min |z| %.1e)' % (
             int((z6.abs() < 2e-5).sum()), float(z6.abs().min()), int((zn.abs() < 2e-5).sum()), float(zn.abs().min())))
         # which of the 4 positions the max-pool picks: an arg-max flip between two nearly equal values is a legitimate discontinuity
