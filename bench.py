@@ -381,6 +381,10 @@ def main():
             dist.destroy_process_group()
         return
     elapsed = timed(step, args.warmup, args.steps)
+    if trainer is not None:
+        # EVERY rank: with the sharded optimiser flush() is a collective (FusedSGD.gather_masters all-gathers the stale parts of
+        # the fp32 masters), so it must not sit inside the rank-0-only profiling block below
+        trainer.flush()
 
     # ---- per-kernel roofline (rank 0, outside the timed region; single-GPU kernels, no collective inside)
     if rank == 0:
@@ -392,7 +396,6 @@ def main():
                 trainer.opt.zero_grad()
                 loss.backward()
                 trainer.opt.step()
-            trainer.flush()
             # rank 0 alone runs these extra steps: no collective may be issued (the other ranks wait at the host-side barrier
             # below): the trainer is switched to its local form -- hooks, BatchNorm sync, loss normalisers (dist_on) and world
             with trainer.local_only():

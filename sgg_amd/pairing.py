@@ -88,34 +88,69 @@ def make_pairing_symmetric(rel_inds, n_boxes, min_edges=256):
     return EdgePairing(rel_inds[prim_idx][:, 1:3].contiguous(), e2u, u2e, bad.to(torch.int32).view(1), U, E)
 
 
-class PairedEdgeFeat(object):
-    """The edge features as [U,C,P,P] pooled rows of the unordered pairs + the edge -> slot map; `dense()` is the reference's
-    [E,C,P,P] tensor.  Behaves as that tensor wherever torch functions or tensor attributes are applied to it."""
+class PairedEdgeFeat(torch.Tensor):
+    """The edge features as [U,C,P,P] pooled rows of the unordered pairs + the edge -> slot map.  A lazy `torch.Tensor`: it reports the
+    shape / dtype / device of the reference's [E,C,P,P] tensor (`Result.edge_feat`, rel_model_base.py:245-260) without owning storage,
+    and the first torch function, method, index or operator applied to it materialises that tensor (`dense()`, one row gather, cached)
+    and carries on with it -- `len(res.edge_feat)`, `res.edge_feat[idx]`, arithmetic, `isinstance(..., torch.Tensor)` behave as they do
+    on the reference's tensor (main.py:185 hands it to augment/gan.py:232-247).  `rows` / `pairing` are what this package's own
+    predict() reads instead."""
+
+    @staticmethod
+    def __new__(cls, rows, pairing):
+        t = torch.Tensor._make_wrapper_subclass(cls, (pairing.E,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device,
+                                                requires_grad=False)
+        t.rows, t.pairing, t._dense = rows, pairing, None
+        return t
 
     def __init__(self, rows, pairing):
-        self.rows, self.pairing = rows, pairing
-        self._dense = None
+        pass
 
     def dense(self):
         if self._dense is None:
             self._dense = self.rows.index_select(0, self.pairing.e2u.long())
         return self._dense
 
-    @property
-    def shape(self):
-        return torch.Size((self.pairing.E,) + tuple(self.rows.shape[1:]))
+    def __copy__(self):
+        return PairedEdgeFeat(self.rows, self.pairing)
 
-    def __getattr__(self, name):
-        if name.startswith('__') or name in ('rows', 'pairing', '_dense'):     # (copy / pickle probe an object before __init__ ran)
-            raise AttributeError(name)
-        return getattr(self.dense(), name)
+    def __deepcopy__(self, memo):
+        import copy
+        return PairedEdgeFeat(copy.deepcopy(self.rows, memo), copy.deepcopy(self.pairing, memo))
+
+    def __reduce_ex__(self, proto):
+        return (PairedEdgeFeat, (self.rows, self.pairing))
+
+    def __repr__(self):
+        return 'PairedEdgeFeat(%s rows of %d unordered pairs for %d edges, %s, %s)' % (
+            tuple(self.rows.shape), self.pairing.U, self.pairing.E, self.rows.dtype, self.rows.device)
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        # metadata of the wrapper itself (no reason to gather 100 MB to answer `.shape`)
+        if func in _META and len(args) >= 1 and isinstance(args[0], PairedEdgeFeat):
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+
         def conv(a):
             if isinstance(a, PairedEdgeFeat):
                 return a.dense()
             if isinstance(a, (tuple, list)):
                 return type(a)(conv(x) for x in a)
             return a
-        return func(*conv(tuple(args)), **{k: conv(v) for k, v in (kwargs or {}).items()})
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*conv(tuple(args)), **{k: conv(v) for k, v in kwargs.items()})
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        # reached only by callers that bypass __torch_function__ (C++ entry points): same rule, the dense tensor stands in
+        from torch.utils._pytree import tree_map
+        conv = lambda a: a.dense() if isinstance(a, PairedEdgeFeat) else a
+        return func(*tree_map(conv, tuple(args)), **tree_map(conv, kwargs or {}))
+
+
+_T = torch.Tensor
+_META = {_T.shape.__get__, _T.dtype.__get__, _T.device.__get__, _T.ndim.__get__, _T.is_cuda.__get__, _T.requires_grad.__get__,
+         _T.grad_fn.__get__, _T.is_leaf.__get__, _T.layout.__get__, _T.size, _T.dim, _T.numel, _T.nelement, _T.element_size,
+         _T.__len__, _T.is_floating_point, _T.is_complex, _T.ndimension}

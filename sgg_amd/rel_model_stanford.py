@@ -181,10 +181,41 @@ class RelModelStanford(RelModelBase):
         _lib.set_tag('')
         return out
 
+    def _watch_pair_flag(self, flag):
+        """Training: the pair tables' device-side flag (an edge list outside the promise the host made to sgg_amd/pairing.py: a
+        relation of a box with itself, an image id out of range, more than two rows on one unordered pair -- any of which would make
+        the pair path add or drop rows silently) leaves for pinned host memory behind the step's kernels and is looked at by the NEXT
+        call of forward() (or by check_pair_flag()), when it has long arrived: no synchronisation, and no step goes unchecked."""
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(flag.device))
+        self.__dict__.setdefault('_pair_flags', []).append((host, ev))
+        if __debug__ and os.environ.get('SGG_CHECK_COUNTS'):
+            self.check_pair_flag(wait=True)
+
+    def check_pair_flag(self, wait=True):
+        """Raise if a training forward's relation list did not fit the unordered-pair tables (see _watch_pair_flag)."""
+        pend = self.__dict__.get('_pair_flags') or []
+        keep = []
+        for host, ev in pend:
+            if not wait and not ev.query():
+                keep.append((host, ev))
+                continue
+            ev.synchronize()
+            if int(host[0]) != 0:
+                self.__dict__['_pair_flags'] = []
+                raise RuntimeError('sgg_amd: a training batch\'s relation rows do not fit the unordered-pair tables (flag %d: 1 = self / '
+                                   'out-of-range relation, 2 = more than two rows on one box pair); the step that used them is wrong -- '
+                                   'filter the relations (filter_dups) or set SGG_EDGE_PAIRS=0' % int(host[0]))
+        self.__dict__['_pair_flags'] = keep
+
     def forward(self, batch):
         """rel_model_stanford.py:110-207.  batch[0] = Blob tuple (dataloaders/blob.py:244-249); only items 0,3,4,5
         (imgs, gt_boxes, gt_classes, gt_rels) are read."""
         assert len(batch) == 1, ('single GPU is only supported in this code', len(batch))
+        if self.__dict__.get('_pair_flags'):
+            self.check_pair_flag(wait=len(self.__dict__['_pair_flags']) > 1)       # the previous step's flag (arrived long ago)
         x, gt_boxes, gt_classes, gt_rels = batch[0][0], batch[0][3], batch[0][4], batch[0][5]
         dev = self.rel_fc.weight.device
         # index tensors that arrive on the host keep a host mirror (no D2H sync later for data the host already has)
@@ -229,8 +260,8 @@ class RelModelStanford(RelModelBase):
                 gt_classes=gt_classes[:, 1].contiguous() if self.mode == 'predcls' else None, replace=self.test_bias)
         if self.training:
             result.rois = rois
-            if pairing is not None and __debug__ and os.environ.get('SGG_CHECK_COUNTS'):
-                assert int(pairing.flag.item()) == 0, ('edge list outside the promise made to the pair tables', int(pairing.flag.item()))
+            if pairing is not None:
+                self._watch_pair_flag(pairing.flag)
             return result                                                                # :179-181
         if self.mode == 'predcls':
             gt = gt_classes[:, 1].contiguous()                                           # :184-185

@@ -373,6 +373,8 @@ class Trainer(object):
             torch.cuda.current_stream(next(self.model.parameters()).device).wait_event(ev)
         if self.dist_on and (self.opt.stale_masters or self.opt.momentum_parts):
             self.opt.gather_masters()
+        if hasattr(self.model, 'check_pair_flag'):
+            self.model.check_pair_flag(wait=True)     # the last steps' pair-table flags (rel_model_stanford._watch_pair_flag)
 
     def _queue_update(self):
         """pipeline mode: wait for the gradient all-reduce, optimiser step and operand rebuild, all on the side stream

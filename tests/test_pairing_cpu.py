@@ -35,6 +35,37 @@ def test_paired_edge_feat_behaves_like_the_dense_tensor():
     assert torch.equal(torch.relu(torch.sub(ef, 5)), torch.relu(dense - 5))
     c = copy.copy(ef)                                                        # no attribute recursion before __init__
     assert torch.equal(c.dense(), dense)
+    assert torch.equal(copy.deepcopy(ef).dense(), dense)
+
+
+def test_paired_edge_feat_is_a_tensor_to_the_callers_of_result_edge_feat():
+    """main.py:185 hands `res.edge_feat` to augment/gan.py:211-259, which takes len(), indexes it with a permutation and does arithmetic
+    on the rows; isinstance(..., torch.Tensor) holds as for the reference's tensor.  Metadata does not materialise the dense tensor."""
+    rows = torch.arange(3 * 2 * 2 * 2, dtype=torch.float32).view(3, 2, 2, 2)
+    e2u = torch.tensor([0, 1, 0, 2, 2, 1], dtype=torch.int32)
+    pm = EdgePairing(torch.zeros((3, 2), dtype=torch.int64), e2u, torch.zeros((3, 2), dtype=torch.int32), torch.zeros(1, dtype=torch.int32), 3, 6)
+    ef = PairedEdgeFeat(rows, pm)
+    dense = rows[e2u.long()]
+    assert isinstance(ef, torch.Tensor)
+    assert len(ef) == 6 and ef.dim() == 4 and ef.size(0) == 6 and ef.numel() == dense.numel() and ef.shape == dense.shape
+    assert ef.dtype == torch.float32 and ef.device == rows.device and not ef.requires_grad and not ef.is_cuda
+    assert ef._dense is None                                                 # none of the above gathered anything
+    assert torch.equal(ef[0], dense[0]) and torch.equal(ef[torch.tensor([4, 1])], dense[[4, 1]]) and torch.equal(ef[1:3], dense[1:3])
+    assert [tuple(r.shape) for r in ef] == [(2, 2, 2)] * 6                   # iteration
+    for a, b in ((ef + 1, dense + 1), (1 + ef, 1 + dense), (ef * 2, dense * 2), (-ef, -dense), (ef / 2, dense / 2), (ef - ef, dense - dense),
+                 (ef > 3, dense > 3), (ef == dense, dense == dense), (ef ** 2, dense ** 2)):
+        assert type(a) is torch.Tensor and torch.equal(a, b)
+    assert type(ef.to(torch.float64)) is torch.Tensor and ef.detach().shape == dense.shape and float(ef.mean()) == float(dense.mean())
+    np.testing.assert_array_equal(np.asarray(ef), dense.numpy())
+    np.testing.assert_array_equal(ef.cpu().numpy(), dense.numpy())
+
+    def discriminator_loss_stand_in(features_real, features_fake):           # the access pattern of augment/gan.py:232-247
+        n = len(features_real)
+        idx = torch.arange(n - 1, -1, -1)[:len(features_fake)]
+        real = features_real[idx].view(len(idx), -1)
+        return (real - features_fake.view(len(idx), -1)).pow(2).mean()
+    fake = torch.ones(4, 2, 2, 2)
+    assert float(discriminator_loss_stand_in(ef, fake)) == float(discriminator_loss_stand_in(dense, fake))
 
 
 def test_symmetric_sparse_lists():
