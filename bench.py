@@ -153,12 +153,12 @@ def pmc_traffic(key):
     return None
 
 
-def imp_iter_ms(model, B, dtype, reps=50, kind='sliced'):
-    """Average duration of ONE IMP gather/gate/scatter launch on a complete 32-box/image graph of B images: `reps` launches
-    back-to-back between two HIP events on the launch stream (outputs pre-allocated).  kind: 'sliced' (the kernel the forward
-    runs: every edge row read once, gate dot products supplied by the GRU gate kernels), 'fused' (node-centric, any graph),
-    'write' / 'read' (the two kernels of the split step: sgg_imp_edge_in_fwd, sgg_imp_ctx_fwd), 'step_mfma' (sgg_imp_step_fwd),
-    'sliced_kernel' (imp_sliced_kernel at any size)."""
+def imp_iter_ms(model, B, dtype, reps=50, kind='ctx'):
+    """Average duration of ONE launch of a kernel of the message-passing step on a complete 32-box/image graph of B images: `reps`
+    launches back-to-back between two HIP events on the launch stream (outputs pre-allocated, hipGraph replay).  kind: 'ctx' = the
+    step's gather / gate / scatter launch (sgg_imp_ctx_fwd: every edge row read once, gates from the dot products, two sums per
+    node out -- routed by size as in the forward), 'ctx_sliced' / 'ctx_mfma' / 'ctx_lists' = its forms wherever they apply,
+    'gate_proj' = the edge GRU's gate kernel that takes the place of the edge inputs (sgg_gru_gate_proj_fwd)."""
     import torch
     from sgg_amd import ops
     dev = model.rel_fc.weight.device
@@ -172,29 +172,25 @@ def imp_iter_ms(model, B, dtype, reps=50, kind='sliced'):
     v = torch.randn(N, H, generator=g).to(dev).to(dtype)
     e = torch.randn(E, H, generator=g).to(dev).to(dtype)
     imp = model.prepared()['imp']
-    e_in, ctx2 = torch.empty_like(e), torch.empty((2, N, H), dtype=dtype, device=dev)
-    if kind in ('sliced', 'sliced_kernel', 'write', 'read', 'step_mfma'):
-        assert ops.imp_sliced_ok(csr, H, dtype)
-        nd = (v.float() @ imp.gate_w[:, :H].t()).contiguous()     # what sgg_gru_gate_fwd's dot epilogue hands over
-        ed = (e.float() @ imp.gate_w[:, H:].t()).contiguous()
-        if kind == 'sliced':          # what the forward launches for these graphs (ops.imp_sliced routes by size)
-            launch = lambda: ops.imp_sliced(v, e, csr, nd, ed, imp.gate_b, e_in, ctx2)
-        elif kind == 'sliced_kernel':  # imp_sliced_kernel itself
-            def launch():
-                os.environ['SGG_IMP_STREAM'] = '0'
-                try:
-                    ops.imp_sliced(v, e, csr, nd, ed, imp.gate_b, e_in, ctx2)
-                finally:
-                    del os.environ['SGG_IMP_STREAM']
-        elif kind == 'step_mfma':   # the whole step in one launch of the matrix-core kernel (opt-in entry point sgg_imp_step_fwd)
-            launch = lambda: ops.imp_step(v, e, csr, nd, ed, imp.gate_b, e_in, ctx2)
-        else:                 # the two halves of the split step (opt-in entry points): write stream (e_in + gates), read stream (ctx)
-            gates = torch.empty((E, 2), dtype=torch.float32, device=dev)
-            ops.imp_edge_in(v, csr, nd, ed, imp.gate_b, E, e_in=e_in, gates_oi=gates)
-            launch = (lambda: ops.imp_edge_in(v, csr, nd, ed, imp.gate_b, E, e_in=e_in, gates_oi=gates)) if kind == 'write' else \
-                (lambda: ops.imp_ctx(e, csr, N, gates, ctx2=ctx2))
+    ctx2 = torch.empty((2, N, H), dtype=dtype, device=dev)
+    nd = (v.float() @ imp.gate_w[:, :H].t()).contiguous()     # what the gate kernels' dot epilogue hands over
+    ed = (e.float() @ imp.gate_w[:, H:].t()).contiguous()
+    form = {'ctx': None, 'ctx_sliced': 's', 'ctx_mfma': 'm', 'ctx_lists': 'l'}.get(kind, None)
+    if kind == 'gate_proj':
+        gh = torch.randn(E, 3 * H, generator=g).to(dev)
+        P = torch.randn(N, 3 * H, generator=g).to(dev)
+        out, dots = torch.empty_like(e), torch.empty((E, 4), dtype=torch.float32, device=dev)
+        launch = lambda: ops.gru_gate_proj(gh, P, imp.edge_gru_b_ih, csr, nd, ed, imp.gate_b, e, out=out, dot_w=imp.gate_w[:, H:], dots=dots)
     else:
-        launch = lambda: ops.imp_fused(v, e, rel, csr, imp.gate_w_c, imp.gate_b, e_in, ctx2)
+        assert ops.imp_sliced_ok(csr, H, dtype)
+
+        def launch():
+            if form is not None:
+                os.environ['SGG_IMP_CTX'] = form
+            try:
+                ops.imp_ctx(e, csr, N, nd, ed, imp.gate_b, ctx2=ctx2)
+            finally:
+                os.environ.pop('SGG_IMP_CTX', None)
     for _ in range(3):
         launch()
     torch.cuda.synchronize()
@@ -430,21 +426,23 @@ def main():
                 best = (tag, ms, desc, flop)
         tag, ms, desc, flop = best
         tf = flop / (ms * 1e-3) / 1e12
-        imp_ms = imp_iter_ms(model, B, tdtype)                   # the fused gather/gate/scatter launch, back-to-back timing
+        # the step's gather / gate / scatter launch (sgg_imp_ctx_fwd), back-to-back timing.  Algorithmic bytes = SURVEY 8(d)'s figure for the
+        # reference's step: read e_i and v_i, WRITE e_in, write ctx, per iteration.  Since round 3 the e_in stream does not exist (node
+        # projection, csrc/imp.hip): the launch delivers the step's outputs in the time of its read stream, `moved_bytes` says what it moves.
+        imp_ms = imp_iter_ms(model, B, tdtype)
         imp_bytes = (2.0 * (E + N) * H) * s + 8.0 * E           # per iteration
+        imp_moved = lambda b_: (992.0 * b_ * H + 2 * 32.0 * b_ * H) * s + 992.0 * b_ * (16 + 8) + 32.0 * b_ * 16   # rows + ctx halves + dots, ids
         imp_gbs = imp_bytes / (imp_ms * 1e-3) / 1e9 if imp_ms else 0.0
-        BL = 128                                                 # same kernel on a graph that fills the chip
+        BL = 128                                                 # same launch on a graph that fills the chip
         impL_ms = imp_iter_ms(model, BL, tdtype)
         from sgg_amd import _lib as _sgg_lib
-        step_units = _sgg_lib.load().sgg_imp_step_min_units()
-        impL_step = tdtype == torch.bfloat16 and BL * (H // 64) >= step_units and os.environ.get('SGG_IMP_STREAM') is None
-        impL_kernel = ('imp_ctx_mfma_kernel<STEP> (persistent one-launch step: gates + edge inputs + block-sparse gate-matrix product on '
-                       'the matrix cores; sgg_imp_sliced_fwd hands >= %d (graph, slice) units to it)' % step_units) if impL_step \
-            else 'imp_sliced_kernel'
-        imp_old = {'B%d' % b_: round(imp_iter_ms(model, b_, tdtype, kind='fused'), 5) for b_ in (B, BL)}   # node-centric kernel, for comparison
-        # the split step's two kernels and the one-launch matrix-core step (opt-in entry points), same graphs
-        imp_split = {'B%d' % b_: {k_: round(imp_iter_ms(model, b_, tdtype, kind=k_), 5) for k_ in ('write', 'read', 'step_mfma', 'sliced_kernel')} for b_ in (B, BL)} \
-            if tdtype == torch.bfloat16 else None
+        mfma_units = _sgg_lib.load().sgg_imp_ctx_mfma_min_units()
+        impL_mfma = tdtype != torch.float32 and BL * (H * 2 // 128) >= mfma_units
+        impL_kernel = ('imp_ctx_mfma_kernel (persistent: LDS-DMA ring, gates from the dot products, block-sparse gate-matrix product on the '
+                       'matrix cores; sgg_imp_ctx_fwd hands >= %d (graph, slice) units to it)' % mfma_units) if impL_mfma else 'imp_ctx_sliced_kernel'
+        imp_forms = {'B%d' % b_: {k_: round(imp_iter_ms(model, b_, tdtype, kind=k_), 5) for k_ in
+                                  (('ctx_sliced', 'ctx_mfma', 'ctx_lists', 'gate_proj') if tdtype != torch.float32 else ('ctx_sliced', 'ctx_lists', 'gate_proj'))}
+                     for b_ in (B, BL)}
         impL_bytes = (2.0 * (992 * BL + 32 * BL) * H) * s + 8.0 * 992 * BL
         impL_gbs = impL_bytes / (impL_ms * 1e-3) / 1e9
         # context for the fraction: what a plain device-to-device copy moving the same number of bytes (half read, half written)
@@ -544,18 +542,20 @@ def main():
                          'note': ('achieved = FLOPs the launch executes / its time; the reference runs this contraction on every EDGE '
                                   '(SURVEY 8(d)), here it runs once per unordered box pair: reference_algorithm_tflops prices the '
                                   'reference\'s FLOPs over the same time') if paired else None},
-            'roofline_imp': {'kernel': 'imp_sliced_kernel (gather + 4 gates + scatter, every edge row read once), one launch per IMP iteration', 'bound': 'hbm',
+            'roofline_imp': {'kernel': 'imp_ctx_sliced_kernel (the IMP gather / gate / scatter step, one launch per iteration: every edge row read once, '
+                                       'gates from dot products, two segmented sums per node; the edge inputs are never formed -- node projection)', 'bound': 'hbm',
                              'achieved': round(imp_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                              'frac': round(imp_gbs / HBM_PEAK_GBS, 4),
-                             'traffic': pmc_traffic('imp_sliced_B8') if (B == 8 and args.dtype == 'bf16') else None,
-                             'algorithmic_bytes': imp_bytes, 'avg_launch_ms': round(imp_ms, 5),
-                             'note': '16.8 MB per launch at B=8: 2.7 us at 6.3 TB/s, below a launch plus two dependent memory latencies; see roofline_imp_large'},
-            'roofline_imp_large': {'kernel': 'the IMP launch of the forward at %d images (%d edges): %s' % (BL, 992 * BL, impL_kernel), 'bound': 'hbm',
+                             'traffic': pmc_traffic('imp_ctx_B8'),
+                             'algorithmic_bytes': imp_bytes, 'moved_bytes': imp_moved(B), 'avg_launch_ms': round(imp_ms, 5),
+                             'note': 'algorithmic_bytes = SURVEY 8(d) for the reference step (incl. the e_in write this design removed algebraically); '
+                                     '8.4 MB actually moved per launch at B=8 -- a launch plus two dependent memory latencies; see roofline_imp_large'},
+            'roofline_imp_large': {'kernel': 'the same launch at %d images (%d edges): %s' % (BL, 992 * BL, impL_kernel), 'bound': 'hbm',
                                    'achieved': round(impL_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                    'frac': round(impL_gbs / HBM_PEAK_GBS, 4),
-                                   'traffic': pmc_traffic('imp_step_mfma_B128' if impL_step else 'imp_sliced_B128') if args.dtype == 'bf16' else None,
-                                   'algorithmic_bytes': impL_bytes, 'avg_launch_ms': round(impL_ms, 5),
-                                   'node_centric_kernel_ms': imp_old, 'split_step_kernels_ms': imp_split,
+                                   'traffic': pmc_traffic('imp_ctx_B128'),
+                                   'algorithmic_bytes': impL_bytes, 'moved_bytes': imp_moved(BL), 'avg_launch_ms': round(impL_ms, 5),
+                                   'forms_ms': imp_forms,
                                    'device_copy_same_bytes': {'GB/s': round(copy_gbs, 1), 'frac_of_copy': round(impL_gbs / copy_gbs, 4)}},
             'kernels': {'sum_kernel_ms_per_step': round(total_ms, 3),
                         'vgg16_ms': round(conv_ms, 3), 'vgg16_tflops': round(vgg_flop / (conv_ms * 1e-3) / 1e12, 1) if conv_ms else 0,

@@ -23,7 +23,7 @@ extern "C" {
 
 #define SGG_ABI_VERSION 1
 
-enum { SGG_F32 = 0, SGG_BF16 = 1 };
+enum { SGG_F32 = 0, SGG_BF16 = 1, SGG_F16 = 2 };
 enum { SGG_ACT_NONE = 0, SGG_ACT_RELU = 1 };
 enum {
     SGG_OK = 0,
@@ -91,7 +91,7 @@ int sgg_rel_assign_tables(const float* det_boxes, const int64_t* det_img, const 
  * order inside a node.  ptr i32[N+1], ids i32[E].  im_inds (optional, i64[N] node->image): when given, rel_inds must be
  * sorted by image (as both pair-index calls emit it) and only the node's own image segment is scanned.
  * so (optional) i32[E,2] = (subject, object) per edge; flags (optional) i32[1]: flags[0] = 1 iff the edge list is sorted
- * by subject (out_ids is the identity), which lets sgg_imp_fused_fwd skip the out-edge index loads. */
+ * by subject (out_ids is the identity). */
 int sgg_edge_csr(const int64_t* rel_inds /*[E,3]*/, int E, int N, const int64_t* im_inds, int* out_ptr, int* out_ids,
                  int* in_ptr, int* in_ids, int* so, int* flags, void* stream);
 
@@ -152,52 +152,28 @@ int sgg_gemm_tn(const void* A, int lda, const void* B, int ldb, void* C, int ldc
                 int splits, float* workspace, void* stream);
 
 /* ---- a-8  IMP gather / gate / scatter: RelModelStanford.message_pass, rel_model_stanford.py:74-91 ----
- * node_gate_dots: d[n,4] = (w_sub[:H].v, w_obj[:H].v, w_out[:H].v, w_in[:H].v)  (vertex halves of the four
- *   Linear(2H,1) gates, :41-45).  gate_w f32[4,2H] rows = sub_vert, obj_vert, out_edge, in_edge; gate_b f32[4].
- * edge_ctx: per edge e=(s,o): g_k = sigmoid(d[node,k] + w_k[H:].e_i[e] + b_k);
- *   e_in[e] = g_sub*v[s] + g_obj*v[o] (:78-81);  gates[e] = (g_out, g_in) for the scatter (:86-89).
- * node_scatter: ctx[n] = sum_{e in out(n)} g_out[e] e_i[e] + sum_{e in in(n)} g_in[e] e_i[e]  (:91; the two dense
- *   one-hot [N,E] matmuls of :60-66 as a wavefront segmented reduction over the CSR lists). */
-int sgg_imp_node_gate_dots(const void* v, int N, int H, const float* gate_w, float* dots, int dtype, void* stream);
-int sgg_imp_edge_ctx_fwd(const void* v, const void* e, const int64_t* rel_inds /*[E,3]*/, int E, int H,
-                         const float* node_dots, const float* gate_w, const float* gate_b, void* e_in,
-                         float* gates /*[E,2]*/, int dtype, void* stream);
-int sgg_imp_node_scatter_fwd(const void* e, const float* gates, const int* out_ptr, const int* out_ids,
-                             const int* in_ptr, const int* in_ids, int N, int H, void* ctx, int dtype, void* stream);
-
-/* Fused form of the three calls above, ONE launch per iteration (the kernel the forward uses): units (n, side);
- * side 0 handles n's out-edges (writes e_in rows, reduces ctx2[0][n] = sum g_out*e), side 1 n's in-edges
- * (ctx2[1][n] = sum g_in*e).  ctx = ctx2[0] + ctx2[1]; the node GRU consumes the halves as a K-split GEMM operand.
- * so / flags / CSR lists from sgg_edge_csr; gate_w here is [4,2H] in the COMPUTE dtype (same rows as above). */
-int sgg_imp_fused_fwd(const void* v, const void* e, const int* so /*[E,2]*/, const int* flags, const int* out_ptr,
-                      const int* out_ids, const int* in_ptr, const int* in_ids, int N, int E, int H, const void* gate_w,
-                      const float* gate_b, void* e_in, void* ctx2 /*[2,N,H]*/, int dtype, void* stream);
-
-/* Sliced form (every edge row read once; the kernel the forward uses when the graphs fit): a workgroup owns (graph, 128-byte
- * slice of the rows); edge pieces are staged in LDS by LDS-DMA, gates come from node_dots f32[N,4] / edge_dots f32[E,4]
- * (sgg_gru_gate_fwd's dot outputs, vertex / edge halves of gate_w), e_in pieces stream out, ctx2 halves are reduced from
- * LDS.  Requires: rel_inds sorted by (graph, subject) (both pair-index calls emit that; out-lists are then ranges), nodes
- * grouped by graph with img_ptr from sgg_graph_ptr, every graph with <= max_nodes <= 64 nodes and <= max_edges edges
- * (SGG_ERR_CAPACITY above sgg_imp_sliced_capacity(H, dtype)).  Same outputs as sgg_imp_fused_fwd.  Launches of at least
- * sgg_imp_step_min_units() units (B graphs x H/64 slices) of bf16 graphs with <= 32 nodes run as sgg_imp_step_fwd (below). */
+ * The four gates of an edge e = (s, o) are sigmoids of Linear(2H, 1) on [vertex ; edge] (:41-45, 78-89): separable, so they arrive as
+ * DOT PRODUCTS made by the kernels that write the state rows (sgg_gru_gate_fwd / sgg_gru_gate_proj_fwd, `dots`):
+ *   g_k(e) = sigmoid(node_dots[node, k] + edge_dots[e, k] + gate_b[k]),  k = 0 sub_vert (node s), 1 obj_vert (node o), 2 out_edge (s), 3 in_edge (o).
+ * The edge inputs e_in[e] = g_sub v[s] + g_obj v[o] (:78-81) are never formed: they are consumed only by the edge GRU's input projection,
+ * W_ih e_in[e] = g_sub (W_ih v[s]) + g_obj (W_ih v[o]), so the nodes are projected once (P = v W_ih^T, sgg_gemm) and
+ * sgg_gru_gate_proj_fwd forms the pre-activations from P[s], P[o] (a-9 below).  What this section exports is the step's READ stream,
+ *   out[0][n] = sum_{s(e)=n} g_a(e) x[e],   out[1][n] = sum_{o(e)=n} g_b(e) x[e],   (a, b) = (pair, pair + 1)
+ * (sum_ctx: their sum in out[0], out is [N,H]) -- the two dense one-hot [N,E] matmuls of :60-66, 91 as segmented sums:
+ *   pair 2, x = e_i: the context ctx = ctx_out + ctx_in (the node GRU consumes the halves as a K-split GEMM operand);
+ *   pair 0, x = d_gi (gradient of the edge GRU's input pre-activations): the gradient of P in the backward.
+ * Every row of x is read once when the host promises (img_ptr from sgg_graph_ptr, max_nodes <= 64, max_edges <= sgg_imp_sliced_capacity)
+ * graphs grouped by image with edges sorted by (graph, subject) -- both pair-index calls emit that: a workgroup owns (graph, 64-byte slice
+ * of the rows); from sgg_imp_ctx_mfma_min_units() (graph, 128-byte slice) units on, 16-bit graphs of <= 32 nodes / <= 1024 edges run as a
+ * block-sparse gate-matrix product on the matrix cores (persistent workgroups, LDS-DMA ring; gates rounded to the rows' format).
+ * Without the promise (img_ptr NULL) the CSR lists of sgg_edge_csr are walked: any edge list, every row read twice.
+ * No atomics anywhere: results are bit-reproducible. */
 int sgg_imp_sliced_capacity(int H, int dtype);
-int sgg_imp_step_min_units(void);
-int sgg_imp_sliced_fwd(const void* v, const void* e, const int* so /*[E,2]*/, const int* out_ptr, const int* in_ptr,
-                       const int* in_ids, const int* img_ptr, int B, int N, int E, int H, const float* node_dots,
-                       const float* edge_dots, const float* gate_b, void* e_in, void* ctx2 /*[2,N,H]*/, int max_edges,
-                       int max_nodes, int sum_ctx /*1: ctx2 is [N,H] = ctx_out + ctx_in (training keeps the sum)*/, int dtype,
-                       void* stream);
-/* The split step.  e_in[e] = g_sub(e) v[s(e)] + g_obj(e) v[o(e)] does not read the edge rows (they enter through edge_dots only), so
- * the step is a WRITE stream -- sgg_imp_edge_in_fwd: any edge list, no graph structure; it also leaves the read stream's two gates of
- * every edge, gates_oi f32[E,2] = (g_out, g_in) (rel_model_stanford.py:86-89), when gates_oi is not NULL -- and a READ stream --
- * sgg_imp_ctx_fwd: ctx2 as in sgg_imp_sliced_fwd from the edge rows and gates_oi, same requirements on the graphs (with `so`, bf16 rows
- * and graphs of <= 32 nodes the sums run as a gate-matrix product on the matrix cores, gates rounded to bf16);
- * SGG_ERR_CAPACITY when a graph has more than 1024 edges / 64 nodes or rows are not a multiple of 64 bytes. */
-int sgg_imp_edge_in_fwd(const void* v, const int* so /*[E,2]*/, const float* node_dots, const float* edge_dots, const float* gate_b,
-                        void* e_in, float* gates_oi /*[E,2] or NULL*/, int E, int H, int dtype, void* stream);
-int sgg_imp_ctx_fwd(const void* e, const float* gates_oi /*[E,2]*/, const int* so /*[E,2] or NULL*/, const int* in_ptr, const int* in_ids,
-                    const int* img_ptr, int B, int N, int E, int H, void* ctx2 /*[2,N,H] or [N,H]*/, int max_edges, int max_nodes, int sum_ctx,
-                    int dtype, void* stream);
+int sgg_imp_ctx_mfma_min_units(void);
+int sgg_imp_ctx_fwd(const void* x /*[E,H]*/, const int* so /*[E,2] (sgg_edge_csr)*/, const int* out_ptr, const int* out_ids, const int* in_ptr,
+                    const int* in_ids, const int* img_ptr /*or NULL*/, int B, int N, int E, int H, const float* node_dots /*[N,4]*/,
+                    const float* edge_dots /*[E,4]*/, const float* gate_b /*[4]*/, int pair /*0 or 2*/, void* out /*[2,N,H] or [N,H]*/,
+                    int max_edges, int max_nodes, int sum_ctx, int dtype, void* stream);
 /* ---- unordered box pairs (edge_pairs.hip).  The union box of (subject, object) and (object, subject) is one box: its RoIAlign row and
  * the long part of fc6 on it (sgg_models/rel_model_base.py:245-260, rel_model_stanford.py:104 compute both per edge) are computed
  * once per unordered pair {i < j} of an image, slot u = ubase[img] + i (2n - i - 1) / 2 + (j - i - 1) (image-local i, j; n boxes).
@@ -230,11 +206,6 @@ int sgg_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C, int 
 int sgg_plane_copy(const void* src, int Hs, int Ws, int src_pad, void* dst, int Hd, int Wd, int dst_pad, int B, int C, int stride, int dtype,
                    void* stream);
 int sgg_add_relu(void* y, const void* x, int64_t n, int dtype, void* stream);
-/* The whole step in one launch of the matrix-core kernel (bf16, graphs of <= 32 nodes / <= 1024 edges, rows a multiple of 128 bytes;
- * SGG_ERR_CAPACITY otherwise): gates from node_dots / edge_dots / gate_b, e_in, ctx2 as sgg_imp_sliced_fwd (ctx sums with bf16 gates). */
-int sgg_imp_step_fwd(const void* v, const void* e, const int* so /*[E,2]*/, const int* img_ptr, int B, int N, int E, int H,
-                     const float* node_dots, const float* edge_dots, const float* gate_b, void* e_in, void* ctx2, int max_edges, int max_nodes,
-                     int sum_ctx, int dtype, void* stream);
 /* img_ptr i32[2*(B+1) + 66*B]: img_ptr[b] = first node of graph b (im_inds i64[N] ascending), img_ptr[B] = N; then
  * img_ptr[B+1+b] = out_ptr[first node of b] = first edge of graph b (out_ptr from sgg_edge_csr, same stream, edges sorted);
  * then per graph 66 graph-relative out-list offsets of its nodes (entries past the last node repeat the edge count). */
@@ -248,7 +219,13 @@ int sgg_gru_gate_fwd(const void* gi, const void* gh, const float* b_hh, const vo
                      const float* dot_w, int dot_ld, float* dots, int g_dtype, int dtype, void* stream);
 /*   dots (optional, f32[M,4]): dots[m,k] = dot_w[k*dot_ld : k*dot_ld+H] . h_out[m,:] (on the stored, rounded values) -- the
  *   vertex / edge halves of the four gate pre-activations of the NEXT message-passing step (:78-89), made while the row is
- *   in registers so that sgg_imp_sliced_fwd never needs a whole row.  Needs H/8 a power of two <= 64. */
+ *   in registers so that no IMP kernel ever needs a whole row.  Needs H/8 a power of two <= 64. */
+/* The edge GRU of a message-passing iteration, e_{i+1} = GRU_e(e_in, e_i) (:83), from the node projection instead of e_in rows:
+ *   gi[e] = g_sub(e) P[s] + g_obj(e) P[o] + b_ih  with P = v_i W_ih^T f32[N,3H] (no bias), gates from node_dots / edge_dots / gate_b (a-8);
+ *   gh f32[M,3H] = e_i W_hh^T + b_hh;  h_prev = e_i;  so i32[M,2] = (subject, object) node rows.  dots as above. */
+int sgg_gru_gate_proj_fwd(const float* gh, const float* P, const float* b_ih, const int* so, const float* node_dots, const float* edge_dots,
+                          const float* gate_b, const void* h_prev, void* h_out, int M, int H, const float* dot_w, int dot_ld, float* dots,
+                          int dtype, void* stream);
 
 /* ---- a-11  eval tail: rel_model_stanford.py:183-207 + filter_dets, lib/surgery.py:17-55 ----
  * obj: softmax over C classes, best class in 1..C-1 and its prob (sgcls/sgdet), or score 1 / given class (predcls
@@ -324,17 +301,22 @@ int sgg_bn_bwd(const void* dy, const unsigned char* arg, const void* x, const fl
  * h=0 first call, b_hh given) -> d_gi, d_gh [M,3H] and dh_prev [M,H] (may be NULL). */
 int sgg_gru_gate_bwd(const void* dh, const float* gi, const float* gh, const float* b_hh, const void* h_prev, void* d_gi,
                      void* d_gh, void* dh_prev, int M, int H, int dtype, void* stream);
-/* backward of sgg_imp_edge_ctx_fwd + sgg_imp_node_scatter_fwd (rel_model_stanford.py:76-91):
- * edge side: d_e[e] += g_out*d_ctx[s] + g_in*d_ctx[o] + sum_k da_k*w_k[H:];  da[E,4] = gate pre-activation gradients
- *   (order sub,obj,out,in);  gsave[E,2] = (g_sub, g_obj).
- * node side: d_v[n] += sum_out g_sub*d_e_in + sum_in g_obj*d_e_in + sum_k S_k[n]*w_k[:H];  nsum[N,4] = S_k[n].
+/* backward of sgg_gru_gate_proj_fwd: from dh[M,H], the saved gh and P (recomputes gi and the cell) -> d_gi, d_gh [M,3H], dh_prev [M,H],
+ * and dq f32[M,2] = (d_gi[e] . P[s], d_gi[e] . P[o]): the gradients of the scalar gates g_sub, g_obj before their sigmoids' derivative. */
+int sgg_gru_gate_proj_bwd(const void* dh, const float* gh, const float* P, const float* b_ih, const int* so, const float* node_dots,
+                          const float* edge_dots, const float* gate_b, const void* h_prev, void* d_gi, void* d_gh, void* dh_prev,
+                          float* dq, int M, int H, int dtype, void* stream);
+/* backward of one message-passing step's gates and context sums (rel_model_stanford.py:76-91), e = (s, o):
+ * edge side: d_e[e] += g_out*d_ctx[s] + g_in*d_ctx[o] + sum_k da_k*w_k[H:];  da[E,4] = gate pre-activation gradients (order sub,obj,out,in):
+ *   da_sub = dq[e,0] g_sub(1-g_sub), da_obj = dq[e,1] g_obj(1-g_obj), da_out = (d_ctx[s].e) g_out(1-g_out), da_in = (d_ctx[o].e) g_in(1-g_in).
+ * node side: d_v[n] += sum_k S_k[n]*w_k[:H] with S_sub/S_out = sums of da[.,0]/da[.,2] over n's out-edges, S_obj/S_in = sums of da[.,1]/da[.,3]
+ *   over its in-edges; nsum[N,4] = (S_sub, S_obj, S_out, S_in).  (The gate-weighted sums of d_gi -- the gradient of P -- are sgg_imp_ctx_fwd
+ *   with pair 0.)
  * gate-weight gradients: d_w_k[H:] = rank4_reduce(da, e_i), d_w_k[:H] = rank4_reduce(nsum, v), d_b = colsum(da). */
-int sgg_imp_edge_ctx_bwd(const void* v, const void* e, const int64_t* rel_inds, int E, int H, const float* node_dots,
-                         const float* gate_w, const float* gate_b, const void* d_e_in, const void* d_ctx, void* d_e, float* da,
-                         float* gsave, int dtype, void* stream);
-int sgg_imp_node_scatter_bwd(const void* d_e_in, const float* gsave, const float* da, const int* out_ptr, const int* out_ids,
-                             const int* in_ptr, const int* in_ids, const float* gate_w, int N, int H, void* d_v, float* nsum,
-                             int dtype, void* stream);
+int sgg_imp_edge_ctx_bwd(const void* e, const int* so, int E, int H, const float* node_dots, const float* edge_dots, const float* gate_w,
+                         const float* gate_b, const float* dq, const void* d_ctx, void* d_e, float* da, int dtype, void* stream);
+int sgg_imp_node_gates_bwd(const float* da, const int* out_ptr, const int* out_ids, const int* in_ptr, const int* in_ids,
+                           const float* gate_w, int N, int H, void* d_v, float* nsum, int dtype, void* stream);
 /* out[k,:H] += sum_r a[r,k]*x[r,:], k<4 (out row stride out_ld; accumulates: the caller zeroes once per step) */
 int sgg_rank4_reduce(const float* a, const void* x, int R, int H, float* out, int out_ld, int dtype, void* stream);
 

@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SGG_HIP_LIB') or os.path.join(_HERE, 'libsgg_hip.so')   # override: kernel experiments only
 
-SGG_F32, SGG_BF16 = 0, 1
+SGG_F32, SGG_BF16, SGG_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU = 0, 1
 ABI_VERSION = 1
 
@@ -43,17 +43,15 @@ SIGNATURES = {
     'sgg_bcast_add': [_P, _P, _I, _I, _I, _I, _P],
     'sgg_gemm': [_P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'sgg_gemm_splitk': [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
-    'sgg_imp_node_gate_dots': [_P, _I, _I, _P, _P, _I, _P],
-    'sgg_imp_edge_ctx_fwd': [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
-    'sgg_imp_node_scatter_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P],
-    'sgg_imp_fused_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     'sgg_gru_gate_fwd': [_P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _P],
     'sgg_imp_sliced_capacity': [_I, _I],
-    'sgg_imp_step_min_units': [],
-    'sgg_imp_sliced_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    'sgg_imp_edge_in_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    'sgg_imp_ctx_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P],
-    'sgg_imp_step_fwd': [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'sgg_imp_ctx_mfma_min_units': [],
+    # x, so, out_ptr, out_ids, in_ptr, in_ids, img_ptr, B, N, E, H, node_dots, edge_dots, gate_b, pair, out, max_edges, max_nodes, sum_ctx, dtype, stream
+    'sgg_imp_ctx_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
+    'sgg_gru_gate_proj_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P],
+    'sgg_gru_gate_proj_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    'sgg_imp_edge_ctx_bwd': [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    'sgg_imp_node_gates_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
     'sgg_graph_ptr': [_P, _I, _I, _P, _P, _P],
     'sgg_im2col': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     'sgg_maxpool3x3s2': [_P, _P, _I, _I, _I, _I, _I, _P],
@@ -76,8 +74,6 @@ SIGNATURES = {
     'sgg_bn_apply': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sgg_bn_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P],
     'sgg_gru_gate_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    'sgg_imp_edge_ctx_bwd': [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
-    'sgg_imp_node_scatter_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
     'sgg_rank4_reduce': [_P, _P, _I, _I, _P, _I, _I, _P],
     'sgg_recall_first_match': [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _F, _I, _P, _P, _P],
     'sgg_freq_bias_fwd': [_P, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P],

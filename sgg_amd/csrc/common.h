@@ -6,11 +6,33 @@
 #include "../../include/sgg_hip.h"
 
 typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef _Float16 f16_t;         // IEEE half: the second 16-bit storage / MFMA operand format (same matrix-core rate as bf16, 11-bit
+                                // significand instead of 8: the mode whose logits meet the parity clause, DESIGN.md "f16")
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// Run BODY once with `T` = the element type `dtype` names (SGG_F32 / SGG_BF16 / SGG_F16); unknown codes return SGG_ERR_DTYPE.
+// SGG_FOR_DTYPE16: the two 16-bit formats only.
+#define SGG_FOR_DTYPE(dtype, ...)                                         \
+    switch (dtype) {                                                      \
+        case SGG_BF16: { using T = bf16_t; __VA_ARGS__; } break;          \
+        case SGG_F16: { using T = f16_t; __VA_ARGS__; } break;            \
+        case SGG_F32: { using T = float; __VA_ARGS__; } break;            \
+        default: return SGG_ERR_DTYPE;                                    \
+    }
+#define SGG_FOR_DTYPE16(dtype, ...)                                       \
+    switch (dtype) {                                                      \
+        case SGG_BF16: { using T = bf16_t; __VA_ARGS__; } break;          \
+        case SGG_F16: { using T = f16_t; __VA_ARGS__; } break;            \
+        default: return SGG_ERR_DTYPE;                                    \
+    }
+static inline int sgg_elem_size(int dtype) { return dtype == SGG_F32 ? 4 : 2; }
+static inline bool sgg_is_dtype(int dtype) { return dtype == SGG_F32 || dtype == SGG_BF16 || dtype == SGG_F16; }
 
 #define SGG_CHECK_LAUNCH()                                   \
     do {                                                     \
@@ -30,6 +52,38 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
+// f32 pair -> f16 pair, round-to-nearest-even (v_cvt_pk_f16_f32 on gfx950); one half -> f32 (v_cvt_f32_f16, SDWA for the high half)
+__device__ __forceinline__ unsigned int pack_f16x2(float lo, float hi) {
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{lo, hi}, f16x2_t));
+}
+__device__ __forceinline__ float f16lo_to_f32(unsigned int w) { return (float)__builtin_bit_cast(f16x2_t, w).x; }
+__device__ __forceinline__ float f16hi_to_f32(unsigned int w) { return (float)__builtin_bit_cast(f16x2_t, w).y; }
+
+// The two 16-bit formats behind one interface: pack two f32 into a dword / unpack a dword's halves / round an f32 to what a store keeps
+template <typename T> struct H16;
+template <> struct H16<bf16_t> {
+    static __device__ __forceinline__ unsigned int pack(float lo, float hi) { return pack_bf16x2(lo, hi); }
+    static __device__ __forceinline__ float lo(unsigned int w) { return __uint_as_float(w << 16); }
+    static __device__ __forceinline__ float hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
+};
+template <> struct H16<f16_t> {
+    static __device__ __forceinline__ unsigned int pack(float lo, float hi) { return pack_f16x2(lo, hi); }
+    static __device__ __forceinline__ float lo(unsigned int w) { return f16lo_to_f32(w); }
+    static __device__ __forceinline__ float hi(unsigned int w) { return f16hi_to_f32(w); }
+};
+template <typename T> __device__ __forceinline__ void unpack8(const u32x4& a, float (&v)[8]) {
+    v[0] = H16<T>::lo(a.x); v[1] = H16<T>::hi(a.x); v[2] = H16<T>::lo(a.y); v[3] = H16<T>::hi(a.y);
+    v[4] = H16<T>::lo(a.z); v[5] = H16<T>::hi(a.z); v[6] = H16<T>::lo(a.w); v[7] = H16<T>::hi(a.w);
+}
+template <typename T> __device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
+    return u32x4{H16<T>::pack(v[0], v[1]), H16<T>::pack(v[2], v[3]), H16<T>::pack(v[4], v[5]), H16<T>::pack(v[6], v[7])};
+}
+// x as it reads back after a store in T
+template <typename T> __device__ __forceinline__ float round_as(float x) {
+    if constexpr (sizeof(T) == 2) return H16<T>::lo(H16<T>::pack(x, 0.f));
+    else return x;
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
@@ -38,6 +92,10 @@ template <> struct Elem<float> {
 template <> struct Elem<bf16_t> {
     static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
     static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+template <> struct Elem<f16_t> {
+    static __device__ __forceinline__ float ld(const f16_t* p) { return (float)*p; }
+    static __device__ __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)v; }
 };
 
 // 8 consecutive elements <-> 8 floats (16-B loads for bf16, 2x16-B for f32)
@@ -53,6 +111,8 @@ __device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
     v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
     v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
 }
+__device__ __forceinline__ void load8(const f16_t* p, float (&v)[8]) { unpack8<f16_t>(*reinterpret_cast<const u32x4*>(p), v); }
+__device__ __forceinline__ void store8(f16_t* p, const float (&v)[8]) { *reinterpret_cast<u32x4*>(p) = pack8<f16_t>(v); }
 __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
     f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
     *reinterpret_cast<f32x4*>(p) = a;
@@ -76,6 +136,12 @@ template <> struct Raw8<bf16_t> {
         v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
     }
 };
+template <> struct Raw8<f16_t> {
+    u32x4 r;
+    __device__ __forceinline__ void load(const f16_t* p) { r = *reinterpret_cast<const u32x4*>(p); }
+    __device__ __forceinline__ void zero() { r = u32x4{0, 0, 0, 0}; }
+    __device__ __forceinline__ void get(float (&v)[8]) const { unpack8<f16_t>(r, v); }
+};
 template <> struct Raw8<float> {
     f32x4 a, b;
     __device__ __forceinline__ void load(const float* p) {
@@ -94,6 +160,14 @@ template <> struct Raw8<float> {
 // e_in at unit scale; round 1, ROCm 7.2 -- suspected missing wait states between the dot and the DPP read).  Do not bring it
 // back without the unit test `test_imp_sliced_vs_oracle_math`, which compares this kernel in bf16 with the dense formula.
 __device__ __forceinline__ float dot8(const Raw8<bf16_t>& w, const Raw8<bf16_t>& x, float acc) {
+    float a[8], b[8];
+    w.get(a);
+    x.get(b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = fmaf(a[j], b[j], acc);
+    return acc;
+}
+__device__ __forceinline__ float dot8(const Raw8<f16_t>& w, const Raw8<f16_t>& x, float acc) {
     float a[8], b[8];
     w.get(a);
     x.get(b);

@@ -347,126 +347,170 @@ __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const T* __restrict__
     if (dh_prev) store8(dh_prev + m * H + c, o_h);
 }
 
-// IMP edge-side backward, one wave per edge e=(s,o).  Inputs: v, e_i (saved), d_e_in[e], d_ctx rows of s and o.
-// Recomputes the four gates, then
-//   d_e[e]    (+)= g_out*d_ctx[s] + g_in*d_ctx[o] + sum_k da_k * w_k[H:]          (accumulated into d_e, which
-//                 already holds the GRU's dh_prev)
-//   da[e,0..3] = d g_k * g_k(1-g_k)   with  d g_sub=<d_e_in,v[s]>, d g_obj=<d_e_in,v[o]>, d g_out=<d_ctx[s],e>, d g_in=<d_ctx[o],e>
-//   gsave[e]   = (g_sub, g_obj) for the node-side reduction of d_v
+// Backward of gru_gate_proj_kernel (imp.hip): the edge GRU of a message-passing iteration whose input pre-activations are
+//   gi[e] = g_sub(e) P[s] + g_obj(e) P[o] + b_ih.  Recomputes gi and the cell from the saved gh, P and dot products, then
+//   d_gi = [d_rpre, d_zpre, d_npre], d_gh = [d_rpre, d_zpre, d_npre * r], dh_prev = dh * z,
+//   dq[e] = (<d_gi, P[s]>, <d_gi, P[o]>)  -- the gradients of the two scalar gates (reduced over the row's H/8 lanes).
 template <typename T>
-__global__ __launch_bounds__(256) void edge_ctx_bwd_kernel(const T* __restrict__ v, const T* __restrict__ e,
-                                                           const int64_t* __restrict__ rel, int E, int H,
-                                                           const float* __restrict__ dots, const float* __restrict__ gw,
-                                                           const float* __restrict__ gb, const T* __restrict__ d_e_in,
-                                                           const T* __restrict__ d_ctx, T* __restrict__ d_e,
-                                                           float* __restrict__ da, float* __restrict__ gsave) {
+__global__ __launch_bounds__(256) void gru_gate_proj_bwd_kernel(const T* __restrict__ dh, const float* __restrict__ gh,
+                                                                const float* __restrict__ P, const float* __restrict__ b_ih,
+                                                                const int* __restrict__ so, const float* __restrict__ ndots,
+                                                                const float* __restrict__ edots, const float* __restrict__ gb,
+                                                                const T* __restrict__ h_prev, T* __restrict__ d_gi, T* __restrict__ d_gh,
+                                                                T* __restrict__ dh_prev, float* __restrict__ dq, long total, int H) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // over M*H/8
+    if (i >= total) return;
+    const int h8 = H >> 3;
+    const long m = i / h8;
+    const int c = (int)(i - m * h8) * 8;
+    const int s = so[2 * m], ob = so[2 * m + 1];
+    const float g_sub = sigmoidf_(ndots[4L * s] + edots[4 * m] + gb[0]);
+    const float g_obj = sigmoidf_(ndots[4L * ob + 1] + edots[4 * m + 1] + gb[1]);
+    float hr[8], hz[8], hn[8], hp[8], g[8], ps[3][8], po[3][8], gi3[3][8];
+    const float* ghm = gh + m * 3 * H + c;
+    load8(ghm, hr);
+    load8(ghm + H, hz);
+    load8(ghm + 2 * H, hn);
+    load8(h_prev + m * H + c, hp);
+    load8(dh + m * H + c, g);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        float bi[8];
+        load8(P + (long)s * 3 * H + q * H + c, ps[q]);
+        load8(P + (long)ob * 3 * H + q * H + c, po[q]);
+        load8(b_ih + q * H + c, bi);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gi3[q][j] = fmaf(g_sub, ps[q][j], fmaf(g_obj, po[q][j], bi[j]));
+    }
+    float o_r[8], o_z[8], o_n[8], o_hn[8], o_h[8];
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float r = 1.f / (1.f + expf(-(gi3[0][j] + hr[j])));
+        const float z = 1.f / (1.f + expf(-(gi3[1][j] + hz[j])));
+        const float n = tanhf(gi3[2][j] + r * hn[j]);
+        const float dn = g[j] * (1.f - z), dz = g[j] * (hp[j] - n);
+        const float dnpre = dn * (1.f - n * n);
+        o_n[j] = dnpre;
+        o_hn[j] = dnpre * r;
+        o_r[j] = dnpre * hn[j] * r * (1.f - r);
+        o_z[j] = dz * z * (1.f - z);
+        o_h[j] = g[j] * z;
+        q0 = fmaf(o_r[j], ps[0][j], fmaf(o_z[j], ps[1][j], fmaf(o_n[j], ps[2][j], q0)));
+        q1 = fmaf(o_r[j], po[0][j], fmaf(o_z[j], po[1][j], fmaf(o_n[j], po[2][j], q1)));
+    }
+    T* a = d_gi + m * 3 * H + c;
+    store8(a, o_r);
+    store8(a + H, o_z);
+    store8(a + 2 * H, o_n);
+    T* b = d_gh + m * 3 * H + c;
+    store8(b, o_r);
+    store8(b + H, o_z);
+    store8(b + 2 * H, o_hn);
+    if (dh_prev) store8(dh_prev + m * H + c, o_h);
+    for (int off = h8 >> 1; off > 0; off >>= 1) {      // rows never straddle a wave (H/8 a power of two <= 64): fixed order
+        q0 += __shfl_xor(q0, off, 64);
+        q1 += __shfl_xor(q1, off, 64);
+    }
+    if (c == 0) {
+        dq[2 * m] = q0;
+        dq[2 * m + 1] = q1;
+    }
+}
+
+// IMP edge-side backward, one wave per edge e=(s,o) (rel_model_stanford.py:76-91 in reverse).  Inputs: e_i (saved), the saved dot
+// products, d_ctx rows of s and o, dq (gru_gate_proj_bwd_kernel).  Recomputes the four gates, then
+//   d_e[e]    (+)= g_out*d_ctx[s] + g_in*d_ctx[o] + sum_k da_k * w_k[H:]     (accumulated into d_e, which already holds the GRU's part)
+//   da[e,0..3] = d g_k * g_k(1-g_k)   with  d g_sub = dq[e,0], d g_obj = dq[e,1], d g_out = <d_ctx[s],e>, d g_in = <d_ctx[o],e>
+template <typename T>
+__global__ __launch_bounds__(256) void edge_ctx_bwd_kernel(const T* __restrict__ e, const int* __restrict__ so, int E, int H,
+                                                           const float* __restrict__ ndots, const float* __restrict__ edots,
+                                                           const float* __restrict__ gw, const float* __restrict__ gb,
+                                                           const float* __restrict__ dq, const T* __restrict__ d_ctx,
+                                                           T* __restrict__ d_e, float* __restrict__ da) {
     const int ed = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (ed >= E) return;
-    const long s = rel[(long)ed * 3 + 1], o = rel[(long)ed * 3 + 2];
+    const long s = so[2L * ed], o = so[2L * ed + 1];
     const int c0 = lane * 8;
     const bool act = c0 < H;
-    float ee[8], sv[8], ov[8], din[8], dcs[8], dco[8], w[4][8];
-    float p[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    float ee[8], dcs[8], dco[8];
+    float q2 = 0.f, q3 = 0.f;
     if (act) {
         load8(e + (long)ed * H + c0, ee);
-        load8(v + s * H + c0, sv);
-        load8(v + o * H + c0, ov);
-        load8(d_e_in + (long)ed * H + c0, din);
         load8(d_ctx + s * H + c0, dcs);
         load8(d_ctx + o * H + c0, dco);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            load8(gw + (long)k * 2 * H + H + c0, w[k]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) p[k] = fmaf(w[k][j], ee[j], p[k]);
-        }
-#pragma unroll
         for (int j = 0; j < 8; ++j) {
-            q[0] = fmaf(din[j], sv[j], q[0]);
-            q[1] = fmaf(din[j], ov[j], q[1]);
-            q[2] = fmaf(dcs[j], ee[j], q[2]);
-            q[3] = fmaf(dco[j], ee[j], q[3]);
+            q2 = fmaf(dcs[j], ee[j], q2);
+            q3 = fmaf(dco[j], ee[j], q3);
         }
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        p[k] = wave_sum(p[k]);
-        q[k] = wave_sum(q[k]);
-    }
+    q2 = wave_sum(q2);
+    q3 = wave_sum(q3);
+    const f32x4 de = *reinterpret_cast<const f32x4*>(edots + 4L * ed);
+    const f32x4 ns = *reinterpret_cast<const f32x4*>(ndots + 4 * s), no = *reinterpret_cast<const f32x4*>(ndots + 4 * o);
     float gk[4], dak[4];
-    gk[0] = sigmoidf_(dots[s * 4 + 0] + p[0] + gb[0]);
-    gk[1] = sigmoidf_(dots[o * 4 + 1] + p[1] + gb[1]);
-    gk[2] = sigmoidf_(dots[s * 4 + 2] + p[2] + gb[2]);
-    gk[3] = sigmoidf_(dots[o * 4 + 3] + p[3] + gb[3]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) dak[k] = q[k] * gk[k] * (1.f - gk[k]);
+    gk[0] = sigmoidf_(ns.x + de.x + gb[0]);
+    gk[1] = sigmoidf_(no.y + de.y + gb[1]);
+    gk[2] = sigmoidf_(ns.z + de.z + gb[2]);
+    gk[3] = sigmoidf_(no.w + de.w + gb[3]);
+    dak[0] = dq[2L * ed] * gk[0] * (1.f - gk[0]);
+    dak[1] = dq[2L * ed + 1] * gk[1] * (1.f - gk[1]);
+    dak[2] = q2 * gk[2] * (1.f - gk[2]);
+    dak[3] = q3 * gk[3] * (1.f - gk[3]);
     if (act) {
         float r[8];
         load8(d_e + (long)ed * H + c0, r);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            r[j] += gk[2] * dcs[j] + gk[3] * dco[j] + dak[0] * w[0][j] + dak[1] * w[1][j] + dak[2] * w[2][j] + dak[3] * w[3][j];
+        for (int k = 0; k < 4; ++k) {
+            float w[8];
+            load8(gw + (long)k * 2 * H + H + c0, w);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = fmaf(dak[k], w[j], r[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += gk[2] * dcs[j] + gk[3] * dco[j];
         store8(d_e + (long)ed * H + c0, r);
     }
     if (lane < 4) da[(long)ed * 4 + lane] = dak[lane];
-    if (lane < 2) gsave[(long)ed * 2 + lane] = gk[lane];
 }
 
-// IMP node-side backward, one workgroup per node n:
-//   d_v[n] (+)= sum_{e in out(n)} g_sub[e]*d_e_in[e] + sum_{e in in(n)} g_obj[e]*d_e_in[e]
-//              + S_sub*w_sub[:H] + S_out*w_out[:H] + S_obj*w_obj[:H] + S_in*w_in[:H]
-//   with S_sub/S_out = sums of da[.,0]/da[.,2] over out(n), S_obj/S_in = sums of da[.,1]/da[.,3] over in(n);
+// IMP node-side backward of the GATES, one workgroup per node n (the gate-weighted sums of d_gi are imp_ctx with pair 0):
+//   d_v[n] += S_sub*w_sub[:H] + S_out*w_out[:H] + S_obj*w_obj[:H] + S_in*w_in[:H]
+//   with S_sub/S_out = sums of da[.,0]/da[.,2] over out(n), S_obj/S_in = sums of da[.,1]/da[.,3] over in(n) (ascending list order);
 //   nsum[n,0..3] = (S_sub, S_obj, S_out, S_in) is also written: the gate weights' vertex-half gradient is nsum^T . v.
 template <typename T>
-__global__ __launch_bounds__(256) void node_scatter_bwd_kernel(const T* __restrict__ d_e_in, const float* __restrict__ gsave,
-                                                               const float* __restrict__ da, const int* __restrict__ out_ptr,
-                                                               const int* __restrict__ out_ids, const int* __restrict__ in_ptr,
-                                                               const int* __restrict__ in_ids, const float* __restrict__ gw,
-                                                               int H, T* __restrict__ d_v, float* __restrict__ nsum) {
-    __shared__ float red[4][MAXH];
-    __shared__ float sred[4][4];
-    const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c0 = lane * 8;
-    const bool act = c0 < H;
-    float acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    float S[4] = {0.f, 0.f, 0.f, 0.f};  // (S_sub, S_obj, S_out, S_in) partials of this wave (lane-uniform)
+__global__ __launch_bounds__(64) void node_gates_bwd_kernel(const float* __restrict__ da, const int* __restrict__ out_ptr,
+                                                            const int* __restrict__ out_ids, const int* __restrict__ in_ptr,
+                                                            const int* __restrict__ in_ids, const float* __restrict__ gw, int H,
+                                                            T* __restrict__ d_v, float* __restrict__ nsum) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    float S[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
         const int* ptr = side ? in_ptr : out_ptr;
         const int* ids = side ? in_ids : out_ids;
         const int beg = ptr[n], end = ptr[n + 1];
-        for (int k = beg + wave; k < end; k += 4) {
+        for (int k = beg + lane; k < end; k += 64) {
             const int id = ids[k];
-            const float g = gsave[(long)id * 2 + side];
             S[side] += da[(long)id * 4 + side];
             S[2 + side] += da[(long)id * 4 + 2 + side];
-            if (act) {
-                float x[8];
-                load8(d_e_in + (long)id * H + c0, x);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fmaf(g, x[j], acc[j]);
-            }
         }
     }
-    if (act) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) red[wave][c0 + j] = acc[j];
-    }
-    if (lane == 0) {
+    for (int k = 0; k < 4; ++k) S[k] = wave_sum(S[k]);
+    if (lane < 4) nsum[(long)n * 4 + lane] = S[lane];
+    for (int c = lane * 8; c < H; c += 512) {
+        float t[8];
+        load8(d_v + (long)n * H + c, t);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sred[wave][k] = S[k];
-    }
-    __syncthreads();
-    float St[4];
+        for (int k = 0; k < 4; ++k) {
+            float w[8];
+            load8(gw + (long)k * 2 * H + c, w);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) St[k] = sred[0][k] + sred[1][k] + sred[2][k] + sred[3][k];
-    if (threadIdx.x < 4) nsum[(long)n * 4 + threadIdx.x] = St[threadIdx.x];
-    for (int c = threadIdx.x; c < H; c += 256) {
-        float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-        t += St[0] * gw[0 * 2 * H + c] + St[1] * gw[1 * 2 * H + c] + St[2] * gw[2 * 2 * H + c] + St[3] * gw[3 * 2 * H + c];
-        Elem<T>::st(d_v + (long)n * H + c, Elem<T>::ld(d_v + (long)n * H + c) + t);
+            for (int j = 0; j < 8; ++j) t[j] = fmaf(S[k], w[j], t[j]);
+        }
+        store8(d_v + (long)n * H + c, t);
     }
 }
 
@@ -962,34 +1006,44 @@ extern "C" int sgg_gru_gate_bwd(const void* dh, const float* gi, const float* gh
     return SGG_OK;
 }
 
-extern "C" int sgg_imp_edge_ctx_bwd(const void* v, const void* e, const int64_t* rel_inds, int E, int H, const float* node_dots,
-                                    const float* gate_w, const float* gate_b, const void* d_e_in, const void* d_ctx, void* d_e,
-                                    float* da, float* gsave, int dtype, void* stream) {
-    if (E == 0) return SGG_OK;
-    if (!v || !e || !rel_inds || !node_dots || !gate_w || !gate_b || !d_e_in || !d_ctx || !d_e || !da || !gsave || E < 0 ||
-        H <= 0 || (H & 7) || H > MAXH)
+extern "C" int sgg_gru_gate_proj_bwd(const void* dh, const float* gh, const float* P, const float* b_ih, const int* so,
+                                     const float* node_dots, const float* edge_dots, const float* gate_b, const void* h_prev, void* d_gi,
+                                     void* d_gh, void* dh_prev, float* dq, int M, int H, int dtype, void* stream) {
+    if (M == 0) return SGG_OK;
+    const int h8 = H / 8;
+    if (!dh || !gh || !P || !b_ih || !so || !node_dots || !edge_dots || !gate_b || !h_prev || !d_gi || !d_gh || !dq || M < 0 || H <= 0 ||
+        (H & 7) || h8 > 64 || (h8 & (h8 - 1)))
         return SGG_ERR_ARG;
-    const dim3 grid((E + 3) / 4), blk(256);
+    const long total = (long)M * h8;
+    const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH2(dtype,
-        hipLaunchKernelGGL(edge_ctx_bwd_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)v, (const bf16_t*)e, rel_inds, E, H, node_dots, gate_w, gate_b, (const bf16_t*)d_e_in, (const bf16_t*)d_ctx, (bf16_t*)d_e, da, gsave),
-        hipLaunchKernelGGL(edge_ctx_bwd_kernel<float>, grid, blk, 0, s, (const float*)v, (const float*)e, rel_inds, E, H, node_dots, gate_w, gate_b, (const float*)d_e_in, (const float*)d_ctx, (float*)d_e, da, gsave));
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(gru_gate_proj_bwd_kernel<T>, grid, blk, 0, s, (const T*)dh, gh, P, b_ih, so, node_dots, edge_dots,
+                                            gate_b, (const T*)h_prev, (T*)d_gi, (T*)d_gh, (T*)dh_prev, dq, total, H));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
 
-extern "C" int sgg_imp_node_scatter_bwd(const void* d_e_in, const float* gsave, const float* da, const int* out_ptr,
-                                        const int* out_ids, const int* in_ptr, const int* in_ids, const float* gate_w, int N,
-                                        int H, void* d_v, float* nsum, int dtype, void* stream) {
-    if (N == 0) return SGG_OK;
-    if (!d_e_in || !gsave || !da || !out_ptr || !out_ids || !in_ptr || !in_ids || !gate_w || !d_v || !nsum || N < 0 || H <= 0 ||
-        (H & 7) || H > MAXH)
+extern "C" int sgg_imp_edge_ctx_bwd(const void* e, const int* so, int E, int H, const float* node_dots, const float* edge_dots,
+                                    const float* gate_w, const float* gate_b, const float* dq, const void* d_ctx, void* d_e, float* da,
+                                    int dtype, void* stream) {
+    if (E == 0) return SGG_OK;
+    if (!e || !so || !node_dots || !edge_dots || !gate_w || !gate_b || !dq || !d_ctx || !d_e || !da || E < 0 || H <= 0 || (H & 7) || H > MAXH)
         return SGG_ERR_ARG;
-    const dim3 grid(N), blk(256);
+    const dim3 grid((E + 3) / 4), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH2(dtype,
-        hipLaunchKernelGGL(node_scatter_bwd_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)d_e_in, gsave, da, out_ptr, out_ids, in_ptr, in_ids, gate_w, H, (bf16_t*)d_v, nsum),
-        hipLaunchKernelGGL(node_scatter_bwd_kernel<float>, grid, blk, 0, s, (const float*)d_e_in, gsave, da, out_ptr, out_ids, in_ptr, in_ids, gate_w, H, (float*)d_v, nsum));
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(edge_ctx_bwd_kernel<T>, grid, blk, 0, s, (const T*)e, so, E, H, node_dots, edge_dots, gate_w, gate_b,
+                                            dq, (const T*)d_ctx, (T*)d_e, da));
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_imp_node_gates_bwd(const float* da, const int* out_ptr, const int* out_ids, const int* in_ptr, const int* in_ids,
+                                      const float* gate_w, int N, int H, void* d_v, float* nsum, int dtype, void* stream) {
+    if (N == 0) return SGG_OK;
+    if (!da || !out_ptr || !out_ids || !in_ptr || !in_ids || !gate_w || !d_v || !nsum || N < 0 || H <= 0 || (H & 7)) return SGG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(node_gates_bwd_kernel<T>, dim3(N), dim3(64), 0, s, da, out_ptr, out_ids, in_ptr, in_ids, gate_w, H,
+                                            (T*)d_v, nsum));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

@@ -18,7 +18,6 @@ class ImpWeights(object):
             setattr(w, g + '_b_ih', p[g + '.bias_ih'].detach().float().contiguous())
             setattr(w, g + '_b_hh', p[g + '.bias_hh'].detach().float().contiguous())
         w.gate_w = torch.cat([p[g + '.0.weight'].detach().float().reshape(1, -1) for g in GATES], 0).contiguous()
-        w.gate_w_c = w.gate_w.to(dtype).contiguous()      # compute-dtype copy for the fused kernel
         w.gate_b = torch.cat([p[g + '.0.bias'].detach().float().reshape(1) for g in GATES], 0).contiguous()
         w.H = w.edge_gru_w_hh.shape[1]
         # node GRU input weight doubled along K: ctx = ctx_out + ctx_in is fed as a K-split operand (linearity)
@@ -57,65 +56,77 @@ def node_lane(device):
 
 
 def message_pass(rel_rep, obj_rep, rel_inds, csr, wts, mp_iter, dtype):
-    """rel_rep [E,H], obj_rep [N,H] (dtype), rel_inds i64[E,3] -> (vert[N,H], edge[E,H]).
-    Two forms of the gather / gate / scatter step: `imp_sliced` (every edge row read once; needs the host-side graph facts
-    of ops.edge_csr(graphs=...), the gate dot products then come out of the GRU gate kernels) or `imp_fused` (any edge list)."""
+    """rel_rep [E,H], obj_rep [N,H] (dtype), rel_inds i64[E,3] -> (vert[N,H], edge[E,H]).  rel_model_stanford.py:68-94 with the node
+    projection (csrc/imp.hip): per iteration
+        ctx   = imp_ctx(e_i)                                   :86-91  the step's read stream (any edge list; sorted graphs: every row once)
+        P_i   = v_i W_ih^T                                     [N,3H] f32 -- replaces e_in and its [E,3H] projection (:76-83)
+        e_i+1 = gru_gate_proj(e_i W_hh^T + b_hh, P_i[s], P_i[o], gates)
+        v_i+1 = GRU_n(ctx, v_i)                                :92
+    The gate pre-activations travel as dot products emitted by the kernels that write v and e."""
     N, H = obj_rep.shape
+    if mp_iter > 0 and not ops.gate_dots_ok(H):
+        raise NotImplementedError('message passing needs hidden_dim / 8 to be a power of two <= 64 (got hidden_dim %d)' % H)
     lane = node_lane(obj_rep.device)
-    sliced = mp_iter > 0 and ops.imp_sliced_ok(csr, H, dtype)
-
-    def step(vert, nd, edge, ed):
-        if sliced:
-            return ops.imp_sliced(vert, edge, csr, nd, ed, wts.gate_b)                       # :76-81,86-91 in one launch
-        return ops.imp_fused(vert, edge, rel_inds, csr, wts.gate_w_c, wts.gate_b)
+    loop = mp_iter > 0
+    wv = wts.gate_w[:, :H]
 
     def unpack(r, want):
         return r if want else (r, None)
 
+    def node_step(ctx2, vert, more, out=None, dots=None):
+        # :92  node_gru(ctx_out + ctx_in, vert): the sum rides in the GEMM's K axis
+        gi = ops.gemm(ctx2[0], wts.node_gru_w_ih2, wts.node_gru_b_ih, out_dtype=torch.float32, A2=ctx2[1])
+        gh = ops.gemm(vert, wts.node_gru_w_hh, wts.node_gru_b_hh, out_dtype=torch.float32)
+        return unpack(ops.gru_gate(gi, gh, None, vert, dtype, out=out, dot_w=wv if more else None, dots=dots), more)
+
+    def edge_step(edge, P, nd, ed, more):
+        gh = ops.gemm(edge, wts.edge_gru_w_hh, wts.edge_gru_b_hh, out_dtype=torch.float32)
+        return unpack(ops.gru_gate_proj(gh, P, wts.edge_gru_b_ih, csr, nd, ed, wts.gate_b, edge, dot_w=wts.gate_w[:, H:] if more else None), more)
+
     if lane is None:
-        vert, nd = unpack(_gru(wts, 'node_gru', obj_rep, None, dtype, dots=sliced), sliced)   # :71
-        edge, ed = unpack(_gru(wts, 'edge_gru', rel_rep, None, dtype, dots=sliced), sliced)   # :72
+        vert, nd = unpack(_gru(wts, 'node_gru', obj_rep, None, dtype, dots=loop), loop)       # :71
+        edge, ed = unpack(_gru(wts, 'edge_gru', rel_rep, None, dtype, dots=loop), loop)       # :72
         for i in range(mp_iter):                                                 # :74
-            more = sliced and i + 1 < mp_iter
-            e_in, ctx2 = step(vert, nd, edge, ed)
-            edge_new, ed = unpack(_gru(wts, 'edge_gru', e_in, edge, dtype, dots=more), more)  # :83
-            # :92  node_gru(ctx_out + ctx_in, vert): the sum rides in the GEMM's K axis
-            gi = ops.gemm(ctx2[0], wts.node_gru_w_ih2, wts.node_gru_b_ih, out_dtype=torch.float32, A2=ctx2[1])
-            gh = ops.gemm(vert, wts.node_gru_w_hh, wts.node_gru_b_hh, out_dtype=torch.float32)
-            vert, nd = unpack(ops.gru_gate(gi, gh, None, vert, dtype, dot_w=wts.gate_w[:, :H] if more else None), more)
-            edge = edge_new
+            more = i + 1 < mp_iter
+            ctx2 = ops.imp_ctx(edge, csr, N, nd, ed, wts.gate_b)
+            P = ops.gemm(vert, wts.edge_gru_w_ih, None, out_dtype=torch.float32)
+            edge_new, ed_new = edge_step(edge, P, nd, ed, more)                  # :83
+            vert, nd = node_step(ctx2, vert, more)
+            edge, ed = edge_new, ed_new
         return vert, edge
     # Two streams.  Memory rules that keep the caching allocator out of trouble: every tensor that crosses streams is
     # allocated on the main stream and stays referenced until the main stream has waited for the last side-stream
-    # event (verts, ndots, keep); temporaries of the side stream (gi, gh) are allocated and freed under the side stream.
+    # event (verts, ndots, Ps, keep); temporaries of the side stream (gi, gh) are allocated and freed under the side stream.
     side, ev_main, ev_side = lane
-    main = torch.cuda.current_stream(obj_rep.device)
-    verts = [torch.empty((N, H), dtype=dtype, device=obj_rep.device) for _ in range(mp_iter + 1)]
-    ndots = [torch.empty((N, 4), dtype=torch.float32, device=obj_rep.device) if sliced else None for _ in range(mp_iter)]
+    dev = obj_rep.device
+    main = torch.cuda.current_stream(dev)
+    verts = [torch.empty((N, H), dtype=dtype, device=dev) for _ in range(mp_iter + 1)]
+    ndots = [torch.empty((N, 4), dtype=torch.float32, device=dev) for _ in range(mp_iter)]
+    Ps = [torch.empty((N, 3 * H), dtype=torch.float32, device=dev) for _ in range(mp_iter)]
     keep = []
     ev_main.record(main)
     side.wait_event(ev_main)                                                     # obj_rep is ready
     with torch.cuda.stream(side):
         gi = ops.gemm(obj_rep, wts.node_gru_w_ih, wts.node_gru_b_ih, out_dtype=torch.float32)
         ops.gru_gate(gi, None, wts.node_gru_b_hh, None, dtype, out=verts[0],                 # :71
-                     dot_w=wts.gate_w[:, :H] if sliced else None, dots=ndots[0] if mp_iter else None)
+                     dot_w=wv if loop else None, dots=ndots[0] if loop else None)
         del gi
+        if loop:
+            ops.gemm(verts[0], wts.edge_gru_w_ih, None, out_dtype=torch.float32, out=Ps[0])
         ev_side.record(side)
-    edge, ed = unpack(_gru(wts, 'edge_gru', rel_rep, None, dtype, dots=sliced), sliced)       # :72
+    edge, ed = unpack(_gru(wts, 'edge_gru', rel_rep, None, dtype, dots=loop), loop)           # :72
     for i in range(mp_iter):                                                     # :74
-        more = sliced and i + 1 < mp_iter
-        main.wait_event(ev_side)                                                 # v_i (and its gate dots) are ready
-        e_in, ctx2 = step(verts[i], ndots[i], edge, ed)
+        more = i + 1 < mp_iter
+        main.wait_event(ev_side)                                                 # v_i, its gate dots and its projection are ready
+        ctx2 = ops.imp_ctx(edge, csr, N, ndots[i], ed, wts.gate_b)
         keep.append(ctx2)
         ev_main.record(main)
         side.wait_event(ev_main)
-        with torch.cuda.stream(side):                                            # :92, K-split sum of the two ctx halves
-            gi = ops.gemm(ctx2[0], wts.node_gru_w_ih2, wts.node_gru_b_ih, out_dtype=torch.float32, A2=ctx2[1])
-            gh = ops.gemm(verts[i], wts.node_gru_w_hh, wts.node_gru_b_hh, out_dtype=torch.float32)
-            ops.gru_gate(gi, gh, None, verts[i], dtype, out=verts[i + 1], dot_w=wts.gate_w[:, :H] if more else None,
-                         dots=ndots[i + 1] if more else None)
-            del gi, gh
+        with torch.cuda.stream(side):
+            node_step(ctx2, verts[i], more, out=verts[i + 1], dots=ndots[i + 1] if more else None)
+            if more:
+                ops.gemm(verts[i + 1], wts.edge_gru_w_ih, None, out_dtype=torch.float32, out=Ps[i + 1])
             ev_side.record(side)
-        edge, ed = unpack(_gru(wts, 'edge_gru', e_in, edge, dtype, dots=more), more)          # :83
+        edge, ed = edge_step(edge, Ps[i], ndots[i], ed, more)                    # :83
     main.wait_event(ev_side)
     return verts[-1], edge

@@ -8,16 +8,16 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, SGG_BF16, SGG_F32  # noqa: F401
+from ._lib import ACT_NONE, ACT_RELU, SGG_BF16, SGG_F16, SGG_F32  # noqa: F401
 
-_DT = {torch.float32: SGG_F32, torch.bfloat16: SGG_BF16}
+_DT = {torch.float32: SGG_F32, torch.bfloat16: SGG_BF16, torch.float16: SGG_F16}
 
 
 def dt(t):
     try:
         return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
     except KeyError:
-        raise TypeError('sgg_amd: unsupported dtype %s (float32 / bfloat16 only)' % (t,))
+        raise TypeError('sgg_amd: unsupported dtype %s (float32 / bfloat16 / float16 only)' % (t,))
 
 
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
@@ -413,149 +413,57 @@ def gemm_tn(A, B, out_dtype=torch.float32, out=None, splits=None):
 
 
 # ---------------------------------------------------------------- a-8 / a-9
-def imp_node_gate_dots(v, gate_w):
-    N, H = v.shape
-    dots = torch.empty((N, 4), dtype=torch.float32, device=v.device)
-    _lib.call('sgg_imp_node_gate_dots', _p(v), N, H, _p(gate_w, torch.float32), _p(dots), dt(v), _stream())
-    return dots
-
-
-def imp_edge_ctx(v, e, rel_inds, dots, gate_w, gate_b, e_in=None, gates=None):
-    E, H = e.shape
-    if e_in is None:
-        e_in = torch.empty_like(e)
-    if gates is None:
-        gates = torch.empty((E, 2), dtype=torch.float32, device=e.device)
-    _lib.call('sgg_imp_edge_ctx_fwd', _p(v), _p(e), _p(rel_inds, torch.int64), E, H, _p(dots, torch.float32),
-              _p(gate_w, torch.float32), _p(gate_b, torch.float32), _p(e_in), _p(gates), dt(e), _stream())
-    return e_in, gates
-
-
-def imp_node_scatter(e, gates, csr, N, ctx=None):
-    H = e.shape[1]
-    out_ptr, out_ids, in_ptr, in_ids = csr[:4]
-    if ctx is None:
-        ctx = torch.empty((N, H), dtype=e.dtype, device=e.device)
-    _lib.call('sgg_imp_node_scatter_fwd', _p(e), _p(gates, torch.float32), _p(out_ptr), _p(out_ids), _p(in_ptr),
-              _p(in_ids), N, H, _p(ctx), dt(e), _stream())
-    return ctx
-
-
-def imp_fused(v, e, rel_inds, csr, gate_w, gate_b, e_in=None, ctx2=None):
-    """One launch per IMP iteration: -> (e_in [E,H], ctx2 [2,N,H]) with ctx = ctx2[0] + ctx2[1].
-    gate_w: [4,2H] in the compute dtype of v/e."""
-    N, H = v.shape
-    E = e.shape[0]
-    out_ptr, out_ids, in_ptr, in_ids, so, flags = csr
-    if e_in is None:
-        e_in = torch.empty_like(e)
-    if ctx2 is None:
-        ctx2 = torch.empty((2, N, H), dtype=v.dtype, device=v.device)
-    _lib.call('sgg_imp_fused_fwd', _p(v), _p(e), _p(so), _p(flags), _p(out_ptr), _p(out_ids), _p(in_ptr), _p(in_ids),
-              N, E, H, _p(gate_w, v.dtype), _p(gate_b, torch.float32), _p(e_in), _p(ctx2), dt(v), _stream())
-    return e_in, ctx2
-
-
 def imp_sliced_ok(csr, H, dtype):
-    """True when the sliced kernel takes these graphs (host-side facts in csr.graphs, see edge_csr)."""
+    """True when the every-row-once kernels take these graphs (host-side facts in csr.graphs, see edge_csr)."""
     g = getattr(csr, 'graphs', None)
-    if g is None or os.environ.get('SGG_IMP_SLICED', '1') == '0':
+    if g is None:
         return False
-    h8 = H // 8
-    if H % 8 or h8 > 64 or (h8 & (h8 - 1)):
-        return False                                   # the gate-dot epilogue of gru_gate needs H/8 a power of two
-    cap = _lib.load().sgg_imp_sliced_capacity(H, _lib.SGG_BF16 if dtype == torch.bfloat16 else _lib.SGG_F32)
+    cap = _lib.load().sgg_imp_sliced_capacity(H, dt(dtype))
     return g[1] <= 64 and g[2] <= cap
 
 
-def imp_sliced(v, e, csr, node_dots, edge_dots, gate_b, e_in=None, ctx2=None, ctx_sum=None):
-    """One launch per IMP iteration, every edge row read once: -> (e_in [E,H], ctx2 [2,N,H]) -- imp_sliced_kernel, or from
-    sgg_imp_step_min_units() units on (bf16, <= 32 nodes per graph) the persistent matrix-core step.  node_dots f32[N,4] /
-    edge_dots f32[E,4] come from gru_gate(dot_w=...).  ctx_sum (optional [N,H] output): the kernel stores ctx_out + ctx_in there
-    instead of the two halves (-> (e_in, ctx_sum))."""
-    N, H = v.shape
-    E = e.shape[0]
-    form = os.environ.get('SGG_IMP_STREAM')       # kernel experiments / cross-checks: 's' split step, 'm' matrix-core step at any size
-    if form == 's' and imp_split_ok(csr, H, v.dtype):
-        return imp_split(v, e, csr, node_dots, edge_dots, gate_b, e_in=e_in, ctx2=ctx2, ctx_sum=ctx_sum)
-    if form == 'm' and imp_step_ok(csr, H, v.dtype):
-        return imp_step(v, e, csr, node_dots, edge_dots, gate_b, e_in=e_in, ctx2=ctx2, ctx_sum=ctx_sum)
+def gate_dots_ok(H):
+    """The dot-product epilogue of the GRU gate kernels reduces over the H/8 lanes of a row: H/8 a power of two <= 64."""
+    h8 = H // 8
+    return H % 8 == 0 and 0 < h8 <= 64 and (h8 & (h8 - 1)) == 0
+
+
+def imp_ctx(x, csr, N, node_dots, edge_dots, gate_b, pair=2, ctx2=None, ctx_sum=None):
+    """The read stream of a message-passing step (sgg_imp_ctx_fwd): ctx2 [2,N,H] = (sum over out-edges g_a x, sum over in-edges g_b x),
+    or their sum in ctx_sum [N,H].  pair 2: (out_edge, in_edge) gates on x = e_i -> the context of rel_model_stanford.py:86-91;
+    pair 0: (sub_vert, obj_vert) gates on x = d_gi -> the gradient of the node projection.  node_dots f32[N,4] / edge_dots f32[E,4] come
+    from the GRU gate kernels (dot_w=...).  Any edge list; graphs promised by edge_csr(graphs=...) go through the every-row-once kernels."""
+    E, H = x.shape
     out_ptr, out_ids, in_ptr, in_ids, so, flags = csr
-    B, max_nodes, max_edges = csr.graphs
-    if e_in is None:
-        e_in = torch.empty_like(e)
     if ctx_sum is None and ctx2 is None:
-        ctx2 = torch.empty((2, N, H), dtype=v.dtype, device=v.device)
+        ctx2 = torch.empty((2, N, H), dtype=x.dtype, device=x.device)
     dst = ctx_sum if ctx_sum is not None else ctx2
-    _lib.call('sgg_imp_sliced_fwd', _p(v), _p(e), _p(so), _p(out_ptr), _p(in_ptr), _p(in_ids), _p(csr.img_ptr), B, N, E, H,
-              _p(node_dots, torch.float32), _p(edge_dots, torch.float32), _p(gate_b, torch.float32), _p(e_in), _p(dst),
-              max_edges, max_nodes, 1 if ctx_sum is not None else 0, dt(v), _stream())
-    return e_in, dst
-
-
-def imp_split_ok(csr, H, dtype):
-    """True when the split step's read stream (sgg_imp_ctx_fwd) takes these graphs: one edge per thread of its workgroup."""
-    g = getattr(csr, 'graphs', None)
-    return imp_sliced_ok(csr, H, dtype) and g[2] <= 1024 and (H * (2 if dtype == torch.bfloat16 else 4)) % 64 == 0
-
-
-def imp_edge_in(v, csr, node_dots, edge_dots, gate_b, E, e_in=None, gates_oi=None):
-    """The write stream of the split step: e_in[e] = g_sub v[s] + g_obj v[o] -> [E,H] (the edge rows are not an input); with
-    gates_oi (f32 [E,2]) it also leaves (g_out, g_in) of every edge for the read stream (imp_ctx)."""
-    N, H = v.shape
-    so = csr[4]
-    if e_in is None:
-        e_in = torch.empty((E, H), dtype=v.dtype, device=v.device)
-    _lib.call('sgg_imp_edge_in_fwd', _p(v), _p(so), _p(node_dots, torch.float32), _p(edge_dots, torch.float32), _p(gate_b, torch.float32),
-              _p(e_in), _p(gates_oi, torch.float32) if gates_oi is not None else None, E, H, dt(v), _stream())
-    return e_in
-
-
-def imp_ctx(e, csr, N, gates_oi, ctx2=None, ctx_sum=None):
-    """The read stream of the split step: ctx2 [2,N,H] = (sum over out-edges g_out e, sum over in-edges g_in e), or their sum in
-    ctx_sum [N,H]; gates_oi f32 [E,2] from imp_edge_in."""
-    E, H = e.shape
-    out_ptr, out_ids, in_ptr, in_ids, so, flags = csr
-    B, max_nodes, max_edges = csr.graphs
-    if gates_oi.shape != (E, 2):
-        raise ValueError('imp_ctx: gates_oi must be f32 [E,2]')
-    if ctx_sum is None and ctx2 is None:
-        ctx2 = torch.empty((2, N, H), dtype=e.dtype, device=e.device)
-    dst = ctx_sum if ctx_sum is not None else ctx2
-    _lib.call('sgg_imp_ctx_fwd', _p(e), _p(gates_oi, torch.float32), _p(so), _p(in_ptr), _p(in_ids), _p(csr.img_ptr), B, N, E, H, _p(dst),
-              max_edges, max_nodes, 1 if ctx_sum is not None else 0, dt(e), _stream())
+    g = csr.graphs if imp_sliced_ok(csr, H, x.dtype) else None
+    B, max_nodes, max_edges = g if g is not None else (0, 0, 0)
+    _lib.call('sgg_imp_ctx_fwd', _p(x), _p(so), _p(out_ptr), _p(out_ids), _p(in_ptr), _p(in_ids),
+              _p(csr.img_ptr) if g is not None else None, B, N, E, H, _p(node_dots, torch.float32), _p(edge_dots, torch.float32),
+              _p(gate_b, torch.float32), pair, _p(dst), max_edges, max_nodes, 1 if ctx_sum is not None else 0, dt(x), _stream())
     return dst
 
 
-def imp_step_ok(csr, H, dtype):
-    """True when the one-launch matrix-core step (sgg_imp_step_fwd) takes these graphs"""
-    g = getattr(csr, 'graphs', None)
-    return imp_sliced_ok(csr, H, dtype) and dtype == torch.bfloat16 and g[1] <= 32 and g[2] <= 1024 and (H * 2) % 128 == 0
-
-
-def imp_step(v, e, csr, node_dots, edge_dots, gate_b, e_in=None, ctx2=None, ctx_sum=None):
-    """The whole IMP step on the matrix-core kernel: -> (e_in [E,H], ctx2 [2,N,H]) or (e_in, ctx_sum [N,H]); same contract as imp_sliced."""
-    N, H = v.shape
-    E = e.shape[0]
+def gru_gate_proj(gh, P, b_ih, csr, node_dots, edge_dots, gate_b, h_prev, out=None, dot_w=None, dots=None):
+    """The edge GRU of a message-passing iteration from the node projection P = v W_ih^T (f32 [N,3H], no bias) instead of e_in rows:
+    gi[e] = g_sub P[s] + g_obj P[o] + b_ih (sgg_gru_gate_proj_fwd).  -> h_out (and dots f32[M,4] with dot_w, as gru_gate)."""
+    M, H3 = gh.shape
+    H = H3 // 3
     so = csr[4]
-    B, max_nodes, max_edges = csr.graphs
-    if e_in is None:
-        e_in = torch.empty_like(e)
-    if ctx_sum is None and ctx2 is None:
-        ctx2 = torch.empty((2, N, H), dtype=v.dtype, device=v.device)
-    dst = ctx_sum if ctx_sum is not None else ctx2
-    _lib.call('sgg_imp_step_fwd', _p(v), _p(e), _p(so), _p(csr.img_ptr), B, N, E, H, _p(node_dots, torch.float32), _p(edge_dots, torch.float32),
-              _p(gate_b, torch.float32), _p(e_in), _p(dst), max_edges, max_nodes, 1 if ctx_sum is not None else 0, dt(v), _stream())
-    return e_in, dst
-
-
-def imp_split(v, e, csr, node_dots, edge_dots, gate_b, e_in=None, ctx2=None, ctx_sum=None, gates_oi=None):
-    """One IMP step as its write stream followed by its read stream; same results as imp_sliced."""
-    E = e.shape[0]
-    if gates_oi is None:
-        gates_oi = torch.empty((E, 2), dtype=torch.float32, device=e.device)
-    e_in = imp_edge_in(v, csr, node_dots, edge_dots, gate_b, E, e_in=e_in, gates_oi=gates_oi)
-    return e_in, imp_ctx(e, csr, v.shape[0], gates_oi, ctx2=ctx2, ctx_sum=ctx_sum)
+    if out is None:
+        out = torch.empty((M, H), dtype=h_prev.dtype, device=gh.device)
+    if dot_w is not None:
+        if dot_w.dtype != torch.float32 or dot_w.stride(1) != 1 or dot_w.shape != (4, H):
+            raise ValueError('gru_gate_proj: dot_w must be an f32 [4,H] view with unit column stride')
+        if dots is None:
+            dots = torch.empty((M, 4), dtype=torch.float32, device=gh.device)
+    _lib.call('sgg_gru_gate_proj_fwd', _p(gh, torch.float32), _p(P, torch.float32), _p(b_ih, torch.float32), _p(so),
+              _p(node_dots, torch.float32), _p(edge_dots, torch.float32), _p(gate_b, torch.float32), _p(h_prev), _p(out), M, H,
+              dot_w.data_ptr() if dot_w is not None else None, dot_w.stride(0) if dot_w is not None else 0,
+              _p(dots, torch.float32) if dot_w is not None else None, dt(out), _stream())
+    return (out, dots) if dot_w is not None else out
 
 
 def gru_gate(gi, gh, b_hh, h_prev, out_dtype, out=None, dot_w=None, dots=None):
@@ -721,24 +629,35 @@ def gru_gate_bwd(dh, gi, gh, b_hh, h_prev, d_gi, d_gh, want_dh_prev=True):
     return dh_prev
 
 
-def imp_edge_ctx_bwd(v, e, rel_inds, dots, gate_w, gate_b, d_e_in, d_ctx, d_e, da=None):
+def gru_gate_proj_bwd(dh, gh, P, b_ih, csr, node_dots, edge_dots, gate_b, h_prev, d_gi, d_gh):
+    """-> (dh_prev, dq f32[M,2]); d_gi / d_gh [M,3H] are written (sgg_gru_gate_proj_bwd)."""
+    M, H = dh.shape
+    dh_prev = torch.empty_like(dh)
+    dq = torch.empty((M, 2), dtype=torch.float32, device=dh.device)
+    _lib.call('sgg_gru_gate_proj_bwd', _p(dh), _p(gh, torch.float32), _p(P, torch.float32), _p(b_ih, torch.float32), _p(csr[4]),
+              _p(node_dots, torch.float32), _p(edge_dots, torch.float32), _p(gate_b, torch.float32), _p(h_prev), _p(d_gi), _p(d_gh),
+              _p(dh_prev), _p(dq), M, H, dt(dh), _stream())
+    return dh_prev, dq
+
+
+def imp_edge_ctx_bwd(e, csr, node_dots, edge_dots, gate_w, gate_b, dq, d_ctx, d_e, da=None):
+    """d_e += the step's gate / context terms; -> da f32[E,4] (sgg_imp_edge_ctx_bwd)."""
     E, H = e.shape
     if da is None:
         da = torch.empty((E, 4), dtype=torch.float32, device=e.device)
-    gsave = torch.empty((E, 2), dtype=torch.float32, device=e.device)
-    _lib.call('sgg_imp_edge_ctx_bwd', _p(v), _p(e), _p(rel_inds, torch.int64), E, H, _p(dots, torch.float32),
-              _p(gate_w, torch.float32), _p(gate_b, torch.float32), _p(d_e_in), _p(d_ctx), _p(d_e), _p(da), _p(gsave),
-              dt(e), _stream())
-    return da, gsave
+    _lib.call('sgg_imp_edge_ctx_bwd', _p(e), _p(csr[4]), E, H, _p(node_dots, torch.float32), _p(edge_dots, torch.float32),
+              _p(gate_w, torch.float32), _p(gate_b, torch.float32), _p(dq, torch.float32), _p(d_ctx), _p(d_e), _p(da), dt(e), _stream())
+    return da
 
 
-def imp_node_scatter_bwd(d_e_in, gsave, da, csr, gate_w, d_v, nsum=None):
+def imp_node_gates_bwd(da, csr, gate_w, d_v, nsum=None):
+    """d_v += sum_k S_k w_k[:H]; -> nsum f32[N,4] (sgg_imp_node_gates_bwd)."""
     N, H = d_v.shape
     out_ptr, out_ids, in_ptr, in_ids = csr[:4]
     if nsum is None:
         nsum = torch.empty((N, 4), dtype=torch.float32, device=d_v.device)
-    _lib.call('sgg_imp_node_scatter_bwd', _p(d_e_in), _p(gsave), _p(da), _p(out_ptr), _p(out_ids), _p(in_ptr), _p(in_ids),
-              _p(gate_w, torch.float32), N, H, _p(d_v), _p(nsum), dt(d_v), _stream())
+    _lib.call('sgg_imp_node_gates_bwd', _p(da, torch.float32), _p(out_ptr), _p(out_ids), _p(in_ptr), _p(in_ids), _p(gate_w, torch.float32),
+              N, H, _p(d_v), _p(nsum), dt(d_v), _stream())
     return nsum
 
 

@@ -163,12 +163,15 @@ class PredictFn(torch.autograd.Function):
         if dropout_p > 0:
             ops.dropout_(x7, dropout_p, seed * 4 + 2)
         # row-stacked inputs / states of the 4 calls of each GRU cell
-        XN = torch.empty((4 * N, H), dtype=dt, device=dev)
-        XE = torch.empty((4 * E, H), dtype=dt, device=dev)
+        T = model.mp_iter
+        XN = torch.empty(((T + 1) * N, H), dtype=dt, device=dev)      # inputs of the node cell: obj_rep, ctx_0 .. ctx_{T-1}
+        # XH = [rel_rep (E rows) ; v_0 .. v_T (N rows each)]: the edge cell's input weight W_ih sees rel_rep in its first call and the node
+        # states v_i in the others (the node projection, csrc/imp.hip) -- one contiguous operand for its weight-gradient contraction
+        XH = torch.empty((E + (T + 1) * N, H), dtype=dt, device=dev)
+        XE0, HN = XH[:E], XH[E:]
         # block c = vert_c / edge_c: the hidden state LEAVING call c = entering call c+1.  (The state entering call 0 is zero: that
-        # call adds nothing to the hidden-weight gradients, whose contractions therefore run over the rows of calls 1..3 only.)
-        HN = torch.empty((4 * N, H), dtype=dt, device=dev)
-        HE = torch.empty((4 * E, H), dtype=dt, device=dev)
+        # call adds nothing to the hidden-weight gradients, whose contractions therefore run over the rows of calls 1..T only.)
+        HE = torch.empty(((T + 1) * E, H), dtype=dt, device=dev)
         ops.gemm(x7, w['obj_unary'], w['obj_unary_b'], out=XN[:N])
         # ---- edges: relu(edge_unary(roi_fmap(edge_feat + conv(rects))))  (Linear ReLU Dropout Linear)
         _lib.set_tag('fc6_edge')
@@ -184,46 +187,39 @@ class PredictFn(torch.autograd.Function):
             ops.dropout_(y6, dropout_p, seed * 4 + 3)
         edge_relu7 = model.fc_layers()[1]          # TwoMLPHead copies (resnet50): ReLU after the edge branch's fc7 as well
         y7 = ops.gemm(y6, w['fc7_edge'], w['fc7_edge_b'], ops.ACT_RELU if edge_relu7 else ops.ACT_NONE)
-        ops.gemm(y7, w['edge_unary'], w['edge_unary_b'], ops.ACT_RELU, out=XE[:E])
+        ops.gemm(y7, w['edge_unary'], w['edge_unary_b'], ops.ACT_RELU, out=XE0)
         sv.update(x6=x6, x7=x7, y6=y6, y7=y7)
-        # ---- message passing (rel_model_stanford.py:68-94)
+        # ---- message passing (rel_model_stanford.py:68-94) with the node projection: per iteration ctx = read stream over e_i,
+        # P_i = v_i W_ih^T, e_{i+1} = gate kernel on (e_i W_hh^T, P_i[s], P_i[o]); the gate dot products come out of the gate kernels
         _lib.set_tag('imp')
         csr = ops.edge_csr(rel_inds, N, im_inds, graphs=getattr(model, '_graphs_hint', None))
-        # sliced step (every edge row read once): the gate dot products come out of the GRU gate kernels -- the vertex ones
-        # are also what the backward needs (`dots`), so the separate node_gate_dots launches go away with it
-        sliced = model.mp_iter > 0 and ops.imp_sliced_ok(csr, H, dt)
-        wv, we = (imp.gate_w[:, :H], imp.gate_w[:, H:]) if sliced else (None, None)
-        gin, ghn, gie, ghe, dots_l, gates_l = [], [], [], [], [], []
+        if T > 0 and not ops.gate_dots_ok(H):
+            raise NotImplementedError('message passing needs hidden_dim / 8 to be a power of two <= 64 (got hidden_dim %d)' % H)
+        wv, we = (imp.gate_w[:, :H], imp.gate_w[:, H:]) if T > 0 else (None, None)
+        gin, ghn, ghe, Ps, nds, eds = [], [], [], [], [], []
         a, b, nd = _gru_fwd(XN[:N], None, imp.node_gru_w_ih, imp.node_gru_w_hh, imp.node_gru_b_ih, imp.node_gru_b_hh, dt, HN[:N], wv)
         gin.append(a); ghn.append(b)
-        a, b, ed = _gru_fwd(XE[:E], None, imp.edge_gru_w_ih, imp.edge_gru_w_hh, imp.edge_gru_b_ih, imp.edge_gru_b_hh, dt, HE[:E], we)
-        gie.append(a); ghe.append(b)
-        for i in range(model.mp_iter):
+        gie0, _, ed = _gru_fwd(XE0, None, imp.edge_gru_w_ih, imp.edge_gru_w_hh, imp.edge_gru_b_ih, imp.edge_gru_b_hh, dt, HE[:E], we)
+        for i in range(T):
             v_i, e_i = HN[i * N:(i + 1) * N], HE[i * E:(i + 1) * E]
-            more = sliced and i + 1 < model.mp_iter
-            ctx_i = XN[(i + 1) * N:(i + 2) * N]                                # ctx = ctx_out + ctx_in (kept for d W_ih)
-            if sliced:
-                dots = nd                                                       # saved for the backward
-                ops.imp_sliced(v_i, e_i, csr, nd, ed, imp.gate_b, e_in=XE[(i + 1) * E:(i + 2) * E], ctx_sum=ctx_i)
-            else:
-                dots = ops.imp_node_gate_dots(v_i, imp.gate_w)                  # saved for the backward
-                _, ctx2 = ops.imp_fused(v_i, e_i, rel_inds, csr, imp.gate_w_c, imp.gate_b, e_in=XE[(i + 1) * E:(i + 2) * E])
-                ctx_i.copy_(ctx2[0])
-                ops.add_(ctx_i, ctx2[1])
-            a, b, ed = _gru_fwd(XE[(i + 1) * E:(i + 2) * E], e_i, imp.edge_gru_w_ih, imp.edge_gru_w_hh, imp.edge_gru_b_ih,
-                                imp.edge_gru_b_hh, dt, HE[(i + 1) * E:(i + 2) * E], we if more else None)
-            gie.append(a); ghe.append(b)
-            a, b, nd = _gru_fwd(XN[(i + 1) * N:(i + 2) * N], v_i, imp.node_gru_w_ih, imp.node_gru_w_hh, imp.node_gru_b_ih,
-                                imp.node_gru_b_hh, dt, HN[(i + 1) * N:(i + 2) * N], wv if more else None)
+            more = i + 1 < T
+            ctx_i = XN[(i + 1) * N:(i + 2) * N]                                # ctx = ctx_out + ctx_in (kept for d W_ih of the node cell)
+            ops.imp_ctx(e_i, csr, N, nd, ed, imp.gate_b, pair=2, ctx_sum=ctx_i)
+            P = ops.gemm(v_i, imp.edge_gru_w_ih, None, out_dtype=torch.float32)
+            gh = ops.gemm(e_i, imp.edge_gru_w_hh, imp.edge_gru_b_hh, out_dtype=torch.float32)
+            r = ops.gru_gate_proj(gh, P, imp.edge_gru_b_ih, csr, nd, ed, imp.gate_b, e_i, out=HE[(i + 1) * E:(i + 2) * E],
+                                  dot_w=we if more else None)
+            ghe.append(gh); Ps.append(P); nds.append(nd); eds.append(ed)
+            a, b, nd_new = _gru_fwd(ctx_i, v_i, imp.node_gru_w_ih, imp.node_gru_w_hh, imp.node_gru_b_ih,
+                                    imp.node_gru_b_hh, dt, HN[(i + 1) * N:(i + 2) * N], wv if more else None)
             gin.append(a); ghn.append(b)
-            dots_l.append(dots)
-        T = model.mp_iter
+            nd, ed = nd_new, (r[1] if more else None)
         vT, eT = HN[T * N:(T + 1) * N], HE[T * E:(T + 1) * E]
         _lib.set_tag('heads')
         obj = ops.gemm(vT, w['obj_fc'], w['obj_fc_b'], out_dtype=torch.float32)
         rel = ops.gemm(eT, w['rel_fc'], w['rel_fc_b'], out_dtype=torch.float32)
-        sv.update(paired=paired, XN=XN, XE=XE, HN=HN, HE=HE, gin=gin, ghn=ghn, gie=gie, ghe=ghe, dots=dots_l, csr=csr, nf=nf, ef=ef,
-                  rel_inds=rel_inds, N=N, E=E, H=H, dropout_p=dropout_p)
+        sv.update(paired=paired, XN=XN, XH=XH, HN=HN, HE=HE, gin=gin, ghn=ghn, gie0=gie0, ghe=ghe, Ps=Ps, nds=nds, eds=eds, csr=csr, nf=nf,
+                  ef=ef, rel_inds=rel_inds, N=N, E=E, H=H, dropout_p=dropout_p)
         _lib.set_tag('')
         ctx.model, ctx.sv = model, sv
         return obj, rel
@@ -234,7 +230,8 @@ class PredictFn(torch.autograd.Function):
         w = train_weights(model)
         t, imp, dt = w['train'], w['imp'], model.compute_dtype
         N, E, H, T = sv['N'], sv['E'], sv['H'], model.mp_iter
-        XN, XE, HN, HE = sv['XN'], sv['XE'], sv['HN'], sv['HE']
+        XN, XH, HN, HE = sv['XN'], sv['XH'], sv['HN'], sv['HE']
+        csr = sv['csr']
         dev = XN.device
         G = {}
         pool = ops.ZeroPool(32768, dev)     # zeroed once: every bias-gradient column sum of this pass accumulates into a slice of it
@@ -302,46 +299,55 @@ class PredictFn(torch.autograd.Function):
             d_e = lin_bwd(d_rel, rows(HE, T, E), t['rel_fc_t'], 'rel_fc', 'bwd_heads')
         # IMP backward (rel_model_stanford.py:74-92 in reverse)
         _lib.set_tag('bwd_imp')
-        dGIn = torch.empty((4 * N, 3 * H), dtype=dt, device=dev)
-        dGHn = torch.empty((4 * N, 3 * H), dtype=dt, device=dev)
-        dGIe = torch.empty((4 * E, 3 * H), dtype=dt, device=dev)
-        dGHe = torch.empty((4 * E, 3 * H), dtype=dt, device=dev)
+        dGIn = torch.empty(((T + 1) * N, 3 * H), dtype=dt, device=dev)
+        dGHn = torch.empty(((T + 1) * N, 3 * H), dtype=dt, device=dev)
+        # d_gi of the edge cell, laid out for its two parameter gradients without a copy: rows [0, T E) = calls T .. 1 (call c at
+        # (T - c) E), rows [T E, (T+1) E) = call 0, then T N rows dP_0 .. dP_{T-1} (gradients of the node projections).
+        # b_ih acts in every call of every edge: its gradient is the column sum of the first (T+1) E rows; W_ih saw rel_rep in call 0
+        # and v_i in the projections: its gradient is the contraction of the LAST E + T N rows with XH = [rel_rep ; v_0 .. v_{T-1}].
+        DG = torch.empty(((T + 1) * E + T * N, 3 * H), dtype=dt, device=dev)
+        dgi_call = lambda c: DG[(T - c) * E:(T - c + 1) * E]
+        dP = lambda i: DG[(T + 1) * E + i * N:(T + 1) * E + (i + 1) * N]
+        dGHe = torch.empty(((T + 1) * E, 3 * H), dtype=dt, device=dev)
         d_gw = torch.zeros((4, 2 * H), dtype=torch.float32, device=dev)
         d_gb = torch.zeros((4, 4), dtype=torch.float32, device=dev)     # column 0 of a 16-byte row per gate: the views handed on stay aligned
         ones = torch.ones((T * E, 1), dtype=dt, device=dev)
         # gate-side partials of all iterations, stacked like HN / HE so that the gate-weight gradients are three
-        # contractions over 3E / 3N rows in phase C instead of nine small ones
+        # contractions over T E / T N rows in phase C instead of 3 T small ones
         da_all = torch.empty((T * E, 4), dtype=torch.float32, device=dev)
         nsum_all = torch.empty((T * N, 4), dtype=torch.float32, device=dev)
         for i in range(T - 1, -1, -1):
             v_i, e_i = rows(HN, i, N), rows(HE, i, E)
+            nd_i, ed_i = sv['nds'][i], sv['eds'][i]
             # v_{i+1} = GRU_n(ctx_i, v_i)
             d_v_prev = ops.gru_gate_bwd(d_v, sv['gin'][i + 1], sv['ghn'][i + 1], None, v_i, rows(dGIn, i + 1, N),
                                         rows(dGHn, i + 1, N))
             d_ctx = ops.gemm(rows(dGIn, i + 1, N), t['node_gru_w_ih_t'])
             ops.add_(d_v_prev, ops.gemm(rows(dGHn, i + 1, N), t['node_gru_w_hh_t']))
-            # e_{i+1} = GRU_e(e_in_i, e_i)
-            d_e_prev = ops.gru_gate_bwd(d_e, sv['gie'][i + 1], sv['ghe'][i + 1], None, e_i, rows(dGIe, i + 1, E),
-                                        rows(dGHe, i + 1, E))
-            d_e_in = ops.gemm(rows(dGIe, i + 1, E), t['edge_gru_w_ih_t'])
+            # e_{i+1} = GRU_e(g_sub P_i[s] + g_obj P_i[o] + b_ih ; e_i)
+            d_e_prev, dq = ops.gru_gate_proj_bwd(d_e, sv['ghe'][i], sv['Ps'][i], imp.edge_gru_b_ih, csr, nd_i, ed_i, imp.gate_b, e_i,
+                                                 dgi_call(i + 1), rows(dGHe, i + 1, E))
             ops.add_(d_e_prev, ops.gemm(rows(dGHe, i + 1, E), t['edge_gru_w_hh_t']))
-            # gather / gate / scatter
-            da, gsave = ops.imp_edge_ctx_bwd(v_i, e_i, sv['rel_inds'], sv['dots'][i], imp.gate_w, imp.gate_b, d_e_in, d_ctx,
-                                             d_e_prev, da=rows(da_all, i, E))
-            ops.imp_node_scatter_bwd(d_e_in, gsave, da, sv['csr'], imp.gate_w, d_v_prev, nsum=rows(nsum_all, i, N))
+            # the four gates and the context sums
+            da = ops.imp_edge_ctx_bwd(e_i, csr, nd_i, ed_i, imp.gate_w, imp.gate_b, dq, d_ctx, d_e_prev, da=rows(da_all, i, E))
+            ops.imp_node_gates_bwd(da, csr, imp.gate_w, d_v_prev, nsum=rows(nsum_all, i, N))
+            # the node projection: dP_i[n] = sum_{s(e)=n} g_sub d_gi[e] + sum_{o(e)=n} g_obj d_gi[e]  (the forward's read stream on
+            # the d_gi rows with the other gate pair), then through W_ih into d_v
+            ops.imp_ctx(dgi_call(i + 1), csr, N, nd_i, ed_i, imp.gate_b, pair=0, ctx_sum=dP(i))
+            ops.add_(d_v_prev, ops.gemm(dP(i), t['edge_gru_w_ih_t']))
             d_v, d_e = d_v_prev, d_e_prev
         # first calls (h = 0): gh = b_hh only
         ops.gru_gate_bwd(d_v, sv['gin'][0], None, imp.node_gru_b_hh, None, rows(dGIn, 0, N), rows(dGHn, 0, N), False)
         d_obj_rep = ops.gemm(rows(dGIn, 0, N), t['node_gru_w_ih_t'])
-        ops.gru_gate_bwd(d_e, sv['gie'][0], None, imp.edge_gru_b_hh, None, rows(dGIe, 0, E), rows(dGHe, 0, E), False)
-        d_rel_rep = ops.gemm(rows(dGIe, 0, E), t['edge_gru_w_ih_t'])
+        ops.gru_gate_bwd(d_e, sv['gie0'], None, imp.edge_gru_b_hh, None, dgi_call(0), rows(dGHe, 0, E), False)
+        d_rel_rep = ops.gemm(dgi_call(0), t['edge_gru_w_ih_t'])
         if T != 3:
             raise NotImplementedError('training is wired for mp_iter == 3')
         p = sv['dropout_p']
         ds = 1.0 / (1.0 - p) if p > 0 else 1.0
         C, PP = model.edge_dim, model.pool_sz ** 2
         _lib.set_tag('bwd_mlp')
-        d_u = ops.act_bwd(d_rel_rep, rows(XE, 0, E))                               # relu(edge_unary)
+        d_u = ops.act_bwd(d_rel_rep, XH[:E])                                       # relu(edge_unary)
         fc, edge_relu7 = model.fc_layers()
         n6e, n7e, n6o, n7o = (fc[k][0] for k in ('fc6_edge', 'fc7_edge', 'fc6_obj', 'fc7_obj'))
         d_y7 = lin_bwd(d_u, sv['y7'], t['edge_unary_t'], 'edge_unary', 'bwd_mlp')
@@ -384,11 +390,12 @@ class PredictFn(torch.autograd.Function):
             dw()
         _lib.set_tag('bwd_imp')
         # GRU parameter gradients: one contraction over the 4 stacked calls; hidden state of call 0 is zero
-        G['edge_gru.weight_ih'], G['edge_gru.bias_ih'] = tn_gemm(dGIe, XE, want_colsum=True, pool=pool)
-        G['edge_gru.weight_hh'] = tn_gemm(dGHe[E:], HE[:3 * E])              # states entering calls 1..3 (call 0: zero state)
+        G['edge_gru.weight_ih'] = tn_gemm(DG[T * E:], XH[:E + T * N])           # [d_gi of call 0 ; dP_0 ..]^T . [rel_rep ; v_0 ..]
+        G['edge_gru.bias_ih'] = ops.colsum(DG[:(T + 1) * E], pool)
+        G['edge_gru.weight_hh'] = tn_gemm(dGHe[E:], HE[:T * E])              # states entering calls 1..T (call 0: zero state)
         G['edge_gru.bias_hh'] = ops.colsum(dGHe, pool)                          # b_hh acts in every call
         G['node_gru.weight_ih'], G['node_gru.bias_ih'] = tn_gemm(dGIn, XN, want_colsum=True, pool=pool)
-        G['node_gru.weight_hh'] = tn_gemm(dGHn[N:], HN[:3 * N])
+        G['node_gru.weight_hh'] = tn_gemm(dGHn[N:], HN[:T * N])
         G['node_gru.bias_hh'] = ops.colsum(dGHn, pool)
         ops.rank4_reduce_(da_all, HE[:T * E], d_gw, col0=H)         # e_i = rows i of HE, v_i = rows i of HN
         ops.rank4_reduce_(nsum_all, HN[:T * N], d_gw, col0=0)

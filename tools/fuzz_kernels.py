@@ -37,21 +37,27 @@ def fuzz_imp():
     csr = ops.edge_csr(cu(rel), N, cu(im), graphs=(nb, max(sizes), max(per)))
     s, o = torch.from_numpy(rel[:, 1]), torch.from_numpy(rel[:, 2])
     gt = [torch.sigmoid(torch.cat((a, e), 1) @ gw[k] + gb[k]) for k, a in enumerate((v[s], v[o], v[s], v[o]))]
-    exp_ein = gt[0][:, None] * v[s] + gt[1][:, None] * v[o]
-    exp_out = torch.zeros(N, H).index_add_(0, s, gt[2][:, None] * e)
-    exp_in = torch.zeros(N, H).index_add_(0, o, gt[3][:, None] * e)
-    tol = dict(atol=3e-5, rtol=1e-5) if dtype == torch.float32 else dict(atol=4e-2, rtol=2e-2)
-    ctol = dict(atol=2e-4, rtol=1e-5) if dtype == torch.float32 else dict(atol=0.5, rtol=3e-2)
-    outs = [('fused', ops.imp_fused(v_d, e_d, cu(rel), csr, gwd.to(dtype), cu(gb)))]
-    if ops.imp_sliced_ok(csr, H, dtype):
-        outs.append(('sliced', ops.imp_sliced(v_d, e_d, csr, nd, ed, cu(gb))))
-        cs = torch.empty((N, H), dtype=dtype, device=dev)
-        ops.imp_sliced(v_d, e_d, csr, nd, ed, cu(gb), ctx_sum=cs)
-        torch.testing.assert_close(cs.float().cpu(), exp_out + exp_in, **ctol)
-    for name, (e_in, ctx2) in outs:
-        torch.testing.assert_close(e_in.float().cpu(), exp_ein, **tol, msg=lambda m: '%s H=%d %s sizes=%s: %s' % (name, H, dtype, sizes, m))
-        torch.testing.assert_close(ctx2[0].float().cpu(), exp_out, **ctol)
-        torch.testing.assert_close(ctx2[1].float().cpu(), exp_in, **ctol)
+    ctol = dict(atol=2e-4, rtol=1e-5) if dtype == torch.float32 else dict(atol=0.5, rtol=3e-2) if dtype == torch.bfloat16 else dict(atol=6e-2, rtol=4e-3)
+    plain = ops.edge_csr(cu(rel), N, cu(im))
+    for pair in (2, 0):                               # the forward's context sums / the backward's projection gradient
+        exp_out = torch.zeros(N, H).index_add_(0, s, gt[pair][:, None] * e)
+        exp_in = torch.zeros(N, H).index_add_(0, o, gt[pair + 1][:, None] * e)
+        outs = [('lists', ops.imp_ctx(e_d, plain, N, nd, ed, cu(gb), pair=pair))]
+        if ops.imp_sliced_ok(csr, H, dtype):
+            outs.append(('promised', ops.imp_ctx(e_d, csr, N, nd, ed, cu(gb), pair=pair)))
+            cs = torch.empty((N, H), dtype=dtype, device=dev)
+            ops.imp_ctx(e_d, csr, N, nd, ed, cu(gb), pair=pair, ctx_sum=cs)
+            torch.testing.assert_close(cs.float().cpu(), exp_out + exp_in, **ctol)
+        for name, ctx2 in outs:
+            msg = lambda m: '%s H=%d %s sizes=%s pair=%d: %s' % (name, H, dtype, sizes, pair, m)  # noqa: E731
+            torch.testing.assert_close(ctx2[0].float().cpu(), exp_out, msg=msg, **ctol)
+            torch.testing.assert_close(ctx2[1].float().cpu(), exp_in, msg=msg, **ctol)
+    # the edge GRU from the node projection against the gate kernel on materialised pre-activations
+    P, gh, b_ih = torch.randn(N, 3 * H, generator=g), torch.randn(E, 3 * H, generator=g), torch.randn(3 * H, generator=g) / 4
+    gi = gt[0][:, None] * P[s] + gt[1][:, None] * P[o] + b_ih
+    got = ops.gru_gate_proj(cu(gh), cu(P), cu(b_ih), csr, nd, ed, cu(gb), e_d)
+    ref = ops.gru_gate(cu(gi), cu(gh), None, e_d, dtype)
+    torch.testing.assert_close(got.float(), ref.float(), **(dict(atol=1e-5, rtol=1e-5) if dtype == torch.float32 else dict(atol=3e-2, rtol=2e-2)))
     stats['imp'] += 1
 
 
