@@ -148,8 +148,8 @@ int sgg_gemm_splitk(const void* A, int lda, const void* W, int ldw, const float*
  * (d W = dY^T X of every nn.Linear on the path, main.py:118).  The reduction rows are staged as they lie and reach the MFMA
  * through ds_read_b64_tr_b16.  Mred % 64 == 0, N % 128 == 0, K % 128 == 0; row strides in elements, multiples of 8.
  * splits > 1: split over the reduction rows, workspace f32[splits, N, K], ldc == K. */
-int sgg_gemm_tn(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int Mred, int N, int K, int out_dtype,
-                int splits, float* workspace, void* stream);
+int sgg_gemm_tn(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int Mred, int N, int K, int in_dtype /* SGG_BF16 or SGG_F16 */,
+                int out_dtype, int splits, float* workspace, void* stream);
 
 /* ---- a-8  IMP gather / gate / scatter: RelModelStanford.message_pass, rel_model_stanford.py:74-91 ----
  * The four gates of an edge e = (s, o) are sigmoids of Linear(2H, 1) on [vertex ; edge] (:41-45, 78-89): separable, so they arrive as
@@ -271,31 +271,34 @@ int sgg_det_output(const float* boxes, const float* scores, const int* labels, c
 int sgg_dropout_fwd(void* x, int64_t n, float p, uint64_t seed, int dtype, void* stream);
 /* dx = dy * (y > 0) * scale : backward of ReLU (scale 1) / ReLU->Dropout (y = saved post-dropout output, scale 1/(1-p)) */
 int sgg_act_bwd(const void* dy, const void* y, void* dx, int64_t n, float scale, int g_dtype, int y_dtype, void* stream);
-/* Cross-entropy of logits f32[M,C] (row stride ld) against labels i64 (element stride label_stride), 'baseline' form of
- * lib/losses.py:41-43,74: loss[0] += weight / norm[0] * sum_rows CE (float atomic: zero `loss` first; `norm` on the device), and
- * grad[M,ldg] (g_dtype, columns >= C zero) = d loss / d logits -- one launch for what F.cross_entropy + autograd do in ~12. */
+/* Reductions of this section are TWO-STAGE: row blocks write partial rows into a caller-provided f32 workspace `ws`, a second launch
+ * adds them in a fixed order -- no float atomics, so a training step is bit-reproducible.  ws sizes are stated per entry.
+ * Cross-entropy of logits f32[M,C] (row stride ld) against labels i64 (element stride label_stride), 'baseline' form of
+ * lib/losses.py:41-43,74: loss[0] += weight / norm[0] * sum_rows CE (zero `loss` first; `norm` on the device), and
+ * grad[M,ldg] (g_dtype, columns >= C zero) = grad_scale * d loss / d logits (grad_scale: the loss scale of the f16 mode, 1 otherwise)
+ * -- one launch for what F.cross_entropy + autograd do in ~12.  ws: f32[(M + 3) / 4].  flag (optional, i32[1], never cleared here):
+ * bit 0 is raised when a label lies outside [0, C) (e.g. torch's ignore_index); such a row adds no loss and gets a zero gradient. */
 int sgg_ce_fwd_bwd(const float* logits, int ld, const int64_t* labels, int label_stride, int M, int C, const float* norm,
-                   float weight, float* loss, void* grad, int ldg, int g_dtype, void* stream);
-/* out[N] = column sums of x[M,N] (row stride ld): bias gradients.  Accumulates with atomics: zero_out = 1 clears `out` first,
- * zero_out = 0 expects the caller to hand over zeros (one cleared workspace for all the sums of a backward pass). */
-int sgg_colsum(const void* x, int M, int N, int ld, float* out, int zero_out, int dtype, void* stream);
+                   float weight, float grad_scale, float* loss, void* grad, int ldg, float* ws, int* flag, int g_dtype, void* stream);
+/* out[N] = column sums of x[M,N] (row stride ld): bias gradients.  ws: f32[64 * N] (may be NULL when M <= 512). */
+int sgg_colsum(const void* x, int M, int N, int ld, float* out, float* ws, int dtype, void* stream);
 /* train-mode BatchNorm2d of the rect conv (lib/get_union_boxes.py:54,58) on row-major [rows, C] activations:
- * bn_stats: sums[2][C] = (sum x, sum x^2), zeroed by the callee; bn_finalize: batch mean / invstd, the affine
+ * bn_stats: sums[2][C] = (sum x, sum x^2), ws f32[64 * 2C]; bn_finalize: batch mean / invstd, the affine
  * (scale, shift) and the running-stat update (momentum 0.01, unbiased var); bn_apply: y = x*scale+shift, optionally
  * followed by the max over 4 consecutive rows (MaxPool2d(3,2,1) on the 2x2 map, :55) with arg-max rows to `arg`;
  * bn_bwd: backward of ReLU -> BN [-> max4]: x = post-ReLU BN input, dy [rows(/4), C] -> dx [rows, C] (gradient at the
- * conv output), sums[2][C] = (dbeta, dgamma), zeroed by the callee.
+ * conv output), sums[2][C] = (dbeta, dgamma), ws f32[64 * 2C] (phases 0 and 1).
  * Synchronised statistics across data-parallel ranks (BatchNorm row): the caller all-reduces `sums` plus a
  * row count between the reduction and its use; count_dev (optional, device f32) then overrides `count` / `rows` as the
  * divisor.  bn_bwd phase: 0 = reduce + apply in one call, 1 = reduce only (local sums out), 2 = apply only (sums in). */
-int sgg_bn_stats(const void* x, int M, int C, float* sums, int dtype, void* stream);
+int sgg_bn_stats(const void* x, int M, int C, float* sums, float* ws, int dtype, void* stream);
 int sgg_bn_finalize(const float* sums, int C, int count, const float* count_dev, const float* gamma, const float* beta,
                     float eps, float momentum, float* run_mean, float* run_var, float* mean, float* invstd, float* scale,
                     float* shift, void* stream);
 int sgg_bn_apply(const void* x, const float* scale, const float* shift, void* out, unsigned char* arg, int rows_out, int C,
                  int max4, int dtype, void* stream);
 int sgg_bn_bwd(const void* dy, const unsigned char* arg, const void* x, const float* mean, const float* invstd,
-               const float* gamma, void* dx, float* sums, int rows, int C, int max4, int phase, const float* count_dev,
+               const float* gamma, void* dx, float* sums, float* ws, int rows, int C, int max4, int phase, const float* count_dev,
                int dtype, void* stream);
 /* nn.GRUCell backward, pointwise part: from dh[M,H] and the saved fp32 pre-activations gi/gh ([M,3H]; gh NULL = the
  * h=0 first call, b_hh given) -> d_gi, d_gh [M,3H] and dh_prev [M,H] (may be NULL). */
@@ -317,26 +320,27 @@ int sgg_imp_edge_ctx_bwd(const void* e, const int* so, int E, int H, const float
                          const float* gate_b, const float* dq, const void* d_ctx, void* d_e, float* da, int dtype, void* stream);
 int sgg_imp_node_gates_bwd(const float* da, const int* out_ptr, const int* out_ids, const int* in_ptr, const int* in_ids,
                            const float* gate_w, int N, int H, void* d_v, float* nsum, int dtype, void* stream);
-/* out[k,:H] += sum_r a[r,k]*x[r,:], k<4 (out row stride out_ld; accumulates: the caller zeroes once per step) */
-int sgg_rank4_reduce(const float* a, const void* x, int R, int H, float* out, int out_ld, int dtype, void* stream);
+/* out[k,:H] += sum_r a[r,k]*x[r,:], k<4 (out row stride out_ld; accumulates: the caller zeroes once per step).  ws: f32[64 * 4 * H] */
+int sgg_rank4_reduce(const float* a, const void* x, int R, int H, float* out, int out_ld, float* ws, int dtype, void* stream);
 
 /* optimiser step of main.py:119-120: global-norm gradient clip (lib/pytorch_misc.py:625-656) + torch.optim.SGD
  * (momentum, weight decay, lib/pytorch_misc.py:144), fused and sync-free: sqnorm_acc accumulates sum(g^2) over all
  * parameters into one device float; sgd_step reads it: coef = min(1, max_norm/(sqrt(norm_sq)*grad_scale + 1e-6)),
- * g' = coef*grad_scale*g + wd*p, buf = first ? g' : momentum*buf + g', p -= lr*buf.  p, buf fp32; g fp32 or bf16. */
-int sgg_sqnorm_acc(const void* g, int64_t n, float* acc, int dtype, void* stream);
+ * g' = coef*grad_scale*g + wd*p, buf = first ? g' : momentum*buf + g', p -= lr*buf.  p, buf fp32; g fp32 or 16-bit.
+ * sqnorm: ws f32[2048] (one partial per workgroup, added in a fixed order). */
+int sgg_sqnorm_acc(const void* g, int64_t n, float* acc, float* ws, int dtype, void* stream);
 int sgg_sgd_step(float* p, const void* g, float* momentum_buf, int64_t n, float lr, float weight_decay, float momentum,
                  int first_step, const float* norm_sq, float max_norm, float grad_scale, int g_dtype, void* stream);
 
 /* Multi-tensor forms of the two calls above: host arrays (length count) of device pointers and sizes, one launch per
  * 32 tensors instead of one per parameter.  All pointers 16-byte aligned.  lr per tensor (the reference's two
- * parameter groups, lib/pytorch_misc.py:135-144).  shadow: optional array (entries may be NULL) of bf16 buffers that
- * receive the updated parameter in the same pass -- the next forward's MFMA operand, so no separate cast pass. */
-int sgg_sqnorm_multi(const void* const* g, const int64_t* n, int count, float* acc, int dtype, void* stream);
+ * parameter groups, lib/pytorch_misc.py:135-144).  shadow: optional array (entries may be NULL) of 16-bit buffers (shadow_dtype:
+ * SGG_BF16 / SGG_F16) that receive the updated parameter in the same pass -- the next forward's MFMA operand, so no separate cast pass. */
+int sgg_sqnorm_multi(const void* const* g, const int64_t* n, int count, float* acc, float* ws /*[2048]*/, int dtype, void* stream);
 int sgg_sgd_multi(float* const* p, const void* const* g, float* const* momentum_buf, void* const* shadow,
                   const int64_t* n, const float* lr, int count, float weight_decay, float momentum, int first_step,
-                  const float* norm_sq, float max_norm, float grad_scale, int g_dtype, int max_blocks /* 0: default 512 */,
-                  void* stream);
+                  const float* norm_sq, float max_norm, float grad_scale, int g_dtype, int shadow_dtype,
+                  int max_blocks /* 0: default 512 */, void* stream);
 
 /* ---- utilities used by the host for weight preparation (load time, not on the step path) ---- */
 int sgg_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, void* stream);
@@ -345,9 +349,10 @@ int sgg_permute_ncp_to_npc(const void* in, void* out, int Nn, int C, int Pp, int
 
 /* out[c][r] = in[r][c] (+ add[r][c / group], add f32 with row stride ld_add, or NULL); row strides in elements.
  * Feeds d W = dY^T X to sgg_gemm; the add form builds (edge_feat + conv(rects))^T for fc6's weight gradient.
- * colsum (optional, f32[C], zeroed by the callee): column sums of `in` (+add) -- the bias gradient of the same dY. */
+ * colsum (optional, f32[C]): column sums of `in` (+add) -- the bias gradient of the same dY; colsum_ws: f32 scratch of >= ceil(R / 64) * C
+ * floats (one partial row per row block, summed in ascending order: no atomics, bit-reproducible). */
 int sgg_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int R, int C, const float* add, int64_t ld_add,
-                  int group, float* colsum, int in_dtype, int out_dtype, void* stream);
+                  int group, float* colsum, float* colsum_ws, int in_dtype, int out_dtype, void* stream);
 /* out[n][c] = sum_{p<group} in[n][c*group + p]  (fp32 in): fc6's folded columns W6sum[n,c] = sum_p W6[n,c,p] */
 int sgg_group_sum(const float* in, int64_t ld_in, void* out, int64_t ld_out, int Nn, int C, int group, int out_dtype,
                   void* stream);

@@ -31,8 +31,29 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
         case SGG_F16: { using T = f16_t; __VA_ARGS__; } break;            \
         default: return SGG_ERR_DTYPE;                                    \
     }
+// two element types at once (`TA` for dtype_a, `TB` for dtype_b): f32 on either side and at most ONE 16-bit format in a call
+#define SGG_PICK2_(H, da, db, ...)                                                      \
+    if ((da) == SGG_F32) { using TA = float; using TB = H; __VA_ARGS__; }               \
+    else if ((db) == SGG_F32) { using TA = H; using TB = float; __VA_ARGS__; }          \
+    else { using TA = H; using TB = H; __VA_ARGS__; }
+#define SGG_FOR_DTYPE2(da, db, ...)                                                                         \
+    {                                                                                                       \
+        const int h__ = (da) != SGG_F32 ? (da) : (db);                                                      \
+        if (((da) != SGG_F32 && (da) != h__) || ((db) != SGG_F32 && (db) != h__)) return SGG_ERR_DTYPE;     \
+        switch (h__) {                                                                                      \
+            case SGG_F32: { using TA = float; using TB = float; __VA_ARGS__; } break;                       \
+            case SGG_BF16: { SGG_PICK2_(bf16_t, da, db, __VA_ARGS__) } break;                               \
+            case SGG_F16: { SGG_PICK2_(f16_t, da, db, __VA_ARGS__) } break;                                 \
+            default: return SGG_ERR_DTYPE;                                                                  \
+        }                                                                                                   \
+    }
 static inline int sgg_elem_size(int dtype) { return dtype == SGG_F32 ? 4 : 2; }
 static inline bool sgg_is_dtype(int dtype) { return dtype == SGG_F32 || dtype == SGG_BF16 || dtype == SGG_F16; }
+
+// out[c] (+)= sum_p parts[p][c], p ascending: the second stage of every column reduction (bias gradients, BatchNorm sums, norms).
+// First stages write one partial row per workgroup row instead of meeting in float atomics, whose arrival order -- and therefore the
+// sum's last bits -- changes from run to run: training is bit-reproducible (util.hip).
+int sgg_reduce_parts(const float* parts, int nparts, int ncols, float* out, int accumulate, hipStream_t s);
 
 #define SGG_CHECK_LAUNCH()                                   \
     do {                                                     \
@@ -82,6 +103,23 @@ template <typename T> __device__ __forceinline__ u32x4 pack8(const float (&v)[8]
 template <typename T> __device__ __forceinline__ float round_as(float x) {
     if constexpr (sizeof(T) == 2) return H16<T>::lo(H16<T>::pack(x, 0.f));
     else return x;
+}
+
+// element type <-> dtype code
+template <typename T> struct DtypeOf;
+template <> struct DtypeOf<float> { static constexpr int value = SGG_F32; };
+template <> struct DtypeOf<bf16_t> { static constexpr int value = SGG_BF16; };
+template <> struct DtypeOf<f16_t> { static constexpr int value = SGG_F16; };
+
+// v_mfma_f32_32x32x16 on 8 packed 16-bit elements per lane, in the format DT names (SGG_BF16 / SGG_F16: same rate, same fragment layout)
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+template <int DT>
+__device__ __forceinline__ f32x16 mfma_32x32x16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    static_assert(DT == SGG_BF16 || DT == SGG_F16, "16-bit operand formats");
+    if constexpr (DT == SGG_BF16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
 
 template <typename T> struct Elem;

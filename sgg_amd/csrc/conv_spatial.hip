@@ -40,10 +40,10 @@ struct ConvArgs {
     int pool;            // 1: out is the 2x2-max-pooled plane [B, H/2+2p, W/2+2p, Cout] (H, W even)
 };
 
-template <bool BF16, int WN, int NI, bool ONEBAR>
+template <int DT, int WN, int NI, bool ONEBAR>
 __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArgs g) {
     constexpr int NW = 4 * WN, CNW = 32 * NI, CN = CNW * WN;   // channels per wave / per block
-    constexpr int ESZ = BF16 ? 2 : 4;
+    constexpr int ESZ = DT == SGG_F32 ? 4 : 2;
     constexpr int PATCH_B = PROWS_PAD * RB, WSLAB_B = CN * RB;
     constexpr int PI = PROWS_PAD / 8;                        // 41 patch DMA instructions
     constexpr int PI_W = (PI + NW - 1) / NW;                 // per wave
@@ -165,9 +165,8 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
                 for (int pj = 0; pj < 2; ++pj)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
-                        if constexpr (BF16) {
-                            acc[pj][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(bf16x8_t, av[ni]), __builtin_bit_cast(bf16x8_t, bv[pj]), acc[pj][ni], 0, 0, 0);
+                        if constexpr (DT != SGG_F32) {
+                            acc[pj][ni] = mfma_32x32x16<DT>(av[ni], bv[pj], acc[pj][ni]);
                         } else {
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
@@ -230,7 +229,8 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
                 for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] + bias8[k], 0.f);
                 const int op = g.out_pad, Ho = g.H >> 1, Wo = g.W >> 1;
                 const long off = (((long)b * (Ho + 2 * op) + yo + op) * (Wo + 2 * op) + xo + op) * g.Cout + n;
-                if constexpr (BF16) store8(reinterpret_cast<bf16_t*>(g.out) + off, v);
+                if constexpr (DT == SGG_BF16) store8(reinterpret_cast<bf16_t*>(g.out) + off, v);
+                else if constexpr (DT == SGG_F16) store8(reinterpret_cast<f16_t*>(g.out) + off, v);
                 else store8(reinterpret_cast<float*>(g.out) + off, v);
             }
             continue;
@@ -250,18 +250,19 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
             const int op = g.out_pad;
             const long off = (((long)b * (g.H + 2 * op) + y + op) * (g.W + 2 * op) + x + op) * g.Cout + n;
             if (SGG_CONV_ABL == 2) continue;
-            if constexpr (BF16) store8(reinterpret_cast<bf16_t*>(g.out) + off, v);
+            if constexpr (DT == SGG_BF16) store8(reinterpret_cast<bf16_t*>(g.out) + off, v);
+            else if constexpr (DT == SGG_F16) store8(reinterpret_cast<f16_t*>(g.out) + off, v);
             else store8(reinterpret_cast<float*>(g.out) + off, v);
         }
     }
 }
 
-template <bool BF16, int WN, int NI, bool ONEBAR = false>
+template <int DT, int WN, int NI, bool ONEBAR = false>
 int launch_spatial(const ConvArgs& g, hipStream_t s) {
     constexpr int CN = 32 * NI * WN;
     constexpr int smem = PROWS_PAD * RB + 2 * CN * RB;
     static_assert(smem >= 4 * WN * 32 * (32 * NI * 4 + 16), "epilogue staging fits");
-    auto k = conv3x3_spatial_kernel<BF16, WN, NI, ONEBAR>;
+    auto k = conv3x3_spatial_kernel<DT, WN, NI, ONEBAR>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -278,7 +279,7 @@ int launch_spatial(const ConvArgs& g, hipStream_t s) {
 
 // returns SGG_OK, or 1 if the shape is not handled here (caller falls through to the implicit-GEMM kernels)
 int sgg_launch_conv_spatial(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H, int W,
-                            int Cin, int Cout, bool bf16, int pool, hipStream_t s) {
+                            int Cin, int Cout, int dt, int pool, hipStream_t s) {
     ConvArgs g{};
     g.pool = pool;
     g.in = (const char*)in; g.w = (const char*)w; g.bias = bias; g.out = (char*)out;
@@ -288,8 +289,10 @@ int sgg_launch_conv_spatial(const void* in, const void* w, const float* bias, vo
     // (4 waves x [64 px x 128 ch] per wave -- NI = 4, a quarter fewer LDS reads -- measured 10-20 % slower than
     //  8 waves x [64 x 64]: the kernel is latency-, not LDS-bandwidth-bound, and the extra waves hide more of it.)
     static const bool onebar = [] { const char* e = getenv("SGG_CONV_ONEBAR"); return e && e[0] == '1'; }();
-    if (Cout % 128 == 0 && bf16 && onebar) return launch_spatial<true, 2, 2, true>(g, s);
-    if (Cout % 128 == 0) return bf16 ? launch_spatial<true, 2, 2>(g, s) : launch_spatial<false, 2, 2>(g, s);
-    if (Cout % 64 == 0) return bf16 ? launch_spatial<true, 1, 2>(g, s) : launch_spatial<false, 1, 2>(g, s);
+    if (Cout % 128 == 0 && dt == SGG_BF16 && onebar) return launch_spatial<SGG_BF16, 2, 2, true>(g, s);
+    if (Cout % 128 == 0)
+        return dt == SGG_BF16 ? launch_spatial<SGG_BF16, 2, 2>(g, s) : dt == SGG_F16 ? launch_spatial<SGG_F16, 2, 2>(g, s) : launch_spatial<SGG_F32, 2, 2>(g, s);
+    if (Cout % 64 == 0)
+        return dt == SGG_BF16 ? launch_spatial<SGG_BF16, 1, 2>(g, s) : dt == SGG_F16 ? launch_spatial<SGG_F16, 1, 2>(g, s) : launch_spatial<SGG_F32, 1, 2>(g, s);
     return 1;
 }

@@ -99,12 +99,7 @@ extern "C" int sgg_transpose_pairsum(const void* x, int64_t ldx, const int* u2e,
     const int Up = (int)ld_out;
     const dim3 grid((C + 63) / 64, (Up + 63) / 64), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SGG_BF16)
-        hipLaunchKernelGGL(transpose_pairsum_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)x, (long)ldx, u2e, (bf16_t*)out, (long)ld_out, U, Up, C);
-    else if (dtype == SGG_F32)
-        hipLaunchKernelGGL(transpose_pairsum_kernel<float>, grid, blk, 0, s, (const float*)x, (long)ldx, u2e, (float*)out, (long)ld_out, U, Up, C);
-    else
-        return SGG_ERR_DTYPE;
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(transpose_pairsum_kernel<T>, grid, blk, 0, s, (const T*)x, (long)ldx, u2e, (T*)out, (long)ld_out, U, Up, C));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -116,12 +111,7 @@ extern "C" int sgg_group_bcast_add(void* y, int64_t ldy, const float* r, int64_t
     const long per_row = ((long)ncol + 7) / 8;
     const dim3 grid((unsigned)((per_row * M + 255) / 256)), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SGG_BF16)
-        hipLaunchKernelGGL(group_bcast_add_kernel<bf16_t>, grid, blk, 0, s, (bf16_t*)y, (long)ldy, r, (long)ldr, M, ncol, group, col0);
-    else if (dtype == SGG_F32)
-        hipLaunchKernelGGL(group_bcast_add_kernel<float>, grid, blk, 0, s, (float*)y, (long)ldy, r, (long)ldr, M, ncol, group, col0);
-    else
-        return SGG_ERR_DTYPE;
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(group_bcast_add_kernel<T>, grid, blk, 0, s, (T*)y, (long)ldy, r, (long)ldr, M, ncol, group, col0));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

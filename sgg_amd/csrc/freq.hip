@@ -78,12 +78,11 @@ extern "C" int sgg_freq_bias_fwd(const void* obj_dists, int N, int C, const int6
     if (!obj_preds || !table || (!obj_dists && !gt_classes) || (E > 0 && (!rel_inds || !rel_out))) return SGG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (N > 0) {
-        if (gt_classes || dtype == SGG_F32)
+        if (gt_classes) {
             freq_obj_pred_kernel<float><<<(N + 3) / 4, 256, 0, s>>>((const float*)obj_dists, N, C, gt_classes, obj_preds);
-        else if (dtype == SGG_BF16)
-            freq_obj_pred_kernel<bf16_t><<<(N + 3) / 4, 256, 0, s>>>((const bf16_t*)obj_dists, N, C, gt_classes, obj_preds);
-        else
-            return SGG_ERR_DTYPE;
+        } else {
+            SGG_FOR_DTYPE(dtype, (freq_obj_pred_kernel<T><<<(N + 3) / 4, 256, 0, s>>>((const T*)obj_dists, N, C, gt_classes, obj_preds)));
+        }
         SGG_CHECK_LAUNCH();
     }
     if (E > 0) {

@@ -50,13 +50,14 @@ __device__ __forceinline__ void fma4(const float* src, float w, float (&acc)[4],
         for (int c = 0; c < 4 && c < left; ++c) acc[c] += w * src[c];
     }
 }
-__device__ __forceinline__ void fma4(const bf16_t* src, float w, float (&acc)[4], int left, bool vec) {
+template <typename T>
+__device__ __forceinline__ void fma4(const T* src, float w, float (&acc)[4], int left, bool vec) {
     if (vec && left >= 4) {
         const uint2 v = *reinterpret_cast<const uint2*>(src);
-        acc[0] += w * __uint_as_float(v.x << 16); acc[1] += w * __uint_as_float(v.x & 0xffff0000u);
-        acc[2] += w * __uint_as_float(v.y << 16); acc[3] += w * __uint_as_float(v.y & 0xffff0000u);
+        acc[0] += w * H16<T>::lo(v.x); acc[1] += w * H16<T>::hi(v.x);
+        acc[2] += w * H16<T>::lo(v.y); acc[3] += w * H16<T>::hi(v.y);
     } else {
-        for (int c = 0; c < 4 && c < left; ++c) acc[c] += w * bf16_to_f32(src[c]);
+        for (int c = 0; c < 4 && c < left; ++c) acc[c] += w * Elem<T>::ld(src + c);
     }
 }
 
@@ -251,12 +252,7 @@ extern "C" int sgg_boxes_to_layout_fwd(const void* vecs, const float* boxes, con
     if (!out || O < 0 || S < 0 || (O > 0 && (!vecs || !boxes || !obj_img))) return SGG_ERR_ARG;
     const dim3 grid((unsigned)((long)N * H * W)), blk(128);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SGG_F32)
-        hipLaunchKernelGGL(layout_fwd_kernel<float>, grid, blk, 0, s, (const float*)vecs, boxes, obj_img, O, S, D, H, W, avg, (float*)out);
-    else if (dtype == SGG_BF16)
-        hipLaunchKernelGGL(layout_fwd_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)vecs, boxes, obj_img, O, S, D, H, W, avg, (bf16_t*)out);
-    else
-        return SGG_ERR_DTYPE;
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(layout_fwd_kernel<T>, grid, blk, 0, s, (const T*)vecs, boxes, obj_img, O, S, D, H, W, avg, (T*)out));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -269,12 +265,7 @@ extern "C" int sgg_boxes_to_layout_bwd(const void* d_out, const float* boxes, co
         return SGG_ERR_ARG;
     const dim3 grid((unsigned)((long)O * (S ? S * S : 1))), blk(128);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SGG_F32)
-        hipLaunchKernelGGL(layout_bwd_kernel<float>, grid, blk, 0, s, (const float*)d_out, boxes, obj_img, counts, S, D, H, W, avg, (float*)d_vecs);
-    else if (dtype == SGG_BF16)
-        hipLaunchKernelGGL(layout_bwd_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)d_out, boxes, obj_img, counts, S, D, H, W, avg, (bf16_t*)d_vecs);
-    else
-        return SGG_ERR_DTYPE;
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(layout_bwd_kernel<T>, grid, blk, 0, s, (const T*)d_out, boxes, obj_img, counts, S, D, H, W, avg, (T*)d_vecs));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -284,12 +275,8 @@ extern "C" int sgg_triple_gather(const void* obj, const void* pred, const int64_
     if (T <= 0) return SGG_OK;
     if (!obj || !pred || !edges || !out || Din <= 0 || De <= 0) return SGG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SGG_F32)
-        hipLaunchKernelGGL(triple_gather_kernel<float>, dim3(T), dim3(256), 0, s, (const float*)obj, (const float*)pred, edges, T, Din, De, (float*)out);
-    else if (dtype == SGG_BF16)
-        hipLaunchKernelGGL(triple_gather_kernel<bf16_t>, dim3(T), dim3(256), 0, s, (const bf16_t*)obj, (const bf16_t*)pred, edges, T, Din, De, (bf16_t*)out);
-    else
-        return SGG_ERR_DTYPE;
+    const int nT = T;     // (`T` names the element type inside SGG_FOR_DTYPE)
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(triple_gather_kernel<T>, dim3(nT), dim3(256), 0, s, (const T*)obj, (const T*)pred, edges, nT, Din, De, (T*)out));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -299,12 +286,7 @@ extern "C" int sgg_triple_pool_fwd(const void* rows, int ld, int o_off, const in
     if (O <= 0 || Hd <= 0) return SGG_OK;
     if (!out_ptr || !in_ptr || !pooled || ld < Hd || o_off < 0 || o_off + Hd > ld) return SGG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SGG_F32)
-        hipLaunchKernelGGL(triple_pool_kernel<float>, dim3(O), dim3(128), 0, s, (const float*)rows, ld, o_off, out_ptr, out_ids, in_ptr, in_ids, Hd, avg, (float*)pooled);
-    else if (dtype == SGG_BF16)
-        hipLaunchKernelGGL(triple_pool_kernel<bf16_t>, dim3(O), dim3(128), 0, s, (const bf16_t*)rows, ld, o_off, out_ptr, out_ids, in_ptr, in_ids, Hd, avg, (bf16_t*)pooled);
-    else
-        return SGG_ERR_DTYPE;
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(triple_pool_kernel<T>, dim3(O), dim3(128), 0, s, (const T*)rows, ld, o_off, out_ptr, out_ids, in_ptr, in_ids, Hd, avg, (T*)pooled));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -314,12 +296,8 @@ extern "C" int sgg_triple_pool_bwd(const void* d_pooled, const int64_t* edges, c
     if (T <= 0 || Hd <= 0) return SGG_OK;
     if (!d_pooled || !edges || !out_ptr || !in_ptr || !d_rows || ld < Hd || o_off < 0 || o_off + Hd > ld) return SGG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SGG_F32)
-        hipLaunchKernelGGL(triple_pool_bwd_kernel<float>, dim3(T), dim3(128), 0, s, (const float*)d_pooled, edges, out_ptr, in_ptr, Hd, avg, ld, o_off, (float*)d_rows);
-    else if (dtype == SGG_BF16)
-        hipLaunchKernelGGL(triple_pool_bwd_kernel<bf16_t>, dim3(T), dim3(128), 0, s, (const bf16_t*)d_pooled, edges, out_ptr, in_ptr, Hd, avg, ld, o_off, (bf16_t*)d_rows);
-    else
-        return SGG_ERR_DTYPE;
+    const int nT = T;     // (`T` names the element type inside SGG_FOR_DTYPE)
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(triple_pool_bwd_kernel<T>, dim3(nT), dim3(128), 0, s, (const T*)d_pooled, edges, out_ptr, in_ptr, Hd, avg, ld, o_off, (T*)d_rows));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

@@ -17,22 +17,22 @@
 
 #include "gemm_args.h"
 
-int sgg_launch_pingpong(const GemmArgs& g, bool bf16, bool conv, hipStream_t s);  // gemm256.hip
+int sgg_launch_pingpong(const GemmArgs& g, int dt, bool conv, hipStream_t s);  // gemm256.hip
 int sgg_launch_conv_spatial(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H, int W,
-                            int Cin, int Cout, bool bf16, int pool, hipStream_t s);            // conv_spatial.hip
+                            int Cin, int Cout, int dt, int pool, hipStream_t s);            // conv_spatial.hip
 
 namespace {
 
 constexpr int ROWB = 128;  // bytes of K per LDS row
 
 // WM x WN waves of 64x64; block tile (64*WM) x (64*WN); 256 threads.
-template <bool BF16, int WM, int WN, bool CONV>
+template <int DT, int WM, int WN, bool CONV>
 __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
     constexpr int LA = 2 * WM, LB = 2 * WN;  // 8-row load instructions per wave per tile
-    constexpr int ESZ = BF16 ? 2 : 4;
+    constexpr int ESZ = DT == SGG_F32 ? 4 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -146,9 +146,8 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
-                    if constexpr (BF16) {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8_t, bv[ni]), __builtin_bit_cast(bf16x8_t, av[mi]), acc[mi][ni], 0, 0, 0);
+                    if constexpr (DT != SGG_F32) {
+                        acc[mi][ni] = mfma_32x32x16<DT>(bv[ni], av[mi], acc[mi][ni]);
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
@@ -207,8 +206,9 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
 // hardware: tools/exp/tr16_probe.hip).  Which 4 stage rows form one read is free as long as both operands agree
 // (a sum does not care about the order of its terms): rows {a, a+1, a+8, a+9} differ in row parity (128 B apart) and in
 // bit 2 of the swizzle key, so the 4 x 64 B a 32-lane pass touches cover all 64 banks exactly once.
-// bf16 only (tr_b16 moves 16-bit elements).  128x128 output tile, 4 waves of 64x64, split-K over the reduction rows.
+// 16-bit operands only (tr_b16 moves 16-bit elements).  128x128 output tile, 4 waves of 64x64, split-K over the reduction rows.
 // ------------------------------------------------------------------------------------------------
+template <int DT>
 __global__ __launch_bounds__(256) void mfma_tile_tn_kernel(const GemmArgs g) {
     constexpr int HALF = 64 * ROWB;                 // one [64 rows][128 B] column half
     constexpr int STAGE = 4 * HALF;                 // A: 2 halves (128 n), B: 2 halves (128 k)
@@ -305,8 +305,7 @@ __global__ __launch_bounds__(256) void mfma_tile_tn_kernel(const GemmArgs g) {
                           (unsigned)(a_hi[SET][mi] >> 32)};                                                                   \
         const u32x4 bv = {(unsigned)b_lo[SET][ni], (unsigned)(b_lo[SET][ni] >> 32), (unsigned)b_hi[SET][ni],                  \
                           (unsigned)(b_hi[SET][ni] >> 32)};                                                                   \
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bv), __builtin_bit_cast(bf16x8_t, av), \
-                                                             acc[mi][ni], 0, 0, 0);                                          \
+        acc[mi][ni] = mfma_32x32x16<DT>(bv, av, acc[mi][ni]);                                                                \
     }
         SGG_TN_READ(0, 0)
         SGG_TN_WAIT(0)
@@ -365,13 +364,13 @@ __global__ __launch_bounds__(256) void mfma_tile_tn_kernel(const GemmArgs g) {
     }
 }
 
-template <bool BF16, int WM, int WN, bool CONV>
+template <int DT, int WM, int WN, bool CONV>
 int launch(const GemmArgs& g, hipStream_t s, int splits = 1) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int smem = 2 * (BM + BN) * ROWB;
     static_assert(smem >= 4 * 32 * 272, "epilogue staging fits");
     const int tilesM = (g.M - g.m_base + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
-    auto k = mfma_tile_kernel<BF16, WM, WN, CONV>;
+    auto k = mfma_tile_kernel<DT, WM, WN, CONV>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -387,7 +386,7 @@ int launch(const GemmArgs& g, hipStream_t s, int splits = 1) {
 // (N >= 256, M large); 256x64 tiles for narrow N; 128x128 otherwise.  SGG_GEMM_FORCE=128 disables the big kernel.
 constexpr int N_CU_CHIP = 256;   // MI355X: one 256x256 ping-pong tile per CU and round
 template <bool CONV>
-int dispatch(GemmArgs g, bool bf16, hipStream_t s) {
+int dispatch(GemmArgs g, int dt, hipStream_t s) {
     static const char* force = getenv("SGG_GEMM_FORCE");
     const bool allow256 = !(force && force[0] == '1' && force[1] == '2');
     const long tiles256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
@@ -402,24 +401,25 @@ int dispatch(GemmArgs g, bool bf16, hipStream_t s) {
             const long tail_max = tmax ? atol(tmax) : 112;
             const int tN = (g.N + 255) / 256;
             const long rem = tiles256 % N_CU_CHIP;
-            if (bf16 && !notail && g.m_base == 0 && tiles256 > N_CU_CHIP && rem > 0 && rem <= tail_max && (tiles256 - rem) % tN == 0) {
+            if (dt != SGG_F32 && !notail && g.m_base == 0 && tiles256 > N_CU_CHIP && rem > 0 && rem <= tail_max && (tiles256 - rem) % tN == 0) {
                 GemmArgs tail = g;
                 tail.m_base = (int)((tiles256 - rem) / tN) * 256;
                 g.M = tail.m_base;
                 g.nt *= 2;
                 g.nt1 *= 2;
-                const int rc = sgg_launch_pingpong(g, bf16, CONV, s);
+                const int rc = sgg_launch_pingpong(g, dt, CONV, s);
                 if (rc != SGG_OK) return rc;
-                return launch<true, 2, 2, CONV>(tail, s);
+                return dt == SGG_BF16 ? launch<SGG_BF16, 2, 2, CONV>(tail, s) : launch<SGG_F16, 2, 2, CONV>(tail, s);
             }
         }
         g.nt *= 2;   // 64-byte K-tiles
         g.nt1 *= 2;
-        return sgg_launch_pingpong(g, bf16, CONV, s);
+        return sgg_launch_pingpong(g, dt, CONV, s);
     }
     const bool narrow = g.N < 128;
-    if (bf16) return narrow ? launch<true, 4, 1, CONV>(g, s) : launch<true, 2, 2, CONV>(g, s);
-    return narrow ? launch<false, 4, 1, CONV>(g, s) : launch<false, 2, 2, CONV>(g, s);
+    if (dt == SGG_BF16) return narrow ? launch<SGG_BF16, 4, 1, CONV>(g, s) : launch<SGG_BF16, 2, 2, CONV>(g, s);
+    if (dt == SGG_F16) return narrow ? launch<SGG_F16, 4, 1, CONV>(g, s) : launch<SGG_F16, 2, 2, CONV>(g, s);
+    return narrow ? launch<SGG_F32, 4, 1, CONV>(g, s) : launch<SGG_F32, 2, 2, CONV>(g, s);
 }
 
 }  // namespace
@@ -428,10 +428,9 @@ static int gemm_impl(const void* A, int lda, const void* A2, int lda2, int K1, c
                      int ldw2, const float* bias, const float* post_scale, const float* post_shift, void* C, int ldc, int M,
                      int N, int K, int act, int in_dtype, int out_dtype, const float* add_rows, int ld_add, const int* add_idx, void* stream,
                      const float* gadd = nullptr, int ld_gadd = 0, int ggroup = 1, int gcol0 = 0) {
-    if (in_dtype != SGG_F32 && in_dtype != SGG_BF16) return SGG_ERR_DTYPE;
-    if (out_dtype != SGG_F32 && out_dtype != SGG_BF16) return SGG_ERR_DTYPE;
+    if (!sgg_is_dtype(in_dtype) || !sgg_is_dtype(out_dtype)) return SGG_ERR_DTYPE;
     if (M == 0 || N == 0) return SGG_OK;
-    const int esz = in_dtype == SGG_BF16 ? 2 : 4;
+    const int esz = sgg_elem_size(in_dtype);
     const int bke = ROWB / esz;
     if (!A || !W || !C || M < 0 || N < 0 || K <= 0 || K % bke) return SGG_ERR_ARG;
     if (!A2) K1 = K;
@@ -449,10 +448,10 @@ static int gemm_impl(const void* A, int lda, const void* A2, int lda2, int K1, c
     g.lda_b = (long)lda * esz; g.lda2_b = (long)lda2 * esz; g.ldw_b = (long)ldw * esz; g.ldw2_b = (long)ldw2 * esz;
     g.nt1 = K1 / bke; g.nt = K / bke;
     g.bias = bias; g.pscale = post_scale; g.pshift = post_shift;
-    g.C = (char*)C; g.ldc = ldc; g.M = M; g.N = N; g.act = act; g.out_bf16 = out_dtype == SGG_BF16;
+    g.C = (char*)C; g.ldc = ldc; g.M = M; g.N = N; g.act = act; g.out_dt = out_dtype;
     g.add_rows = add_rows; g.add_idx = add_idx; g.ld_add = ld_add;
     g.gadd = gadd; g.ld_gadd = ld_gadd; g.ggroup = ggroup; g.gcol0 = gcol0;
-    return dispatch<false>(g, in_dtype == SGG_BF16, (hipStream_t)stream);
+    return dispatch<false>(g, in_dtype, (hipStream_t)stream);
 }
 
 extern "C" int sgg_gemm(const void* A, int lda, const void* A2, int lda2, int K1, const void* W, int ldw, const void* W2,
@@ -515,10 +514,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 extern "C" int sgg_gemm_splitk(const void* A, int lda, const void* W, int ldw, const float* bias, const float* post_scale,
                                const float* post_shift, void* C, int M, int N, int K, int act, int in_dtype, int out_dtype,
                                int splits, float* workspace, void* stream) {
-    if (in_dtype != SGG_F32 && in_dtype != SGG_BF16) return SGG_ERR_DTYPE;
-    if (out_dtype != SGG_F32 && out_dtype != SGG_BF16) return SGG_ERR_DTYPE;
+    if (!sgg_is_dtype(in_dtype) || !sgg_is_dtype(out_dtype)) return SGG_ERR_DTYPE;
     if (M == 0 || N == 0) return SGG_OK;
-    const int esz = in_dtype == SGG_BF16 ? 2 : 4;
+    const int esz = sgg_elem_size(in_dtype);
     const int bke = ROWB / esz;
     if (!A || !W || !C || !workspace || M < 0 || N <= 0 || (N & 7) || K <= 0 || K % bke || splits < 1 || splits > K / bke) return SGG_ERR_ARG;
     if ((lda & 7) || (ldw & 7) || lda < K || ldw < K || (((uintptr_t)A | (uintptr_t)W) & 15)) return SGG_ERR_ARG;
@@ -527,28 +525,25 @@ extern "C" int sgg_gemm_splitk(const void* A, int lda, const void* W, int ldw, c
     g.A = (const char*)A; g.Wt = (const char*)W;
     g.lda_b = (long)lda * esz; g.ldw_b = (long)ldw * esz;
     g.nt = K / bke; g.nt1 = g.nt;
-    g.C = (char*)workspace; g.ldc = N; g.M = M; g.N = N; g.act = SGG_ACT_NONE; g.out_bf16 = 0;
+    g.C = (char*)workspace; g.ldc = N; g.M = M; g.N = N; g.act = SGG_ACT_NONE; g.out_dt = SGG_F32;
     g.splitk_stride = (long)M * N * 4;
     hipStream_t s = (hipStream_t)stream;
-    const bool bf16 = in_dtype == SGG_BF16;
-    const int rc = bf16 ? launch<true, 2, 2, false>(g, s, splits) : launch<false, 2, 2, false>(g, s, splits);
+    const int rc = in_dtype == SGG_BF16 ? launch<SGG_BF16, 2, 2, false>(g, s, splits)
+                   : in_dtype == SGG_F16 ? launch<SGG_F16, 2, 2, false>(g, s, splits) : launch<SGG_F32, 2, 2, false>(g, s, splits);
     if (rc != SGG_OK) return rc;
     const long MN = (long)M * N;
     const dim3 grid((unsigned)((MN / 8 + 255) / 256)), blk(256);
-    if (out_dtype == SGG_BF16)
-        hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, grid, blk, 0, s, workspace, splits, MN, N, bias, act, post_scale, post_shift, (bf16_t*)C);
-    else
-        hipLaunchKernelGGL(splitk_reduce_kernel<float>, grid, blk, 0, s, workspace, splits, MN, N, bias, act, post_scale, post_shift, (float*)C);
+    SGG_FOR_DTYPE(out_dtype, hipLaunchKernelGGL(splitk_reduce_kernel<T>, grid, blk, 0, s, workspace, splits, MN, N, bias, act, post_scale, post_shift, (T*)C));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
 
-// C[N, K] = A[Mred, N]^T . B[Mred, K]  (bf16 in, f32 or bf16 out): the weight-gradient contraction without transposed
+// C[N, K] = A[Mred, N]^T . B[Mred, K]  (16-bit in, f32 or 16-bit out): the weight-gradient contraction without transposed
 // copies of its operands.  Mred % 64 == 0, N % 128 == 0, K % 128 == 0, lda/ldb/ldc multiples of 8.  splits > 1: the
 // reduction rows are split over `splits` workgroups per tile, partial sums in workspace f32[splits, N, K], then one reduce.
 extern "C" int sgg_gemm_tn(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int Mred, int N, int K,
-                           int out_dtype, int splits, float* workspace, void* stream) {
-    if (out_dtype != SGG_F32 && out_dtype != SGG_BF16) return SGG_ERR_DTYPE;
+                           int in_dtype, int out_dtype, int splits, float* workspace, void* stream) {
+    if ((in_dtype != SGG_BF16 && in_dtype != SGG_F16) || !sgg_is_dtype(out_dtype)) return SGG_ERR_DTYPE;
     if (!A || !B || !C || Mred <= 0 || N <= 0 || K <= 0 || (Mred & 63) || (N & 127) || (K & 127) || lda < N || ldb < K ||
         ldc < K || ((lda | ldb | ldc) & 7) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) || splits < 1 ||
         splits > Mred / 64 || (splits > 1 && (!workspace || ldc != K)))
@@ -561,26 +556,25 @@ extern "C" int sgg_gemm_tn(const void* A, int lda, const void* B, int ldb, void*
     g.M = N; g.N = K; g.act = SGG_ACT_NONE;
     hipStream_t s = (hipStream_t)stream;
     constexpr int smem = 2 * 4 * 64 * ROWB;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_tile_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+    auto kern = in_dtype == SGG_BF16 ? mfma_tile_tn_kernel<SGG_BF16> : mfma_tile_tn_kernel<SGG_F16>;
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[in_dtype == SGG_F16]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return SGG_ERR_LAUNCH;
-        attr_done = true;
+        attr_done[in_dtype == SGG_F16] = true;
     }
     if (splits == 1) {
-        g.C = (char*)C; g.ldc = ldc; g.out_bf16 = out_dtype == SGG_BF16;
+        g.C = (char*)C; g.ldc = ldc; g.out_dt = out_dtype;
     } else {
-        g.C = (char*)workspace; g.ldc = K; g.out_bf16 = 0; g.splitk_stride = (long)N * K * 4;
+        g.C = (char*)workspace; g.ldc = K; g.out_dt = SGG_F32; g.splitk_stride = (long)N * K * 4;
     }
-    hipLaunchKernelGGL(mfma_tile_tn_kernel, dim3((N / 128) * (K / 128), splits), dim3(256), smem, s, g);
+    hipLaunchKernelGGL(kern, dim3((N / 128) * (K / 128), splits), dim3(256), smem, s, g);
     SGG_CHECK_LAUNCH();
     if (splits > 1) {
         const long MN = (long)N * K;
         const dim3 grid((unsigned)((MN / 8 + 255) / 256)), blk(256);
-        if (out_dtype == SGG_BF16)
-            hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, grid, blk, 0, s, workspace, splits, MN, K, (const float*)nullptr, SGG_ACT_NONE, (const float*)nullptr, (const float*)nullptr, (bf16_t*)C);
-        else
-            hipLaunchKernelGGL(splitk_reduce_kernel<float>, grid, blk, 0, s, workspace, splits, MN, K, (const float*)nullptr, SGG_ACT_NONE, (const float*)nullptr, (const float*)nullptr, (float*)C);
+        SGG_FOR_DTYPE(out_dtype, hipLaunchKernelGGL(splitk_reduce_kernel<T>, grid, blk, 0, s, workspace, splits, MN, K, (const float*)nullptr, SGG_ACT_NONE,
+                                                    (const float*)nullptr, (const float*)nullptr, (T*)C));
         SGG_CHECK_LAUNCH();
     }
     return SGG_OK;
@@ -588,8 +582,8 @@ extern "C" int sgg_gemm_tn(const void* A, int lda, const void* B, int ldb, void*
 
 extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H,
                                 int W, int Cin, int Cout, int pool, int dtype, void* stream) {
-    if (dtype != SGG_F32 && dtype != SGG_BF16) return SGG_ERR_DTYPE;
-    const int esz = dtype == SGG_BF16 ? 2 : 4;
+    if (!sgg_is_dtype(dtype)) return SGG_ERR_DTYPE;
+    const int esz = sgg_elem_size(dtype);
     const int bke = ROWB / esz;
     if (!in || !w || !out || B <= 0 || H <= 0 || W <= 0 || Cin % bke || Cout % 64 || (out_pad != 0 && out_pad != 1))
         return SGG_ERR_ARG;
@@ -605,7 +599,7 @@ extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias
         const bool want = force ? (force[0] == 's' || (force[0] == 'o' && H >= 64 && W >= 64)) : (H >= 64 && W >= 64 && Cout < 256);   // 'o': round 1's rule
         if (pool && ((H | W) & 1)) return SGG_ERR_ARG;
         if (want || pool) {
-            const int rc = sgg_launch_conv_spatial(in, w, bias, out, out_pad, B, H, W, Cin, Cout, dtype == SGG_BF16, pool, (hipStream_t)stream);
+            const int rc = sgg_launch_conv_spatial(in, w, bias, out, out_pad, B, H, W, Cin, Cout, dtype, pool, (hipStream_t)stream);
             if (rc <= 0) return rc;
         }
         if (pool) return SGG_ERR_ARG;    // the fused pool lives in the spatial kernel only
@@ -615,7 +609,7 @@ extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias
     g.ldw_b = (long)9 * Cin * esz;
     g.nt = 9 * Cin / bke; g.nt1 = g.nt;
     g.bias = bias; g.C = (char*)out; g.M = B * H * W; g.N = Cout; g.act = SGG_ACT_RELU;
-    g.out_bf16 = dtype == SGG_BF16;
+    g.out_dt = dtype;
     g.H = H; g.W = W; g.Cin = Cin; g.out_pad = out_pad;
-    return dispatch<true>(g, dtype == SGG_BF16, (hipStream_t)stream);
+    return dispatch<true>(g, dtype, (hipStream_t)stream);
 }

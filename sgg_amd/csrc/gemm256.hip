@@ -49,10 +49,10 @@ __device__ __forceinline__ long tile_koff(const GemmArgs& g, bool loads_a, int k
     return (long)(seg2 ? kt - g.nt1 : kt) * ROW;
 }
 
-template <bool BF16, bool CONV>
+template <int DT, bool CONV>
 __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int ESZ = BF16 ? 2 : 4;
+    constexpr int ESZ = DT == SGG_F32 ? 4 : 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, q = wave & 3;  // grp: which half of M; q: which 64-wide N slab
@@ -149,9 +149,8 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
     // MFMA (uniform base in SGPRs, segment choice, M0): no branch, no vector ALU work and no M0 write sits between MFMAs.
 #define SGG_MFMA_PAIR(s, mi)                                                                                              \
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                                                    \
-        if constexpr (BF16) {                                                                                             \
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bf[ni][s]),                \
-                                                                  __builtin_bit_cast(bf16x8_t, af[mi][s]), acc[mi][ni], 0, 0, 0); \
+        if constexpr (DT != SGG_F32) {                                                                                    \
+            acc[mi][ni] = mfma_32x32x16<DT>(bf[ni][s], af[mi][s], acc[mi][ni]);                                           \
         } else {                                                                                                          \
             _Pragma("unroll") for (int c = 0; c < 4; ++c) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(             \
                 __uint_as_float(bf[ni][s][c]), __uint_as_float(af[mi][s][c]), acc[mi][ni], 0, 0, 0);                      \
@@ -298,10 +297,10 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
     }
 }
 
-template <bool BF16, bool CONV>
+template <int DT, bool CONV>
 int launch256(const GemmArgs& g, hipStream_t s) {
     const int tilesM = (g.M - g.m_base + 255) / 256, tilesN = (g.N + 255) / 256;
-    auto k = mfma_pingpong_kernel<BF16, CONV>;
+    auto k = mfma_pingpong_kernel<DT, CONV>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
@@ -316,7 +315,8 @@ int launch256(const GemmArgs& g, hipStream_t s) {
 }  // namespace
 
 // g.nt / g.nt1 are in units of 64-byte K-tiles here
-int sgg_launch_pingpong(const GemmArgs& g, bool bf16, bool conv, hipStream_t s) {
-    if (bf16) return conv ? launch256<true, true>(g, s) : launch256<true, false>(g, s);
-    return conv ? launch256<false, true>(g, s) : launch256<false, false>(g, s);
+int sgg_launch_pingpong(const GemmArgs& g, int dt, bool conv, hipStream_t s) {
+    if (dt == SGG_BF16) return conv ? launch256<SGG_BF16, true>(g, s) : launch256<SGG_BF16, false>(g, s);
+    if (dt == SGG_F16) return conv ? launch256<SGG_F16, true>(g, s) : launch256<SGG_F16, false>(g, s);
+    return conv ? launch256<SGG_F32, true>(g, s) : launch256<SGG_F32, false>(g, s);
 }

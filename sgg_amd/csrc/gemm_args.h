@@ -4,8 +4,6 @@
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-
 struct GemmArgs {
     const char* A;
     const char* A2;
@@ -18,7 +16,7 @@ struct GemmArgs {
     const float* pshift;
     char* C;
     long ldc;  // elements
-    int M, N, act, out_bf16;
+    int M, N, act, out_dt;      // out_dt: element type of C (SGG_F32 / SGG_BF16 / SGG_F16)
     // optional gathered-row addend of the pre-activation: += add_rows[(add_idx ? add_idx[m] : m) * ld_add + n]  (f32)
     const float* add_rows;
     const int* add_idx;
@@ -122,7 +120,8 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& g, const ChanVec
     if (g.gadd) {
         const float* r = g.gadd + (long)m * g.ld_gadd;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] += r[(n + k + g.gcol0) / g.ggroup];     // (columns past N: computed, never stored)
+        for (int k = 0; k < 8; ++k)
+            if (k < nv) v[k] += r[(n + k + g.gcol0) / g.ggroup];                   // (never past column N - 1: the last group may end there)
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -133,11 +132,13 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& g, const ChanVec
         v[k] = t;
     }
     if (vec_ok && nv == 8) {
-        if (g.out_bf16) store8(reinterpret_cast<bf16_t*>(g.C) + off, v);
+        if (g.out_dt == SGG_BF16) store8(reinterpret_cast<bf16_t*>(g.C) + off, v);
+        else if (g.out_dt == SGG_F16) store8(reinterpret_cast<f16_t*>(g.C) + off, v);
         else store8(reinterpret_cast<float*>(g.C) + off, v);
     } else {
         for (int k = 0; k < nv; ++k) {
-            if (g.out_bf16) reinterpret_cast<bf16_t*>(g.C)[off + k] = f32_to_bf16(v[k]);
+            if (g.out_dt == SGG_BF16) reinterpret_cast<bf16_t*>(g.C)[off + k] = f32_to_bf16(v[k]);
+            else if (g.out_dt == SGG_F16) reinterpret_cast<f16_t*>(g.C)[off + k] = (f16_t)v[k];
             else reinterpret_cast<float*>(g.C)[off + k] = v[k];
         }
     }

@@ -958,8 +958,10 @@ extern "C" int sgg_graph_ptr(const int64_t* im_inds, int N, int B, const int* ou
 }
 
 // (graph, 64-channel slice) units from which sgg_imp_ctx_fwd hands 16-bit graphs of <= 32 nodes to the persistent matrix-core kernel
-// (256 workgroups, one per CU: four units each)
-constexpr int IMP_MFMA_MIN_UNITS = 1024;
+// (256 workgroups, one per CU: eight units each).  Measured (bf16, complete 32-node graphs, H = 512; sliced / matrix-core, us):
+// 8 images 7.1 / 13.0, 32: 12.7 / 13.8, 128: 39.0 / 41.1, 512: 172 / 152 -- the short-lived kernel's 64-byte requests stream rows
+// that sit in the Infinity Cache faster, the persistent kernel's 128-byte DMA pieces win once the rows come from HBM.
+constexpr int IMP_MFMA_MIN_UNITS = 2048;
 extern "C" int sgg_imp_ctx_mfma_min_units(void) { return IMP_MFMA_MIN_UNITS; }
 
 // largest per-graph edge count the sliced kernel takes at this row width (0: rows too narrow for any slicing)

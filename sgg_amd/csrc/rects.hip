@@ -197,14 +197,10 @@ extern "C" int sgg_union_rect_patches(const float* rois, const int64_t* pairs, i
         return SGG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
 #define SGG_PATCHES(T, RAW) hipLaunchKernelGGL((rect_patches_kernel<T, RAW>), dim3(E), dim3(256), 0, s, rois, pairs, P, (T*)out, Kpad, im_wh)
-    if (dtype == SGG_BF16) {
-        if (raster) SGG_PATCHES(bf16_t, true);
-        else SGG_PATCHES(bf16_t, false);
-    } else if (dtype == SGG_F32) {
-        if (raster) SGG_PATCHES(float, true);
-        else SGG_PATCHES(float, false);
+    if (raster) {
+        SGG_FOR_DTYPE(dtype, SGG_PATCHES(T, true));
     } else {
-        return SGG_ERR_DTYPE;
+        SGG_FOR_DTYPE(dtype, SGG_PATCHES(T, false));
     }
 #undef SGG_PATCHES
     SGG_CHECK_LAUNCH();
@@ -216,12 +212,7 @@ extern "C" int sgg_max4_rows(const void* in, void* out, int E, int C, int dtype,
     if (!in || !out || E < 0 || C <= 0 || (C & 7)) return SGG_ERR_ARG;
     const long total = (long)E * (C / 8);
     const int grid = (int)((total + 255) / 256);
-    if (dtype == SGG_BF16)
-        hipLaunchKernelGGL(max4_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, total, C);
-    else if (dtype == SGG_F32)
-        hipLaunchKernelGGL(max4_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)in, (float*)out, total, C);
-    else
-        return SGG_ERR_DTYPE;
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(max4_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)in, (T*)out, total, C));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -231,12 +222,7 @@ extern "C" int sgg_bcast_add(void* x, const float* add_rc, int R, int PP, int C,
     if (!x || !add_rc || R < 0 || PP <= 0 || C <= 0 || (((long)C * PP) & 7)) return SGG_ERR_ARG;
     const long total = (long)R * ((long)C * PP / 8);
     const int grid = (int)((total + 255) / 256);
-    if (dtype == SGG_BF16)
-        hipLaunchKernelGGL(bcast_add_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, add_rc, total, PP, C);
-    else if (dtype == SGG_F32)
-        hipLaunchKernelGGL(bcast_add_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (float*)x, add_rc, total, PP, C);
-    else
-        return SGG_ERR_DTYPE;
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(bcast_add_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (T*)x, add_rc, total, PP, C));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

@@ -5,11 +5,6 @@
 #include "common.h"
 #include "../../include/sgg_hip.h"
 
-#define SGG_DISPATCH_T(dtype, CALL_BF16, CALL_F32) \
-    if ((dtype) == SGG_BF16) { CALL_BF16; }        \
-    else if ((dtype) == SGG_F32) { CALL_F32; }     \
-    else return SGG_ERR_DTYPE;
-
 namespace {
 
 // Patch matrix of a k x k / stride s / padding p convolution: row = output pixel (b, yo, xo), columns (ky, kx, c), zero-filled to
@@ -133,19 +128,13 @@ extern "C" int sgg_im2col(const void* src, int B, int H, int W, int Ca, int C, i
     const bool vec = src_dtype == dst_dtype && C % 8 == 0 && Ca % 8 == 0 && Kp % 8 == 0;
     if (vec) {
         const long total = (long)B * Ho * Wo * (Kp / 8);
-        SGG_DISPATCH_T(src_dtype,
-            hipLaunchKernelGGL(im2col8_kernel<bf16_t>, grid_for(total), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, H, W, Ca, C, src_pad, k, stride, pad, Ho, Wo, Kp, total),
-            hipLaunchKernelGGL(im2col8_kernel<float>, grid_for(total), dim3(256), 0, s, (const float*)src, (float*)dst, H, W, Ca, C, src_pad, k, stride, pad, Ho, Wo, Kp, total));
+        SGG_FOR_DTYPE(src_dtype, hipLaunchKernelGGL(im2col8_kernel<T>, grid_for(total), dim3(256), 0, s, (const T*)src, (T*)dst, H, W, Ca, C, src_pad, k, stride,
+                                                    pad, Ho, Wo, Kp, total));
     } else {
         const long total = (long)B * Ho * Wo * Kp;
-        if (src_dtype == SGG_F32 && dst_dtype == SGG_BF16)
-            hipLaunchKernelGGL((im2col_kernel<float, bf16_t>), grid_for(total), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, H, W, Ca, C, src_pad, k, stride, pad, Ho, Wo, Kp, total);
-        else if (src_dtype == SGG_F32 && dst_dtype == SGG_F32)
-            hipLaunchKernelGGL((im2col_kernel<float, float>), grid_for(total), dim3(256), 0, s, (const float*)src, (float*)dst, H, W, Ca, C, src_pad, k, stride, pad, Ho, Wo, Kp, total);
-        else if (src_dtype == SGG_BF16 && dst_dtype == SGG_BF16)
-            hipLaunchKernelGGL((im2col_kernel<bf16_t, bf16_t>), grid_for(total), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, H, W, Ca, C, src_pad, k, stride, pad, Ho, Wo, Kp, total);
-        else
-            return SGG_ERR_DTYPE;
+        if (src_dtype != SGG_F32 && src_dtype != dst_dtype) return SGG_ERR_DTYPE;      // f32 -> any, or like -> like
+        SGG_FOR_DTYPE2(src_dtype, dst_dtype, hipLaunchKernelGGL((im2col_kernel<TA, TB>), grid_for(total), dim3(256), 0, s, (const TA*)src, (TB*)dst, H, W, Ca, C,
+                                                                src_pad, k, stride, pad, Ho, Wo, Kp, total));
     }
     SGG_CHECK_LAUNCH();
     return SGG_OK;
@@ -157,9 +146,7 @@ extern "C" int sgg_maxpool3x3s2(const void* in, void* out, int B, int H, int W, 
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long total = (long)B * Ho * Wo * (C / 8);
     hipStream_t s = (hipStream_t)stream;
-    SGG_DISPATCH_T(dtype,
-        hipLaunchKernelGGL(maxpool3s2_kernel<bf16_t>, grid_for(total), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, H, W, C, Ho, Wo, total),
-        hipLaunchKernelGGL(maxpool3s2_kernel<float>, grid_for(total), dim3(256), 0, s, (const float*)in, (float*)out, H, W, C, Ho, Wo, total));
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(maxpool3s2_kernel<T>, grid_for(total), dim3(256), 0, s, (const T*)in, (T*)out, H, W, C, Ho, Wo, total));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -172,9 +159,8 @@ extern "C" int sgg_plane_copy(const void* src, int Hs, int Ws, int src_pad, void
     if ((Hd - 1) * stride >= Hs || (Wd - 1) * stride >= Ws) return SGG_ERR_ARG;
     const long total = (long)B * Hd * Wd * (C / 8);
     hipStream_t s = (hipStream_t)stream;
-    SGG_DISPATCH_T(dtype,
-        hipLaunchKernelGGL(plane_copy_kernel<bf16_t>, grid_for(total), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, Hs, Ws, src_pad, Hd, Wd, dst_pad, C, stride, total),
-        hipLaunchKernelGGL(plane_copy_kernel<float>, grid_for(total), dim3(256), 0, s, (const float*)src, (float*)dst, Hs, Ws, src_pad, Hd, Wd, dst_pad, C, stride, total));
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(plane_copy_kernel<T>, grid_for(total), dim3(256), 0, s, (const T*)src, (T*)dst, Hs, Ws, src_pad, Hd, Wd, dst_pad, C,
+                                            stride, total));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -183,9 +169,7 @@ extern "C" int sgg_add_relu(void* y, const void* x, int64_t n, int dtype, void* 
     if (n == 0) return SGG_OK;
     if (!y || !x || n < 0 || (n & 7)) return SGG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    SGG_DISPATCH_T(dtype,
-        hipLaunchKernelGGL(add_relu_kernel<bf16_t>, grid_for(n / 8), dim3(256), 0, s, (bf16_t*)y, (const bf16_t*)x, (long)(n / 8)),
-        hipLaunchKernelGGL(add_relu_kernel<float>, grid_for(n / 8), dim3(256), 0, s, (float*)y, (const float*)x, (long)(n / 8)));
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(add_relu_kernel<T>, grid_for(n / 8), dim3(256), 0, s, (T*)y, (const T*)x, (long)(n / 8)));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

@@ -160,24 +160,17 @@ int pow2ceil(int x) {
 extern "C" int sgg_eval_tail(const void* obj_dists, int N, int C, const void* rel_dists, int E, int P,
                              const int64_t* rel_inds, const int64_t* gt_classes, float* obj_scores, int64_t* obj_preds,
                              int64_t* rels, float* pred_scores, void* work, int dtype, void* stream) {
-    if (dtype != SGG_F32 && dtype != SGG_BF16) return SGG_ERR_DTYPE;
+    if (!sgg_is_dtype(dtype)) return SGG_ERR_DTYPE;
     if (!obj_dists || !obj_scores || !obj_preds || N <= 0 || C < 2 || E < 0 || P < 2) return SGG_ERR_ARG;
     if (E > 0 && (!rel_dists || !rel_inds || !rels || !pred_scores || !work)) return SGG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const bool bf = dtype == SGG_BF16;
-    if (bf)
-        hipLaunchKernelGGL(obj_tail_kernel<bf16_t>, dim3((N + 3) / 4), dim3(256), 0, s, (const bf16_t*)obj_dists, N, C, gt_classes, obj_scores, obj_preds);
-    else
-        hipLaunchKernelGGL(obj_tail_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, s, (const float*)obj_dists, N, C, gt_classes, obj_scores, obj_preds);
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(obj_tail_kernel<T>, dim3((N + 3) / 4), dim3(256), 0, s, (const T*)obj_dists, N, C, gt_classes, obj_scores, obj_preds));
     if (E > 0) {
         const int n2 = pow2ceil(E);
         float* keys = (float*)work;
         int* idx = (int*)work + n2;
         float* probs = (float*)work + 2 * (size_t)n2;
-        if (bf)
-            hipLaunchKernelGGL(rel_tail_kernel<bf16_t>, dim3((n2 + 3) / 4), dim3(256), 0, s, (const bf16_t*)rel_dists, E, P, rel_inds, obj_scores, probs, keys, idx, n2);
-        else
-            hipLaunchKernelGGL(rel_tail_kernel<float>, dim3((n2 + 3) / 4), dim3(256), 0, s, (const float*)rel_dists, E, P, rel_inds, obj_scores, probs, keys, idx, n2);
+        SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(rel_tail_kernel<T>, dim3((n2 + 3) / 4), dim3(256), 0, s, (const T*)rel_dists, E, P, rel_inds, obj_scores, probs, keys, idx, n2));
         if (E <= 16384) {
             if (hipMemsetAsync(idx, 0, sizeof(int) * (size_t)E, s) != hipSuccess) return SGG_ERR_LAUNCH;
             const int split = E >= 2048 ? 8 : 1;

@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const TG* __restrict__ dy,
     store8(dx + i * 8, g);
 }
 
-// column sums of x[M,N] (bias gradients): grid (N/64, MSPLIT); each block reduces a row range, atomics merge
+// column sums of x[M,N] (bias gradients): grid (N/64, MSPLIT); each block reduces a row range into ITS row of out[MSPLIT][N]
+// (sgg_reduce_parts adds the rows in a fixed order: no float atomics, bit-reproducible)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int M, int N, int ld, float* __restrict__ out,
                                                      int rows_per_block) {
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
         for (int r = r0 + w; r < r1; r += 4) s += Elem<T>::ld(x + (long)r * ld + c);
     red[w][threadIdx.x & 63] = s;
     __syncthreads();
-    if (w == 0 && c < N) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (w == 0 && c < N) out[(long)blockIdx.y * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 // column sums with 16-byte loads: 8 lanes x 8 columns per block column, 32 row lanes (N % 8 == 0, ld % 8 == 0, 16-byte base)
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void colsum8_kernel(const T* __restrict__ x, i
         float a = 0.f;
 #pragma unroll 8
         for (int k = 0; k < 32; ++k) a += red[k][threadIdx.x];
-        atomicAdd(&out[blockIdx.x * 64 + threadIdx.x], a);
+        out[(long)blockIdx.y * N + blockIdx.x * 64 + threadIdx.x] = a;
     }
 }
 
@@ -112,8 +113,8 @@ __global__ __launch_bounds__(256) void colsum2_kernel(const T* __restrict__ x, c
     __syncthreads();
     if (w == 0 && c < N) {
         const int t = threadIdx.x;
-        atomicAdd(&out[c], red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]);
-        atomicAdd(&out[N + c], red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]);
+        out[(long)blockIdx.y * 2 * N + c] = red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t];
+        out[(long)blockIdx.y * 2 * N + N + c] = red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t];
     }
 }
 
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
             float a = 0.f;
 #pragma unroll 8
             for (int k = 0; k < 32; ++k) a += red[which][k][cc];
-            atomicAdd(&out[which * C + blockIdx.x * 64 + cc], a);
+            out[(long)blockIdx.y * 2 * C + which * C + blockIdx.x * 64 + cc] = a;
         }
     }
 }
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             float a = 0.f;
 #pragma unroll 8
             for (int k = 0; k < 32; ++k) a += red[which][k][cc];
-            atomicAdd(&sums[which * C + blockIdx.x * 64 + cc], a);
+            sums[(long)blockIdx.y * 2 * C + which * C + blockIdx.x * 64 + cc] = a;
         }
     }
 }
@@ -515,10 +516,10 @@ __global__ __launch_bounds__(64) void node_gates_bwd_kernel(const float* __restr
 }
 
 // small dense reduction  out[k][h] += sum_r a[r][k] * x[r][h]  for k < 4 (gate-weight gradients):
-// grid (H/64, RSPLIT); a is f32 [R,4], x is T [R,H]
+// grid (H/64, RSPLIT); a is f32 [R,4], x is T [R,H]; every row block writes its [4][H] partial, rank4_finalize_kernel adds them
 template <typename T>
 __global__ __launch_bounds__(256) void rank4_reduce_kernel(const float* __restrict__ a, const T* __restrict__ x, int R, int H,
-                                                           float* __restrict__ out, int out_ld, int rows_per_block) {
+                                                           float* __restrict__ out, int rows_per_block) {
     // 8 lanes x 8 channels (16-byte loads when H % 8 == 0) cover the block's 64 channels, 32 row lanes walk the rows
     __shared__ float red[32][4][65];
     const int cl = (threadIdx.x & 7) * 8, rl = threadIdx.x >> 3;
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(256) void rank4_reduce_kernel(const float* __restri
         float t = 0.f;
 #pragma unroll 8
         for (int q = 0; q < 32; ++q) t += red[q][k][cc];
-        atomicAdd(&out[(long)k * out_ld + blockIdx.x * 64 + cc], t);
+        out[((long)blockIdx.y * 4 + k) * H + blockIdx.x * 64 + cc] = t;       // parts [split][4][H]
     }
 }
 
@@ -587,20 +588,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
 }
 
-template <typename T, bool MAX4>
-void bn_bwd_launch(const void* dy, const unsigned char* arg, const void* x, const float* mean, const float* invstd,
-                   const float* gamma, void* dx, float* sums, int rows, int C, int rpb, dim3 g1, dim3 g2, float inv,
-                   int phase, const float* count_dev, hipStream_t s) {
-    if (phase != 2)
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MAX4>), g1, dim3(256), 0, s, (const T*)dy, arg, (const T*)x, mean, invstd, sums, rows, C, rpb);
-    if (phase != 1)
-        hipLaunchKernelGGL((bn_bwd_kernel<T, MAX4>), g2, dim3(256), 0, s, (const T*)dy, arg, (const T*)x, mean, invstd, gamma, sums, (T*)dx, (long)rows, C, inv, count_dev);
-}
-
 // ---- optimiser step (main.py:119-120: grad_clip then SGD with momentum, lib/pytorch_misc.py:144,625-656)
-// sum of squares of g into *acc (one atomic per block); 4 independent 8-element pieces in flight per thread
+// sum of squares of g: one partial per block (part[blockIdx.x]; reduce_scalar_kernel adds them in a fixed order); 4 independent
+// 8-element pieces in flight per thread
 template <typename T>
-__global__ __launch_bounds__(256) void sqnorm_kernel(const T* __restrict__ g, long n, float* __restrict__ acc) {
+__global__ __launch_bounds__(256) void sqnorm_kernel(const T* __restrict__ g, long n, float* __restrict__ part) {
     __shared__ float red[4];
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     const long stride = (long)gridDim.x * 256 * 8;
@@ -635,7 +627,7 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const T* __restrict__ g, lo
     float s = wave_sum((s0 + s1) + (s2 + s3));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // torch.optim.SGD(momentum, weight_decay, dampening 0) with the global-norm clip folded in:
@@ -647,6 +639,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const T
                                                   const float* __restrict__ norm_sq, float max_norm, float grad_scale) {
     float coef = grad_scale;
     if (norm_sq) {
+        if (!(*norm_sq < 3.0e38f)) return;      // non-finite gradients (an overflowed scaled gradient of the f16 mode, a NaN): skip the step
         const float c = max_norm / (sqrtf(*norm_sq) * grad_scale + 1e-6f);
         if (c < 1.f) coef *= c;
     }
@@ -668,7 +661,7 @@ struct MultiTab {
     const void* g[MT_MAX];
     float* p[MT_MAX];
     float* buf[MT_MAX];
-    bf16_t* shadow[MT_MAX];         // optional compute-dtype copy of the updated parameter (the next forward's operand)
+    void* shadow[MT_MAX];           // optional 16-bit copy of the updated parameter (the next forward's operand), type TS of the kernel
     long n[MT_MAX];
     int chunk0[MT_MAX + 1];         // prefix sum of ceil(n / MT_CHUNK)
     float lr[MT_MAX];
@@ -688,13 +681,13 @@ __device__ __forceinline__ void mt_load4(const TG* g, float (&v)[4]) {
         v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
     } else {
         const uint2 q = *reinterpret_cast<const uint2*>(g);
-        v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u);
-        v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
+        v[0] = H16<TG>::lo(q.x); v[1] = H16<TG>::hi(q.x);
+        v[2] = H16<TG>::lo(q.y); v[3] = H16<TG>::hi(q.y);
     }
 }
 
 template <typename TG>
-__global__ __launch_bounds__(256) void sqnorm_multi_kernel(const MultiTab tab, float* __restrict__ acc) {
+__global__ __launch_bounds__(256) void sqnorm_multi_kernel(const MultiTab tab, float* __restrict__ part) {
     __shared__ float red[4];
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     const int total = tab.chunk0[tab.count];
@@ -721,14 +714,15 @@ __global__ __launch_bounds__(256) void sqnorm_multi_kernel(const MultiTab tab, f
     const float w = wave_sum((s[0] + s[1]) + (s[2] + s[3]));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-template <typename TG>
+template <typename TG, typename TS>
 __global__ __launch_bounds__(256) void sgd_multi_kernel(const MultiTab tab, float wd, float mom, int first,
                                                         const float* __restrict__ norm_sq, float max_norm, float grad_scale) {
     float coef = grad_scale;
     if (norm_sq) {
+        if (!(*norm_sq < 3.0e38f)) return;      // non-finite gradients (an overflowed scaled gradient of the f16 mode, a NaN): skip the step
         const float c = max_norm / (sqrtf(*norm_sq) * grad_scale + 1e-6f);
         if (c < 1.f) coef *= c;
     }
@@ -739,7 +733,7 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const MultiTab tab, floa
         const TG* g = reinterpret_cast<const TG*>(tab.g[t]);
         float* p = tab.p[t];
         float* buf = tab.buf[t];
-        bf16_t* sh = tab.shadow[t];
+        TS* sh = reinterpret_cast<TS*>(tab.shadow[t]);
         const float lr = tab.lr[t];
         const long base = (long)(c - tab.chunk0[t]) * MT_CHUNK;
         float gv[4][4], pv[4][4], bv[4][4];
@@ -769,8 +763,8 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const MultiTab tab, floa
                 *reinterpret_cast<float4*>(p + i) = make_float4(np[0], np[1], np[2], np[3]);
                 if (sh) {
                     uint2 o;
-                    o.x = pack_bf16x2(np[0], np[1]);
-                    o.y = pack_bf16x2(np[2], np[3]);
+                    o.x = H16<TS>::pack(np[0], np[1]);
+                    o.y = H16<TS>::pack(np[2], np[3]);
                     *reinterpret_cast<uint2*>(sh + i) = o;
                 }
             } else {
@@ -780,7 +774,7 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const MultiTab tab, floa
                     const float b = first ? gg : mom * buf[k] + gg;
                     buf[k] = b;
                     p[k] = pk - lr * b;
-                    if (sh) sh[k] = f32_to_bf16(p[k]);
+                    if (sh) Elem<TS>::st(sh + k, p[k]);
                 }
             }
         }
@@ -797,24 +791,47 @@ inline int split_rows(int M, int& rows_per_block) {
 
 }  // namespace
 
-#define DISPATCH2(dtype, BF, F32) \
-    if ((dtype) == SGG_BF16) { BF; } else if ((dtype) == SGG_F32) { F32; } else return SGG_ERR_DTYPE;
-
 namespace {
 // ------------------------------------------------------------------------------------------------
 // Cross-entropy of a logit matrix, loss and gradient in ONE launch (lib/losses.py:41-43,74 -- the 'baseline' form: summed CE of the
 // rows divided by a batch-level normaliser).  One wave per row: max, sum of exponentials, -log p[label]; the gradient
 // (softmax - onehot) * weight / norm is written in the dtype the backward's GEMMs take, zero-padded to `ldg` columns (the heads are
 // 151 / 51 wide, the GEMMs want multiples of 64: no separate pad + cast passes).  `norm` lives on the device (a data-parallel step
-// all-reduces it), the loss is accumulated with one float atomic per row block.
+// all-reduces it); every row block writes its loss partial (reduce_scalar_kernel adds them in a fixed order: no float atomics).
+// A label outside [0, C) (e.g. torch's ignore_index) contributes no loss and a zero gradient row, and raises bit 0 of *flag.
 // torch's own path for the two heads is ~25 tiny launches per step (log_softmax, nll, their backwards, casts, pads).
 // ------------------------------------------------------------------------------------------------
+// acc (+)= sum of part[0 .. n): one workgroup, thread t adds part[t], part[t + 256], ... in order, then a fixed LDS tree
+__global__ __launch_bounds__(256) void reduce_scalar_kernel(const float* __restrict__ part, int n, float* __restrict__ acc, int accumulate) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) acc[0] = accumulate ? acc[0] + red[0] : red[0];
+}
+
+// out[k][c] += sum_p parts[p][k][c]  (k < 4, c < H; out row stride out_ld), p ascending
+__global__ __launch_bounds__(256) void rank4_finalize_kernel(const float* __restrict__ parts, int nparts, int H, float* __restrict__ out,
+                                                             int out_ld) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 4 * H) return;
+    const int k = i / H, c = i - k * H;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += parts[(long)p * 4 * H + i];
+    out[(long)k * out_ld + c] += s;
+}
+
 template <typename TG>
 __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels,
-                                                         int label_stride, int M, int C, const float* __restrict__ norm, float weight,
-                                                         float* __restrict__ loss, TG* __restrict__ grad, int ldg) {
+                                                         int label_stride, int M, int C, const float* __restrict__ norm, float weight, float grad_scale,
+                                                         float* __restrict__ part, TG* __restrict__ grad, int ldg, int* __restrict__ flag) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    __shared__ float part[4];
+    __shared__ float ws4[4];
     float mine = 0.f;
     if (row < M) {
         const float* x = logits + (long)row * ld;
@@ -824,36 +841,42 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict
         float se = 0.f;
         for (int c = lane; c < C; c += 64) se += __expf(x[c] - mx);
         se = wave_sum(se);
-        const int lab = (int)labels[(long)row * label_stride];
-        const float scale = weight / norm[0];
+        const long lab_raw = labels[(long)row * label_stride];
+        const bool ok = lab_raw >= 0 && lab_raw < C;
+        const int lab = ok ? (int)lab_raw : 0;
+        const float scale = ok ? weight / norm[0] : 0.f;
         const float lse = mx + __logf(se);
-        if (lane == 0) mine = (lse - x[lab]) * scale;
+        if (lane == 0) mine = ok ? (lse - x[lab]) * scale : 0.f;
+        if (!ok && lane == 0 && flag) atomicOr(flag, 1);
         TG* g = grad + (long)row * ldg;
         for (int c = lane; c < ldg; c += 64) {
             float v = 0.f;
-            if (c < C) v = (__expf(x[c] - lse) - (c == lab ? 1.f : 0.f)) * scale;
+            if (c < C) v = (__expf(x[c] - lse) - (c == lab ? 1.f : 0.f)) * scale * grad_scale;
             Elem<TG>::st(g + c, v);
         }
     }
-    if (lane == 0) part[threadIdx.x >> 6] = mine;
+    if (lane == 0) ws4[threadIdx.x >> 6] = mine;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) part[blockIdx.x] = (ws4[0] + ws4[1]) + (ws4[2] + ws4[3]);
 }
 }  // namespace
 
-// loss[0] += weight / norm[0] * sum_rows CE(logits[row], labels[row * label_stride]);  grad[M, ldg] = d loss / d logits (zero-padded)
+// Workspaces: every reduction below is two-stage -- row blocks write partial rows into `ws`, a second launch adds them in a fixed order
+// (no float atomics: bit-reproducible).  ws sizes are stated per entry (split_rows caps the row blocks of the column reductions at 64).
+
+// loss[0] += weight / norm[0] * sum_rows CE(logits[row], labels[row * label_stride]);  grad[M, ldg] = grad_scale * d loss / d logits
+// (zero-padded).  ws: f32[(M + 3) / 4].  flag (optional): bit 0 raised when a label lies outside [0, C) (that row: no loss, zero gradient).
 extern "C" int sgg_ce_fwd_bwd(const float* logits, int ld, const int64_t* labels, int label_stride, int M, int C, const float* norm,
-                              float weight, float* loss, void* grad, int ldg, int g_dtype, void* stream) {
+                              float weight, float grad_scale, float* loss, void* grad, int ldg, float* ws, int* flag, int g_dtype,
+                              void* stream) {
     if (M == 0) return SGG_OK;
-    if (!logits || !labels || !norm || !loss || !grad || M < 0 || C <= 0 || ld < C || ldg < C || label_stride <= 0) return SGG_ERR_ARG;
+    if (!logits || !labels || !norm || !loss || !grad || !ws || M < 0 || C <= 0 || ld < C || ldg < C || label_stride <= 0) return SGG_ERR_ARG;
     const dim3 grid((M + 3) / 4), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    if (g_dtype == SGG_BF16)
-        hipLaunchKernelGGL(ce_fwd_bwd_kernel<bf16_t>, grid, blk, 0, s, logits, ld, labels, label_stride, M, C, norm, weight, loss, (bf16_t*)grad, ldg);
-    else if (g_dtype == SGG_F32)
-        hipLaunchKernelGGL(ce_fwd_bwd_kernel<float>, grid, blk, 0, s, logits, ld, labels, label_stride, M, C, norm, weight, loss, (float*)grad, ldg);
-    else
-        return SGG_ERR_DTYPE;
+    SGG_FOR_DTYPE(g_dtype, hipLaunchKernelGGL(ce_fwd_bwd_kernel<T>, grid, blk, 0, s, logits, ld, labels, label_stride, M, C, norm, weight, grad_scale,
+                                              ws, (T*)grad, ldg, flag));
+    SGG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(256), 0, s, ws, (int)grid.x, loss, 1);
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -864,8 +887,7 @@ extern "C" int sgg_dropout_fwd(void* x, int64_t n, float p, uint64_t seed, int d
     const long n8 = n / 8;
     const dim3 grid((unsigned)((n8 + 255) / 256)), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH2(dtype, hipLaunchKernelGGL(dropout_kernel<bf16_t>, grid, blk, 0, s, (bf16_t*)x, n8, p, (unsigned long long)seed),
-              hipLaunchKernelGGL(dropout_kernel<float>, grid, blk, 0, s, (float*)x, n8, p, (unsigned long long)seed));
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(dropout_kernel<T>, grid, blk, 0, s, (T*)x, n8, p, (unsigned long long)seed));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -877,59 +899,45 @@ extern "C" int sgg_act_bwd(const void* dy, const void* y, void* dx, int64_t n, f
     const long n8 = n / 8;
     const dim3 grid((unsigned)((n8 + 255) / 256)), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    if (g_dtype == SGG_BF16 && y_dtype == SGG_BF16)
-        hipLaunchKernelGGL((act_bwd_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, n8, scale);
-    else if (g_dtype == SGG_F32 && y_dtype == SGG_F32)
-        hipLaunchKernelGGL((act_bwd_kernel<float, float>), grid, blk, 0, s, (const float*)dy, (const float*)y, (float*)dx, n8, scale);
-    else if (g_dtype == SGG_F32 && y_dtype == SGG_BF16)
-        hipLaunchKernelGGL((act_bwd_kernel<float, bf16_t>), grid, blk, 0, s, (const float*)dy, (const bf16_t*)y, (float*)dx, n8, scale);
-    else if (g_dtype == SGG_BF16 && y_dtype == SGG_F32)
-        hipLaunchKernelGGL((act_bwd_kernel<bf16_t, float>), grid, blk, 0, s, (const bf16_t*)dy, (const float*)y, (bf16_t*)dx, n8, scale);
-    else
-        return SGG_ERR_DTYPE;
+    SGG_FOR_DTYPE2(g_dtype, y_dtype, hipLaunchKernelGGL((act_bwd_kernel<TA, TB>), grid, blk, 0, s, (const TA*)dy, (const TB*)y, (TA*)dx, n8, scale));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
 
-extern "C" int sgg_colsum(const void* x, int M, int N, int ld, float* out, int zero_out, int dtype, void* stream) {
+// out[c] = sum_r x[r][c].  ws: f32[64 * N] (row blocks' partial sums; not needed -- may be NULL -- when M <= 512)
+extern "C" int sgg_colsum(const void* x, int M, int N, int ld, float* out, float* ws, int dtype, void* stream) {
     if (!out || N <= 0 || M < 0 || ld < N) return SGG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    // the kernel accumulates with atomics: `out` must start at zero -- zeroed here, or by the caller (zero_out = 0: e.g. a slice
-    // of one workspace cleared once for all the bias gradients of a backward pass, instead of a memset launch per call)
-    if (zero_out && hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s) != hipSuccess) return SGG_ERR_LAUNCH;
-    if (M == 0) return SGG_OK;
+    if (M == 0) return hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s) == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
     if (!x) return SGG_ERR_ARG;
     int rpb;
     const int split = split_rows(M, rpb);
+    if (split > 1 && !ws) return SGG_ERR_ARG;
+    float* dst = split > 1 ? ws : out;
     const dim3 grid((N + 63) / 64, split), blk(256);
     if ((N & 7) == 0 && (ld & 7) == 0 && ((uintptr_t)x & 15) == 0) {
-        DISPATCH2(dtype, hipLaunchKernelGGL(colsum8_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)x, M, N, ld, out, rpb),
-                  hipLaunchKernelGGL(colsum8_kernel<float>, grid, blk, 0, s, (const float*)x, M, N, ld, out, rpb));
+        SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(colsum8_kernel<T>, grid, blk, 0, s, (const T*)x, M, N, ld, dst, rpb));
     } else {
-        DISPATCH2(dtype, hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)x, M, N, ld, out, rpb),
-                  hipLaunchKernelGGL(colsum_kernel<float>, grid, blk, 0, s, (const float*)x, M, N, ld, out, rpb));
+        SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, blk, 0, s, (const T*)x, M, N, ld, dst, rpb));
     }
     SGG_CHECK_LAUNCH();
-    return SGG_OK;
+    return split > 1 ? sgg_reduce_parts(ws, split, N, out, 0, s) : SGG_OK;
 }
 
-// train-mode BatchNorm statistics of x[M,C]: sums[0][c] = sum x, sums[1][c] = sum x^2 (zeroed by the callee)
-extern "C" int sgg_bn_stats(const void* x, int M, int C, float* sums, int dtype, void* stream) {
-    if (!x || !sums || M <= 0 || C <= 0) return SGG_ERR_ARG;
+// train-mode BatchNorm statistics of x[M,C]: sums[0][c] = sum x, sums[1][c] = sum x^2.  ws: f32[64 * 2C]
+extern "C" int sgg_bn_stats(const void* x, int M, int C, float* sums, float* ws, int dtype, void* stream) {
+    if (!x || !sums || !ws || M <= 0 || C <= 0) return SGG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(sums, 0, sizeof(float) * 2 * (size_t)C, s) != hipSuccess) return SGG_ERR_LAUNCH;
     int rpb;
     const int split = split_rows(M, rpb);
     const dim3 grid((C + 63) / 64, split), blk(256);
     if ((C & 7) == 0) {
-        DISPATCH2(dtype, hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)x, M, C, sums, rpb),
-                  hipLaunchKernelGGL(bn_stats_kernel<float>, grid, blk, 0, s, (const float*)x, M, C, sums, rpb));
+        SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(bn_stats_kernel<T>, grid, blk, 0, s, (const T*)x, M, C, ws, rpb));
     } else {
-        DISPATCH2(dtype, hipLaunchKernelGGL((colsum2_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (const bf16_t*)x, (const bf16_t*)x, M, C, sums, rpb),
-                  hipLaunchKernelGGL((colsum2_kernel<float, float>), grid, blk, 0, s, (const float*)x, (const float*)x, M, C, sums, rpb));
+        SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL((colsum2_kernel<T, T>), grid, blk, 0, s, (const T*)x, (const T*)x, M, C, ws, rpb));
     }
     SGG_CHECK_LAUNCH();
-    return SGG_OK;
+    return sgg_reduce_parts(ws, split, 2 * C, sums, 0, s);
 }
 
 extern "C" int sgg_bn_finalize(const float* sums, int C, int count, const float* count_dev, const float* gamma,
@@ -952,11 +960,9 @@ extern "C" int sgg_bn_apply(const void* x, const float* scale, const float* shif
     const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
     hipStream_t s = (hipStream_t)stream;
     if (max4) {
-        DISPATCH2(dtype, hipLaunchKernelGGL((bn_apply_kernel<bf16_t, true>), grid, blk, 0, s, (const bf16_t*)x, scale, shift, (bf16_t*)out, arg, (long)rows_out, C),
-                  hipLaunchKernelGGL((bn_apply_kernel<float, true>), grid, blk, 0, s, (const float*)x, scale, shift, (float*)out, arg, (long)rows_out, C));
+        SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, true>), grid, blk, 0, s, (const T*)x, scale, shift, (T*)out, arg, (long)rows_out, C));
     } else {
-        DISPATCH2(dtype, hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), grid, blk, 0, s, (const bf16_t*)x, scale, shift, (bf16_t*)out, arg, (long)rows_out, C),
-                  hipLaunchKernelGGL((bn_apply_kernel<float, false>), grid, blk, 0, s, (const float*)x, scale, shift, (float*)out, arg, (long)rows_out, C));
+        SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, false>), grid, blk, 0, s, (const T*)x, scale, shift, (T*)out, arg, (long)rows_out, C));
     }
     SGG_CHECK_LAUNCH();
     return SGG_OK;
@@ -964,30 +970,38 @@ extern "C" int sgg_bn_apply(const void* x, const float* scale, const float* shif
 
 // backward of [ReLU ->] BatchNorm(batch stats) [-> max over 4 rows]: x[rows,C] = post-ReLU input of the BN,
 // dy[rows(/4),C]; outputs dx[rows,C] (gradient at the conv output, ReLU folded) and sums[2][C] = (dbeta, dgamma).
+// ws: f32[64 * 2C] (phases 0 and 1: the row blocks' partial sums)
 extern "C" int sgg_bn_bwd(const void* dy, const unsigned char* arg, const void* x, const float* mean, const float* invstd,
-                          const float* gamma, void* dx, float* sums, int rows, int C, int max4, int phase,
+                          const float* gamma, void* dx, float* sums, float* ws, int rows, int C, int max4, int phase,
                           const float* count_dev, int dtype, void* stream) {
     if (!dy || !x || !mean || !invstd || !gamma || !dx || !sums || rows <= 0 || C <= 0 || (C & 7) || (max4 && !arg))
         return SGG_ERR_ARG;
-    if (phase < 0 || phase > 2 || (count_dev && phase != 2)) return SGG_ERR_ARG;
+    if (phase < 0 || phase > 2 || (count_dev && phase != 2) || (phase != 2 && !ws)) return SGG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (phase != 2 && hipMemsetAsync(sums, 0, sizeof(float) * 2 * (size_t)C, s) != hipSuccess) return SGG_ERR_LAUNCH;
     int rpb;
     const int split = split_rows(rows, rpb);
     const dim3 g1((C + 63) / 64, split);
     const long total = (long)rows * (C / 8);
     const dim3 g2((unsigned)((total + 255) / 256));
     const float inv = 1.0f / (float)rows;
-    if (dtype == SGG_BF16) {
-        if (max4) bn_bwd_launch<bf16_t, true>(dy, arg, x, mean, invstd, gamma, dx, sums, rows, C, rpb, g1, g2, inv, phase, count_dev, s);
-        else bn_bwd_launch<bf16_t, false>(dy, arg, x, mean, invstd, gamma, dx, sums, rows, C, rpb, g1, g2, inv, phase, count_dev, s);
-    } else if (dtype == SGG_F32) {
-        if (max4) bn_bwd_launch<float, true>(dy, arg, x, mean, invstd, gamma, dx, sums, rows, C, rpb, g1, g2, inv, phase, count_dev, s);
-        else bn_bwd_launch<float, false>(dy, arg, x, mean, invstd, gamma, dx, sums, rows, C, rpb, g1, g2, inv, phase, count_dev, s);
-    } else {
-        return SGG_ERR_DTYPE;
+    if (phase != 2) {
+        if (max4) {
+            SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), g1, dim3(256), 0, s, (const T*)dy, arg, (const T*)x, mean, invstd, ws, rows, C, rpb));
+        } else {
+            SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), g1, dim3(256), 0, s, (const T*)dy, arg, (const T*)x, mean, invstd, ws, rows, C, rpb));
+        }
+        SGG_CHECK_LAUNCH();
+        const int rc = sgg_reduce_parts(ws, split, 2 * C, sums, 0, s);
+        if (rc != SGG_OK) return rc;
     }
-    SGG_CHECK_LAUNCH();
+    if (phase != 1) {
+        if (max4) {
+            SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, true>), g2, dim3(256), 0, s, (const T*)dy, arg, (const T*)x, mean, invstd, gamma, sums, (T*)dx, (long)rows, C, inv, count_dev));
+        } else {
+            SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, false>), g2, dim3(256), 0, s, (const T*)dy, arg, (const T*)x, mean, invstd, gamma, sums, (T*)dx, (long)rows, C, inv, count_dev));
+        }
+        SGG_CHECK_LAUNCH();
+    }
     return SGG_OK;
 }
 
@@ -999,9 +1013,8 @@ extern "C" int sgg_gru_gate_bwd(const void* dh, const float* gi, const float* gh
     const long total = (long)M * (H / 8);
     const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH2(dtype,
-        hipLaunchKernelGGL(gru_gate_bwd_kernel<bf16_t>, grid, blk, 0, s, (const bf16_t*)dh, gi, gh, b_hh, (const bf16_t*)h_prev, (bf16_t*)d_gi, (bf16_t*)d_gh, (bf16_t*)dh_prev, total, H),
-        hipLaunchKernelGGL(gru_gate_bwd_kernel<float>, grid, blk, 0, s, (const float*)dh, gi, gh, b_hh, (const float*)h_prev, (float*)d_gi, (float*)d_gh, (float*)dh_prev, total, H));
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(gru_gate_bwd_kernel<T>, grid, blk, 0, s, (const T*)dh, gi, gh, b_hh, (const T*)h_prev, (T*)d_gi, (T*)d_gh,
+                                            (T*)dh_prev, total, H));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -1048,30 +1061,32 @@ extern "C" int sgg_imp_node_gates_bwd(const float* da, const int* out_ptr, const
     return SGG_OK;
 }
 
-// out[k, :H] += sum_r a[r,k] * x[r,:]  (k < 4; out row stride out_ld; NOT zeroed: accumulates over IMP iterations)
-extern "C" int sgg_rank4_reduce(const float* a, const void* x, int R, int H, float* out, int out_ld, int dtype, void* stream) {
+// out[k, :H] += sum_r a[r,k] * x[r,:]  (k < 4; out row stride out_ld; NOT zeroed: accumulates over calls).  ws: f32[64 * 4 * H]
+extern "C" int sgg_rank4_reduce(const float* a, const void* x, int R, int H, float* out, int out_ld, float* ws, int dtype, void* stream) {
     if (R == 0) return SGG_OK;
-    if (!a || !x || !out || R < 0 || H <= 0 || out_ld < H) return SGG_ERR_ARG;
+    if (!a || !x || !out || !ws || R < 0 || H <= 0 || out_ld < H) return SGG_ERR_ARG;
     int rpb;
     const int split = split_rows(R, rpb);
     const dim3 grid((H + 63) / 64, split), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH2(dtype, hipLaunchKernelGGL(rank4_reduce_kernel<bf16_t>, grid, blk, 0, s, a, (const bf16_t*)x, R, H, out, out_ld, rpb),
-              hipLaunchKernelGGL(rank4_reduce_kernel<float>, grid, blk, 0, s, a, (const float*)x, R, H, out, out_ld, rpb));
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(rank4_reduce_kernel<T>, grid, blk, 0, s, a, (const T*)x, R, H, ws, rpb));
+    SGG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(rank4_finalize_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, s, ws, split, H, out, out_ld);
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
 
-// acc += sum(g^2)  (acc NOT zeroed: the caller clears it once per step and accumulates over all parameters)
-extern "C" int sgg_sqnorm_acc(const void* g, int64_t n, float* acc, int dtype, void* stream) {
+// acc += sum(g^2)  (acc NOT zeroed: the caller clears it once per step and accumulates over all parameters).  ws: f32[2048]
+extern "C" int sgg_sqnorm_acc(const void* g, int64_t n, float* acc, float* ws, int dtype, void* stream) {
     if (n == 0) return SGG_OK;
-    if (!g || !acc || n < 0) return SGG_ERR_ARG;
+    if (!g || !acc || !ws || n < 0) return SGG_ERR_ARG;
     long blocks = (n / 8 + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH2(dtype, hipLaunchKernelGGL(sqnorm_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)g, (long)n, acc),
-              hipLaunchKernelGGL(sqnorm_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)g, (long)n, acc));
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(sqnorm_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, (const T*)g, (long)n, ws));
+    SGG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(256), 0, s, ws, (int)blocks, acc, 1);
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -1084,9 +1099,8 @@ extern "C" int sgg_sgd_step(float* p, const void* g, float* momentum_buf, int64_
     long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH2(g_dtype,
-        hipLaunchKernelGGL(sgd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, p, (const bf16_t*)g, momentum_buf, (long)n, lr, weight_decay, momentum, first_step, norm_sq, max_norm, grad_scale),
-        hipLaunchKernelGGL(sgd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, p, (const float*)g, momentum_buf, (long)n, lr, weight_decay, momentum, first_step, norm_sq, max_norm, grad_scale));
+    SGG_FOR_DTYPE(g_dtype, hipLaunchKernelGGL(sgd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, p, (const T*)g, momentum_buf, (long)n, lr,
+                                              weight_decay, momentum, first_step, norm_sq, max_norm, grad_scale));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -1103,7 +1117,7 @@ int mt_fill(MultiTab& tab, int lo, int hi, const void* const* g, float* const* p
         tab.g[k] = g[i];
         tab.p[k] = p ? p[i] : nullptr;
         tab.buf[k] = buf ? buf[i] : nullptr;
-        tab.shadow[k] = shadow ? (bf16_t*)shadow[i] : nullptr;
+        tab.shadow[k] = shadow ? shadow[i] : nullptr;
         tab.n[k] = n[i];
         tab.lr[k] = lr ? lr[i] : 0.f;
         tab.chunk0[k + 1] = tab.chunk0[k] + (int)((n[i] + MT_CHUNK - 1) / MT_CHUNK);
@@ -1113,10 +1127,10 @@ int mt_fill(MultiTab& tab, int lo, int hi, const void* const* g, float* const* p
 }  // namespace
 
 // acc += sum_i sum(g_i^2) over `count` tensors in one launch per 32 tensors (host arrays of device pointers / sizes).
-// Every g_i must be 16-byte aligned.
-extern "C" int sgg_sqnorm_multi(const void* const* g, const int64_t* n, int count, float* acc, int dtype, void* stream) {
+// Every g_i must be 16-byte aligned.  ws: f32[2048]
+extern "C" int sgg_sqnorm_multi(const void* const* g, const int64_t* n, int count, float* acc, float* ws, int dtype, void* stream) {
     if (count == 0) return SGG_OK;
-    if (!g || !n || !acc || count < 0) return SGG_ERR_ARG;
+    if (!g || !n || !acc || !ws || count < 0) return SGG_ERR_ARG;
     for (int i = 0; i < count; ++i)
         if (n[i] < 0 || (n[i] > 0 && (!g[i] || ((uintptr_t)g[i] & 15)))) return SGG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -1125,21 +1139,23 @@ extern "C" int sgg_sqnorm_multi(const void* const* g, const int64_t* n, int coun
         const int chunks = mt_fill(tab, lo, min(count, lo + MT_MAX), g, nullptr, nullptr, nullptr, n, nullptr);
         if (!chunks) continue;
         const dim3 grid((unsigned)min(chunks, 2048));
-        DISPATCH2(dtype, hipLaunchKernelGGL(sqnorm_multi_kernel<bf16_t>, grid, dim3(256), 0, s, tab, acc),
-                  hipLaunchKernelGGL(sqnorm_multi_kernel<float>, grid, dim3(256), 0, s, tab, acc));
+        SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(sqnorm_multi_kernel<T>, grid, dim3(256), 0, s, tab, ws));
+        SGG_CHECK_LAUNCH();
+        hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(256), 0, s, ws, (int)grid.x, acc, 1);
         SGG_CHECK_LAUNCH();
     }
     return SGG_OK;
 }
 
 // sgg_sgd_step over `count` tensors in one launch per 32 tensors; lr per tensor (parameter groups).  shadow (optional
-// array, entries may be NULL): bf16 copy of each updated parameter, written in the same pass.
+// array, entries may be NULL): 16-bit copy (shadow_dtype: SGG_BF16 / SGG_F16) of each updated parameter, written in the same pass.
 extern "C" int sgg_sgd_multi(float* const* p, const void* const* g, float* const* momentum_buf, void* const* shadow,
                              const int64_t* n, const float* lr, int count, float weight_decay, float momentum,
-                             int first_step, const float* norm_sq, float max_norm, float grad_scale, int g_dtype,
+                             int first_step, const float* norm_sq, float max_norm, float grad_scale, int g_dtype, int shadow_dtype,
                              int max_blocks, void* stream) {
     if (count == 0) return SGG_OK;
     if (!p || !g || !momentum_buf || !n || !lr || count < 0) return SGG_ERR_ARG;
+    if (shadow_dtype != SGG_BF16 && shadow_dtype != SGG_F16) return SGG_ERR_DTYPE;
     for (int i = 0; i < count; ++i) {
         if (n[i] < 0) return SGG_ERR_ARG;
         if (n[i] == 0) continue;
@@ -1155,9 +1171,13 @@ extern "C" int sgg_sgd_multi(float* const* p, const void* const* g, float* const
         // few, fat workgroups (12 float4 loads in flight per thread): 512 already stream at full bandwidth, and leave wave
         // slots for the kernels of another stream (the trainer's pipeline mode asks for 256: the VGG forward runs beside it)
         const dim3 grid((unsigned)min(chunks, max_blocks > 0 ? max_blocks : 512));
-        DISPATCH2(g_dtype,
-            hipLaunchKernelGGL(sgd_multi_kernel<bf16_t>, grid, dim3(256), 0, s, tab, weight_decay, momentum, first_step, norm_sq, max_norm, grad_scale),
-            hipLaunchKernelGGL(sgd_multi_kernel<float>, grid, dim3(256), 0, s, tab, weight_decay, momentum, first_step, norm_sq, max_norm, grad_scale));
+        if (shadow_dtype == SGG_BF16) {
+            SGG_FOR_DTYPE(g_dtype, hipLaunchKernelGGL((sgd_multi_kernel<T, bf16_t>), grid, dim3(256), 0, s, tab, weight_decay, momentum, first_step, norm_sq,
+                                                      max_norm, grad_scale));
+        } else {
+            SGG_FOR_DTYPE(g_dtype, hipLaunchKernelGGL((sgd_multi_kernel<T, f16_t>), grid, dim3(256), 0, s, tab, weight_decay, momentum, first_step, norm_sq,
+                                                      max_norm, grad_scale));
+        }
         SGG_CHECK_LAUNCH();
     }
     return SGG_OK;

@@ -68,11 +68,11 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ i
         for (int k = 0; k < 8; ++k) t[rr][cc + k] = v[k];
     }
     __syncthreads();
-    if (colsum && tid < 64 && c0 + tid < C) {   // bias gradient for free: column sums of the tile (rows >= R are zero)
+    if (colsum && tid < 64 && c0 + tid < C) {   // bias gradient for free: column sums of the tile (rows >= R are zero) -> this row block's partial
         float s = 0.f;
 #pragma unroll 8
         for (int k = 0; k < 64; ++k) s += t[k][tid];
-        atomicAdd(&colsum[c0 + tid], s);
+        colsum[(long)blockIdx.y * C + c0 + tid] = s;
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -91,10 +91,10 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ i
 }
 
 // 16-bit-output form: 128x128 tiles (eight 16-byte loads in flight per thread, 256-byte row segments), the tile kept
-// in LDS as bf16 PAIRS [row][col/2] with a 65-word row stride: the b32 writes and the column reads (8 row-chunks x 8
+// in LDS as 16-bit PAIRS [row][col/2] with a 65-word row stride: the b32 writes and the column reads (8 row-chunks x 8
 // column pairs per wave) are both bank-conflict free, and one ds_read_b32 feeds two output columns.
-template <typename TI>
-__global__ __launch_bounds__(256) void transpose16_kernel(const TI* __restrict__ in, long ld_in, bf16_t* __restrict__ out,
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void transpose16_kernel(const TI* __restrict__ in, long ld_in, TO* __restrict__ out,
                                                           long ld_out, int R, int C, const float* __restrict__ add,
                                                           long ld_add, int group, float* __restrict__ colsum) {
     __shared__ unsigned int t[128][65];
@@ -142,15 +142,14 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const TI* __restrict__
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) t[rr][(cc >> 1) + k] = pack_bf16x2(v[q][2 * k], v[q][2 * k + 1]);
+        for (int k = 0; k < 4; ++k) t[rr][(cc >> 1) + k] = H16<TO>::pack(v[q][2 * k], v[q][2 * k + 1]);
     }
     __syncthreads();
-    if (colsum && tid < 128 && c0 + tid < C) {   // bias gradient for free (rows >= R are zero)
+    if (colsum && tid < 128 && c0 + tid < C) {   // bias gradient for free (rows >= R are zero) -> this row block's partial
         float s = 0.f;
-        const int sh = (tid & 1) * 16;
 #pragma unroll 8
-        for (int k = 0; k < 128; ++k) s += __uint_as_float(((t[k][tid >> 1] >> sh) & 0xffffu) << 16);
-        atomicAdd(&colsum[c0 + tid], s);
+        for (int k = 0; k < 128; ++k) s += (tid & 1) ? H16<TO>::hi(t[k][tid >> 1]) : H16<TO>::lo(t[k][tid >> 1]);
+        colsum[(long)blockIdx.y * C + c0 + tid] = s;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -165,7 +164,7 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const TI* __restrict__
         for (int h = 0; h < 2; ++h) {
             if (c + h >= C) break;
             const unsigned sel = h ? 0x07060302u : 0x05040100u;   // v_perm_b32: one selector BYTE per output byte
-            bf16_t* dst = out + (long)(c + h) * ld_out + r;
+            TO* dst = out + (long)(c + h) * ld_out + r;
             if (r + 8 <= R && vout) {
                 u32x4 o;
                 o.x = __builtin_amdgcn_perm(w[1], w[0], sel);
@@ -174,7 +173,7 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const TI* __restrict__
                 o.w = __builtin_amdgcn_perm(w[7], w[6], sel);
                 *reinterpret_cast<u32x4*>(dst) = o;
             } else {
-                for (int k = 0; k < 8 && r + k < R; ++k) dst[k] = (bf16_t)((w[k] >> (16 * h)) & 0xffffu);
+                for (int k = 0; k < 8 && r + k < R; ++k) reinterpret_cast<unsigned short*>(dst)[k] = (unsigned short)((w[k] >> (16 * h)) & 0xffffu);
             }
         }
     }
@@ -213,7 +212,31 @@ __global__ __launch_bounds__(256) void add_kernel(T* __restrict__ y, const TX* _
     store8(y + i * 8, a);
 }
 
+// out[c] (+)= sum_p parts[p][c] in ascending p (fixed order: bit-reproducible)
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ parts, int nparts, int ncols, float* __restrict__ out,
+                                                           int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncols) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // four chains for memory-level parallelism, combined in a fixed order
+    int p = 0;
+    for (; p + 4 <= nparts; p += 4) {
+        s0 += parts[(long)p * ncols + c];
+        s1 += parts[(long)(p + 1) * ncols + c];
+        s2 += parts[(long)(p + 2) * ncols + c];
+        s3 += parts[(long)(p + 3) * ncols + c];
+    }
+    for (; p < nparts; ++p) s0 += parts[(long)p * ncols + c];
+    const float t = (s0 + s1) + (s2 + s3);
+    out[c] = accumulate ? out[c] + t : t;
+}
+
 }  // namespace
+
+int sgg_reduce_parts(const float* parts, int nparts, int ncols, float* out, int accumulate, hipStream_t s) {
+    if (ncols <= 0) return SGG_OK;
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((ncols + 255) / 256), dim3(256), 0, s, parts, nparts, ncols, out, accumulate);
+    return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
+}
 
 extern "C" int sgg_abi_version(void) { return SGG_ABI_VERSION; }
 extern "C" const char* sgg_build_info(void) { return "sgg_hip gfx950 (CDNA4) " __DATE__ " " __TIME__; }
@@ -224,16 +247,7 @@ extern "C" int sgg_cast(const void* in, void* out, int64_t n, int in_dtype, int 
     if ((((uintptr_t)in) | ((uintptr_t)out)) & 15) return SGG_ERR_ARG;
     const dim3 grid((unsigned)((n + 2047) / 2048)), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    if (in_dtype == SGG_F32 && out_dtype == SGG_BF16)
-        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), grid, blk, 0, s, (const float*)in, (bf16_t*)out, (long)n);
-    else if (in_dtype == SGG_BF16 && out_dtype == SGG_F32)
-        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), grid, blk, 0, s, (const bf16_t*)in, (float*)out, (long)n);
-    else if (in_dtype == SGG_F32 && out_dtype == SGG_F32)
-        hipLaunchKernelGGL((cast_kernel<float, float>), grid, blk, 0, s, (const float*)in, (float*)out, (long)n);
-    else if (in_dtype == SGG_BF16 && out_dtype == SGG_BF16)
-        hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (const bf16_t*)in, (bf16_t*)out, (long)n);
-    else
-        return SGG_ERR_DTYPE;
+    SGG_FOR_DTYPE2(in_dtype, out_dtype, hipLaunchKernelGGL((cast_kernel<TA, TB>), grid, blk, 0, s, (const TA*)in, (TB*)out, (long)n));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -244,40 +258,40 @@ extern "C" int sgg_permute_ncp_to_npc(const void* in, void* out, int Nn, int C, 
     if (!in || !out || Nn < 0 || C <= 0 || Pp <= 0 || Nn > 65535) return SGG_ERR_ARG;
     const dim3 grid((Pp + 31) / 32, (C + 31) / 32, Nn), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    if (in_dtype == SGG_F32 && out_dtype == SGG_BF16)
-        hipLaunchKernelGGL((permute_kernel<float, bf16_t>), grid, blk, 0, s, (const float*)in, (bf16_t*)out, C, Pp);
-    else if (in_dtype == SGG_F32 && out_dtype == SGG_F32)
-        hipLaunchKernelGGL((permute_kernel<float, float>), grid, blk, 0, s, (const float*)in, (float*)out, C, Pp);
-    else if (in_dtype == SGG_BF16 && out_dtype == SGG_BF16)
-        hipLaunchKernelGGL((permute_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (const bf16_t*)in, (bf16_t*)out, C, Pp);
-    else if (in_dtype == SGG_BF16 && out_dtype == SGG_F32)
-        hipLaunchKernelGGL((permute_kernel<bf16_t, float>), grid, blk, 0, s, (const bf16_t*)in, (float*)out, C, Pp);
-    else
-        return SGG_ERR_DTYPE;
+    SGG_FOR_DTYPE2(in_dtype, out_dtype, hipLaunchKernelGGL((permute_kernel<TA, TB>), grid, blk, 0, s, (const TA*)in, (TB*)out, C, Pp));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
 
+// colsum (optional): the column sums of `in` (f32[C]); colsum_ws: f32 scratch of >= ceil(R / 64) * C floats for the row blocks' partial sums
 extern "C" int sgg_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int R, int C, const float* add,
-                             int64_t ld_add, int group, float* colsum, int in_dtype, int out_dtype, void* stream) {
+                             int64_t ld_add, int group, float* colsum, float* colsum_ws, int in_dtype, int out_dtype, void* stream) {
     if (R == 0 || C == 0) return SGG_OK;
-    if (!in || !out || R < 0 || C < 0 || ld_in < C || ld_out < R || (add && group <= 0)) return SGG_ERR_ARG;
-    const dim3 grid((C + 63) / 64, (R + 63) / 64), blk(256);
+    if (!in || !out || R < 0 || C < 0 || ld_in < C || ld_out < R || (add && group <= 0) || (colsum && !colsum_ws)) return SGG_ERR_ARG;
+    if (!sgg_is_dtype(in_dtype) || !sgg_is_dtype(out_dtype)) return SGG_ERR_DTYPE;
     hipStream_t s = (hipStream_t)stream;
     if (group <= 0) group = 1;
-    if (colsum && hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)C, s) != hipSuccess) return SGG_ERR_LAUNCH;
-    const dim3 grid16((C + 127) / 128, (R + 127) / 128);
-    if (in_dtype == SGG_BF16 && out_dtype == SGG_BF16)
-        hipLaunchKernelGGL(transpose16_kernel<bf16_t>, grid16, blk, 0, s, (const bf16_t*)in, (long)ld_in, (bf16_t*)out, (long)ld_out, R, C, add, (long)ld_add, group, colsum);
-    else if (in_dtype == SGG_F32 && out_dtype == SGG_F32)
-        hipLaunchKernelGGL((transpose_kernel<float, float>), grid, blk, 0, s, (const float*)in, (long)ld_in, (float*)out, (long)ld_out, R, C, add, (long)ld_add, group, colsum);
-    else if (in_dtype == SGG_F32 && out_dtype == SGG_BF16)
-        hipLaunchKernelGGL(transpose16_kernel<float>, grid16, blk, 0, s, (const float*)in, (long)ld_in, (bf16_t*)out, (long)ld_out, R, C, add, (long)ld_add, group, colsum);
-    else if (in_dtype == SGG_BF16 && out_dtype == SGG_F32)
-        hipLaunchKernelGGL((transpose_kernel<bf16_t, float>), grid, blk, 0, s, (const bf16_t*)in, (long)ld_in, (float*)out, (long)ld_out, R, C, add, (long)ld_add, group, colsum);
-    else
-        return SGG_ERR_DTYPE;
+    float* part = colsum ? colsum_ws : nullptr;
+    int nparts;
+    if (out_dtype != SGG_F32) {      // 16-bit output: 128 x 128 tiles
+        const dim3 grid16((C + 127) / 128, (R + 127) / 128), blk(256);
+        nparts = (int)grid16.y;
+        if (in_dtype != SGG_F32 && in_dtype != out_dtype) return SGG_ERR_DTYPE;
+        SGG_FOR_DTYPE16(out_dtype,
+            if (in_dtype == SGG_F32)
+                hipLaunchKernelGGL((transpose16_kernel<float, T>), grid16, blk, 0, s, (const float*)in, (long)ld_in, (T*)out, (long)ld_out, R, C, add,
+                                   (long)ld_add, group, part);
+            else
+                hipLaunchKernelGGL((transpose16_kernel<T, T>), grid16, blk, 0, s, (const T*)in, (long)ld_in, (T*)out, (long)ld_out, R, C, add,
+                                   (long)ld_add, group, part));
+    } else {
+        const dim3 grid((C + 63) / 64, (R + 63) / 64), blk(256);
+        nparts = (int)grid.y;
+        SGG_FOR_DTYPE(in_dtype, hipLaunchKernelGGL((transpose_kernel<T, float>), grid, blk, 0, s, (const T*)in, (long)ld_in, (float*)out, (long)ld_out,
+                                                   R, C, add, (long)ld_add, group, part));
+    }
     SGG_CHECK_LAUNCH();
+    if (colsum) return sgg_reduce_parts(part, nparts, C, colsum, 0, s);
     return SGG_OK;
 }
 
@@ -289,12 +303,7 @@ extern "C" int sgg_group_sum(const float* in, int64_t ld_in, void* out, int64_t 
     const dim3 grid((C + 63) / 64, Nn), blk(256);
     const size_t smem = sizeof(float) * 64 * (size_t)group;
     hipStream_t s = (hipStream_t)stream;
-    if (out_dtype == SGG_BF16)
-        hipLaunchKernelGGL(group_sum_kernel<bf16_t>, grid, blk, smem, s, in, (long)ld_in, (bf16_t*)out, (long)ld_out, Nn, C, group);
-    else if (out_dtype == SGG_F32)
-        hipLaunchKernelGGL(group_sum_kernel<float>, grid, blk, smem, s, in, (long)ld_in, (float*)out, (long)ld_out, Nn, C, group);
-    else
-        return SGG_ERR_DTYPE;
+    SGG_FOR_DTYPE(out_dtype, hipLaunchKernelGGL(group_sum_kernel<T>, grid, blk, smem, s, in, (long)ld_in, (T*)out, (long)ld_out, Nn, C, group));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -305,16 +314,7 @@ extern "C" int sgg_add(void* y, const void* x, int64_t n, int y_dtype, int x_dty
     const long n8 = n / 8;
     const dim3 grid((unsigned)((n8 + 255) / 256)), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    if (y_dtype == SGG_BF16 && x_dtype == SGG_BF16)
-        hipLaunchKernelGGL((add_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (bf16_t*)y, (const bf16_t*)x, n8);
-    else if (y_dtype == SGG_F32 && x_dtype == SGG_F32)
-        hipLaunchKernelGGL((add_kernel<float, float>), grid, blk, 0, s, (float*)y, (const float*)x, n8);
-    else if (y_dtype == SGG_BF16 && x_dtype == SGG_F32)
-        hipLaunchKernelGGL((add_kernel<bf16_t, float>), grid, blk, 0, s, (bf16_t*)y, (const float*)x, n8);
-    else if (y_dtype == SGG_F32 && x_dtype == SGG_BF16)
-        hipLaunchKernelGGL((add_kernel<float, bf16_t>), grid, blk, 0, s, (float*)y, (const bf16_t*)x, n8);
-    else
-        return SGG_ERR_DTYPE;
+    SGG_FOR_DTYPE2(y_dtype, x_dtype, hipLaunchKernelGGL((add_kernel<TA, TB>), grid, blk, 0, s, (TA*)y, (const TB*)x, n8));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

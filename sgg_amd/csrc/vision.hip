@@ -147,15 +147,14 @@ __global__ __launch_bounds__(256) void conv1_1_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv1_1 on the matrix cores (bf16 storage mode).  K = 27 padded to 32 = two v_mfma_f32_32x32x16_bf16 k-steps.
+// conv1_1 on the matrix cores (16-bit storage modes).  K = 27 padded to 32 = two v_mfma_f32_32x32x16 k-steps.
 // A wave owns 32 consecutive pixels of one image row x all 64 output channels: each lane gathers its pixel's 3x3x3
-// patch with nine 16-byte loads (NHWC4 fp32, coalesced along x), packs the k-slice its MFMA fragment needs to bf16,
+// patch with nine 16-byte loads (NHWC4 fp32, coalesced along x), packs the k-slice its MFMA fragment needs to the 16-bit format,
 // and the 32x64 result goes through LDS so that the wave writes one contiguous 4-KiB piece of the output row.
 // ------------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
-
+template <typename T>
 __global__ __launch_bounds__(256) void conv1_1_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                           const float* __restrict__ bias, T* __restrict__ out,
                                                            int nseg, int segs_per_row, int H, int W) {
     constexpr int LROW = 136;  // bytes per staged pixel row (128 + 8: conflict-free ds_write_b64)
     __shared__ __attribute__((aligned(16))) char stage[4][32 * LROW];
@@ -173,7 +172,7 @@ __global__ __launch_bounds__(256) void conv1_1_mfma_kernel(const float* __restri
                 const int k = s * 16 + h * 8 + j;
                 v[j] = k < 27 ? w[(nt * 32 + m) * 27 + k] : 0.f;
             }
-            wf[nt][s] = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            wf[nt][s] = pack8<T>(v);
         }
     float bv[2][4][4];
 #pragma unroll
@@ -205,7 +204,7 @@ __global__ __launch_bounds__(256) void conv1_1_mfma_kernel(const float* __restri
             float t[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) t[j] = h ? V[s * 16 + 8 + j] : V[s * 16 + j];
-            af[s] = u32x4{pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3]), pack_bf16x2(t[4], t[5]), pack_bf16x2(t[6], t[7])};
+            af[s] = pack8<T>(t);
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -214,13 +213,12 @@ __global__ __launch_bounds__(256) void conv1_1_mfma_kernel(const float* __restri
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 2; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, wf[nt][s]),
-                                                              __builtin_bit_cast(bf16x8_v, af[s]), acc, 0, 0, 0);
+                acc = mfma_32x32x16<DtypeOf<T>::value>(wf[nt][s], af[s], acc);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float o0 = fmaxf(acc[4 * q] + bv[nt][q][0], 0.f), o1 = fmaxf(acc[4 * q + 1] + bv[nt][q][1], 0.f);
                 const float o2 = fmaxf(acc[4 * q + 2] + bv[nt][q][2], 0.f), o3 = fmaxf(acc[4 * q + 3] + bv[nt][q][3], 0.f);
-                u32x2 pk = {pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)};
+                u32x2 pk = {H16<T>::pack(o0, o1), H16<T>::pack(o2, o3)};
                 *reinterpret_cast<u32x2*>(st + m * LROW + (nt * 32 + 8 * q + 4 * h) * 2) = pk;
             }
         }
@@ -228,7 +226,7 @@ __global__ __launch_bounds__(256) void conv1_1_mfma_kernel(const float* __restri
         // compiler from moving the reads above the writes
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        bf16_t* orow = out + (((long)b * (H + 2) + y + 1) * (W + 2) + x0 + 1) * 64;
+        T* orow = out + (((long)b * (H + 2) + y + 1) * (W + 2) + x0 + 1) * 64;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int px = it * 8 + (lane >> 3), ch = (lane & 7) * 16;
@@ -441,11 +439,12 @@ __global__ __launch_bounds__(512, 4) void roi_align_kernel(const T* __restrict__
     for (int L0 = tid * 8; L0 < total; L0 += (int)blockDim.x * 8) {
         int c = L0 / PP, p = L0 - c * PP;
         if constexpr (sizeof(T) == 2) {
-            // raw 16-bit moves: no bf16 -> f32 -> bf16 round trip
+            // raw 16-bit moves: no 16-bit -> f32 -> 16-bit round trip
+            const unsigned short* traw = reinterpret_cast<const unsigned short*>(tile);
             unsigned int w[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const unsigned int h = (L0 + k < total) ? (unsigned int)tile[p * TS + c] : 0u;
+                const unsigned int h = (L0 + k < total) ? (unsigned int)traw[p * TS + c] : 0u;
                 w[k >> 1] |= h << ((k & 1) * 16);
                 if (++p == PP) {
                     p = 0;
@@ -455,7 +454,7 @@ __global__ __launch_bounds__(512, 4) void roi_align_kernel(const T* __restrict__
             if (L0 + 8 <= total) {
                 *reinterpret_cast<u32x4*>(o + L0) = u32x4{w[0], w[1], w[2], w[3]};
             } else {
-                for (int k = 0; L0 + k < total; ++k) o[L0 + k] = (T)((w[k >> 1] >> ((k & 1) * 16)) & 0xffffu);
+                for (int k = 0; L0 + k < total; ++k) reinterpret_cast<unsigned short*>(o)[L0 + k] = (unsigned short)((w[k >> 1] >> ((k & 1) * 16)) & 0xffffu);
             }
         } else {
             float v[8];
@@ -570,14 +569,8 @@ extern "C" int sgg_roi_align_bwd(const void* d_out, int B, int H, int W, int C, 
     if (!d_out || !rois || !d_fmap || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || R < 0 || P <= 0 || sampling <= 0 ||
         P * sampling > MAXS || Nroi <= 0)
         return SGG_ERR_ARG;
-    if (dtype == SGG_BF16)
-        hipLaunchKernelGGL(roi_align_bwd_kernel<bf16_t>, dim3(R), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)d_out, B, H, W, C, rois,
-                           pairs, R, spatial_scale, P, sampling, d_fmap);
-    else if (dtype == SGG_F32)
-        hipLaunchKernelGGL(roi_align_bwd_kernel<float>, dim3(R), dim3(256), 0, (hipStream_t)stream, (const float*)d_out, B, H, W, C, rois,
-                           pairs, R, spatial_scale, P, sampling, d_fmap);
-    else
-        return SGG_ERR_DTYPE;
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(roi_align_bwd_kernel<T>, dim3(R), dim3(256), 0, (hipStream_t)stream, (const T*)d_out, B, H, W, C, rois,
+                                            pairs, R, spatial_scale, P, sampling, d_fmap));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -626,11 +619,11 @@ extern "C" int sgg_conv1_1(const float* in, const float* w, const float* bias, v
     if (!in || !w || !bias || !out || B <= 0 || H <= 0 || W <= 0) return SGG_ERR_ARG;
     const long npix = (long)B * H * W;
     const int grid = (int)((npix + 63) / 64);
-    if (out_dtype == SGG_BF16) {
+    if (out_dtype == SGG_BF16 || out_dtype == SGG_F16) {
         const int segs_per_row = (W + 31) / 32, nseg = B * H * segs_per_row;
         const int g2 = min((nseg + 3) / 4, 256 * 8);
-        hipLaunchKernelGGL(conv1_1_mfma_kernel, dim3(g2), dim3(256), 0, (hipStream_t)stream, in, w, bias, (bf16_t*)out, nseg,
-                           segs_per_row, H, W);
+        SGG_FOR_DTYPE16(out_dtype, hipLaunchKernelGGL(conv1_1_mfma_kernel<T>, dim3(g2), dim3(256), 0, (hipStream_t)stream, in, w, bias, (T*)out, nseg,
+                                                      segs_per_row, H, W));
     }
     else if (out_dtype == SGG_F32)
         hipLaunchKernelGGL(conv1_1_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, w, bias, (float*)out, npix, H, W);
@@ -645,12 +638,7 @@ extern "C" int sgg_maxpool2x2(const void* in, void* out, int out_pad, int B, int
         return SGG_ERR_ARG;
     const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
     const int grid = (int)((total + 255) / 256);
-    if (dtype == SGG_BF16)
-        hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, out_pad, H, W, C, total);
-    else if (dtype == SGG_F32)
-        hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)in, (float*)out, out_pad, H, W, C, total);
-    else
-        return SGG_ERR_DTYPE;
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(maxpool_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)in, (T*)out, out_pad, H, W, C, total));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -666,7 +654,8 @@ extern "C" int sgg_roi_align_fwd(const void* fmap, int B, int H, int W, int C, c
         sampling <= 0 || P * sampling > MAXS)
         return SGG_ERR_ARG;
     if (!pairs && R != Nroi) return SGG_ERR_ARG;
-    const size_t esz = dtype == SGG_BF16 ? 2 : 4;
+    if (!sgg_is_dtype(dtype)) return SGG_ERR_DTYPE;
+    const size_t esz = sgg_elem_size(dtype);
     // channel slices per RoI only when the LDS tile would not fit (measured: slicing for occupancy is slower, the
     // kernel is bound by the per-RoI sample setup and gathers, not by resident waves); slices stay multiples of 8
     // channels and (CS*P*P) a multiple of 8 elements so that every store is a full 16-byte piece
@@ -674,27 +663,15 @@ extern "C" int sgg_roi_align_fwd(const void* fmap, int B, int H, int W, int C, c
     while ((size_t)P * P * (C / nsplit + 8) * esz > 104 * 1024 && (C / nsplit) % 16 == 0 && nsplit < 16) nsplit *= 2;
     const size_t smem = (size_t)P * P * (C / nsplit + 8) * esz;
     if (smem > 150 * 1024 || C % (8 * nsplit)) return SGG_ERR_ARG;
-    if (dtype == SGG_BF16) {
-        static bool done = false;
-        if (!done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+    static bool done[3] = {false, false, false};
+    SGG_FOR_DTYPE(dtype,
+        if (!done[dtype]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
                 return SGG_ERR_LAUNCH;
-            done = true;
+            done[dtype] = true;
         }
-        hipLaunchKernelGGL(roi_align_kernel<bf16_t>, dim3(R, nsplit), dim3(roi_threads()), smem, (hipStream_t)stream, (const bf16_t*)fmap, B, H, W, C,
-                           rois, pairs, R, spatial_scale, P, sampling, add_ec, (bf16_t*)out);
-    } else if (dtype == SGG_F32) {
-        static bool done = false;
-        if (!done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-                return SGG_ERR_LAUNCH;
-            done = true;
-        }
-        hipLaunchKernelGGL(roi_align_kernel<float>, dim3(R, nsplit), dim3(roi_threads()), smem, (hipStream_t)stream, (const float*)fmap, B, H, W, C,
-                           rois, pairs, R, spatial_scale, P, sampling, add_ec, (float*)out);
-    } else {
-        return SGG_ERR_DTYPE;
-    }
+        hipLaunchKernelGGL(roi_align_kernel<T>, dim3(R, nsplit), dim3(roi_threads()), smem, (hipStream_t)stream, (const T*)fmap, B, H, W, C,
+                           rois, pairs, R, spatial_scale, P, sampling, add_ec, (T*)out));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

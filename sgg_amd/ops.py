@@ -13,6 +13,18 @@ from ._lib import ACT_NONE, ACT_RELU, SGG_BF16, SGG_F16, SGG_F32  # noqa: F401
 _DT = {torch.float32: SGG_F32, torch.bfloat16: SGG_BF16, torch.float16: SGG_F16}
 
 
+HALF = (torch.bfloat16, torch.float16)     # the two 16-bit storage / MFMA operand formats (same kernels, same rates)
+
+
+def is_half(t):
+    return (t.dtype if isinstance(t, torch.Tensor) else t) in HALF
+
+
+def _ws(n, device):
+    """f32 scratch for a two-stage reduction (partial rows summed in a fixed order: no float atomics anywhere in a step)"""
+    return torch.empty(max(int(n), 1), dtype=torch.float32, device=device)
+
+
 def dt(t):
     try:
         return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
@@ -282,7 +294,7 @@ def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None
         return out
     # short-M, long-K contractions (fc6 on the object rows) do not fill the chip with output tiles: split K
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    kt = K // (64 if A.dtype == torch.bfloat16 else 32)
+    kt = K // (64 if is_half(A) else 32)
     can_split = A2 is None and N % 8 == 0 and out.is_contiguous() and A.stride(0) >= K and W.stride(0) >= K
     if can_split and ((splits is None and tiles <= 96 and kt >= 64) or (splits is not None and splits > 1)):
         if splits is None:
@@ -364,7 +376,7 @@ def gemm_full_waves(A, W, out_dtype=None, gadd=None):
     N = W.shape[0]
     tm, tn = M // 256, N // 256
     rem = (tm * tn) % N_CU
-    kt = K // (64 if A.dtype == torch.bfloat16 else 32)
+    kt = K // (64 if is_half(A) else 32)
 
     def main(Wp, out, col0=0):
         if gadd is None:
@@ -389,8 +401,8 @@ def gemm_full_waves(A, W, out_dtype=None, gadd=None):
 
 
 def gemm_tn_ok(A, B):
-    """Shapes / dtypes sgg_gemm_tn takes (bf16, reduction rows % 64, both column counts % 128, 16-byte aligned rows)."""
-    return (A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.shape[0] == B.shape[0] and A.shape[0] % 64 == 0 and
+    """Shapes / dtypes sgg_gemm_tn takes (one 16-bit format, reduction rows % 64, both column counts % 128, 16-byte aligned rows)."""
+    return (is_half(A) and B.dtype == A.dtype and A.shape[0] == B.shape[0] and A.shape[0] % 64 == 0 and
             A.shape[1] % 128 == 0 and B.shape[1] % 128 == 0 and A.stride(1) == 1 and B.stride(1) == 1 and
             A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
 
@@ -408,7 +420,7 @@ def gemm_tn(A, B, out_dtype=torch.float32, out=None, splits=None):
             splits = max(1, min(16, 512 // tiles, Mred // 256))
     ws = torch.empty((splits, N, K), dtype=torch.float32, device=A.device) if splits > 1 else None
     _lib.call('sgg_gemm_tn', _p(A, rows_ok=True), A.stride(0), _p(B, rows_ok=True), B.stride(0), _p(out, rows_ok=True),
-              out.stride(0), Mred, N, K, dt(out), splits, _p(ws) if ws is not None else None, _stream())
+              out.stride(0), Mred, N, K, dt(A), dt(out), splits, _p(ws) if ws is not None else None, _stream())
     return out
 
 
@@ -537,40 +549,25 @@ def act_bwd(dy, y, scale=1.0):
     return dx
 
 
-def ce_fwd_bwd(logits, labels, norm, weight, loss, grad):
-    """loss[0] += weight / norm[0] * sum CE(logits, labels); grad [M, ldg] (bf16 / f32, zero-padded columns) = d loss / d logits.
-    logits f32 [M,C]; labels i64, any 1-D view (e.g. a column of rel_labels); norm, loss: f32 device scalars."""
+def ce_fwd_bwd(logits, labels, norm, weight, loss, grad, grad_scale=1.0, flag=None):
+    """loss[0] += weight / norm[0] * sum CE(logits, labels); grad [M, ldg] (16-bit / f32, zero-padded columns) = grad_scale * d loss / d logits.
+    logits f32 [M,C]; labels i64, any 1-D view (e.g. a column of rel_labels); norm, loss: f32 device scalars; flag (optional i32[1]):
+    bit 0 is raised when a label lies outside [0, C) (that row adds no loss and gets a zero gradient)."""
     M, C = logits.shape
     assert logits.dtype == torch.float32 and logits.stride(1) == 1 and labels.dtype == torch.int64 and labels.dim() == 1
     assert grad.shape[0] == M and grad.shape[1] >= C and grad.stride(1) == 1
+    ws = _ws((M + 3) // 4, logits.device)
     _lib.call('sgg_ce_fwd_bwd', logits.data_ptr(), logits.stride(0), labels.data_ptr(), labels.stride(0), M, C, norm.data_ptr(),
-              float(weight), loss.data_ptr(), grad.data_ptr(), grad.stride(0), dt(grad), _stream())
-
-
-class ZeroPool(object):
-    """One zero-filled f32 workspace, carved into slices: the accumulate-with-atomics kernels (column sums = bias gradients) then
-    need one fill launch per backward pass instead of one memset per call."""
-
-    def __init__(self, nfloats, device):
-        self.buf = torch.zeros(nfloats, dtype=torch.float32, device=device)
-        self.used = 0
-
-    def take(self, n):
-        n_al = (n + 3) // 4 * 4                       # 16-byte aligned slices
-        if self.used + n_al > self.buf.numel():
-            return None
-        out = self.buf[self.used:self.used + n]
-        self.used += n_al
-        return out
+              float(weight), float(grad_scale), loss.data_ptr(), grad.data_ptr(), grad.stride(0), _p(ws), _p(flag, torch.int32) if flag is not None else None,
+              dt(grad), _stream())
 
 
 def colsum(x, pool=None):
+    """column sums of x[M,N] (bias gradients), f32[N]: row blocks' partial sums added in a fixed order (`pool`: unused, kept for callers)"""
     M, N = x.shape
-    out = pool.take(N) if pool is not None else None
-    zero = 0 if out is not None else 1
-    if out is None:
-        out = torch.empty(N, dtype=torch.float32, device=x.device)
-    _lib.call('sgg_colsum', _p(x, rows_ok=True), M, N, x.stride(0), _p(out), zero, dt(x), _stream())
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    ws = _ws(64 * N, x.device) if M > 512 else None
+    _lib.call('sgg_colsum', _p(x, rows_ok=True), M, N, x.stride(0), _p(out), _p(ws) if ws is not None else None, dt(x), _stream())
     return out
 
 
@@ -582,7 +579,7 @@ def bn_train(x, gamma, beta, run_mean, run_var, eps, momentum, max4, reduce_fn=N
     M, C = x.shape
     dev = x.device
     sums = torch.empty(2 * C + 1, dtype=torch.float32, device=dev)      # [sum x | sum x^2 | row count]
-    _lib.call('sgg_bn_stats', _p(x), M, C, _p(sums), dt(x), _stream())
+    _lib.call('sgg_bn_stats', _p(x), M, C, _p(sums), _p(_ws(64 * 2 * C, dev)), dt(x), _stream())
     count_dev = None
     if reduce_fn is not None:
         sums[2 * C:].fill_(float(M))
@@ -607,7 +604,8 @@ def bn_bwd(dy, arg, x, mean, invstd, gamma, max4, reduce_fn=None):
     rows, C = x.shape
     dx = torch.empty_like(x)
     sums = torch.empty(2 * C + 1, dtype=torch.float32, device=x.device)
-    args = (_p(dy), _p(arg) if max4 else None, _p(x), _p(mean), _p(invstd), _p(gamma, torch.float32), _p(dx), _p(sums),
+    ws = _ws(64 * 2 * C, x.device)
+    args = (_p(dy), _p(arg) if max4 else None, _p(x), _p(mean), _p(invstd), _p(gamma, torch.float32), _p(dx), _p(sums), _p(ws),
             rows, C, int(max4))
     if reduce_fn is None:
         _lib.call('sgg_bn_bwd', *args, 0, None, dt(x), _stream())
@@ -664,8 +662,8 @@ def imp_node_gates_bwd(da, csr, gate_w, d_v, nsum=None):
 def rank4_reduce_(a, x, out, col0=0):
     """out[k, col0:col0+H] += sum_r a[r,k] * x[r,:]   (out f32 [4, ld])"""
     R, H = x.shape
-    _lib.call('sgg_rank4_reduce', _p(a, torch.float32), _p(x), R, H, out.data_ptr() + 4 * col0, out.stride(0), dt(x),
-              _stream())
+    _lib.call('sgg_rank4_reduce', _p(a, torch.float32), _p(x), R, H, out.data_ptr() + 4 * col0, out.stride(0), _p(_ws(64 * 4 * H, x.device)),
+              dt(x), _stream())
 
 
 def transpose(x, pad_to=64, dtype=None, add=None, group=1, want_colsum=False):
@@ -676,9 +674,10 @@ def transpose(x, pad_to=64, dtype=None, add=None, group=1, want_colsum=False):
     dtype = dtype or x.dtype
     out = (torch.zeros if Rp != R else torch.empty)((C, Rp), dtype=dtype, device=x.device)
     cs = torch.empty(C, dtype=torch.float32, device=x.device) if want_colsum else None
+    ws = _ws((R + 63) // 64 * C, x.device) if want_colsum else None
     _lib.call('sgg_transpose', _p(x, rows_ok=True), x.stride(0), _p(out), Rp, R, C,
               _p(add, torch.float32) if add is not None else None, add.stride(0) if add is not None else 0, group,
-              _p(cs) if want_colsum else None, dt(x), dt(out), _stream())
+              _p(cs) if want_colsum else None, _p(ws) if want_colsum else None, dt(x), dt(out), _stream())
     return (out, cs) if want_colsum else out
 
 

@@ -59,7 +59,7 @@ def to_nhwc(x, dtype):
     v = x.permute(0, 2, 3, 1)
     if v.is_contiguous():
         return v if v.dtype == dtype else ops.cast(v, dtype)
-    if x.dtype not in (torch.float32, torch.bfloat16):
+    if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
         x = x.float()
     return ops.permute_ncp_to_npc(x.reshape(R, C, Ph * Pw), dtype).view(R, Ph, Pw, C)
 
@@ -67,7 +67,7 @@ def to_nhwc(x, dtype):
 def to_rows(x, dtype):
     """RoI features [R,C,P,P] (any strides / float dtype) -> contiguous [R, C*P*P] in `dtype` (fc6's A operand)."""
     R = x.shape[0]
-    if x.dtype not in (torch.float32, torch.bfloat16):
+    if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
         x = x.float()
     x = x.contiguous()                      # no-op for the tensors RoIAlign produced
     if x.dtype != dtype:
@@ -92,7 +92,7 @@ class _RoIFeatures(torch.autograd.Function):
     def backward(ctx, d_node, d_edge):
         rois, union_inds = ctx.saved_tensors
         shape, scale, in_dtype = ctx.meta
-        prep = lambda g: g.contiguous() if g.dtype in (torch.float32, torch.bfloat16) else g.float().contiguous()
+        prep = lambda g: g.contiguous() if g.dtype in (torch.float32, torch.bfloat16, torch.float16) else g.float().contiguous()
         d_fm = ops.roi_align_bwd(prep(d_node), shape, rois, None, scale)
         ops.roi_align_bwd(prep(d_edge), shape, rois, union_inds, scale, d_fmap=d_fm)
         return d_fm.permute(0, 3, 1, 2).to(in_dtype), None, None, None, None, None
@@ -176,7 +176,10 @@ class RelModelBase(nn.Module):
         raise NotImplementedError('forward')
 
     def set_compute_dtype(self, dtype):
-        """torch.float32 = exact-fp32 MFMA parity mode; torch.bfloat16 = throughput mode (fp32 accumulate)."""
+        """torch.float32 = exact-fp32 MFMA mode (the reference's own precision: the 1e-3 parity bar); torch.float16 / torch.bfloat16 =
+        16-bit storage and MFMA operands with fp32 accumulation -- the same kernels at the same rates.  float16 (11-bit significand) is the
+        throughput mode whose logits stay within 0.1 / 0.03 of the reference's (DESIGN.md "f16"); bfloat16 (8 bits, wider exponent) is kept
+        as BASELINE.json words its configuration: 8 times the rounding error, no loss scaling needed in training."""
         ops.dt(dtype)
         self.compute_dtype = dtype
         return self

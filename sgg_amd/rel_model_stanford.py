@@ -95,10 +95,10 @@ class RelModelStanford(RelModelBase):
         return sh
 
     def shadow_buffers(self):
-        """{param name: bf16 buffer} the optimiser may refresh in place of a later cast (empty in fp32 mode)."""
-        if self.compute_dtype != torch.bfloat16:
+        """{param name: 16-bit buffer} the optimiser may refresh in place of a later cast (empty in fp32 mode)."""
+        if not ops.is_half(self.compute_dtype):
             return {}
-        return {n: t for n, t in self._shadow.items() if t.dtype == torch.bfloat16}
+        return {n: t for n, t in self._shadow.items() if t.dtype == self.compute_dtype}
 
     def mark_shadow_fresh(self, names):
         """The optimiser just wrote these shadows from the updated masters (call after weights_version moved)."""
@@ -115,7 +115,7 @@ class RelModelStanford(RelModelBase):
         ri3 = torch.cat((rel_inds.new_zeros((rel_inds.shape[0], 1)), rel_inds), 1).contiguous()
         csr = ops.edge_csr(ri3, obj_rep.shape[0])
         cast = lambda t: t.contiguous() if t.dtype == dtype else ops.cast(t.float() if t.dtype not in
-                                                                          (torch.float32, torch.bfloat16) else t, dtype)
+                                                                          (torch.float32, torch.bfloat16, torch.float16) else t, dtype)
         return message_pass(cast(rel_rep), cast(obj_rep), ri3, csr, w['imp'], self.mp_iter, dtype)
 
     def predict(self, node_feat, edge_feat, rel_inds, rois, im_sizes, _im_inds=None, _graphs=None):

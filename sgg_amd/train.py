@@ -46,13 +46,13 @@ def _pad_cols(x, mult, dtype):
 USE_TN = True      # tests flip this to cross-check the TN kernel against the transposes + NT path at benchmark grid sizes
 
 
-def tn_gemm(X, Y, out=None, want_colsum=False, out_dtype=torch.float32, pool=None):
+def tn_gemm(X, Y, out=None, want_colsum=False, out_dtype=torch.float32):
     """X[M,a]^T . Y[M,b] -> f32 [a,b]  (weight gradients).  Rows are zero-padded to a multiple of 64 by the transposes.
     want_colsum: also return colsum(X) (the bias gradient when X = dY), computed inside X's transpose pass."""
     if out is None and USE_TN and ops.gemm_tn_ok(X, Y):
-        # bf16, aligned shapes: the TN kernel reads dY and X as they lie (no transposed copies); bias gradient = colsum(dY)
+        # 16-bit, aligned shapes: the TN kernel reads dY and X as they lie (no transposed copies); bias gradient = colsum(dY)
         dw = ops.gemm_tn(X, Y, out_dtype=out_dtype)
-        return (dw, ops.colsum(X, pool)) if want_colsum else dw
+        return (dw, ops.colsum(X)) if want_colsum else dw
     if want_colsum:
         xt, cs = ops.transpose(X, want_colsum=True)
         return ops.gemm(xt, ops.transpose(Y), out_dtype=out_dtype, out=out), cs
@@ -140,7 +140,7 @@ class PredictFn(torch.autograd.Function):
         # backward's critical path.  The buffer is allocated under that stream and handed back to it when sv is dropped.
         from .imp import node_lane
         lane = node_lane(dev)
-        if lane is not None and dt == torch.bfloat16:
+        if lane is not None and ops.is_half(dt):
             side, ev_main, _ = lane
             ev_main.record(torch.cuda.current_stream(dev))
             side.wait_event(ev_main)                                 # ef and rect are ready
@@ -234,7 +234,6 @@ class PredictFn(torch.autograd.Function):
         csr = sv['csr']
         dev = XN.device
         G = {}
-        pool = ops.ZeroPool(32768, dev)     # zeroed once: every bias-gradient column sum of this pass accumulates into a slice of it
         rows = lambda buf, c, n: buf[c * n:(c + 1) * n]
         # Data-parallel hooks (set by the trainer): a big gradient is handed over the moment it exists so that its
         # all-reduce overlaps the rest of the backward; with a bf16 wire the GEMM emits the wire dtype directly.
@@ -265,15 +264,15 @@ class PredictFn(torch.autograd.Function):
             def dw():
                 _lib.set_tag(tag)
                 n_out = dY.shape[1] if not prepadded else n_out_
-                if (n_out % 128 or prepadded) and dt == torch.bfloat16 and not big:
+                if (n_out % 128 or prepadded) and ops.is_half(dt) and not big:
                     # narrow heads (151 / 51 outputs): zero-pad dY to 128 columns so that the TN kernel takes it
                     dYp = dY if prepadded else _pad_cols(dY, 128, dt)
                     if USE_TN and ops.gemm_tn_ok(dYp, X):
                         G[name + '.weight'] = ops.gemm_tn(dYp, X)[:n_out].contiguous()
-                        G[name + '.bias'] = ops.colsum(dYp, pool)[:n_out].contiguous()
+                        G[name + '.bias'] = ops.colsum(dYp)[:n_out].contiguous()
                         return
                 dYr = dY[:, :n_out].contiguous() if prepadded else dY
-                G[name + '.weight'], G[name + '.bias'] = tn_gemm(dYr, X, want_colsum=True, pool=pool,
+                G[name + '.weight'], G[name + '.bias'] = tn_gemm(dYr, X, want_colsum=True,
                                                                  out_dtype=big_dtype() if big else torch.float32)
                 if big:
                     hook(name + '.weight')
@@ -289,7 +288,7 @@ class PredictFn(torch.autograd.Function):
         _lib.set_tag('bwd_heads')
         pre = getattr(model, '_logit_grads', None)       # Trainer's fused loss: (d_obj [N,256], d_rel [E,128]) in dt, zero-padded
         model._logit_grads = None
-        if pre is not None and dt == torch.bfloat16 and pre[0].dtype == dt and pre[0].shape[0] == N and pre[1].shape[0] == E:
+        if pre is not None and ops.is_half(dt) and pre[0].dtype == dt and pre[0].shape[0] == N and pre[1].shape[0] == E:
             d_v = lin_bwd(pre[0], rows(HN, T, N), t['obj_fc_t'], 'obj_fc', 'bwd_heads', n_out=d_obj.shape[1])
             d_e = lin_bwd(pre[1], rows(HE, T, E), t['rel_fc_t'], 'rel_fc', 'bwd_heads', n_out=d_rel.shape[1])
         else:
@@ -375,7 +374,7 @@ class PredictFn(torch.autograd.Function):
             # rows of the unordered pairs: d W6[n,(c,p)] = sum_u (d_pre6[e1(u),n] + d_pre6[e2(u),n]) pooled[u,c,p]  +  (sum_e d_pre6[e,n] rect[e,c])
             # broadcast over p -- the second term is the gradient through W6's group sums (the folded rect term of the forward)
             d6t = ops.transpose_pairsum(d_pre6, paired.u2e)
-            G[n6e + '.bias'] = ops.colsum(d_pre6, pool)
+            G[n6e + '.bias'] = ops.colsum(d_pre6)
             G[n6e + '.weight'] = ops.gemm_full_waves(d6t, x6t, out_dtype=big_dtype(), gadd=(tn_gemm(d_pre6, sv['rect']), PP))
         else:
             d6t, G[n6e + '.bias'] = ops.transpose(d_pre6, want_colsum=True)
@@ -383,7 +382,7 @@ class PredictFn(torch.autograd.Function):
         hook(n6e + '.weight')
         del x6t, d6t
         _lib.set_tag('bwd_mlp_obj')
-        G[n6o + '.weight'], G[n6o + '.bias'] = tn_gemm(d_p6, sv['nf'], want_colsum=True, pool=pool, out_dtype=big_dtype())
+        G[n6o + '.weight'], G[n6o + '.bias'] = tn_gemm(d_p6, sv['nf'], want_colsum=True, out_dtype=big_dtype())
         hook(n6o + '.weight')
         # ---- phase C: everything deferred, largest first (fc7 x2 carry their own hooks)
         for dw in deferred[::-1]:                      # fc7 node, unary node, fc7 edge, unary edge, heads
@@ -391,12 +390,12 @@ class PredictFn(torch.autograd.Function):
         _lib.set_tag('bwd_imp')
         # GRU parameter gradients: one contraction over the 4 stacked calls; hidden state of call 0 is zero
         G['edge_gru.weight_ih'] = tn_gemm(DG[T * E:], XH[:E + T * N])           # [d_gi of call 0 ; dP_0 ..]^T . [rel_rep ; v_0 ..]
-        G['edge_gru.bias_ih'] = ops.colsum(DG[:(T + 1) * E], pool)
+        G['edge_gru.bias_ih'] = ops.colsum(DG[:(T + 1) * E])
         G['edge_gru.weight_hh'] = tn_gemm(dGHe[E:], HE[:T * E])              # states entering calls 1..T (call 0: zero state)
-        G['edge_gru.bias_hh'] = ops.colsum(dGHe, pool)                          # b_hh acts in every call
-        G['node_gru.weight_ih'], G['node_gru.bias_ih'] = tn_gemm(dGIn, XN, want_colsum=True, pool=pool)
+        G['edge_gru.bias_hh'] = ops.colsum(dGHe)                          # b_hh acts in every call
+        G['node_gru.weight_ih'], G['node_gru.bias_ih'] = tn_gemm(dGIn, XN, want_colsum=True)
         G['node_gru.weight_hh'] = tn_gemm(dGHn[N:], HN[:T * N])
-        G['node_gru.bias_hh'] = ops.colsum(dGHn, pool)
+        G['node_gru.bias_hh'] = ops.colsum(dGHn)
         ops.rank4_reduce_(da_all, HE[:T * E], d_gw, col0=H)         # e_i = rows i of HE, v_i = rows i of HN
         ops.rank4_reduce_(nsum_all, HN[:T * N], d_gw, col0=0)
         ops.rank4_reduce_(da_all, ones, d_gb)
@@ -409,7 +408,7 @@ class PredictFn(torch.autograd.Function):
         bn_sync = getattr(model, '_bn_sync', None)
         d_c2, db2, dg2 = ops.bn_bwd(d_rect, None, sv['h3'], sv['m2'], sv['is2'], t['rc_g2'], False, bn_sync)
         G['union_boxes.conv.6.weight'], G['union_boxes.conv.6.bias'] = dg2, db2
-        gw2, gb2 = tn_gemm(d_c2, sv['h2'], want_colsum=True, pool=pool)                       # [d, d2] centre tap
+        gw2, gb2 = tn_gemm(d_c2, sv['h2'], want_colsum=True)                       # [d, d2] centre tap
         full = torch.zeros(tuple(model.union_boxes.conv[4].weight.shape), dtype=torch.float32, device=dev)
         full[:, :, 1, 1] = gw2
         G['union_boxes.conv.4.weight'] = full
@@ -417,7 +416,7 @@ class PredictFn(torch.autograd.Function):
         d_h2 = ops.gemm(d_c2, t['rc_w2_t'])                                        # [E,d2]
         d_c1, db1, dg1 = ops.bn_bwd(d_h2, sv['arg'], sv['h1'], sv['m1'], sv['is1'], t['rc_g1'], True, bn_sync)
         G['union_boxes.conv.2.weight'], G['union_boxes.conv.2.bias'] = dg1, db1
-        gw1, gb1 = tn_gemm(d_c1, sv['patches'], want_colsum=True, pool=pool)                  # [d2,128]
+        gw1, gb1 = tn_gemm(d_c1, sv['patches'], want_colsum=True)                  # [d2,128]
         G['union_boxes.conv.0.weight'] = gw1[:, :98].reshape(tuple(model.union_boxes.conv[0].weight.shape)).contiguous()
         G['union_boxes.conv.0.bias'] = gb1
         _lib.set_tag('')

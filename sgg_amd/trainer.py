@@ -35,6 +35,8 @@ class FusedSGD(torch.optim.Optimizer):
         self.steps = 0
         self._norm = None
         self._norm_parts = None
+        self._norm_ws = None
+        self.sync_norm = False     # data-parallel: every rank clips with the SAME squared norm (Trainer turns it on)
         self.stale_masters = {}    # sharded data-parallel steps: {param: (lo, hi)} whose fp32 master is current only in [lo, hi)
         self.momentum_parts = {}   # ... and whose momentum buffer is
         self.on_update = None
@@ -61,6 +63,7 @@ class FusedSGD(torch.optim.Optimizer):
         dev = next(self.params()).device
         if self._norm is None:
             self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._norm_ws = torch.empty(2048, dtype=torch.float32, device=dev)      # partial sums of sgg_sqnorm_multi (fixed-order reduction)
         self._norm.zero_()
         grads = grads or {}
         shards = {p: r for p, r in (shards or {}).items() if r is not None}
@@ -95,7 +98,7 @@ class FusedSGD(torch.optim.Optimizer):
             self._norm_parts = torch.zeros(1, dtype=torch.float32, device=dev)
         pending = []
         for part in (False, True):                              # whole tensors first, then this rank's parts of the sharded ones
-            for dtype in (torch.float32, torch.bfloat16):      # gradients arrive fp32 (local) or bf16 (off the wire)
+            for dtype in (torch.float32, torch.bfloat16, torch.float16):      # gradients arrive fp32 (local) or 16-bit (off the wire)
                 sel = [t for t in live if t[1].dtype == dtype and (t[0] in shards) == part]
                 if not sel:
                     continue
@@ -110,17 +113,24 @@ class FusedSGD(torch.optim.Optimizer):
                 lr = np.ascontiguousarray(np.array([l for _, _, l in sel], dtype=np.float32))
                 if norm is not None:
                     acc = self._norm_parts.data_ptr() if part else norm
-                    _lib.call('sgg_sqnorm_multi', gp.ctypes.data, nn.ctypes.data, len(sel), acc, ops.dt(sel[0][1]), stream)
+                    _lib.call('sgg_sqnorm_multi', gp.ctypes.data, nn.ctypes.data, len(sel), acc, self._norm_ws.data_ptr(), ops.dt(sel[0][1]), stream)
                 pending.append((dtype, gp, pp, bp, sp, nn, lr, len(sel), sel))
-        if shards and norm is not None:                         # the parts' squared norms of all ranks join the replicated ones
+        if norm is not None and (shards or self.sync_norm):
+            # the parts' squared norms of all ranks join the replicated tensors' one, and EVERY rank ends up with the same number: the
+            # replicated share travels as norm / world (the reduced gradients are the same bits on every rank and the local reduction
+            # order is fixed, so the shares are equal and their sum is the local value again -- exactly, for power-of-two worlds; ranks
+            # that disagreed in a last bit would get the mean instead of drifting apart), the parts as they are
             import torch.distributed as dist
-            dist.all_reduce(self._norm_parts, op=dist.ReduceOp.SUM)
-            self._norm.add_(self._norm_parts)
-            self._norm_parts.zero_()
+            world = dist.get_world_size()
+            pair = torch.stack((self._norm[0] / world, self._norm_parts[0] if self._norm_parts is not None else self._norm.new_zeros(())))
+            dist.all_reduce(pair, op=dist.ReduceOp.SUM)
+            self._norm.copy_((pair[0] + pair[1]).view(1))
+            if self._norm_parts is not None:
+                self._norm_parts.zero_()
         for dtype, gp, pp, bp, sp, nn, lr, cnt, _keep in pending:  # every norm contribution lands before the first update
             _lib.call('sgg_sgd_multi', pp.ctypes.data, gp.ctypes.data, bp.ctypes.data, sp.ctypes.data, nn.ctypes.data,
                       lr.ctypes.data, cnt, float(wd), float(mom), int(first), norm,
-                      float(self.clip or 0.0), float(grad_scale), ops.dt(dtype), int(self.max_blocks), stream)
+                      float(self.clip or 0.0), float(grad_scale), ops.dt(dtype), self._shadow_dt(shadows), int(self.max_blocks), stream)
         if shards:                                              # every rank gets every part of the updated operands
             import torch.distributed as dist
             for p, _, _ in live:
@@ -141,8 +151,16 @@ class FusedSGD(torch.optim.Optimizer):
             self.on_update()   # parameters changed through raw pointers: tell the owner to refresh derived operands
         return None
 
-    def grad_norm(self):
-        return float(self._norm.sqrt().item())
+    @staticmethod
+    def _shadow_dt(shadows):
+        for t in shadows.values():
+            if t is not None:
+                return ops.dt(t)
+        return _lib.SGG_BF16
+
+    def grad_norm(self, grad_scale=1.0):
+        """global gradient norm of the last step (of the UNSCALED gradients when the step's grad_scale is passed)"""
+        return float(self._norm.sqrt().item()) * float(grad_scale)
 
     @torch.no_grad()
     def gather_masters(self, momentum=True):
@@ -198,6 +216,11 @@ class Trainer(object):
         # Every update still happens, in order; read parameters through flush() in this mode.
         self.pipeline = pipeline
         self.fused_loss = True          # step(): loss + logit gradients by sgg_ce_fwd_bwd where it applies (tests flip it to compare)
+        # f16 compute: activation gradients are 16-bit tensors with five exponent bits -- the loss is scaled by `loss_scale` on the way
+        # into the backward (every backward kernel is linear in the incoming gradient) and the optimiser divides it out again
+        # (grad_scale of sgg_sgd_multi, applied in fp32; the clip works on the unscaled norm).  A step whose scaled gradients overflow
+        # has a non-finite norm: the update kernels skip it.  bf16 / f32: scale 1.
+        self.loss_scale_f16 = float(os.environ.get('SGG_LOSS_SCALE', '1024'))
         self._norm_cache = {}
         if pipeline:
             self.opt.max_blocks = int(os.environ.get('SGG_OPT_BLOCKS', '256'))   # leave wave slots for the VGG forward running beside the update
@@ -207,6 +230,7 @@ class Trainer(object):
         self.dist_on = self.world > 1 or (force_dist and dist.is_available() and dist.is_initialized())
         self._local = {}          # one GPU: wire-dtype gradients of the big tensors, kept out of autograd for the optimiser
         self._local_wire = comm_dtype if comm_dtype == torch.bfloat16 else None
+        self.opt.sync_norm = self.dist_on and self.world > 1
         if not self.dist_on and self._local_wire is not None:
             by_name_l = dict(named)
 
@@ -272,6 +296,10 @@ class Trainer(object):
         full = torch.empty((rows, part.shape[1]), dtype=part.dtype, device=part.device)
         dist.all_gather_into_tensor(full.view(-1), part.reshape(-1))
         return full
+
+    @property
+    def loss_scale(self):
+        return self.loss_scale_f16 if self.model.compute_dtype == torch.float16 else 1.0
 
     def _shards(self, reduced):
         return {p: self.buckets.shard_of(p) for p in reduced} if self.shard_optimizer else None
@@ -340,8 +368,10 @@ class Trainer(object):
         d_rel = torch.empty((E, 128), dtype=dt_, device=dev)
         alpha, beta, gamma = self.loss_weights
         assert alpha == beta == 1, ('wrong loss is used, use dnorm or dnorm-fgbg', alpha, beta)          # lib/losses.py:41
-        ops.ce_fwd_bwd(res.rm_obj_dists.detach(), res.rm_obj_labels, norm[0:1], 1.0, loss, d_obj)
-        ops.ce_fwd_bwd(res.rel_dists.detach(), res.rel_labels[:, -1], norm[1:2], gamma, loss, d_rel)
+        if getattr(self, '_label_flag', None) is None:
+            self._label_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.ce_fwd_bwd(res.rm_obj_dists.detach(), res.rm_obj_labels, norm[0:1], 1.0, loss, d_obj, self.loss_scale, self._label_flag)
+        ops.ce_fwd_bwd(res.rel_dists.detach(), res.rel_labels[:, -1], norm[1:2], gamma, loss, d_rel, self.loss_scale, self._label_flag)
         m._logit_grads = (d_obj, d_rel)
         return loss[0]
 
@@ -375,6 +405,12 @@ class Trainer(object):
             self.opt.gather_masters()
         if hasattr(self.model, 'check_pair_flag'):
             self.model.check_pair_flag(wait=True)     # the last steps' pair-table flags (rel_model_stanford._watch_pair_flag)
+        flag = getattr(self, '_label_flag', None)
+        if flag is not None and int(flag.item()) != 0:
+            flag.zero_()
+            raise ValueError('sgg_amd: a class / predicate label outside [0, C) reached the fused cross-entropy since the last flush() '
+                             '(such rows added no loss and got zero gradients; F.cross_entropy\'s ignore_index behaves like that, any other '
+                             'value is a data error)')
 
     def _queue_update(self):
         """pipeline mode: wait for the gradient all-reduce, optimiser step and operand rebuild, all on the side stream
@@ -395,7 +431,7 @@ class Trainer(object):
             reduced = self.buckets.all_reduce(average=False) if self.dist_on else dict(self._local)
             for t in (reduced or {}).values():
                 t.record_stream(side)
-            self.opt.step(grads=reduced, shards=self._shards(reduced) if self.dist_on else None)
+            self.opt.step(grad_scale=1.0 / self.loss_scale, grads=reduced, shards=self._shards(reduced) if self.dist_on else None)
             train_weights(self.model)
             ev = torch.cuda.Event()
             ev.record(side)
@@ -406,12 +442,12 @@ class Trainer(object):
         self.model.train()
         if not self._queued:
             self._prefetch_operands()
-        local = not self.dist_on and getattr(self, '_keep', None) is not None and self.model.compute_dtype == torch.bfloat16
+        local = not self.dist_on and getattr(self, '_keep', None) is not None and ops.is_half(self.model.compute_dtype)
         if not self.dist_on:
             self._local = {}
         res = self.model([batch])
         # the fused loss covers what the benchmark runs: 'baseline' CE, bf16 compute, logits straight out of predict()
-        fused = (self.fused_loss and self.loss_type == 'baseline' and self.model.compute_dtype == torch.bfloat16 and
+        fused = (self.fused_loss and self.loss_type == 'baseline' and ops.is_half(self.model.compute_dtype) and
                  not getattr(self.model, 'use_bias', False) and res.rm_obj_dists.shape[1] <= 256 and res.rel_dists.shape[1] <= 128)
         loss = self._fused_losses(res) if fused else self.losses(res)
         self.opt.zero_grad()
@@ -423,7 +459,7 @@ class Trainer(object):
                 torch.autograd.backward([res.rm_obj_dists, res.rel_dists],
                                         [torch.empty_like(res.rm_obj_dists), torch.empty_like(res.rel_dists)])
             else:
-                loss.backward()
+                (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
         finally:
             self.model._logit_grads = None
             if local:
@@ -431,6 +467,6 @@ class Trainer(object):
         self._queued = self.pipeline and self._queue_update()
         if not self._queued:
             reduced = self.buckets.all_reduce(average=False) if self.dist_on else dict(self._local)
-            self.opt.step(grads=reduced, shards=self._shards(reduced) if self.dist_on else None)
+            self.opt.step(grad_scale=1.0 / self.loss_scale, grads=reduced, shards=self._shards(reduced) if self.dist_on else None)
         self.model.global_batch_iter = getattr(self.model, 'global_batch_iter', 0) + 1
         return loss.detach()

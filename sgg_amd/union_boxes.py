@@ -100,7 +100,7 @@ class UnionBoxesAndFeats(nn.Module):
         """union_pools [E,dim,7,7] -> union_pools + conv(rects) (lib/get_union_boxes.py:101), a new tensor."""
         E, C = union_pools.shape[0], union_pools.shape[1]
         x = union_pools
-        if x.dtype not in (torch.float32, torch.bfloat16):
+        if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
             x = x.float()
         rf = self.rect_feat(rois, union_inds, x.dtype, im_sizes).float().contiguous()
         x = x.contiguous().clone()

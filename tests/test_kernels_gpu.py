@@ -597,48 +597,57 @@ def test_gru_gate_proj_equals_gru_on_materialised_edge_inputs(ops, dtype, H, siz
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-def test_imp_ctx_at_chip_filling_size_is_the_matrix_core_kernel_and_matches_the_dense_formula(ops, dtype, monkeypatch):
-    """128 images x (32 nodes, 992 edges) x H = 512 -- the launch `roofline_imp_large` times: 1024 (graph, 128-byte slice) units =
-    sgg_imp_ctx_mfma_min_units(), so sgg_imp_ctx_fwd runs the persistent matrix-core kernel; checked against the dense formula (f32
-    torch on the GPU) and against the sliced kernel on the same inputs."""
+def test_imp_ctx_at_chip_filling_size_matches_the_dense_formula(ops, dtype, monkeypatch):
+    """128 images x (32 nodes, 992 edges) x H = 512 -- the launch `roofline_imp_large` times -- in the form the forward runs at that size
+    (the sliced kernel) and in the persistent matrix-core form, against the dense formula (f32 torch on the GPU); then the routing
+    threshold: from sgg_imp_ctx_mfma_min_units() (graph, 128-byte slice) units on (256 images) the matrix-core kernel runs."""
     from sgg_amd import _lib
     B, n, H = 128, 32, 512
-    assert _lib.load().sgg_imp_ctx_mfma_min_units() == B * (H * 2 // 128)
     g = torch.Generator().manual_seed(9)
-    im = torch.arange(B).repeat_interleave(n)
-    rel, _ = ops.pair_index_eval(cu(im))
-    N, E = B * n, B * n * (n - 1)
-    rel = rel[:E]
-    e = cu(torch.randn(E, H, generator=g).to(dtype))
-    nd, ed, gb = cu(torch.randn(N, 4, generator=g)), cu(torch.randn(E, 4, generator=g)), cu(torch.randn(4, generator=g))
-    csr = ops.edge_csr(rel, N, cu(im), graphs=(B, n, n * (n - 1)))
+
+    def case(B):
+        im = torch.arange(B).repeat_interleave(n)
+        rel, _ = ops.pair_index_eval(cu(im))
+        N, E = B * n, B * n * (n - 1)
+        rel = rel[:E]
+        e = cu(torch.randn(E, H, generator=g).to(dtype))
+        nd, ed, gb = cu(torch.randn(N, 4, generator=g)), cu(torch.randn(E, 4, generator=g)), cu(torch.randn(4, generator=g))
+        return rel, N, E, e, nd, ed, gb, ops.edge_csr(rel, N, cu(im), graphs=(B, n, n * (n - 1)))
+
+    def forms(args, pair=2):
+        rel, N, E, e, nd, ed, gb, csr = args
+        out = {}
+        for name, env in (('routed', None), ('mfma', 'm'), ('sliced', 's')):
+            if env:
+                monkeypatch.setenv('SGG_IMP_CTX', env)
+            else:
+                monkeypatch.delenv('SGG_IMP_CTX', raising=False)
+            out[name] = ops.imp_ctx(e, csr, N, nd, ed, gb, pair=pair)
+        monkeypatch.delenv('SGG_IMP_CTX', raising=False)
+        return out
+    args = case(B)
+    rel, N, E, e, nd, ed, gb, csr = args
     s, o = rel[:, 1], rel[:, 2]
+    tol = TOL16[dtype][1]
     for pair in (2, 0):
         ga = torch.sigmoid(nd[s, pair] + ed[:, pair] + gb[pair])
         gbv = torch.sigmoid(nd[o, pair + 1] + ed[:, pair + 1] + gb[pair + 1])
         exp_a, exp_b = _ctx_expect(e.float(), rel, ga, gbv, N)
-        monkeypatch.delenv('SGG_IMP_CTX', raising=False)
-        routed = ops.imp_ctx(e, csr, N, nd, ed, gb, pair=pair)
-        monkeypatch.setenv('SGG_IMP_CTX', 'm')
-        mfma = ops.imp_ctx(e, csr, N, nd, ed, gb, pair=pair)
-        monkeypatch.setenv('SGG_IMP_CTX', 's')
-        sliced = ops.imp_ctx(e, csr, N, nd, ed, gb, pair=pair)
-        monkeypatch.delenv('SGG_IMP_CTX', raising=False)
-        assert torch.equal(routed, mfma) and not torch.equal(routed, sliced)     # (16-bit gates in the product: not the sliced kernel's bits)
-        tol = TOL16[dtype][1]
-        for got in (routed, sliced):
+        out = forms(args, pair)
+        assert torch.equal(out['routed'], out['sliced']) and not torch.equal(out['mfma'], out['sliced'])   # (16-bit gates in the product: other bits)
+        for got in (out['mfma'], out['sliced']):
             torch.testing.assert_close(got[0].float(), exp_a, **tol)
             torch.testing.assert_close(got[1].float(), exp_b, **tol)
         csum = ops.imp_ctx(e, csr, N, nd, ed, gb, pair=pair, ctx_sum=torch.empty((N, H), dtype=dtype, device=DEV))
         torch.testing.assert_close(csum.float(), exp_a + exp_b, **tol)
-    # one unit fewer: the sliced kernel
-    keep = B - 1
-    csr2 = ops.edge_csr(rel[:keep * n * (n - 1)].contiguous(), keep * n, cu(im[:keep * n]), graphs=(keep, n, n * (n - 1)))
-    a = ops.imp_ctx(e[:keep * n * (n - 1)], csr2, keep * n, nd[:keep * n], ed[:keep * n * (n - 1)], gb)
-    monkeypatch.setenv('SGG_IMP_CTX', 's')
-    b = ops.imp_ctx(e[:keep * n * (n - 1)], csr2, keep * n, nd[:keep * n], ed[:keep * n * (n - 1)], gb)
-    monkeypatch.delenv('SGG_IMP_CTX', raising=False)
-    assert torch.equal(a, b)
+    del args, out, exp_a, exp_b
+    units = _lib.load().sgg_imp_ctx_mfma_min_units()
+    Bt = units // (H * 2 // 128)
+    out = forms(case(Bt))
+    assert torch.equal(out['routed'], out['mfma'])
+    torch.testing.assert_close(out['mfma'].float(), out['sliced'].float(), **tol)
+    out = forms(case(Bt - 1))
+    assert torch.equal(out['routed'], out['sliced'])
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
