@@ -31,7 +31,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
-MFMA_PEAK_TF = {'bf16': 2500.0, 'f32': 157.3}   # dense peaks, MI355X_MICROARCH.md
+MFMA_PEAK_TF = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}   # dense peaks, MI355X_MICROARCH.md (bf16 and f16 MFMA run at the same rate)
 
 
 def parse():
@@ -40,7 +40,8 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=8, help='images per GPU (global batch 64 at 8 GPUs)')
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--dtype', default='f16', choices=['f16', 'bf16', 'f32'],
+                    help='storage / MFMA operand format: f16 (default: the 16-bit mode that meets the parity clause), bf16 (same speed, 8x the rounding error), f32')
     ap.add_argument('--mode', default='train', choices=['train', 'infer', 'sgdet'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-f32', action='store_true', help='skip the short exact-fp32 runs reported under "f32_mode"')
@@ -324,7 +325,7 @@ def main():
 
     import sgg_amd
     from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
-    tdtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    tdtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[args.dtype]
     B = args.batch
     model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgdet' if args.mode == 'sgdet' else 'sgcls')).to(dev).eval()
     model.set_compute_dtype(tdtype)
@@ -390,8 +391,8 @@ def main():
                 res = model([batch])
                 loss = trainer.losses(res)
                 trainer.opt.zero_grad()
-                loss.backward()
-                trainer.opt.step()
+                (loss * trainer.loss_scale).backward()
+                trainer.opt.step(grad_scale=1.0 / trainer.loss_scale)
             # rank 0 alone runs these extra steps: no collective may be issued (the other ranks wait at the host-side barrier
             # below): the trainer is switched to its local form -- hooks, BatchNorm sync, loss normalisers (dist_on) and world
             with trainer.local_only():
@@ -399,7 +400,7 @@ def main():
         else:
             kt = kernel_times(infer_step, reps=5)
         E, N, H = 992 * B, 32 * B, 512
-        s = 2 if args.dtype == 'bf16' else 4
+        s = 4 if args.dtype == 'f32' else 2
         peak = MFMA_PEAK_TF[args.dtype]
         get = lambda name, tag: kt.get((name, tag), (0.0, 0))
         per_step = lambda name, tag: get(name, tag)[0] * get(name, tag)[1]
@@ -536,7 +537,7 @@ def main():
                        'pipeline': 'optimiser update of step k runs on a side stream under the frozen VGG forward of step k+1 (every update inside the timed region)'},
             'roofline': {'kernel': '256x256 ping-pong MFMA kernel (+ the 128x128 split-K launch that replaces a nearly empty last round), %s' % desc, 'bound': 'mfma', 'achieved': round(tf, 2), 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': round(tf / peak, 4),
-                         'traffic': pmc_traffic('fc6_edge_gemm' if tag == 'fc6_edge' else 'fc6_dW_gemm') if (B == 8 and args.dtype == 'bf16') else None,
+                         'traffic': pmc_traffic('fc6_edge_gemm' if tag == 'fc6_edge' else 'fc6_dW_gemm') if (B == 8 and args.dtype != 'f32') else None,
                          'ms_per_step': round(ms, 4), 'executed_flop': flop,
                          'reference_algorithm_tflops': round(ref_flop[tag] / (ms * 1e-3) / 1e12, 2),
                          'note': ('achieved = FLOPs the launch executes / its time; the reference runs this contraction on every EDGE '
@@ -566,7 +567,7 @@ def main():
             line['other_mode'] = other_line
         if pcie:
             line['pcie_inclusive'] = pcie
-        if world == 1 and not args.force_dist and args.dtype == 'bf16' and not args.no_f32 and os.environ.get('SGG_EDGE_PAIRS', '1') != '0' \
+        if world == 1 and not args.force_dist and args.dtype != 'f32' and not args.no_f32 and os.environ.get('SGG_EDGE_PAIRS', '1') != '0' \
                 and args.mode in ('train', 'infer'):
             # the same steps with the edge branch computed PER EDGE, as the reference does (SGG_EDGE_PAIRS=0): short runs beside the headline
             os.environ['SGG_EDGE_PAIRS'] = '0'
@@ -584,7 +585,7 @@ def main():
                                                '3 (train) / 2 (inference) warm-up + 8 timed steps; never `value`'}
             if el_pe is not None:
                 line['per_edge_branch'].update(train_images_per_s=round(B * 8 / el_pe, 2), train_ms_per_step=round(1e3 * el_pe / 8, 3))
-        if world == 1 and not args.force_dist and args.dtype == 'bf16' and not args.no_f32:
+        if world == 1 and not args.force_dist and args.dtype != 'f32' and not args.no_f32:
             # the reference computes in fp32: the same two steps in exact-fp32 mode (v_mfma_f32_32x32x2_f32, the mode the 1e-3 parity
             # bar is checked in), short runs, reported beside the bf16 headline -- never `value`
             if trainer is not None:

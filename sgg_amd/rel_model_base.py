@@ -145,7 +145,7 @@ class RelModelBase(nn.Module):
             from .sparse_targets import FrequencyBias
             self.freq_bias = FrequencyBias(train_data)                                # rel_model_base.py:120-121
         # HIP-path settings (not in the reference): storage/compute type of activations and weights.
-        self.compute_dtype = torch.bfloat16
+        self.compute_dtype = torch.float16       # see set_compute_dtype
         self._prep = {}
         self._shadow, self._shadow_tags = {}, {}     # compute-dtype weight copies (rel_model_stanford._shadow_cast)
 

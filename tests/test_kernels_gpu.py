@@ -40,7 +40,7 @@ def rand_boxes(rng, n):
                                    (256, 4096, 8192), (37, 512, 4096), (200, 1536, 6400),
                                    # 256x256 ping-pong kernel (N >= 256 and >= 128 tiles): ragged M/N tails, 1..many K-tiles
                                    (4096, 2048, 512), (5000, 1800, 192), (4100, 2048, 128), (4096, 2050, 64), (7936, 4096, 1024)])
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm(ops, M, N, K, dtype):
     g = torch.Generator().manual_seed(M * N + K)
     A = torch.randn(M, K, generator=g).to(dtype)
@@ -61,7 +61,7 @@ def test_gemm_transpose_detecting(ops):
     torch.testing.assert_close(out.cpu(), W.t().contiguous(), atol=1e-6, rtol=0)
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_split_k_and_affine(ops, dtype):
     g = torch.Generator().manual_seed(5)
     M, K1, K2, N = 300, 256, 128, 192
@@ -77,7 +77,7 @@ def test_gemm_split_k_and_affine(ops, dtype):
     torch.testing.assert_close(outb.float().cpu(), ref, atol=1e-4 if dtype == torch.float32 else 6e-2, rtol=0)
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_split_weights_w2(ops, dtype):
     g = torch.Generator().manual_seed(8)
     M, K1, K2, N = 5000, 1024, 512, 2048          # big enough for the 256x256 kernel too
@@ -89,7 +89,7 @@ def test_gemm_split_weights_w2(ops, dtype):
         torch.testing.assert_close(out.cpu(), ref[:rows], atol=2e-4 if dtype == torch.float32 else 8e-2, rtol=0)
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 def test_transpose_add_and_group_sum(ops, dtype):
     g = torch.Generator().manual_seed(2)
     R, C, group = 203, 7 * 24, 7
@@ -129,7 +129,7 @@ def test_gemm_rejects_bad_k(ops):
 
 
 # ----------------------------------------------------------------------------------------- conv / pool / prep
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('B,H,W,Cin,Cout', [(1, 16, 16, 64, 64), (2, 10, 14, 64, 128), (1, 38, 38, 128, 256),
                                             (2, 76, 76, 64, 1024), (3, 62, 70, 128, 512),
                                             # LDS-resident-patch kernel (H,W >= 64): ragged tiles, 1-2 channel slabs, 64/128/256 outputs
@@ -153,7 +153,7 @@ def test_conv3x3(ops, dtype, B, H, W, Cin, Cout):
             assert float(got[:, 0].min()) == 7.0 and float(got[:, :, 0].min()) == 7.0
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 def test_conv3x3_relu_with_fused_maxpool(ops, dtype):
     """conv + ReLU + MaxPool2d(2) in one kernel == the two separate kernels, bit for bit (max commutes with bias + ReLU
     and with the output rounding); sizes that leave partial 16x16 tiles on both axes."""
@@ -327,7 +327,7 @@ def test_rect_feat_pipeline_vs_reference_golden(ops, golden, tag):
     np.testing.assert_allclose(rf.cpu().numpy(), g[tag + '_rect_feat'], atol=2e-5)
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 def test_roi_align_bwd_is_the_adjoint_of_the_forward(ops, dtype):
     """sgg_roi_align_bwd: <g, RoIAlign(f)> == <RoIAlign^T(g), f> for random f, g (node boxes and fused union boxes, incl. boxes that
     leave the map and a degenerate one) -- the forward itself is checked against the oracle in test_roi_align; plus a finite-
@@ -414,7 +414,7 @@ def test_raw_boxes_raster_and_rect_feat_vs_reference_golden(ops, golden):
 
 
 # ----------------------------------------------------------------------------------------- RoIAlign
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 def test_roi_align(ops, dtype):
     rng = np.random.RandomState(4)
     B, C, H, W, N = 3, 64, 38, 38, 12
@@ -797,7 +797,7 @@ def test_eval_tail_sizes_sorted_and_permutation(ops, E):
 
 @pytest.mark.parametrize('shape', [(64, 128, 128), (256, 256, 384), (7936, 512, 256), (1024, 1536, 512),
                                    (7936, 512, 4096), (512, 4096, 2048)])   # the last two: > 256 workgroups (two per CU)
-@pytest.mark.parametrize('out_dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('out_dtype', [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_tn_matches_transposed_product(ops, shape, out_dtype):
     """sgg_gemm_tn (reduction rows staged as they lie, ds_read_b64_tr_b16 fragments) == A^T . B, single pass and split-K."""
     Mred, N, K = shape

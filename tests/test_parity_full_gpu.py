@@ -1,13 +1,15 @@
-"""Parity of the BENCHMARKED configuration (bf16 compute) against the fp32 CPU oracle, with explicit numbers:
+"""Parity of the BENCHMARKED configuration against the fp32 CPU oracle, with explicit numbers:
 
- (i)  logits of the bench batch -- 8 x 592x592 frames, 32 boxes and 992 edges each, seed 111, bf16 -- against
-      oracle.forward_gtbox on the same inputs and weights: max / mean absolute error reported and bounded (the fp32 mode's 1e-3
-      bar is tests/test_model_gpu.py's; this is the bound the bf16 headline runs under);
- (ii) R@K of the HIP forward (bf16 and fp32) against R@K of the ORACLE forward -- three forwards, one evaluator each -- on 2 048
-      ground-truth triplets (one triplet = 0.05 points), with a head trained until its softmaxes mean something (R@50 ~ 40 %): the
-      north star's +-0.1 on R@50 holds exactly (0.00 in every cell) in fp32 mode; bf16 mode differs by 1 - 3 triplets of 2 048
-      (0.05 - 0.15 points) graph-constrained and 5 - 7 (0.24 - 0.34) unconstrained, is bounded at 0.35 / 0.6 and says so.
-Both write what they measured to gpurun_out/ (copied to profiles/ by the round's author)."""
+ (i)  logits of the bench batch -- 8 x 592x592 frames, 32 boxes and 992 edges each, seed 111 -- against oracle.forward_gtbox on the
+      same inputs and weights, in all three modes: f32 (the reference's own precision: the north star's 1e-3 bar), f16 (the benchmarked
+      16-bit mode: rel <= 0.03, obj <= 0.1 -- the bounds VERDICT r2 set) and bf16 (BASELINE.json's wording of the configuration: the same
+      kernels at the same speed with 8x the rounding error -- reported and bounded where it is, not where the clause wants it);
+ (ii) R@K of the HIP forward (f16, bf16 and fp32) against R@K of the ORACLE forward -- four forwards, one evaluator each -- on 2 048
+      ground-truth triplets (one triplet = 0.05 points), with a head trained (in f16) until its softmaxes mean something (R@50 ~ 40 %):
+      the north star's +-0.1 on R@50 is demanded of f32 AND f16 in every cell (graph-constrained and not, sgcls and predcls,
+      K = 20 / 50 / 100).
+Both write what they measured to gpurun_out/ (copied to profiles/ by the round's author).  Training is bit-reproducible since round 3
+(tests/test_f16_gpu.py), so these numbers no longer move from run to run."""
 import json
 import os
 import time
@@ -45,10 +47,13 @@ def _logits(model, batch):
     return od.float().cpu().numpy(), rd.float().cpu().numpy(), rel_inds.cpu().numpy()
 
 
-# bounds of (i): about twice what was observed on MI355X (profiles/r02_parity_bench_config.json: obj max 0.42 / mean 0.059, rel max
-# 0.097 / mean 0.018, against logits of magnitude <= 3.9 / 2.4 with the He-initialised random weights of the bench; fp32 mode:
-# 7.5e-5 / 1.8e-5).  The object logits carry more error than the relation logits: a node's context is a sum of 62 gated edge rows
-# that is stored in bf16 (one rounding of a value ~8x the size of its terms) before it enters the node GRU, three times over.
+# bounds of (i).  f16: VERDICT r2's bars (observed on MI355X: obj max 0.056 / mean 0.0076, rel max 0.011 / mean 0.0019, against logits of
+# magnitude <= 3.9 / 2.4 with the He-initialised random weights of the bench; fp32 mode: 7.5e-5 / 1.8e-5).  bf16: about twice what was
+# observed (obj max 0.42 / mean 0.058, rel max 0.10 / mean 0.018).  Where the 16-bit error comes from was measured with
+# tools/precision_probe.py (profiles/r03_precision_probe.txt): it is the operand rounding of the contractions -- VGG-16's 13 layers alone
+# are obj 0.35 / rel 0.076 of the bf16 figures, the head's GEMMs most of the rest; node-side state storage (round 2's guess) is 0.01.
+F16_MAX_ABS = {'obj': 0.1, 'rel': 0.03}
+F16_MEAN_ABS = {'obj': 0.015, 'rel': 0.004}
 BF16_MAX_ABS = {'obj': 0.85, 'rel': 0.2}
 BF16_MEAN_ABS = {'obj': 0.12, 'rel': 0.04}
 
@@ -69,7 +74,7 @@ def test_bench_config_bf16_logits_within_stated_tolerance():
     t_ref = time.time() - t0
     ref_od, ref_rd = ref['rm_obj_dists'].numpy(), ref['rel_dists'].numpy()
     report = {'config': '8 x 592x592, 32 boxes, 992 edges per image, seed 111', 'oracle_seconds': round(t_ref, 1)}
-    for name, dt in (('f32', torch.float32), ('bf16', torch.bfloat16)):
+    for name, dt in (('f32', torch.float32), ('f16', torch.float16), ('bf16', torch.bfloat16)):
         model.set_compute_dtype(dt)
         od, rd, rel_inds = _logits(model, batch)
         np.testing.assert_array_equal(rel_inds, ref['rel_inds'])
@@ -80,10 +85,13 @@ def test_bench_config_bf16_logits_within_stated_tolerance():
                         'rel_logit_absmax': float(np.abs(ref_rd).max()),
                         'obj_argmax_agreement': float((od[:, 1:].argmax(1) == ref_od[:, 1:].argmax(1)).mean()),
                         'rel_argmax_agreement': float((rd[:, 1:].argmax(1) == ref_rd[:, 1:].argmax(1)).mean())}
-    _dump('r02_parity_bench_config.json', report)
+    _dump('r03_parity_bench_config.json', report)
     print(json.dumps(report, indent=1))
-    f32, b16 = report['f32'], report['bf16']
+    f32, f16, b16 = report['f32'], report['f16'], report['bf16']
     assert f32['obj_max_abs'] <= 1e-3 and f32['rel_max_abs'] <= 1e-3, f32                 # the north star's fp32 bar, at full size
+    assert f16['obj_max_abs'] <= F16_MAX_ABS['obj'] and f16['rel_max_abs'] <= F16_MAX_ABS['rel'], f16
+    assert f16['obj_mean_abs'] <= F16_MEAN_ABS['obj'] and f16['rel_mean_abs'] <= F16_MEAN_ABS['rel'], f16
+    assert f16['obj_argmax_agreement'] >= 0.97 and f16['rel_argmax_agreement'] >= 0.99, f16
     assert b16['obj_max_abs'] <= BF16_MAX_ABS['obj'] and b16['rel_max_abs'] <= BF16_MAX_ABS['rel'], b16
     assert b16['obj_mean_abs'] <= BF16_MEAN_ABS['obj'] and b16['rel_mean_abs'] <= BF16_MEAN_ABS['rel'], b16
 
@@ -133,7 +141,7 @@ def _single(b, i):
 
 
 def test_recall_of_hip_forward_equals_recall_of_oracle_forward():
-    """Three independent forwards per image (HIP bf16, HIP fp32, CPU oracle fp32), each scored by its own evaluator; 64 images x 32
+    """Four independent forwards per image (HIP f16, HIP bf16, HIP fp32, CPU oracle fp32), each scored by its own evaluator; 64 images x 32
     GT relations = 2 048 triplets per table, sgcls and predcls, graph-constrained and not."""
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
@@ -144,7 +152,7 @@ def test_recall_of_hip_forward_equals_recall_of_oracle_forward():
     from sgg_amd.trainer import Trainer
     B, steps = 8, int(os.environ.get('SGG_PARITY_STEPS', '800'))
     model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls', min_size=S_R, max_size=S_R)).to(DEV)
-    model.set_compute_dtype(torch.bfloat16)
+    model.set_compute_dtype(torch.float16)
     model.dropout_p = 0.0
     train_set = [_painted_batch(900 + s, B) for s in range(4)]
 
@@ -166,7 +174,7 @@ def test_recall_of_hip_forward_equals_recall_of_oracle_forward():
     held = [_painted_batch(5000 + s, B) for s in range(4)]
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     KS = (20, 50, 100)
-    paths = ('hip_bf16', 'hip_fp32', 'oracle_fp32')
+    paths = ('hip_f16', 'hip_bf16', 'hip_fp32', 'oracle_fp32')
     evs = {(m, w, mp): BasicSceneGraphEvaluator(m, multiple_preds=mp) for m in ('sgcls', 'predcls') for w in paths for mp in (False, True)}
     gts = {m: [] for m in ('sgcls', 'predcls')}
     preds = {(m, w): [] for m in ('sgcls', 'predcls') for w in paths}
@@ -182,7 +190,7 @@ def test_recall_of_hip_forward_equals_recall_of_oracle_forward():
                 model.mode = mode
                 outs = {}
                 with torch.no_grad():
-                    for name, dt in (('hip_bf16', torch.bfloat16), ('hip_fp32', torch.float32)):
+                    for name, dt in (('hip_f16', torch.float16), ('hip_bf16', torch.bfloat16), ('hip_fp32', torch.float32)):
                         model.set_compute_dtype(dt)
                         outs[name] = model([one])
                     outs['oracle_fp32'] = ref['dets'] if mode == 'sgcls' else O.eval_tail(
@@ -198,22 +206,19 @@ def test_recall_of_hip_forward_equals_recall_of_oracle_forward():
         ev.evaluate_scene_graph_batch(gts[mode], preds[(mode, name)])
         table['%s %s %s' % (mode, name, 'noGC' if mp else 'GC')] = {('R@%d' % k): 100 * float(np.mean(ev.result_dict[mode + '_recall'][k])) for k in KS}
     worst = {}
-    for name in ('hip_bf16', 'hip_fp32'):
+    for name in ('hip_f16', 'hip_bf16', 'hip_fp32'):
         for g in ('GC', 'noGC'):
             worst['%s %s' % (name, g)] = max(abs(table['%s %s %s' % (m, name, g)]['R@%d' % k] - table['%s oracle_fp32 %s' % (m, g)]['R@%d' % k])
                                              for m in ('sgcls', 'predcls') for k in KS)
     report = {'gt_triplets': n_trip, 'images': len(gts['sgcls']), 'train_steps': steps, 'final_loss': final_loss, 'recall_percent': table,
               'largest_abs_difference_to_oracle_points': worst, 'one_triplet_is_points': 100.0 / n_trip}
-    _dump('r02_recall_parity.json', report)
+    _dump('r03_recall_parity.json', report)
     print(json.dumps(report, indent=1))
     r50 = table['sgcls oracle_fp32 GC']['R@50']
     assert 5.0 < r50 < 95.0, 'recall at the floor / ceiling: the comparison would not discriminate'
-    # fp32 mode (what the north star's parity clause is stated in): within +-0.1 everywhere -- observed: identical in all 12 cells
+    # the north star's +-0.1 points: demanded of the fp32 mode AND of the benchmarked f16 mode in every cell (observed: 0.00 / <= 0.05)
     assert worst['hip_fp32 GC'] <= 0.1 and worst['hip_fp32 noGC'] <= 0.1, worst
-    # bf16 mode (what the headline throughput runs in) does NOT meet +-0.1 reliably: the head ends in a different place every run
-    # (float atomics in the BatchNorm column sums), and over three runs the graph-constrained cells differed from the oracle by
-    # 0.05 / 0.05 / 0.15 points (1 - 3 triplets of 2 048), the unconstrained ones -- every (pair, predicate) score of an image in one
-    # ranking, decided by near-ties that bf16 rounding flips -- by 0.24 - 0.34 (5 - 7 triplets).  Bounded here at 0.35 / 0.6 and
-    # reported as measured (profiles/r02_recall_parity.json); +-0.1 is what the fp32 mode delivers.
+    assert worst['hip_f16 GC'] <= 0.1 and worst['hip_f16 noGC'] <= 0.1, worst
+    # bf16 (8 bits of significand) is reported where it is: 1 - 3 triplets of 2 048 graph-constrained, 5 - 7 unconstrained in round 2
     assert worst['hip_bf16 GC'] <= 0.35, worst
     assert worst['hip_bf16 noGC'] <= 0.6, worst
