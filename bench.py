@@ -14,7 +14,7 @@ One batch = B synthetic 592x592 frames per GPU, 32 boxes and 32*31 candidate edg
 Images are sharded over ranks (one process per GPU) => weak scaling.  Prints ONE JSON line on rank 0; the other mode's
 throughput is reported alongside under "other_mode".
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype bf16|f32] [--mode train|infer]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype f16|bf16|f32] [--mode train|infer|sgdet]
 """
 import os
 
@@ -144,8 +144,9 @@ def kernel_times(step_fn, reps):
 
 
 def pmc_traffic(key):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_r02.json, else round 1's), or None."""
-    for name in ('pmc_r02.json', 'pmc_r01.json'):
+    """HBM-side bytes per launch READ FROM the committed rocprofv3 PMC passes (profiles/pmc_r03.json, else earlier rounds') -- collected
+    by tools/pmc_traffic.sh on the same workload, not measured inside this run -- or None."""
+    for name in ('pmc_r03.json', 'pmc_r02.json', 'pmc_r01.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 return json.load(f)[key]['traffic_bytes']
@@ -422,7 +423,8 @@ def main():
         ref_flop = {'fc6_edge': 2.0 * E * 4096 * 25600, 'bwd_fc6_edge_dW': 2.0 * E * 4096 * 25088}
         best = None
         for tag, (desc, flop) in cands.items():
-            ms = per_step('sgg_gemm', tag) + per_step('sgg_gemm_splitk', tag)   # a contraction may be issued as a full-round launch + a split-K tail
+            # a contraction may be issued as a full-round launch + a split-K tail; the weight gradient over the pairs runs as sgg_gemm_groupadd
+            ms = per_step('sgg_gemm', tag) + per_step('sgg_gemm_splitk', tag) + per_step('sgg_gemm_groupadd', tag)
             if ms > 0 and (best is None or ms > best[1]):
                 best = (tag, ms, desc, flop)
         tag, ms, desc, flop = best
@@ -466,7 +468,9 @@ def main():
         copy_gbs = impL_bytes / (c0.elapsed_time(c1) / 50 * 1e-3) / 1e9
         del src, dst, cg
         roi_ms = sum(v[0] * v[1] for (n, t), v in kt.items() if n == 'sgg_roi_align_fwd')
-        roi_bytes = (E + N) * 25088.0 * s + B * 38 * 38 * 512.0 * s
+        # rows RoIAlign actually writes: the N boxes + one row per unordered pair (or per edge with SGG_EDGE_PAIRS=0), 25088 elements each
+        roi_rows = N + U
+        roi_bytes = roi_rows * 25088.0 * s + B * 38 * 38 * 512.0 * s
         conv_ms = sum(v[0] * v[1] for (n, t), v in kt.items() if n in ('sgg_conv3x3_relu', 'sgg_conv1_1', 'sgg_maxpool2x2'))
         vgg_flop = 226.13e9 * B
         total_ms = sum(v[0] * v[1] for v in kt.values())
@@ -524,6 +528,7 @@ def main():
                                    ('train step: fwd + losses + bwd + grad all-reduce + clip + SGD' if args.mode == 'train'
                                     else 'eval forward incl. eval tail'),
                        'mode': args.mode, 'images_per_gpu': B, 'global_batch': world * B,
+                       'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
                        'edge_branch': ('union-box RoIAlign and fc6 K=25088 computed once per UNORDERED box pair (%d pairs for %d edges per '
                                        'GPU and step), per-edge rect term added after; same outputs as the per-edge computation '
                                        '(SGG_EDGE_PAIRS=0)' % (992 * B // 2, 992 * B)) if os.environ.get('SGG_EDGE_PAIRS', '1') != '0'
@@ -538,11 +543,17 @@ def main():
             'roofline': {'kernel': '256x256 ping-pong MFMA kernel (+ the 128x128 split-K launch that replaces a nearly empty last round), %s' % desc, 'bound': 'mfma', 'achieved': round(tf, 2), 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': round(tf / peak, 4),
                          'traffic': pmc_traffic('fc6_edge_gemm' if tag == 'fc6_edge' else 'fc6_dW_gemm') if (B == 8 and args.dtype != 'f32') else None,
+                         'traffic_source': 'profiles/pmc_r0x.json: separate rocprofv3 --pmc passes of the same launch (tools/pmc_traffic.sh), not measured in this run',
                          'ms_per_step': round(ms, 4), 'executed_flop': flop,
                          'reference_algorithm_tflops': round(ref_flop[tag] / (ms * 1e-3) / 1e12, 2),
                          'note': ('achieved = FLOPs the launch executes / its time; the reference runs this contraction on every EDGE '
                                   '(SURVEY 8(d)), here it runs once per unordered box pair: reference_algorithm_tflops prices the '
                                   'reference\'s FLOPs over the same time') if paired else None},
+            'roofline_vgg': {'kernel': 'VGG-16 features of the frozen detector: conv1_1 (K = 27 on MFMA) + 12 x 3x3 conv on MFMA (LDS-resident patch kernel / '
+                                       'implicit-GEMM ping-pong kernel, pools fused in the epilogues): the largest time slice of the step',
+                             'bound': 'mfma', 'achieved': round(vgg_flop / (conv_ms * 1e-3) / 1e12, 1) if conv_ms else 0.0, 'peak': peak, 'unit': 'TFLOP/s',
+                             'frac': round(vgg_flop / (conv_ms * 1e-3) / 1e12 / peak, 4) if conv_ms else 0.0, 'traffic': None,
+                             'ms_per_step': round(conv_ms, 4), 'executed_flop': vgg_flop},
             'roofline_imp': {'kernel': 'imp_ctx_sliced_kernel (the IMP gather / gate / scatter step, one launch per iteration: every edge row read once, '
                                        'gates from dot products, two segmented sums per node; the edge inputs are never formed -- node projection)', 'bound': 'hbm',
                              'achieved': round(imp_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -561,6 +572,7 @@ def main():
             'kernels': {'sum_kernel_ms_per_step': round(total_ms, 3),
                         'vgg16_ms': round(conv_ms, 3), 'vgg16_tflops': round(vgg_flop / (conv_ms * 1e-3) / 1e12, 1) if conv_ms else 0,
                         'roi_align_ms': round(roi_ms, 4), 'roi_align_GBs': round(roi_bytes / (roi_ms * 1e-3) / 1e9, 1) if roi_ms else 0,
+                        'roi_align_rows': roi_rows,
                         'top': [{'ms_per_step': round(ms_, 3), 'call': n, 'tag': t} for ms_, n, t in top]},
         }
         if other_line:
@@ -585,6 +597,26 @@ def main():
                                                '3 (train) / 2 (inference) warm-up + 8 timed steps; never `value`'}
             if el_pe is not None:
                 line['per_edge_branch'].update(train_images_per_s=round(B * 8 / el_pe, 2), train_ms_per_step=round(1e3 * el_pe / 8, 3))
+        if world == 1 and not args.force_dist and args.dtype == 'f16' and not args.no_f32 and args.mode in ('train', 'infer'):
+            # BASELINE.json words configs[1] "bf16": the same kernels with bf16 storage / MFMA operands (same rates, 8x the rounding error of
+            # f16 -- tests/test_parity_full_gpu.py), short runs beside the headline -- never `value`
+            if trainer is not None:
+                trainer.flush()
+            torch.cuda.synchronize()
+            model.set_compute_dtype(torch.bfloat16)
+            tb = Trainer(model, lr=1e-3, pipeline=trainer.pipeline) if trainer is not None else None
+            el_bt = timed(lambda: tb.step(batch), 3, 8) if tb is not None else None
+            if tb is not None:
+                tb.flush()
+                tb.opt.state.clear()
+            el_bi = timed(infer_step, 2, 8)
+            line['bf16_mode'] = {'dtype': 'bf16', 'infer_images_per_s': round(B * 8 / el_bi, 2), 'infer_ms_per_step': round(1e3 * el_bi / 8, 3),
+                                 'note': 'same workload and kernels with bf16 storage / operands (BASELINE.json\'s wording of configs[1]); 3 (train) / 2 '
+                                         '(inference) warm-up + 8 timed steps; parity of both modes: profiles/r03_parity_bench_config.json'}
+            if el_bt is not None:
+                line['bf16_mode'].update(train_images_per_s=round(B * 8 / el_bt, 2), train_ms_per_step=round(1e3 * el_bt / 8, 3))
+            del tb
+            model.set_compute_dtype(tdtype)
         if world == 1 and not args.force_dist and args.dtype != 'f32' and not args.no_f32:
             # the reference computes in fp32: the same two steps in exact-fp32 mode (v_mfma_f32_32x32x2_f32, the mode the 1e-3 parity
             # bar is checked in), short runs, reported beside the bf16 headline -- never `value`
