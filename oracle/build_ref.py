@@ -4,8 +4,10 @@
 
 The shipped Cython-0.29 generated C (draw_rectangles.c) does not compile against numpy 2.x,
 so the .pyx is re-cythonized with the installed Cython.  Nothing from /root/reference is copied
-into the repository: the generated C and the shared object land in oracle/_ref/ (git-ignored;
-it DOES travel to the GPU box as a prebuilt file).  Used as checker / CPU baseline only.
+into the repository: only the compiled shared object stays in oracle/_ref/ (git-ignored; the Cython-generated C -- the
+reference's source in another form -- is deleted right after the compile, so what travels to the GPU box with the
+snapshot is a binary like this package's own built .so files).  Used to generate tests/golden/raster.npz here; nothing on
+the GPU box loads it (the golden file does its job there).
 """
 import os
 import subprocess
@@ -32,7 +34,11 @@ def build(verbose=True):
     cmd = ['gcc', '-O2', '-fPIC', '-shared', '-fwrapv', '-Wno-cpp',
            '-DNPY_NO_DEPRECATED_API=NPY_1_7_API_VERSION',
            '-I', sysconfig.get_paths()['include'], '-I', numpy.get_include(), c_file, '-o', so]
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+    finally:
+        if os.path.exists(c_file):
+            os.remove(c_file)            # generated from the reference's source: never kept
     if verbose:
         print('[oracle/_ref] built', so)
     return True

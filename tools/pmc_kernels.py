@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs the roofline kernels in isolation (for rocprofv3 --pmc passes): the fc6 GEMM on the unordered box pairs (forward and weight
-gradient, B=8: 3968 pairs) and the IMP gather/gate/scatter step at B=8 and B=128.  Usage under the profiler:
+gradient, B=8: 3968 pairs), the IMP gather / gate / scatter launch and the projected edge-GRU gate kernel at B=8 and B=128 (f16).  Usage under the profiler:
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d out -o fetch -- python3 tools/pmc_kernels.py
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d out -o write -- python3 tools/pmc_kernels.py
 """
@@ -14,7 +14,7 @@ from sgg_amd import ops  # noqa: E402
 
 dev = 'cuda:0'
 g = torch.Generator().manual_seed(0)
-dt = torch.bfloat16
+dt = torch.float16
 # fc6 on the unordered box pairs (sgg_amd/pairing.py): [U, 25088] . [4096, 25088]^T, f32 out
 M, N, K1 = 3968, 4096, 25088
 A = torch.randn(M, K1, generator=g).to(dev).to(dt).relu()
@@ -31,10 +31,12 @@ for _ in range(3):
     dW = ops.gemm_full_waves(At, Bt, out_dtype=dt)
 torch.cuda.synchronize()
 del At, Bt, dW
-# IMP fused
+# the IMP step's launch (sgg_imp_ctx_fwd: every edge row read once, two gated sums per node) and the gate kernel that takes the place
+# of the edge inputs (sgg_gru_gate_proj_fwd), at B = 8 and B = 128
 H, n = 512, 32
 gw = (torch.randn(4, 2 * H, generator=g) / 30).to(dev)
 gb = torch.randn(4, generator=g).to(dev)
+b_ih = torch.randn(3 * H, generator=g).to(dev)
 for B in (8, 128):
     Nn, E = n * B, n * (n - 1) * B
     im = torch.arange(B, device=dev).repeat_interleave(n)
@@ -44,14 +46,10 @@ for B in (8, 128):
     v = torch.randn(Nn, H, generator=g).to(dev).to(dt)
     e = torch.randn(E, H, generator=g).to(dev).to(dt)
     nd, ed = (v.float() @ gw[:, :H].t()).contiguous(), (e.float() @ gw[:, H:].t()).contiguous()
+    gh, P = torch.randn(E, 3 * H, generator=g).to(dev), torch.randn(Nn, 3 * H, generator=g).to(dev)
     for _ in range(3):
-        ops.imp_fused(v, e, rel, csr, gw.to(dt), gb)
-    os.environ['SGG_IMP_STREAM'] = '0'            # imp_sliced_kernel at both sizes
+        ops.imp_ctx(e, csr, Nn, nd, ed, gb)
     for _ in range(3):
-        ops.imp_sliced(v, e, csr, nd, ed, gb)
-    del os.environ['SGG_IMP_STREAM']
-    if B == 128:                                  # what the forward launches at this size: the persistent matrix-core step
-        for _ in range(3):
-            ops.imp_sliced(v, e, csr, nd, ed, gb)
+        ops.gru_gate_proj(gh, P, b_ih, csr, nd, ed, gb, e, dot_w=gw[:, H:])
     torch.cuda.synchronize()
 print('done')

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM-side traffic of the roofline kernels (fc6 GEMMs, IMP step) from two rocprofv3 PMC passes, one counter each, and the kernel-trace
-# summaries of the train / inference bench.  Run on the GPU box from the repo root:   bash tools/pmc_traffic.sh gpurun_out/pmc_r02
-out=${1:-gpurun_out/pmc_r02}
+# summaries of the train / inference bench.  Run on the GPU box from the repo root:   bash tools/pmc_traffic.sh gpurun_out/pmc_r03
+out=${1:-gpurun_out/pmc_r03}
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/$out
 cd /tmp && export TMPDIR=/tmp
@@ -28,20 +28,20 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
             key = 'fc6_edge_gemm'
         elif 'mfma_pingpong_kernel' in k and wgs >= 1500:
             key = 'fc6_dW_gemm'
-        elif 'imp_sliced_kernel' in k:
-            key = 'imp_sliced_B8' if wgs <= 256 else 'imp_sliced_B128'
-        elif 'imp_ctx_mfma_kernel<true>' in k or 'imp_ctx_mfma_kernel<1>' in k:
-            key = 'imp_step_mfma_B128'
+        elif 'imp_ctx_sliced_kernel' in k:
+            key = 'imp_ctx_B8' if wgs <= 256 else 'imp_ctx_B128'
+        elif 'gru_gate_proj_kernel' in k:
+            key = 'gate_proj_B8' if wgs <= 4096 else 'gate_proj_B128'
         if key:
             res.setdefault(key, {})[c + '_KiB_avg'] = sum(v) / len(v)
             res[key]['launches'] = len(v)
 for key, d in res.items():
     # MI355X_MICROARCH.md (HBM / rocprofv3 section): counters in KiB; FETCH_SIZE reports half of the bytes of wide coalesced reads on gfx950
     d['traffic_bytes'] = int(1024 * (2 * d.get('FETCH_SIZE_KiB_avg', 0) + d.get('WRITE_SIZE_KiB_avg', 0)))
-res['_about'] = ('HBM-side traffic per launch of the roofline kernels from rocprofv3 PMC passes on MI355X (round 2): '
+res['_about'] = ('HBM-side traffic per launch of the roofline kernels from rocprofv3 PMC passes on MI355X (round 3, f16): '
                  'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -f csv -- python3 tools/pmc_kernels.py, one counter per pass '
                  '(tools/pmc_traffic.sh). Units KiB; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md; the counters sit '
                  'on the fabric side of L2, Infinity-Cache hits included.')
-json.dump(res, open('$out/pmc_r02.json', 'w'), indent=1, sort_keys=True)
+json.dump(res, open('$out/pmc_r03.json', 'w'), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
 PY
