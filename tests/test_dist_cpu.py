@@ -242,3 +242,63 @@ def test_bf16_wire_sum_error_bound_8_ranks():
     eps = 2.0 ** -8                                                        # bf16: 8 significand bits -> half-ulp = 2^-9 relative
     assert bool((err <= 8 * eps * part + 1e-30).all())
     assert float(err.norm() / exact.norm()) < 1e-2
+
+
+def _shard8_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from sgg_amd import dist as D
+    D.init('gloo')
+    g = torch.Generator().manual_seed(7)                       # the same parameters on every rank, rank-dependent gradients
+    shapes = [(64, 40), (24, 8), (13, 9), (640,), (100,), (3,), (8, 8, 3, 3)]    # 2560, 192, 117, 640, 100, 3, 576 elements
+    params = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    grads = [torch.randn(s, generator=g) for s in shapes]
+    for p, gr in zip(params, grads):
+        p.grad = gr * (rank + 1)
+    total = sum(range(1, world + 1))
+    gb = D.GradBuckets(params, big_bytes=400, shard=True)        # 'big' = >= 100 fp32 elements
+    ok = [p.numel() >= 100 for p in params] == [gb.is_big(p) for p in params]
+    want = {0: True, 1: True, 2: False, 3: True, 4: False, 6: True}   # sharded iff the element count splits into 8 x (multiple of 8)
+    for i, sharded in want.items():
+        rng = gb.shard_of(params[i])
+        n = params[i].numel()
+        ok = ok and ((rng == (rank * n // world, (rank + 1) * n // world)) if sharded else rng is None)
+    gb.start(params[0], params[0].grad)                          # one of them early, from "inside the backward"
+    out = gb.all_reduce(average=False)
+    for i, (p, gr) in enumerate(zip(params, grads)):
+        exp = (gr * total).reshape(-1)
+        rng = gb.shard_of(p)
+        got = out[p] if p in out else p.grad
+        if rng is not None:
+            ok = ok and got.shape == (rng[1] - rng[0],) and torch.allclose(got.float(), exp[rng[0]:rng[1]], atol=1e-5)
+        else:
+            ok = ok and torch.allclose(got.float().reshape(-1), exp, atol=1e-5)
+        ok = ok and got.data_ptr() % 16 == 0
+    # what FusedSGD does with the parts afterwards: update its part, all-gather the whole tensor back in place
+    for p in (params[0], params[3], params[6]):
+        lo, hi = gb.shard_of(p)
+        flat = p.data.view(-1)
+        flat[lo:hi] -= 0.1 * out[p].float()
+        dist.all_gather_into_tensor(flat, flat[lo:hi].clone())
+    q.put((rank, bool(ok), [p.detach().reshape(-1).tolist() for p in params]))      # (plain lists: no shared-memory handles to outlive the rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_grad_buckets_world_size_8():
+    """GradBuckets(shard=True) on EIGHT gloo ranks (BASELINE configs[3]: 8 x MI355X): which tensors split (element counts that are 8 x a
+    multiple of 8) and which fall back to the all-reduce (117, 100 elements), every rank's part of the summed gradient, early-started or
+    not, 16-byte aligned views, and the update + in-place all-gather round trip leaving the same parameters on every rank."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard8_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r for r, _, _ in out] == list(range(8)) and all(ok for _, ok, _ in out)
+    for _, _, ps in out[1:]:
+        assert ps == out[0][2]
