@@ -294,64 +294,140 @@ class GAN(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------ main.py:124-194
+def _dp_world():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def allreduce_grads_(params, scale=1.0):
+    """SUM the gradients of `params` over the ranks in place (one flat fp32 message: the GAN's ~20 M parameters), then multiply by `scale`.
+    Parameters without a gradient on this rank contribute zeros (and receive the others' sum)."""
+    import torch.distributed as dist
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return
+    if _dp_world() > 1:
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if scale != 1.0:
+            flat.mul_(scale)
+        off = 0
+        for p in params:
+            n = p.numel()
+            g = flat[off:off + n].view_as(p).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
+    elif scale != 1.0:
+        for p in params:
+            if p.grad is not None:
+                p.grad.mul_(scale)
+
+
 def gan_train_step(sgg_model, gan, res, gt_boxes, gt_objects, gt_rels, optimizer, G_optimizer, D_optimizer, *, ganw=1.0,
                    attachG=False, ganlosses=('D', 'G', 'rec'), loss_type='baseline', loss_weights=(1, 1, 1), clip=5.0,
-                   gt_objects_fake=None):
+                   gt_objects_fake=None, trainer=None):
     """The GAN part of one training iteration -- what main.py:124-194 does after the SGG model's own update, with the same calls in
     the same order: generate feature maps from the (perturbed) scene graph, extract node / edge features from them with the SGG
     model's RoIAlign (differentiable into the maps: sgg_roi_align_bwd), classify them with the SGG head, update G (adversarial +
     reconstruction losses; the SGG model too when 'rec' is on), then update D on real vs generated features.
     `res` is the Result of the SGG model's training forward on the same batch.  -> {loss name: value} as main.py logs them.
     gt_objects_fake: the perturbed objects, `sgg_amd.sg_perturb.SceneGraphPerturb(...).perturb(gt_objects.clone(), gt_rels.clone())`
-    (main.py:131-134); default = the real ones (`-perturb` off)."""
+    (main.py:131-134); default = the real ones (`-perturb` off).
+
+    Data parallel (one process per GPU, torch.distributed initialised; BASELINE configs[4]): every rank runs this on ITS images.  The
+    adversarial losses are means over a rank's nodes / edges / images: each is weighted by (local rows / global rows) and the
+    gradients of G, D and the SGG model are SUM-reduced over the ranks before their optimiser steps, so that one iteration equals
+    the single-process iteration on the concatenated batch (tests/test_gan_dist_gpu.py).  The reconstruction losses use the trainer's
+    global normalisers.  `trainer` (a sgg_amd.trainer.Trainer of `sgg_model`): the SGG model's update then goes through
+    Trainer.update() -- the backward's early-started reduce-scatters / all-reduces, wire-dtype buffers, sharded fused clip + SGD,
+    loss scale of the f16 mode -- instead of `optimizer.step()` (pass optimizer=None).  Without a trainer the gradients are
+    all-reduced here and `optimizer` steps on them.  The GAN's own BatchNorm layers (BatchNorm2d of the refinement network,
+    BatchNorm1d of the graph convolutions when BN=True) use batch statistics: convert them with
+    `torch.nn.SyncBatchNorm.convert_sync_batchnorm(gan)` for statistics over every rank's images (what the test does), or keep
+    replica-local statistics."""
     from .trainer import Trainer
+    import torch.distributed as dist
+    world = _dp_world()
     gan.train()
     if gt_objects_fake is None:
         gt_objects_fake = gt_objects.clone()
     fmaps = gan(gt_objects_fake, sgg_model.get_scaled_boxes(gt_boxes, res.im_inds, res.im_sizes_org), gt_rels)
-    nodes_fake, edges_fake = sgg_model.node_edge_features(fmaps, res.rois, res.rel_inds[:, 1:], res.im_sizes)
-    obj_fake, rel_fake = sgg_model.predict(nodes_fake if attachG else nodes_fake.detach(), edges_fake if attachG else edges_fake.detach(),
-                                           res.rel_inds, rois=res.rois, im_sizes=res.im_sizes)
-    # ---- generator (main.py:151-176)
-    optimizer.zero_grad()
-    G_optimizer.zero_grad()
-    losses = {}
-    losses_G = {}
-    losses_G.update(gan.loss(features_fake=nodes_fake, is_nodes=True, labels_fake=gt_objects_fake[:, -1]))
-    losses_G.update(gan.loss(features_fake=edges_fake, labels_fake=res.rel_labels[:, -1]))
-    losses_G.update(gan.loss(features_fake=fmaps, is_fmaps=True))
-    losses_G = {k: ganw * v for k, v in losses_G.items()}
-    if 'rec' in ganlosses:
-        class _R(object):        # the loss code of the trainer takes a Result-shaped object
-            pass
-        r = _R()
-        r.rm_obj_dists, r.rm_obj_labels, r.rel_dists, r.rel_labels = obj_fake, gt_objects_fake[:, -1], rel_fake, res.rel_labels
-        rec = Trainer.losses(_LossCfg(loss_type, loss_weights), r)
-        losses_G['rec'] = rec                                    # node + edge reconstruction losses (main.py:163-170), summed
-    if losses_G:
-        sum(losses_G.values()).backward()
+    # a data-parallel Trainer leaves its gradient hook on the model: without `trainer` every gradient of this function's backward
+    # must land in p.grad (the plain optimiser reads it there)
+    saved_hook = getattr(sgg_model, '_grad_ready_hook', None)
+    if trainer is None and saved_hook is not None:
+        sgg_model._grad_ready_hook = None
+    try:
+        nodes_fake, edges_fake = sgg_model.node_edge_features(fmaps, res.rois, res.rel_inds[:, 1:], res.im_sizes)
+        obj_fake, rel_fake = sgg_model.predict(nodes_fake if attachG else nodes_fake.detach(), edges_fake if attachG else edges_fake.detach(),
+                                               res.rel_inds, rois=res.rois, im_sizes=res.im_sizes)
+        # rows behind the three kinds of discriminator means, on this rank and over all ranks
+        rows = torch.tensor([float(nodes_fake.shape[0]), float(edges_fake.shape[0]), float(fmaps.shape[0])], dtype=torch.float64, device=fmaps.device)
+        share = {'obj': 1.0, 'rel': 1.0, 'fmap': 1.0}
+        if world > 1:
+            tot = rows.clone()
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            share = {k: float(rows[i] / tot[i]) for i, k in enumerate(('obj', 'rel', 'fmap'))}
+        weigh = lambda d: {k: ganw * share[k.split('_', 1)[1]] * v for k, v in d.items()}
+        G_params = [p for n, p in gan.named_parameters() if n.startswith('G_')]
+        D_params = [p for n, p in gan.named_parameters() if n.startswith('D_')]
+        scale = trainer.loss_scale if trainer is not None else 1.0        # f16 compute of the SGG head: scaled backward, unscaled updates
+        # ---- generator (main.py:151-176)
+        if trainer is not None:
+            trainer.opt.zero_grad()
+        else:
+            optimizer.zero_grad()
+        G_optimizer.zero_grad()
+        losses = {}
+        losses_G = {}
+        losses_G.update(gan.loss(features_fake=nodes_fake, is_nodes=True, labels_fake=gt_objects_fake[:, -1]))
+        losses_G.update(gan.loss(features_fake=edges_fake, labels_fake=res.rel_labels[:, -1]))
+        losses_G.update(gan.loss(features_fake=fmaps, is_fmaps=True))
+        losses_G = weigh(losses_G)
         if 'rec' in ganlosses:
-            if clip:
-                torch.nn.utils.clip_grad_norm_([p for p in sgg_model.parameters() if p.grad is not None], clip)
-            optimizer.step()
-        G_optimizer.step()
-        losses.update(losses_G)
-    # ---- discriminators (main.py:178-191)
-    D_optimizer.zero_grad()
-    losses_D = {}
-    losses_D.update(gan.loss(res.node_feat, nodes_fake, is_nodes=True, updateD=True, labels_fake=gt_objects_fake[:, -1], labels_real=gt_objects[:, -1]))
-    losses_D.update(gan.loss(res.edge_feat, edges_fake, updateD=True, labels_fake=res.rel_labels[:, -1]))
-    losses_D.update(gan.loss(res.fmap, fmaps, updateD=True, is_fmaps=True))
-    losses_D = {k: ganw * v for k, v in losses_D.items()}
-    if losses_D:
-        sum(losses_D.values()).backward()
-        D_optimizer.step()
-        losses.update(losses_D)
+            class _R(object):        # the loss code of the trainer takes a Result-shaped object
+                pass
+            r = _R()
+            r.rm_obj_dists, r.rm_obj_labels, r.rel_dists, r.rel_labels = obj_fake, gt_objects_fake[:, -1], rel_fake, res.rel_labels
+            rec = trainer.losses(r) if trainer is not None else Trainer.losses(_LossCfg(loss_type, loss_weights, world), r)
+            losses_G['rec'] = rec                                    # node + edge reconstruction losses (main.py:163-170), summed
+        if losses_G:
+            total = sum(losses_G.values())
+            (total * scale if scale != 1.0 else total).backward()
+            if 'rec' in ganlosses:
+                if trainer is not None:
+                    trainer.update()                                 # reduce over ranks + clip + SGD (sharded / fused), unscales
+                else:
+                    allreduce_grads_([p for p in sgg_model.parameters() if p.requires_grad])
+                    if clip:
+                        torch.nn.utils.clip_grad_norm_([p for p in sgg_model.parameters() if p.grad is not None], clip)
+                    optimizer.step()
+            allreduce_grads_(G_params, 1.0 / scale)
+            G_optimizer.step()
+            losses.update(losses_G)
+        # ---- discriminators (main.py:178-191)
+        D_optimizer.zero_grad()
+        losses_D = {}
+        losses_D.update(gan.loss(res.node_feat, nodes_fake, is_nodes=True, updateD=True, labels_fake=gt_objects_fake[:, -1], labels_real=gt_objects[:, -1]))
+        losses_D.update(gan.loss(res.edge_feat, edges_fake, updateD=True, labels_fake=res.rel_labels[:, -1]))
+        losses_D.update(gan.loss(res.fmap, fmaps, updateD=True, is_fmaps=True))
+        losses_D = weigh(losses_D)
+        if losses_D:
+            sum(losses_D.values()).backward()
+            allreduce_grads_(D_params)
+            D_optimizer.step()
+            losses.update(losses_D)
+    finally:
+        if trainer is None and saved_hook is not None:
+            sgg_model._grad_ready_hook = saved_hook
     return {k: v.detach() for k, v in losses.items()}
 
 
 class _LossCfg(object):
     """what Trainer.losses reads from `self` (loss form and weights; one process)"""
 
-    def __init__(self, loss_type, loss_weights):
-        self.loss_type, self.loss_weights, self.dist_on, self.world = loss_type, tuple(float(x) for x in loss_weights), False, 1
+    def __init__(self, loss_type, loss_weights, world=1):
+        self.loss_type, self.loss_weights, self.dist_on, self.world = loss_type, tuple(float(x) for x in loss_weights), world > 1, world

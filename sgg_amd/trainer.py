@@ -438,6 +438,15 @@ class Trainer(object):
         self.model._operands_ready = ev
         return True
 
+    def update(self):
+        """The tail of a step for gradients that already exist (p.grad, the early-started buckets of the backward's hooks, the kept
+        wire-dtype gradients of the one-GPU path): reduce over the ranks, global-norm clip, SGD -- on the current stream.  step() ends
+        with it; callers that run their own backward through the model (the GAN iteration's reconstruction losses, feature_gan.
+        gan_train_step) call it instead of a plain optimiser's step()."""
+        reduced = self.buckets.all_reduce(average=False) if self.dist_on else dict(self._local)
+        self.opt.step(grad_scale=1.0 / self.loss_scale, grads=reduced, shards=self._shards(reduced) if self.dist_on else None)
+        self._local = {}
+
     def step(self, batch):
         self.model.train()
         if not self._queued:
@@ -466,7 +475,6 @@ class Trainer(object):
                 self.model._grad_ready_hook = self.model._grad_wire_dtype = None
         self._queued = self.pipeline and self._queue_update()
         if not self._queued:
-            reduced = self.buckets.all_reduce(average=False) if self.dist_on else dict(self._local)
-            self.opt.step(grad_scale=1.0 / self.loss_scale, grads=reduced, shards=self._shards(reduced) if self.dist_on else None)
+            self.update()
         self.model.global_batch_iter = getattr(self.model, 'global_batch_iter', 0) + 1
         return loss.detach()
