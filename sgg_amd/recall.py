@@ -239,8 +239,8 @@ class BasicSceneGraphEvaluator(object):
             rel_scores = rel_scores[pred_inds_per_gt]
             order = argsort_desc(rel_scores[:, 1:])
             order[:, 1] += 1
-            ranked = np.column_stack((pred_rel_inds[order[:, 0]], order[:, 1]))
-            matches = intersect_2d(ranked, gt_rels)
+            ranked_rels = np.column_stack((pred_rel_inds[order[:, 0]], order[:, 1]))      # (not `ranked`: that is the cache parameter)
+            matches = intersect_2d(ranked_rels, gt_rels)
             for k in result_dict[mode + '_recall']:
                 result_dict[mode + '_recall'][k].append(float(matches[:k].any(0).sum()) / float(gt_rels.shape[0]))
             if self.per_triplet:
@@ -250,7 +250,11 @@ class BasicSceneGraphEvaluator(object):
         else:
             raise ValueError('invalid mode')
 
-        key = (id(pred_entry), mode, bool(multiple_preds), mode == 'objcls' and id(gt_entry))
+        # the ranking cache is keyed on the prediction entry; in objcls mode the ranked relations are derived from the GROUND TRUTH
+        # (and callers build temporary gt dicts whose ids CPython may reuse within one cache's lifetime): never cached there
+        if mode == 'objcls':
+            ranked = None
+        key = (id(pred_entry), mode, bool(multiple_preds))
         hit = ranked.get(key) if ranked is not None else None
         if hit is not None:
             pred_rels, predicate_scores, overall_order = hit
