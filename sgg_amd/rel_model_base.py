@@ -385,6 +385,9 @@ class RelModelBase(nn.Module):
             if max_edges is not None:
                 rel_labels._sgg_max_edges = max_edges       # sub-sampling only removes rows: still an upper bound
                 rel_labels._sgg_max_per_pair = max_per_pair
+                # every ordered pair exactly once, nothing sub-sampled: the rows are the evaluation candidate list (plus labels), so
+                # the graph index tables cached per box-count signature apply (rel_model_stanford.forward)
+                rel_labels._sgg_plain = bool(R == len(fg_pairs) and rel_labels.shape[0] == n_cand)
             obj_labels = gt_classes[:, 1].contiguous()
         else:
             obj_labels = gt_classes[:, 1]

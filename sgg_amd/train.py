@@ -192,7 +192,10 @@ class PredictFn(torch.autograd.Function):
         # ---- message passing (rel_model_stanford.py:68-94) with the node projection: per iteration ctx = read stream over e_i,
         # P_i = v_i W_ih^T, e_{i+1} = gate kernel on (e_i W_hh^T, P_i[s], P_i[o]); the gate dot products come out of the gate kernels
         _lib.set_tag('imp')
-        csr = ops.edge_csr(rel_inds, N, im_inds, graphs=getattr(model, '_graphs_hint', None))
+        csr = getattr(model, '_csr_hint', None)       # index tables cached per box-count signature (rel_model_stanford.forward)
+        model._csr_hint = None
+        if csr is None:
+            csr = ops.edge_csr(rel_inds, N, im_inds, graphs=getattr(model, '_graphs_hint', None))
         if T > 0 and not ops.gate_dots_ok(H):
             raise NotImplementedError('message passing needs hidden_dim / 8 to be a power of two <= 64 (got hidden_dim %d)' % H)
         wv, we = (imp.gate_w[:, :H], imp.gate_w[:, H:]) if T > 0 else (None, None)
@@ -437,7 +440,7 @@ class PredictFn(torch.autograd.Function):
 
 
 def predict_train(model, node_feat, edge_feat, rel_inds, rois, im_inds=None, seed=None, dropout_p=DROPOUT_P, graphs=None,
-                  im_sizes=None, pairing=None):
+                  im_sizes=None, pairing=None, csr=None):
     """Autograd-connected training forward of the head.  node_feat/edge_feat: [.,P,P,C]-contiguous (NHWC) tensors
     in the compute dtype."""
     N, E = node_feat.shape[0], edge_feat.shape[0]      # (E: rows of edge_feat -- the unordered pairs when `pairing` is given)
@@ -448,5 +451,6 @@ def predict_train(model, node_feat, edge_feat, rel_inds, rois, im_inds=None, see
     model._graphs_hint = graphs     # host-side facts about the graphs (ops.edge_csr), read by PredictFn.forward
     model._im_sizes_hint = im_sizes  # image sizes for the 'raw_boxes' raster (lib/get_union_boxes.py:71-78)
     model._pairing_hint = pairing    # sgg_amd/pairing.py: edge_feat holds one row per unordered box pair
+    model._csr_hint = csr
     return PredictFn.apply(model, node_feat.reshape(N, -1), edge_feat.reshape(E, -1), rois.float().contiguous(),
                            rel_inds.contiguous(), im_inds, seed, float(dropout_p), *params)
