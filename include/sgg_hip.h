@@ -139,9 +139,9 @@ int sgg_gemm(const void* A, int lda, const void* A2, int lda2, int K1, const voi
              int in_dtype, int out_dtype, void* stream);
 
 /* Split-K form for short-M contractions (fc6 on the object rows: M = 32B): `splits` workgroups per output tile reduce
- * K ranges into workspace f32[splits, M, N]; one reduce + epilogue pass writes C[M,N] (ldc == N, N % 8 == 0). */
+ * K ranges into workspace f32[splits, M, N]; one reduce + epilogue pass writes C[M,N] (row stride ldc, a multiple of 8; N % 8 == 0). */
 int sgg_gemm_splitk(const void* A, int lda, const void* W, int ldw, const float* bias, const float* post_scale,
-                    const float* post_shift, void* C, int M, int N, int K, int act, int in_dtype, int out_dtype, int splits,
+                    const float* post_shift, void* C, int ldc, int M, int N, int K, int act, int in_dtype, int out_dtype, int splits,
                     float* workspace, void* stream);
 
 /* Weight-gradient contraction without transposed operand copies: C[N, K] = A[Mred, N]^T . B[Mred, K], bf16 in, f32 / bf16 out
@@ -274,12 +274,12 @@ int sgg_act_bwd(const void* dy, const void* y, void* dx, int64_t n, float scale,
 /* Reductions of this section are TWO-STAGE: row blocks write partial rows into a caller-provided f32 workspace `ws`, a second launch
  * adds them in a fixed order -- no float atomics, so a training step is bit-reproducible.  ws sizes are stated per entry.
  * Cross-entropy of logits f32[M,C] (row stride ld) against labels i64 (element stride label_stride), 'baseline' form of
- * lib/losses.py:41-43,74: loss[0] += weight / norm[0] * sum_rows CE (zero `loss` first; `norm` on the device), and
+ * lib/losses.py:41-43,74: loss[0] (+)= weight / norm[0] * sum_rows CE (accumulate = 0: overwritten -- the first head; `norm` on the device), and
  * grad[M,ldg] (g_dtype, columns >= C zero) = grad_scale * d loss / d logits (grad_scale: the loss scale of the f16 mode, 1 otherwise)
  * -- one launch for what F.cross_entropy + autograd do in ~12.  ws: f32[(M + 3) / 4].  flag (optional, i32[1], never cleared here):
  * bit 0 is raised when a label lies outside [0, C) (e.g. torch's ignore_index); such a row adds no loss and gets a zero gradient. */
 int sgg_ce_fwd_bwd(const float* logits, int ld, const int64_t* labels, int label_stride, int M, int C, const float* norm,
-                   float weight, float grad_scale, float* loss, void* grad, int ldg, float* ws, int* flag, int g_dtype, void* stream);
+                   float weight, float grad_scale, float* loss, int accumulate, void* grad, int ldg, float* ws, int* flag, int g_dtype, void* stream);
 /* out[N] = column sums of x[M,N] (row stride ld): bias gradients.  ws: f32[64 * N] (may be NULL when M <= 512). */
 int sgg_colsum(const void* x, int M, int N, int ld, float* out, float* ws, int dtype, void* stream);
 /* train-mode BatchNorm2d of the rect conv (lib/get_union_boxes.py:54,58) on row-major [rows, C] activations:
@@ -320,23 +320,23 @@ int sgg_imp_edge_ctx_bwd(const void* e, const int* so, int E, int H, const float
                          const float* gate_b, const float* dq, const void* d_ctx, void* d_e, float* da, int dtype, void* stream);
 int sgg_imp_node_gates_bwd(const float* da, const int* out_ptr, const int* out_ids, const int* in_ptr, const int* in_ids,
                            const float* gate_w, int N, int H, void* d_v, float* nsum, int dtype, void* stream);
-/* out[k,:H] += sum_r a[r,k]*x[r,:], k<4 (out row stride out_ld; accumulates: the caller zeroes once per step).  ws: f32[64 * 4 * H] */
-int sgg_rank4_reduce(const float* a, const void* x, int R, int H, float* out, int out_ld, float* ws, int dtype, void* stream);
+/* out[k,:H] (+)= sum_r a[r,k]*x[r,:], k<4 (out row stride out_ld; accumulate = 0: overwritten).  ws: f32[64 * 4 * H] */
+int sgg_rank4_reduce(const float* a, const void* x, int R, int H, float* out, int out_ld, float* ws, int accumulate, int dtype, void* stream);
 
 /* optimiser step of main.py:119-120: global-norm gradient clip (lib/pytorch_misc.py:625-656) + torch.optim.SGD
  * (momentum, weight decay, lib/pytorch_misc.py:144), fused and sync-free: sqnorm_acc accumulates sum(g^2) over all
- * parameters into one device float; sgd_step reads it: coef = min(1, max_norm/(sqrt(norm_sq)*grad_scale + 1e-6)),
+ * parameters into one device float (accumulate = 0 on the first call of a step overwrites it: no clearing launch); sgd_step reads it: coef = min(1, max_norm/(sqrt(norm_sq)*grad_scale + 1e-6)),
  * g' = coef*grad_scale*g + wd*p, buf = first ? g' : momentum*buf + g', p -= lr*buf.  p, buf fp32; g fp32 or 16-bit.
  * sqnorm: ws f32[2048] (one partial per workgroup, added in a fixed order). */
-int sgg_sqnorm_acc(const void* g, int64_t n, float* acc, float* ws, int dtype, void* stream);
+int sgg_sqnorm_acc(const void* g, int64_t n, float* acc, float* ws, int accumulate, int dtype, void* stream);
 int sgg_sgd_step(float* p, const void* g, float* momentum_buf, int64_t n, float lr, float weight_decay, float momentum,
                  int first_step, const float* norm_sq, float max_norm, float grad_scale, int g_dtype, void* stream);
 
 /* Multi-tensor forms of the two calls above: host arrays (length count) of device pointers and sizes, one launch per
- * 32 tensors instead of one per parameter.  All pointers 16-byte aligned.  lr per tensor (the reference's two
+ * 32 tensors instead of one per parameter.  Pointers 16-byte aligned (tensors of fewer than 4 elements: any alignment).  lr per tensor (the reference's two
  * parameter groups, lib/pytorch_misc.py:135-144).  shadow: optional array (entries may be NULL) of 16-bit buffers (shadow_dtype:
  * SGG_BF16 / SGG_F16) that receive the updated parameter in the same pass -- the next forward's MFMA operand, so no separate cast pass. */
-int sgg_sqnorm_multi(const void* const* g, const int64_t* n, int count, float* acc, float* ws /*[2048]*/, int dtype, void* stream);
+int sgg_sqnorm_multi(const void* const* g, const int64_t* n, int count, float* acc, float* ws /*[2048]*/, int accumulate, int dtype, void* stream);
 int sgg_sgd_multi(float* const* p, const void* const* g, float* const* momentum_buf, void* const* shadow,
                   const int64_t* n, const float* lr, int count, float weight_decay, float momentum, int first_step,
                   const float* norm_sq, float max_norm, float grad_scale, int g_dtype, int shadow_dtype,

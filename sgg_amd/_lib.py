@@ -42,7 +42,7 @@ SIGNATURES = {
     'sgg_max4_rows': [_P, _P, _I, _I, _I, _P],
     'sgg_bcast_add': [_P, _P, _I, _I, _I, _I, _P],
     'sgg_gemm': [_P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    'sgg_gemm_splitk': [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    'sgg_gemm_splitk': [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     'sgg_gru_gate_fwd': [_P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _P],
     'sgg_imp_sliced_capacity': [_I, _I],
     'sgg_imp_ctx_mfma_min_units': [],
@@ -67,19 +67,19 @@ SIGNATURES = {
     'sgg_det_output': [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     'sgg_dropout_fwd': [_P, _L, _F, ctypes.c_uint64, _I, _P],
     'sgg_act_bwd': [_P, _P, _P, _L, _F, _I, _I, _P],
-    'sgg_ce_fwd_bwd': [_P, _I, _P, _I, _I, _I, _P, _F, _F, _P, _P, _I, _P, _P, _I, _P],
+    'sgg_ce_fwd_bwd': [_P, _I, _P, _I, _I, _I, _P, _F, _F, _P, _I, _P, _I, _P, _P, _I, _P],
     'sgg_colsum': [_P, _I, _I, _I, _P, _P, _I, _P],
     'sgg_bn_stats': [_P, _I, _I, _P, _P, _I, _P],
     'sgg_bn_finalize': [_P, _I, _I, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],
     'sgg_bn_apply': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sgg_bn_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P],
     'sgg_gru_gate_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    'sgg_rank4_reduce': [_P, _P, _I, _I, _P, _I, _P, _I, _P],
+    'sgg_rank4_reduce': [_P, _P, _I, _I, _P, _I, _P, _I, _I, _P],
     'sgg_recall_first_match': [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _F, _I, _P, _P, _P],
     'sgg_freq_bias_fwd': [_P, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P],
     'sgg_freq_bias_bwd': [_P, _P, _I, _I, _P, _P],
     'sgg_gemm_tn': [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
-    'sgg_sqnorm_multi': [_P, _P, _I, _P, _P, _I, _P],
+    'sgg_sqnorm_multi': [_P, _P, _I, _P, _P, _I, _I, _P],
     'sgg_sgd_multi': [_P, _P, _P, _P, _P, _P, _I, _F, _F, _I, _P, _F, _F, _I, _I, _I, _P],
     'sgg_transpose': [_P, _L, _P, _L, _I, _I, _P, _L, _I, _P, _P, _I, _I, _P],
     'sgg_group_sum': [_P, _L, _P, _L, _I, _I, _I, _I, _P],
@@ -89,7 +89,7 @@ SIGNATURES = {
     'sgg_group_bcast_add': [_P, _L, _P, _L, _I, _I, _I, _I, _I, _P],
     'sgg_gemm_groupadd': [_P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     'sgg_add': [_P, _P, _L, _I, _I, _P],
-    'sgg_sqnorm_acc': [_P, _L, _P, _P, _I, _P],
+    'sgg_sqnorm_acc': [_P, _L, _P, _P, _I, _I, _P],
     'sgg_sgd_step': [_P, _P, _P, _L, _F, _F, _F, _I, _P, _F, _F, _I, _P],
     'sgg_cast': [_P, _P, _L, _I, _I, _P],
     'sgg_permute_ncp_to_npc': [_P, _P, _I, _I, _I, _I, _I, _P],

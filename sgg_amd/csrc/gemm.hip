@@ -486,7 +486,7 @@ namespace {
 template <typename TO>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, long MN, int N, const float* __restrict__ bias,
                                                             int act, const float* __restrict__ ps, const float* __restrict__ pt,
-                                                            TO* __restrict__ out) {
+                                                            TO* __restrict__ out, long ldc) {
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
     if (i >= MN) return;
     float acc[8], t[8];
@@ -505,14 +505,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         if (pt) v += pt[n + k];
         acc[k] = v;
     }
-    store8(out + i, acc);
+    store8(out + (i / N) * ldc + n, acc);          // N % 8 == 0: the 8 values lie in one row
 }
 }  // namespace
 
 // Split-K form for short-M GEMMs (e.g. fc6 on the 256 object rows: 64 tiles x K = 25088): `splits` blocks per output
-// tile, each reducing a K range into workspace[s] (fp32 [M,N]), then one reduce + epilogue pass.  N % 8 == 0, ldc == N.
+// tile, each reducing a K range into workspace[s] (fp32 [M,N]), then one reduce + epilogue pass.  N % 8 == 0, ldc % 8 == 0, C 16-byte aligned.
 extern "C" int sgg_gemm_splitk(const void* A, int lda, const void* W, int ldw, const float* bias, const float* post_scale,
-                               const float* post_shift, void* C, int M, int N, int K, int act, int in_dtype, int out_dtype,
+                               const float* post_shift, void* C, int ldc, int M, int N, int K, int act, int in_dtype, int out_dtype,
                                int splits, float* workspace, void* stream) {
     if (!sgg_is_dtype(in_dtype) || !sgg_is_dtype(out_dtype)) return SGG_ERR_DTYPE;
     if (M == 0 || N == 0) return SGG_OK;
@@ -520,6 +520,7 @@ extern "C" int sgg_gemm_splitk(const void* A, int lda, const void* W, int ldw, c
     const int bke = ROWB / esz;
     if (!A || !W || !C || !workspace || M < 0 || N <= 0 || (N & 7) || K <= 0 || K % bke || splits < 1 || splits > K / bke) return SGG_ERR_ARG;
     if ((lda & 7) || (ldw & 7) || lda < K || ldw < K || (((uintptr_t)A | (uintptr_t)W) & 15)) return SGG_ERR_ARG;
+    if (ldc < N || (ldc & 7) || ((uintptr_t)C & 15)) return SGG_ERR_ARG;
     if ((long)M * lda * esz > 0xffff0000L || (long)N * ldw * esz > 0xffff0000L) return SGG_ERR_SPAN;   // 32-bit lane offsets
     GemmArgs g{};
     g.A = (const char*)A; g.Wt = (const char*)W;
@@ -533,7 +534,7 @@ extern "C" int sgg_gemm_splitk(const void* A, int lda, const void* W, int ldw, c
     if (rc != SGG_OK) return rc;
     const long MN = (long)M * N;
     const dim3 grid((unsigned)((MN / 8 + 255) / 256)), blk(256);
-    SGG_FOR_DTYPE(out_dtype, hipLaunchKernelGGL(splitk_reduce_kernel<T>, grid, blk, 0, s, workspace, splits, MN, N, bias, act, post_scale, post_shift, (T*)C));
+    SGG_FOR_DTYPE(out_dtype, hipLaunchKernelGGL(splitk_reduce_kernel<T>, grid, blk, 0, s, workspace, splits, MN, N, bias, act, post_scale, post_shift, (T*)C, (long)ldc));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -574,7 +575,7 @@ extern "C" int sgg_gemm_tn(const void* A, int lda, const void* B, int ldb, void*
         const long MN = (long)N * K;
         const dim3 grid((unsigned)((MN / 8 + 255) / 256)), blk(256);
         SGG_FOR_DTYPE(out_dtype, hipLaunchKernelGGL(splitk_reduce_kernel<T>, grid, blk, 0, s, workspace, splits, MN, K, (const float*)nullptr, SGG_ACT_NONE,
-                                                    (const float*)nullptr, (const float*)nullptr, (T*)C));
+                                                    (const float*)nullptr, (const float*)nullptr, (T*)C, (long)K));
         SGG_CHECK_LAUNCH();
     }
     return SGG_OK;

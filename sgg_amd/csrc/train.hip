@@ -815,15 +815,15 @@ __global__ __launch_bounds__(256) void reduce_scalar_kernel(const float* __restr
     if (threadIdx.x == 0) acc[0] = accumulate ? acc[0] + red[0] : red[0];
 }
 
-// out[k][c] += sum_p parts[p][k][c]  (k < 4, c < H; out row stride out_ld), p ascending
+// out[k][c] (+)= sum_p parts[p][k][c]  (k < 4, c < H; out row stride out_ld), p ascending
 __global__ __launch_bounds__(256) void rank4_finalize_kernel(const float* __restrict__ parts, int nparts, int H, float* __restrict__ out,
-                                                             int out_ld) {
+                                                             int out_ld, int accumulate) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= 4 * H) return;
     const int k = i / H, c = i - k * H;
     float s = 0.f;
     for (int p = 0; p < nparts; ++p) s += parts[(long)p * 4 * H + i];
-    out[(long)k * out_ld + c] += s;
+    out[(long)k * out_ld + c] = accumulate ? out[(long)k * out_ld + c] + s : s;
 }
 
 template <typename TG>
@@ -867,16 +867,22 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict
 // loss[0] += weight / norm[0] * sum_rows CE(logits[row], labels[row * label_stride]);  grad[M, ldg] = grad_scale * d loss / d logits
 // (zero-padded).  ws: f32[(M + 3) / 4].  flag (optional): bit 0 raised when a label lies outside [0, C) (that row: no loss, zero gradient).
 extern "C" int sgg_ce_fwd_bwd(const float* logits, int ld, const int64_t* labels, int label_stride, int M, int C, const float* norm,
-                              float weight, float grad_scale, float* loss, void* grad, int ldg, float* ws, int* flag, int g_dtype,
+                              float weight, float grad_scale, float* loss, int accumulate, void* grad, int ldg, float* ws, int* flag, int g_dtype,
                               void* stream) {
-    if (M == 0) return SGG_OK;
+    if (M == 0) {
+        if (!accumulate && loss) {          // no rows: the loss is 0
+            hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss, 0, loss, 0);
+            SGG_CHECK_LAUNCH();
+        }
+        return SGG_OK;
+    }
     if (!logits || !labels || !norm || !loss || !grad || !ws || M < 0 || C <= 0 || ld < C || ldg < C || label_stride <= 0) return SGG_ERR_ARG;
     const dim3 grid((M + 3) / 4), blk(256);
     hipStream_t s = (hipStream_t)stream;
     SGG_FOR_DTYPE(g_dtype, hipLaunchKernelGGL(ce_fwd_bwd_kernel<T>, grid, blk, 0, s, logits, ld, labels, label_stride, M, C, norm, weight, grad_scale,
                                               ws, (T*)grad, ldg, flag));
     SGG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(256), 0, s, ws, (int)grid.x, loss, 1);
+    hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(256), 0, s, ws, (int)grid.x, loss, accumulate);
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -1062,31 +1068,32 @@ extern "C" int sgg_imp_node_gates_bwd(const float* da, const int* out_ptr, const
 }
 
 // out[k, :H] += sum_r a[r,k] * x[r,:]  (k < 4; out row stride out_ld; NOT zeroed: accumulates over calls).  ws: f32[64 * 4 * H]
-extern "C" int sgg_rank4_reduce(const float* a, const void* x, int R, int H, float* out, int out_ld, float* ws, int dtype, void* stream) {
-    if (R == 0) return SGG_OK;
-    if (!a || !x || !out || !ws || R < 0 || H <= 0 || out_ld < H) return SGG_ERR_ARG;
+extern "C" int sgg_rank4_reduce(const float* a, const void* x, int R, int H, float* out, int out_ld, float* ws, int accumulate, int dtype,
+                                void* stream) {
+    if (R == 0 && accumulate) return SGG_OK;
+    if (!out || R < 0 || H <= 0 || out_ld < H || (R > 0 && (!a || !x || !ws))) return SGG_ERR_ARG;
     int rpb;
     const int split = split_rows(R, rpb);
     const dim3 grid((H + 63) / 64, split), blk(256);
     hipStream_t s = (hipStream_t)stream;
     SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(rank4_reduce_kernel<T>, grid, blk, 0, s, a, (const T*)x, R, H, ws, rpb));
     SGG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(rank4_finalize_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, s, ws, split, H, out, out_ld);
+    hipLaunchKernelGGL(rank4_finalize_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, s, ws, R > 0 ? split : 0, H, out, out_ld, accumulate);
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
 
-// acc += sum(g^2)  (acc NOT zeroed: the caller clears it once per step and accumulates over all parameters).  ws: f32[2048]
-extern "C" int sgg_sqnorm_acc(const void* g, int64_t n, float* acc, float* ws, int dtype, void* stream) {
-    if (n == 0) return SGG_OK;
-    if (!g || !acc || !ws || n < 0) return SGG_ERR_ARG;
+// acc (+)= sum(g^2)  (accumulate = 0 for the first tensor of a step, 1 for the others: no separate clearing launch).  ws: f32[2048]
+extern "C" int sgg_sqnorm_acc(const void* g, int64_t n, float* acc, float* ws, int accumulate, int dtype, void* stream) {
+    if (n == 0 && accumulate) return SGG_OK;
+    if ((!g && n > 0) || !acc || !ws || n < 0) return SGG_ERR_ARG;
     long blocks = (n / 8 + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     hipStream_t s = (hipStream_t)stream;
     SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(sqnorm_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, (const T*)g, (long)n, ws));
     SGG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(256), 0, s, ws, (int)blocks, acc, 1);
+    hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(256), 0, s, ws, (int)blocks, acc, accumulate);
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -1126,14 +1133,14 @@ int mt_fill(MultiTab& tab, int lo, int hi, const void* const* g, float* const* p
 }
 }  // namespace
 
-// acc += sum_i sum(g_i^2) over `count` tensors in one launch per 32 tensors (host arrays of device pointers / sizes).
-// Every g_i must be 16-byte aligned.  ws: f32[2048]
-extern "C" int sgg_sqnorm_multi(const void* const* g, const int64_t* n, int count, float* acc, float* ws, int dtype, void* stream) {
-    if (count == 0) return SGG_OK;
-    if (!g || !n || !acc || !ws || count < 0) return SGG_ERR_ARG;
-    for (int i = 0; i < count; ++i)
-        if (n[i] < 0 || (n[i] > 0 && (!g[i] || ((uintptr_t)g[i] & 15)))) return SGG_ERR_ARG;
+// acc (+)= sum_i sum(g_i^2) over `count` tensors in one launch per 32 tensors (host arrays of device pointers / sizes); accumulate = 0:
+// acc is overwritten (the first call of a step).  Every g_i of 4 or more elements must be 16-byte aligned.  ws: f32[2048]
+extern "C" int sgg_sqnorm_multi(const void* const* g, const int64_t* n, int count, float* acc, float* ws, int accumulate, int dtype, void* stream) {
+    if (!acc || !ws || count < 0 || (count > 0 && (!g || !n))) return SGG_ERR_ARG;
+    for (int i = 0; i < count; ++i)        // (tensors of fewer than 4 elements take the scalar path: any alignment)
+        if (n[i] < 0 || (n[i] > 0 && !g[i]) || (n[i] >= 4 && ((uintptr_t)g[i] & 15))) return SGG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    bool launched = false;
     for (int lo = 0; lo < count; lo += MT_MAX) {
         MultiTab tab;
         const int chunks = mt_fill(tab, lo, min(count, lo + MT_MAX), g, nullptr, nullptr, nullptr, n, nullptr);
@@ -1141,7 +1148,12 @@ extern "C" int sgg_sqnorm_multi(const void* const* g, const int64_t* n, int coun
         const dim3 grid((unsigned)min(chunks, 2048));
         SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(sqnorm_multi_kernel<T>, grid, dim3(256), 0, s, tab, ws));
         SGG_CHECK_LAUNCH();
-        hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(256), 0, s, ws, (int)grid.x, acc, 1);
+        hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(256), 0, s, ws, (int)grid.x, acc, (accumulate || launched) ? 1 : 0);
+        SGG_CHECK_LAUNCH();
+        launched = true;
+    }
+    if (!launched && !accumulate) {         // nothing to add: acc = 0
+        hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(256), 0, s, ws, 0, acc, 0);
         SGG_CHECK_LAUNCH();
     }
     return SGG_OK;
@@ -1160,7 +1172,8 @@ extern "C" int sgg_sgd_multi(float* const* p, const void* const* g, float* const
         if (n[i] < 0) return SGG_ERR_ARG;
         if (n[i] == 0) continue;
         if (!p[i] || !g[i] || !momentum_buf[i]) return SGG_ERR_ARG;
-        if (((uintptr_t)p[i] | (uintptr_t)g[i] | (uintptr_t)momentum_buf[i] | (shadow ? (uintptr_t)shadow[i] : 0)) & 15)
+        // (tensors of fewer than 4 elements -- a gate bias inside a packed block -- take the scalar path: any alignment)
+        if (n[i] >= 4 && (((uintptr_t)p[i] | (uintptr_t)g[i] | (uintptr_t)momentum_buf[i] | (shadow ? (uintptr_t)shadow[i] : 0)) & 15))
             return SGG_ERR_ARG;
     }
     hipStream_t s = (hipStream_t)stream;

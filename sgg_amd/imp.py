@@ -10,19 +10,42 @@ class ImpWeights(object):
     """Device operands of the loop: GRU matrices in the compute dtype, biases and the four gate vectors in fp32."""
 
     @classmethod
-    def from_state(cls, p, dtype):
+    def from_state(cls, p, dtype, cast=None):
+        """p: {name: parameter}.  cast(name, parameter) -> the compute-dtype operand (the model passes its shadow buffers, which a
+        fused optimiser keeps current in its update pass; default: a cast).  The four gate layers (Linear(2H, 1) each) are kept in
+        ONE [4,2H] / [4] fp32 block: their parameters are re-pointed at views of it (once; again after something gave them storage
+        of their own, e.g. module.to()), so the kernels read the block the optimiser updates -- no per-step concatenation."""
         w = cls()
+        cast = cast or (lambda name, t: t.detach().to(dtype).contiguous())
         for g in ('edge_gru', 'node_gru'):
-            setattr(w, g + '_w_ih', p[g + '.weight_ih'].detach().to(dtype).contiguous())
-            setattr(w, g + '_w_hh', p[g + '.weight_hh'].detach().to(dtype).contiguous())
+            setattr(w, g + '_w_ih', cast(g + '.weight_ih', p[g + '.weight_ih']))
+            setattr(w, g + '_w_hh', cast(g + '.weight_hh', p[g + '.weight_hh']))
             setattr(w, g + '_b_ih', p[g + '.bias_ih'].detach().float().contiguous())
             setattr(w, g + '_b_hh', p[g + '.bias_hh'].detach().float().contiguous())
-        w.gate_w = torch.cat([p[g + '.0.weight'].detach().float().reshape(1, -1) for g in GATES], 0).contiguous()
-        w.gate_b = torch.cat([p[g + '.0.bias'].detach().float().reshape(1) for g in GATES], 0).contiguous()
+        w.gate_w = pack_rows([p[g + '.0.weight'] for g in GATES])              # [4,2H]: (vertex half | edge half) of each gate
+        w.gate_b = pack_rows([p[g + '.0.bias'] for g in GATES]).view(-1)       # [4]
         w.H = w.edge_gru_w_hh.shape[1]
-        # node GRU input weight doubled along K: ctx = ctx_out + ctx_in is fed as a K-split operand (linearity)
-        w.node_gru_w_ih2 = torch.cat((w.node_gru_w_ih, w.node_gru_w_ih), 1).contiguous()
         return w
+
+
+def pack_rows(params):
+    """-> f32 [len(params), n] whose row i IS params[i] (each a parameter of n elements): the parameters' storage is moved into one
+    block the first time (and whenever they are found apart again); afterwards this costs no launch."""
+    n = params[0].numel()
+    first = params[0].data
+    esz = first.element_size()
+    packed = (first.dtype == torch.float32 and first.is_contiguous() and
+              all(q.dtype == torch.float32 and q.numel() == n and q.data.is_contiguous() and
+                  q.data.untyped_storage().data_ptr() == first.untyped_storage().data_ptr() and
+                  q.data_ptr() == first.data_ptr() + i * n * esz for i, q in enumerate(params)) and
+              first.untyped_storage().nbytes() >= first.storage_offset() * esz + len(params) * n * esz)
+    if not packed:
+        with torch.no_grad():
+            block = torch.cat([q.detach().float().reshape(1, n) for q in params], 0).contiguous()
+            for i, q in enumerate(params):
+                q.data = block[i].view(q.shape)
+        first = params[0].data
+    return torch.as_strided(first, (len(params), n), (n, 1))
 
 
 def _gru(wts, which, x, h, dtype, out=None, dots=False):
@@ -75,7 +98,7 @@ def message_pass(rel_rep, obj_rep, rel_inds, csr, wts, mp_iter, dtype):
 
     def node_step(ctx2, vert, more, out=None, dots=None):
         # :92  node_gru(ctx_out + ctx_in, vert): the sum rides in the GEMM's K axis
-        gi = ops.gemm(ctx2[0], wts.node_gru_w_ih2, wts.node_gru_b_ih, out_dtype=torch.float32, A2=ctx2[1])
+        gi = ops.gemm(ctx2[0], wts.node_gru_w_ih, wts.node_gru_b_ih, out_dtype=torch.float32, A2=ctx2[1], W2=wts.node_gru_w_ih)
         gh = ops.gemm(vert, wts.node_gru_w_hh, wts.node_gru_b_hh, out_dtype=torch.float32)
         return unpack(ops.gru_gate(gi, gh, None, vert, dtype, out=out, dot_w=wv if more else None, dots=dots), more)
 

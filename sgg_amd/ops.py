@@ -172,6 +172,14 @@ def rel_assign_tables(det_boxes, det_img, det_labels, gt_boxes, gt_classes, fg_t
     return gt_iou, match, poss
 
 
+def pairs_of(rel_inds):
+    """(subject, object) columns of rel_inds i64[E,3] as a contiguous i64[E,2]: the copy a cached edge list carries, or a new one"""
+    p = getattr(rel_inds, '_sgg_pairs', None)
+    if p is not None and p.shape[0] == rel_inds.shape[0] and p.device == rel_inds.device:
+        return p
+    return rel_inds[:, 1:].contiguous()
+
+
 class Csr(tuple):
     """(out_ptr, out_ids, in_ptr, in_ids, so, flags) + what the sliced IMP kernel needs: `img_ptr` i32[B+1] (first node of each
     graph) and `graphs` = (B, max_nodes, max_edges) known on the host; both None when the caller gave no hint."""
@@ -295,7 +303,8 @@ def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None
     # short-M, long-K contractions (fc6 on the object rows) do not fill the chip with output tiles: split K
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     kt = K // (64 if is_half(A) else 32)
-    can_split = A2 is None and N % 8 == 0 and out.is_contiguous() and A.stride(0) >= K and W.stride(0) >= K
+    can_split = (A2 is None and N % 8 == 0 and out.stride(1) == 1 and out.stride(0) % 8 == 0 and out.data_ptr() % 16 == 0 and
+                 A.stride(0) >= K and W.stride(0) >= K)
     if can_split and ((splits is None and tiles <= 96 and kt >= 64) or (splits is not None and splits > 1)):
         if splits is None:
             splits = max(2, min(16, 512 // tiles, kt // 8))
@@ -303,7 +312,7 @@ def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None
         _lib.call('sgg_gemm_splitk', _p(A, rows_ok=True), A.stride(0), _p(W, rows_ok=True), W.stride(0),
                   _p(bias, torch.float32) if bias is not None else None,
                   _p(post_scale, torch.float32) if post_scale is not None else None,
-                  _p(post_shift, torch.float32) if post_shift is not None else None, _p(out), M, N, K, act, dt(A), dt(out),
+                  _p(post_shift, torch.float32) if post_shift is not None else None, _p(out, rows_ok=True), out.stride(0), M, N, K, act, dt(A), dt(out),
                   splits, _p(ws), _stream())
         return out
     _lib.call('sgg_gemm', _p(A, rows_ok=True), A.stride(0), _p(A2, rows_ok=True) if A2 is not None else None,
@@ -393,10 +402,9 @@ def gemm_full_waves(A, W, out_dtype=None, gadd=None):
     out = torch.empty((M, N), dtype=out_dtype or A.dtype, device=A.device)
     main(W[:n1], out[:, :n1])
     tail_tiles = (M // 128) * ((N - n1) // 128)
-    tail = gemm(A, W[n1:], out_dtype=out.dtype, splits=max(2, min(8, (2 * N_CU) // tail_tiles, kt // 8)))
+    tail = gemm(A, W[n1:], out=out[:, n1:], splits=max(2, min(8, (2 * N_CU) // tail_tiles, kt // 8)))     # straight into its columns
     if gadd is not None:
         group_bcast_add_(tail, gadd[0], gadd[1], col0=n1)
-    out[:, n1:].copy_(tail)
     return out
 
 
@@ -549,8 +557,8 @@ def act_bwd(dy, y, scale=1.0):
     return dx
 
 
-def ce_fwd_bwd(logits, labels, norm, weight, loss, grad, grad_scale=1.0, flag=None):
-    """loss[0] += weight / norm[0] * sum CE(logits, labels); grad [M, ldg] (16-bit / f32, zero-padded columns) = grad_scale * d loss / d logits.
+def ce_fwd_bwd(logits, labels, norm, weight, loss, grad, grad_scale=1.0, flag=None, accumulate=True):
+    """loss[0] += (accumulate=False: =) weight / norm[0] * sum CE(logits, labels); grad [M, ldg] (16-bit / f32, zero-padded columns) = grad_scale * d loss / d logits.
     logits f32 [M,C]; labels i64, any 1-D view (e.g. a column of rel_labels); norm, loss: f32 device scalars; flag (optional i32[1]):
     bit 0 is raised when a label lies outside [0, C) (that row adds no loss and gets a zero gradient)."""
     M, C = logits.shape
@@ -558,7 +566,7 @@ def ce_fwd_bwd(logits, labels, norm, weight, loss, grad, grad_scale=1.0, flag=No
     assert grad.shape[0] == M and grad.shape[1] >= C and grad.stride(1) == 1
     ws = _ws((M + 3) // 4, logits.device)
     _lib.call('sgg_ce_fwd_bwd', logits.data_ptr(), logits.stride(0), labels.data_ptr(), labels.stride(0), M, C, norm.data_ptr(),
-              float(weight), float(grad_scale), loss.data_ptr(), grad.data_ptr(), grad.stride(0), _p(ws), _p(flag, torch.int32) if flag is not None else None,
+              float(weight), float(grad_scale), loss.data_ptr(), int(bool(accumulate)), grad.data_ptr(), grad.stride(0), _p(ws), _p(flag, torch.int32) if flag is not None else None,
               dt(grad), _stream())
 
 
@@ -659,20 +667,24 @@ def imp_node_gates_bwd(da, csr, gate_w, d_v, nsum=None):
     return nsum
 
 
-def rank4_reduce_(a, x, out, col0=0):
-    """out[k, col0:col0+H] += sum_r a[r,k] * x[r,:]   (out f32 [4, ld])"""
+def rank4_reduce_(a, x, out, col0=0, accumulate=True):
+    """out[k, col0:col0+H] += (accumulate=False: =) sum_r a[r,k] * x[r,:]   (out f32 [4, ld])"""
     R, H = x.shape
     _lib.call('sgg_rank4_reduce', _p(a, torch.float32), _p(x), R, H, out.data_ptr() + 4 * col0, out.stride(0), _p(_ws(64 * 4 * H, x.device)),
-              dt(x), _stream())
+              int(bool(accumulate)), dt(x), _stream())
 
 
-def transpose(x, pad_to=64, dtype=None, add=None, group=1, want_colsum=False):
+def transpose(x, pad_to=64, dtype=None, add=None, group=1, want_colsum=False, out=None):
     """x [R,C] (row-strided ok) -> [C, Rp] with Rp = R rounded up to `pad_to`, zero padded.
-    add f32[R, C/group]: out[c][r] = x[r][c] + add[r][c // group].  want_colsum: also return the column sums of x (f32[C])."""
+    add f32[R, C/group]: out[c][r] = x[r][c] + add[r][c // group].  want_colsum: also return the column sums of x (f32[C]).
+    out (optional): a [C, Rp] buffer of an earlier call with the same shapes -- its padding columns are zero already and stay so."""
     R, C = x.shape
     Rp = (R + pad_to - 1) // pad_to * pad_to
     dtype = dtype or x.dtype
-    out = (torch.zeros if Rp != R else torch.empty)((C, Rp), dtype=dtype, device=x.device)
+    if out is None:
+        out = (torch.zeros if Rp != R else torch.empty)((C, Rp), dtype=dtype, device=x.device)
+    else:
+        assert tuple(out.shape) == (C, Rp) and out.dtype == dtype and out.is_contiguous()
     cs = torch.empty(C, dtype=torch.float32, device=x.device) if want_colsum else None
     ws = _ws((R + 63) // 64 * C, x.device) if want_colsum else None
     _lib.call('sgg_transpose', _p(x, rows_ok=True), x.stride(0), _p(out), Rp, R, C,

@@ -221,21 +221,24 @@ class RelModelBase(nn.Module):
             ratios.append((s, e, float(nw) / float(w), float(nh) / float(h)))
         gt_boxes = gt_boxes.float()
         if all(r[2] == 1.0 and r[3] == 1.0 for r in ratios):
-            priors = gt_boxes.clone()
+            priors = gt_boxes                                    # nothing resized: the same tensor (nothing downstream writes into it)
         else:
             scale = torch.ones((gt_boxes.shape[0], 4), dtype=torch.float32)
             for s, e, rw, rh in ratios:
                 scale[s:e] = torch.tensor([rw, rh, rw, rh])
             priors = gt_boxes * scale.to(gt_boxes.device, non_blocking=True)
-        rois, obj_labels, rel_labels = self.gt_labels(gt_boxes, gt_classes, gt_rels, segs=segs)   # :189
-        im_inds = gt_classes[:, 0].long()
+        # what depends on the boxes-per-image counts only lives on the device once per count signature: the image index per box
+        # (i64, contiguous, and as an f32 column for the RoI rows) and the first box of every image -- a step launches nothing for them
+        seg_t = self._segment_tensors(segs, im_host, gt_boxes.device)
+        _, obj_labels, rel_labels = self.gt_labels(gt_boxes, gt_classes, gt_rels, segs=segs, _seg_t=seg_t)   # :189
+        im_inds = seg_t['im_inds']
         result = Result(od_obj_labels=obj_labels, rm_box_priors=priors, rm_obj_labels=obj_labels,
                         rel_labels=rel_labels, im_inds=im_inds)
         result.rm_box_priors_org = gt_boxes
         result.im_sizes_org = [image_hw(x[i]) for i, _, _ in segs]
         result.im_sizes = sizes
         result.fmap = as_nchw_view(fmap)
-        result.rois = torch.cat((im_inds.float()[:, None], priors), 1)
+        result.rois = torch.cat((seg_t['im_col'], priors), 1)
         result._num_pairs = sum((e - s) * (e - s - 1) for _, s, e in segs)   # host-side count (private)
         result._segs = segs                                                    # (image, first box, end box): host-side (private)
         # host-side facts about the graphs (private): (images, most nodes, most candidate edges in one image).  In training
@@ -312,11 +315,27 @@ class RelModelBase(nn.Module):
         assert boxes_scaled.max() <= 1 + 1e-3, (boxes_scaled.max(), boxes.max(), im_sizes)
         return boxes_scaled
 
-    def gt_labels(self, gt_boxes, gt_classes, gt_rels=None, sample_factor=-1, segs=None):
-        """rel_model_base.py:277-300 + proposal_assignments_gtbox (lib/proposal_assignments_gtbox.py:7-80)."""
+    def _segment_tensors(self, segs, im_host, dev):
+        key = (tuple((i, e - s) for i, s, e in segs), str(dev))
+        cache = self.__dict__.setdefault('_seg_cache', {})
+        t = cache.get(key)
+        if t is None:
+            if len(cache) > 64:
+                cache.clear()
+            im = torch.tensor(im_host, dtype=torch.int64).to(dev)
+            first = [0] * (segs[-1][0] + 1)
+            for i, s, _ in segs:
+                first[i] = s
+            t = cache[key] = dict(im_inds=im, im_col=im.float()[:, None].contiguous(),
+                                  first=torch.tensor(first, dtype=torch.int32).to(dev))
+        return t
+
+    def gt_labels(self, gt_boxes, gt_classes, gt_rels=None, sample_factor=-1, segs=None, _seg_t=None):
+        """rel_model_base.py:277-300 + proposal_assignments_gtbox (lib/proposal_assignments_gtbox.py:7-80).
+        `_seg_t` (private, faster_rcnn): the cached per-signature index tensors; the RoI rows are then left to the caller (None)."""
         assert gt_boxes is not None
         im_inds = gt_classes[:, 0]
-        rois = torch.cat((im_inds.float()[:, None], gt_boxes.float()), 1)
+        rois = torch.cat((im_inds.float()[:, None], gt_boxes.float()), 1) if _seg_t is None else None
         if gt_rels is not None and self.training:
             if segs is None:
                 segs = list(enumerate_by_image_host(im_inds.to('cpu').tolist()))
@@ -327,8 +346,8 @@ class RelModelBase(nn.Module):
             n_cand = sum((e - s) * (e - s - 1) for _, s, e in segs)
             R = gt_rels.shape[0]
             cap = n_cand + R
-            out, count = ops.pair_index_train(im_inds.long().contiguous(), gt_rels.long().contiguous(),
-                                              torch.tensor(first, dtype=torch.int32).to(im_inds.device), cap)
+            out, count = ops.pair_index_train(_seg_t['im_inds'] if _seg_t is not None else im_inds.long().contiguous(), gt_rels.long().contiguous(),
+                                              _seg_t['first'] if _seg_t is not None else torch.tensor(first, dtype=torch.int32).to(im_inds.device), cap)
             # rows = candidates + (extra rows for duplicate FG relations on one pair); FG pairs replace a candidate.
             # With a host mirror of gt_rels the count is computed here (R is a few dozen); otherwise read it back.
             rels_host = getattr(gt_rels, '_sgg_host', None)
@@ -388,7 +407,7 @@ class RelModelBase(nn.Module):
                 # every ordered pair exactly once, nothing sub-sampled: the rows are the evaluation candidate list (plus labels), so
                 # the graph index tables cached per box-count signature apply (rel_model_stanford.forward)
                 rel_labels._sgg_plain = bool(R == len(fg_pairs) and rel_labels.shape[0] == n_cand)
-            obj_labels = gt_classes[:, 1].contiguous()
+            obj_labels = gt_classes[:, 1]               # (a strided view: the fused cross-entropy and F.cross_entropy both take it)
         else:
             obj_labels = gt_classes[:, 1]
             rel_labels = None

@@ -69,7 +69,7 @@ class RelModelStanford(RelModelBase):
         w['fc6_obj_b'] = f(fc['fc6_obj'][1].bias)
         w['fc6_edge_b'] = f(fc['fc6_edge'][1].bias)
         sd = {k: v for k, v in self.head_named_parameters() if 'gru' in k or 'w_fc' in k}
-        w['imp'] = ImpWeights.from_state(sd, dtype)
+        w['imp'] = ImpWeights.from_state(sd, dtype, cast=self._shadow_cast)
         self._prep = dict(key=key, val=w)
         return w
 
@@ -138,7 +138,7 @@ class RelModelStanford(RelModelBase):
                                  graphs=_graphs, im_sizes=im_sizes, pairing=paired, csr=_csr)
         w = self.prepared()
         # :100  union_boxes(edge_feat, rois, rel_inds[:,1:]) -- conv(rects)[E,512]; the broadcast add rides in fc6's K
-        rect = self.union_boxes.rect_feat(rois, rel_inds[:, 1:].contiguous(), dtype, im_sizes)
+        rect = self.union_boxes.rect_feat(rois, ops.pairs_of(rel_inds), dtype, im_sizes)
         # :103  obj_unary(roi_fmap_obj(node_feat)) -- three short-M GEMMs (256 rows), latency-bound: on the node lane's
         # stream they run under the edge MLP below instead of in front of it (message_pass keeps using that lane)
         def node_mlp():
@@ -244,13 +244,15 @@ class RelModelStanford(RelModelBase):
             ckey = (tuple((i, e - s) for i, s, e in segs), str(dev), os.environ.get('SGG_EDGE_PAIRS', '1')) if (
                 segs is not None and plain and self.mode != 'sgdet' and os.environ.get('SGG_GRAPH_CACHE', '1') != '0') else None
             cached = self.__dict__.setdefault('_graph_cache', {}).get(ckey) if ckey is not None else None
-            if cached is not None and not self.training:
-                rel_inds = cached['rel_inds']
+            if cached is not None:
+                rel_inds = cached['rel_inds']        # (training, one row per ordered pair: the label rows' first three columns are this list)
             else:
                 rel_inds = self.get_rel_inds(result.rel_labels if self.training else None, im_inds, boxes,
                                              _num=getattr(result, '_num_pairs', None))   # :144
             result.rel_inds = rel_inds
-            rois = torch.cat((im_inds[:, None].float(), boxes), 1)                       # :146
+            rois = getattr(result, 'rois', None)                                         # :146 (both branches of faster_rcnn leave it)
+            if rois is None:
+                rois = torch.cat((im_inds[:, None].float(), boxes), 1)
             # every unordered box pair pooled (and, in predict, sent through fc6's long contraction) once: sgg_amd/pairing.py
             pairing = None
             if cached is not None:
@@ -269,6 +271,7 @@ class RelModelStanford(RelModelBase):
             if cached is None:
                 if len(self._graph_cache) > 32:
                     self._graph_cache.clear()
+                rel_inds._sgg_pairs = rel_inds[:, 1:].contiguous()          # (subject, object) columns as the kernels take them: ops.pairs_of
                 cached = self._graph_cache[ckey] = dict(rel_inds=rel_inds, pairing=pairing,
                                                         csr=ops.edge_csr(rel_inds, rois.shape[0], im_inds.contiguous(),
                                                                          graphs=getattr(result, '_graphs', None)))

@@ -60,32 +60,49 @@ def tn_gemm(X, Y, out=None, want_colsum=False, out_dtype=torch.float32):
 
 
 def train_weights(model):
-    """Forward operands (model.prepared()) + the transposed copies the backward needs, cached on the same key."""
+    """Forward operands (model.prepared()) + the transposed copies the backward needs, cached on the same key.  The derived buffers
+    are allocated once per (model, dtype) and rewritten in place after every update: a rebuild is the library's transposes plus two
+    strided copies, no allocation and no fill."""
     w = model.prepared()
     if 'train' in w:
         return w
     dt = model.compute_dtype
+    keep = model.__dict__.setdefault('_train_bufs', {})
+    if keep.get('dtype') != dt or keep.get('device') != model.rel_fc.weight.device:
+        keep.clear()
+        keep.update(dtype=dt, device=model.rel_fc.weight.device)
+
+    def tr(name, x):
+        out = keep.get(name)
+        if out is not None and (out.shape[0] != x.shape[1] or out.shape[1] < x.shape[0]):
+            out = None
+        keep[name] = ops.transpose(x, out=out)
+        return keep[name]
     t = {}
     for name in ('fc7_obj', 'obj_unary', 'fc7_edge', 'edge_unary', 'obj_fc', 'rel_fc'):
-        t[name + '_t'] = ops.transpose(w[name])                         # [K, Np]
-    C = model.edge_dim
-    t['w6sum_t'] = ops.transpose(w['fc6_edge_sum'])                      # [C, 4096]
+        t[name + '_t'] = tr(name + '_t', w[name])                        # [K, Np]
+    t['w6sum_t'] = tr('w6sum_t', w['fc6_edge_sum'])                      # [C, 4096]
     imp = w['imp']
     for g in ('edge_gru', 'node_gru'):
-        t[g + '_w_ih_t'] = ops.transpose(getattr(imp, g + '_w_ih'))     # [H, 3H]
-        t[g + '_w_hh_t'] = ops.transpose(getattr(imp, g + '_w_hh'))
+        t[g + '_w_ih_t'] = tr(g + '_w_ih_t', getattr(imp, g + '_w_ih'))  # [H, 3H]
+        t[g + '_w_hh_t'] = tr(g + '_w_hh_t', getattr(imp, g + '_w_hh'))
     ub = model.union_boxes
     f = lambda p: p.detach().float().contiguous()
-    d2, d = ub.conv[0].weight.shape[0], ub.conv[4].weight.shape[0]
+    c0, c4 = ub.conv[0].weight, ub.conv[4].weight
+    d2, d = c0.shape[0], c4.shape[0]
     if d2 % 64:
         raise NotImplementedError('training needs union_boxes dim/2 to be a multiple of 64')
-    w1 = torch.zeros((d2, 128), dtype=torch.float32, device=ub.conv[0].weight.device)
-    w1[:, :98] = f(ub.conv[0].weight).reshape(d2, 98)
-    t['rc_w1'] = w1.to(dt)
+    w1, w2 = keep.get('rc_w1'), keep.get('rc_w2')
+    if w1 is None or tuple(w1.shape) != (d2, 128) or tuple(w2.shape) != (d, d2):
+        w1 = keep['rc_w1'] = torch.zeros((d2, 128), dtype=dt, device=c0.device)     # 7x7x2 taps = 98 columns of the 128-wide patch rows
+        w2 = keep['rc_w2'] = torch.empty((d, d2), dtype=dt, device=c0.device)
+    with torch.no_grad():
+        w1[:, :98].copy_(c0.detach().reshape(d2, 98))                       # (one converting strided copy each)
+        w2.copy_(c4.detach()[:, :, 1, 1])                                   # centre tap (the only one that sees data)
+    t['rc_w1'], t['rc_w2'] = w1, w2
     t['rc_b1'] = f(ub.conv[0].bias)
-    t['rc_w2'] = f(ub.conv[4].weight)[:, :, 1, 1].contiguous().to(dt)     # centre tap (the only one that sees data)
     t['rc_b2'] = f(ub.conv[4].bias)
-    t['rc_w2_t'] = ops.transpose(t['rc_w2'])                               # [d2, d]
+    t['rc_w2_t'] = tr('rc_w2_t', w2)                                        # [d2, d]
     t['rc_g1'], t['rc_be1'] = f(ub.conv[2].weight), f(ub.conv[2].bias)
     t['rc_g2'], t['rc_be2'] = f(ub.conv[6].weight), f(ub.conv[6].bias)
     t['ones'] = None
@@ -120,7 +137,7 @@ class PredictFn(torch.autograd.Function):
         dev = nf.device
         sv = {}
         # ---- rect conv, batch-statistics BatchNorm (lib/get_union_boxes.py:51-59)
-        pairs = rel_inds[:, 1:].contiguous()
+        pairs = ops.pairs_of(rel_inds)
         patches = ops.union_rect_patches(rois, pairs, dt, ub.pooling_size * 4 - 1, 128,
                                          im_sizes=ub.raster_sizes(getattr(model, '_im_sizes_hint', None)))   # [4E,128]
         h1 = ops.gemm(patches, t['rc_w1'], t['rc_b1'], ops.ACT_RELU)                               # [4E,d2]
@@ -131,9 +148,7 @@ class PredictFn(torch.autograd.Function):
         h3 = ops.gemm(h2, t['rc_w2'], t['rc_b2'], ops.ACT_RELU)                                    # [E,d]
         rect, _, m2, is2 = ops.bn_train(h3, t['rc_g2'], t['rc_be2'], bn2.running_mean, bn2.running_var, bn2.eps,
                                         bn2.momentum, False, bn_sync)
-        with torch.no_grad():
-            bn1.num_batches_tracked += 1
-            bn2.num_batches_tracked += 1
+        ub.count_train_batch()                    # BatchNorm's num_batches_tracked, applied when somebody looks (union_boxes.py)
         sv.update(patches=patches, h1=h1, h2=h2, arg=arg, m1=m1, is1=is1, h3=h3, m2=m2, is2=is2, rect=rect)
         # (edge_feat + conv(rects))^T, the X operand of fc6's weight gradient, depends on forward data only: its 0.25 ms of
         # HBM-bound transposing runs NOW on the node lane's stream, under the MFMA-bound fc6 GEMMs below, instead of on the
@@ -311,9 +326,7 @@ class PredictFn(torch.autograd.Function):
         dgi_call = lambda c: DG[(T - c) * E:(T - c + 1) * E]
         dP = lambda i: DG[(T + 1) * E + i * N:(T + 1) * E + (i + 1) * N]
         dGHe = torch.empty(((T + 1) * E, 3 * H), dtype=dt, device=dev)
-        d_gw = torch.zeros((4, 2 * H), dtype=torch.float32, device=dev)
-        d_gb = torch.zeros((4, 4), dtype=torch.float32, device=dev)     # column 0 of a 16-byte row per gate: the views handed on stay aligned
-        ones = torch.ones((T * E, 1), dtype=dt, device=dev)
+        d_gw = torch.empty((4, 2 * H), dtype=torch.float32, device=dev)      # both halves are written whole in phase C
         # gate-side partials of all iterations, stacked like HN / HE so that the gate-weight gradients are three
         # contractions over T E / T N rows in phase C instead of 3 T small ones
         da_all = torch.empty((T * E, 4), dtype=torch.float32, device=dev)
@@ -399,12 +412,12 @@ class PredictFn(torch.autograd.Function):
         G['node_gru.weight_ih'], G['node_gru.bias_ih'] = tn_gemm(dGIn, XN, want_colsum=True)
         G['node_gru.weight_hh'] = tn_gemm(dGHn[N:], HN[:T * N])
         G['node_gru.bias_hh'] = ops.colsum(dGHn)
-        ops.rank4_reduce_(da_all, HE[:T * E], d_gw, col0=H)         # e_i = rows i of HE, v_i = rows i of HN
-        ops.rank4_reduce_(nsum_all, HN[:T * N], d_gw, col0=0)
-        ops.rank4_reduce_(da_all, ones, d_gb)
-        for k, g in enumerate(GATES):                       # views of the two accumulators (nothing writes them after this point)
+        ops.rank4_reduce_(da_all, HE[:T * E], d_gw, col0=H, accumulate=False)         # e_i = rows i of HE, v_i = rows i of HN
+        ops.rank4_reduce_(nsum_all, HN[:T * N], d_gw, col0=0, accumulate=False)
+        d_gb = ops.colsum(da_all)                           # the gate biases: column sums of the gate pre-activation gradients
+        for k, g in enumerate(GATES):                       # views of the two results (nothing writes them after this point)
             G[g + '.0.weight'] = d_gw[k:k + 1]
-            G[g + '.0.bias'] = d_gb[k, :1]
+            G[g + '.0.bias'] = d_gb[k:k + 1]
         _lib.set_tag('bwd_rect')
         d_rect = ops.gemm(d_pre6, t['w6sum_t'])                                    # [E,C]
         # rect conv backward (BatchNorm with batch statistics)
@@ -412,9 +425,8 @@ class PredictFn(torch.autograd.Function):
         d_c2, db2, dg2 = ops.bn_bwd(d_rect, None, sv['h3'], sv['m2'], sv['is2'], t['rc_g2'], False, bn_sync)
         G['union_boxes.conv.6.weight'], G['union_boxes.conv.6.bias'] = dg2, db2
         gw2, gb2 = tn_gemm(d_c2, sv['h2'], want_colsum=True)                       # [d, d2] centre tap
-        full = torch.zeros(tuple(model.union_boxes.conv[4].weight.shape), dtype=torch.float32, device=dev)
-        full[:, :, 1, 1] = gw2
-        G['union_boxes.conv.4.weight'] = full
+        # only the centre tap of this 3x3 convolution sees data (1x1 input, padding 1): its gradient with a ring of zeros, one launch
+        G['union_boxes.conv.4.weight'] = torch.nn.functional.pad(gw2[:, :, None, None], (1, 1, 1, 1))
         G['union_boxes.conv.4.bias'] = gb2
         d_h2 = ops.gemm(d_c2, t['rc_w2_t'])                                        # [E,d2]
         d_c1, db1, dg1 = ops.bn_bwd(d_h2, sv['arg'], sv['h1'], sv['m1'], sv['is1'], t['rc_g1'], True, bn_sync)

@@ -64,7 +64,7 @@ class FusedSGD(torch.optim.Optimizer):
         if self._norm is None:
             self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
             self._norm_ws = torch.empty(2048, dtype=torch.float32, device=dev)      # partial sums of sgg_sqnorm_multi (fixed-order reduction)
-        self._norm.zero_()
+        norm_started = False                                    # the first sgg_sqnorm_multi of the step overwrites the accumulator
         grads = grads or {}
         shards = {p: r for p, r in (shards or {}).items() if r is not None}
         live = []                                               # (param, gradient, lr)
@@ -113,8 +113,12 @@ class FusedSGD(torch.optim.Optimizer):
                 lr = np.ascontiguousarray(np.array([l for _, _, l in sel], dtype=np.float32))
                 if norm is not None:
                     acc = self._norm_parts.data_ptr() if part else norm
-                    _lib.call('sgg_sqnorm_multi', gp.ctypes.data, nn.ctypes.data, len(sel), acc, self._norm_ws.data_ptr(), ops.dt(sel[0][1]), stream)
+                    _lib.call('sgg_sqnorm_multi', gp.ctypes.data, nn.ctypes.data, len(sel), acc, self._norm_ws.data_ptr(),
+                              1 if (part or norm_started) else 0, ops.dt(sel[0][1]), stream)
+                    norm_started = norm_started or not part
                 pending.append((dtype, gp, pp, bp, sp, nn, lr, len(sel), sel))
+        if norm is not None and not norm_started:
+            self._norm.zero_()                                  # every live tensor is sharded: the replicated share is 0
         if norm is not None and (shards or self.sync_norm):
             # the parts' squared norms of all ranks join the replicated tensors' one, and EVERY rank ends up with the same number: the
             # replicated share travels as norm / world (the reduced gradients are the same bits on every rank and the local reduction
@@ -363,14 +367,14 @@ class Trainer(object):
             if norm is None:
                 norm = self._norm_cache[key] = torch.tensor([float(N), float(E)], dtype=torch.float32, device=dev)
         dt_ = m.compute_dtype
-        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)          # written by the first head's call, added to by the second
         d_obj = torch.empty((N, 256), dtype=dt_, device=dev)           # 151 -> 256, 51 -> 128: what the TN weight-gradient kernel takes
         d_rel = torch.empty((E, 128), dtype=dt_, device=dev)
         alpha, beta, gamma = self.loss_weights
         assert alpha == beta == 1, ('wrong loss is used, use dnorm or dnorm-fgbg', alpha, beta)          # lib/losses.py:41
         if getattr(self, '_label_flag', None) is None:
             self._label_flag = torch.zeros(1, dtype=torch.int32, device=dev)
-        ops.ce_fwd_bwd(res.rm_obj_dists.detach(), res.rm_obj_labels, norm[0:1], 1.0, loss, d_obj, self.loss_scale, self._label_flag)
+        ops.ce_fwd_bwd(res.rm_obj_dists.detach(), res.rm_obj_labels, norm[0:1], 1.0, loss, d_obj, self.loss_scale, self._label_flag, accumulate=False)
         ops.ce_fwd_bwd(res.rel_dists.detach(), res.rel_labels[:, -1], norm[1:2], gamma, loss, d_rel, self.loss_scale, self._label_flag)
         m._logit_grads = (d_obj, d_rel)
         return loss[0]
@@ -403,6 +407,8 @@ class Trainer(object):
             torch.cuda.current_stream(next(self.model.parameters()).device).wait_event(ev)
         if self.dist_on and (self.opt.stale_masters or self.opt.momentum_parts):
             self.opt.gather_masters()
+        if hasattr(getattr(self.model, 'union_boxes', None), 'flush_batch_counts'):
+            self.model.union_boxes.flush_batch_counts()
         if hasattr(self.model, 'check_pair_flag'):
             self.model.check_pair_flag(wait=True)     # the last steps' pair-table flags (rel_model_stanford._watch_pair_flag)
         flag = getattr(self, '_label_flag', None)

@@ -73,6 +73,21 @@ class UnionBoxesAndFeats(nn.Module):
             nn.BatchNorm2d(dim, momentum=BATCHNORM_MOMENTUM),
         )
         self._prep = {}
+        # train-mode forwards of the HIP path count here; the two BatchNorms' `num_batches_tracked` buffers (device scalars that only
+        # checkpoints read: momentum is a constant) receive the count when a state_dict is taken or flush_batch_counts() is called --
+        # not with two device launches per step
+        self._pending_batches = 0
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.flush_batch_counts())
+
+    def count_train_batch(self):
+        self._pending_batches += 1
+
+    def flush_batch_counts(self):
+        n, self._pending_batches = self._pending_batches, 0
+        if n:
+            with torch.no_grad():
+                self.conv[2].num_batches_tracked += n
+                self.conv[6].num_batches_tracked += n
 
     def prepared(self, dtype):
         key = (dtype, tuple(p._version for p in self.parameters()), tuple(b._version for b in self.buffers()),
