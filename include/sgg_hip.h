@@ -197,11 +197,15 @@ int sgg_gemm_groupadd(const void* A, int lda, const void* W, int ldw, const floa
  * run on sgg_gemm / sgg_conv3x3_relu).  NHWC, C a multiple of 8 except where noted.
  * sgg_im2col: patch matrix of a k x k / stride / pad convolution, row = output pixel, columns (ky, kx, c) zero-filled to Kp; src is a
  *   plane [B, H+2 src_pad, W+2 src_pad, Ca] of which the first C channels are used (any C; f32 -> bf16 conversion allowed).
+ * sgg_col2im: the adjoint of sgg_im2col on a dense plane (src_pad 0, Ca = C): d_src[B,H,W,C] = gathered sums of d_cols[B*Ho*Wo, Kp] -- the
+ *   input gradient of a convolution run as patch matrix x GEMM (the GAN's generator / discriminators, augment/gan.py:74-160, crn.py:64-142).
  * sgg_maxpool3x3s2: MaxPool2d(3, stride 2, padding 1) on [B,H,W,C] -> [B,(H-1)/2+1,(W-1)/2+1,C].
  * sgg_plane_copy: dst[b,y,x,:] = src[b, y*stride, x*stride, :] between planes with borders src_pad / dst_pad (interiors only).
  * sgg_add_relu: y = max(y + x, 0). */
 int sgg_im2col(const void* src, int B, int H, int W, int Ca, int C, int src_pad, int k, int stride, int pad, int Ho, int Wo, void* dst,
                int Kp, int src_dtype, int dst_dtype, void* stream);
+int sgg_col2im(const void* d_cols, int B, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo, int Kp, void* d_src, int dtype,
+               void* stream);
 int sgg_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C, int dtype, void* stream);
 int sgg_plane_copy(const void* src, int Hs, int Ws, int src_pad, void* dst, int Hd, int Wd, int dst_pad, int B, int C, int stride, int dtype,
                    void* stream);

@@ -52,6 +52,37 @@ __global__ __launch_bounds__(256) void im2col8_kernel(const T* __restrict__ src,
     store8(dst + row * Kp + col, v);
 }
 
+// Adjoint of im2col (the input gradient of a convolution run as patch matrix x GEMM): d_src[b,y,x,c] = sum over the taps (ky,kx) whose
+// output pixel (yo,xo) = ((y + p - ky) / s, (x + p - kx) / s) exists of d_cols[(b,yo,xo), (ky,kx,c)].  One thread per input element: a
+// gather, every sum in a fixed order (no atomics).  d_cols [B*Ho*Wo, Kp], d_src [B,H,W,C] dense.
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ cols, T* __restrict__ dsrc, int H, int W, int C, int k, int s, int p,
+                                                     int Ho, int Wo, int Kp, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int x = (int)(r % W);
+    r /= W;
+    const int y = (int)(r % H);
+    const int b = (int)(r / H);
+    float acc = 0.f;
+    for (int ky = 0; ky < k; ++ky) {
+        const int ty = y + p - ky;
+        if (ty < 0 || ty % s) continue;
+        const int yo = ty / s;
+        if (yo >= Ho) continue;
+        for (int kx = 0; kx < k; ++kx) {
+            const int tx = x + p - kx;
+            if (tx < 0 || tx % s) continue;
+            const int xo = tx / s;
+            if (xo >= Wo) continue;
+            acc += Elem<T>::ld(cols + (((long)b * Ho + yo) * Wo + xo) * Kp + (ky * k + kx) * C + c);
+        }
+    }
+    Elem<T>::st(dsrc + i, acc);
+}
+
 // MaxPool2d(kernel 3, stride 2, padding 1) on NHWC rows [B, H, W, C] -> [B, Ho, Wo, C]
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool3s2_kernel(const T* __restrict__ in, T* __restrict__ out, int H, int W, int C, int Ho, int Wo,
@@ -136,6 +167,18 @@ extern "C" int sgg_im2col(const void* src, int B, int H, int W, int Ca, int C, i
         SGG_FOR_DTYPE2(src_dtype, dst_dtype, hipLaunchKernelGGL((im2col_kernel<TA, TB>), grid_for(total), dim3(256), 0, s, (const TA*)src, (TB*)dst, H, W, Ca, C,
                                                                 src_pad, k, stride, pad, Ho, Wo, Kp, total));
     }
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_col2im(const void* d_cols, int B, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo, int Kp, void* d_src, int dtype,
+                          void* stream) {
+    if (B == 0) return SGG_OK;
+    if (!d_cols || !d_src || B < 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || stride <= 0 || pad < 0 || Kp < k * k * C) return SGG_ERR_ARG;
+    if (Ho != (H + 2 * pad - k) / stride + 1 || Wo != (W + 2 * pad - k) / stride + 1) return SGG_ERR_ARG;
+    const long total = (long)B * H * W * C;
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(col2im_kernel<T>, grid_for(total), dim3(256), 0, (hipStream_t)stream, (const T*)d_cols, (T*)d_src, H, W, C, k,
+                                            stride, pad, Ho, Wo, Kp, total));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

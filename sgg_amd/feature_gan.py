@@ -2,14 +2,15 @@
 (augment/gan.py:17-259: constructor arguments, parameter names -- the reference's `state_dict()` loads by name -- `forward`,
 `loss`, `loss_fn`), `dummy_nodes` (augment/gan.py:262-289), `RefinementNetwork` / `RefinementModule` (augment/crn.py:64-142).
 
-What runs where.  The generator's data movement is this package's HIP code: the scene-graph convolutions gather / pool through
-`triple_gather` / `triple_pool`, and the per-object 7x7 patches are resampled onto the 38x38 canvas and summed per image by the
-one-launch `boxes_to_layout` kernel (sgg_amd/gan_ops.py, csrc/gan.hip), each with its adjoint, so the whole model trains.  The small
-dense layers around them -- the Linear layers of the graph convolutions, the 3x3 / 1x1 convolutions on 7x7 patches, the cascaded
-refinement network on the 38x38 canvas, the three spectral-norm discriminators -- are plain library layers (torch.nn on ROCm:
-MIOpen / hipBLASLt), as the reference runs them through cuDNN: they are dense library shapes with no gather in them, and
-nothing on the SGCls hot path depends on them.  `features.hdf5` (the `vis_cond` file of real per-class 512x7x7 features) is read
-by sgg_amd/hdf5_lite.py.
+What runs where.  Everything with a contraction or a gather in it is this package's HIP code: the scene-graph convolutions gather /
+pool through `triple_gather` / `triple_pool` and multiply through `sgg_amd.dense.Linear`; the 3x3 / 1x1 convolutions on the 7x7
+patches, the cascaded refinement network on the 38x38 canvas and the three spectral-norm discriminators are `sgg_amd.dense.Conv2d`
+(patch matrix + the exact-fp32 MFMA GEMM, backward through the same GEMM and `sgg_col2im`); the per-object patches are resampled onto
+the canvas and summed per image by the one-launch `boxes_to_layout` kernel (sgg_amd/gan_ops.py, csrc/gan.hip) -- each with its adjoint,
+so the whole model trains.  The networks are channels-last from end to end: a feature map is the [B*H*W, C] row matrix the GEMM reads,
+`forward` returns an NCHW *view* of it (what the SGG model's RoIAlign takes without a copy).  Elementwise pieces (activations, batch
+normalisation, 2x2 average pools, nearest-neighbour upsampling, the losses) are torch expressions.  `features.hdf5` (the `vis_cond`
+file of real per-class 512x7x7 features) is read by sgg_amd/hdf5_lite.py.
 
 Not carried: the GloVe tables (`lib/word_vectors.py`; `embed_objs` is only used by the scene-graph perturbations
 (sgg_amd/sg_perturb.py), and `init_embed` "led to worse results" and is off in the reference): pass `embed_objs=` / `embed_rels=`
@@ -19,84 +20,117 @@ import numpy as np
 import torch
 import torch.nn as nn
 from torch.nn import functional as F
-from torch.nn.functional import binary_cross_entropy_with_logits as BCE
-from torch.nn.utils import spectral_norm
 
-from .gan_ops import GraphTripleConvNet, boxes_to_layout
+from . import dense
+from .gan_ops import GraphTripleConvNet, boxes_to_layout_nhwc
+
+
+def to_nhwc(x):
+    """NCHW tensor -> channels-last tensor [B,H,W,C] (no copy when x is an NCHW view of channels-last memory, as the detector's maps are)"""
+    return x.permute(0, 2, 3, 1)
+
+
+def to_nchw(x):
+    return x.permute(0, 3, 1, 2)
+
+
+class _OnPlanes(nn.Module):
+    """runs a torch NCHW spatial op on a channels-last tensor through views (the op sees channels_last memory)"""
+
+    def __init__(self, fn):
+        super(_OnPlanes, self).__init__()
+        self.fn = fn
+
+    def forward(self, x):
+        return to_nhwc(self.fn(to_nchw(x)))
+
+
+class InstanceNormRows(nn.Module):
+    """nn.InstanceNorm2d (no affine, no running statistics: nothing in the state_dict) on channels-last maps"""
+
+    def __init__(self, eps=1e-5):
+        super(InstanceNormRows, self).__init__()
+        self.eps = eps
+
+    def forward(self, x):
+        mean = x.mean((1, 2), keepdim=True)
+        var = (x - mean).square().mean((1, 2), keepdim=True)
+        return (x - mean) * torch.rsqrt(var + self.eps)
 
 
 # ------------------------------------------------------------------------------------------------ augment/crn.py
 def get_normalization_2d(channels, normalization):
-    """augment/crn.py:38-46"""
-    if normalization == 'instance':
-        return nn.InstanceNorm2d(channels)
-    if normalization == 'batch':
-        return nn.BatchNorm2d(channels)
-    if normalization == 'none':
-        return None
-    raise ValueError('Unrecognized normalization type "%s"' % normalization)
+    """augment/crn.py:38-46, channels-last layers"""
+    table = {'instance': lambda: InstanceNormRows(), 'batch': lambda: dense.BatchNormRows(channels), 'none': lambda: None}
+    if normalization not in table:
+        raise ValueError('Unrecognized normalization type "%s"' % normalization)
+    return table[normalization]()
 
 
 def get_activation(name):
     """augment/crn.py:49-62: 'relu', 'leakyrelu', 'leakyrelu-<slope>' -- and, as there, EVERY name ends up a LeakyReLU (the
     reference overwrites `name` before the lookup); the slope defaults to torch's 0.01."""
-    kwargs = {}
-    if name.lower().startswith('leakyrelu') and '-' in name:
-        kwargs = {'negative_slope': float(name.split('-')[1])}
-    return nn.LeakyReLU(**kwargs)
+    slope = float(name.split('-')[1]) if name.lower().startswith('leakyrelu') and '-' in name else 0.01
+    return nn.LeakyReLU(negative_slope=slope)
 
 
 class RefinementModule(nn.Module):
-    """augment/crn.py:64-94: conv3x3 -> norm -> act -> conv3x3 -> norm -> act on [layout pooled to the feature size | features]."""
+    """One scale of the cascade (augment/crn.py:64-94): [layout at this scale | incoming features] -> two 3x3 convolutions, each followed
+    by normalisation and activation.  `net` keeps the reference's Sequential indices (a missing normalisation shifts them, as there).
+    Channels-last: layout [B,h,w,Dl], feats [B,h,w,Df] -> [B,h,w,Dout]."""
 
     def __init__(self, layout_dim, input_dim, output_dim, normalization='instance', activation='leakyrelu'):
         super(RefinementModule, self).__init__()
-        layers = [nn.Conv2d(layout_dim + input_dim, output_dim, kernel_size=3, padding=1),
-                  get_normalization_2d(output_dim, normalization), get_activation(activation),
-                  nn.Conv2d(output_dim, output_dim, kernel_size=3, padding=1),
-                  get_normalization_2d(output_dim, normalization), get_activation(activation)]
-        layers = [layer for layer in layers if layer is not None]
-        for layer in layers:
-            if isinstance(layer, nn.Conv2d):
-                nn.init.kaiming_normal_(layer.weight)
-        self.net = nn.Sequential(*layers)
+        stack = []
+        for n_in in (layout_dim + input_dim, output_dim):
+            conv = dense.Conv2d(n_in, output_dim, 3, padding=1)
+            nn.init.kaiming_normal_(conv.weight)
+            stack += [conv, get_normalization_2d(output_dim, normalization), get_activation(activation)]
+        self.net = nn.Sequential(*[m for m in stack if m is not None])
 
     def forward(self, layout, feats):
-        HH, H = layout.shape[2], feats.shape[2]
-        assert HH >= H
-        if HH > H:
-            layout = F.adaptive_avg_pool2d(layout, output_size=H)
-        return self.net(torch.cat([layout, feats], dim=1))
+        assert layout.shape[1:3] == feats.shape[1:3], (tuple(layout.shape), tuple(feats.shape))
+        return self.net(torch.cat((layout, feats), dim=-1))
 
 
 class RefinementNetwork(nn.Module):
-    """augment/crn.py:97-142: a cascade over len(dims)-1 scales, coarse to fine, the output has the layout's size."""
+    """Cascaded refinement (augment/crn.py:97-142) over len(dims) - 1 scales.  The coarsest scale is the layout size halved once per
+    module; every module sees the layout average-pooled to its scale and the previous module's output upsampled (nearest) to it -- by
+    2 between modules, and straight to the layout's own size for the last one (three modules on a 38x38 layout: 4 -> 8 -> 16 -> 38).  The first
+    module's incoming features are one zero channel.  A 3x3 convolution ends it.  forward: NCHW in, NCHW (view) out."""
 
     def __init__(self, dims, normalization='instance', activation='leakyrelu'):
         super(RefinementNetwork, self).__init__()
-        layout_dim = dims[0]
-        self.refinement_modules = nn.ModuleList()
-        for i in range(1, len(dims)):
-            self.refinement_modules.append(RefinementModule(layout_dim, 1 if i == 1 else dims[i - 1], dims[i],
-                                                            normalization=normalization, activation=activation))
-        self.output_conv = nn.Sequential(nn.Conv2d(dims[-1], dims[-1], kernel_size=3, padding=1))
-        nn.init.kaiming_normal_(self.output_conv[0].weight)
+        self.refinement_modules = nn.ModuleList(
+            RefinementModule(dims[0], dims[i - 1] if i > 1 else 1, dims[i], normalization=normalization, activation=activation)
+            for i in range(1, len(dims)))
+        last = dense.Conv2d(dims[-1], dims[-1], 3, padding=1)
+        nn.init.kaiming_normal_(last.weight)
+        self.output_conv = nn.Sequential(last)
+
+    def scales(self, H, W):
+        n = len(self.refinement_modules)
+        h, w = H >> n, W >> n
+        assert h > 0 and w > 0, 'the layout is too small for %d refinement modules' % n
+        return [(h << (i + 1), w << (i + 1)) for i in range(n - 1)] + [(H, W)]
+
+    def refine(self, layout):
+        """channels-last: [B,H,W,D0] -> [B,H,W,dims[-1]]"""
+        B, H, W, _ = layout.shape
+        planes = to_nchw(layout)
+        feats = None
+        for mod, (h, w) in zip(self.refinement_modules, self.scales(H, W)):
+            at_scale = layout if (h, w) == (H, W) else to_nhwc(F.adaptive_avg_pool2d(planes, (h, w)))
+            if feats is None:
+                feats = layout.new_zeros((B, h, w, 1))
+            else:
+                feats = to_nhwc(F.interpolate(to_nchw(feats), size=(h, w), mode='nearest'))
+            feats = mod(at_scale, feats)
+        return self.output_conv(feats)
 
     def forward(self, layout):
-        N, _, H, W = layout.shape
         self.layout = layout
-        input_H, input_W = H, W
-        for _ in range(len(self.refinement_modules)):
-            input_H //= 2
-            input_W //= 2
-        assert input_H != 0 and input_W != 0
-        feats = torch.zeros(N, 1, input_H, input_W, dtype=layout.dtype, device=layout.device)
-        last = len(self.refinement_modules) - 1
-        for i, mod in enumerate(self.refinement_modules):
-            # (38 -> 4 -> 8 -> 16 -> 38: the last step goes to the layout's own size, not x2)
-            feats = F.interpolate(feats, size=(H, W), mode='nearest') if i == last else F.interpolate(feats, scale_factor=2, mode='nearest')
-            feats = mod(layout, feats)
-        return self.output_conv(feats)
+        return to_nchw(self.refine(to_nhwc(layout)))
 
 
 # ------------------------------------------------------------------------------------------------ augment/gan.py
@@ -182,11 +216,10 @@ class GAN(nn.Module):
                 elif item == 'R':
                     mods.append(nn.ReLU())
                 elif item in ('P', 'Pc'):
-                    mods.append(nn.AvgPool2d(2, ceil_mode=item == 'Pc'))
+                    mods.append(_OnPlanes(nn.AvgPool2d(2, ceil_mode=item == 'Pc')))
                 else:
                     n_out, ks = item
-                    c = nn.Conv2d(n_in, n_out, kernel_size=ks, padding=0)
-                    mods.append(spectral_norm(c) if SN else c)
+                    mods.append(dense.Conv2d(n_in, n_out, ks, padding=0, spectral=SN))
                     n_in = n_out
             return nn.Sequential(*(mods + [nn.Flatten()]))
 
@@ -203,9 +236,9 @@ class GAN(nn.Module):
         self.G_gcn = GraphTripleConvNet(input_dim=embed_dim + 4, input_edge_dim=embed_dim,
                                         output_dim=hidden_dim // 2 * pool_sz * pool_sz, num_layers=n_layers_G,
                                         hidden_dim=hidden_dim, pooling='avg', mlp_normalization='batch' if BN else 'none')
-        self.G_node = nn.Sequential(nn.Conv2d(hidden_dim // 2, hidden_dim, kernel_size=3, padding=1), nn.ReLU(),
-                                    nn.Conv2d(hidden_dim, hidden_dim, kernel_size=3, padding=1), nn.ReLU())
-        self.G_proj = nn.Conv2d(hidden_dim + int(vis_cond is not None) * n_ch, hidden_dim, kernel_size=1)
+        self.G_node = nn.Sequential(dense.Conv2d(hidden_dim // 2, hidden_dim, 3, padding=1), nn.ReLU(),
+                                    dense.Conv2d(hidden_dim, hidden_dim, 3, padding=1), nn.ReLU())
+        self.G_proj = dense.Conv2d(hidden_dim + int(vis_cond is not None) * n_ch, hidden_dim, 1)
         self.G_refine = RefinementNetwork(dims=(hidden_dim, n_ch // 4, n_ch // 2, n_ch), normalization='batch',
                                           activation='leakyrelu-0.2')
 
@@ -226,11 +259,13 @@ class GAN(nn.Module):
         return torch.zeros((n, 1), device=self.device)
 
     def loss_fn(self, predictions, is_fake=True, updateD=False):
-        """augment/gan.py:162-171"""
-        if updateD:
-            return BCE(predictions, self.y_fake(len(predictions)) if is_fake else self.y_real(len(predictions)))
-        assert is_fake
-        return BCE(predictions, self.y_real(len(predictions)))
+        """augment/gan.py:162-171: binary cross-entropy of the logits against "fake" / "real" for a discriminator update, against
+        "real" for the generator's (which only ever scores generated samples)."""
+        n = len(predictions)
+        if not updateD:
+            assert is_fake
+            return F.binary_cross_entropy_with_logits(predictions, self.y_real(n))
+        return F.binary_cross_entropy_with_logits(predictions, self.y_fake(n) if is_fake else self.y_real(n))
 
     def sample_real_features(self, classes):
         """augment/gan.py:193-199: one random real 512x7x7 feature of each object's class out of features.hdf5 (numpy's global RNG,
@@ -243,54 +278,64 @@ class GAN(nn.Module):
             feats.append(torch.from_numpy(np.asarray(dset[ind])).view(1, self.n_ch, self.pool_sz, self.pool_sz))
         return torch.cat(feats)
 
+    def generate(self, gt_objects, boxes_scaled, gt_rels):
+        """The generator, channels-last: -> fake feature maps [B, fmap_sz, fmap_sz, n_ch] (augment/gan.py:174-208)."""
+        P = self.pool_sz
+        objs, boxes, rels = dummy_nodes(gt_objects, boxes_scaled, gt_rels)        # one all-connected extra node per image
+        node_in = torch.cat((self.G_obj_embed(objs[:, -1]), boxes), dim=1)        # class embedding | box
+        node_out, _ = self.G_gcn(node_in, self.G_rel_embed(rels[:, -1]), rels[:, 1:3])
+        real = torch.nonzero(objs[:, -1]).view(-1)                                # the dummies (class 0) leave again
+        objs, boxes = objs[real], boxes[real]
+        n = real.numel()
+        # a node's vector is a (channels, P, P) block in the reference's order; the convolutions here want (P, P, channels)
+        patches = self.G_node(node_out[real].view(n, -1, P, P).permute(0, 2, 3, 1))
+        assert patches.shape[0] == objs.shape[0] == boxes.shape[0], (patches.shape, objs.shape, boxes.shape)
+        if self.h5_data is not None:       # conditioning: a real feature of the same class in front of the generated one
+            seen = self.sample_real_features(objs[:, -1].detach().cpu()).to(patches)
+            patches = torch.cat((seen.permute(0, 2, 3, 1), patches), dim=-1)
+        canvas = boxes_to_layout_nhwc(self.G_proj(patches), boxes, objs[:, 0], self.fmap_sz, self.fmap_sz, pooling='sum')
+        return F.relu(self.G_refine.refine(canvas))
+
     def forward(self, gt_objects, boxes_scaled, gt_rels):
-        """augment/gan.py:174-208 -> fake feature maps [B, n_ch, fmap_sz, fmap_sz]"""
-        gt_objects, boxes_scaled, gt_rels = dummy_nodes(gt_objects, boxes_scaled, gt_rels)
-        obj_vecs = self.G_obj_embed(gt_objects[:, -1])
-        pred_vecs = self.G_rel_embed(gt_rels[:, -1])
-        obj_fg = torch.nonzero(gt_objects[:, -1]).view(-1)
-        nodes_fake = self.G_gcn(torch.cat((obj_vecs, boxes_scaled), dim=1), pred_vecs, gt_rels[:, 1:3])[0][obj_fg]
-        n_obj = len(obj_fg)
-        gt_objects, boxes = gt_objects[obj_fg], boxes_scaled[obj_fg]
-        assert len(nodes_fake) == len(gt_objects) == len(boxes), (nodes_fake.shape, gt_objects.shape, boxes.shape)
-        nodes_fake = self.G_node(nodes_fake.view(n_obj, -1, self.pool_sz, self.pool_sz))
-        if self.h5_data is not None:
-            vis = self.sample_real_features(gt_objects[:, -1].detach().cpu())
-            nodes_fake = torch.cat((vis.to(nodes_fake), nodes_fake), dim=1)
-        layout = boxes_to_layout(self.G_proj(nodes_fake), boxes, gt_objects[:, 0], self.fmap_sz, self.fmap_sz, pooling='sum')
-        return F.relu(self.G_refine(layout))
+        """augment/gan.py:174-208 -> fake feature maps [B, n_ch, fmap_sz, fmap_sz] (an NCHW view of channels-last memory, the form the
+        detector's own maps have in this package)"""
+        return to_nchw(self.generate(gt_objects, boxes_scaled, gt_rels))
+
+    def _roi_planes(self, feats, labels, n_classes):
+        """RoI features [n, n_ch*P*P] or [n, n_ch, P, P] (channel-major, as RoIAlign writes them) -> [n, P, P, n_ch + n_classes]: the
+        discriminator's channels-last input with the class appended as one-hot planes (augment/gan.py:222-231)."""
+        P = self.pool_sz
+        n = feats.shape[0]
+        x = feats.reshape(n, -1, P, P).permute(0, 2, 3, 1)
+        hot = F.one_hot(labels.view(-1), n_classes).to(x.dtype)
+        return torch.cat((x, hot[:, None, None, :].expand(n, P, P, n_classes)), dim=-1)
 
     def loss(self, features_real=None, features_fake=None, is_nodes=False, updateD=False, labels_fake=None, labels_real=None,
              is_fmaps=False):
-        """augment/gan.py:211-259 -> {'D_obj' | 'D_rel' | 'D_fmap' | 'G_obj' | 'G_rel' | 'G_fmap': loss} (or {} when the side is off)"""
-        if updateD and 'D' not in self.losses:
+        """augment/gan.py:211-259 -> {'D_obj' | 'D_rel' | 'D_fmap' | 'G_obj' | 'G_rel' | 'G_fmap': loss} (or {} when the side is off).
+        A discriminator update scores real and generated samples (both detached); a generator update scores the generated ones only,
+        with the gradient flowing back into them."""
+        side = 'D' if updateD else 'G'
+        if side not in self.losses:
             return {}
-        if not updateD and 'G' not in self.losses:
-            return {}
-        # the SGG model may run in bf16 (its RoI features and feature maps then arrive in bf16); the discriminators are fp32 layers
-        wd = self.D_global[0].bias.dtype
-        features_fake = features_fake.to(wd) if features_fake is not None else None
-        features_real = features_real.to(wd) if features_real is not None else None
-        if not is_fmaps:
-            def conditioned(feats, labels, n_classes):                     # class one-hot planes appended to the 7x7 features
-                n = len(feats)
-                y = torch.zeros(n, n_classes, device=feats.device, dtype=feats.dtype).scatter_(1, labels.view(-1, 1), 1)
-                return y[:, :, None, None].expand(n, -1, self.pool_sz, self.pool_sz)
-            n_classes = len(self.obj_classes if is_nodes else self.rel_classes)
-            n_fake = len(features_fake)
-            y_fill_fake = conditioned(features_fake, labels_fake, n_classes)
-            features_fake = torch.cat([features_fake.view(n_fake, -1, self.pool_sz, self.pool_sz), y_fill_fake], 1)
-            if updateD:
-                n_real = len(features_real)
-                y_fill_real = y_fill_fake.clone() if labels_real is None else conditioned(features_real, labels_real, n_classes)
-                features_real = torch.cat([features_real.view(n_real, -1, self.pool_sz, self.pool_sz), y_fill_real], 1)
-        fn = self.D_global if is_fmaps else (self.D_nodes if is_nodes else self.D_edges)
+        kind = 'fmap' if is_fmaps else ('obj' if is_nodes else 'rel')
+        net = {'fmap': self.D_global, 'obj': self.D_nodes, 'rel': self.D_edges}[kind]
         if not updateD:
             assert labels_real is None and features_real is None, 'do not need real labels/features in case of G update'
-        real_loss = self.loss_fn(fn(features_real.detach()), is_fake=False, updateD=True) if updateD else 0
-        fake_loss = self.loss_fn(fn(features_fake.detach() if updateD else features_fake), is_fake=True, updateD=updateD)
-        key = '_'.join(('D' if updateD else 'G', 'fmap' if is_fmaps else ('obj' if is_nodes else 'rel')))
-        return {key: real_loss + fake_loss}
+        # the SGG model may run in a 16-bit mode (its RoI features and feature maps then arrive in it); the discriminators are fp32 layers
+        f32 = lambda t: None if t is None else t.to(torch.float32)        # noqa: E731
+        fake, real = f32(features_fake), f32(features_real)
+        if is_fmaps:
+            prep = lambda t, _labels: to_nhwc(t)                          # noqa: E731
+        else:
+            n_classes = len(self.obj_classes if is_nodes else self.rel_classes)
+            prep = lambda t, labels: self._roi_planes(t, labels, n_classes)   # noqa: E731
+        if updateD:
+            total = self.loss_fn(net(prep(real, labels_fake if labels_real is None else labels_real).detach()), is_fake=False, updateD=True) + \
+                self.loss_fn(net(prep(fake, labels_fake).detach()), is_fake=True, updateD=True)
+        else:
+            total = self.loss_fn(net(prep(fake, labels_fake)), is_fake=True, updateD=False)
+        return {side + '_' + kind: total}
 
 
 # ------------------------------------------------------------------------------------------------ main.py:124-194
@@ -346,8 +391,8 @@ def gan_train_step(sgg_model, gan, res, gt_boxes, gt_objects, gt_rels, optimizer
     loss scale of the f16 mode -- instead of `optimizer.step()` (pass optimizer=None).  Without a trainer the gradients are
     all-reduced here and `optimizer` steps on them.  The GAN's own BatchNorm layers (BatchNorm2d of the refinement network,
     BatchNorm1d of the graph convolutions when BN=True) use batch statistics: convert them with
-    `torch.nn.SyncBatchNorm.convert_sync_batchnorm(gan)` for statistics over every rank's images (what the test does), or keep
-    replica-local statistics."""
+    `sgg_amd.dense.sync_batchnorm_(gan)` (the channels-last counterpart of torch.nn.SyncBatchNorm.convert_sync_batchnorm) for
+    statistics over every rank's images (what the test does), or keep replica-local statistics."""
     from .trainer import Trainer
     import torch.distributed as dist
     world = _dp_world()

@@ -1,7 +1,6 @@
-"""GAN generator data movement (started): `boxes_to_layout` (augment/layout.py:33-71) and the gather / pooling steps
-of `GraphTripleConv` (augment/graphconv.py:51-119) as HIP kernels behind the reference's signatures, differentiable.
-
-The rest of the GAN (CRN refinement, discriminators, losses, augment/gan.py) is not built; see DESIGN.md.
+"""GAN generator data movement: `boxes_to_layout` (augment/layout.py:33-71) and the gather / pooling steps of
+`GraphTripleConv` (augment/graphconv.py:51-119) as HIP kernels behind the reference's signatures, differentiable; the graph
+convolution's MLPs on sgg_amd/dense.py.  The model around them: sgg_amd/feature_gan.py.
 """
 import torch
 
@@ -117,17 +116,18 @@ def triple_pool(new_t_vecs, edges, num_objs, hidden_dim, o_off, pooling='avg'):
 
 def build_mlp(dim_list, activation='relu', batch_norm='none', dropout=0, final_nonlinearity=True):
     """graphconv.py:157-176: Linear [BatchNorm1d] [ReLU | LeakyReLU] ... with the reference's Sequential indices (checkpoints load).
-    The contractions here are plain library GEMMs; the HIP kernels of this module are the gather and the pooling."""
+    The Linear layers multiply on this package's GEMM (sgg_amd/dense.py), the normalisation is its row-matrix BatchNorm."""
+    from . import dense
+    act = {'relu': torch.nn.ReLU, 'leakyrelu': torch.nn.LeakyReLU}.get(activation)
     layers = []
-    for i in range(len(dim_list) - 1):
-        layers.append(torch.nn.Linear(dim_list[i], dim_list[i + 1]))
-        if i != len(dim_list) - 2 or final_nonlinearity:
+    n_layers = len(dim_list) - 1
+    for i, (d_in, d_out) in enumerate(zip(dim_list[:-1], dim_list[1:])):
+        layers.append(dense.Linear(d_in, d_out))
+        if i < n_layers - 1 or final_nonlinearity:
             if batch_norm == 'batch':
-                layers.append(torch.nn.BatchNorm1d(dim_list[i + 1]))
-            if activation == 'relu':
-                layers.append(torch.nn.ReLU())
-            elif activation == 'leakyrelu':
-                layers.append(torch.nn.LeakyReLU())
+                layers.append(dense.BatchNormRows(d_out))
+            if act is not None:
+                layers.append(act())
         if dropout > 0:
             layers.append(torch.nn.Dropout(p=dropout))
     return torch.nn.Sequential(*layers)

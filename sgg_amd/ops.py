@@ -719,6 +719,16 @@ def im2col(x, k, stride, pad, src_pad=0, C=None, Kp=None, dtype=None):
     return out, Ho, Wo
 
 
+def col2im(d_cols, shape, k, stride, pad):
+    """Adjoint of im2col on a dense NHWC plane: d_cols [B*Ho*Wo, Kp] -> d_x of `shape` = (B, H, W, C)."""
+    B, H, W, C = shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    assert d_cols.shape[0] == B * Ho * Wo and d_cols.is_contiguous()
+    out = torch.empty(shape, dtype=d_cols.dtype, device=d_cols.device)
+    _lib.call('sgg_col2im', _p(d_cols), B, H, W, C, k, stride, pad, Ho, Wo, d_cols.shape[1], _p(out), dt(out), _stream())
+    return out
+
+
 def maxpool3x3s2(x):
     """MaxPool2d(3, stride=2, padding=1) on NHWC [B,H,W,C]."""
     B, H, W, C = x.shape

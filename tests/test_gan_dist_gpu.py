@@ -27,6 +27,7 @@ def _free_port():
 
 def _iteration(batch, use_trainer, dist_on):
     import sgg_amd
+    from sgg_amd import dense
     from sgg_amd.feature_gan import GAN, gan_train_step
     from sgg_amd.synthetic import SyntheticData, init_weights
     from sgg_amd.trainer import Trainer
@@ -42,7 +43,7 @@ def _iteration(batch, use_trainer, dist_on):
     gan = GAN(data.ind_to_classes, data.ind_to_predicates, n_ch=model.edge_dim, pool_sz=model.pool_sz, fmap_sz=model.fmap_sz, n_layers_G=2,
               BN=False, device=dev).to(dev)                       # (BatchNorm1d of the graph convolutions would be replica-local)
     if dist_on:      # the refinement network's BatchNorm2d layers (augment/crn.py: normalization='batch'): statistics over every rank's images
-        gan = torch.nn.SyncBatchNorm.convert_sync_batchnorm(gan)
+        gan = dense.sync_batchnorm_(gan)            # (the channels-last counterpart of SyncBatchNorm.convert_sync_batchnorm)
     dev_batch = tuple(t_.to(dev) if isinstance(t_, torch.Tensor) else t_ for t_ in batch)
     model.train()
     tr = Trainer(model, lr=1e-2, comm_dtype=None, sync_bn=True) if (use_trainer or dist_on) else None
