@@ -201,7 +201,9 @@ int sgg_gemm_groupadd(const void* A, int lda, const void* W, int ldw, const floa
  *   input gradient of a convolution run as patch matrix x GEMM (the GAN's generator / discriminators, augment/gan.py:74-160, crn.py:64-142).
  * sgg_maxpool3x3s2: MaxPool2d(3, stride 2, padding 1) on [B,H,W,C] -> [B,(H-1)/2+1,(W-1)/2+1,C].
  * sgg_plane_copy: dst[b,y,x,:] = src[b, y*stride, x*stride, :] between planes with borders src_pad / dst_pad (interiors only).
- * sgg_add_relu: y = max(y + x, 0). */
+ * sgg_add_relu: y = max(y + x, 0).
+ * sgg_upsample_add: y[B,H,W,C] += nearest-neighbour upsampling of top[B,Ht,Wt,C] to (H,W) -- the top-down join of the feature pyramid
+ *   ([3P] FeaturePyramidNetwork: F.interpolate(mode='nearest') + add; the detector of sgdet with backbone='resnet50'). */
 int sgg_im2col(const void* src, int B, int H, int W, int Ca, int C, int src_pad, int k, int stride, int pad, int Ho, int Wo, void* dst,
                int Kp, int src_dtype, int dst_dtype, void* stream);
 int sgg_col2im(const void* d_cols, int B, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo, int Kp, void* d_src, int dtype,
@@ -210,6 +212,7 @@ int sgg_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C, int 
 int sgg_plane_copy(const void* src, int Hs, int Ws, int src_pad, void* dst, int Hd, int Wd, int dst_pad, int B, int C, int stride, int dtype,
                    void* stream);
 int sgg_add_relu(void* y, const void* x, int64_t n, int dtype, void* stream);
+int sgg_upsample_add(void* y, const void* top, int B, int H, int W, int Ht, int Wt, int C, int dtype, void* stream);
 /* img_ptr i32[2*(B+1) + 66*B]: img_ptr[b] = first node of graph b (im_inds i64[N] ascending), img_ptr[B] = N; then
  * img_ptr[B+1+b] = out_ptr[first node of b] = first edge of graph b (out_ptr from sgg_edge_csr, same stream, edges sorted);
  * then per graph 66 graph-relative out-list offsets of its nodes (entries past the last node repeat the edge count). */

@@ -54,6 +54,7 @@ SIGNATURES = {
     'sgg_imp_node_gates_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
     'sgg_graph_ptr': [_P, _I, _I, _P, _P, _P],
     'sgg_im2col': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P],
+    'sgg_upsample_add': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'sgg_col2im': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     'sgg_maxpool3x3s2': [_P, _P, _I, _I, _I, _I, _I, _P],
     'sgg_plane_copy': [_P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],

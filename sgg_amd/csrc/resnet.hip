@@ -132,6 +132,30 @@ __global__ __launch_bounds__(256) void plane_copy_kernel(const T* __restrict__ s
     store8(dst + (((long)b * (Hd + 2 * dp) + y + dp) * (Wd + 2 * dp) + x + dp) * C + cc, v);
 }
 
+// FPN top-down join: y[b,y,x,:] += top[b, sy(y), sx(x), :], nearest-neighbour source index floor(dst * in / out) computed in fp32 as
+// F.interpolate(mode='nearest') does (clamped to the last row / column).  8 channels per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_add_kernel(T* __restrict__ y, const T* __restrict__ top, int H, int W, int Ht, int Wt, int C,
+                                                           long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c8 = C >> 3;
+    const int cc = (int)(i % c8) * 8;
+    long r = i / c8;
+    const int x = (int)(r % W);
+    r /= W;
+    const int yy = (int)(r % H);
+    const int b = (int)(r / H);
+    const float fy = (float)Ht / (float)H, fx = (float)Wt / (float)W;
+    const int sy = min((int)floorf((float)yy * fy), Ht - 1), sx = min((int)floorf((float)x * fx), Wt - 1);
+    float a[8], t[8];
+    load8(y + i * 8, a);
+    load8(top + (((long)b * Ht + sy) * Wt + sx) * C + cc, t);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] += t[q];
+    store8(y + i * 8, a);
+}
+
 // y = max(y + x, 0)  (the residual join of a bottleneck block)
 template <typename T>
 __global__ __launch_bounds__(256) void add_relu_kernel(T* __restrict__ y, const T* __restrict__ x, long n8) {
@@ -179,6 +203,16 @@ extern "C" int sgg_col2im(const void* d_cols, int B, int H, int W, int C, int k,
     const long total = (long)B * H * W * C;
     SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(col2im_kernel<T>, grid_for(total), dim3(256), 0, (hipStream_t)stream, (const T*)d_cols, (T*)d_src, H, W, C, k,
                                             stride, pad, Ho, Wo, Kp, total));
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_upsample_add(void* y, const void* top, int B, int H, int W, int Ht, int Wt, int C, int dtype, void* stream) {
+    if (B == 0) return SGG_OK;
+    if (!y || !top || B < 0 || H <= 0 || W <= 0 || Ht <= 0 || Wt <= 0 || C <= 0 || (C & 7)) return SGG_ERR_ARG;
+    const long total = (long)B * H * W * (C / 8);
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(upsample_add_kernel<T>, grid_for(total), dim3(256), 0, (hipStream_t)stream, (T*)y, (const T*)top, H, W, Ht, Wt, C,
+                                            total));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

@@ -746,6 +746,14 @@ def plane_copy(x, out, src_pad=0, dst_pad=0, stride=1):
     return out
 
 
+def upsample_add_(y, top):
+    """y [B,H,W,C] += nearest-neighbour upsampling of top [B,Ht,Wt,C] to (H,W), in place"""
+    B, H, W, C = y.shape
+    assert top.shape[0] == B and top.shape[3] == C and top.dtype == y.dtype
+    _lib.call('sgg_upsample_add', _p(y), _p(top), B, H, W, top.shape[1], top.shape[2], C, dt(y), _stream())
+    return y
+
+
 def add_relu_(y, x):
     """y = max(y + x, 0) in place"""
     assert y.shape == x.shape and y.dtype == x.dtype

@@ -251,8 +251,6 @@ class RelModelBase(nn.Module):
     def _faster_rcnn_sgdet(self, x, gt_classes):
         """rel_model_base.py:209-235: RPN + RoI heads (sgg_amd/sgdet.py), <= 50 detections per image."""
         from . import sgdet
-        if self.backbone != 'vgg16':
-            raise NotImplementedError('sgdet with backbone %s (RPN over five pyramid levels, multi-level RoIAlign) is not built' % self.backbone)
         # The detector is frozen (main.py:62-63) and always runs as an inference detector here, also under model.train():
         # torchvision's RoIHeads in training mode returns losses and no detections, which is why the reference documents
         # SGDet training as unsupported (README.md:214-218).  rm_obj_labels are the detector's labels, as at :221,:228.
@@ -262,10 +260,14 @@ class RelModelBase(nn.Module):
         else:
             ids = list(range(len(x)))
         images = [x[i] for i in ids]
-        fmap, sizes, padded = self.detector.features(images, dtype)
+        pyramid = None
+        if self.backbone == 'resnet50':          # RPN over P2 .. P5 + pool, box head over P2 .. P5 ([3P] maskrcnn_resnet50_fpn)
+            fmap, sizes, padded, pyramid = self.detector.features(images, dtype, pyramid=True)
+        else:
+            fmap, sizes, padded = self.detector.features(images, dtype)
         self.fmap_hw = (fmap.shape[1], fmap.shape[2])
         orig = [image_hw(im) for im in images]
-        dets = sgdet.detect(self, fmap, sizes, padded, orig, self.spatial_scale(sizes))
+        dets = sgdet.detect(self, fmap, sizes, padded, orig, self.spatial_scale(sizes), pyramid=pyramid)
         priors, priors_org, labels, im_inds = [], [], [], []
         for i, (bx, bx_org, lab, _) in enumerate(dets):
             if bx.shape[0] <= 1:

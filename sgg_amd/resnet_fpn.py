@@ -14,7 +14,9 @@ So the gt-box modes (predcls / sgcls) need: stem, layer1-4, the lateral 1x1 and 
 Every convolution is a contraction on this package's MFMA kernels: 1x1 convolutions are GEMMs on the NHWC rows; the 7x7 stem and the
 three stride-2 3x3 convolutions go through a patch matrix (`sgg_im2col`) + GEMM; the thirteen stride-1 3x3 convolutions run on the
 spatial-conv kernel over zero-bordered planes.  FrozenBatchNorm is folded into the convolution weights when they are prepared.
-sgdet with this backbone (RPN over five levels, multi-level RoIAlign) is not built.
+sgdet (the detector branch, rel_model_base.py:209-235) needs the whole pyramid: `features(..., pyramid=True)` also returns P2 .. P5 --
+lateral 1x1 convolutions of C2 .. C5, the top-down nearest-neighbour joins (`sgg_upsample_add`) and the four 3x3 output convolutions
+-- for the five-level RPN and the four-level RoIAlign of sgg_amd/sgdet.py.
 """
 import math
 
@@ -155,14 +157,15 @@ class ResNet50FPNDetector(nn.Module):
                     d['wd'], d['bd'] = rows(wd), bd
                 blocks.append(d)
         p['blocks'] = blocks
-        p['inner'] = (rows(fpn.inner_blocks[3].weight.detach().float()), fpn.inner_blocks[3].bias.detach().float().contiguous())
-        p['layer'] = (rows(fpn.layer_blocks[3].weight.detach().float()), fpn.layer_blocks[3].bias.detach().float().contiguous())
+        p['inner'] = [(rows(m.weight.detach().float()), m.bias.detach().float().contiguous()) for m in fpn.inner_blocks]
+        p['layer'] = [(rows(m.weight.detach().float()), m.bias.detach().float().contiguous()) for m in fpn.layer_blocks]
         self._prep = dict(key=key, val=p)
         return p
 
-    def features(self, images, dtype):
+    def features(self, images, dtype, pyramid=False):
         """images as VGGDetector.features takes them.  Returns (fmap NHWC [B,Hf,Wf,256] in `dtype` -- the 'pool' level --, image
-        sizes [(h,w)] after resize, (Hp,Wp) padded size)."""
+        sizes [(h,w)] after resize, (Hp,Wp) padded size); pyramid=True: a fourth item, the list [P2, P3, P4, P5] (NHWC, strides
+        4 .. 32) the detector's RPN and box head read besides the 'pool' level."""
         dev = self.backbone.body.conv1.weight.device
         sizes = [self.transform.resized_hw(*image_hw(im)) for im in images]
         d = self.transform.size_divisible
@@ -191,7 +194,11 @@ class ResNet50FPNDetector(nn.Module):
         del cols
         x = ops.maxpool3x3s2(x)
         H, W = x.shape[1], x.shape[2]
-        for blk in p['blocks']:
+        stage_end, done, c_maps = [], 0, []
+        for _, _, nblk, _ in LAYERS:
+            done += nblk
+            stage_end.append(done - 1)
+        for bi, blk in enumerate(p['blocks']):
             mid, s = blk['mid'], blk['stride']
             cin = x.shape[3]
             a = ops.gemm(x.view(-1, cin), blk['w1'], blk['b1'], ops.ACT_RELU)                       # 1x1
@@ -216,11 +223,27 @@ class ResNet50FPNDetector(nn.Module):
             ops.add_relu_(y, idn)
             H, W = Ho, Wo
             x = y.view(B, H, W, y.shape[1])
+            if pyramid and bi in stage_end:
+                c_maps.append(x)                                                                    # C2 .. C5
         # FPN level 3 = the top of the pyramid: lateral 1x1, output 3x3 (no activation), then LastLevelMaxPool (kernel 1, stride 2)
-        inner = ops.gemm(x.view(-1, x.shape[3]), p['inner'][0], p['inner'][1]).view(B, H, W, 256)
-        ip = torch.zeros((B, H + 2, W + 2, 256), dtype=dtype, device=dev)
-        ops.plane_copy(inner, ip, dst_pad=1)
-        cols, _, _ = ops.im2col(ip, 3, 1, 1, src_pad=1)
-        p5 = ops.gemm(cols, p['layer'][0], p['layer'][1]).view(B, H, W, 256)
+        def lateral(c, k):
+            return ops.gemm(c.view(-1, c.shape[3]), p['inner'][k][0], p['inner'][k][1]).view(c.shape[0], c.shape[1], c.shape[2], 256)
+
+        def output(inner, k):                       # 3x3, padding 1, no activation: patch matrix x [256, 2304]
+            h, w = inner.shape[1], inner.shape[2]
+            ip = torch.zeros((B, h + 2, w + 2, 256), dtype=dtype, device=dev)
+            ops.plane_copy(inner, ip, dst_pad=1)
+            cols, _, _ = ops.im2col(ip, 3, 1, 1, src_pad=1)
+            return ops.gemm(cols, p['layer'][k][0], p['layer'][k][1]).view(B, h, w, 256)
+
+        inner = lateral(x, 3)
+        p5 = output(inner, 3)
         pool = ops.plane_copy(p5, torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 256), dtype=dtype, device=dev), stride=2)
-        return pool, sizes, (Hp, Wp)
+        if not pyramid:
+            return pool, sizes, (Hp, Wp)
+        # top-down pathway ([3P] FeaturePyramidNetwork.forward): P_k = output_k(lateral_k(C_k) + upsample(inner_{k+1}))
+        levels = [p5]
+        for k in (2, 1, 0):
+            inner = ops.upsample_add_(lateral(c_maps[k], k), inner)
+            levels.insert(0, output(inner, k))
+        return pool, sizes, (Hp, Wp), levels

@@ -133,11 +133,6 @@ def test_relation_model_with_resnet50_backbone_matches_oracle():
     np.testing.assert_allclose(obj_scores, rs, atol=1e-3)
     np.testing.assert_array_equal(rels[:20], rr[:20])
     np.testing.assert_allclose(pred_scores[:20], rp[:20], atol=1e-3)
-    # sgdet with this backbone is not built: say so instead of running something else
-    model.mode = 'sgdet'
-    with pytest.raises(NotImplementedError):
-        model([dev_batch])
-    model.mode = 'sgcls'
     # ---- training forward and the gradients of every head parameter against torch autograd of the oracle (TwoMLPHead layout:
     # no Dropout, ReLU after the edge branch's fc7), then one Trainer step in bf16
     from sgg_amd.train import param_names
@@ -165,3 +160,120 @@ def test_relation_model_with_resnet50_backbone_matches_oracle():
     tr = Trainer(model, lr=1e-3)
     losses = [float(tr.step(dev_batch)) for _ in range(4)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_pyramid_levels_match_oracle(dtype):
+    """P2 .. P5 (lateral 1x1, top-down nearest joins, 3x3 outputs) + the 'pool' level against the oracle's FeaturePyramidNetwork"""
+    det = seeded_detector(1).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    imgs = [torch.rand(3, 150, 200, generator=g), torch.rand(3, 170, 160, generator=g)]
+    det.transform.min_size, det.transform.max_size = 192, 256
+    with torch.no_grad():
+        pool, sizes, padded, levels = det.features([im.to(DEV) for im in imgs], dtype, pyramid=True)
+        batch, osizes, _ = O.transform(imgs, None, 192, 256)
+        p = {'detector.' + k: v.float().cpu() for k, v in det.state_dict().items()}
+        want = O.resnet50_fpn_levels(batch, p)
+    assert [tuple(s_) for s_ in sizes] == [tuple(s_) for s_ in osizes] and padded == tuple(batch.shape[-2:])
+    assert [lv.shape[1] for lv in levels] == [padded[0] // s_ for s_ in (4, 8, 16, 32)]
+    for got, ref in zip(levels + [pool], want):
+        got = got.float().permute(0, 3, 1, 2).cpu()
+        assert got.shape == ref.shape
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= (3e-4 if dtype == torch.float32 else 2e-2), err
+
+
+def test_upsample_add_equals_interpolate():
+    from sgg_amd import ops
+    g = torch.Generator().manual_seed(1)
+    for (h, w, ht, wt) in ((8, 10, 4, 5), (7, 9, 4, 5), (38, 38, 16, 16)):
+        y = torch.randn(2, h, w, 16, generator=g).to(DEV)
+        top = torch.randn(2, ht, wt, 16, generator=g).to(DEV)
+        want = y + F.interpolate(top.permute(0, 3, 1, 2), size=(h, w), mode='nearest').permute(0, 2, 3, 1)
+        assert torch.equal(ops.upsample_add_(y.clone(), top), want)
+
+
+@pytest.fixture(scope='module')
+def sgdet_r50():
+    import sgg_amd
+    from sgg_amd.resnet_fpn import FrozenBatchNorm2d
+    from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
+    torch.manual_seed(6)
+    S = 192
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgdet', backbone='resnet50', min_size=S, max_size=S))
+    for m in model.modules():
+        if isinstance(m, FrozenBatchNorm2d):
+            m.weight.uniform_(0.5, 1.0)
+            m.running_var.uniform_(0.6, 1.4)
+            m.running_mean.normal_(0, 0.1)
+    with torch.no_grad():        # small regression outputs: proposals stay near their anchors, so NMS has many distinct boxes to order
+        model.detector.rpn.head.bbox_pred.weight.mul_(0.01)
+        model.detector.roi_heads.box_predictor.bbox_pred.weight.mul_(0.05)
+    sd = {k: v.detach().float().clone() for k, v in model.state_dict().items()}
+    model.to(DEV).eval().set_compute_dtype(torch.float32)
+    model.set_box_score_thresh(0.0)
+    batch = synthetic_batch(B=2, S=S, n_boxes=4, n_fg=2, seed=2)
+    with torch.no_grad():
+        ref = O.sgdet_detect(batch[0], sd, score_thresh=0.0, min_size=S, max_size=S, backbone='resnet50')
+    return model, sd, batch, ref, S
+
+
+def test_fpn_proposals_and_level_assignment_match_oracle(sgdet_r50):
+    """RPN over the five maps (3 anchors per location, one size per level), per-level top-1000, NMS inside a level only; LevelMapper;
+    four-level RoIAlign -- each against the oracle on the SAME inputs (the HIP path's own pyramid)."""
+    from sgg_amd import sgdet
+    model, sd, batch, ref, S = sgdet_r50
+    with torch.no_grad():
+        pool, sizes, padded, levels = model.detector.features([im.to(DEV) for im in batch[0]], torch.float32, pyramid=True)
+        w = sgdet.prepared(model, fpn=True)
+        img_hw = torch.tensor([[float(s_[0]), float(s_[1])] for s_ in sizes], device=DEV)
+        rois, offs = sgdet.propose(model, w, levels + [pool], img_hw, padded)
+        nchw = [lv.float().permute(0, 3, 1, 2).cpu() for lv in levels + [pool]]
+        want = O.rpn_proposals_fpn(nchw, sd, sizes, padded)
+    for b, exp in enumerate(want):
+        got = rois[offs[b]:offs[b + 1]].cpu()
+        assert (got[:, 0] == b).all() and abs(len(got) - len(exp)) <= max(2, len(exp) // 50)
+        # random-init objectness is nearly tied, so compare as sets: almost every proposal has a twin within 0.05 px
+        d = (got[:, None, 1:] - exp[None]).abs().amax(2).min(1)[0]
+        assert (d < 5e-2).float().mean() >= 0.9, (b, float((d < 5e-2).float().mean()))
+    # level assignment and the pooled features of the oracle's own proposals
+    props = want[0][:200]
+    np.testing.assert_array_equal(sgdet.pyramid_level_of(torch.cat((torch.zeros(len(props), 1), props), 1).to(DEV), 4).cpu().numpy(),
+                                  O.fpn_level_of(props).numpy())
+    boxes = torch.tensor([[2., 3., 30., 40.], [0., 0., 190., 150.], [50., 20., 170., 140.], [10., 10., 12., 13.]])    # levels 0 .. 2
+    top = float(max(s_[0] for s_ in sizes))
+    scales = [2.0 ** round(np.log2(float(m.shape[1]) / top)) for m in levels]
+    with torch.no_grad():
+        feat = sgdet.box_features(model, levels, scales, torch.cat((torch.zeros(4, 1), boxes), 1).to(DEV))
+    exp = O.multiscale_roi_align(nchw[:4], boxes, 0, sizes).reshape(4, -1)
+    torch.testing.assert_close(feat.float().cpu(), exp, atol=2e-4, rtol=1e-3)
+
+
+def test_sgdet_with_resnet50_backbone_matches_oracle(sgdet_r50):
+    """rel_model_base.py:209-235 with backbone='resnet50' (GQA SGGen): detections as sets (random-init scores are nearly tied, see
+    test_sgdet_gpu.py), then the whole forward against the oracle fed with the HIP path's own detections."""
+    model, sd, batch, ref, S = sgdet_r50
+    with torch.no_grad():
+        res = model.faster_rcnn(batch[0], None, batch[4].to(DEV), None)
+    im = res.im_inds.cpu().numpy()
+    dets = ref[-1]
+    for b, (eb, es, el) in enumerate(dets):
+        gb = res.rm_box_priors.cpu().numpy()[im == b]
+        gl = res.rm_obj_labels.cpu().numpy()[im == b]
+        assert len(gb) == len(eb) <= 50
+        hit = sum(bool(((np.abs(eb.numpy() - bx[None]).max(1) < 5e-2) & (el.numpy() == lb)).any()) for bx, lb in zip(gb, gl))
+        assert hit >= 0.8 * len(gb), (b, hit, len(gb))
+    assert tuple(res.fmap.shape[1:]) == (256, 3, 3)
+    with torch.no_grad():
+        boxes, cls, scores, rels, pred_scores = model([batch])
+        exp = O.forward_from_detections(res.fmap.float().cpu(), res.im_inds.cpu().numpy(), res.rm_box_priors.cpu().numpy(),
+                                        res.rm_box_priors_org.cpu().numpy(), res.im_sizes, sd)
+    rb, rc, rs, rr, rp = exp['dets']
+    np.testing.assert_allclose(boxes, rb, atol=1e-5)
+    np.testing.assert_array_equal(cls, rc)
+    np.testing.assert_allclose(scores, rs, atol=1e-3)
+    assert rels.shape == rr.shape
+    key = lambda r: r[:, 0] * 100000 + r[:, 1]                                  # noqa: E731
+    go, ro = np.argsort(key(rels)), np.argsort(key(rr))
+    np.testing.assert_array_equal(rels[go], rr[ro])
+    np.testing.assert_allclose(pred_scores[go], rp[ro], atol=1e-3)
