@@ -277,3 +277,41 @@ def test_sgdet_with_resnet50_backbone_matches_oracle(sgdet_r50):
     go, ro = np.argsort(key(rels)), np.argsort(key(rr))
     np.testing.assert_array_equal(rels[go], rr[ro])
     np.testing.assert_allclose(pred_scores[go], rp[ro], atol=1e-3)
+
+
+def test_sgdet_resnet50_full_size_runs_in_f16():
+    """The GQA SGGen configuration at its real size (1333-pixel frames: maps of 336 .. 21 cells, 338 k anchors, <= 4 823 candidates per
+    image into the level-wise NMS, 1 000 proposals through the four-level RoIAlign and the 12544 -> 1024 box head) in the default f16
+    mode: structure of the output."""
+    import sgg_amd
+    from sgg_amd.resnet_fpn import FrozenBatchNorm2d
+    from sgg_amd.synthetic import SyntheticData, init_weights
+    torch.manual_seed(8)
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgdet', backbone='resnet50'))
+    for m in model.modules():
+        if isinstance(m, FrozenBatchNorm2d):
+            m.weight.uniform_(0.5, 1.0)
+            m.running_var.uniform_(0.6, 1.4)
+    with torch.no_grad():
+        model.detector.rpn.head.bbox_pred.weight.mul_(0.01)
+        model.detector.roi_heads.box_predictor.bbox_pred.weight.mul_(0.05)
+    model.to(DEV).eval()
+    assert model.compute_dtype == torch.float16
+    model.set_box_score_thresh(0.0)
+    g = torch.Generator().manual_seed(1)
+    imgs = [torch.rand(3, 1000, 1000, generator=g), torch.rand(3, 900, 1100, generator=g)]
+    gt_classes = torch.tensor([[0, 1], [1, 1]])
+    batch = (imgs, None, 0, torch.zeros(2, 4), gt_classes, None, None, None)
+    with torch.no_grad():
+        res = model.faster_rcnn(imgs, None, gt_classes.to(DEV), None)
+        assert tuple(res.fmap.shape[1:]) == (256, 21, 21)
+        n = [int((res.im_inds == b).sum()) for b in range(2)]
+        assert all(2 <= k <= 50 for k in n)
+        bx = res.rm_box_priors
+        assert (bx[:, 2] > bx[:, 0]).all() and (bx[:, 3] > bx[:, 1]).all() and bx.min() >= 0 and bx[:, 2].max() <= 1333 + 1e-3
+        assert (res.rm_obj_labels >= 1).all() and (res.rm_obj_labels < 151).all()
+        boxes, cls, scores, rels, pred_scores = model([batch])
+    assert boxes.shape[0] == sum(n) == cls.shape[0] and np.isfinite(pred_scores).all() and np.isfinite(scores).all()
+    assert rels.shape[1] == 2 and (rels[:, 0] != rels[:, 1]).all() and pred_scores.shape == (rels.shape[0], 51)
+    trip = pred_scores[:, 1:].max(1) * scores[rels[:, 0]] * scores[rels[:, 1]]
+    assert (trip[:-1] >= trip[1:] - 1e-6).all()
