@@ -40,8 +40,11 @@ struct ConvArgs {
     int pool;            // 1: out is the 2x2-max-pooled plane [B, H/2+2p, W/2+2p, Cout] (H, W even)
 };
 
+#ifndef SGG_CONV_WPE
+#define SGG_CONV_WPE 1      // kernel experiments only: minimum waves per SIMD the register allocation must allow
+#endif
 template <int DT, int WN, int NI, bool ONEBAR>
-__global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArgs g) {
+__global__ __launch_bounds__(256 * WN, SGG_CONV_WPE) void conv3x3_spatial_kernel(const ConvArgs g) {
     constexpr int NW = 4 * WN, CNW = 32 * NI, CN = CNW * WN;   // channels per wave / per block
     constexpr int ESZ = DT == SGG_F32 ? 4 : 2;
     constexpr int PATCH_B = PROWS_PAD * RB, WSLAB_B = CN * RB;
@@ -120,15 +123,20 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
 #ifndef SGG_CONV_ABL
-#define SGG_CONV_ABL 0   // kernel experiments only: 1 no main loop (tile prologue + epilogue cost), 2 no output stores
+#define SGG_CONV_ABL 0   // kernel experiments only: 1 no main loop (tile prologue + epilogue cost), 2 no output stores,
+                         // 3 no barriers / waits (wrong results), 4 no LDS fragment reads, 5 no MFMA, 6 no global->LDS staging
 #endif
     const int nchunk = SGG_CONV_ABL == 1 ? 0 : (g.Cin * ESZ) / RB;
     for (int ch = 0; ch < nchunk; ++ch) {
         if (ONEBAR && ch) lds_reads_done_barrier();      // every wave is done with the previous patch and slab 0's buffer
-        stage_patch(ch);
-        stage_w(0, ch, 0);
+        if (SGG_CONV_ABL != 6) {
+            stage_patch(ch);
+            stage_w(0, ch, 0);
+        }
         for (int tap = 0; tap < 9; ++tap) {
-            if constexpr (ONEBAR) {
+            if constexpr (SGG_CONV_ABL == 3) {
+                if (tap + 1 < 9) stage_w(tap + 1, ch, (tap + 1) & 1);
+            } else if constexpr (ONEBAR) {
                 // One barrier per tap: after it, slab `tap` (and the patch) have landed for every wave, and every wave
                 // has finished tap-1 -- the buffer tap-1 used is free and the slab for tap+1 can be streamed into it.
                 wait_vmcnt<0>();
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
                 if (tap + 1 < 9) stage_w(tap + 1, ch, (tap + 1) & 1);
             } else {
                 if (tap + 1 < 9) {
-                    stage_w(tap + 1, ch, (tap + 1) & 1);
+                    if (SGG_CONV_ABL != 6) stage_w(tap + 1, ch, (tap + 1) & 1);
                     wait_vmcnt<WI_W>();                  // everything but the slab just issued has landed
                 } else {
                     wait_vmcnt<0>();
@@ -157,10 +165,24 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
             for (int s = 0; s < 4; ++s) {
                 const int slot = 2 * s + fh;
                 u32x4 av[NI], bv[2];
+                if constexpr (SGG_CONV_ABL == 4) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) av[i] = u32x4{(unsigned)slot, (unsigned)tap, 1u, 2u};
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) bv[i] = u32x4{(unsigned)ch, 3u, (unsigned)slot, 4u};
+                } else {
 #pragma unroll
                 for (int i = 0; i < NI; ++i) av[i] = *reinterpret_cast<const u32x4*>(wb + woff[i] + ((slot ^ wkey[i]) << 4));
 #pragma unroll
                 for (int i = 0; i < 2; ++i) bv[i] = *reinterpret_cast<const u32x4*>(patch + poff[i] + ((slot ^ pkey[i]) << 4));
+                }
+                if constexpr (SGG_CONV_ABL == 5) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(av[i]));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(bv[i]));
+                    continue;
+                }
 #pragma unroll
                 for (int pj = 0; pj < 2; ++pj)
 #pragma unroll
@@ -175,7 +197,7 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
                         }
                     }
             }
-            if constexpr (!ONEBAR) lds_reads_done_barrier();       // slab buffer (tap&1) and, after tap 8, the patch are free
+            if constexpr (!ONEBAR && SGG_CONV_ABL != 3) lds_reads_done_barrier();       // slab buffer (tap&1) and, after tap 8, the patch are free
         }
     }
 
@@ -260,8 +282,9 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_spatial_kernel(const ConvArg
 template <int DT, int WN, int NI, bool ONEBAR = false>
 int launch_spatial(const ConvArgs& g, hipStream_t s) {
     constexpr int CN = 32 * NI * WN;
-    constexpr int smem = PROWS_PAD * RB + 2 * CN * RB;
-    static_assert(smem >= 4 * WN * 32 * (32 * NI * 4 + 16), "epilogue staging fits");
+    constexpr int smem_main = PROWS_PAD * RB + 2 * CN * RB, smem_epi = 4 * WN * 32 * (32 * NI * 4 + 16);   // operand tiles | epilogue staging
+    constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
+    static_assert(smem <= 160 * 1024, "fits the CU's LDS");
     auto k = conv3x3_spatial_kernel<DT, WN, NI, ONEBAR>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -290,6 +313,9 @@ int sgg_launch_conv_spatial(const void* in, const void* w, const float* bias, vo
     //  8 waves x [64 x 64]: the kernel is latency-, not LDS-bandwidth-bound, and the extra waves hide more of it.)
     static const bool onebar = [] { const char* e = getenv("SGG_CONV_ONEBAR"); return e && e[0] == '1'; }();
     if (Cout % 128 == 0 && dt == SGG_BF16 && onebar) return launch_spatial<SGG_BF16, 2, 2, true>(g, s);
+    static const int wide = [] { const char* e = getenv("SGG_CONV_WIDE"); return e ? atoi(e) : 0; }();     // experiments: 64 px x 128 ch per wave
+    if (wide && Cout % 256 == 0 && dt != SGG_F32)
+        return dt == SGG_BF16 ? launch_spatial<SGG_BF16, 2, 4>(g, s) : launch_spatial<SGG_F16, 2, 4>(g, s);
     if (Cout % 128 == 0)
         return dt == SGG_BF16 ? launch_spatial<SGG_BF16, 2, 2>(g, s) : dt == SGG_F16 ? launch_spatial<SGG_F16, 2, 2>(g, s) : launch_spatial<SGG_F32, 2, 2>(g, s);
     if (Cout % 64 == 0)

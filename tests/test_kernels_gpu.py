@@ -153,6 +153,42 @@ def test_conv3x3(ops, dtype, B, H, W, Cin, Cout):
             assert float(got[:, 0].min()) == 7.0 and float(got[:, :, 0].min()) == 7.0
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('nq,tw', [(4, 16), (4, 32), (2, 16), (2, 32)])
+@pytest.mark.parametrize('B,H,W,Cin,Cout,pool', [(2, 70, 90, 192, 256, False), (1, 64, 64, 64, 256, True), (3, 66, 100, 64, 512, True),
+                                                 (1, 97, 65, 320, 256, False)])
+def test_conv3x3_pingpong_patch_kernel(ops, dtype, nq, tw, B, H, W, Cin, Cout, pool, monkeypatch):
+    """csrc/conv_pp.hip under both workgroup widths (128 / 256 channels) and both tile shapes (16x16 / 8x32): 2-10 channel slabs of 32 (the patch
+    double buffer and the weight ring wrap several times), tiles that overhang the right and the bottom edge, with and without the fused
+    pool, both output paddings; against torch's fp32 convolution of the same 16-bit operands."""
+    monkeypatch.setenv('SGG_CONV_PP', str(nq))
+    monkeypatch.setenv('SGG_CONV_PP_TW', str(tw))
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g).to(dtype)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(dtype)
+    b = torch.randn(Cout, generator=g)
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), b, padding=1).relu()
+    if pool:
+        ref = torch.nn.functional.max_pool2d(ref, 2)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    xp = torch.zeros(B, H + 2, W + 2, Cin, dtype=dtype)
+    xp[:, 1:-1, 1:-1] = x.permute(0, 2, 3, 1)
+    for op in (0, 1):
+        out = torch.full((B, Ho + 2 * op, Wo + 2 * op, Cout), 7.0, dtype=dtype, device=DEV)
+        ops.conv3x3_relu(cu(xp), cu(w.permute(0, 2, 3, 1)), cu(b), out, op, pool=pool)
+        got = out.float().cpu()
+        inner = got[:, op:Ho + op, op:Wo + op] if op else got
+        torch.testing.assert_close(inner.permute(0, 3, 1, 2), ref, atol=3e-2, rtol=3e-2)
+        if op:  # border untouched
+            assert float(got[:, 0].min()) == 7.0 and float(got[:, :, 0].min()) == 7.0 and float(got[:, -1].min()) == 7.0 and float(got[:, :, -1].min()) == 7.0
+    # the same launch twice: identical bits (no race between the two wave groups, the DMA ring and the patch buffers)
+    o1 = torch.zeros((B, Ho + 2, Wo + 2, Cout), dtype=dtype, device=DEV)
+    o2 = torch.zeros_like(o1)
+    ops.conv3x3_relu(cu(xp), cu(w.permute(0, 2, 3, 1)), cu(b), o1, 1, pool=pool)
+    ops.conv3x3_relu(cu(xp), cu(w.permute(0, 2, 3, 1)), cu(b), o2, 1, pool=pool)
+    assert torch.equal(o1, o2)
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 def test_conv3x3_relu_with_fused_maxpool(ops, dtype):
     """conv + ReLU + MaxPool2d(2) in one kernel == the two separate kernels, bit for bit (max commutes with bias + ReLU
