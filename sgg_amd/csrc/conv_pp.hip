@@ -39,10 +39,10 @@ constexpr int NSTG = 4;
 // The 256-pixel output tile is TH rows x TW columns (16 x 16 or 8 x 32): the launcher picks the shape that wastes fewer MFMAs on pixels
 // outside the map and fills the last round of workgroups better (152 x 152 maps, batch 8: 800 tiles of 16 x 16 = 3.1 rounds of 256 CUs
 // with 15 % of the pixels outside; 760 tiles of 8 x 32 = 2.97 rounds with 5 % outside).
-template <int TW>
+template <int TW, int NPG>
 struct TileGeom {
-    static constexpr int TH = 256 / TW, PW = TW + 2, ROWS = (TH + 2) * PW;      // patch: (TH + 2) x (TW + 2) rows of 64 B
-    static constexpr int PIECES = (ROWS + 15) / 16;                             // DMA instructions of 16 rows (21 / 22)
+    static constexpr int TH = 128 * NPG / TW, PW = TW + 2, ROWS = (TH + 2) * PW;   // patch: (TH + 2) x (TW + 2) rows of 64 B
+    static constexpr int PIECES = (ROWS + 15) / 16;                             // DMA instructions of 16 rows (21 / 22; 39 for 512 pixels)
     static constexpr int BYTES = PIECES * 1024;                                 // per patch buffer
     static constexpr int CB = TW / 16;                                          // 32-pixel blocks (2 rows x 16 columns) side by side
 };
@@ -66,6 +66,7 @@ __device__ __forceinline__ void wait_vm() {
 }
 __device__ __forceinline__ void wait_vm_n(int n) {          // folds to one instruction when n is a constant after unrolling
     switch (n) {
+        case 1: wait_vm<1>(); break;
         case 2: wait_vm<2>(); break;
         case 3: wait_vm<3>(); break;
         case 4: wait_vm<4>(); break;
@@ -75,13 +76,17 @@ __device__ __forceinline__ void wait_vm_n(int n) {          // folds to one inst
     }
 }
 
-template <int DT, int NQ, int TW>
-__global__ __launch_bounds__(128 * NQ, 2) void conv3x3_pp_kernel(const ConvPPArgs g) {     // two waves per SIMD (NQ = 2: from two workgroups)
+// NQ channel slabs of 64 x NPG pixel groups of 128 = NW waves: (4, 2) 256 px x 256 ch; (2, 2) 256 px x 128 ch, four waves, two workgroups
+// per CU; (2, 4) 512 px x 128 ch (the 128-channel layers with eight waves: half the weight traffic per MFMA of the four-wave form).
+template <int DT, int NQ, int NPG, int TW>
+__global__ __launch_bounds__(64 * NQ * NPG, 2) void conv3x3_pp_kernel(const ConvPPArgs g) {     // two waves per SIMD (four-wave form: from two workgroups)
     static_assert(DT == SGG_BF16 || DT == SGG_F16, "16-bit element types");
-    using TG = TileGeom<TW>;
+    using TG = TileGeom<TW, NPG>;
     constexpr int PT_PW = TG::PW, PT_ROWS = TG::ROWS, PATCH_PIECES = TG::PIECES, PATCH_B = TG::BYTES;
-    constexpr int NW = 2 * NQ, CN = 64 * NQ;
+    constexpr int NW = NQ * NPG, CN = 64 * NQ;
     constexpr int WST = CN * PROW;                            // bytes per weight stage
+    constexpr int WI = CN / 16 / NW;                          // weight-slab DMA instructions per wave and K-tile (2 or 1)
+    static_assert(WI * 16 * NW == CN, "weight rows divide over the waves");
     constexpr int PTAPS = (PATCH_PIECES + NW - 1) / NW;       // taps 3 .. 3 + PTAPS - 1 of a slab carry the next slab's patch (one piece per wave)
     static_assert(3 + PTAPS <= 9, "patch pieces fit the taps of one slab");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -90,7 +95,8 @@ __global__ __launch_bounds__(128 * NQ, 2) void conv3x3_pp_kernel(const ConvPPArg
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave / NQ, q = wave % NQ;
+    const int pg = wave / NQ, q = wave % NQ;                 // pixel group (128 pixels), channel slab
+    const int grp = wave / (NW / 2);                         // phase group: waves w and w + 4 share a SIMD and must be in opposite phases
 
     // block -> (image, tile, channel block); channel blocks of one tile are adjacent (they share the input patch in L2)
     const int ncb = g.Cout / CN;
@@ -105,10 +111,10 @@ __global__ __launch_bounds__(128 * NQ, 2) void conv3x3_pp_kernel(const ConvPPArg
     const int nch = g.Cin / 32;
 
     // ---- DMA duty.  Weights: wave w stages rows [32 w, 32 w + 32) of the slab, two instructions of 16 rows.  Patch: pieces wave, wave + NW, ..
-    unsigned wsrc[2];
+    unsigned wsrc[WI];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = wave * 32 + j * 16 + (lane >> 2);
+    for (int j = 0; j < WI; ++j) {
+        const int r = wave * (16 * WI) + j * 16 + (lane >> 2);
         const int chunk = (lane & 3) ^ ((r >> 2) & 3);
         wsrc[j] = (unsigned)((long)(n0 + r) * 9 * g.Cin * 2 + chunk * 16);
     }
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(128 * NQ, 2) void conv3x3_pp_kernel(const ConvPPArg
         return uniform_ptr(g.w + ((long)t * g.Cin + c * 32) * 2);
     };
     auto issue_w = [&](const char* ub, int kt, int j) {
-        glds16_su(ub, wsrc[j], wring + (kt & (NSTG - 1)) * WST + (wave * 32 + j * 16) * PROW);
+        glds16_su(ub, wsrc[j], wring + (kt & (NSTG - 1)) * WST + (wave * (16 * WI) + j * 16) * PROW);
     };
     auto issue_p = [&](int slab, int j) {                                  // piece j of this wave, patch of `slab` (clamped) into buffer slab & 1
         const char* ub = uniform_ptr(g.in + (long)min(slab, nch - 1) * PROW);
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(128 * NQ, 2) void conv3x3_pp_kernel(const ConvPPArg
     int prow0[4];          // patch row (tap 0,0) of this lane's pixel in the four 32-pixel blocks of the wave
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int blk = grp * 4 + i;                            // block -> (row pair, 16-column half)
+        const int blk = pg * 4 + i;                             // block -> (row pair, 16-column part)
         prow0[i] = ((blk / TG::CB) * 2 + pp_py(fr)) * PT_PW + (blk % TG::CB) * 16 + pp_px(fr);
     }
     int boff[2], bkey[2];
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(128 * NQ, 2) void conv3x3_pp_kernel(const ConvPPArg
         issue_w(ub, kt + 3, 0);
         __builtin_amdgcn_sched_barrier(0);
         PP_MFMA_PAIR(0, 1)
-        issue_w(ub, kt + 3, 1);
+        if constexpr (WI > 1) issue_w(ub, kt + 3, 1);
         __builtin_amdgcn_sched_barrier(0);
         PP_MFMA_PAIR(0, 2)
         if (with_patch) {
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(128 * NQ, 2) void conv3x3_pp_kernel(const ConvPPArg
         __builtin_amdgcn_s_setprio(0);
     };
     // DMA instructions a wave issues with K-tile position `tap`
-    auto n_at = [](int tap) { tap %= 9; return 2 + ((tap >= 3 && tap < 3 + PTAPS) ? 1 : 0); };
+    auto n_at = [](int tap) { tap %= 9; return WI + ((tap >= 3 && tap < 3 + PTAPS) ? 1 : 0); };
 
     // ---- prologue: the patch of slab 0, K-tiles 0..2 in flight; patch and tile 0 landed and visible
 #pragma unroll
@@ -221,9 +227,9 @@ __global__ __launch_bounds__(128 * NQ, 2) void conv3x3_pp_kernel(const ConvPPArg
     for (int t = 0; t < 3; ++t) {
         const char* ub = w_base(0, t);
         issue_w(ub, t, 0);
-        issue_w(ub, t, 1);
+        if constexpr (WI > 1) issue_w(ub, t, 1);
     }
-    wait_vm<4>();
+    wait_vm<2 * WI>();
     __builtin_amdgcn_s_barrier();
 
     if (grp == 0) {
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(128 * NQ, 2) void conv3x3_pp_kernel(const ConvPPArg
                 *reinterpret_cast<f32x4*>(est + fr * ESTRIDE + (ni * 32 + 8 * c4 + 4 * fh) * 4) = v;
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own LDS writes landed (same wave reads them back)
-        const int blk = grp * 4 + mi;
+        const int blk = pg * 4 + mi;
         const int yb = y0 + (blk / TG::CB) * 2, xb = x0 + (blk % TG::CB) * 16;     // first image row / column of this 2 x 16 block
         if (g.pool) {
             // fused MaxPool2d(2): the block is 8 complete 2x2 windows; max first, then bias + ReLU (they commute with max)
@@ -325,15 +331,16 @@ __global__ __launch_bounds__(128 * NQ, 2) void conv3x3_pp_kernel(const ConvPPArg
     }
 }
 
-template <int DT, int NQ, int TW>
+template <int DT, int NQ, int NPG, int TW>
 int launch_pp(ConvPPArgs g, hipStream_t s) {
-    constexpr int NW = 2 * NQ, CN = 64 * NQ;
-    constexpr int smem_main = 2 * TileGeom<TW>::BYTES + NSTG * CN * PROW, smem_epi = NW * 32 * 272;
+    constexpr int NW = NQ * NPG, CN = 64 * NQ;
+    using TG = TileGeom<TW, NPG>;
+    constexpr int smem_main = 2 * TG::BYTES + NSTG * CN * PROW, smem_epi = NW * 32 * 272;
     g.tiles_x = (g.W + TW - 1) / TW;
-    g.tiles_y = (g.H + TileGeom<TW>::TH - 1) / TileGeom<TW>::TH;
+    g.tiles_y = (g.H + TG::TH - 1) / TG::TH;
     constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
     static_assert(smem <= 160 * 1024, "fits the CU's LDS");
-    auto k = conv3x3_pp_kernel<DT, NQ, TW>;
+    auto k = conv3x3_pp_kernel<DT, NQ, NPG, TW>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -347,16 +354,17 @@ int launch_pp(ConvPPArgs g, hipStream_t s) {
 }
 
 template <int DT>
-int launch_pp_dt(const ConvPPArgs& g, int nq, int tw, hipStream_t s) {
-    if (nq == 4) return tw == 32 ? launch_pp<DT, 4, 32>(g, s) : launch_pp<DT, 4, 16>(g, s);
-    return tw == 32 ? launch_pp<DT, 2, 32>(g, s) : launch_pp<DT, 2, 16>(g, s);
+int launch_pp_dt(const ConvPPArgs& g, int nq, int npg, int tw, hipStream_t s) {
+    if (nq == 4) return tw == 32 ? launch_pp<DT, 4, 2, 32>(g, s) : launch_pp<DT, 4, 2, 16>(g, s);
+    if (npg == 4) return tw == 32 ? launch_pp<DT, 2, 4, 32>(g, s) : launch_pp<DT, 2, 4, 16>(g, s);
+    return tw == 32 ? launch_pp<DT, 2, 2, 32>(g, s) : launch_pp<DT, 2, 2, 16>(g, s);
 }
 
 // share of the launch's MFMA work that lands on map pixels, times how full its rounds of workgroups are
-double pp_efficiency(int B, int H, int W, int Cout, int nq, int tw) {
-    const int th = 256 / tw, ty = (H + th - 1) / th, tx = (W + tw - 1) / tw;
+double pp_efficiency(int B, int H, int W, int Cout, int nq, int npg, int tw) {
+    const int th = 128 * npg / tw, ty = (H + th - 1) / th, tx = (W + tw - 1) / tw;
     const long wgs = (long)B * ty * tx * (Cout / (64 * nq));
-    const long slots = 256L * (nq == 4 ? 1 : 2);                  // workgroups the chip holds at once
+    const long slots = 256L * (nq * npg == 4 ? 2 : 1);           // workgroups the chip holds at once (four-wave form: two per CU)
     const long rounds = (wgs + slots - 1) / slots;
     return ((double)H * W / ((double)ty * th * tx * tw)) * ((double)wgs / (double)(rounds * slots));
 }
@@ -364,15 +372,25 @@ double pp_efficiency(int B, int H, int W, int Cout, int nq, int tw) {
 }  // namespace
 
 // returns SGG_OK, or 1 if the shape is not handled here (the caller falls through to the other convolution kernels).
-// nq: 4 = 256-channel workgroups (eight waves), 2 = 128-channel workgroups (four waves), 0 = choose.  tw: 16 / 32 = tile width, 0 = choose.
+// form: 0 = choose; 42 = 256 px x 256 ch; 22 = 256 px x 128 ch (four waves); 24 = 512 px x 128 ch.  tw: 16 / 32 = tile width, 0 = choose.
 int sgg_launch_conv_pp(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H, int W, int Cin, int Cout,
-                       int dt, int pool, int nq, int tw, hipStream_t s) {
+                       int dt, int pool, int form, int tw, hipStream_t s) {
     if ((dt != SGG_BF16 && dt != SGG_F16) || Cin % 32 || Cout % 128) return 1;
     ConvPPArgs g{};
     g.in = (const char*)in; g.w = (const char*)w; g.bias = bias; g.out = (char*)out;
     g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.out_pad = out_pad; g.pool = pool;
-    if (nq == 0) nq = Cout % 256 == 0 ? 4 : 2;
-    if (nq == 4 && Cout % 256) return 1;
-    if (tw == 0) tw = pp_efficiency(B, H, W, Cout, nq, 32) > pp_efficiency(B, H, W, Cout, nq, 16) + 0.02 ? 32 : 16;
-    return dt == SGG_BF16 ? launch_pp_dt<SGG_BF16>(g, nq, tw, s) : launch_pp_dt<SGG_F16>(g, nq, tw, s);
+    if (form == 42 && Cout % 256) return 1;
+    double best = -1.0;
+    int bq = 0, bg = 0, bt = 0;
+    // candidates in order of preference (eight-wave forms first); a later one must be clearly better to win
+    const int cand[6][3] = {{4, 2, 16}, {4, 2, 32}, {2, 4, 16}, {2, 4, 32}, {2, 2, 16}, {2, 2, 32}};
+    for (const auto& c : cand) {
+        if (c[0] == 4 && Cout % 256) continue;
+        if (form && form != c[0] * 10 + c[1]) continue;
+        if (tw && tw != c[2]) continue;
+        const double e = pp_efficiency(B, H, W, Cout, c[0], c[1], c[2]);
+        if (e > best + 0.02) best = e, bq = c[0], bg = c[1], bt = c[2];
+    }
+    if (!bq) return 1;
+    return dt == SGG_BF16 ? launch_pp_dt<SGG_BF16>(g, bq, bg, bt, s) : launch_pp_dt<SGG_F16>(g, bq, bg, bt, s);
 }

@@ -19,7 +19,7 @@
 
 int sgg_launch_pingpong(const GemmArgs& g, int dt, bool conv, hipStream_t s);  // gemm256.hip
 int sgg_launch_conv_pp(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H, int W, int Cin, int Cout,
-                       int dt, int pool, int nq, int tw, hipStream_t s);  // conv_pp.hip
+                       int dt, int pool, int form, int tw, hipStream_t s);  // conv_pp.hip
 int sgg_launch_conv_spatial(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H, int W,
                             int Cin, int Cout, int dt, int pool, hipStream_t s);            // conv_spatial.hip
 
@@ -602,11 +602,11 @@ extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias
         const bool want = force ? (force[0] == 's' || (force[0] == 'o' && H >= 64 && W >= 64)) : (H >= 64 && W >= 64 && Cout < 256);   // 'o': round 1's rule
         if (pool && ((H | W) & 1)) return SGG_ERR_ARG;
         {
-            const char* pp = getenv("SGG_CONV_PP");                 // experiments: 0 = off, 2 / 4 = force the workgroup width
+            const char* pp = getenv("SGG_CONV_PP");                 // experiments: 0 = off, 42 / 22 / 24 = force the workgroup form (conv_pp.hip)
             const char* ptw = getenv("SGG_CONV_PP_TW");             //              16 / 32 = force the tile width
             const int nq = pp ? atoi(pp) : 0, tw = ptw ? atoi(ptw) : 0;
             if (!(pp && pp[0] == '0') && !force && H >= 64 && W >= 64 && Cout >= 128) {
-                const int rc = sgg_launch_conv_pp(in, w, bias, out, out_pad, B, H, W, Cin, Cout, dtype, pool, nq == 2 || nq == 4 ? nq : 0, tw == 16 || tw == 32 ? tw : 0, (hipStream_t)stream);
+                const int rc = sgg_launch_conv_pp(in, w, bias, out, out_pad, B, H, W, Cin, Cout, dtype, pool, nq == 42 || nq == 22 || nq == 24 ? nq : 0, tw == 16 || tw == 32 ? tw : 0, (hipStream_t)stream);
                 if (rc <= 0) return rc;
             }
         }

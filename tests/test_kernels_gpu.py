@@ -154,11 +154,11 @@ def test_conv3x3(ops, dtype, B, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('nq,tw', [(4, 16), (4, 32), (2, 16), (2, 32)])
+@pytest.mark.parametrize('nq,tw', [(42, 16), (42, 32), (22, 16), (22, 32), (24, 16), (24, 32)])
 @pytest.mark.parametrize('B,H,W,Cin,Cout,pool', [(2, 70, 90, 192, 256, False), (1, 64, 64, 64, 256, True), (3, 66, 100, 64, 512, True),
                                                  (1, 97, 65, 320, 256, False)])
 def test_conv3x3_pingpong_patch_kernel(ops, dtype, nq, tw, B, H, W, Cin, Cout, pool, monkeypatch):
-    """csrc/conv_pp.hip under both workgroup widths (128 / 256 channels) and both tile shapes (16x16 / 8x32): 2-10 channel slabs of 32 (the patch
+    """csrc/conv_pp.hip under its three workgroup forms (256 px x 256 ch, 256 x 128, 512 x 128) and both tile widths (16 / 32): 2-10 channel slabs of 32 (the patch
     double buffer and the weight ring wrap several times), tiles that overhang the right and the bottom edge, with and without the fused
     pool, both output paddings; against torch's fp32 convolution of the same 16-bit operands."""
     monkeypatch.setenv('SGG_CONV_PP', str(nq))
