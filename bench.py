@@ -549,8 +549,8 @@ def main():
                          'note': ('achieved = FLOPs the launch executes / its time; the reference runs this contraction on every EDGE '
                                   '(SURVEY 8(d)), here it runs once per unordered box pair: reference_algorithm_tflops prices the '
                                   'reference\'s FLOPs over the same time') if paired else None},
-            'roofline_vgg': {'kernel': 'VGG-16 features of the frozen detector: conv1_1 (K = 27 on MFMA) + 12 x 3x3 conv on MFMA (LDS-resident patch kernel / '
-                                       'implicit-GEMM ping-pong kernel, pools fused in the epilogues): the largest time slice of the step',
+            'roofline_vgg': {'kernel': 'VGG-16 features of the frozen detector: conv1_1 (K = 27 on MFMA) + 12 x 3x3 conv on MFMA (conv_pp.hip: LDS-resident patch under a '
+                                       'ping-pong schedule; conv1_2 on the lock-step patch kernel, conv5 as implicit GEMM; pools fused in the epilogues): the largest time slice of the step',
                              'bound': 'mfma', 'achieved': round(vgg_flop / (conv_ms * 1e-3) / 1e12, 1) if conv_ms else 0.0, 'peak': peak, 'unit': 'TFLOP/s',
                              'frac': round(vgg_flop / (conv_ms * 1e-3) / 1e12 / peak, 4) if conv_ms else 0.0, 'traffic': None,
                              'ms_per_step': round(conv_ms, 4), 'executed_flop': vgg_flop},
