@@ -58,6 +58,13 @@ int sgg_image_prep_batch(const void* const* imgs, const int* h0, const int* w0, 
  * Activations live in zero-bordered NHWC buffers [B, H+2*pad, W+2*pad, C]. */
 int sgg_conv1_1(const float* in_nhwc4, const float* w /*[64][27] (ky,kx,c)*/, const float* bias, void* out, int B,
                 int H, int W, int out_dtype, void* stream);
+/* conv1_1 + ReLU + conv1_2 + ReLU [+ MaxPool2d(2)] in ONE launch (16-bit modes; vgg16.features[0:4] / [0:5], rel_model_base.py:310-312): conv1_1's
+ * 64-channel full-resolution output is computed per tile inside LDS and never written.  in_nhwc4 as for sgg_conv1_1; w2 [64][3][3][64];
+ * w1_frags: conv1_1's weights [64][27] (k = (ky*3+kx)*3 + c) as MFMA fragments, 4096 bytes written by sgg_conv1_pack_weights (once per
+ * weight change; 16-byte aligned, like b1). */
+int sgg_conv1_pack_weights(const float* w1 /*[64][27]*/, void* frags /*4096 bytes*/, int dtype, void* stream);
+int sgg_conv1_block(const float* in_nhwc4, const void* w1_frags, const float* b1, const void* w2, const float* b2, void* out, int out_pad,
+                    int B, int H, int W, int pool, int dtype, void* stream);
 /* pool = 1: the following MaxPool2d(2) is fused into the epilogue -- out is the pooled plane [B, H/2+2p, W/2+2p, Cout]
  * (H, W even; LDS-patch kernel only: returns SGG_ERR_ARG for shapes that kernel does not take). */
 int sgg_conv3x3_relu(const void* in /*pad 1*/, const void* w /*[Cout][3][3][Cin]*/, const float* bias, void* out,

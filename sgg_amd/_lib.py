@@ -24,6 +24,8 @@ SIGNATURES = {
     'sgg_image_prep_u8': [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     'sgg_image_prep_batch': [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P],
     'sgg_conv1_1': [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'sgg_conv1_block': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    'sgg_conv1_pack_weights': [_P, _P, _I, _P],
     'sgg_conv3x3_relu': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'sgg_maxpool2x2': [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     'sgg_pair_index_eval': [_P, _P, _I, _I, _P, _I, _P, _P, _P],

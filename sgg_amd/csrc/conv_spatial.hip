@@ -13,6 +13,7 @@
 // Activations are zero-bordered NHWC planes, so the patch never needs border tests; tiles that overhang the right /
 // bottom edge clamp their loads inside the plane and mask their stores.
 #include <cstdlib>
+#include <type_traits>
 #include "gemm_args.h"
 
 namespace {
@@ -38,12 +39,21 @@ struct ConvArgs {
     char* out;           // [B, H+2p, W+2p, Cout]
     int B, H, W, Cin, Cout, out_pad, tiles_x, tiles_y;
     int pool;            // 1: out is the 2x2-max-pooled plane [B, H/2+2p, W/2+2p, Cout] (H, W even)
+    // FUSE1 kernels (conv1_1 computed inside conv1_2): the normalised image plane [B, H+2, W+2, 4] f32, conv1_1's weights as MFMA
+    // fragments [2 nt][2 k-steps][64 lanes] x 16 B (conv1_pack_kernel) and its bias; `in` is unused
+    const float* img;
+    const char* w1f;
+    const float* b1;
 };
 
 #ifndef SGG_CONV_WPE
 #define SGG_CONV_WPE 1      // kernel experiments only: minimum waves per SIMD the register allocation must allow
 #endif
-template <int DT, int WN, int NI, bool ONEBAR>
+// FUSE1 (conv1_2 of VGG-16, Cin = 64 = one 128-byte slab): the 18x18x64 input patch is not loaded but COMPUTED -- conv1_1 (3 -> 64, K = 27
+// padded to 32 = two MFMA k-steps per 32 pixels and 32 channels) + bias + ReLU of the 20x20 image patch, written straight into the
+// swizzled LDS patch; patch pixels outside the image are conv1_2's zero padding.  conv1_1's full-resolution output (the largest
+// activation of the network: 0.36 GB per 8 frames, written once and read 1.27x) never exists; +6 % MFMA work for the halo.
+template <int DT, int WN, int NI, bool ONEBAR, bool FUSE1 = false>
 __global__ __launch_bounds__(256 * WN, SGG_CONV_WPE) void conv3x3_spatial_kernel(const ConvArgs g) {
     constexpr int NW = 4 * WN, CNW = 32 * NI, CN = CNW * WN;   // channels per wave / per block
     constexpr int ESZ = DT == SGG_F32 ? 4 : 2;
@@ -127,9 +137,76 @@ __global__ __launch_bounds__(256 * WN, SGG_CONV_WPE) void conv3x3_spatial_kernel
                          // 3 no barriers / waits (wrong results), 4 no LDS fragment reads, 5 no MFMA, 6 no global->LDS staging
 #endif
     const int nchunk = SGG_CONV_ABL == 1 ? 0 : (g.Cin * ESZ) / RB;
+    if constexpr (FUSE1 && DT != SGG_F32) {
+        using TT = typename std::conditional<DT == SGG_BF16, bf16_t, f16_t>::type;
+        char* ipatch = wbuf + 2 * WSLAB_B;                   // 20 x 20 pixels x (4 f32)
+        stage_w(0, 0, 0);                                    // conv1_2's first weight slab streams under the producer
+        for (int i = tid; i < 400; i += 256 * WN) {
+            const int iy = i / 20, ix = i - iy * 20;
+            const int gy = min(max(y0 - 1 + iy, 0), g.H + 1), gx = min(max(x0 - 1 + ix, 0), g.W + 1);
+            *reinterpret_cast<f32x4*>(ipatch + i * 16) = *reinterpret_cast<const f32x4*>(g.img + (((long)b * (g.H + 2) + gy) * (g.W + 2) + gx) * 4);
+        }
+        // conv1_1 weight fragments (packed once per weight update: four coalesced 16-byte loads per lane) and the lane's bias groups
+        u32x4 wf[2][2];
+        f32x4 bq[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) wf[nt][s2] = *reinterpret_cast<const u32x4*>(g.w1f + ((nt * 2 + s2) * 64 + lane) * 16);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) bq[nt][q4] = *reinterpret_cast<const f32x4*>(g.b1 + nt * 32 + 8 * q4 + 4 * fh);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // the image patch is visible
+        constexpr int NBLK = (PROWS + 31) / 32;              // 11 blocks of 32 patch pixels
+        for (int blk = wave; blk < NBLK; blk += NW) {
+            const int p = blk * 32 + fr, pc = min(p, PROWS - 1);
+            const int py = pc / PW, px = pc - py * PW;
+            float V[32];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(ipatch + ((py + ky) * 20 + px + kx) * 16);
+                    V[(ky * 3 + kx) * 3 + 0] = t4.x;
+                    V[(ky * 3 + kx) * 3 + 1] = t4.y;
+                    V[(ky * 3 + kx) * 3 + 2] = t4.z;
+                }
+#pragma unroll
+            for (int k = 27; k < 32; ++k) V[k] = 0.f;
+            u32x4 af1[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float t8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t8[j] = fh ? V[s2 * 16 + 8 + j] : V[s2 * 16 + j];
+                af1[s2] = pack8<TT>(t8);
+            }
+            const int Y = y0 - 1 + py, X = x0 - 1 + px;
+            const bool inside = Y >= 0 && Y < g.H && X >= 0 && X < g.W;     // else: conv1_2's zero padding
+            const int key = (pc >> 1) & 7;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                f32x16 a1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a1[r] = 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) a1 = mfma_32x32x16<DT>(wf[nt][s2], af1[s2], a1);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 bb = bq[nt][q4];
+                    const float o0 = inside ? fmaxf(a1[4 * q4] + bb.x, 0.f) : 0.f, o1 = inside ? fmaxf(a1[4 * q4 + 1] + bb.y, 0.f) : 0.f;
+                    const float o2 = inside ? fmaxf(a1[4 * q4 + 2] + bb.z, 0.f) : 0.f, o3 = inside ? fmaxf(a1[4 * q4 + 3] + bb.w, 0.f) : 0.f;
+                    const u32x2 pk = {H16<TT>::pack(o0, o1), H16<TT>::pack(o2, o3)};
+                    if (p < PROWS) *reinterpret_cast<u32x2*>(patch + pc * RB + (((nt * 4 + q4) ^ key) << 4) + 8 * fh) = pk;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's patch rows are written before it reaches the first tap's barrier
+    }
     for (int ch = 0; ch < nchunk; ++ch) {
         if (ONEBAR && ch) lds_reads_done_barrier();      // every wave is done with the previous patch and slab 0's buffer
-        if (SGG_CONV_ABL != 6) {
+        if (SGG_CONV_ABL != 6 && !FUSE1) {
             stage_patch(ch);
             stage_w(0, ch, 0);
         }
@@ -279,13 +356,13 @@ __global__ __launch_bounds__(256 * WN, SGG_CONV_WPE) void conv3x3_spatial_kernel
     }
 }
 
-template <int DT, int WN, int NI, bool ONEBAR = false>
+template <int DT, int WN, int NI, bool ONEBAR = false, bool FUSE1 = false>
 int launch_spatial(const ConvArgs& g, hipStream_t s) {
     constexpr int CN = 32 * NI * WN;
-    constexpr int smem_main = PROWS_PAD * RB + 2 * CN * RB, smem_epi = 4 * WN * 32 * (32 * NI * 4 + 16);   // operand tiles | epilogue staging
+    constexpr int smem_main = PROWS_PAD * RB + 2 * CN * RB + (FUSE1 ? 400 * 16 : 0), smem_epi = 4 * WN * 32 * (32 * NI * 4 + 16);   // operand tiles | epilogue staging
     constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
     static_assert(smem <= 160 * 1024, "fits the CU's LDS");
-    auto k = conv3x3_spatial_kernel<DT, WN, NI, ONEBAR>;
+    auto k = conv3x3_spatial_kernel<DT, WN, NI, ONEBAR, FUSE1>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -321,4 +398,41 @@ int sgg_launch_conv_spatial(const void* in, const void* w, const float* bias, vo
     if (Cout % 64 == 0)
         return dt == SGG_BF16 ? launch_spatial<SGG_BF16, 1, 2>(g, s) : dt == SGG_F16 ? launch_spatial<SGG_F16, 1, 2>(g, s) : launch_spatial<SGG_F32, 1, 2>(g, s);
     return 1;
+}
+
+namespace {
+// conv1_1's weights [64][27] f32 -> the A-operand fragments of its two MFMA k-steps: frag[nt][s][lane] = 8 values k = s*16 + (lane>>5)*8 + j of
+// channel nt*32 + (lane & 31), zero for k >= 27, in the 16-bit type T
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_pack_kernel(const float* __restrict__ w1, char* __restrict__ frags) {
+    const int i = threadIdx.x, lane = i & 63, s = (i >> 6) & 1, nt = i >> 7;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = s * 16 + (lane >> 5) * 8 + j;
+        v[j] = k < 27 ? w1[(nt * 32 + (lane & 31)) * 27 + k] : 0.f;
+    }
+    *reinterpret_cast<u32x4*>(frags + i * 16) = pack8<T>(v);
+}
+}  // namespace
+
+int sgg_launch_conv1_pack(const float* w1, void* frags, int dt, hipStream_t s) {
+    if (dt == SGG_BF16) hipLaunchKernelGGL(conv1_pack_kernel<bf16_t>, dim3(1), dim3(256), 0, s, w1, (char*)frags);
+    else hipLaunchKernelGGL(conv1_pack_kernel<f16_t>, dim3(1), dim3(256), 0, s, w1, (char*)frags);
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+// conv1_1 + ReLU + conv1_2 + ReLU (+ MaxPool2d(2)) of VGG-16 in one launch (16-bit modes): see FUSE1 above.  img: [B, H+2, W+2, 4] f32 (zero border).
+int sgg_launch_conv1_block(const float* img, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int out_pad, int B,
+                           int H, int W, int dt, int pool, hipStream_t s) {
+    if (dt != SGG_BF16 && dt != SGG_F16) return 1;
+    ConvArgs g{};
+    g.pool = pool;
+    g.in = nullptr; g.w = (const char*)w2; g.bias = b2; g.out = (char*)out;
+    g.img = img; g.w1f = (const char*)w1; g.b1 = b1;
+    g.B = B; g.H = H; g.W = W; g.Cin = 64; g.Cout = 64; g.out_pad = out_pad;
+    g.tiles_x = (W + TILE - 1) / TILE;
+    g.tiles_y = (H + TILE - 1) / TILE;
+    return dt == SGG_BF16 ? launch_spatial<SGG_BF16, 1, 2, false, true>(g, s) : launch_spatial<SGG_F16, 1, 2, false, true>(g, s);
 }

@@ -18,6 +18,9 @@
 #include "gemm_args.h"
 
 int sgg_launch_pingpong(const GemmArgs& g, int dt, bool conv, hipStream_t s);  // gemm256.hip
+int sgg_launch_conv1_block(const float* img, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int out_pad, int B,
+                           int H, int W, int dt, int pool, hipStream_t s);  // conv_spatial.hip
+int sgg_launch_conv1_pack(const float* w1, void* frags, int dt, hipStream_t s);
 int sgg_launch_conv_pp(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H, int W, int Cin, int Cout,
                        int dt, int pool, int form, int tw, hipStream_t s);  // conv_pp.hip
 int sgg_launch_conv_spatial(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H, int W,
@@ -581,6 +584,26 @@ extern "C" int sgg_gemm_tn(const void* A, int lda, const void* B, int ldb, void*
         SGG_CHECK_LAUNCH();
     }
     return SGG_OK;
+}
+
+// The first block of VGG-16 in one launch (16-bit modes): conv1_1 (3 -> 64) + ReLU + conv1_2 (64 -> 64) + ReLU [+ MaxPool2d(2)].
+// in_nhwc4: the normalised image plane [B, H+2, W+2, 4] f32 with zero border (sgg_image_prep*); w1_frags: conv1_1's weights as packed by
+// sgg_conv1_pack_weights (4 KiB, `dtype`); w2 [64][3][3][64] in `dtype`; out: [B, H+2p, W+2p, 64], or the pooled plane
+// [B, H/2+2p, W/2+2p, 64] with pool = 1 (H, W even).
+extern "C" int sgg_conv1_pack_weights(const float* w1 /*[64][27], k = (ky*3+kx)*3 + c*/, void* frags /*4096 bytes*/, int dtype, void* stream) {
+    if (dtype != SGG_BF16 && dtype != SGG_F16) return SGG_ERR_DTYPE;
+    if (!w1 || !frags || ((uintptr_t)frags & 15)) return SGG_ERR_ARG;
+    return sgg_launch_conv1_pack(w1, frags, dtype, (hipStream_t)stream);
+}
+
+extern "C" int sgg_conv1_block(const float* in_nhwc4, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int out_pad,
+                               int B, int H, int W, int pool, int dtype, void* stream) {
+    if (dtype != SGG_BF16 && dtype != SGG_F16) return SGG_ERR_DTYPE;
+    if (!in_nhwc4 || !w1 || ((uintptr_t)w1 & 15) || ((uintptr_t)b1 & 15) || !b1 || !w2 || !b2 || !out || B <= 0 || H <= 0 || W <= 0 || (out_pad != 0 && out_pad != 1)) return SGG_ERR_ARG;
+    if (pool && ((H | W) & 1)) return SGG_ERR_ARG;
+    if ((long)B * (H + 2) * (W + 2) * 16 > 0xffff0000L) return SGG_ERR_SPAN;
+    const int rc = sgg_launch_conv1_block(in_nhwc4, w1, b1, w2, b2, out, out_pad, B, H, W, dtype, pool, (hipStream_t)stream);
+    return rc <= 0 ? rc : SGG_ERR_ARG;
 }
 
 extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H,

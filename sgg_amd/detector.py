@@ -8,6 +8,7 @@ sgg_models/rel_model_base.py:92-108, so that `state_dict()` keys are identical
 HOLD parameters -- the arithmetic runs in libsgg_hip.so.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -123,6 +124,8 @@ class VGGDetector(nn.Module):
                 co, ci = w.shape[0], w.shape[1]
                 wk = ops.permute_ncp_to_npc(w.reshape(co, ci, 9), torch.float32 if i == 0 else dtype)  # [co,9,ci]
                 ws.append((wk.reshape(co, 9 * ci), c.bias.detach().float().contiguous(), ci, co))
+            if ops.is_half(dtype) and ws[0][0].is_cuda:
+                ws[0] = ws[0] + (ops.conv1_pack_weights(ws[0][0], dtype),)      # conv1_1 as MFMA fragments (the fused first block)
             self._prep = dict(key=key, val=ws)
         return self._prep['val']
 
@@ -178,9 +181,21 @@ class VGGDetector(nn.Module):
                 ops.maxpool2x2(x, y, 1)
                 H, W = H // 2, W // 2
             else:
-                w, bias, ci, co = ws[ci_layer]
+                w, bias, ci, co = ws[ci_layer][:4]
                 last = ci_layer == n_conv - 1
                 op = 0 if last else 1
+                if (ci_layer == 0 and ops.is_half(dtype) and li + 2 < len(cfg) and cfg[li + 1] == 64 and cfg[li + 2] == 'M' and
+                        ops.conv_pool_fusable(H, W, 64) and os.environ.get('SGG_CONV1_FUSE', '1') != '0'):
+                    # the first block in one launch: conv1_1's full-resolution 64-channel map (the largest activation of the network) is
+                    # computed tile by tile inside conv1_2's LDS patch and never written (csrc/conv_spatial.hip FUSE1)
+                    w2, bias2 = ws[1][:2]
+                    y = self._buf('a%d' % (li + 2), (B, H // 2 + 2, W // 2 + 2, 64), dtype, dev, True)
+                    ops.conv1_block(x, ws[0][4], bias, w2.view(64, 3, 3, 64), bias2, y, 1, pool=True)
+                    H, W = H // 2, W // 2
+                    ci_layer += 2
+                    li += 3
+                    x = y
+                    continue
                 # conv followed by MaxPool2d(2): the pool rides in the conv epilogue (the full-resolution map is never written)
                 fuse = (ci_layer > 0 and li + 1 < len(cfg) and cfg[li + 1] == 'M' and ops.conv_pool_fusable(H, W, co))
                 if fuse:

@@ -109,6 +109,24 @@ def conv1_1(x_nhwc4, w, bias, out):
               B, H, W, dt(out), _stream())
 
 
+def conv1_pack_weights(w1, dtype):
+    """conv1_1's weights f32 [64,27] -> the 4-KiB fragment block sgg_conv1_block reads (once per weight change)"""
+    frags = torch.empty(4096, dtype=torch.uint8, device=w1.device)
+    _lib.call('sgg_conv1_pack_weights', _p(w1, torch.float32), _p(frags), dt(torch.empty(0, dtype=dtype)), _stream())
+    return frags
+
+
+def conv1_block(x_nhwc4, w1_frags, b1, w2, b2, out, out_pad, pool=False):
+    """conv1_1 + ReLU + conv1_2 + ReLU (+ MaxPool2d(2)) of VGG-16 in one launch (16-bit `out`); x_nhwc4 f32 [B,H+2,W+2,4];
+    w1_frags from conv1_pack_weights (same 16-bit type as `out`)."""
+    B, H, W = x_nhwc4.shape[0], x_nhwc4.shape[1] - 2, x_nhwc4.shape[2] - 2
+    assert x_nhwc4.dtype == torch.float32 and x_nhwc4.shape[3] == 4 and is_half(out.dtype) and w2.dtype == out.dtype
+    assert w1_frags.dtype == torch.uint8 and w1_frags.numel() == 4096
+    _lib.call('sgg_conv1_block', _p(x_nhwc4), _p(w1_frags), _p(b1, torch.float32), _p(w2), _p(b2, torch.float32), _p(out), int(out_pad),
+              B, H, W, int(bool(pool)), dt(out), _stream())
+    return out
+
+
 def conv_pool_fusable(H, W, Cout):
     """Shapes for which conv3x3_relu(pool=True) exists: the LDS-patch kernel's (wide maps, even sizes)."""
     return H >= 64 and W >= 64 and H % 2 == 0 and W % 2 == 0 and Cout % 64 == 0

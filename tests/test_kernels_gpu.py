@@ -213,6 +213,34 @@ def test_conv3x3_relu_with_fused_maxpool(ops, dtype):
         ops.conv3x3_relu(xd[:, :-1], wd, bd, got, 1, pool=True)                                   # odd height
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('B,H,W,pool', [(2, 64, 96, True), (1, 70, 58, True), (3, 48, 80, False), (1, 608, 608, True)])
+def test_conv1_block_equals_conv1_1_then_conv1_2(ops, dtype, B, H, W, pool):
+    """sgg_conv1_block (conv1_1 computed inside conv1_2's LDS patch) == the two launches, bit for bit: the same MFMA products, the same
+    16-bit rounding of conv1_1's output, zero padding at the image border, tiles that overhang the right / bottom edge."""
+    g = torch.Generator().manual_seed(H + W)
+    img = torch.zeros(B, H + 2, W + 2, 4)
+    img[:, 1:-1, 1:-1, :3] = torch.randn(B, H, W, 3, generator=g)
+    w1 = torch.randn(64, 27, generator=g) / 5
+    b1 = torch.randn(64, generator=g) * 0.1
+    w2 = (torch.randn(64, 3, 3, 64, generator=g) / 24).to(dtype)
+    b2 = torch.randn(64, generator=g) * 0.1
+    imd, w1d, b1d, w2d, b2d = cu(img), cu(w1), cu(b1), cu(w2), cu(b2)
+    y1 = torch.zeros(B, H + 2, W + 2, 64, device=DEV, dtype=dtype)
+    ops.conv1_1(imd, w1d, b1d, y1)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    ref = torch.full((B, Ho + 2, Wo + 2, 64), 7.0, device=DEV, dtype=dtype)
+    ops.conv3x3_relu(y1, w2d, b2d, ref, 1, pool=pool)
+    got = torch.full((B, Ho + 2, Wo + 2, 64), 7.0, device=DEV, dtype=dtype)
+    frags = ops.conv1_pack_weights(w1d, dtype)
+    ops.conv1_block(imd, frags, b1d, w2d, b2d, got, 1, pool=pool)
+    assert torch.equal(got, ref)
+    assert float(got[:, 1:-1, 1:-1].float().abs().max()) > 0.1 and float(got[:, 0].float().min()) == 7.0
+    got0 = torch.empty((B, Ho, Wo, 64), device=DEV, dtype=dtype)
+    ops.conv1_block(imd, frags, b1d, w2d, b2d, got0, 0, pool=pool)
+    assert torch.equal(got0, ref[:, 1:-1, 1:-1])
+
+
 def test_image_prep_conv1_1_maxpool(ops):
     g = torch.Generator().manual_seed(3)
     B, S, Hp = 2, 40, 64
