@@ -6,7 +6,7 @@ from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
 from sgg_amd.trainer import Trainer
 dev = 'cuda:0'
 model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls')).to(dev)
-model.set_compute_dtype(torch.bfloat16)
+model.set_compute_dtype(torch.float16)
 b = list(synthetic_batch(B=8, S=592, n_boxes=32, n_fg=6, seed=111))
 b[0] = [im.to(dev) for im in b[0]]
 from sgg_amd.rel_model_base import to_device_with_mirror
