@@ -11,10 +11,12 @@ Dense gradient contractions reuse the MFMA GEMM:  dX = dY . W  is  gemm(dY, W^T)
 dW = dY^T . X  is  gemm(dY^T, X^T)  on transposed copies.  GRU weights are shared by the 4 calls of each cell; their
 gradients are single GEMMs over the row-stacked calls (no accumulation passes).
 """
+import os
+
 import torch
 
 from . import _lib, ops
-from .imp import GATES
+from .imp import GATES, node_lane
 
 DROPOUT_P = 0.5  # nn.Dropout() default in torchvision's VGG classifier
 
@@ -295,7 +297,7 @@ class PredictFn(torch.autograd.Function):
                 if big:
                     hook(name + '.weight')
             n_out_ = n_out
-            deferred.append(dw)
+            deferred.append((name, dw))
             if not want_dx:
                 return None
             if prepadded:                                   # W^T is padded to a multiple of 64 columns: a strided view of dY matches it
@@ -375,7 +377,54 @@ class PredictFn(torch.autograd.Function):
         d_p7 = ops.act_bwd(d_x7, sv['x7'], ds)
         d_x6 = lin_bwd(d_p7, sv['x6'], t['fc7_obj_t'], n7o, 'bwd_mlp_obj', big=True)
         d_p6 = ops.act_bwd(d_x6, sv['x6'], ds)
-        # ---- phase B: the two fc6 weight gradients
+        # ---- the lane: everything below depends on phase A only and is latency- / HBM-bound (256-row contractions with 100 M outputs, the
+        # node GRU's parameter gradients, the rect conv's backward with its two BatchNorms): it runs on the node lane's stream UNDER the
+        # MFMA-bound fc6 / fc7 weight gradients of the edge branch instead of after them (SGG_BWD_LANE=0: in line, as before round 3)
+        node_side = {'obj_fc', 'obj_unary', n7o}
+
+        def lane_work():
+            _lib.set_tag('bwd_mlp_obj')
+            G[n6o + '.weight'], G[n6o + '.bias'] = tn_gemm(d_p6, sv['nf'], want_colsum=True, out_dtype=big_dtype())
+            hook(n6o + '.weight')
+            for name, dw in deferred[::-1]:                # fc7 node, unary node, obj_fc
+                if name in node_side:
+                    dw()
+            _lib.set_tag('bwd_imp')
+            G['node_gru.weight_ih'], G['node_gru.bias_ih'] = tn_gemm(dGIn, XN, want_colsum=True)
+            G['node_gru.weight_hh'] = tn_gemm(dGHn[N:], HN[:T * N])
+            G['node_gru.bias_hh'] = ops.colsum(dGHn)
+            _lib.set_tag('bwd_rect')
+            d_rect = ops.gemm(d_pre6, t['w6sum_t'])                                    # [E,C]
+            # rect conv backward (BatchNorm with batch statistics)
+            bn_sync = getattr(model, '_bn_sync', None)
+            d_c2, db2, dg2 = ops.bn_bwd(d_rect, None, sv['h3'], sv['m2'], sv['is2'], t['rc_g2'], False, bn_sync)
+            G['union_boxes.conv.6.weight'], G['union_boxes.conv.6.bias'] = dg2, db2
+            gw2, gb2 = tn_gemm(d_c2, sv['h2'], want_colsum=True)                       # [d, d2] centre tap
+            # only the centre tap of this 3x3 convolution sees data (1x1 input, padding 1): its gradient with a ring of zeros, one launch
+            G['union_boxes.conv.4.weight'] = torch.nn.functional.pad(gw2[:, :, None, None], (1, 1, 1, 1))
+            G['union_boxes.conv.4.bias'] = gb2
+            d_h2 = ops.gemm(d_c2, t['rc_w2_t'])                                        # [E,d2]
+            d_c1, db1, dg1 = ops.bn_bwd(d_h2, sv['arg'], sv['h1'], sv['m1'], sv['is1'], t['rc_g1'], True, bn_sync)
+            G['union_boxes.conv.2.weight'], G['union_boxes.conv.2.bias'] = dg1, db1
+            gw1, gb1 = tn_gemm(d_c1, sv['patches'], want_colsum=True)                  # [d2,128]
+            G['union_boxes.conv.0.weight'] = gw1[:, :98].reshape(tuple(model.union_boxes.conv[0].weight.shape)).contiguous()
+            G['union_boxes.conv.0.bias'] = gb1
+            _lib.set_tag('')
+
+        lane = node_lane(dev) if os.environ.get('SGG_BWD_LANE', '1') != '0' else None
+        lane_done, lane_keys = None, ()
+        if lane is not None:
+            side = lane[0]
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(dev))
+            side.wait_event(ready)                         # phase A is complete (d_p6, d_pre6, the node GRU's gate gradients)
+            before = set(G)
+            with torch.cuda.stream(side):
+                lane_work()
+                lane_done = torch.cuda.Event()
+                lane_done.record(side)
+            lane_keys = tuple(set(G) - before)
+        # ---- phase B: the fc6 weight gradient of the edge branch
         _lib.set_tag('bwd_fc6_edge_dW')
         # d W6[n,(c,p)] = sum_e d_pre6[e,n] * (edge_feat[e,c,p] + rect[e,c]): the folded term rides in the transpose
         paired = sv['paired']
@@ -397,43 +446,30 @@ class PredictFn(torch.autograd.Function):
             G[n6e + '.weight'] = ops.gemm_full_waves(d6t, x6t, out_dtype=big_dtype())
         hook(n6e + '.weight')
         del x6t, d6t
-        _lib.set_tag('bwd_mlp_obj')
-        G[n6o + '.weight'], G[n6o + '.bias'] = tn_gemm(d_p6, sv['nf'], want_colsum=True, out_dtype=big_dtype())
-        hook(n6o + '.weight')
-        # ---- phase C: everything deferred, largest first (fc7 x2 carry their own hooks)
-        for dw in deferred[::-1]:                      # fc7 node, unary node, fc7 edge, unary edge, heads
-            dw()
+        # ---- phase C on the main stream: the edge-side weight gradients, largest first (fc7 carries its own hook)
+        for name, dw in deferred[::-1]:                # fc7 edge, unary edge, rel_fc (the node-side ones ran / run on the lane)
+            if name not in node_side:
+                dw()
         _lib.set_tag('bwd_imp')
         # GRU parameter gradients: one contraction over the 4 stacked calls; hidden state of call 0 is zero
         G['edge_gru.weight_ih'] = tn_gemm(DG[T * E:], XH[:E + T * N])           # [d_gi of call 0 ; dP_0 ..]^T . [rel_rep ; v_0 ..]
         G['edge_gru.bias_ih'] = ops.colsum(DG[:(T + 1) * E])
         G['edge_gru.weight_hh'] = tn_gemm(dGHe[E:], HE[:T * E])              # states entering calls 1..T (call 0: zero state)
         G['edge_gru.bias_hh'] = ops.colsum(dGHe)                          # b_hh acts in every call
-        G['node_gru.weight_ih'], G['node_gru.bias_ih'] = tn_gemm(dGIn, XN, want_colsum=True)
-        G['node_gru.weight_hh'] = tn_gemm(dGHn[N:], HN[:T * N])
-        G['node_gru.bias_hh'] = ops.colsum(dGHn)
         ops.rank4_reduce_(da_all, HE[:T * E], d_gw, col0=H, accumulate=False)         # e_i = rows i of HE, v_i = rows i of HN
         ops.rank4_reduce_(nsum_all, HN[:T * N], d_gw, col0=0, accumulate=False)
         d_gb = ops.colsum(da_all)                           # the gate biases: column sums of the gate pre-activation gradients
         for k, g in enumerate(GATES):                       # views of the two results (nothing writes them after this point)
             G[g + '.0.weight'] = d_gw[k:k + 1]
             G[g + '.0.bias'] = d_gb[k:k + 1]
-        _lib.set_tag('bwd_rect')
-        d_rect = ops.gemm(d_pre6, t['w6sum_t'])                                    # [E,C]
-        # rect conv backward (BatchNorm with batch statistics)
-        bn_sync = getattr(model, '_bn_sync', None)
-        d_c2, db2, dg2 = ops.bn_bwd(d_rect, None, sv['h3'], sv['m2'], sv['is2'], t['rc_g2'], False, bn_sync)
-        G['union_boxes.conv.6.weight'], G['union_boxes.conv.6.bias'] = dg2, db2
-        gw2, gb2 = tn_gemm(d_c2, sv['h2'], want_colsum=True)                       # [d, d2] centre tap
-        # only the centre tap of this 3x3 convolution sees data (1x1 input, padding 1): its gradient with a ring of zeros, one launch
-        G['union_boxes.conv.4.weight'] = torch.nn.functional.pad(gw2[:, :, None, None], (1, 1, 1, 1))
-        G['union_boxes.conv.4.bias'] = gb2
-        d_h2 = ops.gemm(d_c2, t['rc_w2_t'])                                        # [E,d2]
-        d_c1, db1, dg1 = ops.bn_bwd(d_h2, sv['arg'], sv['h1'], sv['m1'], sv['is1'], t['rc_g1'], True, bn_sync)
-        G['union_boxes.conv.2.weight'], G['union_boxes.conv.2.bias'] = dg1, db1
-        gw1, gb1 = tn_gemm(d_c1, sv['patches'], want_colsum=True)                  # [d2,128]
-        G['union_boxes.conv.0.weight'] = gw1[:, :98].reshape(tuple(model.union_boxes.conv[0].weight.shape)).contiguous()
-        G['union_boxes.conv.0.bias'] = gb1
+        if lane_done is None:
+            lane_work()
+        else:                                               # everything the lane produced is complete before anything downstream reads it
+            main = torch.cuda.current_stream(dev)
+            main.wait_event(lane_done)
+            for kname in lane_keys:
+                if isinstance(G.get(kname), torch.Tensor):
+                    G[kname].record_stream(main)          # allocated under the lane's stream, consumed (and freed) under this one
         _lib.set_tag('')
         ctx.sv = None
         shapes = dict(model.head_named_parameters())
