@@ -393,6 +393,15 @@ class PredictFn(torch.autograd.Function):
             G['node_gru.weight_ih'], G['node_gru.bias_ih'] = tn_gemm(dGIn, XN, want_colsum=True)
             G['node_gru.weight_hh'] = tn_gemm(dGHn[N:], HN[:T * N])
             G['node_gru.bias_hh'] = ops.colsum(dGHn)
+            # HBM-bound reductions of the edge GRU / the gates (column sums over 4 E rows, rank-4 contractions): also under the GEMMs
+            G['edge_gru.bias_ih'] = ops.colsum(DG[:(T + 1) * E])
+            G['edge_gru.bias_hh'] = ops.colsum(dGHe)                          # b_hh acts in every call
+            ops.rank4_reduce_(da_all, HE[:T * E], d_gw, col0=H, accumulate=False)         # e_i = rows i of HE, v_i = rows i of HN
+            ops.rank4_reduce_(nsum_all, HN[:T * N], d_gw, col0=0, accumulate=False)
+            d_gb = ops.colsum(da_all)                           # the gate biases: column sums of the gate pre-activation gradients
+            for k, g in enumerate(GATES):                       # views of the two results (nothing writes them after this point)
+                G[g + '.0.weight'] = d_gw[k:k + 1]
+                G[g + '.0.bias'] = d_gb[k:k + 1]
             _lib.set_tag('bwd_rect')
             d_rect = ops.gemm(d_pre6, t['w6sum_t'])                                    # [E,C]
             # rect conv backward (BatchNorm with batch statistics)
@@ -453,15 +462,7 @@ class PredictFn(torch.autograd.Function):
         _lib.set_tag('bwd_imp')
         # GRU parameter gradients: one contraction over the 4 stacked calls; hidden state of call 0 is zero
         G['edge_gru.weight_ih'] = tn_gemm(DG[T * E:], XH[:E + T * N])           # [d_gi of call 0 ; dP_0 ..]^T . [rel_rep ; v_0 ..]
-        G['edge_gru.bias_ih'] = ops.colsum(DG[:(T + 1) * E])
         G['edge_gru.weight_hh'] = tn_gemm(dGHe[E:], HE[:T * E])              # states entering calls 1..T (call 0: zero state)
-        G['edge_gru.bias_hh'] = ops.colsum(dGHe)                          # b_hh acts in every call
-        ops.rank4_reduce_(da_all, HE[:T * E], d_gw, col0=H, accumulate=False)         # e_i = rows i of HE, v_i = rows i of HN
-        ops.rank4_reduce_(nsum_all, HN[:T * N], d_gw, col0=0, accumulate=False)
-        d_gb = ops.colsum(da_all)                           # the gate biases: column sums of the gate pre-activation gradients
-        for k, g in enumerate(GATES):                       # views of the two results (nothing writes them after this point)
-            G[g + '.0.weight'] = d_gw[k:k + 1]
-            G[g + '.0.bias'] = d_gb[k:k + 1]
         if lane_done is None:
             lane_work()
         else:                                               # everything the lane produced is complete before anything downstream reads it
