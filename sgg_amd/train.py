@@ -112,6 +112,14 @@ def train_weights(model):
     return w
 
 
+def _imp_lane(dev):
+    """the node lane's stream for the node cell of the training loop (SGG_TRAIN_IMP_LANE=0: everything on one stream)"""
+    if os.environ.get('SGG_TRAIN_IMP_LANE', '1') == '0':
+        return None
+    lane = node_lane(dev)
+    return lane[0] if lane is not None else None
+
+
 def _gru_fwd(x, h, w_ih, w_hh, b_ih, b_hh, dtype, out, dot_w=None):
     """-> (gi, gh, dots): dots f32[M,4] = the new state's gate dot products against dot_w (None without dot_w)."""
     gi = ops.gemm(x, w_ih, b_ih, out_dtype=torch.float32)
@@ -217,23 +225,52 @@ class PredictFn(torch.autograd.Function):
             raise NotImplementedError('message passing needs hidden_dim / 8 to be a power of two <= 64 (got hidden_dim %d)' % H)
         wv, we = (imp.gate_w[:, :H], imp.gate_w[:, H:]) if T > 0 else (None, None)
         gin, ghn, ghe, Ps, nds, eds = [], [], [], [], [], []
-        a, b, nd = _gru_fwd(XN[:N], None, imp.node_gru_w_ih, imp.node_gru_w_hh, imp.node_gru_b_ih, imp.node_gru_b_hh, dt, HN[:N], wv)
+        # The node cell is three launches on 32 B rows -- pure launch / DRAM latency -- and depends on (ctx_i, v_i) only: on the node lane's
+        # stream it runs beside the edge cell of the same iteration (as in message_pass of the evaluation path) instead of after it.
+        main = torch.cuda.current_stream(dev)
+        side = _imp_lane(dev)
+        node_done = None
+
+        def node_cell(x, h, out, dots_w, after):
+            """-> (gi, gh, dots) of the node GRU; on the lane when there is one (`after`: main-stream event its inputs wait for)"""
+            nonlocal node_done
+            if side is None:
+                return _gru_fwd(x, h, imp.node_gru_w_ih, imp.node_gru_w_hh, imp.node_gru_b_ih, imp.node_gru_b_hh, dt, out, dots_w)
+            side.wait_event(after)
+            with torch.cuda.stream(side):
+                res = _gru_fwd(x, h, imp.node_gru_w_ih, imp.node_gru_w_hh, imp.node_gru_b_ih, imp.node_gru_b_hh, dt, out, dots_w)
+                node_done = torch.cuda.Event()
+                node_done.record(side)
+            for r_ in res:
+                if r_ is not None:
+                    r_.record_stream(main)            # allocated under the lane's stream, read (and freed) under the main one
+            return res
+
+        def mark(stream=None):
+            ev_ = torch.cuda.Event()
+            ev_.record(stream or main)
+            return ev_
+
+        a, b, nd = node_cell(XN[:N], None, HN[:N], wv, mark() if side is not None else None)
         gin.append(a); ghn.append(b)
         gie0, _, ed = _gru_fwd(XE0, None, imp.edge_gru_w_ih, imp.edge_gru_w_hh, imp.edge_gru_b_ih, imp.edge_gru_b_hh, dt, HE[:E], we)
         for i in range(T):
             v_i, e_i = HN[i * N:(i + 1) * N], HE[i * E:(i + 1) * E]
             more = i + 1 < T
             ctx_i = XN[(i + 1) * N:(i + 2) * N]                                # ctx = ctx_out + ctx_in (kept for d W_ih of the node cell)
+            if node_done is not None:
+                main.wait_event(node_done)                                    # v_i and its gate dot products
             ops.imp_ctx(e_i, csr, N, nd, ed, imp.gate_b, pair=2, ctx_sum=ctx_i)
+            a, b, nd_new = node_cell(ctx_i, v_i, HN[(i + 1) * N:(i + 2) * N], wv if more else None, mark() if side is not None else None)
             P = ops.gemm(v_i, imp.edge_gru_w_ih, None, out_dtype=torch.float32)
             gh = ops.gemm(e_i, imp.edge_gru_w_hh, imp.edge_gru_b_hh, out_dtype=torch.float32)
             r = ops.gru_gate_proj(gh, P, imp.edge_gru_b_ih, csr, nd, ed, imp.gate_b, e_i, out=HE[(i + 1) * E:(i + 2) * E],
                                   dot_w=we if more else None)
             ghe.append(gh); Ps.append(P); nds.append(nd); eds.append(ed)
-            a, b, nd_new = _gru_fwd(ctx_i, v_i, imp.node_gru_w_ih, imp.node_gru_w_hh, imp.node_gru_b_ih,
-                                    imp.node_gru_b_hh, dt, HN[(i + 1) * N:(i + 2) * N], wv if more else None)
             gin.append(a); ghn.append(b)
             nd, ed = nd_new, (r[1] if more else None)
+        if node_done is not None:
+            main.wait_event(node_done)
         vT, eT = HN[T * N:(T + 1) * N], HE[T * E:(T + 1) * E]
         _lib.set_tag('heads')
         obj = ops.gemm(vT, w['obj_fc'], w['obj_fc_b'], out_dtype=torch.float32)
@@ -333,18 +370,36 @@ class PredictFn(torch.autograd.Function):
         # contractions over T E / T N rows in phase C instead of 3 T small ones
         da_all = torch.empty((T * E, 4), dtype=torch.float32, device=dev)
         nsum_all = torch.empty((T * N, 4), dtype=torch.float32, device=dev)
+        main_s = torch.cuda.current_stream(dev)
+        imp_side = _imp_lane(dev)
         for i in range(T - 1, -1, -1):
             v_i, e_i = rows(HN, i, N), rows(HE, i, E)
             nd_i, ed_i = sv['nds'][i], sv['eds'][i]
-            # v_{i+1} = GRU_n(ctx_i, v_i)
-            d_v_prev = ops.gru_gate_bwd(d_v, sv['gin'][i + 1], sv['ghn'][i + 1], None, v_i, rows(dGIn, i + 1, N),
-                                        rows(dGHn, i + 1, N))
-            d_ctx = ops.gemm(rows(dGIn, i + 1, N), t['node_gru_w_ih_t'])
-            ops.add_(d_v_prev, ops.gemm(rows(dGHn, i + 1, N), t['node_gru_w_hh_t']))
+            # v_{i+1} = GRU_n(ctx_i, v_i): four launches on 32 B rows, independent of the edge cell's backward below -- on the node lane
+            def node_part(d_v=d_v, v_i=v_i, i=i):
+                d_v_prev = ops.gru_gate_bwd(d_v, sv['gin'][i + 1], sv['ghn'][i + 1], None, v_i, rows(dGIn, i + 1, N),
+                                            rows(dGHn, i + 1, N))
+                d_ctx = ops.gemm(rows(dGIn, i + 1, N), t['node_gru_w_ih_t'])
+                ops.add_(d_v_prev, ops.gemm(rows(dGHn, i + 1, N), t['node_gru_w_hh_t']))
+                return d_v_prev, d_ctx
+            if imp_side is None:
+                d_v_prev, d_ctx = node_part()
+            else:
+                ev_in = torch.cuda.Event()
+                ev_in.record(main_s)
+                imp_side.wait_event(ev_in)                      # d_v (the previous iteration's join)
+                with torch.cuda.stream(imp_side):
+                    d_v_prev, d_ctx = node_part()
+                    ev_node = torch.cuda.Event()
+                    ev_node.record(imp_side)
+                d_v_prev.record_stream(main_s)
+                d_ctx.record_stream(main_s)
             # e_{i+1} = GRU_e(g_sub P_i[s] + g_obj P_i[o] + b_ih ; e_i)
             d_e_prev, dq = ops.gru_gate_proj_bwd(d_e, sv['ghe'][i], sv['Ps'][i], imp.edge_gru_b_ih, csr, nd_i, ed_i, imp.gate_b, e_i,
                                                  dgi_call(i + 1), rows(dGHe, i + 1, E))
             ops.add_(d_e_prev, ops.gemm(rows(dGHe, i + 1, E), t['edge_gru_w_hh_t']))
+            if imp_side is not None:
+                main_s.wait_event(ev_node)
             # the four gates and the context sums
             da = ops.imp_edge_ctx_bwd(e_i, csr, nd_i, ed_i, imp.gate_w, imp.gate_b, dq, d_ctx, d_e_prev, da=rows(da_all, i, E))
             ops.imp_node_gates_bwd(da, csr, imp.gate_w, d_v_prev, nsum=rows(nsum_all, i, N))
