@@ -155,6 +155,34 @@ def pmc_traffic(key):
     return None
 
 
+def contraction_alone_ms(tag, pairs, dtype, reps=10):
+    """The roofline contraction launched on its own (nothing on a second stream beside it), same shapes and element types as in the step:
+    average of `reps` launches between two events."""
+    import torch
+    from sgg_amd import ops
+    dev = 'cuda:%d' % torch.cuda.current_device()
+    g = torch.Generator().manual_seed(0)
+    if tag == 'fc6_edge':
+        A = torch.randn(pairs, 25088, generator=g).to(dev).to(dtype).relu()
+        W = (torch.randn(4096, 25088, generator=g) / 160).to(dev).to(dtype)
+        out = torch.empty(pairs, 4096, device=dev, dtype=torch.float32)
+        run = lambda: ops.gemm(A, W, out=out, out_dtype=torch.float32)          # noqa: E731
+    else:
+        A = (torch.randn(4096, pairs, generator=g) / 50).to(dev).to(dtype)
+        W = torch.randn(25088, pairs, generator=g).to(dev).to(dtype).relu()
+        run = lambda: ops.gemm_full_waves(A, W, out_dtype=torch.bfloat16)       # noqa: E731
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
 def imp_iter_ms(model, B, dtype, reps=50, kind='ctx'):
     """Average duration of ONE launch of a kernel of the message-passing step on a complete 32-box/image graph of B images: `reps`
     launches back-to-back between two HIP events on the launch stream (outputs pre-allocated, hipGraph replay).  kind: 'ctx' = the
@@ -429,6 +457,7 @@ def main():
                 best = (tag, ms, desc, flop)
         tag, ms, desc, flop = best
         tf = flop / (ms * 1e-3) / 1e12
+        alone_ms = contraction_alone_ms(tag, U, tdtype) if (paired and tdtype != torch.float32) else None
         # the step's gather / gate / scatter launch (sgg_imp_ctx_fwd), back-to-back timing.  Algorithmic bytes = SURVEY 8(d)'s figure for the
         # reference's step: read e_i and v_i, WRITE e_in, write ctx, per iteration.  Since round 3 the e_in stream does not exist (node
         # projection, csrc/imp.hip): the launch delivers the step's outputs in the time of its read stream, `moved_bytes` says what it moves.
@@ -545,6 +574,9 @@ def main():
                          'traffic': pmc_traffic('fc6_edge_gemm' if tag == 'fc6_edge' else 'fc6_dW_gemm') if (B == 8 and args.dtype != 'f32') else None,
                          'traffic_source': 'profiles/pmc_r0x.json: separate rocprofv3 --pmc passes of the same launch (tools/pmc_traffic.sh), not measured in this run',
                          'ms_per_step': round(ms, 4), 'executed_flop': flop,
+                         'alone': ({'ms': round(alone_ms, 4), 'TFLOP/s': round(flop / (alone_ms * 1e-3) / 1e12, 1),
+                                    'note': 'the same contraction launched on its own (incl. its split-K tail): in the step the node lane\'s stream runs HBM-bound reductions '
+                                            'and 256-row contractions beside it (DESIGN 10), which lengthens this launch and shortens the step'} if alone_ms else None),
                          'reference_algorithm_tflops': round(ref_flop[tag] / (ms * 1e-3) / 1e12, 2),
                          'note': ('achieved = FLOPs the launch executes / its time; the reference runs this contraction on every EDGE '
                                   '(SURVEY 8(d)), here it runs once per unordered box pair: reference_algorithm_tflops prices the '
