@@ -164,3 +164,42 @@ def test_training_is_bit_reproducible(dtype, pipeline):
         assert torch.equal(s1[n], s2[n]), n
     for n in m1:
         assert torch.equal(m1[n], m2[n]), n
+
+
+def test_second_stream_work_changes_no_bit(monkeypatch):
+    """The node lane's stream (the backward's node-side / reduction / rect-conv work, the node cell of the training loop) is
+    scheduling only: ten train steps with it give the weights, momenta and losses of ten steps with everything on one stream, bit for
+    bit -- and a missing event between the two streams would show up here as a difference."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import sgg_amd
+    from sgg_amd.rel_model_base import to_device_with_mirror
+    from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
+    from sgg_amd.trainer import Trainer
+    batches = []
+    for seed in (41, 42):
+        b = list(synthetic_batch(B=8, S=592, n_boxes=32, n_fg=6, seed=seed))       # the bench's shapes: kernels long enough to overlap
+        b[0] = [im.to(DEV) for im in b[0]]
+        b[3], b[4], b[5] = b[3].to(DEV), to_device_with_mirror(b[4], DEV), to_device_with_mirror(b[5], DEV)
+        batches.append(tuple(b))
+
+    def run(lanes):
+        for k in ('SGG_BWD_LANE', 'SGG_TRAIN_IMP_LANE'):
+            monkeypatch.setenv(k, '1' if lanes else '0')
+        torch.manual_seed(99)
+        model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls')).to(DEV)
+        tr = Trainer(model, lr=1e-2, pipeline=True)
+        losses = [float(tr.step(batches[i % 2])) for i in range(10)]
+        tr.flush()
+        torch.cuda.synchronize()
+        state = {n: t.detach().clone() for n, t in model.state_dict().items() if not n.startswith('detector.')}
+        mom = {tr.opt.name_of[p]: tr.opt.state[p]['momentum_buffer'].clone() for p in tr.opt.params() if 'momentum_buffer' in tr.opt.state[p]}
+        del tr, model
+        return losses, state, mom
+    l1, s1, m1 = run(True)
+    l0, s0, m0 = run(False)
+    assert l1 == l0, list(zip(l1, l0))
+    for n in s1:
+        assert torch.equal(s1[n], s0[n]), n
+    for n in m1:
+        assert torch.equal(m1[n], m0[n]), n
