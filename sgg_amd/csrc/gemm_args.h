@@ -78,7 +78,8 @@ __device__ __forceinline__ void tile_coords(int bid, int tilesM, int tilesN, int
 // lane and tile -- cost ~10 us of a 744-tile launch: the vector-memory issue rate, not bytes.)
 struct ChanVec8 {
     float bias[8], ps[8], pt[8];
-    bool has_ps, has_pt;
+    int gidx[8];                // group-addend column of each of the lane's 8 output columns ((n + k + gcol0) / ggroup: one division per
+    bool has_ps, has_pt;        // column and TILE here instead of one per column and stored row in the epilogue)
 };
 __device__ __forceinline__ void load_chan8(const float* p, int n, int N, float (&out)[8], float fill) {
     if (!p) {
@@ -100,6 +101,10 @@ __device__ __forceinline__ ChanVec8 load_chanvec8(const GemmArgs& g, int n) {
     load_chan8(g.pshift, n, g.N, c.pt, 0.f);
     c.has_ps = g.pscale != nullptr;
     c.has_pt = g.pshift != nullptr;
+    if (g.gadd) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c.gidx[k] = (min(n + k, g.N - 1) + g.gcol0) / g.ggroup;
+    }
     return c;
 }
 
@@ -121,7 +126,7 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& g, const ChanVec
         const float* r = g.gadd + (long)m * g.ld_gadd;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-            if (k < nv) v[k] += r[(n + k + g.gcol0) / g.ggroup];                   // (never past column N - 1: the last group may end there)
+            if (k < nv) v[k] += r[c.gidx[k]];                                      // (never past column N - 1: the last group may end there)
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {

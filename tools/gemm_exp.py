@@ -24,3 +24,21 @@ for N in (4096, 8192, 16384):
     run(4096, N, 128)
 run(4096, 24576, 128, torch.float32)
 run(4096, 24576, 128, torch.float16)
+
+
+def run_gadd(M, N, K):
+    from sgg_amd import _lib
+    A = torch.randn(M, K, device=dev).to(dt)
+    W = torch.randn(N, K, device=dev).to(dt)
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    r = torch.randn(M, N // 49 + 1, device=dev)
+    f = lambda: _lib.call('sgg_gemm_groupadd', ops._p(A), A.stride(0), ops._p(W), W.stride(0), ops._p(r), r.stride(0), 49, 0, ops._p(out), out.stride(0),
+                          M, N, K, ops.dt(A), ops.dt(out), ops._stream())
+    ms = timeit(f, reps=20)
+    ref = (A[:64].float() @ W[:490].float().t()) + r[:64, :10].repeat_interleave(49, 1)
+    err = float((out[:64, :490].float() - ref).abs().max() / ref.abs().max())
+    print('group-add epilogue M=%d N=%d K=%d: %.3f ms %5.0f TF, rel err %.1e' % (M, N, K, ms, 2.0 * M * N * K / ms / 1e9, err), flush=True)
+
+
+run_gadd(4096, 24576, 3968)
+run(4096, 24576, 3968)
