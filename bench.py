@@ -456,6 +456,8 @@ def main():
             if ms > 0 and (best is None or ms > best[1]):
                 best = (tag, ms, desc, flop)
         tag, ms, desc, flop = best
+        fwd_ms = per_step('sgg_gemm', 'fc6_edge') + per_step('sgg_gemm_splitk', 'fc6_edge')
+        fwd_desc, fwd_flop = cands['fc6_edge']
         tf = flop / (ms * 1e-3) / 1e12
         alone_ms = contraction_alone_ms(tag, U, tdtype) if (paired and tdtype != torch.float32) else None
         # the step's gather / gate / scatter launch (sgg_imp_ctx_fwd), back-to-back timing.  Algorithmic bytes = SURVEY 8(d)'s figure for the
@@ -581,6 +583,10 @@ def main():
                          'note': ('achieved = FLOPs the launch executes / its time; the reference runs this contraction on every EDGE '
                                   '(SURVEY 8(d)), here it runs once per unordered box pair: reference_algorithm_tflops prices the '
                                   'reference\'s FLOPs over the same time') if paired else None},
+            'roofline_fc6_forward': ({'kernel': '256x256 ping-pong MFMA kernel, ' + fwd_desc, 'bound': 'mfma', 'achieved': round(fwd_flop / (fwd_ms * 1e-3) / 1e12, 2),
+                                      'peak': peak, 'unit': 'TFLOP/s', 'frac': round(fwd_flop / (fwd_ms * 1e-3) / 1e12 / peak, 4), 'ms_per_step': round(fwd_ms, 4),
+                                      'executed_flop': fwd_flop, 'note': 'the second largest contraction (248 tiles = one round, 784 K-tiles per tile): '
+                                      'round 2 reported this launch as `roofline`'} if (fwd_ms > 0 and tag != 'fc6_edge') else None),
             'roofline_vgg': {'kernel': 'VGG-16 features of the frozen detector: conv1_1 (K = 27 on MFMA, computed inside conv1_2) + 12 x 3x3 conv on MFMA (conv_pp.hip: LDS-resident patch under a '
                                        'ping-pong schedule; conv1_2 on the lock-step patch kernel, conv5 as implicit GEMM; pools fused in the epilogues): the largest time slice of the step',
                              'bound': 'mfma', 'achieved': round(vgg_flop / (conv_ms * 1e-3) / 1e12, 1) if conv_ms else 0.0, 'peak': peak, 'unit': 'TFLOP/s',
