@@ -313,13 +313,41 @@ class PredictFn(torch.autograd.Function):
         # (83 % of all gradient bytes), each followed by its hook; (C) every other weight gradient, deferred to here so
         # that it runs while the fc6 all-reduces occupy the links.
         deferred = []
+        _bl = node_lane(dev) if os.environ.get('SGG_BWD_LANE', '1') != '0' else None
+        bwd_lane = _bl[0] if _bl is not None else None
 
         def lin_bwd(dY, X, Wt, name, tag, want_dx=True, big=False, n_out=None):
             """Y = X W^T + b : returns dX now; dW (f32 [N,K]) and db are computed in phase C.  n_out: dY arrives already
             zero-padded to a multiple of 128 columns (the fused loss kernel writes it so) and only its first n_out are real."""
             prepadded = n_out is not None
+            # The E-row fc7 weight gradient ([4096 x 4096] over 7936 rows): the TN kernel (no transposed copies) takes 287 us, the ping-pong
+            # kernel on ready transposes 223 us (tools/tn_bench.py) -- and the two transposes (HBM-bound, 65 MB each way) cost nothing when
+            # the node lane's stream makes them NOW, while the main stream is still busy with the dX chain
+            tposed = None
+            # (without the lane the same contraction runs with the transposes in line: the lane is scheduling only, never a different sum)
+            if big and ops.is_half(dt) and not prepadded and dY.shape[0] >= 4096 and dY.shape[0] % 64 == 0 and os.environ.get('SGG_DW_NT', '1') != '0':
+                if bwd_lane is not None:
+                    ready_ = torch.cuda.Event()
+                    ready_.record(torch.cuda.current_stream(dev))
+                    bwd_lane.wait_event(ready_)
+                    with torch.cuda.stream(bwd_lane):
+                        tposed = (ops.transpose(dY), ops.transpose(X), torch.cuda.Event())
+                        tposed[2].record(bwd_lane)
+                else:
+                    tposed = (ops.transpose(dY), ops.transpose(X), None)
+
             def dw():
                 _lib.set_tag(tag)
+                if tposed is not None:
+                    if tposed[2] is not None:
+                        main_ = torch.cuda.current_stream(dev)
+                        main_.wait_event(tposed[2])
+                        tposed[0].record_stream(main_)
+                        tposed[1].record_stream(main_)
+                    G[name + '.weight'] = ops.gemm(tposed[0], tposed[1], out_dtype=big_dtype())
+                    G[name + '.bias'] = ops.colsum(dY)
+                    hook(name + '.weight')
+                    return
                 n_out = dY.shape[1] if not prepadded else n_out_
                 if (n_out % 128 or prepadded) and ops.is_half(dt) and not big:
                     # narrow heads (151 / 51 outputs): zero-pad dY to 128 columns so that the TN kernel takes it
@@ -558,3 +586,4 @@ def predict_train(model, node_feat, edge_feat, rel_inds, rois, im_inds=None, see
     model._csr_hint = csr
     return PredictFn.apply(model, node_feat.reshape(N, -1), edge_feat.reshape(E, -1), rois.float().contiguous(),
                            rel_inds.contiguous(), im_inds, seed, float(dropout_p), *params)
+
