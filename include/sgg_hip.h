@@ -5,8 +5,9 @@
  * 0 or a negative SGG_ERR_* code.  The caller (sgg_amd/, a Python host over torch for memory and streams)
  * owns every buffer.  Citations are file:line in the reference tree (/root/reference).
  *
- * Element types: SGG_F32 (fp32 storage, fp32 MFMA/VALU arithmetic -- the 1e-3 parity mode) and SGG_BF16
- * (bf16 storage, fp32 accumulate -- the throughput mode of BASELINE config 2).
+ * Element types: SGG_F32 (fp32 storage, fp32 MFMA/VALU arithmetic -- the 1e-3 parity mode), SGG_BF16
+ * (bf16 storage, fp32 accumulate -- the wording of BASELINE config 2) and SGG_F16 (IEEE half storage, fp32
+ * accumulate: same kernels and rates as bf16 with 8x less rounding error -- the default throughput mode).
  *
  * Feature-map / RoI-feature layout is channels-last (NHWC): the same logical tensors the reference holds
  * as NCHW, handed to Python as permuted views.
@@ -21,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGG_ABI_VERSION 1
+#define SGG_ABI_VERSION 5   /* bump whenever a prototype below changes: tests/abi.lock pins (version, digest of the prototypes) */
 
 enum { SGG_F32 = 0, SGG_BF16 = 1, SGG_F16 = 2 };
 enum { SGG_ACT_NONE = 0, SGG_ACT_RELU = 1 };
@@ -291,9 +292,16 @@ int sgg_act_bwd(const void* dy, const void* y, void* dx, int64_t n, float scale,
  * lib/losses.py:41-43,74: loss[0] (+)= weight / norm[0] * sum_rows CE (accumulate = 0: overwritten -- the first head; `norm` on the device), and
  * grad[M,ldg] (g_dtype, columns >= C zero) = grad_scale * d loss / d logits (grad_scale: the loss scale of the f16 mode, 1 otherwise)
  * -- one launch for what F.cross_entropy + autograd do in ~12.  ws: f32[(M + 3) / 4].  flag (optional, i32[1], never cleared here):
- * bit 0 is raised when a label lies outside [0, C) (e.g. torch's ignore_index); such a row adds no loss and gets a zero gradient. */
+ * bit 0 is raised when a label lies outside [0, C) (e.g. torch's ignore_index); such a row adds no loss and gets a zero gradient.
+ * mode 0: 'baseline' as above.  mode 1 'dnorm' / mode 2 'dnorm-fgbg' (lib/losses.py:44-63, the density-normalised edge losses): `norm`
+ * is f32[2] = (M_FG, M_BG) ON THE DEVICE (sgg_label_counts; summed over the ranks by the caller), a row's weight is
+ * weight * (label > 0 ? (M_FG > 0 ? alpha / M_FG : 1) : mode 1 ? (M_BG > 0 && M_FG > 0 ? beta / M_FG : 1) : (M_BG > 0 ? beta / M_BG : 1))
+ * -- the reference's edge_weights incl. its "stay 1" branches, chosen per row on the device: no host synchronisation. */
 int sgg_ce_fwd_bwd(const float* logits, int ld, const int64_t* labels, int label_stride, int M, int C, const float* norm,
-                   float weight, float grad_scale, float* loss, int accumulate, void* grad, int ldg, float* ws, int* flag, int g_dtype, void* stream);
+                   float weight, float grad_scale, float* loss, int accumulate, void* grad, int ldg, float* ws, int* flag, int g_dtype,
+                   int mode, float alpha, float beta, void* stream);
+/* counts[0] (+)= #{labels > 0}, counts[1] (+)= #{labels == 0} as f32 (M_FG, M_BG of lib/losses.py:29-34; M < 2^24). */
+int sgg_label_counts(const int64_t* labels, int label_stride, int M, float* counts, int accumulate, void* stream);
 /* out[N] = column sums of x[M,N] (row stride ld): bias gradients.  ws: f32[64 * N] (may be NULL when M <= 512). */
 int sgg_colsum(const void* x, int M, int N, int ld, float* out, float* ws, int dtype, void* stream);
 /* train-mode BatchNorm2d of the rect conv (lib/get_union_boxes.py:54,58) on row-major [rows, C] activations:
@@ -349,12 +357,14 @@ int sgg_sgd_step(float* p, const void* g, float* momentum_buf, int64_t n, float 
 /* Multi-tensor forms of the two calls above: host arrays (length count) of device pointers and sizes, one launch per
  * 32 tensors instead of one per parameter.  Pointers 16-byte aligned (tensors of fewer than 4 elements: any alignment).  lr per tensor (the reference's two
  * parameter groups, lib/pytorch_misc.py:135-144).  shadow: optional array (entries may be NULL) of 16-bit buffers (shadow_dtype:
- * SGG_BF16 / SGG_F16) that receive the updated parameter in the same pass -- the next forward's MFMA operand, so no separate cast pass. */
+ * SGG_BF16 / SGG_F16) that receive the updated parameter in the same pass -- the next forward's MFMA operand, so no separate cast pass.
+ * A non-finite *norm_sq (overflowed scaled gradients of the f16 mode, a NaN batch) skips the update: no parameter, momentum or shadow is
+ * touched and skipped[0] (optional i32 device counter; hand it to ONE call per step) is incremented. */
 int sgg_sqnorm_multi(const void* const* g, const int64_t* n, int count, float* acc, float* ws /*[2048]*/, int accumulate, int dtype, void* stream);
 int sgg_sgd_multi(float* const* p, const void* const* g, float* const* momentum_buf, void* const* shadow,
                   const int64_t* n, const float* lr, int count, float weight_decay, float momentum, int first_step,
                   const float* norm_sq, float max_norm, float grad_scale, int g_dtype, int shadow_dtype,
-                  int max_blocks /* 0: default 512 */, void* stream);
+                  int max_blocks /* 0: default 512 */, int* skipped, void* stream);
 
 /* ---- utilities used by the host for weight preparation (load time, not on the step path) ---- */
 int sgg_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, void* stream);

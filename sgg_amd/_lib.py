@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('SGG_HIP_LIB') or os.path.join(_HERE, 'libsgg_hip.so')
 
 SGG_F32, SGG_BF16, SGG_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 5
 
 _P, _I, _F, _L = c_void_p, c_int, c_float, c_int64
 
@@ -71,7 +71,8 @@ SIGNATURES = {
     'sgg_det_output': [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     'sgg_dropout_fwd': [_P, _L, _F, ctypes.c_uint64, _I, _P],
     'sgg_act_bwd': [_P, _P, _P, _L, _F, _I, _I, _P],
-    'sgg_ce_fwd_bwd': [_P, _I, _P, _I, _I, _I, _P, _F, _F, _P, _I, _P, _I, _P, _P, _I, _P],
+    'sgg_ce_fwd_bwd': [_P, _I, _P, _I, _I, _I, _P, _F, _F, _P, _I, _P, _I, _P, _P, _I, _I, _F, _F, _P],
+    'sgg_label_counts': [_P, _I, _I, _P, _I, _P],
     'sgg_colsum': [_P, _I, _I, _I, _P, _P, _I, _P],
     'sgg_bn_stats': [_P, _I, _I, _P, _P, _I, _P],
     'sgg_bn_finalize': [_P, _I, _I, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],
@@ -84,7 +85,7 @@ SIGNATURES = {
     'sgg_freq_bias_bwd': [_P, _P, _I, _I, _P, _P],
     'sgg_gemm_tn': [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     'sgg_sqnorm_multi': [_P, _P, _I, _P, _P, _I, _I, _P],
-    'sgg_sgd_multi': [_P, _P, _P, _P, _P, _P, _I, _F, _F, _I, _P, _F, _F, _I, _I, _I, _P],
+    'sgg_sgd_multi': [_P, _P, _P, _P, _P, _P, _I, _F, _F, _I, _P, _F, _F, _I, _I, _I, _P, _P],
     'sgg_transpose': [_P, _L, _P, _L, _I, _I, _P, _L, _I, _P, _P, _I, _I, _P],
     'sgg_group_sum': [_P, _L, _P, _L, _I, _I, _I, _I, _P],
     'sgg_pair_slots': [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
@@ -119,12 +120,15 @@ def load():
         raise ImportError('sgg_amd: %s not found -- the HIP extension is mandatory (no CPU fallback). '
                           'Build it: make -C sgg_amd/csrc' % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
+    # the version first: a stale build must fail here, before a call with shifted arguments can reach the device
+    lib.sgg_abi_version.argtypes, lib.sgg_abi_version.restype = [], c_int
+    if lib.sgg_abi_version() != ABI_VERSION:
+        raise ImportError('sgg_amd: %s has ABI version %d, this package binds version %d: rebuild (make -C sgg_amd/csrc)'
+                          % (LIB_PATH, lib.sgg_abi_version(), ABI_VERSION))
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, c_int)
-    if lib.sgg_abi_version() != ABI_VERSION:
-        raise ImportError('sgg_amd: ABI version mismatch (%d != %d): rebuild' % (lib.sgg_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -719,10 +719,14 @@ __global__ __launch_bounds__(256) void sqnorm_multi_kernel(const MultiTab tab, f
 
 template <typename TG, typename TS>
 __global__ __launch_bounds__(256) void sgd_multi_kernel(const MultiTab tab, float wd, float mom, int first,
-                                                        const float* __restrict__ norm_sq, float max_norm, float grad_scale) {
+                                                        const float* __restrict__ norm_sq, float max_norm, float grad_scale,
+                                                        int* __restrict__ skipped) {
     float coef = grad_scale;
     if (norm_sq) {
-        if (!(*norm_sq < 3.0e38f)) return;      // non-finite gradients (an overflowed scaled gradient of the f16 mode, a NaN): skip the step
+        if (!(*norm_sq < 3.0e38f)) {            // non-finite gradients (an overflowed scaled gradient of the f16 mode, a NaN): skip the step
+            if (skipped && blockIdx.x == 0 && threadIdx.x == 0) skipped[0] += 1;   // ... and say so (one launch per step is handed the counter)
+            return;
+        }
         const float c = max_norm / (sqrtf(*norm_sq) * grad_scale + 1e-6f);
         if (c < 1.f) coef *= c;
     }
@@ -829,7 +833,8 @@ __global__ __launch_bounds__(256) void rank4_finalize_kernel(const float* __rest
 template <typename TG>
 __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels,
                                                          int label_stride, int M, int C, const float* __restrict__ norm, float weight, float grad_scale,
-                                                         float* __restrict__ part, TG* __restrict__ grad, int ldg, int* __restrict__ flag) {
+                                                         float* __restrict__ part, TG* __restrict__ grad, int ldg, int* __restrict__ flag,
+                                                         int mode, float alpha, float beta) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     __shared__ float ws4[4];
     float mine = 0.f;
@@ -844,7 +849,16 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict
         const long lab_raw = labels[(long)row * label_stride];
         const bool ok = lab_raw >= 0 && lab_raw < C;
         const int lab = ok ? (int)lab_raw : 0;
-        const float scale = ok ? weight / norm[0] : 0.f;
+        float scale = 0.f;
+        if (ok && mode == 0) scale = weight / norm[0];                       // lib/losses.py:41-43: every row 1 / M
+        else if (ok) {                                                       // :44-63: density-normalised edge weights, counts on the device
+            const float mfg = norm[0], mbg = norm[1];
+            float w = 1.f;                                                   // edge_weights = ones(M)
+            if (lab_raw > 0) { if (mfg > 0.f) w = alpha / mfg; }             // :50-51
+            else if (mode == 1) { if (mbg > 0.f && mfg > 0.f) w = beta / mfg; }   // :56-57  'dnorm'
+            else { if (mbg > 0.f) w = beta / mbg; }                          // :59-60  'dnorm-fgbg'
+            scale = weight * w;
+        }
         const float lse = mx + __logf(se);
         if (lane == 0) mine = ok ? (lse - x[lab]) * scale : 0.f;
         if (!ok && lane == 0 && flag) atomicOr(flag, 1);
@@ -859,6 +873,28 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = (ws4[0] + ws4[1]) + (ws4[2] + ws4[3]);
 }
+
+// counts[0] (+)= #{labels > 0}, counts[1] (+)= #{labels == 0}: M_FG / M_BG of lib/losses.py:29-34 as device numbers (integers in f32:
+// exact below 2^24 rows).  One workgroup: the rows of a batch are a few thousand.
+__global__ __launch_bounds__(1024) void label_counts_kernel(const int64_t* __restrict__ labels, int label_stride, int M,
+                                                            float* __restrict__ counts, int accumulate) {
+    __shared__ int sfg[16], sbg[16];
+    int fg = 0, bg = 0;
+    for (int r = threadIdx.x; r < M; r += 1024) {
+        const long l = labels[(long)r * label_stride];
+        fg += l > 0;
+        bg += l == 0;
+    }
+    for (int o = 32; o; o >>= 1) { fg += __shfl_xor(fg, o); bg += __shfl_xor(bg, o); }
+    if ((threadIdx.x & 63) == 0) { sfg[threadIdx.x >> 6] = fg; sbg[threadIdx.x >> 6] = bg; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0, b = 0;
+        for (int i = 0; i < 16; ++i) { a += sfg[i]; b += sbg[i]; }
+        counts[0] = (accumulate ? counts[0] : 0.f) + (float)a;
+        counts[1] = (accumulate ? counts[1] : 0.f) + (float)b;
+    }
+}
 }  // namespace
 
 // Workspaces: every reduction below is two-stage -- row blocks write partial rows into `ws`, a second launch adds them in a fixed order
@@ -866,9 +902,17 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict
 
 // loss[0] += weight / norm[0] * sum_rows CE(logits[row], labels[row * label_stride]);  grad[M, ldg] = grad_scale * d loss / d logits
 // (zero-padded).  ws: f32[(M + 3) / 4].  flag (optional): bit 0 raised when a label lies outside [0, C) (that row: no loss, zero gradient).
+extern "C" int sgg_label_counts(const int64_t* labels, int label_stride, int M, float* counts, int accumulate, void* stream) {
+    if (!counts || M < 0 || (M > 0 && !labels) || label_stride <= 0 || M >= (1 << 24)) return SGG_ERR_ARG;
+    hipLaunchKernelGGL(label_counts_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, labels, label_stride, M, counts, accumulate);
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
 extern "C" int sgg_ce_fwd_bwd(const float* logits, int ld, const int64_t* labels, int label_stride, int M, int C, const float* norm,
                               float weight, float grad_scale, float* loss, int accumulate, void* grad, int ldg, float* ws, int* flag, int g_dtype,
-                              void* stream) {
+                              int mode, float alpha, float beta, void* stream) {
+    if (mode < 0 || mode > 2) return SGG_ERR_ARG;
     if (M == 0) {
         if (!accumulate && loss) {          // no rows: the loss is 0
             hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss, 0, loss, 0);
@@ -880,7 +924,7 @@ extern "C" int sgg_ce_fwd_bwd(const float* logits, int ld, const int64_t* labels
     const dim3 grid((M + 3) / 4), blk(256);
     hipStream_t s = (hipStream_t)stream;
     SGG_FOR_DTYPE(g_dtype, hipLaunchKernelGGL(ce_fwd_bwd_kernel<T>, grid, blk, 0, s, logits, ld, labels, label_stride, M, C, norm, weight, grad_scale,
-                                              ws, (T*)grad, ldg, flag));
+                                              ws, (T*)grad, ldg, flag, mode, alpha, beta));
     SGG_CHECK_LAUNCH();
     hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(256), 0, s, ws, (int)grid.x, loss, accumulate);
     SGG_CHECK_LAUNCH();
@@ -1164,7 +1208,7 @@ extern "C" int sgg_sqnorm_multi(const void* const* g, const int64_t* n, int coun
 extern "C" int sgg_sgd_multi(float* const* p, const void* const* g, float* const* momentum_buf, void* const* shadow,
                              const int64_t* n, const float* lr, int count, float weight_decay, float momentum,
                              int first_step, const float* norm_sq, float max_norm, float grad_scale, int g_dtype, int shadow_dtype,
-                             int max_blocks, void* stream) {
+                             int max_blocks, int* skipped, void* stream) {
     if (count == 0) return SGG_OK;
     if (!p || !g || !momentum_buf || !n || !lr || count < 0) return SGG_ERR_ARG;
     if (shadow_dtype != SGG_BF16 && shadow_dtype != SGG_F16) return SGG_ERR_DTYPE;
@@ -1186,10 +1230,10 @@ extern "C" int sgg_sgd_multi(float* const* p, const void* const* g, float* const
         const dim3 grid((unsigned)min(chunks, max_blocks > 0 ? max_blocks : 512));
         if (shadow_dtype == SGG_BF16) {
             SGG_FOR_DTYPE(g_dtype, hipLaunchKernelGGL((sgd_multi_kernel<T, bf16_t>), grid, dim3(256), 0, s, tab, weight_decay, momentum, first_step, norm_sq,
-                                                      max_norm, grad_scale));
+                                                      max_norm, grad_scale, lo == 0 ? skipped : (int*)nullptr));
         } else {
             SGG_FOR_DTYPE(g_dtype, hipLaunchKernelGGL((sgd_multi_kernel<T, f16_t>), grid, dim3(256), 0, s, tab, weight_decay, momentum, first_step, norm_sq,
-                                                      max_norm, grad_scale));
+                                                      max_norm, grad_scale, lo == 0 ? skipped : (int*)nullptr));
         }
         SGG_CHECK_LAUNCH();
     }

@@ -441,7 +441,11 @@ def gan_train_step(sgg_model, gan, res, gt_boxes, gt_objects, gt_rels, optimizer
             losses_G['rec'] = rec                                    # node + edge reconstruction losses (main.py:163-170), summed
         if losses_G:
             total = sum(losses_G.values())
-            (total * scale if scale != 1.0 else total).backward()
+            sgg_model._loss_scaled = trainer is not None
+            try:
+                (total * scale if scale != 1.0 else total).backward()
+            finally:
+                sgg_model._loss_scaled = False
             if 'rec' in ganlosses:
                 if trainer is not None:
                     trainer.update()                                 # reduce over ranks + clip + SGD (sharded / fused), unscales
@@ -451,7 +455,14 @@ def gan_train_step(sgg_model, gan, res, gt_boxes, gt_objects, gt_rels, optimizer
                         torch.nn.utils.clip_grad_norm_([p for p in sgg_model.parameters() if p.grad is not None], clip)
                     optimizer.step()
             allreduce_grads_(G_params, 1.0 / scale)
-            G_optimizer.step()
+            # a scaled f16 backward that overflowed: the SGG update above was skipped by its norm check; the generator's optimiser has no
+            # such guard, so an inf / NaN gradient would go into G's weights (and Adam's moments) for good -- skip its step too
+            g_ok = True
+            if scale != 1.0:
+                gs = [p.grad for p in G_params if p.grad is not None]
+                g_ok = bool(torch.stack([g.isfinite().all() for g in gs]).all()) if gs else True
+            if g_ok:
+                G_optimizer.step()
             losses.update(losses_G)
         # ---- discriminators (main.py:178-191)
         D_optimizer.zero_grad()

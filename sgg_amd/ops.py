@@ -575,17 +575,33 @@ def act_bwd(dy, y, scale=1.0):
     return dx
 
 
-def ce_fwd_bwd(logits, labels, norm, weight, loss, grad, grad_scale=1.0, flag=None, accumulate=True):
+CE_MODES = {'baseline': 0, 'dnorm': 1, 'dnorm-fgbg': 2}
+
+
+def ce_fwd_bwd(logits, labels, norm, weight, loss, grad, grad_scale=1.0, flag=None, accumulate=True, mode='baseline', alpha=1.0, beta=1.0):
     """loss[0] += (accumulate=False: =) weight / norm[0] * sum CE(logits, labels); grad [M, ldg] (16-bit / f32, zero-padded columns) = grad_scale * d loss / d logits.
     logits f32 [M,C]; labels i64, any 1-D view (e.g. a column of rel_labels); norm, loss: f32 device scalars; flag (optional i32[1]):
-    bit 0 is raised when a label lies outside [0, C) (that row adds no loss and gets a zero gradient)."""
+    bit 0 is raised when a label lies outside [0, C) (that row adds no loss and gets a zero gradient).
+    mode 'dnorm' / 'dnorm-fgbg' (lib/losses.py:44-63): norm = f32[2] (M_FG, M_BG) on the device (label_counts), rows weighted per the
+    reference's edge_weights with alpha / beta; `weight` is gamma."""
     M, C = logits.shape
     assert logits.dtype == torch.float32 and logits.stride(1) == 1 and labels.dtype == torch.int64 and labels.dim() == 1
     assert grad.shape[0] == M and grad.shape[1] >= C and grad.stride(1) == 1
+    assert norm.dtype == torch.float32 and norm.numel() >= (1 if mode == 'baseline' else 2)
     ws = _ws((M + 3) // 4, logits.device)
     _lib.call('sgg_ce_fwd_bwd', logits.data_ptr(), logits.stride(0), labels.data_ptr(), labels.stride(0), M, C, norm.data_ptr(),
               float(weight), float(grad_scale), loss.data_ptr(), int(bool(accumulate)), grad.data_ptr(), grad.stride(0), _p(ws), _p(flag, torch.int32) if flag is not None else None,
-              dt(grad), _stream())
+              dt(grad), CE_MODES[mode], float(alpha), float(beta), _stream())
+
+
+def label_counts(labels, out=None, accumulate=False):
+    """f32[2] = (#labels > 0, #labels == 0) on the device: M_FG, M_BG of lib/losses.py:29-34 without a host round trip"""
+    assert labels.dtype == torch.int64 and labels.dim() == 1
+    if out is None:
+        out = torch.empty(2, dtype=torch.float32, device=labels.device)
+    _lib.call('sgg_label_counts', labels.data_ptr() if labels.numel() else None, max(labels.stride(0), 1), labels.shape[0], _p(out),
+              int(bool(accumulate)), _stream())
+    return out
 
 
 def colsum(x, pool=None):

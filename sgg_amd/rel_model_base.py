@@ -221,7 +221,7 @@ class RelModelBase(nn.Module):
             ratios.append((s, e, float(nw) / float(w), float(nh) / float(h)))
         gt_boxes = gt_boxes.float()
         if all(r[2] == 1.0 and r[3] == 1.0 for r in ratios):
-            priors = gt_boxes                                    # nothing resized: the same tensor (nothing downstream writes into it)
+            priors = gt_boxes.clone()                            # rel_model_base.py:197: a copy -- a consumer that rescales result.rm_box_priors in place must not edit the batch's gt_boxes
         else:
             scale = torch.ones((gt_boxes.shape[0], 4), dtype=torch.float32)
             for s, e, rw, rh in ratios:

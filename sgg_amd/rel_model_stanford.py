@@ -271,6 +271,7 @@ class RelModelStanford(RelModelBase):
             result.node_feat, result.edge_feat = self.node_edge_features(
                 result.fmap, rois, rel_inds[:, 1:], im_sizes=result.im_sizes, _pairing=pairing)   # :148
         csr = None
+        fresh_tables = cached is None
         if ckey is not None:
             if cached is None:
                 if len(self._graph_cache) > 32:
@@ -290,8 +291,12 @@ class RelModelStanford(RelModelBase):
                 gt_classes=gt_classes[:, 1].contiguous() if self.mode == 'predcls' else None, replace=self.test_bias)
         if self.training:
             result.rois = rois
-            if pairing is not None:
-                self._watch_pair_flag(pairing.flag)
+            if pairing is not None and (ckey is None or fresh_tables):
+                self._watch_pair_flag(pairing.flag)        # (a cache hit re-reads tables whose flag was looked at when they were built)
+            if ckey is not None:
+                # the cached index tensors serve every later batch of this box-count signature: hand out a copy, so that reference-style
+                # consumer code which edits result.rel_inds in place (index offsets, ...) cannot corrupt them
+                result.rel_inds = rel_inds.clone()
             return result                                                                # :179-181
         if self.mode == 'predcls':
             gt = gt_classes[:, 1].contiguous()                                           # :184-185

@@ -286,6 +286,13 @@ class PredictFn(torch.autograd.Function):
         model, sv = ctx.model, ctx.sv
         w = train_weights(model)
         t, imp, dt = w['train'], w['imp'], model.compute_dtype
+        if dt == torch.float16 and not getattr(model, '_loss_scaled', False) and not getattr(model, '_warned_f16_backward', False):
+            # f16 activation gradients have five exponent bits: the Trainer scales the loss (and un-scales in the optimiser); a plain
+            # `loss.backward(); optimizer.step()` loop does not -- small gradients flush to zero without any error
+            import warnings
+            warnings.warn('sgg_amd: f16 backward outside sgg_amd.trainer.Trainer -- no loss scale is applied; scale the loss yourself and set '
+                          'model._loss_scaled = True, or train with set_compute_dtype(torch.bfloat16)', RuntimeWarning)
+            model._warned_f16_backward = True
         N, E, H, T = sv['N'], sv['E'], sv['H'], model.mp_iter
         XN, XH, HN, HE = sv['XN'], sv['XH'], sv['HN'], sv['HE']
         csr = sv['csr']

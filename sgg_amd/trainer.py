@@ -42,6 +42,7 @@ class FusedSGD(torch.optim.Optimizer):
         self.on_update = None
         self.max_blocks = 0        # workgroups of the update kernel (0: library default); the pipelined trainer lowers it
         self.shadow_of = None      # callable -> {param name: compute-dtype buffer the update should also write}
+        self.skipped = None        # i32[1] on the device: steps the kernels skipped because the gradient norm was not finite
         self.wrote_shadow = []
 
     def params(self):
@@ -64,6 +65,7 @@ class FusedSGD(torch.optim.Optimizer):
         if self._norm is None:
             self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
             self._norm_ws = torch.empty(2048, dtype=torch.float32, device=dev)      # partial sums of sgg_sqnorm_multi (fixed-order reduction)
+            self.skipped = torch.zeros(1, dtype=torch.int32, device=dev)
         norm_started = False                                    # the first sgg_sqnorm_multi of the step overwrites the accumulator
         grads = grads or {}
         shards = {p: r for p, r in (shards or {}).items() if r is not None}
@@ -84,11 +86,13 @@ class FusedSGD(torch.optim.Optimizer):
             return None
         # torch's first step sets buf = d_p; a zero buffer gives the same number (mom * 0 + d_p), so parameters that meet their
         # first gradient later -- or after a partial load_state_dict -- simply start from zeros
-        first = all('momentum_buffer' not in self.state[p] for p, _, _ in live)
+        # (always zeros, never `empty` + a "first step" kernel flag: a first step that the kernels SKIP -- f16 overflow at the loss scale, a
+        # NaN batch -- would otherwise leave the buffer uninitialised for the second step's mom * buf + g)
+        first = False
         for p, _, _ in live:
             st = self.state[p]
             if st.get('momentum_buffer') is None:
-                st['momentum_buffer'] = torch.empty_like(p, dtype=torch.float32) if first else torch.zeros_like(p, dtype=torch.float32)
+                st['momentum_buffer'] = torch.zeros_like(p, dtype=torch.float32)
         shadows = self.shadow_of() if self.shadow_of is not None else {}
         norm = self._norm.data_ptr() if self.clip and self.clip > 0 else None
         for p, gr, _ in live:
@@ -131,10 +135,11 @@ class FusedSGD(torch.optim.Optimizer):
             self._norm.copy_((pair[0] + pair[1]).view(1))
             if self._norm_parts is not None:
                 self._norm_parts.zero_()
-        for dtype, gp, pp, bp, sp, nn, lr, cnt, _keep in pending:  # every norm contribution lands before the first update
+        for k, (dtype, gp, pp, bp, sp, nn, lr, cnt, _keep) in enumerate(pending):  # every norm contribution lands before the first update
             _lib.call('sgg_sgd_multi', pp.ctypes.data, gp.ctypes.data, bp.ctypes.data, sp.ctypes.data, nn.ctypes.data,
                       lr.ctypes.data, cnt, float(wd), float(mom), int(first), norm,
-                      float(self.clip or 0.0), float(grad_scale), ops.dt(dtype), self._shadow_dt(shadows), int(self.max_blocks), stream)
+                      float(self.clip or 0.0), float(grad_scale), ops.dt(dtype), self._shadow_dt(shadows), int(self.max_blocks),
+                      self.skipped.data_ptr() if k == 0 else None, stream)
         if shards:                                              # every rank gets every part of the updated operands
             import torch.distributed as dist
             for p, _, _ in live:
@@ -332,50 +337,65 @@ class Trainer(object):
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
                 return obj_ce / t[0] + gamma * rel_ce.sum() / t[1]
             return obj_ce / n_obj + gamma * rel_ce.sum() / M                         # lib/losses.py:41-43,74
-        fg = labels > 0
-        m_fg, m_bg = float(fg.sum().item()), float((~fg).sum().item())
-        if self.world > 1:
-            n_obj, m_fg, m_bg = sum_over_ranks([n_obj, m_fg, m_bg], device=res.rel_dists.device)
-        w = torch.ones_like(rel_ce)
-        if m_fg > 0:
-            w[fg] = alpha / m_fg                                                      # :50-51
-        if self.loss_type == 'dnorm':
-            if m_bg > 0 and m_fg > 0:
-                w[~fg] = beta / m_fg                                                  # :56-57
-        elif self.loss_type == 'dnorm-fgbg':
-            if m_bg > 0:
-                w[~fg] = beta / m_bg                                                  # :59-60
-        else:
+        if self.loss_type not in ('dnorm', 'dnorm-fgbg'):
             raise NotImplementedError(self.loss_type)
-        return obj_ce / n_obj + (gamma * rel_ce * w).sum()                            # :62-63
+        # density-normalised forms (lib/losses.py:44-63): M_FG / M_BG stay ON THE DEVICE -- counted, summed over the ranks and turned into
+        # the row weights there (the reference's len(idx_fg) is a host number; a .item() here would stall the host between forward and
+        # backward on every step).  The reference's "stay 1" branches (M_FG == 0, M_BG == 0) are torch.where selections.
+        fg = labels > 0
+        cnt = torch.stack((fg.sum(), (labels == 0).sum())).to(torch.float32)
+        if self.dist_on:
+            t = torch.cat((cnt.new_full((1,), n_obj), cnt))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            n_obj, cnt = t[0], t[1:]
+        m_fg, m_bg = cnt[0], cnt[1]
+        one = torch.ones((), dtype=rel_ce.dtype, device=rel_ce.device)
+        w_fg = torch.where(m_fg > 0, alpha / m_fg.clamp(min=1), one)                  # :50-51
+        if self.loss_type == 'dnorm':
+            w_bg = torch.where((m_bg > 0) & (m_fg > 0), beta / m_fg.clamp(min=1), one)    # :56-57
+        else:
+            w_bg = torch.where(m_bg > 0, beta / m_bg.clamp(min=1), one)               # :59-60
+        return obj_ce / n_obj + (gamma * rel_ce * torch.where(fg, w_fg, w_bg)).sum()  # :62-63
 
     def _fused_losses(self, res):
-        """'baseline' losses and their logit gradients in two launches (sgg_ce_fwd_bwd) instead of torch's ~25: returns the loss
-        (device scalar, no autograd graph) after leaving the zero-padded compute-dtype gradients where PredictFn.backward
-        picks them up (model._logit_grads).  Same numbers as losses() + autograd: sum CE / global normaliser."""
+        """All three loss forms of lib/losses.py and their logit gradients in two launches (sgg_ce_fwd_bwd; + one counting launch for the
+        density-normalised forms) instead of torch's ~25: returns the loss (device scalar, no autograd graph) after leaving the zero-padded
+        compute-dtype gradients where PredictFn.backward picks them up (model._logit_grads).  Same numbers as losses() + autograd: sum CE /
+        global normaliser.  Nothing here reads a device value on the host: M_FG / M_BG of 'dnorm' / 'dnorm-fgbg' are counted by
+        sgg_label_counts, all-reduced as a device tensor and applied per row inside the kernel."""
         m = self.model
         dev = res.rel_dists.device
         N, E = res.rm_obj_dists.shape[0], res.rel_dists.shape[0]
-        key = (N, E)
+        alpha, beta, gamma = self.loss_weights
+        dnorm = self.loss_type != 'baseline'
+        if not dnorm:
+            assert alpha == beta == 1, ('wrong loss is used, use dnorm or dnorm-fgbg', alpha, beta)      # lib/losses.py:41
+        labels = res.rel_labels[:, -1]
         if self.dist_on:
-            norm = torch.empty(2, dtype=torch.float32, device=dev)
+            norm = torch.empty(3, dtype=torch.float32, device=dev)       # [N | E] or [N | M_FG | M_BG], summed over the ranks
             norm[0].fill_(float(N))
-            norm[1].fill_(float(E))
+            if dnorm:
+                ops.label_counts(labels, norm[1:3])
+            else:
+                norm[1].fill_(float(E))
             dist.all_reduce(norm, op=dist.ReduceOp.SUM)
+        elif dnorm:
+            norm = torch.empty(3, dtype=torch.float32, device=dev)
+            norm[0].fill_(float(N))
+            ops.label_counts(labels, norm[1:3])
         else:
-            norm = self._norm_cache.get(key)
+            norm = self._norm_cache.get((N, E))
             if norm is None:
-                norm = self._norm_cache[key] = torch.tensor([float(N), float(E)], dtype=torch.float32, device=dev)
+                norm = self._norm_cache[(N, E)] = torch.tensor([float(N), float(E), 0.0], dtype=torch.float32, device=dev)
         dt_ = m.compute_dtype
         loss = torch.empty(1, dtype=torch.float32, device=dev)          # written by the first head's call, added to by the second
         d_obj = torch.empty((N, 256), dtype=dt_, device=dev)           # 151 -> 256, 51 -> 128: what the TN weight-gradient kernel takes
         d_rel = torch.empty((E, 128), dtype=dt_, device=dev)
-        alpha, beta, gamma = self.loss_weights
-        assert alpha == beta == 1, ('wrong loss is used, use dnorm or dnorm-fgbg', alpha, beta)          # lib/losses.py:41
         if getattr(self, '_label_flag', None) is None:
             self._label_flag = torch.zeros(1, dtype=torch.int32, device=dev)
         ops.ce_fwd_bwd(res.rm_obj_dists.detach(), res.rm_obj_labels, norm[0:1], 1.0, loss, d_obj, self.loss_scale, self._label_flag, accumulate=False)
-        ops.ce_fwd_bwd(res.rel_dists.detach(), res.rel_labels[:, -1], norm[1:2], gamma, loss, d_rel, self.loss_scale, self._label_flag)
+        ops.ce_fwd_bwd(res.rel_dists.detach(), labels, norm[1:3], gamma, loss, d_rel, self.loss_scale, self._label_flag,
+                       mode=self.loss_type, alpha=alpha, beta=beta)
         m._logit_grads = (d_obj, d_rel)
         return loss[0]
 
@@ -411,6 +431,20 @@ class Trainer(object):
             self.model.union_boxes.flush_batch_counts()
         if hasattr(self.model, 'check_pair_flag'):
             self.model.check_pair_flag(wait=True)     # the last steps' pair-table flags (rel_model_stanford._watch_pair_flag)
+        if self.opt.skipped is not None and self.loss_scale != 1.0:
+            # f16: steps whose scaled gradients overflowed were skipped by the update kernels (counted on the device).  A static scale that
+            # overflows on EVERY step would otherwise skip silently while `steps` and the LR schedule advance: halve it and say so.
+            n_skipped, n_steps = int(self.opt.skipped.item()), self.opt.steps - getattr(self, '_steps_at_flush', 0)
+            self.skipped_steps = getattr(self, 'skipped_steps', 0) + n_skipped
+            self._steps_at_flush = self.opt.steps
+            self.opt.skipped.zero_()
+            if n_skipped:
+                import warnings
+                msg = 'sgg_amd: %d of the last %d train steps were skipped (non-finite gradients at loss scale %g)' % (n_skipped, n_steps, self.loss_scale_f16)
+                if n_steps > 0 and 2 * n_skipped >= n_steps and self.loss_scale_f16 > 1.0:
+                    self.loss_scale_f16 = max(1.0, self.loss_scale_f16 / 2.0)
+                    msg += '; loss scale lowered to %g' % self.loss_scale_f16
+                warnings.warn(msg, RuntimeWarning)
         flag = getattr(self, '_label_flag', None)
         if flag is not None and int(flag.item()) != 0:
             flag.zero_()
@@ -461,13 +495,14 @@ class Trainer(object):
         if not self.dist_on:
             self._local = {}
         res = self.model([batch])
-        # the fused loss covers what the benchmark runs: 'baseline' CE, bf16 compute, logits straight out of predict()
-        fused = (self.fused_loss and self.loss_type == 'baseline' and ops.is_half(self.model.compute_dtype) and
+        # the fused loss covers the three loss forms of lib/losses.py in the 16-bit modes, logits straight out of predict()
+        fused = (self.fused_loss and self.loss_type in ops.CE_MODES and ops.is_half(self.model.compute_dtype) and
                  not getattr(self.model, 'use_bias', False) and res.rm_obj_dists.shape[1] <= 256 and res.rel_dists.shape[1] <= 128)
         loss = self._fused_losses(res) if fused else self.losses(res)
         self.opt.zero_grad()
         if local:
             self.model._grad_ready_hook, self.model._grad_wire_dtype = self._keep, self._local_wire
+        self.model._loss_scaled = True          # this backward carries the f16 loss scale (train.py warns about one that does not)
         try:
             if fused:
                 # the real gradients wait in model._logit_grads; autograd only needs placeholders of the outputs' shape (no launch)
@@ -477,6 +512,7 @@ class Trainer(object):
                 (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
         finally:
             self.model._logit_grads = None
+            self.model._loss_scaled = False
             if local:
                 self.model._grad_ready_hook = self.model._grad_wire_dtype = None
         self._queued = self.pipeline and self._queue_update()

@@ -118,3 +118,61 @@ def test_blob_tuple_layout_matches_reference_contract():
         Blob(num_gpus=2)
     with pytest.raises(ValueError):
         blob[1]
+
+
+def test_abi_version_is_bumped_with_the_prototypes():
+    """ADVICE r3 / VERDICT r3 item 12: a prototype change must come with a new SGG_ABI_VERSION, otherwise a stale
+    libsgg_hip.so passes load()'s check and is called with shifted arguments.  tests/abi.lock (written by
+    tools/abi_lock.py, which never re-points a recorded version) pins version -> digest of all prototypes."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import abi_lock
+    from sgg_amd import _lib
+    lock = json.load(open(os.path.join(ROOT, 'tests', 'abi.lock')))
+    v = abi_lock.header_version()
+    assert v == _lib.ABI_VERSION == _lib.load().sgg_abi_version()
+    assert lock.get(str(v)) == abi_lock.digest(), \
+        'prototypes of include/sgg_hip.h changed: bump SGG_ABI_VERSION (header + _lib.py), then run tools/abi_lock.py'
+    assert v == max(int(k) for k in lock)
+
+
+def test_stale_library_version_is_refused(monkeypatch):
+    from sgg_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'ABI_VERSION', _lib.ABI_VERSION + 1)
+    with pytest.raises(ImportError, match='ABI version'):
+        _lib.load()
+
+
+def test_integration_md_stubs_match_the_bound_signatures():
+    """Every python code block of INTEGRATION.md that binds or calls a C symbol does so with the header's argument
+    list: `lib.<sym>.argtypes = [...]` equals _lib.SIGNATURES[sym], `lib.<sym>(...)` passes that many arguments."""
+    import ast
+    import ctypes
+    from sgg_amd import _lib
+    md = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    blocks = re.findall(r'```python\n(.*?)```', md, flags=re.S)
+    assert blocks
+    bound, called = set(), set()
+    for src in blocks:
+        try:
+            tree = ast.parse(src)
+        except SyntaxError:                    # prose-like excerpts ("..." lines) bind nothing
+            tree = ast.parse(src.replace('\n...\n', '\n'))
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Attribute) \
+                    and node.targets[0].attr == 'argtypes' and isinstance(node.targets[0].value, ast.Attribute):
+                sym = node.targets[0].value.attr
+                got = eval(compile(ast.Expression(node.value), 'INTEGRATION.md', 'eval'), {'ctypes': ctypes})
+                assert got == _lib.SIGNATURES[sym], (sym, got, _lib.SIGNATURES[sym])
+                bound.add(sym)
+            if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr.startswith('sgg_') \
+                    and node.func.attr in _lib.SIGNATURES:
+                assert len(node.args) == len(_lib.SIGNATURES[node.func.attr]), \
+                    (node.func.attr, len(node.args), len(_lib.SIGNATURES[node.func.attr]))
+                called.add(node.func.attr)
+            if isinstance(node, ast.Compare) and isinstance(node.left, ast.Call) \
+                    and getattr(node.left.func, 'attr', '') == 'sgg_abi_version':
+                assert node.comparators[0].value == _lib.ABI_VERSION
+    assert 'sgg_union_rects_fwd' in bound and 'sgg_union_rects_fwd' in called

@@ -302,3 +302,16 @@ def test_sharded_grad_buckets_world_size_8():
     assert [r for r, _, _ in out] == list(range(8)) and all(ok for _, ok, _ in out)
     for _, _, ps in out[1:]:
         assert ps == out[0][2]
+
+
+def test_trainer_losses_never_read_device_values_on_the_host():
+    """no `.item()` / `.tolist()` / float(tensor) between forward and backward -- the normalisers of all three loss
+    forms stay device tensors (the world-size-2 test above checks their values, incl. M_FG = 0 on one rank)."""
+    import inspect
+    import re
+    from sgg_amd.trainer import Trainer
+    for fn in (Trainer.losses, Trainer._fused_losses):
+        src = re.sub(r'""".*?"""', '', inspect.getsource(fn), flags=re.S)
+        src = '\n'.join(l.split('#')[0] for l in src.splitlines())
+        for needle in ('.item()', '.tolist()', '.cpu()', 'sum_over_ranks', 'synchronize'):
+            assert needle not in src, (fn.__name__, needle)

@@ -64,7 +64,9 @@ def test_f16_gradients_vs_oracle_autograd(env):
     scale = 1024.0
     loss = ((res.rm_obj_dists * Wo.to(DEV)).sum() + (res.rel_dists * Wr.to(DEV)).sum()) * scale
     model.zero_grad()
+    model._loss_scaled = True            # this test scales the loss itself
     loss.backward()
+    model._loss_scaled = False
     pn = set(param_names(model))
     p = {k: v.clone().requires_grad_(k in pn) for k, v in sd.items()}
     od, rd = O.predict(res.node_feat.float().cpu().contiguous(), res.edge_feat.float().cpu().contiguous(), res.rel_inds.cpu().numpy(),
@@ -203,3 +205,56 @@ def test_second_stream_work_changes_no_bit(monkeypatch):
         assert torch.equal(s1[n], s0[n]), n
     for n in m1:
         assert torch.equal(m1[n], m0[n]), n
+
+
+def test_first_step_overflow_leaves_no_uninitialised_momentum(env):
+    """when the FIRST step of a run is skipped by the non-finite-norm guard the momentum buffers must still be defined
+    (zeros), otherwise step 2 computes mom * garbage + g.  Run: overflowing step 0, then good steps == a run without the bad step."""
+    from sgg_amd.rel_model_base import to_device_with_mirror
+    from sgg_amd.trainer import Trainer
+    model, sd, batch = env
+    model.set_compute_dtype(torch.float16)
+    model.dropout_p = 0.0
+    b = list(batch)
+    b[0] = [im.to(DEV) for im in b[0]]
+    b[3], b[4], b[5] = b[3].to(DEV), to_device_with_mirror(b[4], DEV), to_device_with_mirror(b[5], DEV)
+    out = {}
+    for bad_first in (True, False):
+        model.load_state_dict(sd)
+        tr = Trainer(model, lr=2e-2)
+        if bad_first:
+            # poison the caching allocator's free blocks: a buffer taken with `empty` would now hold NaNs
+            junk = [torch.full((1 << 22,), float('nan'), device=DEV) for _ in range(8)]
+            del junk
+            tr.loss_scale_f16 = 1e9
+            tr.step(tuple(b))
+            tr.flush()
+            assert not np.isfinite(tr.opt.grad_norm())
+            for p in tr.opt.params():
+                buf = tr.opt.state[p].get('momentum_buffer')
+                assert buf is not None and float(buf.abs().max()) == 0.0
+            tr.loss_scale_f16 = 1024.0
+        for _ in range(3):
+            tr.step(tuple(b))
+        tr.flush()
+        out[bad_first] = {n: p.detach().clone() for n, p in model.named_parameters() if not n.startswith('detector.')}
+    for n in out[True]:
+        assert torch.isfinite(out[True][n]).all(), n
+        assert torch.equal(out[True][n], out[False][n]), n
+    model.eval()
+    model.dropout_p = 0.5
+
+
+def test_f16_backward_outside_the_trainer_warns(env):
+    """the default compute type is f16 but the loss scale lives in the Trainer -- a reference-style loop
+    (loss.backward(); optimizer.step()) must not run an unscaled f16 backward silently."""
+    model, sd, batch = env
+    model.load_state_dict(sd)
+    model.set_compute_dtype(torch.float16)
+    model.train()
+    model._warned_f16_backward = False
+    res = model([tuple(batch)])
+    with pytest.warns(RuntimeWarning, match='no loss scale'):
+        (res.rm_obj_dists.sum() + res.rel_dists.sum()).backward()
+    model.zero_grad()
+    model.eval()

@@ -597,3 +597,61 @@ def test_fused_cross_entropy_equals_torch_losses_and_autograd(env):
         assert diff <= 0.08 * step + 1e-7, (n, float(step), float(diff))
     model.dropout_p = 0.5
     model.eval()
+
+
+@pytest.mark.parametrize('loss_type', ['dnorm', 'dnorm-fgbg'])
+def test_fused_density_normalised_cross_entropy(env, loss_type):
+    """sgg_ce_fwd_bwd with the row weights of lib/losses.py:44-63 chosen ON THE DEVICE from device-side M_FG / M_BG
+    (sgg_label_counts) -- against the reference's outputs (tests/golden/losses.npz, incl. the no-FG case), against the oracle +
+    autograd on random rows for every branch (no FG, no BG, both) with alpha / beta / gamma, then a whole Trainer step either way."""
+    from sgg_amd import ops
+    from sgg_amd.trainer import Trainer
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'losses.npz'))
+    for labels, key in ((gold['rel_labels'], 'edge_'), (np.zeros_like(gold['rel_labels']), 'edge_nofg_')):
+        logits, lab = cu(gold['rel_dists']).float(), cu(labels).long()
+        cnt = ops.label_counts(lab)
+        assert cnt.tolist() == [float((labels > 0).sum()), float((labels == 0).sum())]
+        loss = torch.zeros(1, device=DEV)
+        grad = torch.empty((logits.shape[0], 64), dtype=torch.float32, device=DEV)
+        ops.ce_fwd_bwd(logits, lab, cnt, 1.0, loss, grad, accumulate=False, mode=loss_type)
+        np.testing.assert_allclose(float(loss), float(gold[key + loss_type]), rtol=2e-6)
+    g = torch.Generator().manual_seed(11)
+    for M, C, p_fg in ((300, 51, 0.2), (64, 51, 0.0), (40, 51, 1.0), (1, 51, 1.0), (2000, 51, 0.03)):
+        logits = (torch.randn(M, C, generator=g) * 3).to(DEV)
+        lab = torch.where(torch.rand(M, generator=g) < p_fg, torch.randint(1, C, (M,), generator=g), torch.zeros(M, dtype=torch.long))
+        lab4 = torch.stack((lab * 0, lab * 0, lab * 0, lab), 1).to(DEV)          # the predicate column of rel_labels: a strided view
+        w = (0.7, 1.9, 1.3)
+        cnt = ops.label_counts(lab4[:, -1])
+        ops.label_counts(lab4[:, -1], cnt, accumulate=True)                        # two "ranks" with the same rows: counts double
+        assert cnt.tolist() == [2.0 * float((lab > 0).sum()), 2.0 * float((lab == 0).sum())]
+        cnt = ops.label_counts(lab4[:, -1])
+        for gdt in (torch.float32, torch.float16):
+            loss = torch.full((1,), 5.0, device=DEV)
+            grad = torch.full((M, 128), 7.0, dtype=gdt, device=DEV)
+            ops.ce_fwd_bwd(logits, lab4[:, -1], cnt, w[2], loss, grad, grad_scale=8.0, mode=loss_type, alpha=w[0], beta=w[1])
+            x = logits.detach().cpu().clone().requires_grad_(True)
+            ref = O.edge_losses(x, lab, loss_type, loss_weights=w)
+            ref.backward()
+            assert abs(float(loss) - 5.0 - float(ref)) <= 2e-5 * max(1.0, abs(float(ref))), (M, p_fg, float(loss) - 5.0, float(ref))
+            tol = dict(atol=1e-6, rtol=1e-5) if gdt == torch.float32 else dict(atol=2e-3, rtol=2e-3)
+            torch.testing.assert_close(grad[:, :C].float().cpu() / 8.0, x.grad, **tol)
+            assert float(grad[:, C:].float().abs().max()) == 0.0
+    model, sd, batch = env
+    model.set_compute_dtype(torch.float16)
+    model.dropout_p = 0.0
+    out = {}
+    for fused in (False, True):
+        model.load_state_dict(sd)
+        tr = Trainer(model, lr=2e-2, loss_type=loss_type, loss_weights=(1.0, 0.8, 1.5))
+        tr.fused_loss = fused
+        losses = [float(tr.step(tuple(batch))) for _ in range(2)]
+        tr.flush()
+        out[fused] = (losses, {n: p.detach().float().cpu().clone() for n, p in model.named_parameters() if not n.startswith('detector.')})
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=2e-3)
+    for n, w_ref in out[False][1].items():
+        step = (w_ref - sd[n].float()).abs().max()
+        diff = (w_ref - out[True][1][n]).abs().max()
+        assert diff <= 0.08 * step + 1e-7, (n, float(step), float(diff))
+    model.dropout_p = 0.5
+    model.eval()
+    model.set_compute_dtype(torch.float32)
