@@ -10,7 +10,12 @@
 --mode sgdet (BASELINE configs[2], not the headline): a step = the SGDet eval forward -- VGG-16, RPN over 21 660 anchors, 1 000
   proposals per image after NMS, the box head on all of them, per-class NMS, <= 50 detections, overlap-filtered pairs, union-box
   RoIAlign, IMP, tail -- with the detector's score threshold at 0 (random-init weights: every candidate enters the per-class NMS).
-One batch = B synthetic 592x592 frames per GPU, 32 boxes and 32*31 candidate edges per image, inputs resident in HBM.
+One batch = B synthetic 592x592 frames per GPU, 32 boxes and 32*31 candidate edges per image.  The timed steps ROTATE over NB = 4
+distinct batches per rank (different images, boxes, classes and gt_rels; the last one with another boxes-per-image signature:
+30..34 boxes, 256 in total), handed over the way the reference's boundary hands them over (rel_model_base.py:180):
+HOST-resident Blob tuples (decoded u8 images, gt_boxes / gt_classes / gt_rels on the host) through sgg_amd.blob.DeviceStager --
+one pinned async copy per batch, issued one step ahead on a copy stream, so batch k is in HBM when step k starts.  `value` is that
+rate; `hbm_resident` is the same rotation over copies that live in HBM from the start (no copy inside the timed region).
 Images are sharded over ranks (one process per GPU) => weak scaling.  Prints ONE JSON line on rank 0; the other mode's
 throughput is reported alongside under "other_mode".
 
@@ -37,8 +42,8 @@ MFMA_PEAK_TF = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}   # dense peaks, MI
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--batch', type=int, default=8, help='images per GPU (global batch 64 at 8 GPUs)')
     ap.add_argument('--dtype', default='f16', choices=['f16', 'bf16', 'f32'],
                     help='storage / MFMA operand format: f16 (default: the 16-bit mode that meets the parity clause), bf16 (same speed, 8x the rounding error), f32')
@@ -48,6 +53,9 @@ def parse():
     ap.add_argument('--force-dist', action='store_true',
                     help='diagnostic: at 1 GPU, run the data-parallel code path on a 1-rank RCCL group')
     ap.add_argument('--cpu-images', type=int, default=8)
+    ap.add_argument('--loss', default='baseline', choices=['baseline', 'dnorm', 'dnorm-fgbg'], help='lib/losses.py form (train mode)')
+    ap.add_argument('--input', default='host', choices=['host', 'hbm'],
+                    help="what `value` times: 'host' (default) = host-resident Blob tuples through DeviceStager.prefetch; 'hbm' = batches resident in HBM")
     ap.add_argument('--dry', action='store_true',
                     help='no GPU: check the launcher / rank environment with one gloo all-reduce and print the JSON skeleton')
     return ap.parse_args()
@@ -263,26 +271,34 @@ def cpu_baseline(n_images, seed, timed=3):
     sd = model.state_dict()
     batch = synthetic_batch(B=n_images, S=592, n_boxes=32, n_fg=6, seed=seed)
     avail = os.cpu_count() or 1
-    cores = min(avail, 32)      # measured on the GPU box (256 hardware threads): torch-CPU conv/GEMM is fastest at 32 threads
-    torch.set_num_threads(cores)
-    full, post = [], []
+    # torch-CPU conv / GEMM on the GPU box (EPYC 9575F, 256 hardware threads) is fastest near 32 threads; BASELINE.md section 4 says
+    # os.cpu_count(): both are timed, the faster one is `value` (its thread count is `cores`), the other is listed under `by_threads`
+    by_threads = {}
+    detail = {}
     with torch.no_grad():
-        for it in range(1 + timed):
-            t0 = time.time()
-            res = O.forward_gtbox(batch[0], batch[3], batch[4], batch[5], sd, mode='sgcls')
-            t1 = time.time()
-            O.predict(res['node_feat'], res['edge_feat'], res['rel_inds'], res['rois'], sd, im_sizes=res['im_sizes'])
-            t2 = time.time()
-            if it > 0:
-                full.append(t1 - t0)
-                post.append(t2 - t1)
-    dt, dp = sum(full) / len(full), sum(post) / len(post)
-    return {'value': round(n_images / dt, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'cpu_model': cpu_model_name(), 'host_threads_available': avail,
+        for cores, n_timed in ((min(avail, 32), max(1, timed - 1)), (avail, 1)) if avail > 32 else ((avail, timed),):
+            torch.set_num_threads(cores)
+            full, post = [], []
+            for it in range(1 + n_timed):
+                t0 = time.time()
+                res = O.forward_gtbox(batch[0], batch[3], batch[4], batch[5], sd, mode='sgcls')
+                t1 = time.time()
+                O.predict(res['node_feat'], res['edge_feat'], res['rel_inds'], res['rois'], sd, im_sizes=res['im_sizes'])
+                t2 = time.time()
+                if it > 0:
+                    full.append(t1 - t0)
+                    post.append(t2 - t1)
+            by_threads[cores] = round(n_images / (sum(full) / len(full)), 4)
+            detail[cores] = (sum(full) / len(full), min(full), max(full), sum(post) / len(post), n_timed)
+    cores = max(by_threads, key=lambda c: by_threads[c])
+    dt, lo, hi, dp, n_timed = detail[cores]
+    return {'value': by_threads[cores], 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'cpu_model': cpu_model_name(), 'host_threads_available': avail, 'by_threads': {str(k): v for k, v in by_threads.items()},
             'post_roialign_images_per_s': round(n_images / dp, 4),
             'sample': '1 warm-up + %d timed forwards of %d synthetic 592x592 images (32 boxes, 992 edges each, seed %d), torch-CPU fp32 '
-                      'oracle on %d threads: %.1f s per forward (min %.1f, max %.1f), of which predict() %.1f s'
-                      % (timed, n_images, seed, cores, dt, min(full), max(full), dp)}
+                      'oracle on %d threads: %.1f s per forward (min %.1f, max %.1f), of which predict() %.1f s; `by_threads`: the same '
+                      'forward at the other thread count (os.cpu_count() = %d)'
+                      % (n_timed, n_images, seed, cores, dt, lo, hi, dp, avail)}
 
 
 def sgdet_bench(args, model, batch, timed, world, rank, B, dev):
@@ -292,10 +308,10 @@ def sgdet_bench(args, model, batch, timed, world, rank, B, dev):
     model.detector.mode = 'refinerels'
     model.set_box_score_thresh(0.0)
 
-    def step():
+    def step(b=None):
         model.eval()
         with torch.no_grad():
-            return model([batch])
+            return model([batch if b is None else b])
     out = step()
     n_det, n_edges = len(out[1]), len(out[3])
     elapsed = timed(step, args.warmup, args.steps)
@@ -358,42 +374,74 @@ def main():
     B = args.batch
     model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgdet' if args.mode == 'sgdet' else 'sgcls')).to(dev).eval()
     model.set_compute_dtype(tdtype)
-    # images sharded by rank: rank r owns global images [r*B, (r+1)*B)  (seed differs per rank)
-    batch = list(synthetic_batch(B=B, S=592, n_boxes=32, n_fg=6, seed=111 + rank))
-    batch[0] = [im.to(dev) for im in batch[0]]          # inputs resident in HBM before the timed region
-    from sgg_amd.rel_model_base import to_device_with_mirror
-    # the index tensors keep their host originals as mirrors (as a Blob keeps its chunk sizes): no D2H sync inside the step
-    batch[3], batch[4], batch[5] = batch[3].to(dev), to_device_with_mirror(batch[4], dev), to_device_with_mirror(batch[5], dev)
-    batch = tuple(batch)
+    # images sharded by rank: rank r owns global images [r*B, (r+1)*B) of every global batch (seeds differ per rank and per batch).
+    # NB distinct batches per rank; the last has another boxes-per-image signature (same 32-box mean: 30..34, 256 boxes per 8 images).
+    from sgg_amd.blob import DeviceStager
+    NB = 4
+    ragged_counts = [(30, 34, 32, 32, 31, 33, 32, 32)[i % 8] for i in range(B)]
+    host_batches = []
+    for k in range(NB):
+        hb = list(synthetic_batch(B=B, S=592, n_boxes=32, n_fg=6, seed=111 + rank + 1000 * k, counts=ragged_counts if k == NB - 1 else None))
+        # the boundary's form (dataloaders/blob.py): decoded u8 [h,w,3] images + index tensors, all on the HOST
+        hb[0] = [(im * 255).round().to(torch.uint8).permute(1, 2, 0).contiguous() for im in hb[0]]
+        host_batches.append(tuple(hb))
+    stager = DeviceStager(dev)
+    # the same batches resident in HBM (staged once, copied out of the stager's slots; index tensors keep their host mirrors, as a
+    # Blob keeps its chunk sizes: no D2H sync inside the step)
+    dev_batches = []
+    for hb in host_batches:
+        st = list(stager.stage(hb))
+        st[0] = [im.clone() for im in st[0]]
+        for i in (3, 4, 5):
+            mirror = getattr(st[i], '_sgg_host', None)
+            st[i] = st[i].clone()
+            if mirror is not None:
+                st[i]._sgg_host = mirror
+        dev_batches.append(tuple(st))
+    torch.cuda.synchronize()
+    batch = dev_batches[0]
+    edges_per_batch = [sum(int(c) * (int(c) - 1) for c in torch.bincount(hb[4][:, 0]).tolist()) for hb in host_batches]
+
+    def feed_hbm(n):
+        return (dev_batches[i % NB] for i in range(n))
+
+    def feed_host(n):
+        return stager.prefetch(host_batches[i % NB] for i in range(n))
 
     from sgg_amd.trainer import Trainer
-    trainer = None if args.mode != 'train' else Trainer(model, lr=1e-3, force_dist=args.force_dist, pipeline=os.environ.get('SGG_PIPELINE', '1') != '0', sync_bn=os.environ.get('SGG_SYNC_BN', '1') != '0')
+    trainer = None if args.mode != 'train' else Trainer(model, lr=1e-3, force_dist=args.force_dist, loss_type=args.loss,
+                                                        pipeline=os.environ.get('SGG_PIPELINE', '1') != '0', sync_bn=os.environ.get('SGG_SYNC_BN', '1') != '0')
 
-    def infer_step():
+    def infer_step(b=None):
         model.eval()
         with torch.no_grad():
-            return model([batch])
+            return model([batch if b is None else b])
 
-    def train_step():
-        return trainer.step(batch)
+    def train_step(b=None):
+        return trainer.step(batch if b is None else b)
 
     step = train_step if args.mode == 'train' else infer_step
 
-    def timed(fn, warmup, steps):
+    def timed(fn, warmup, steps, feed=feed_hbm):
+        """`warmup` untimed + EXACTLY `steps` timed steps, each on the next batch of `feed` (one iterator over warmup + steps batches: with
+        the prefetching feed the first timed batch was staged during the last warm-up step, as in steady state)."""
+        it = iter(feed(warmup + steps))
         for _ in range(warmup):
-            fn()
+            fn(next(it))
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            fn()
+            fn(next(it))
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        for _ in it:           # (lets the prefetch generator finish)
+            pass
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -406,10 +454,30 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    elapsed = timed(step, args.warmup, args.steps)
+    head_feed, other_feed = (feed_host, feed_hbm) if args.input == 'host' else (feed_hbm, feed_host)
+    if trainer is not None and trainer.dist_on:
+        trainer.buckets.timing = []
+    elapsed = timed(step, args.warmup, args.steps, head_feed)
+    comm = None
+    if trainer is not None and trainer.dist_on:
+        # per step: bytes this rank handed to RCCL (reduce-scatter / all-reduce inputs + the all-gathered operands) and how long the stream
+        # that waits for the wire handles stood still for them (in pipeline mode that is the side stream: the main stream is already in
+        # the next step's VGG forward, the wait is exposed only where the next head forward then waits for the rebuilt operands)
+        torch.cuda.synchronize()
+        waits = [a.elapsed_time(b) for a, b in trainer.buckets.timing[-args.steps:]]
+        trainer.buckets.timing = None
+        comm = {'rccl_bytes': int(trainer.buckets.bytes_last + getattr(trainer.opt, 'gather_bytes_last', 0)),
+                'reduce_bytes': int(trainer.buckets.bytes_last), 'all_gather_bytes': int(getattr(trainer.opt, 'gather_bytes_last', 0)),
+                'comm_exposed_ms': round(sum(waits) / max(1, len(waits)), 4), 'comm_exposed_ms_max': round(max(waits), 4) if waits else None,
+                'wire_dtype': 'bf16', 'waiting_stream': 'side (pipeline)' if trainer.pipeline else 'main',
+                'note': 'bytes per rank and step handed to collectives; comm_exposed_ms = event-timed wait on the wire handles, mean over the timed steps'}
     if trainer is not None:
         # EVERY rank: with the sharded optimiser flush() is a collective (FusedSGD.gather_masters all-gathers the stale parts of
         # the fp32 masters), so it must not sit inside the rank-0-only profiling block below
+        trainer.flush()
+    # the other input form, same rotation, same number of steps (every rank: the train step holds collectives)
+    elapsed_other = timed(step, args.warmup, args.steps, other_feed)
+    if trainer is not None:
         trainer.flush()
 
     # ---- per-kernel roofline (rank 0, outside the timed region; single-GPU kernels, no collective inside)
@@ -420,7 +488,9 @@ def main():
                 res = model([batch])
                 loss = trainer.losses(res)
                 trainer.opt.zero_grad()
+                model._loss_scaled = True
                 (loss * trainer.loss_scale).backward()
+                model._loss_scaled = False
                 trainer.opt.step(grad_scale=1.0 / trainer.loss_scale)
             # rank 0 alone runs these extra steps: no collective may be issued (the other ranks wait at the host-side barrier
             # below): the trainer is switched to its local form -- hooks, BatchNorm sync, loss normalisers (dist_on) and world
@@ -512,53 +582,40 @@ def main():
         if other is not None and world == 1:
             el2 = timed(other, 2, 10)
             other_line = {'mode': 'infer', 'value': round(B * 10 / el2, 2), 'unit': 'images/s', 'ms_per_step': round(1e3 * el2 / 10, 3)}
-        # PCIe-inclusive rates (never `value`): the reference's boundary hands over HOST images (list of f32 [3,S,S],
-        # rel_model_base.py:180); (a) exactly that, per-image pageable copies inside the forward; (b) decoded u8 images
-        # through sgg_amd.blob.DeviceStager (pinned, one async copy per batch, prefetched one step ahead)
+        # the reference's literal boundary: a list of f32 [3,S,S] HOST tensors (SquarePad + ToTensor done on the CPU, rel_model_base.py:180),
+        # copied per image inside the forward (pageable memory, no prefetch) -- short run, informational
         pcie = None
         if world == 1 and not args.force_dist:
-            from sgg_amd.blob import DeviceStager
-            run = (lambda b: trainer.step(b)) if args.mode == 'train' else (lambda b: model([b]))
-            ctx = torch.enable_grad() if args.mode == 'train' else torch.no_grad()
             n = 10
-            host = list(batch)
-            host[0] = [im.cpu() for im in batch[0]]
-            host[3], host[4], host[5] = batch[3].cpu(), batch[4].cpu(), batch[5].cpu()
-            u8 = list(host)
-            u8[0] = [(im * 255).round().to(torch.uint8).permute(1, 2, 0).contiguous() for im in host[0]]
-            stager = DeviceStager()
-            with ctx:
-                if args.mode != 'train':
-                    model.eval()
-                for _ in range(2):
-                    run(tuple(host))
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(n):
-                    run(tuple(host))
-                torch.cuda.synchronize()
-                t_f32 = time.perf_counter() - t0
-                for b_ in stager.prefetch([tuple(u8)] * 2):
-                    run(b_)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for b_ in stager.prefetch([tuple(u8)] * n):
-                    run(b_)
-                torch.cuda.synchronize()
-                t_u8 = time.perf_counter() - t0
-            pcie = {'host_f32_per_image_copies': round(B * n / t_f32, 2), 'host_u8_pinned_prefetch': round(B * n / t_u8, 2),
-                    'unit': 'images/s', 'note': 'inputs start in host memory; not the headline value'}
+            f32_host = []
+            for hb in host_batches:
+                t = list(hb)
+                t[0] = [im.permute(2, 0, 1).float().div(255) for im in hb[0]]
+                f32_host.append(tuple(t))
+            el_f32 = timed(step, 2, n, lambda m: (f32_host[i % NB] for i in range(m)))
+            if trainer is not None:
+                trainer.flush()
+            pcie = {'host_f32_per_image_copies': round(B * n / el_f32, 2), 'unit': 'images/s',
+                    'note': 'reference-style input: f32 CHW host tensors, pageable, one copy per image inside the forward; 2 warm-up + %d steps' % n}
         line = {
             'metric': 'images/sec (whole node), VG SGCls IMP %s step' % ('train' if args.mode == 'train' else 'inference'),
             'value': round(world * B * args.steps / elapsed, 3),
             'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'input': ('host-resident Blob tuples (decoded u8 images + gt tensors on the host) through DeviceStager.prefetch: one pinned async '
+                      'copy per batch on a copy stream, one step ahead' if args.input == 'host' else 'batches resident in HBM'),
+            ('hbm_resident' if args.input == 'host' else 'host_input'): {
+                'value': round(world * B * args.steps / elapsed_other, 3), 'unit': 'images/s', 'ms_per_step': round(1e3 * elapsed_other / args.steps, 3),
+                'steps': args.steps, 'note': 'the same rotation over the same %d batches with the %s' % (
+                    NB, 'inputs resident in HBM before the timed region (no copy inside it)' if args.input == 'host' else 'host-resident inputs through DeviceStager.prefetch')},
             'config': {'workload': 'VG SGCls rel_model_stanford (IMP) %s, 592x592 frames, 32 boxes/img, 992 edges/img, '
                                    '3 IMP iters (BASELINE configs[1]/[3])' %
                                    ('train step: fwd + losses + bwd + grad all-reduce + clip + SGD' if args.mode == 'train'
                                     else 'eval forward incl. eval tail'),
-                       'mode': args.mode, 'images_per_gpu': B, 'global_batch': world * B,
+                       'mode': args.mode, 'images_per_gpu': B, 'global_batch': world * B, 'loss': args.loss if args.mode == 'train' else None,
+                       'batches': '%d distinct batches per rank in rotation (own images / boxes / classes / gt_rels); edges per batch %s -- the last '
+                                  'one has %s boxes per image' % (NB, edges_per_batch, '/'.join(str(c) for c in ragged_counts)),
                        'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
                        'edge_branch': ('union-box RoIAlign and fc6 K=25088 computed once per UNORDERED box pair (%d pairs for %d edges per '
                                        'GPU and step), per-edge rect term added after; same outputs as the per-edge computation '
@@ -597,14 +654,20 @@ def main():
                              'achieved': round(imp_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                              'frac': round(imp_gbs / HBM_PEAK_GBS, 4),
                              'traffic': pmc_traffic('imp_ctx_B8'),
-                             'algorithmic_bytes': imp_bytes, 'moved_bytes': imp_moved(B), 'avg_launch_ms': round(imp_ms, 5),
-                             'note': 'algorithmic_bytes = SURVEY 8(d) for the reference step (incl. the e_in write this design removed algebraically); '
-                                     '8.4 MB actually moved per launch at B=8 -- a launch plus two dependent memory latencies; see roofline_imp_large'},
+                             'reference_algorithm_bytes': imp_bytes, 'moved_bytes': imp_moved(B), 'avg_launch_ms': round(imp_ms, 5),
+                             'achieved_moved': round(imp_moved(B) / (imp_ms * 1e-3) / 1e9, 1) if imp_ms else 0.0,
+                             'frac_moved': round(imp_moved(B) / (imp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if imp_ms else 0.0,
+                             'note': 'achieved / frac price SURVEY 8(d)\'s bytes of the REFERENCE step (incl. the e_in write this design removed '
+                                     'algebraically) over the launch time; achieved_moved / frac_moved price the bytes this launch really moves (= PMC '
+                                     'traffic). At B=8 the launch is latency-bound (a launch + two dependent memory levels; roofline time 1-2 us): the '
+                                     '0.80 target is not reachable as a standalone launch at this size -- see roofline_imp_large'},
             'roofline_imp_large': {'kernel': 'the same launch at %d images (%d edges): %s' % (BL, 992 * BL, impL_kernel), 'bound': 'hbm',
                                    'achieved': round(impL_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                    'frac': round(impL_gbs / HBM_PEAK_GBS, 4),
                                    'traffic': pmc_traffic('imp_ctx_B128'),
-                                   'algorithmic_bytes': impL_bytes, 'moved_bytes': imp_moved(BL), 'avg_launch_ms': round(impL_ms, 5),
+                                   'reference_algorithm_bytes': impL_bytes, 'moved_bytes': imp_moved(BL), 'avg_launch_ms': round(impL_ms, 5),
+                                   'achieved_moved': round(imp_moved(BL) / (impL_ms * 1e-3) / 1e9, 1),
+                                   'frac_moved': round(imp_moved(BL) / (impL_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                    'forms_ms': imp_forms,
                                    'device_copy_same_bytes': {'GB/s': round(copy_gbs, 1), 'frac_of_copy': round(impL_gbs / copy_gbs, 4)}},
             'kernels': {'sum_kernel_ms_per_step': round(total_ms, 3),
@@ -613,6 +676,8 @@ def main():
                         'roi_align_rows': roi_rows,
                         'top': [{'ms_per_step': round(ms_, 3), 'call': n, 'tag': t} for ms_, n, t in top]},
         }
+        if comm:
+            line['comm'] = comm
         if other_line:
             line['other_mode'] = other_line
         if pcie:
@@ -623,7 +688,7 @@ def main():
             os.environ['SGG_EDGE_PAIRS'] = '0'
             try:
                 if trainer is not None:
-                    el_pe = timed(lambda: trainer.step(batch), 3, 8)
+                    el_pe = timed(train_step, 3, 8)
                     trainer.flush()
                 else:
                     el_pe = None
@@ -642,8 +707,8 @@ def main():
                 trainer.flush()
             torch.cuda.synchronize()
             model.set_compute_dtype(torch.bfloat16)
-            tb = Trainer(model, lr=1e-3, pipeline=trainer.pipeline) if trainer is not None else None
-            el_bt = timed(lambda: tb.step(batch), 3, 8) if tb is not None else None
+            tb = Trainer(model, lr=1e-3, pipeline=trainer.pipeline, loss_type=args.loss) if trainer is not None else None
+            el_bt = timed(lambda b: tb.step(b), 3, 8) if tb is not None else None
             if tb is not None:
                 tb.flush()
                 tb.opt.state.clear()
@@ -664,8 +729,8 @@ def main():
             torch.cuda.synchronize()
             model.set_compute_dtype(torch.float32)
             torch.cuda.empty_cache()                 # fp32 activations are twice the size: let the allocator start from whole blocks
-            t32 = Trainer(model, lr=1e-3, pipeline=trainer.pipeline if trainer is not None else True)
-            el_t = timed(lambda: t32.step(batch), 4, 5)
+            t32 = Trainer(model, lr=1e-3, pipeline=trainer.pipeline if trainer is not None else True, loss_type=args.loss)
+            el_t = timed(lambda b: t32.step(b), 4, 5)
             t32.flush()
             el_i = timed(infer_step, 2, 5)
             line['f32_mode'] = {'dtype': 'f32', 'train_images_per_s': round(B * 5 / el_t, 2), 'train_ms_per_step': round(1e3 * el_t / 5, 3),

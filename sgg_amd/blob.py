@@ -121,7 +121,7 @@ class DeviceStager(object):
 
     ALIGN = 256
 
-    def __init__(self, device=None, slots=2):
+    def __init__(self, device=None, slots=3):
         if not torch.cuda.is_available():
             raise RuntimeError('DeviceStager needs the GPU')
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
@@ -135,10 +135,9 @@ class DeviceStager(object):
             return torch.from_numpy(np.ascontiguousarray(x))
         return x.contiguous()
 
-    def _stage_async(self, batch):
-        """Packs `batch` into the next slot and launches its copy on the copy stream.  -> (device tuple, slot)"""
-        slot = self.slots[self._next]
-        self._next = (self._next + 1) % len(self.slots)
+    def _pack(self, batch, slot):
+        """Host half of staging: packs the batch's tensors into the slot's pinned buffer (plain memcpys; may run on a worker thread: numpy
+        releases the GIL for them).  -> (items, offsets, total bytes, images, {tuple index: host tensor})"""
         imgs = [self._as_tensor(im) for im in batch[0]]
         rest = {i: self._as_tensor(batch[i]) for i in (3, 4, 5) if torch.is_tensor(batch[i]) or isinstance(batch[i], np.ndarray)}
         items = imgs + [rest[i] for i in sorted(rest)]
@@ -161,6 +160,12 @@ class DeviceStager(object):
             n = t.numel() * t.element_size()
             if n:
                 np.copyto(dst[o:o + n], t.numpy().reshape(-1).view(np.uint8))
+        return items, offs, total, len(imgs), rest
+
+    def _launch(self, batch, slot, packed):
+        """Device half: ONE async copy of the packed bytes on the copy stream (issued from the consumer's thread, so that it is ordered
+        behind the compute already queued there) + the device views.  -> (device tuple, slot)"""
+        items, offs, total, n_img, rest = packed
         # device: whoever read this slot's previous contents was enqueued on the compute stream before this call
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.stream):
@@ -171,12 +176,18 @@ class DeviceStager(object):
             n = t.numel() * t.element_size()
             views.append(slot.device[o:o + n].view(t.dtype).view(t.shape))
         out = list(batch)
-        out[0] = views[:len(imgs)]
+        out[0] = views[:n_img]
         for k, i in enumerate(sorted(rest)):
-            out[i] = views[len(imgs) + k]
+            out[i] = views[n_img + k]
             if i in (4, 5):
                 out[i]._sgg_host = rest[i]     # host mirror of gt_classes / gt_rels (rel_model_base.host_of): no D2H sync later
         return tuple(out), slot
+
+    def _stage_async(self, batch):
+        """Packs `batch` into the next slot and launches its copy on the copy stream.  -> (device tuple, slot)"""
+        slot = self.slots[self._next]
+        self._next = (self._next + 1) % len(self.slots)
+        return self._launch(batch, slot, self._pack(batch, slot))
 
     def stage(self, batch):
         """batch: the tuple of Blob.__getitem__(0).  -> same tuple with items 0,3,4,5 (imgs, gt_boxes, gt_classes, gt_rels)
@@ -185,20 +196,69 @@ class DeviceStager(object):
         torch.cuda.current_stream(self.device).wait_event(slot.event)
         return out
 
-    def prefetch(self, loader):
+    def prefetch(self, loader, threaded=True):
         """Generator over device-resident batches: the copy of the next batch is issued before the current one is handed to
-        the caller, so it runs under the caller's compute.  `loader` yields Blobs or batch tuples."""
-        it = iter(loader)
+        the caller, so it runs under the caller's compute.  `loader` yields Blobs or batch tuples.
+        threaded (default): the loader itself and the packing into pinned memory (~1 ms of memcpys per 8-image batch) run on a worker
+        thread, one batch ahead -- the consumer's thread, which is the one that launches the step's ~250 kernels, only issues the copy.
+        A batch's pinned buffer is reused once the copy out of it has finished (slot event), its device buffer once the compute that
+        read it has been queued (the copy stream waits for the compute stream at issue, as in stage())."""
+        if not threaded:
+            it = iter(loader)
 
-        def grab():
-            try:
-                b = next(it)
-            except StopIteration:
-                return None
-            return self._stage_async(b[0] if isinstance(b, Blob) else b)
-        cur = grab()
-        while cur is not None:
-            nxt = grab()                                                   # copy i+1 is in flight ...
-            torch.cuda.current_stream(self.device).wait_event(cur[1].event)
-            yield cur[0]                                                   # ... while the caller computes on batch i
-            cur = nxt
+            def grab():
+                try:
+                    b = next(it)
+                except StopIteration:
+                    return None
+                return self._stage_async(b[0] if isinstance(b, Blob) else b)
+        else:
+            import queue
+            import threading
+            S = len(self.slots)
+            q = queue.Queue(maxsize=max(1, S - 1))
+            free = [threading.Event() for _ in range(S)]      # slot k: the copy out of its pinned buffer has been ISSUED (event recorded)
+            for f in free:
+                f.set()
+            stop = threading.Event()
+
+            def work():
+                try:
+                    k = self._next
+                    for b in loader:
+                        b = b[0] if isinstance(b, Blob) else b
+                        while not free[k].wait(0.05):
+                            if stop.is_set():
+                                return
+                        free[k].clear()
+                        q.put((b, k, self._pack(b, self.slots[k])))
+                        k = (k + 1) % S
+                        if stop.is_set():
+                            return
+                    q.put(None)
+                except BaseException as e:      # surfaces in the consumer
+                    q.put(e)
+            th = threading.Thread(target=work, name='sgg-stager', daemon=True)
+            th.start()
+
+            def grab():
+                item = q.get()
+                if item is None:
+                    return None
+                if isinstance(item, BaseException):
+                    raise item
+                b, k, packed = item
+                out = self._launch(b, self.slots[k], packed)
+                self._next = (k + 1) % S
+                free[k].set()
+                return out
+        try:
+            cur = grab()
+            while cur is not None:
+                nxt = grab()                                                   # copy i+1 is in flight ...
+                torch.cuda.current_stream(self.device).wait_event(cur[1].event)
+                yield cur[0]                                                   # ... while the caller computes on batch i
+                cur = nxt
+        finally:
+            if threaded:
+                stop.set()

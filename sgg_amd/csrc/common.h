@@ -9,6 +9,7 @@ typedef unsigned short bf16_t;  // raw bfloat16 bits
 typedef _Float16 f16_t;         // IEEE half: the second 16-bit storage / MFMA operand format (same matrix-core rate as bf16, 11-bit
                                 // significand instead of 8: the mode whose logits meet the parity clause, DESIGN.md "f16")
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;

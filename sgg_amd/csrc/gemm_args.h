@@ -29,6 +29,12 @@ struct GemmArgs {
     long splitk_stride;         // bytes between the fp32 partial outputs of consecutive K splits (gridDim.y > 1)
     // conv mode: A is a zero-bordered NHWC plane [B,H+2,W+2,Cin]; C is [B,H+2p,W+2p,N]
     int H, W, Cin, out_pad;
+    // stream-K form of the ping-pong kernel (tile_sched.h): the last sk_tiles tiles (in logical tile order) are cut into equal K-unit
+    // ranges over the grid's workgroups, the dp_rounds * gridDim.x tiles before them run one per workgroup and round
+    char* sk_ws;                // partial-accumulator slots, one per workgroup (SK_SLOT_BYTES each)
+    unsigned* sk_flags;         // one word per slot: the epoch of the launch that published it
+    unsigned sk_epoch;
+    int sk_dp_rounds, sk_tiles;
 };
 
 __device__ __forceinline__ void glds16(const char* g, char* l) {
@@ -60,9 +66,8 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// XCD-contiguous logical id, then groups of GM M-panels walk N (L2 reuse of both operand panels)
-__device__ __forceinline__ void tile_coords(int bid, int tilesM, int tilesN, int& tm, int& tn) {
-    const int L = xcd_remap(bid, tilesM * tilesN);
+// logical tile id -> tile coordinates: groups of GM M-panels walk N (L2 reuse of both operand panels)
+__device__ __forceinline__ void tile_coords_logical(int L, int tilesM, int tilesN, int& tm, int& tn) {
     constexpr int GM = 8;
     const int per_group = GM * tilesN;
     const int grp = L / per_group;
@@ -71,6 +76,10 @@ __device__ __forceinline__ void tile_coords(int bid, int tilesM, int tilesN, int
     const int inl = L - grp * per_group;
     tm = gm0 + inl % gsz;
     tn = inl / gsz;
+}
+// XCD-contiguous logical id of a workgroup (consecutive block ids land on different XCDs), then the walk above
+__device__ __forceinline__ void tile_coords(int bid, int tilesM, int tilesN, int& tm, int& tn) {
+    tile_coords_logical(xcd_remap(bid, tilesM * tilesN), tilesM, tilesN, tm, tn);
 }
 
 // The per-channel epilogue vectors (bias, post-scale, post-shift) of the 8 consecutive n a lane stores: loaded ONCE per

@@ -74,6 +74,11 @@ class GradBuckets(object):
         # updated compute-dtype operand is all-gathered (FusedSGD.step).  Same bytes on the links as the all-reduce (a ring
         # all-reduce IS a reduce-scatter + an all-gather), 1/world of the optimiser's HBM traffic per rank.
         self.shard = shard
+        # measurement hooks (bench.py): bytes handed to collectives by the last step, and -- when `timing` is a list -- one event pair
+        # per step around the waits on the wire handles (how long the waiting stream stood still for the links)
+        self.bytes_last = 0
+        self._bytes = 0
+        self.timing = None
 
     def is_big(self, p):
         return any(p is q for q in self.big)
@@ -91,6 +96,7 @@ class GradBuckets(object):
     def _reduce(self, p, buf):
         """-> (tensor the optimiser will read, work handle)"""
         rng = self.shard_of(p)
+        self._bytes += buf.numel() * buf.element_size()
         if rng is None:
             return buf, dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
         out = torch.empty(rng[1] - rng[0], dtype=buf.dtype, device=buf.device)
@@ -145,9 +151,18 @@ class GradBuckets(object):
             off += n + pad
         flat = torch.cat(pieces) if pieces else None
         if flat is not None:
+            self._bytes += flat.numel() * flat.element_size()
             works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+        ev = None
+        if self.timing is not None and flat is not None and flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in works:
             w.wait()
+        if ev is not None:
+            ev[1].record()
+            self.timing.append(ev)
+        self.bytes_last, self._bytes = self._bytes, 0
         self._keepalive = []
         for p, buf in bufs:
             if buf is not p.grad:

@@ -34,16 +34,16 @@ def init_weights(model, seed=111):
     return model
 
 
-def synthetic_batch(B=8, S=592, n_boxes=32, n_fg=6, seed=111, ragged=False):
+def synthetic_batch(B=8, S=592, n_boxes=32, n_fg=6, seed=111, ragged=False, counts=None):
     """Blob-layout tuple (dataloaders/blob.py:244-249): (imgs list f32[3,S,S] on host, im_sizes, image_offset,
     gt_boxes f32[G,4], gt_classes i64[G,2], gt_rels i64[R,4], proposals, fns).  Boxes: x1,y1~U[0,0.68S),
-    w,h~U[12,0.32S) clipped to S-1 (BASELINE.md 4 at S=592: U[0,400), U[12,192))."""
+    w,h~U[12,0.32S) clipped to S-1 (BASELINE.md 4 at S=592: U[0,400), U[12,192)).  counts: boxes per image (overrides n_boxes / ragged)."""
     rng = np.random.RandomState(seed)
     g = torch.Generator().manual_seed(seed)
     imgs = [torch.rand(3, S, S, generator=g) for _ in range(B)]
     boxes, classes, rels = [], [], []
     for b in range(B):
-        n = n_boxes if not ragged else max(2, n_boxes - 3 * b)
+        n = int(counts[b]) if counts is not None else (n_boxes if not ragged else max(2, n_boxes - 3 * b))
         xy = rng.uniform(0, 400.0 / 592 * S, size=(n, 2))
         wh = rng.uniform(12, max(13.0, 192.0 / 592 * S), size=(n, 2))
         boxes.append(np.concatenate((xy, np.minimum(xy + wh, S - 1)), 1).astype(np.float32))

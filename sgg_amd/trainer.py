@@ -140,6 +140,7 @@ class FusedSGD(torch.optim.Optimizer):
                       lr.ctypes.data, cnt, float(wd), float(mom), int(first), norm,
                       float(self.clip or 0.0), float(grad_scale), ops.dt(dtype), self._shadow_dt(shadows), int(self.max_blocks),
                       self.skipped.data_ptr() if k == 0 else None, stream)
+        self.gather_bytes_last = 0
         if shards:                                              # every rank gets every part of the updated operands
             import torch.distributed as dist
             for p, _, _ in live:
@@ -147,6 +148,7 @@ class FusedSGD(torch.optim.Optimizer):
                     sh = shadows.get(self.name_of.get(p))
                     full = (sh if sh is not None else p.data).view(-1)
                     dist.all_gather_into_tensor(full, full[shards[p][0]:shards[p][1]])
+                    self.gather_bytes_last += full.numel() * full.element_size()
             self.stale_masters = {p: shards[p] for p, _, _ in live if p in shards and shadows.get(self.name_of.get(p)) is not None}
             self.momentum_parts = {p: shards[p] for p, _, _ in live if p in shards}
         names = set(self.name_of.get(p) for p, _, _ in live)

@@ -77,3 +77,38 @@ def test_forward_from_staged_u8_blob_equals_forward_from_f32_tensors(env):
         again = model([stager.stage(loader[1][0])])
     for a, b in zip(again, outs[1]):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize('threaded', [True, False])
+def test_prefetch_delivers_every_batch_intact_in_order(env, threaded):
+    """DeviceStager.prefetch over more batches than slots, the packing on a worker thread (default) or in line: every batch arrives
+    once, in order, with its own bytes -- while the consumer keeps the device busy between batches (so that copies really overlap)."""
+    from sgg_amd.blob import DeviceStager
+    rng = np.random.RandomState(7)
+    batches = []
+    for k in range(11):
+        nb = 3 + k % 4
+        imgs = [rng.randint(0, 256, size=(64 + 8 * (k % 3), 96, 3)).astype(np.uint8) for _ in range(2)]
+        batches.append((imgs, np.array([[96, 96, 1.0]] * 2), 0, torch.from_numpy(rng.rand(nb, 4).astype(np.float32)),
+                        torch.from_numpy(rng.randint(0, 9, size=(nb, 2))), torch.from_numpy(rng.randint(0, 9, size=(k + 1, 4))), None, ['a', 'b']))
+    stager = DeviceStager(slots=3)
+    busy = torch.randn(2048, 2048, device=DEV)
+    got = []
+    for b in stager.prefetch(iter(batches), threaded=threaded):
+        for _ in range(4):
+            busy = (busy @ busy).clamp_(-1, 1)                 # compute queued on the consumer's stream while the next copy flies
+        got.append(([im.clone() for im in b[0]], b[3].clone(), b[4].clone(), b[5].clone(), b[5]._sgg_host))
+    torch.cuda.synchronize()
+    assert len(got) == len(batches)
+    for (imgs, boxes, cls, rels, host_rels), ref in zip(got, batches):
+        for a, r in zip(imgs, ref[0]):
+            np.testing.assert_array_equal(a.cpu().numpy(), r)
+        assert torch.equal(boxes.cpu(), ref[3]) and torch.equal(cls.cpu(), ref[4]) and torch.equal(rels.cpu(), ref[5])
+        assert torch.equal(host_rels, ref[5])
+    # a loader that raises surfaces in the consumer
+    def bad():
+        yield batches[0]
+        raise KeyError('decode failed')
+    with pytest.raises(KeyError):
+        for _ in stager.prefetch(bad(), threaded=threaded):
+            pass
