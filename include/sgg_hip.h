@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGG_ABI_VERSION 6   /* bump whenever a prototype below changes: tests/abi.lock pins (version, digest of the prototypes) */
+#define SGG_ABI_VERSION 7   /* bump whenever a prototype below changes: tests/abi.lock pins (version, digest of the prototypes) */
 
 enum { SGG_F32 = 0, SGG_BF16 = 1, SGG_F16 = 2 };
 enum { SGG_ACT_NONE = 0, SGG_ACT_RELU = 1 };
@@ -113,10 +113,12 @@ int sgg_roi_align_fwd(const void* fmap, int B, int H, int W, int C, const float*
                       int R, float spatial_scale, int P, int sampling, const float* add_ec, void* out, int dtype,
                       void* stream);
 /* Backward of the call above into the feature map (needed where fmap requires grad: the GAN feature-augmentation path,
- * main.py:141): d_fmap f32[B,H,W,C] += RoIAlign^T(d_out[R,C,P,P]) -- float atomics, the caller zeroes d_fmap (or
- * accumulates the node and the union-box call into one map).  Same rois / pairs / scale arguments as the forward. */
+ * main.py:141): d_fmap f32[B,H,W,C] += RoIAlign^T(d_out) -- a gather (one wave per feature-map cell walks the RoIs in
+ * ascending order: one writer per cell, fixed summation order, NO atomics: bit-reproducible); the caller zeroes d_fmap (or accumulates
+ * the node and the union-box call into one map).  Same rois / pairs / scale arguments as the forward.  layout 0: d_out is the
+ * forward's [R,C,P,P]; layout 1: channels-last [R,P,P,C] (sgg_permute_ncp_to_npc; 16-byte loads -- what the host wrapper passes). */
 int sgg_roi_align_bwd(const void* d_out, int B, int H, int W, int C, const float* rois, int Nroi, const int64_t* pairs, int R,
-                      float spatial_scale, int P, int sampling, float* d_fmap, int dtype, void* stream);
+                      float spatial_scale, int P, int sampling, float* d_fmap, int dtype, int layout, void* stream);
 
 /* ---- a-5  union-mask raster ----
  * raster 0 (edge_model 'motifs', the default): draw_union_boxes, lib/draw_rectangles/draw_rectangles.pyx:12-67 -- coverage of
@@ -302,16 +304,17 @@ int sgg_ce_fwd_bwd(const float* logits, int ld, const int64_t* labels, int label
                    int mode, float alpha, float beta, void* stream);
 /* counts[0] (+)= #{labels > 0}, counts[1] (+)= #{labels == 0} as f32 (M_FG, M_BG of lib/losses.py:29-34; M < 2^24). */
 int sgg_label_counts(const int64_t* labels, int label_stride, int M, float* counts, int accumulate, void* stream);
-/* Stream-K scheduling of the 256x256 ping-pong GEMM / implicit-GEMM convolution launches of `stream` (csrc/tile_sched.h): with a
- * workspace registered, a launch whose tile count is not a multiple of the CU count runs as ONE persistent launch (grid = CUs) in which
- * the last round's K-tiles are spread over all CUs; a split tile is one accumulation chain handed from one workgroup to the next through
- * the workspace, so every output bit equals the plain launch's.  ws: sgg_streamk_workspace_bytes() bytes of device memory, 256-byte
- * aligned, its first 1 KiB (the flag words) zeroed ONCE by the caller; it must outlive every launch on `stream`.  One workspace per
- * stream (launches of a stream are ordered); ws = NULL forgets the stream.  SGG_STREAMK=0 disables the form, =1 forces it wherever
- * it applies (default: when a plain launch would leave >= 4 % of its rounds' tile slots empty). */
+/* Stream-K scheduling of the 256x256 ping-pong GEMM launches of `stream` (csrc/tile_sched.h, csrc/gemm256_sk.hip): with a workspace
+ * registered and the mode switched on, a launch whose tile count is not a multiple of the CU count runs as ONE persistent launch (grid =
+ * CUs) in which the last round's K-tiles are spread over all CUs; a split tile is one accumulation chain handed from one workgroup to
+ * the next through the workspace, so every output bit equals the plain launch's.  ws: sgg_streamk_workspace_bytes() bytes of device
+ * memory, 256-byte aligned, its first 1 KiB (the flag words) zeroed ONCE by the caller; it must outlive every launch on `stream`.  One
+ * workspace per stream (launches of a stream are ordered); ws = NULL forgets the stream.  OFF by default (sgg_streamk_mode / the
+ * environment variable SGG_STREAMK): correct and bit-identical, measured no faster than the plain launches yet. */
 int64_t sgg_streamk_workspace_bytes(void);
 int sgg_streamk_workspace(void* stream, void* ws, int64_t bytes);
-/* 0: never; 1: wherever it applies; 2: the default rule above; other values: no change.  Returns the previous mode. */
+/* 0: never (default); 1: wherever it applies; 2: where a plain launch would leave >= 4 % of its tile slots empty; 3: tests; other values: query only.
+ * Returns the previous mode. */
 int sgg_streamk_mode(int mode);
 /* out[N] = column sums of x[M,N] (row stride ld): bias gradients.  ws: f32[64 * N] (may be NULL when M <= 512). */
 int sgg_colsum(const void* x, int M, int N, int ld, float* out, float* ws, int dtype, void* stream);

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('SGG_HIP_LIB') or os.path.join(_HERE, 'libsgg_hip.so')
 
 SGG_F32, SGG_BF16, SGG_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _P, _I, _F, _L = c_void_p, c_int, c_float, c_int64
 
@@ -38,7 +38,7 @@ SIGNATURES = {
     'sgg_triple_pool_bwd': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P],
     'sgg_edge_csr': [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],  # rel, E, N, im_inds, out_ptr, out_ids, in_ptr, in_ids, so, flags, stream
     'sgg_roi_align_fwd': [_P, _I, _I, _I, _I, _P, _I, _P, _I, _F, _I, _I, _P, _P, _I, _P],
-    'sgg_roi_align_bwd': [_P, _I, _I, _I, _I, _P, _I, _P, _I, _F, _I, _I, _P, _I, _P],
+    'sgg_roi_align_bwd': [_P, _I, _I, _I, _I, _P, _I, _P, _I, _F, _I, _I, _P, _I, _I, _P],
     'sgg_union_rects_fwd': [_P, _P, _I, _I, _F, _P, _I, _P, _P],
     'sgg_union_rect_patches': [_P, _P, _I, _I, _P, _I, _I, _P, _I, _P],
     'sgg_max4_rows': [_P, _P, _I, _I, _I, _P],

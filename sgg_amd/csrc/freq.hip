@@ -59,14 +59,32 @@ __global__ __launch_bounds__(256) void freq_gather_add_kernel(const int64_t* __r
     if (p == 0 && row_idx) row_idx[e] = row;
 }
 
-// d_table[row_idx[e], :] += d_out[e, :]  (nn.Embedding's dense weight gradient); few edges share a class pair, so the float
-// atomics see little contention
+// d_table[row_idx[e], :] += d_out[e, :]  (nn.Embedding's dense weight gradient) WITHOUT atomics: a wave owns edge e; it scans the
+// edges before e for the same table row (someone earlier owns the row: nothing to do), otherwise it is the row's first edge and adds
+// d_out of every edge with that row in ascending edge order.  O(E^2) 4-byte compares from L2 (E = 8k: 63 M, ~20 us), one writer per
+// table row, a fixed summation order: bit-reproducible (the float atomicAdd form it replaces was not; main.py -use_bias training).
 __global__ __launch_bounds__(256) void freq_scatter_kernel(const float* __restrict__ d_out, const int32_t* __restrict__ row_idx, int E,
                                                            int P, float* __restrict__ d_table) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)E * P) return;
-    const int e = (int)(i / P), p = (int)(i - (long)e * P);
-    atomicAdd(d_table + (long)row_idx[e] * P + p, d_out[i]);
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= E) return;
+    const int row = row_idx[e];
+    bool earlier = false;
+    for (int j = lane; j < e; j += 64) earlier |= row_idx[j] == row;
+    if (__ballot(earlier)) return;                     // (wave-uniform: the whole wave leaves)
+    for (int p0 = 0; p0 < P; p0 += 64) {
+        const int p = p0 + lane;
+        float acc = p < P ? d_table[(long)row * P + p] : 0.f;
+        for (int j0 = e; j0 < E; j0 += 64) {           // edges j >= e with the same row, 64 at a time, consumed in ascending order
+            const int j = j0 + lane;
+            unsigned long long m = __ballot(j < E && row_idx[j] == row);
+            while (m) {
+                const int k = __builtin_ctzll(m);
+                m &= m - 1;
+                if (p < P) acc += d_out[(long)(j0 + k) * P + p];
+            }
+        }
+        if (p < P) d_table[(long)row * P + p] = acc;
+    }
 }
 
 }  // namespace
@@ -98,8 +116,7 @@ extern "C" int sgg_freq_bias_bwd(const float* d_out, const int32_t* row_idx, int
     if (E < 0 || P < 1) return SGG_ERR_ARG;
     if (E == 0) return SGG_OK;
     if (!d_out || !row_idx || !d_table) return SGG_ERR_ARG;
-    const long total = (long)E * P;
-    freq_scatter_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(d_out, row_idx, E, P, d_table);
+    freq_scatter_kernel<<<(unsigned)((E + 3) / 4), 256, 0, (hipStream_t)stream>>>(d_out, row_idx, E, P, d_table);
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

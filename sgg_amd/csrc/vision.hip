@@ -478,99 +478,144 @@ __global__ __launch_bounds__(512, 4) void roi_align_kernel(const T* __restrict__
 namespace {
 // ------------------------------------------------------------------------------------------------
 // RoIAlign backward into the feature map (the GAN / feature-augmentation callers, where fmap requires grad: main.py:141; SURVEY
-// 8b lists it as `sgg_roi_align_bwd`).  Exact adjoint of roi_align_kernel: every (bin, sample, tap) of the forward adds
-// weight / S^2 * d_out[r, c, ph, pw] to d_fmap[b, y, x, c].  One workgroup per RoI, a lane owns 8 channels; float atomics on the
-// fp32 NHWC gradient map (RoIs of one image overlap).  d_out is the forward's layout [R, C, P, P] (T); d_fmap f32 [B,H,W,C].
+// 8b lists it as `sgg_roi_align_bwd`).  Exact adjoint of roi_align_kernel, as a GATHER: a wave owns one feature-map cell (b, y, x) and
+// all C channels (a lane = 8 channels); it walks the RoIs in ascending order (64 candidates per ballot: same image, cell inside the rows
+// and columns the RoI's samples touch), and for every bin (ph, pw) whose samples reach the cell adds
+//     wy(ph) * wx(pw) / S^2 * d_out[r, :, ph, pw],     w(p) = sum over the bin's S samples of ([lo == cell] (1 - l) + [hi == cell] l)
+// -- the forward's per-axis sample table (same clamping, same validity rule), separable, so the weights are two short sums.  One
+// writer per cell and a fixed order of RoIs and bins: no atomics, bit-reproducible (round 3's form scattered with float atomicAdd).
+// d_out is the forward's layout [R, C, P, P] (layout 0) or channels-last [R, P, P, C] (layout 1: 16-byte loads instead of eight 2-byte
+// ones at a 98-byte stride; sgg_permute_ncp_to_npc makes it); d_fmap f32 [B,H,W,C] +=.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+__device__ __forceinline__ void roi_axis(const float* __restrict__ rois, const int64_t* __restrict__ pairs, long r, int axis, float scale,
+                                         float& start, float& bin, int P) {
+    float lo_c, hi_c;
+    if (pairs) {
+        const float* a = rois + pairs[2 * r] * 5;
+        const float* b = rois + pairs[2 * r + 1] * 5;
+        lo_c = fminf(a[2 - axis], b[2 - axis]);
+        hi_c = fmaxf(a[4 - axis], b[4 - axis]);
+    } else {
+        const float* a = rois + r * 5;
+        lo_c = a[2 - axis];
+        hi_c = a[4 - axis];
+    }
+    start = lo_c * scale;
+    const float end = hi_c * scale;
+    bin = fmaxf(end - start, 1.0f) / (float)P;
+}
+// the forward's sample k = p * S + i of one axis: rows lo / hi and the interpolation weight l (valid = false: the sample reads nothing)
+__device__ __forceinline__ bool roi_sample(float start, float bin, int p, int i, int S, int L, int& lo, int& hi, float& l) {
+    float c = start + (float)p * bin + ((float)i + 0.5f) * bin / (float)S;
+    if (c < -1.0f || c > (float)L) return false;
+    c = c <= 0.f ? 0.f : c;
+    lo = (int)c;
+    if (lo >= L - 1) {
+        hi = lo = L - 1;
+        c = (float)lo;
+    } else {
+        hi = lo + 1;
+    }
+    l = c - (float)lo;
+    return true;
+}
+__device__ __forceinline__ float roi_bin_weight(float start, float bin, int p, int S, int L, int cell) {
+    float w = 0.f;
+    for (int i = 0; i < S; ++i) {
+        int lo, hi;
+        float l;
+        if (!roi_sample(start, bin, p, i, S, L, lo, hi, l)) continue;
+        if (lo == cell) w += 1.f - l;
+        if (hi == cell) w += l;
+    }
+    return w;
+}
+
+template <typename T, int LAYOUT>
 __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const T* __restrict__ d_out, int B, int H, int W, int C,
                                                             const float* __restrict__ rois, const int64_t* __restrict__ pairs, int R,
                                                             float scale, int P, int S, float* __restrict__ d_fmap) {
-    __shared__ int s_lo[2][MAXS], s_hi[2][MAXS];
-    __shared__ float s_l[2][MAXS], s_h[2][MAXS];
-    __shared__ int s_b;
-    const int r = blockIdx.x, tid = threadIdx.x, PS = P * S;
-    if (tid < 2 * PS) {                       // the forward's sample table, verbatim
-        const int axis = tid / PS, k = tid - axis * PS;
-        float lo_c, hi_c, bi;
-        if (pairs) {
-            const float* a = rois + pairs[2 * (long)r] * 5;
-            const float* b = rois + pairs[2 * (long)r + 1] * 5;
-            bi = a[0];
-            lo_c = fminf(a[2 - axis], b[2 - axis]);
-            hi_c = fmaxf(a[4 - axis], b[4 - axis]);
-        } else {
-            const float* a = rois + (long)r * 5;
-            bi = a[0];
-            lo_c = a[2 - axis];
-            hi_c = a[4 - axis];
-        }
-        const int L = axis == 0 ? H : W;
-        const float start = lo_c * scale, end = hi_c * scale;
-        const float len = fmaxf(end - start, 1.0f);
-        const float bin = len / (float)P;
-        const int p = k / S, i = k - p * S;
-        float c = start + (float)p * bin + ((float)i + 0.5f) * bin / (float)S;
-        const bool valid = !(c < -1.0f || c > (float)L);
-        c = c <= 0.f ? 0.f : c;
-        int lo = (int)c, hi;
-        if (lo >= L - 1) {
-            hi = lo = L - 1;
-            c = (float)lo;
-        } else {
-            hi = lo + 1;
-        }
-        const float l = c - (float)lo;
-        s_lo[axis][k] = valid ? lo : 0;
-        s_hi[axis][k] = valid ? hi : 0;
-        s_l[axis][k] = l;
-        s_h[axis][k] = valid ? 1.f - l : -1.f;
-        if (tid == 0) s_b = min(max((int)bi, 0), B - 1);
-    }
-    __syncthreads();
-    float* gm = d_fmap + (long)s_b * H * W * C;
+    const int cell = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (cell >= B * H * W) return;
+    const int b = cell / (H * W), yx = cell - b * (H * W), y = yx / W, x = yx - y * W;
     const float inv = 1.0f / (float)(S * S);
     const int PP = P * P;
-    for (int c0 = tid * 8; c0 < C; c0 += 256 * 8) {
-        for (int bin = 0; bin < PP; ++bin) {
-            const int ph = bin / P, pw = bin - ph * P;
-            float g[8];
+    for (int cb = 0; cb < C; cb += 512) {
+        const int c0 = cb + lane * 8;
+        const bool on = c0 < C;
+        float acc[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) g[k] = Elem<T>::ld(d_out + ((long)r * C + c0 + k) * PP + bin) * inv;
-            for (int iy = 0; iy < S; ++iy) {
-                const int ky = ph * S + iy;
-                const float hy = s_h[0][ky], ly = s_l[0][ky];
-                if (hy < 0.f) continue;
-                for (int ix = 0; ix < S; ++ix) {
-                    const int kx = pw * S + ix;
-                    const float hx = s_h[1][kx], lx = s_l[1][kx];
-                    if (hx < 0.f) continue;
-                    float* t00 = gm + ((long)s_lo[0][ky] * W + s_lo[1][kx]) * C + c0;
-                    float* t01 = gm + ((long)s_lo[0][ky] * W + s_hi[1][kx]) * C + c0;
-                    float* t10 = gm + ((long)s_hi[0][ky] * W + s_lo[1][kx]) * C + c0;
-                    float* t11 = gm + ((long)s_hi[0][ky] * W + s_hi[1][kx]) * C + c0;
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        for (int r0 = 0; r0 < R; r0 += 64) {
+            // candidates: this lane's RoI lies in image b and its first / last sample rows and columns enclose the cell
+            const long r = r0 + lane;
+            bool touch = false;
+            if (r < R) {
+                const int bi = min(max((int)rois[(pairs ? pairs[2 * r] : r) * 5], 0), B - 1);
+                if (bi == b) {
+                    float sy, by, sx, bx;
+                    roi_axis(rois, pairs, r, 0, scale, sy, by, P);
+                    roi_axis(rois, pairs, r, 1, scale, sx, bx, P);
+                    const float y_first = sy + 0.5f * by / (float)S, y_last = sy + (float)(P - 1) * by + ((float)(S - 1) + 0.5f) * by / (float)S;
+                    const float x_first = sx + 0.5f * bx / (float)S, x_last = sx + (float)(P - 1) * bx + ((float)(S - 1) + 0.5f) * bx / (float)S;
+                    touch = (float)y >= floorf(fmaxf(y_first, 0.f)) - 1.f && (float)y <= floorf(fmaxf(y_last, 0.f)) + 1.f &&
+                            (float)x >= floorf(fmaxf(x_first, 0.f)) - 1.f && (float)x <= floorf(fmaxf(x_last, 0.f)) + 1.f;
+                }
+            }
+            unsigned long long m = __ballot(touch);
+            while (m) {
+                const int j = __builtin_ctzll(m);
+                m &= m - 1;
+                const long rr = r0 + j;
+                float sy, by, sx, bx;
+                roi_axis(rois, pairs, rr, 0, scale, sy, by, P);
+                roi_axis(rois, pairs, rr, 1, scale, sx, bx, P);
+                for (int ph = 0; ph < P; ++ph) {
+                    const float wy = roi_bin_weight(sy, by, ph, S, H, y);
+                    if (wy == 0.f) continue;
+                    for (int pw = 0; pw < P; ++pw) {
+                        const float wx = roi_bin_weight(sx, bx, pw, S, W, x);
+                        if (wx == 0.f) continue;
+                        const float w = wy * wx * inv;
+                        if (!on) continue;
+                        if constexpr (LAYOUT == 1) {
+                            float g[8];
+                            load8(d_out + ((long)rr * PP + ph * P + pw) * C + c0, g);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        atomicAdd(t00 + k, hy * hx * g[k]);
-                        atomicAdd(t01 + k, hy * lx * g[k]);
-                        atomicAdd(t10 + k, ly * hx * g[k]);
-                        atomicAdd(t11 + k, ly * lx * g[k]);
+                            for (int k = 0; k < 8; ++k) acc[k] += w * g[k];
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) acc[k] += w * Elem<T>::ld(d_out + ((long)rr * C + c0 + k) * PP + ph * P + pw);
+                        }
                     }
                 }
             }
+        }
+        if (on) {
+            float* dst = d_fmap + (long)cell * C + c0;
+            float old[8];
+            load8(dst, old);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) old[k] += acc[k];
+            store8(dst, old);
         }
     }
 }
 }  // namespace
 
 extern "C" int sgg_roi_align_bwd(const void* d_out, int B, int H, int W, int C, const float* rois, int Nroi, const int64_t* pairs,
-                                 int R, float spatial_scale, int P, int sampling, float* d_fmap, int dtype, void* stream) {
+                                 int R, float spatial_scale, int P, int sampling, float* d_fmap, int dtype, int layout, void* stream) {
     if (R == 0) return SGG_OK;
     if (!d_out || !rois || !d_fmap || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || R < 0 || P <= 0 || sampling <= 0 ||
-        P * sampling > MAXS || Nroi <= 0)
+        P * sampling > MAXS || Nroi <= 0 || (layout != 0 && layout != 1) || ((uintptr_t)d_fmap & 15) || (layout == 1 && ((uintptr_t)d_out & 15)))
         return SGG_ERR_ARG;
-    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(roi_align_bwd_kernel<T>, dim3(R), dim3(256), 0, (hipStream_t)stream, (const T*)d_out, B, H, W, C, rois,
-                                            pairs, R, spatial_scale, P, sampling, d_fmap));
+    const dim3 grid((unsigned)(((long)B * H * W + 3) / 4)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (layout == 1) {
+        SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL((roi_align_bwd_kernel<T, 1>), grid, blk, 0, s, (const T*)d_out, B, H, W, C, rois, pairs, R, spatial_scale, P, sampling, d_fmap));
+    } else {
+        SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL((roi_align_bwd_kernel<T, 0>), grid, blk, 0, s, (const T*)d_out, B, H, W, C, rois, pairs, R, spatial_scale, P, sampling, d_fmap));
+    }
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

@@ -49,8 +49,9 @@ _streamk_ws = {}     # (device index, raw stream) -> workspace tensor registered
 def streamk_enable(stream=None, device=None):
     """Registers a stream-K workspace (sgg_streamk_workspace, 64 MiB) for `stream` (default: the current one), once: from then on the
     256x256 ping-pong GEMM / convolution launches on it whose tile count leaves a round partly empty run as one persistent launch
-    (csrc/tile_sched.h) -- the same bits, fewer idle CUs.  The model calls this for the streams it launches on; SGG_STREAMK=0 skips it."""
-    if os.environ.get('SGG_STREAMK', '') == '0':
+    (csrc/tile_sched.h) -- the same bits, fewer idle CUs.  The model calls this for the streams it launches on; a no-op while the mode is 0
+    (the default: sgg_streamk_mode / SGG_STREAMK)."""
+    if _lib.load().sgg_streamk_mode(-1) == 0:          # off (the default, csrc/gemm256_sk.hip): no workspace is held
         return False
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
     raw = stream.cuda_stream if stream is not None else (_raw_stream(dev) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream)
@@ -289,14 +290,18 @@ def roi_align(fmap_nhwc, rois, pairs=None, spatial_scale=1.0 / 16, P=7, sampling
 
 
 def roi_align_bwd(d_out, fmap_shape, rois, pairs=None, spatial_scale=1.0 / 16, sampling=2, d_fmap=None):
-    """d_out [R,C,P,P] -> d_fmap f32 [B,H,W,C] (+= when given): the adjoint of roi_align (GAN path: fmap requires grad)."""
+    """d_out [R,C,P,P] -> d_fmap f32 [B,H,W,C] (+= when given): the adjoint of roi_align (GAN path: fmap requires grad).  A gather per
+    feature-map cell (no atomics: bit-reproducible); d_out is re-laid out channels-last first so that the gather reads 16-byte pieces."""
     B, H, W, C = fmap_shape
     R, P = d_out.shape[0], d_out.shape[-1]
     if d_fmap is None:
         d_fmap = torch.zeros((B, H, W, C), dtype=torch.float32, device=d_out.device)
-    _lib.call('sgg_roi_align_bwd', _p(d_out), B, H, W, C, _p(rois, torch.float32), rois.shape[0],
+    if R == 0:
+        return d_fmap
+    g = permute_ncp_to_npc(d_out.reshape(R, C, P * P))                   # [R, P*P, C]
+    _lib.call('sgg_roi_align_bwd', _p(g), B, H, W, C, _p(rois, torch.float32), rois.shape[0],
               _p(pairs, torch.int64) if pairs is not None else None, R, float(spatial_scale), P, sampling, _p(d_fmap, torch.float32),
-              dt(d_out), _stream())
+              dt(g), 1, _stream())
     return d_fmap
 
 

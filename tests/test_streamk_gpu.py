@@ -16,7 +16,7 @@ def ops():
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     from sgg_amd import ops
-    prev = ops.streamk_mode(2)
+    prev = ops.streamk_mode(1)
     yield ops
     ops.streamk_mode(prev)
     ops.streamk_disable()
@@ -28,10 +28,10 @@ def both(ops, fn, modes=(1, 3)):
     plain = fn()
     outs = []
     for m in modes:
-        ops.streamk_enable()
         ops.streamk_mode(m)
+        ops.streamk_enable()
         outs.append(fn())
-    ops.streamk_mode(2)
+    ops.streamk_mode(1)
     torch.cuda.synchronize()
     return plain, outs
 
@@ -73,10 +73,10 @@ def test_fc6_weight_gradient_shape_and_repeated_launches(ops):
     r = torch.randn(4096, 512, generator=g).to(DEV)
     ops.streamk_disable()
     plain = ops.gemm_full_waves(A, W, out_dtype=torch.bfloat16, gadd=(r, 49))      # main launch + split-K tail: NOT the single-chain order
-    ops.streamk_mode(0)
     ops.streamk_enable()
+    ops.streamk_mode(0)
     one = ops.gemm_full_waves(A, W, out_dtype=torch.bfloat16, gadd=(r, 49))         # mode 0 + workspace: one plain launch of all 1568 tiles
-    ops.streamk_mode(2)
+    ops.streamk_mode(1)
     side = torch.cuda.Stream()
     busy = torch.randn(4096, 4096, device=DEV)
     for it in range(12):

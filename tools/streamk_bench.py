@@ -41,8 +41,8 @@ def main():
             ops.streamk_disable()
             tp.append(timed(fn, reps))
             ref = out.clone()
-            ops.streamk_enable()
             prev = ops.streamk_mode(1)
+            ops.streamk_enable()
             ts.append(timed(fn, reps))
             same = same and torch.equal(out, ref)
             ops.streamk_mode(prev)
