@@ -301,6 +301,30 @@ def cpu_baseline(n_images, seed, timed=3):
                       % (n_timed, n_images, seed, cores, dt, lo, hi, dp, avail)}
 
 
+def sgdet_cpu_baseline(n_images, seed):
+    """BASELINE configs[2] on the host: the oracle's SGDet forward (VGG-16, RPN, 1000 proposals, box head, per-class NMS, IMP) on a bounded
+    sample -- `n_images` images, 1 timed forward after a warm-up of the first image only (the box head alone is ~0.4 TFLOP per image)."""
+    import torch
+    import sgg_amd
+    from oracle import sgg_oracle as O
+    from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgdet'))
+    sd = model.state_dict()
+    batch = synthetic_batch(B=n_images, S=592, n_boxes=32, n_fg=6, seed=seed)
+    avail = os.cpu_count() or 1
+    cores = min(avail, 32)
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        O.forward_sgdet(batch[0][:1], sd, score_thresh=0.0)
+        t0 = time.time()
+        O.forward_sgdet(batch[0], sd, score_thresh=0.0)
+        dt = time.time() - t0
+    return {'value': round(n_images / dt, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model_name(),
+            'host_threads_available': avail,
+            'sample': '1 warm-up forward of one image + 1 timed forward of %d synthetic 592x592 images (seed %d, score threshold 0), the '
+                      'oracle\'s SGDet forward (torch-CPU fp32 + numpy NMS) on %d threads: %.1f s' % (n_images, seed, cores, dt)}
+
+
 def sgdet_bench(args, model, batch, timed, world, rank, B, dev):
     """--mode sgdet: images/s of the SGDet eval forward at its real size + the per-call kernel times of one profiled pass."""
     import torch
@@ -319,19 +343,32 @@ def sgdet_bench(args, model, batch, timed, world, rank, B, dev):
         return
     kt = kernel_times(step, reps=3)
     total_ms = sum(v[0] * v[1] for v in kt.values())
-    top = sorted(((v[0] * v[1], n, t) for (n, t), v in kt.items()), reverse=True)[:10]
+    top = sorted(((v[0] * v[1], n, t) for (n, t), v in kt.items()), reverse=True)[:int(os.environ.get('SGG_BENCH_TOP', '12'))]
     # the box head's fc6 on <= 1000 proposals per image is the largest contraction of this mode
     fc6 = max(((v[0] * v[1], n, t) for (n, t), v in kt.items() if n == 'sgg_gemm'), default=(0.0, '', ''))
+    K = int(getattr(model.detector, 'last_proposals', 0))
+    flop = 2.0 * K * 4096 * 25088
+    peak = MFMA_PEAK_TF[args.dtype]
+    tf = flop / (fc6[0] * 1e-3) / 1e12 if fc6[0] else 0.0
+    per = lambda names: sum(v[0] * v[1] for (n, t), v in kt.items() if n in names)       # noqa: E731
     line = {'metric': 'images/sec (whole node), VG SGDet eval forward (detector + IMP)', 'value': round(world * B * args.steps / elapsed, 3),
             'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': args.dtype, 'data': 'synthetic',
+            'dtype': args.dtype, 'data': 'synthetic', 'input': 'batches resident in HBM (rotation of 4)',
             'config': {'workload': 'VG SGDet (BASELINE configs[2]): 592x592 frames, RPN 21 660 anchors -> 1 000 proposals/img, box head, '
                                    'per-class NMS, <= 50 detections/img, overlap-filtered pairs, union RoIAlign, 3 IMP iters, eval tail',
                        'mode': 'sgdet', 'images_per_gpu': B, 'detections_per_step': n_det, 'candidate_edges_per_step': n_edges,
-                       'score_thresh': 0.0, 'weights': 'random init (He)'},
+                       'proposals_per_step': K, 'score_thresh': 0.0, 'weights': 'random init (He)'},
+            'roofline': {'kernel': 'box head fc6 on the proposals: [%d x 25088] . [4096 x 25088]^T (256x256 ping-pong MFMA kernel)' % K,
+                         'bound': 'mfma', 'achieved': round(tf, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(tf / peak, 4), 'traffic': None,
+                         'ms_per_step': round(fc6[0], 4), 'executed_flop': flop},
             'kernels': {'sum_kernel_ms_per_step': round(total_ms, 3), 'largest_gemm_ms': round(fc6[0], 3),
+                        'vgg16_ms': round(per(('sgg_conv3x3_relu', 'sgg_conv1_1', 'sgg_conv1_block', 'sgg_maxpool2x2')), 3),
+                        'sort_ms': round(per(('sgg_segmented_sort_desc', 'sgg_gather_topk', 'sgg_topk_select')), 4),
+                        'nms_ms': round(per(('sgg_nms',)), 4),
                         'top': [{'ms_per_step': round(ms_, 3), 'call': n, 'tag': t} for ms_, n, t in top]}}
+    if world == 1 and not args.no_cpu_baseline:
+        line['cpu_baseline'] = sgdet_cpu_baseline(min(args.cpu_images, 2), 111)
     import ctypes
     ctypes.CDLL(None).fflush(None)
     print(json.dumps(line), flush=True)

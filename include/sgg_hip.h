@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGG_ABI_VERSION 7   /* bump whenever a prototype below changes: tests/abi.lock pins (version, digest of the prototypes) */
+#define SGG_ABI_VERSION 8   /* bump whenever a prototype below changes: tests/abi.lock pins (version, digest of the prototypes) */
 
 enum { SGG_F32 = 0, SGG_BF16 = 1, SGG_F16 = 2 };
 enum { SGG_ACT_NONE = 0, SGG_ACT_RELU = 1 };
@@ -67,9 +67,10 @@ int sgg_conv1_pack_weights(const float* w1 /*[64][27]*/, void* frags /*4096 byte
 int sgg_conv1_block(const float* in_nhwc4, const void* w1_frags, const float* b1, const void* w2, const float* b2, void* out, int out_pad,
                     int B, int H, int W, int pool, int dtype, void* stream);
 /* pool = 1: the following MaxPool2d(2) is fused into the epilogue -- out is the pooled plane [B, H/2+2p, W/2+2p, Cout]
- * (H, W even; LDS-patch kernel only: returns SGG_ERR_ARG for shapes that kernel does not take). */
+ * (H, W even; LDS-patch kernel only: returns SGG_ERR_ARG for shapes that kernel does not take).  out_dtype: element type of `out`;
+ * != dtype (the x3 mode: f16 split operands in, f32 out) runs on the implicit-GEMM kernels, without the fused pool. */
 int sgg_conv3x3_relu(const void* in /*pad 1*/, const void* w /*[Cout][3][3][Cin]*/, const float* bias, void* out,
-                     int out_pad, int B, int H, int W, int Cin, int Cout, int pool, int dtype, void* stream);
+                     int out_pad, int B, int H, int W, int Cin, int Cout, int pool, int dtype, int out_dtype, void* stream);
 int sgg_maxpool2x2(const void* in /*pad 1*/, void* out, int out_pad, int B, int H, int W, int C, int dtype,
                    void* stream);
 
@@ -379,6 +380,12 @@ int sgg_sgd_multi(float* const* p, const void* const* g, float* const* momentum_
                   const int64_t* n, const float* lr, int count, float weight_decay, float momentum, int first_step,
                   const float* norm_sq, float max_norm, float grad_scale, int g_dtype, int shadow_dtype,
                   int max_blocks /* 0: default 512 */, int* skipped, void* stream);
+
+/* The x3 mode's operand form (a fast mode inside the 1e-3 parity clause): x f32 [rows, K] (row stride ldx) -> out f16
+ * [rows, 3 K_pad] (row stride ldo), x = hi + lo with hi = f16(x), lo = f16(x - hi).  mode 0 (activations): [hi | hi | lo]; mode 1
+ * (weights): [hi | lo | hi] -- one f16 MFMA contraction over the 3 K_pad columns then accumulates hi.hi + hi.lo + lo.hi in fp32 (22
+ * significand bits per operand; the lo.lo term is dropped).  K_pad % 8 == 0 (the GEMMs want % 32), columns K .. K_pad - 1 are zero. */
+int sgg_split3(const float* x, int64_t ldx, int64_t rows, int K, int K_pad, void* out, int64_t ldo, int mode, void* stream);
 
 /* ---- utilities used by the host for weight preparation (load time, not on the step path) ---- */
 int sgg_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, void* stream);

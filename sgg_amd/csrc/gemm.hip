@@ -611,8 +611,9 @@ extern "C" int sgg_conv1_block(const float* in_nhwc4, const void* w1, const floa
 }
 
 extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H,
-                                int W, int Cin, int Cout, int pool, int dtype, void* stream) {
-    if (!sgg_is_dtype(dtype)) return SGG_ERR_DTYPE;
+                                int W, int Cin, int Cout, int pool, int dtype, int out_dtype, void* stream) {
+    if (!sgg_is_dtype(dtype) || !sgg_is_dtype(out_dtype)) return SGG_ERR_DTYPE;
+    if (out_dtype != dtype && pool) return SGG_ERR_ARG;       // another output type: the implicit-GEMM kernels only (no fused pool)
     const int esz = sgg_elem_size(dtype);
     const int bke = ROWB / esz;
     if (!in || !w || !out || B <= 0 || H <= 0 || W <= 0 || Cin % bke || Cout % 64 || (out_pad != 0 && out_pad != 1))
@@ -626,13 +627,14 @@ extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias
         // measured (round 2, after the scalar-base DMA went into every kernel; TFLOP/s spatial vs implicit GEMM at B=8): conv1_2 620 / 477,
         // conv2_1 594 / 558, conv2_2 781 / 750, conv3_1 749 / 826, conv3_2 881 / 981, conv4_1 781 / 795, conv4_2 849 / 890, conv5 713 / 688
         // (conv5: 37x37 there, 38x38 in the detector): the narrow layers on the patch kernel, the >= 256-channel ones on the GEMM
-        const bool want = force ? (force[0] == 's' || (force[0] == 'o' && H >= 64 && W >= 64)) : (H >= 64 && W >= 64 && Cout < 256);   // 'o': round 1's rule
+        const bool same_out = out_dtype == dtype;
+        const bool want = same_out && (force ? (force[0] == 's' || (force[0] == 'o' && H >= 64 && W >= 64)) : (H >= 64 && W >= 64 && Cout < 256));   // 'o': round 1's rule
         if (pool && ((H | W) & 1)) return SGG_ERR_ARG;
         {
             const char* pp = getenv("SGG_CONV_PP");                 // experiments: 0 = off, 42 / 22 / 24 = force the workgroup form (conv_pp.hip)
             const char* ptw = getenv("SGG_CONV_PP_TW");             //              16 / 32 = force the tile width
             const int nq = pp ? atoi(pp) : 0, tw = ptw ? atoi(ptw) : 0;
-            if (!(pp && pp[0] == '0') && !force && H >= 64 && W >= 64 && Cout >= 128) {
+            if (same_out && !(pp && pp[0] == '0') && !force && H >= 64 && W >= 64 && Cout >= 128) {
                 const int rc = sgg_launch_conv_pp(in, w, bias, out, out_pad, B, H, W, Cin, Cout, dtype, pool, nq == 42 || nq == 22 || nq == 24 ? nq : 0, tw == 16 || tw == 32 ? tw : 0, (hipStream_t)stream);
                 if (rc <= 0) return rc;
             }
@@ -648,7 +650,7 @@ extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias
     g.ldw_b = (long)9 * Cin * esz;
     g.nt = 9 * Cin / bke; g.nt1 = g.nt;
     g.bias = bias; g.C = (char*)out; g.M = B * H * W; g.N = Cout; g.act = SGG_ACT_RELU;
-    g.out_dt = dtype;
+    g.out_dt = out_dtype;
     g.H = H; g.W = W; g.Cin = Cin; g.out_pad = out_pad;
     return dispatch<true>(g, dtype, (hipStream_t)stream);
 }

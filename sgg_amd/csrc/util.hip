@@ -241,6 +241,51 @@ int sgg_reduce_parts(const float* parts, int nparts, int ncols, float* out, int 
 extern "C" int sgg_abi_version(void) { return SGG_ABI_VERSION; }
 extern "C" const char* sgg_build_info(void) { return "sgg_hip gfx950 (CDNA4) " __DATE__ " " __TIME__; }
 
+namespace {
+// Split-operand form of an fp32 matrix for the 16-bit MFMA (the x3 mode): x = hi + lo with hi = f16(x), lo = f16(x - hi)
+// (22 significand bits between them).  Row r of x[rows, K] becomes three K_pad-wide segments of f16: activations (mode 0) [hi | hi | lo],
+// weights (mode 1) [hi | lo | hi] -- so that ONE f16 contraction over 3 K_pad computes hi.hi + hi.lo + lo.hi in the MFMA's fp32
+// accumulator (the lo.lo term, 2^-22 relative, is dropped).  Columns K .. K_pad - 1 of every segment are zero.
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, long ldx, int K, int Kp, f16_t* __restrict__ out, long ldo,
+                                                     long rows, int mode) {
+    const int c8 = Kp / 8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * c8) return;
+    const long r = i / c8;
+    const int c = (int)(i - r * c8) * 8;
+    float v[8], hi[8], lo[8];
+    if (c + 8 <= K && ((reinterpret_cast<uintptr_t>(x + r * ldx + c) & 15) == 0)) {
+        load8(x + r * ldx + c, v);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = c + k < K ? x[r * ldx + c + k] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        hi[k] = round_as<f16_t>(v[k]);
+        lo[k] = v[k] - hi[k];
+    }
+    f16_t* o = out + r * ldo + c;
+    store8(o, hi);
+    store8(o + Kp, mode == 0 ? hi : lo);
+    store8(o + 2 * Kp, mode == 0 ? lo : hi);
+}
+}  // namespace
+
+// out f16 [rows, 3 * K_pad] (row stride ldo >= 3 K_pad, 16-byte aligned rows) = the split form of x f32 [rows, K] (row stride ldx);
+// K_pad % 8 == 0, K_pad >= K.  mode 0: [hi | hi | lo] (the A operand), mode 1: [hi | lo | hi] (the weights).
+extern "C" int sgg_split3(const float* x, int64_t ldx, int64_t rows, int K, int K_pad, void* out, int64_t ldo, int mode, void* stream) {
+    if (rows == 0) return SGG_OK;
+    if (!x || !out || rows < 0 || K <= 0 || K_pad < K || (K_pad & 7) || ldx < K || ldo < 3L * K_pad || (ldo & 7) || (mode != 0 && mode != 1) ||
+        ((uintptr_t)out & 15))
+        return SGG_ERR_ARG;
+    const long n = rows * (K_pad / 8);
+    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, K, K_pad, (f16_t*)out, (long)ldo,
+                       (long)rows, mode);
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
 extern "C" int sgg_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, void* stream) {
     if (n == 0) return SGG_OK;
     if (!in || !out || n < 0) return SGG_ERR_ARG;

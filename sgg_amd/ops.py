@@ -176,7 +176,7 @@ def conv1_block(x_nhwc4, w1_frags, b1, w2, b2, out, out_pad, pool=False):
 
 def conv_pool_fusable(H, W, Cout):
     """Shapes for which conv3x3_relu(pool=True) exists: the LDS-patch kernel's (wide maps, even sizes)."""
-    return H >= 64 and W >= 64 and H % 2 == 0 and W % 2 == 0 and Cout % 64 == 0
+    return H >= 64 and W >= 64 and H % 2 == 0 and W % 2 == 0 and Cout % 64 == 0 and not _SPLIT3[0]     # (x3 mode: conv, then the pool kernel)
 
 
 def conv3x3_relu(x, w, bias, out, out_pad, pool=False):
@@ -185,6 +185,18 @@ def conv3x3_relu(x, w, bias, out, out_pad, pool=False):
     B, H, W, Cin = x.shape[0], x.shape[1] - 2, x.shape[2] - 2, x.shape[3]
     Cout = w.shape[0]
     assert w.dtype == x.dtype == out.dtype
+    if _SPLIT3[0] and x.dtype == torch.float32 and Cin % 32 == 0:
+        # x3 mode: the plane and the weights as f16 (hi, lo) pairs with 3 Cin channels ([hi | hi | lo] per pixel, [hi | lo | hi] per tap),
+        # one f16 implicit-GEMM convolution with fp32 output (a zero border splits into zeros)
+        assert not pool
+        step = max(1, SPAN_LIMIT // (x.shape[1] * x.shape[2] * 3 * Cin * 2))
+        w3 = split3(w.reshape(Cout * 9, Cin), weights=True)
+        for b0 in range(0, B, step):
+            xb = x[b0:b0 + step]
+            x3 = split3(xb.reshape(-1, Cin))
+            _lib.call('sgg_conv3x3_relu', _p(x3), _p(w3), _p(bias, torch.float32), _p(out[b0:b0 + step]), out_pad, xb.shape[0], H, W, 3 * Cin, Cout, 0,
+                      SGG_F16, SGG_F32, _stream())
+        return
     per_image = x.shape[1] * x.shape[2] * Cin * x.element_size()
     if B * per_image > SPAN_LIMIT and B > 1:        # planes of 4 GiB or more (conv1_2 input above ~45 fp32 images): image blocks
         step = max(1, SPAN_LIMIT // per_image)
@@ -192,7 +204,7 @@ def conv3x3_relu(x, w, bias, out, out_pad, pool=False):
             conv3x3_relu(x[b0:b0 + step], w, bias, out[b0:b0 + step], out_pad, pool)
         return
     _lib.call('sgg_conv3x3_relu', _p(x), _p(w), _p(bias, torch.float32), _p(out), out_pad, B, H, W, Cin, Cout, int(pool),
-              dt(x), _stream())
+              dt(x), dt(out), _stream())
 
 
 def maxpool2x2(x, out, out_pad):
@@ -346,6 +358,46 @@ def bcast_add_(x, add_rc):
     return x
 
 
+# ---------------------------------------------------------------- the x3 mode
+# fp32 storage everywhere, every MFMA contraction on f16 SPLIT operands: x = hi + lo (two f16 halves, 22 significand bits), products
+# hi.hi + hi.lo + lo.hi accumulated in fp32 by ONE f16 GEMM over the 3 K concatenated segments [hi | hi | lo] . [hi | lo | hi]^T
+# (sgg_split3).  The matrix cores' 16-bit rate (2.5 PFLOP/s dense, i.e. 833 TFLOP/s of fp32-grade products) instead of
+# v_mfma_f32_32x32x2_f32's 157 TFLOP/s, results within ~1e-6 relative of the exact-fp32 mode: the fast mode that meets the north
+# star's 1e-3 clause (RelModelBase.set_compute_dtype(torch.float32, split3=True)).  Process-wide switch: the model sets it.
+_SPLIT3 = [False]
+
+
+def set_split3(on):
+    prev = _SPLIT3[0]
+    _SPLIT3[0] = bool(on)
+    return prev
+
+
+def split3_on():
+    return _SPLIT3[0]
+
+
+def split3(x, weights=False):
+    """x f32 [rows, K] (row-strided ok) -> f16 [rows, 3 * K_pad], K_pad = K rounded up to 32: [hi | hi | lo] (weights: [hi | lo | hi])"""
+    rows, K = x.shape
+    assert x.dtype == torch.float32 and x.stride(1) == 1
+    Kp = (K + 31) // 32 * 32
+    out = torch.empty((rows, 3 * Kp), dtype=torch.float16, device=x.device)
+    _lib.call('sgg_split3', _p(x, torch.float32, rows_ok=True), x.stride(0), rows, K, Kp, _p(out), out.stride(0), 1 if weights else 0, _stream())
+    return out
+
+
+def _split3_operands(A, W, A2, W2):
+    """the f16 operands [A3 | A23], [W3 | W23] of a split-operand contraction (W given whole [N, K1 + K2] or as W, W2)"""
+    K1 = A.shape[1]
+    Wa = W if (W2 is not None or A2 is None) else W[:, :K1]
+    Wb = W2 if W2 is not None else (W[:, K1:] if A2 is not None else None)
+    A3, W3 = split3(A), split3(Wa, weights=True)
+    if A2 is None:
+        return A3, W3, None, None
+    return A3, W3, split3(A2), split3(Wb, weights=True)
+
+
 # ---------------------------------------------------------------- a-7
 def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None, post_shift=None, out=None, W2=None, splits=None):
     """act([A[M,K1] | A2[M,K2]] . [W | W2]^T + bias) * post_scale + post_shift -> [M,N].
@@ -360,6 +412,10 @@ def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None
     out_dtype = out_dtype or A.dtype
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    if _SPLIT3[0] and A.dtype == torch.float32:
+        # x3 mode: the same contraction on split f16 operands (3 K columns per segment), fp32 accumulate, `out` as asked
+        A3, W3, A23, W23 = _split3_operands(A, W, A2, W2)
+        return gemm(A3, W3, bias, act, out_dtype, A23, post_scale, post_shift, out, W23, splits)
     # the kernels address an operand's rows as (uniform base + 32-bit lane offset): an A operand of 4 GiB or more (fc6 on > 85 k
     # edges in bf16, > 42 k in fp32) goes through in row blocks (SGG_ERR_SPAN is what the entry point returns otherwise)
     row_bytes = max(A.stride(0) * A.element_size(), A2.stride(0) * A2.element_size() if A2 is not None else 0)
@@ -403,6 +459,9 @@ def gemm_addrows(A, W, bias, add_rows, add_idx=None, act=ACT_NONE, out_dtype=Non
     out_dtype = out_dtype or A.dtype
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    if _SPLIT3[0] and A.dtype == torch.float32:
+        A, W = split3(A), split3(W, weights=True)
+        K = A.shape[1]
     _lib.call('sgg_gemm_addrows', _p(A, rows_ok=True), A.stride(0), _p(W, rows_ok=True), W.stride(0),
               _p(bias, torch.float32) if bias is not None else None, _p(add_rows, torch.float32, rows_ok=True), add_rows.stride(0),
               _p(add_idx, torch.int32) if add_idx is not None else None, _p(out, rows_ok=True), out.stride(0), M, N, K, act, dt(A), dt(out),
@@ -460,6 +519,8 @@ def gemm_full_waves(A, W, out_dtype=None, gadd=None):
         if gadd is None:
             return gemm(A, Wp, out=out, out_dtype=out_dtype)
         r, group = gadd
+        if _SPLIT3[0] and A.dtype == torch.float32:          # x3 mode: the split-operand GEMM, then the group addend as its own pass
+            return group_bcast_add_(gemm(A, Wp, out=out, out_dtype=out_dtype), r, group, col0=col0)
         if out is None:
             out = torch.empty((M, Wp.shape[0]), dtype=out_dtype or A.dtype, device=A.device)
         _lib.call('sgg_gemm_groupadd', _p(A, rows_ok=True), A.stride(0), _p(Wp, rows_ok=True), Wp.stride(0), _p(r, torch.float32, rows_ok=True),

@@ -175,13 +175,20 @@ class RelModelBase(nn.Module):
     def forward(self, batch):
         raise NotImplementedError('forward')
 
-    def set_compute_dtype(self, dtype):
+    def set_compute_dtype(self, dtype, split3=False):
         """torch.float32 = exact-fp32 MFMA mode (the reference's own precision: the 1e-3 parity bar); torch.float16 / torch.bfloat16 =
         16-bit storage and MFMA operands with fp32 accumulation -- the same kernels at the same rates.  float16 (11-bit significand) is the
         throughput mode whose logits stay within 0.1 / 0.03 of the reference's (DESIGN.md "f16"); bfloat16 (8 bits, wider exponent) is kept
         as BASELINE.json words its configuration: 8 times the rounding error, no loss scaling needed in training."""
         ops.dt(dtype)
+        if split3 and dtype != torch.float32:
+            raise ValueError('split3 (the x3 mode) is a form of the fp32 mode: set_compute_dtype(torch.float32, split3=True)')
         self.compute_dtype = dtype
+        # x3 mode (sgg_amd/ops.py "the x3 mode"): fp32 storage and element-wise arithmetic as in the exact-fp32 mode, every MFMA contraction on
+        # f16 split operands (hi + lo, three products, fp32 accumulate): fp32-grade logits (within the 1e-3 clause) at several times the
+        # exact mode's rate.  The switch is process-wide (ops.set_split3): one compute mode at a time.
+        self.split3 = bool(split3)
+        ops.set_split3(self.split3)
         return self
 
     def spatial_scale(self, im_sizes):

@@ -221,6 +221,7 @@ def detect(model, fmap, image_sizes, padded_hw, orig_sizes, spatial_scale, pyram
         scales = [2.0 ** round(math.log2(float(m.shape[1]) / top)) for m in box_maps]      # [3P] MultiScaleRoIAlign.infer_scale
     rois, offs_h = propose(model, w, rpn_maps, img_hw, padded_hw)
     K = offs_h[-1]
+    det.last_proposals = K          # (bench.py prices the box head's contractions with it)
     if K == 0:
         raise ValueError('at least two objects must be detected to build relationships, make sure the detector is properly '
                          'pretrained', [])

@@ -223,3 +223,76 @@ def test_two_ranks_stay_bit_equal_over_20_steps_and_survive_a_rank0_only_pass(cf
     assert got[0][3] and got[1][3]
     tot = [a + b for a, b in zip(got[0][0], got[1][0])]         # per-rank losses are local sums over global normalisers
     assert tot[-1] < tot[0] and all(np.isfinite(tot))
+
+
+def _worker8(rank, world, port, cfg, q):
+    """one image per rank of an 8-image global batch (ragged box counts): whole Trainer steps, sharded optimiser over 8 ranks"""
+    os.environ.update(RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from sgg_amd.synthetic import shard_batch, synthetic_batch
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dtype, comm, steps, opts = cfg
+    g = synthetic_batch(B=8, S=S, n_boxes=6, n_fg=3, seed=33, counts=[6, 3, 5, 2, 7, 4, 6, 3])
+    losses, w, rm, tr = _one_step(dtype, comm, shard_batch(g, rank, rank + 1), steps, opts)
+    assert tr.dist_on and tr.world == 8 and tr.shard_optimizer
+    big = [p for p in tr.buckets.big]
+    assert len(big) >= 4 and all(tr.buckets.shard_of(p) == (rank * p.numel() // 8, (rank + 1) * p.numel() // 8) for p in big)
+    q.put((rank, losses, {n: w[n] for n in NAMES[:6]} if rank else w, rm))      # (rank 0 sends every tensor, the others a few: the queue stays small)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_8_whole_trainer_steps_equal_single_process_on_concatenated_batch():
+    """the WHOLE data-parallel step at the world size of the target node (8 ranks, here sharing one GPU over gloo) --
+    f16 compute with the loss scale, bf16 wire, gradient hooks inside the backward, reduce-scatter over 8 parts, sharded fused SGD,
+    all-gather of the updated operands, synchronised BatchNorm, global loss normalisers, the update pipelined on the side stream --
+    against ONE process on the concatenated 8-image batch: losses add up, every rank ends with the single-process weights."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    cfg = (torch.float16, torch.bfloat16, 2, dict(sync_bn=True, pipeline=True))
+    dtype, comm, steps, opts = cfg
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, cfg, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    import queue
+    import time
+    got = {}
+    t0 = time.time()
+    while len(got) < len(procs):
+        try:
+            r, losses, w, rm = q.get(timeout=5)
+            got[r] = (losses, w, rm)
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > 900:
+                for p in procs:
+                    p.kill()
+                pytest.fail('a rank exited with %s (or the steps timed out)' % dead)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    from sgg_amd.synthetic import synthetic_batch
+    g = synthetic_batch(B=8, S=S, n_boxes=6, n_fg=3, seed=33, counts=[6, 3, 5, 2, 7, 4, 6, 3])
+    ref_losses, ref_w, ref_rm, _ = _one_step(dtype, comm, g, steps, dict(pipeline=True))
+    import sgg_amd
+    from sgg_amd.synthetic import SyntheticData, init_weights
+    w0 = {n: p.detach().float().numpy() for n, p in
+          init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls', min_size=S, max_size=S)).named_parameters() if n in NAMES}
+    for k in range(steps):
+        tot = sum(got[r][0][k] for r in range(8))
+        assert abs(tot - ref_losses[k]) <= 3e-2 * abs(ref_losses[k]), (k, tot, ref_losses[k])
+    for n in NAMES:
+        step = np.abs(ref_w[n] - w0[n]).max()
+        assert step > 0, n
+        for r in range(8):
+            if n not in got[r][1]:
+                continue
+            diff = np.abs(got[r][1][n] - ref_w[n]).max()
+            assert diff <= 0.15 * step + 1e-8, (n, r, float(step), float(diff))
+            np.testing.assert_allclose(got[r][1][n], got[0][1][n], rtol=0, atol=1e-6 * max(1.0, float(np.abs(ref_w[n]).max())))
+    for r in range(8):
+        np.testing.assert_allclose(got[r][2], ref_rm, atol=2e-2)

@@ -74,8 +74,11 @@ def test_bench_config_bf16_logits_within_stated_tolerance():
     t_ref = time.time() - t0
     ref_od, ref_rd = ref['rm_obj_dists'].numpy(), ref['rel_dists'].numpy()
     report = {'config': '8 x 592x592, 32 boxes, 992 edges per image, seed 111', 'oracle_seconds': round(t_ref, 1)}
-    for name, dt in (('f32', torch.float32), ('f16', torch.float16), ('bf16', torch.bfloat16)):
-        model.set_compute_dtype(dt)
+    for name, dt in (('f32', torch.float32), ('x3', 'x3'), ('f16', torch.float16), ('bf16', torch.bfloat16)):
+        if dt == 'x3':
+            model.set_compute_dtype(torch.float32, split3=True)      # the fast mode inside the 1e-3 clause: f16 split operands, fp32 accumulate
+        else:
+            model.set_compute_dtype(dt)
         od, rd, rel_inds = _logits(model, batch)
         np.testing.assert_array_equal(rel_inds, ref['rel_inds'])
         assert od.shape == (256, 151) and rd.shape == (7936, 51)
@@ -85,10 +88,14 @@ def test_bench_config_bf16_logits_within_stated_tolerance():
                         'rel_logit_absmax': float(np.abs(ref_rd).max()),
                         'obj_argmax_agreement': float((od[:, 1:].argmax(1) == ref_od[:, 1:].argmax(1)).mean()),
                         'rel_argmax_agreement': float((rd[:, 1:].argmax(1) == ref_rd[:, 1:].argmax(1)).mean())}
-    _dump('r03_parity_bench_config.json', report)
+    model.set_compute_dtype(torch.float16)
+    _dump('r04_parity_bench_config.json', report)
     print(json.dumps(report, indent=1))
     f32, f16, b16 = report['f32'], report['f16'], report['bf16']
     assert f32['obj_max_abs'] <= 1e-3 and f32['rel_max_abs'] <= 1e-3, f32                 # the north star's fp32 bar, at full size
+    x3 = report['x3']
+    assert x3['obj_max_abs'] <= 1e-3 and x3['rel_max_abs'] <= 1e-3, x3                    # ... which the x3 mode meets too
+    assert x3['obj_argmax_agreement'] == 1.0 and x3['rel_argmax_agreement'] == 1.0, x3
     assert f16['obj_max_abs'] <= F16_MAX_ABS['obj'] and f16['rel_max_abs'] <= F16_MAX_ABS['rel'], f16
     assert f16['obj_mean_abs'] <= F16_MEAN_ABS['obj'] and f16['rel_mean_abs'] <= F16_MEAN_ABS['rel'], f16
     assert f16['obj_argmax_agreement'] >= 0.97 and f16['rel_argmax_agreement'] >= 0.99, f16

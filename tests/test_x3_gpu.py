@@ -1,0 +1,143 @@
+"""The x3 mode (sgg_amd/ops.py "the x3 mode", sgg_split3): fp32 storage, every MFMA contraction on f16 SPLIT operands
+(x = hi + lo; hi.hi + hi.lo + lo.hi accumulated in fp32 by one f16 GEMM over 3 K columns).  Results must be fp32-grade: contractions
+within ~1e-6 relative of float64, the model's logits within the north star's 1e-3 of the CPU oracle (in fact within 1e-4 of the
+exact-fp32 mode), gradients equal to the exact mode's, a Trainer run."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sgg_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+S = 96
+
+
+@pytest.fixture()
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from sgg_amd import ops
+    prev = ops.set_split3(False)
+    yield ops
+    ops.set_split3(prev)
+
+
+def test_split3_halves_reconstruct_the_operand(ops):
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(37, 200, generator=g) * torch.logspace(-4, 2, 200)).to(DEV)       # magnitudes over six decades
+    for weights in (False, True):
+        s3 = ops.split3(x, weights=weights).float()
+        Kp = 224
+        assert s3.shape == (37, 3 * Kp)
+        hi, a, b = s3[:, :200], s3[:, Kp:Kp + 200], s3[:, 2 * Kp:2 * Kp + 200]
+        lo = a if weights else b
+        assert torch.equal(hi, b if weights else a)
+        assert float(s3[:, 200:Kp].abs().max()) == 0 and float(s3[:, Kp + 200:2 * Kp].abs().max()) == 0
+        assert torch.equal(hi, x.half().float())
+        err = (hi.double() + lo.double() - x.double()).abs()
+        # 22 significand bits where lo is a normal f16 number; an absolute floor of half an f16 subnormal step (3e-8) below that
+        assert bool((err <= x.double().abs() * 2.0 ** -21 + 3.1e-8).all()), float(err.max())
+
+
+@pytest.mark.parametrize('M,N,K', [(300, 520, 512), (1024, 4096, 25088), (256, 151, 4096), (3968, 256, 98)])
+def test_x3_gemm_is_fp32_grade(ops, M, N, K):
+    g = torch.Generator().manual_seed(M + K)
+    Kp = (K + 15) // 16 * 16
+    A = torch.zeros(M, Kp)
+    W = torch.zeros(N, Kp)
+    A[:, :K] = torch.randn(M, K, generator=g).relu() * 3
+    W[:, :K] = torch.randn(N, K, generator=g) * (2.0 / K) ** 0.5
+    bias = torch.randn(N, generator=g)
+    ref = (A.double() @ W.double().t() + bias.double()).relu()
+    A, W, bias = A.to(DEV), W.to(DEV), bias.to(DEV)
+    exact = ops.gemm(A, W, bias=bias, act=ops.ACT_RELU).double().cpu()
+    ops.set_split3(True)
+    got = ops.gemm(A, W, bias=bias, act=ops.ACT_RELU)
+    ops.set_split3(False)
+    assert got.dtype == torch.float32
+    scale = float(ref.abs().max())
+    e_x3, e_f32 = float((got.double().cpu() - ref).abs().max()) / scale, float((exact - ref).abs().max()) / scale
+    print('K=%d: x3 %.2e, exact-fp32 MFMA %.2e (relative to the largest output)' % (K, e_x3, e_f32))
+    assert e_x3 <= 4e-6, (e_x3, e_f32)
+    # two K segments (fc6's fold) and the gathered-row addend of the pair path
+    A2 = (torch.randn(M, 64, generator=g)).to(DEV)
+    W2 = (torch.randn(N, 64, generator=g) / 8).to(DEV)
+    ref2 = A.double().cpu() @ W.double().cpu().t() + A2.double().cpu() @ W2.double().cpu().t()
+    ops.set_split3(True)
+    got2 = ops.gemm(A, W, A2=A2, W2=W2)
+    rows = torch.randn(7, N, generator=g).to(DEV)
+    idx = torch.randint(0, 7, (M,), generator=g).int().to(DEV)
+    got3 = ops.gemm_addrows(A, W, bias, rows, idx)
+    ops.set_split3(False)
+    assert float((got2.double().cpu() - ref2).abs().max()) <= 4e-6 * float(ref2.abs().max())
+    ref3 = A.double().cpu() @ W.double().cpu().t() + rows.double().cpu()[idx.long().cpu()] + bias.double().cpu()
+    assert float((got3.double().cpu() - ref3).abs().max()) <= 4e-6 * float(ref3.abs().max())
+
+
+def test_x3_conv_is_fp32_grade(ops):
+    B, H, Wd, Ci, Co = 2, 76, 76, 64, 128
+    g = torch.Generator().manual_seed(5)
+    x = torch.zeros(B, H + 2, Wd + 2, Ci)
+    x[:, 1:-1, 1:-1] = torch.randn(B, H, Wd, Ci, generator=g).relu()
+    w = torch.randn(Co, 3, 3, Ci, generator=g) * (2.0 / (9 * Ci)) ** 0.5
+    b = torch.randn(Co, generator=g) * 0.1
+    ref = torch.nn.functional.conv2d(x[:, 1:-1, 1:-1].permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=1).relu()
+    ops.set_split3(True)
+    out = torch.zeros(B, H + 2, Wd + 2, Co, device=DEV)
+    ops.conv3x3_relu(x.to(DEV), w.to(DEV), b.to(DEV), out, 1)
+    ops.set_split3(False)
+    got = out[:, 1:-1, 1:-1].permute(0, 3, 1, 2).double().cpu()
+    assert float(out[:, 0].abs().max()) == 0 and float(out[:, :, -1].abs().max()) == 0          # the zero border is untouched
+    assert float((got - ref).abs().max()) <= 4e-6 * float(ref.abs().max())
+
+
+def test_x3_model_forward_gradients_and_trainer(ops):
+    import sgg_amd
+    from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
+    from sgg_amd.trainer import Trainer
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls', min_size=S, max_size=S))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV).eval()
+    batch = synthetic_batch(B=3, S=S, n_boxes=7, n_fg=3, seed=5, ragged=True)
+    with torch.no_grad():
+        ref = O.forward_gtbox(batch[0], batch[3], batch[4], batch[5], sd, min_size=S, max_size=S)['dets']
+        model.set_compute_dtype(torch.float32)
+        exact = model([tuple(batch)])
+        model.set_compute_dtype(torch.float32, split3=True)
+        assert ops.split3_on() and model.split3
+        got = model([tuple(batch)])
+    np.testing.assert_array_equal(got[3], ref[3])
+    np.testing.assert_allclose(got[4], ref[4], atol=1e-3)                 # the north star's bar, against the CPU oracle
+    np.testing.assert_allclose(got[2], ref[2], atol=1e-3)
+    np.testing.assert_allclose(got[4], exact[4], atol=1e-4)               # and as good as the exact-fp32 MFMA mode
+    # gradients: train-mode forward + backward in both modes
+    model.train()
+    model.dropout_p = 0.0
+    grads = {}
+    for split in (False, True):
+        model.load_state_dict(sd)
+        model.set_compute_dtype(torch.float32, split3=split)
+        res = model([tuple(batch)])
+        g = torch.Generator().manual_seed(0)
+        Wo = torch.randn(res.rm_obj_dists.shape, generator=g).to(DEV)
+        Wr = torch.randn(res.rel_dists.shape, generator=g).to(DEV)
+        model.zero_grad()
+        ((res.rm_obj_dists * Wo).sum() + (res.rel_dists * Wr).sum()).backward()
+        grads[split] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    assert len(grads[True]) == len(grads[False]) >= 30
+    for n, ge in grads[False].items():
+        gx = grads[True][n]
+        assert float((gx - ge).abs().max()) <= 2e-4 * float(ge.abs().max()) + 1e-7, n
+    # a Trainer run in the x3 mode
+    model.load_state_dict(sd)
+    model.set_compute_dtype(torch.float32, split3=True)
+    tr = Trainer(model, lr=2e-2)
+    losses = [float(tr.step(tuple(batch))) for _ in range(8)]
+    tr.flush()
+    assert losses[-1] < 0.9 * losses[0], losses
+    assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
+    model.set_compute_dtype(torch.float16)
+    model.eval()
+    model.dropout_p = 0.5
+    assert not ops.split3_on()
