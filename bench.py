@@ -152,9 +152,9 @@ def kernel_times(step_fn, reps):
 
 
 def pmc_traffic(key):
-    """HBM-side bytes per launch READ FROM the committed rocprofv3 PMC passes (profiles/pmc_r03.json, else earlier rounds') -- collected
+    """HBM-side bytes per launch READ FROM the committed rocprofv3 PMC passes (profiles/pmc_r04.json, else earlier rounds') -- collected
     by tools/pmc_traffic.sh on the same workload, not measured inside this run -- or None."""
-    for name in ('pmc_r03.json', 'pmc_r02.json', 'pmc_r01.json'):
+    for name in ('pmc_r04.json', 'pmc_r03.json', 'pmc_r02.json', 'pmc_r01.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 return json.load(f)[key]['traffic_bytes']
@@ -215,7 +215,7 @@ def imp_iter_ms(model, B, dtype, reps=50, kind='ctx'):
     ed = (e.float() @ imp.gate_w[:, H:].t()).contiguous()
     form = {'ctx': None, 'ctx_sliced': 's', 'ctx_mfma': 'm', 'ctx_lists': 'l'}.get(kind, None)
     if kind == 'gate_proj':
-        gh = torch.randn(E, 3 * H, generator=g).to(dev)
+        gh = torch.randn(E, 3 * H, generator=g).to(dev).to(ops.gh_dtype(dtype))      # as the GEMM in front of it hands it over
         P = torch.randn(N, 3 * H, generator=g).to(dev)
         out, dots = torch.empty_like(e), torch.empty((E, 4), dtype=torch.float32, device=dev)
         launch = lambda: ops.gru_gate_proj(gh, P, imp.edge_gru_b_ih, csr, nd, ed, imp.gate_b, e, out=out, dot_w=imp.gate_w[:, H:], dots=dots)

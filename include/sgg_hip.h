@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGG_ABI_VERSION 8   /* bump whenever a prototype below changes: tests/abi.lock pins (version, digest of the prototypes) */
+#define SGG_ABI_VERSION 10   /* bump whenever a prototype below changes: tests/abi.lock pins (version, digest of the prototypes) */
 
 enum { SGG_F32 = 0, SGG_BF16 = 1, SGG_F16 = 2 };
 enum { SGG_ACT_NONE = 0, SGG_ACT_RELU = 1 };
@@ -240,10 +240,11 @@ int sgg_gru_gate_fwd(const void* gi, const void* gh, const float* b_hh, const vo
  *   in registers so that no IMP kernel ever needs a whole row.  Needs H/8 a power of two <= 64. */
 /* The edge GRU of a message-passing iteration, e_{i+1} = GRU_e(e_in, e_i) (:83), from the node projection instead of e_in rows:
  *   gi[e] = g_sub(e) P[s] + g_obj(e) P[o] + b_ih  with P = v_i W_ih^T f32[N,3H] (no bias), gates from node_dots / edge_dots / gate_b (a-8);
- *   gh f32[M,3H] = e_i W_hh^T + b_hh;  h_prev = e_i;  so i32[M,2] = (subject, object) node rows.  dots as above. */
-int sgg_gru_gate_proj_fwd(const float* gh, const float* P, const float* b_ih, const int* so, const float* node_dots, const float* edge_dots,
+ *   gh [M,3H] (gh_dtype) = e_i W_hh^T + b_hh;  h_prev = e_i;  so i32[M,2] = (subject, object) node rows.  dots as above. */
+int sgg_gru_gate_proj_fwd(const void* gh, const float* P, const float* b_ih, const int* so, const float* node_dots, const float* edge_dots,
                           const float* gate_b, const void* h_prev, void* h_out, int M, int H, const float* dot_w, int dot_ld, float* dots,
-                          int dtype, void* stream);
+                          int dtype, int gh_dtype /* SGG_F32, or dtype: gh straight out of the GEMM's epilogue in the state's 16-bit type */,
+                          void* stream);
 
 /* ---- a-11  eval tail: rel_model_stanford.py:183-207 + filter_dets, lib/surgery.py:17-55 ----
  * obj: softmax over C classes, best class in 1..C-1 and its prob (sgcls/sgdet), or score 1 / given class (predcls
@@ -273,6 +274,12 @@ int sgg_segmented_sort_desc(const float* keys_in, float* keys_out, int* vals_tmp
 int sgg_gather_topk(const float* keys_sorted, const int* vals_sorted, const int* seg_off, const float* boxes,
                     const int* labels_in, const float* img_hw, int B, int take, float min_size, float* out_boxes,
                     float* out_scores, int* out_labels, unsigned char* valid, void* stream);
+/* The two calls above in one, for take <= 4096: the `take` best-scoring candidates of every segment, best first, equal scores by lower
+ * index (the order of the stable sort), gathered / clipped / validated like sgg_gather_topk -- a 4-pass radix SELECT over the segment's
+ * scores + an LDS bitonic sort of the selected ones, one workgroup per image; nothing that is not wanted is sorted. */
+int sgg_topk_gather(const float* scores, const int* seg_off, const float* boxes, const int* labels_in, const float* img_hw, int B,
+                    int take, float min_size, float* out_boxes, float* out_scores, int* out_labels, unsigned char* valid,
+                    void* stream);
 int sgg_nms(const float* boxes, const int* labels, const unsigned char* valid, int B, int n, float thresh, int max_keep,
             void* mask_ws, int* keep_idx, int* keep_cnt, void* stream);
 int sgg_compact_rois(const float* boxes, const int* keep_idx, const int* keep_cnt, int B, int n, int max_keep, float* rois,
@@ -343,9 +350,9 @@ int sgg_gru_gate_bwd(const void* dh, const float* gi, const float* gh, const flo
                      void* d_gh, void* dh_prev, int M, int H, int dtype, void* stream);
 /* backward of sgg_gru_gate_proj_fwd: from dh[M,H], the saved gh and P (recomputes gi and the cell) -> d_gi, d_gh [M,3H], dh_prev [M,H],
  * and dq f32[M,2] = (d_gi[e] . P[s], d_gi[e] . P[o]): the gradients of the scalar gates g_sub, g_obj before their sigmoids' derivative. */
-int sgg_gru_gate_proj_bwd(const void* dh, const float* gh, const float* P, const float* b_ih, const int* so, const float* node_dots,
+int sgg_gru_gate_proj_bwd(const void* dh, const void* gh, const float* P, const float* b_ih, const int* so, const float* node_dots,
                           const float* edge_dots, const float* gate_b, const void* h_prev, void* d_gi, void* d_gh, void* dh_prev,
-                          float* dq, int M, int H, int dtype, void* stream);
+                          float* dq, int M, int H, int dtype, int gh_dtype, void* stream);
 /* backward of one message-passing step's gates and context sums (rel_model_stanford.py:76-91), e = (s, o):
  * edge side: d_e[e] += g_out*d_ctx[s] + g_in*d_ctx[o] + sum_k da_k*w_k[H:];  da[E,4] = gate pre-activation gradients (order sub,obj,out,in):
  *   da_sub = dq[e,0] g_sub(1-g_sub), da_obj = dq[e,1] g_obj(1-g_obj), da_out = (d_ctx[s].e) g_out(1-g_out), da_in = (d_ctx[o].e) g_in(1-g_in).

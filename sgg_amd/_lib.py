@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('SGG_HIP_LIB') or os.path.join(_HERE, 'libsgg_hip.so')
 
 SGG_F32, SGG_BF16, SGG_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 10
 
 _P, _I, _F, _L = c_void_p, c_int, c_float, c_int64
 
@@ -51,8 +51,8 @@ SIGNATURES = {
     'sgg_imp_ctx_mfma_min_units': [],
     # x, so, out_ptr, out_ids, in_ptr, in_ids, img_ptr, B, N, E, H, node_dots, edge_dots, gate_b, pair, out, max_edges, max_nodes, sum_ctx, dtype, stream
     'sgg_imp_ctx_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
-    'sgg_gru_gate_proj_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P],
-    'sgg_gru_gate_proj_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    'sgg_gru_gate_proj_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _P],
+    'sgg_gru_gate_proj_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sgg_imp_edge_ctx_bwd': [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     'sgg_imp_node_gates_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
     'sgg_graph_ptr': [_P, _I, _I, _P, _P, _P],
@@ -66,6 +66,7 @@ SIGNATURES = {
     'sgg_rpn_decode': [_P, _I, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P],
     'sgg_segmented_sort_desc': [_P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P],
     'sgg_gather_topk': [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P],
+    'sgg_topk_gather': [_P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P],
     'sgg_nms': [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P],
     'sgg_compact_rois': [_P, _P, _P, _I, _I, _I, _P, _P, _P],
     'sgg_det_candidates': [_P, _I, _P, _I, _I, _P, _F, _F, _P, _P, _P, _P],

@@ -101,6 +101,151 @@ __global__ __launch_bounds__(256) void gather_topk_kernel(const float* __restric
     valid[i] = ok ? 1 : 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Top-k of every image's candidates, best first -- what sgg_segmented_sort_desc + sgg_gather_topk produce, without sorting the
+// candidates that are not wanted (RPN: the 1000 best of 21 660 anchors; detections: the 4096 best of up to 150 000 (proposal, class)
+// pairs per image -- round 2-3 sorted all 1.2 M of them with rocPRIM: 0.65 ms of a 6.7-ms step).  One 1024-thread workgroup per image:
+//   1. float -> order-preserving u32 key; 4-pass MSB radix SELECT (256-bin LDS histogram per pass, only keys that match the prefix
+//      found so far are counted) -> the threshold key thr and how many candidates equal to it are still needed;
+//   2. candidates with key > thr (any order) and the `need` lowest-indexed ones with key == thr (an ordered block scan, only when
+//      more tie than are needed) go into LDS as 64-bit (key, ~index) words -- all distinct;
+//   3. bitonic sort of those <= 4096 words, descending: score descending, index ascending = the order of a stable descending sort;
+//   4. the gather of gather_topk_kernel (clip to the image, validity).
+// Each pass streams the image's scores once from L2 (600 KB for 150 000 candidates).
+// ------------------------------------------------------------------------------------------------
+constexpr int TOPK_MAX = 4096;
+__device__ __forceinline__ unsigned topk_key(float f) {
+    if (f != f) return 0u;                                       // NaN: never selected before a real score
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__global__ __launch_bounds__(1024) void topk_gather_kernel(const float* __restrict__ scores, const int* __restrict__ seg_off,
+                                                           const float* __restrict__ boxes, const int* __restrict__ labels_in,
+                                                           const float* __restrict__ img_hw, int take, float min_size,
+                                                           float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                           int* __restrict__ out_labels, unsigned char* __restrict__ valid) {
+    __shared__ unsigned long long sel[TOPK_MAX];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_eq, s_cnt, s_wave[16];
+    __shared__ int s_need;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int s0 = seg_off[b], n = seg_off[b + 1] - s0;
+    const int T = min(min(take, n), TOPK_MAX);
+    const float* sc = scores + s0;
+    unsigned prefix = 0u, mask = 0u;
+    int need = T;
+    for (int pass = 3; pass >= 0 && T > 0; --pass) {
+        const int shift = pass * 8;
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        for (int i = tid; i < n; i += 1024) {
+            const unsigned k = topk_key(sc[i]);
+            if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int cum = 0, d = 255;
+            for (; d > 0; --d) {
+                if (cum + (int)hist[d] >= need) break;
+                cum += (int)hist[d];
+            }
+            s_prefix = prefix | ((unsigned)d << shift);
+            s_need = need - cum;
+            s_eq = hist[d];
+        }
+        __syncthreads();
+        prefix = s_prefix;
+        need = s_need;
+        mask |= 0xffu << shift;
+    }
+    const unsigned thr = prefix;
+    const int eq_total = (int)s_eq;                              // candidates with key == thr; `need` (>= 1) of them are taken
+    if (tid == 0) s_cnt = 0u;
+    __syncthreads();
+    // (a) every candidate above the threshold: exactly T - need of them, in arrival order (the sort below orders them)
+    for (int i = tid; i < n && T > 0; i += 1024) {
+        const unsigned k = topk_key(sc[i]);
+        if (k > thr) sel[atomicAdd(&s_cnt, 1u)] = ((unsigned long long)k << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+    }
+    __syncthreads();
+    const int base = T - need;
+    if (tid == 0) s_cnt = 0u;
+    __syncthreads();
+    // (b) `need` of the candidates AT the threshold: the lowest indices (a stable sort's order) -- by an ordered block scan when more
+    // tie than are needed; when all of them are taken, or the tie is at -inf (entries that are invalid whichever they are), in
+    // arrival order
+    const bool ordered_ties = T > 0 && eq_total > need && thr != topk_key(-INFINITY);
+    if (!ordered_ties) {
+        for (int i = tid; i < n && T > 0; i += 1024) {
+            if (topk_key(sc[i]) == thr) {
+                const unsigned c = atomicAdd(&s_cnt, 1u);
+                if (c < (unsigned)need) sel[base + c] = ((unsigned long long)thr << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+            }
+        }
+    } else {
+        int taken = 0;                                           // (uniform: every thread keeps the same count)
+        for (int c0 = 0; c0 < n && taken < need; c0 += 1024) {
+            const int i = c0 + tid;
+            const bool eq = i < n && topk_key(sc[i]) == thr;
+            const unsigned long long bal = __ballot(eq);
+            if (lane == 0) s_wave[wv] = (unsigned)__popcll(bal);
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int w = 0; w < 16; ++w) {
+                if (w < wv) before += (int)s_wave[w];
+                total += (int)s_wave[w];
+            }
+            const int rank = taken + before + (int)__popcll(bal & ((1ull << lane) - 1ull));
+            if (eq && rank < need) sel[base + rank] = ((unsigned long long)thr << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+            taken += total;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // pad to a power of two with the lowest word, sort descending
+    int P2 = 1;
+    while (P2 < T) P2 <<= 1;
+    for (int i = T + tid; i < P2; i += 1024) sel[i] = 0ull;
+    __syncthreads();
+    for (int k = 2; k <= P2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P2; i += 1024) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned long long a = sel[i], c = sel[p];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? a < c : a > c) {
+                        sel[i] = c;
+                        sel[p] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int r = tid; r < take; r += 1024) {
+        bool ok = r < T;
+        float scv = -INFINITY;
+        Box bx{0, 0, 0, 0};
+        int lab = 0;
+        if (ok) {
+            const unsigned idx = 0xffffffffu - (unsigned)(sel[r] & 0xffffffffull);
+            scv = sc[idx];
+            const long src = (long)s0 + idx;
+            const float* p = boxes + src * 4;
+            bx = clip(Box{p[0], p[1], p[2], p[3]}, img_hw[b * 2], img_hw[b * 2 + 1]);
+            if (labels_in) lab = labels_in[src];
+            ok = (scv > -INFINITY) && (bx.x2 - bx.x1 >= min_size) && (bx.y2 - bx.y1 >= min_size);
+        }
+        const long o = (long)b * take + r;
+        float* ob = out_boxes + o * 4;
+        ob[0] = bx.x1; ob[1] = bx.y1; ob[2] = bx.x2; ob[3] = bx.y2;
+        out_scores[o] = scv;
+        if (out_labels) out_labels[o] = lab;
+        valid[o] = ok ? 1 : 0;
+    }
+}
+
 // NMS suppression bit-matrix: mask[b][i][w] bit j = (j > i) && IoU(i,j) > thresh [&& same label]
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ labels,
                                                       const unsigned char* __restrict__ valid, int n, int nw, float thresh,
@@ -140,6 +285,73 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* 
         if (lane + 64 < nw) removed[1] |= row[lane + 64];
     }
     if (lane == 0) keep_cnt[b] = cnt;
+}
+
+// Greedy NMS when only a few boxes are kept (detections: <= 50 of 4096 candidates): the suppression rows of the KEPT boxes only,
+// computed when a box is kept -- round 2-3 built the whole n x n bit-matrix first (nms_mask_kernel: 2 M workgroups for n = 4096,
+// 0.46 ms) and scanned it with one wave (0.2 ms).  One 1024-thread workgroup per image, boxes / labels in LDS; the alive set is a
+// bitmap of 64 words (wave w owns words w, w+16, w+32, w+48: lane = bit); per kept box: wave 0 finds the next alive candidate
+// (64 lanes x one word each, a min-reduce), everybody tests its candidates behind it against that box, each wave clears the
+// suppressed bits of its own words with a ballot -- no atomics, the order of kept boxes is the score order.
+constexpr int NMS_LAZY_N = 4096;
+__global__ __launch_bounds__(1024) void nms_lazy_kernel(const float* __restrict__ boxes, const int* __restrict__ labels,
+                                                        const unsigned char* __restrict__ valid, int n, float thresh, int max_keep,
+                                                        int* __restrict__ keep_idx, int* __restrict__ keep_cnt) {
+    __shared__ float4 sbox[NMS_LAZY_N];
+    __shared__ int slab[NMS_LAZY_N];
+    __shared__ unsigned long long alive[64];
+    __shared__ int s_next;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int j = tid; j < NMS_LAZY_N; j += 1024) {
+        if (j < n) {
+            sbox[j] = *reinterpret_cast<const float4*>(boxes + ((long)b * n + j) * 4);
+            slab[j] = labels ? labels[(long)b * n + j] : 0;
+        }
+    }
+    for (int q = 0; q < 4; ++q) {                              // this wave's four words of the alive bitmap
+        const int w = wv + 16 * q, j = w * 64 + lane;
+        const unsigned long long m = __ballot(j < n && valid[(long)b * n + j]);
+        if (lane == 0) alive[w] = m;
+    }
+    __syncthreads();
+    int cnt = 0, cur = 0;
+    while (cnt < max_keep) {
+        if (wv == 0) {                                           // first alive candidate at or behind `cur`
+            unsigned long long m = alive[lane];
+            const int w0 = cur >> 6;
+            if (lane < w0) m = 0ull;
+            else if (lane == w0) m &= ~0ull << (cur & 63);
+            int first = m ? lane * 64 + __builtin_ctzll(m) : 0x7fffffff;
+            for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off, 64));
+            if (lane == 0) s_next = first;
+        }
+        __syncthreads();
+        const int i = s_next;
+        if (i >= n) break;                                       // (uniform)
+        if (tid == 0) keep_idx[(long)b * max_keep + cnt] = i;
+        ++cnt;
+        cur = i + 1;
+        const float4 bi = sbox[i];
+        const int li = slab[i];
+        const float a1 = (bi.z - bi.x) * (bi.w - bi.y);
+        for (int q = 0; q < 4; ++q) {
+            const int w = wv + 16 * q, j = w * 64 + lane;
+            if (w * 64 + 63 <= i) continue;                      // (uniform per wave: the whole word lies in front of box i)
+            bool kill = false;
+            if (j > i && j < n && ((alive[w] >> lane) & 1ull) && slab[j] == li) {
+                const float4 bj = sbox[j];
+                const float a2 = (bj.z - bj.x) * (bj.w - bj.y);
+                const float iw = fmaxf(fminf(bi.z, bj.z) - fmaxf(bi.x, bj.x), 0.f);
+                const float ih = fmaxf(fminf(bi.w, bj.w) - fmaxf(bi.y, bj.y), 0.f);
+                const float inter = iw * ih;
+                kill = inter / (a1 + a2 - inter) > thresh;
+            }
+            const unsigned long long km = __ballot(kill);
+            if (lane == 0 && km) alive[w] &= ~km;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) keep_cnt[b] = cnt;
 }
 
 // compact kept boxes of all images into rois [total,5] = (img, box); offsets[b] = first row of image b
@@ -257,6 +469,18 @@ extern "C" int sgg_gather_topk(const float* keys_sorted, const int* vals_sorted,
     return SGG_OK;
 }
 
+// The `take` (<= 4096) best-scoring candidates of every segment, best first (ties: lower index first), gathered like sgg_gather_topk:
+// = sgg_segmented_sort_desc + sgg_gather_topk without sorting what is not wanted (radix select + LDS bitonic sort, one workgroup per image)
+extern "C" int sgg_topk_gather(const float* scores, const int* seg_off, const float* boxes, const int* labels_in, const float* img_hw, int B,
+                               int take, float min_size, float* out_boxes, float* out_scores, int* out_labels, unsigned char* valid,
+                               void* stream) {
+    if (!scores || !seg_off || !boxes || !img_hw || !out_boxes || !out_scores || !valid || B <= 0 || take <= 0 || take > TOPK_MAX) return SGG_ERR_ARG;
+    hipLaunchKernelGGL(topk_gather_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, scores, seg_off, boxes, labels_in, img_hw, take, min_size,
+                       out_boxes, out_scores, out_labels, valid);
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
 // greedy NMS on score-ordered boxes [B,n,4] (n <= 8192): keep_idx i32[B,max_keep], keep_cnt i32[B].
 // labels != NULL: class-aware (batched_nms).  mask_ws: u64[B*n*ceil(n/64)] scratch.
 extern "C" int sgg_nms(const float* boxes, const int* labels, const unsigned char* valid, int B, int n, float thresh, int max_keep,
@@ -264,6 +488,13 @@ extern "C" int sgg_nms(const float* boxes, const int* labels, const unsigned cha
     if (!boxes || !valid || !mask_ws || !keep_idx || !keep_cnt || B <= 0 || n <= 0 || n > 8192 || max_keep <= 0) return SGG_ERR_ARG;
     const int nw = (n + 63) / 64;
     hipStream_t s = (hipStream_t)stream;
+    static const char* lazy_off = getenv("SGG_NMS_LAZY");       // "0": always the bit-matrix form (cross-checks)
+    if (max_keep <= 128 && n <= NMS_LAZY_N && !(lazy_off && lazy_off[0] == '0')) {
+        // few boxes kept (detections): only the kept boxes' suppression rows are ever computed
+        hipLaunchKernelGGL(nms_lazy_kernel, dim3(B), dim3(1024), 0, s, boxes, labels, valid, n, thresh, max_keep, keep_idx, keep_cnt);
+        SGG_CHECK_LAUNCH();
+        return SGG_OK;
+    }
     hipLaunchKernelGGL(nms_mask_kernel, dim3(nw, n, B), dim3(64), 0, s, boxes, labels, valid, n, nw, thresh, (unsigned long long*)mask_ws);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, s, (const unsigned long long*)mask_ws, valid, n, nw, max_keep, keep_idx, keep_cnt);
     SGG_CHECK_LAUNCH();

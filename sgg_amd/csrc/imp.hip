@@ -101,8 +101,8 @@ __global__ __launch_bounds__(256) void gru_gate_kernel(const TG* __restrict__ gi
 //   e_{i+1}[e] = GRU pointwise(gi[e], gh[e], e_i[e])
 // One lane = 8 channels of one edge; the two gates are per-row scalars made from the dot products (every lane of the row computes
 // them: two exps against 24 for the cell).  P rows are shared by the 2(n-1) edges of a node: L1 / L2 hits (196 KB per image).
-template <typename T>
-__global__ __launch_bounds__(256) void gru_gate_proj_kernel(const float* __restrict__ gh, const float* __restrict__ P,
+template <typename T, typename TG>
+__global__ __launch_bounds__(256) void gru_gate_proj_kernel(const TG* __restrict__ gh, const float* __restrict__ P,
                                                             const float* __restrict__ b_ih, const int* __restrict__ so,
                                                             const float* __restrict__ ndots, const float* __restrict__ edots,
                                                             const float* __restrict__ gb, const T* __restrict__ h_prev,
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void gru_gate_proj_kernel(const float* __restr
     const float g_sub = sigmoidf_(ndots[4L * s] + edots[4 * m] + gb[0]);
     const float g_obj = sigmoidf_(ndots[4L * ob + 1] + edots[4 * m + 1] + gb[1]);
     float hr[8], hz[8], hn[8], hp[8], o[8], gi3[3][8];
-    const float* ghm = gh + m * 3 * H + c;
+    const TG* ghm = gh + m * 3 * H + c;       // (gh in the compute type: 16-bit halves the kernel's largest stream)
     load8(ghm, hr);
     load8(ghm + H, hz);
     load8(ghm + 2 * H, hn);
@@ -932,11 +932,12 @@ extern "C" int sgg_gru_gate_fwd(const void* gi, const void* gh, const float* b_h
     return SGG_OK;
 }
 
-extern "C" int sgg_gru_gate_proj_fwd(const float* gh, const float* P, const float* b_ih, const int* so, const float* node_dots,
+extern "C" int sgg_gru_gate_proj_fwd(const void* gh, const float* P, const float* b_ih, const int* so, const float* node_dots,
                                      const float* edge_dots, const float* gate_b, const void* h_prev, void* h_out, int M, int H,
-                                     const float* dot_w, int dot_ld, float* dots, int dtype, void* stream) {
+                                     const float* dot_w, int dot_ld, float* dots, int dtype, int gh_dtype, void* stream) {
     if (M == 0) return SGG_OK;
     if (!gh || !P || !b_ih || !so || !node_dots || !edge_dots || !gate_b || !h_prev || !h_out || M < 0 || H <= 0 || (H & 7)) return SGG_ERR_ARG;
+    if (gh_dtype != SGG_F32 && gh_dtype != dtype) return SGG_ERR_DTYPE;      // gh: f32, or the state's own element type
     if (dots) {
         const int h8 = H / 8;
         if (!dot_w || dot_ld < H || h8 > 64 || (h8 & (h8 - 1))) return SGG_ERR_ARG;
@@ -944,8 +945,13 @@ extern "C" int sgg_gru_gate_proj_fwd(const float* gh, const float* P, const floa
     const long total = (long)M * (H / 8);
     const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(gru_gate_proj_kernel<T>, grid, blk, 0, s, gh, P, b_ih, so, node_dots, edge_dots, gate_b,
-                                            (const T*)h_prev, (T*)h_out, total, H, dot_w, dot_ld, dots));
+    if (gh_dtype == SGG_F32) {
+        SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL((gru_gate_proj_kernel<T, float>), grid, blk, 0, s, (const float*)gh, P, b_ih, so, node_dots, edge_dots, gate_b,
+                                                (const T*)h_prev, (T*)h_out, total, H, dot_w, dot_ld, dots));
+    } else {
+        SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL((gru_gate_proj_kernel<T, T>), grid, blk, 0, s, (const T*)gh, P, b_ih, so, node_dots, edge_dots, gate_b,
+                                                (const T*)h_prev, (T*)h_out, total, H, dot_w, dot_ld, dots));
+    }
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

@@ -352,8 +352,8 @@ __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const T* __restrict__
 //   gi[e] = g_sub(e) P[s] + g_obj(e) P[o] + b_ih.  Recomputes gi and the cell from the saved gh, P and dot products, then
 //   d_gi = [d_rpre, d_zpre, d_npre], d_gh = [d_rpre, d_zpre, d_npre * r], dh_prev = dh * z,
 //   dq[e] = (<d_gi, P[s]>, <d_gi, P[o]>)  -- the gradients of the two scalar gates (reduced over the row's H/8 lanes).
-template <typename T>
-__global__ __launch_bounds__(256) void gru_gate_proj_bwd_kernel(const T* __restrict__ dh, const float* __restrict__ gh,
+template <typename T, typename TG>
+__global__ __launch_bounds__(256) void gru_gate_proj_bwd_kernel(const T* __restrict__ dh, const TG* __restrict__ gh,
                                                                 const float* __restrict__ P, const float* __restrict__ b_ih,
                                                                 const int* __restrict__ so, const float* __restrict__ ndots,
                                                                 const float* __restrict__ edots, const float* __restrict__ gb,
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void gru_gate_proj_bwd_kernel(const T* __restr
     const float g_sub = sigmoidf_(ndots[4L * s] + edots[4 * m] + gb[0]);
     const float g_obj = sigmoidf_(ndots[4L * ob + 1] + edots[4 * m + 1] + gb[1]);
     float hr[8], hz[8], hn[8], hp[8], g[8], ps[3][8], po[3][8], gi3[3][8];
-    const float* ghm = gh + m * 3 * H + c;
+    const TG* ghm = gh + m * 3 * H + c;
     load8(ghm, hr);
     load8(ghm + H, hz);
     load8(ghm + 2 * H, hn);
@@ -1069,19 +1069,25 @@ extern "C" int sgg_gru_gate_bwd(const void* dh, const float* gi, const float* gh
     return SGG_OK;
 }
 
-extern "C" int sgg_gru_gate_proj_bwd(const void* dh, const float* gh, const float* P, const float* b_ih, const int* so,
+extern "C" int sgg_gru_gate_proj_bwd(const void* dh, const void* gh, const float* P, const float* b_ih, const int* so,
                                      const float* node_dots, const float* edge_dots, const float* gate_b, const void* h_prev, void* d_gi,
-                                     void* d_gh, void* dh_prev, float* dq, int M, int H, int dtype, void* stream) {
+                                     void* d_gh, void* dh_prev, float* dq, int M, int H, int dtype, int gh_dtype, void* stream) {
     if (M == 0) return SGG_OK;
     const int h8 = H / 8;
     if (!dh || !gh || !P || !b_ih || !so || !node_dots || !edge_dots || !gate_b || !h_prev || !d_gi || !d_gh || !dq || M < 0 || H <= 0 ||
         (H & 7) || h8 > 64 || (h8 & (h8 - 1)))
         return SGG_ERR_ARG;
+    if (gh_dtype != SGG_F32 && gh_dtype != dtype) return SGG_ERR_DTYPE;
     const long total = (long)M * h8;
     const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(gru_gate_proj_bwd_kernel<T>, grid, blk, 0, s, (const T*)dh, gh, P, b_ih, so, node_dots, edge_dots,
-                                            gate_b, (const T*)h_prev, (T*)d_gi, (T*)d_gh, (T*)dh_prev, dq, total, H));
+    if (gh_dtype == SGG_F32) {
+        SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL((gru_gate_proj_bwd_kernel<T, float>), grid, blk, 0, s, (const T*)dh, (const float*)gh, P, b_ih, so, node_dots,
+                                                edge_dots, gate_b, (const T*)h_prev, (T*)d_gi, (T*)d_gh, (T*)dh_prev, dq, total, H));
+    } else {
+        SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL((gru_gate_proj_bwd_kernel<T, T>), grid, blk, 0, s, (const T*)dh, (const T*)gh, P, b_ih, so, node_dots,
+                                                edge_dots, gate_b, (const T*)h_prev, (T*)d_gi, (T*)d_gh, (T*)dh_prev, dq, total, H));
+    }
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

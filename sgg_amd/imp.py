@@ -104,7 +104,7 @@ def message_pass(rel_rep, obj_rep, rel_inds, csr, wts, mp_iter, dtype):
         return unpack(ops.gru_gate(gi, gh, None, vert, dtype, out=out, dot_w=wv if more else None, dots=dots), more)
 
     def edge_step(edge, P, nd, ed, more):
-        gh = ops.gemm(edge, wts.edge_gru_w_hh, wts.edge_gru_b_hh, out_dtype=torch.float32)
+        gh = ops.gemm(edge, wts.edge_gru_w_hh, wts.edge_gru_b_hh, out_dtype=ops.gh_dtype(dtype))
         return unpack(ops.gru_gate_proj(gh, P, wts.edge_gru_b_ih, csr, nd, ed, wts.gate_b, edge, dot_w=wts.gate_w[:, H:] if more else None), more)
 
     if lane is None:

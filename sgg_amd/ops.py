@@ -596,6 +596,14 @@ def imp_ctx(x, csr, N, node_dots, edge_dots, gate_b, pair=2, ctx2=None, ctx_sum=
     return dst
 
 
+def gh_dtype(state_dtype):
+    """Element type of the edge GRU's hidden pre-activations gh = e W_hh^T + b_hh between the GEMM that writes them and the gate kernel
+    that reads them straight back: the state's own 16-bit type (half the bytes of the gate kernel's largest stream: 48.8 MB -> 24.4 MB
+    per iteration at 8 images; the added rounding, 2^-11 of a pre-activation, sits inside the 16-bit modes' parity bounds --
+    tests/test_parity_full_gpu.py), f32 in the f32 modes.  SGG_GH_F32=1 keeps round 3's f32."""
+    return state_dtype if (is_half(state_dtype) and os.environ.get('SGG_GH_F32', '0') != '1') else torch.float32
+
+
 def gru_gate_proj(gh, P, b_ih, csr, node_dots, edge_dots, gate_b, h_prev, out=None, dot_w=None, dots=None):
     """The edge GRU of a message-passing iteration from the node projection P = v W_ih^T (f32 [N,3H], no bias) instead of e_in rows:
     gi[e] = g_sub P[s] + g_obj P[o] + b_ih (sgg_gru_gate_proj_fwd).  -> h_out (and dots f32[M,4] with dot_w, as gru_gate)."""
@@ -609,10 +617,10 @@ def gru_gate_proj(gh, P, b_ih, csr, node_dots, edge_dots, gate_b, h_prev, out=No
             raise ValueError('gru_gate_proj: dot_w must be an f32 [4,H] view with unit column stride')
         if dots is None:
             dots = torch.empty((M, 4), dtype=torch.float32, device=gh.device)
-    _lib.call('sgg_gru_gate_proj_fwd', _p(gh, torch.float32), _p(P, torch.float32), _p(b_ih, torch.float32), _p(so),
+    _lib.call('sgg_gru_gate_proj_fwd', _p(gh), _p(P, torch.float32), _p(b_ih, torch.float32), _p(so),
               _p(node_dots, torch.float32), _p(edge_dots, torch.float32), _p(gate_b, torch.float32), _p(h_prev), _p(out), M, H,
               dot_w.data_ptr() if dot_w is not None else None, dot_w.stride(0) if dot_w is not None else 0,
-              _p(dots, torch.float32) if dot_w is not None else None, dt(out), _stream())
+              _p(dots, torch.float32) if dot_w is not None else None, dt(out), dt(gh), _stream())
     return (out, dots) if dot_w is not None else out
 
 
@@ -786,9 +794,9 @@ def gru_gate_proj_bwd(dh, gh, P, b_ih, csr, node_dots, edge_dots, gate_b, h_prev
     M, H = dh.shape
     dh_prev = torch.empty_like(dh)
     dq = torch.empty((M, 2), dtype=torch.float32, device=dh.device)
-    _lib.call('sgg_gru_gate_proj_bwd', _p(dh), _p(gh, torch.float32), _p(P, torch.float32), _p(b_ih, torch.float32), _p(csr[4]),
+    _lib.call('sgg_gru_gate_proj_bwd', _p(dh), _p(gh), _p(P, torch.float32), _p(b_ih, torch.float32), _p(csr[4]),
               _p(node_dots, torch.float32), _p(edge_dots, torch.float32), _p(gate_b, torch.float32), _p(h_prev), _p(d_gi), _p(d_gh),
-              _p(dh_prev), _p(dq), M, H, dt(dh), _stream())
+              _p(dh_prev), _p(dq), M, H, dt(dh), dt(gh), _stream())
     return dh_prev, dq
 
 

@@ -47,6 +47,17 @@ def _sort_desc(keys, seg_off, nseg, seg_len_hint=0):
     return keys_out, vals_out
 
 
+TOPK_MAX = 4096          # sgg_topk_gather's capacity (one workgroup's LDS)
+USE_TOPK = True          # tests flip it to cross-check against the library sort
+
+
+def _topk_gather(scores, seg, boxes, labels, img_hw, B, take, min_size, pb, ps, pl, pv):
+    """radix select + sort of the `take` best candidates per segment (sgg_topk_gather) instead of a full sort of all of them"""
+    _lib.call('sgg_topk_gather', scores.data_ptr(), seg.data_ptr(), boxes.data_ptr(), labels.data_ptr() if labels is not None else None,
+              img_hw.data_ptr(), B, take, float(min_size), pb.data_ptr(), ps.data_ptr(), pl.data_ptr() if pl is not None else None,
+              pv.data_ptr(), ops._stream())
+
+
 def _nms(boxes, labels, valid, thresh, max_keep):
     B, n = boxes.shape[0], boxes.shape[1]
     dev = boxes.device
@@ -127,11 +138,14 @@ def _top_per_image(boxes, scores, labels, img_hw, take, min_size):
     B, n = scores.shape
     dev = scores.device
     seg = torch.arange(0, B + 1, dtype=torch.int32, device=dev) * n
-    ks, vs = _sort_desc(scores.reshape(-1), seg, B, n)
     pb = torch.empty((B, take, 4), dtype=torch.float32, device=dev)
     ps = torch.empty((B, take), dtype=torch.float32, device=dev)
     pl = torch.empty((B, take), dtype=torch.int32, device=dev) if labels is not None else None
     pv = torch.empty((B, take), dtype=torch.uint8, device=dev)
+    if take <= TOPK_MAX and USE_TOPK:
+        _topk_gather(scores.reshape(-1), seg, boxes, labels, img_hw, B, take, min_size, pb, ps, pl, pv)
+        return pb, ps, pl, pv
+    ks, vs = _sort_desc(scores.reshape(-1), seg, B, n)
     _lib.call('sgg_gather_topk', ks.data_ptr(), vs.data_ptr(), seg.data_ptr(), boxes.data_ptr(), labels.data_ptr() if labels is not None else None,
               img_hw.data_ptr(), B, take, float(min_size), pb.data_ptr(), ps.data_ptr(), pl.data_ptr() if pl is not None else None,
               pv.data_ptr(), ops._stream())
@@ -237,14 +251,17 @@ def detect(model, fmap, image_sizes, padded_hw, orig_sizes, spatial_scale, pyram
     _lib.call('sgg_det_candidates', pred.data_ptr(), pred.stride(0), rois.data_ptr(), K, C, img_hw.data_ptr(),
               float(det.roi_heads.score_thresh), DET_MIN_SIZE, cs.data_ptr(), cb.data_ptr(), cl.data_ptr(), stream)
     cseg = torch.tensor([o * (C - 1) for o in offs_h], dtype=torch.int32, device=dev)
-    ks2, vs2 = _sort_desc(cs, cseg, B, 0)
     cap = DET_PRE_NMS_CAP
     db = torch.empty((B, cap, 4), dtype=torch.float32, device=dev)
     ds = torch.empty((B, cap), dtype=torch.float32, device=dev)
     dl = torch.empty((B, cap), dtype=torch.int32, device=dev)
     dv = torch.empty((B, cap), dtype=torch.uint8, device=dev)
-    _lib.call('sgg_gather_topk', ks2.data_ptr(), vs2.data_ptr(), cseg.data_ptr(), cb.data_ptr(), cl.data_ptr(), img_hw.data_ptr(), B,
-              cap, DET_MIN_SIZE, db.data_ptr(), ds.data_ptr(), dl.data_ptr(), dv.data_ptr(), stream)
+    if cap <= TOPK_MAX and USE_TOPK:
+        _topk_gather(cs, cseg, cb, cl, img_hw, B, cap, DET_MIN_SIZE, db, ds, dl, dv)
+    else:
+        ks2, vs2 = _sort_desc(cs, cseg, B, 0)
+        _lib.call('sgg_gather_topk', ks2.data_ptr(), vs2.data_ptr(), cseg.data_ptr(), cb.data_ptr(), cl.data_ptr(), img_hw.data_ptr(), B,
+                  cap, DET_MIN_SIZE, db.data_ptr(), ds.data_ptr(), dl.data_ptr(), dv.data_ptr(), stream)
     mk = int(det.roi_heads.detections_per_img)
     kidx, kcnt = _nms(db, dl, dv, float(det.roi_heads.nms_thresh), mk)
     ob = torch.zeros((B, mk, 4), dtype=torch.float32, device=dev)

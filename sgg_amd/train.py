@@ -263,7 +263,7 @@ class PredictFn(torch.autograd.Function):
             ops.imp_ctx(e_i, csr, N, nd, ed, imp.gate_b, pair=2, ctx_sum=ctx_i)
             a, b, nd_new = node_cell(ctx_i, v_i, HN[(i + 1) * N:(i + 2) * N], wv if more else None, mark() if side is not None else None)
             P = ops.gemm(v_i, imp.edge_gru_w_ih, None, out_dtype=torch.float32)
-            gh = ops.gemm(e_i, imp.edge_gru_w_hh, imp.edge_gru_b_hh, out_dtype=torch.float32)
+            gh = ops.gemm(e_i, imp.edge_gru_w_hh, imp.edge_gru_b_hh, out_dtype=ops.gh_dtype(dt))       # (saved for the backward in that type too)
             r = ops.gru_gate_proj(gh, P, imp.edge_gru_b_ih, csr, nd, ed, imp.gate_b, e_i, out=HE[(i + 1) * E:(i + 2) * E],
                                   dot_w=we if more else None)
             ghe.append(gh); Ps.append(P); nds.append(nd); eds.append(ed)

@@ -658,6 +658,14 @@ def test_gru_gate_proj_equals_gru_on_materialised_edge_inputs(ops, dtype, H, siz
     torch.testing.assert_close(dots.cpu(), out.float().cpu() @ gw[:, H:].t(), atol=3e-5, rtol=1e-5)   # dots are of the state AS STORED
     plain = ops.gru_gate_proj(cu(gh), cu(P), cu(b_ih), csr, cu(nd), cu(ed), cu(gb), cu(hp))
     assert torch.equal(plain, out)
+    if dtype != torch.float32:
+        # gh handed over in the state's 16-bit type (what the forward does since round 4): the same kernel arithmetic on the rounded values
+        gh16 = cu(gh).to(dtype)
+        a16 = ops.gru_gate_proj(gh16, cu(P), cu(b_ih), csr, cu(nd), cu(ed), cu(gb), cu(hp))
+        b16 = ops.gru_gate_proj(gh16.float(), cu(P), cu(b_ih), csr, cu(nd), cu(ed), cu(gb), cu(hp))
+        assert torch.equal(a16, b16)
+        with pytest.raises(TypeError):
+            ops.gru_gate_proj(gh16.to(torch.float16 if dtype == torch.bfloat16 else torch.bfloat16), cu(P), cu(b_ih), csr, cu(nd), cu(ed), cu(gb), cu(hp))
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])

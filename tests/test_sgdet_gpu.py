@@ -275,3 +275,81 @@ def test_sgdet_full_size_config3():
     trip = pred_scores[:, 1:].max(1) * scores[rels[:, 0]] * scores[rels[:, 1]]
     assert (trip[:-1] >= trip[1:] - 1e-6).all()                                                   # sorted by triple score
     assert (boxes[:, 0] <= boxes[:, 2]).all() and boxes.min() >= 0 and boxes.max() <= 592 + 1e-3
+
+
+def test_topk_select_equals_stable_sort_then_gather():
+    """sgg_topk_gather (radix select + LDS bitonic sort of the wanted candidates) against the path it replaces
+    (rocPRIM stable segmented sort of ALL candidates + sgg_gather_topk): identical boxes, scores, labels, validity -- with exact score
+    ties across the threshold (lower index first), -inf candidates, segments shorter than `take`, ragged segments."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import ctypes
+    from sgg_amd import _lib, ops, sgdet
+    g = torch.Generator().manual_seed(3)
+    for B, n, take, ties in ((8, 21660, 1000, False), (3, 150000, 4096, True), (4, 700, 1000, True), (2, 5000, 4096, False), (5, 4096, 4096, True)):
+        scores = torch.randn(B, n, generator=g)
+        if ties:
+            scores = (scores * 8).round() / 8                     # many exact ties, also at the selection threshold
+        scores[:, ::7] = float('-inf')
+        boxes = torch.rand(B, n, 4, generator=g) * 300
+        boxes[..., 2:] += boxes[..., :2]
+        labels = torch.randint(1, 150, (B, n), generator=g).int()
+        hw = torch.tensor([[592.0, 592.0]] * B)
+        sc, bx, lb, hw = scores.to(DEV), boxes.to(DEV).contiguous(), labels.to(DEV), hw.to(DEV)
+        out = {}
+        for use in (True, False):
+            sgdet.USE_TOPK = use
+            out[use] = sgdet._top_per_image(bx, sc, lb, hw, take, 1.0)
+        sgdet.USE_TOPK = True
+        torch.cuda.synchronize()
+        for a, b_ in zip(out[True], out[False]):
+            assert torch.equal(a, b_), (B, n, take)
+    # ragged segments (the detection candidates of images with different proposal counts)
+    lens = [1200, 0, 6000, 37]
+    seg = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    N = int(sum(lens))
+    sc = ((torch.randn(N, generator=g) * 4).round() / 4).to(DEV)
+    bx = (torch.rand(N, 4, generator=g) * 200).to(DEV)
+    bx[:, 2:] += bx[:, :2]
+    lb = torch.randint(1, 150, (N,), generator=g).int().to(DEV)
+    hw = torch.tensor([[592.0, 592.0]] * 4, device=DEV)
+    take = 4096
+    res = {}
+    for use in (True, False):
+        pb = torch.empty((4, take, 4), device=DEV); ps = torch.empty((4, take), device=DEV)
+        pl = torch.empty((4, take), dtype=torch.int32, device=DEV); pv = torch.empty((4, take), dtype=torch.uint8, device=DEV)
+        if use:
+            sgdet._topk_gather(sc, seg, bx, lb, hw, 4, take, 1.0, pb, ps, pl, pv)
+        else:
+            ks, vs = sgdet._sort_desc(sc, seg, 4, 0)
+            _lib.call('sgg_gather_topk', ks.data_ptr(), vs.data_ptr(), seg.data_ptr(), bx.data_ptr(), lb.data_ptr(), hw.data_ptr(), 4, take, 1.0,
+                      pb.data_ptr(), ps.data_ptr(), pl.data_ptr(), pv.data_ptr(), ops._stream())
+        res[use] = (pb, ps, pl, pv)
+    torch.cuda.synchronize()
+    for a, b_ in zip(res[True], res[False]):
+        assert torch.equal(a, b_)
+
+
+def test_lazy_nms_equals_the_bit_matrix_form():
+    """sgg_nms with few boxes to keep (detections: 50 of 4096) computes only the kept boxes' suppression rows (nms_lazy_kernel); with more
+    (RPN: 1000) it builds the n x n bit-matrix and scans it.  Greedy NMS keeps a prefix-stable list: the first 50 of a 200-box run of the
+    matrix form are the lazy form's 50 -- class-aware and class-agnostic, with invalid candidates, n up to the LDS capacity."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from sgg_amd import sgdet
+    g = torch.Generator().manual_seed(8)
+    for B, n in ((8, 4096), (3, 1000), (2, 65), (1, 1)):
+        xy = torch.rand(B, n, 2, generator=g) * 500
+        wh = torch.rand(B, n, 2, generator=g) * 150 + 4
+        boxes = torch.cat((xy, xy + wh), 2).to(DEV).contiguous()
+        labels = torch.randint(1, 12, (B, n), generator=g, dtype=torch.int32).to(DEV)
+        valid = (torch.rand(B, n, generator=g) > 0.2).to(torch.uint8).to(DEV)
+        for lab in (labels, None):
+            for thr in (0.5, 0.05):
+                k_small, c_small = sgdet._nms(boxes, lab, valid, thr, min(50, n))
+                k_big, c_big = sgdet._nms(boxes, lab, valid, thr, 200)
+                torch.cuda.synchronize()
+                for b in range(B):
+                    m = int(c_small[b])
+                    assert m == min(int(c_big[b]), 50, n) or (int(c_big[b]) >= 50 and m == 50)
+                    assert torch.equal(k_small[b, :m], k_big[b, :m]), (B, n, b, thr)

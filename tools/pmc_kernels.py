@@ -46,7 +46,7 @@ for B in (8, 128):
     v = torch.randn(Nn, H, generator=g).to(dev).to(dt)
     e = torch.randn(E, H, generator=g).to(dev).to(dt)
     nd, ed = (v.float() @ gw[:, :H].t()).contiguous(), (e.float() @ gw[:, H:].t()).contiguous()
-    gh, P = torch.randn(E, 3 * H, generator=g).to(dev), torch.randn(Nn, 3 * H, generator=g).to(dev)
+    gh, P = torch.randn(E, 3 * H, generator=g).to(dev).to(ops.gh_dtype(dt)), torch.randn(Nn, 3 * H, generator=g).to(dev)
     for _ in range(3):
         ops.imp_ctx(e, csr, Nn, nd, ed, gb)
     for _ in range(3):

@@ -1,7 +1,8 @@
 #!/bin/bash
 # HBM-side traffic of the roofline kernels (fc6 GEMMs, IMP step) from two rocprofv3 PMC passes, one counter each, and the kernel-trace
-# summaries of the train / inference bench.  Run on the GPU box from the repo root:   bash tools/pmc_traffic.sh gpurun_out/pmc_r03
-out=${1:-gpurun_out/pmc_r03}
+# summaries of the train / inference bench.  Run on the GPU box from the repo root:   bash tools/pmc_traffic.sh gpurun_out/pmc_r04 r04
+out=${1:-gpurun_out/pmc_r04}
+tag=${2:-r04}
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/$out
 cd /tmp && export TMPDIR=/tmp
@@ -38,10 +39,10 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
 for key, d in res.items():
     # MI355X_MICROARCH.md (HBM / rocprofv3 section): counters in KiB; FETCH_SIZE reports half of the bytes of wide coalesced reads on gfx950
     d['traffic_bytes'] = int(1024 * (2 * d.get('FETCH_SIZE_KiB_avg', 0) + d.get('WRITE_SIZE_KiB_avg', 0)))
-res['_about'] = ('HBM-side traffic per launch of the roofline kernels from rocprofv3 PMC passes on MI355X (round 3, f16): '
+res['_about'] = ('HBM-side traffic per launch of the roofline kernels from rocprofv3 PMC passes on MI355X ($tag, f16): '
                  'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -f csv -- python3 tools/pmc_kernels.py, one counter per pass '
                  '(tools/pmc_traffic.sh). Units KiB; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md; the counters sit '
                  'on the fabric side of L2, Infinity-Cache hits included.')
-json.dump(res, open('$out/pmc_r03.json', 'w'), indent=1, sort_keys=True)
+json.dump(res, open('$out/pmc_$tag.json', 'w'), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
 PY
