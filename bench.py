@@ -369,7 +369,7 @@ def sgdet_bench(args, model, batch, timed, world, rank, B, dev):
                          'ms_per_step': round(fc6[0], 4), 'executed_flop': flop},
             'kernels': {'sum_kernel_ms_per_step': round(total_ms, 3), 'largest_gemm_ms': round(fc6[0], 3),
                         'vgg16_ms': round(per(('sgg_conv3x3_relu', 'sgg_conv1_1', 'sgg_conv1_block', 'sgg_maxpool2x2')), 3),
-                        'sort_ms': round(per(('sgg_segmented_sort_desc', 'sgg_gather_topk', 'sgg_topk_select')), 4),
+                        'sort_ms': round(per(('sgg_segmented_sort_desc', 'sgg_gather_topk', 'sgg_topk_gather')), 4),
                         'nms_ms': round(per(('sgg_nms',)), 4),
                         'top': [{'ms_per_step': round(ms_, 3), 'call': n, 'tag': t} for ms_, n, t in top]}}
     if world == 1 and not args.no_cpu_baseline:

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void gather_topk_kernel(const float* __restric
 constexpr int TOPK_MAX = 4096;
 __device__ __forceinline__ unsigned topk_key(float f) {
     if (f != f) return 0u;                                       // NaN: never selected before a real score
-    const unsigned u = __float_as_uint(f);
+    const unsigned u = __float_as_uint(f == 0.f ? 0.f : f);      // (-0 and +0 are ONE key, as for a comparison sort and for rocPRIM's float sort)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __global__ __launch_bounds__(1024) void topk_gather_kernel(const float* __restrict__ scores, const int* __restrict__ seg_off,

@@ -302,8 +302,12 @@ def test_topk_select_equals_stable_sort_then_gather():
             out[use] = sgdet._top_per_image(bx, sc, lb, hw, take, 1.0)
         sgdet.USE_TOPK = True
         torch.cuda.synchronize()
-        for a, b_ in zip(out[True], out[False]):
-            assert torch.equal(a, b_), (B, n, take)
+        for k, (a, b_) in enumerate(zip(out[True], out[False])):
+            if not torch.equal(a, b_):
+                bad = (a != b_).reshape(B, take, -1).any(-1).nonzero()
+                raise AssertionError((B, n, take, 'output', k, 'first mismatches (image, rank)', bad[:6].tolist(), int(bad.shape[0]),
+                                      out[True][1].flatten()[:0].tolist(), [float(out[True][1][i, r]) for i, r in bad[:4].tolist()],
+                                      [float(out[False][1][i, r]) for i, r in bad[:4].tolist()]))
     # ragged segments (the detection candidates of images with different proposal counts)
     lens = [1200, 0, 6000, 37]
     seg = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
