@@ -18,6 +18,7 @@
 #include "gemm_args.h"
 
 int sgg_launch_pingpong(const GemmArgs& g, int dt, bool conv, hipStream_t s);  // gemm256.hip
+int sgg_launch_pingpong_splitk(const GemmArgs& g, int dt, int splits, hipStream_t s);  // gemm256.hip
 int sgg_pingpong_streamk(long tiles, int nt, void* stream, int* dp_rounds, int* sk_tiles);   // gemm256.hip: 1 = such a launch takes the stream-K form
 int sgg_launch_conv1_block(const float* img, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int out_pad, int B,
                            int H, int W, int dt, int pool, hipStream_t s);  // conv_spatial.hip
@@ -538,8 +539,20 @@ extern "C" int sgg_gemm_splitk(const void* A, int lda, const void* W, int ldw, c
     g.C = (char*)workspace; g.ldc = N; g.M = M; g.N = N; g.act = SGG_ACT_NONE; g.out_dt = SGG_F32;
     g.splitk_stride = (long)M * N * 4;
     hipStream_t s = (hipStream_t)stream;
-    const int rc = in_dtype == SGG_BF16 ? launch<SGG_BF16, 2, 2, false>(g, s, splits)
-                   : in_dtype == SGG_F16 ? launch<SGG_F16, 2, 2, false>(g, s, splits) : launch<SGG_F32, 2, 2, false>(g, s, splits);
+    // whole 256x256 tiles whose slices fill at least half of the chip (the last tile columns of fc6's weight gradient: 32 tiles x 8 slices):
+    // the ping-pong kernel (one slice per CU); otherwise the 128x128 kernel
+    const long tiles256 = (long)(M / 256) * (N / 256);
+    static const char* no256 = getenv("SGG_SPLITK_128");
+    int rc;
+    if (!(no256 && no256[0] == '1') && M % 256 == 0 && N % 256 == 0 && tiles256 * splits >= N_CU_CHIP / 2 && tiles256 * splits <= 2 * N_CU_CHIP &&
+        g.nt * 2 / splits >= 8) {
+        g.nt *= 2;          // 64-byte K-tiles
+        g.nt1 = g.nt;
+        rc = sgg_launch_pingpong_splitk(g, in_dtype, splits, s);
+    } else {
+        rc = in_dtype == SGG_BF16 ? launch<SGG_BF16, 2, 2, false>(g, s, splits)
+             : in_dtype == SGG_F16 ? launch<SGG_F16, 2, 2, false>(g, s, splits) : launch<SGG_F32, 2, 2, false>(g, s, splits);
+    }
     if (rc != SGG_OK) return rc;
     const long MN = (long)M * N;
     const dim3 grid((unsigned)((MN / 8 + 255) / 256)), blk(256);

@@ -201,13 +201,21 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
         else wait_vmcnt<0>();
     };
 
-    const int nt = g.nt;
-    // ---- prologue: tiles 0..2 in flight, tile 0 landed and visible
+    // K range of this workgroup: all of it, or -- split-K launches (gridDim.y > 1: a few output tiles with a long reduction, e.g. the
+    // last two tile columns of fc6's weight gradient) -- slice blockIdx.y of the K-tiles, summed into the fp32 partial output
+    // g.C + blockIdx.y * splitk_stride that a reduce pass adds up (sgg_gemm_splitk)
+    int kb = 0, nt = g.nt;
+    if (gridDim.y > 1) {
+        const int per = (g.nt + (int)gridDim.y - 1) / (int)gridDim.y;
+        kb = min((int)blockIdx.y * per, g.nt);
+        nt = min(kb + per, g.nt);
+    }
+    // ---- prologue: tiles kb..kb+2 in flight, tile kb landed and visible
 #pragma unroll
     for (int t = 0; t < 3; ++t)
-        if (t < nt) issue(t);
-    if (nt >= 3) wait_vmcnt<8>();
-    else if (nt == 2) wait_vmcnt<4>();
+        if (kb + t < nt) issue(kb + t);
+    if (nt - kb >= 3) wait_vmcnt<8>();
+    else if (nt - kb == 2) wait_vmcnt<4>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
 
@@ -216,9 +224,9 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
     // readers (group 1, LOAD kt-1) retired their ds_reads before the barrier that ended slot 2kt-1.
     // The K loop is peeled: nt-3 steady iterations whose MFMA phase carries the DMA of tile kt+3, then the last three without
     // any -- one copy of the MFMA block per loop, no branch inside a phase.
-    const int nsteady = max(nt - 3, 0);
+    const int nsteady = max(nt - 3, kb);
     if (grp == 0) {
-        for (int kt = 0; kt < nsteady; ++kt) {
+        for (int kt = kb; kt < nsteady; ++kt) {
             load_frags(kt);                                  // slot 2kt : LOAD
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
         __builtin_amdgcn_s_barrier();  // slot 2nt: group 1 finishes its last MFMA phase
     } else {
         __builtin_amdgcn_s_barrier();  // slot 0: idle
-        for (int kt = 0; kt < nsteady; ++kt) {
+        for (int kt = kb; kt < nsteady; ++kt) {
             load_frags(kt);                                  // slot 2kt+1 : LOAD
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -266,6 +274,9 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
     // ---- epilogue through LDS: per wave a [32][64] f32 staging tile (row stride 272 B), one 32-row block at a time
     constexpr int ESTRIDE = 272;
     char* est = smem + wave * (32 * ESTRIDE);
+    GemmArgs gs = g;                                                     // (split-K: this slice's partial output)
+    gs.C = g.C + (long)blockIdx.y * g.splitk_stride;
+    const GemmArgs& g_ = gs;
     // Lean form for the common case (an interior tile of a plain GEMM: bias, ReLU, optionally the group addend of fc6's weight gradient).
     // tools/sk_trace.py timed the general form below at 10-15 us of a 140-us tile -- not memory, VALU ISSUE: ~4000 instructions per
     // wave (64-bit address arithmetic and bounds tests per store, an integer division per group-addend column, loads between the
@@ -275,9 +286,9 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
     {
         const int esz_out = g.out_dt == SGG_F32 ? 4 : 2;
         const bool fast = !CONV && !g.add_rows && !g.pscale && !g.pshift && (g.ldc & 7) == 0 && m0 + 256 <= g.M && n0 + 256 <= g.N &&
-                          (!g.gadd || g.ggroup >= 8) && (long)g.M * g.ldc * esz_out < 0xffff0000L && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0;
+                          (!g.gadd || g.ggroup >= 8) && (long)g.M * g.ldc * esz_out < 0xffff0000L && (reinterpret_cast<uintptr_t>(g_.C) & 15) == 0;
         if (fast) {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)min((long)g.M * g.ldc * esz_out, 0xffffffffL), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g_.C, 0, (int)min((long)g.M * g.ldc * esz_out, 0xffffffffL), 0x00020000);
             const int rl = lane >> 3, cl = (lane & 7) * 8;
             const int row0 = m0 + grp * 128 + rl, col0 = n0 + q * 64 + cl;
             const unsigned voff = ((unsigned)row0 * (unsigned)g.ldc + (unsigned)col0) * (unsigned)esz_out;
@@ -365,13 +376,13 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
             const f32x4 lo = *reinterpret_cast<const f32x4*>(est + rl * ESTRIDE + cl * 4);
             const f32x4 hi = *reinterpret_cast<const f32x4*>(est + rl * ESTRIDE + cl * 4 + 16);
             v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-            epilogue_store8(g, cv, v, m, n, out_offset<CONV>(g, m, n), vec_ok);
+            epilogue_store8(g_, cv, v, m, n, out_offset<CONV>(g_, m, n), vec_ok);
         }
     }
 }
 
 template <int DT, bool CONV>
-int launch256(const GemmArgs& g, hipStream_t s) {
+int launch256(const GemmArgs& g, hipStream_t s, int splits = 1) {
     const int tilesM = (g.M - g.m_base + 255) / 256, tilesN = (g.N + 255) / 256;
     auto k = mfma_pingpong_kernel<DT, CONV>;
     static bool attr_done = false;
@@ -380,7 +391,7 @@ int launch256(const GemmArgs& g, hipStream_t s) {
             return SGG_ERR_LAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL(k, dim3(tilesM * tilesN), dim3(512), SMEM, s, g);
+    hipLaunchKernelGGL(k, dim3(tilesM * tilesN, splits), dim3(512), SMEM, s, g);
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
@@ -397,4 +408,12 @@ int sgg_launch_pingpong(const GemmArgs& g, int dt, bool conv, hipStream_t s) {
     if (dt == SGG_BF16) return conv ? launch256<SGG_BF16, true>(g, s) : launch256<SGG_BF16, false>(g, s);
     if (dt == SGG_F16) return conv ? launch256<SGG_F16, true>(g, s) : launch256<SGG_F16, false>(g, s);
     return conv ? launch256<SGG_F32, true>(g, s) : launch256<SGG_F32, false>(g, s);
+}
+
+// split-K launch of the ping-pong kernel: `splits` K slices per 256x256 tile into fp32 partials at g.C + slice * g.splitk_stride
+// (g.out_dt = SGG_F32, no bias / activation: the caller's reduce pass applies them).  g.nt in 64-byte K-tiles.
+int sgg_launch_pingpong_splitk(const GemmArgs& g, int dt, int splits, hipStream_t s) {
+    if (dt == SGG_BF16) return launch256<SGG_BF16, false>(g, s, splits);
+    if (dt == SGG_F16) return launch256<SGG_F16, false>(g, s, splits);
+    return launch256<SGG_F32, false>(g, s, splits);
 }

@@ -532,7 +532,12 @@ def gemm_full_waves(A, W, out_dtype=None, gadd=None):
     out = torch.empty((M, N), dtype=out_dtype or A.dtype, device=A.device)
     main(W[:n1], out[:, :n1])
     tail_tiles = (M // 128) * ((N - n1) // 128)
-    tail = gemm(A, W[n1:], out=out[:, n1:], splits=max(2, min(8, (2 * N_CU) // tail_tiles, kt // 8)))     # straight into its columns
+    tiles256 = (M // 256) * ((N - n1) // 256)
+    if tiles256 and N_CU // tiles256 >= 2:      # the 256x256 ping-pong kernel's own split-K form: one K slice per CU (32 tiles x 8 slices)
+        splits = max(2, min(16, N_CU // tiles256, kt // 8))
+    else:
+        splits = max(2, min(8, (2 * N_CU) // tail_tiles, kt // 8))
+    tail = gemm(A, W[n1:], out=out[:, n1:], splits=splits)     # straight into its columns
     if gadd is not None:
         group_bcast_add_(tail, gadd[0], gadd[1], col0=n1)
     return out
