@@ -266,18 +266,24 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     if (lane == 0) mask[((long)b * n + i) * nw + w] = m;
 }
 
-// greedy scan, one wave per image: lane l owns word l (+64..) of the removed-set
+// greedy scan, one wave per image: lane l owns word l (+64..) of the removed-set.  The validity flags enter the removed-set up front (a
+// ballot per 64 candidates): the loop itself touches memory only when a box is KEPT (its suppression row) -- with a flag load per
+// candidate the scan of 1000 RPN candidates cost 182 us (one dependent global load per iteration), not the rows.
 __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
                                                       const unsigned char* __restrict__ valid, int n, int nw, int max_keep,
                                                       int* __restrict__ keep_idx, int* __restrict__ keep_cnt) {
     const int b = blockIdx.x, lane = threadIdx.x;
     unsigned long long removed[2] = {0ull, 0ull};   // nw <= 128
+    for (int w = 0; w < nw; ++w) {
+        const int j = w * 64 + lane;
+        const unsigned long long inv = __ballot(!(j < n && valid[(long)b * n + j]));
+        if (lane == (w & 63)) removed[w >> 6] |= inv;
+    }
     int cnt = 0;
     for (int i = 0; i < n && cnt < max_keep; ++i) {
         const int w = i >> 6;
         const unsigned long long rw = w < 64 ? __shfl(removed[0], w, 64) : __shfl(removed[1], w - 64, 64);
-        const bool dead = (rw >> (i & 63)) & 1ull;
-        if (dead || !valid[(long)b * n + i]) continue;   // wave-uniform
+        if ((rw >> (i & 63)) & 1ull) continue;           // suppressed or invalid (wave-uniform)
         if (lane == 0) keep_idx[(long)b * max_keep + cnt] = i;
         ++cnt;
         const unsigned long long* row = mask + ((long)b * n + i) * nw;
