@@ -279,7 +279,44 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, 
 // Phase 2: the tile is written out transposed, as the reference's [C][P][P] block (what fc6's K axis expects without
 //   any weight re-ordering): 25088 contiguous elements per RoI, 16-byte pieces per lane.
 // RoIs are visited XCD-contiguously: RoIs are sorted by image, so one image's map stays in one XCD's L2.
+// Round 4 also measured a windowed form (one workgroup per (RoI, 128-byte channel slice); the cells a band of bin rows touches copied
+// once into LDS by LDS-DMA, taps from LDS: 262 cells per union box on average instead of 784 tap requests): correct, 0.34-0.55 ms against
+// 0.177 ms for this kernel -- a workgroup's chain (box loads, window plan, DMA, barrier, taps, barrier, write) is latency, and the LDS
+// it needs leaves 12-16 waves per CU to hide it.  tools/roi_bench.py times this kernel at the bench configuration.
 // ------------------------------------------------------------------------------------------------
+// t = w * tap / t += w * tap on a packed 8-channel piece; the 16-bit float form converts inside the FMA (v_fma_mix_f32)
+template <typename T>
+__device__ __forceinline__ void tap_mul8(const Raw8<T>& tp, float w, float (&t)[8]) {
+    float v[8];
+    tp.get(v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = w * v[k];
+}
+template <typename T>
+__device__ __forceinline__ void tap_fma8(const Raw8<T>& tp, float w, float (&t)[8]) {
+    float v[8];
+    tp.get(v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = fmaf(w, v[k], t[k]);
+}
+#define SGG_MIX_LO(d, h, w, c) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(w), "v"(c))
+#define SGG_MIX_HI(d, h, w, c) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(w), "v"(c))
+template <>
+__device__ __forceinline__ void tap_mul8<f16_t>(const Raw8<f16_t>& tp, float w, float (&t)[8]) {
+    const float z = 0.f;
+    SGG_MIX_LO(t[0], tp.r.x, w, z); SGG_MIX_HI(t[1], tp.r.x, w, z);
+    SGG_MIX_LO(t[2], tp.r.y, w, z); SGG_MIX_HI(t[3], tp.r.y, w, z);
+    SGG_MIX_LO(t[4], tp.r.z, w, z); SGG_MIX_HI(t[5], tp.r.z, w, z);
+    SGG_MIX_LO(t[6], tp.r.w, w, z); SGG_MIX_HI(t[7], tp.r.w, w, z);
+}
+template <>
+__device__ __forceinline__ void tap_fma8<f16_t>(const Raw8<f16_t>& tp, float w, float (&t)[8]) {
+    SGG_MIX_LO(t[0], tp.r.x, w, t[0]); SGG_MIX_HI(t[1], tp.r.x, w, t[1]);
+    SGG_MIX_LO(t[2], tp.r.y, w, t[2]); SGG_MIX_HI(t[3], tp.r.y, w, t[3]);
+    SGG_MIX_LO(t[4], tp.r.z, w, t[4]); SGG_MIX_HI(t[5], tp.r.z, w, t[5]);
+    SGG_MIX_LO(t[6], tp.r.w, w, t[6]); SGG_MIX_HI(t[7], tp.r.w, w, t[7]);
+}
+
 constexpr int MAXS = 32;  // max P*sampling samples per axis
 
 template <typename T>
@@ -347,47 +384,56 @@ __global__ __launch_bounds__(512, 4) void roi_align_kernel(const T* __restrict__
             // The reference's sampling_ratio.  All 16 taps of a bin are requested before the first is used (16 instead
             // of 4 independent 16-byte loads per lane: the kernel is bound by gather latency, not bytes; 0.48 -> 0.38 ms).
             // Samples outside the map keep weight 0 and read pixel 0.
-            auto issue = [&](int bin, Raw8<T> (&tap)[16], float (&wgt)[16]) {
+            // Bilinear interpolation is separable and the bin's four samples share their rows and columns pairwise, so the 16 taps
+            // are 4 rows x 4 columns:  out = sum_r wy[r] (sum_c wx[c] F[r][c])  -- 16 + 4 FMAs per channel instead of 16 weight
+            // products, 16 conversions and 16 FMAs (the 16-bit taps are converted inside v_fma_mix_f32); round 4: the kernel was
+            // co-limited by this VALU work and the L2 -> L1 gathers.  Row r = (sample iy, lo / hi row), column c = (sample ix, lo / hi).
+            auto issue = [&](int bin, Raw8<T> (&tap)[16], float (&wy)[4], float (&wx)[4]) {
                 const int ph = bin / P, pw = bin - ph * P;
+#pragma unroll
+                for (int ix = 0; ix < 2; ++ix) {
+                    const int kx = pw * 2 + ix;
+                    const float hx = s_h[1][kx], lx = s_l[1][kx];
+                    wx[2 * ix] = hx >= 0.f ? hx : 0.f;
+                    wx[2 * ix + 1] = hx >= 0.f ? lx : 0.f;
+                }
 #pragma unroll
                 for (int iy = 0; iy < 2; ++iy) {
                     const int ky = ph * 2 + iy;
                     const float hy = s_h[0][ky], ly = s_l[0][ky];
-                    const bool vy = hy >= 0.f;
+                    wy[2 * iy] = hy >= 0.f ? hy : 0.f;
+                    wy[2 * iy + 1] = hy >= 0.f ? ly : 0.f;
                     const T* row_lo = fm + (long)s_lo[0][ky] * W * C + c0;
                     const T* row_hi = fm + (long)s_hi[0][ky] * W * C + c0;
 #pragma unroll
                     for (int ix = 0; ix < 2; ++ix) {
                         const int kx = pw * 2 + ix;
-                        const float hx = s_h[1][kx], lx = s_l[1][kx];
-                        const bool ok = vy && hx >= 0.f;
                         const int xl = s_lo[1][kx] * C, xh = s_hi[1][kx] * C;
                         const int q = (iy * 2 + ix) * 4;
                         tap[q].load(row_lo + xl);
                         tap[q + 1].load(row_lo + xh);
                         tap[q + 2].load(row_hi + xl);
                         tap[q + 3].load(row_hi + xh);
-                        wgt[q] = ok ? hy * hx : 0.f;
-                        wgt[q + 1] = ok ? hy * lx : 0.f;
-                        wgt[q + 2] = ok ? ly * hx : 0.f;
-                        wgt[q + 3] = ok ? ly * lx : 0.f;
                     }
                 }
             };
-            auto finish = [&](int bin, const Raw8<T> (&tap)[16], const float (&wgt)[16]) {
+            auto finish = [&](int bin, const Raw8<T> (&tap)[16], const float (&wy)[4], const float (&wx)[4]) {
                 float acc[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) acc[k] = 0.f;
 #pragma unroll
-                for (int sidx = 0; sidx < 4; ++sidx) {
-                    float v1[8], v2[8], v3[8], v4[8];
-                    tap[4 * sidx].get(v1);
-                    tap[4 * sidx + 1].get(v2);
-                    tap[4 * sidx + 2].get(v3);
-                    tap[4 * sidx + 3].get(v4);
-                    const float w1 = wgt[4 * sidx], w2 = wgt[4 * sidx + 1], w3 = wgt[4 * sidx + 2], w4 = wgt[4 * sidx + 3];
+                for (int iy = 0; iy < 2; ++iy) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[k] += w1 * v1[k] + w2 * v2[k] + w3 * v3[k] + w4 * v4[k];
+                    for (int ry = 0; ry < 2; ++ry) {
+                        float t[8];
+                        tap_mul8(tap[(iy * 2) * 4 + ry * 2], wx[0], t);
+                        tap_fma8(tap[(iy * 2) * 4 + ry * 2 + 1], wx[1], t);
+                        tap_fma8(tap[(iy * 2 + 1) * 4 + ry * 2], wx[2], t);
+                        tap_fma8(tap[(iy * 2 + 1) * 4 + ry * 2 + 1], wx[3], t);
+                        const float w = wy[iy * 2 + ry];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) acc[k] = fmaf(w, t[k], acc[k]);
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) acc[k] = acc[k] * inv + addv[k];
@@ -395,9 +441,9 @@ __global__ __launch_bounds__(512, 4) void roi_align_kernel(const T* __restrict__
             };
             for (int bin = wave; bin < PP; bin += NWV) {   // (two bins = 32 loads in flight measured slower: 0.46 vs 0.38 ms)
                 Raw8<T> tap[16];
-                float wgt[16];
-                issue(bin, tap, wgt);
-                finish(bin, tap, wgt);
+                float wy[4], wx[4];
+                issue(bin, tap, wy, wx);
+                finish(bin, tap, wy, wx);
             }
             continue;
         }
@@ -472,6 +518,7 @@ __global__ __launch_bounds__(512, 4) void roi_align_kernel(const T* __restrict__
         }
     }
 }
+
 
 }  // namespace
 
