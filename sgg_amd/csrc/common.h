@@ -245,6 +245,9 @@ __device__ __forceinline__ float wave_max(float v) {
 // 1 / (1 + e^-x) on the hardware reciprocal (v_rcp_f32, 1 ulp): `1.0f / y` compiles to the 11-instruction IEEE division sequence,
 // which was a tenth of the VALU work of an IMP edge.  Every kernel that makes a gate (forward, recompute in the backward) uses this one.
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// tanh as 1 - 2 / (e^{2x} + 1) on v_exp_f32 / v_rcp_f32: absolute error ~1e-7, exact limits (+-1) for large |x|.  The GRU cells of the
+// forward (imp.hip) and of the backward's recomputation (train.hip) use the SAME two functions, so a recomputed gate equals the forward's.
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 // Workgroup barrier in front of an LDS buffer REFILL (LDS-DMA or ds_write by any wave after the barrier): this wave's LDS reads of
 // the buffer must have COMPLETED, not merely been issued, when it arrives.  A bare s_barrier does not say that: the compiler sinks

@@ -326,9 +326,9 @@ __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const T* __restrict__
     float o_r[8], o_z[8], o_n[8], o_hn[8], o_h[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float r = 1.f / (1.f + expf(-(ir[j] + hr[j])));
-        const float z = 1.f / (1.f + expf(-(iz[j] + hz[j])));
-        const float n = tanhf(in_[j] + r * hn[j]);
+        const float r = sigmoidf_(ir[j] + hr[j]);
+        const float z = sigmoidf_(iz[j] + hz[j]);
+        const float n = tanh_fast(in_[j] + r * hn[j]);
         const float dn = g[j] * (1.f - z), dz = g[j] * (hp[j] - n);
         const float dnpre = dn * (1.f - n * n);
         o_n[j] = dnpre;
@@ -387,9 +387,9 @@ __global__ __launch_bounds__(256) void gru_gate_proj_bwd_kernel(const T* __restr
     float q0 = 0.f, q1 = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float r = 1.f / (1.f + expf(-(gi3[0][j] + hr[j])));
-        const float z = 1.f / (1.f + expf(-(gi3[1][j] + hz[j])));
-        const float n = tanhf(gi3[2][j] + r * hn[j]);
+        const float r = sigmoidf_(gi3[0][j] + hr[j]);
+        const float z = sigmoidf_(gi3[1][j] + hz[j]);
+        const float n = tanh_fast(gi3[2][j] + r * hn[j]);
         const float dn = g[j] * (1.f - z), dz = g[j] * (hp[j] - n);
         const float dnpre = dn * (1.f - n * n);
         o_n[j] = dnpre;
