@@ -176,9 +176,13 @@ def contraction_alone_ms(tag, pairs, dtype, reps=10):
         out = torch.empty(pairs, 4096, device=dev, dtype=torch.float32)
         run = lambda: ops.gemm(A, W, out=out, out_dtype=torch.float32)          # noqa: E731
     else:
-        A = (torch.randn(4096, pairs, generator=g) / 50).to(dev).to(dtype)
-        W = torch.randn(25088, pairs, generator=g).to(dev).to(dtype).relu()
-        run = lambda: ops.gemm_full_waves(A, W, out_dtype=torch.bfloat16)       # noqa: E731
+        A = (torch.randn(pairs, 4096, generator=g) / 50).to(dev).to(dtype)
+        W = torch.randn(pairs, 25088, generator=g).to(dev).to(dtype).relu()
+        if ops.gemm_tn256_ok(A, W):          # the TN form the step runs: (pair sums of dY)^T . pooled rows, both as they lie
+            run = lambda: ops.gemm_tn_full_waves(A, W, out_dtype=dtype)         # noqa: E731
+        else:
+            A, W = A.t().contiguous(), W.t().contiguous()
+            run = lambda: ops.gemm_full_waves(A, W, out_dtype=dtype)            # noqa: E731
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -554,7 +558,7 @@ def main():
         if paired:
             cands = {'fc6_edge': ('fc6 on the unordered box pairs, forward: [%d x 25088] . [4096 x 25088]^T (f32 out; the per-edge rect '
                                   'term, bias and ReLU follow in a K = 512 launch)' % U, 2.0 * U * 4096 * 25088),
-                     'bwd_fc6_edge_dW': ('fc6 weight gradient over the unordered pairs: [4096 x %d] . [25088 x %d]^T' % (U, U),
+                     'bwd_fc6_edge_dW': ('fc6 weight gradient over the unordered pairs: [%d x 4096]^T . [%d x 25088]' % (U, U),
                                          2.0 * U * 4096 * 25088)}
         else:
             cands = {'fc6_edge': ('fc6 on edges, forward: [%d x 25600] . [4096 x 25600]^T' % E, 2.0 * E * 4096 * 25600),
@@ -564,7 +568,9 @@ def main():
         best = None
         for tag, (desc, flop) in cands.items():
             # a contraction may be issued as a full-round launch + a split-K tail; the weight gradient over the pairs runs as sgg_gemm_groupadd
-            ms = per_step('sgg_gemm', tag) + per_step('sgg_gemm_splitk', tag) + per_step('sgg_gemm_groupadd', tag)
+            # (since round 4 as sgg_gemm_tn256 + the last tile columns on sgg_gemm_tn: both operands read as they lie)
+            ms = (per_step('sgg_gemm', tag) + per_step('sgg_gemm_splitk', tag) + per_step('sgg_gemm_groupadd', tag) +
+                  per_step('sgg_gemm_tn256', tag) + per_step('sgg_gemm_tn', tag))
             if ms > 0 and (best is None or ms > best[1]):
                 best = (tag, ms, desc, flop)
         tag, ms, desc, flop = best
@@ -670,7 +676,10 @@ def main():
                            if (trainer is not None and trainer.shard_optimizer) else 'RCCL gradient all-reduce (bf16 on the wire)'),
                        'weights': 'random init (He), frozen VGG16 + trainable IMP head (247.75 M params)',
                        'pipeline': 'optimiser update of step k runs on a side stream under the frozen VGG forward of step k+1 (every update inside the timed region)'},
-            'roofline': {'kernel': '256x256 ping-pong MFMA kernel (+ the 128x128 split-K launch that replaces a nearly empty last round), %s' % desc, 'bound': 'mfma', 'achieved': round(tf, 2), 'peak': peak,
+            'roofline': {'kernel': ('256x256 ping-pong MFMA kernel%s (+ the 128x128 split-K launch that replaces a nearly empty last round), %s' % (
+                             ', TN form: both operands staged with the reduction index as the slow axis, fragments through ds_read_b64_tr_b16, no '
+                             'transposed copies' if (tag == 'bwd_fc6_edge_dW' and get('sgg_gemm_tn256', tag)[1]) else '', desc)),
+                         'bound': 'mfma', 'achieved': round(tf, 2), 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': round(tf / peak, 4),
                          'traffic': pmc_traffic('fc6_edge_gemm' if tag == 'fc6_edge' else 'fc6_dW_gemm') if (B == 8 and args.dtype != 'f32') else None,
                          'traffic_source': 'profiles/pmc_r0x.json: separate rocprofv3 --pmc passes of the same launch (tools/pmc_traffic.sh), not measured in this run',

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGG_ABI_VERSION 10   /* bump whenever a prototype below changes: tests/abi.lock pins (version, digest of the prototypes) */
+#define SGG_ABI_VERSION 11   /* bump whenever a prototype below changes: tests/abi.lock pins (version, digest of the prototypes) */
 
 enum { SGG_F32 = 0, SGG_BF16 = 1, SGG_F16 = 2 };
 enum { SGG_ACT_NONE = 0, SGG_ACT_RELU = 1 };
@@ -158,9 +158,16 @@ int sgg_gemm_splitk(const void* A, int lda, const void* W, int ldw, const float*
 /* Weight-gradient contraction without transposed operand copies: C[N, K] = A[Mred, N]^T . B[Mred, K], bf16 in, f32 / bf16 out
  * (d W = dY^T X of every nn.Linear on the path, main.py:118).  The reduction rows are staged as they lie and reach the MFMA
  * through ds_read_b64_tr_b16.  Mred % 64 == 0, N % 128 == 0, K % 128 == 0; row strides in elements, multiples of 8.
- * splits > 1: split over the reduction rows, workspace f32[splits, N, K], ldc == K. */
+ * splits > 1: split over the reduction rows, workspace f32[splits, N, K].  Whole 256 x 256 output tiles, 128 of them or more, and
+ * splits == 1 run on the ping-pong kernel's TN form (below).
+ * sgg_gemm_tn256: that form behind its own entry -- N % 256 == 0, K % 256 == 0, ANY Mred (the last Mred mod 32 reduction rows pass
+ *   through pad_ws, 64 (N + K) bytes, as a zero-padded K-tile; pad_ws may be NULL when Mred % 32 == 0), optionally with the group addend
+ *   of sgg_gemm_groupadd in the epilogue: C[n][k] += gadd[n][(k + col0) / group] (gadd NULL: none).  The fc6 weight gradient of
+ *   loss.backward() (main.py:118) over the unordered box pairs reads dY and the pooled features as they lie through this entry. */
 int sgg_gemm_tn(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int Mred, int N, int K, int in_dtype /* SGG_BF16 or SGG_F16 */,
                 int out_dtype, int splits, float* workspace, void* stream);
+int sgg_gemm_tn256(const void* A, int lda, const void* B, int ldb, const float* gadd, int ld_gadd, int group, int col0, void* C, int ldc,
+                   int Mred, int N, int K, int in_dtype /* SGG_BF16 or SGG_F16 */, int out_dtype, void* pad_ws, void* stream);
 
 /* ---- a-8  IMP gather / gate / scatter: RelModelStanford.message_pass, rel_model_stanford.py:74-91 ----
  * The four gates of an edge e = (s, o) are sigmoids of Linear(2H, 1) on [vertex ; edge] (:41-45, 78-89): separable, so they arrive as
@@ -193,6 +200,7 @@ int sgg_imp_ctx_fwd(const void* x /*[E,H]*/, const int* so /*[E,2] (sgg_edge_csr
  *   ucount i32[U] is scratch; *flag: bit 0 = an edge outside its image's boxes, bit 1 = more than two edges on a pair.
  * gemm_addrows: sgg_gemm with an f32 row add_rows[add_idx[m]] (add_idx NULL: row m) added before bias and activation.
  * transpose_pairsum: out [C, ld_out] (x's element type) with out[c][u] = x[a][c] + x[b][c], (a, b) = u2e[u] in ascending order; columns >= U are 0.
+ * pairsum: the same sums as rows, out [U, ld_out] with out[u][c] = x[a][c] + x[b][c] (C % 8 == 0): the operand of sgg_gemm_tn256.
  * group_bcast_add: y[m][j] += r[m][(j + col0) / group], j < ncol  (the rect term's share of fc6's weight gradient);
  * gemm_groupadd: the same addend in the epilogue of sgg_gemm (no bias, no activation). */
 int sgg_pair_slots(const int64_t* rel_inds, const int* first, const int* ubase, const int* cnt, int E, int B, int U, int* e2u, int* u2e,
@@ -200,6 +208,7 @@ int sgg_pair_slots(const int64_t* rel_inds, const int* first, const int* ubase, 
 int sgg_gemm_addrows(const void* A, int lda, const void* W, int ldw, const float* bias, const float* add_rows, int ld_add,
                      const int* add_idx, void* C, int ldc, int M, int N, int K, int act, int in_dtype, int out_dtype, void* stream);
 int sgg_transpose_pairsum(const void* x, int64_t ldx, const int* u2e, void* out, int64_t ld_out, int U, int C, int dtype, void* stream);
+int sgg_pairsum(const void* x, int64_t ldx, const int* u2e, void* out, int64_t ld_out, int U, int C, int dtype, void* stream);
 int sgg_group_bcast_add(void* y, int64_t ldy, const float* r, int64_t ldr, int M, int ncol, int group, int col0, int dtype, void* stream);
 int sgg_gemm_groupadd(const void* A, int lda, const void* W, int ldw, const float* gadd, int ld_gadd, int group, int col0, void* C, int ldc,
                       int M, int N, int K, int in_dtype, int out_dtype, void* stream);

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('SGG_HIP_LIB') or os.path.join(_HERE, 'libsgg_hip.so')
 
 SGG_F32, SGG_BF16, SGG_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _P, _I, _F, _L = c_void_p, c_int, c_float, c_int64
 
@@ -89,6 +89,7 @@ SIGNATURES = {
     'sgg_freq_bias_fwd': [_P, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P],
     'sgg_freq_bias_bwd': [_P, _P, _I, _I, _P, _P],
     'sgg_gemm_tn': [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    'sgg_gemm_tn256': [_P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     'sgg_sqnorm_multi': [_P, _P, _I, _P, _P, _I, _I, _P],
     'sgg_sgd_multi': [_P, _P, _P, _P, _P, _P, _I, _F, _F, _I, _P, _F, _F, _I, _I, _I, _P, _P],
     'sgg_transpose': [_P, _L, _P, _L, _I, _I, _P, _L, _I, _P, _P, _I, _I, _P],
@@ -96,6 +97,7 @@ SIGNATURES = {
     'sgg_pair_slots': [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     'sgg_gemm_addrows': [_P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'sgg_transpose_pairsum': [_P, _L, _P, _P, _L, _I, _I, _I, _P],
+    'sgg_pairsum': [_P, _L, _P, _P, _L, _I, _I, _I, _P],
     'sgg_group_bcast_add': [_P, _L, _P, _L, _I, _I, _I, _I, _I, _P],
     'sgg_gemm_groupadd': [_P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     'sgg_add': [_P, _P, _L, _I, _I, _P],

@@ -57,6 +57,27 @@ __global__ __launch_bounds__(256) void transpose_pairsum_kernel(const T* __restr
     }
 }
 
+// out[u][c] = x[a][c] + x[b][c]: the rows form of the sum above (the TN weight-gradient kernel reads it as it lies); same arithmetic
+template <typename T>
+__global__ __launch_bounds__(256) void pairsum_kernel(const T* __restrict__ x, long ldx, const int* __restrict__ u2e, T* __restrict__ out,
+                                                      long ld_out, int U, int C8) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)U * C8) return;
+    const int u = (int)(i / C8), c = (int)(i - (long)u * C8) * 8;
+    const int a = u2e[2 * u], b = u2e[2 * u + 1];
+    const int lo = (a >= 0 && b >= 0) ? min(a, b) : max(a, b), hi = (a >= 0 && b >= 0) ? max(a, b) : -1;
+    float v[8], w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = 0.f;
+    if (lo >= 0) load8(x + (long)lo * ldx + c, v);
+    if (hi >= 0) {
+        load8(x + (long)hi * ldx + c, w);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += w[k];
+    }
+    store8(out + (long)u * ld_out + c, v);
+}
+
 // y[m][j] += r[m][(j + col0) / group],  j < ncol
 template <typename T>
 __global__ __launch_bounds__(256) void group_bcast_add_kernel(T* __restrict__ y, long ldy, const float* __restrict__ r, long ldr, int M,
@@ -100,6 +121,18 @@ extern "C" int sgg_transpose_pairsum(const void* x, int64_t ldx, const int* u2e,
     const dim3 grid((C + 63) / 64, (Up + 63) / 64), blk(256);
     hipStream_t s = (hipStream_t)stream;
     SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(transpose_pairsum_kernel<T>, grid, blk, 0, s, (const T*)x, (long)ldx, u2e, (T*)out, (long)ld_out, U, Up, C));
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_pairsum(const void* x, int64_t ldx, const int* u2e, void* out, int64_t ld_out, int U, int C, int dtype, void* stream) {
+    if (U == 0 || C == 0) return SGG_OK;
+    if (!x || !u2e || !out || U < 0 || C < 0 || (C & 7) || ld_out < C || ldx < C || ((ldx | ld_out) & 7) || (((uintptr_t)x | (uintptr_t)out) & 15))
+        return SGG_ERR_ARG;
+    const long total = (long)U * (C / 8);
+    hipStream_t s = (hipStream_t)stream;
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(pairsum_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const T*)x, (long)ldx, u2e, (T*)out,
+                                            (long)ld_out, U, C / 8));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

@@ -18,6 +18,7 @@
 #include "gemm_args.h"
 
 int sgg_launch_pingpong(const GemmArgs& g, int dt, bool conv, hipStream_t s);  // gemm256.hip
+int sgg_launch_pingpong_tn(const GemmArgs& g, int dt, int splits, hipStream_t s);                 // gemm256.hip: TN form (g.nt in 32-row K-tiles)
 int sgg_launch_pingpong_splitk(const GemmArgs& g, int dt, int splits, hipStream_t s);  // gemm256.hip
 int sgg_pingpong_streamk(long tiles, int nt, void* stream, int* dp_rounds, int* sk_tiles);   // gemm256.hip: 1 = such a launch takes the stream-K form
 int sgg_launch_conv1_block(const float* img, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int out_pad, int B,
@@ -569,7 +570,7 @@ extern "C" int sgg_gemm_tn(const void* A, int lda, const void* B, int ldb, void*
     if ((in_dtype != SGG_BF16 && in_dtype != SGG_F16) || !sgg_is_dtype(out_dtype)) return SGG_ERR_DTYPE;
     if (!A || !B || !C || Mred <= 0 || N <= 0 || K <= 0 || (Mred & 63) || (N & 127) || (K & 127) || lda < N || ldb < K ||
         ldc < K || ((lda | ldb | ldc) & 7) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) || splits < 1 ||
-        splits > Mred / 64 || (splits > 1 && (!workspace || ldc != K)))
+        splits > Mred / 64 || (splits > 1 && !workspace))
         return SGG_ERR_ARG;
     if ((long)Mred * lda * 2 > 0xffff0000L || (long)Mred * ldb * 2 > 0xffff0000L) return SGG_ERR_SPAN;   // 32-bit lane offsets
     GemmArgs g{};
@@ -578,6 +579,14 @@ extern "C" int sgg_gemm_tn(const void* A, int lda, const void* B, int ldb, void*
     g.nt = Mred / 64; g.nt1 = g.nt;
     g.M = N; g.N = K; g.act = SGG_ACT_NONE;
     hipStream_t s = (hipStream_t)stream;
+    // whole 256x256 tiles and enough of them: the ping-pong kernel's TN form (gemm256.hip).  SGG_TN_PP=0 keeps the 128x128 kernel, 2 takes
+    // the ping-pong form whenever the shapes allow it.
+    static const int tn_pp = getenv("SGG_TN_PP") ? atoi(getenv("SGG_TN_PP")) : 1;
+    if (tn_pp && splits == 1 && !(N & 255) && !(K & 255) && ((long)(N / 256) * (K / 256) >= 128 || tn_pp == 2)) {
+        g.nt = Mred / 32; g.nt1 = g.nt;
+        g.C = (char*)C; g.ldc = ldc; g.out_dt = out_dtype;
+        return sgg_launch_pingpong_tn(g, in_dtype, 1, s);
+    }
     constexpr int smem = 2 * 4 * 64 * ROWB;
     auto kern = in_dtype == SGG_BF16 ? mfma_tile_tn_kernel<SGG_BF16> : mfma_tile_tn_kernel<SGG_F16>;
     static bool attr_done[2] = {false, false};
@@ -597,10 +606,54 @@ extern "C" int sgg_gemm_tn(const void* A, int lda, const void* B, int ldb, void*
         const long MN = (long)N * K;
         const dim3 grid((unsigned)((MN / 8 + 255) / 256)), blk(256);
         SGG_FOR_DTYPE(out_dtype, hipLaunchKernelGGL(splitk_reduce_kernel<T>, grid, blk, 0, s, workspace, splits, MN, K, (const float*)nullptr, SGG_ACT_NONE,
-                                                    (const float*)nullptr, (const float*)nullptr, (T*)C, (long)K));
+                                                    (const float*)nullptr, (const float*)nullptr, (T*)C, (long)ldc));
         SGG_CHECK_LAUNCH();
     }
     return SGG_OK;
+}
+
+namespace {
+// the last (Mred mod 32) reduction rows of both operands, copied into one zero-padded K-tile: ws = [32][N] then [32][K] (16-bit elements)
+__global__ __launch_bounds__(256) void tn_tail_pad_kernel(const char* __restrict__ A, long lda_b, const char* __restrict__ B, long ldb_b,
+                                                          int row0, int Mred, int N, int K, char* __restrict__ ws) {
+    const int per_row = (N + K) / 8;                              // 16-byte pieces per padded row
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 32 * per_row) return;
+    const int r = i / per_row, c = (i - r * per_row) * 8;
+    u32x4 v = {0, 0, 0, 0};
+    if (row0 + r < Mred) v = c < N ? *reinterpret_cast<const u32x4*>(A + (long)(row0 + r) * lda_b + (long)c * 2)
+                                   : *reinterpret_cast<const u32x4*>(B + (long)(row0 + r) * ldb_b + (long)(c - N) * 2);
+    char* dst = c < N ? ws + ((long)r * N + c) * 2 : ws + (long)32 * N * 2 + ((long)r * K + (c - N)) * 2;
+    *reinterpret_cast<u32x4*>(dst) = v;
+}
+}  // namespace
+
+// The ping-pong kernel's TN form behind its own entry: C[N,K] = A[Mred,N]^T . B[Mred,K] (+ gadd[n][(k + col0) / group]) for whole 256x256
+// output tiles and ANY number of reduction rows (the last Mred mod 32 rows go through pad_ws, 64 (N + K) bytes, as a zero-padded K-tile).
+extern "C" int sgg_gemm_tn256(const void* A, int lda, const void* B, int ldb, const float* gadd, int ld_gadd, int group, int col0, void* C,
+                              int ldc, int Mred, int N, int K, int in_dtype, int out_dtype, void* pad_ws, void* stream) {
+    if ((in_dtype != SGG_BF16 && in_dtype != SGG_F16) || !sgg_is_dtype(out_dtype)) return SGG_ERR_DTYPE;
+    if (!A || !B || !C || Mred <= 0 || N <= 0 || K <= 0 || (N & 255) || (K & 255) || lda < N || ldb < K || ldc < K || ((lda | ldb | ldc) & 7) ||
+        (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)pad_ws) & 15) || ((Mred & 31) && !pad_ws))
+        return SGG_ERR_ARG;
+    if (gadd && (group <= 0 || col0 < 0 || (long)ld_gadd * group < (long)K + col0)) return SGG_ERR_ARG;
+    if (32L * lda * 2 + 2L * N > 0xffff0000L || 32L * ldb * 2 + 2L * K > 0xffff0000L) return SGG_ERR_SPAN;     // 32-bit lane offsets inside a K-tile
+    hipStream_t s = (hipStream_t)stream;
+    GemmArgs g{};
+    g.A = (const char*)A; g.Wt = (const char*)B;
+    g.lda_b = (long)lda * 2; g.ldw_b = (long)ldb * 2;
+    g.nt1 = Mred / 32; g.nt = (Mred + 31) / 32;
+    if (Mred & 31) {
+        g.A2 = (const char*)pad_ws; g.lda2_b = (long)N * 2;
+        g.W2 = (const char*)pad_ws + 32L * N * 2; g.ldw2_b = (long)K * 2;
+        const int pieces = 32 * ((N + K) / 8);
+        hipLaunchKernelGGL(tn_tail_pad_kernel, dim3((pieces + 255) / 256), dim3(256), 0, s, g.A, g.lda_b, g.Wt, g.ldw_b, g.nt1 * 32, Mred, N, K, (char*)pad_ws);
+        SGG_CHECK_LAUNCH();
+    }
+    g.M = N; g.N = K; g.act = SGG_ACT_NONE;
+    g.C = (char*)C; g.ldc = ldc; g.out_dt = out_dtype;
+    g.gadd = gadd; g.ld_gadd = ld_gadd; g.ggroup = group; g.gcol0 = col0;
+    return sgg_launch_pingpong_tn(g, in_dtype, 1, s);
 }
 
 // The first block of VGG-16 in one launch (16-bit modes): conv1_1 (3 -> 64) + ReLU + conv1_2 (64 -> 64) + ReLU [+ MaxPool2d(2)].

@@ -19,6 +19,12 @@
 // LDS image per stage: A rows [256][64 B] then W rows [256][64 B], lane-linear for global_load_lds
 // (16 rows per 1-KiB wave instruction); 16-byte slot swizzle phys = slot ^ ((row>>2)&3) applied on the source
 // address and on the ds_read_b128 (conflict-free for the 32-row fragment reads).
+//
+// TN form (template flag, 16-bit only; round 4): C[m][n] = sum_k A[k][m] * W[k][n] -- both operands lie with the REDUCTION index as
+// their slow axis (weight gradients dW = dY^T X: no transposed copies of dY and X).  Same schedule, ring and epilogue; a stage holds,
+// per operand, four [32 k-rows][128 B] column blocks (64 columns each, the 128x128 TN kernel's swizzled image in gemm.hip) filled by
+// the same lane-linear DMA (an instruction = 8 k-rows x 128 B), and a fragment (8 reduction elements of one column per lane) is two
+// ds_read_b64_tr_b16 of stage rows {a, a+1, a+8, a+9} -- both operands use the same row order, which is all a sum needs.
 #include "gemm_args.h"
 
 namespace {
@@ -29,9 +35,13 @@ constexpr int NSTAGE = 4;
 constexpr int SMEM = NSTAGE * STAGE;    // 128 KiB
 
 // byte offset of K-tile kt inside its source rows and which of the two K segments it belongs to (uniform values)
-template <bool CONV>
+template <bool CONV, bool TN = false>
 __device__ __forceinline__ long tile_koff(const GemmArgs& g, bool loads_a, int kt, int tpc, int esz, bool& seg2) {
     seg2 = false;
+    if constexpr (TN) {     // 32 reduction rows further down; K-tiles from nt1 on come out of the second pair of operands (the padded tail rows)
+        seg2 = g.A2 && kt >= g.nt1;
+        return seg2 ? (long)(kt - g.nt1) * 32 * (loads_a ? g.lda2_b : g.ldw2_b) : (long)kt * 32 * (loads_a ? g.lda_b : g.ldw_b);
+    }
 #ifdef SGG_GEMM_ABL_HOT   // experiment: every K-tile re-reads tile 0 (operands stay in L2): what the memory side costs
     kt = 0;
 #endif
@@ -49,8 +59,9 @@ __device__ __forceinline__ long tile_koff(const GemmArgs& g, bool loads_a, int k
     return (long)(seg2 ? kt - g.nt1 : kt) * ROW;
 }
 
-template <int DT, bool CONV>
+template <int DT, bool CONV, bool TN = false>
 __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
+    static_assert(!TN || (!CONV && DT != SGG_F32), "TN form: plain GEMM on 16-bit operands (ds_read_b64_tr_b16 moves 16-bit elements)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ESZ = DT == SGG_F32 ? 4 : 2;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -68,6 +79,14 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
     const char* rp2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+        if constexpr (TN) {   // piece j = k-rows 8j .. 8j+7 of column block (wave & 3): lane -> (row 8j + lane/8, swizzled 16-byte chunk)
+            const int r = j * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+            rp[j] = (loads_a ? g.A + (long)r * g.lda_b + (long)m0 * 2 : g.Wt + (long)r * g.ldw_b + (long)n0 * 2) + (wave & 3) * 128 + chunk * 16;
+            rp2[j] = !g.A2 ? nullptr
+                           : (loads_a ? g.A2 + (long)r * g.lda2_b + (long)m0 * 2 : g.W2 + (long)r * g.ldw2_b + (long)n0 * 2) + (wave & 3) * 128 + chunk * 16;
+            continue;
+        }
         const int r = (wave & 3) * 64 + j * 16 + (lane >> 2);
         const int chunk = (lane & 3) ^ ((r >> 2) & 3);
         if (loads_a) {
@@ -97,7 +116,7 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
 #undef SGG_VO2
     auto issue = [&](int kt) {
         bool seg2;
-        const long koff = tile_koff<CONV>(g, loads_a, kt, tpc, ESZ, seg2);
+        const long koff = tile_koff<CONV, TN>(g, loads_a, kt, tpc, ESZ, seg2);
         const char* ub = uniform_ptr((seg2 ? sbase2 : sbase) + koff - 3072);      // the -3 KiB pairs with the +3 KiB inside vo_*
         char* dst = smem + (kt & (NSTAGE - 1)) * STAGE + lds_rows0;
         glds16_off<0>(ub + (seg2 ? vo2_0 : vo_0), dst);
@@ -132,7 +151,52 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
 
     u32x4 af[4][2], bf[2][2];
 
+    // TN: transposing reads.  kg = lane>>5: which 8 of the k-step's 16 reduction rows; 16-lane group g16 = (lane>>4)&1: columns 16 g16.. of the
+    // 32-column block; p = lane&15 hands in stage row a + (0,1,8,9)[p>>2], 4 columns from 4 (p&3), and receives column p's 4 elements
+    unsigned tn_a[2][2][4], tn_b[2][2][2];            // [k-step][lo / hi 4 of the 8][block]: workgroup-relative LDS byte offsets in a stage
+    if constexpr (TN) {
+        const int kg = lane >> 5, g16 = (lane >> 4) & 1, p = lane & 15;
+        const int rsel = ((p >> 2) & 1) + ((p >> 3) << 3);
+        const unsigned lds0 = (unsigned)(unsigned long)(lds_void_t*)smem;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = 16 * s + 2 * (2 * kg + h) + rsel, key = (row >> 1) & 7;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int col = (i & 1) * 32 + g16 * 16 + 4 * (p & 3);
+                    tn_a[s][h][i] = lds0 + (grp * 2 + (i >> 1)) * 4096 + row * 128 + ((((col >> 3) ^ key) << 4) | (((col >> 2) & 1) << 3));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int col = i * 32 + g16 * 16 + 4 * (p & 3);
+                    tn_b[s][h][i] = lds0 + 256 * ROW + q * 4096 + row * 128 + ((((col >> 3) ^ key) << 4) | (((col >> 2) & 1) << 3));
+                }
+            }
+    }
     auto load_frags = [&](int kt) {
+        if constexpr (TN) {
+            const unsigned st = (kt & (NSTAGE - 1)) * STAGE;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    unsigned long long lo, hi;
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(tn_b[s][0][i] + st) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(tn_b[s][1][i] + st) : "memory");
+                    bf[i][s] = u32x4{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    unsigned long long lo, hi;
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(tn_a[s][0][i] + st) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(tn_a[s][1][i] + st) : "memory");
+                    af[i][s] = u32x4{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+                }
+            }
+            return;
+        }
         const char* st = smem + (kt & (NSTAGE - 1)) * STAGE;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -158,7 +222,7 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
     }
     auto compute_dma = [&](int pf) {
         bool seg2;
-        const long koff = tile_koff<CONV>(g, loads_a, pf, tpc, ESZ, seg2);
+        const long koff = tile_koff<CONV, TN>(g, loads_a, pf, tpc, ESZ, seg2);
         const char* ub = uniform_ptr((seg2 ? sbase2 : sbase) + koff - 3072);
         char* dst = smem + (pf & (NSTAGE - 1)) * STAGE + lds_rows0;
         const unsigned o0 = seg2 ? vo2_0 : vo_0, o1 = seg2 ? vo2_1 : vo_1, o2 = seg2 ? vo2_2 : vo_2, o3 = seg2 ? vo2_3 : vo_3;
@@ -381,10 +445,10 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
     }
 }
 
-template <int DT, bool CONV>
+template <int DT, bool CONV, bool TN = false>
 int launch256(const GemmArgs& g, hipStream_t s, int splits = 1) {
     const int tilesM = (g.M - g.m_base + 255) / 256, tilesN = (g.N + 255) / 256;
-    auto k = mfma_pingpong_kernel<DT, CONV>;
+    auto k = mfma_pingpong_kernel<DT, CONV, TN>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
@@ -416,4 +480,13 @@ int sgg_launch_pingpong_splitk(const GemmArgs& g, int dt, int splits, hipStream_
     if (dt == SGG_BF16) return launch256<SGG_BF16, false>(g, s, splits);
     if (dt == SGG_F16) return launch256<SGG_F16, false>(g, s, splits);
     return launch256<SGG_F32, false>(g, s, splits);
+}
+
+// TN form: g.A = [Kred][M] (lda_b bytes per reduction row), g.Wt = [Kred][N]; g.nt = K-tiles of 32 reduction rows, the first g.nt1 of them
+// in A / Wt, the rest (the zero-padded tail rows) in A2 / W2; M, N multiples of 256; 16-bit operands.
+// splits > 1: K slices into fp32 partials (as sgg_launch_pingpong_splitk).
+int sgg_launch_pingpong_tn(const GemmArgs& g, int dt, int splits, hipStream_t s) {
+    if (dt == SGG_BF16) return launch256<SGG_BF16, false, true>(g, s, splits);
+    if (dt == SGG_F16) return launch256<SGG_F16, false, true>(g, s, splits);
+    return SGG_ERR_DTYPE;
 }

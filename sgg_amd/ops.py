@@ -543,17 +543,75 @@ def gemm_full_waves(A, W, out_dtype=None, gadd=None):
     return out
 
 
+TN256 = os.environ.get('SGG_TN256', '1') != '0'     # the ping-pong kernel's TN form for the large weight gradients (0: transposes + NT)
+
+
+def _tn_operands_ok(A, B):
+    return (is_half(A) and B.dtype == A.dtype and A.dim() == 2 and B.dim() == 2 and A.shape[0] == B.shape[0] and A.shape[0] > 0 and
+            A.stride(1) == 1 and B.stride(1) == 1 and A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0 and
+            A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
+
+
+def gemm_tn256_ok(A, B, min_tiles=128):
+    """Shapes sgg_gemm_tn256 takes and is worth taking (whole 256 x 256 output tiles, half a round of them or more; any row count)."""
+    return (TN256 and _tn_operands_ok(A, B) and A.shape[1] % 256 == 0 and B.shape[1] % 256 == 0 and
+            (A.shape[1] // 256) * (B.shape[1] // 256) >= min_tiles)
+
+
 def gemm_tn_ok(A, B):
-    """Shapes / dtypes sgg_gemm_tn takes (one 16-bit format, reduction rows % 64, both column counts % 128, 16-byte aligned rows)."""
-    return (is_half(A) and B.dtype == A.dtype and A.shape[0] == B.shape[0] and A.shape[0] % 64 == 0 and
-            A.shape[1] % 128 == 0 and B.shape[1] % 128 == 0 and A.stride(1) == 1 and B.stride(1) == 1 and
-            A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
+    """Shapes / dtypes the TN kernels take: one 16-bit format, 16-byte aligned rows, and either reduction rows % 64 with both column
+    counts % 128 (sgg_gemm_tn) or whole 256 x 256 tiles with any row count (sgg_gemm_tn256)."""
+    return (_tn_operands_ok(A, B) and A.shape[0] % 64 == 0 and A.shape[1] % 128 == 0 and B.shape[1] % 128 == 0) or gemm_tn256_ok(A, B)
+
+
+def gemm_tn256(A, B, out_dtype=torch.float32, out=None, gadd=None, col0=0):
+    """A[Mred,N]^T . B[Mred,K] -> [N,K] on the ping-pong kernel's TN form; gadd = (r f32 [N, .], group): out[n, k] += r[n, (k + col0) // group]."""
+    Mred, N = A.shape
+    K = B.shape[1]
+    if out is None:
+        out = torch.empty((N, K), dtype=out_dtype, device=A.device)
+    pad = torch.empty((32 * (N + K),), dtype=A.dtype, device=A.device) if Mred % 32 else None
+    r, group = gadd if gadd is not None else (None, 1)
+    _lib.call('sgg_gemm_tn256', _p(A, rows_ok=True), A.stride(0), _p(B, rows_ok=True), B.stride(0),
+              _p(r, torch.float32, rows_ok=True) if r is not None else None, r.stride(0) if r is not None else 0, group, col0,
+              _p(out, rows_ok=True), out.stride(0), Mred, N, K, dt(A), dt(out), _p(pad) if pad is not None else None, _stream())
+    return out
+
+
+def gemm_tn_full_waves(A, B, out_dtype=None, gadd=None):
+    """gemm_full_waves for the TN form (fc6's weight gradient: 16 x 98 tiles = 6.125 rounds): whole rounds on sgg_gemm_tn256, the tile
+    columns of a nearly empty last round on the 128 x 128 TN kernel's split form (which needs reduction rows % 64: otherwise one launch)."""
+    Mred, N = A.shape
+    K = B.shape[1]
+    tm, tn = N // 256, K // 256
+    rem = (tm * tn) % N_CU
+    out = torch.empty((N, K), dtype=out_dtype or A.dtype, device=A.device)
+    if tm * tn < 2 * N_CU or rem == 0 or rem > N_CU // 4 or rem % tm or Mred % 64 or Mred < 1024:
+        return gemm_tn256(A, B, out=out, gadd=gadd)
+    n1 = K - (rem // tm) * 256
+    gemm_tn256(A, B[:, :n1], out=out[:, :n1], gadd=gadd)
+    tail_tiles = (N // 128) * ((K - n1) // 128)
+    splits = max(2, min(8, (2 * N_CU) // tail_tiles, Mred // 512))
+    tail = gemm_tn(A, B[:, n1:], out=out[:, n1:], splits=splits)
+    if gadd is not None:
+        group_bcast_add_(tail, gadd[0], gadd[1], col0=n1)
+    return out
+
+
+def pairsum(x, u2e):
+    """x [E, C], u2e i32 [U, 2] -> [U, C] (x's dtype): the sum of every unordered pair's (at most two) edge rows, as rows."""
+    U, C = u2e.shape[0], x.shape[1]
+    out = torch.empty((U, C), dtype=x.dtype, device=x.device)
+    _lib.call('sgg_pairsum', _p(x, rows_ok=True), x.stride(0), _p(u2e, torch.int32), _p(out), out.stride(0), U, C, dt(x), _stream())
+    return out
 
 
 def gemm_tn(A, B, out_dtype=torch.float32, out=None, splits=None):
     """A[Mred,N]^T . B[Mred,K] -> [N,K]: the weight gradient dW = dY^T X without transposed copies of dY and X."""
     Mred, N = A.shape
     K = B.shape[1]
+    if splits in (None, 1) and gemm_tn256_ok(A, B):
+        return gemm_tn256(A, B, out_dtype=out_dtype, out=out)
     if out is None:
         out = torch.empty((N, K), dtype=out_dtype, device=A.device)
     tiles = (N // 128) * (K // 128)

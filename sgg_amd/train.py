@@ -165,13 +165,17 @@ class PredictFn(torch.autograd.Function):
         # backward's critical path.  The buffer is allocated under that stream and handed back to it when sv is dropped.
         from .imp import node_lane
         lane = node_lane(dev)
+        # unordered pairs, 16-bit: fc6's weight gradient runs on the TN form of the ping-pong kernel, straight from the pooled rows
+        sv['tn6'] = paired is not None and ef.dim() == 2 and w['fc6_edge'].shape[0] % 256 == 0 and ops.gemm_tn256_ok(ef, ef)
         if lane is not None and ops.is_half(dt):
             side, ev_main, _ = lane
             ev_main.record(torch.cuda.current_stream(dev))
             side.wait_event(ev_main)                                 # ef and rect are ready
             with torch.cuda.stream(side):
                 PPs = model.pool_sz ** 2
-                if paired is not None:      # the rect term does not ride here: it differs between a pair's two edges (backward)
+                if sv.get('tn6'):
+                    pass                    # the weight gradient reads the pooled rows as they lie (sgg_gemm_tn256): no transposed copy
+                elif paired is not None:    # the rect term does not ride here: it differs between a pair's two edges (backward)
                     sv['x6t'] = ops.transpose(ef)
                 else:
                     sv['x6t'] = ops.transpose(ef, add=rect.float() if rect.dtype != torch.float32 else rect, group=PPs)
@@ -332,7 +336,8 @@ class PredictFn(torch.autograd.Function):
             # the node lane's stream makes them NOW, while the main stream is still busy with the dX chain
             tposed = None
             # (without the lane the same contraction runs with the transposes in line: the lane is scheduling only, never a different sum)
-            if big and ops.is_half(dt) and not prepadded and dY.shape[0] >= 4096 and dY.shape[0] % 64 == 0 and os.environ.get('SGG_DW_NT', '1') != '0':
+            if (big and ops.is_half(dt) and not prepadded and dY.shape[0] >= 4096 and dY.shape[0] % 64 == 0 and os.environ.get('SGG_DW_NT', '1') != '0'
+                    and not ops.gemm_tn256_ok(dY, X)):      # (whole 256 x 256 tiles: tn_gemm below takes the ping-pong kernel's TN form, no copies)
                 if bwd_lane is not None:
                     ready_ = torch.cuda.Event()
                     ready_.record(torch.cuda.current_stream(dev))
@@ -527,14 +532,24 @@ class PredictFn(torch.autograd.Function):
         _lib.set_tag('bwd_fc6_edge_dW')
         # d W6[n,(c,p)] = sum_e d_pre6[e,n] * (edge_feat[e,c,p] + rect[e,c]): the folded term rides in the transpose
         paired = sv['paired']
-        if 'x6t' in sv:
+        x6t = d6t = None
+        if sv.get('tn6'):
+            pass
+        elif 'x6t' in sv:
             torch.cuda.current_stream(dev).wait_event(sv['x6t_ready'])
             x6t = sv['x6t']
         elif paired is not None:
             x6t = ops.transpose(sv['ef'])
         else:
             x6t = ops.transpose(sv['ef'], add=sv['rect'].float() if sv['rect'].dtype != torch.float32 else sv['rect'], group=PP)
-        if paired is not None:
+        if sv.get('tn6'):
+            # the same two terms as below, the first as  (pair sums of d_pre6)^T . pooled  with both operands read as they lie
+            G[n6e + '.bias'] = ops.colsum(d_pre6)
+            _lib.set_tag('bwd_fc6_rect_term')
+            r6 = tn_gemm(d_pre6, sv['rect'])
+            _lib.set_tag('bwd_fc6_edge_dW')
+            G[n6e + '.weight'] = ops.gemm_tn_full_waves(ops.pairsum(d_pre6, paired.u2e), sv['ef'], out_dtype=big_dtype(), gadd=(r6, PP))
+        elif paired is not None:
             # rows of the unordered pairs: d W6[n,(c,p)] = sum_u (d_pre6[e1(u),n] + d_pre6[e2(u),n]) pooled[u,c,p]  +  (sum_e d_pre6[e,n] rect[e,c])
             # broadcast over p -- the second term is the gradient through W6's group sums (the folded rect term of the forward)
             d6t = ops.transpose_pairsum(d_pre6, paired.u2e)

@@ -888,6 +888,75 @@ def test_gemm_tn_matches_transposed_product(ops, shape, out_dtype):
     torch.testing.assert_close(got.cpu(), wide[:, 128:].float().t() @ B.float(), atol=2e-3 * (Mred ** 0.5), rtol=1e-4)
 
 
+@pytest.mark.parametrize('shape', [(64, 4096, 2048), (192, 2048, 4096), (3968, 4096, 2048), (7936, 4096, 4096)])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_gemm_tn_pingpong_form(ops, shape, dtype):
+    """Whole 256x256 tiles, 128 of them or more: sgg_gemm_tn runs the ping-pong kernel's TN form (gemm256.hip: operands staged with the
+    reduction index as the slow axis, fragments through ds_read_b64_tr_b16).  Against A^T . B in fp32 and against the 128x128 TN kernel
+    (the split-K route); 2, 6, 124 and 248 K-tiles (prologue / peeled tail of the K loop); non-symmetric operands."""
+    Mred, N, K = shape
+    g = torch.Generator().manual_seed(Mred + K)
+    A = (torch.randn(Mred, N, generator=g) / 4).to(dtype)
+    B = (torch.randn(Mred, K, generator=g) + 0.25).to(dtype)
+    ref = (cu(A).float().t() @ cu(B).float()).cpu()
+    got = ops.gemm_tn(cu(A), cu(B), out_dtype=torch.float32, splits=1)
+    torch.testing.assert_close(got.cpu(), ref, atol=2e-3 * (Mred ** 0.5), rtol=1e-4)
+    if Mred >= 128:
+        other = ops.gemm_tn(cu(A), cu(B), out_dtype=torch.float32, splits=2)        # 128x128 kernel, two K slices
+        torch.testing.assert_close(got.cpu(), other.cpu(), atol=1e-3 * (Mred ** 0.5), rtol=1e-5)
+    out16 = ops.gemm_tn(cu(A), cu(B), out_dtype=dtype, splits=1)
+    torch.testing.assert_close(out16.float().cpu(), ref, atol=0.02 * (Mred ** 0.5), rtol=2e-2)
+    # column blocks of wider matrices (row pitch != columns), as the fc6 weight gradient's main launch takes them
+    wide = torch.randn(Mred, K + 256, generator=g).to(dtype)
+    got = ops.gemm_tn(cu(A), cu(wide)[:, 256:], out_dtype=torch.float32, splits=1)
+    torch.testing.assert_close(got.cpu(), (cu(A).float().t() @ cu(wide)[:, 256:].float()).cpu(), atol=2e-3 * (Mred ** 0.5), rtol=1e-4)
+
+
+@pytest.mark.parametrize('Mred', [3973, 31, 64, 1000])
+def test_gemm_tn256_any_row_count_and_group_addend(ops, Mred):
+    """sgg_gemm_tn256: reduction rows that are no multiple of 32 pass through the zero-padded tail tile (the ragged batch of the bench
+    has 3973 unordered pairs); the group addend of fc6's weight gradient in the epilogue; column blocks as operands."""
+    g = torch.Generator().manual_seed(Mred)
+    N, K, group = 2048, 4096 + 256, 49
+    A = (torch.randn(Mred, N, generator=g) / 4).to(torch.float16)
+    B = (torch.randn(Mred, K, generator=g) + 0.25).to(torch.float16)
+    r = torch.randn(N, (K + group - 1) // group + 1, generator=g)
+    ref = (cu(A).float().t() @ cu(B).float()).cpu()
+    got = ops.gemm_tn256(cu(A), cu(B), out_dtype=torch.float32)
+    torch.testing.assert_close(got.cpu(), ref, atol=2e-3 * (Mred ** 0.5), rtol=1e-4)
+    add = r[:, torch.arange(K) // group]
+    got = ops.gemm_tn256(cu(A), cu(B), out_dtype=torch.float32, gadd=(cu(r), group))
+    torch.testing.assert_close(got.cpu(), ref + add, atol=2e-3 * (Mred ** 0.5), rtol=1e-4)
+    got = ops.gemm_tn256(cu(A), cu(B)[:, 256:], out_dtype=torch.float32, gadd=(cu(r), group), col0=256)
+    torch.testing.assert_close(got.cpu(), (ref + add)[:, 256:], atol=2e-3 * (Mred ** 0.5), rtol=1e-4)
+    assert ops.gemm_tn_ok(cu(A), cu(B)) and ops.gemm_tn256_ok(cu(A), cu(B))
+    torch.testing.assert_close(ops.gemm_tn(cu(A), cu(B)).cpu(), ref, atol=2e-3 * (Mred ** 0.5), rtol=1e-4)     # the routed entry
+
+
+def test_gemm_tn_full_waves_and_pairsum(ops):
+    """fc6's weight gradient as the backward runs it: pair sums of the edge rows (rows form == the transposed form), whole rounds on
+    sgg_gemm_tn256 + the last tile columns on the 128 x 128 TN kernel's split form, group addend everywhere -- against one launch and
+    against the transposes + NT route (gemm_full_waves)."""
+    g = torch.Generator().manual_seed(5)
+    U, E, N, K, group = 3968, 7936, 4096, 25088, 49
+    d = cu((torch.randn(E, N, generator=g) / 8).to(torch.float16))
+    ef = cu(torch.randn(U, K, generator=g).relu().to(torch.float16))
+    u2e = torch.stack((torch.arange(U) * 2 + 1, torch.arange(U) * 2), 1).to(torch.int32)
+    u2e[5, 1] = -1
+    u2e[9] = -1
+    u2e = cu(u2e)
+    d6 = ops.pairsum(d, u2e)
+    d6t = ops.transpose_pairsum(d, u2e)
+    assert torch.equal(d6.t().contiguous(), d6t[:, :U].contiguous())
+    r = cu(torch.randn(N, 512, generator=g))
+    one = ops.gemm_tn256(d6, ef, out_dtype=torch.float16, gadd=(r, group))
+    two = ops.gemm_tn_full_waves(d6, ef, out_dtype=torch.float16, gadd=(r, group))
+    nt = ops.gemm_full_waves(d6t, ops.transpose(ef), out_dtype=torch.float16, gadd=(r, group))
+    torch.testing.assert_close(two.float(), one.float(), atol=0.05, rtol=2e-3)
+    torch.testing.assert_close(two.float(), nt.float(), atol=0.05, rtol=2e-3)
+    assert torch.equal(two[:, :24576], one[:, :24576])          # the main launch computes these columns the same way
+
+
 def test_gemm_full_waves_equals_one_launch():
     """the fc6 weight-gradient shape (16 x 98 tiles = 6.125 rounds): full-round launch + split-K tail vs the single launch, and a
     short reduction that must fall back to the single launch"""

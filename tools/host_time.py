@@ -52,5 +52,33 @@ def main():
     print('synchronised after every step: median %.3f ms' % (lat[len(lat) // 2] * 1e3))
 
 
+
+
+def profile():
+    """cProfile of the issue path (python tools/host_time.py profile): where the host's time per step goes"""
+    import cProfile
+    import pstats
+    dev = 'cuda:0'
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls')).to(dev).eval()
+    model.set_compute_dtype(torch.float16)
+    b = list(synthetic_batch(B=8, S=592, n_boxes=32, n_fg=6, seed=111))
+    b[0] = [im.to(dev) for im in b[0]]
+    b[3], b[4], b[5] = b[3].to(dev), to_device_with_mirror(b[4], dev), to_device_with_mirror(b[5], dev)
+    b = tuple(b)
+    tr = Trainer(model, lr=1e-3)
+    for _ in range(8):
+        tr.step(b)
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(10):
+        tr.step(b)
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats('tottime').print_stats(28)
+    st.sort_stats('cumtime').print_stats(22)
+
+
 if __name__ == '__main__':
-    main()
+    profile() if (len(sys.argv) > 1 and sys.argv[1] == 'profile') else main()

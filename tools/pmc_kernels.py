@@ -23,12 +23,13 @@ out = torch.empty(M, N, device=dev, dtype=torch.float32)
 for _ in range(3):
     ops.gemm(A, W, out=out, out_dtype=torch.float32)
 torch.cuda.synchronize()
-# its weight gradient (the train step's largest contraction): dW[4096, 25088] = (pair-summed d_pre6)^T [4096, U] . pooled^T [25088, U]^T
+# its weight gradient (the train step's largest contraction): dW[4096, 25088] = (pair-summed d_pre6 [U, 4096])^T . pooled [U, 25088], the
+# TN form of the ping-pong kernel: both operands as they lie
 Mg, Ng, Kg = 4096, 25088, 3968
-At = (torch.randn(Mg, Kg, generator=g) / 50).to(dev).to(dt)
-Bt = torch.randn(Ng, Kg, generator=g).to(dev).to(dt).relu()
+At = (torch.randn(Kg, Mg, generator=g) / 50).to(dev).to(dt)
+Bt = torch.randn(Kg, Ng, generator=g).to(dev).to(dt).relu()
 for _ in range(3):
-    dW = ops.gemm_full_waves(At, Bt, out_dtype=dt)
+    dW = ops.gemm_tn_full_waves(At, Bt, out_dtype=dt)
 torch.cuda.synchronize()
 del At, Bt, dW
 # the IMP step's launch (sgg_imp_ctx_fwd: every edge row read once, two gated sums per node) and the gate kernel that takes the place

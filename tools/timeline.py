@@ -50,3 +50,17 @@ if qcol:
         per.setdefault(r[3], 0.0)
         per[r[3]] += (min(r[2], hi) - r[1]) / 3e3
     print('kernel time per queue and step (us):', {k: round(v, 1) for k, v in sorted(per.items(), key=lambda kv: -kv[1])})
+    # what each queue spends its time on (us per step, launches per step)
+    import re
+    for qid in sorted(per, key=lambda k: -per[k]):
+        agg = {}
+        for r in sel:
+            if r[3] != qid:
+                continue
+            nm = re.sub(r'\(anonymous namespace\)::|void |_ZN12_GLOBAL__N_1\d+', '', r[0])[:60]
+            a = agg.setdefault(nm, [0.0, 0])
+            a[0] += (min(r[2], hi) - r[1]) / 3e3
+            a[1] += 1
+        print('queue %s:' % qid)
+        for nm, (us, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:16]:
+            print('   %8.1f us  %5.1f x  %s' % (us, n / 3.0, nm))

@@ -5,7 +5,7 @@ from sgg_amd import ops
 from tools.gemm_bench import timeit
 dev = 'cuda:0'
 for name, Mred, N, K in (('gru_w_ih', 31744, 1536, 512), ('fc7', 7936, 4096, 4096), ('unary', 7936, 512, 4096),
-                         ('fc6', 7936, 4096, 25088), ('fc6_obj', 256, 4096, 25088), ('rect1', 31744, 256, 128)):
+                         ('fc6', 7936, 4096, 25088), ('fc6_pairs', 3968, 4096, 25088), ('fc6_obj', 256, 4096, 25088), ('rect1', 31744, 256, 128)):
     A = (torch.randn(Mred, N, device=dev) / 8).bfloat16()
     B = torch.randn(Mred, K, device=dev).relu().bfloat16()
     out = torch.empty(N, K, device=dev, dtype=torch.float32)
