@@ -587,6 +587,23 @@ extern "C" int sgg_gemm_tn(const void* A, int lda, const void* B, int ldb, void*
         g.C = (char*)C; g.ldc = ldc; g.out_dt = out_dtype;
         return sgg_launch_pingpong_tn(g, in_dtype, 1, s);
     }
+    // split form on the ping-pong kernel for few 256x256 tiles with a long reduction (unary / GRU weight gradients): measured (tools/tn_bench.py,
+    // us, this route / the 128x128 kernel at its best split) GRU [31744 x 1536]^T [31744 x 512] 73 / 89, unary [7936 x 512]^T [7936 x 4096] 55 / 50 --
+    // the fp32 partials (tiles x splits x 256 KB) cost what the faster tile loop gains; off unless SGG_TN_PP_SPLIT=1
+    static const int tn_pp_split = getenv("SGG_TN_PP_SPLIT") ? atoi(getenv("SGG_TN_PP_SPLIT")) : 0;
+    const long t256 = (long)(N / 256) * (K / 256);
+    if (tn_pp && tn_pp_split && splits > 1 && !(N & 255) && !(K & 255) && t256 * splits >= 128 && t256 * splits <= 512 && Mred / 32 / splits >= 8) {
+        g.nt = Mred / 32; g.nt1 = g.nt;
+        g.C = (char*)workspace; g.ldc = K; g.out_dt = SGG_F32; g.splitk_stride = (long)N * K * 4;
+        const int rc = sgg_launch_pingpong_tn(g, in_dtype, splits, s);
+        if (rc != SGG_OK) return rc;
+        const long MN = (long)N * K;
+        const dim3 grid((unsigned)((MN / 8 + 255) / 256)), blk(256);
+        SGG_FOR_DTYPE(out_dtype, hipLaunchKernelGGL(splitk_reduce_kernel<T>, grid, blk, 0, s, workspace, splits, MN, K, (const float*)nullptr, SGG_ACT_NONE,
+                                                    (const float*)nullptr, (const float*)nullptr, (T*)C, (long)ldc));
+        SGG_CHECK_LAUNCH();
+        return SGG_OK;
+    }
     constexpr int smem = 2 * 4 * 64 * ROWB;
     auto kern = in_dtype == SGG_BF16 ? mfma_tile_tn_kernel<SGG_BF16> : mfma_tile_tn_kernel<SGG_F16>;
     static bool attr_done[2] = {false, false};

@@ -10,6 +10,13 @@ for name, Mred, N, K in (('gru_w_ih', 31744, 1536, 512), ('fc7', 7936, 4096, 409
     B = torch.randn(Mred, K, device=dev).relu().bfloat16()
     out = torch.empty(N, K, device=dev, dtype=torch.float32)
     t_tn = timeit(lambda: ops.gemm_tn(A, B, out=out), reps=20)
+    extra = ''
+    if N % 256 == 0 and K % 256 == 0 and (N // 256) * (K // 256) < 128:
+        t256 = (N // 256) * (K // 256)
+        for sp in (max(2, 128 // t256), max(2, 256 // t256), max(2, 512 // t256)):
+            if Mred // 32 // sp >= 8 and sp <= Mred // 64:
+                t_s = timeit(lambda: ops.gemm_tn(A, B, out=out, splits=sp), reps=20)
+                extra += '  splits=%d %.1f us' % (sp, t_s * 1e3)
     t_nt = timeit(lambda: ops.gemm(ops.transpose(A), ops.transpose(B), out_dtype=torch.float32, out=out), reps=20)
     fl = 2.0 * Mred * N * K
-    print('%-8s Mred=%5d N=%4d K=%5d   TN %8.1f us (%6.0f TF)   transposes+NT %8.1f us (%6.0f TF)' % (name, Mred, N, K, t_tn * 1e3, fl / t_tn / 1e9, t_nt * 1e3, fl / t_nt / 1e9))
+    print('%-8s Mred=%5d N=%4d K=%5d   TN %8.1f us (%6.0f TF)   transposes+NT %8.1f us (%6.0f TF)' % (name, Mred, N, K, t_tn * 1e3, fl / t_tn / 1e9, t_nt * 1e3, fl / t_nt / 1e9) + extra)
