@@ -431,7 +431,10 @@ def main():
         # the boundary's form (dataloaders/blob.py): decoded u8 [h,w,3] images + index tensors, all on the HOST
         hb[0] = [(im * 255).round().to(torch.uint8).permute(1, 2, 0).contiguous() for im in hb[0]]
         host_batches.append(tuple(hb))
-    stager = DeviceStager(dev)
+    # 16 staging slots (pinned + device, ~9 MB each): the issuing thread may run that many batches ahead of the GPU, so a host-side stall
+    # (a ~100 ms descheduling on a loaded host, measured in round 4: one such stall per 200 steps cost 5 % with 3 slots) drains the
+    # queue instead of the GPU
+    stager = DeviceStager(dev, slots=int(os.environ.get('SGG_STAGER_SLOTS', '16')))
     # the same batches resident in HBM (staged once, copied out of the stager's slots; index tensors keep their host mirrors, as a
     # Blob keeps its chunk sizes: no D2H sync inside the step)
     dev_batches = []
@@ -452,14 +455,15 @@ def main():
         return (dev_batches[i % NB] for i in range(n))
 
     def feed_host(n):
-        return stager.prefetch(host_batches[i % NB] for i in range(n))
+        return stager.prefetch((host_batches[i % NB] for i in range(n)), threaded=os.environ.get('SGG_STAGER_THREAD', '1') != '0')
 
     from sgg_amd.trainer import Trainer
     trainer = None if args.mode != 'train' else Trainer(model, lr=1e-3, force_dist=args.force_dist, loss_type=args.loss,
                                                         pipeline=os.environ.get('SGG_PIPELINE', '1') != '0', sync_bn=os.environ.get('SGG_SYNC_BN', '1') != '0')
 
     def infer_step(b=None):
-        model.eval()
+        if model.training:
+            model.eval()
         with torch.no_grad():
             return model([batch if b is None else b])
 
@@ -468,19 +472,51 @@ def main():
 
     step = train_step if args.mode == 'train' else infer_step
 
+    feed_ms = [0.0]     # ... of which inside the feed's next()
+    issue_ms = [0.0]    # of the last timed() call: host time per step until the last step was ISSUED (no synchronisation inside)
+
     def timed(fn, warmup, steps, feed=feed_hbm):
         """`warmup` untimed + EXACTLY `steps` timed steps, each on the next batch of `feed` (one iterator over warmup + steps batches: with
         the prefetching feed the first timed batch was staged during the last warm-up step, as in steady state)."""
         it = iter(feed(warmup + steps))
         for _ in range(warmup):
             fn(next(it))
+        if os.environ.get('SGG_GC_FREEZE', '1') != '0':
+            # as sgg_amd.trainer.Trainer does after its third step: the long-lived objects (model, operand caches, batches) leave the cyclic
+            # collector's sight -- a full collection over them is one 80-110 ms pause of the issuing thread per ~100 steps
+            import gc
+            gc.collect()
+            gc.freeze()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        prof_ = None
+        if os.environ.get('SGG_BENCH_CPROFILE'):        # where the issuing thread's time goes (stderr); slows the loop down
+            import cProfile
+            prof_ = cProfile.Profile()
+            prof_.enable()
         t0 = time.perf_counter()
+        feed_s = 0.0
+        per_step = []
         for _ in range(steps):
-            fn(next(it))
+            ta = time.perf_counter()
+            b_ = next(it)
+            feed_s += time.perf_counter() - ta
+            fn(b_)
+            per_step.append(time.perf_counter() - ta)
+        if os.environ.get('SGG_BENCH_STEPTIMES'):
+            ps = sorted(per_step)
+            sys.stderr.write('host time per step (ms): median %.2f p90 %.2f max %.2f; the five longest at steps %s; first ten %s\n' % (
+                1e3 * ps[len(ps) // 2], 1e3 * ps[int(len(ps) * 0.9)], 1e3 * ps[-1],
+                sorted(range(len(per_step)), key=lambda i: -per_step[i])[:5], ['%.1f' % (1e3 * v) for v in per_step[:10]]))
+        feed_ms[0] = 1e3 * feed_s / max(steps, 1)
+        if prof_ is not None:
+            prof_.disable()
+            import pstats
+            pstats.Stats(prof_, stream=sys.stderr).sort_stats('tottime').print_stats(45)
+            pstats.Stats(prof_, stream=sys.stderr).sort_stats('cumtime').print_stats(60)
+        issue_ms[0] = 1e3 * (time.perf_counter() - t0) / max(steps, 1)     # host: all steps issued (the queue may have pushed back)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -504,6 +540,7 @@ def main():
     if trainer is not None and trainer.dist_on:
         trainer.buckets.timing = []
     elapsed = timed(step, args.warmup, args.steps, head_feed)
+    head_issue_ms, head_feed_ms = issue_ms[0], feed_ms[0]
     comm = None
     if trainer is not None and trainer.dist_on:
         # per step: bytes this rank handed to RCCL (reduce-scatter / all-reduce inputs + the all-gathered operands) and how long the stream
@@ -523,6 +560,7 @@ def main():
         trainer.flush()
     # the other input form, same rotation, same number of steps (every rank: the train step holds collectives)
     elapsed_other = timed(step, args.warmup, args.steps, other_feed)
+    other_issue_ms = issue_ms[0]
     if trainer is not None:
         trainer.flush()
 
@@ -649,12 +687,12 @@ def main():
             'metric': 'images/sec (whole node), VG SGCls IMP %s step' % ('train' if args.mode == 'train' else 'inference'),
             'value': round(world * B * args.steps / elapsed, 3),
             'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'host_issue_ms_per_step': round(head_issue_ms, 3), 'host_feed_ms_per_step': round(head_feed_ms, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'input': ('host-resident Blob tuples (decoded u8 images + gt tensors on the host) through DeviceStager.prefetch: one pinned async '
                       'copy per batch on a copy stream, one step ahead' if args.input == 'host' else 'batches resident in HBM'),
             ('hbm_resident' if args.input == 'host' else 'host_input'): {
-                'value': round(world * B * args.steps / elapsed_other, 3), 'unit': 'images/s', 'ms_per_step': round(1e3 * elapsed_other / args.steps, 3),
+                'value': round(world * B * args.steps / elapsed_other, 3), 'unit': 'images/s', 'ms_per_step': round(1e3 * elapsed_other / args.steps, 3), 'host_issue_ms_per_step': round(other_issue_ms, 3),
                 'steps': args.steps, 'note': 'the same rotation over the same %d batches with the %s' % (
                     NB, 'inputs resident in HBM before the timed region (no copy inside it)' if args.input == 'host' else 'host-resident inputs through DeviceStager.prefetch')},
             'config': {'workload': 'VG SGCls rel_model_stanford (IMP) %s, 592x592 frames, 32 boxes/img, 992 edges/img, '

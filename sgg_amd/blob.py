@@ -111,6 +111,7 @@ class _Slot(object):
         self.pinned_np = None
         self.device = None
         self.event = torch.cuda.Event()
+        self.consumed = None      # prefetch(): recorded on the compute stream once the step that read this slot's batch has been issued
 
 
 class DeviceStager(object):
@@ -156,18 +157,32 @@ class DeviceStager(object):
         # and the OpenMP workers then spin-wait next to the HIP runtime's threads -- measured: 6.5 ms per staged forward
         # with this pack, 30-40 ms (random 60-100 ms stalls) with tensor.copy_ on a 128-thread host
         dst = slot.pinned_np
-        for t, o in zip(items, offs):
-            n = t.numel() * t.element_size()
-            if n:
-                np.copyto(dst[o:o + n], t.numpy().reshape(-1).view(np.uint8))
+        flat = [t.numpy().reshape(-1).view(np.uint8) for t in items]
+        k = 0
+        # images of one size whose bytes are a multiple of ALIGN lie back to back: ONE concatenate into the pinned buffer (one stretch
+        # without the interpreter lock instead of one per image -- on the worker thread every re-acquisition stalls the issuing thread)
+        n0 = flat[0].size if flat else 0
+        if len(imgs) > 1 and n0 and n0 % self.ALIGN == 0 and all(f.size == n0 for f in flat[:len(imgs)]):
+            k = len(imgs)
+            np.concatenate(flat[:k], out=dst[:k * n0])
+        for f, o in zip(flat[k:], offs[k:]):
+            if f.size:
+                np.copyto(dst[o:o + f.size], f)
         return items, offs, total, len(imgs), rest
 
-    def _launch(self, batch, slot, packed):
+    def _launch(self, batch, slot, packed, ring=False):
         """Device half: ONE async copy of the packed bytes on the copy stream (issued from the consumer's thread, so that it is ordered
         behind the compute already queued there) + the device views.  -> (device tuple, slot)"""
         items, offs, total, n_img, rest = packed
-        # device: whoever read this slot's previous contents was enqueued on the compute stream before this call
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        # device: whoever read this slot's previous contents was enqueued on the compute stream before this call.  prefetch() knows the
+        # exact point (slot.consumed: the end of the step that read them, several steps back with a deep ring) -- the copy waits for THAT,
+        # not for everything queued so far: waiting for the whole compute stream ties the copy to the previous step's last kernel, and the
+        # HIP runtime then resolves the cross-queue dependency with the calling thread blocked (measured: 2.2-2.6 ms per step inside this
+        # call, the issuing thread never more than one step ahead of the GPU)
+        if ring and slot.consumed is not None:
+            self.stream.wait_event(slot.consumed)
+        else:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.stream):
             slot.device[:total].copy_(slot.pinned[:total], non_blocking=True)
             slot.event.record(self.stream)
@@ -183,11 +198,13 @@ class DeviceStager(object):
                 out[i]._sgg_host = rest[i]     # host mirror of gt_classes / gt_rels (rel_model_base.host_of): no D2H sync later
         return tuple(out), slot
 
-    def _stage_async(self, batch):
+    def _stage_async(self, batch, ring=False):
         """Packs `batch` into the next slot and launches its copy on the copy stream.  -> (device tuple, slot)"""
         slot = self.slots[self._next]
         self._next = (self._next + 1) % len(self.slots)
-        return self._launch(batch, slot, self._pack(batch, slot))
+        if not ring:
+            slot.consumed = None
+        return self._launch(batch, slot, self._pack(batch, slot), ring)
 
     def stage(self, batch):
         """batch: the tuple of Blob.__getitem__(0).  -> same tuple with items 0,3,4,5 (imgs, gt_boxes, gt_classes, gt_rels)
@@ -203,6 +220,8 @@ class DeviceStager(object):
         thread, one batch ahead -- the consumer's thread, which is the one that launches the step's ~250 kernels, only issues the copy.
         A batch's pinned buffer is reused once the copy out of it has finished (slot event), its device buffer once the compute that
         read it has been queued (the copy stream waits for the compute stream at issue, as in stage())."""
+        for sl in self.slots:          # (events of an earlier generator say nothing about who read the slots last)
+            sl.consumed = None
         if not threaded:
             it = iter(loader)
 
@@ -211,7 +230,7 @@ class DeviceStager(object):
                     b = next(it)
                 except StopIteration:
                     return None
-                return self._stage_async(b[0] if isinstance(b, Blob) else b)
+                return self._stage_async(b[0] if isinstance(b, Blob) else b, ring=True)
         else:
             import queue
             import threading
@@ -248,7 +267,7 @@ class DeviceStager(object):
                 if isinstance(item, BaseException):
                     raise item
                 b, k, packed = item
-                out = self._launch(b, self.slots[k], packed)
+                out = self._launch(b, self.slots[k], packed, ring=True)
                 self._next = (k + 1) % S
                 free[k].set()
                 return out
@@ -258,6 +277,9 @@ class DeviceStager(object):
                 nxt = grab()                                                   # copy i+1 is in flight ...
                 torch.cuda.current_stream(self.device).wait_event(cur[1].event)
                 yield cur[0]                                                   # ... while the caller computes on batch i
+                if cur[1].consumed is None:
+                    cur[1].consumed = torch.cuda.Event()
+                cur[1].consumed.record(torch.cuda.current_stream(self.device))  # the step on batch i has been issued: its slot may be refilled after this point
                 cur = nxt
         finally:
             if threaded:

@@ -24,7 +24,7 @@ def main():
     b[0] = [im.to(dev) for im in b[0]]
     b[3], b[4], b[5] = b[3].to(dev), to_device_with_mirror(b[4], dev), to_device_with_mirror(b[5], dev)
     b = tuple(b)
-    tr = Trainer(model, lr=1e-3)
+    tr = Trainer(model, lr=1e-3, pipeline=True)
     for _ in range(8):
         tr.step(b)
     torch.cuda.synchronize()
@@ -65,7 +65,7 @@ def profile():
     b[0] = [im.to(dev) for im in b[0]]
     b[3], b[4], b[5] = b[3].to(dev), to_device_with_mirror(b[4], dev), to_device_with_mirror(b[5], dev)
     b = tuple(b)
-    tr = Trainer(model, lr=1e-3)
+    tr = Trainer(model, lr=1e-3, pipeline=True)
     for _ in range(8):
         tr.step(b)
     torch.cuda.synchronize()
