@@ -130,6 +130,19 @@ class DeviceStager(object):
         self.slots = [_Slot() for _ in range(slots)]
         self._next = 0
 
+    def _alloc(self, slot, cap):
+        slot.pinned = torch.empty(cap, dtype=torch.uint8).pin_memory()
+        slot.pinned_np = slot.pinned.numpy()
+        slot.device = torch.empty(cap, dtype=torch.uint8, device=self.device)
+
+    def reserve(self, nbytes):
+        """Allocates every slot's pinned and device buffer for batches of up to `nbytes` packed bytes now (else: at the first batch)."""
+        for slot in self.slots:
+            if slot.pinned is None or slot.pinned.numel() < nbytes:
+                slot.event.synchronize()
+                self._alloc(slot, int(nbytes))
+        return self
+
     @staticmethod
     def _as_tensor(x):
         if isinstance(x, np.ndarray):
@@ -149,10 +162,10 @@ class DeviceStager(object):
         total = max(total, self.ALIGN)
         slot.event.synchronize()       # host: the previous copy OUT of this pinned buffer has finished
         if slot.pinned is None or slot.pinned.numel() < total:
-            cap = int(total * 1.25)
-            slot.pinned = torch.empty(cap, dtype=torch.uint8).pin_memory()
-            slot.pinned_np = slot.pinned.numpy()
-            slot.device = torch.empty(cap, dtype=torch.uint8, device=self.device)
+            self._alloc(slot, int(total * 1.25))
+            for other in self.slots:   # the whole ring now, not one pinned allocation (milliseconds each) per step for the next len(slots) steps
+                if other.pinned is None:
+                    self._alloc(other, int(total * 1.25))
         # pack with plain single-threaded memcpys (numpy views): torch's CPU copy_ fans a 1 MB image out over every core,
         # and the OpenMP workers then spin-wait next to the HIP runtime's threads -- measured: 6.5 ms per staged forward
         # with this pack, 30-40 ms (random 60-100 ms stalls) with tensor.copy_ on a 128-thread host

@@ -1,8 +1,7 @@
 """Where does the host-input step lose time against the HBM-resident one?  Same trainer, same four batches, 100 steps per variant:
   hbm          batches resident in HBM
   host         DeviceStager.prefetch (pinned async copy on the copy stream, one step ahead)
-  host-nocopy  the same path without the H2D copy itself (the slot's device buffer keeps what an earlier batch left: timing only)
-  host-main    the copy issued on the compute stream instead of the copy stream"""
+  host-Nslots  ring depth"""
 import os
 import sys
 import time
@@ -26,26 +25,6 @@ for k in range(NB):
     hb = list(synthetic_batch(B=8, S=592, n_boxes=32, n_fg=6, seed=111 + 1000 * k))
     hb[0] = [(im * 255).round().to(torch.uint8).permute(1, 2, 0).contiguous() for im in hb[0]]
     hbs.append(tuple(hb))
-
-
-class NoCopy(DeviceStager):
-    def _launch(self, batch, slot, packed):
-        real = torch.Tensor.copy_
-        try:
-            torch.Tensor.copy_ = lambda self_, src, non_blocking=False: self_
-            return DeviceStager._launch(self, batch, slot, packed)
-        finally:
-            torch.Tensor.copy_ = real
-
-
-class MainStream(DeviceStager):
-    def _launch(self, batch, slot, packed):
-        keep = self.stream
-        self.stream = torch.cuda.current_stream(self.device)
-        try:
-            return DeviceStager._launch(self, batch, slot, packed)
-        finally:
-            self.stream = keep
 
 
 st = DeviceStager(dev)
@@ -84,8 +63,10 @@ def run(name, feed):
 
 
 for rep in range(2):
+    run('host-3slots', DeviceStager(dev, slots=3).prefetch(hbs[i % NB] for i in range(n + w)))
     run('hbm', (devb[i % NB] for i in range(n + w)))
-    run('host', DeviceStager(dev).prefetch(hbs[i % NB] for i in range(n + w)))
-    run('host-nocopy', NoCopy(dev).prefetch(hbs[i % NB] for i in range(n + w)))
-    run('host-main', MainStream(dev).prefetch(hbs[i % NB] for i in range(n + w)))
-    run('host-inline', DeviceStager(dev).prefetch((hbs[i % NB] for i in range(n + w)), threaded=False))
+    run('host-16', DeviceStager(dev, slots=16).prefetch(hbs[i % NB] for i in range(n + w)))
+    run('host-6slots', DeviceStager(dev, slots=6).prefetch(hbs[i % NB] for i in range(n + w)))
+    run('host-3slots', DeviceStager(dev, slots=3).prefetch(hbs[i % NB] for i in range(n + w)))
+    run('host-inline16', DeviceStager(dev, slots=16).prefetch((hbs[i % NB] for i in range(n + w)), threaded=False))
+    run('host-inline3', DeviceStager(dev, slots=3).prefetch((hbs[i % NB] for i in range(n + w)), threaded=False))

@@ -65,19 +65,25 @@ def profile():
     b[0] = [im.to(dev) for im in b[0]]
     b[3], b[4], b[5] = b[3].to(dev), to_device_with_mirror(b[4], dev), to_device_with_mirror(b[5], dev)
     b = tuple(b)
-    tr = Trainer(model, lr=1e-3, pipeline=True)
+    if len(sys.argv) > 2 and sys.argv[2] == 'infer':
+        def step_(b_):
+            with torch.no_grad():
+                return model([b_])
+    else:
+        tr = Trainer(model, lr=1e-3, pipeline=True)
+        step_ = tr.step
     for _ in range(8):
-        tr.step(b)
+        step_(b)
     torch.cuda.synchronize()
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(10):
-        tr.step(b)
+        step_(b)
     pr.disable()
     torch.cuda.synchronize()
     st = pstats.Stats(pr)
-    st.sort_stats('tottime').print_stats(28)
-    st.sort_stats('cumtime').print_stats(22)
+    st.sort_stats('tottime').print_stats(30)
+    st.sort_stats('cumtime').print_stats(45)
 
 
 if __name__ == '__main__':
