@@ -183,7 +183,7 @@ class DeviceStager(object):
                 np.copyto(dst[o:o + f.size], f)
         return items, offs, total, len(imgs), rest
 
-    def _launch(self, batch, slot, packed, ring=False):
+    def _launch(self, batch, slot, packed, ring=False, after=None):
         """Device half: ONE async copy of the packed bytes on the copy stream (issued from the consumer's thread, so that it is ordered
         behind the compute already queued there) + the device views.  -> (device tuple, slot)"""
         items, offs, total, n_img, rest = packed
@@ -192,7 +192,9 @@ class DeviceStager(object):
         # not for everything queued so far: waiting for the whole compute stream ties the copy to the previous step's last kernel, and the
         # HIP runtime then resolves the cross-queue dependency with the calling thread blocked (measured: 2.2-2.6 ms per step inside this
         # call, the issuing thread never more than one step ahead of the GPU)
-        if ring and slot.consumed is not None:
+        if after is not None:                       # (prefetch()'s worker thread: an event of the consumer's stream, see there)
+            self.stream.wait_event(after)
+        elif ring and slot.consumed is not None:
             self.stream.wait_event(slot.consumed)
         else:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))
@@ -229,10 +231,11 @@ class DeviceStager(object):
     def prefetch(self, loader, threaded=True):
         """Generator over device-resident batches: the copy of the next batch is issued before the current one is handed to
         the caller, so it runs under the caller's compute.  `loader` yields Blobs or batch tuples.
-        threaded (default): the loader itself and the packing into pinned memory (~1 ms of memcpys per 8-image batch) run on a worker
-        thread, one batch ahead -- the consumer's thread, which is the one that launches the step's ~250 kernels, only issues the copy.
-        A batch's pinned buffer is reused once the copy out of it has finished (slot event), its device buffer once the compute that
-        read it has been queued (the copy stream waits for the compute stream at issue, as in stage())."""
+        threaded (default): the loader itself, the packing into pinned memory (~1 ms of memcpys per 8-image batch) and the launch of the
+        copy run on a worker thread, up to len(slots) - 1 batches ahead -- the consumer's thread, which is the one that launches the step's
+        kernels, only makes its stream wait for the copy's event.  A batch's pinned buffer is reused once the copy out of it has finished
+        (slot event), its device buffer once the step that read it has been ISSUED by the consumer (slot.consumed, an event on the consumer's
+        stream that the next copy into the slot waits for)."""
         for sl in self.slots:          # (events of an earlier generator say nothing about who read the slots last)
             sl.consumed = None
         if not threaded:
@@ -249,13 +252,20 @@ class DeviceStager(object):
             import threading
             S = len(self.slots)
             q = queue.Queue(maxsize=max(1, S - 1))
-            free = [threading.Event() for _ in range(S)]      # slot k: the copy out of its pinned buffer has been ISSUED (event recorded)
+            # slot k: its DEVICE buffer may be overwritten (the consumer has recorded `consumed` for the batch that was in it, or the slot
+            # has not been used by this generator).  The worker does everything up to and including the launch of the copy -- the consumer's
+            # thread, which issues the step's kernels, only takes a finished item off the queue (round 4: 0.3 ms per batch on that thread
+            # before, which a loop that synchronises every step -- inference, `filter_dets` on the host -- pays in full)
+            free = [threading.Event() for _ in range(S)]
             for f in free:
                 f.set()
             stop = threading.Event()
+            start_ev = torch.cuda.Event()
+            start_ev.record(torch.cuda.current_stream(self.device))     # whatever read the slots before this generator was queued before this point
 
             def work():
                 try:
+                    torch.cuda.set_device(self.device)
                     k = self._next
                     for b in loader:
                         b = b[0] if isinstance(b, Blob) else b
@@ -263,7 +273,15 @@ class DeviceStager(object):
                             if stop.is_set():
                                 return
                         free[k].clear()
-                        q.put((b, k, self._pack(b, self.slots[k])))
+                        slot = self.slots[k]
+                        item = self._launch(b, slot, self._pack(b, slot), ring=True, after=slot.consumed if slot.consumed is not None else start_ev)
+                        while True:
+                            try:
+                                q.put(item + (k,), timeout=0.05)
+                                break
+                            except queue.Full:
+                                if stop.is_set():
+                                    return
                         k = (k + 1) % S
                         if stop.is_set():
                             return
@@ -279,11 +297,8 @@ class DeviceStager(object):
                     return None
                 if isinstance(item, BaseException):
                     raise item
-                b, k, packed = item
-                out = self._launch(b, self.slots[k], packed, ring=True)
-                self._next = (k + 1) % S
-                free[k].set()
-                return out
+                self._next = (item[2] + 1) % S
+                return item
         try:
             cur = grab()
             while cur is not None:
@@ -293,6 +308,8 @@ class DeviceStager(object):
                 if cur[1].consumed is None:
                     cur[1].consumed = torch.cuda.Event()
                 cur[1].consumed.record(torch.cuda.current_stream(self.device))  # the step on batch i has been issued: its slot may be refilled after this point
+                if threaded:
+                    free[cur[2]].set()
                 cur = nxt
         finally:
             if threaded:
