@@ -16,7 +16,7 @@ model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls')).to
 tr = Trainer(model, lr=1e-3, pipeline=True)
 for i in range(10): tr.step(bs[i%3])
 tr.flush(); torch.cuda.synchronize()
-for chunk in range(12):
+for chunk in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
     t0=time.time()
     for i in range(100): tr.step(bs[i%3])
     tr.flush(); torch.cuda.synchronize()
