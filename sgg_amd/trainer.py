@@ -480,6 +480,16 @@ class Trainer(object):
         self.model._operands_ready = ev
         return True
 
+    def __del__(self):
+        # the objects frozen by step() (gc.freeze) go back under the collector's eyes with their trainer: a process that builds many
+        # models (test suites, sweeps) must not keep their reference cycles alive for good
+        if getattr(self, '_gc_frozen', False):
+            try:
+                import gc
+                gc.unfreeze()
+            except Exception:
+                pass
+
     def update(self):
         """The tail of a step for gradients that already exist (p.grad, the early-started buckets of the backward's hooks, the kept
         wire-dtype gradients of the one-GPU path): reduce over the ranks, global-norm clip, SGD -- on the current stream.  step() ends
