@@ -1,7 +1,7 @@
 """How busy is the GPU inside one train step?  From a rocprofv3 --kernel-trace database (rocpd schema): the kernels of the last full steps,
 their union coverage of the wall time (any stream), the time during which exactly one / two or more kernels run, and the largest gaps.
     rocprofv3 --kernel-trace -d out -o t -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32
-    python tools/timeline.py out/.../t_results.db"""
+    python tools/timeline.py out/.../t_results.db [first step]"""
 import sqlite3
 import sys
 
@@ -15,7 +15,8 @@ marks = [r[1] for r in rows if 'conv3x3_spatial_kernel' in r[0] and 'true' in r[
 if len(marks) < 4:
     marks = [r[1] for r in rows if 'image_prep_batch' in r[0]]
 print('steps seen:', len(marks))
-lo, hi = marks[-4], marks[-1]                      # three whole steps
+k0 = int(sys.argv[2]) if len(sys.argv) > 2 else len(marks) - 4     # first of the three whole steps looked at (default: the last three)
+lo, hi = marks[k0], marks[k0 + 3]
 sel = [r for r in rows if lo <= r[1] < hi]
 wall = (hi - lo) / 1e3
 events = []
