@@ -235,7 +235,10 @@ class DeviceStager(object):
         copy run on a worker thread, up to len(slots) - 1 batches ahead -- the consumer's thread, which is the one that launches the step's
         kernels, only makes its stream wait for the copy's event.  A batch's pinned buffer is reused once the copy out of it has finished
         (slot event), its device buffer once the step that read it has been ISSUED by the consumer (slot.consumed, an event on the consumer's
-        stream that the next copy into the slot waits for)."""
+        stream that the next copy into the slot waits for).
+        Contract (as with any loader that hands out recycled device buffers): everything that reads batch i must be ISSUED, on the stream
+        that is current when the generator is resumed, before batch i + 1 is requested -- work issued on batch i after that request is not
+        ordered against the copy that refills its slot len(slots) batches later.  Clone what has to live longer."""
         for sl in self.slots:          # (events of an earlier generator say nothing about who read the slots last)
             sl.consumed = None
         if not threaded:
