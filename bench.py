@@ -689,8 +689,9 @@ def main():
             'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'host_issue_ms_per_step': round(head_issue_ms, 3), 'host_feed_ms_per_step': round(head_feed_ms, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'input': ('host-resident Blob tuples (decoded u8 images + gt tensors on the host) through DeviceStager.prefetch: one pinned async '
-                      'copy per batch on a copy stream, one step ahead' if args.input == 'host' else 'batches resident in HBM'),
+            'input': ('host-resident Blob tuples (decoded u8 images + gt tensors on the host) through DeviceStager.prefetch: a worker thread packs '
+                      'each batch into pinned memory and launches ONE async copy per batch on a copy stream (ring of %d slots, ahead of the '
+                      'consumer); gc.freeze() after warm-up' % len(stager.slots) if args.input == 'host' else 'batches resident in HBM'),
             ('hbm_resident' if args.input == 'host' else 'host_input'): {
                 'value': round(world * B * args.steps / elapsed_other, 3), 'unit': 'images/s', 'ms_per_step': round(1e3 * elapsed_other / args.steps, 3), 'host_issue_ms_per_step': round(other_issue_ms, 3),
                 'steps': args.steps, 'note': 'the same rotation over the same %d batches with the %s' % (
