@@ -84,6 +84,7 @@ def profile():
     st = pstats.Stats(pr)
     st.sort_stats('tottime').print_stats(30)
     st.sort_stats('cumtime').print_stats(45)
+    st.print_callees('_queue_update|train_weights|prepared')
 
 
 if __name__ == '__main__':
