@@ -9,7 +9,7 @@ from sgg_amd import ops
 dev = 'cuda:0'
 cu = lambda t: (torch.from_numpy(np.ascontiguousarray(t)) if isinstance(t, np.ndarray) else t.contiguous()).to(dev)
 rng = np.random.RandomState(0)
-stats = {'imp': 0, 'gemm': 0, 'tn': 0, 'conv': 0, 'roi': 0, 'raster': 0, 'pairs': 0, 'unordered': 0}
+stats = {'imp': 0, 'gemm': 0, 'tn': 0, 'tn256': 0, 'conv': 0, 'roi': 0, 'raster': 0, 'pairs': 0, 'unordered': 0}
 
 
 def fuzz_imp():
@@ -94,6 +94,31 @@ def fuzz_tn():
     ref = A.float().t() @ B.float()
     torch.testing.assert_close(out.cpu(), ref, atol=0.05 * (Mred ** 0.5) / 8, rtol=2e-2, msg=lambda m: 'tn Mred=%d N=%d K=%d: %s' % (Mred, N, K, m))
     stats['tn'] += 1
+
+
+def fuzz_tn256():
+    """sgg_gemm_tn256 (the ping-pong kernel's TN form): whole 256 x 256 tiles, ANY number of reduction rows (the zero-padded tail tile),
+    both 16-bit types, optional group addend, column blocks of wider operands, 16-bit / fp32 output"""
+    Mred = int(rng.randint(1, 1500))
+    N, K = 256 * int(rng.randint(1, 4)), 256 * int(rng.randint(1, 5))
+    dtype = torch.float16 if rng.rand() < 0.5 else torch.bfloat16
+    g = torch.Generator().manual_seed(int(rng.randint(1 << 30)))
+    extra = 256 * int(rng.randint(0, 2))
+    A = (torch.randn(Mred, N, generator=g) / 4).to(dtype)
+    Bw = torch.randn(Mred, K + extra, generator=g).to(dtype)
+    B = Bw[:, extra:]
+    ref = cu(A).float().t() @ cu(Bw)[:, extra:].float()
+    gadd = None
+    if rng.rand() < 0.5:
+        group = int(rng.choice([8, 49, 64]))
+        r = torch.randn(N, (K + extra) // group + 2, generator=g)
+        gadd = (cu(r), group)
+        ref = ref + cu(r)[:, (torch.arange(K, device=dev) + extra) // group]
+    out_dtype = torch.float32 if rng.rand() < 0.5 else dtype
+    out = ops.gemm_tn256(cu(A), cu(Bw)[:, extra:], out_dtype=out_dtype, gadd=gadd, col0=extra if gadd is not None else 0)
+    tol = dict(atol=2e-3 * (Mred ** 0.5) + 1e-3, rtol=1e-4) if out_dtype == torch.float32 else dict(atol=0.03 * (Mred ** 0.5) + 0.05, rtol=2e-2)
+    torch.testing.assert_close(out.float(), ref, msg=lambda m: 'tn256 Mred=%d N=%d K=%d %s gadd=%s: %s' % (Mred, N, K, dtype, gadd is not None, m), **tol)
+    stats['tn256'] = stats.get('tn256', 0) + 1
 
 
 def fuzz_conv():
@@ -250,6 +275,7 @@ def run(budget=60.0, seed=0):
         fuzz_imp()
         fuzz_gemm()
         fuzz_tn()
+        fuzz_tn256()
         fuzz_conv()
         fuzz_roi()
         fuzz_raster()
