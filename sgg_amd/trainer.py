@@ -518,12 +518,15 @@ class Trainer(object):
             self.model._grad_ready_hook, self.model._grad_wire_dtype = self._keep, self._local_wire
         self.model._loss_scaled = True          # this backward carries the f16 loss scale (train.py warns about one that does not)
         try:
-            if fused:
-                # the real gradients wait in model._logit_grads; autograd only needs placeholders of the outputs' shape (no launch)
-                torch.autograd.backward([res.rm_obj_dists, res.rel_dists],
-                                        [torch.empty_like(res.rm_obj_dists), torch.empty_like(res.rel_dists)])
-            else:
-                (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
+            # the backward of the head is ONE Python function (train.PredictFn.backward): run it on this thread instead of handing it to
+            # autograd's device thread and waiting for it (SGG_BWD_THREAD=1 restores the engine's default)
+            with torch.autograd.set_multithreading_enabled(os.environ.get('SGG_BWD_THREAD', '0') == '1'):
+                if fused:
+                    # the real gradients wait in model._logit_grads; autograd only needs placeholders of the outputs' shape (no launch)
+                    torch.autograd.backward([res.rm_obj_dists, res.rel_dists],
+                                            [torch.empty_like(res.rm_obj_dists), torch.empty_like(res.rel_dists)])
+                else:
+                    (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
         finally:
             self.model._logit_grads = None
             self.model._loss_scaled = False
