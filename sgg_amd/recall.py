@@ -13,7 +13,6 @@ What runs where: the graph-unconstrained ranking (argsort of obj_s * obj_o * rel
 of the FIRST matching prediction of each GT triplet: |union(pred_to_gt[:K])| = #{g : first_rank[g] < K}.
 The bookkeeping around it (result_dict layout, printing, per-predicate evaluator lists) is host Python as in the reference.
 """
-import math
 import pickle
 
 import numpy as np

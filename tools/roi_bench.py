@@ -8,7 +8,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def run():
-    import numpy as np
     import torch
 
     from sgg_amd import ops
