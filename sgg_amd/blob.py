@@ -239,8 +239,13 @@ class DeviceStager(object):
         Contract (as with any loader that hands out recycled device buffers): everything that reads batch i must be ISSUED, on the stream
         that is current when the generator is resumed, before batch i + 1 is requested -- work issued on batch i after that request is not
         ordered against the copy that refills its slot len(slots) batches later.  Clone what has to live longer."""
+        if len(self.slots) < 2:
+            # batch i + 1 is copied while batch i is being read: with one slot that copy would overwrite the batch in use (in line), or the
+            # worker would wait for a slot that is only released after the first yield (threaded: a deadlock)
+            raise ValueError('DeviceStager.prefetch needs at least 2 slots (got %d); stage() works with one' % len(self.slots))
         for sl in self.slots:          # (events of an earlier generator say nothing about who read the slots last)
             sl.consumed = None
+        th = None
         if not threaded:
             it = iter(loader)
 
@@ -288,9 +293,18 @@ class DeviceStager(object):
                         k = (k + 1) % S
                         if stop.is_set():
                             return
-                    q.put(None)
+                    put_last(None)
                 except BaseException as e:      # surfaces in the consumer
-                    q.put(e)
+                    put_last(e)
+
+            def put_last(item):
+                """the end-of-stream mark / the worker's exception: never blocks for good on a consumer that has gone away"""
+                while not stop.is_set():
+                    try:
+                        q.put(item, timeout=0.05)
+                        return
+                    except queue.Full:
+                        pass
             th = threading.Thread(target=work, name='sgg-stager', daemon=True)
             th.start()
 
@@ -317,3 +331,5 @@ class DeviceStager(object):
         finally:
             if threaded:
                 stop.set()
+                if th is not None and th is not threading.current_thread():
+                    th.join(timeout=5.0)      # no late _launch of this generator's worker beside a following prefetch() / stage() on the same slots

@@ -549,7 +549,14 @@ int launch256_sk(const GemmArgs& g, int grid, hipStream_t s) {
 }
 
 std::mutex sk_mu;
-std::map<void*, SkWorkspace> sk_reg;      // stream -> its workspace (launches of one stream are ordered: one set of slots suffices)
+// (device, stream) -> its workspace (launches of one stream are ordered: one set of slots suffices).  The device is part of the key: the
+// default stream is the same handle (0) on every device of a process.
+std::map<std::pair<int, void*>, SkWorkspace> sk_reg;
+std::pair<int, void*> sk_key(void* stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    return std::make_pair(dev, stream);
+}
 int sk_mode_value = -1;
 int sk_mode() {
     if (sk_mode_value < 0) {
@@ -564,8 +571,20 @@ int sk_mode() {
 
 SkWorkspace* sgg_sk_workspace_of(void* stream) {
     std::lock_guard<std::mutex> lk(sk_mu);
-    auto it = sk_reg.find(stream);
+    auto it = sk_reg.find(sk_key(stream));
     return it == sk_reg.end() ? nullptr : &it->second;
+}
+
+// The workspace of `stream` with its launch epoch advanced (under the registry's lock), by value; false: no workspace
+static bool sk_next_epoch(void* stream, SkWorkspace& out) {
+    std::lock_guard<std::mutex> lk(sk_mu);
+    auto it = sk_reg.find(sk_key(stream));
+    if (it == sk_reg.end()) return false;
+    SkWorkspace& w = it->second;
+    w.epoch = (w.epoch + 1) & 0x7fffffffu;
+    if (w.epoch == 0) w.epoch = 1;
+    out = w;
+    return true;
 }
 
 int sgg_sk_grid() {
@@ -586,7 +605,7 @@ extern "C" int64_t sgg_streamk_workspace_bytes(void) { return (int64_t)SK_MAX_GR
 extern "C" int sgg_streamk_workspace(void* stream, void* ws, int64_t bytes) {
     std::lock_guard<std::mutex> lk(sk_mu);
     if (!ws) {
-        sk_reg.erase(stream);
+        sk_reg.erase(sk_key(stream));
         return SGG_OK;
     }
     if (((uintptr_t)ws & 255) || bytes < sgg_streamk_workspace_bytes()) return SGG_ERR_ARG;
@@ -595,7 +614,7 @@ extern "C" int sgg_streamk_workspace(void* stream, void* ws, int64_t bytes) {
     w.slots = reinterpret_cast<char*>(ws) + SK_MAX_GRID * 4;      // ... then the slots
     w.epoch = 0;
     w.max_grid = SK_MAX_GRID;
-    sk_reg[stream] = w;
+    sk_reg[sk_key(stream)] = w;
     return SGG_OK;
 }
 
@@ -615,6 +634,11 @@ int sgg_pingpong_streamk(long tiles, int nt, void* stream, int* dp_rounds, int* 
     if (mode == 0) return 0;
     const int G = sgg_sk_grid();
     if (G <= 0 || !sgg_sk_workspace_of(stream)) return 0;
+    // The hand-over flags carry the launch's EPOCH, a host counter that travels in the kernel arguments: a launch captured into a
+    // hipGraph would replay with the epoch it was captured with, find the flags of its previous replay "published" and read slots the
+    // current replay is still writing.  A capturing stream therefore always gets the plain launch (same bits, one kernel per round).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 0;
     int dp = 0, sk = 0;
     sk_split(tiles, G, dp, sk);
     if (sk == 0 || nt < 2 * SK_MIN_SEG) return 0;
@@ -635,11 +659,10 @@ int sgg_launch_pingpong_sk(const GemmArgs& g_in, int dt, bool conv, hipStream_t 
     // the stream-K form's epilogue carries bias, activation and a group addend whose groups span >= 40 columns (256 columns touch <= 8)
     const bool epilogue_ok = !g.pscale && !g.pshift && !g.add_rows && (!g.gadd || g.ggroup >= 40);
     if (g.m_base != 0 || !epilogue_ok || !sgg_pingpong_streamk(tiles, g.nt, (void*)s, &dp, &sk)) return 1;
-    SkWorkspace* w = sgg_sk_workspace_of((void*)s);
+    SkWorkspace w;
+    if (!sk_next_epoch((void*)s, w)) return 1;
     const int G = sgg_sk_grid();
-    w->epoch = (w->epoch + 1) & 0x7fffffffu;
-    if (w->epoch == 0) w->epoch = 1;
-    g.sk_ws = w->slots; g.sk_flags = w->flags; g.sk_epoch = w->epoch | (sk_mode() == 3 ? 0x80000000u : 0u); g.sk_dp_rounds = dp; g.sk_tiles = sk;
+    g.sk_ws = w.slots; g.sk_flags = w.flags; g.sk_epoch = w.epoch | (sk_mode() == 3 ? 0x80000000u : 0u); g.sk_dp_rounds = dp; g.sk_tiles = sk;
     if (dt == SGG_BF16) return conv ? launch256_sk<SGG_BF16, true>(g, G, s) : launch256_sk<SGG_BF16, false>(g, G, s);
     if (dt == SGG_F16) return conv ? launch256_sk<SGG_F16, true>(g, G, s) : launch256_sk<SGG_F16, false>(g, G, s);
     return conv ? launch256_sk<SGG_F32, true>(g, G, s) : launch256_sk<SGG_F32, false>(g, G, s);

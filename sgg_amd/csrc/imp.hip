@@ -28,6 +28,25 @@ constexpr int MAXH = 512;  // one wave covers H <= 512 with 8 channels per lane
 // v_rcp_f32, common.h: the precise expf / division / tanhf made this HBM-streaming kernel VALU-bound -- 18.4 -> 14.1 us at 8 images).
 // `o` (the new state, 8 channels of row m) -> h_out; with dot_w also the four gate dot products of the row AS STORED.
 // H/8 lanes (a power of two <= 64) hold one row, rows never straddle a wave, whole rows are active or inactive together.
+// x from the lane's DPP partner, 0 where the control selects no lane / the row mask excludes the row (VALU only: no LDS crossbar)
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ float dpp_get(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xF, false));
+}
+
+// Sum of x over a group of G consecutive lanes (G a power of two <= 64, groups aligned), valid in the group's LAST lane.  DPP only:
+// quad permutes, half-row / row mirrors, then row_bcast15 / row_bcast31 carry a row's total into the next row(s).  (Until round 5 this
+// was a ds_bpermute butterfly; tools/gate_race.py showed that form returning a wrong partial in ~15 % of the launches of the f32 gate
+// kernel while an f16 MFMA GEMM of another stream shared the chip -- the x3 mode's non-reproducible logits)
+__device__ __forceinline__ float group_sum_last_lane(float x, int G) {
+    if (G >= 2) x += dpp_get<0xB1>(x);             // quad_perm [1,0,3,2]
+    if (G >= 4) x += dpp_get<0x4E>(x);             // quad_perm [2,3,0,1]: every lane of a quad holds the quad's sum
+    if (G >= 8) x += dpp_get<0x141>(x);            // row_half_mirror: ... of 8 lanes
+    if (G >= 16) x += dpp_get<0x140>(x);           // row_mirror: every lane of a 16-lane row holds the row's sum
+    if (G >= 32) x += dpp_get<0x142, 0xA>(x);      // row_bcast15 into rows 1 and 3: rows 0+1, rows 2+3
+    if (G >= 64) x += dpp_get<0x143, 0xC>(x);      // row_bcast31 into rows 2 and 3: row 3 holds all four
+    return x;
+}
+
 template <typename T>
 __device__ __forceinline__ void gru_store_with_dots(float (&o)[8], T* __restrict__ h_out, long m, int c, int H,
                                                     const float* __restrict__ dot_w, int dot_ld, float* __restrict__ dots) {
@@ -44,11 +63,10 @@ __device__ __forceinline__ void gru_store_with_dots(float (&o)[8], T* __restrict
 #pragma unroll
         for (int j = 0; j < 8; ++j) p[k] = fmaf(w[j], o[j], p[k]);
     }
-    for (int off = (H >> 3) >> 1; off > 0; off >>= 1) {
+    const int G = H >> 3;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) p[k] += __shfl_xor(p[k], off, 64);
-    }
-    if (c == 0) *reinterpret_cast<f32x4*>(dots + m * 4) = f32x4{p[0], p[1], p[2], p[3]};
+    for (int k = 0; k < 4; ++k) p[k] = group_sum_last_lane(p[k], G);
+    if (c == H - 8) *reinterpret_cast<f32x4*>(dots + m * 4) = f32x4{p[0], p[1], p[2], p[3]};
 }
 
 __device__ __forceinline__ void gru_cell(const float (&ir)[8], const float (&iz)[8], const float (&in_)[8], const float (&hr)[8],

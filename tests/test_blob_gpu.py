@@ -112,3 +112,24 @@ def test_prefetch_delivers_every_batch_intact_in_order(env, threaded):
     with pytest.raises(KeyError):
         for _ in stager.prefetch(bad(), threaded=threaded):
             pass
+
+
+@pytest.mark.parametrize('threaded', [True, False])
+def test_prefetch_refuses_one_slot_and_survives_an_abandoned_consumer(env, threaded):
+    """slots=1 used to deadlock (threaded) or overwrite the batch in use (in line); a consumer that walks away must not leave the
+    worker blocked on its queue or racing a following prefetch() on the same slots."""
+    import threading
+    from sgg_amd.blob import DeviceStager
+    rng = np.random.RandomState(3)
+    mk = lambda: ([rng.randint(0, 256, size=(32, 48, 3)).astype(np.uint8)], np.array([[48, 48, 1.0]]), 0, torch.rand(2, 4),
+                  torch.zeros((2, 2), dtype=torch.int64), torch.zeros((1, 4), dtype=torch.int64), None, ['a'])
+    with pytest.raises(ValueError):
+        next(DeviceStager(slots=1).prefetch(iter([mk(), mk()]), threaded=threaded))
+    stager = DeviceStager(slots=2)
+    before = threading.active_count()
+    gen = stager.prefetch(iter([mk() for _ in range(9)]), threaded=threaded)
+    next(gen)
+    gen.close()                                   # the consumer goes away after one batch
+    assert threading.active_count() <= before     # the worker has been joined
+    assert sum(1 for _ in stager.prefetch(iter([mk() for _ in range(5)]), threaded=threaded)) == 5
+    torch.cuda.synchronize()

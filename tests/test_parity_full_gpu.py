@@ -1,109 +1,30 @@
 """Parity of the BENCHMARKED configuration against the fp32 CPU oracle, with explicit numbers:
 
- (i)  logits of the bench batch -- 8 x 592x592 frames, 32 boxes and 992 edges each, seed 111 -- against oracle.forward_gtbox on the
-      same inputs and weights, in all three modes: f32 (the reference's own precision: the north star's 1e-3 bar), f16 (the benchmarked
-      16-bit mode: rel <= 0.03, obj <= 0.1 -- the bounds VERDICT r2 set) and bf16 (BASELINE.json's wording of the configuration: the same
-      kernels at the same speed with 8x the rounding error -- reported and bounded where it is, not where the clause wants it);
- (ii) R@K of the HIP forward (f16, bf16 and fp32) against R@K of the ORACLE forward -- four forwards, one evaluator each -- on 2 048
+ (i)  R@K of the HIP forward (f16, bf16 and fp32) against R@K of the ORACLE forward -- four forwards, one evaluator each -- on 2 048
       ground-truth triplets (one triplet = 0.05 points), with a head trained (in f16) until its softmaxes mean something (R@50 ~ 40 %):
       the north star's +-0.1 on R@50 is demanded of f32 AND f16 in every cell (graph-constrained and not, sgcls and predcls,
-      K = 20 / 50 / 100).
+      K = 20 / 50 / 100).  First in the file: it is the evidence the 16-bit bounds of (ii) rest on.
+ (ii) logits of the bench batch -- 8 x 592x592 frames, 32 boxes and 992 edges each, seed 111 -- against oracle.forward_gtbox on the
+      same inputs and weights, ONE TEST PER MODE: f32 (the reference's own precision: the north star's 1e-3 bar),
+      f16 (the benchmarked 16-bit mode: rel <= 0.03, obj <= 0.1 -- the bounds VERDICT r2 set) and bf16 (BASELINE.json's wording of the
+      configuration: the same kernels at the same speed with 8x the rounding error -- reported and bounded where it is, not where the
+      clause wants it).  The x3 mode's tests at this size live in tests/test_zz_x3_bench_gpu.py (collected last).
 Both write what they measured to gpurun_out/ (copied to profiles/ by the round's author).  Training is bit-reproducible since round 3
-(tests/test_f16_gpu.py), so these numbers no longer move from run to run."""
+(tests/test_f16_gpu.py), so these numbers do not move from run to run."""
 import json
 import os
-import time
 
 import numpy as np
 import pytest
 import torch
 
 from oracle import sgg_oracle as O
+from tests.parity_common import DEV, dump as _dump, mode_report
 
 pytestmark = pytest.mark.gpu
-DEV = 'cuda:0'
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _dump(name, payload):
-    out = os.path.join(ROOT, 'gpurun_out')
-    try:
-        os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, name), 'w') as f:
-            json.dump(payload, f, indent=1, sort_keys=True)
-    except OSError:
-        pass
-
-
-def _logits(model, batch):
-    """(obj_dists, rel_dists, rel_inds) of the eval forward, before the tail."""
-    dev = model.rel_fc.weight.device
-    with torch.no_grad():
-        res = model.faster_rcnn(batch[0], batch[3].to(dev), batch[4].to(dev), None)
-        rel_inds = model.get_rel_inds(None, res.im_inds, res.rm_box_priors)
-        rois = torch.cat((res.im_inds[:, None].float(), res.rm_box_priors), 1)
-        nf, ef = model.node_edge_features(res.fmap, rois, rel_inds[:, 1:], res.im_sizes)
-        od, rd = model.predict(nf, ef, rel_inds, rois, res.im_sizes, _im_inds=res.im_inds.contiguous())
-    return od.float().cpu().numpy(), rd.float().cpu().numpy(), rel_inds.cpu().numpy()
-
-
-# bounds of (i).  f16: VERDICT r2's bars (observed on MI355X: obj max 0.056 / mean 0.0076, rel max 0.011 / mean 0.0019, against logits of
-# magnitude <= 3.9 / 2.4 with the He-initialised random weights of the bench; fp32 mode: 7.5e-5 / 1.8e-5).  bf16: about twice what was
-# observed (obj max 0.42 / mean 0.058, rel max 0.10 / mean 0.018).  Where the 16-bit error comes from was measured with
-# tools/precision_probe.py (profiles/r03_precision_probe.txt): it is the operand rounding of the contractions -- VGG-16's 13 layers alone
-# are obj 0.35 / rel 0.076 of the bf16 figures, the head's GEMMs most of the rest; node-side state storage (round 2's guess) is 0.01.
-F16_MAX_ABS = {'obj': 0.1, 'rel': 0.03}
-F16_MEAN_ABS = {'obj': 0.015, 'rel': 0.004}
-BF16_MAX_ABS = {'obj': 0.85, 'rel': 0.2}
-BF16_MEAN_ABS = {'obj': 0.12, 'rel': 0.04}
-
-
-def test_bench_config_bf16_logits_within_stated_tolerance():
-    if not torch.cuda.is_available():
-        pytest.skip('no GPU')
-    import sgg_amd
-    from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
-    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls'))
-    sd = {k: v.clone() for k, v in model.state_dict().items()}
-    model.to(DEV).eval()
-    batch = synthetic_batch(B=8, S=592, n_boxes=32, n_fg=6, seed=111)          # bench.py's rank-0 batch
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    t0 = time.time()
-    with torch.no_grad():
-        ref = O.forward_gtbox(batch[0], batch[3], batch[4], batch[5], sd, mode='sgcls')
-    t_ref = time.time() - t0
-    ref_od, ref_rd = ref['rm_obj_dists'].numpy(), ref['rel_dists'].numpy()
-    report = {'config': '8 x 592x592, 32 boxes, 992 edges per image, seed 111', 'oracle_seconds': round(t_ref, 1)}
-    for name, dt in (('f32', torch.float32), ('x3', 'x3'), ('f16', torch.float16), ('bf16', torch.bfloat16)):
-        if dt == 'x3':
-            model.set_compute_dtype(torch.float32, split3=True)      # the fast mode inside the 1e-3 clause: f16 split operands, fp32 accumulate
-        else:
-            model.set_compute_dtype(dt)
-        od, rd, rel_inds = _logits(model, batch)
-        np.testing.assert_array_equal(rel_inds, ref['rel_inds'])
-        assert od.shape == (256, 151) and rd.shape == (7936, 51)
-        e_o, e_r = np.abs(od - ref_od), np.abs(rd - ref_rd)
-        report[name] = {'obj_max_abs': float(e_o.max()), 'obj_mean_abs': float(e_o.mean()), 'rel_max_abs': float(e_r.max()),
-                        'rel_mean_abs': float(e_r.mean()), 'obj_logit_absmax': float(np.abs(ref_od).max()),
-                        'rel_logit_absmax': float(np.abs(ref_rd).max()),
-                        'obj_argmax_agreement': float((od[:, 1:].argmax(1) == ref_od[:, 1:].argmax(1)).mean()),
-                        'rel_argmax_agreement': float((rd[:, 1:].argmax(1) == ref_rd[:, 1:].argmax(1)).mean())}
-    model.set_compute_dtype(torch.float16)
-    _dump('r04_parity_bench_config.json', report)
-    print(json.dumps(report, indent=1))
-    f32, f16, b16 = report['f32'], report['f16'], report['bf16']
-    assert f32['obj_max_abs'] <= 1e-3 and f32['rel_max_abs'] <= 1e-3, f32                 # the north star's fp32 bar, at full size
-    x3 = report['x3']
-    assert x3['obj_max_abs'] <= 1e-3 and x3['rel_max_abs'] <= 1e-3, x3                    # ... which the x3 mode meets too
-    assert x3['obj_argmax_agreement'] == 1.0 and x3['rel_argmax_agreement'] == 1.0, x3
-    assert f16['obj_max_abs'] <= F16_MAX_ABS['obj'] and f16['rel_max_abs'] <= F16_MAX_ABS['rel'], f16
-    assert f16['obj_mean_abs'] <= F16_MEAN_ABS['obj'] and f16['rel_mean_abs'] <= F16_MEAN_ABS['rel'], f16
-    assert f16['obj_argmax_agreement'] >= 0.97 and f16['rel_argmax_agreement'] >= 0.99, f16
-    assert b16['obj_max_abs'] <= BF16_MAX_ABS['obj'] and b16['rel_max_abs'] <= BF16_MAX_ABS['rel'], b16
-    assert b16['obj_mean_abs'] <= BF16_MEAN_ABS['obj'] and b16['rel_mean_abs'] <= BF16_MEAN_ABS['rel'], b16
-
-
-# ------------------------------------------------------------------------------------------------- (ii) recall parity
+# ------------------------------------------------------------------------------------------------- (i) recall parity
 S_R, NB_R, NREL_R, NCLS_R = 320, 16, 32, 24
 
 
@@ -219,7 +140,7 @@ def test_recall_of_hip_forward_equals_recall_of_oracle_forward():
                                              for m in ('sgcls', 'predcls') for k in KS)
     report = {'gt_triplets': n_trip, 'images': len(gts['sgcls']), 'train_steps': steps, 'final_loss': final_loss, 'recall_percent': table,
               'largest_abs_difference_to_oracle_points': worst, 'one_triplet_is_points': 100.0 / n_trip}
-    _dump('r03_recall_parity.json', report)
+    _dump('r05_recall_parity.json', report)
     print(json.dumps(report, indent=1))
     r50 = table['sgcls oracle_fp32 GC']['R@50']
     assert 5.0 < r50 < 95.0, 'recall at the floor / ceiling: the comparison would not discriminate'
@@ -229,3 +150,42 @@ def test_recall_of_hip_forward_equals_recall_of_oracle_forward():
     # bf16 (8 bits of significand) is reported where it is: 1 - 3 triplets of 2 048 graph-constrained, 5 - 7 unconstrained in round 2
     assert worst['hip_bf16 GC'] <= 0.35, worst
     assert worst['hip_bf16 noGC'] <= 0.6, worst
+
+
+# ------------------------------------------------------------------------------------------------- (ii) logits at the bench configuration
+# f16: VERDICT r2's bars (observed on MI355X: obj max 0.056 / mean 0.0076, rel max 0.011 / mean 0.0019, against logits of
+# magnitude <= 3.9 / 2.4 with the He-initialised random weights of the bench; fp32 mode: 7.5e-5 / 1.8e-5).  bf16: about twice what was
+# observed (obj max 0.42 / mean 0.058, rel max 0.10 / mean 0.018).  Where the 16-bit error comes from was measured with
+# tools/precision_probe.py (profiles/r03_precision_probe.txt): it is the operand rounding of the contractions -- VGG-16's 13 layers alone
+# are obj 0.35 / rel 0.076 of the bf16 figures, the head's GEMMs most of the rest; node-side state storage (round 2's guess) is 0.01.
+F16_MAX_ABS = {'obj': 0.1, 'rel': 0.03}
+F16_MEAN_ABS = {'obj': 0.015, 'rel': 0.004}
+BF16_MAX_ABS = {'obj': 0.85, 'rel': 0.2}
+BF16_MEAN_ABS = {'obj': 0.12, 'rel': 0.04}
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+
+
+def test_bench_config_f32_logits_within_the_north_stars_1e3():
+    _gpu()
+    f32 = mode_report('f32')
+    assert f32['obj_max_abs'] <= 1e-3 and f32['rel_max_abs'] <= 1e-3, f32                 # the north star's fp32 bar, at full size
+    assert f32['obj_argmax_agreement'] == 1.0 and f32['rel_argmax_agreement'] == 1.0, f32
+
+
+def test_bench_config_f16_logits_within_stated_bounds():
+    _gpu()
+    f16 = mode_report('f16')
+    assert f16['obj_max_abs'] <= F16_MAX_ABS['obj'] and f16['rel_max_abs'] <= F16_MAX_ABS['rel'], f16
+    assert f16['obj_mean_abs'] <= F16_MEAN_ABS['obj'] and f16['rel_mean_abs'] <= F16_MEAN_ABS['rel'], f16
+    assert f16['obj_argmax_agreement'] >= 0.97 and f16['rel_argmax_agreement'] >= 0.99, f16
+
+
+def test_bench_config_bf16_logits_within_stated_bounds():
+    _gpu()
+    b16 = mode_report('bf16')
+    assert b16['obj_max_abs'] <= BF16_MAX_ABS['obj'] and b16['rel_max_abs'] <= BF16_MAX_ABS['rel'], b16
+    assert b16['obj_mean_abs'] <= BF16_MEAN_ABS['obj'] and b16['rel_mean_abs'] <= BF16_MEAN_ABS['rel'], b16
