@@ -385,6 +385,9 @@ def sgdet_bench(args, model, batch, timed, world, rank, B, dev):
 
 def main():
     args = parse()
+    if os.environ.get('SGG_BENCH_NOGC'):          # debugging only: no cyclic collection at all
+        import gc
+        gc.disable()
     host_group = None
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(launch(args))          # nothing above this line has touched the GPU
@@ -474,6 +477,7 @@ def main():
 
     feed_ms = [0.0]     # ... of which inside the feed's next()
     issue_ms = [0.0]    # of the last timed() call: host time per step until the last step was ISSUED (no synchronisation inside)
+    wait_ms = [0.0]     # ... of which the issuing thread spent WAITING for the GPU on purpose (the replayed step's run-ahead bound, sgg_amd/graph_step.py)
 
     def timed(fn, warmup, steps, feed=feed_hbm):
         """`warmup` untimed + EXACTLY `steps` timed steps, each on the next batch of `feed` (one iterator over warmup + steps batches: with
@@ -498,6 +502,7 @@ def main():
             prof_.enable()
         t0 = time.perf_counter()
         feed_s = 0.0
+        w0 = trainer.graphs.stats['wait_s'] if (trainer is not None and trainer.graphs is not None) else 0.0
         per_step = []
         for _ in range(steps):
             ta = time.perf_counter()
@@ -517,6 +522,7 @@ def main():
             pstats.Stats(prof_, stream=sys.stderr).sort_stats('tottime').print_stats(45)
             pstats.Stats(prof_, stream=sys.stderr).sort_stats('cumtime').print_stats(60)
         issue_ms[0] = 1e3 * (time.perf_counter() - t0) / max(steps, 1)     # host: all steps issued (the queue may have pushed back)
+        wait_ms[0] = 1e3 * ((trainer.graphs.stats['wait_s'] if (trainer is not None and trainer.graphs is not None) else 0.0) - w0) / max(steps, 1)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -537,10 +543,26 @@ def main():
             dist.destroy_process_group()
         return
     head_feed, other_feed = (feed_host, feed_hbm) if args.input == 'host' else (feed_hbm, feed_host)
+    primed = 0
+    if trainer is not None and trainer.graphs is not None:
+        # hipGraph capture of the train step (sgg_amd/graph_step.py) happens per batch signature after three plain steps of that kind, and a
+        # capture costs tens of milliseconds: like any one-time initialisation it is kept out of the W warm-up + K timed steps -- the
+        # rotation is run (untimed, real steps: every update is applied) until every batch of it has been replayed from its graphs
+        for b_ in head_feed(8 * NB):
+            train_step(b_)
+            primed += 1
+        trainer.flush()
+        torch.cuda.synchronize()
+        if os.environ.get('SGG_BENCH_MEMSNAP'):          # debugging: where every segment of the caching allocator lies (private graph pools included)
+            snap = [dict(address=sg['address'], size=sg['total_size'], pool=str(sg.get('segment_pool_id')), stream=sg.get('stream'),
+                         blocks=[(b_['address'] if 'address' in b_ else None, b_['size'], b_['state']) for b_ in sg['blocks']][:400])
+                    for sg in torch.cuda.memory_snapshot()]
+            with open(os.environ['SGG_BENCH_MEMSNAP'], 'w') as f_:
+                json.dump(snap, f_)
     if trainer is not None and trainer.dist_on:
         trainer.buckets.timing = []
     elapsed = timed(step, args.warmup, args.steps, head_feed)
-    head_issue_ms, head_feed_ms = issue_ms[0], feed_ms[0]
+    head_issue_ms, head_feed_ms, head_wait_ms = issue_ms[0], feed_ms[0], wait_ms[0]
     comm = None
     if trainer is not None and trainer.dist_on:
         # per step: bytes this rank handed to RCCL (reduce-scatter / all-reduce inputs + the all-gathered operands) and how long the stream
@@ -687,7 +709,7 @@ def main():
             'metric': 'images/sec (whole node), VG SGCls IMP %s step' % ('train' if args.mode == 'train' else 'inference'),
             'value': round(world * B * args.steps / elapsed, 3),
             'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'host_issue_ms_per_step': round(head_issue_ms, 3), 'host_feed_ms_per_step': round(head_feed_ms, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'host_issue_ms_per_step': round(head_issue_ms - head_wait_ms, 3), 'host_wait_ms_per_step': round(head_wait_ms, 3), 'host_feed_ms_per_step': round(head_feed_ms, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'input': ('host-resident Blob tuples (decoded u8 images + gt tensors on the host) through DeviceStager.prefetch: a worker thread packs '
                       'each batch into pinned memory and launches ONE async copy per batch on a copy stream (ring of %d slots, ahead of the '
@@ -714,7 +736,11 @@ def main():
                             'updated bf16 operands all-gathered; the other tensors all-reduced' % world)
                            if (trainer is not None and trainer.shard_optimizer) else 'RCCL gradient all-reduce (bf16 on the wire)'),
                        'weights': 'random init (He), frozen VGG16 + trainable IMP head (247.75 M params)',
-                       'pipeline': 'optimiser update of step k runs on a side stream under the frozen VGG forward of step k+1 (every update inside the timed region)'},
+                       'pipeline': 'optimiser update of step k runs on a side stream under the frozen VGG forward of step k+1 (every update inside the timed region)',
+                       'hipgraph': (dict(trainer.graphs.stats, disabled=trainer.graphs.disabled,
+                                         priming_steps_before_warmup=primed,
+                                         note='train step replayed as one-stream hipGraphs per batch signature (U: update of the previous step, on the lane stream || V: VGG forward; B: head forward + loss + backward in three segments, the backward lane work beside the fc6 / fc7 weight gradients), sgg_amd/graph_step.py; counts over the whole process; wait_s = the issuing thread held back on purpose (at most 8 steps ahead, one device synchronisation per 32 steps)')
+                                    if (trainer is not None and trainer.graphs is not None) else None)},
             'roofline': {'kernel': ('256x256 ping-pong MFMA kernel%s (+ the 128x128 split-K launch that replaces a nearly empty last round), %s' % (
                              ', TN form: both operands staged with the reduction index as the slow axis, fragments through ds_read_b64_tr_b16, no '
                              'transposed copies' if (tag == 'bwd_fc6_edge_dW' and get('sgg_gemm_tn256', tag)[1]) else '', desc)),

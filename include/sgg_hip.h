@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGG_ABI_VERSION 11   /* bump whenever a prototype below changes: tests/abi.lock pins (version, digest of the prototypes) */
+#define SGG_ABI_VERSION 12   /* bump whenever a prototype below changes: tests/abi.lock pins (version, digest of the prototypes) */
 
 enum { SGG_F32 = 0, SGG_BF16 = 1, SGG_F16 = 2 };
 enum { SGG_ACT_NONE = 0, SGG_ACT_RELU = 1 };
@@ -303,6 +303,9 @@ int sgg_det_output(const float* boxes, const float* scores, const int* labels, c
  * forward ones; buffers documented "zeroed by the callee" are cleared with hipMemsetAsync on the same stream. */
 /* nn.Dropout(p), in place, counter-based RNG (element i keeps iff hash(seed,i) >= p*2^32): rel_model_base.py:110-111 */
 int sgg_dropout_fwd(void* x, int64_t n, float p, uint64_t seed, int dtype, void* stream);
+/* the same mask as sgg_dropout_fwd(seed = seed_dev[0] * 4 + salt), the step's seed read from device memory (u64[1]) at run time: a launch
+ * captured into a hipGraph (sgg_amd/graph_step.py) draws a new mask on every replay */
+int sgg_dropout_fwd_dev(void* x, int64_t n, float p, const uint64_t* seed_dev, uint64_t salt, int dtype, void* stream);
 /* dx = dy * (y > 0) * scale : backward of ReLU (scale 1) / ReLU->Dropout (y = saved post-dropout output, scale 1/(1-p)) */
 int sgg_act_bwd(const void* dy, const void* y, void* dx, int64_t n, float scale, int g_dtype, int y_dtype, void* stream);
 /* Reductions of this section are TWO-STAGE: row blocks write partial rows into a caller-provided f32 workspace `ws`, a second launch

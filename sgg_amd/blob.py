@@ -131,9 +131,11 @@ class DeviceStager(object):
         self._next = 0
 
     def _alloc(self, slot, cap):
-        slot.pinned = torch.empty(cap, dtype=torch.uint8).pin_memory()
-        slot.pinned_np = slot.pinned.numpy()
-        slot.device = torch.empty(cap, dtype=torch.uint8, device=self.device)
+        from ._lib import CAPTURE_LOCK
+        with CAPTURE_LOCK:
+            slot.pinned = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            slot.pinned_np = slot.pinned.numpy()
+            slot.device = torch.empty(cap, dtype=torch.uint8, device=self.device)
 
     def reserve(self, nbytes):
         """Allocates every slot's pinned and device buffer for batches of up to `nbytes` packed bytes now (else: at the first batch)."""
@@ -192,15 +194,17 @@ class DeviceStager(object):
         # not for everything queued so far: waiting for the whole compute stream ties the copy to the previous step's last kernel, and the
         # HIP runtime then resolves the cross-queue dependency with the calling thread blocked (measured: 2.2-2.6 ms per step inside this
         # call, the issuing thread never more than one step ahead of the GPU)
-        if after is not None:                       # (prefetch()'s worker thread: an event of the consumer's stream, see there)
-            self.stream.wait_event(after)
-        elif ring and slot.consumed is not None:
-            self.stream.wait_event(slot.consumed)
-        else:
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(self.stream):
-            slot.device[:total].copy_(slot.pinned[:total], non_blocking=True)
-            slot.event.record(self.stream)
+        from ._lib import CAPTURE_LOCK
+        with CAPTURE_LOCK:                          # (no GPU call of this thread while another one captures a hipGraph: sgg_amd/graph_step.py)
+            if after is not None:                       # (prefetch()'s worker thread: an event of the consumer's stream, see there)
+                self.stream.wait_event(after)
+            elif ring and slot.consumed is not None:
+                self.stream.wait_event(slot.consumed)
+            else:
+                self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.stream):
+                slot.device[:total].copy_(slot.pinned[:total], non_blocking=True)
+                slot.event.record(self.stream)
         views = []
         for t, o in zip(items, offs):
             n = t.numel() * t.element_size()

@@ -31,6 +31,23 @@ __global__ __launch_bounds__(256) void dropout_kernel(T* __restrict__ x, long n8
     store8(x + i * 8, v);
 }
 
+// the same with the seed in device memory: seed = seed_dev[0] * 4 + salt (what the host computes for its by-value form) -- a launch captured
+// into a hipGraph draws a new mask on every replay once the host has written the step's seed there
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_dev_kernel(T* __restrict__ x, long n8, float p, const unsigned long long* __restrict__ seed_dev,
+                                                          unsigned long long salt) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const unsigned long long seed = seed_dev[0] * 4ull + salt;
+    float v[8];
+    load8(x + i * 8, v);
+    const float scale = 1.f / (1.f - p);
+    const unsigned int thr = (unsigned int)(p * 4294967296.0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = hash_u32(seed ^ (unsigned long long)(i * 8 + k)) >= thr ? v[k] * scale : 0.f;
+    store8(x + i * 8, v);
+}
+
 // dx = dy * (y > 0) * scale  : backward of ReLU (scale 1) or ReLU->Dropout (y is the saved post-dropout value,
 // scale 1/(1-p): y > 0 iff the unit was kept and its pre-activation was positive)
 template <typename TG, typename TY>
@@ -941,6 +958,18 @@ extern "C" int sgg_dropout_fwd(void* x, int64_t n, float p, uint64_t seed, int d
     const dim3 grid((unsigned)((n8 + 255) / 256)), blk(256);
     hipStream_t s = (hipStream_t)stream;
     SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(dropout_kernel<T>, grid, blk, 0, s, (T*)x, n8, p, (unsigned long long)seed));
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
+
+extern "C" int sgg_dropout_fwd_dev(void* x, int64_t n, float p, const uint64_t* seed_dev, uint64_t salt, int dtype, void* stream) {
+    if (n == 0) return SGG_OK;
+    if (!x || !seed_dev || n < 0 || (n & 7) || !(p >= 0.f && p < 1.f)) return SGG_ERR_ARG;
+    const long n8 = n / 8;
+    const dim3 grid((unsigned)((n8 + 255) / 256)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(dropout_dev_kernel<T>, grid, blk, 0, s, (T*)x, n8, p, (const unsigned long long*)seed_dev,
+                                            (unsigned long long)salt));
     SGG_CHECK_LAUNCH();
     return SGG_OK;
 }

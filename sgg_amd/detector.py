@@ -138,10 +138,16 @@ class VGGDetector(nn.Module):
             self._bufs[k] = b
         return b
 
-    def features(self, images, dtype):
+    def features(self, images, dtype, out=None):
         """images: list of f32[3,h,w] tensors in [0,1] (host or device) -- what the reference's SquarePad + ToTensor
         produce -- or of u8[h0,w0,3] decoded images, for which those two steps run inside the prep kernel.
-        Returns (fmap NHWC [B,Hf,Wf,512] in `dtype`, image_sizes [(h,w)] after resize, (Hp,Wp) padded size)."""
+        Returns (fmap NHWC [B,Hf,Wf,512] in `dtype`, image_sizes [(h,w)] after resize, (Hp,Wp) padded size).
+        out (optional): the [B,Hf,Wf,512] tensor the last convolution writes (a caller that replays the head as a hipGraph keeps the map
+        at one address, sgg_amd/graph_step.py).  `self._features_override` (same caller): a ready (fmap, sizes, padded) triple returned
+        as it is -- the map was computed by another launch sequence."""
+        ov = getattr(self, '_features_override', None)
+        if ov is not None:
+            return ov
         dev = self.backbone[0].weight.device
         sizes = [self.transform.resized_hw(*image_hw(im)) for im in images]
         d = self.transform.size_divisible
@@ -205,7 +211,9 @@ class VGGDetector(nn.Module):
                     li += 1
                 else:
                     # the final map is handed to the caller (Result.fmap): a fresh tensor, never a cached plane
-                    y = torch.empty((B, H, W, co), dtype=dtype, device=dev) if last else \
+                    if last and out is not None:
+                        assert tuple(out.shape) == (B, H, W, co) and out.dtype == dtype and out.is_contiguous(), (out.shape, (B, H, W, co))
+                    y = (out if out is not None else torch.empty((B, H, W, co), dtype=dtype, device=dev)) if last else \
                         self._buf('a%d' % li, (B, H + 2, W + 2, co), dtype, dev, True)
                     if ci_layer == 0:
                         ops.conv1_1(x, w, bias, y)

@@ -185,7 +185,7 @@ def conv3x3_relu(x, w, bias, out, out_pad, pool=False):
     B, H, W, Cin = x.shape[0], x.shape[1] - 2, x.shape[2] - 2, x.shape[3]
     Cout = w.shape[0]
     assert w.dtype == x.dtype == out.dtype
-    if _SPLIT3[0] and x.dtype == torch.float32 and Cin % 32 == 0:
+    if _SPLIT3[0] and x.dtype == torch.float32 and Cin % 64 == 0:      # (split3 pads K to 64: other widths stay on the exact-fp32 kernel)
         # x3 mode: the plane and the weights as f16 (hi, lo) pairs with 3 Cin channels ([hi | hi | lo] per pixel, [hi | lo | hi] per tap),
         # one f16 implicit-GEMM convolution with fp32 output (a zero border splits into zeros)
         assert not pool
@@ -370,6 +370,8 @@ _SPLIT3 = [False]
 def set_split3(on):
     prev = _SPLIT3[0]
     _SPLIT3[0] = bool(on)
+    if prev and not on:
+        split3_cache_clear()        # leaving the mode: the cached weight splits (up to gigabytes) go back to the allocator
     return prev
 
 
@@ -378,13 +380,49 @@ def split3_on():
 
 
 def split3(x, weights=False):
-    """x f32 [rows, K] (row-strided ok) -> f16 [rows, 3 * K_pad], K_pad = K rounded up to 32: [hi | hi | lo] (weights: [hi | lo | hi])"""
+    """x f32 [rows, K] (row-strided ok) -> f16 [rows, 3 * K_pad], K_pad = K rounded up to 64: [hi | hi | lo] (weights: [hi | lo | hi]).
+    (K_pad a multiple of 64 keeps 3 K_pad a multiple of the f16 kernels' 64-element K-tile for every K: ADVICE r4.)
+    weights=True: the result is cached until the tensor changes (same storage, shape, strides and autograd version) -- the weights are
+    constants in evaluation, and in training they change once per step, not once per contraction."""
     rows, K = x.shape
     assert x.dtype == torch.float32 and x.stride(1) == 1
-    Kp = (K + 31) // 32 * 32
+    key = None
+    if weights and _SPLIT3_CACHE_BYTES > 0:
+        key = (x.data_ptr(), rows, K, x.stride(0), x._version, str(x.device))
+        hit = _split3_cache.get(key)
+        if hit is not None:
+            _split3_cache.move_to_end(key)
+            cur = _stream()
+            if hit[2] != cur:            # made under another stream (the node lane / the main stream): order this stream behind the split
+                torch.cuda.current_stream(x.device).wait_event(hit[3])
+                hit[1].record_stream(torch.cuda.current_stream(x.device))
+            return hit[1]
+    Kp = (K + 63) // 64 * 64
     out = torch.empty((rows, 3 * Kp), dtype=torch.float16, device=x.device)
     _lib.call('sgg_split3', _p(x, torch.float32, rows_ok=True), x.stride(0), rows, K, Kp, _p(out), out.stride(0), 1 if weights else 0, _stream())
+    if key is not None:
+        # the entry holds the source tensor too: its storage cannot be recycled for another tensor with the same address while the entry lives.
+        # Entries are dropped oldest first beyond SGG_SPLIT3_CACHE_MB (default 6144; 0 = no cache); a split made under one stream is only
+        # handed to work issued later on the same device (stream order of the caller, as for every cached operand of model.prepared())
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(x.device))
+        _split3_cache[key] = (x, out, _stream(), ev)
+        _split3_cache_size[0] += out.numel() * 2
+        while _split3_cache_size[0] > _SPLIT3_CACHE_BYTES and len(_split3_cache) > 1:
+            _, old = _split3_cache.popitem(last=False)
+            _split3_cache_size[0] -= old[1].numel() * 2
     return out
+
+
+import collections  # noqa: E402
+_split3_cache = collections.OrderedDict()
+_split3_cache_size = [0]
+_SPLIT3_CACHE_BYTES = int(os.environ.get('SGG_SPLIT3_CACHE_MB', '6144')) << 20
+
+
+def split3_cache_clear():
+    _split3_cache.clear()
+    _split3_cache_size[0] = 0
 
 
 def _split3_operands(A, W, A2, W2):
@@ -747,8 +785,14 @@ def permute_ncp_to_npc(x, dtype=None):
 
 
 # ---------------------------------------------------------------- training side
-def dropout_(x, p, seed):
-    _lib.call('sgg_dropout_fwd', _p(x), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, dt(x), _stream())
+def dropout_(x, p, seed, salt=0):
+    """nn.Dropout(p) in place.  seed: an int -- the mask of hash(seed * 4 + salt, element) -- or a u64 / i64 [1] DEVICE tensor holding
+    that int (read by the kernel at run time: the form a captured hipGraph replays with a new seed, sgg_amd/graph_step.py); same mask."""
+    if torch.is_tensor(seed):
+        assert seed.is_cuda and seed.numel() == 1 and seed.element_size() == 8
+        _lib.call('sgg_dropout_fwd_dev', _p(x), x.numel(), float(p), seed.data_ptr(), int(salt), dt(x), _stream())
+    else:
+        _lib.call('sgg_dropout_fwd', _p(x), x.numel(), float(p), (int(seed) * 4 + int(salt)) & 0xFFFFFFFFFFFFFFFF, dt(x), _stream())
     return x
 
 
@@ -910,10 +954,11 @@ def transpose(x, pad_to=64, dtype=None, add=None, group=1, want_colsum=False, ou
     return (out, cs) if want_colsum else out
 
 
-def group_sum(w, C, group, dtype):
-    """w f32[N, C*group] -> [N, C] in dtype: sums over each run of `group` consecutive columns."""
+def group_sum(w, C, group, dtype, out=None):
+    """w f32[N, C*group] -> [N, C] in dtype: sums over each run of `group` consecutive columns (out: an earlier result's buffer, rewritten)."""
     Nn = w.shape[0]
-    out = torch.empty((Nn, C), dtype=dtype, device=w.device)
+    if out is None or tuple(out.shape) != (Nn, C) or out.dtype != dtype or out.device != w.device or not out.is_contiguous():
+        out = torch.empty((Nn, C), dtype=dtype, device=w.device)
     _lib.call('sgg_group_sum', _p(w, torch.float32), w.stride(0), _p(out), C, Nn, C, group, dt(out), _stream())
     return out
 

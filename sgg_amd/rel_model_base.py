@@ -48,6 +48,31 @@ def host_of(t):
     return t.detach().to('cpu')
 
 
+def rels_host_facts(rows, sizes):
+    """What the host can say about a batch's ground-truth relation rows [(img, subj, obj, pred)] given the boxes per image {img: count}
+    (lib/proposal_assignments_gtbox.py:28-45 counts them on the device): regular -- every row names two different boxes of an image of
+    the batch (otherwise the device count decides); fg_pairs -- distinct ordered (img, subj, obj); max_edges -- most label rows one image
+    ends up with (its candidates - its distinct FG pairs + its FG relations); max_per_pair -- most rows on one unordered box pair."""
+    fg, regular = set(), True
+    for im, s_, o_, _ in rows:
+        if im in sizes and s_ != o_ and 0 <= s_ < sizes[im] and 0 <= o_ < sizes[im]:
+            fg.add((im, s_, o_))
+        else:
+            regular = False
+    max_edges = max_per_pair = None
+    if regular:
+        per_im = {i: sz * (sz - 1) for i, sz in sizes.items()}
+        for im, _, _ in fg:
+            per_im[im] -= 1
+        fg_rows = {}
+        for im, s_, o_, _ in rows:
+            per_im[im] += 1
+            fg_rows[(im, s_, o_)] = fg_rows.get((im, s_, o_), 0) + 1
+        max_edges = max(per_im.values())
+        max_per_pair = max([2] + [c + max(1, fg_rows.get((im, o_, s_), 0)) for (im, s_, o_), c in fg_rows.items()])
+    return dict(regular=regular, fg_pairs=len(fg), max_edges=max_edges, max_per_pair=max_per_pair)
+
+
 def as_nchw_view(x_nhwc):
     return x_nhwc.permute(0, 3, 1, 2)
 
@@ -183,6 +208,8 @@ class RelModelBase(nn.Module):
         ops.dt(dtype)
         if split3 and dtype != torch.float32:
             raise ValueError('split3 (the x3 mode) is a form of the fp32 mode: set_compute_dtype(torch.float32, split3=True)')
+        if dtype != self.compute_dtype or bool(split3) != getattr(self, 'split3', False):
+            self._operand_generation = getattr(self, '_operand_generation', 0) + 1     # derived operands get new buffers: captured launch sequences (graph_step.py) are void
         self.compute_dtype = dtype
         # x3 mode (sgg_amd/ops.py "the x3 mode"): fp32 storage and element-wise arithmetic as in the exact-fp32 mode, every MFMA contraction on
         # f16 split operands (hi + lo, three products, fp32 accumulate): fp32-grade logits (within the 1e-3 clause) at several times the
@@ -361,28 +388,10 @@ class RelModelBase(nn.Module):
             # With a host mirror of gt_rels the count is computed here (R is a few dozen); otherwise read it back.
             rels_host = getattr(gt_rels, '_sgg_host', None)
             if rels_host is not None and tuple(rels_host.shape) == tuple(gt_rels.shape):
-                sizes = {i: e - s for i, s, e in segs}
-                fg_pairs, regular = set(), True
-                for im, s_, o_, _ in rels_host.tolist():
-                    if im in sizes and s_ != o_ and 0 <= s_ < sizes[im] and 0 <= o_ < sizes[im]:
-                        fg_pairs.add((im, s_, o_))
-                    else:
-                        regular = False          # self / out-of-range relation: let the device count decide
-                n = n_cand - len(fg_pairs) + R if regular else int(count.item())
-                max_edges = None
-                if regular:      # rows of image i = its candidates - its distinct FG pairs + its FG relations
-                    per_im = {i: sz * (sz - 1) for i, sz in sizes.items()}
-                    for im, _, _ in fg_pairs:
-                        per_im[im] -= 1
-                    for im, _, _, _ in rels_host.tolist():
-                        per_im[im] += 1
-                    max_edges = max(per_im.values())
-                    # most rows on one unordered box pair (sgg_amd/pairing.py keeps two): each direction has one row, or one per
-                    # FG relation on it
-                    fg_rows = {}
-                    for im, s_, o_, _ in rels_host.tolist():
-                        fg_rows[(im, s_, o_)] = fg_rows.get((im, s_, o_), 0) + 1
-                    max_per_pair = max([2] + [c + max(1, fg_rows.get((im, o_, s_), 0)) for (im, s_, o_), c in fg_rows.items()])
+                facts = rels_host_facts(rels_host.tolist(), {i: e - s for i, s, e in segs})
+                regular, fg_pairs = facts['regular'], facts['fg_pairs']
+                n = n_cand - fg_pairs + R if regular else int(count.item())
+                max_edges, max_per_pair = facts['max_edges'], facts['max_per_pair']
             else:
                 n = int(count.item())
                 max_edges = None
@@ -415,7 +424,7 @@ class RelModelBase(nn.Module):
                 rel_labels._sgg_max_per_pair = max_per_pair
                 # every ordered pair exactly once, nothing sub-sampled: the rows are the evaluation candidate list (plus labels), so
                 # the graph index tables cached per box-count signature apply (rel_model_stanford.forward)
-                rel_labels._sgg_plain = bool(R == len(fg_pairs) and rel_labels.shape[0] == n_cand)
+                rel_labels._sgg_plain = bool(R == fg_pairs and rel_labels.shape[0] == n_cand)
             obj_labels = gt_classes[:, 1]               # (a strided view: the fused cross-entropy and F.cross_entropy both take it)
         else:
             obj_labels = gt_classes[:, 1]

@@ -60,7 +60,12 @@ class RelModelStanford(RelModelBase):
         w6e = f(fc['fc6_edge'][1].weight)
         w['fc6_edge'] = self._shadow_cast(fc['fc6_edge'][0] + '.weight', w6e)   # [obj_dim, C*49], K order (c,ph,pw) as in the reference
         gs = getattr(self, '_sharded_group_sum', None)             # a trainer with a sharded optimiser: sums of this rank's rows, gathered
-        w['fc6_edge_sum'] = (gs or ops.group_sum)(w6e, C, PP, dtype)    # [obj_dim, C]
+        if gs is not None:
+            w['fc6_edge_sum'] = gs(w6e, C, PP, dtype)                    # [obj_dim, C]
+        else:
+            # rewritten in place (like the shadows and the transposed copies of train_weights): a derived operand keeps its address for as
+            # long as the compute dtype stays, so that launch sequences replayed as hipGraphs keep reading the current values
+            w['fc6_edge_sum'] = self._sum_buf = ops.group_sum(w6e, C, PP, dtype, out=self.__dict__.get('_sum_buf'))
         for name, pname, mod in (('fc7_obj',) + fc['fc7_obj'], ('fc7_edge',) + fc['fc7_edge'],
                                  ('obj_unary', 'obj_unary', self.obj_unary), ('edge_unary', 'edge_unary', self.edge_unary),
                                  ('obj_fc', 'obj_fc', self.obj_fc), ('rel_fc', 'rel_fc', self.rel_fc)):
@@ -135,7 +140,7 @@ class RelModelStanford(RelModelBase):
             # the resnet50 configuration have no Dropout layers (the VGG classifier's sit after fc6 and fc7)
             from .train import predict_train
             return predict_train(self, nf, ef, rel_inds, rois, _im_inds, dropout_p=self.dropout_p if self.backbone == 'vgg16' else 0.0,
-                                 graphs=_graphs, im_sizes=im_sizes, pairing=paired, csr=_csr)
+                                 graphs=_graphs, im_sizes=im_sizes, pairing=paired, csr=_csr, seed=self.__dict__.get('_seed_dev'))
         w = self.prepared()
         # :100  union_boxes(edge_feat, rois, rel_inds[:,1:]) -- conv(rects)[E,512]; the broadcast add rides in fc6's K
         rect = self.union_boxes.rect_feat(rois, ops.pairs_of(rel_inds), dtype, im_sizes)

@@ -187,10 +187,10 @@ class PredictFn(torch.autograd.Function):
         x6 = ops.gemm(nf, w['fc6_obj'], w['fc6_obj_b'], ops.ACT_RELU)
         _lib.set_tag('mlp')
         if dropout_p > 0:
-            ops.dropout_(x6, dropout_p, seed * 4 + 1)
+            ops.dropout_(x6, dropout_p, seed, 1)
         x7 = ops.gemm(x6, w['fc7_obj'], w['fc7_obj_b'], ops.ACT_RELU)
         if dropout_p > 0:
-            ops.dropout_(x7, dropout_p, seed * 4 + 2)
+            ops.dropout_(x7, dropout_p, seed, 2)
         # row-stacked inputs / states of the 4 calls of each GRU cell
         T = model.mp_iter
         XN = torch.empty(((T + 1) * N, H), dtype=dt, device=dev)      # inputs of the node cell: obj_rep, ctx_0 .. ctx_{T-1}
@@ -213,7 +213,7 @@ class PredictFn(torch.autograd.Function):
             y6 = ops.gemm(ef, w['fc6_edge'], w['fc6_edge_b'], ops.ACT_RELU, A2=rect, W2=w['fc6_edge_sum'])
         _lib.set_tag('mlp')
         if dropout_p > 0:
-            ops.dropout_(y6, dropout_p, seed * 4 + 3)
+            ops.dropout_(y6, dropout_p, seed, 3)
         edge_relu7 = model.fc_layers()[1]          # TwoMLPHead copies (resnet50): ReLU after the edge branch's fc7 as well
         y7 = ops.gemm(y6, w['fc7_edge'], w['fc7_edge_b'], ops.ACT_RELU if edge_relu7 else ops.ACT_NONE)
         ops.gemm(y7, w['edge_unary'], w['edge_unary_b'], ops.ACT_RELU, out=XE0)
@@ -517,7 +517,14 @@ class PredictFn(torch.autograd.Function):
 
         lane = node_lane(dev) if os.environ.get('SGG_BWD_LANE', '1') != '0' else None
         lane_done, lane_keys = None, ()
-        if lane is not None:
+        # a capture in progress (sgg_amd/graph_step.py): the lane's work becomes a graph of its own, replayed on the lane's stream beside the
+        # graph of phases B and C -- the capture is cut here, after the lane's work, and once more where the two meet
+        split = getattr(model, '_graph_split', None)
+        if split is not None:
+            split.next('lane')
+            lane_work()
+            split.next('main')
+        elif lane is not None:
             side = lane[0]
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(dev))
@@ -568,7 +575,9 @@ class PredictFn(torch.autograd.Function):
         # GRU parameter gradients: one contraction over the 4 stacked calls; hidden state of call 0 is zero
         G['edge_gru.weight_ih'] = tn_gemm(DG[T * E:], XH[:E + T * N])           # [d_gi of call 0 ; dP_0 ..]^T . [rel_rep ; v_0 ..]
         G['edge_gru.weight_hh'] = tn_gemm(dGHe[E:], HE[:T * E])              # states entering calls 1..T (call 0: zero state)
-        if lane_done is None:
+        if split is not None:
+            split.next('joined')                            # what follows (and the memory it recycles) runs after the lane's graph has finished
+        elif lane_done is None:
             lane_work()
         else:                                               # everything the lane produced is complete before anything downstream reads it
             main = torch.cuda.current_stream(dev)

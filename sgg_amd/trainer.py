@@ -198,7 +198,7 @@ class Trainer(object):
 
     def __init__(self, model, lr=1e-3, momentum=0.9, weight_decay=1e-4, clip=5.0, loss_type='baseline',
                  comm_dtype=torch.bfloat16, force_dist=False, sync_bn=True, pipeline=False, loss_weights=(1, 1, 1),
-                 shard_optimizer=None):
+                 shard_optimizer=None, graph=None):
         self.model = model
         for n, p in model.named_parameters():
             if n.startswith('detector.'):
@@ -236,6 +236,7 @@ class Trainer(object):
         if pipeline:
             self.opt.max_blocks = int(os.environ.get('SGG_OPT_BLOCKS', '256'))   # leave wave slots for the VGG forward running beside the update
         self._queued = False
+        self.graphs = None        # sgg_amd.graph_step.GraphStep when the step is replayed as hipGraphs (set at the end of __init__)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         # force_dist: run the distributed code path on a 1-rank group too (tests exercise RCCL plumbing on one GPU)
         self.dist_on = self.world > 1 or (force_dist and dist.is_available() and dist.is_initialized())
@@ -268,6 +269,13 @@ class Trainer(object):
             # union_boxes.conv BatchNorm: statistics over the edges of the GLOBAL batch, i.e. the numbers a
             # single process would compute on the concatenated batch; sync_bn=False = replica-local statistics.
             model._bn_sync = (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)) if sync_bn else None
+        # graph (default: on for the pipelined one-GPU trainer; SGG_GRAPH=0 turns it off): the step replayed as hipGraphs wherever the
+        # batch allows it (sgg_amd/graph_step.py) -- same kernels, same arguments, same order; ~0.3 ms of host time per step instead of 3.5 - 5.5
+        if graph is None:
+            graph = os.environ.get('SGG_GRAPH', '1') != '0'
+        if graph and pipeline and not self.dist_on and torch.cuda.is_available():
+            from .graph_step import GraphStep
+            self.graphs = GraphStep(self)
 
     def local_only(self):
         """Context manager: inside it the trainer and the model issue NO collective (gradient hooks, BatchNorm statistics,
@@ -310,7 +318,12 @@ class Trainer(object):
 
     @property
     def loss_scale(self):
-        return self.loss_scale_f16 if self.model.compute_dtype == torch.float16 else 1.0
+        # f16 compute, and the x3 mode: its contractions split every operand -- the backward's dY included -- into f16 halves (five exponent
+        # bits: |x| < 6e-8 has no hi half, |x| < 0.125 a subnormal lo half), and head gradients at the bench size are 1e-6 .. 1e-8 per
+        # element.  Same mechanism as f16: scaled loss in, grad_scale out, a step whose scaled gradients overflow is skipped.
+        if self.model.compute_dtype == torch.float16 or getattr(self.model, 'split3', False):
+            return self.loss_scale_f16
+        return 1.0
 
     def _shards(self, reduced):
         return {p: self.buckets.shard_of(p) for p in reduced} if self.shard_optimizer else None
@@ -424,6 +437,8 @@ class Trainer(object):
     def flush(self):
         """Make the current stream wait for a queued optimiser update (pipeline mode) before parameters are read; with a sharded
         optimiser also gather the fp32 masters and momentum buffers (a collective: every rank calls flush())."""
+        if self.graphs is not None:
+            self.graphs.flush()          # the last replayed step's update has not been applied yet (it rides in the NEXT step's first graph)
         ev = getattr(self.model, '_operands_ready', None)
         if ev is not None:
             torch.cuda.current_stream(next(self.model.parameters()).device).wait_event(ev)
@@ -499,11 +514,9 @@ class Trainer(object):
         self.opt.step(grad_scale=1.0 / self.loss_scale, grads=reduced, shards=self._shards(reduced) if self.dist_on else None)
         self._local = {}
 
-    def step(self, batch):
-        if not self.model.training:      # (a walk over ~90 modules and their __setattr__: 0.35 ms of the issuing thread per step when repeated)
-            self.model.train()
-        if not self._queued:
-            self._prefetch_operands()
+    def _forward_backward(self, batch):
+        """forward, loss and backward of one batch on the current stream -> the loss (device scalar); the gradients are left in p.grad
+        and, on one GPU with a 16-bit wire type, in self._local (the big tensors, kept out of autograd for the optimiser)."""
         local = not self.dist_on and getattr(self, '_keep', None) is not None and ops.is_half(self.model.compute_dtype)
         if not self.dist_on:
             self._local = {}
@@ -532,6 +545,20 @@ class Trainer(object):
             self.model._loss_scaled = False
             if local:
                 self.model._grad_ready_hook = self.model._grad_wire_dtype = None
+        return loss
+
+    def step(self, batch):
+        if not self.model.training:      # (a walk over ~90 modules and their __setattr__: 0.35 ms of the issuing thread per step when repeated)
+            self.model.train()
+        if self.graphs is not None:
+            # one GPU, 16-bit, pipelined: the step as two replayed hipGraphs per batch signature (sgg_amd/graph_step.py); None = this batch
+            # runs through the launch-by-launch path below (warm-up of a new signature, shapes the capture does not take, ...)
+            out = self.graphs.step(batch)
+            if out is not None:
+                return out
+        if not self._queued:
+            self._prefetch_operands()
+        loss = self._forward_backward(batch)
         self._queued = self.pipeline and self._queue_update()
         if not self._queued:
             self.update()

@@ -1,0 +1,103 @@
+"""The train step replayed as hipGraphs (sgg_amd/graph_step.py) against the launch-by-launch step of Trainer:
+the same kernels with the same arguments in the same stream order, so after n steps -- over two batch signatures, through the warm-up,
+the captures and the replays -- every parameter, momentum buffer and BatchNorm statistic is bit-equal, and so is every step's loss."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+S = 160
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+
+
+def _batches(dev_images=True):
+    from sgg_amd.rel_model_base import to_device_with_mirror
+    from sgg_amd.synthetic import synthetic_batch
+    out = []
+    for k, counts in enumerate(((7, 7, 7), (7, 7, 7), (6, 8, 7), (7, 7, 7))):
+        b = list(synthetic_batch(B=3, S=S, n_boxes=7, n_fg=3, seed=50 + k, counts=counts))
+        b[0] = [(im * 255).round().to(torch.uint8).permute(1, 2, 0).contiguous().to(DEV) for im in b[0]]     # decoded u8 images, as the boundary hands them over
+        b[3] = b[3].to(DEV)
+        b[4], b[5] = to_device_with_mirror(b[4], DEV), to_device_with_mirror(b[5], DEV)
+        out.append(tuple(b))
+    return out
+
+
+def _run(graph, steps, dtype, sd, batches, lr_drop_at=None):
+    import sgg_amd
+    from sgg_amd.synthetic import SyntheticData, init_weights
+    from sgg_amd.trainer import Trainer
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls', min_size=S, max_size=S))
+    if sd is not None:
+        model.load_state_dict(sd)
+    model.to(DEV)
+    model.set_compute_dtype(dtype)
+    tr = Trainer(model, lr=2e-2, pipeline=True, graph=graph)
+    assert (tr.graphs is not None) == graph
+    torch.manual_seed(1234)                    # the dropout seeds of both runs come from torch's CPU generator
+    losses = []
+    for i in range(steps):
+        if lr_drop_at is not None and i == lr_drop_at:
+            for g in tr.opt.param_groups:      # what a MultiStepLR milestone does: the graphs that baked the old rate must not be replayed
+                g['lr'] *= 0.1
+        losses.append(tr.step(batches[i % len(batches)]))
+    tr.flush()
+    torch.cuda.synchronize()
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    mom = {n: tr.opt.state[p]['momentum_buffer'].clone() for n, p in model.named_parameters() if p in tr.opt.state and 'momentum_buffer' in tr.opt.state[p]}
+    stats = dict(tr.graphs.stats) if tr.graphs is not None else None
+    disabled = tr.graphs.disabled if tr.graphs is not None else None
+    return [float(x) for x in losses], state, mom, stats, disabled, tr.opt.steps
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_graph_steps_equal_plain_steps_bit_for_bit(dtype):
+    _gpu()
+    os.environ['SGG_GRAPH_STRICT'] = '1'
+    try:
+        batches = _batches()
+        steps = 26          # 4 batches in rotation, two signatures: both are warmed (3 plain steps each), captured (B, then A per predecessor) and replayed
+        l0, s0, m0, _, _, n0 = _run(False, steps, dtype, None, batches, lr_drop_at=19)
+        l1, s1, m1, stats, disabled, n1 = _run(True, steps, dtype, None, batches, lr_drop_at=19)
+    finally:
+        os.environ.pop('SGG_GRAPH_STRICT', None)
+    assert disabled is None, disabled
+    assert stats['replayed'] >= 12 and stats['captures'] >= 4, stats
+    assert n0 == n1 == steps
+    assert l0 == l1, [(i, a, b) for i, (a, b) in enumerate(zip(l0, l1)) if a != b][:5]
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+    assert set(m0) == set(m1)
+    for k in m0:
+        assert torch.equal(m0[k], m1[k]), k
+    assert all(torch.isfinite(v.float()).all() for v in s1.values())
+    assert l1[-1] < l1[0]
+
+
+def test_graph_step_falls_back_on_batches_it_does_not_take():
+    """host-resident images, and a relation list with two relations on one ordered pair: plain steps, same results as a trainer without graphs"""
+    _gpu()
+    from sgg_amd.rel_model_base import to_device_with_mirror
+    batches = _batches()
+    odd = list(batches[0])
+    rels = odd[5]._sgg_host.clone()
+    rels = torch.cat((rels, rels[:1]), 0)                 # a duplicate relation: one more label row, no cached tables
+    rels[-1, 3] = (rels[-1, 3] % 50) + 1
+    order = torch.argsort(rels[:, 0], stable=True)
+    odd[5] = to_device_with_mirror(rels[order].contiguous(), DEV)
+    host = list(batches[1])
+    host[0] = [im.cpu() for im in host[0]]
+    seq = [batches[0]] * 5 + [tuple(odd), batches[0], tuple(host), batches[0], batches[0]]
+    l0, s0, _, _, _, _ = _run(False, len(seq), torch.float16, None, seq)
+    l1, s1, _, stats, disabled, _ = _run(True, len(seq), torch.float16, None, seq)
+    assert disabled is None, disabled
+    assert stats['replayed'] >= 4 and stats['plain'] >= 5, stats
+    assert l0 == l1
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k

@@ -521,6 +521,53 @@ def test_gru_gate_vs_reference_golden(ops, golden):
     np.testing.assert_allclose(out0.cpu().numpy(), g['out_h0'], atol=2e-6)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('H', [8, 16, 32, 64, 128, 256, 512])
+def test_gru_gate_dot_epilogue_every_row_width(ops, dtype, H):
+    """the four gate dot products a gate kernel emits = (the state row AS STORED) . w_k, for every row width the DPP reduction handles
+    (H / 8 lanes per row: 1 .. 64; several rows per wave below 512)"""
+    g = torch.Generator().manual_seed(H)
+    M = 77
+    gi, gh, hp = torch.randn(M, 3 * H, generator=g), torch.randn(M, 3 * H, generator=g), torch.randn(M, H, generator=g)
+    gate_w = cu(torch.randn(4, 2 * H, generator=g))
+    for dot_w in (gate_w[:, :H], gate_w[:, H:]):
+        out, dots = ops.gru_gate(cu(gi), cu(gh), None, cu(hp.to(dtype)), dtype, dot_w=dot_w)
+        want = out.double() @ dot_w.double().t()
+        assert float((dots.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_gate_dots_are_reproducible_beside_another_streams_gemm(ops):
+    """Round 5: the x3 mode's logits moved from run to run because the f32 gate kernel's dot products -- then a
+    ds_bpermute butterfly -- came out wrong in ~15 % of its launches while the node lane ran the x3 GEMM of the node GRU (tools/gate_race.py).
+    The same arrangement here: 200 launches beside that GEMM, every one bit-equal to the first and right."""
+    torch.manual_seed(0)
+    E, N, H = 7936, 256, 512
+    gi, b_hh = torch.randn(E, 3 * H, device=DEV), torch.randn(3 * H, device=DEV) * 0.1
+    gate_w = (torch.randn(4, 2 * H, device=DEV) * 0.05).contiguous()
+    we = gate_w[:, H:]
+    obj, W = torch.randn(N, H, device=DEV), (torch.randn(3 * H, H, device=DEV) * 0.04).contiguous()
+    side = torch.cuda.Stream(device=DEV)
+    ref_h, ref_d = ops.gru_gate(gi, None, b_hh, None, torch.float32, dot_w=we)
+    assert float((ref_d - ref_h @ we.t()).abs().max()) < 1e-5
+    bad = 0
+    prev = ops.set_split3(False)
+    try:
+        for _ in range(200):
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ops.set_split3(True)
+                for _ in range(3):
+                    ops.gemm(obj, W, None, out_dtype=torch.float32)
+                ops.set_split3(False)
+            h, d = ops.gru_gate(gi, None, b_hh, None, torch.float32, dot_w=we)
+            bad += int(not (torch.equal(d, ref_d) and torch.equal(h, ref_h)))
+            torch.cuda.current_stream().wait_stream(side)
+    finally:
+        ops.set_split3(prev)
+    torch.cuda.synchronize()
+    assert bad == 0, '%d of 200 launches differ' % bad
+
+
 @pytest.mark.parametrize('tag', ['h32_b1', 'h64_b3', 'h32_sampled', 'h128_b2'])
 def test_message_pass_vs_reference_golden(ops, golden, tag):
     g = golden('message_pass')

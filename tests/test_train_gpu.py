@@ -40,6 +40,11 @@ def test_dropout_statistics_and_backward_mask(env):
     y2 = ops.dropout_(x.clone(), 0.5, 1234).float()
     assert torch.equal(y, y2)                                    # counter-based: same seed, same mask
     assert not torch.equal(y, ops.dropout_(x.clone(), 0.5, 1235).float())
+    # the seed read from device memory (the form a captured hipGraph replays): the same mask as the by-value form, salt included
+    seed_dev = torch.tensor([1234], dtype=torch.int64, device=DEV)
+    assert torch.equal(y, ops.dropout_(x.clone(), 0.5, seed_dev).float())
+    assert torch.equal(ops.dropout_(x.clone(), 0.5, 77, 3), ops.dropout_(x.clone(), 0.5, seed_dev.fill_(77), 3))
+    assert not torch.equal(ops.dropout_(x.clone(), 0.5, 77, 3), ops.dropout_(x.clone(), 0.5, 77, 2))
     dx = ops.act_bwd(torch.ones_like(x), y.to(torch.bfloat16), 2.0).float()
     assert torch.equal(dx, y)                                    # gradient passes exactly where the unit was kept
 

@@ -28,7 +28,7 @@ def test_split3_halves_reconstruct_the_operand(ops):
     x = (torch.randn(37, 200, generator=g) * torch.logspace(-4, 2, 200)).to(DEV)       # magnitudes over six decades
     for weights in (False, True):
         s3 = ops.split3(x, weights=weights).float()
-        Kp = 224
+        Kp = 256          # K rounded up to 64
         assert s3.shape == (37, 3 * Kp)
         hi, a, b = s3[:, :200], s3[:, Kp:Kp + 200], s3[:, 2 * Kp:2 * Kp + 200]
         lo = a if weights else b
