@@ -252,6 +252,26 @@ def imp_iter_ms(model, B, dtype, reps=50, kind='ctx'):
     return e0.elapsed_time(e1) / reps
 
 
+def graph_launch_us(fn, reps=50):
+    """average duration (us) of one launch of fn: `reps` launches captured into one hipGraph, one replay between two events (as imp_iter_ms)"""
+    import torch
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(reps):
+            fn()
+    graph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / reps
+
+
 def cpu_model_name():
     try:
         with open('/proc/cpuinfo') as f:
@@ -645,6 +665,15 @@ def main():
         imp_bytes = (2.0 * (E + N) * H) * s + 8.0 * E           # per iteration
         imp_moved = lambda b_: (992.0 * b_ * H + 2 * 32.0 * b_ * H) * s + 992.0 * b_ * (16 + 8) + 32.0 * b_ * 16   # rows + ctx halves + dots, ids
         imp_gbs = imp_bytes / (imp_ms * 1e-3) / 1e9 if imp_ms else 0.0
+        # what ANY launch costs at this size on this box, timed the same way (the measured argument): a launch that moves
+        # nothing (one element filled), and a plain device copy of the step's input rows (E x H elements read AND written: 1.8x the bytes
+        # the IMP launch moves, no dependent loads, no reduction)
+        rows_ = torch.empty((E, H), dtype=tdtype, device=dev)
+        rows2_, one_ = torch.empty_like(rows_), torch.zeros(1, device=dev)
+        imp_floor = {'empty_launch_us': round(graph_launch_us(lambda: one_.fill_(1.0)), 3),
+                     'copy_of_the_input_rows_us': round(graph_launch_us(lambda: rows2_.copy_(rows_)), 3),
+                     'copy_bytes': 2 * rows_.numel() * rows_.element_size(), 'imp_launch_us': round(1e3 * imp_ms, 3)}
+        del rows_, rows2_
         BL = 128                                                 # same launch on a graph that fills the chip
         impL_ms = imp_iter_ms(model, BL, tdtype)
         from sgg_amd import _lib as _sgg_lib
@@ -773,6 +802,7 @@ def main():
                              'reference_algorithm_bytes': imp_bytes, 'moved_bytes': imp_moved(B), 'avg_launch_ms': round(imp_ms, 5),
                              'achieved_moved': round(imp_moved(B) / (imp_ms * 1e-3) / 1e9, 1) if imp_ms else 0.0,
                              'frac_moved': round(imp_moved(B) / (imp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if imp_ms else 0.0,
+                             'floor_at_this_size': imp_floor,
                              'note': 'achieved / frac price SURVEY 8(d)\'s bytes of the REFERENCE step (incl. the e_in write this design removed '
                                      'algebraically) over the launch time; achieved_moved / frac_moved price the bytes this launch really moves (= PMC '
                                      'traffic). At B=8 the launch is latency-bound (a launch + two dependent memory levels; roofline time 1-2 us): the '

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGG_ABI_VERSION 12   /* bump whenever a prototype below changes: tests/abi.lock pins (version, digest of the prototypes) */
+#define SGG_ABI_VERSION 13   /* bump whenever a prototype below changes: tests/abi.lock pins (version, digest of the prototypes) */
 
 enum { SGG_F32 = 0, SGG_BF16 = 1, SGG_F16 = 2 };
 enum { SGG_ACT_NONE = 0, SGG_ACT_RELU = 1 };
@@ -467,6 +467,16 @@ int sgg_triple_pool_fwd(const void* rows, int ld, int o_off, const int* out_ptr,
                         const int* in_ids, int O, int Hd, int avg, void* pooled, int dtype, void* stream);
 int sgg_triple_pool_bwd(const void* d_pooled, const int64_t* edges, const int* out_ptr, const int* in_ptr, int T, int Hd, int avg,
                         int ld, int o_off, void* d_rows, int dtype, void* stream);
+
+/* ---------------------------------------------------------------- (e) the exchange step: gradient all-reduce over RCCL
+ * The data-parallel train step's one collective (main.py:116-120 run on N GPUs) for a host that is not torch: thin entry points
+ * over ncclGetUniqueId / ncclCommInitRank / ncclAllReduce(sum) / ncclCommDestroy of the RCCL the process carries (looked up with dlopen at
+ * the first call: SGG_RCCL_LIB, then librccl.so; no link-time dependency).  This repo's Python host uses torch.distributed('nccl') -- the
+ * same library -- through sgg_amd/dist.py.  One communicator per process = per GPU (the current HIP device). */
+int sgg_allreduce_unique_id(void* id128);                                             /* rank 0: 128 bytes to hand to every rank */
+int sgg_allreduce_init(const void* id128, int world, int rank, void** comm);
+int sgg_allreduce_sum(void* comm, void* buf, int64_t n, int dtype, void* stream);     /* in place, SGG_F32 / SGG_BF16 / SGG_F16 */
+int sgg_allreduce_destroy(void* comm);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('SGG_HIP_LIB') or os.path.join(_HERE, 'libsgg_hip.so')
 
 SGG_F32, SGG_BF16, SGG_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU = 0, 1
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 import threading  # noqa: E402
 # held by sgg_amd.graph_step while it captures a hipGraph, and by every other thread of this package around its own GPU calls (the
@@ -78,6 +78,10 @@ SIGNATURES = {
     'sgg_det_output': [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     'sgg_dropout_fwd': [_P, _L, _F, ctypes.c_uint64, _I, _P],
     'sgg_dropout_fwd_dev': [_P, _L, _F, _P, ctypes.c_uint64, _I, _P],
+    'sgg_allreduce_unique_id': [_P],
+    'sgg_allreduce_init': [_P, _I, _I, _P],
+    'sgg_allreduce_sum': [_P, _P, _L, _I, _P],
+    'sgg_allreduce_destroy': [_P],
     'sgg_act_bwd': [_P, _P, _P, _L, _F, _I, _I, _P],
     'sgg_ce_fwd_bwd': [_P, _I, _P, _I, _I, _I, _P, _F, _F, _P, _I, _P, _I, _P, _P, _I, _I, _F, _F, _P],
     'sgg_label_counts': [_P, _I, _I, _P, _I, _P],

@@ -296,3 +296,30 @@ def test_world_size_8_whole_trainer_steps_equal_single_process_on_concatenated_b
             np.testing.assert_allclose(got[r][1][n], got[0][1][n], rtol=0, atol=1e-6 * max(1.0, float(np.abs(ref_w[n]).max())))
     for r in range(8):
         np.testing.assert_allclose(got[r][2], ref_rm, atol=2e-2)
+
+
+def test_c_abi_allreduce_binds_the_processes_rccl():
+    """sgg_allreduce_* (SURVEY 8b, 8e): the gradient exchange for a host that is not torch -- RCCL looked up at run time (the copy torch
+    loaded), one communicator per GPU.  One rank here (RCCL refuses two ranks on one device): the sum over one rank is the tensor itself,
+    in every element type, on a side stream; bad arguments come back as error codes."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import ctypes
+    from sgg_amd import _lib
+    lib = _lib.load()
+    ident = ctypes.create_string_buffer(128)
+    assert lib.sgg_allreduce_unique_id(ident) == 0
+    comm = ctypes.c_void_p()
+    assert lib.sgg_allreduce_init(ident, 1, 0, ctypes.byref(comm)) == 0 and comm.value
+    s = torch.cuda.Stream()
+    for dt, code in ((torch.float32, _lib.SGG_F32), (torch.bfloat16, _lib.SGG_BF16), (torch.float16, _lib.SGG_F16)):
+        x = torch.randn(100003, device='cuda:0').to(dt)
+        want = x.clone()
+        s.wait_stream(torch.cuda.current_stream())
+        assert lib.sgg_allreduce_sum(comm, x.data_ptr(), x.numel(), code, s.cuda_stream) == 0
+        s.synchronize()
+        assert torch.equal(x, want)
+    assert lib.sgg_allreduce_sum(comm, None, 5, _lib.SGG_F32, None) == -1       # SGG_ERR_ARG
+    assert lib.sgg_allreduce_sum(comm, x.data_ptr(), 0, 99, None) == 0          # nothing to do
+    assert lib.sgg_allreduce_sum(comm, x.data_ptr(), 4, 99, None) != 0          # unknown element type
+    assert lib.sgg_allreduce_destroy(comm) == 0
