@@ -43,6 +43,42 @@ class _B(object):
     __slots__ = ('segments', 'static', 'loss', 'pgrads', 'local', 'fmap', 'sizes', 'padded', 'sig', 'replays')
 
 
+_MASKED = {}
+
+
+def masked_streams(dev, cus):
+    """(stream restricted to `cus` compute units, stream restricted to the other ones) of device `dev`, or None: hipExtStreamCreateWithCUMask
+    through the HIP runtime this process already carries.  Used for the update || VGG-forward pair of a replayed step: the optimiser's update
+    is an HBM stream that needs few CUs, the convolutions need every matrix core they can get -- sharing CUs (one update workgroup beside the
+    convolution's on every CU) cost the pair 0.9 ms of the 1.75 + 1.7 ms the two take alone (tools/graph_probe.py)."""
+    key = (str(dev), int(cus))
+    if key in _MASKED:
+        return _MASKED[key]
+    out = None
+    try:
+        import ctypes
+        total = torch.cuda.get_device_properties(dev).multi_processor_count
+        if 0 < cus < total:
+            hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so'))
+            words = (total + 31) // 32
+
+            def make(bits):
+                arr = (ctypes.c_uint32 * words)(*[(bits >> (32 * i)) & 0xffffffff for i in range(words)])
+                h = ctypes.c_void_p()
+                with torch.cuda.device(dev):
+                    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), arr)
+                if rc != 0 or not h.value:
+                    raise RuntimeError('hipExtStreamCreateWithCUMask -> %d' % rc)
+                return torch.cuda.ExternalStream(h.value, device=dev)
+            low = (1 << cus) - 1
+            out = (make(low), make(((1 << total) - 1) & ~low))
+    except Exception as e:         # no masked streams: the pair shares the chip as before
+        warnings.warn('sgg_amd: CU-masked streams unavailable (%s)' % e, RuntimeWarning)
+        out = None
+    _MASKED[key] = out
+    return out
+
+
 def _dbg(tag):
     """SGG_GRAPH_DEBUG=1: synchronise after every graph launch and say which one it was (a faulting replay then names itself)"""
     if os.environ.get('SGG_GRAPH_DEBUG') == '1':
@@ -76,6 +112,9 @@ class GraphStep(object):
         # ... and that alone was not enough: with the host held to 2 or 8 steps ahead by EVENT waits a 400-step run still faulted, with a device-wide
         # synchronisation every 32 steps it does not (5 of 5 bench runs of 200 / 400 steps, tools/graph_probe.py 400).  Cost: the queue drains
         # once per 32 steps (~0.4 ms of 220).
+        # > 0: the update on that many CUs of its own, the VGG forward on the others (hipExtStreamCreateWithCUMask).  EXPERIMENT, off: replaying a
+        # graph on such a stream faulted on this runtime (round 5); kept for a runtime that takes it -- the pair loses 0.9 ms to sharing CUs
+        self.update_cus = int(os.environ.get('SGG_GRAPH_UPDATE_CUS', '0'))
         self.sync_every = int(os.environ.get('SGG_GRAPH_SYNC_EVERY', '32'))
         self.since_sync = 0
 
@@ -381,8 +420,9 @@ class GraphStep(object):
                 loss = tr._forward_backward(st)
                 return loss, {p: p.grad for p in tr.opt.params() if p.grad is not None}, dict(tr._local)
             b.segments, (b.loss, b.pgrads, b.local) = self._capture_segments(body)
-            if [t for t, _ in b.segments] not in (['head'], ['head', 'lane', 'main', 'joined']):
-                raise RuntimeError('unexpected capture segments %s' % [t for t, _ in b.segments])
+            tags = [t for t, _ in b.segments]
+            if tags[0] != 'head' or any(t not in ('lane', 'main', 'joined') for t in tags[1:]) or tags.count('lane') != tags.count('joined'):
+                raise RuntimeError('unexpected capture segments %s' % tags)
         finally:
             det._features_override = None
             m.__dict__['_seed_dev'] = None
@@ -415,6 +455,9 @@ class GraphStep(object):
                 self.U[ukey] = u
             lane = node_lane(dev)
             side = lane[0] if lane is not None else main
+            masked = masked_streams(dev, self.update_cus) if (self.update_cus and side is not main) else None
+            if masked is not None:
+                side = masked[0]                # the update on its own few CUs, the VGG forward (below) on the others
             if side is not main:
                 side.wait_stream(main)          # the gradients (the previous step's graph B) and whatever else this stream has queued
                 with torch.cuda.stream(side):
@@ -431,7 +474,15 @@ class GraphStep(object):
         if v is None:
             v, _ = self._capture(lambda: m.detector.features(b.static[0], m.compute_dtype, out=b.fmap))
             self.V[vkey] = v
-        v.replay()
+        masked = masked_streams(dev, self.update_cus) if (self.update_cus and done is not None) else None
+        if masked is not None:
+            vs = masked[1]
+            vs.wait_stream(main)
+            with torch.cuda.stream(vs):
+                v.replay()
+            main.wait_stream(vs)
+        else:
+            v.replay()
         _dbg('V (VGG forward)')
         if done is not None:
             main.wait_event(done)
@@ -461,29 +512,27 @@ class GraphStep(object):
             m.union_boxes.count_train_batch()       # (the capture itself counted the first one)
 
     def _launch_B(self, b):
-        if len(b.segments) == 1:
-            b.segments[0][1].replay()
-        else:
-            # forward + phase A | the backward's lane work (node lane's stream) || phases B and C | what follows their meeting point
-            from .imp import node_lane
-            dev = self.seed.device
-            main = torch.cuda.current_stream(dev)
-            lane = node_lane(dev)
-            side = lane[0] if lane is not None else main
-            g = dict(b.segments)
-            g['head'].replay()
-            _dbg('B head')
-            if side is not main:
+        """the segments in capture order: 'head' / 'joined' on the calling stream ('joined' after the lane's graph has finished), 'lane' on the
+        node lane's stream beside the 'main' segment that follows it"""
+        from .imp import node_lane
+        dev = self.seed.device
+        main = torch.cuda.current_stream(dev)
+        lane = node_lane(dev)
+        side = lane[0] if lane is not None else main
+        done = None
+        for tag, g in b.segments:
+            if tag == 'lane' and side is not main:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    g['lane'].replay()
+                    if g is not None:
+                        g.replay()
                     done = torch.cuda.Event()
                     done.record(side)
-                g['main'].replay()
+                continue
+            if tag == 'joined' and done is not None:
                 main.wait_event(done)
-                _dbg('B lane || main')
-            else:
-                g['lane'].replay()
-                g['main'].replay()
-            if g['joined'] is not None:
-                g['joined'].replay()
+                done = None
+            if g is not None:
+                g.replay()
+        if done is not None:
+            main.wait_event(done)

@@ -182,15 +182,6 @@ class PredictFn(torch.autograd.Function):
                 ev = torch.cuda.Event()
                 ev.record(side)
             sv['x6t_ready'] = ev
-        # ---- nodes: obj_unary(roi_fmap_obj(node_feat))  (Linear ReLU Dropout Linear ReLU Dropout)
-        _lib.set_tag('fc6_obj')
-        x6 = ops.gemm(nf, w['fc6_obj'], w['fc6_obj_b'], ops.ACT_RELU)
-        _lib.set_tag('mlp')
-        if dropout_p > 0:
-            ops.dropout_(x6, dropout_p, seed, 1)
-        x7 = ops.gemm(x6, w['fc7_obj'], w['fc7_obj_b'], ops.ACT_RELU)
-        if dropout_p > 0:
-            ops.dropout_(x7, dropout_p, seed, 2)
         # row-stacked inputs / states of the 4 calls of each GRU cell
         T = model.mp_iter
         XN = torch.empty(((T + 1) * N, H), dtype=dt, device=dev)      # inputs of the node cell: obj_rep, ctx_0 .. ctx_{T-1}
@@ -201,7 +192,23 @@ class PredictFn(torch.autograd.Function):
         # block c = vert_c / edge_c: the hidden state LEAVING call c = entering call c+1.  (The state entering call 0 is zero: that
         # call adds nothing to the hidden-weight gradients, whose contractions therefore run over the rows of calls 1..T only.)
         HE = torch.empty(((T + 1) * E, H), dtype=dt, device=dev)
+        # a capture in progress (sgg_amd/graph_step.py): the node branch's MLP (256 rows against 25088-wide weights: HBM- and latency-bound) becomes
+        # a graph of its own, replayed on the lane's stream beside the edge branch's MFMA-bound MLP; the two meet in front of the message passing
+        fsplit = getattr(model, '_graph_split', None)
+        if fsplit is not None:
+            fsplit.next('lane')
+        # ---- nodes: obj_unary(roi_fmap_obj(node_feat))  (Linear ReLU Dropout Linear ReLU Dropout)
+        _lib.set_tag('fc6_obj')
+        x6 = ops.gemm(nf, w['fc6_obj'], w['fc6_obj_b'], ops.ACT_RELU)
+        _lib.set_tag('mlp')
+        if dropout_p > 0:
+            ops.dropout_(x6, dropout_p, seed, 1)
+        x7 = ops.gemm(x6, w['fc7_obj'], w['fc7_obj_b'], ops.ACT_RELU)
+        if dropout_p > 0:
+            ops.dropout_(x7, dropout_p, seed, 2)
         ops.gemm(x7, w['obj_unary'], w['obj_unary_b'], out=XN[:N])
+        if fsplit is not None:
+            fsplit.next('main')
         # ---- edges: relu(edge_unary(roi_fmap(edge_feat + conv(rects))))  (Linear ReLU Dropout Linear)
         _lib.set_tag('fc6_edge')
         if paired is not None:       # the long contraction once per unordered pair (f32), then per edge: + rect term + bias, ReLU
@@ -218,6 +225,8 @@ class PredictFn(torch.autograd.Function):
         y7 = ops.gemm(y6, w['fc7_edge'], w['fc7_edge_b'], ops.ACT_RELU if edge_relu7 else ops.ACT_NONE)
         ops.gemm(y7, w['edge_unary'], w['edge_unary_b'], ops.ACT_RELU, out=XE0)
         sv.update(x6=x6, x7=x7, y6=y6, y7=y7)
+        if fsplit is not None:
+            fsplit.next('joined')
         # ---- message passing (rel_model_stanford.py:68-94) with the node projection: per iteration ctx = read stream over e_i,
         # P_i = v_i W_ih^T, e_{i+1} = gate kernel on (e_i W_hh^T, P_i[s], P_i[o]); the gate dot products come out of the gate kernels
         _lib.set_tag('imp')

@@ -1,0 +1,69 @@
+"""What slows the VGG-16 forward down beside the optimiser's update (2.5 ms for the pair against 1.75 + 1.7 ms alone)?  The forward (graph V
+of a replayed step) is timed alone and beside: workgroups that only occupy wave slots (one per CU, sleeping), workgroups that stream
+memory at several grid sizes, and the update itself (graph U).     python tools/pair_probe.py"""
+import ctypes
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import sgg_amd
+from sgg_amd.rel_model_base import to_device_with_mirror
+from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
+from sgg_amd.trainer import Trainer
+
+
+def main():
+    dev = 'cuda:0'
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'native', 'libspin.so'))
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls')).to(dev).eval()
+    model.set_compute_dtype(torch.float16)
+    b = list(synthetic_batch(B=8, S=592, n_boxes=32, n_fg=6, seed=111))
+    b[0] = [(im * 255).round().to(torch.uint8).permute(1, 2, 0).contiguous().to(dev) for im in b[0]]
+    b[3], b[4], b[5] = b[3].to(dev), to_device_with_mirror(b[4], dev), to_device_with_mirror(b[5], dev)
+    b = tuple(b)
+    tr = Trainer(model, lr=1e-3, pipeline=True)
+    for _ in range(10):
+        tr.step(b)
+    tr.flush()
+    torch.cuda.synchronize()
+    g = tr.graphs
+    V = next(iter(g.V.values()))
+    U = next(iter(g.U.values()))
+    side = torch.cuda.Stream()
+    sink = torch.zeros(4, device=dev)
+    n4 = (1 << 30) // 16
+    src, dst = torch.empty(1 << 30, dtype=torch.uint8, device=dev), torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def run(name, beside, reps=20):
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            e0, e1, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if beside is not None:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    beside(side)
+                    e2.record(side)
+            V.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append((e0.elapsed_time(e1), e0.elapsed_time(e2) if beside is not None else 0.0))
+        ts.sort()
+        v, o = ts[len(ts) // 2]
+        print('%-64s VGG forward %.3f ms   the other %.3f ms' % (name, v, o), flush=True)
+    run('alone', None)
+    for blocks in (256, 512, 1024):
+        run('beside %4d sleeping workgroups (2.2 ms, no memory traffic)' % blocks, lambda s, blocks=blocks: lib.spin(blocks, 220000, P(sink), ctypes.c_void_p(s.cuda_stream)))
+    for blocks in (32, 64, 128, 256, 1024):
+        run('beside a 4 GiB copy stream on %4d workgroups' % blocks,
+            lambda s, blocks=blocks: lib.stream_copy(blocks, P(src), P(dst), n4, 2, ctypes.c_void_p(s.cuda_stream)))
+    run('beside the update (graph U)', lambda s: U.replay())
+
+
+if __name__ == '__main__':
+    main()
