@@ -853,7 +853,7 @@ def main():
                 trainer.flush()
             torch.cuda.synchronize()
             model.set_compute_dtype(torch.bfloat16)
-            tb = Trainer(model, lr=1e-3, pipeline=trainer.pipeline, loss_type=args.loss) if trainer is not None else None
+            tb = Trainer(model, lr=1e-3, pipeline=trainer.pipeline, loss_type=args.loss, graph=False) if trainer is not None else None     # (11 steps: launch by launch, no capture inside the short run)
             el_bt = timed(lambda b: tb.step(b), 3, 8) if tb is not None else None
             if tb is not None:
                 tb.flush()
@@ -877,7 +877,7 @@ def main():
             for key, split in (('x3_mode', True), ('f32_mode', False)):
                 model.set_compute_dtype(torch.float32, split3=split)
                 torch.cuda.empty_cache()             # fp32 activations are twice the size: let the allocator start from whole blocks
-                t32 = Trainer(model, lr=1e-3, pipeline=trainer.pipeline if trainer is not None else True, loss_type=args.loss)
+                t32 = Trainer(model, lr=1e-3, pipeline=trainer.pipeline if trainer is not None else True, loss_type=args.loss, graph=False)
                 el_t = timed(lambda b: t32.step(b), 4, 5)
                 t32.flush()
                 el_i = timed(infer_step, 2, 5)

@@ -115,6 +115,9 @@ class GraphStep(object):
         # > 0: the update on that many CUs of its own, the VGG forward on the others (hipExtStreamCreateWithCUMask).  EXPERIMENT, off: replaying a
         # graph on such a stream faulted on this runtime (round 5); kept for a runtime that takes it -- the pair loses 0.9 ms to sharing CUs
         self.update_cus = int(os.environ.get('SGG_GRAPH_UPDATE_CUS', '0'))
+        # W^T copies of the backward made on the lane inside B's forward instead of inside U: measured (round 5) U alone 1.65 -> 1.56 ms, B 4.18 ->
+        # 4.27 ms, the step 6.78 -> 6.86 ms -- not kept (off), the switch stays for a box where the update is the longer half of the pair
+        self.defer_transposes = os.environ.get('SGG_GRAPH_DEFER_TRANSPOSES', '0') == '1'
         self.sync_every = int(os.environ.get('SGG_GRAPH_SYNC_EVERY', '32'))
         self.since_sync = 0
 
@@ -414,6 +417,7 @@ class GraphStep(object):
         del probe
         b.sizes, b.padded = sizes, padded
         m.__dict__['_seed_dev'] = self.seed
+        m.__dict__['_transposes_in_forward'] = self.defer_transposes
         det._features_override = (b.fmap, sizes, padded)
         try:
             def body():
@@ -426,6 +430,7 @@ class GraphStep(object):
         finally:
             det._features_override = None
             m.__dict__['_seed_dev'] = None
+            m.__dict__['_transposes_in_forward'] = False
         self.B[sig] = b
         return b
 
@@ -450,7 +455,9 @@ class GraphStep(object):
 
                 def body():
                     tr.opt.step(grad_scale=1.0 / tr.loss_scale, grads=dict(prev.local), shards=None)
-                    train_weights(m)
+                    # the W^T copies of the backward (0.25 ms of transposes) are not made here but on the lane inside B's forward: the update
+                    # is the long pole of the update || VGG-forward pair, and nothing reads those copies before the backward
+                    train_weights(m, transposes=not self.defer_transposes)
                 u, _ = self._capture(body, pool='lane')    # (the optimiser's Python-side bookkeeping of ONE update ran during the capture: the replay below is that update)
                 self.U[ukey] = u
             lane = node_lane(dev)

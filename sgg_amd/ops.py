@@ -400,6 +400,14 @@ def split3(x, weights=False):
     Kp = (K + 63) // 64 * 64
     out = torch.empty((rows, 3 * Kp), dtype=torch.float16, device=x.device)
     _lib.call('sgg_split3', _p(x, torch.float32, rows_ok=True), x.stride(0), rows, K, Kp, _p(out), out.stride(0), 1 if weights else 0, _stream())
+    if key is not None and _split3_seen.get(key, 0) == 0:
+        # first sighting of this tensor version: not kept yet -- in training the big weights change every step and are split once per
+        # step, caching them would only push a gigabyte of dead splits through the allocator per step (x3 train 21 -> 31 ms when it did);
+        # a version that comes back (evaluation; the GRU weights, split several times per step) is kept from its second sighting on
+        if len(_split3_seen) > 4096:
+            _split3_seen.clear()
+        _split3_seen[key] = 1
+        key = None
     if key is not None:
         # the entry holds the source tensor too: its storage cannot be recycled for another tensor with the same address while the entry lives.
         # Entries are dropped oldest first beyond SGG_SPLIT3_CACHE_MB (default 6144; 0 = no cache); a split made under one stream is only
@@ -416,12 +424,14 @@ def split3(x, weights=False):
 
 import collections  # noqa: E402
 _split3_cache = collections.OrderedDict()
+_split3_seen = {}
 _split3_cache_size = [0]
 _SPLIT3_CACHE_BYTES = int(os.environ.get('SGG_SPLIT3_CACHE_MB', '6144')) << 20
 
 
 def split3_cache_clear():
     _split3_cache.clear()
+    _split3_seen.clear()
     _split3_cache_size[0] = 0
 
 

@@ -61,10 +61,40 @@ def tn_gemm(X, Y, out=None, want_colsum=False, out_dtype=torch.float32):
     return ops.gemm(ops.transpose(X), ops.transpose(Y), out_dtype=out_dtype, out=out)
 
 
-def train_weights(model):
+TRANSPOSED = ('fc7_obj', 'obj_unary', 'fc7_edge', 'edge_unary', 'obj_fc', 'rel_fc')      # W^T copies for the dX GEMMs of the backward
+
+
+def _transposed_operands(model, w, keep, t):
+    """the backward-only operands: W^T copies (dX = dY W runs as an NT GEMM on W^T), written in place into `keep`'s buffers"""
+    def tr(name, x):
+        out = keep.get(name)
+        if out is not None and (out.shape[0] != x.shape[1] or out.shape[1] < x.shape[0]):
+            out = None
+        keep[name] = ops.transpose(x, out=out)
+        return keep[name]
+    for name in TRANSPOSED:
+        t[name + '_t'] = tr(name + '_t', w[name])                        # [K, Np]
+    t['w6sum_t'] = tr('w6sum_t', w['fc6_edge_sum'])                      # [C, 4096]
+    imp = w['imp']
+    for g in ('edge_gru', 'node_gru'):
+        t[g + '_w_ih_t'] = tr(g + '_w_ih_t', getattr(imp, g + '_w_ih'))  # [H, 3H]
+        t[g + '_w_hh_t'] = tr(g + '_w_hh_t', getattr(imp, g + '_w_hh'))
+    t['rc_w2_t'] = tr('rc_w2_t', t['rc_w2'])                              # [d2, d]
+
+
+def rebuild_transposes(model):
+    """The W^T copies again from the current operands, in place (no allocation once they exist).  A replayed step (sgg_amd/graph_step.py)
+    makes them on the lane beside the edge branch's forward MLP instead of inside the update: they are read by the backward only, and the
+    update is the long pole of the update || VGG-forward pair."""
+    w = model.prepared()
+    _transposed_operands(model, w, model.__dict__['_train_bufs'], w['train'])
+
+
+def train_weights(model, transposes=True):
     """Forward operands (model.prepared()) + the transposed copies the backward needs, cached on the same key.  The derived buffers
     are allocated once per (model, dtype) and rewritten in place after every update: a rebuild is the library's transposes plus two
-    strided copies, no allocation and no fill."""
+    strided copies, no allocation and no fill.  transposes=False (a replayed step's update graph): the W^T copies keep their buffers but are
+    NOT rewritten here -- the caller has rebuild_transposes() run before the backward reads them."""
     w = model.prepared()
     if 'train' in w:
         return w
@@ -73,21 +103,7 @@ def train_weights(model):
     if keep.get('dtype') != dt or keep.get('device') != model.rel_fc.weight.device:
         keep.clear()
         keep.update(dtype=dt, device=model.rel_fc.weight.device)
-
-    def tr(name, x):
-        out = keep.get(name)
-        if out is not None and (out.shape[0] != x.shape[1] or out.shape[1] < x.shape[0]):
-            out = None
-        keep[name] = ops.transpose(x, out=out)
-        return keep[name]
     t = {}
-    for name in ('fc7_obj', 'obj_unary', 'fc7_edge', 'edge_unary', 'obj_fc', 'rel_fc'):
-        t[name + '_t'] = tr(name + '_t', w[name])                        # [K, Np]
-    t['w6sum_t'] = tr('w6sum_t', w['fc6_edge_sum'])                      # [C, 4096]
-    imp = w['imp']
-    for g in ('edge_gru', 'node_gru'):
-        t[g + '_w_ih_t'] = tr(g + '_w_ih_t', getattr(imp, g + '_w_ih'))  # [H, 3H]
-        t[g + '_w_hh_t'] = tr(g + '_w_hh_t', getattr(imp, g + '_w_hh'))
     ub = model.union_boxes
     f = lambda p: p.detach().float().contiguous()
     c0, c4 = ub.conv[0].weight, ub.conv[4].weight
@@ -104,7 +120,12 @@ def train_weights(model):
     t['rc_w1'], t['rc_w2'] = w1, w2
     t['rc_b1'] = f(ub.conv[0].bias)
     t['rc_b2'] = f(ub.conv[4].bias)
-    t['rc_w2_t'] = tr('rc_w2_t', w2)                                        # [d2, d]
+    names = [n + '_t' for n in TRANSPOSED] + ['w6sum_t', 'rc_w2_t'] + [g + s_ for g in ('edge_gru', 'node_gru') for s_ in ('_w_ih_t', '_w_hh_t')]
+    if transposes or any(keep.get(n) is None for n in names):
+        _transposed_operands(model, w, keep, t)
+    else:
+        for n in names:
+            t[n] = keep[n]                                                  # (stale until rebuild_transposes)
     t['rc_g1'], t['rc_be1'] = f(ub.conv[2].weight), f(ub.conv[2].bias)
     t['rc_g2'], t['rc_be2'] = f(ub.conv[6].weight), f(ub.conv[6].bias)
     t['ones'] = None
@@ -208,6 +229,8 @@ class PredictFn(torch.autograd.Function):
             ops.dropout_(x7, dropout_p, seed, 2)
         ops.gemm(x7, w['obj_unary'], w['obj_unary_b'], out=XN[:N])
         if fsplit is not None:
+            if getattr(model, '_transposes_in_forward', False):
+                rebuild_transposes(model)        # (the replayed step's update graph left them out: made here, on the lane, read by the backward)
             fsplit.next('main')
         # ---- edges: relu(edge_unary(roi_fmap(edge_feat + conv(rects))))  (Linear ReLU Dropout Linear)
         _lib.set_tag('fc6_edge')

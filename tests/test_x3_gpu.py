@@ -141,3 +141,22 @@ def test_x3_model_forward_gradients_and_trainer(ops):
     model.eval()
     model.dropout_p = 0.5
     assert not ops.split3_on()
+
+
+def test_split3_weight_cache_follows_the_tensors_version(ops):
+    """weights=True: a tensor version that comes back is split once more and then served from the cache (same object); an in-place change
+    (what the optimiser's version bump announces) gets a new split; leaving the mode empties the cache"""
+    w = torch.randn(96, 200, device=DEV)
+    ops.split3_cache_clear()
+    a = ops.split3(w, weights=True)
+    b = ops.split3(w, weights=True)              # second sighting: kept from here on
+    c = ops.split3(w, weights=True)
+    assert c is b and torch.equal(a, b)
+    w.mul_(2.0)                                  # (bumps w._version)
+    d = ops.split3(w, weights=True)
+    assert d is not b and torch.equal(d[:, :200].float(), w.half().float())
+    act = ops.split3(w)                          # activations are never cached
+    assert act is not ops.split3(w)
+    ops.set_split3(True)
+    ops.set_split3(False)
+    assert ops.split3(w, weights=True) is not d
