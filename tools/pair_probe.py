@@ -56,6 +56,32 @@ def main():
         ts.sort()
         v, o = ts[len(ts) // 2]
         print('%-64s VGG forward %.3f ms   the other %.3f ms' % (name, v, o), flush=True)
+    # is it the kernel BOUNDARIES of the forward (14 launches) or co-residency itself?  one long MFMA kernel instead of the forward:
+    from sgg_amd import ops
+    A = torch.randn(15872, 25088, device=dev).half()
+    Wb = torch.randn(4096, 25088, device=dev).half()
+    outb = torch.empty(15872, 4096, device=dev, dtype=torch.float16)
+
+    def run_gemm(name, beside, reps=10):
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if beside is not None:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    beside(side)
+            ops.gemm(A, Wb, out=outb)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        print('%-64s one GEMM launch (3.3 TFLOP) %.3f ms' % (name, ts[len(ts) // 2]), flush=True)
+    run_gemm('alone', None)
+    run_gemm('beside 256 sleeping workgroups (3 ms)', lambda s: lib.spin(256, 300000, P(sink), ctypes.c_void_p(s.cuda_stream)))
+    run_gemm('beside a 4 GiB copy stream on 256 workgroups x3', lambda s: [lib.stream_copy(256, P(src), P(dst), n4, 2, ctypes.c_void_p(s.cuda_stream)) for _ in range(3)])
+    del A, Wb, outb
     run('alone', None)
     for blocks in (256, 512, 1024):
         run('beside %4d sleeping workgroups (2.2 ms, no memory traffic)' % blocks, lambda s, blocks=blocks: lib.spin(blocks, 220000, P(sink), ctypes.c_void_p(s.cuda_stream)))
