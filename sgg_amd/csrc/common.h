@@ -55,6 +55,9 @@ static inline bool sgg_is_dtype(int dtype) { return dtype == SGG_F32 || dtype ==
 // First stages write one partial row per workgroup row instead of meeting in float atomics, whose arrival order -- and therefore the
 // sum's last bits -- changes from run to run: training is bit-reproducible (util.hip).
 int sgg_reduce_parts(const float* parts, int nparts, int ncols, float* out, int accumulate, hipStream_t s);
+// p[0 .. n) = v (32-bit words) with a kernel, on `s` (util.hip).  Used instead of hipMemsetAsync wherever a call may be captured into a
+// hipGraph: a captured memset node (sgg_eval_tail's, round 5) made the replay fault on ROCm 7.0; a fill kernel replays fine.
+int sgg_fill_u32(void* p, unsigned v, size_t n, hipStream_t s);
 
 #define SGG_CHECK_LAUNCH()                                   \
     do {                                                     \

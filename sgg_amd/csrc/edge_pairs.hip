@@ -105,9 +105,9 @@ extern "C" int sgg_pair_slots(const int64_t* rel_inds, const int* first, const i
     if (E == 0) return SGG_OK;
     if (!rel_inds || !first || !ubase || !cnt || !e2u || !u2e || !ucount || !flag || E < 0 || B <= 0 || U <= 0) return SGG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(u2e, 0xff, sizeof(int) * 2 * (size_t)U, s) != hipSuccess) return SGG_ERR_LAUNCH;
-    if (hipMemsetAsync(ucount, 0, sizeof(int) * (size_t)U, s) != hipSuccess) return SGG_ERR_LAUNCH;
-    if (hipMemsetAsync(flag, 0, sizeof(int), s) != hipSuccess) return SGG_ERR_LAUNCH;
+    if (sgg_fill_u32(u2e, 0xffffffffu, 2 * (size_t)U, s) != SGG_OK || sgg_fill_u32(ucount, 0u, (size_t)U, s) != SGG_OK ||
+        sgg_fill_u32(flag, 0u, 1, s) != SGG_OK)
+        return SGG_ERR_LAUNCH;
     hipLaunchKernelGGL(pair_slots_kernel, dim3((E + 255) / 256), dim3(256), 0, s, rel_inds, first, ubase, cnt, E, B, e2u, u2e, ucount, flag);
     SGG_CHECK_LAUNCH();
     return SGG_OK;

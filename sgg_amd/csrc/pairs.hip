@@ -260,7 +260,7 @@ extern "C" int sgg_pair_index_train(const int64_t* im_inds, int N, const int64_t
     int* rowoff = work;                 // N+1
     int* cnt = work + N + 2;            // N*N
     int* rank = cnt + (long)N * N;      // R
-    if (hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)N * N, s) != hipSuccess) return SGG_ERR_LAUNCH;
+    if (sgg_fill_u32(cnt, 0u, (size_t)N * N, s) != SGG_OK) return SGG_ERR_LAUNCH;
     if (R > 0) hipLaunchKernelGGL(fg_mark_kernel, dim3((R + 255) / 256), dim3(256), 0, s, gt_rels, R, img_first, N, cnt, rank);
     hipLaunchKernelGGL(pair_train_kernel<false>, dim3(N), dim3(64), 0, s, im_inds, N, cnt, rowoff, rel_labels, cap);
     hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, s, rowoff, N, count);

@@ -172,7 +172,7 @@ extern "C" int sgg_eval_tail(const void* obj_dists, int N, int C, const void* re
         float* probs = (float*)work + 2 * (size_t)n2;
         SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(rel_tail_kernel<T>, dim3((n2 + 3) / 4), dim3(256), 0, s, (const T*)rel_dists, E, P, rel_inds, obj_scores, probs, keys, idx, n2));
         if (E <= 16384) {
-            if (hipMemsetAsync(idx, 0, sizeof(int) * (size_t)E, s) != hipSuccess) return SGG_ERR_LAUNCH;
+            if (sgg_fill_u32(idx, 0u, (size_t)E, s) != SGG_OK) return SGG_ERR_LAUNCH;      // (not hipMemsetAsync: common.h)
             const int split = E >= 2048 ? 8 : 1;
             hipLaunchKernelGGL(rank_kernel, dim3((E + 255) / 256, split), dim3(256), 0, s, keys, E, idx, split);
             hipLaunchKernelGGL(tail_scatter_kernel, dim3((E + 3) / 4), dim3(256), 0, s, idx, rel_inds, probs, E, P, rels, pred_scores);

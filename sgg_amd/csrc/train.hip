@@ -990,7 +990,7 @@ extern "C" int sgg_act_bwd(const void* dy, const void* y, void* dx, int64_t n, f
 extern "C" int sgg_colsum(const void* x, int M, int N, int ld, float* out, float* ws, int dtype, void* stream) {
     if (!out || N <= 0 || M < 0 || ld < N) return SGG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (M == 0) return hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s) == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
+    if (M == 0) return sgg_fill_u32(out, 0u, (size_t)N, s);
     if (!x) return SGG_ERR_ARG;
     int rpb;
     const int split = split_rows(M, rpb);

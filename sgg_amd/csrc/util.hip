@@ -244,6 +244,19 @@ int sgg_reduce_parts(const float* parts, int nparts, int ncols, float* out, int 
     return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void fill_u32_kernel(unsigned* __restrict__ p, unsigned v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+}  // namespace
+
+int sgg_fill_u32(void* p, unsigned v, size_t n, hipStream_t s) {
+    if (n == 0) return SGG_OK;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (unsigned*)p, v, n);
+    return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ERR_LAUNCH;
+}
+
 extern "C" int sgg_abi_version(void) { return SGG_ABI_VERSION; }
 extern "C" const char* sgg_build_info(void) { return "sgg_hip gfx950 (CDNA4) " __DATE__ " " __TIME__; }
 

@@ -159,7 +159,12 @@ class VGGDetector(nn.Module):
         # the prep kernel writes image interiors only: the pad region of a previous, LARGER image in the same slot must be cleared --
         # i.e. only when the per-image sizes differ from the last call's on this (cached) plane
         sig = (tuple(sizes), x0.data_ptr())
-        if getattr(self, '_x0_sig', None) != sig:
+        if torch.cuda.is_current_stream_capturing():
+            # a launch sequence that will be replayed (sgg_amd/graph_step.py, graph_forward.py) cannot know what ran before it: it clears the plane
+            # every time (48 MB at 8 frames: ~10 us), and the next plain call does too
+            x0.zero_()
+            self._x0_sig = ('captured',)
+        elif getattr(self, '_x0_sig', None) != sig:
             if getattr(self, '_x0_sig', None) is not None:
                 x0.zero_()
             self._x0_sig = sig

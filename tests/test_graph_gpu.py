@@ -101,3 +101,49 @@ def test_graph_step_falls_back_on_batches_it_does_not_take():
     assert l0 == l1
     for k in s0:
         assert torch.equal(s0[k], s1[k]), k
+
+
+@pytest.mark.parametrize('mode', ['sgcls', 'predcls'])
+def test_eval_forward_graph_equals_plain_forward_bit_for_bit(mode):
+    """sgg_amd/graph_forward.py: model([batch]) in eval mode with device-resident inputs -- two plain calls per signature, then one replayed
+    hipGraph per call; the five result arrays equal the plain forward's (SGG_GRAPH=0) bit for bit, also after the weights changed"""
+    _gpu()
+    import numpy as np
+    import sgg_amd
+    from sgg_amd.synthetic import SyntheticData, init_weights
+    batches = _batches()
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode=mode, min_size=S, max_size=S)).to(DEV).eval()
+    model.set_compute_dtype(torch.float16)
+    seq = [batches[0], batches[1], batches[0], batches[2], batches[1], batches[2], batches[3], batches[2], batches[0], batches[2]]
+
+    def run_all(graph):
+        os.environ['SGG_GRAPH'] = '1' if graph else '0'
+        os.environ['SGG_GRAPH_STRICT'] = '1'
+        try:
+            model.enable_eval_graphs(graph)
+            outs = []
+            with torch.no_grad():
+                for b in seq:
+                    outs.append(model([b]))
+            eg = model.__dict__.get('_eval_graphs')
+            return outs, (dict(eg.stats) if eg is not None and eg is not True else None), (eg.disabled if eg is not None and eg is not True else None)
+        finally:
+            os.environ.pop('SGG_GRAPH', None)
+            os.environ.pop('SGG_GRAPH_STRICT', None)
+    plain, _, _ = run_all(False)
+    graphed, stats, disabled = run_all(True)
+    assert disabled is None, disabled
+    assert stats['replayed'] >= 5 and stats['captures'] == 2, stats
+    for a, b in zip(plain, graphed):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+    # the weights move (what a training step between two evaluations does): the graphs are made again and follow
+    with torch.no_grad():
+        model.rel_fc.weight.mul_(1.5)
+    plain2, _, _ = run_all(False)
+    graphed2, stats2, _ = run_all(True)
+    assert stats2['replayed'] >= 5
+    assert not all(np.array_equal(x, y) for x, y in zip(plain[0], plain2[0]))
+    for a, b in zip(plain2, graphed2):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
