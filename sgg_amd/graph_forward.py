@@ -87,7 +87,9 @@ class EvalGraphs(object):
         g = self.G.get(sig)
         if g is None:
             n = self.warm.get(sig, 0)
-            if n < WARM_CALLS:
+            if n < WARM_CALLS or len(self.G) >= int(os.environ.get('SGG_GRAPH_SIGNATURES', '8')):      # (bounded: see graph_step.py)
+                if len(self.warm) > 4096:
+                    self.warm.clear()
                 self.warm[sig] = n + 1
                 self.stats['plain'] += 1
                 return None

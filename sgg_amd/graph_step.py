@@ -107,6 +107,7 @@ class GraphStep(object):
         # hundreds of graph launches, and on this runtime (ROCm 7.0 HIP) that ends in "Memory access fault by GPU": 200 unsynchronised steps
         # (1000 launches in flight) faulted in 12 of 12 bench runs, 25 and 60 steps in none (tools/graph_fault_stats.sh).  The host waits for
         # the step issued DEPTH steps ago before it issues the next one: the GPU's queue never runs dry, the runtime's never overflows.
+        self.max_signatures = int(os.environ.get('SGG_GRAPH_SIGNATURES', '8'))
         self.depth = max(1, int(os.environ.get('SGG_GRAPH_DEPTH', '8')))
         self.inflight = []
         # ... and that alone was not enough: with the host held to 2 or 8 steps ahead by EVENT waits a 400-step run still faulted, with a device-wide
@@ -188,8 +189,12 @@ class GraphStep(object):
             return None
         b = self.B.get(sig)
         if b is None:
+            # real data rarely repeats a signature (boxes per image vary): the bookkeeping stays bounded, and at most MAX_SIGNATURES kinds of
+            # batch are ever captured (each holds its step's activations, ~0.5 GB per image at the bench size) -- the rest run launch by launch
             n = self.warm.get(sig, 0)
-            if n < WARM_STEPS:
+            if n < WARM_STEPS or len(self.B) >= self.max_signatures:
+                if len(self.warm) > 4096:
+                    self.warm.clear()
                 self.warm[sig] = n + 1
                 self.flush()
                 self.stats['plain'] += 1
