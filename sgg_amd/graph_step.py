@@ -90,7 +90,8 @@ def _dbg(tag):
 
 class GraphStep(object):
     def __init__(self, trainer):
-        self.tr = trainer
+        import weakref
+        self.tr = weakref.proxy(trainer)          # (no cycle trainer <-> graphs: the captured pools go when the trainer goes)
         self.model = trainer.model
         self.warm = {}            # signature -> launch-by-launch steps seen
         self.B = {}               # signature -> _B

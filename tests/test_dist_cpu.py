@@ -225,6 +225,22 @@ def test_bench_launcher_spawns_ranks_dry():
     assert json.loads([l for l in r.stdout.strip().splitlines() if l.startswith('{')][-1])['n_gpus'] == 2
 
 
+def test_bench_one_gpu_run_is_guarded_and_falls_back_once():
+    """`python bench.py` on one GPU runs in a child process started before anything touches the GPU; a child that dies (here: no GPU at
+    all) is repeated ONCE with the train step launched kernel by kernel (SGG_GRAPH=0) and its exit code is passed on."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'SGG_BENCH_CHILD',
+                                                            'SGG_GRAPH', 'SGG_BENCH_GUARD')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '1', '--warmup', '0', '--no-f32', '--no-cpu-baseline'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is here: the run succeeds (tests/-m gpu cover it)')
+    assert r.returncode != 0
+    assert r.stderr.count('once more with the train step launch by launch') == 1, r.stderr[-1500:]
+
+
 def test_bf16_wire_sum_error_bound_8_ranks():
     """GradBuckets sums the big gradients in bf16 on the wire.  Bound for 8 ranks, worst case = a chain of 7 bf16 additions (ring
     reduce-scatter: every hop adds two bf16 numbers and rounds): against the fp32 sum of the fp32 gradients the error stays
