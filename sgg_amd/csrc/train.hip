@@ -704,6 +704,23 @@ __device__ __forceinline__ void mt_load4(const TG* g, float (&v)[4]) {
     }
 }
 
+// the same 4 elements as they lie (no conversion: nothing waits for the load), and their unpacking
+template <typename TG> struct MtRaw4 { mt_u32x2 r; };
+template <> struct MtRaw4<float> { f32x4 r; };
+template <typename TG>
+__device__ __forceinline__ void mt_load4_raw(const TG* g, MtRaw4<TG>& q) {
+    q.r = __builtin_nontemporal_load(reinterpret_cast<const decltype(q.r)*>(g));
+}
+template <typename TG>
+__device__ __forceinline__ void mt_unpack4(const MtRaw4<TG>& q, float (&v)[4]) {
+    if constexpr (sizeof(TG) == 4) {
+        v[0] = q.r.x; v[1] = q.r.y; v[2] = q.r.z; v[3] = q.r.w;
+    } else {
+        v[0] = H16<TG>::lo(q.r.x); v[1] = H16<TG>::hi(q.r.x);
+        v[2] = H16<TG>::lo(q.r.y); v[3] = H16<TG>::hi(q.r.y);
+    }
+}
+
 template <typename TG>
 __global__ __launch_bounds__(256) void sqnorm_multi_kernel(const MultiTab tab, float* __restrict__ part) {
     __shared__ float red[4];
@@ -735,8 +752,10 @@ __global__ __launch_bounds__(256) void sqnorm_multi_kernel(const MultiTab tab, f
     if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// (5 waves per SIMD = at most 96 VGPRs: the update's workgroup must fit beside a convolution workgroup of the VGG forward, whose two waves
+// per SIMD hold 416 of the 512 registers -- with more it would not share a CU with one, and one of the two kernels would wait for the other)
 template <typename TG, typename TS>
-__global__ __launch_bounds__(256) void sgd_multi_kernel(const MultiTab tab, float wd, float mom, int first,
+__global__ __launch_bounds__(256, 5) void sgd_multi_kernel(const MultiTab tab, float wd, float mom, int first,
                                                         const float* __restrict__ norm_sq, float max_norm, float grad_scale,
                                                         int* __restrict__ skipped) {
     float coef = grad_scale;
@@ -758,49 +777,58 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const MultiTab tab, floa
         TS* sh = reinterpret_cast<TS*>(tab.shadow[t]);
         const float lr = tab.lr[t];
         const long base = (long)(c - tab.chunk0[t]) * MT_CHUNK;
-        float gv[4][4], pv[4][4], bv[4][4];
-        bool full[4];
+        if (base + MT_CHUNK <= n) {
+            // A whole chunk (all but the last one of a tensor): its 12 loads per thread are issued as they lie -- no conversion, no bounds
+            // test, no branch between them -- and only then used.  (Round 5: in the per-quarter form below the compiler put a full
+            // `s_waitcnt vmcnt(0)` in front of every quarter's loads, 3 loads in flight instead of 12; a bare kernel with this access
+            // pattern streams 5.2 GB in 0.92 ms on the same 256 workgroups, this one needed 1.4 - 1.5 -- tools/pair_probe.py.)
+            MtRaw4<TG> rg[4];
+            f32x4 rp[4], rb[4];
+            // (uniform chunk pointers + 32-bit lane offsets: scalar-base addressing, no 64-bit address per load kept in VGPRs)
+            const TG* __restrict__ gc = g + base;
+            float* __restrict__ pc = p + base;
+            float* __restrict__ bc = buf + base;
+            TS* __restrict__ sc = sh ? sh + base : nullptr;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {   // all loads of the chunk in flight before the first use
-            const long i = base + (q * 256 + threadIdx.x) * 4;
-            full[q] = i + 4 <= n;
-            if (full[q]) {
-                mt_load4(g + i, gv[q]);
-                mt_load4(p + i, pv[q]);
-                if (!first) mt_load4(buf + i, bv[q]);
+            for (int q = 0; q < 4; ++q) {
+                const int i = (q * 256 + (int)threadIdx.x) * 4;
+                mt_load4_raw(gc + i, rg[q]);
+                rp[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pc + i));
+                if (!first) rb[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(bc + i));
             }
-        }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const long i = base + (q * 256 + threadIdx.x) * 4;
-            if (full[q]) {
+            for (int q = 0; q < 4; ++q) {
+                const int i = (q * 256 + (int)threadIdx.x) * 4;
+                float gq[4];
+                mt_unpack4(rg[q], gq);
+                const float pq[4] = {rp[q].x, rp[q].y, rp[q].z, rp[q].w};
+                const float bq[4] = {rb[q].x, rb[q].y, rb[q].z, rb[q].w};
                 float nb[4], np[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float gg = coef * gv[q][k] + wd * pv[q][k];
-                    nb[k] = first ? gg : mom * bv[q][k] + gg;
-                    np[k] = pv[q][k] - lr * nb[k];
+                    const float gg = coef * gq[k] + wd * pq[k];
+                    nb[k] = first ? gg : mom * bq[k] + gg;
+                    np[k] = pq[k] - lr * nb[k];
                 }
-                // fp32 master and momentum: written once per step, read again a step later -- non-temporal, so that 2 GB of them do not push
-                // the VGG forward's operands out of L2 / the Infinity Cache (6.99 -> 6.94 ms per step, tools/drift.py, same box)
-                __builtin_nontemporal_store(f32x4{nb[0], nb[1], nb[2], nb[3]}, reinterpret_cast<f32x4*>(buf + i));
-                __builtin_nontemporal_store(f32x4{np[0], np[1], np[2], np[3]}, reinterpret_cast<f32x4*>(p + i));
-                if (sh) {
+                __builtin_nontemporal_store(f32x4{nb[0], nb[1], nb[2], nb[3]}, reinterpret_cast<f32x4*>(bc + i));
+                __builtin_nontemporal_store(f32x4{np[0], np[1], np[2], np[3]}, reinterpret_cast<f32x4*>(pc + i));
+                if (sc) {
                     uint2 o;
                     o.x = H16<TS>::pack(np[0], np[1]);
                     o.y = H16<TS>::pack(np[2], np[3]);
-                    *reinterpret_cast<uint2*>(sh + i) = o;
-                }
-            } else {
-                for (long k = i; k < n; ++k) {
-                    const float pk = p[k];
-                    const float gg = coef * Elem<TG>::ld(g + k) + wd * pk;
-                    const float b = first ? gg : mom * buf[k] + gg;
-                    buf[k] = b;
-                    p[k] = pk - lr * b;
-                    if (sh) Elem<TS>::st(sh + k, p[k]);
+                    *reinterpret_cast<uint2*>(sc + i) = o;
                 }
             }
+            continue;
+        }
+        // the last, partial chunk of a tensor (and tensors shorter than a chunk): element by element -- at most 4095 elements per tensor
+        for (long k = base + threadIdx.x; k < n; k += 256) {
+            const float pk = p[k];
+            const float gg = coef * Elem<TG>::ld(g + k) + wd * pk;
+            const float b = first ? gg : mom * buf[k] + gg;
+            buf[k] = b;
+            p[k] = pk - lr * b;
+            if (sh) Elem<TS>::st(sh + k, p[k]);
         }
     }
 }

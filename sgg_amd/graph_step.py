@@ -120,6 +120,9 @@ class GraphStep(object):
         # W^T copies of the backward made on the lane inside B's forward instead of inside U: measured (round 5) U alone 1.65 -> 1.56 ms, B 4.18 ->
         # 4.27 ms, the step 6.78 -> 6.86 ms -- not kept (off), the switch stays for a box where the update is the longer half of the pair
         self.defer_transposes = os.environ.get('SGG_GRAPH_DEFER_TRANSPOSES', '0') == '1'
+        # the rebuild of the derived operands as a graph of its own on the calling stream after the pair has met (its dozen short launches then
+        # pay no kernel-boundary penalty beside the forward): measured 6.92 - 7.08 ms per step against 6.81 - 6.88 with the rebuild inside U -- off
+        self.split_update = os.environ.get('SGG_GRAPH_SPLIT_UPDATE', '0') == '1'
         self.sync_every = int(os.environ.get('SGG_GRAPH_SYNC_EVERY', '32'))
         self.since_sync = 0
 
@@ -449,7 +452,7 @@ class GraphStep(object):
         dev = self.seed.device
         main = torch.cuda.current_stream(dev)
         prev = self.pending
-        done = None
+        done, rebuild = None, None
         if prev is None:
             self._wait_operands()       # the step before was a plain one: its update is queued on the lane, the head waits for it as a plain step would
         else:
@@ -458,14 +461,19 @@ class GraphStep(object):
             fresh = u is None
             if fresh:
                 self._point_grads(prev)
-
-                def body():
-                    tr.opt.step(grad_scale=1.0 / tr.loss_scale, grads=dict(prev.local), shards=None)
-                    # the W^T copies of the backward (0.25 ms of transposes) are not made here but on the lane inside B's forward: the update
-                    # is the long pole of the update || VGG-forward pair, and nothing reads those copies before the backward
-                    train_weights(m, transposes=not self.defer_transposes)
-                u, _ = self._capture(body, pool='lane')    # (the optimiser's Python-side bookkeeping of ONE update ran during the capture: the replay below is that update)
-                self.U[ukey] = u
+                # (SGG_GRAPH_SPLIT_UPDATE=1: U1 = the squared norms + clip + SGD on the lane's stream beside the VGG forward, U2 = the rebuild of
+                # the weight-derived operands on the calling stream AFTER the two have met -- measured slower, see __init__)
+                if self.split_update:
+                    u1, _ = self._capture(lambda: tr.opt.step(grad_scale=1.0 / tr.loss_scale, grads=dict(prev.local), shards=None), pool='lane')
+                    # (the optimiser's Python-side bookkeeping of ONE update ran during the capture: the replay below is that update)
+                    u2, _ = self._capture(lambda: train_weights(m, transposes=not self.defer_transposes), pool='main')
+                else:
+                    def body():
+                        tr.opt.step(grad_scale=1.0 / tr.loss_scale, grads=dict(prev.local), shards=None)
+                        train_weights(m, transposes=not self.defer_transposes)
+                    u1, _ = self._capture(body, pool='lane')
+                    u2 = None
+                u = self.U[ukey] = (u1, u2)
             lane = node_lane(dev)
             side = lane[0] if lane is not None else main
             masked = masked_streams(dev, self.update_cus) if (self.update_cus and side is not main) else None
@@ -474,14 +482,15 @@ class GraphStep(object):
             if side is not main:
                 side.wait_stream(main)          # the gradients (the previous step's graph B) and whatever else this stream has queued
                 with torch.cuda.stream(side):
-                    u.replay()
+                    u[0].replay()
                     done = torch.cuda.Event()
                     done.record(side)
             else:
-                u.replay()
+                u[0].replay()
             _dbg('U (update) %s' % ('captured' if fresh else 'replayed'))
             if not fresh:
                 self._after_update()
+            rebuild = u[1]
         vkey = (id(b), str(m.compute_dtype))
         v = self.V.get(vkey)
         if v is None:
@@ -499,6 +508,8 @@ class GraphStep(object):
         _dbg('V (VGG forward)')
         if done is not None:
             main.wait_event(done)
+        if rebuild is not None:
+            rebuild.replay()
         self.pending = None
 
     def _after_update(self):

@@ -234,7 +234,9 @@ class Trainer(object):
         self.loss_scale_f16 = float(os.environ.get('SGG_LOSS_SCALE', '1024'))
         self._norm_cache = {}
         if pipeline:
-            self.opt.max_blocks = int(os.environ.get('SGG_OPT_BLOCKS', '256'))   # leave wave slots for the VGG forward running beside the update
+            # leave wave slots for the VGG forward running beside the update (round 5, after the update kernel's loads were un-serialised:
+            # 192 workgroups 6.81 - 6.88 ms per step, 256: 6.87 - 6.94, same box)
+            self.opt.max_blocks = int(os.environ.get('SGG_OPT_BLOCKS', '192'))
         self._queued = False
         self.graphs = None        # sgg_amd.graph_step.GraphStep when the step is replayed as hipGraphs (set at the end of __init__)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1

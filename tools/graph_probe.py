@@ -132,8 +132,11 @@ def main():
         i, t = timed(lambda: g._launch_B(bb), steps)
         print('graph B alone (head forward + loss + backward): issue %.3f ms, %.3f ms per replay' % (i, t))
         for k, a in g.U.items():
-            i, t = timed(lambda: a.replay(), steps)
-            print('graph U alone (clip + SGD + operand rebuild): issue %.3f ms, %.3f ms per replay' % (i, t))
+            i, t = timed(lambda: a[0].replay(), steps)
+            print('graph U1 alone (norms + clip + SGD): issue %.3f ms, %.3f ms per replay' % (i, t))
+            if a[1] is not None:
+                i, t = timed(lambda: a[1].replay(), steps)
+                print('graph U2 alone (operand rebuild): issue %.3f ms, %.3f ms per replay' % (i, t))
         for k, a in g.V.items():
             i, t = timed(lambda: a.replay(), steps)
             print('graph V alone (VGG-16 forward): issue %.3f ms, %.3f ms per replay' % (i, t))

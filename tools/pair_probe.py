@@ -31,7 +31,7 @@ def main():
     torch.cuda.synchronize()
     g = tr.graphs
     V = next(iter(g.V.values()))
-    U = next(iter(g.U.values()))
+    U = next(iter(g.U.values()))[0]
     side = torch.cuda.Stream()
     sink = torch.zeros(4, device=dev)
     n4 = (1 << 30) // 16
@@ -89,6 +89,40 @@ def main():
         run('beside a 4 GiB copy stream on %4d workgroups' % blocks,
             lambda s, blocks=blocks: lib.stream_copy(blocks, P(src), P(dst), n4, 2, ctypes.c_void_p(s.cuda_stream)))
     run('beside the update (graph U)', lambda s: U.replay())
+    # the update's own access pattern as a bare streaming kernel: 250 M parameters, p / m f32, g / shadow f16 (5 GB per pass)
+    npar = 250 * (1 << 20)
+    pp, mm = torch.zeros(npar, device=dev), torch.zeros(npar, device=dev)
+    gg, ss = torch.zeros(npar, device=dev, dtype=torch.float16), torch.empty(npar, device=dev, dtype=torch.float16)
+    cnt = torch.zeros(4, dtype=torch.int32, device=dev)
+    for blocks, mode in ((256, 0), (256, 1), (512, 0), (1024, 0)):
+        def sgd(s, blocks=blocks, mode=mode):
+            lib.sgd_stream(blocks, P(pp), P(mm), P(gg), P(ss), ctypes.c_long(npar), mode, P(cnt), ctypes.c_void_p(s.cuda_stream))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sgd(torch.cuda.current_stream())
+        e0.record()
+        sgd(torch.cuda.current_stream())
+        e1.record()
+        torch.cuda.synchronize()
+        print('bare update stream alone, %d workgroups, %s chunks: %.3f ms for 5.24 GB (%.2f TB/s)' % (
+            blocks, 'static' if mode == 0 else 'fetched', e0.elapsed_time(e1), 5.243 / e0.elapsed_time(e1)), flush=True)
+        run('beside the bare update stream (%d workgroups, %s)' % (blocks, 'static' if mode == 0 else 'fetched'), sgd)
+    del pp, mm, gg, ss
+    # a streaming kernel that claims a few CUs by their hardware id (tools/native/spin.hip): what does it reach, what does it cost the forward?
+    state = torch.zeros(4096, dtype=torch.int32, device=dev)
+    for cus, workers in ((4, 4), (4, 8), (6, 4), (8, 4), (8, 2), (32, 1)):
+        def claim(s, cus=cus, workers=workers):
+            lib.claim_stream_copy(8192, P(src), P(dst), n4, 2, P(state), cus, workers, ctypes.c_void_p(s.cuda_stream))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        claim(torch.cuda.current_stream())
+        e1.record()
+        torch.cuda.synchronize()
+        st = state.tolist()
+        print('claiming copy alone: %d CUs per XCD x %d workers: %.3f ms for 4.3 GB (%.2f TB/s); CUs claimed per XCD %s, workers %d' % (
+            cus, workers, e0.elapsed_time(e1), 4.295 / e0.elapsed_time(e1), st[4032:4040], st[4041]), flush=True)
+        run('beside the claiming copy (%d CUs per XCD x %d workers)' % (cus, workers), claim)
 
 
 if __name__ == '__main__':
