@@ -599,6 +599,12 @@ class PredictFn(torch.autograd.Function):
             G[n6e + '.weight'] = ops.gemm_full_waves(d6t, x6t, out_dtype=big_dtype())
         hook(n6e + '.weight')
         del x6t, d6t
+        early_join = split is not None and os.environ.get('SGG_GRAPH_EARLY_JOIN', '1') != '0'
+        if early_join:
+            # replayed step: the lane's graph meets the calling stream HERE, after the one long launch it hides under (the fc6 weight gradient,
+            # 0.75 ms against ~0.4 ms of lane work) -- the dozen launches of phase C then run with no kernel of another queue resident (each of
+            # their boundaries costs 15 - 30 us otherwise, tools/pair_probe.py)
+            split.next('joined')
         # ---- phase C on the main stream: the edge-side weight gradients, largest first (fc7 carries its own hook)
         for name, dw in deferred[::-1]:                # fc7 edge, unary edge, rel_fc (the node-side ones ran / run on the lane)
             if name not in node_side:
@@ -608,7 +614,8 @@ class PredictFn(torch.autograd.Function):
         G['edge_gru.weight_ih'] = tn_gemm(DG[T * E:], XH[:E + T * N])           # [d_gi of call 0 ; dP_0 ..]^T . [rel_rep ; v_0 ..]
         G['edge_gru.weight_hh'] = tn_gemm(dGHe[E:], HE[:T * E])              # states entering calls 1..T (call 0: zero state)
         if split is not None:
-            split.next('joined')                            # what follows (and the memory it recycles) runs after the lane's graph has finished
+            if not early_join:
+                split.next('joined')                        # what follows (and the memory it recycles) runs after the lane's graph has finished
         elif lane_done is None:
             lane_work()
         else:                                               # everything the lane produced is complete before anything downstream reads it
