@@ -107,11 +107,29 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const TI* __restrict__
     // guarded loop below the compiler may not hoist a division by a run-time value
     const int c_h = c0 + (tid & 15) * 8;
     const int cg_h = (add && group >= 8) ? c_h / group : 0, left_h = group - (c_h - cg_h * group);
+    // An interior tile (the common case): its eight 16-byte pieces per thread are requested as they lie -- no conversion, no bounds test, no
+    // branch between the loads -- and unpacked afterwards.  (Round 5: in the guarded loop below every load8 converts at once and sits in its
+    // own branch region, and the compiler waits for each load before it issues the next: one load in flight per thread instead of eight.)
+    const bool whole = vin && r0 + 128 <= R && c0 + 128 <= C && sizeof(TI) == 2;
+    if (whole) {
+        u32x4 raw[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int id = tid + q * 256, rr = id >> 4, cc = (id & 15) * 8;
+            raw[q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(in) + ((long)(r0 + rr) * ld_in + c0 + cc) * (long)sizeof(TI));
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if constexpr (sizeof(TI) == 2) unpack8<TI>(raw[q], v[q]);
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int id = tid + q * 256, rr = id >> 4, cc = (id & 15) * 8;
         const int r = r0 + rr, c = c0 + cc;
-        if (r < R && c + 8 <= C && vin) {
+        if (whole) {
+            // (loaded above)
+        } else if (r < R && c + 8 <= C && vin) {
             load8(in + (long)r * ld_in + c, v[q]);
         } else {
 #pragma unroll
