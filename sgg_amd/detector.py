@@ -185,7 +185,12 @@ class VGGDetector(nn.Module):
         x, ci_layer, n_conv = x0, 0, len(ws)
         cfg = list(VGG16_CFG)
         li = 0
+        split = getattr(self, '_features_split', None)    # (sgg_amd/graph_step.py: told after every layer how many convolutions are done)
+        told = 0
         while li < len(cfg):
+            if split is not None and ci_layer != told:
+                told = ci_layer
+                split(ci_layer)
             v = cfg[li]
             if v == 'M':
                 y = self._buf('a%d' % li, (B, H // 2 + 2, W // 2 + 2, x.shape[3]), dtype, dev, True)

@@ -88,6 +88,17 @@ def _dbg(tag):
         sys.stderr.flush()
 
 
+class _Seq(object):
+    """graphs replayed back to back on the current stream (graph V in one or two parts)"""
+
+    def __init__(self, parts):
+        self.parts = list(parts)
+
+    def replay(self):
+        for g in self.parts:
+            g.replay()
+
+
 class GraphStep(object):
     def __init__(self, trainer):
         import weakref
@@ -125,6 +136,11 @@ class GraphStep(object):
         self.split_update = os.environ.get('SGG_GRAPH_SPLIT_UPDATE', '0') == '1'
         self.sync_every = int(os.environ.get('SGG_GRAPH_SYNC_EVERY', '32'))
         self.since_sync = 0
+        # graph V in two parts, the update released after the first: the forward's first layers (the fused conv1 block, conv2_x: large maps, short
+        # reductions) are the ones that suffer beside the update's 5 GB stream (kernel trace of a replayed step: conv1 block 281 -> 425 us,
+        # conv2_1 / conv2_2 168 -> 251 / 296 us, conv3_1 ... conv5_3 unchanged) -- so they run first, alone, and the update runs beside the rest.
+        # The number = convolutions in the first part (0: one graph, the update beside all of it)
+        self.v_split = int(os.environ.get('SGG_GRAPH_VSPLIT', '0'))
 
     # ------------------------------------------------------------------ what the capture takes
     def _signature(self, batch):
@@ -453,6 +469,15 @@ class GraphStep(object):
         main = torch.cuda.current_stream(dev)
         prev = self.pending
         done, rebuild = None, None
+        vkey = (id(b), str(m.compute_dtype), self.v_split)
+        v = self.V.get(vkey)
+        if v is None:
+            v = self.V[vkey] = self._capture_V(b)
+        split_v = len(v.parts) > 1 and not self.update_cus
+        if split_v:
+            for part in v.parts[:-1]:       # the first layers before the update is released (it waits for this stream below)
+                part.replay()
+            _dbg('V1 (VGG forward, first part)')
         if prev is None:
             self._wait_operands()       # the step before was a plain one: its update is queued on the lane, the head waits for it as a plain step would
         else:
@@ -491,11 +516,6 @@ class GraphStep(object):
             if not fresh:
                 self._after_update()
             rebuild = u[1]
-        vkey = (id(b), str(m.compute_dtype))
-        v = self.V.get(vkey)
-        if v is None:
-            v, _ = self._capture(lambda: m.detector.features(b.static[0], m.compute_dtype, out=b.fmap))
-            self.V[vkey] = v
         masked = masked_streams(dev, self.update_cus) if (self.update_cus and done is not None) else None
         if masked is not None:
             vs = masked[1]
@@ -503,6 +523,8 @@ class GraphStep(object):
             with torch.cuda.stream(vs):
                 v.replay()
             main.wait_stream(vs)
+        elif split_v:
+            v.parts[-1].replay()
         else:
             v.replay()
         _dbg('V (VGG forward)')
@@ -511,6 +533,21 @@ class GraphStep(object):
         if rebuild is not None:
             rebuild.replay()
         self.pending = None
+
+    def _capture_V(self, b):
+        """the VGG forward of b's static images into b.fmap: one graph, or two cut after the first `v_split` convolutions"""
+        m = self.model
+        det = m.detector
+        fn = lambda: det.features(b.static[0], m.compute_dtype, out=b.fmap)
+        k = self.v_split
+        if k <= 0:
+            return _Seq([self._capture(fn)[0]])
+        det._features_split = lambda convs_done: m.__dict__['_graph_split'].next('main') if convs_done == k else None
+        try:
+            segs, _ = self._capture_segments(fn)
+        finally:
+            det._features_split = None
+        return _Seq([g for _, g in segs if g is not None])
 
     def _after_update(self):
         """what FusedSGD.step / Trainer._bump do on the host for one update, for an update that ran inside a replayed graph"""

@@ -80,6 +80,27 @@ def test_graph_steps_equal_plain_steps_bit_for_bit(dtype):
     assert l1[-1] < l1[0]
 
 
+def test_graph_steps_with_the_forward_in_two_graphs_equal_plain_steps():
+    """SGG_GRAPH_VSPLIT=4: graph V cut after conv2_2, the update released after the first part -- scheduling only, the same bits"""
+    _gpu()
+    os.environ['SGG_GRAPH_STRICT'] = '1'
+    os.environ['SGG_GRAPH_VSPLIT'] = '4'
+    try:
+        batches = _batches()
+        l0, s0, m0, _, _, _ = _run(False, 14, torch.float16, None, batches)
+        l1, s1, m1, stats, disabled, _ = _run(True, 14, torch.float16, None, batches)
+    finally:
+        os.environ.pop('SGG_GRAPH_STRICT', None)
+        os.environ.pop('SGG_GRAPH_VSPLIT', None)
+    assert disabled is None, disabled
+    assert stats['replayed'] >= 4, stats
+    assert l0 == l1
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+    for k in m0:
+        assert torch.equal(m0[k], m1[k]), k
+
+
 def test_graph_step_falls_back_on_batches_it_does_not_take():
     """host-resident images, and a relation list with two relations on one ordered pair: plain steps, same results as a trainer without graphs"""
     _gpu()

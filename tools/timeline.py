@@ -65,3 +65,10 @@ if qcol:
         print('queue %s:' % qid)
         for nm, (us, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:16]:
             print('   %8.1f us  %5.1f x  %s' % (us, n / 3.0, nm))
+import os
+if os.environ.get('DUMP'):            # one step, every launch: start offset, duration, queue, name  (DUMP=<file>)
+    lo1, hi1 = marks[k0], marks[k0 + 1]
+    with open(os.environ['DUMP'], 'w') as f:
+        for r in rows:
+            if lo1 <= r[1] < hi1:
+                f.write('%9.1f %8.1f  q%s  %s\n' % ((r[1] - lo1) / 1e3, (r[2] - r[1]) / 1e3, r[3] if qcol else '-', r[0][:110]))
