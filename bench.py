@@ -681,6 +681,23 @@ def main():
                 kt = kernel_times(infer_step, reps=5)
             finally:
                 model.__dict__['_eval_graphs'] = saved_eg
+        # the same forward as one back-to-back sequence on an otherwise idle GPU (ten forwards between two events, the image prep kernel included):
+        # `roofline_vgg.ms_per_step` below sums per-launch event pairs inside a step, which also time the event records between the launches
+        vgg_alone = None
+        try:
+            with torch.no_grad():
+                for _ in range(2):
+                    model.detector.features(batch[0], model.compute_dtype)
+                torch.cuda.synchronize()
+                v0, v1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                v0.record()
+                for _ in range(10):
+                    model.detector.features(batch[0], model.compute_dtype)
+                v1.record()
+                torch.cuda.synchronize()
+                vgg_alone = v0.elapsed_time(v1) / 10
+        except Exception:
+            vgg_alone = None
         E, N, H = 992 * B, 32 * B, 512
         s = 4 if args.dtype == 'f32' else 2
         peak = MFMA_PEAK_TF[args.dtype]
@@ -856,7 +873,9 @@ def main():
                                        'ping-pong schedule; conv1_2 on the lock-step patch kernel, conv5 as implicit GEMM; pools fused in the epilogues): the largest time slice of the step',
                              'bound': 'mfma', 'achieved': round(vgg_flop / (conv_ms * 1e-3) / 1e12, 1) if conv_ms else 0.0, 'peak': peak, 'unit': 'TFLOP/s',
                              'frac': round(vgg_flop / (conv_ms * 1e-3) / 1e12 / peak, 4) if conv_ms else 0.0, 'traffic': None,
-                             'ms_per_step': round(conv_ms, 4), 'executed_flop': vgg_flop},
+                             'ms_per_step': round(conv_ms, 4), 'executed_flop': vgg_flop,
+                             'back_to_back_ms': round(vgg_alone, 4) if vgg_alone else None,
+                             'back_to_back_frac': round(vgg_flop / (vgg_alone * 1e-3) / 1e12 / peak, 4) if vgg_alone else None},
             'roofline_imp': {'kernel': 'imp_ctx_sliced_kernel (the IMP gather / gate / scatter step, one launch per iteration: every edge row read once, '
                                        'gates from dot products, two segmented sums per node; the edge inputs are never formed -- node projection)', 'bound': 'hbm',
                              'achieved': round(imp_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

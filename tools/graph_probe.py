@@ -71,6 +71,7 @@ def main():
                 t_[0] = [im.cpu() for im in hb[0]]
                 t_[3], t_[4], t_[5] = hb[3].cpu(), hb[4]._sgg_host, hb[5]._sgg_host
                 host.append(tuple(t_))
+            _shift = [torch.cuda.Stream() for _ in range(int(os.environ.get('STAGER_SHIFT', '0')))]      # (which pool stream -- which hardware queue -- the H2D copies get)
             stager = DeviceStager(dev, slots=16)
             n = 3 * steps
             print('stager feed ...', flush=True)
