@@ -754,7 +754,9 @@ __global__ __launch_bounds__(256) void sqnorm_multi_kernel(const MultiTab tab, f
 
 // (5 waves per SIMD = at most 96 VGPRs: the update's workgroup must fit beside a convolution workgroup of the VGG forward, whose two waves
 // per SIMD hold 416 of the 512 registers -- with more it would not share a CU with one, and one of the two kernels would wait for the other)
-template <typename TG, typename TS>
+// QD: quarters of a chunk whose loads are issued together (4: all 12 loads of the chunk in flight per thread; 2: six at a time -- an
+// experiment knob, SGG_OPT_DEPTH, for the update beside the VGG forward: fewer requests in flight, less queueing in front of the forward's)
+template <typename TG, typename TS, int QD>
 __global__ __launch_bounds__(256, 5) void sgd_multi_kernel(const MultiTab tab, float wd, float mom, int first,
                                                         const float* __restrict__ norm_sq, float max_norm, float grad_scale,
                                                         int* __restrict__ skipped) {
@@ -790,14 +792,16 @@ __global__ __launch_bounds__(256, 5) void sgd_multi_kernel(const MultiTab tab, f
             float* __restrict__ bc = buf + base;
             TS* __restrict__ sc = sh ? sh + base : nullptr;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+          for (int q0 = 0; q0 < 4; q0 += QD) {
+#pragma unroll
+            for (int q = q0; q < q0 + QD; ++q) {
                 const int i = (q * 256 + (int)threadIdx.x) * 4;
                 mt_load4_raw(gc + i, rg[q]);
                 rp[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pc + i));
                 if (!first) rb[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(bc + i));
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = q0; q < q0 + QD; ++q) {
                 const int i = (q * 256 + (int)threadIdx.x) * 4;
                 float gq[4];
                 mt_unpack4(rg[q], gq);
@@ -819,6 +823,7 @@ __global__ __launch_bounds__(256, 5) void sgd_multi_kernel(const MultiTab tab, f
                     *reinterpret_cast<uint2*>(sc + i) = o;
                 }
             }
+          }
             continue;
         }
         // the last, partial chunk of a tensor (and tensors shorter than a chunk): element by element -- at most 4095 elements per tensor
@@ -1294,13 +1299,15 @@ extern "C" int sgg_sgd_multi(float* const* p, const void* const* g, float* const
         // few, fat workgroups (12 float4 loads in flight per thread): 512 already stream at full bandwidth, and leave wave
         // slots for the kernels of another stream (the trainer's pipeline mode asks for 256: the VGG forward runs beside it)
         const dim3 grid((unsigned)min(chunks, max_blocks > 0 ? max_blocks : 512));
+        static const int depth = [] { const char* e = getenv("SGG_OPT_DEPTH"); return e ? atoi(e) : 4; }();
+#define SGG_SGD_LAUNCH(TS_, QD_) SGG_FOR_DTYPE(g_dtype, hipLaunchKernelGGL((sgd_multi_kernel<T, TS_, QD_>), grid, dim3(256), 0, s, tab, weight_decay, \
+                                                                          momentum, first_step, norm_sq, max_norm, grad_scale, lo == 0 ? skipped : (int*)nullptr))
         if (shadow_dtype == SGG_BF16) {
-            SGG_FOR_DTYPE(g_dtype, hipLaunchKernelGGL((sgd_multi_kernel<T, bf16_t>), grid, dim3(256), 0, s, tab, weight_decay, momentum, first_step, norm_sq,
-                                                      max_norm, grad_scale, lo == 0 ? skipped : (int*)nullptr));
+            if (depth == 2) { SGG_SGD_LAUNCH(bf16_t, 2); } else if (depth == 1) { SGG_SGD_LAUNCH(bf16_t, 1); } else { SGG_SGD_LAUNCH(bf16_t, 4); }
         } else {
-            SGG_FOR_DTYPE(g_dtype, hipLaunchKernelGGL((sgd_multi_kernel<T, f16_t>), grid, dim3(256), 0, s, tab, weight_decay, momentum, first_step, norm_sq,
-                                                      max_norm, grad_scale, lo == 0 ? skipped : (int*)nullptr));
+            if (depth == 2) { SGG_SGD_LAUNCH(f16_t, 2); } else if (depth == 1) { SGG_SGD_LAUNCH(f16_t, 1); } else { SGG_SGD_LAUNCH(f16_t, 4); }
         }
+#undef SGG_SGD_LAUNCH
         SGG_CHECK_LAUNCH();
     }
     return SGG_OK;
