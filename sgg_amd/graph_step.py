@@ -43,42 +43,6 @@ class _B(object):
     __slots__ = ('segments', 'static', 'loss', 'pgrads', 'local', 'fmap', 'sizes', 'padded', 'sig', 'replays')
 
 
-_MASKED = {}
-
-
-def masked_streams(dev, cus):
-    """(stream restricted to `cus` compute units, stream restricted to the other ones) of device `dev`, or None: hipExtStreamCreateWithCUMask
-    through the HIP runtime this process already carries.  Used for the update || VGG-forward pair of a replayed step: the optimiser's update
-    is an HBM stream that needs few CUs, the convolutions need every matrix core they can get -- sharing CUs (one update workgroup beside the
-    convolution's on every CU) cost the pair 0.9 ms of the 1.75 + 1.7 ms the two take alone (tools/graph_probe.py)."""
-    key = (str(dev), int(cus))
-    if key in _MASKED:
-        return _MASKED[key]
-    out = None
-    try:
-        import ctypes
-        total = torch.cuda.get_device_properties(dev).multi_processor_count
-        if 0 < cus < total:
-            hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so'))
-            words = (total + 31) // 32
-
-            def make(bits):
-                arr = (ctypes.c_uint32 * words)(*[(bits >> (32 * i)) & 0xffffffff for i in range(words)])
-                h = ctypes.c_void_p()
-                with torch.cuda.device(dev):
-                    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), arr)
-                if rc != 0 or not h.value:
-                    raise RuntimeError('hipExtStreamCreateWithCUMask -> %d' % rc)
-                return torch.cuda.ExternalStream(h.value, device=dev)
-            low = (1 << cus) - 1
-            out = (make(low), make(((1 << total) - 1) & ~low))
-    except Exception as e:         # no masked streams: the pair shares the chip as before
-        warnings.warn('sgg_amd: CU-masked streams unavailable (%s)' % e, RuntimeWarning)
-        out = None
-    _MASKED[key] = out
-    return out
-
-
 def _dbg(tag):
     """SGG_GRAPH_DEBUG=1: synchronise after every graph launch and say which one it was (a faulting replay then names itself)"""
     if os.environ.get('SGG_GRAPH_DEBUG') == '1':
@@ -125,9 +89,6 @@ class GraphStep(object):
         # ... and that alone was not enough: with the host held to 2 or 8 steps ahead by EVENT waits a 400-step run still faulted, with a device-wide
         # synchronisation every 32 steps it does not (5 of 5 bench runs of 200 / 400 steps, tools/graph_probe.py 400).  Cost: the queue drains
         # once per 32 steps (~0.4 ms of 220).
-        # > 0: the update on that many CUs of its own, the VGG forward on the others (hipExtStreamCreateWithCUMask).  EXPERIMENT, off: replaying a
-        # graph on such a stream faulted on this runtime (round 5); kept for a runtime that takes it -- the pair loses 0.9 ms to sharing CUs
-        self.update_cus = int(os.environ.get('SGG_GRAPH_UPDATE_CUS', '0'))
         # W^T copies of the backward made on the lane inside B's forward instead of inside U: measured (round 5) U alone 1.65 -> 1.56 ms, B 4.18 ->
         # 4.27 ms, the step 6.78 -> 6.86 ms -- not kept (off), the switch stays for a box where the update is the longer half of the pair
         self.defer_transposes = os.environ.get('SGG_GRAPH_DEFER_TRANSPOSES', '0') == '1'
@@ -473,11 +434,8 @@ class GraphStep(object):
         v = self.V.get(vkey)
         if v is None:
             v = self.V[vkey] = self._capture_V(b)
-        split_v = len(v.parts) > 1 and not self.update_cus
-        if split_v:
-            for part in v.parts[:-1]:       # the first layers before the update is released (it waits for this stream below)
-                part.replay()
-            _dbg('V1 (VGG forward, first part)')
+        for part in v.parts[:-1]:           # SGG_GRAPH_VSPLIT: the first layers before the update is released (it waits for this stream below)
+            part.replay()
         if prev is None:
             self._wait_operands()       # the step before was a plain one: its update is queued on the lane, the head waits for it as a plain step would
         else:
@@ -501,9 +459,6 @@ class GraphStep(object):
                 u = self.U[ukey] = (u1, u2)
             lane = node_lane(dev)
             side = lane[0] if lane is not None else main
-            masked = masked_streams(dev, self.update_cus) if (self.update_cus and side is not main) else None
-            if masked is not None:
-                side = masked[0]                # the update on its own few CUs, the VGG forward (below) on the others
             if side is not main:
                 side.wait_stream(main)          # the gradients (the previous step's graph B) and whatever else this stream has queued
                 with torch.cuda.stream(side):
@@ -516,17 +471,7 @@ class GraphStep(object):
             if not fresh:
                 self._after_update()
             rebuild = u[1]
-        masked = masked_streams(dev, self.update_cus) if (self.update_cus and done is not None) else None
-        if masked is not None:
-            vs = masked[1]
-            vs.wait_stream(main)
-            with torch.cuda.stream(vs):
-                v.replay()
-            main.wait_stream(vs)
-        elif split_v:
-            v.parts[-1].replay()
-        else:
-            v.replay()
+        v.parts[-1].replay()
         _dbg('V (VGG forward)')
         if done is not None:
             main.wait_event(done)

@@ -95,11 +95,8 @@ def main():
     assert g is not None and g.disabled is None and g.B and g.U and g.V, 'graphs are not up'
     for k, (u1, u2) in list(g.U.items()):
         g.U[k] = (Stamped(u1, 'U', st), u2)
-    for k, v in list(g.V.items()):
-        if len(v.parts) > 1:            # SGG_GRAPH_VSPLIT: 'V' = the first part (the update is released after it), 'V2' = the rest
-            v.parts = [Stamped(x, 'V' if i == 0 else 'V%d' % (i + 1), st) for i, x in enumerate(v.parts)]
-        else:
-            g.V[k] = Stamped(v, 'V', st)
+    for k, v in list(g.V.items()):       # 'V' = the first part (SGG_GRAPH_VSPLIT: the update is released after it), 'V2' = the rest
+        v.parts = [Stamped(x, 'V' if i == 0 else 'V%d' % (i + 1), st) for i, x in enumerate(v.parts)]
     for bb in g.B.values():
         bb.segments = [(tag, Stamped(x, 'B.' + tag, st) if x is not None else None) for tag, x in bb.segments]
     feed = g._feed
