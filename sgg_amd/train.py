@@ -599,11 +599,13 @@ class PredictFn(torch.autograd.Function):
             G[n6e + '.weight'] = ops.gemm_full_waves(d6t, x6t, out_dtype=big_dtype())
         hook(n6e + '.weight')
         del x6t, d6t
-        early_join = split is not None and os.environ.get('SGG_GRAPH_EARLY_JOIN', '1') != '0'
+        # SGG_GRAPH_EARLY_JOIN=1 (replayed step): the lane's graph meets the calling stream HERE, right after the fc6 weight gradient, and phase C
+        # runs with no kernel of another queue resident.  Off by default since the end of round 5: stream-position stamps (tools/step_stamps.py)
+        # show the calling stream idle for ~0.2 ms at that meeting point while the lane finishes (its work is stretched ~1.8x under the long
+        # launch), and phase C beside the lane's tail costs less than that wait -- same box, alternating: 7.20 / 7.09 / 7.20 / 7.05 / 7.20 / 7.06 ms per
+        # bench step (profiles/r05_join_placement.txt); the earlier 6.79 -> 6.755 ms in favour of the early join was inside the noise
+        early_join = split is not None and os.environ.get('SGG_GRAPH_EARLY_JOIN', '0') == '1'
         if early_join:
-            # replayed step: the lane's graph meets the calling stream HERE, after the one long launch it hides under (the fc6 weight gradient,
-            # 0.75 ms against ~0.4 ms of lane work) -- the dozen launches of phase C then run with no kernel of another queue resident (each of
-            # their boundaries costs 15 - 30 us otherwise, tools/pair_probe.py)
             split.next('joined')
         # ---- phase C on the main stream: the edge-side weight gradients, largest first (fc7 carries its own hook)
         for name, dw in deferred[::-1]:                # fc7 edge, unary edge, rel_fc (the node-side ones ran / run on the lane)
