@@ -50,6 +50,7 @@ def parse():
     ap.add_argument('--mode', default='train', choices=['train', 'infer', 'sgdet'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-f32', action='store_true', help='skip the short exact-fp32 runs reported under "f32_mode"')
+    ap.add_argument('--no-side-modes', action='store_true', help='skip the other single-GPU configs reported beside the headline (sgdet_mode, gqa_gan_mode)')
     ap.add_argument('--force-dist', action='store_true',
                     help='diagnostic: at 1 GPU, run the data-parallel code path on a 1-rank RCCL group')
     ap.add_argument('--cpu-images', type=int, default=8)
@@ -356,77 +357,114 @@ def cpu_baseline(n_images, seed, timed=3):
 
 def sgdet_cpu_baseline(n_images, seed):
     """BASELINE configs[2] on the host: the oracle's SGDet forward (VGG-16, RPN, 1000 proposals, box head, per-class NMS, IMP) on a bounded
-    sample -- `n_images` images, 1 timed forward after a warm-up of the first image only (the box head alone is ~0.4 TFLOP per image)."""
+    sample -- `n_images` images, 1 timed forward after a warm-up of the first image only (the box head alone is ~0.4 TFLOP per image).
+    The same synthetic detector as the GPU leg (synthetic.spread_detector_: 1 000 proposals and 50 detections per image)."""
     import torch
     import sgg_amd
     from oracle import sgg_oracle as O
-    from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
+    from sgg_amd.synthetic import SyntheticData, init_weights, spread_detector_, synthetic_batch
     model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgdet'))
-    sd = model.state_dict()
+    sd = spread_detector_(model.state_dict())
     batch = synthetic_batch(B=n_images, S=592, n_boxes=32, n_fg=6, seed=seed)
     avail = os.cpu_count() or 1
     cores = min(avail, 32)
     torch.set_num_threads(cores)
     with torch.no_grad():
-        O.forward_sgdet(batch[0][:1], sd, score_thresh=0.0)
+        O.forward_sgdet(batch[0][:1], sd, score_thresh=SGDET_THRESH)
         t0 = time.time()
-        O.forward_sgdet(batch[0], sd, score_thresh=0.0)
+        out = O.forward_sgdet(batch[0], sd, score_thresh=SGDET_THRESH)
         dt = time.time() - t0
     return {'value': round(n_images / dt, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model_name(),
-            'host_threads_available': avail,
-            'sample': '1 warm-up forward of one image + 1 timed forward of %d synthetic 592x592 images (seed %d, score threshold 0), the '
-                      'oracle\'s SGDet forward (torch-CPU fp32 + numpy NMS) on %d threads: %.1f s' % (n_images, seed, cores, dt)}
+            'host_threads_available': avail, 'detections': int(len(out['labels'])), 'candidate_edges': int(len(out['rel_inds'])),
+            'sample': '1 warm-up forward of one image + 1 timed forward of %d synthetic 592x592 images (seed %d, score threshold %.2f), the '
+                      'oracle\'s SGDet forward (torch-CPU fp32 + numpy NMS) on %d threads: %.1f s' % (n_images, seed, SGDET_THRESH, cores, dt)}
 
 
-def sgdet_bench(args, model, batch, timed, world, rank, B, dev):
-    """--mode sgdet: images/s of the SGDet eval forward at its real size + the per-call kernel times of one profiled pass."""
-    import torch
-    model.mode = 'sgdet'
+SGDET_THRESH = 0.05        # lib/eval.py:125-132: the evaluation starts at 0.2 and retries at 0.05 / 0.01; the synthetic class head is peaked enough for any of them
+
+
+def sgdet_model(dev, tdtype):
+    """RelModelStanford(mode='sgdet') with He-initialised weights and the synthetic detector that proposes like a trained one
+    (sgg_amd/synthetic.py: spread_detector_)."""
+    import sgg_amd
+    from sgg_amd.synthetic import SyntheticData, init_weights, spread_detector_
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgdet'))
+    spread_detector_(model.state_dict())         # (state_dict tensors alias the parameters: in place)
+    model.to(dev).eval()
+    model.set_compute_dtype(tdtype)
     model.detector.mode = 'refinerels'
-    model.set_box_score_thresh(0.0)
+    model.set_box_score_thresh(SGDET_THRESH)
+    return model
+
+
+def sgdet_measure(args, model, batches, timed, B, dev, steps, warmup, cpu_images=0):
+    """images/s of the SGDet eval forward at BASELINE configs[2]'s size (8 x 1 000 proposals through the box head) over a rotation of
+    `batches` + the per-call kernel times of one profiled pass -> dict (the `--mode sgdet` line, or `sgdet_mode` of the default line)."""
+    import torch
 
     def step(b=None):
         model.eval()
         with torch.no_grad():
-            return model([batch if b is None else b])
+            return model([batches[0] if b is None else b])
     out = step()
     n_det, n_edges = len(out[1]), len(out[3])
-    elapsed = timed(step, args.warmup, args.steps)
-    if rank != 0:
-        return
+    offs = list(model.detector.last_proposal_offsets)
+    elapsed = timed(step, warmup, steps, lambda n: (batches[i % len(batches)] for i in range(n)))
     kt = kernel_times(step, reps=3)
     total_ms = sum(v[0] * v[1] for v in kt.values())
     top = sorted(((v[0] * v[1], n, t) for (n, t), v in kt.items()), reverse=True)[:int(os.environ.get('SGG_BENCH_TOP', '12'))]
-    # the largest contraction of the step: the relation head's fc6 on the union-box rows of the detections' candidate pairs (one row per
-    # UNORDERED pair: the overlap-filtered list is symmetric), or -- with a detector that proposes many boxes -- the box head's fc6
-    fc6 = max(((v[0] * v[1], n, t) for (n, t), v in kt.items() if n == 'sgg_gemm'), default=(0.0, '', ''))
+    # the largest contraction of the step: the box head's fc6 on the proposals ([K x 25088] . [4096 x 25088]^T: at 8 x 1 000 proposals twice
+    # the relation head's), unless a detector proposes so few boxes that the relation head's fc6 on the union-box rows is longer
+    gemms = {t: v[0] * v[1] for (n, t), v in kt.items() if n in ('sgg_gemm', 'sgg_gemm_splitk')}
     K = int(getattr(model.detector, 'last_proposals', 0))
     paired = os.environ.get('SGG_EDGE_PAIRS', '1') != '0'
-    rows = (n_edges // 2 if paired else n_edges) if fc6[2] == 'fc6_edge' else K
-    what = ('relation head fc6 on the union-box rows of the %d candidate edges (%d rows)' % (n_edges, rows)) if fc6[2] == 'fc6_edge' else \
+    tag = max(gemms, key=lambda t: gemms[t]) if gemms else ''
+    ms = gemms.get(tag, 0.0)
+    rows = (n_edges // 2 if paired else n_edges) if tag == 'fc6_edge' else K
+    if tag not in ('fc6_edge', 'box_fc6'):
+        tag, ms = 'box_fc6', gemms.get('box_fc6', 0.0)
+        rows = K
+    what = ('relation head fc6 on the union-box rows of the %d candidate edges (%d rows)' % (n_edges, rows)) if tag == 'fc6_edge' else \
         ('box head fc6 on the %d proposals' % K)
     flop = 2.0 * rows * 4096 * 25088
     peak = MFMA_PEAK_TF[args.dtype]
-    tf = flop / (fc6[0] * 1e-3) / 1e12 if fc6[0] else 0.0
+    tf = flop / (ms * 1e-3) / 1e12 if ms else 0.0
     per = lambda names: sum(v[0] * v[1] for (n, t), v in kt.items() if n in names)       # noqa: E731
-    line = {'metric': 'images/sec (whole node), VG SGDet eval forward (detector + IMP)', 'value': round(world * B * args.steps / elapsed, 3),
-            'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': args.dtype, 'data': 'synthetic', 'input': 'batches resident in HBM (rotation of 4)',
-            'config': {'workload': 'VG SGDet (BASELINE configs[2]): 592x592 frames, RPN 21 660 anchors -> 1 000 proposals/img, box head, '
-                                   'per-class NMS, <= 50 detections/img, overlap-filtered pairs, union RoIAlign, 3 IMP iters, eval tail',
-                       'mode': 'sgdet', 'images_per_gpu': B, 'detections_per_step': n_det, 'candidate_edges_per_step': n_edges,
-                       'proposals_per_step': K, 'score_thresh': 0.0, 'weights': 'random init (He)'},
-            'roofline': {'kernel': '%s: [%d x 25088] . [4096 x 25088]^T (256x256 ping-pong MFMA kernel)' % (what, rows),
-                         'bound': 'mfma', 'achieved': round(tf, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(tf / peak, 4), 'traffic': None,
-                         'ms_per_step': round(fc6[0], 4), 'executed_flop': flop},
-            'kernels': {'sum_kernel_ms_per_step': round(total_ms, 3), 'largest_gemm_ms': round(fc6[0], 3),
-                        'vgg16_ms': round(per(('sgg_conv3x3_relu', 'sgg_conv1_1', 'sgg_conv1_block', 'sgg_maxpool2x2')), 3),
-                        'sort_ms': round(per(('sgg_segmented_sort_desc', 'sgg_gather_topk', 'sgg_topk_gather')), 4),
-                        'nms_ms': round(per(('sgg_nms',)), 4),
-                        'top': [{'ms_per_step': round(ms_, 3), 'call': n, 'tag': t} for ms_, n, t in top]}}
-    if world == 1 and not args.no_cpu_baseline:
-        line['cpu_baseline'] = sgdet_cpu_baseline(min(args.cpu_images, 2), 111)
+    res = {'value': round(B * steps / elapsed, 3), 'unit': 'images/s', 'steps': steps, 'warmup': warmup,
+           'ms_per_step': round(1e3 * elapsed / steps, 3), 'dtype': args.dtype,
+           'input': 'batches resident in HBM (rotation of %d)' % len(batches),
+           'config': {'workload': 'VG SGDet (BASELINE configs[2]): 592x592 frames, RPN 21 660 anchors -> %d proposals/img after NMS 0.7, box '
+                                  'head on all of them, per-class NMS 0.5, <= 50 detections/img, overlap-filtered pairs, union RoIAlign, '
+                                  '3 IMP iters, eval tail' % (K // max(B, 1)),
+                      'mode': 'sgdet', 'images_per_gpu': B, 'detections_per_step': n_det, 'candidate_edges_per_step': n_edges,
+                      'proposals_per_step': K, 'proposals_per_image': [offs[i + 1] - offs[i] for i in range(len(offs) - 1)],
+                      'score_thresh': SGDET_THRESH,
+                      'weights': 'random init (He) + synthetic.spread_detector_: RPN deltas x 0.02 and an objectness bias for the 32-px anchors '
+                                 '(1 000 proposals survive NMS 0.7), class head x 2 with a random bias, box regression grows detections to object size'},
+           'roofline': {'kernel': '%s: [%d x 25088] . [4096 x 25088]^T (256x256 ping-pong MFMA kernel)' % (what, rows),
+                        'bound': 'mfma', 'achieved': round(tf, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(tf / peak, 4), 'traffic': None,
+                        'ms_per_step': round(ms, 4), 'executed_flop': flop},
+           'kernels': {'sum_kernel_ms_per_step': round(total_ms, 3), 'largest_gemm_ms': round(ms, 3),
+                       'vgg16_ms': round(per(('sgg_conv3x3_relu', 'sgg_conv1_1', 'sgg_conv1_block', 'sgg_maxpool2x2')), 3),
+                       'sort_ms': round(per(('sgg_segmented_sort_desc', 'sgg_gather_topk', 'sgg_topk_gather')), 4),
+                       'nms_ms': round(per(('sgg_nms',)), 4),
+                       'top': [{'ms_per_step': round(ms_, 3), 'call': n, 'tag': t} for ms_, n, t in top]}}
+    if cpu_images:
+        res['cpu_baseline'] = sgdet_cpu_baseline(cpu_images, 111)
+    return res
+
+
+def sgdet_bench(args, batches, timed, world, rank, B, dev, tdtype):
+    """--mode sgdet: the SGDet eval forward as the line's `value` (every rank runs its own images: no collective)."""
+    model = sgdet_model(dev, tdtype)
+    res = sgdet_measure(args, model, batches, timed, B, dev, args.steps, args.warmup,
+                        cpu_images=(min(args.cpu_images, 2) if (world == 1 and rank == 0 and not args.no_cpu_baseline) else 0))
+    if rank != 0:
+        return
+    line = {'metric': 'images/sec (whole node), VG SGDet eval forward (detector + IMP)', 'value': round(world * res['value'], 3),
+            'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': res['ms_per_step'],
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic'}
+    line.update({k: v for k, v in res.items() if k not in line})
     import ctypes
     ctypes.CDLL(None).fflush(None)
     print(json.dumps(line), flush=True)
@@ -595,7 +633,8 @@ def main():
         return el
 
     if args.mode == 'sgdet':
-        sgdet_bench(args, model, batch, timed, world, rank, B, dev)
+        del model
+        sgdet_bench(args, dev_batches, timed, world, rank, B, dev, tdtype)
         if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
@@ -973,6 +1012,22 @@ def main():
                 t32.opt.state.clear()
                 del t32
             model.set_compute_dtype(tdtype)
+        if world == 1 and not args.force_dist and args.dtype != 'f32' and not args.no_side_modes and args.mode == 'train':
+            # BASELINE configs[2] beside the headline (the driver only runs the default line): the SGDet eval forward at the config's size
+            # -- 8 x 1 000 proposals through the box head -- with its own roofline (the box head's fc6) and its own CPU baseline
+            if trainer is not None:
+                trainer.flush()
+                trainer.opt.state.clear()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            try:
+                sm = sgdet_model(dev, tdtype)
+                line['sgdet_mode'] = sgdet_measure(args, sm, dev_batches, timed, B, dev, 20, 4,
+                                                   cpu_images=0 if args.no_cpu_baseline else 1)
+                del sm
+            except Exception as e:          # a side measurement never takes the headline down; the line says what happened
+                line['sgdet_mode'] = {'error': repr(e)[:400]}
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.cpu_images, 111)
     else:

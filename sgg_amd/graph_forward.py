@@ -25,7 +25,7 @@ WARM_CALLS = 2
 
 
 class _G(object):
-    __slots__ = ('graph', 'static', 'packed', 'meta')
+    __slots__ = ('graph', 'static', 'packed', 'meta', 'pins')
 
 
 class EvalGraphs(object):
@@ -159,6 +159,8 @@ class EvalGraphs(object):
                 else:
                     os.environ[k] = v
         g.graph = graph
+        from .graph_step import pin_caches
+        g.pins = pin_caches(m)              # the per-signature index tensors the graph reads live as long as the graph
         self.G[sig] = g
         self.stats['captures'] += 1
         return g

@@ -40,7 +40,19 @@ WARM_STEPS = 3        # launch-by-launch steps of a new signature before its cap
 
 class _B(object):
     """one captured head step: graph, its static inputs, the tensors it leaves its results in"""
-    __slots__ = ('segments', 'static', 'loss', 'pgrads', 'local', 'fmap', 'sizes', 'padded', 'sig', 'replays')
+    __slots__ = ('segments', 'static', 'loss', 'pgrads', 'local', 'fmap', 'sizes', 'padded', 'sig', 'replays', 'pins')
+
+
+def pin_caches(model):
+    """References to every per-signature index tensor a capture may have baked the address of: the model's candidate-edge
+    cache (rel_inds, CSR lists, pairing -- rel_model_stanford.py `_graph_cache`), its segment tensors (rel_model_base.py `_seg_cache`)
+    and the unordered-pair tables (pairing._TABLES).  Those caches evict by clearing themselves; a graph that holds the entries it was
+    captured with keeps their storage alive (and at its address) for as long as the graph lives -- the caches may forget them, the
+    plain path then simply builds equal tensors elsewhere.  Small: index tensors of a few MB per signature."""
+    from . import pairing
+    if os.environ.get('SGG_GRAPH_NO_PINS') == '1':        # (tests only: shows that the eviction test fails without the pins)
+        return None
+    return (dict(model.__dict__.get('_graph_cache') or {}), dict(model.__dict__.get('_seg_cache') or {}), dict(pairing._TABLES))
 
 
 def _dbg(tag):
@@ -73,6 +85,7 @@ class GraphStep(object):
         self.U = {}               # (id of the B whose gradients it applies, optimiser scalars) -> graph: clip + SGD + rebuild of the derived operands
         self.V = {}               # (id of the B it feeds) -> graph: VGG-16 forward of B's static images into B's feature map
         self.pending = None       # the _B whose gradients have not been applied yet
+        self._last_pending = None # ... as it was when the current step() began (what an exception handler needs to know)
         self.pending_scalars = None   # ... and the optimiser's scalars at the end of that step (the plain path queues the update there)
         self.generation = None
         self.disabled = None      # reason (str) once a capture failed
@@ -169,6 +182,7 @@ class GraphStep(object):
             self.stats['plain'] += 1
             return None
         b = self.B.get(sig)
+        self._last_pending = self.pending
         if b is None:
             # real data rarely repeats a signature (boxes per image vary): the bookkeeping stays bounded, and at most MAX_SIGNATURES kinds of
             # batch are ever captured (each holds its step's activations, ~0.5 GB per image at the bench size) -- the rest run launch by launch
@@ -180,6 +194,9 @@ class GraphStep(object):
                 self.flush()
                 self.stats['plain'] += 1
                 return None
+        if self.seed is None:
+            self.seed = torch.zeros(1, dtype=torch.int64, device=batch[3].device)
+        captured = b is not None
         try:
             import time
             t_w = time.perf_counter()
@@ -200,6 +217,10 @@ class GraphStep(object):
             ev.record(torch.cuda.current_stream(self.seed.device))
             self.inflight.append(ev)
         except Exception as e:          # a capture that fails leaves the plain path, for good (and says why, once)
+            if captured and self.U_ready(b):
+                # nothing was being captured: an error out of a plain replay (out of memory, a bad batch, a fault) is the caller's to see
+                self._abort_capture()
+                raise
             if self.disabled is None:
                 self.disabled = '%s: %s' % (type(e).__name__, e)
                 warnings.warn('sgg_amd: hipGraph capture of the train step failed (%s); continuing launch by launch' % self.disabled, RuntimeWarning)
@@ -212,11 +233,24 @@ class GraphStep(object):
         self.stats['replayed'] += 1
         return b.loss.detach().clone()
 
+    def U_ready(self, b):
+        """True when a step on `b` replays captured graphs only (B, its V, and the U of whatever is pending): no capture can be the source
+        of an exception then"""
+        m = self.model
+        if (id(b), str(m.compute_dtype), self.v_split) not in self.V:
+            return False
+        prev = self._last_pending
+        return prev is None or (id(prev), self._opt_scalars(), str(m.compute_dtype)) in self.U
+
     def flush(self):
-        """apply the update a replayed step has left pending, launch by launch, on the current stream"""
+        """apply the update a replayed step has left pending, launch by launch, on the current stream -- with the optimiser's scalars as they
+        were at the END of that step (where the plain pipelined path queues its update): a scheduler that stepped between step() and flush()
+        does not change the last update of an epoch"""
         b = self.pending
         if b is None:
             return
+        if self.pending_scalars is not None and self._opt_scalars()[:3] != self.pending_scalars[:3] and not self._in_flush_with:
+            return self._flush_with(self.pending_scalars)
         self.pending = None
         tr = self.tr
         self._point_grads(b)
@@ -226,14 +260,18 @@ class GraphStep(object):
         from .train import train_weights
         train_weights(self.model)       # the derived operands too (in place): a replayed B that follows reads them without asking
 
+    _in_flush_with = False
+
     def _flush_with(self, scalars):
         groups = self.tr.opt.param_groups
+        self._in_flush_with = True
         now = [(g['lr'], g['momentum'], g['weight_decay']) for g in groups]
         for g, lr, mo, wd in zip(groups, scalars[0], scalars[1], scalars[2]):
             g['lr'], g['momentum'], g['weight_decay'] = lr, mo, wd
         try:
             self.flush()
         finally:
+            self._in_flush_with = False
             for g, (lr, mo, wd) in zip(groups, now):
                 g['lr'], g['momentum'], g['weight_decay'] = lr, mo, wd
 
@@ -380,8 +418,6 @@ class GraphStep(object):
     def _capture_B(self, sig, batch):
         tr, m = self.tr, self.model
         dev = batch[3].device
-        if self.seed is None:
-            self.seed = torch.zeros(1, dtype=torch.int64, device=dev)
         # this step's update of the previous (plain) step is already queued on the lane: the head must wait for it as a plain step would --
         # outside the capture (an event of a stream that is not being captured)
         self.flush()
@@ -417,6 +453,7 @@ class GraphStep(object):
             det._features_override = None
             m.__dict__['_seed_dev'] = None
             m.__dict__['_transposes_in_forward'] = False
+        b.pins = pin_caches(m)          # the index tensors the captured launches read stay alive with the graph
         self.B[sig] = b
         return b
 
@@ -454,7 +491,12 @@ class GraphStep(object):
                     def body():
                         tr.opt.step(grad_scale=1.0 / tr.loss_scale, grads=dict(prev.local), shards=None)
                         train_weights(m, transposes=not self.defer_transposes)
-                    u1, _ = self._capture(body, pool='lane')
+                    steps_before = tr.opt.steps
+                    try:
+                        u1, _ = self._capture(body, pool='lane')
+                    except Exception:
+                        tr.opt.steps = steps_before         # nothing a failed capture recorded has run: the host-side count of updates neither
+                        raise
                     u2 = None
                 u = self.U[ukey] = (u1, u2)
             lane = node_lane(dev)
@@ -463,10 +505,12 @@ class GraphStep(object):
                 side.wait_stream(main)          # the gradients (the previous step's graph B) and whatever else this stream has queued
                 with torch.cuda.stream(side):
                     u[0].replay()
+                    self.pending = None         # issued: whatever fails from here on, these gradients are never applied a second time
                     done = torch.cuda.Event()
                     done.record(side)
             else:
                 u[0].replay()
+                self.pending = None
             _dbg('U (update) %s' % ('captured' if fresh else 'replayed'))
             if not fresh:
                 self._after_update()

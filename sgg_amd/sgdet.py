@@ -236,14 +236,21 @@ def detect(model, fmap, image_sizes, padded_hw, orig_sizes, spatial_scale, pyram
     rois, offs_h = propose(model, w, rpn_maps, img_hw, padded_hw)
     K = offs_h[-1]
     det.last_proposals = K          # (bench.py prices the box head's contractions with it)
+    det.last_proposal_offsets = list(offs_h)        # per image: [0, k0, k0 + k1, ...] (tests assert the config's 1 000 per image)
+    det.last_rois = rois
     if K == 0:
         raise ValueError('at least two objects must be detected to build relationships, make sure the detector is properly '
                          'pretrained', [])
     # ---- RoI heads: RoIAlign -> fc6 -> fc7 -> (cls_score | bbox_pred)
     feat = box_features(model, box_maps, scales, rois)
+    tag0 = _lib._tag[0]
+    _lib.set_tag('box_fc6')
     x = ops.gemm(feat, w['fc6'], w['fc6_b'], ops.ACT_RELU)
+    _lib.set_tag('box_fc7')
     x = ops.gemm(x, w['fc7'], w['fc7_b'], ops.ACT_RELU)
+    _lib.set_tag('box_pred')
     pred = ops.gemm(x, w['pred'], w['pred_b'], out_dtype=torch.float32)                                    # [K, 5C]
+    _lib.set_tag(tag0)
     ncand = K * (C - 1)
     cs = torch.empty(ncand, dtype=torch.float32, device=dev)
     cb = torch.empty((ncand, 4), dtype=torch.float32, device=dev)

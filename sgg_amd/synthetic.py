@@ -34,6 +34,37 @@ def init_weights(model, seed=111):
     return model
 
 
+def spread_detector_(sd, grow=6.0, gain=2.0, seed=17):
+    """SGDet (BASELINE configs[2]) needs a detector that BEHAVES like a trained one: ~1000 proposals per image after the RPN's NMS and up
+    to 50 detections with distinct scores.  A He-initialised RPN does not: its box deltas are O(1) per anchor side (every proposal is
+    clipped to the frame) and its objectness is dominated by a per-anchor constant, so the 1000 best anchors are 1000 shifted copies
+    of one large anchor and NMS 0.7 leaves ~13 of them.  In place, on a state dict (or anything with those keys):
+      * rpn.head.bbox_pred x 0.02 (proposals stay near their anchors), rpn.head.cls_logits.weight x 0.25 and a bias that puts the 32-px
+        anchors (3 ratios x 1444 positions, mutual IoU <= 0.56) ahead of the others: the 1000 best survive NMS 0.7 -> 1000 proposals/img;
+      * roi_heads.box_predictor: cls_score x `gain` with a random bias (peaked but distinct softmax scores), bbox_pred x 0.2 with a
+        log(`grow`) bias on (dw, dh) so that detections grow to object size and overlap (the overlap filter then keeps ~500 edges/img).
+    Same arithmetic, same kernels; only the synthetic weights change.  Returns sd."""
+    import math
+    pre = 'detector.rpn.head.'
+    sd[pre + 'bbox_pred.weight'].mul_(0.02)
+    sd[pre + 'bbox_pred.bias'].mul_(0.02)
+    sd[pre + 'cls_logits.weight'].mul_(0.25)
+    A = sd[pre + 'cls_logits.bias'].numel()
+    n_sizes = A // 3                                   # anchor a = ratio * n_sizes + size (rel_model_base.py:94-95: ratio-major)
+    b = torch.full((A,), -8.0)
+    b[0::n_sizes] = 8.0
+    sd[pre + 'cls_logits.bias'].copy_(b)
+    pre = 'detector.roi_heads.box_predictor.'
+    g = torch.Generator().manual_seed(seed)
+    sd[pre + 'cls_score.weight'].mul_(gain)
+    sd[pre + 'cls_score.bias'].copy_(torch.randn(sd[pre + 'cls_score.bias'].shape, generator=g))
+    sd[pre + 'bbox_pred.weight'].mul_(0.2)
+    bb = sd[pre + 'bbox_pred.bias'].view(-1, 4)
+    bb.mul_(0.2)
+    bb[:, 2:] += 5.0 * math.log(grow)                  # [3P] RoIHeads box coder weights (10, 10, 5, 5)
+    return sd
+
+
 def synthetic_batch(B=8, S=592, n_boxes=32, n_fg=6, seed=111, ragged=False, counts=None):
     """Blob-layout tuple (dataloaders/blob.py:244-249): (imgs list f32[3,S,S] on host, im_sizes, image_offset,
     gt_boxes f32[G,4], gt_classes i64[G,2], gt_rels i64[R,4], proposals, fns).  Boxes: x1,y1~U[0,0.68S),
@@ -70,3 +101,23 @@ def shard_batch(batch, lo, hi):
     r = rels[rk].clone()
     r[:, 0] -= lo
     return (list(imgs[lo:hi]), im_sizes[lo:hi], off, boxes[keep].clone(), cls, r, props, list(fns[lo:hi]))
+
+
+class GQASyntheticData(object):
+    """`train_data` stand-in with GQA's vocabulary (BASELINE configs[4]): 1 703 object + 310 predicate classes + background
+    (pretrain_detector.py:122 builds the GQA detector with 1 704 classes; the GQA scene graphs the reference's loader reads
+    -- dataloaders/gqa.py -- carry 310 predicate names, i.e. 311 with the background)."""
+    ind_to_classes = ['__background__'] + ['gqa_obj%d' % i for i in range(1, 1704)]
+    ind_to_predicates = ['__background__'] + ['gqa_pred%d' % i for i in range(1, 311)]
+
+
+def relabel_batch(batch, n_obj, n_pred, seed=0):
+    """the same Blob tuple with object classes drawn from 1..n_obj-1 and predicates from 1..n_pred-1 (synthetic_batch draws VG's 150 / 50)"""
+    rng = np.random.RandomState(seed)
+    b = list(batch)
+    cls = b[4].clone()
+    cls[:, 1] = torch.from_numpy(rng.randint(1, n_obj, size=cls.shape[0]))
+    rels = b[5].clone()
+    rels[:, 3] = torch.from_numpy(rng.randint(1, n_pred, size=rels.shape[0]))
+    b[4], b[5] = cls, rels
+    return tuple(b)

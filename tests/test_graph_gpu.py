@@ -124,6 +124,98 @@ def test_graph_step_falls_back_on_batches_it_does_not_take():
         assert torch.equal(s0[k], s1[k]), k
 
 
+def _other_signatures(n):
+    """n batches with n distinct boxes-per-image signatures (none of them _batches()'s): each makes one entry in the model's candidate-edge
+    cache, its segment cache and the pair tables"""
+    from sgg_amd.rel_model_base import to_device_with_mirror
+    from sgg_amd.synthetic import synthetic_batch
+    out = []
+    for k in range(n):
+        counts = (3 + k % 6, 3 + (k // 6) % 6, 9 + k // 36)
+        b = list(synthetic_batch(B=3, S=S, n_boxes=7, n_fg=2, seed=900 + k, counts=counts))
+        b[0] = [(im * 255).round().to(torch.uint8).permute(1, 2, 0).contiguous().to(DEV) for im in b[0]]
+        b[3] = b[3].to(DEV)
+        b[4], b[5] = to_device_with_mirror(b[4], DEV), to_device_with_mirror(b[5], DEV)
+        out.append(tuple(b))
+    assert len({tuple(torch.bincount(b[4]._sgg_host[:, 0]).tolist()) for b in out}) == n
+    return out
+
+
+def test_replays_survive_the_eviction_of_the_per_signature_caches():
+    """a captured step reads the candidate-edge list, its CSR lists and the pair tables at the addresses they had at capture.
+    Those caches evict by clearing themselves (> 32 / > 64 signatures).  Capture one signature, push 70 OTHER signatures through the plain
+    path (every cache is cleared at least once, the freed index tensors are overwritten with garbage by allocations of the same sizes), then
+    replay the first: bit-equal to a trainer without graphs fed the same sequence."""
+    _gpu()
+    import gc
+    os.environ['SGG_GRAPH_STRICT'] = '1'
+    try:
+        first = _batches()[0]
+        others = _other_signatures(70)
+        seq = [first] * 6 + others + [first] * 4
+        l0, s0, m0, _, _, _ = _run(False, len(seq), torch.float16, None, seq)
+        # (the run with graphs: after the 70 plain steps, scribble over whatever the allocator holds free -- a use-after-free then reads garbage
+        # indices: wrong losses or a fault, not a silent pass)
+        import sgg_amd
+        from sgg_amd import pairing
+        from sgg_amd.synthetic import SyntheticData, init_weights
+        from sgg_amd.trainer import Trainer
+        model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls', min_size=S, max_size=S)).to(DEV)
+        model.set_compute_dtype(torch.float16)
+        tr = Trainer(model, lr=2e-2, pipeline=True, graph=True)
+        torch.manual_seed(1234)
+        l1 = []
+        for i, b in enumerate(seq):
+            if i == 6 + len(others):
+                assert tr.graphs.stats['replayed'] >= 2, tr.graphs.stats
+                key0 = [k for k in tr.graphs.B][0]
+                assert not any(k[0] == tuple((i_, 7) for i_ in range(3)) for k in model._graph_cache), 'the cache was not evicted: the test tests nothing'
+                gc.collect()
+                torch.cuda.synchronize()
+                junk = [torch.full((n,), 0x7fffffff, dtype=torch.int32, device=DEV) for n in (64, 256, 1024, 4096, 16384, 65536) for _ in range(64)]
+                del junk
+                torch.cuda.synchronize()
+            l1.append(float(tr.step(b)))
+        tr.flush()
+        torch.cuda.synchronize()
+        stats, disabled = dict(tr.graphs.stats), tr.graphs.disabled
+        s1 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    finally:
+        os.environ.pop('SGG_GRAPH_STRICT', None)
+    assert disabled is None, disabled
+    assert stats['replayed'] >= 6, stats
+    assert l0 == l1, [(i, a, b) for i, (a, b) in enumerate(zip(l0, l1)) if a != b][:5]
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+
+
+def test_flush_after_a_scheduler_step_applies_the_pending_update_with_the_old_rate():
+    """scheduler.step() between the last step() of an epoch and flush() must not change that step's update (the plain pipelined
+    path queued it with the old rate at the end of the step)"""
+    _gpu()
+    import sgg_amd
+    from sgg_amd.synthetic import SyntheticData, init_weights
+    from sgg_amd.trainer import Trainer
+    batches = _batches()
+    out = []
+    for graph in (False, True):
+        model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls', min_size=S, max_size=S)).to(DEV)
+        model.set_compute_dtype(torch.float16)
+        tr = Trainer(model, lr=2e-2, pipeline=True, graph=graph)
+        torch.manual_seed(77)
+        for i in range(8):
+            tr.step(batches[0])
+        if graph:
+            assert tr.graphs.stats['replayed'] >= 3 and tr.graphs.pending is not None
+        for g in tr.opt.param_groups:
+            g['lr'] *= 0.1                  # the epoch's scheduler step
+        tr.flush()
+        torch.cuda.synchronize()
+        out.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+    for k in out[0]:
+        assert torch.equal(out[0][k], out[1][k]), k
+
+
 @pytest.mark.parametrize('mode', ['sgcls', 'predcls'])
 def test_eval_forward_graph_equals_plain_forward_bit_for_bit(mode):
     """sgg_amd/graph_forward.py: model([batch]) in eval mode with device-resident inputs -- two plain calls per signature, then one replayed
