@@ -47,7 +47,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=8, help='images per GPU (global batch 64 at 8 GPUs)')
     ap.add_argument('--dtype', default='f16', choices=['f16', 'bf16', 'f32'],
                     help='storage / MFMA operand format: f16 (default: the 16-bit mode that meets the parity clause), bf16 (same speed, 8x the rounding error), f32')
-    ap.add_argument('--mode', default='train', choices=['train', 'infer', 'sgdet'])
+    ap.add_argument('--mode', default='train', choices=['train', 'infer', 'sgdet', 'gqa_gan'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-f32', action='store_true', help='skip the short exact-fp32 runs reported under "f32_mode"')
     ap.add_argument('--no-side-modes', action='store_true', help='skip the other single-GPU configs reported beside the headline (sgdet_mode, gqa_gan_mode)')
@@ -470,6 +470,155 @@ def sgdet_bench(args, batches, timed, world, rank, B, dev, tdtype):
     print(json.dumps(line), flush=True)
 
 
+def gqa_gan_setup(dev, tdtype, B, S=1333, n_batches=2, gan_compute=None):
+    """BASELINE configs[4] on one GPU: RelModelStanford(backbone='resnet50') with GQA's vocabulary (1 704 / 311 classes), the GAN of
+    augment/gan.py on its 256 x 21 x 21 'pool'-level maps, B synthetic 1333 x 1333 frames (config.py:76-78 forces the backbone,
+    rel_model_base.py:62-65 its frame size), 32 boxes and 992 candidate edges per image, labels drawn from the GQA vocabulary."""
+    import torch
+    import sgg_amd
+    from sgg_amd import dense
+    from sgg_amd.feature_gan import GAN
+    from sgg_amd.rel_model_base import to_device_with_mirror
+    from sgg_amd.resnet_fpn import FrozenBatchNorm2d
+    from sgg_amd.synthetic import GQASyntheticData, init_weights, relabel_batch, synthetic_batch
+    from sgg_amd.trainer import Trainer
+    data = GQASyntheticData()
+    torch.manual_seed(111)
+    model = init_weights(sgg_amd.RelModelStanford(data, mode='sgcls', backbone='resnet50'))
+    for m in model.modules():
+        if isinstance(m, FrozenBatchNorm2d):
+            m.weight.uniform_(0.5, 1.0)
+            m.running_var.uniform_(0.6, 1.4)
+    for n, p in model.named_parameters():
+        if n.startswith('detector.'):
+            p.requires_grad = False               # main.py:62-63
+    model.to(dev)
+    model.set_compute_dtype(tdtype)
+    gan = GAN(data.ind_to_classes, data.ind_to_predicates, n_ch=model.edge_dim, pool_sz=model.pool_sz, fmap_sz=model.fmap_sz, device=dev).to(dev)
+    if gan_compute is not None:
+        dense.set_compute(gan_compute)
+    batches = []
+    for k in range(n_batches):
+        b = list(relabel_batch(synthetic_batch(B=B, S=S, n_boxes=32, n_fg=6, seed=111 + 1000 * k), len(data.ind_to_classes),
+                               len(data.ind_to_predicates), seed=k))
+        b[0] = [im.to(dev) for im in b[0]]
+        b[3] = b[3].to(dev)
+        b[4], b[5] = to_device_with_mirror(b[4], dev), to_device_with_mirror(b[5], dev)
+        batches.append(tuple(b))
+    tr = Trainer(model, lr=1e-3, pipeline=False, graph=False)
+    # lib/pytorch_misc.py:113-114 (Adam for G and D; config.py defaults lrG = lrD = 1e-4? no checkpoint here: the rates only scale the update)
+    G_opt = torch.optim.Adam([p for n, p in gan.named_parameters() if n.startswith('G_')], lr=1e-4, betas=(0.5, 0.999))
+    D_opt = torch.optim.Adam([p for n, p in gan.named_parameters() if n.startswith('D_')], lr=1e-4, betas=(0.5, 0.999))
+    return model, gan, tr, G_opt, D_opt, batches
+
+
+def gqa_gan_measure(args, dev, tdtype, timed, B, steps, warmup, cpu=True):
+    """images/s of one GQA + GAN training iteration (main.py:100-194: SGG forward, losses, backward, clip + SGD, then the generator
+    and discriminator updates incl. the reconstruction update of the SGG model) + per-call kernel times of a profiled pass."""
+    import torch
+    from sgg_amd import _lib
+    from sgg_amd.feature_gan import gan_train_step
+    model, gan, tr, G_opt, D_opt, batches = gqa_gan_setup(dev, tdtype, B, gan_compute=os.environ.get('SGG_GAN_COMPUTE'))
+    state = {}
+
+    def step(b=None):
+        b = batches[0] if b is None else b
+        model.train()
+        _lib.set_tag('sgg')
+        res = model([b])                                        # main.py:103
+        loss = tr.losses(res)                                   # :106-114
+        tr.opt.zero_grad()
+        model._loss_scaled = True
+        try:
+            (loss * tr.loss_scale).backward()                   # :117-118
+        finally:
+            model._loss_scaled = False
+        tr.update()                                             # :119-120 (global-norm clip + SGD)
+        _lib.set_tag('gan')
+        state['losses'] = gan_train_step(model, gan, res, b[3], b[4], b[5], None, G_opt, D_opt, trainer=tr)    # :124-194
+        _lib.set_tag('')
+        return state['losses']
+    step()
+    torch.cuda.synchronize()
+    elapsed = timed(step, warmup, steps, lambda n: (batches[i % len(batches)] for i in range(n)))
+    kt = kernel_times(step, reps=2)
+    total_ms = sum(v[0] * v[1] for v in kt.values())
+    top = sorted(((v[0] * v[1], n, t, v[1]) for (n, t), v in kt.items()), reverse=True)[:int(os.environ.get('SGG_BENCH_TOP', '14'))]
+    by_tag = {}
+    for (n, t), v in kt.items():
+        by_tag[t] = by_tag.get(t, 0.0) + v[0] * v[1]
+    # the largest contraction: the edge discriminator's first 3x3 convolution on the [E, 7, 7, 256 + 311] class-conditioned RoI features
+    # (augment/gan.py:222-231): E x 25 output positions x 256 channels x 9 (256 + 311) taps, run on generated rows (G update), real + generated
+    # rows (D update) and in both backwards
+    E = 992 * B
+    d_edge_flop = 2.0 * E * 25 * 256 * 9 * (256 + 311)
+    from sgg_amd import dense
+    gemm_ms = sum(v[0] * v[1] for (n, t), v in kt.items() if n in ('sgg_gemm', 'sgg_gemm_splitk') and t == 'gan')
+    mode = dense.compute_mode()
+    peak = {'f32': MFMA_PEAK_TF['f32'], 'x3': MFMA_PEAK_TF['f16'] / 3.0, 'f16': MFMA_PEAK_TF['f16']}[mode]
+    res = {'value': round(B * steps / elapsed, 3), 'unit': 'images/s', 'steps': steps, 'warmup': warmup, 'ms_per_step': round(1e3 * elapsed / steps, 3),
+           'dtype': args.dtype, 'gan_dense_layers': {'f32': 'exact fp32 MFMA (v_mfma_f32_32x32x2_f32)', 'x3': 'f16 split operands (hi + lo), three products, fp32 accumulate: fp32-grade',
+                                                       'f16': 'f16 operands, fp32 accumulate'}[mode],
+           'config': {'workload': 'GQA SGCls + GAN feature augmentation (BASELINE configs[4]) on one GPU: %d synthetic 1333x1333 frames, ResNet-50-FPN '
+                                  'detector (frozen), 32 boxes / 992 edges per image, 1704 object / 311 predicate classes, IMP head train step + '
+                                  'generator / discriminator / reconstruction updates (main.py:100-194)' % B,
+                      'mode': 'gqa_gan', 'images_per_gpu': B, 'object_classes': 1704, 'predicate_classes': 311,
+                      'losses': {k: round(float(v), 4) for k, v in state['losses'].items()}},
+           'kernels': {'sum_kernel_ms_per_step': round(total_ms, 3), 'by_part_ms': {k or 'other': round(v, 3) for k, v in by_tag.items()},
+                       'gan_gemm_ms': round(gemm_ms, 3),
+                       'top': [{'ms_per_step': round(ms_, 3), 'call': n, 'tag': t, 'launches': k} for ms_, n, t, k in top]}}
+    # roofline of the largest single contraction, timed on its own (same shapes, same entry point)
+    try:
+        x = torch.randn(E * 25, 9 * (256 + 311) // 32 * 32 + 32, device=dev)
+        w = torch.randn(256, x.shape[1], device=dev)
+        from sgg_amd import ops
+        for _ in range(2):
+            dense.product(x, w)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dense.product(x, w)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        flop = 2.0 * x.shape[0] * x.shape[1] * 256
+        res['roofline'] = {'kernel': 'D_edges first convolution as rows x weights^T: [%d x %d] . [256 x %d]^T (%s)' % (x.shape[0], x.shape[1], x.shape[1], mode),
+                           'bound': 'mfma', 'achieved': round(flop / (ms * 1e-3) / 1e12, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                           'frac': round(flop / (ms * 1e-3) / 1e12 / peak, 4), 'traffic': None, 'ms_per_launch': round(ms, 4), 'executed_flop': flop,
+                           'note': 'peak = the dense MFMA rate of the arithmetic the layer runs in (x3: a third of the f16 rate, three products per fp32-grade product)'}
+        del x, w
+    except Exception as e:
+        res['roofline'] = {'error': repr(e)[:300]}
+    if cpu:
+        res['cpu_baseline'] = gqa_gan_cpu_baseline()
+    return res
+
+
+def gqa_gan_cpu_baseline():
+    """the oracle on the host, bounded: the ResNet-50-FPN 'pool'-level forward of ONE 1333 x 1333 frame + the relation head's eval forward on
+    its 32 boxes / 992 edges (oracle/sgg_oracle.py forward_gtbox with the resnet50 state dict); the GAN half has no CPU restatement at this
+    size (its parity is pinned at the golden vectors' size, tests/golden/gan_model.npz), so this is the SGG half's rate only -- said so."""
+    import torch
+    import sgg_amd
+    from oracle import sgg_oracle as O
+    from sgg_amd.synthetic import GQASyntheticData, init_weights, relabel_batch, synthetic_batch
+    data = GQASyntheticData()
+    model = init_weights(sgg_amd.RelModelStanford(data, mode='sgcls', backbone='resnet50'))
+    sd = {k: v.detach().float() for k, v in model.state_dict().items()}
+    b = relabel_batch(synthetic_batch(B=1, S=1333, n_boxes=32, n_fg=6, seed=111), 1704, 311)
+    avail = os.cpu_count() or 1
+    cores = min(avail, 32)
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        t0 = time.time()
+        O.forward_gtbox(b[0], b[3].numpy(), b[4].numpy(), b[5].numpy(), sd, mode='sgcls', min_size=1333, max_size=1333)
+        dt = time.time() - t0
+    return {'value': round(1.0 / dt, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model_name(),
+            'host_threads_available': avail,
+            'sample': 'ONE eval forward of one synthetic 1333x1333 frame (32 boxes, 992 edges, GQA vocabulary) through the oracle (torch-CPU fp32) on '
+                      '%d threads: %.1f s; the SGG half of the iteration only (no backward, no GAN): an upper bound of the CPU rate' % (cores, dt)}
+
+
 def main():
     args = parse()
     if os.environ.get('SGG_BENCH_NOGC'):          # debugging only: no cyclic collection at all
@@ -632,6 +781,21 @@ def main():
             el = float(t.item())
         return el
 
+    if args.mode == 'gqa_gan':
+        del model
+        res = gqa_gan_measure(args, dev, tdtype, timed, B, args.steps, args.warmup, cpu=(world == 1 and not args.no_cpu_baseline))
+        if rank == 0:
+            line = {'metric': 'images/sec (whole node), GQA SGCls + GAN training iteration', 'value': round(world * res['value'], 3), 'unit': 'images/s',
+                    'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': res['ms_per_step'], 'higher_is_better': True,
+                    'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic'}
+            line.update({k: v for k, v in res.items() if k not in line})
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+            print(json.dumps(line), flush=True)
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.mode == 'sgdet':
         del model
         sgdet_bench(args, dev_batches, timed, world, rank, B, dev, tdtype)

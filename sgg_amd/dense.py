@@ -21,6 +21,38 @@ import torch.nn.functional as F
 from . import ops
 
 
+# Arithmetic of every contraction in this file (process-wide; set_compute):
+#   'x3'  (default) f16 split operands x = hi + lo, products hi.hi + hi.lo + lo.hi accumulated in fp32 on the 16-bit matrix cores (ops.gemm's
+#         split-operand lowering, csrc/util.hip sgg_split3): results within ~1e-6 relative of exact fp32 at a third of the f16 MFMA rate
+#         (833 TFLOP/s peak instead of v_mfma_f32_32x32x2_f32's 157) -- the golden vectors of tests/golden/gan_model.npz hold at their
+#         fp32 tolerances;
+#   'f32' exact-fp32 MFMA (rounds 1 - 5);
+#   'f16' operands rounded to f16 once, fp32 accumulate (the SGG head's default mode; for the GAN an accuracy trade the caller opts into).
+_COMPUTE = ['x3']
+
+
+def set_compute(mode):
+    assert mode in ('x3', 'f32', 'f16'), mode
+    prev = _COMPUTE[0]
+    _COMPUTE[0] = mode
+    return prev
+
+
+def compute_mode():
+    return _COMPUTE[0]
+
+
+def product(x, w, bias=None):
+    """x [M,Kp] f32 . w [N,Kp]^T (+ bias) -> [M,N] f32 in the file's arithmetic (Kp a multiple of 32, zero-padded)"""
+    mode = _COMPUTE[0]
+    if mode == 'f16':
+        x16, w16 = ops.cast(x, torch.float16), ops.cast(w, torch.float16)
+        if x16.shape[1] % 64:
+            x16, w16 = F.pad(x16, (0, 64 - x16.shape[1] % 64)), F.pad(w16, (0, 64 - w16.shape[1] % 64))
+        return ops.gemm(x16, w16, bias, out_dtype=torch.float32)
+    return ops.gemm(x, w, bias, out_dtype=torch.float32, x3=(mode == 'x3'))
+
+
 def _need_gpu(x):
     if not x.is_cuda:
         raise RuntimeError('sgg_amd.dense: the dense layers run on the HIP kernels only (got a %s tensor)' % x.device.type)
@@ -50,7 +82,7 @@ class _Affine(torch.autograd.Function):
         ctx.dims = (x.shape[1], w.shape[0], w.shape[1], b is not None)
         if xp.shape[0] == 0:
             return xp.new_zeros((0, w.shape[0]))
-        return ops.gemm(xp, wp, b.detach().float().contiguous() if b is not None else None, out_dtype=torch.float32)
+        return product(xp, wp, b.detach().float().contiguous() if b is not None else None)
 
     @staticmethod
     def backward(ctx, dy):
@@ -64,10 +96,10 @@ class _Affine(torch.autograd.Function):
         dy = dy.contiguous().float()
         if ctx.needs_input_grad[0]:
             wt = ops.transpose(wp, pad_to=32)                           # [Kp, N32]
-            dx = ops.gemm(_cols32(dy), wt, out_dtype=torch.float32)[:, :Kx]
+            dx = product(_cols32(dy), wt)[:, :Kx]
         if ctx.needs_input_grad[1]:
             # dW = dy^T x: both operands transposed once (zero-padded reduction rows), then the same GEMM
-            dw = ops.gemm(ops.transpose(dy), ops.transpose(xp), out_dtype=torch.float32)[:, :K]
+            dw = product(ops.transpose(dy), ops.transpose(xp))[:, :K]
         if has_b and ctx.needs_input_grad[2]:
             db = ops.colsum(dy)
         return dx, dw, db

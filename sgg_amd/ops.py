@@ -447,7 +447,7 @@ def _split3_operands(A, W, A2, W2):
 
 
 # ---------------------------------------------------------------- a-7
-def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None, post_shift=None, out=None, W2=None, splits=None):
+def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None, post_shift=None, out=None, W2=None, splits=None, x3=None):
     """act([A[M,K1] | A2[M,K2]] . [W | W2]^T + bias) * post_scale + post_shift -> [M,N].
     W is [N,K1+K2], or [N,K1] when the second K segment's weights are given separately as W2 [N,K2]."""
     M, K1 = A.shape
@@ -460,8 +460,9 @@ def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None
     out_dtype = out_dtype or A.dtype
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=A.device)
-    if _SPLIT3[0] and A.dtype == torch.float32:
-        # x3 mode: the same contraction on split f16 operands (3 K columns per segment), fp32 accumulate, `out` as asked
+    if (_SPLIT3[0] if x3 is None else x3) and A.dtype == torch.float32:
+        # x3 mode (or a caller that asks for it: x3=True; x3=False keeps an fp32 product exact inside the mode): the same contraction on split
+        # f16 operands (3 K columns per segment), fp32 accumulate, `out` as asked
         A3, W3, A23, W23 = _split3_operands(A, W, A2, W2)
         return gemm(A3, W3, bias, act, out_dtype, A23, post_scale, post_shift, out, W23, splits)
     # the kernels address an operand's rows as (uniform base + 32-bit lane offset): an A operand of 4 GiB or more (fc6 on > 85 k
