@@ -160,10 +160,15 @@ def check(code, what):
 # HIP events recorded on the stream the kernel is launched on; keys are (symbol, tag).
 profiler = None
 _tag = ['']
+_tag_prefix = ['']      # a coarse label in front of the tags the model sets itself (bench.py: 'gan:' around the GAN half of an iteration)
 
 
 def set_tag(tag):
     _tag[0] = tag
+
+
+def set_tag_prefix(prefix):
+    _tag_prefix[0] = prefix
 
 
 def call(name, *args):
@@ -175,4 +180,4 @@ def call(name, *args):
     e0.record()
     check(getattr(load(), name)(*args), name)
     e1.record()
-    profiler.setdefault((name, _tag[0]), []).append((e0, e1))
+    profiler.setdefault((name, _tag_prefix[0] + _tag[0]), []).append((e0, e1))

@@ -50,6 +50,17 @@ def product(x, w, bias=None):
         if x16.shape[1] % 64:
             x16, w16 = F.pad(x16, (0, 64 - x16.shape[1] % 64)), F.pad(w16, (0, 64 - w16.shape[1] % 64))
         return ops.gemm(x16, w16, bias, out_dtype=torch.float32)
+    if mode == 'x3':
+        # the split operands are 3 K f16 columns per row: a long reduction (a weight gradient: K = the rows of the layer's input) is cut into
+        # K ranges that stay under the kernels' 4 GiB operand span, partial products summed in fp32 (in range order: deterministic)
+        rows = max(x.shape[0], w.shape[0])
+        kmax = max(64, (ops.SPAN_LIMIT // (rows * 6)) // 64 * 64)
+        if x.shape[1] > kmax:
+            out = None
+            for k0 in range(0, x.shape[1], kmax):
+                part = ops.gemm(x[:, k0:k0 + kmax], w[:, k0:k0 + kmax], bias if k0 == 0 else None, out_dtype=torch.float32, x3=True)
+                out = part if out is None else out.add_(part)
+            return out
     return ops.gemm(x, w, bias, out_dtype=torch.float32, x3=(mode == 'x3'))
 
 

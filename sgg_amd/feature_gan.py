@@ -310,6 +310,27 @@ class GAN(nn.Module):
         hot = F.one_hot(labels.view(-1), n_classes).to(x.dtype)
         return torch.cat((x, hot[:, None, None, :].expand(n, P, P, n_classes)), dim=-1)
 
+    def _score_rois(self, net, feats, labels, n_classes):
+        """net(_roi_planes(feats, labels)) without forming the one-hot planes (augment/gan.py:222-231 concatenates n_classes constant planes
+        to every RoI feature: 1 704 of 1 960 input channels of D_nodes with GQA's vocabulary, 311 of 567 of D_edges).  The first layer is
+        a 3x3 convolution WITHOUT padding, so each of its outputs sees all nine taps of a plane that is constant over the patch: the class
+        channels contribute sum_taps W[:, n_ch + label, ky, kx] -- one row of a [n_classes, Cout] table, the same at every output position.
+        conv([x | onehot]) = conv(x; W[:, :n_ch]) + table[label]: the same sum in another order, 2.2x (edges) / 7.7x (nodes) fewer
+        multiply-adds and patch-matrix bytes; the gradient reaches W's class channels through the table (index_select's adjoint)."""
+        P = self.pool_sz
+        n = feats.shape[0]
+        x = feats.reshape(n, -1, P, P).permute(0, 2, 3, 1)
+        first = net[0]
+        assert first.padding == 0 and first.in_channels == x.shape[-1] + n_classes, (first.padding, first.in_channels, x.shape, n_classes)
+        w = first.effective_weight()
+        C = x.shape[-1]
+        y = dense.conv2d(x, w[:, :C], first.bias, padding=0)
+        table = w[:, C:].sum((2, 3)).t()                                 # [n_classes, Cout]
+        y = y + table.index_select(0, labels.view(-1))[:, None, None, :]
+        for m in list(net)[1:]:
+            y = m(y)
+        return y
+
     def loss(self, features_real=None, features_fake=None, is_nodes=False, updateD=False, labels_fake=None, labels_real=None,
              is_fmaps=False):
         """augment/gan.py:211-259 -> {'D_obj' | 'D_rel' | 'D_fmap' | 'G_obj' | 'G_rel' | 'G_fmap': loss} (or {} when the side is off).
@@ -326,15 +347,15 @@ class GAN(nn.Module):
         f32 = lambda t: None if t is None else t.to(torch.float32)        # noqa: E731
         fake, real = f32(features_fake), f32(features_real)
         if is_fmaps:
-            prep = lambda t, _labels: to_nhwc(t)                          # noqa: E731
+            score = lambda t, _labels: net(to_nhwc(t))                    # noqa: E731
         else:
             n_classes = len(self.obj_classes if is_nodes else self.rel_classes)
-            prep = lambda t, labels: self._roi_planes(t, labels, n_classes)   # noqa: E731
+            score = lambda t, labels: self._score_rois(net, t, labels, n_classes)   # noqa: E731
         if updateD:
-            total = self.loss_fn(net(prep(real, labels_fake if labels_real is None else labels_real).detach()), is_fake=False, updateD=True) + \
-                self.loss_fn(net(prep(fake, labels_fake).detach()), is_fake=True, updateD=True)
+            total = self.loss_fn(score(real.detach(), labels_fake if labels_real is None else labels_real), is_fake=False, updateD=True) + \
+                self.loss_fn(score(fake.detach(), labels_fake), is_fake=True, updateD=True)
         else:
-            total = self.loss_fn(net(prep(fake, labels_fake)), is_fake=True, updateD=False)
+            total = self.loss_fn(score(fake, labels_fake), is_fake=True, updateD=False)
         return {side + '_' + kind: total}
 
 

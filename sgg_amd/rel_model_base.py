@@ -123,6 +123,21 @@ class _RoIFeatures(torch.autograd.Function):
         return d_fm.permute(0, 3, 1, 2).to(in_dtype), None, None, None, None, None
 
 
+_PARITY_SAID = {}
+
+
+def _say_parity(clause):
+    """once per process and mode: the default is the fast 16-bit mode, and a caller following INTEGRATION.md should know
+    what it costs before comparing logits with the reference's"""
+    if clause['logits_within_1e-3'] or _PARITY_SAID.get(clause['mode']):
+        return
+    _PARITY_SAID[clause['mode']] = True
+    import logging
+    logging.getLogger('sgg_amd').warning(
+        'sgg_amd: compute mode %s -- %s.  For logits within 1e-3 of the fp32 reference: model.set_compute_dtype(torch.float32, split3=True) '
+        '(x3 mode) or model.set_compute_dtype(torch.float32) (exact).', clause['mode'], clause['note'])
+
+
 class RelModelBase(nn.Module):
     """RELATIONSHIPS (sgg_models/rel_model_base.py:22-123)."""
 
@@ -171,6 +186,7 @@ class RelModelBase(nn.Module):
             self.freq_bias = FrequencyBias(train_data)                                # rel_model_base.py:120-121
         # HIP-path settings (not in the reference): storage/compute type of activations and weights.
         self.compute_dtype = torch.float16       # see set_compute_dtype
+        _say_parity(self.parity_clause)
         self._prep = {}
         self._shadow, self._shadow_tags = {}, {}     # compute-dtype weight copies (rel_model_stanford._shadow_cast)
 
@@ -216,7 +232,24 @@ class RelModelBase(nn.Module):
         # exact mode's rate.  The switch is process-wide (ops.set_split3): one compute mode at a time.
         self.split3 = bool(split3)
         ops.set_split3(self.split3)
+        _say_parity(self.parity_clause)
         return self
+
+    @property
+    def parity_clause(self):
+        """Which of the north star's two parity clauses the CURRENT compute mode meets on the benchmark configuration (8 x 592x592, 32 boxes;
+        measured by tests/test_parity_full_gpu.py, records under profiles/r0x_parity_bench_config.json / r0x_recall_parity.json):
+        rel_dists / obj_dists within 1e-3 of the fp32 reference, and R@K within +-0.1 points."""
+        dt = self.compute_dtype
+        if dt == torch.float32:
+            mode = 'x3' if getattr(self, 'split3', False) else 'f32'
+            return {'mode': mode, 'logits_within_1e-3': True, 'recall_within_0.1': True,
+                    'note': 'fp32-grade: logits within 4e-4 (x3) / 8e-5 (exact fp32) of the reference'}
+        if dt == torch.float16:
+            return {'mode': 'f16', 'logits_within_1e-3': False, 'recall_within_0.1': True,
+                    'note': 'f16 operands: logits within ~0.05 (obj) / 0.01 (rel) of the fp32 reference -- the 1e-3 clause is NOT met; R@K within 0.05 points (met)'}
+        return {'mode': 'bf16', 'logits_within_1e-3': False, 'recall_within_0.1': False,
+                'note': 'bf16 operands: logits within ~0.44 (obj) / 0.10 (rel) of the fp32 reference and R@K up to 0.2 points off -- NEITHER parity clause is met'}
 
     def spatial_scale(self, im_sizes):
         """[3P] MultiScaleRoIAlign.infer_scale: 2^round(log2(fmap_size / image_size)); 1/16 at the configs."""

@@ -82,7 +82,7 @@ def mode_report(name):
            'rel_logit_absmax': float(np.abs(ref_rd).max()),
            'obj_argmax_agreement': float((od[:, 1:].argmax(1) == ref_od[:, 1:].argmax(1)).mean()),
            'rel_argmax_agreement': float((rd[:, 1:].argmax(1) == ref_rd[:, 1:].argmax(1)).mean())}
-    dump('r05_parity_bench_config.json', {'config': '8 x 592x592, 32 boxes, 992 edges per image, seed 111', 'oracle_seconds': s['oracle_seconds'],
+    dump('r06_parity_bench_config.json', {'config': '8 x 592x592, 32 boxes, 992 edges per image, seed 111', 'oracle_seconds': s['oracle_seconds'],
                                           name: rep}, merge=True)
     print(name, json.dumps(rep, indent=1))
     return rep

@@ -158,7 +158,7 @@ def test_gan_iteration_with_the_gqa_vocabulary():
     torch.manual_seed(11)
     gan = GAN(data.ind_to_classes, data.ind_to_predicates, n_ch=model.edge_dim, pool_sz=model.pool_sz, fmap_sz=model.fmap_sz, n_layers_G=2,
               device=DEV).to(DEV)
-    assert gan.D_nodes[0].weight.shape[1] == 256 + NOBJ and gan.D_edges[0].weight.shape[1] == 256 + NPRED
+    assert gan.D_nodes[0].weight_orig.shape[1] == 256 + NOBJ and gan.D_edges[0].weight_orig.shape[1] == 256 + NPRED
     assert tuple(gan.G_obj_embed.weight.shape) == (NOBJ, 200) and tuple(gan.G_rel_embed.weight.shape) == (NPRED, 200)
     batch = _batch(B=2, n_boxes=5, n_fg=4, seed=31)
     dev_batch = tuple(t_.to(DEV) if isinstance(t_, torch.Tensor) else t_ for t_ in batch)

@@ -140,7 +140,7 @@ def test_recall_of_hip_forward_equals_recall_of_oracle_forward():
                                              for m in ('sgcls', 'predcls') for k in KS)
     report = {'gt_triplets': n_trip, 'images': len(gts['sgcls']), 'train_steps': steps, 'final_loss': final_loss, 'recall_percent': table,
               'largest_abs_difference_to_oracle_points': worst, 'one_triplet_is_points': 100.0 / n_trip}
-    _dump('r05_recall_parity.json', report)
+    _dump('r06_recall_parity.json', report)
     print(json.dumps(report, indent=1))
     r50 = table['sgcls oracle_fp32 GC']['R@50']
     assert 5.0 < r50 < 95.0, 'recall at the floor / ceiling: the comparison would not discriminate'

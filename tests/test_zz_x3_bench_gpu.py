@@ -131,7 +131,7 @@ def test_x3_bench_config_head_gradients_match_exact_fp32():
     for n, ge in grads[False].items():
         scale = float(ge.abs().max())
         worst[n] = float((grads[True][n] - ge).abs().max()) / scale if scale > 0 else 0.0
-    dump('r05_x3_gradients_bench_config.json', {'relative_to_each_tensors_largest_gradient': worst})
+    dump('r06_x3_gradients_bench_config.json', {'relative_to_each_tensors_largest_gradient': worst})
     bound = lambda n: 3e-2 if n.startswith('union_boxes.conv.') else 5e-3
     bad = {n: v for n, v in worst.items() if v > bound(n)}
     assert not bad, bad
