@@ -1230,6 +1230,14 @@ def main():
             except Exception as e:          # a side measurement never takes the headline down; the line says what happened
                 line['sgdet_mode'] = {'error': repr(e)[:400]}
             torch.cuda.empty_cache()
+            # BASELINE configs[4] on one GPU: GQA vocabulary + ResNet-50-FPN + the GAN iteration (main.py:100-194), short run
+            try:
+                line['gqa_gan_mode'] = gqa_gan_measure(args, dev, tdtype, timed, B, 5, 2, cpu=not args.no_cpu_baseline)
+            except Exception as e:
+                line['gqa_gan_mode'] = {'error': repr(e)[:400]}
+            from sgg_amd import ops as _ops
+            _ops.split3_cache_clear()
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.cpu_images, 111)
         # which of the north star's parity clauses each reported throughput meets
