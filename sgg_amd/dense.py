@@ -22,13 +22,13 @@ from . import ops
 
 
 # Arithmetic of every contraction in this file (process-wide; set_compute):
-#   'x3'  (default) f16 split operands x = hi + lo, products hi.hi + hi.lo + lo.hi accumulated in fp32 on the 16-bit matrix cores (ops.gemm's
-#         split-operand lowering, csrc/util.hip sgg_split3): results within ~1e-6 relative of exact fp32 at a third of the f16 MFMA rate
-#         (833 TFLOP/s peak instead of v_mfma_f32_32x32x2_f32's 157) -- the golden vectors of tests/golden/gan_model.npz hold at their
-#         fp32 tolerances;
-#   'f32' exact-fp32 MFMA (rounds 1 - 5);
+#   'f32' (default) exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): any magnitude, the golden vectors' tolerances;
+#   'x3'  f16 split operands x = hi + lo, products hi.hi + hi.lo + lo.hi accumulated in fp32 on the 16-bit matrix cores (ops.gemm's
+#         split-operand lowering, csrc/util.hip sgg_split3): ~1e-6 relative of exact fp32 -- for operands INSIDE f16's range only (an
+#         unnormalised discriminator whose activations pass 65504 overflows the hi half: measured, tools/dbg_gan.py), and at the GAN's
+#         shapes the split passes cost what the faster products gain (bench.py --mode gqa_gan: 72 ms either way) -- opt-in;
 #   'f16' operands rounded to f16 once, fp32 accumulate (the SGG head's default mode; for the GAN an accuracy trade the caller opts into).
-_COMPUTE = ['x3']
+_COMPUTE = ['f32']
 
 
 def set_compute(mode):

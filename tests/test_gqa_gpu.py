@@ -172,11 +172,12 @@ def test_gan_iteration_with_the_gqa_vocabulary():
         w = gan.D_nodes[0].effective_weight()
         # (float64 on the host: the reference of this check must not be another GPU library's algorithm choice)
         want = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), gan.D_nodes[0].bias.double().cpu()).permute(0, 2, 3, 1)
-        torch.testing.assert_close(got.double().cpu(), want, atol=2e-4, rtol=1e-3)
-        # ... and the form the losses use (class planes as a table lookup, GAN._score_rois) against the same reference through the whole stack
+        scale = float(want.abs().max())
+        assert float((got.double().cpu() - want).abs().max()) <= 2e-5 * scale, (float((got.double().cpu() - want).abs().max()), scale)
+        # ... and the form the losses use (class planes as a table lookup, GAN._score_rois) against the plain stack on the one-hot planes
         full = gan.D_nodes(x)
         fast = gan._score_rois(gan.D_nodes, res.node_feat.float(), dev_batch[4][:, 1], NOBJ)
-        torch.testing.assert_close(fast, full, atol=2e-4, rtol=1e-3)
+        assert torch.isfinite(full).all() and float((fast - full).abs().max()) <= 2e-5 * float(full.abs().max()), (fast.flatten()[:4], full.flatten()[:4])
     gan.train()
     sgg_params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.SGD(sgg_params, lr=1e-3, momentum=0.9)
