@@ -14,7 +14,7 @@ S = 256
 NOBJ, NPRED = 1704, 311
 
 
-def _model(mode):
+def _model(mode, S=S):
     import sgg_amd
     from sgg_amd.resnet_fpn import FrozenBatchNorm2d
     from sgg_amd.synthetic import GQASyntheticData, init_weights
@@ -28,7 +28,7 @@ def _model(mode):
     return model
 
 
-def _batch(B=2, n_boxes=6, n_fg=4, seed=21):
+def _batch(B=2, n_boxes=6, n_fg=4, seed=21, S=S):
     from sgg_amd.synthetic import relabel_batch, synthetic_batch
     return relabel_batch(synthetic_batch(B=B, S=S, n_boxes=n_boxes, n_fg=n_fg, seed=seed), NOBJ, NPRED, seed=seed)
 
@@ -148,7 +148,9 @@ def test_gan_iteration_with_the_gqa_vocabulary():
     import torch.nn.functional as F
     from sgg_amd.feature_gan import GAN, gan_train_step
     from sgg_amd.synthetic import GQASyntheticData
-    model = _model('sgcls').to(DEV)
+    FS = 1333                     # the config's frame size: 21 x 21 'pool'-level maps, what the global discriminator's layer table is built for
+    model = _model('sgcls', S=None).to(DEV)
+    assert model.detector.transform.min_size == FS
     model.set_compute_dtype(torch.float32)
     model.dropout_p = 0.0
     for n, p in model.named_parameters():
@@ -160,10 +162,12 @@ def test_gan_iteration_with_the_gqa_vocabulary():
               device=DEV).to(DEV)
     assert gan.D_nodes[0].weight_orig.shape[1] == 256 + NOBJ and gan.D_edges[0].weight_orig.shape[1] == 256 + NPRED
     assert tuple(gan.G_obj_embed.weight.shape) == (NOBJ, 200) and tuple(gan.G_rel_embed.weight.shape) == (NPRED, 200)
-    batch = _batch(B=2, n_boxes=5, n_fg=4, seed=31)
+    batch = _batch(B=2, n_boxes=5, n_fg=4, seed=31, S=FS)
     dev_batch = tuple(t_.to(DEV) if isinstance(t_, torch.Tensor) else t_ for t_ in batch)
+    dev_batch = ([im.to(DEV) for im in batch[0]],) + dev_batch[1:]
     model.train()
     res = model([dev_batch])
+    assert tuple(res.fmap.shape[1:]) == (256, 21, 21)
     # D_nodes' first layer on RoI features with 1 704 one-hot planes against torch's convolution of the same (spectrally normalised) weight
     x = gan._roi_planes(res.node_feat.float(), dev_batch[4][:, 1], NOBJ)
     gan.eval()
