@@ -1218,6 +1218,19 @@ def main():
                                       'launch by launch (no hipGraph replay in this mode)' % (wt, wi, kt_, ki))
                              if split else 'same workload, exact-fp32 MFMA; 4 (train) / 2 (inference) warm-up + 5 timed steps'}
                 if split:
+                    # the same mode with an f16 BACKWARD (set_compute_dtype(float32, split3=True, backward_f16=True)): the forward -- what both parity
+                    # clauses are about -- unchanged (bit-equal logits), the backward's contractions one f16 product instead of three under the loss
+                    # scale: gradients at the f16 mode's accuracy (tests/test_x3_gpu.py).  Reported beside the strict form, never instead of it.
+                    model.set_compute_dtype(torch.float32, split3=True, backward_f16=True)
+                    t32.flush()
+                    el_tf = timed(lambda b: t32.step(b), wt, kt_)
+                    t32.flush()
+                    model.set_compute_dtype(torch.float32, split3=True)
+                    line[key]['train_f16_backward'] = {
+                        'images_per_s': round(B * kt_ / el_tf, 2), 'ms_per_step': round(1e3 * el_tf / kt_, 3), 'steps': kt_, 'warmup': wt,
+                        'note': 'x3 forward (logits within 1e-3: same bits as the strict x3 forward) + f16 backward contractions under the loss scale '
+                                '(gradients within 1e-2 of each tensor\'s largest entry, the f16 mode\'s accuracy): mixed-precision training with an '
+                                'fp32-grade forward'}
                     line[key]['vs_headline'] = {'train_x': round((el_t / kt_) / (elapsed / args.steps), 2) if args.mode == 'train' else None,
                                                 'note': 'x3 train step / the f16 headline step (three products per product bound it at <= 3x on the contraction share)'}
                 t32.opt.state.clear()

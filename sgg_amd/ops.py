@@ -379,16 +379,12 @@ def split3_on():
     return _SPLIT3[0]
 
 
-def split3(x, weights=False):
-    """x f32 [rows, K] (row-strided ok) -> f16 [rows, 3 * K_pad], K_pad = K rounded up to 64: [hi | hi | lo] (weights: [hi | lo | hi]).
-    (K_pad a multiple of 64 keeps 3 K_pad a multiple of the f16 kernels' 64-element K-tile for every K: ADVICE r4.)
-    weights=True: the result is cached until the tensor changes (same storage, shape, strides and autograd version) -- the weights are
+def _cached_operand(x, tag, make):
+    """make(x) for a WEIGHT operand, cached until the tensor changes (same storage, shape, strides and autograd version) -- weights are
     constants in evaluation, and in training they change once per step, not once per contraction."""
-    rows, K = x.shape
-    assert x.dtype == torch.float32 and x.stride(1) == 1
     key = None
-    if weights and _SPLIT3_CACHE_BYTES > 0:
-        key = (x.data_ptr(), rows, K, x.stride(0), x._version, str(x.device))
+    if _SPLIT3_CACHE_BYTES > 0:
+        key = (tag, x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), x._version, str(x.device))
         hit = _split3_cache.get(key)
         if hit is not None:
             _split3_cache.move_to_end(key)
@@ -397,9 +393,7 @@ def split3(x, weights=False):
                 torch.cuda.current_stream(x.device).wait_event(hit[3])
                 hit[1].record_stream(torch.cuda.current_stream(x.device))
             return hit[1]
-    Kp = (K + 63) // 64 * 64
-    out = torch.empty((rows, 3 * Kp), dtype=torch.float16, device=x.device)
-    _lib.call('sgg_split3', _p(x, torch.float32, rows_ok=True), x.stride(0), rows, K, Kp, _p(out), out.stride(0), 1 if weights else 0, _stream())
+    out = make(x)
     if key is not None and _split3_seen.get(key, 0) == 0:
         # first sighting of this tensor version: not kept yet -- in training the big weights change every step and are split once per
         # step, caching them would only push a gigabyte of dead splits through the allocator per step (x3 train 21 -> 31 ms when it did);
@@ -420,6 +414,49 @@ def split3(x, weights=False):
             _, old = _split3_cache.popitem(last=False)
             _split3_cache_size[0] -= old[1].numel() * 2
     return out
+
+
+def split3(x, weights=False):
+    """x f32 [rows, K] (row-strided ok) -> f16 [rows, 3 * K_pad], K_pad = K rounded up to 64: [hi | hi | lo] (weights: [hi | lo | hi]).
+    (K_pad a multiple of 64 keeps 3 K_pad a multiple of the f16 kernels' 64-element K-tile for every K: ADVICE r4.)
+    weights=True: the result is cached until the tensor changes (_cached_operand)."""
+    rows, K = x.shape
+    assert x.dtype == torch.float32 and x.stride(1) == 1
+
+    def make(x):
+        Kp = (K + 63) // 64 * 64
+        out = torch.empty((rows, 3 * Kp), dtype=torch.float16, device=x.device)
+        _lib.call('sgg_split3', _p(x, torch.float32, rows_ok=True), x.stride(0), rows, K, Kp, _p(out), out.stride(0), 1 if weights else 0, _stream())
+        return out
+    return _cached_operand(x, 'x3', make) if weights else make(x)
+
+
+# x3 mode with an f16 BACKWARD (RelModelBase.set_compute_dtype(torch.float32, split3=True, backward_f16=True)): the forward's contractions
+# run on split operands (fp32-grade logits: both parity clauses of the north star are about the forward), the backward's on operands
+# rounded to f16 ONCE -- one MFMA product instead of three, under the Trainer's loss scale, i.e. gradients at the accuracy of the f16
+# mode (whose 800-step training stays within 0.05 points of the fp32 reference's R@K, tests/test_parity_full_gpu.py).  What standard
+# mixed-precision training does, with an fp32-grade forward.  train.PredictFn.backward switches it on for its duration.
+_BWD16 = [False]
+
+
+def set_backward_f16(on):
+    prev = _BWD16[0]
+    _BWD16[0] = bool(on)
+    return prev
+
+
+def half_operand(x, weights=False):
+    """x f32 [rows, K] -> f16 [rows, K_pad] (K_pad = K rounded up to 64, zero columns), rounded once"""
+    rows, K = x.shape
+
+    def make(x):
+        Kp = (K + 63) // 64 * 64
+        if Kp == K:
+            return cast(x, torch.float16)
+        out = torch.zeros((rows, Kp), dtype=torch.float16, device=x.device)
+        out[:, :K].copy_(x)
+        return out
+    return _cached_operand(x, 'h16', make) if weights else make(x)
 
 
 import collections  # noqa: E402
@@ -463,6 +500,12 @@ def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None
     if (_SPLIT3[0] if x3 is None else x3) and A.dtype == torch.float32:
         # x3 mode (or a caller that asks for it: x3=True; x3=False keeps an fp32 product exact inside the mode): the same contraction on split
         # f16 operands (3 K columns per segment), fp32 accumulate, `out` as asked
+        if _BWD16[0] and x3 is None:
+            K1_ = A.shape[1]
+            Wa = W if (W2 is not None or A2 is None) else W[:, :K1_]
+            Wb = W2 if W2 is not None else (W[:, K1_:] if A2 is not None else None)
+            return gemm(half_operand(A), half_operand(Wa, weights=True), bias, act, out_dtype, half_operand(A2) if A2 is not None else None,
+                        post_scale, post_shift, out, half_operand(Wb, weights=True) if Wb is not None else None, splits)
         A3, W3, A23, W23 = _split3_operands(A, W, A2, W2)
         return gemm(A3, W3, bias, act, out_dtype, A23, post_scale, post_shift, out, W23, splits)
     # the kernels address an operand's rows as (uniform base + 32-bit lane offset): an A operand of 4 GiB or more (fc6 on > 85 k
@@ -509,7 +552,7 @@ def gemm_addrows(A, W, bias, add_rows, add_idx=None, act=ACT_NONE, out_dtype=Non
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=A.device)
     if _SPLIT3[0] and A.dtype == torch.float32:
-        A, W = split3(A), split3(W, weights=True)
+        A, W = (half_operand(A), half_operand(W, weights=True)) if _BWD16[0] else (split3(A), split3(W, weights=True))
         K = A.shape[1]
     _lib.call('sgg_gemm_addrows', _p(A, rows_ok=True), A.stride(0), _p(W, rows_ok=True), W.stride(0),
               _p(bias, torch.float32) if bias is not None else None, _p(add_rows, torch.float32, rows_ok=True), add_rows.stride(0),

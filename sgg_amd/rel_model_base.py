@@ -216,7 +216,7 @@ class RelModelBase(nn.Module):
     def forward(self, batch):
         raise NotImplementedError('forward')
 
-    def set_compute_dtype(self, dtype, split3=False):
+    def set_compute_dtype(self, dtype, split3=False, backward_f16=False):
         """torch.float32 = exact-fp32 MFMA mode (the reference's own precision: the 1e-3 parity bar); torch.float16 / torch.bfloat16 =
         16-bit storage and MFMA operands with fp32 accumulation -- the same kernels at the same rates.  float16 (11-bit significand) is the
         throughput mode whose logits stay within 0.1 / 0.03 of the reference's (DESIGN.md "f16"); bfloat16 (8 bits, wider exponent) is kept
@@ -231,6 +231,12 @@ class RelModelBase(nn.Module):
         # f16 split operands (hi + lo, three products, fp32 accumulate): fp32-grade logits (within the 1e-3 clause) at several times the
         # exact mode's rate.  The switch is process-wide (ops.set_split3): one compute mode at a time.
         self.split3 = bool(split3)
+        # x3 with backward_f16=True: the training BACKWARD's contractions on operands rounded to f16 once (one MFMA product instead of three,
+        # under the Trainer's loss scale): the forward -- what both parity clauses are about -- stays fp32-grade, the gradients have the f16
+        # mode's accuracy (ops.set_backward_f16).  Mixed-precision training with an fp32-grade forward.
+        if backward_f16 and not split3:
+            raise ValueError('backward_f16 is an option of the x3 mode: set_compute_dtype(torch.float32, split3=True, backward_f16=True)')
+        self.backward_f16 = bool(backward_f16)
         ops.set_split3(self.split3)
         _say_parity(self.parity_clause)
         return self

@@ -319,6 +319,15 @@ class PredictFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_obj, d_rel):
+        # x3 mode with an f16 backward (ops.set_backward_f16): the contractions below round their operands to f16 once instead of splitting them
+        prev = ops.set_backward_f16(bool(getattr(ctx.model, 'backward_f16', False)) and ops.split3_on())
+        try:
+            return PredictFn._backward(ctx, d_obj, d_rel)
+        finally:
+            ops.set_backward_f16(prev)
+
+    @staticmethod
+    def _backward(ctx, d_obj, d_rel):
         model, sv = ctx.model, ctx.sv
         w = train_weights(model)
         t, imp, dt = w['train'], w['imp'], model.compute_dtype

@@ -143,6 +143,60 @@ def test_x3_model_forward_gradients_and_trainer(ops):
     assert not ops.split3_on()
 
 
+def test_x3_with_f16_backward_keeps_the_forward_and_gives_f16_grade_gradients(ops):
+    """set_compute_dtype(float32, split3=True, backward_f16=True): the train-mode forward is the x3 forward bit for bit (logits inside the
+    1e-3 clause), the backward's contractions round their operands to f16 once under the loss scale -- every head gradient within 1 % of
+    its tensor's largest entry of the exact-fp32 mode's (the strict x3 backward: 2e-4), a Trainer run converges, nothing leaks out of
+    the backward (the switch is off again afterwards)"""
+    import sgg_amd
+    from sgg_amd.synthetic import SyntheticData, init_weights, synthetic_batch
+    from sgg_amd.trainer import Trainer
+    model = init_weights(sgg_amd.RelModelStanford(SyntheticData(), mode='sgcls', min_size=S, max_size=S))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV).train()
+    model.dropout_p = 0.0
+    batch = synthetic_batch(B=3, S=S, n_boxes=7, n_fg=3, seed=5, ragged=True)
+    out, grads = {}, {}
+    scale = 1024.0                                   # what the Trainer's loss scale does for the f16 operands of the backward
+    for name, kw in (('exact', dict()), ('x3', dict(split3=True)), ('x3f', dict(split3=True, backward_f16=True))):
+        model.load_state_dict(sd)
+        model.set_compute_dtype(torch.float32, **kw)
+        res = model([tuple(batch)])
+        g = torch.Generator().manual_seed(0)
+        Wo = torch.randn(res.rm_obj_dists.shape, generator=g).to(DEV)
+        Wr = torch.randn(res.rel_dists.shape, generator=g).to(DEV)
+        model.zero_grad()
+        model._loss_scaled = True
+        try:
+            (((res.rm_obj_dists * Wo).sum() + (res.rel_dists * Wr).sum()) * scale).backward()
+        finally:
+            model._loss_scaled = False
+        assert not ops._BWD16[0]
+        out[name] = (res.rm_obj_dists.detach().clone(), res.rel_dists.detach().clone())
+        grads[name] = {n: p.grad.detach().clone() / scale for n, p in model.named_parameters() if p.grad is not None}
+    assert torch.equal(out['x3'][0], out['x3f'][0]) and torch.equal(out['x3'][1], out['x3f'][1])
+    worst = {}
+    for n, ge in grads['exact'].items():
+        m = float(ge.abs().max()) + 1e-12
+        worst[n] = (float((grads['x3'][n] - ge).abs().max()) / m, float((grads['x3f'][n] - ge).abs().max()) / m)
+    assert max(v[0] for v in worst.values()) <= 2e-4, sorted(worst.items(), key=lambda kv: -kv[1][0])[:3]
+    assert max(v[1] for v in worst.values()) <= 1e-2, sorted(worst.items(), key=lambda kv: -kv[1][1])[:3]
+    assert max(v[1] for v in worst.values()) > 1e-5            # (it really is another arithmetic)
+    model.load_state_dict(sd)
+    model.set_compute_dtype(torch.float32, split3=True, backward_f16=True)
+    tr = Trainer(model, lr=2e-2)
+    losses = [float(tr.step(tuple(batch))) for _ in range(8)]
+    tr.flush()
+    assert losses[-1] < 0.9 * losses[0], losses
+    assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
+    with pytest.raises(ValueError):
+        model.set_compute_dtype(torch.float16, backward_f16=True)
+    model.set_compute_dtype(torch.float16)
+    model.eval()
+    model.dropout_p = 0.5
+    assert not ops.split3_on() and not model.backward_f16
+
+
 def test_split3_weight_cache_follows_the_tensors_version(ops):
     """weights=True: a tensor version that comes back is split once more and then served from the cache (same object); an in-place change
     (what the optimiser's version bump announces) gets a new split; leaving the mode empties the cache"""
