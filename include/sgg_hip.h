@@ -22,9 +22,15 @@
 extern "C" {
 #endif
 
-#define SGG_ABI_VERSION 13   /* bump whenever a prototype below changes: tests/abi.lock pins (version, digest of the prototypes) */
+#define SGG_ABI_VERSION 14   /* bump whenever a prototype below changes: tests/abi.lock pins (version, digest of the prototypes) */
 
-enum { SGG_F32 = 0, SGG_BF16 = 1, SGG_F16 = 2 };
+enum { SGG_F32 = 0, SGG_BF16 = 1, SGG_F16 = 2,
+       /* a PAIR of f16 planes x = hi + lo (hi = f16(x), lo = f16(x - hi): 22 significand bits) -- the operand / activation format of the x3
+        * mode (fp32-grade products on the 16-bit matrix cores: hi.hi + hi.lo + lo.hi accumulated in fp32, the MFMA loop walks the three
+        * plane combinations itself).  A row of K values is [hi (K_pad) | lo (K_pad)], K_pad = K rounded up to 64; an NHWC pixel of C
+        * channels is [hi (C) | lo (C)].  Accepted ONLY where an entry point says so (sgg_gemm / sgg_gemm_splitk / sgg_gemm_addrows /
+        * sgg_conv3x3_relu as operand and output type, sgg_maxpool2x2, sgg_split2, sgg_conv1_1 as output type). */
+       SGG_PAIR16 = 3 };
 enum { SGG_ACT_NONE = 0, SGG_ACT_RELU = 1 };
 enum {
     SGG_OK = 0,
@@ -399,6 +405,12 @@ int sgg_sgd_multi(float* const* p, const void* const* g, float* const* momentum_
                   const int64_t* n, const float* lr, int count, float weight_decay, float momentum, int first_step,
                   const float* norm_sq, float max_norm, float grad_scale, int g_dtype, int shadow_dtype,
                   int max_blocks /* 0: default 512 */, int* skipped, void* stream);
+
+/* x f32 [rows, K] (row stride ldx) -> the PAIR form (SGG_PAIR16): out f16 [rows, 2 * K_pad] = [hi (K_pad) | lo (K_pad)], hi = f16(x),
+ * lo = f16(x - hi), columns K .. K_pad - 1 zero.  K_pad % 8 == 0 (the GEMMs want % 64), ldo >= 2 K_pad.  The operand format of the x3 mode
+ * since round 6 (sgg_split3's [hi | hi | lo] rows are kept for the two-segment contractions).  Replaces: nothing in the reference (fp32
+ * cuBLAS products, sgg_models/rel_model_stanford.py:97-107); it is how this library gets fp32-grade products out of the 16-bit matrix cores. */
+int sgg_split2(const float* x, int64_t ldx, int64_t rows, int K, int K_pad, void* out, int64_t ldo, void* stream);
 
 /* The x3 mode's operand form (a fast mode inside the 1e-3 parity clause): x f32 [rows, K] (row stride ldx) -> out f16
  * [rows, 3 K_pad] (row stride ldo), x = hi + lo with hi = f16(x), lo = f16(x - hi).  mode 0 (activations): [hi | hi | lo]; mode 1

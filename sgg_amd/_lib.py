@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('SGG_HIP_LIB') or os.path.join(_HERE, 'libsgg_hip.so')
 
 SGG_F32, SGG_BF16, SGG_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU = 0, 1
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 import threading  # noqa: E402
 # held by sgg_amd.graph_step while it captures a hipGraph, and by every other thread of this package around its own GPU calls (the
@@ -33,6 +33,7 @@ SIGNATURES = {
     'sgg_conv1_pack_weights': [_P, _P, _I, _P],
     'sgg_conv3x3_relu': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'sgg_split3': [_P, _L, _L, _I, _I, _P, _L, _I, _P],
+    'sgg_split2': [_P, _L, _L, _I, _I, _P, _L, _P],
     'sgg_maxpool2x2': [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     'sgg_pair_index_eval': [_P, _P, _I, _I, _P, _I, _P, _P, _P],
     'sgg_pair_index_train': [_P, _I, _P, _I, _P, _P, _I, _P, _P, _P],

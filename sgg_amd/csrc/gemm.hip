@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
             const int hw = g.H * g.W;
             const int b = m / hw, rem = m - b * hw;
             const int y = rem / g.W, x = rem - y * g.W;
-            arp[j] = (unsigned)(((long)(b * (g.H + 2) + y) * (g.W + 2) + x) * g.Cin * ESZ + chunk * 16);
+            arp[j] = (unsigned)(((long)(b * (g.H + 2) + y) * (g.W + 2) + x) * (g.cin_px ? g.cin_px : g.Cin) * ESZ + chunk * 16);
             arp2[j] = 0;
         } else {
             arp[j] = (unsigned)((long)m * g.lda_b + chunk * 16);
@@ -87,21 +87,37 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
     auto stage = [&](int kt, int buf) {
         char* sa = smem + buf * STAGE;
         char* sb = sa + A_BYTES;
-        long koff;
-        bool seg2 = false;
-        if constexpr (CONV) {
-            const int tap = kt / tpc, c0 = kt - tap * tpc;
-            const int ky = tap / 3, kx = tap - ky * 3;
-            koff = ((long)(ky * (g.W + 2) + kx) * g.Cin) * ESZ + c0 * ROWB;
+        long koff, woff;
+        bool seg2 = false, wseg2 = false;
+        if (g.x3t) {
+            // pair operands [hi | lo]: segment 0 = (A hi, W hi), 1 = (A hi, W lo), 2 = (A lo, W hi); in conv mode per tap
+            if constexpr (CONV) {
+                const int tap = kt / (3 * tpc), r = kt - tap * 3 * tpc;
+                const int seg = r / tpc, c0 = r - seg * tpc;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                koff = ((long)(ky * (g.W + 2) + kx) * g.cin_px + (seg == 2 ? g.Cin : 0)) * ESZ + c0 * ROWB;
+                woff = ((long)tap * g.cin_px + (seg == 1 ? g.Cin : 0)) * ESZ + c0 * ROWB;
+            } else {
+                const int seg = (kt >= g.x3t) + (kt >= 2 * g.x3t), kk = kt - seg * g.x3t;
+                koff = (long)((seg == 2 ? g.x3t : 0) + kk) * ROWB;
+                woff = (long)((seg == 1 ? g.x3t : 0) + kk) * ROWB;
+            }
         } else {
-            seg2 = kt >= g.nt1;
-            koff = (long)(seg2 ? kt - g.nt1 : kt) * ROWB;
+            if constexpr (CONV) {
+                const int tap = kt / tpc, c0 = kt - tap * tpc;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                koff = ((long)(ky * (g.W + 2) + kx) * g.Cin) * ESZ + c0 * ROWB;
+            } else {
+                seg2 = kt >= g.nt1;
+                koff = (long)(seg2 ? kt - g.nt1 : kt) * ROWB;
+            }
+            wseg2 = !CONV && g.W2 && kt >= g.nt1;
+            woff = (long)(wseg2 ? kt - g.nt1 : kt) * ROWB;
         }
         const char* ua = uniform_ptr((seg2 ? g.A2 : g.A) + koff);
 #pragma unroll
         for (int j = 0; j < LA; ++j) glds16_su(ua, seg2 ? arp2[j] : arp[j], sa + (wave * LA + j) * 8 * ROWB);
-        const bool wseg2 = !CONV && g.W2 && kt >= g.nt1;
-        const char* ub = uniform_ptr((wseg2 ? g.W2 : g.Wt) + (long)(wseg2 ? kt - g.nt1 : kt) * ROWB);
+        const char* ub = uniform_ptr((wseg2 ? g.W2 : g.Wt) + woff);
 #pragma unroll
         for (int j = 0; j < LB; ++j) glds16_su(ub, wseg2 ? brp2[j] : brp[j], sb + (wave * LB + j) * 8 * ROWB);
     };
@@ -418,6 +434,7 @@ int dispatch(GemmArgs g, int dt, hipStream_t s) {
                 g.M = tail.m_base;
                 g.nt *= 2;
                 g.nt1 *= 2;
+                g.x3t *= 2;
                 const int rc = sgg_launch_pingpong(g, dt, CONV, s);
                 if (rc != SGG_OK) return rc;
                 return dt == SGG_BF16 ? launch<SGG_BF16, 2, 2, CONV>(tail, s) : launch<SGG_F16, 2, 2, CONV>(tail, s);
@@ -425,6 +442,7 @@ int dispatch(GemmArgs g, int dt, hipStream_t s) {
         }
         g.nt *= 2;   // 64-byte K-tiles
         g.nt1 *= 2;
+        g.x3t *= 2;
         return sgg_launch_pingpong(g, dt, CONV, s);
     }
     const bool narrow = g.N < 128;
@@ -439,17 +457,23 @@ static int gemm_impl(const void* A, int lda, const void* A2, int lda2, int K1, c
                      int ldw2, const float* bias, const float* post_scale, const float* post_shift, void* C, int ldc, int M,
                      int N, int K, int act, int in_dtype, int out_dtype, const float* add_rows, int ld_add, const int* add_idx, void* stream,
                      const float* gadd = nullptr, int ld_gadd = 0, int ggroup = 1, int gcol0 = 0) {
-    if (!sgg_is_dtype(in_dtype) || !sgg_is_dtype(out_dtype)) return SGG_ERR_DTYPE;
+    // SGG_PAIR16 operands: A [M, >= 2 K] and W [N, >= 2 K] hold f16 planes [hi (K) | lo (K)], K per plane (a multiple of 64); the kernels
+    // walk hi.hi + hi.lo + lo.hi.  SGG_PAIR16 output: C row = [hi (ldc / 2) | lo (ldc / 2)].
+    const bool pair_in = in_dtype == SGG_PAIR16, pair_out = out_dtype == SGG_PAIR16;
+    if (pair_in) in_dtype = SGG_F16;
+    if (!sgg_is_dtype(in_dtype) || !(pair_out || sgg_is_dtype(out_dtype))) return SGG_ERR_DTYPE;
     if (M == 0 || N == 0) return SGG_OK;
     const int esz = sgg_elem_size(in_dtype);
     const int bke = ROWB / esz;
     if (!A || !W || !C || M < 0 || N < 0 || K <= 0 || K % bke) return SGG_ERR_ARG;
+    if (pair_in && (A2 || W2 || lda < 2 * K || ldw < 2 * K)) return SGG_ERR_ARG;
+    if (pair_out && ((ldc & 15) || ldc / 2 < N || gadd)) return SGG_ERR_ARG;
     if (!A2) K1 = K;
     if (K1 <= 0 || K1 > K || K1 % bke) return SGG_ERR_ARG;
     if ((lda & 7) || (ldw & 7) || (A2 && (lda2 & 7)) || (W2 && (ldw2 & 7))) return SGG_ERR_ARG;
     if (W2 && (!A2 || (((uintptr_t)W2) & 15) || ldw2 < K - K1 || ldw < K1)) return SGG_ERR_ARG;
     if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)(A2 ? A2 : A)) & 15) return SGG_ERR_ARG;
-    if (lda < K1 || (!W2 && ldw < K) || ldc < N || (A2 && lda2 < K - K1)) return SGG_ERR_ARG;
+    if (lda < K1 || (!W2 && ldw < K) || (!pair_out && ldc < N) || (A2 && lda2 < K - K1)) return SGG_ERR_ARG;
     // the kernels address operand rows as (uniform base + 32-bit lane offset): every operand must span < 4 GiB
     const long lim = 0xffff0000L;
     if ((long)M * lda * esz > lim || (long)N * ldw * esz > lim || (A2 && (long)M * lda2 * esz > lim) || (W2 && (long)N * ldw2 * esz > lim))
@@ -458,8 +482,12 @@ static int gemm_impl(const void* A, int lda, const void* A2, int lda2, int K1, c
     g.A = (const char*)A; g.A2 = (const char*)A2; g.Wt = (const char*)W; g.W2 = (const char*)W2;
     g.lda_b = (long)lda * esz; g.lda2_b = (long)lda2 * esz; g.ldw_b = (long)ldw * esz; g.ldw2_b = (long)ldw2 * esz;
     g.nt1 = K1 / bke; g.nt = K / bke;
+    if (pair_in) {
+        g.x3t = K / bke; g.nt = 3 * g.x3t; g.nt1 = g.nt;
+    }
     g.bias = bias; g.pscale = post_scale; g.pshift = post_shift;
     g.C = (char*)C; g.ldc = ldc; g.M = M; g.N = N; g.act = act; g.out_dt = out_dtype;
+    g.pair_off = pair_out ? ldc / 2 : 0;
     g.add_rows = add_rows; g.add_idx = add_idx; g.ld_add = ld_add;
     g.gadd = gadd; g.ld_gadd = ld_gadd; g.ggroup = ggroup; g.gcol0 = gcol0;
     return dispatch<false>(g, in_dtype, (hipStream_t)stream);
@@ -525,18 +553,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 extern "C" int sgg_gemm_splitk(const void* A, int lda, const void* W, int ldw, const float* bias, const float* post_scale,
                                const float* post_shift, void* C, int ldc, int M, int N, int K, int act, int in_dtype, int out_dtype,
                                int splits, float* workspace, void* stream) {
+    const bool pair_in = in_dtype == SGG_PAIR16;       // pair operands [hi (K) | lo (K)], K per plane: the K range that is split is 3 K long
+    if (pair_in) in_dtype = SGG_F16;
     if (!sgg_is_dtype(in_dtype) || !sgg_is_dtype(out_dtype)) return SGG_ERR_DTYPE;
     if (M == 0 || N == 0) return SGG_OK;
     const int esz = sgg_elem_size(in_dtype);
     const int bke = ROWB / esz;
     if (!A || !W || !C || !workspace || M < 0 || N <= 0 || (N & 7) || K <= 0 || K % bke || splits < 1 || splits > K / bke) return SGG_ERR_ARG;
-    if ((lda & 7) || (ldw & 7) || lda < K || ldw < K || (((uintptr_t)A | (uintptr_t)W) & 15)) return SGG_ERR_ARG;
+    if ((lda & 7) || (ldw & 7) || lda < (pair_in ? 2 : 1) * K || ldw < (pair_in ? 2 : 1) * K || (((uintptr_t)A | (uintptr_t)W) & 15)) return SGG_ERR_ARG;
     if (ldc < N || (ldc & 7) || ((uintptr_t)C & 15)) return SGG_ERR_ARG;
     if ((long)M * lda * esz > 0xffff0000L || (long)N * ldw * esz > 0xffff0000L) return SGG_ERR_SPAN;   // 32-bit lane offsets
     GemmArgs g{};
     g.A = (const char*)A; g.Wt = (const char*)W;
     g.lda_b = (long)lda * esz; g.ldw_b = (long)ldw * esz;
     g.nt = K / bke; g.nt1 = g.nt;
+    if (pair_in) {
+        g.x3t = g.nt; g.nt = 3 * g.x3t; g.nt1 = g.nt;
+    }
     g.C = (char*)workspace; g.ldc = N; g.M = M; g.N = N; g.act = SGG_ACT_NONE; g.out_dt = SGG_F32;
     g.splitk_stride = (long)M * N * 4;
     hipStream_t s = (hipStream_t)stream;
@@ -549,6 +582,7 @@ extern "C" int sgg_gemm_splitk(const void* A, int lda, const void* W, int ldw, c
         g.nt * 2 / splits >= 8) {
         g.nt *= 2;          // 64-byte K-tiles
         g.nt1 = g.nt;
+        g.x3t *= 2;
         rc = sgg_launch_pingpong_splitk(g, in_dtype, splits, s);
     } else {
         rc = in_dtype == SGG_BF16 ? launch<SGG_BF16, 2, 2, false>(g, s, splits)
@@ -695,15 +729,19 @@ extern "C" int sgg_conv1_block(const float* in_nhwc4, const void* w1, const floa
 
 extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H,
                                 int W, int Cin, int Cout, int pool, int dtype, int out_dtype, void* stream) {
-    if (!sgg_is_dtype(dtype) || !sgg_is_dtype(out_dtype)) return SGG_ERR_DTYPE;
-    if (out_dtype != dtype && pool) return SGG_ERR_ARG;       // another output type: the implicit-GEMM kernels only (no fused pool)
+    // SGG_PAIR16 input: `in` is a pair plane [B, H+2, W+2, 2 Cin] (pixel = [hi (Cin) | lo (Cin)]), `w` [Cout][9][2 Cin] likewise; the
+    // implicit-GEMM kernels walk hi.hi + hi.lo + lo.hi per tap (x3 mode).  SGG_PAIR16 output: [B, H+2p, W+2p, 2 Cout].
+    const bool pair_in = dtype == SGG_PAIR16, pair_out = out_dtype == SGG_PAIR16;
+    if (pair_in) dtype = SGG_F16;
+    if (!sgg_is_dtype(dtype) || !(pair_out || sgg_is_dtype(out_dtype))) return SGG_ERR_DTYPE;
+    if ((pair_in || out_dtype != dtype) && pool) return SGG_ERR_ARG;       // another output type: the implicit-GEMM kernels only (no fused pool)
     const int esz = sgg_elem_size(dtype);
     const int bke = ROWB / esz;
     if (!in || !w || !out || B <= 0 || H <= 0 || W <= 0 || Cin % bke || Cout % 64 || (out_pad != 0 && out_pad != 1))
         return SGG_ERR_ARG;
     if ((long)B * H * W > 0x7fffffffL) return SGG_ERR_ARG;
-    if ((long)B * (H + 2) * (W + 2) * Cin * esz > 0xffff0000L || 9L * Cin * Cout * esz > 0xffff0000L) return SGG_ERR_SPAN;   // 32-bit lane offsets
-    {
+    if ((long)B * (H + 2) * (W + 2) * Cin * esz * (pair_in ? 2 : 1) > 0xffff0000L || 9L * Cin * Cout * esz * (pair_in ? 2 : 1) > 0xffff0000L) return SGG_ERR_SPAN;   // 32-bit lane offsets
+    if (!pair_in) {
         // wide-spatial layers: LDS-resident input patch kernel (conv_spatial.hip); small maps: implicit GEMM.
         // SGG_CONV_FORCE=gemm|spatial|old overrides (experiments only).
         static const char* force = getenv("SGG_CONV_FORCE");
@@ -730,10 +768,16 @@ extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias
     }
     GemmArgs g{};
     g.A = (const char*)in; g.Wt = (const char*)w;
-    g.ldw_b = (long)9 * Cin * esz;
+    g.ldw_b = (long)9 * Cin * esz * (pair_in ? 2 : 1);
     g.nt = 9 * Cin / bke; g.nt1 = g.nt;
+    if (pair_in) {
+        g.x3t = Cin / bke; g.nt *= 3; g.nt1 = g.nt; g.cin_px = 2 * Cin;
+    }
     g.bias = bias; g.C = (char*)out; g.M = B * H * W; g.N = Cout; g.act = SGG_ACT_RELU;
     g.out_dt = out_dtype;
+    if (pair_out) {
+        g.cout_px = 2 * Cout; g.pair_off = Cout;
+    }
     g.H = H; g.W = W; g.Cin = Cin; g.out_pad = out_pad;
     return dispatch<true>(g, dtype, (hipStream_t)stream);
 }

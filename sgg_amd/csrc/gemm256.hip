@@ -45,6 +45,20 @@ __device__ __forceinline__ long tile_koff(const GemmArgs& g, bool loads_a, int k
 #ifdef SGG_GEMM_ABL_HOT   // experiment: every K-tile re-reads tile 0 (operands stay in L2): what the memory side costs
     kt = 0;
 #endif
+    if (g.x3t) {    // pair operands [hi | lo]: segment 0 = (A hi, W hi), 1 = (A hi, W lo), 2 = (A lo, W hi); in conv mode per tap
+        if constexpr (CONV) {
+            const int tap = kt / (3 * tpc), r = kt - tap * 3 * tpc;
+            const int seg = r / tpc, c0 = r - seg * tpc;
+            if (loads_a) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                return ((long)(ky * (g.W + 2) + kx) * g.cin_px + (seg == 2 ? g.Cin : 0)) * esz + c0 * ROW;
+            }
+            return ((long)tap * g.cin_px + (seg == 1 ? g.Cin : 0)) * esz + c0 * ROW;
+        } else {
+            const int seg = (kt >= g.x3t) + (kt >= 2 * g.x3t), kk = kt - seg * g.x3t;
+            return (long)((seg == (loads_a ? 2 : 1) ? g.x3t : 0) + kk) * ROW;
+        }
+    }
     if (loads_a) {
         if constexpr (CONV) {
             const int tap = kt / tpc, c0 = kt - tap * tpc;
@@ -349,7 +363,7 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
     // block in the instruction's scalar offset; no bounds tests; ~600 instructions.
     {
         const int esz_out = g.out_dt == SGG_F32 ? 4 : 2;
-        const bool fast = !CONV && !g.add_rows && !g.pscale && !g.pshift && (g.ldc & 7) == 0 && m0 + 256 <= g.M && n0 + 256 <= g.N &&
+        const bool fast = !CONV && g.out_dt != SGG_PAIR16 && !g.add_rows && !g.pscale && !g.pshift && (g.ldc & 7) == 0 && m0 + 256 <= g.M && n0 + 256 <= g.N &&
                           (!g.gadd || g.ggroup >= 8) && (long)g.M * g.ldc * esz_out < 0xffff0000L && (reinterpret_cast<uintptr_t>(g_.C) & 15) == 0;
         if (fast) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g_.C, 0, (int)min((long)g.M * g.ldc * esz_out, 0xffffffffL), 0x00020000);

@@ -658,6 +658,7 @@ int sgg_launch_pingpong_sk(const GemmArgs& g_in, int dt, bool conv, hipStream_t 
     int dp = 0, sk = 0;
     // the stream-K form's epilogue carries bias, activation and a group addend whose groups span >= 40 columns (256 columns touch <= 8)
     const bool epilogue_ok = !g.pscale && !g.pshift && !g.add_rows && (!g.gadd || g.ggroup >= 40);
+    if (g.x3t || g.out_dt == SGG_PAIR16) return 1;       // pair operands / outputs (x3 mode): the plain ping-pong kernel walks the plane segments
     if (g.m_base != 0 || !epilogue_ok || !sgg_pingpong_streamk(tiles, g.nt, (void*)s, &dp, &sk)) return 1;
     SkWorkspace w;
     if (!sk_next_epoch((void*)s, w)) return 1;

@@ -35,6 +35,14 @@ struct GemmArgs {
     unsigned* sk_flags;         // one word per slot: the epoch of the launch that published it
     unsigned sk_epoch;
     int sk_dp_rounds, sk_tiles;
+    // x3 mode on PAIR operands (SGG_PAIR16: a row / pixel is [hi | lo], two f16 planes): x3t = K-tiles per plane (0 = off).  The K loop then
+    // runs over 3 x3t tiles -- segment 0 (A hi, W hi), 1 (A hi, W lo), 2 (A lo, W hi) -- per tap in conv mode.  Conv mode: Cin = channels
+    // per PLANE, cin_px = channels per input pixel (2 Cin for a pair plane; 0 = Cin), the weights' taps are [hi (Cin) | lo (Cin)] as well.
+    int x3t, cin_px;
+    // output: out_dt == SGG_PAIR16 writes hi at the element offset and lo pair_off elements further; conv mode: cout_px = elements per
+    // output pixel (2 N for a pair plane; 0 = N)
+    long pair_off;
+    int cout_px;
 };
 
 __device__ __forceinline__ void glds16(const char* g, char* l) {
@@ -145,6 +153,25 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& g, const ChanVec
         if (c.has_pt) t = t + c.pt[k];
         v[k] = t;
     }
+    if (g.out_dt == SGG_PAIR16) {              // x = hi + lo: two f16 planes, pair_off elements apart
+        float hi[8], lo[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            hi[k] = round_as<f16_t>(v[k]);
+            lo[k] = v[k] - hi[k];
+        }
+        f16_t* ph = reinterpret_cast<f16_t*>(g.C) + off;
+        if (vec_ok && nv == 8) {
+            store8(ph, hi);
+            store8(ph + g.pair_off, lo);
+        } else {
+            for (int k = 0; k < nv; ++k) {
+                ph[k] = (f16_t)hi[k];
+                ph[g.pair_off + k] = (f16_t)lo[k];
+            }
+        }
+        return;
+    }
     if (vec_ok && nv == 8) {
         if (g.out_dt == SGG_BF16) store8(reinterpret_cast<bf16_t*>(g.C) + off, v);
         else if (g.out_dt == SGG_F16) store8(reinterpret_cast<f16_t*>(g.C) + off, v);
@@ -165,7 +192,7 @@ __device__ __forceinline__ long out_offset(const GemmArgs& g, int m, int n) {
         const int b = m / hw, rem = m - b * hw;
         const int y = rem / g.W, x = rem - y * g.W;
         const int op = g.out_pad;
-        return ((long)(b * (g.H + 2 * op) + y + op) * (g.W + 2 * op) + x + op) * g.N + n;
+        return ((long)(b * (g.H + 2 * op) + y + op) * (g.W + 2 * op) + x + op) * (g.cout_px ? g.cout_px : g.N) + n;
     } else {
         return (long)m * g.ldc + n;
     }
@@ -177,7 +204,7 @@ __device__ __forceinline__ const char* a_row_ptr(const GemmArgs& g, int m, int e
         const int hw = g.H * g.W;
         const int b = m / hw, rem = m - b * hw;
         const int y = rem / g.W, x = rem - y * g.W;
-        return g.A + ((long)(b * (g.H + 2) + y) * (g.W + 2) + x) * g.Cin * esz;
+        return g.A + ((long)(b * (g.H + 2) + y) * (g.W + 2) + x) * (g.cin_px ? g.cin_px : g.Cin) * esz;
     } else {
         return g.A + (long)m * g.lda_b;
     }

@@ -307,7 +307,42 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
     store8(o + Kp, mode == 0 ? hi : lo);
     store8(o + 2 * Kp, mode == 0 ? lo : hi);
 }
+
+// The PAIR form (SGG_PAIR16): row r of x[rows, K] -> [hi (K_pad) | lo (K_pad)], columns K .. K_pad - 1 zero.  What the x3 GEMMs read
+// since round 6 (the kernels walk the plane segments themselves: no duplicated hi plane, 4 bytes written per element instead of 6).
+__global__ __launch_bounds__(256) void split2_kernel(const float* __restrict__ x, long ldx, int K, int Kp, f16_t* __restrict__ out, long ldo, long rows) {
+    const int c8 = Kp / 8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * c8) return;
+    const long r = i / c8;
+    const int c = (int)(i - r * c8) * 8;
+    float v[8], hi[8], lo[8];
+    if (c + 8 <= K && ((reinterpret_cast<uintptr_t>(x + r * ldx + c) & 15) == 0)) {
+        load8(x + r * ldx + c, v);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = c + k < K ? x[r * ldx + c + k] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        hi[k] = round_as<f16_t>(v[k]);
+        lo[k] = v[k] - hi[k];
+    }
+    f16_t* o = out + r * ldo + c;
+    store8(o, hi);
+    store8(o + Kp, lo);
+}
 }  // namespace
+
+// out f16 [rows, 2 * K_pad] (row stride ldo >= 2 K_pad, 16-byte aligned rows) = the PAIR form (SGG_PAIR16) of x f32 [rows, K]
+extern "C" int sgg_split2(const float* x, int64_t ldx, int64_t rows, int K, int K_pad, void* out, int64_t ldo, void* stream) {
+    if (rows == 0) return SGG_OK;
+    if (!x || !out || rows < 0 || K <= 0 || K_pad < K || (K_pad & 7) || ldx < K || ldo < 2L * K_pad || (ldo & 7) || ((uintptr_t)out & 15)) return SGG_ERR_ARG;
+    const long n = rows * (K_pad / 8);
+    hipLaunchKernelGGL(split2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, K, K_pad, (f16_t*)out, (long)ldo, (long)rows);
+    SGG_CHECK_LAUNCH();
+    return SGG_OK;
+}
 
 // out f16 [rows, 3 * K_pad] (row stride ldo >= 3 K_pad, 16-byte aligned rows) = the split form of x f32 [rows, K] (row stride ldx);
 // K_pad % 8 == 0, K_pad >= K.  mode 0: [hi | hi | lo] (the A operand), mode 1: [hi | lo | hi] (the weights).

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void image_prep_batch_kernel(const PrepTab t, 
 // a-2  conv1_1 (3 -> 64, 3x3, pad 1) + ReLU, fp32 VALU (K = 27 is too thin for MFMA, the layer is
 // write-bound: 64 outputs per 27 inputs).  256 threads = 64 pixels x 4 groups of 16 output channels.
 // ------------------------------------------------------------------------------------------------
-template <typename OutT>
+template <typename OutT, bool PAIR = false>
 __global__ __launch_bounds__(256) void conv1_1_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                       const float* __restrict__ bias, OutT* __restrict__ out, long npix,
                                                       int H, int W) {
@@ -141,9 +141,25 @@ __global__ __launch_bounds__(256) void conv1_1_kernel(const float* __restrict__ 
         o0[j] = fmaxf(acc[j], 0.f);
         o1[j] = fmaxf(acc[8 + j], 0.f);
     }
-    OutT* op = out + (((long)b * (H + 2) + y + 1) * (W + 2) + x + 1) * 64 + cg;
-    store8(op, o0);
-    store8(op + 8, o1);
+    if constexpr (PAIR) {        // x3 mode: the [hi (64) | lo (64)] pixel of a pair plane (SGG_PAIR16)
+        float h0[8], h1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            h0[j] = round_as<f16_t>(o0[j]);
+            h1[j] = round_as<f16_t>(o1[j]);
+            o0[j] -= h0[j];
+            o1[j] -= h1[j];
+        }
+        OutT* op = out + (((long)b * (H + 2) + y + 1) * (W + 2) + x + 1) * 128 + cg;
+        store8(op, h0);
+        store8(op + 8, h1);
+        store8(op + 64, o0);
+        store8(op + 72, o1);
+    } else {
+        OutT* op = out + (((long)b * (H + 2) + y + 1) * (W + 2) + x + 1) * 64 + cg;
+        store8(op, o0);
+        store8(op + 8, o1);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -268,6 +284,42 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, 
 #pragma unroll
     for (int k = 0; k < 8; ++k) a[k] = fmaxf(a[k], t[k]);
     store8(out + (((long)b * (Ho + 2 * op) + yo + op) * (Wo + 2 * op) + xo + op) * C + cc, a);
+}
+
+// the same on a PAIR plane (SGG_PAIR16: pixel = [hi (C) | lo (C)], x = hi + lo): the maximum of the four fp32 values, split again (exact:
+// the maximum IS one of the four inputs, so its split is that input's)
+__global__ __launch_bounds__(256) void maxpool_pair_kernel(const f16_t* __restrict__ in, f16_t* __restrict__ out, int op, int H, int W,
+                                                           int C, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c8 = C >> 3;
+    const int cc = (int)(i % c8) * 8;
+    long p = i / c8;
+    const int Wo = W >> 1, Ho = H >> 1;
+    const int xo = (int)(p % Wo);
+    p /= Wo;
+    const int yo = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const f16_t* s = in + (((long)b * (H + 2) + 2 * yo + 1) * (W + 2) + 2 * xo + 1) * 2 * C + cc;
+    float a[8], h[8], l[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = -3.0e38f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f16_t* sq = s + ((long)(q >> 1) * (W + 2) + (q & 1)) * 2 * C;
+        load8(sq, h);
+        load8(sq + C, l);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = fmaxf(a[k], h[k] + l[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        h[k] = round_as<f16_t>(a[k]);
+        l[k] = a[k] - h[k];
+    }
+    f16_t* o = out + (((long)b * (Ho + 2 * op) + yo + op) * (Wo + 2 * op) + xo + op) * 2 * C + cc;
+    store8(o, h);
+    store8(o + C, l);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -719,6 +771,8 @@ extern "C" int sgg_conv1_1(const float* in, const float* w, const float* bias, v
     }
     else if (out_dtype == SGG_F32)
         hipLaunchKernelGGL(conv1_1_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, w, bias, (float*)out, npix, H, W);
+    else if (out_dtype == SGG_PAIR16)      // fp32 arithmetic, the 64-channel map as a pair plane [B, H+2, W+2, 128] (x3 mode)
+        hipLaunchKernelGGL((conv1_1_kernel<f16_t, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, in, w, bias, (f16_t*)out, npix, H, W);
     else
         return SGG_ERR_DTYPE;
     SGG_CHECK_LAUNCH();
@@ -730,6 +784,11 @@ extern "C" int sgg_maxpool2x2(const void* in, void* out, int out_pad, int B, int
         return SGG_ERR_ARG;
     const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
     const int grid = (int)((total + 255) / 256);
+    if (dtype == SGG_PAIR16) {          // C = channels per plane
+        hipLaunchKernelGGL(maxpool_pair_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16_t*)in, (f16_t*)out, out_pad, H, W, C, total);
+        SGG_CHECK_LAUNCH();
+        return SGG_OK;
+    }
     SGG_FOR_DTYPE(dtype, hipLaunchKernelGGL(maxpool_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)in, (T*)out, out_pad, H, W, C, total));
     SGG_CHECK_LAUNCH();
     return SGG_OK;

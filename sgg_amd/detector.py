@@ -138,6 +138,40 @@ class VGGDetector(nn.Module):
             self._bufs[k] = b
         return b
 
+    def _features_x3(self, x0, ws, B, Hp, Wp, dev, out):
+        """The x3 mode's VGG-16 on PAIR planes (include/sgg_hip.h SGG_PAIR16: every activation as two f16 planes hi + lo, 22 significand
+        bits): conv1_1 in fp32 arithmetic writes the first pair plane, every 3x3 convolution reads a pair plane and writes the next one
+        from its epilogue (fp32 accumulator -> ReLU -> hi / lo), the pools run on pair planes, the last convolution writes the fp32 map
+        RoIAlign reads.  No split pass over any activation, no [hi | hi | lo] copy (round 5: 14 sgg_split3 launches, ~1 ms per batch of 8)."""
+        f16 = torch.float16
+        cfg = list(VGG16_CFG)
+        H, W = Hp, Wp
+        w, bias = ws[0][:2]
+        x = self._buf('p0', (B, H + 2, W + 2, 128), f16, dev, True)
+        ops.conv1_1(x0, w, bias, x, pair=True)
+        ci_layer, n_conv = 1, len(ws)
+        for li in range(1, len(cfg)):
+            v = cfg[li]
+            if v == 'M':
+                C = x.shape[3] // 2
+                y = self._buf('p%d' % li, (B, H // 2 + 2, W // 2 + 2, 2 * C), f16, dev, True)
+                ops.maxpool2x2_pair(x, y, 1)
+                H, W = H // 2, W // 2
+            else:
+                w, bias, ci, co = ws[ci_layer][:4]
+                last = ci_layer == n_conv - 1
+                if last:
+                    if out is not None:
+                        assert tuple(out.shape) == (B, H, W, co) and out.dtype == torch.float32 and out.is_contiguous()
+                    y = out if out is not None else torch.empty((B, H, W, co), dtype=torch.float32, device=dev)
+                    ops.conv3x3_relu_pair(x, w.view(co, 3, 3, ci), bias, y, 0, pair_out=False)
+                else:
+                    y = self._buf('p%d' % li, (B, H + 2, W + 2, 2 * co), f16, dev, True)
+                    ops.conv3x3_relu_pair(x, w.view(co, 3, 3, ci), bias, y, 1, pair_out=True)
+                ci_layer += 1
+            x = y
+        return x
+
     def features(self, images, dtype, out=None):
         """images: list of f32[3,h,w] tensors in [0,1] (host or device) -- what the reference's SquarePad + ToTensor
         produce -- or of u8[h0,w0,3] decoded images, for which those two steps run inside the prep kernel.
@@ -181,6 +215,8 @@ class VGGDetector(nn.Module):
                     im = im.to(device=dev, dtype=torch.float32, non_blocking=True)
             staged.append(im)
         ops.image_prep_batch(staged, sizes, x0)          # one launch for the batch (was one per image)
+        if dtype == torch.float32 and ops.split3_on() and ops.PAIR_GEMM and getattr(self, '_features_split', None) is None:
+            return self._features_x3(x0, ws, B, Hp, Wp, dev, out), sizes, (Hp, Wp)
         H, W = Hp, Wp
         x, ci_layer, n_conv = x0, 0, len(ws)
         cfg = list(VGG16_CFG)

@@ -36,7 +36,7 @@ class EvalGraphs(object):
         self.disabled = None
         self.pool = None
         self.since_sync = 0
-        self.sync_every = int(os.environ.get('SGG_GRAPH_SYNC_EVERY', '32'))
+        self.sync_every = int(os.environ.get('SGG_GRAPH_SYNC_EVERY', '0'))      # (round 6: off, see graph_step.py)
         self.stats = dict(replayed=0, plain=0, captures=0)
 
     def _signature(self, batch):

@@ -11,6 +11,7 @@ from . import _lib
 from ._lib import ACT_NONE, ACT_RELU, SGG_BF16, SGG_F16, SGG_F32  # noqa: F401
 
 _DT = {torch.float32: SGG_F32, torch.bfloat16: SGG_BF16, torch.float16: SGG_F16}
+SGG_PAIR16 = 3      # include/sgg_hip.h: a row / pixel as two f16 planes [hi | lo] (the x3 mode's operand and activation format)
 
 
 HALF = (torch.bfloat16, torch.float16)     # the two 16-bit storage / MFMA operand formats (same kernels, same rates)
@@ -150,10 +151,12 @@ def image_prep_batch(images, sizes, out_nhwc4):
               u8.ctypes.data, n, _p(out_nhwc4, torch.float32), Hp, Wp, _stream())
 
 
-def conv1_1(x_nhwc4, w, bias, out):
+def conv1_1(x_nhwc4, w, bias, out, pair=False):
+    """pair=True: `out` is a PAIR plane f16 [B, H+2, W+2, 128] (pixel = [hi (64) | lo (64)]), the x3 mode's form of the fp32 map"""
     B, H, W = x_nhwc4.shape[0], x_nhwc4.shape[1] - 2, x_nhwc4.shape[2] - 2
+    assert not pair or (out.dtype == torch.float16 and out.shape[3] == 128)
     _lib.call('sgg_conv1_1', _p(x_nhwc4, torch.float32), _p(w, torch.float32), _p(bias, torch.float32), _p(out),
-              B, H, W, dt(out), _stream())
+              B, H, W, SGG_PAIR16 if pair else dt(out), _stream())
 
 
 def conv1_pack_weights(w1, dtype):
@@ -205,6 +208,30 @@ def conv3x3_relu(x, w, bias, out, out_pad, pool=False):
         return
     _lib.call('sgg_conv3x3_relu', _p(x), _p(w), _p(bias, torch.float32), _p(out), out_pad, B, H, W, Cin, Cout, int(pool),
               dt(x), dt(out), _stream())
+
+
+def conv3x3_relu_pair(xp, w, bias, out, out_pad, pair_out):
+    """x3 mode on PAIR planes (include/sgg_hip.h SGG_PAIR16): xp f16 [B, H+2, W+2, 2 Cin] zero-bordered (pixel = [hi | lo]), w f32
+    [Cout, 3, 3, Cin] (its pair form [Cout, 9, 2 Cin] is made once per weight version and cached); out: a pair plane
+    f16 [B, H+2p, W+2p, 2 Cout] (pair_out) or f32 [B, H+2p, W+2p, Cout].  The implicit-GEMM kernels walk hi.hi + hi.lo + lo.hi per tap:
+    no split pass over the activations, no [hi | hi | lo] copy of them."""
+    B, H, W, Cin = xp.shape[0], xp.shape[1] - 2, xp.shape[2] - 2, xp.shape[3] // 2
+    Cout = w.shape[0]
+    assert xp.dtype == torch.float16 and Cin % 64 == 0 and w.dtype == torch.float32
+    wp = split2(w.reshape(Cout * 9, Cin), weights=True)                # [Cout * 9, 2 Cin]: tap = [hi (Cin) | lo (Cin)]
+    assert (out.dtype == torch.float16 and out.shape[3] == 2 * Cout) if pair_out else (out.dtype == torch.float32 and out.shape[3] == Cout)
+    step = max(1, SPAN_LIMIT // (xp.shape[1] * xp.shape[2] * 2 * Cin * 2))
+    for b0 in range(0, B, step):
+        xb = xp[b0:b0 + step]
+        _lib.call('sgg_conv3x3_relu', _p(xb), _p(wp), _p(bias, torch.float32), _p(out[b0:b0 + step]), out_pad, xb.shape[0], H, W, Cin, Cout, 0,
+                  SGG_PAIR16, SGG_PAIR16 if pair_out else SGG_F32, _stream())
+
+
+def maxpool2x2_pair(xp, out, out_pad):
+    """MaxPool2d(2) on a PAIR plane [B, H+2, W+2, 2 C] -> [B, H/2+2p, W/2+2p, 2 C]"""
+    B, H, W, C = xp.shape[0], xp.shape[1] - 2, xp.shape[2] - 2, xp.shape[3] // 2
+    assert xp.dtype == out.dtype == torch.float16 and out.shape[3] == 2 * C
+    _lib.call('sgg_maxpool2x2', _p(xp), _p(out), out_pad, B, H, W, C, SGG_PAIR16, _stream())
 
 
 def maxpool2x2(x, out, out_pad):
@@ -431,6 +458,49 @@ def split3(x, weights=False):
     return _cached_operand(x, 'x3', make) if weights else make(x)
 
 
+def split2(x, weights=False):
+    """x f32 [rows, K] (row-strided ok) -> the PAIR form f16 [rows, 2 * K_pad] = [hi | lo] (K_pad = K rounded up to 64): what the x3
+    contractions read since round 6 -- the kernels walk (A hi, W hi), (A hi, W lo), (A lo, W hi) over the two planes themselves, so
+    nothing is duplicated (4 bytes written per element; sgg_split3's [hi | hi | lo] rows: 6).  weights=True: cached per tensor version."""
+    rows, K = x.shape
+    assert x.dtype == torch.float32 and x.stride(1) == 1
+
+    def make(x):
+        Kp = (K + 63) // 64 * 64
+        out = torch.empty((rows, 2 * Kp), dtype=torch.float16, device=x.device)
+        _lib.call('sgg_split2', _p(x, torch.float32, rows_ok=True), x.stride(0), rows, K, Kp, _p(out), out.stride(0), _stream())
+        return out
+    return _cached_operand(x, 'x2', make) if weights else make(x)
+
+
+PAIR_GEMM = os.environ.get('SGG_X3_PAIR', '1') != '0'      # 0: round 5's [hi | hi | lo] operands (sgg_split3) everywhere
+
+
+def _gemm_pair(A, W, bias, act, post_scale, post_shift, out, splits):
+    """act(A . W^T + bias) * post_scale + post_shift for fp32 A [M,K], W [N,K] on PAIR operands (x3 mode) -> out (fp32 / 16-bit as allocated)"""
+    M, K = A.shape
+    N = W.shape[0]
+    Ap, Wp = split2(A), split2(W, weights=True)
+    Kp = Ap.shape[1] // 2
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    kt = 3 * Kp // 64
+    can_split = N % 8 == 0 and out.stride(1) == 1 and out.stride(0) % 8 == 0 and out.data_ptr() % 16 == 0
+    bias_p = _p(bias, torch.float32) if bias is not None else None
+    ps_p = _p(post_scale, torch.float32) if post_scale is not None else None
+    pt_p = _p(post_shift, torch.float32) if post_shift is not None else None
+    if can_split and ((splits is None and tiles <= 96 and kt >= 64) or (splits is not None and splits > 1)):
+        if splits is None:
+            splits = max(2, min(16, 512 // tiles, kt // 8))
+        splits = min(splits, Kp // 64)
+        ws = torch.empty((splits, M, N), dtype=torch.float32, device=A.device)
+        _lib.call('sgg_gemm_splitk', _p(Ap), Ap.stride(0), _p(Wp), Wp.stride(0), bias_p, ps_p, pt_p, _p(out, rows_ok=True), out.stride(0), M, N, Kp, act,
+                  SGG_PAIR16, dt(out), splits, _p(ws), _stream())
+        return out
+    _lib.call('sgg_gemm', _p(Ap), Ap.stride(0), None, 0, Kp, _p(Wp), Wp.stride(0), None, 0, bias_p, ps_p, pt_p, _p(out, rows_ok=True), out.stride(0),
+              M, N, Kp, act, SGG_PAIR16, dt(out), _stream())
+    return out
+
+
 # x3 mode with an f16 BACKWARD (RelModelBase.set_compute_dtype(torch.float32, split3=True, backward_f16=True)): the forward's contractions
 # run on split operands (fp32-grade logits: both parity clauses of the north star are about the forward), the backward's on operands
 # rounded to f16 ONCE -- one MFMA product instead of three, under the Trainer's loss scale, i.e. gradients at the accuracy of the f16
@@ -506,6 +576,8 @@ def gemm(A, W, bias=None, act=ACT_NONE, out_dtype=None, A2=None, post_scale=None
             Wb = W2 if W2 is not None else (W[:, K1_:] if A2 is not None else None)
             return gemm(half_operand(A), half_operand(Wa, weights=True), bias, act, out_dtype, half_operand(A2) if A2 is not None else None,
                         post_scale, post_shift, out, half_operand(Wb, weights=True) if Wb is not None else None, splits)
+        if PAIR_GEMM and A2 is None and W2 is None and M * ((A.shape[1] + 63) // 64 * 64) * 4 < SPAN_LIMIT and A.stride(0) >= A.shape[1]:
+            return _gemm_pair(A, W, bias, act, post_scale, post_shift, out, splits)
         A3, W3, A23, W23 = _split3_operands(A, W, A2, W2)
         return gemm(A3, W3, bias, act, out_dtype, A23, post_scale, post_shift, out, W23, splits)
     # the kernels address an operand's rows as (uniform base + 32-bit lane offset): an A operand of 4 GiB or more (fc6 on > 85 k
@@ -551,13 +623,21 @@ def gemm_addrows(A, W, bias, add_rows, add_idx=None, act=ACT_NONE, out_dtype=Non
     out_dtype = out_dtype or A.dtype
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    in_dt = None
     if _SPLIT3[0] and A.dtype == torch.float32:
-        A, W = (half_operand(A), half_operand(W, weights=True)) if _BWD16[0] else (split3(A), split3(W, weights=True))
-        K = A.shape[1]
+        if _BWD16[0]:
+            A, W = half_operand(A), half_operand(W, weights=True)
+            K = A.shape[1]
+        elif PAIR_GEMM:
+            A, W = split2(A), split2(W, weights=True)
+            K, in_dt = A.shape[1] // 2, SGG_PAIR16
+        else:
+            A, W = split3(A), split3(W, weights=True)
+            K = A.shape[1]
     _lib.call('sgg_gemm_addrows', _p(A, rows_ok=True), A.stride(0), _p(W, rows_ok=True), W.stride(0),
               _p(bias, torch.float32) if bias is not None else None, _p(add_rows, torch.float32, rows_ok=True), add_rows.stride(0),
-              _p(add_idx, torch.int32) if add_idx is not None else None, _p(out, rows_ok=True), out.stride(0), M, N, K, act, dt(A), dt(out),
-              _stream())
+              _p(add_idx, torch.int32) if add_idx is not None else None, _p(out, rows_ok=True), out.stride(0), M, N, K, act,
+              in_dt if in_dt is not None else dt(A), dt(out), _stream())
     return out
 
 

@@ -80,6 +80,30 @@ def test_graph_steps_equal_plain_steps_bit_for_bit(dtype):
     assert l1[-1] < l1[0]
 
 
+def test_300_replayed_steps_without_any_device_synchronisation_equal_plain_steps():
+    """300 steps (four batches, two signatures) with the periodic device-wide synchronisation OFF (SGG_GRAPH_SYNC_EVERY=0)
+    and the host free to run 64 steps ahead: every loss, parameter and momentum buffer bit-equal to the launch-by-launch run."""
+    _gpu()
+    os.environ['SGG_GRAPH_STRICT'] = '1'
+    os.environ['SGG_GRAPH_SYNC_EVERY'] = '0'
+    os.environ['SGG_GRAPH_DEPTH'] = '64'
+    try:
+        batches = _batches()
+        l0, s0, m0, _, _, n0 = _run(False, 300, torch.float16, None, batches)
+        l1, s1, m1, stats, disabled, n1 = _run(True, 300, torch.float16, None, batches)
+    finally:
+        for k in ('SGG_GRAPH_STRICT', 'SGG_GRAPH_SYNC_EVERY', 'SGG_GRAPH_DEPTH'):
+            os.environ.pop(k, None)
+    assert disabled is None, disabled
+    assert stats['replayed'] >= 280, stats
+    assert n0 == n1 == 300
+    assert l0 == l1, [(i, a, b) for i, (a, b) in enumerate(zip(l0, l1)) if a != b][:5]
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+    for k in m0:
+        assert torch.equal(m0[k], m1[k]), k
+
+
 def test_graph_steps_with_the_forward_in_two_graphs_equal_plain_steps():
     """SGG_GRAPH_VSPLIT=4: graph V cut after conv2_2, the update released after the first part -- scheduling only, the same bits"""
     _gpu()

@@ -143,6 +143,92 @@ def test_x3_model_forward_gradients_and_trainer(ops):
     assert not ops.split3_on()
 
 
+def test_pair_operand_gemm_conv_pool_kernels(ops):
+    """Round 6: the x3 contractions on PAIR operands (SGG_PAIR16: rows / pixels as two f16 planes [hi | lo]; the kernels walk hi.hi + hi.lo
+    + lo.hi themselves).  sgg_split2 against its definition; the pair GEMM (tile kernel, ping-pong kernel, split-K; K not a multiple of 64;
+    bias + ReLU + per-channel affine) against a float64 product at the x3 mode's accuracy and against round 5's [hi | hi | lo] form; the
+    pair convolution (pair plane in, pair plane or fp32 out) against torch's fp32 convolution; the pair max pool; conv1_1's pair output."""
+    import torch.nn.functional as F
+    from sgg_amd import _lib
+    g = torch.Generator().manual_seed(7)
+    # ---- split2
+    x = (torch.randn(37, 200, generator=g) * torch.logspace(-3, 2, 200)).to(DEV)
+    p2 = ops.split2(x)
+    assert p2.shape == (37, 2 * 256) and p2.dtype == torch.float16
+    hi = x.half()
+    assert torch.equal(p2[:, :200], hi) and torch.equal(p2[:, 256:456], (x - hi.float()).half())
+    assert float(p2[:, 200:256].abs().max()) == 0 and float(p2[:, 456:].abs().max()) == 0
+    assert float((p2[:, :200].float() + p2[:, 256:456].float() - x).abs().max()) <= 2e-6 * float(x.abs().max())
+    # ---- GEMM
+    ops.set_split3(True)
+    try:
+        for M, N, K, bias, act, affine in ((300, 200, 1000, True, ops.ACT_RELU, True),        # 128x128 tile kernel, K padded to 1024
+                                           (2048, 4096, 512, True, ops.ACT_NONE, False),     # 256x256 ping-pong kernel
+                                           (256, 4096, 4096, True, ops.ACT_RELU, False),     # split-K (short M, long K)
+                                           (64, 40, 64, False, ops.ACT_NONE, False)):
+            A = torch.randn(M, K, generator=g).to(DEV)
+            W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+            b = torch.randn(N, generator=g).to(DEV) if bias else None
+            ps = (torch.rand(N, generator=g) + 0.5).to(DEV) if affine else None
+            pt = torch.randn(N, generator=g).to(DEV) if affine else None
+            want = A.double() @ W.double().t()
+            if b is not None:
+                want = want + b.double()
+            if act == ops.ACT_RELU:
+                want = want.clamp_min(0)
+            if affine:
+                want = want * ps.double() + pt.double()
+            ops.PAIR_GEMM = True
+            got = ops.gemm(A, W, b, act, post_scale=ps, post_shift=pt)
+            ops.PAIR_GEMM = False
+            old = ops.gemm(A, W, b, act, post_scale=ps, post_shift=pt)
+            ops.PAIR_GEMM = True
+            scale = float(want.abs().max())
+            assert got.dtype == torch.float32 and float((got.double() - want).abs().max()) <= 2e-5 * scale, (M, N, K, float((got.double() - want).abs().max()), scale)
+            assert float((got - old).abs().max()) <= 4e-6 * scale, (M, N, K)          # same three products, another order
+    finally:
+        ops.PAIR_GEMM = True
+        ops.set_split3(False)
+    # ---- convolution on pair planes: [B, H+2, W+2, 2 Cin] -> pair plane / fp32
+    for B, H, W, Cin, Cout in ((2, 38, 38, 128, 256), (1, 80, 72, 64, 64), (8, 76, 76, 256, 512)):
+        x = torch.randn(B, Cin, H, W, generator=g).relu().to(DEV)
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(DEV)
+        b = torch.randn(Cout, generator=g).to(DEV)
+        want = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)).permute(0, 2, 3, 1)       # NHWC
+        xp = torch.zeros(B, H + 2, W + 2, 2 * Cin, dtype=torch.float16, device=DEV)
+        xn = x.permute(0, 2, 3, 1).contiguous()
+        xp[:, 1:-1, 1:-1] = ops.split2(xn.reshape(-1, Cin)).view(B, H, W, 2 * Cin)
+        wk = w.permute(0, 2, 3, 1).contiguous()                                                          # [Cout, ky, kx, Cin]
+        out32 = torch.empty(B, H, W, Cout, dtype=torch.float32, device=DEV)
+        ops.conv3x3_relu_pair(xp, wk, b, out32, 0, pair_out=False)
+        scale = float(want.abs().max())
+        assert float((out32.double() - want).abs().max()) <= 2e-5 * scale, (B, H, Cin, Cout, float((out32.double() - want).abs().max()), scale)
+        outp = torch.zeros(B, H + 2, W + 2, 2 * Cout, dtype=torch.float16, device=DEV)
+        ops.conv3x3_relu_pair(xp, wk, b, outp, 1, pair_out=True)
+        inner = outp[:, 1:-1, 1:-1]
+        assert torch.equal(inner[..., :Cout], out32.half())                                              # hi = f16(value), lo = f16(value - hi)
+        assert torch.equal(inner[..., Cout:], (out32 - out32.half().float()).half())
+        assert float(outp[:, 0].abs().max()) == 0 and float(outp[:, :, -1].abs().max()) == 0             # the zero border is left alone
+        if H % 2 == 0 and W % 2 == 0:
+            pooled = torch.zeros(B, H // 2 + 2, W // 2 + 2, 2 * Cout, dtype=torch.float16, device=DEV)
+            ops.maxpool2x2_pair(outp, pooled, 1)
+            val = inner[..., :Cout].float() + inner[..., Cout:].float()
+            wantp = F.max_pool2d(val.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+            gotp = pooled[:, 1:-1, 1:-1]
+            assert torch.equal(gotp[..., :Cout].float() + gotp[..., Cout:].float(), wantp)
+    # ---- conv1_1 with a pair plane as output
+    B, H, W = 2, 48, 64
+    img = torch.zeros(B, H + 2, W + 2, 4, device=DEV)
+    img[:, 1:-1, 1:-1, :3] = torch.randn(B, H, W, 3, generator=g).to(DEV)
+    w1 = (torch.randn(64, 27, generator=g) / 5).to(DEV)
+    b1 = torch.randn(64, generator=g).to(DEV)
+    ref = torch.zeros(B, H + 2, W + 2, 64, device=DEV)
+    ops.conv1_1(img, w1, b1, ref)
+    pp = torch.zeros(B, H + 2, W + 2, 128, dtype=torch.float16, device=DEV)
+    ops.conv1_1(img, w1, b1, pp, pair=True)
+    assert torch.equal(pp[..., :64], ref.half()) and torch.equal(pp[..., 64:], (ref - ref.half().float()).half())
+
+
 def test_x3_with_f16_backward_keeps_the_forward_and_gives_f16_grade_gradients(ops):
     """set_compute_dtype(float32, split3=True, backward_f16=True): the train-mode forward is the x3 forward bit for bit (logits inside the
     1e-3 clause), the backward's contractions round their operands to f16 once under the loss scale -- every head gradient within 1 % of
