@@ -138,10 +138,22 @@ __global__ __launch_bounds__(1024) void topk_gather_kernel(const float* __restri
         const int shift = pass * 8;
         if (tid < 256) hist[tid] = 0u;
         __syncthreads();
+        // runs of one digit are counted in a register and added once: with a score threshold most of an image's 150 K class candidates are
+        // -inf -- one key, one bin, i.e. every thread's every element an atomic on the same LDS word (round 6: 0.85 ms per SGDet step)
+        unsigned run_d = 0xffffffffu, run_n = 0u;
         for (int i = tid; i < n; i += 1024) {
             const unsigned k = topk_key(sc[i]);
-            if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+            if ((k & mask) != prefix) continue;
+            const unsigned d = (k >> shift) & 255u;
+            if (d == run_d) {
+                ++run_n;
+            } else {
+                if (run_n) atomicAdd(&hist[run_d], run_n);
+                run_d = d;
+                run_n = 1u;
+            }
         }
+        if (run_n) atomicAdd(&hist[run_d], run_n);
         __syncthreads();
         if (tid == 0) {
             int cum = 0, d = 255;
@@ -177,7 +189,7 @@ __global__ __launch_bounds__(1024) void topk_gather_kernel(const float* __restri
     const bool ordered_ties = T > 0 && eq_total > need && thr != topk_key(-INFINITY);
     if (!ordered_ties) {
         for (int i = tid; i < n && T > 0; i += 1024) {
-            if (topk_key(sc[i]) == thr) {
+            if (topk_key(sc[i]) == thr && *(volatile unsigned*)&s_cnt < (unsigned)need) {      // (once `need` are taken nobody queues up for the counter)
                 const unsigned c = atomicAdd(&s_cnt, 1u);
                 if (c < (unsigned)need) sel[base + c] = ((unsigned long long)thr << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
             }
