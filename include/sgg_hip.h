@@ -72,6 +72,14 @@ int sgg_conv1_1(const float* in_nhwc4, const float* w /*[64][27] (ky,kx,c)*/, co
 int sgg_conv1_pack_weights(const float* w1 /*[64][27]*/, void* frags /*4096 bytes*/, int dtype, void* stream);
 int sgg_conv1_block(const float* in_nhwc4, const void* w1_frags, const float* b1, const void* w2, const float* b2, void* out, int out_pad,
                     int B, int H, int W, int pool, int dtype, void* stream);
+/* The x3 mode's 3x3 convolution (pad 1) + bias + ReLU [+ MaxPool2d(2)] on PAIR planes (SGG_PAIR16), patch kernel form: `in` [B, H+2, W+2, 2 Cin]
+ * zero-bordered with pixel = [hi (Cin) | lo (Cin)]; `w3` f16 [Cout][9][3 Cin] with tap = [hi | lo | hi] (sgg_split3 mode 1 of the [Cout * 9, Cin]
+ * weight matrix); `out` [B, H+2p, W+2p, 2 Cout] (pool = 1: [B, H/2+2p, W/2+2p, 2 Cout]), hi / lo made from the fp32 accumulator after bias,
+ * ReLU and the pool.  H, W >= 64, Cout % 128 == 0, Cin % 32 == 0, else SGG_ERR_ARG (use sgg_conv3x3_relu with dtype SGG_PAIR16).
+ * Replaces: [3P] vgg16.features' conv + ReLU (+ pool) pairs at fp32 grade (sgg_models/rel_model_base.py:184,310-312). */
+int sgg_conv3x3_relu_x3(const void* in, const void* w3, const float* bias, void* out, int out_pad, int B, int H, int W, int Cin, int Cout,
+                        int pool, void* stream);
+
 /* pool = 1: the following MaxPool2d(2) is fused into the epilogue -- out is the pooled plane [B, H/2+2p, W/2+2p, Cout]
  * (H, W even; LDS-patch kernel only: returns SGG_ERR_ARG for shapes that kernel does not take).  out_dtype: element type of `out`;
  * != dtype (the x3 mode: f16 split operands in, f32 out) runs on the implicit-GEMM kernels, without the fused pool. */

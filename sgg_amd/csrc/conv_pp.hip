@@ -53,6 +53,11 @@ struct ConvPPArgs {
     const float* bias;
     char* out;           // [B, H+2p, W+2p, Cout]   (pool: [B, H/2+2p, W/2+2p, Cout])
     int B, H, W, Cin, Cout, out_pad, tiles_x, tiles_y, pool;
+    // X3 form (the x3 mode on PAIR planes, include/sgg_hip.h SGG_PAIR16): `in` is [B, H+2, W+2, 2 Cpl] with pixel = [hi (Cpl) | lo (Cpl)], `w` is
+    // [Cout][9][3 Cpl] with tap = [hi | lo | hi] (sgg_split3's weight form), Cin = 3 Cpl VIRTUAL channels: slab v of 32 reads plane channels
+    // (v mod Cpl/32) of the hi plane for v < 2 Cpl/32 and of the lo plane after -- hi.hi + hi.lo + lo.hi in the accumulator; `out` is a pair
+    // plane [.., 2 Cout] written from the fp32 accumulator (bias, ReLU, optional 2x2 max, THEN the split)
+    int Cpl;
 };
 
 // MFMA column (lane & 31) -> pixel of a 2 x 16 block: each ds_read_b128 lane group ({0-3,12-15,20-27} / {4-11,16-19,28-31}) gets one image row
@@ -78,7 +83,7 @@ __device__ __forceinline__ void wait_vm_n(int n) {          // folds to one inst
 
 // NQ channel slabs of 64 x NPG pixel groups of 128 = NW waves: (4, 2) 256 px x 256 ch; (2, 2) 256 px x 128 ch, four waves, two workgroups
 // per CU; (2, 4) 512 px x 128 ch (the 128-channel layers with eight waves: half the weight traffic per MFMA of the four-wave form).
-template <int DT, int NQ, int NPG, int TW>
+template <int DT, int NQ, int NPG, int TW, bool X3 = false>
 __global__ __launch_bounds__(64 * NQ * NPG, 2) void conv3x3_pp_kernel(const ConvPPArgs g) {     // two waves per SIMD (four-wave form: from two workgroups)
     static_assert(DT == SGG_BF16 || DT == SGG_F16, "16-bit element types");
     using TG = TileGeom<TW, NPG>;
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(64 * NQ * NPG, 2) void conv3x3_pp_kernel(const Conv
         const int py = r / PT_PW, px = r - py * PT_PW;
         const int gy = min(y0 + py, g.H + 1), gx = min(x0 + px, g.W + 1);
         const int chunk = (lane & 3) ^ ((r >> 2) & 3);
-        psrc[j] = (unsigned)((((long)b * (g.H + 2) + gy) * (g.W + 2) + gx) * g.Cin * 2 + chunk * 16);
+        psrc[j] = (unsigned)((((long)b * (g.H + 2) + gy) * (g.W + 2) + gx) * (X3 ? 2 * g.Cpl : g.Cin) * 2 + chunk * 16);
     }
     // weight pieces of K-tile kt (clamped to the last one) into ring stage kt & 3; with them, at taps 3 .. 3+PTAPS-1, one patch piece of the NEXT slab
     auto w_base = [&](int slab, int tap) -> const char* {                 // (slab, tap) past the end: the last K-tile again
@@ -138,7 +143,14 @@ __global__ __launch_bounds__(64 * NQ * NPG, 2) void conv3x3_pp_kernel(const Conv
         glds16_su(ub, wsrc[j], wring + (kt & (NSTG - 1)) * WST + (wave * (16 * WI) + j * 16) * PROW);
     };
     auto issue_p = [&](int slab, int j) {                                  // piece j of this wave, patch of `slab` (clamped) into buffer slab & 1
-        const char* ub = uniform_ptr(g.in + (long)min(slab, nch - 1) * PROW);
+        const int sl = min(slab, nch - 1);
+        long poff = (long)sl * PROW;
+        if constexpr (X3) {
+            const int nc = g.Cpl / 32;                                      // slabs per plane
+            const int seg = (sl >= nc) + (sl >= 2 * nc);
+            poff = (long)(sl - seg * nc) * PROW + (seg == 2 ? (long)g.Cpl * 2 : 0);
+        }
+        const char* ub = uniform_ptr(g.in + poff);
         glds16_su(ub, psrc[j], pbuf + (slab & 1) * PATCH_B + min(wave + j * NW, PATCH_PIECES - 1) * 1024);
     };
 
@@ -278,6 +290,22 @@ __global__ __launch_bounds__(64 * NQ * NPG, 2) void conv3x3_pp_kernel(const Conv
     using TO = typename std::conditional<DT == SGG_BF16, bf16_t, f16_t>::type;
     TO* const outp = reinterpret_cast<TO*>(g.out);
     const int cl = (lane & 7) * 8, n = n0 + q * 64 + cl, op = g.out_pad;
+    const int opx = X3 ? 2 * g.Cout : g.Cout;                   // elements per output pixel
+    auto put8 = [&](long pixel, float (&v)[8]) {                // 8 channels of one output pixel (pair plane: hi, and lo Cout further)
+        if constexpr (X3) {
+            float lo[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float h = round_as<f16_t>(v[k]);
+                lo[k] = v[k] - h;
+                v[k] = h;
+            }
+            store8(outp + pixel * opx + n, v);
+            store8(outp + pixel * opx + g.Cout + n, lo);
+        } else {
+            store8(outp + pixel * opx + n, v);
+        }
+    };
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
@@ -310,7 +338,7 @@ __global__ __launch_bounds__(64 * NQ * NPG, 2) void conv3x3_pp_kernel(const Conv
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] + bias8[k], 0.f);
                 const int Ho = g.H >> 1, Wo = g.W >> 1;
-                store8(outp + (((long)b * (Ho + 2 * op) + yo + op) * (Wo + 2 * op) + xo + op) * g.Cout + n, v);
+                put8(((long)b * (Ho + 2 * op) + yo + op) * (Wo + 2 * op) + xo + op, v);
             }
         } else {
 #pragma unroll
@@ -324,14 +352,14 @@ __global__ __launch_bounds__(64 * NQ * NPG, 2) void conv3x3_pp_kernel(const Conv
                 v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] + bias8[k], 0.f);
-                store8(outp + (((long)b * (g.H + 2 * op) + y + op) * (g.W + 2 * op) + x + op) * g.Cout + n, v);
+                put8(((long)b * (g.H + 2 * op) + y + op) * (g.W + 2 * op) + x + op, v);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging tile is rewritten by the next block
     }
 }
 
-template <int DT, int NQ, int NPG, int TW>
+template <int DT, int NQ, int NPG, int TW, bool X3 = false>
 int launch_pp(ConvPPArgs g, hipStream_t s) {
     constexpr int NW = NQ * NPG, CN = 64 * NQ;
     using TG = TileGeom<TW, NPG>;
@@ -340,7 +368,7 @@ int launch_pp(ConvPPArgs g, hipStream_t s) {
     g.tiles_y = (g.H + TG::TH - 1) / TG::TH;
     constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
     static_assert(smem <= 160 * 1024, "fits the CU's LDS");
-    auto k = conv3x3_pp_kernel<DT, NQ, NPG, TW>;
+    auto k = conv3x3_pp_kernel<DT, NQ, NPG, TW, X3>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -353,11 +381,11 @@ int launch_pp(ConvPPArgs g, hipStream_t s) {
     return SGG_OK;
 }
 
-template <int DT>
+template <int DT, bool X3 = false>
 int launch_pp_dt(const ConvPPArgs& g, int nq, int npg, int tw, hipStream_t s) {
-    if (nq == 4) return tw == 32 ? launch_pp<DT, 4, 2, 32>(g, s) : launch_pp<DT, 4, 2, 16>(g, s);
-    if (npg == 4) return tw == 32 ? launch_pp<DT, 2, 4, 32>(g, s) : launch_pp<DT, 2, 4, 16>(g, s);
-    return tw == 32 ? launch_pp<DT, 2, 2, 32>(g, s) : launch_pp<DT, 2, 2, 16>(g, s);
+    if (nq == 4) return tw == 32 ? launch_pp<DT, 4, 2, 32, X3>(g, s) : launch_pp<DT, 4, 2, 16, X3>(g, s);
+    if (npg == 4) return tw == 32 ? launch_pp<DT, 2, 4, 32, X3>(g, s) : launch_pp<DT, 2, 4, 16, X3>(g, s);
+    return tw == 32 ? launch_pp<DT, 2, 2, 32, X3>(g, s) : launch_pp<DT, 2, 2, 16, X3>(g, s);
 }
 
 // share of the launch's MFMA work that lands on map pixels, times how full its rounds of workgroups are
@@ -370,6 +398,32 @@ double pp_efficiency(int B, int H, int W, int Cout, int nq, int npg, int tw) {
 }
 
 }  // namespace
+
+static int pick_pp_form(int B, int H, int W, int Cout, int form, int tw, int& bq, int& bg, int& bt) {
+    double best = -1.0;
+    bq = bg = bt = 0;
+    const int cand[6][3] = {{4, 2, 16}, {4, 2, 32}, {2, 4, 16}, {2, 4, 32}, {2, 2, 16}, {2, 2, 32}};
+    for (const auto& c : cand) {
+        if (c[0] == 4 && Cout % 256) continue;
+        if (form && form != c[0] * 10 + c[1]) continue;
+        if (tw && tw != c[2]) continue;
+        const double e = pp_efficiency(B, H, W, Cout, c[0], c[1], c[2]);
+        if (e > best + 0.02) best = e, bq = c[0], bg = c[1], bt = c[2];
+    }
+    return bq;
+}
+
+// X3 form (pair planes in and out, weights [Cout][9][3 Cpl] = [hi | lo | hi] per tap): SGG_OK, or 1 if the shape is not handled
+int sgg_launch_conv_pp_x3(const void* in, const void* w3, const float* bias, void* out, int out_pad, int B, int H, int W, int Cpl, int Cout,
+                          int pool, hipStream_t s) {
+    if (Cpl % 32 || Cout % 128) return 1;
+    ConvPPArgs g{};
+    g.in = (const char*)in; g.w = (const char*)w3; g.bias = bias; g.out = (char*)out;
+    g.B = B; g.H = H; g.W = W; g.Cin = 3 * Cpl; g.Cpl = Cpl; g.Cout = Cout; g.out_pad = out_pad; g.pool = pool;
+    int bq, bg, bt;
+    if (!pick_pp_form(B, H, W, Cout, 0, 0, bq, bg, bt)) return 1;
+    return launch_pp_dt<SGG_F16, true>(g, bq, bg, bt, s);
+}
 
 // returns SGG_OK, or 1 if the shape is not handled here (the caller falls through to the other convolution kernels).
 // form: 0 = choose; 42 = 256 px x 256 ch; 22 = 256 px x 128 ch (four waves); 24 = 512 px x 128 ch.  tw: 16 / 32 = tile width, 0 = choose.

@@ -26,6 +26,8 @@ int sgg_launch_conv1_block(const float* img, const void* w1, const float* b1, co
 int sgg_launch_conv1_pack(const float* w1, void* frags, int dt, hipStream_t s);
 int sgg_launch_conv_pp(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H, int W, int Cin, int Cout,
                        int dt, int pool, int form, int tw, hipStream_t s);  // conv_pp.hip
+int sgg_launch_conv_pp_x3(const void* in, const void* w3, const float* bias, void* out, int out_pad, int B, int H, int W, int Cpl, int Cout,
+                          int pool, hipStream_t s);   // conv_pp.hip
 int sgg_launch_conv_spatial(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H, int W,
                             int Cin, int Cout, int dt, int pool, hipStream_t s);            // conv_spatial.hip
 
@@ -98,7 +100,8 @@ __global__ __launch_bounds__(256) void mfma_tile_kernel(const GemmArgs g) {
                 koff = ((long)(ky * (g.W + 2) + kx) * g.cin_px + (seg == 2 ? g.Cin : 0)) * ESZ + c0 * ROWB;
                 woff = ((long)tap * g.cin_px + (seg == 1 ? g.Cin : 0)) * ESZ + c0 * ROWB;
             } else {
-                const int seg = (kt >= g.x3t) + (kt >= 2 * g.x3t), kk = kt - seg * g.x3t;
+                int seg, kk;
+                x3_tile(g, kt, seg, kk);
                 koff = (long)((seg == 2 ? g.x3t : 0) + kk) * ROWB;
                 woff = (long)((seg == 1 ? g.x3t : 0) + kk) * ROWB;
             }
@@ -435,6 +438,7 @@ int dispatch(GemmArgs g, int dt, hipStream_t s) {
                 g.nt *= 2;
                 g.nt1 *= 2;
                 g.x3t *= 2;
+                g.x3c *= 2;
                 const int rc = sgg_launch_pingpong(g, dt, CONV, s);
                 if (rc != SGG_OK) return rc;
                 return dt == SGG_BF16 ? launch<SGG_BF16, 2, 2, CONV>(tail, s) : launch<SGG_F16, 2, 2, CONV>(tail, s);
@@ -443,6 +447,7 @@ int dispatch(GemmArgs g, int dt, hipStream_t s) {
         g.nt *= 2;   // 64-byte K-tiles
         g.nt1 *= 2;
         g.x3t *= 2;
+        g.x3c *= 2;
         return sgg_launch_pingpong(g, dt, CONV, s);
     }
     const bool narrow = g.N < 128;
@@ -484,6 +489,7 @@ static int gemm_impl(const void* A, int lda, const void* A2, int lda2, int K1, c
     g.nt1 = K1 / bke; g.nt = K / bke;
     if (pair_in) {
         g.x3t = K / bke; g.nt = 3 * g.x3t; g.nt1 = g.nt;
+        g.x3c = x3_chunk_tiles(g.x3t, 8);           // chunks of <= 512 elements per plane
     }
     g.bias = bias; g.pscale = post_scale; g.pshift = post_shift;
     g.C = (char*)C; g.ldc = ldc; g.M = M; g.N = N; g.act = act; g.out_dt = out_dtype;
@@ -569,6 +575,8 @@ extern "C" int sgg_gemm_splitk(const void* A, int lda, const void* W, int ldw, c
     g.nt = K / bke; g.nt1 = g.nt;
     if (pair_in) {
         g.x3t = g.nt; g.nt = 3 * g.x3t; g.nt1 = g.nt;
+        // split-K slices cut the 3 x3t tiles at arbitrary tile boundaries: any order of the (segment, K-tile) pairs sums the same products
+        g.x3c = x3_chunk_tiles(g.x3t, 8);
     }
     g.C = (char*)workspace; g.ldc = N; g.M = M; g.N = N; g.act = SGG_ACT_NONE; g.out_dt = SGG_F32;
     g.splitk_stride = (long)M * N * 4;
@@ -583,6 +591,7 @@ extern "C" int sgg_gemm_splitk(const void* A, int lda, const void* W, int ldw, c
         g.nt *= 2;          // 64-byte K-tiles
         g.nt1 = g.nt;
         g.x3t *= 2;
+        g.x3c *= 2;
         rc = sgg_launch_pingpong_splitk(g, in_dtype, splits, s);
     } else {
         rc = in_dtype == SGG_BF16 ? launch<SGG_BF16, 2, 2, false>(g, s, splits)
@@ -727,6 +736,19 @@ extern "C" int sgg_conv1_block(const float* in_nhwc4, const void* w1, const floa
     return rc <= 0 ? rc : SGG_ERR_ARG;
 }
 
+// The x3 mode's 3x3 convolution + ReLU [+ MaxPool2d(2)] on the patch kernel (conv_pp.hip): `in` a PAIR plane [B, H+2, W+2, 2 Cin] (SGG_PAIR16), `w3`
+// f16 [Cout][9][3 Cin] with tap = [hi | lo | hi] (sgg_split3, weight form), `out` a PAIR plane [B, H+2p, W+2p, 2 Cout] (pool: of the pooled size).
+// Maps of >= 64 cells a side, Cout % 128 == 0, Cin % 32 == 0; SGG_ERR_ARG otherwise (the caller takes sgg_conv3x3_relu's pair form).
+extern "C" int sgg_conv3x3_relu_x3(const void* in, const void* w3, const float* bias, void* out, int out_pad, int B, int H, int W, int Cin, int Cout,
+                                   int pool, void* stream) {
+    if (!in || !w3 || !bias || !out || B <= 0 || H < 64 || W < 64 || Cin % 32 || Cout % 128 || (out_pad != 0 && out_pad != 1)) return SGG_ERR_ARG;
+    if (pool && ((H | W) & 1)) return SGG_ERR_ARG;
+    if ((long)B * (H + 2) * (W + 2) * Cin * 4 > 0xffff0000L || 27L * Cin * Cout * 2 > 0xffff0000L) return SGG_ERR_SPAN;
+    if ((((uintptr_t)in | (uintptr_t)w3 | (uintptr_t)out) & 15)) return SGG_ERR_ARG;
+    const int rc = sgg_launch_conv_pp_x3(in, w3, bias, out, out_pad, B, H, W, Cin, Cout, pool, (hipStream_t)stream);
+    return rc <= 0 ? rc : SGG_ERR_ARG;
+}
+
 extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H,
                                 int W, int Cin, int Cout, int pool, int dtype, int out_dtype, void* stream) {
     // SGG_PAIR16 input: `in` is a pair plane [B, H+2, W+2, 2 Cin] (pixel = [hi (Cin) | lo (Cin)]), `w` [Cout][9][2 Cin] likewise; the
@@ -772,6 +794,7 @@ extern "C" int sgg_conv3x3_relu(const void* in, const void* w, const float* bias
     g.nt = 9 * Cin / bke; g.nt1 = g.nt;
     if (pair_in) {
         g.x3t = Cin / bke; g.nt *= 3; g.nt1 = g.nt; g.cin_px = 2 * Cin;
+        g.x3c = g.x3t;                               // (conv mode walks the three segments per tap: its own chunking)
     }
     g.bias = bias; g.C = (char*)out; g.M = B * H * W; g.N = Cout; g.act = SGG_ACT_RELU;
     g.out_dt = out_dtype;

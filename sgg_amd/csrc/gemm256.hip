@@ -55,7 +55,8 @@ __device__ __forceinline__ long tile_koff(const GemmArgs& g, bool loads_a, int k
             }
             return ((long)tap * g.cin_px + (seg == 1 ? g.Cin : 0)) * esz + c0 * ROW;
         } else {
-            const int seg = (kt >= g.x3t) + (kt >= 2 * g.x3t), kk = kt - seg * g.x3t;
+            int seg, kk;
+            x3_tile(g, kt, seg, kk);
             return (long)((seg == (loads_a ? 2 : 1) ? g.x3t : 0) + kk) * ROW;
         }
     }
@@ -128,9 +129,25 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
     const unsigned vo2_0 = SGG_VO2(0), vo2_1 = SGG_VO2(1), vo2_2 = SGG_VO2(2), vo2_3 = SGG_VO2(3);
 #undef SGG_VO
 #undef SGG_VO2
+    // x3 GEMM on pair operands (plain, not conv): the K-tiles are requested strictly in order (prologue kb .. kb+2, then kt + 3 per iteration),
+    // so (segment, K-tile inside the plane) is a running state instead of two integer divisions per K-tile inside the MFMA phase
+    const bool x3_run = !CONV && !TN && g.x3t != 0;
+    int x3_seg = 0, x3_r = 0, x3_base = 0;          // next tile: chunk base x3_base, segment x3_seg, offset x3_r inside the chunk
+    auto x3_next_koff = [&]() -> long {
+        const int kk = x3_base + x3_r;
+        const long off = (long)((x3_seg == (loads_a ? 2 : 1) ? g.x3t : 0) + kk) * ROW;
+        if (++x3_r == g.x3c) {
+            x3_r = 0;
+            if (++x3_seg == 3) {
+                x3_seg = 0;
+                x3_base += g.x3c;
+            }
+        }
+        return off;
+    };
     auto issue = [&](int kt) {
-        bool seg2;
-        const long koff = tile_koff<CONV, TN>(g, loads_a, kt, tpc, ESZ, seg2);
+        bool seg2 = false;
+        const long koff = x3_run ? x3_next_koff() : tile_koff<CONV, TN>(g, loads_a, kt, tpc, ESZ, seg2);
         const char* ub = uniform_ptr((seg2 ? sbase2 : sbase) + koff - 3072);      // the -3 KiB pairs with the +3 KiB inside vo_*
         char* dst = smem + (kt & (NSTAGE - 1)) * STAGE + lds_rows0;
         glds16_off<0>(ub + (seg2 ? vo2_0 : vo_0), dst);
@@ -235,8 +252,8 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
         }                                                                                                                 \
     }
     auto compute_dma = [&](int pf) {
-        bool seg2;
-        const long koff = tile_koff<CONV, TN>(g, loads_a, pf, tpc, ESZ, seg2);
+        bool seg2 = false;
+        const long koff = x3_run ? x3_next_koff() : tile_koff<CONV, TN>(g, loads_a, pf, tpc, ESZ, seg2);
         const char* ub = uniform_ptr((seg2 ? sbase2 : sbase) + koff - 3072);
         char* dst = smem + (pf & (NSTAGE - 1)) * STAGE + lds_rows0;
         const unsigned o0 = seg2 ? vo2_0 : vo_0, o1 = seg2 ? vo2_1 : vo_1, o2 = seg2 ? vo2_2 : vo_2, o3 = seg2 ? vo2_3 : vo_3;
@@ -287,6 +304,12 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
         const int per = (g.nt + (int)gridDim.y - 1) / (int)gridDim.y;
         kb = min((int)blockIdx.y * per, g.nt);
         nt = min(kb + per, g.nt);
+    }
+    if (x3_run && kb > 0) {          // a split-K slice starts inside the sequence
+        const int c3 = 3 * g.x3c, chunk = kb / c3, r = kb - chunk * c3;
+        x3_seg = (r >= g.x3c) + (r >= 2 * g.x3c);
+        x3_r = r - x3_seg * g.x3c;
+        x3_base = chunk * g.x3c;
     }
     // ---- prologue: tiles kb..kb+2 in flight, tile kb landed and visible
 #pragma unroll

@@ -39,11 +39,26 @@ struct GemmArgs {
     // runs over 3 x3t tiles -- segment 0 (A hi, W hi), 1 (A hi, W lo), 2 (A lo, W hi) -- per tap in conv mode.  Conv mode: Cin = channels
     // per PLANE, cin_px = channels per input pixel (2 Cin for a pair plane; 0 = Cin), the weights' taps are [hi (Cin) | lo (Cin)] as well.
     int x3t, cin_px;
+    int x3c;                    // plain GEMM: the three segments are walked CHUNK by chunk of x3c K-tiles (x3c divides x3t): (A hi, W hi), (A hi, W lo),
+                                // (A lo, W hi) of one K range back to back, so the second use of a hi panel finds it in L2 instead of re-streaming it
     // output: out_dt == SGG_PAIR16 writes hi at the element offset and lo pair_off elements further; conv mode: cout_px = elements per
     // output pixel (2 N for a pair plane; 0 = N)
     long pair_off;
     int cout_px;
 };
+
+// K-tile kt of an x3 GEMM on pair operands -> (segment 0..2, K-tile inside the plane): chunks of x3c tiles, the three segments per chunk
+__device__ __forceinline__ void x3_tile(const GemmArgs& g, int kt, int& seg, int& kk) {
+    const int c3 = 3 * g.x3c;
+    const int chunk = kt / c3, r = kt - chunk * c3;
+    seg = (r >= g.x3c) + (r >= 2 * g.x3c);
+    kk = chunk * g.x3c + (r - seg * g.x3c);
+}
+static inline int x3_chunk_tiles(int x3t, int max_c) {          // host: the largest divisor of x3t that is <= max_c
+    int c = x3t < max_c ? x3t : max_c;
+    while (c > 1 && x3t % c) --c;
+    return c < 1 ? 1 : c;
+}
 
 __device__ __forceinline__ void glds16(const char* g, char* l) {
     __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)l, 16, 0, 0);

@@ -150,8 +150,12 @@ class VGGDetector(nn.Module):
         x = self._buf('p0', (B, H + 2, W + 2, 128), f16, dev, True)
         ops.conv1_1(x0, w, bias, x, pair=True)
         ci_layer, n_conv = 1, len(ws)
+        skip_pool = False
         for li in range(1, len(cfg)):
             v = cfg[li]
+            if v == 'M' and skip_pool:            # (rode in the previous convolution's epilogue)
+                skip_pool = False
+                continue
             if v == 'M':
                 C = x.shape[3] // 2
                 y = self._buf('p%d' % li, (B, H // 2 + 2, W // 2 + 2, 2 * C), f16, dev, True)
@@ -165,6 +169,16 @@ class VGGDetector(nn.Module):
                         assert tuple(out.shape) == (B, H, W, co) and out.dtype == torch.float32 and out.is_contiguous()
                     y = out if out is not None else torch.empty((B, H, W, co), dtype=torch.float32, device=dev)
                     ops.conv3x3_relu_pair(x, w.view(co, 3, 3, ci), bias, y, 0, pair_out=False)
+                elif ops.conv_pp_x3_ok(H, W, ci, co):
+                    # conv2_1 .. conv4_3: the LDS-resident patch kernel's x3 form, the block's MaxPool2d(2) in its epilogue
+                    pool = li + 1 < len(cfg) and cfg[li + 1] == 'M' and H % 2 == 0 and W % 2 == 0
+                    if pool:
+                        y = self._buf('p%d' % (li + 1), (B, H // 2 + 2, W // 2 + 2, 2 * co), f16, dev, True)
+                        H, W = H // 2, W // 2
+                        skip_pool = True
+                    else:
+                        y = self._buf('p%d' % li, (B, H + 2, W + 2, 2 * co), f16, dev, True)
+                    ops.conv3x3_relu_x3pp(x, w.view(co, 3, 3, ci), bias, y, 1, pool=pool)
                 else:
                     y = self._buf('p%d' % li, (B, H + 2, W + 2, 2 * co), f16, dev, True)
                     ops.conv3x3_relu_pair(x, w.view(co, 3, 3, ci), bias, y, 1, pair_out=True)

@@ -210,6 +210,23 @@ def conv3x3_relu(x, w, bias, out, out_pad, pool=False):
               dt(x), dt(out), _stream())
 
 
+def conv_pp_x3_ok(H, W, Cin, Cout):
+    """shapes the patch kernel's x3 form takes (sgg_conv3x3_relu_x3: pair plane in and out, optional fused 2x2 max pool)"""
+    return H >= 64 and W >= 64 and Cin % 64 == 0 and Cout % 128 == 0 and os.environ.get('SGG_X3_CONV_PP', '1') != '0'
+
+
+def conv3x3_relu_x3pp(xp, w, bias, out, out_pad, pool=False):
+    """the x3 convolution on the LDS-resident patch kernel (conv_pp.hip): pair plane in, pair plane out (pooled with pool=True)"""
+    B, H, W, Cin = xp.shape[0], xp.shape[1] - 2, xp.shape[2] - 2, xp.shape[3] // 2
+    Cout = w.shape[0]
+    assert xp.dtype == out.dtype == torch.float16 and out.shape[3] == 2 * Cout and conv_pp_x3_ok(H, W, Cin, Cout)
+    w3 = split3(w.reshape(Cout * 9, Cin), weights=True)                # [Cout * 9, 3 Cin]: tap = [hi | lo | hi]
+    step = max(1, SPAN_LIMIT // (xp.shape[1] * xp.shape[2] * 2 * Cin * 2))
+    for b0 in range(0, B, step):
+        xb = xp[b0:b0 + step]
+        _lib.call('sgg_conv3x3_relu_x3', _p(xb), _p(w3), _p(bias, torch.float32), _p(out[b0:b0 + step]), out_pad, xb.shape[0], H, W, Cin, Cout, int(pool), _stream())
+
+
 def conv3x3_relu_pair(xp, w, bias, out, out_pad, pair_out):
     """x3 mode on PAIR planes (include/sgg_hip.h SGG_PAIR16): xp f16 [B, H+2, W+2, 2 Cin] zero-bordered (pixel = [hi | lo]), w f32
     [Cout, 3, 3, Cin] (its pair form [Cout, 9, 2 Cin] is made once per weight version and cached); out: a pair plane

@@ -229,6 +229,43 @@ def test_pair_operand_gemm_conv_pool_kernels(ops):
     assert torch.equal(pp[..., :64], ref.half()) and torch.equal(pp[..., 64:], (ref - ref.half().float()).half())
 
 
+@pytest.mark.parametrize('shape', [(2, 152, 152, 128, 256, False), (2, 152, 152, 256, 256, True), (1, 304, 304, 64, 128, False),
+                                   (1, 304, 296, 128, 128, True), (3, 76, 76, 256, 512, True), (1, 100, 70, 64, 256, False)])
+def test_x3_convolution_on_the_patch_kernel(ops, shape):
+    """sgg_conv3x3_relu_x3 (conv_pp.hip, X3 form: pair plane in, weights [hi | lo | hi] per tap, pair plane out from the fp32 accumulator,
+    optional fused 2x2 max pool) against a float64 convolution and against the implicit-GEMM pair form (same products, another order)"""
+    import torch.nn.functional as F
+    B, H, W, Cin, Cout, pool = shape
+    g = torch.Generator().manual_seed(H + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g).relu().to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    want = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    if pool:
+        want = F.max_pool2d(want, 2)
+    want = want.permute(0, 2, 3, 1)
+    xp = torch.zeros(B, H + 2, W + 2, 2 * Cin, dtype=torch.float16, device=DEV)
+    xp[:, 1:-1, 1:-1] = ops.split2(x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous()).view(B, H, W, 2 * Cin)
+    wk = w.permute(0, 2, 3, 1).contiguous()
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    out = torch.zeros(B, Ho + 2, Wo + 2, 2 * Cout, dtype=torch.float16, device=DEV)
+    assert ops.conv_pp_x3_ok(H, W, Cin, Cout)
+    ops.conv3x3_relu_x3pp(xp, wk, b, out, 1, pool=pool)
+    inner = out[:, 1:-1, 1:-1]
+    got = inner[..., :Cout].double() + inner[..., Cout:].double()
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-5 * scale, (shape, float((got - want).abs().max()), scale)
+    assert float(out[:, 0].abs().max()) == 0 and float(out[:, -1].abs().max()) == 0 and float(out[:, :, 0].abs().max()) == 0 and float(out[:, :, -1].abs().max()) == 0
+    ref = torch.zeros(B, H + 2, W + 2, 2 * Cout, dtype=torch.float16, device=DEV)
+    ops.conv3x3_relu_pair(xp, wk, b, ref, 1, pair_out=True)
+    if pool:
+        pooled = torch.zeros_like(out)
+        ops.maxpool2x2_pair(ref, pooled, 1)
+        ref = pooled
+    r = ref[:, 1:-1, 1:-1]
+    assert float((got - (r[..., :Cout].double() + r[..., Cout:].double())).abs().max()) <= 4e-6 * scale
+
+
 def test_x3_with_f16_backward_keeps_the_forward_and_gives_f16_grade_gradients(ops):
     """set_compute_dtype(float32, split3=True, backward_f16=True): the train-mode forward is the x3 forward bit for bit (logits inside the
     1e-3 clause), the backward's contractions round their operands to f16 once under the loss scale -- every head gradient within 1 % of
