@@ -184,7 +184,7 @@ def kernel_times(step_fn, reps):
 def pmc_traffic(key):
     """HBM-side bytes per launch READ FROM the committed rocprofv3 PMC passes (profiles/pmc_r04.json, else earlier rounds') -- collected
     by tools/pmc_traffic.sh on the same workload, not measured inside this run -- or None."""
-    for name in ('pmc_r04.json', 'pmc_r03.json', 'pmc_r02.json', 'pmc_r01.json'):
+    for name in ('pmc_r06.json', 'pmc_r05.json', 'pmc_r04.json', 'pmc_r03.json', 'pmc_r02.json', 'pmc_r01.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 return json.load(f)[key]['traffic_bytes']
@@ -1214,8 +1214,10 @@ def main():
                              'train_steps': kt_, 'train_warmup': wt, 'infer_steps': ki, 'infer_warmup': wi,
                              'mfma_peak_TFLOPs': round(MFMA_PEAK_TF['f16'] / 3.0, 1) if split else MFMA_PEAK_TF['f32'],
                              'note': ('same workload: three f16 MFMA products per fp32-grade product (hi.hi + hi.lo + lo.hi), logits within 1e-3 of the '
-                                      'fp32 reference (profiles/r0x_parity_bench_config.json: x3); %d (train) / %d (inference) warm-up + %d / %d timed steps, '
-                                      'launch by launch (no hipGraph replay in this mode)' % (wt, wi, kt_, ki))
+                                      'fp32 reference (profiles/r0x_parity_bench_config.json: x3).  Round 6: activations and weights as PAIRS of f16 planes '
+                                      '(SGG_PAIR16), the MFMA loops walk the plane segments themselves, VGG-16 writes pair planes from its epilogues (no split '
+                                      'pass, conv2_1 .. conv4_3 on the patch kernel with the pools fused).  %d (train) / %d (inference) warm-up + %d / %d timed '
+                                      'steps, launch by launch (no hipGraph replay in this mode)' % (wt, wi, kt_, ki))
                              if split else 'same workload, exact-fp32 MFMA; 4 (train) / 2 (inference) warm-up + 5 timed steps'}
                 if split:
                     # the same mode with an f16 BACKWARD (set_compute_dtype(float32, split3=True, backward_f16=True)): the forward -- what both parity
