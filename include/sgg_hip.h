@@ -75,7 +75,8 @@ int sgg_conv1_block(const float* in_nhwc4, const void* w1_frags, const float* b1
 /* The x3 mode's 3x3 convolution (pad 1) + bias + ReLU [+ MaxPool2d(2)] on PAIR planes (SGG_PAIR16), patch kernel form: `in` [B, H+2, W+2, 2 Cin]
  * zero-bordered with pixel = [hi (Cin) | lo (Cin)]; `w3` f16 [Cout][9][3 Cin] with tap = [hi | lo | hi] (sgg_split3 mode 1 of the [Cout * 9, Cin]
  * weight matrix); `out` [B, H+2p, W+2p, 2 Cout] (pool = 1: [B, H/2+2p, W/2+2p, 2 Cout]), hi / lo made from the fp32 accumulator after bias,
- * ReLU and the pool.  H, W >= 64, Cout % 128 == 0, Cin % 32 == 0, else SGG_ERR_ARG (use sgg_conv3x3_relu with dtype SGG_PAIR16).
+ * ReLU and the pool.  H, W >= 64, Cout % 128 == 0 and Cin % 32 == 0 (conv_pp.hip) or Cout % 64 == 0 and Cin % 64 == 0 (conv_spatial.hip),
+ * else SGG_ERR_ARG (use sgg_conv3x3_relu with dtype SGG_PAIR16).
  * Replaces: [3P] vgg16.features' conv + ReLU (+ pool) pairs at fp32 grade (sgg_models/rel_model_base.py:184,310-312). */
 int sgg_conv3x3_relu_x3(const void* in, const void* w3, const float* bias, void* out, int out_pad, int B, int H, int W, int Cin, int Cout,
                         int pool, void* stream);

@@ -44,6 +44,9 @@ struct ConvArgs {
     const float* img;
     const char* w1f;
     const float* b1;
+    // X3 form (x3 mode on PAIR planes, as conv_pp.hip's): `in` [B, H+2, W+2, 2 Cpl] with pixel = [hi (Cpl) | lo (Cpl)], `w` [Cout][9][3 Cpl] with
+    // tap = [hi | lo | hi], Cin = 3 Cpl virtual channels; `out` a pair plane [.., 2 Cout] from the fp32 accumulator (bias, ReLU, pool, split)
+    int Cpl;
 };
 
 #ifndef SGG_CONV_WPE
@@ -53,8 +56,9 @@ struct ConvArgs {
 // padded to 32 = two MFMA k-steps per 32 pixels and 32 channels) + bias + ReLU of the 20x20 image patch, written straight into the
 // swizzled LDS patch; patch pixels outside the image are conv1_2's zero padding.  conv1_1's full-resolution output (the largest
 // activation of the network: 0.36 GB per 8 frames, written once and read 1.27x) never exists; +6 % MFMA work for the halo.
-template <int DT, int WN, int NI, bool ONEBAR, bool FUSE1 = false>
+template <int DT, int WN, int NI, bool ONEBAR, bool FUSE1 = false, bool X3 = false>
 __global__ __launch_bounds__(256 * WN, SGG_CONV_WPE) void conv3x3_spatial_kernel(const ConvArgs g) {
+    static_assert(!X3 || (DT == SGG_F16 && !FUSE1), "X3 form: f16 planes");
     constexpr int NW = 4 * WN, CNW = 32 * NI, CN = CNW * WN;   // channels per wave / per block
     constexpr int ESZ = DT == SGG_F32 ? 4 : 2;
     constexpr int PATCH_B = PROWS_PAD * RB, WSLAB_B = CN * RB;
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256 * WN, SGG_CONV_WPE) void conv3x3_spatial_kernel
         const int py = r / PW, px = r - py * PW;
         const int gy = min(y0 + py, g.H + 1), gx = min(x0 + px, g.W + 1);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        psrc[j] = (unsigned)((((long)b * (g.H + 2) + gy) * (g.W + 2) + gx) * g.Cin * ESZ + chunk * 16);
+        psrc[j] = (unsigned)((((long)b * (g.H + 2) + gy) * (g.W + 2) + gx) * (X3 ? 2 * g.Cpl : g.Cin) * ESZ + chunk * 16);
     }
     unsigned wsrc[WI_W];
 #pragma unroll
@@ -100,7 +104,13 @@ __global__ __launch_bounds__(256 * WN, SGG_CONV_WPE) void conv3x3_spatial_kernel
         wsrc[j] = (unsigned)((long)(n0 + r) * 9 * g.Cin * ESZ + chunk * 16);
     }
     auto stage_patch = [&](int chunk) {
-        const char* ub = uniform_ptr(g.in + (long)chunk * RB);
+        long poff = (long)chunk * RB;
+        if constexpr (X3) {                                   // virtual slab -> (plane, slab inside the plane)
+            const int nc = g.Cpl * ESZ / RB;
+            const int seg = (chunk >= nc) + (chunk >= 2 * nc);
+            poff = (long)(chunk - seg * nc) * RB + (seg == 2 ? (long)g.Cpl * ESZ : 0);
+        }
+        const char* ub = uniform_ptr(g.in + poff);
 #pragma unroll
         for (int j = 0; j < PI_W; ++j)
             if (wave + j * NW < PI) glds16_su(ub, psrc[j], patch + (wave + j * NW) * 8 * RB);
@@ -327,6 +337,19 @@ __global__ __launch_bounds__(256 * WN, SGG_CONV_WPE) void conv3x3_spatial_kernel
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] + bias8[k], 0.f);
                 const int op = g.out_pad, Ho = g.H >> 1, Wo = g.W >> 1;
+                if constexpr (X3) {
+                    float lo8[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float h = round_as<f16_t>(v[k]);
+                        lo8[k] = v[k] - h;
+                        v[k] = h;
+                    }
+                    f16_t* o = reinterpret_cast<f16_t*>(g.out) + (((long)b * (Ho + 2 * op) + yo + op) * (Wo + 2 * op) + xo + op) * 2 * g.Cout + n;
+                    store8(o, v);
+                    store8(o + g.Cout, lo8);
+                    continue;
+                }
                 const long off = (((long)b * (Ho + 2 * op) + yo + op) * (Wo + 2 * op) + xo + op) * g.Cout + n;
                 if constexpr (DT == SGG_BF16) store8(reinterpret_cast<bf16_t*>(g.out) + off, v);
                 else if constexpr (DT == SGG_F16) store8(reinterpret_cast<f16_t*>(g.out) + off, v);
@@ -347,6 +370,19 @@ __global__ __launch_bounds__(256 * WN, SGG_CONV_WPE) void conv3x3_spatial_kernel
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] + bias8[k], 0.f);
             const int op = g.out_pad;
+            if constexpr (X3) {
+                float lo8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float h = round_as<f16_t>(v[k]);
+                    lo8[k] = v[k] - h;
+                    v[k] = h;
+                }
+                f16_t* o = reinterpret_cast<f16_t*>(g.out) + (((long)b * (g.H + 2 * op) + y + op) * (g.W + 2 * op) + x + op) * 2 * g.Cout + n;
+                store8(o, v);
+                store8(o + g.Cout, lo8);
+                continue;
+            }
             const long off = (((long)b * (g.H + 2 * op) + y + op) * (g.W + 2 * op) + x + op) * g.Cout + n;
             if (SGG_CONV_ABL == 2) continue;
             if constexpr (DT == SGG_BF16) store8(reinterpret_cast<bf16_t*>(g.out) + off, v);
@@ -356,13 +392,13 @@ __global__ __launch_bounds__(256 * WN, SGG_CONV_WPE) void conv3x3_spatial_kernel
     }
 }
 
-template <int DT, int WN, int NI, bool ONEBAR = false, bool FUSE1 = false>
+template <int DT, int WN, int NI, bool ONEBAR = false, bool FUSE1 = false, bool X3 = false>
 int launch_spatial(const ConvArgs& g, hipStream_t s) {
     constexpr int CN = 32 * NI * WN;
     constexpr int smem_main = PROWS_PAD * RB + 2 * CN * RB + (FUSE1 ? 400 * 16 : 0), smem_epi = 4 * WN * 32 * (32 * NI * 4 + 16);   // operand tiles | epilogue staging
     constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
     static_assert(smem <= 160 * 1024, "fits the CU's LDS");
-    auto k = conv3x3_spatial_kernel<DT, WN, NI, ONEBAR, FUSE1>;
+    auto k = conv3x3_spatial_kernel<DT, WN, NI, ONEBAR, FUSE1, X3>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -398,6 +434,21 @@ int sgg_launch_conv_spatial(const void* in, const void* w, const float* bias, vo
     if (Cout % 64 == 0)
         return dt == SGG_BF16 ? launch_spatial<SGG_BF16, 1, 2>(g, s) : dt == SGG_F16 ? launch_spatial<SGG_F16, 1, 2>(g, s) : launch_spatial<SGG_F32, 1, 2>(g, s);
     return 1;
+}
+
+// X3 form (pair planes, weights [hi | lo | hi] per tap): the 64-channel layer of VGG-16 (conv1_2) and anything else the patch kernel of
+// conv_pp.hip does not take.  SGG_OK, or 1 if the shape is not handled.
+int sgg_launch_conv_spatial_x3(const void* in, const void* w3, const float* bias, void* out, int out_pad, int B, int H, int W, int Cpl, int Cout,
+                               int pool, hipStream_t s) {
+    if (Cpl % 64 || Cout % 64) return 1;
+    ConvArgs g{};
+    g.pool = pool;
+    g.in = (const char*)in; g.w = (const char*)w3; g.bias = bias; g.out = (char*)out;
+    g.B = B; g.H = H; g.W = W; g.Cin = 3 * Cpl; g.Cpl = Cpl; g.Cout = Cout; g.out_pad = out_pad;
+    g.tiles_x = (W + TILE - 1) / TILE;
+    g.tiles_y = (H + TILE - 1) / TILE;
+    if (Cout % 128 == 0) return launch_spatial<SGG_F16, 2, 2, false, false, true>(g, s);
+    return launch_spatial<SGG_F16, 1, 2, false, false, true>(g, s);
 }
 
 namespace {

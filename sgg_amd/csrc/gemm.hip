@@ -28,6 +28,8 @@ int sgg_launch_conv_pp(const void* in, const void* w, const float* bias, void* o
                        int dt, int pool, int form, int tw, hipStream_t s);  // conv_pp.hip
 int sgg_launch_conv_pp_x3(const void* in, const void* w3, const float* bias, void* out, int out_pad, int B, int H, int W, int Cpl, int Cout,
                           int pool, hipStream_t s);   // conv_pp.hip
+int sgg_launch_conv_spatial_x3(const void* in, const void* w3, const float* bias, void* out, int out_pad, int B, int H, int W, int Cpl, int Cout,
+                               int pool, hipStream_t s);   // conv_spatial.hip
 int sgg_launch_conv_spatial(const void* in, const void* w, const float* bias, void* out, int out_pad, int B, int H, int W,
                             int Cin, int Cout, int dt, int pool, hipStream_t s);            // conv_spatial.hip
 
@@ -741,11 +743,12 @@ extern "C" int sgg_conv1_block(const float* in_nhwc4, const void* w1, const floa
 // Maps of >= 64 cells a side, Cout % 128 == 0, Cin % 32 == 0; SGG_ERR_ARG otherwise (the caller takes sgg_conv3x3_relu's pair form).
 extern "C" int sgg_conv3x3_relu_x3(const void* in, const void* w3, const float* bias, void* out, int out_pad, int B, int H, int W, int Cin, int Cout,
                                    int pool, void* stream) {
-    if (!in || !w3 || !bias || !out || B <= 0 || H < 64 || W < 64 || Cin % 32 || Cout % 128 || (out_pad != 0 && out_pad != 1)) return SGG_ERR_ARG;
+    if (!in || !w3 || !bias || !out || B <= 0 || H < 64 || W < 64 || Cin % 32 || Cout % 64 || (out_pad != 0 && out_pad != 1)) return SGG_ERR_ARG;
     if (pool && ((H | W) & 1)) return SGG_ERR_ARG;
     if ((long)B * (H + 2) * (W + 2) * Cin * 4 > 0xffff0000L || 27L * Cin * Cout * 2 > 0xffff0000L) return SGG_ERR_SPAN;
     if ((((uintptr_t)in | (uintptr_t)w3 | (uintptr_t)out) & 15)) return SGG_ERR_ARG;
-    const int rc = sgg_launch_conv_pp_x3(in, w3, bias, out, out_pad, B, H, W, Cin, Cout, pool, (hipStream_t)stream);
+    int rc = Cout % 128 == 0 ? sgg_launch_conv_pp_x3(in, w3, bias, out, out_pad, B, H, W, Cin, Cout, pool, (hipStream_t)stream) : 1;
+    if (rc > 0) rc = sgg_launch_conv_spatial_x3(in, w3, bias, out, out_pad, B, H, W, Cin, Cout, pool, (hipStream_t)stream);     // (64-channel layers)
     return rc <= 0 ? rc : SGG_ERR_ARG;
 }
 

@@ -212,7 +212,7 @@ def conv3x3_relu(x, w, bias, out, out_pad, pool=False):
 
 def conv_pp_x3_ok(H, W, Cin, Cout):
     """shapes the patch kernel's x3 form takes (sgg_conv3x3_relu_x3: pair plane in and out, optional fused 2x2 max pool)"""
-    return H >= 64 and W >= 64 and Cin % 64 == 0 and Cout % 128 == 0 and os.environ.get('SGG_X3_CONV_PP', '1') != '0'
+    return H >= 64 and W >= 64 and Cin % 64 == 0 and Cout % 64 == 0 and os.environ.get('SGG_X3_CONV_PP', '1') != '0'
 
 
 def conv3x3_relu_x3pp(xp, w, bias, out, out_pad, pool=False):

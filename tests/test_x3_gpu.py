@@ -230,7 +230,7 @@ def test_pair_operand_gemm_conv_pool_kernels(ops):
 
 
 @pytest.mark.parametrize('shape', [(2, 152, 152, 128, 256, False), (2, 152, 152, 256, 256, True), (1, 304, 304, 64, 128, False),
-                                   (1, 304, 296, 128, 128, True), (3, 76, 76, 256, 512, True), (1, 100, 70, 64, 256, False)])
+                                   (1, 304, 296, 128, 128, True), (3, 76, 76, 256, 512, True), (1, 100, 70, 64, 256, False), (2, 304, 304, 64, 64, True), (1, 96, 120, 64, 64, False), (1, 80, 80, 128, 192, True)])
 def test_x3_convolution_on_the_patch_kernel(ops, shape):
     """sgg_conv3x3_relu_x3 (conv_pp.hip, X3 form: pair plane in, weights [hi | lo | hi] per tap, pair plane out from the fp32 accumulator,
     optional fused 2x2 max pool) against a float64 convolution and against the implicit-GEMM pair form (same products, another order)"""
