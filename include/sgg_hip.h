@@ -339,18 +339,6 @@ int sgg_ce_fwd_bwd(const float* logits, int ld, const int64_t* labels, int label
                    int mode, float alpha, float beta, void* stream);
 /* counts[0] (+)= #{labels > 0}, counts[1] (+)= #{labels == 0} as f32 (M_FG, M_BG of lib/losses.py:29-34; M < 2^24). */
 int sgg_label_counts(const int64_t* labels, int label_stride, int M, float* counts, int accumulate, void* stream);
-/* Stream-K scheduling of the 256x256 ping-pong GEMM launches of `stream` (csrc/tile_sched.h, csrc/gemm256_sk.hip): with a workspace
- * registered and the mode switched on, a launch whose tile count is not a multiple of the CU count runs as ONE persistent launch (grid =
- * CUs) in which the last round's K-tiles are spread over all CUs; a split tile is one accumulation chain handed from one workgroup to
- * the next through the workspace, so every output bit equals the plain launch's.  ws: sgg_streamk_workspace_bytes() bytes of device
- * memory, 256-byte aligned, its first 1 KiB (the flag words) zeroed ONCE by the caller; it must outlive every launch on `stream`.  One
- * workspace per stream (launches of a stream are ordered); ws = NULL forgets the stream.  OFF by default (sgg_streamk_mode / the
- * environment variable SGG_STREAMK): correct and bit-identical, measured no faster than the plain launches yet. */
-int64_t sgg_streamk_workspace_bytes(void);
-int sgg_streamk_workspace(void* stream, void* ws, int64_t bytes);
-/* 0: never (default); 1: wherever it applies; 2: where a plain launch would leave >= 4 % of its tile slots empty; 3: tests; other values: query only.
- * Returns the previous mode. */
-int sgg_streamk_mode(int mode);
 /* out[N] = column sums of x[M,N] (row stride ld): bias gradients.  ws: f32[64 * N] (may be NULL when M <= 512). */
 int sgg_colsum(const void* x, int M, int N, int ld, float* out, float* ws, int dtype, void* stream);
 /* train-mode BatchNorm2d of the rect conv (lib/get_union_boxes.py:54,58) on row-major [rows, C] activations:

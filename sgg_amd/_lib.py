@@ -87,9 +87,6 @@ SIGNATURES = {
     'sgg_act_bwd': [_P, _P, _P, _L, _F, _I, _I, _P],
     'sgg_ce_fwd_bwd': [_P, _I, _P, _I, _I, _I, _P, _F, _F, _P, _I, _P, _I, _P, _P, _I, _I, _F, _F, _P],
     'sgg_label_counts': [_P, _I, _I, _P, _I, _P],
-    'sgg_streamk_workspace_bytes': [],
-    'sgg_streamk_workspace': [_P, _P, _L],
-    'sgg_streamk_mode': [_I],
     'sgg_colsum': [_P, _I, _I, _I, _P, _P, _I, _P],
     'sgg_bn_stats': [_P, _I, _I, _P, _P, _I, _P],
     'sgg_bn_finalize': [_P, _I, _I, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],
@@ -118,7 +115,7 @@ SIGNATURES = {
     'sgg_cast': [_P, _P, _L, _I, _I, _P],
     'sgg_permute_ncp_to_npc': [_P, _P, _I, _I, _I, _I, _I, _P],
 }
-_RESTYPE = {'sgg_build_info': c_char_p, 'sgg_streamk_workspace_bytes': c_int64}
+_RESTYPE = {'sgg_build_info': c_char_p}
 
 _ERRORS = {-1: (ValueError, 'bad argument (size / alignment / null pointer)'),
            -2: (TypeError, 'unsupported element type'),

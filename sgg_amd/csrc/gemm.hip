@@ -20,7 +20,6 @@
 int sgg_launch_pingpong(const GemmArgs& g, int dt, bool conv, hipStream_t s);  // gemm256.hip
 int sgg_launch_pingpong_tn(const GemmArgs& g, int dt, int splits, hipStream_t s);                 // gemm256.hip: TN form (g.nt in 32-row K-tiles)
 int sgg_launch_pingpong_splitk(const GemmArgs& g, int dt, int splits, hipStream_t s);  // gemm256.hip
-int sgg_pingpong_streamk(long tiles, int nt, void* stream, int* dp_rounds, int* sk_tiles);   // gemm256.hip: 1 = such a launch takes the stream-K form
 int sgg_launch_conv1_block(const float* img, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int out_pad, int B,
                            int H, int W, int dt, int pool, hipStream_t s);  // conv_spatial.hip
 int sgg_launch_conv1_pack(const float* w1, void* frags, int dt, hipStream_t s);
@@ -430,10 +429,7 @@ int dispatch(GemmArgs g, int dt, hipStream_t s) {
             const long tail_max = tmax ? atol(tmax) : 112;
             const int tN = (g.N + 255) / 256;
             const long rem = tiles256 % N_CU_CHIP;
-            // (none of that when the launch's stream has a stream-K workspace: the persistent form of the kernel spreads the tail's K-tiles
-            // over all CUs itself, tile_sched.h)
-            if (dt != SGG_F32 && !notail && g.m_base == 0 && tiles256 > N_CU_CHIP && rem > 0 && rem <= tail_max && (tiles256 - rem) % tN == 0 &&
-                !sgg_pingpong_streamk(tiles256, g.nt * 2, (void*)s, nullptr, nullptr)) {
+            if (dt != SGG_F32 && !notail && g.m_base == 0 && tiles256 > N_CU_CHIP && rem > 0 && rem <= tail_max && (tiles256 - rem) % tN == 0) {
                 GemmArgs tail = g;
                 tail.m_base = (int)((tiles256 - rem) / tN) * 256;
                 g.M = tail.m_base;

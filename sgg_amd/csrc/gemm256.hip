@@ -379,7 +379,7 @@ __global__ __launch_bounds__(512) void mfma_pingpong_kernel(const GemmArgs g) {
     gs.C = g.C + (long)blockIdx.y * g.splitk_stride;
     const GemmArgs& g_ = gs;
     // Lean form for the common case (an interior tile of a plain GEMM: bias, ReLU, optionally the group addend of fc6's weight gradient).
-    // tools/sk_trace.py timed the general form below at 10-15 us of a 140-us tile -- not memory, VALU ISSUE: ~4000 instructions per
+    // s_memrealtime stamps (round 4) timed the general form below at 10-15 us of a 140-us tile -- not memory, VALU ISSUE: ~4000 instructions per
     // wave (64-bit address arithmetic and bounds tests per store, an integer division per group-addend column, loads between the
     // stores that each wait for the previous store's round trip) at 4 cycles each and two waves per SIMD.  Here: every global load
     // (bias, the lane's 16 x 2 group addends) BEFORE the first store; ONE 32-bit lane offset into a buffer descriptor of C, the row
@@ -499,13 +499,8 @@ int launch256(const GemmArgs& g, hipStream_t s, int splits = 1) {
 
 }  // namespace
 
-int sgg_launch_pingpong_sk(const GemmArgs& g, int dt, bool conv, hipStream_t s);   // gemm256_sk.hip: the persistent stream-K form, or 1
-
 // g.nt / g.nt1 are in units of 64-byte K-tiles here
 int sgg_launch_pingpong(const GemmArgs& g, int dt, bool conv, hipStream_t s) {
-    // a launch whose last round of tiles would be partly empty takes the persistent stream-K form when its stream has a workspace
-    const int rc = sgg_launch_pingpong_sk(g, dt, conv, s);
-    if (rc <= 0) return rc;
     if (dt == SGG_BF16) return conv ? launch256<SGG_BF16, true>(g, s) : launch256<SGG_BF16, false>(g, s);
     if (dt == SGG_F16) return conv ? launch256<SGG_F16, true>(g, s) : launch256<SGG_F16, false>(g, s);
     return conv ? launch256<SGG_F32, true>(g, s) : launch256<SGG_F32, false>(g, s);

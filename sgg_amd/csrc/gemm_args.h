@@ -29,12 +29,6 @@ struct GemmArgs {
     long splitk_stride;         // bytes between the fp32 partial outputs of consecutive K splits (gridDim.y > 1)
     // conv mode: A is a zero-bordered NHWC plane [B,H+2,W+2,Cin]; C is [B,H+2p,W+2p,N]
     int H, W, Cin, out_pad;
-    // stream-K form of the ping-pong kernel (tile_sched.h): the last sk_tiles tiles (in logical tile order) are cut into equal K-unit
-    // ranges over the grid's workgroups, the dp_rounds * gridDim.x tiles before them run one per workgroup and round
-    char* sk_ws;                // partial-accumulator slots, one per workgroup (SK_SLOT_BYTES each)
-    unsigned* sk_flags;         // one word per slot: the epoch of the launch that published it
-    unsigned sk_epoch;
-    int sk_dp_rounds, sk_tiles;
     // x3 mode on PAIR operands (SGG_PAIR16: a row / pixel is [hi | lo], two f16 planes): x3t = K-tiles per plane (0 = off).  The K loop then
     // runs over 3 x3t tiles -- segment 0 (A hi, W hi), 1 (A hi, W lo), 2 (A lo, W hi) -- per tap in conv mode.  Conv mode: Cin = channels
     // per PLANE, cin_px = channels per input pixel (2 Cin for a pair plane; 0 = Cin), the weights' taps are [hi (Cin) | lo (Cin)] as well.

@@ -669,10 +669,19 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const T* __restrict_
                 float sy, by, sx, bx;
                 roi_axis(rois, pairs, rr, 0, scale, sy, by, P);
                 roi_axis(rois, pairs, rr, 1, scale, sx, bx, P);
-                for (int ph = 0; ph < P; ++ph) {
+                // only the bins whose sample coordinates can reach this cell (a superset by one bin on each side; bins outside it have weight 0
+                // and were skipped one by one before round 6 -- 49 weight evaluations per RoI and cell where 4 - 9 matter: 6.9 -> ms of the GAN
+                // iteration's two launches); same bins, same ascending order: the same sum
+                int ph0 = max(0, (int)floorf(((float)y - 1.f - sy) / by) - 1), ph1 = min(P - 1, (int)floorf(((float)y + 1.f - sy) / by) + 1);
+                int pw0 = max(0, (int)floorf(((float)x - 1.f - sx) / bx) - 1), pw1 = min(P - 1, (int)floorf(((float)x + 1.f - sx) / bx) + 1);
+                if (y == 0) ph0 = 0;
+                if (y == H - 1) ph1 = P - 1;
+                if (x == 0) pw0 = 0;
+                if (x == W - 1) pw1 = P - 1;
+                for (int ph = ph0; ph <= ph1; ++ph) {
                     const float wy = roi_bin_weight(sy, by, ph, S, H, y);
                     if (wy == 0.f) continue;
-                    for (int pw = 0; pw < P; ++pw) {
+                    for (int pw = pw0; pw <= pw1; ++pw) {
                         const float wx = roi_bin_weight(sx, bx, pw, S, W, x);
                         if (wx == 0.f) continue;
                         const float w = wy * wx * inv;

@@ -75,7 +75,6 @@ def node_lane(device):
     key = (device.type, device.index)
     if key not in _SIDE:
         _SIDE[key] = (torch.cuda.Stream(device=device), torch.cuda.Event(), torch.cuda.Event())
-        ops.streamk_enable(_SIDE[key][0], device)       # the lane launches big GEMMs too (weight gradients): its own stream-K workspace
     return _SIDE[key]
 
 

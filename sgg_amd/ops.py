@@ -44,53 +44,6 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-_streamk_ws = {}     # (device index, raw stream) -> workspace tensor registered with the library (kept alive here)
-
-
-def streamk_enable(stream=None, device=None):
-    """Registers a stream-K workspace (sgg_streamk_workspace, 64 MiB) for `stream` (default: the current one), once: from then on the
-    256x256 ping-pong GEMM / convolution launches on it whose tile count leaves a round partly empty run as one persistent launch
-    (csrc/tile_sched.h) -- the same bits, fewer idle CUs.  The model calls this for the streams it launches on; a no-op while the mode is 0
-    (the default: sgg_streamk_mode / SGG_STREAMK)."""
-    if _lib.load().sgg_streamk_mode(-1) == 0:          # off (the default, csrc/gemm256_sk.hip): no workspace is held
-        return False
-    dev = torch.cuda.current_device() if device is None else torch.device(device).index
-    raw = stream.cuda_stream if stream is not None else (_raw_stream(dev) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream)
-    key = (dev, raw)
-    if key in _streamk_ws:
-        return True
-    n = int(_lib.load().sgg_streamk_workspace_bytes())
-    with torch.cuda.device(dev):
-        ws = torch.empty(n + 256, dtype=torch.uint8, device='cuda:%d' % dev)
-        off = (-ws.data_ptr()) % 256
-        ws[off:off + 1024].zero_()                     # the flag words: zero once, launch epochs afterwards
-        torch.cuda.current_stream(dev).synchronize()   # (the zeroing ran on the current stream; the workspace may serve another one)
-    _lib.check(_lib.load().sgg_streamk_workspace(raw, ws.data_ptr() + off, n), 'sgg_streamk_workspace')
-    _streamk_ws[key] = ws
-    return True
-
-
-def streamk_disable():
-    """Forgets every registered stream-K workspace (tests: the plain launches, for bit comparisons)"""
-    for (dev, raw) in list(_streamk_ws):
-        _lib.check(_lib.load().sgg_streamk_workspace(raw, None, 0), 'sgg_streamk_workspace')
-    torch.cuda.synchronize()
-    _streamk_ws.clear()
-
-
-def streamk_mode(mode):
-    """0 never / 1 wherever it applies / 2 default rule (>= 4 % of a plain launch's tile slots empty); returns the previous mode"""
-    return int(_lib.load().sgg_streamk_mode(int(mode)))
-
-
-def streamk_on():
-    """True when the current stream has a stream-K workspace (gemm_full_waves then leaves the tail to the kernel's own scheduler)"""
-    if not _streamk_ws:
-        return False
-    dev = torch.cuda.current_device()
-    return (dev, _stream()) in _streamk_ws
-
-
 def _p(t, dtype=None, rows_ok=False):
     if t is None:
         return None
@@ -715,7 +668,7 @@ def gemm_full_waves(A, W, out_dtype=None, gadd=None):
         _lib.call('sgg_gemm_groupadd', _p(A, rows_ok=True), A.stride(0), _p(Wp, rows_ok=True), Wp.stride(0), _p(r, torch.float32, rows_ok=True),
                   r.stride(0), group, col0, _p(out, rows_ok=True), out.stride(0), M, Wp.shape[0], K, dt(A), dt(out), _stream())
         return out
-    if M % 256 or N % 256 or tm * tn < 2 * N_CU or rem == 0 or rem > N_CU // 4 or rem % tm or kt < 32 or streamk_on():   # short reductions: nothing to split; stream-K: the kernel's own scheduler spreads the last round
+    if M % 256 or N % 256 or tm * tn < 2 * N_CU or rem == 0 or rem > N_CU // 4 or rem % tm or kt < 32:   # short reductions: nothing to split
         return main(W, None)
     n1 = N - (rem // tm) * 256
     out = torch.empty((M, N), dtype=out_dtype or A.dtype, device=A.device)

@@ -236,7 +236,6 @@ class RelModelStanford(RelModelBase):
             self.check_pair_flag(wait='older')       # flags of the steps before the previous one have long arrived; the previous one's is only polled
         x, gt_boxes, gt_classes, gt_rels = batch[0][0], batch[0][3], batch[0][4], batch[0][5]
         dev = self.rel_fc.weight.device
-        ops.streamk_enable()     # (once per stream) persistent stream-K form of the big GEMM / conv launches: csrc/tile_sched.h
         # index tensors that arrive on the host keep a host mirror (no D2H sync later for data the host already has)
         mv = lambda t: to_device_with_mirror(t, dev) if not t.is_cuda else t
         gt_boxes, gt_classes = gt_boxes.to(dev), mv(gt_classes)
