@@ -426,6 +426,12 @@ int sgg_permute_ncp_to_npc(const void* in, void* out, int Nn, int C, int Pp, int
  * floats (one partial row per row block, summed in ascending order: no atomics, bit-reproducible). */
 int sgg_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int R, int C, const float* add, int64_t ld_add,
                   int group, float* colsum, float* colsum_ws, int in_dtype, int out_dtype, void* stream);
+/* n <= 16 plain 16-bit transposes in ONE launch: out[i] [C_i rows, row stride ld_out_i] = in[i] [R_i, C_i]^T (row stride ld_in_i); columns past R_i of
+ * an output row are not written.  Arrays of n host-side entries.  The W^T copies of the training backward's dX contractions (dX = dY W as an NT GEMM on
+ * W^T), rebuilt after every optimiser update: no reference counterpart (cuBLAS takes a transpose flag), scheduling only. */
+int sgg_transpose_multi(const void* const* in, const int64_t* ld_in, void* const* out, const int64_t* ld_out, const int* R, const int* C, int n,
+                        int dtype, void* stream);
+
 /* out[n][c] = sum_{p<group} in[n][c*group + p]  (fp32 in): fc6's folded columns W6sum[n,c] = sum_p W6[n,c,p] */
 int sgg_group_sum(const float* in, int64_t ld_in, void* out, int64_t ld_out, int Nn, int C, int group, int out_dtype,
                   void* stream);

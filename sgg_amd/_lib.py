@@ -33,6 +33,7 @@ SIGNATURES = {
     'sgg_conv1_pack_weights': [_P, _P, _I, _P],
     'sgg_conv3x3_relu': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'sgg_conv3x3_relu_x3': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    'sgg_transpose_multi': [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     'sgg_split3': [_P, _L, _L, _I, _I, _P, _L, _I, _P],
     'sgg_split2': [_P, _L, _L, _I, _I, _P, _L, _P],
     'sgg_maxpool2x2': [_P, _P, _I, _I, _I, _I, _I, _I, _P],

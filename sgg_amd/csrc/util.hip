@@ -94,11 +94,10 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ i
 // in LDS as 16-bit PAIRS [row][col/2] with a 65-word row stride: the b32 writes and the column reads (8 row-chunks x 8
 // column pairs per wave) are both bank-conflict free, and one ds_read_b32 feeds two output columns.
 template <typename TI, typename TO>
-__global__ __launch_bounds__(256) void transpose16_kernel(const TI* __restrict__ in, long ld_in, TO* __restrict__ out,
-                                                          long ld_out, int R, int C, const float* __restrict__ add,
-                                                          long ld_add, int group, float* __restrict__ colsum) {
-    __shared__ unsigned int t[128][65];
-    const int r0 = blockIdx.y * 128, c0 = blockIdx.x * 128;
+__device__ __forceinline__ void transpose16_tile(unsigned int (&t)[128][65], const int bx, const int by, const TI* __restrict__ in, long ld_in,
+                                                 TO* __restrict__ out, long ld_out, int R, int C, const float* __restrict__ add,
+                                                 long ld_add, int group, float* __restrict__ colsum) {
+    const int r0 = by * 128, c0 = bx * 128;
     const int tid = threadIdx.x;
     const bool vin = ((ld_in & 7) == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
     const bool vout = ((ld_out & 7) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
@@ -167,7 +166,7 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const TI* __restrict__
         float s = 0.f;
 #pragma unroll 8
         for (int k = 0; k < 128; ++k) s += (tid & 1) ? H16<TO>::hi(t[k][tid >> 1]) : H16<TO>::lo(t[k][tid >> 1]);
-        colsum[(long)blockIdx.y * C + c0 + tid] = s;
+        colsum[(long)by * C + c0 + tid] = s;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -195,6 +194,36 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const TI* __restrict__
             }
         }
     }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void transpose16_kernel(const TI* __restrict__ in, long ld_in, TO* __restrict__ out,
+                                                          long ld_out, int R, int C, const float* __restrict__ add,
+                                                          long ld_add, int group, float* __restrict__ colsum) {
+    __shared__ unsigned int t[128][65];
+    transpose16_tile<TI, TO>(t, blockIdx.x, blockIdx.y, in, ld_in, out, ld_out, R, C, add, ld_add, group, colsum);
+}
+
+// Several plain 16-bit transposes in ONE launch (the W^T copies the backward's dX contractions read, rebuilt after every optimiser update:
+// twelve launches of 4 - 67 us on the update's stream in rounds 3 - 5, 0.24 ms per step beside the VGG forward; as one launch their
+// 140 MB move in ~50 us).  Workgroup -> (tensor, tile) through the table's running tile counts.
+constexpr int TMULTI_MAX = 16;
+struct TransposeTab {
+    const void* in[TMULTI_MAX];
+    void* out[TMULTI_MAX];
+    long ld_in[TMULTI_MAX], ld_out[TMULTI_MAX];
+    int R[TMULTI_MAX], C[TMULTI_MAX], tile0[TMULTI_MAX + 1];
+    int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void transpose16_multi_kernel(const TransposeTab tab) {
+    __shared__ unsigned int t[128][65];
+    const int b = blockIdx.x;
+    int k = 0;
+    while (k + 1 < tab.n && b >= tab.tile0[k + 1]) ++k;               // (uniform)
+    const int local = b - tab.tile0[k], tx = (tab.C[k] + 127) / 128;
+    transpose16_tile<T, T>(t, local % tx, local / tx, (const T*)tab.in[k], tab.ld_in[k], (T*)tab.out[k], tab.ld_out[k], tab.R[k], tab.C[k], nullptr, 0, 1,
+                           nullptr);
 }
 
 // out[n][c] = sum_{p < group} in[n][c*group + p]   (W6sum: the K columns that fold `+ conv(rects)` into fc6)
@@ -409,6 +438,29 @@ extern "C" int sgg_transpose(const void* in, int64_t ld_in, void* out, int64_t l
     }
     SGG_CHECK_LAUNCH();
     if (colsum) return sgg_reduce_parts(part, nparts, C, colsum, 0, s);
+    return SGG_OK;
+}
+
+// n <= 16 transposes in one launch: out[i] [C_i, ld_out_i] = in[i] [R_i, C_i]^T (row stride ld_in_i), 16-bit element type `dtype` on both sides;
+// columns R_i .. ld_out_i - 1 of the outputs are NOT written (zero padding made once by the caller stays).
+extern "C" int sgg_transpose_multi(const void* const* in, const int64_t* ld_in, void* const* out, const int64_t* ld_out, const int* R, const int* C, int n,
+                                   int dtype, void* stream) {
+    if (n == 0) return SGG_OK;
+    if (!in || !ld_in || !out || !ld_out || !R || !C || n < 0 || n > TMULTI_MAX) return SGG_ERR_ARG;
+    if (dtype != SGG_BF16 && dtype != SGG_F16) return SGG_ERR_DTYPE;
+    TransposeTab tab{};
+    tab.n = n;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!in[i] || !out[i] || R[i] <= 0 || C[i] <= 0 || ld_in[i] < C[i] || ld_out[i] < R[i]) return SGG_ERR_ARG;
+        tab.in[i] = in[i]; tab.out[i] = out[i]; tab.ld_in[i] = ld_in[i]; tab.ld_out[i] = ld_out[i]; tab.R[i] = R[i]; tab.C[i] = C[i];
+        tab.tile0[i] = tiles;
+        tiles += ((C[i] + 127) / 128) * ((R[i] + 127) / 128);
+    }
+    tab.tile0[n] = tiles;
+    hipStream_t s = (hipStream_t)stream;
+    SGG_FOR_DTYPE16(dtype, hipLaunchKernelGGL(transpose16_multi_kernel<T>, dim3(tiles), dim3(256), 0, s, tab));
+    SGG_CHECK_LAUNCH();
     return SGG_OK;
 }
 

@@ -1058,6 +1058,21 @@ def transpose(x, pad_to=64, dtype=None, add=None, group=1, want_colsum=False, ou
     return (out, cs) if want_colsum else out
 
 
+def transpose_multi(pairs):
+    """[(x [R,C] 16-bit (row-strided ok), out [C, Rp >= R])] -> every out = x^T in ONE launch (sgg_transpose_multi; at most 16 per launch).  The outputs'
+    padding columns are left as they are (zero since their allocation)."""
+    import ctypes
+    for i0 in range(0, len(pairs), 16):
+        chunk = pairs[i0:i0 + 16]
+        n = len(chunk)
+        dtc = dt(chunk[0][0])
+        PA, LA, IA = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+        for x, o in chunk:
+            assert x.dim() == 2 and x.stride(1) == 1 and o.is_contiguous() and o.shape[0] == x.shape[1] and o.shape[1] >= x.shape[0] and dt(x) == dt(o) == dtc
+        _lib.call('sgg_transpose_multi', PA(*[x.data_ptr() for x, _ in chunk]), LA(*[x.stride(0) for x, _ in chunk]), PA(*[o.data_ptr() for _, o in chunk]),
+                  LA(*[o.stride(0) for _, o in chunk]), IA(*[x.shape[0] for x, _ in chunk]), IA(*[x.shape[1] for x, _ in chunk]), n, dtc, _stream())
+
+
 def group_sum(w, C, group, dtype, out=None):
     """w f32[N, C*group] -> [N, C] in dtype: sums over each run of `group` consecutive columns (out: an earlier result's buffer, rewritten)."""
     Nn = w.shape[0]

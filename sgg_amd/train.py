@@ -66,10 +66,15 @@ TRANSPOSED = ('fc7_obj', 'obj_unary', 'fc7_edge', 'edge_unary', 'obj_fc', 'rel_f
 
 def _transposed_operands(model, w, keep, t):
     """the backward-only operands: W^T copies (dX = dY W runs as an NT GEMM on W^T), written in place into `keep`'s buffers"""
+    batch = []          # 16-bit modes: every W^T copy whose buffer exists already is rewritten by ONE launch (ops.transpose_multi) at the end
+
     def tr(name, x):
         out = keep.get(name)
         if out is not None and (out.shape[0] != x.shape[1] or out.shape[1] < x.shape[0]):
             out = None
+        if out is not None and ops.is_half(x) and out.dtype == x.dtype and x.stride(1) == 1 and MULTI_TRANSPOSE:
+            batch.append((x, out))
+            return out
         keep[name] = ops.transpose(x, out=out)
         return keep[name]
     for name in TRANSPOSED:
@@ -80,6 +85,11 @@ def _transposed_operands(model, w, keep, t):
         t[g + '_w_ih_t'] = tr(g + '_w_ih_t', getattr(imp, g + '_w_ih'))  # [H, 3H]
         t[g + '_w_hh_t'] = tr(g + '_w_hh_t', getattr(imp, g + '_w_hh'))
     t['rc_w2_t'] = tr('rc_w2_t', t['rc_w2'])                              # [d2, d]
+    if batch:
+        ops.transpose_multi(batch)
+
+
+MULTI_TRANSPOSE = os.environ.get('SGG_MULTI_TRANSPOSE', '1') != '0'
 
 
 def rebuild_transposes(model):

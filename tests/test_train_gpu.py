@@ -660,3 +660,29 @@ def test_fused_density_normalised_cross_entropy(env, loss_type):
     model.dropout_p = 0.5
     model.eval()
     model.set_compute_dtype(torch.float32)
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_transpose_multi_equals_the_single_transposes(dtype):
+    """sgg_transpose_multi: the twelve W^T copies of the backward in one launch -- bit-equal to ops.transpose one by one (shapes of the model's
+    weights incl. narrow / ragged ones, a row-strided source, padded outputs whose padding columns stay zero)"""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from sgg_amd import ops
+    g = torch.Generator().manual_seed(5)
+    shapes = [(4096, 4096), (512, 4096), (151, 512), (51, 512), (4096, 512), (1536, 512), (1536, 512), (512, 256), (130, 70), (64, 1000)]
+    pairs, want = [], []
+    for i, (R, C) in enumerate(shapes):
+        x = torch.randn(R, C + (8 if i % 3 == 0 else 0), generator=g).to('cuda:0').to(dtype)[:, :C]       # (some sources are row-strided)
+        ref = ops.transpose(x)
+        out = torch.zeros_like(ref)
+        pairs.append((x, out))
+        want.append(ref)
+    ops.transpose_multi(pairs)
+    for (x, out), ref in zip(pairs, want):
+        assert torch.equal(out, ref), (tuple(x.shape), float((out.float() - ref.float()).abs().max()))
+    more = pairs * 2                                  # 20 entries: two launches
+    for _, o in more:
+        o.fill_(0)
+    ops.transpose_multi(more)
+    for (x, out), ref in zip(pairs, want):
+        assert torch.equal(out, ref)
