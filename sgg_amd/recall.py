@@ -225,26 +225,23 @@ class BasicSceneGraphEvaluator(object):
             pred_boxes = np.asarray(pred_entry['pred_boxes']).astype(float)
             pred_classes, obj_scores = np.asarray(pred_entry['pred_classes']), np.asarray(pred_entry['obj_scores'])
         elif mode == 'preddet':                                  # :167-194, host only
-            prc = intersect_2d(pred_rel_inds, gt_rels[:, :2])
-            if prc.size == 0:
-                for k in result_dict[mode + '_recall']:
-                    result_dict[mode + '_recall'][k].append(0.0)
-                if self.per_triplet:
-                    for k in result_dict[mode + '_recall_norm']:
-                        result_dict[mode + '_recall_norm'][k].append(0.0)
+            # predicate detection: the predictions on the GROUND-TRUTH pairs only -- for every gt pair the first prediction row on that pair
+            pair_hits = intersect_2d(pred_rel_inds, gt_rels[:, :2])                     # [predictions, gt pairs]
+            recalls = (result_dict[mode + '_recall'], result_dict[mode + '_recall_norm'] if self.per_triplet else {})
+            if pair_hits.size == 0:
+                for table in recalls:
+                    for k in table:
+                        table[k].append(0.0)
                 return None
-            pred_inds_per_gt = prc.argmax(0)
-            pred_rel_inds = pred_rel_inds[pred_inds_per_gt]
-            rel_scores = rel_scores[pred_inds_per_gt]
-            order = argsort_desc(rel_scores[:, 1:])
-            order[:, 1] += 1
-            ranked_rels = np.column_stack((pred_rel_inds[order[:, 0]], order[:, 1]))      # (not `ranked`: that is the cache parameter)
-            matches = intersect_2d(ranked_rels, gt_rels)
-            for k in result_dict[mode + '_recall']:
-                result_dict[mode + '_recall'][k].append(float(matches[:k].any(0).sum()) / float(gt_rels.shape[0]))
-            if self.per_triplet:
-                for k in result_dict[mode + '_recall_norm']:
-                    result_dict[mode + '_recall_norm'][k].append(float(matches[:k].any(0).sum()) / float(gt_rels.shape[0]))
+            rows = np.argmax(pair_hits, axis=0)                                         # (first matching prediction per gt pair)
+            on_gt_pairs, their_scores = pred_rel_inds[rows], rel_scores[rows]
+            by_score = argsort_desc(their_scores[:, 1:])                                # (pair row, predicate - 1), best first
+            ranked_rels = np.concatenate((on_gt_pairs[by_score[:, 0]], by_score[:, 1:2] + 1), axis=1)    # (not `ranked`: that is the cache parameter)
+            found = intersect_2d(ranked_rels, gt_rels)
+            n_gt = float(gt_rels.shape[0])
+            for table in recalls:
+                for k in table:
+                    table[k].append(float(found[:k].any(0).sum()) / n_gt)
             return None
         else:
             raise ValueError('invalid mode')
@@ -266,8 +263,10 @@ class BasicSceneGraphEvaluator(object):
             predicate_scores = rel_scores[score_inds[:, 0], score_inds[:, 1] + 1]
         else:                                                    # :220-222
             overall_order = None
-            pred_rels = np.column_stack((pred_rel_inds, 1 + rel_scores[:, 1:].argmax(1)))
-            predicate_scores = rel_scores[:, 1:].max(1)
+            fg = rel_scores[:, 1:]                                                     # graph constraint: one predicate per pair, the best non-background one
+            best = fg.argmax(1)
+            pred_rels = np.concatenate((pred_rel_inds, best[:, None] + 1), axis=1)
+            predicate_scores = fg[np.arange(len(fg)), best]
         if ranked is not None and hit is None:
             ranked[key] = (pred_rels, predicate_scores, overall_order)
         prep = dict(gt_rels=gt_rels, gt_boxes=gt_boxes, gt_classes=gt_classes, pred_rels=pred_rels, pred_boxes=pred_boxes,
