@@ -11,7 +11,13 @@ import os as _os
 # silently serialised (measured: 11.6 vs 10.2 ms per data-parallel step).  Must be set before the HIP runtime starts.
 _os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
-from . import _lib
+# torch FIRST: its wheel bundles its own HIP runtime (libamdhip64), and libsgg_hip.so must bind to THAT copy -- whichever libamdhip64 is
+# loaded first serves both.  With `import sgg_amd` as a process's first import the library used to pull in the system ROCm's runtime
+# ahead of torch's: two runtimes in one process, and the first kernel launch failed (found in round 6 by running build() and smoke() in
+# one process; tests/test_abi_cpu.py::test_import_order).
+import torch as _torch  # noqa: E402,F401
+
+from . import _lib  # noqa: E402
 
 _lib.load()
 

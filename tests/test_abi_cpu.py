@@ -176,3 +176,21 @@ def test_integration_md_stubs_match_the_bound_signatures():
                     and getattr(node.left.func, 'attr', '') == 'sgg_abi_version':
                 assert node.comparators[0].value == _lib.ABI_VERSION
     assert 'sgg_union_rects_fwd' in bound and 'sgg_union_rects_fwd' in called
+
+
+def test_import_order_torch_is_loaded_before_the_library():
+    """`import sgg_amd` as the FIRST import of a process (what `from sgg_amd import RelModelStanford` at the top of main.py is): torch -- and
+    with it the HIP runtime its wheel bundles -- must be in the process before libsgg_hip.so is loaded, or the library binds the system
+    ROCm's libamdhip64 and the two runtimes do not share streams / modules (round 6: the first launch failed)."""
+    import subprocess
+    import sys
+    code = ("import sys\n"
+            "import sgg_amd\n"
+            "import ctypes\n"
+            "assert 'torch' in sys.modules\n"
+            "maps = open('/proc/self/maps').read()\n"
+            "hips = sorted({l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l})\n"
+            "print(hips)\n"
+            "assert len(hips) <= 1, hips\n")
+    out = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
