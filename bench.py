@@ -479,7 +479,9 @@ def sgdet_measure(args, model, batches, timed, B, dev, steps, warmup, cpu_images
                       'weights': 'random init (He) + synthetic.spread_detector_: RPN deltas x 0.02 and an objectness bias for the 32-px anchors '
                                  '(1 000 proposals survive NMS 0.7), class head x 2 with a random bias, box regression grows detections to object size'},
            'roofline': {'kernel': '%s: [%d x 25088] . [4096 x 25088]^T (256x256 ping-pong MFMA kernel)' % (what, rows),
-                        'bound': 'mfma', 'achieved': round(tf, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(tf / peak, 4), 'traffic': None,
+                        'bound': 'mfma', 'achieved': round(tf, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(tf / peak, 4),
+                        'traffic': pmc_traffic('box_fc6_gemm') if (tag == 'box_fc6' and K == 8000 and args.dtype == 'f16') else None,
+                        'traffic_source': 'profiles/pmc_r0x.json (separate rocprofv3 --pmc passes of the same launch, tools/pmc_traffic.sh), not measured in this run',
                         'ms_per_step': round(ms, 4), 'executed_flop': flop},
            'kernels': {'sum_kernel_ms_per_step': round(total_ms, 3), 'largest_gemm_ms': round(ms, 3),
                        'vgg16_ms': round(per(('sgg_conv3x3_relu', 'sgg_conv1_1', 'sgg_conv1_block', 'sgg_maxpool2x2')), 3),

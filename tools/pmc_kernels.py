@@ -23,6 +23,21 @@ out = torch.empty(M, N, device=dev, dtype=torch.float32)
 for _ in range(3):
     ops.gemm(A, W, out=out, out_dtype=torch.float32)
 torch.cuda.synchronize()
+# the SGDet box head's fc6 at BASELINE configs[2]'s size: [8000 proposals, 25088] . [4096, 25088]^T, 16-bit out (512 workgroups = two rounds)
+Ab = torch.randn(8000, K1, generator=g).to(dev).to(dt).relu()
+bb = torch.randn(N, generator=g).to(dev)
+for _ in range(3):
+    ops.gemm(Ab, W, bb, ops.ACT_RELU)
+torch.cuda.synchronize()
+del Ab
+# the x3 mode's form of the first contraction: the same fc6 on PAIR operands (SGG_PAIR16: the MFMA loop walks hi.hi + hi.lo + lo.hi)
+A32, W32 = A.float(), W.float()
+ops.set_split3(True)
+for _ in range(3):
+    ops.gemm(A32, W32, out=out, out_dtype=torch.float32)
+ops.set_split3(False)
+torch.cuda.synchronize()
+del A32, W32
 # its weight gradient (the train step's largest contraction): dW[4096, 25088] = (pair-summed d_pre6 [U, 4096])^T . pooled [U, 25088], the
 # TN form of the ping-pong kernel: both operands as they lie
 Mg, Ng, Kg = 4096, 25088, 3968
