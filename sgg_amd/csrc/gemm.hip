@@ -690,10 +690,15 @@ __global__ __launch_bounds__(256) void tn_tail_pad_kernel(const char* __restrict
 // output tiles and ANY number of reduction rows (the last Mred mod 32 rows go through pad_ws, 64 (N + K) bytes, as a zero-padded K-tile).
 extern "C" int sgg_gemm_tn256(const void* A, int lda, const void* B, int ldb, const float* gadd, int ld_gadd, int group, int col0, void* C,
                               int ldc, int Mred, int N, int K, int in_dtype, int out_dtype, void* pad_ws, void* stream) {
+    // SGG_PAIR16 operands (x3 mode): A [Mred, >= 2 N] = [hi (N) | lo (N)] per row, B [Mred, >= 2 K] likewise; the kernel walks hi.hi + hi.lo + lo.hi
+    // over the same reduction rows.  Whole K-tiles only (Mred % 32 == 0).
+    const bool pair_in = in_dtype == SGG_PAIR16;
+    if (pair_in) in_dtype = SGG_F16;
     if ((in_dtype != SGG_BF16 && in_dtype != SGG_F16) || !sgg_is_dtype(out_dtype)) return SGG_ERR_DTYPE;
     if (!A || !B || !C || Mred <= 0 || N <= 0 || K <= 0 || (N & 255) || (K & 255) || lda < N || ldb < K || ldc < K || ((lda | ldb | ldc) & 7) ||
         (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)pad_ws) & 15) || ((Mred & 31) && !pad_ws))
         return SGG_ERR_ARG;
+    if (pair_in && ((Mred & 31) || lda < 2 * N || ldb < 2 * K)) return SGG_ERR_ARG;
     if (gadd && (group <= 0 || col0 < 0 || (long)ld_gadd * group < (long)K + col0)) return SGG_ERR_ARG;
     if (32L * lda * 2 + 2L * N > 0xffff0000L || 32L * ldb * 2 + 2L * K > 0xffff0000L) return SGG_ERR_SPAN;     // 32-bit lane offsets inside a K-tile
     hipStream_t s = (hipStream_t)stream;
@@ -701,6 +706,10 @@ extern "C" int sgg_gemm_tn256(const void* A, int lda, const void* B, int ldb, co
     g.A = (const char*)A; g.Wt = (const char*)B;
     g.lda_b = (long)lda * 2; g.ldw_b = (long)ldb * 2;
     g.nt1 = Mred / 32; g.nt = (Mred + 31) / 32;
+    if (pair_in) {
+        g.x3t = g.nt; g.nt *= 3; g.nt1 = g.nt;
+        g.x3c = x3_chunk_tiles(g.x3t, 16);
+    }
     if (Mred & 31) {
         g.A2 = (const char*)pad_ws; g.lda2_b = (long)N * 2;
         g.W2 = (const char*)pad_ws + 32L * N * 2; g.ldw2_b = (long)K * 2;

@@ -39,6 +39,14 @@ template <bool CONV, bool TN = false>
 __device__ __forceinline__ long tile_koff(const GemmArgs& g, bool loads_a, int kt, int tpc, int esz, bool& seg2) {
     seg2 = false;
     if constexpr (TN) {     // 32 reduction rows further down; K-tiles from nt1 on come out of the second pair of operands (the padded tail rows)
+        if (g.x3t) {
+            // x3 mode on PAIR operands, TN form: both operands are [Mred][hi (cols) | lo (cols)]; the three segments walk the SAME reduction rows
+            // with another column plane: 0 = (A hi, B hi), 1 = (A hi, B lo), 2 = (A lo, B hi); plane stride = the operand's column count
+            int seg, kk;
+            x3_tile(g, kt, seg, kk);
+            const long plane = (loads_a ? seg == 2 : seg == 1) ? (long)(loads_a ? g.M : g.N) * 2 : 0;
+            return (long)kk * 32 * (loads_a ? g.lda_b : g.ldw_b) + plane;
+        }
         seg2 = g.A2 && kt >= g.nt1;
         return seg2 ? (long)(kt - g.nt1) * 32 * (loads_a ? g.lda2_b : g.ldw2_b) : (long)kt * 32 * (loads_a ? g.lda_b : g.ldw_b);
     }

@@ -720,6 +720,27 @@ def gemm_tn256(A, B, out_dtype=torch.float32, out=None, gadd=None, col0=0):
     return out
 
 
+def gemm_tn_x3_ok(A, B):
+    """fp32 operands the x3 mode's TN form takes (sgg_gemm_tn256 on PAIR operands): whole 256 x 256 tiles, whole 32-row K-tiles"""
+    return (PAIR_GEMM and TN256 and A.dtype == B.dtype == torch.float32 and A.shape[0] == B.shape[0] and A.shape[0] % 32 == 0 and
+            A.shape[1] % 256 == 0 and B.shape[1] % 256 == 0 and A.stride(1) == 1 and B.stride(1) == 1 and
+            A.shape[0] * A.shape[1] * 4 < SPAN_LIMIT and B.shape[0] * B.shape[1] * 4 < SPAN_LIMIT and os.environ.get('SGG_X3_TN', '1') != '0')
+
+
+def gemm_tn_x3(A, B, out_dtype=torch.float32, out=None):
+    """A[Mred,N]^T . B[Mred,K] -> [N,K] for fp32 A, B in the x3 arithmetic, both operands AS THEY LIE (no transposed copies): their PAIR forms
+    [Mred, hi | lo] through the ping-pong kernel's TN form, which walks hi.hi + hi.lo + lo.hi over the same reduction rows"""
+    Mred, N = A.shape
+    K = B.shape[1]
+    Ap, Bp = split2(A), split2(B)
+    assert Ap.shape[1] == 2 * N and Bp.shape[1] == 2 * K
+    if out is None:
+        out = torch.empty((N, K), dtype=out_dtype, device=A.device)
+    _lib.call('sgg_gemm_tn256', _p(Ap), Ap.stride(0), _p(Bp), Bp.stride(0), None, 0, 1, 0, _p(out, rows_ok=True), out.stride(0), Mred, N, K,
+              SGG_PAIR16, dt(out), None, _stream())
+    return out
+
+
 def gemm_tn_full_waves(A, B, out_dtype=None, gadd=None):
     """gemm_full_waves for the TN form (fc6's weight gradient: 16 x 98 tiles = 6.125 rounds): whole rounds on sgg_gemm_tn256, the tile
     columns of a nearly empty last round on the 128 x 128 TN kernel's split form (which needs reduction rows % 64: otherwise one launch)."""

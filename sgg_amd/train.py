@@ -51,6 +51,10 @@ USE_TN = True      # tests flip this to cross-check the TN kernel against the tr
 def tn_gemm(X, Y, out=None, want_colsum=False, out_dtype=torch.float32):
     """X[M,a]^T . Y[M,b] -> f32 [a,b]  (weight gradients).  Rows are zero-padded to a multiple of 64 by the transposes.
     want_colsum: also return colsum(X) (the bias gradient when X = dY), computed inside X's transpose pass."""
+    if (out is None and USE_TN and ops.split3_on() and not ops._BWD16[0] and ops.gemm_tn_x3_ok(X, Y)):
+        # x3 mode: the same contraction on PAIR operands, both read as they lie (round 6: no fp32 transposes, no split of transposed copies)
+        dw = ops.gemm_tn_x3(X, Y, out_dtype=out_dtype)
+        return (dw, ops.colsum(X)) if want_colsum else dw
     if out is None and USE_TN and ops.gemm_tn_ok(X, Y):
         # 16-bit, aligned shapes: the TN kernel reads dY and X as they lie (no transposed copies); bias gradient = colsum(dY)
         dw = ops.gemm_tn(X, Y, out_dtype=out_dtype)
@@ -591,7 +595,18 @@ class PredictFn(torch.autograd.Function):
         # d W6[n,(c,p)] = sum_e d_pre6[e,n] * (edge_feat[e,c,p] + rect[e,c]): the folded term rides in the transpose
         paired = sv['paired']
         x6t = d6t = None
-        if sv.get('tn6'):
+        # x3 mode (strict backward): the pair-summed gradient rows and the pooled rows as PAIR operands through the TN form, both as they lie
+        ef2d = sv['ef'].reshape(sv['ef'].shape[0], -1) if paired is not None else None
+        x3_tn6 = (paired is not None and not sv.get('tn6') and 'x6t' not in sv and ops.split3_on() and not ops._BWD16[0] and USE_TN and
+                  d_pre6.dtype == torch.float32 and ef2d.dtype == torch.float32 and ef2d.shape[0] % 32 == 0 and
+                  ops.gemm_tn_x3_ok(ef2d.new_empty((ef2d.shape[0], d_pre6.shape[1])), ef2d))
+        if x3_tn6:
+            G[n6e + '.bias'] = ops.colsum(d_pre6)
+            _lib.set_tag('bwd_fc6_rect_term')
+            r6 = tn_gemm(d_pre6, sv['rect'])
+            _lib.set_tag('bwd_fc6_edge_dW')
+            G[n6e + '.weight'] = ops.group_bcast_add_(ops.gemm_tn_x3(ops.pairsum(d_pre6, paired.u2e), ef2d, out_dtype=big_dtype()), r6, PP)
+        elif sv.get('tn6'):
             pass
         elif 'x6t' in sv:
             torch.cuda.current_stream(dev).wait_event(sv['x6t_ready'])
@@ -600,7 +615,9 @@ class PredictFn(torch.autograd.Function):
             x6t = ops.transpose(sv['ef'])
         else:
             x6t = ops.transpose(sv['ef'], add=sv['rect'].float() if sv['rect'].dtype != torch.float32 else sv['rect'], group=PP)
-        if sv.get('tn6'):
+        if x3_tn6:
+            pass
+        elif sv.get('tn6'):
             # the same two terms as below, the first as  (pair sums of d_pre6)^T . pooled  with both operands read as they lie
             G[n6e + '.bias'] = ops.colsum(d_pre6)
             _lib.set_tag('bwd_fc6_rect_term')

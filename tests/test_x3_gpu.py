@@ -266,6 +266,28 @@ def test_x3_convolution_on_the_patch_kernel(ops, shape):
     assert float((got - (r[..., :Cout].double() + r[..., Cout:].double())).abs().max()) <= 4e-6 * scale
 
 
+@pytest.mark.parametrize('shape', [(3968, 4096, 25088), (7936, 512, 4096), (256, 512, 1536), (96, 256, 256)])
+def test_x3_weight_gradient_contraction_on_pair_operands_as_they_lie(ops, shape):
+    """ops.gemm_tn_x3: dW = dY^T X for fp32 dY [M, a], X [M, b] in the x3 arithmetic through the ping-pong kernel's TN form on PAIR operands (no
+    transposed copies): against a float64 product, and against the transposes + NT form it replaces"""
+    M, a, b = shape
+    g = torch.Generator().manual_seed(M + a)
+    dY = (torch.randn(M, a, generator=g) / 30).to(DEV)
+    X = torch.randn(M, b, generator=g).relu().to(DEV)
+    assert ops.gemm_tn_x3_ok(dY, X)
+    got = ops.gemm_tn_x3(dY, X)
+    idx = torch.randint(0, a, (64,), generator=g).to(DEV)
+    want = dY[:, idx].double().t() @ X.double()                       # 64 sampled output rows in float64
+    scale = float(want.abs().max())
+    assert got.shape == (a, b) and float((got[idx].double() - want).abs().max()) <= 2e-5 * scale, (shape, float((got[idx].double() - want).abs().max()), scale)
+    ops.set_split3(True)
+    try:
+        old = ops.gemm(ops.transpose(dY), ops.transpose(X), out_dtype=torch.float32)
+    finally:
+        ops.set_split3(False)
+    assert float((got - old).abs().max()) <= 1e-5 * scale
+
+
 def test_x3_with_f16_backward_keeps_the_forward_and_gives_f16_grade_gradients(ops):
     """set_compute_dtype(float32, split3=True, backward_f16=True): the train-mode forward is the x3 forward bit for bit (logits inside the
     1e-3 clause), the backward's contractions round their operands to f16 once under the loss scale -- every head gradient within 1 % of
