@@ -720,10 +720,14 @@ def gemm_tn256(A, B, out_dtype=torch.float32, out=None, gadd=None, col0=0):
     return out
 
 
+X3_TN_MIN_TILES = int(os.environ.get('SGG_X3_TN_MIN_TILES', '128'))
+
+
 def gemm_tn_x3_ok(A, B):
     """fp32 operands the x3 mode's TN form takes (sgg_gemm_tn256 on PAIR operands): whole 256 x 256 tiles, whole 32-row K-tiles"""
     return (PAIR_GEMM and TN256 and A.dtype == B.dtype == torch.float32 and A.shape[0] == B.shape[0] and A.shape[0] % 32 == 0 and
             A.shape[1] % 256 == 0 and B.shape[1] % 256 == 0 and A.stride(1) == 1 and B.stride(1) == 1 and
+            (A.shape[1] // 256) * (B.shape[1] // 256) >= X3_TN_MIN_TILES and          # (a few output tiles with a long reduction: the split-K NT form fills the chip)
             A.shape[0] * A.shape[1] * 4 < SPAN_LIMIT and B.shape[0] * B.shape[1] * 4 < SPAN_LIMIT and os.environ.get('SGG_X3_TN', '1') != '0')
 
 
