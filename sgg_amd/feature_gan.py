@@ -449,6 +449,14 @@ def gan_train_step(sgg_model, gan, res, gt_boxes, gt_objects, gt_rels, optimizer
         G_optimizer.zero_grad()
         losses = {}
         losses_G = {}
+        # The generator's update scores generated samples with the discriminators but never steps them: main.py:151-176 lets autograd fill the
+        # discriminators' .grad all the same and D_optimizer.zero_grad() (:179) throws it away.  The same update without that work: the
+        # discriminators' parameters do not require a gradient while the generator's losses are built and back-propagated (their weight-gradient
+        # contractions -- the largest of the iteration: D_edges' first layer alone is a [256 x 198400] . [198400 x 2304] product at the GQA
+        # configuration -- are never formed); the gradient THROUGH them into the generated features is untouched.
+        d_req = [(p, p.requires_grad) for p in D_params]
+        for p, _ in d_req:
+            p.requires_grad_(False)
         losses_G.update(gan.loss(features_fake=nodes_fake, is_nodes=True, labels_fake=gt_objects_fake[:, -1]))
         losses_G.update(gan.loss(features_fake=edges_fake, labels_fake=res.rel_labels[:, -1]))
         losses_G.update(gan.loss(features_fake=fmaps, is_fmaps=True))
@@ -485,6 +493,9 @@ def gan_train_step(sgg_model, gan, res, gt_boxes, gt_objects, gt_rels, optimizer
             if g_ok:
                 G_optimizer.step()
             losses.update(losses_G)
+        for p_, req_ in d_req:                   # (the discriminators learn again)
+            p_.requires_grad_(req_)
+        d_req = []
         # ---- discriminators (main.py:178-191)
         D_optimizer.zero_grad()
         losses_D = {}
@@ -498,6 +509,8 @@ def gan_train_step(sgg_model, gan, res, gt_boxes, gt_objects, gt_rels, optimizer
             D_optimizer.step()
             losses.update(losses_D)
     finally:
+        for p_, req_ in locals().get('d_req', []):
+            p_.requires_grad_(req_)
         if trainer is None and saved_hook is not None:
             sgg_model._grad_ready_hook = saved_hook
     return {k: v.detach() for k, v in losses.items()}
